@@ -1,0 +1,162 @@
+"""Model hyper-parameters and the reference's state_dict name/shape manifest.
+
+Presets restate the shipped configs: reference conf/train_pytorch_tacotron2.sa.student.yaml:5-19 (S)
+and conf/train_pytorch_tacotron2.sa.yaml:5-19 (T).  Predictor sizes are the literals hard-coded in
+reference nets/knowledge_distillation/e2e_tts_tacotron2_sa_kd_student.py:549-600 and the ESPnet
+DurationPredictor defaults used at :538-544.
+"""
+from collections import OrderedDict
+from dataclasses import dataclass, replace
+
+
+@dataclass(frozen=True)
+class HParams:
+    idim: int = 80  # phoneme vocabulary (PAD=0)
+    odim: int = 80  # mel bins
+    embed_dim: int = 256
+    elayers: int = 1
+    eunits: int = 256
+    econv_layers: int = 3
+    econv_chans: int = 256
+    econv_filts: int = 5
+    dlayers: int = 2
+    dunits: int = 256
+    prenet_layers: int = 2
+    prenet_units: int = 256
+    postnet_layers: int = 5
+    postnet_chans: int = 128
+    postnet_filts: int = 5
+    use_batch_norm: bool = True
+    use_concate: bool = True
+    use_residual: bool = False
+    reduction_factor: int = 1
+    dropout_rate: float = 0.5
+    zoneout_rate: float = 0.1
+    duration_predictor_layers: int = 2
+    duration_predictor_chans: int = 384
+    duration_predictor_kernel_size: int = 3
+    duration_predictor_dropout_rate: float = 0.1
+    variance_predictor_layers: int = 2
+    variance_predictor_chans: int = 384
+    variance_predictor_kernel_size: int = 3
+    variance_predictor_dropout_rate: float = 0.5
+    variance_embed_kernel_size: int = 9
+    variance_embed_dropout_rate: float = 0.5
+    use_fe_condition: bool = True
+    append_position: bool = True
+    use_masking: bool = True
+
+    def check_supported(self):
+        """The HIP path covers the shipped recipe only; anything else fails loudly."""
+        bad = []
+        if self.elayers != 1: bad.append("elayers != 1")
+        if self.dlayers != 2: bad.append("dlayers != 2")
+        if self.prenet_layers != 2: bad.append("prenet_layers != 2")
+        if self.postnet_layers < 2: bad.append("postnet_layers < 2")
+        if not self.use_batch_norm: bad.append("use_batch_norm False")
+        if not self.use_concate: bad.append("use_concate False")
+        if self.use_residual: bad.append("use_residual True")
+        if self.reduction_factor != 1: bad.append("reduction_factor != 1")
+        if not self.use_fe_condition: bad.append("use_fe_condition False")
+        if not self.append_position: bad.append("append_position False")
+        if self.econv_chans != self.embed_dim or self.eunits != self.econv_chans:
+            bad.append("embed_dim/econv_chans/eunits differ")
+        if self.zoneout_rate <= 0.0: bad.append("zoneout_rate <= 0")
+        if bad:
+            raise NotImplementedError("fcl-taco2_amd HIP path: unsupported configuration: " + ", ".join(bad))
+        return self
+
+
+def student_hparams(**kw):
+    """FCL-taco2-S."""
+    return replace(HParams(), **kw)
+
+
+def teacher_hparams(**kw):
+    """FCL-taco2-T."""
+    return replace(
+        HParams(embed_dim=512, eunits=512, econv_chans=512, dunits=1024, postnet_chans=512), **kw
+    )
+
+
+def _bn(spec, prefix, c):
+    spec[prefix + ".weight"] = (c,)
+    spec[prefix + ".bias"] = (c,)
+    spec[prefix + ".running_mean"] = (c,)
+    spec[prefix + ".running_var"] = (c,)
+    spec[prefix + ".num_batches_tracked"] = ()
+
+
+def _predictor(spec, prefix, idim, layers, chans, ksz):
+    for i in range(layers):
+        cin = idim if i == 0 else chans
+        spec["%s.conv.%d.0.weight" % (prefix, i)] = (chans, cin, ksz)
+        spec["%s.conv.%d.0.bias" % (prefix, i)] = (chans,)
+        spec["%s.conv.%d.2.weight" % (prefix, i)] = (chans,)  # LayerNorm
+        spec["%s.conv.%d.2.bias" % (prefix, i)] = (chans,)
+    spec[prefix + ".linear.weight"] = (1, chans)
+    spec[prefix + ".linear.bias"] = (1,)
+
+
+def param_spec(hp, projections_to=None, share_proj=True):
+    """Ordered {state_dict key: shape}, equal to the reference model's `state_dict()` manifest.
+
+    projections_to: teacher HParams -> include the student's KD projection matrices
+    (reference encoder_sa_kd.py:112-122, decoder_sa_kd.py:478-490, ..._kd_student.py:602-603).
+    Verified against the imported reference by oracle/gen_golden.py (tests/golden/manifest.json).
+    """
+    s = OrderedDict()
+    E, C, H = hp.embed_dim, hp.econv_chans, hp.eunits // 2
+    s["enc.embed.weight"] = (hp.idim, E)
+    for i in range(hp.econv_layers):
+        s["enc.convs.%d.0.weight" % i] = (C, E if i == 0 else C, hp.econv_filts)
+        _bn(s, "enc.convs.%d.1" % i, C)
+    for sfx in ("", "_reverse"):
+        s["enc.blstm.weight_ih_l0" + sfx] = (4 * H, C)
+        s["enc.blstm.weight_hh_l0" + sfx] = (4 * H, H)
+        s["enc.blstm.bias_ih_l0" + sfx] = (4 * H,)
+        s["enc.blstm.bias_hh_l0" + sfx] = (4 * H,)
+    T = projections_to
+    if T is not None:
+        s["enc.embed_proj.weight"] = (T.embed_dim, E)
+        for i in range(1 if share_proj else hp.econv_layers):
+            s["enc.convs_proj.%d.weight" % i] = (T.econv_chans, C)
+        s["enc.blstm_proj.weight"] = (T.eunits, hp.eunits)
+    D, U, P = hp.eunits, hp.dunits, hp.prenet_units
+    for l in range(hp.dlayers):
+        iu = D + P + (1 if hp.append_position else 0) if l == 0 else U
+        s["dec.lstm.%d.cell.weight_ih" % l] = (4 * U, iu)
+        s["dec.lstm.%d.cell.weight_hh" % l] = (4 * U, U)
+        s["dec.lstm.%d.cell.bias_ih" % l] = (4 * U,)
+        s["dec.lstm.%d.cell.bias_hh" % l] = (4 * U,)
+    for l in range(hp.prenet_layers):
+        s["dec.prenet.prenet.%d.0.weight" % l] = (P, hp.odim if l == 0 else P)
+        s["dec.prenet.prenet.%d.0.bias" % l] = (P,)
+    Cp = hp.postnet_chans
+    for l in range(hp.postnet_layers):
+        ci = hp.odim if l == 0 else Cp
+        co = hp.odim if l == hp.postnet_layers - 1 else Cp
+        s["dec.postnet.postnet.%d.0.weight" % l] = (co, ci, hp.postnet_filts)
+        _bn(s, "dec.postnet.postnet.%d.1" % l, co)
+    s["dec.feat_out.weight"] = (hp.odim * hp.reduction_factor, U + D)
+    if T is not None:
+        s["dec.prenet_proj.weight"] = (T.prenet_units, P)
+        if share_proj:
+            s["dec.lstm_proj.weight"] = (T.dunits, U)
+            s["dec.post_proj.weight"] = (T.postnet_chans, Cp)
+        else:
+            s["dec.lstm0_proj.weight"] = (T.dunits, U)
+            s["dec.lstm1_proj.weight"] = (T.dunits, U)
+            for l in range(4):
+                s["dec.post%d_proj.weight" % l] = (T.postnet_chans, Cp)
+    _predictor(s, "duration_predictor", D, hp.duration_predictor_layers,
+               hp.duration_predictor_chans, hp.duration_predictor_kernel_size)
+    for nm in ("pitch", "energy"):
+        _predictor(s, nm + "_predictor", D, hp.variance_predictor_layers,
+                   hp.variance_predictor_chans, hp.variance_predictor_kernel_size)
+        s[nm + "_embed.0.weight"] = (D, 1, hp.variance_embed_kernel_size)
+        s[nm + "_embed.0.bias"] = (D,)
+    if T is not None:
+        s["pemb_proj.weight"] = (T.eunits, hp.eunits)
+        s["eemb_proj.weight"] = (T.eunits, hp.eunits)
+    return s

@@ -1,0 +1,379 @@
+#!/usr/bin/env python3
+"""gen_golden.py — run the REAL reference (/root/reference) on CPU and dump golden vectors.
+
+TEST TOOLING.  Runs only in the container that has /root/reference (never on the GPU box).  It imports
+the reference's `nets/**`, `variance_predictor.py` and `tts.py:CustomConverter` UNMODIFIED through
+`oracle/espnet_shim` (+ attribute-auto-stub modules for chainer/apex/kaldiio/... that tts.py imports at
+module level but the converter never touches), loads closed-form weights
+(`fcl_taco2_amd.synthetic.closed_form_state_dict`) with `load_state_dict`, and writes small `.npz` /
+`.json` fixtures to tests/golden/.  Nothing of the reference's source text is written anywhere.
+
+    python -B oracle/gen_golden.py            # regenerates every set (≈1 min)
+
+Sets: manifest, G1 (tiny dims, every stage, inference+forward, teacher+student,
+share_proj on/off), G2 (full S dims, 1 utt, prenet dropout 0), G2T (full T dims), G2B (3 utterances for
+the batched extension), G3 (injected prenet dropout masks), G4 (integer: duration rounding, converter
+layout), G5 (training losses + a few gradients, eval-dropout-off), G6 (padding leak + zero-duration
+failure record).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "espnet_shim"))
+sys.path.insert(0, REF)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import fcl_taco2_amd  # noqa: E402,F401
+from fcl_taco2_amd import hparams as HP  # noqa: E402
+from fcl_taco2_amd import synthetic as SYN  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+class _AutoStub(types.ModuleType):
+    """Module whose every attribute is a fresh empty class (usable as base class or callable)."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        cls = type(name, (), {"__init__": lambda self, *a, **k: None})
+        setattr(self, name, cls)
+        return cls
+
+
+def _install_stubs():
+    for m in ["chainer", "chainer.training", "chainer.training.extensions", "kaldiio", "matplotlib",
+              "tensorboardX", "apex", "apex.amp", "espnet.asr", "espnet.asr.asr_utils",
+              "espnet.asr.pytorch_backend", "espnet.asr.pytorch_backend.asr_init", "espnet.utils.dataset",
+              "espnet.utils.dynamic_import", "espnet.utils.training", "espnet.utils.training.evaluator",
+              "espnet.utils.deterministic_utils", "espnet.utils.training.train_utils",
+              "espnet.utils.training.iterators", "espnet.utils.training.tensorboard_logger"]:
+        if m not in sys.modules:
+            sys.modules[m] = _AutoStub(m)
+    sys.modules["chainer"].training = sys.modules["chainer.training"]
+    sys.modules["chainer.training"].extensions = sys.modules["chainer.training.extensions"]
+    sys.modules["apex"].amp = sys.modules["apex.amp"]
+    sys.modules["matplotlib"].use = lambda *a, **k: None
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def ns(hp, **extra):
+    d = {k: getattr(hp, k) for k in (
+        "embed_dim elayers eunits econv_layers econv_chans econv_filts dlayers dunits prenet_layers "
+        "prenet_units postnet_layers postnet_chans postnet_filts use_batch_norm use_concate use_residual "
+        "reduction_factor dropout_rate zoneout_rate use_masking duration_predictor_layers "
+        "duration_predictor_chans duration_predictor_kernel_size duration_predictor_dropout_rate").split()}
+    d["encoder_resume"] = None
+    d.update(extra)
+    return argparse.Namespace(**d)
+
+
+COM = dict(use_fe_condition=True, append_position=True, distill_output_knowledge=True,
+           distill_encoder_knowledge=True, distill_decoder_knowledge=True, distill_prosody_knowledge=True,
+           is_train=True)
+
+
+def build(role, hp, thp=None, share_proj=True):
+    from nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+    from nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
+    from nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa as Teacher
+
+    com = argparse.Namespace(share_proj=share_proj, **COM)
+    if role == "student":
+        m = _quiet(Student, hp.idim, hp.odim, ns(hp), com, ns(thp))
+        spec = HP.param_spec(hp, thp, share_proj)
+    elif role == "kd_teacher":
+        m = _quiet(KDTeacher, hp.idim, hp.odim, ns(hp), com)
+        spec = HP.param_spec(hp)
+    else:
+        m = _quiet(Teacher, hp.idim, hp.odim, ns(hp), com)
+        spec = HP.param_spec(hp)
+    ref_spec = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert ref_spec == {k: tuple(v) for k, v in spec.items()}, "param_spec != reference state_dict manifest"
+    sd = SYN.closed_form_state_dict(spec)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m.eval()
+    return m, spec
+
+
+@contextlib.contextmanager
+def injected_dropout(keep_masks):
+    """Patch torch.nn.functional.dropout so every training=True call consumes the next closed-form keep
+    mask.  keep_masks: iterator of uint8 arrays."""
+    import torch.nn.functional as F
+
+    orig = F.dropout
+    it = iter(keep_masks)
+
+    def fake(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        keep = torch.from_numpy(next(it)).to(x.dtype)
+        assert keep.shape == x.shape
+        return x * keep * (1.0 / (1.0 - p))
+
+    F.dropout = fake
+    try:
+        yield
+    finally:
+        F.dropout = orig
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-28s %8.1f KB  %s" % (name + ".npz", os.path.getsize(path) / 1024.0, sorted(arrs)[:6]))
+
+
+TINY_S = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20,
+                            postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0)
+TINY_T = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
+                            postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0)
+
+
+def gen_manifest():
+    man = {}
+    S, T = HP.student_hparams(), HP.teacher_hparams()
+    for tag, role, hp, thp, share in [("student_share", "student", S, T, True), ("student_noshare", "student", S, T, False),
+                                      ("teacher", "teacher", T, None, True), ("kd_teacher", "kd_teacher", T, None, True)]:
+        m, spec = build(role, hp, thp, share)
+        man[tag] = {k: list(v) for k, v in spec.items()}
+        man[tag + "_nparams"] = int(sum(p.numel() for p in m.parameters()))
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(man, f, indent=0, sort_keys=True)
+    print("manifest.json", {k: v for k, v in man.items() if k.endswith("_nparams")})
+
+
+def stage_dump(m, x, dur):
+    """Every tensor after every H-row of inference(), by calling the reference sub-modules in the order
+    ..._kd_student.py:804-863 does."""
+    from espnet.nets.pytorch_backend.nets_utils import make_pad_mask
+
+    with torch.no_grad():
+        emb = m.enc.embed(x.unsqueeze(0)).transpose(1, 2)
+        c = emb
+        convs = []
+        for i in range(len(m.enc.convs)):
+            c = m.enc.convs[i](c)
+            convs.append(c)
+        h = m.enc.inference(x)
+        ilens = torch.LongTensor([h.shape[0]])
+        pad = make_pad_mask(ilens)
+        d_log = m.duration_predictor(h.unsqueeze(0), pad)
+        d_int = m.duration_predictor.inference(h.unsqueeze(0), pad)
+        p = m.pitch_predictor(h.unsqueeze(0), pad.unsqueeze(-1))
+        e = m.energy_predictor(h.unsqueeze(0), pad.unsqueeze(-1))
+        pe = m.pitch_embed(p.transpose(1, 2)).transpose(1, 2)
+        ee = m.energy_embed(e.transpose(1, 2)).transpose(1, 2)
+        after = m.inference(x, None, dur=dur)
+    out = dict(x=t2n(x), dur=t2n(dur), embed=t2n(emb[0].t()), h=t2n(h), d_log=t2n(d_log[0]), d_int=t2n(d_int[0]),
+               p_outs=t2n(p[0]), e_outs=t2n(e[0]), p_embs=t2n(pe[0]), e_embs=t2n(ee[0]), after=t2n(after))
+    for i, cv in enumerate(convs):
+        out["conv%d" % i] = t2n(cv[0].t())
+    return out
+
+
+def before_from(m, x, dur):
+    """`before` (pre-postnet) mel: re-run dec.inference with the postnet output captured by a hook."""
+    cap = {}
+    hk = m.dec.postnet.register_forward_pre_hook(lambda mod, inp: cap.__setitem__("before", inp[0].detach().clone()))
+    with torch.no_grad():
+        m.inference(x, None, dur=dur)
+    hk.remove()
+    return t2n(cap["before"][0].t())
+
+
+def make_converter_batch(hp, seed, batch=4):
+    from tts import CustomConverter
+
+    xs, ys, ds, f0, en = SYN.training_batch(hp.odim, hp.idim, batch=batch, seed=seed)
+    conv = CustomConverter(reduction_factor=1, use_fe_condition=True, append_position=True)
+    b = conv([(xs, ys, None, ds, f0, en)])
+    return (xs, ys, ds, f0, en), b
+
+
+def gen_g1():
+    rng = np.random.RandomState(11)
+    x = torch.from_numpy(rng.randint(1, TINY_S.idim, size=7).astype(np.int64))
+    dur = torch.tensor([1, 3, 2, 5, 1, 4, 2])
+    for tag, role, hp, thp, share in [("student_share", "student", TINY_S, TINY_T, True),
+                                      ("student_noshare", "student", TINY_S, TINY_T, False),
+                                      ("teacher", "teacher", TINY_T, None, True)]:
+        m, _ = build(role, hp, thp, share)
+        d = stage_dump(m, x, dur)
+        d["before"] = before_from(m, x, dur)
+        save("g1_infer_" + tag, **d)
+    # teacher-forced forward: kd_teacher 5-tuple -> student losses; and the plain teacher's losses
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    kt, _ = build("kd_teacher", TINY_T)
+    with torch.no_grad():
+        know = kt(**b)
+    flat = dict(t_after=t2n(know[0]), t_before=t2n(know[1]))
+    for grp, items in (("t_enc", know[2]), ("t_dec", know[3]), ("t_pro", know[4])):
+        for i, it in enumerate(items):
+            flat["%s%d" % (grp, i)] = t2n(it)
+    for share in (True, False):
+        st, _ = build("student", TINY_S, TINY_T, share)
+        with torch.no_grad():
+            loss = st(teacher_knowledge=know, **b)
+        rep = {list(d.keys())[0]: list(d.values())[0] for d in st.reporter.last}
+        flat["student_%s_loss" % ("share" if share else "noshare")] = np.float32(loss.item())
+        for k, v in rep.items():
+            flat["student_%s_%s" % ("share" if share else "noshare", k)] = np.float32(v)
+    te, _ = build("teacher", TINY_T)
+    with torch.no_grad():
+        loss = te(**b)
+    for d in te.reporter.last:
+        for k, v in d.items():
+            flat["teacher_" + k] = np.float32(v)
+    save("g1_forward", **flat)
+
+
+def c1_inputs(hp, n=80, seed=137):
+    x, d = SYN.utterance_c1(hp.idim, n, seed)
+    return torch.from_numpy(x), torch.from_numpy(d)
+
+
+def gen_g2_g3():
+    S0 = HP.student_hparams(dropout_rate=0.0)
+    T = HP.teacher_hparams()
+    x, dur = c1_inputs(S0)
+    m, _ = build("student", S0, T, True)
+    with torch.no_grad():
+        after = m.inference(x, None, dur=dur)
+        h = m.enc.inference(x)
+    save("g2_student_c1", x=t2n(x), dur=t2n(dur), after=t2n(after), before=before_from(m, x, dur), h=t2n(h))
+    # G2B: three utterances of different lengths -> the batched extension must equal per-utterance inference
+    xs, ds = SYN.batch_c2(S0.idim, batch=3, t_lo=20, t_hi=40, seed=99)
+    d = {}
+    for i, (xi, di) in enumerate(zip(xs, ds)):
+        with torch.no_grad():
+            d["after%d" % i] = t2n(m.inference(torch.from_numpy(xi), None, dur=torch.from_numpy(di)))
+        d["x%d" % i], d["dur%d" % i] = xi, di
+    save("g2b_student_batch3", **d)
+    # G3: dropout 0.5 with injected masks
+    S = HP.student_hparams()
+    m, _ = build("student", S, T, True)
+    n_steps, N = int(dur.max()), int((dur > 0).sum())
+    keep = SYN.closed_form_keep_mask((n_steps, 2, N, S.prenet_units), seed=2024)
+    with injected_dropout(keep[t, l] for t in range(n_steps) for l in range(2)):
+        with torch.no_grad():
+            after = m.inference(x, None, dur=dur)
+    save("g3_student_c1_masked", x=t2n(x), dur=t2n(dur), after=t2n(after), keep_seed=np.int64(2024))
+    # run-to-run stochasticity record (D8): two un-patched calls differ
+    with torch.no_grad():
+        a, b = m.inference(x, None, dur=dur), m.inference(x, None, dur=dur)
+    rec = {"d8_two_calls_max_abs_diff": float((a - b).abs().max())}
+    # G2T: full T dims, config[0] of BASELINE.json (batch 1, CPU)
+    T0 = HP.teacher_hparams(dropout_rate=0.0)
+    mt, _ = build("teacher", T0)
+    with torch.no_grad():
+        after = mt.inference(x, None, dur=dur)
+    save("g2t_teacher_c1", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    return rec
+
+
+def gen_g4():
+    # duration rounding: ties in the linear domain (round-half-even), negatives, clamp
+    lin = np.array([-3.0, -0.5, -0.49, 0.0, 0.49, 0.5, 0.51, 1.5, 2.5, 3.5, 4.5, 7.49, 7.5, 49.5, 50.5, 1e4], np.float32)
+    lin_round = t2n(torch.clamp(torch.round(torch.from_numpy(lin)), min=0).long())
+    logits = np.array([-20.0, -1.0, -0.2, 0.0, 0.3, 0.6931472, 1.0, 1.5, 2.0, 2.3978953, 3.0, 3.9, 5.0], np.float32)
+    from espnet.nets.pytorch_backend.fastspeech.duration_predictor import DurationPredictor  # the shim's
+
+    dp = DurationPredictor(4)
+    dp.eval()
+    ref = t2n(torch.clamp(torch.round(torch.from_numpy(logits).exp() - dp.offset), min=0).long())
+    d = dict(lin=lin, lin_round=lin_round, logits=logits, logits_round=ref)
+    # converter layout incl. zero-duration phonemes (B=4) — the real tts.py:CustomConverter
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    xs, ys, ds, f0, en = raw
+    for i in range(len(xs)):
+        d["in_xs%d" % i], d["in_ys%d" % i], d["in_ds%d" % i], d["in_f0%d" % i], d["in_en%d" % i] = xs[i], ys[i], ds[i], f0[i], en[i]
+    for k, v in b.items():
+        d["out_" + k] = t2n(v)
+    # a second, larger one at mel dim 80 for the index maps only
+    raw2, b2 = make_converter_batch(HP.student_hparams(), seed=21, batch=6)
+    for i in range(6):
+        d["in2_ds%d" % i] = raw2[2][i]
+    for k in ("non_zero_lens_mask", "ds_nonzeros", "output_masks", "position", "ilens", "olens"):
+        d["out2_" + k] = t2n(b2[k])
+    save("g4_integer", **d)
+
+
+def gen_g5():
+    """Training: total loss, every named loss and gradients of a few parameters for one B=4 batch,
+    model.eval() (running-stat BN, nn.Dropout off, eval zoneout), prenet dropout 0."""
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    te, _ = build("teacher", TINY_T)
+    for p in te.parameters():
+        p.grad = None
+    loss = te(**b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()))
+    for k in ["dec.feat_out.weight", "enc.embed.weight", "duration_predictor.linear.weight",
+              "dec.lstm.0.cell.weight_hh", "dec.prenet.prenet.0.0.bias", "pitch_embed.0.weight",
+              "dec.postnet.postnet.4.0.weight", "enc.blstm.weight_hh_l0_reverse"]:
+        d["grad:" + k] = t2n(dict(te.named_parameters())[k].grad).copy()  # copy: clip_grad_norm_ below scales in place
+    gn = torch.nn.utils.clip_grad_norm_(te.parameters(), 1.0)
+    d["grad_norm"] = np.float32(float(gn))
+    save("g5_teacher_train", **d)
+
+
+def gen_g6(rec):
+    m, _ = build("teacher", TINY_T)
+    rng = np.random.RandomState(5)
+    x0 = rng.randint(1, TINY_T.idim, size=9).astype(np.int64)
+    x1 = rng.randint(1, TINY_T.idim, size=5).astype(np.int64)
+    xs = torch.zeros(2, 9, dtype=torch.long)
+    xs[0, :9], xs[1, :5] = torch.from_numpy(x0), torch.from_numpy(x1)
+    with torch.no_grad():
+        hs, hlens = m.enc(xs, [9, 5])
+        h1 = m.enc.inference(torch.from_numpy(x1))
+    save("g6_padding_leak", xs=t2n(xs), ilens=np.array([9, 5]), hs_batched=t2n(hs), h1_single=t2n(h1))
+    rec["g6_leak_max_abs_on_shorter"] = float((hs[1, :5] - h1).abs().max())
+    # zero predicted duration crashes reference inference
+    try:
+        with torch.no_grad():
+            m.inference(torch.from_numpy(x1), None, dur=torch.tensor([2, 0, 1, 3, 1]))
+        rec["zero_duration"] = "no error"
+    except AssertionError:
+        rec["zero_duration"] = "AssertionError"
+    with open(os.path.join(OUT, "records.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print("records.json", rec)
+
+
+def main():
+    assert os.path.isdir(REF), "gen_golden.py needs /root/reference (survey container only)"
+    os.makedirs(OUT, exist_ok=True)
+    _install_stubs()
+    gen_manifest()
+    gen_g1()
+    rec = gen_g2_g3()
+    gen_g4()
+    gen_g5()
+    gen_g6(rec)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,27 @@
+"""Shared test helpers: closed-form state_dicts as torch tensors, tiny hparams used by the goldens."""
+import numpy as np
+import torch
+
+import fcl_taco2_amd  # noqa: F401
+from fcl_taco2_amd import hparams as HP
+from fcl_taco2_amd import synthetic as SYN
+
+TINY_S = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20,
+                            postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0)
+TINY_T = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
+                            postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0)
+
+
+def np_state_dict(hp, thp=None, share_proj=True):
+    return SYN.closed_form_state_dict(HP.param_spec(hp, thp, share_proj))
+
+
+def torch_state_dict(hp, thp=None, share_proj=True):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np_state_dict(hp, thp, share_proj).items()}
+
+
+def max_abs(a, b):
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+    b = b.detach().cpu().numpy() if hasattr(b, "detach") else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0

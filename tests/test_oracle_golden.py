@@ -1,0 +1,177 @@
+"""Pin the CPU oracle (oracle/fcl_oracle.py) against outputs of the REAL reference (tests/golden/*.npz,
+made by oracle/gen_golden.py in the survey container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import TINY_S, TINY_T, max_abs, torch_state_dict
+from conftest import GOLDEN
+from fcl_taco2_amd import hparams as HP
+from fcl_taco2_amd import synthetic as SYN
+from oracle import fcl_oracle as O
+
+TOL_STAGE = 1e-5  # per-stage fp32 tolerance on tiny dims (SURVEY.md §8c recommends <= 1e-4)
+TOL_MEL = 2e-4    # full-dims mel vs the reference (north_star bar is 1e-3)
+
+
+def test_manifest_matches_reference():
+    man = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+    S, T = HP.student_hparams(), HP.teacher_hparams()
+    for tag, spec in [("student_share", HP.param_spec(S, T, True)), ("student_noshare", HP.param_spec(S, T, False)),
+                      ("teacher", HP.param_spec(T)), ("kd_teacher", HP.param_spec(T))]:
+        assert {k: list(v) for k, v in spec.items()} == man[tag]
+    assert man["student_share_nparams"] == 6466595 and man["teacher_nparams"] == 28972579
+
+
+@pytest.mark.parametrize("tag,hp,thp,share", [("student_share", TINY_S, TINY_T, True),
+                                              ("student_noshare", TINY_S, TINY_T, False),
+                                              ("teacher", TINY_T, None, True)])
+def test_g1_inference_every_stage(golden, tag, hp, thp, share):
+    g = golden("g1_infer_" + tag)
+    sd = torch_state_dict(hp, thp, share)
+    x, dur = torch.from_numpy(g["x"]), torch.from_numpy(g["dur"])
+    with torch.no_grad():
+        enc, taps = O.encoder_forward(sd, hp, x.unsqueeze(0), [x.numel()])
+        assert max_abs(taps[0][0], g["embed"]) == 0.0
+        for i in range(3):
+            assert max_abs(taps[1 + i][0], g["conv%d" % i]) < TOL_STAGE
+        assert max_abs(enc[0], g["h"]) < TOL_STAGE
+        pad = O.make_pad_mask([x.numel()])
+        assert max_abs(O.duration_predictor(sd, hp, enc, pad)[0], g["d_log"]) < TOL_STAGE
+        assert np.array_equal(O.duration_predictor(sd, hp, enc, pad, inference=True)[0].numpy(), g["d_int"])
+        r = O.inference(sd, hp, x, dur=dur)
+    for k in ("p_outs", "e_outs", "p_embs", "e_embs", "before", "after"):
+        assert max_abs(r[k], g[k]) < TOL_STAGE, k
+
+
+def test_g2_full_student_mel(golden):
+    g = golden("g2_student_c1")
+    hp = HP.student_hparams(dropout_rate=0.0)
+    sd = torch_state_dict(hp, HP.teacher_hparams())
+    x, d = SYN.utterance_c1(hp.idim)
+    assert np.array_equal(x, g["x"]) and np.array_equal(d, g["dur"])
+    with torch.no_grad():
+        r = O.inference(sd, hp, torch.from_numpy(x), dur=torch.from_numpy(d))
+    assert max_abs(r["h"], g["h"]) < TOL_MEL
+    assert max_abs(r["before"], g["before"]) < TOL_MEL
+    assert max_abs(r["after"], g["after"]) < TOL_MEL
+    assert r["after"].shape == (int(d.sum()), 80)
+
+
+def test_g2b_batched_extension(golden):
+    g = golden("g2b_student_batch3")
+    hp = HP.student_hparams(dropout_rate=0.0)
+    sd = torch_state_dict(hp, HP.teacher_hparams())
+    xs = [torch.from_numpy(g["x%d" % i]) for i in range(3)]
+    ds = [torch.from_numpy(g["dur%d" % i]) for i in range(3)]
+    with torch.no_grad():
+        mels = O.synthesize_batch(sd, hp, xs, ds)
+    for i in range(3):
+        assert max_abs(mels[i], g["after%d" % i]) < TOL_MEL
+
+
+def test_g3_injected_prenet_dropout(golden):
+    g = golden("g3_student_c1_masked")
+    hp = HP.student_hparams()
+    sd = torch_state_dict(hp, HP.teacher_hparams())
+    x, d = torch.from_numpy(g["x"]), torch.from_numpy(g["dur"])
+    keep = torch.from_numpy(SYN.closed_form_keep_mask((int(d.max()), 2, int((d > 0).sum()), hp.prenet_units), int(g["keep_seed"])))
+    with torch.no_grad():
+        r = O.inference(sd, hp, x, dur=d, prenet_keep=keep)
+    assert max_abs(r["after"], g["after"]) < TOL_MEL
+
+
+def test_g2t_full_teacher_mel(golden):
+    g = golden("g2t_teacher_c1")
+    hp = HP.teacher_hparams(dropout_rate=0.0)
+    sd = torch_state_dict(hp)
+    with torch.no_grad():
+        r = O.inference(sd, hp, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]))
+    assert max_abs(r["after"], g["after"]) < TOL_MEL
+
+
+def test_g4_duration_rounding_bit_exact(golden):
+    g = golden("g4_integer")
+    lin = torch.from_numpy(g["lin"])
+    assert np.array_equal(torch.clamp(torch.round(lin), min=0).long().numpy(), g["lin_round"])
+    # half-to-even on exact ties, clamp of negatives
+    assert g["lin_round"].tolist()[:11] == [0, 0, 0, 0, 0, 0, 1, 2, 2, 4, 4]
+    assert np.array_equal(O.duration_round(torch.from_numpy(g["logits"])).numpy(), g["logits_round"])
+
+
+def _raw_batch(g, n, pre="in_"):
+    return ([g[pre + "xs%d" % i] for i in range(n)], [g[pre + "ys%d" % i] for i in range(n)],
+            [g[pre + "ds%d" % i] for i in range(n)], [g[pre + "f0%d" % i] for i in range(n)],
+            [g[pre + "en%d" % i] for i in range(n)])
+
+
+def test_g4_converter_layout_bit_exact(golden):
+    g = golden("g4_integer")
+    b = O.convert_batch(*_raw_batch(g, 4))
+    for k in ("xs", "ilens", "ys", "olens", "extras", "new_ys", "non_zero_lens_mask", "ds_nonzeros",
+              "output_masks", "position", "f0", "energy"):
+        assert np.array_equal(b[k].numpy(), g["out_" + k]), k
+    assert (g["out_non_zero_lens_mask"] == 0).sum() > (g["out_xs"] == 0).sum() - 1  # has zero-duration phonemes
+
+
+def _know(g):
+    return (torch.from_numpy(g["t_after"]), torch.from_numpy(g["t_before"]),
+            [torch.from_numpy(g["t_enc%d" % i]) for i in range(5)],
+            [torch.from_numpy(g["t_dec%d" % i]) for i in range(8)],
+            [torch.from_numpy(g["t_pro%d" % i]) for i in range(5)])
+
+
+def test_g1_forward_teacher_student_losses(golden):
+    g4, g = golden("g4_integer"), golden("g1_forward")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    with torch.no_grad():
+        kt = O.model_forward(torch_state_dict(TINY_T), TINY_T, b, "kd_teacher")
+    know = _know(g)
+    assert max_abs(kt[0], know[0]) < TOL_STAGE and max_abs(kt[1], know[1]) < TOL_STAGE
+    for mine, ref in zip(kt[2] + kt[3] + kt[4], know[2] + know[3] + know[4]):
+        assert max_abs(mine, ref) < TOL_STAGE
+    for share in (True, False):
+        tag = "student_%s_" % ("share" if share else "noshare")
+        with torch.no_grad():
+            rep = O.model_forward(torch_state_dict(TINY_S, TINY_T, share), TINY_S, b, "student", TINY_T, share, know)
+        for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss",
+                  "output_mse_loss", "encoder_loss", "decoder_loss", "prosody_loss"):
+            assert abs(float(rep[k]) - float(g[tag + k])) < 1e-4 * max(1.0, abs(float(g[tag + k]))), (k, float(rep[k]), float(g[tag + k]))
+    with torch.no_grad():
+        rep = O.model_forward(torch_state_dict(TINY_T), TINY_T, b, "teacher")
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(rep[k]) - float(g["teacher_" + k])) < 1e-4 * max(1.0, abs(float(g["teacher_" + k]))), k
+
+
+def test_g5_training_gradients(golden):
+    g4, g = golden("g4_integer"), golden("g5_teacher_train")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in torch_state_dict(TINY_T).items()}
+    rep = O.model_forward(sd, TINY_T, b, "teacher")
+    rep["loss"].backward()
+    assert abs(float(rep["loss"]) - float(g["loss"])) < 1e-4
+    for k in g:
+        if k.startswith("grad:"):
+            ref = g[k]
+            assert max_abs(sd[k[5:]].grad, ref) < 1e-4 * max(1.0, float(np.abs(ref).max())), k
+    params = [v for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in params if p.grad is not None))
+    assert abs(float(gn) - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
+
+
+def test_g6_padding_leak_and_zero_duration(golden):
+    g = golden("g6_padding_leak")
+    rec = json.load(open(os.path.join(GOLDEN, "records.json")))
+    sd = torch_state_dict(TINY_T)
+    with torch.no_grad():
+        hs, _ = O.encoder_forward(sd, TINY_T, torch.from_numpy(g["xs"]), g["ilens"].tolist())
+        h1 = O.encoder_inference(sd, TINY_T, torch.from_numpy(g["xs"][1, :5]))
+    assert max_abs(hs, g["hs_batched"]) < TOL_STAGE
+    assert max_abs(h1, g["h1_single"]) < TOL_STAGE
+    assert max_abs(hs[1, :5], h1) > 1e-3  # the leak is real and reproduced
+    assert rec["zero_duration"] == "AssertionError"
+    with pytest.raises(AssertionError):
+        O.inference(sd, TINY_T, torch.from_numpy(g["xs"][1, :5]), dur=torch.tensor([2, 0, 1, 3, 1]))
