@@ -1,0 +1,84 @@
+"""ctypes binding of libfcl_hip.so (include/fcl_hip.h).  Fails loudly when the library is missing.
+
+This is the only place the package touches the shared library.  There is no CPU fallback: if the HIP
+extension cannot be loaded, importing any compute entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcl_hip.so")
+
+# name -> (restype, argtypes); mirrors include/fcl_hip.h one to one
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [("c", _I), ("p", _I), ("u", _I), ("odim", _I)] + [
+        (n, _P) for n in ("prenet_w0", "prenet_b0", "prenet_w1", "prenet_b1", "w0_att", "w0_pre", "w0_pos", "w0_hh", "b0",
+                          "w1_ih", "w1_hh", "b1", "wf_h", "wf_att")
+    ] + [("zoneout_rate", _F), ("prenet_dropout", _F)]
+
+
+class DecoderIO(C.Structure):
+    _fields_ = [("n", _I), ("lmax", _I), ("att_c", _P), ("dur", _P), ("live_rows_host", _P), ("frame_off", _P),
+                ("teacher_ys", _P), ("dropout_mode", _I), ("prenet_keep", _P), ("seed", C.c_uint32), ("before", _P),
+                ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+
+
+SIGNATURES = {
+    "fcl_last_error": (C.c_char_p, []),
+    "fcl_version": (_I, []),
+    "fcl_pack_conv1d_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "fcl_fold_batchnorm": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "fcl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "fcl_add_vec": (_I, [_P, _P, _P, _I, _P]),
+    "fcl_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "fcl_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcl_conv1d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcl_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_duration_round_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P]),
+    "fcl_variance_embed_add_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
+    "fcl_position_table_fwd": (_I, [_P, _P, _I, _I, _P]),
+    "fcl_gather_rows_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "fcl_bilstm_workspace_bytes": (_Z, [_I, _I, _I]),
+    "fcl_bilstm_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P, _Z, _P]),
+    "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
+    "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
+}
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+DROP_NONE, DROP_MASK, DROP_RNG = 0, 1, 2
+
+_lib = None
+
+
+class FclError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfcl_hip.so and bind every symbol of include/fcl_hip.h.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FclError(
+            "fcl-taco2_amd: %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C fcl-taco2_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().fcl_last_error()
+        raise FclError("libfcl_hip error %d: %s" % (rc, msg.decode("utf-8", "replace") if msg else "?"))

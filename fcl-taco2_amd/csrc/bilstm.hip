@@ -1,0 +1,164 @@
+// bilstm.hip — H3: the encoder's 1-layer bidirectional LSTM over packed sequences (gfx950).
+//
+// Step 1 (both algorithms): input projections for every time step at once, one MFMA GEMM per direction:
+//     Gx_d[b*T + t, :] = x[b*T + t, :] . W_ih_d^T + (b_ih_d + b_hh_d)                    [B*T, 4H]
+// Step 2, the recurrence, is latency-bound (T dependent steps of a [4H x H] mat-vec per utterance):
+//   algo 2 "persistent": one workgroup per (utterance, direction); thread j keeps row j of W_hh in
+//          REGISTERS for the whole sequence (H floats/thread; H=128 -> 256 KB per workgroup, the fused
+//          mat-vec with persistent weights of the north star), h is broadcast from LDS, the cell update
+//          runs on the first H threads; 2 barriers per step, no global traffic but Gx in / h out.
+//   algo 1 "steps": one fused LSTM-step GEMM launch (gemm_f32.hip) per time step and direction, rows =
+//          utterances, packed-sequence semantics via row_len.  Any H; also the cross-check of algo 2.
+#include "fcl_common.h"
+
+namespace fcl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int H>
+__global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
+                                                                   const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                                   const int* __restrict__ lens, float* __restrict__ out, int T) {
+    __shared__ __attribute__((aligned(16))) float h_s[H];
+    __shared__ float g_s[4 * H];
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    const float* gx = (dir ? gx_r : gx_f) + (size_t)b * T * (4 * H);
+    const float* whh = dir ? whh_r : whh_f;
+    const int len = lens[b];
+
+    float w[H];
+#pragma unroll
+    for (int k = 0; k < H; k += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(whh + (size_t)j * H + k);
+        w[k] = v[0]; w[k + 1] = v[1]; w[k + 2] = v[2]; w[k + 3] = v[3];
+    }
+    if (j < H) h_s[j] = 0.f;
+    float c = 0.f;
+    // zero the padded tail of this direction's half of the output rows
+    for (int t = len + (j / H); t < T; t += 4)
+        out[((size_t)b * T + t) * (2 * H) + dir * H + (j % H)] = 0.f;
+    __syncthreads();
+
+    int t = dir ? len - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float gnext = len > 0 ? gx[(size_t)t * (4 * H) + j] : 0.f;
+    for (int s = 0; s < len; ++s, t += dt) {
+        const float gcur = gnext;
+        if (s + 1 < len) gnext = gx[(size_t)(t + dt) * (4 * H) + j];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < H; k += 4) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(&h_s[k]);  // same address in every lane: LDS broadcast
+            a0 = fmaf(w[k], hv[0], a0);
+            a1 = fmaf(w[k + 1], hv[1], a1);
+            a2 = fmaf(w[k + 2], hv[2], a2);
+            a3 = fmaf(w[k + 3], hv[3], a3);
+        }
+        g_s[j] = gcur + ((a0 + a1) + (a2 + a3));
+        __syncthreads();
+        if (j < H) {
+            const float ig = sigm(g_s[j]), fg = sigm(g_s[H + j]), gg = tanhf(g_s[2 * H + j]), og = sigm(g_s[3 * H + j]);
+            c = fg * c + ig * gg;
+            const float h = og * tanhf(c);
+            h_s[j] = h;
+            out[((size_t)b * T + t) * (2 * H) + dir * H + j] = h;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void fill_kernel(float* p, long long n, float v) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+}  // namespace fcl
+
+using namespace fcl;
+
+extern "C" {
+
+// workspace: Gx_f [B*T,4H] | Gx_r [B*T,4H] | h[2][2 dirs][B,H] | c[2 dirs][B,H]
+size_t fcl_bilstm_workspace_bytes(int b, int t, int h) {
+    if (b <= 0 || t <= 0 || h <= 0) return 0;
+    return sizeof(float) * ((size_t)2 * b * t * 4 * h + (size_t)6 * b * h) + 256;
+}
+
+int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
+                   const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,
+                   int algo, void* workspace, size_t workspace_bytes, fcl_stream_t stream) {
+    FCL_REQUIRE(x && lens && w_ih_f && w_hh_f && b_f && w_ih_r && w_hh_r && b_r && out, FCL_ERR_INVALID, "bilstm_fwd: null argument");
+    FCL_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && (c & 3) == 0 && (h & 3) == 0, FCL_ERR_SHAPE, "bilstm_fwd: bad sizes B=%d T=%d C=%d H=%d", b, t, c, h);
+    FCL_REQUIRE(workspace && workspace_bytes >= fcl_bilstm_workspace_bytes(b, t, h), FCL_ERR_WORKSPACE, "bilstm_fwd: workspace too small");
+    FCL_REQUIRE(aligned16(workspace) && aligned16(out), FCL_ERR_ALIGN, "bilstm_fwd: 16-byte alignment required");
+    hipStream_t s = (hipStream_t)stream;
+    float* gx_f = reinterpret_cast<float*>(workspace);
+    float* gx_r = gx_f + (size_t)b * t * 4 * h;
+    float* hbuf = gx_r + (size_t)b * t * 4 * h;  // [2 ping-pong][2 dirs][B,H]
+    float* cbuf = hbuf + (size_t)4 * b * h;      // [2 dirs][B,H]
+
+    for (int d = 0; d < 2; ++d) {
+        GemmArgs g = {};
+        g.term[0] = GemmTerm{x, d ? w_ih_r : w_ih_f, c, c, c, 0};
+        g.nterms = 1;
+        g.M = b * t;
+        g.N = 4 * h;
+        g.bias = d ? b_r : b_f;
+        g.Y = d ? gx_r : gx_f;
+        g.ldy = 4 * h;
+        int rc = launch_gemm(g, s);
+        if (rc) return rc;
+    }
+    const bool can_persist = (h == 8 || h == 16 || h == 32 || h == 64 || h == 128);
+    if (algo == 0) algo = can_persist ? 2 : 1;
+    FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);
+    if (algo == 2) {
+        dim3 grid(b, 2);
+#define FCL_BILSTM_CASE(HH) \
+    case HH: hipLaunchKernelGGL((bilstm_persistent_kernel<HH>), grid, dim3(4 * HH), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t); break;
+        switch (h) {
+            FCL_BILSTM_CASE(8)
+            FCL_BILSTM_CASE(16)
+            FCL_BILSTM_CASE(32)
+            FCL_BILSTM_CASE(64)
+            FCL_BILSTM_CASE(128)
+        }
+#undef FCL_BILSTM_CASE
+        return check_hip(hipGetLastError(), "bilstm persistent launch");
+    }
+    // algo 1: per-step launches
+    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, s, hbuf, (long long)6 * b * h, 0.f);
+    for (int d = 0; d < 2; ++d) {
+        float* hp[2] = {hbuf + (size_t)d * b * h, hbuf + (size_t)(2 + d) * b * h};
+        int cur = 0;
+        for (int st = 0; st < t; ++st) {
+            const int tt = d ? t - 1 - st : st;
+            LstmStepArgs a = {};
+            a.term[0] = GemmTerm{hp[cur], d ? w_hh_r : w_hh_f, h, h, h, 0};
+            a.nterms = 1;
+            a.M = b;
+            a.U = h;
+            a.G = d ? gx_r : gx_f;
+            a.g_row_mul = t;
+            a.g_row_add = tt;
+            a.step = tt;
+            a.h_in = hp[cur];
+            a.h_out = hp[cur ^ 1];
+            a.c = cbuf + (size_t)d * b * h;
+            a.zoneout = 0.f;
+            a.row_len = lens;
+            a.out2 = out;
+            a.out2_row_mul = t;
+            a.out2_row_add = tt;
+            a.ld2 = 2 * h;
+            a.out2_col_off = d * h;
+            int rc = launch_lstm_step(a, s);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// capi.hip — extern "C" surface of libfcl_hip.so: error plumbing, GEMM-backed ops, the decoder loop.
+#include <stdarg.h>
+#include <string.h>
+
+#include "fcl_common.h"
+
+namespace fcl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    return FCL_ERR_HIP;
+}
+
+__global__ void zero_kernel(float* p, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+static inline size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
+
+struct DecoderWs {
+    float *G0, *F0, *pre_a, *pre_b, *h0[2], *c0, *h1[2], *c1, *prev;
+    size_t bytes;
+};
+
+static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
+    DecoderWs ws;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+        off += align_up(floats * sizeof(float));
+        return p;
+    };
+    const size_t N = (size_t)n;
+    ws.G0 = take(N * 4 * w->u);
+    ws.F0 = take(N * w->odim);
+    ws.pre_a = take(N * w->p);
+    ws.pre_b = take(N * w->p);
+    // recurrent state is contiguous so one kernel zeroes it
+    ws.h0[0] = take(N * w->u);
+    ws.h0[1] = take(N * w->u);
+    ws.c0 = take(N * w->u);
+    ws.h1[0] = take(N * w->u);
+    ws.h1[1] = take(N * w->u);
+    ws.c1 = take(N * w->u);
+    ws.prev = take(N * w->odim);
+    ws.bytes = off;
+    return ws;
+}
+
+}  // namespace fcl
+
+using namespace fcl;
+
+extern "C" {
+
+const char* fcl_last_error(void) { return g_err; }
+int fcl_version(void) { return 100; }
+
+int fcl_linear_fwd(const float* x, int lda, const float* w, int ldw, const float* bias, float* y, int ldy, int m, int n,
+                   int k, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(x && w && y, FCL_ERR_INVALID, "linear_fwd: null argument");
+    FCL_REQUIRE(act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "linear_fwd: bad act %d", act);
+    FCL_REQUIRE(lda >= k && ldw >= k && ldy >= n, FCL_ERR_SHAPE, "linear_fwd: leading dimensions too small");
+    GemmArgs g = {};
+    g.term[0] = GemmTerm{x, w, lda, ldw, k, 0};
+    g.nterms = 1;
+    g.M = m;
+    g.N = n;
+    g.bias = bias;
+    g.act = act;
+    g.Y = y;
+    g.ldy = ldy;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
+                   const float* residual, float* y, int m, int cin, int cout, int k, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(x && wp && y && seg_lo && seg_hi, FCL_ERR_INVALID, "conv1d_fwd: null argument");
+    FCL_REQUIRE(k >= 1 && (k & 1) && k <= FCL_MAX_TERMS, FCL_ERR_SHAPE, "conv1d_fwd: kernel size %d must be odd and <= %d", k, FCL_MAX_TERMS);
+    FCL_REQUIRE(act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "conv1d_fwd: bad act %d", act);
+    FCL_REQUIRE(y != x, FCL_ERR_INVALID, "conv1d_fwd: in-place convolution is not supported");
+    GemmArgs g = {};
+    for (int j = 0; j < k; ++j) g.term[j] = GemmTerm{x, wp + (size_t)j * cout * cin, cin, cin, cin, j - (k - 1) / 2};
+    g.nterms = k;
+    g.M = m;
+    g.N = cout;
+    g.seg_lo = seg_lo;
+    g.seg_hi = seg_hi;
+    g.bias = bias;
+    g.act = act;
+    g.R = residual;
+    g.ldr = cout;
+    g.Y = y;
+    g.ldy = cout;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n) {
+    if (!w || n <= 0) return 0;
+    return carve(w, n, nullptr).bytes + 256;
+}
+
+int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, fcl_stream_t stream) {
+    FCL_REQUIRE(w && io, FCL_ERR_INVALID, "decoder_loop_fwd: null argument");
+    FCL_REQUIRE(w->c > 0 && w->p > 0 && w->u > 0 && w->odim > 0 && !(w->c & 3) && !(w->p & 3) && !(w->u & 3) && !(w->odim & 3),
+                FCL_ERR_SHAPE, "decoder_loop_fwd: C/P/U/odim must be positive multiples of 4 (got %d/%d/%d/%d)", w->c, w->p, w->u, w->odim);
+    FCL_REQUIRE(w->prenet_w0 && w->prenet_b0 && w->prenet_w1 && w->prenet_b1 && w->w0_att && w->w0_pre && w->w0_pos && w->w0_hh && w->b0 &&
+                    w->w1_ih && w->w1_hh && w->b1 && w->wf_h && w->wf_att,
+                FCL_ERR_INVALID, "decoder_loop_fwd: null weight pointer");
+    FCL_REQUIRE(io->n >= 0 && io->lmax >= 0, FCL_ERR_SHAPE, "decoder_loop_fwd: bad N=%d Lmax=%d", io->n, io->lmax);
+    if (io->n == 0 || io->lmax == 0) return 0;
+    FCL_REQUIRE(io->att_c && io->dur && io->live_rows_host && io->frame_off && io->before, FCL_ERR_INVALID, "decoder_loop_fwd: null io pointer");
+    FCL_REQUIRE(io->dropout_mode >= FCL_DROP_NONE && io->dropout_mode <= FCL_DROP_RNG, FCL_ERR_INVALID, "decoder_loop_fwd: bad dropout_mode");
+    FCL_REQUIRE(io->dropout_mode != FCL_DROP_MASK || io->prenet_keep, FCL_ERR_INVALID, "decoder_loop_fwd: FCL_DROP_MASK needs prenet_keep");
+    FCL_REQUIRE(w->prenet_dropout >= 0.f && w->prenet_dropout < 1.f, FCL_ERR_INVALID, "decoder_loop_fwd: bad prenet_dropout");
+    FCL_REQUIRE(io->workspace && aligned16(io->workspace) && io->workspace_bytes >= fcl_decoder_loop_workspace_bytes(w, io->n), FCL_ERR_WORKSPACE,
+                "decoder_loop_fwd: workspace missing, misaligned or smaller than fcl_decoder_loop_workspace_bytes()");
+    {
+        int prev = io->n;
+        FCL_REQUIRE(io->live_rows_host[0] == io->n, FCL_ERR_INVALID, "decoder_loop_fwd: live_rows_host[0] must equal N (all durations > 0)");
+        for (int t = 0; t < io->lmax; ++t) {
+            FCL_REQUIRE(io->live_rows_host[t] > 0 && io->live_rows_host[t] <= prev, FCL_ERR_INVALID,
+                        "decoder_loop_fwd: live_rows_host must be positive and non-increasing (rows sorted by duration descending)");
+            prev = io->live_rows_host[t];
+        }
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int N = io->n, C = w->c, P = w->p, U = w->u, O = w->odim;
+    DecoderWs ws = carve(w, N, io->workspace);
+
+    // zero recurrent state (h0[2], c0, h1[2], c1 are contiguous) and prev_out
+    {
+        const long long n_state = (long long)((char*)ws.prev - (char*)ws.h0[0]) / 4 + (long long)N * O;
+        hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, ws.h0[0], n_state);
+        FCL_HIP(hipGetLastError());
+    }
+    // loop-invariant hoists: att_c is constant across steps, so its share of the LSTM-0
+    // gate pre-activations and of feat_out is one GEMM each instead of Lmax of them.
+    {
+        GemmArgs g = {};
+        g.term[0] = GemmTerm{io->att_c, w->w0_att, C, C, C, 0};
+        g.nterms = 1; g.M = N; g.N = 4 * U; g.bias = w->b0; g.Y = ws.G0; g.ldy = 4 * U;
+        int rc = launch_gemm(g, s);
+        if (rc) return rc;
+        GemmArgs f = {};
+        f.term[0] = GemmTerm{io->att_c, w->wf_att, C, C, C, 0};
+        f.nterms = 1; f.M = N; f.N = O; f.Y = ws.F0; f.ldy = O;
+        rc = launch_gemm(f, s);
+        if (rc) return rc;
+    }
+    const float keep_scale = 1.0f / (1.0f - w->prenet_dropout);
+    const int drop_mode = (w->prenet_dropout > 0.f) ? io->dropout_mode : FCL_DROP_NONE;
+    int cur = 0;
+    for (int t = 0; t < io->lmax; ++t) {
+        const int n = io->live_rows_host[t];
+        // H6 prenet: 2 x {Linear -> ReLU -> dropout (always on)}
+        GemmArgs p0 = {};
+        if (io->teacher_ys && t > 0) p0.term[0] = GemmTerm{io->teacher_ys + (size_t)(t - 1) * O, w->prenet_w0, io->lmax * O, O, O, 0};
+        else p0.term[0] = GemmTerm{ws.prev, w->prenet_w0, O, O, O, 0};
+        p0.nterms = 1; p0.M = n; p0.N = P; p0.bias = w->prenet_b0; p0.act = FCL_ACT_RELU; p0.Y = ws.pre_a; p0.ldy = P;
+        p0.drop_mode = drop_mode; p0.keep_scale = keep_scale; p0.drop_p = w->prenet_dropout;
+        if (drop_mode == FCL_DROP_MASK) { p0.keep = io->prenet_keep + ((size_t)(t * 2 + 0) * N) * P; p0.ldkeep = P; }
+        p0.rng_seed = io->seed * 2654435761u + (unsigned)(t * 2 + 0);
+        int rc = launch_gemm(p0, s);
+        if (rc) return rc;
+        GemmArgs p1 = p0;
+        p1.term[0] = GemmTerm{ws.pre_a, w->prenet_w1, P, P, P, 0};
+        p1.bias = w->prenet_b1; p1.Y = ws.pre_b;
+        if (drop_mode == FCL_DROP_MASK) p1.keep = io->prenet_keep + ((size_t)(t * 2 + 1) * N) * P;
+        p1.rng_seed = io->seed * 2654435761u + (unsigned)(t * 2 + 1);
+        if (io->tap_prenet) { p1.Y2 = io->tap_prenet; p1.ldy2 = P; p1.y2_row_base = io->frame_off; p1.y2_row_add = t; }
+        rc = launch_gemm(p1, s);
+        if (rc) return rc;
+        // H7 layer 0: gates = G0 + prenet . W_pre^T + pos * w_pos + h0 . W_hh^T ; cell ; zoneout
+        LstmStepArgs l0 = {};
+        l0.term[0] = GemmTerm{ws.pre_b, w->w0_pre, P, P, P, 0};
+        l0.term[1] = GemmTerm{ws.h0[cur], w->w0_hh, U, U, U, 0};
+        l0.nterms = 2; l0.M = n; l0.U = U; l0.G = ws.G0; l0.g_row_mul = 1; l0.g_row_add = 0;
+        l0.rank1_w = w->w0_pos; l0.dur = io->dur; l0.step = t;
+        l0.h_in = ws.h0[cur]; l0.h_out = ws.h0[cur ^ 1]; l0.c = ws.c0; l0.zoneout = w->zoneout_rate;
+        if (io->tap_lstm0) { l0.out2 = io->tap_lstm0; l0.out2_row_base = io->frame_off; l0.out2_row_add = t; l0.ld2 = U; }
+        rc = launch_lstm_step(l0, s);
+        if (rc) return rc;
+        // H7 layer 1
+        LstmStepArgs l1 = {};
+        l1.term[0] = GemmTerm{ws.h0[cur ^ 1], w->w1_ih, U, U, U, 0};
+        l1.term[1] = GemmTerm{ws.h1[cur], w->w1_hh, U, U, U, 0};
+        l1.nterms = 2; l1.M = n; l1.U = U; l1.bias = w->b1; l1.step = t;
+        l1.h_in = ws.h1[cur]; l1.h_out = ws.h1[cur ^ 1]; l1.c = ws.c1; l1.zoneout = w->zoneout_rate;
+        if (io->tap_lstm1) { l1.out2 = io->tap_lstm1; l1.out2_row_base = io->frame_off; l1.out2_row_add = t; l1.ld2 = U; }
+        rc = launch_lstm_step(l1, s);
+        if (rc) return rc;
+        // H8 feat_out (+ H10 scatter to the frame-major output): out = h1 . Wf_h^T + F0
+        GemmArgs f = {};
+        f.term[0] = GemmTerm{ws.h1[cur ^ 1], w->wf_h, U, U, U, 0};
+        f.nterms = 1; f.M = n; f.N = O; f.C0 = ws.F0; f.ldc0 = O; f.Y = ws.prev; f.ldy = O;
+        f.Y2 = io->before; f.ldy2 = O; f.y2_row_base = io->frame_off; f.y2_row_add = t;
+        rc = launch_gemm(f, s);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return 0;
+}
+
+}  // extern "C"

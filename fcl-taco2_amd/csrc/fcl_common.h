@@ -1,0 +1,114 @@
+// fcl_common.h — shared declarations for libfcl_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/fcl_hip.h"
+
+namespace fcl {
+
+// ---- error plumbing: never throw across the C boundary ------------------------------------------
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define FCL_REQUIRE(cond, code, ...)            \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::fcl::set_error(__VA_ARGS__);      \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+#define FCL_HIP(expr)                                         \
+    do {                                                      \
+        int _rc = ::fcl::check_hip((expr), #expr);            \
+        if (_rc != 0) return _rc;                             \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- fused multi-term GEMM (gemm_f32.hip) ---------------------------------------------------------
+// Y[m, n] = epi( sum_t sum_k A_t[row_t(m), k] * W_t[n, k] )    A_t, W_t are K-contiguous (row-major)
+// row_t(m) = (a_row_map ? a_row_map[m] : m) + shift_t, contributing 0 outside [seg_lo[m], seg_hi[m]).
+struct GemmTerm {
+    const float* A;
+    const float* W;
+    int lda;    // floats between A rows   (multiple of 4)
+    int ldw;    // floats between W rows   (multiple of 4)
+    int K;      // multiple of 4
+    int shift;  // row shift (conv tap offset), 0 for linear terms
+};
+
+enum { FCL_MAX_TERMS = 9 };
+
+struct GemmArgs {
+    GemmTerm term[FCL_MAX_TERMS];
+    int nterms;
+    int M, N;
+    const int* seg_lo;  // [M] or null (required when any shift != 0)
+    const int* seg_hi;
+    const float* bias;  // [N] or null
+    const float* rank1_a;  // optional: acc += rank1_a[m * rank1_lda] * rank1_w[n]
+    int rank1_lda;
+    const float* rank1_w;
+    const float* C0;  // optional [M, N] added before the activation
+    int ldc0;
+    int act;  // FCL_ACT_*
+    const uint8_t* keep;  // optional {0,1} keep mask [M, N] applied after act, times keep_scale
+    int ldkeep;
+    float keep_scale;
+    unsigned int rng_seed;  // drop_mode 2: counter-hash Bernoulli(keep 1-p) instead of a mask
+    float drop_p;
+    int drop_mode;  // 0 none, 1 mask, 2 rng
+    const float* R;  // optional residual added after act/dropout
+    int ldr;
+    float* Y;
+    int ldy;
+    float* Y2;  // optional scattered copy: row = y2_row_base[m] + y2_row_add
+    int ldy2;
+    const int* y2_row_base;
+    int y2_row_add;
+};
+
+// ---- fused LSTM step (gemm_f32.hip) ----------------------------------------------------------------
+// gates[m, g*U+u] = sum_t A_t[m,:] . W_t[g*U+u,:] + G[m*g_row_mul + g_row_add, g*U+u] | bias + rank1
+// then the LSTMCell + zoneout epilogue, all four gates of a unit held by one lane.
+struct LstmStepArgs {
+    GemmTerm term[3];
+    int nterms;
+    int M, U;
+    const float* G;  // optional pre-activation init [*, 4U]
+    long long g_row_mul;
+    long long g_row_add;
+    const float* bias;  // optional [4U]
+    const float* rank1_w;  // optional [4U] with position computed in-kernel: pos = step / dur[m]
+    const int* dur;        // [M] (rank1 only)
+    int step;
+    const float* h_in;  // [M, U] previous hidden (also usually a term's A)
+    float* h_out;       // [M, U] (must not alias h_in)
+    float* c;           // [M, U] in place
+    float zoneout;      // eval-form rate (0 = plain LSTMCell)
+    const uint8_t* zone_keep_h;  // optional train-form masks [M, U] (1 keeps the OLD state)
+    const uint8_t* zone_keep_c;
+    const int* row_len;  // optional: row live iff step < row_len[m] (packed BiLSTM semantics)
+    float* out2;         // optional: out2[row*ld2 + col_off + u] = live ? h_new : 0, with
+                         // row = (out2_row_base ? out2_row_base[m] : m*out2_row_mul) + out2_row_add
+    const int* out2_row_base;
+    long long out2_row_mul;
+    long long out2_row_add;
+    int ld2;
+    int out2_col_off;
+};
+
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
+
+// counter hash shared by the rng-dropout epilogue (and mirrored nowhere on the host: rng mode is the
+// production mode and is not bit-reproducible against the reference's torch RNG stream by design).
+__host__ __device__ static inline unsigned int hash_u32(unsigned int x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
+}  // namespace fcl

@@ -1,0 +1,320 @@
+// gemm_f32.hip — fp32 MFMA (v_mfma_f32_16x16x4_f32) multi-term GEMM and fused LSTM-step kernels, gfx950.
+//
+// One tiling serves every dense contraction on the FCL-taco2 path (SURVEY.md §8a H2,H4-H8,H11):
+//   * Linear layers          : 1 term, W is the PyTorch [out, in] matrix used in place (K-contiguous).
+//   * Conv1d (channels-last) : k terms, one per tap, A rows shifted by (j - pad) and zero-filled outside
+//                              the row's segment [seg_lo, seg_hi) — an LDS-tiled stencil-as-GEMM.
+//   * LSTM / LSTMCell step   : 2-3 terms (input part, recurrent part), the four gates of a hidden unit
+//                              accumulate in the same lane so the cell + zoneout update is the epilogue.
+// Geometry: workgroup = WM x WN waves (64 lanes each); every wave owns a 16-row x 64-column strip as
+// four 16x16 accumulator tiles; K is consumed in 32-wide chunks staged global -> registers -> LDS
+// (double-buffered, one barrier per chunk).  A and W fragments are both "row x 4 consecutive k" float4
+// LDS reads: lane (r = lane&15, q = lane>>4) feeds element e of its float4 as MFMA k-slot q, so the four
+// MFMAs of a float4 cover k = {4q+e}; A and W use the same assignment, hence the sum over k is complete.
+// f32-in MFMA is an exact fmaf chain (guide §3), so results differ from the CPU reference only by
+// summation order.
+#include "fcl_common.h"
+
+namespace fcl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;          // k-chunk (floats): one 128-B line per row
+constexpr int LDS_LD = BK + 4;  // padded LDS row stride (floats); 144 B keeps float4 alignment
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int WM, int WN, bool LSTM>
+struct Geo {
+    static constexpr int BM = 16 * WM;
+    static constexpr int BN = 64 * WN;
+    static constexpr int THREADS = 64 * WM * WN;
+    static constexpr int NA = (BM * 8 + THREADS - 1) / THREADS;  // float4 loads of A per thread per chunk
+    static constexpr int NB = (BN * 8 + THREADS - 1) / THREADS;
+    static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDS_LD;
+};
+
+// Shared main loop.  n0: first output column (generic) or first hidden unit (LSTM).  NU: N (generic) or U.
+template <int WM, int WN, bool LSTM>
+__device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0,
+                                         int NU, const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
+                                         float* lds, f32x4 (&acc)[4]) {
+    using G = Geo<WM, WN, LSTM>;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // per-thread loader coordinates
+    int a_row[G::NA], a_lo[G::NA], a_hi[G::NA];
+    bool a_ok[G::NA];
+#pragma unroll
+    for (int i = 0; i < G::NA; ++i) {
+        const int idx = tid + i * G::THREADS;
+        const int row = idx >> 3;
+        const int m = m0 + row;
+        a_ok[i] = (idx < G::BM * 8) && (m < M);
+        a_row[i] = m;
+        a_lo[i] = 0;
+        a_hi[i] = 0x7fffffff;
+        if (seg_lo != nullptr && a_ok[i]) {
+            a_lo[i] = seg_lo[m];
+            a_hi[i] = seg_hi[m];
+        }
+    }
+    long long b_row[G::NB];  // W row index, -1 = zero row
+#pragma unroll
+    for (int i = 0; i < G::NB; ++i) {
+        const int idx = tid + i * G::THREADS;
+        const int row = idx >> 3;  // tile column 0..BN-1
+        long long wr = -1;
+        if (idx < G::BN * 8) {
+            if (LSTM) {
+                const int u = n0 + (row >> 6) * 16 + (row & 15);
+                const int g = (row >> 4) & 3;
+                if (u < NU) wr = (long long)g * NU + u;
+            } else {
+                const int n = n0 + row;
+                if (n < NU) wr = n;
+            }
+        }
+        b_row[i] = wr;
+    }
+    const int c4 = (tid & 7) * 4;  // idx & 7 is the same for every i because THREADS % 8 == 0
+
+    f32x4 ra[G::NA], rb[G::NB];
+    auto fetch = [&](int t, int k0) {
+        const GemmTerm T = terms[t];
+        const int k = k0 + c4;
+        const bool kin = k < T.K;
+#pragma unroll
+        for (int i = 0; i < G::NA; ++i) {
+            const int src = a_row[i] + T.shift;
+            const bool ok = a_ok[i] && kin && src >= a_lo[i] && src < a_hi[i];
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(T.A + (size_t)src * T.lda + k);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < G::NB; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b_row[i] >= 0 && kin) v = *reinterpret_cast<const f32x4*>(T.W + (size_t)b_row[i] * T.ldw + k);
+            rb[i] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+        float* A_l = lds + buf * (G::BM + G::BN) * LDS_LD;
+        float* B_l = A_l + G::BM * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < G::NA; ++i) {
+            const int idx = tid + i * G::THREADS;
+            if (idx < G::BM * 8) *reinterpret_cast<f32x4*>(A_l + (idx >> 3) * LDS_LD + c4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < G::NB; ++i) {
+            const int idx = tid + i * G::THREADS;
+            if (idx < G::BN * 8) *reinterpret_cast<f32x4*>(B_l + (idx >> 3) * LDS_LD + c4) = rb[i];
+        }
+    };
+
+    int t = 0, k0 = 0;
+    fetch(0, 0);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        // advance to the next (term, k0) chunk
+        int tn = t, kn = k0 + BK;
+        if (kn >= terms[t].K) { tn = t + 1; kn = 0; }
+        const bool has_next = tn < nterms;
+        if (has_next) fetch(tn, kn);
+
+        const float* A_l = lds + buf * (G::BM + G::BN) * LDS_LD;
+        const float* B_l = A_l + G::BM * LDS_LD;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(A_l + (wm * 16 + r16) * LDS_LD + s * 16 + kq * 4);
+            f32x4 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(B_l + (wn * 64 + j * 16 + r16) * LDS_LD + s * 16 + kq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
+            }
+        }
+        if (!has_next) break;
+        stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        t = tn;
+        k0 = kn;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
+    using G = Geo<WM, WN, false>;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+    const int m0 = blockIdx.y * G::BM, n0 = blockIdx.x * G::BN;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<WM, WN, false>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, lds, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 15, rq = lane >> 4;
+    const unsigned int seed = hash_u32(a.rng_seed);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + col;
+        if (n >= a.N) continue;
+        const float bn = a.bias ? a.bias[n] : 0.f;
+        const float r1w = a.rank1_w ? a.rank1_w[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 16 + rq * 4 + r;
+            if (m >= a.M) continue;
+            float v = acc[j][r] + bn;
+            if (a.rank1_a) v += a.rank1_a[(size_t)m * a.rank1_lda] * r1w;
+            if (a.C0) v += a.C0[(size_t)m * a.ldc0 + n];
+            if (a.act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (a.act == FCL_ACT_TANH) v = tanhf(v);
+            if (a.drop_mode == 1) {
+                v = a.keep[(size_t)m * a.ldkeep + n] ? v * a.keep_scale : 0.f;
+            } else if (a.drop_mode == 2) {
+                const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)a.N + (unsigned int)n) ^ seed);
+                v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
+            }
+            if (a.R) v += a.R[(size_t)m * a.ldr + n];
+            a.Y[(size_t)m * a.ldy + n] = v;
+            if (a.Y2) a.Y2[(size_t)(a.y2_row_base[m] + a.y2_row_add) * a.ldy2 + n] = v;
+        }
+    }
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepArgs a) {
+    using G = Geo<WM, WN, true>;
+    __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
+    const int m0 = blockIdx.y * G::BM, u0 = blockIdx.x * (16 * WN);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<WM, WN, true>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int u = u0 + wn * 16 + (lane & 15);
+    const int rq = lane >> 4;
+    if (u >= a.U) return;
+    float bg[4], pw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bg[g] = a.bias ? a.bias[g * a.U + u] : 0.f;
+        pw[g] = a.rank1_w ? a.rank1_w[g * a.U + u] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 16 + rq * 4 + r;
+        if (m >= a.M) continue;
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = acc[g][r] + bg[g];
+        if (a.G) {
+            const float* gr = a.G + (size_t)((long long)m * a.g_row_mul + a.g_row_add) * (4 * a.U);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] += gr[g * a.U + u];
+        }
+        if (a.rank1_w) {
+            const float pos = (float)a.step / (float)a.dur[m];  // reference: arange(d).float() / d
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] += pos * pw[g];
+        }
+        const size_t off = (size_t)m * a.U + u;
+        const float h_old = a.h_in[off], c_old = a.c[off];
+        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+        const float c_new = fg * c_old + ig * gg;
+        const float h_new = og * tanhf(c_new);
+        float h_o, c_o;
+        if (a.zone_keep_h) {  // train-form zoneout: mask=1 keeps the old state
+            h_o = a.zone_keep_h[off] ? h_old : h_new;
+            c_o = a.zone_keep_c[off] ? c_old : c_new;
+        } else {  // eval form (rate 0 => plain cell): rate*old + (1-rate)*new
+            h_o = a.zoneout * h_old + (1.0f - a.zoneout) * h_new;
+            c_o = a.zoneout * c_old + (1.0f - a.zoneout) * c_new;
+        }
+        bool live = true;
+        if (a.row_len) live = a.step < a.row_len[m];
+        a.h_out[off] = live ? h_o : h_old;
+        a.c[off] = live ? c_o : c_old;
+        if (a.out2) {
+            const long long row = (a.out2_row_base ? (long long)a.out2_row_base[m] : (long long)m * a.out2_row_mul) + a.out2_row_add;
+            a.out2[(size_t)row * a.ld2 + a.out2_col_off + u] = live ? h_o : 0.f;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+static int check_terms(const GemmTerm* t, int n, int maxn, bool need_seg, const int* lo) {
+    FCL_REQUIRE(n >= 1 && n <= maxn, FCL_ERR_INVALID, "gemm: nterms %d out of range [1,%d]", n, maxn);
+    for (int i = 0; i < n; ++i) {
+        FCL_REQUIRE(t[i].A && t[i].W, FCL_ERR_INVALID, "gemm: term %d has a null operand", i);
+        FCL_REQUIRE(t[i].K > 0 && (t[i].K & 3) == 0, FCL_ERR_SHAPE, "gemm: term %d K=%d must be a positive multiple of 4", i, t[i].K);
+        FCL_REQUIRE((t[i].lda & 3) == 0 && (t[i].ldw & 3) == 0, FCL_ERR_SHAPE, "gemm: term %d lda=%d/ldw=%d must be multiples of 4", i, t[i].lda, t[i].ldw);
+        FCL_REQUIRE(aligned16(t[i].A) && aligned16(t[i].W), FCL_ERR_ALIGN, "gemm: term %d operands must be 16-byte aligned", i);
+        if (t[i].shift != 0) FCL_REQUIRE(need_seg && lo, FCL_ERR_INVALID, "gemm: shifted term %d needs seg_lo/seg_hi", i);
+    }
+    return 0;
+}
+
+int launch_gemm(const GemmArgs& a, hipStream_t s) {
+    FCL_REQUIRE(a.M >= 0 && a.N > 0, FCL_ERR_SHAPE, "gemm: bad M=%d N=%d", a.M, a.N);
+    if (a.M == 0) return 0;
+    int rc = check_terms(a.term, a.nterms, FCL_MAX_TERMS, true, a.seg_lo);
+    if (rc) return rc;
+    FCL_REQUIRE(a.Y, FCL_ERR_INVALID, "gemm: null output");
+    FCL_REQUIRE(a.drop_mode != 1 || a.keep, FCL_ERR_INVALID, "gemm: drop_mode 1 needs a keep mask");
+    FCL_REQUIRE(!a.Y2 || a.y2_row_base, FCL_ERR_INVALID, "gemm: Y2 needs y2_row_base");
+    // 64x64 tiles while they fill the chip (>= 256 workgroups), else 32x128 / 16x256 to get more row tiles.
+    const long long wg64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    if (wg64 >= 256 || a.N <= 64) {
+        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
+        hipLaunchKernelGGL((gemm_kernel<4, 1>), grid, dim3(256), 0, s, a);
+    } else if (a.N <= 128 || (long long)((a.M + 31) / 32) * ((a.N + 127) / 128) >= 256) {
+        dim3 grid((a.N + 127) / 128, (a.M + 31) / 32);
+        hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((a.N + 255) / 256, (a.M + 15) / 16);
+        hipLaunchKernelGGL((gemm_kernel<1, 4>), grid, dim3(256), 0, s, a);
+    }
+    return check_hip(hipGetLastError(), "gemm launch");
+}
+
+int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
+    FCL_REQUIRE(a.M >= 0 && a.U > 0, FCL_ERR_SHAPE, "lstm_step: bad M=%d U=%d", a.M, a.U);
+    if (a.M == 0) return 0;
+    int rc = check_terms(a.term, a.nterms, 3, false, nullptr);
+    if (rc) return rc;
+    FCL_REQUIRE(a.h_in && a.h_out && a.c && a.h_in != a.h_out, FCL_ERR_INVALID, "lstm_step: h_in/h_out/c must be set and h_out must not alias h_in");
+    FCL_REQUIRE(!a.rank1_w || a.dur, FCL_ERR_INVALID, "lstm_step: rank1_w needs dur");
+    FCL_REQUIRE((a.zone_keep_h == nullptr) == (a.zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_step: zoneout masks come in pairs");
+    const long long wg64 = (long long)((a.M + 63) / 64) * ((a.U + 15) / 16);
+    if (wg64 >= 256 || a.U <= 16) {
+        dim3 grid((a.U + 15) / 16, (a.M + 63) / 64);
+        hipLaunchKernelGGL((lstm_step_kernel<4, 1>), grid, dim3(256), 0, s, a);
+    } else if (a.U <= 32 || (long long)((a.M + 31) / 32) * ((a.U + 31) / 32) >= 192) {
+        dim3 grid((a.U + 31) / 32, (a.M + 31) / 32);
+        hipLaunchKernelGGL((lstm_step_kernel<2, 2>), grid, dim3(256), 0, s, a);
+    } else {
+        dim3 grid((a.U + 63) / 64, (a.M + 15) / 16);
+        hipLaunchKernelGGL((lstm_step_kernel<1, 4>), grid, dim3(256), 0, s, a);
+    }
+    return check_hip(hipGetLastError(), "lstm_step launch");
+}
+
+}  // namespace fcl

@@ -1,0 +1,269 @@
+// pointwise.hip — HBM-bound gather / normalisation / integer kernels of the FCL-taco2 path (gfx950).
+// Every kernel is coalesced along the channel dimension (channels-last rows), float4 where widths allow.
+#include "fcl_common.h"
+
+namespace fcl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- plan-time packing ----------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ scale, float* __restrict__ out,
+                                 int cout, int cin, int k) {
+    const long long total = (long long)k * cout * cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        const int co = (int)((i / cin) % cout);
+        const int j = (int)(i / ((long long)cin * cout));
+        float v = w[((size_t)co * cin + ci) * k + j];
+        if (scale) v *= scale[co];
+        out[i] = v;
+    }
+}
+
+__global__ void fold_bn_kernel(const float* g, const float* b, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) {
+        const float s = g[i] / sqrtf(var[i] + eps);
+        scale[i] = s;
+        shift[i] = b[i] - mean[i] * s;
+    }
+}
+
+__global__ void copy2d_kernel(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols) {
+    const long long total = (long long)rows * cols;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i % cols);
+        dst[(size_t)r * ld_dst + c] = src[(size_t)r * ld_src + c];
+    }
+}
+
+__global__ void add_vec_kernel(const float* a, const float* b, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// ---- H1 embedding / H9 row gather -------------------------------------------------------------------
+// one wave per row, float4 lanes
+template <typename IdxT>
+__global__ void gather_rows_kernel(const float* __restrict__ src, const IdxT* __restrict__ idx, float* __restrict__ dst,
+                                   int n, int c, long long src_rows) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const long long r = (long long)idx[wave];
+    const bool ok = r >= 0 && (src_rows < 0 || r < src_rows);
+    if ((c & 3) == 0) {
+        for (int j = lane * 4; j < c; j += 256) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4*>(src + (size_t)r * c + j);
+            *reinterpret_cast<f32x4*>(dst + (size_t)wave * c + j) = v;
+        }
+    } else {
+        for (int j = lane; j < c; j += 64) dst[(size_t)wave * c + j] = ok ? src[(size_t)r * c + j] : 0.f;
+    }
+}
+
+// ---- H4/H5 channel LayerNorm (+ Linear(C->1) + masked_fill) ------------------------------------------
+// one wave per row; two-pass (mean, then centred variance) like torch's CPU kernel numerics.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int MAXPER>
+__global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 float eps, float* __restrict__ y, const float* __restrict__ lin_w,
+                                 const float* __restrict__ lin_b, const uint8_t* __restrict__ pad_mask,
+                                 float* __restrict__ scalar, int m, int c) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= m) return;
+    float v[MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int j = lane + i * 64;
+        v[i] = j < c ? x[(size_t)row * c + j] : 0.f;
+        s += v[i];
+    }
+    const float mean = wave_sum(s) / (float)c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int j = lane + i * 64;
+        const float d = j < c ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)c + eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int j = lane + i * 64;
+        if (j < c) {
+            const float o = (v[i] - mean) * rstd * gamma[j] + beta[j];
+            if (y) y[(size_t)row * c + j] = o;
+            if (lin_w) dot += o * lin_w[j];
+        }
+    }
+    if (lin_w) {
+        dot = wave_sum(dot);
+        if (lane == 0) {
+            float r = dot + lin_b[0];
+            if (pad_mask && pad_mask[row]) r = 0.f;
+            scalar[row] = r;
+        }
+    }
+}
+
+// ---- H4 duration rounding (INT) -------------------------------------------------------------------
+__global__ void duration_round_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int n, int linear_domain,
+                                      float offset, const uint8_t* __restrict__ pad_mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i];
+    if (!linear_domain) v = expf(v) - offset;
+    v = rintf(v);  // round-half-to-even == torch.round
+    v = fmaxf(v, 0.f);
+    int64_t d = (int64_t)v;
+    if (pad_mask && pad_mask[i]) d = 0;
+    out[i] = d;
+}
+
+// ---- H5 variance embeds + hs + p_embs + e_embs --------------------------------------------------------
+__global__ void variance_embed_add_kernel(const float* __restrict__ hs, const float* __restrict__ p,
+                                          const float* __restrict__ e, const float* __restrict__ wp,
+                                          const float* __restrict__ bp, const float* __restrict__ we,
+                                          const float* __restrict__ be, const int* __restrict__ seg_lo,
+                                          const int* __restrict__ seg_hi, float* __restrict__ out, float* __restrict__ p_emb,
+                                          float* __restrict__ e_emb, int m, int c, int k) {
+    const int row = blockIdx.x;
+    if (row >= m) return;
+    const int lo = seg_lo[row], hi = seg_hi[row], pad = (k - 1) / 2;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        float ap = bp[ch], ae = be[ch];
+        for (int j = 0; j < k; ++j) {
+            const int r = row + j - pad;
+            if (r >= lo && r < hi) {
+                ap = fmaf(wp[ch * k + j], p[r], ap);
+                ae = fmaf(we[ch * k + j], e[r], ae);
+            }
+        }
+        const size_t o = (size_t)row * c + ch;
+        if (p_emb) p_emb[o] = ap;
+        if (e_emb) e_emb[o] = ae;
+        if (out) out[o] = (hs[o] + ap) + ae;  // reference order: (h + p_embs) + e_embs
+    }
+}
+
+// ---- H10 position table ---------------------------------------------------------------------------
+__global__ void position_table_kernel(const int* __restrict__ dur, float* __restrict__ pos, int n, int lmax) {
+    const long long total = (long long)n * lmax;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / lmax), t = (int)(i % lmax);
+        const int d = dur[r];
+        pos[i] = t < d ? (float)t / (float)d : 0.f;
+    }
+}
+
+static inline int grid_for(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace fcl
+
+using namespace fcl;
+
+extern "C" {
+
+int fcl_pack_conv1d_weight(const float* w, const float* scale, float* out, int cout, int cin, int k, fcl_stream_t stream) {
+    FCL_REQUIRE(w && out && cout > 0 && cin > 0 && k > 0, FCL_ERR_INVALID, "pack_conv1d_weight: bad arguments");
+    const long long total = (long long)k * cout * cin;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, scale, out, cout, cin, k);
+    return check_hip(hipGetLastError(), "pack_conv1d_weight");
+}
+
+int fcl_fold_batchnorm(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                       float* scale, float* shift, int c, fcl_stream_t stream) {
+    FCL_REQUIRE(gamma && beta && mean && var && scale && shift && c > 0, FCL_ERR_INVALID, "fold_batchnorm: bad arguments");
+    hipLaunchKernelGGL(fold_bn_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, mean, var, eps, scale, shift, c);
+    return check_hip(hipGetLastError(), "fold_batchnorm");
+}
+
+int fcl_copy2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, fcl_stream_t stream) {
+    FCL_REQUIRE(dst && src && rows > 0 && cols > 0 && ld_dst >= cols && ld_src >= cols, FCL_ERR_INVALID, "copy2d: bad arguments");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src, rows, cols);
+    return check_hip(hipGetLastError(), "copy2d");
+}
+
+int fcl_add_vec(const float* a, const float* b, float* out, int n, fcl_stream_t stream) {
+    FCL_REQUIRE(a && b && out && n > 0, FCL_ERR_INVALID, "add_vec: bad arguments");
+    hipLaunchKernelGGL(add_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return check_hip(hipGetLastError(), "add_vec");
+}
+
+int fcl_embedding_fwd(const int64_t* ids, const float* table, float* out, int m, int v, int e, fcl_stream_t stream) {
+    FCL_REQUIRE(ids && table && out && m >= 0 && v > 0 && e > 0, FCL_ERR_INVALID, "embedding_fwd: bad arguments");
+    if (m == 0) return 0;
+    FCL_REQUIRE((e & 3) != 0 || (aligned16(table) && aligned16(out)), FCL_ERR_ALIGN, "embedding_fwd: 16-byte alignment required");
+    hipLaunchKernelGGL((gather_rows_kernel<int64_t>), dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, out, m, e, (long long)v);
+    return check_hip(hipGetLastError(), "embedding_fwd");
+}
+
+int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n, int c, fcl_stream_t stream) {
+    FCL_REQUIRE(src && idx && dst && n >= 0 && c > 0, FCL_ERR_INVALID, "gather_rows_fwd: bad arguments");
+    if (n == 0) return 0;
+    FCL_REQUIRE((c & 3) != 0 || (aligned16(src) && aligned16(dst)), FCL_ERR_ALIGN, "gather_rows_fwd: 16-byte alignment required");
+    hipLaunchKernelGGL((gather_rows_kernel<int32_t>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, c, -1LL);
+    return check_hip(hipGetLastError(), "gather_rows_fwd");
+}
+
+int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, const float* lin_w,
+                      const float* lin_b, const uint8_t* pad_mask, float* scalar, int m, int c, fcl_stream_t stream) {
+    FCL_REQUIRE(x && gamma && beta && m >= 0 && c > 0, FCL_ERR_INVALID, "layernorm_fwd: bad arguments");
+    FCL_REQUIRE(y || lin_w, FCL_ERR_INVALID, "layernorm_fwd: nothing to compute (y and lin_w both NULL)");
+    FCL_REQUIRE(!lin_w || (lin_b && scalar), FCL_ERR_INVALID, "layernorm_fwd: lin_w needs lin_b and scalar");
+    FCL_REQUIRE(c <= 1024, FCL_ERR_SHAPE, "layernorm_fwd: C=%d > 1024 unsupported", c);
+    if (m == 0) return 0;
+    dim3 grid((m + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (c <= 64) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
+    else if (c <= 256) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
+    else if (c <= 512) hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
+    else hipLaunchKernelGGL((layernorm_kernel<16>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
+    return check_hip(hipGetLastError(), "layernorm_fwd");
+}
+
+int fcl_duration_round_fwd(const float* x, int64_t* out, int n, int linear_domain, float offset, const uint8_t* pad_mask,
+                           fcl_stream_t stream) {
+    FCL_REQUIRE(x && out && n >= 0, FCL_ERR_INVALID, "duration_round_fwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(duration_round_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, n, linear_domain, offset, pad_mask);
+    return check_hip(hipGetLastError(), "duration_round_fwd");
+}
+
+int fcl_variance_embed_add_fwd(const float* hs, const float* p, const float* e, const float* wp, const float* bp,
+                               const float* we, const float* be, const int32_t* seg_lo, const int32_t* seg_hi, float* out,
+                               float* p_emb, float* e_emb, int m, int c, int k, fcl_stream_t stream) {
+    FCL_REQUIRE(p && e && wp && bp && we && be && seg_lo && seg_hi && m >= 0 && c > 0 && k > 0 && (k & 1), FCL_ERR_INVALID,
+                "variance_embed_add_fwd: bad arguments");
+    FCL_REQUIRE(out || p_emb || e_emb, FCL_ERR_INVALID, "variance_embed_add_fwd: no output");
+    FCL_REQUIRE(!out || hs, FCL_ERR_INVALID, "variance_embed_add_fwd: out needs hs");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(variance_embed_add_kernel, dim3(m), dim3(c >= 256 ? 256 : 64), 0, (hipStream_t)stream, hs, p, e, wp, bp, we, be,
+                       seg_lo, seg_hi, out, p_emb, e_emb, m, c, k);
+    return check_hip(hipGetLastError(), "variance_embed_add_fwd");
+}
+
+int fcl_position_table_fwd(const int32_t* dur, float* pos, int n, int lmax, fcl_stream_t stream) {
+    FCL_REQUIRE(dur && pos && n >= 0 && lmax > 0, FCL_ERR_INVALID, "position_table_fwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(position_table_kernel, dim3(grid_for((long long)n * lmax, 256)), dim3(256), 0, (hipStream_t)stream, dur, pos, n, lmax);
+    return check_hip(hipGetLastError(), "position_table_fwd");
+}
+
+}  // extern "C"

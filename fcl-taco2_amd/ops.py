@@ -1,0 +1,152 @@
+"""Tensor-level wrappers over the C ABI.  torch is used for device memory and the stream handle only;
+every FLOP runs in libfcl_hip.so.  All tensors must be contiguous fp32 / int32 / int64 / uint8 CUDA(HIP)
+tensors; nothing here falls back to torch ops."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, DROP_MASK, DROP_NONE, DROP_RNG, check  # noqa: F401
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.FclError("fcl-taco2_amd: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.FclError("fcl-taco2_amd: expected contiguous %s, got %s contiguous=%s" % (dtype, t.dtype, t.is_contiguous()))
+    return t.data_ptr()
+
+
+def pack_conv1d_weight(w, scale=None):
+    cout, cin, k = w.shape
+    out = torch.empty(k, cout, cin, device=w.device, dtype=torch.float32)
+    check(_lib.load().fcl_pack_conv1d_weight(_p(w), _p(scale), _p(out), cout, cin, k, _stream()))
+    return out
+
+
+def fold_batchnorm(gamma, beta, mean, var, eps=1e-5):
+    scale, shift = torch.empty_like(gamma), torch.empty_like(gamma)
+    check(_lib.load().fcl_fold_batchnorm(_p(gamma), _p(beta), _p(mean), _p(var), eps, _p(scale), _p(shift), gamma.numel(), _stream()))
+    return scale, shift
+
+
+def copy_cols(src, col0, ncols):
+    """Contiguous copy of src[:, col0:col0+ncols]."""
+    rows, ld = src.shape
+    dst = torch.empty(rows, ncols, device=src.device, dtype=torch.float32)
+    check(_lib.load().fcl_copy2d(_p(dst), ncols, src.data_ptr() + 4 * col0, ld, rows, ncols, _stream()))
+    return dst
+
+
+def add_vec(a, b):
+    out = torch.empty_like(a)
+    check(_lib.load().fcl_add_vec(_p(a), _p(b), _p(out), a.numel(), _stream()))
+    return out
+
+
+def embedding(ids, table):
+    m = ids.numel()
+    v, e = table.shape
+    out = torch.empty(m, e, device=table.device, dtype=torch.float32)
+    check(_lib.load().fcl_embedding_fwd(_p(ids, torch.int64), _p(table), _p(out), m, v, e, _stream()))
+    return out
+
+
+def linear(x, w, bias=None, act=ACT_NONE):
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty(m, n, device=x.device, dtype=torch.float32)
+    check(_lib.load().fcl_linear_fwd(_p(x), k, _p(w), w.shape[1], _p(bias), _p(y), n, m, n, k, act, _stream()))
+    return y
+
+
+def conv1d(x, wp, bias, seg_lo, seg_hi, act=ACT_NONE, residual=None):
+    m, cin = x.shape
+    k, cout, cin2 = wp.shape
+    assert cin2 == cin
+    y = torch.empty(m, cout, device=x.device, dtype=torch.float32)
+    check(_lib.load().fcl_conv1d_fwd(_p(x), _p(wp), _p(bias), _p(seg_lo, torch.int32), _p(seg_hi, torch.int32), _p(residual), _p(y),
+                                     m, cin, cout, k, act, _stream()))
+    return y
+
+
+def layernorm(x, gamma, beta, eps, want_y=True, lin_w=None, lin_b=None, pad_mask=None):
+    m, c = x.shape
+    y = torch.empty_like(x) if want_y else None
+    scalar = torch.empty(m, device=x.device, dtype=torch.float32) if lin_w is not None else None
+    check(_lib.load().fcl_layernorm_fwd(_p(x), _p(gamma), _p(beta), eps, _p(y), _p(lin_w), _p(lin_b), _p(pad_mask, torch.uint8), _p(scalar),
+                                        m, c, _stream()))
+    return y, scalar
+
+
+def duration_round(x, linear_domain=False, offset=1.0, pad_mask=None):
+    out = torch.empty(x.numel(), device=x.device, dtype=torch.int64)
+    check(_lib.load().fcl_duration_round_fwd(_p(x), _p(out, torch.int64), x.numel(), int(linear_domain), offset, _p(pad_mask, torch.uint8), _stream()))
+    return out
+
+
+def variance_embed_add(hs, p, e, wp, bp, we, be, seg_lo, seg_hi, want_embs=False):
+    m, c = hs.shape
+    k = wp.shape[-1]
+    out = torch.empty_like(hs)
+    pe = torch.empty_like(hs) if want_embs else None
+    ee = torch.empty_like(hs) if want_embs else None
+    check(_lib.load().fcl_variance_embed_add_fwd(_p(hs), _p(p), _p(e), _p(wp), _p(bp), _p(we), _p(be), _p(seg_lo, torch.int32),
+                                                 _p(seg_hi, torch.int32), _p(out), _p(pe), _p(ee), m, c, k, _stream()))
+    return out, pe, ee
+
+
+def position_table(dur_i32, lmax):
+    n = dur_i32.numel()
+    pos = torch.empty(n, lmax, device=dur_i32.device, dtype=torch.float32)
+    check(_lib.load().fcl_position_table_fwd(_p(dur_i32, torch.int32), _p(pos), n, lmax, _stream()))
+    return pos
+
+
+def gather_rows(src, idx_i32):
+    n, c = idx_i32.numel(), src.shape[1]
+    dst = torch.empty(n, c, device=src.device, dtype=torch.float32)
+    check(_lib.load().fcl_gather_rows_fwd(_p(src), _p(idx_i32, torch.int32), _p(dst), n, c, _stream()))
+    return dst
+
+
+def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0):
+    c = x.shape[1]
+    h = w_hh_f.shape[1]
+    lib = _lib.load()
+    nbytes = lib.fcl_bilstm_workspace_bytes(b, t, h)
+    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
+    out = torch.empty(b * t, 2 * h, device=x.device, dtype=torch.float32)
+    check(lib.fcl_bilstm_fwd(_p(x), _p(lens_i32, torch.int32), _p(w_ih_f), _p(w_hh_f), _p(b_f), _p(w_ih_r), _p(w_hh_r), _p(b_r), _p(out),
+                             b, t, c, h, algo, ws.data_ptr(), nbytes, _stream()))
+    return out
+
+
+def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher_ys=None, dropout_mode=DROP_NONE,
+                 prenet_keep=None, seed=0, want_taps=False):
+    """dw: plan.DecoderPack (holds the ctypes DecoderWeights + the tensors it points to).
+    live_rows: host numpy int32 [Lmax].  Returns before [F, odim] (+ taps)."""
+    lib = _lib.load()
+    n = att_c.shape[0]
+    lmax = int(live_rows.shape[0])
+    nbytes = lib.fcl_decoder_loop_workspace_bytes(C.byref(dw.struct), n)
+    ws = torch.empty(nbytes, device=att_c.device, dtype=torch.uint8)
+    before = torch.empty(n_frames, dw.struct.odim, device=att_c.device, dtype=torch.float32)
+    taps = None
+    if want_taps:
+        taps = (torch.empty(n_frames, dw.struct.p, device=att_c.device), torch.empty(n_frames, dw.struct.u, device=att_c.device),
+                torch.empty(n_frames, dw.struct.u, device=att_c.device))
+    io = _lib.DecoderIO(
+        n=n, lmax=lmax, att_c=_p(att_c), dur=_p(dur_i32, torch.int32), live_rows_host=live_rows.ctypes.data,
+        frame_off=_p(frame_off_i32, torch.int32), teacher_ys=_p(teacher_ys), dropout_mode=dropout_mode,
+        prenet_keep=_p(prenet_keep, torch.uint8), seed=seed & 0xFFFFFFFF, before=_p(before),
+        tap_prenet=_p(taps[0]) if taps else None, tap_lstm0=_p(taps[1]) if taps else None, tap_lstm1=_p(taps[2]) if taps else None,
+        workspace=ws.data_ptr(), workspace_bytes=nbytes)
+    check(lib.fcl_decoder_loop_fwd(C.byref(dw.struct), C.byref(io), _stream()))
+    return (before, taps) if want_taps else before

@@ -1,0 +1,123 @@
+"""SynthesisPlan — device-resident, kernel-ready weights built once from a reference-named state_dict.
+
+Packing (all by libfcl_hip kernels, not torch ops):
+  * Conv1d+BatchNorm(eval) -> tap-major [k, Cout, Cin] weights with the BN scale folded in, BN shift as bias
+    (reference encoder_sa.py:61-78, decoder_sa.py:199-263);
+  * decoder LSTMCell-0 `weight_ih` split into its att_c / prenet / position column blocks and `feat_out.weight`
+    into its lstm / att_c blocks, so the att_c parts are hoisted out of the time loop;
+  * bias_ih + bias_hh summed.
+LSTM / Linear matrices are used in place: torch's [out, in] layout is already the K-contiguous W the GEMM wants.
+"""
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .hparams import param_spec
+
+BN_EPS = 1e-5
+LN_EPS = 1e-12
+
+
+class ConvPack(object):
+    __slots__ = ("wp", "bias", "k", "cin", "cout")
+
+
+class PredictorPack(object):
+    __slots__ = ("convs", "ln", "lin_w", "lin_b")
+
+
+class DecoderPack(object):
+    """Holds the ctypes struct and keeps alive every tensor it points to."""
+
+    def __init__(self):
+        self.struct = _lib.DecoderWeights()
+        self.keep = []
+
+
+def _dev(sd, k, device):
+    v = sd[k]
+    if isinstance(v, np.ndarray):
+        v = torch.from_numpy(np.ascontiguousarray(v))
+    return v.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class SynthesisPlan(object):
+    def __init__(self, state_dict, hp, device="cuda:0"):
+        hp.check_supported()
+        _lib.load()
+        self.hp = hp
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.FclError("fcl-taco2_amd: SynthesisPlan needs a GPU device (no CPU fallback)")
+        missing = [k for k in param_spec(hp) if k not in state_dict]
+        if missing:
+            raise KeyError("state_dict is missing reference keys: %s ..." % missing[:4])
+        g = lambda k: _dev(state_dict, k, self.device)
+        with torch.cuda.device(self.device):
+            self.embed = g("enc.embed.weight")
+            self.enc_convs = [self._conv_bn(g, "enc.convs.%d" % i) for i in range(hp.econv_layers)]
+            self.blstm = {}
+            for sfx, tag in (("", "f"), ("_reverse", "r")):
+                self.blstm["w_ih_" + tag] = g("enc.blstm.weight_ih_l0" + sfx)
+                self.blstm["w_hh_" + tag] = g("enc.blstm.weight_hh_l0" + sfx)
+                self.blstm["b_" + tag] = ops.add_vec(g("enc.blstm.bias_ih_l0" + sfx), g("enc.blstm.bias_hh_l0" + sfx))
+            self.duration = self._predictor(g, "duration_predictor", hp.duration_predictor_layers)
+            self.pitch = self._predictor(g, "pitch_predictor", hp.variance_predictor_layers)
+            self.energy = self._predictor(g, "energy_predictor", hp.variance_predictor_layers)
+            self.pitch_embed_w = g("pitch_embed.0.weight").reshape(hp.eunits, -1).contiguous()
+            self.pitch_embed_b = g("pitch_embed.0.bias")
+            self.energy_embed_w = g("energy_embed.0.weight").reshape(hp.eunits, -1).contiguous()
+            self.energy_embed_b = g("energy_embed.0.bias")
+            self.postnet = [self._conv_bn(g, "dec.postnet.postnet.%d" % i) for i in range(hp.postnet_layers)]
+            self.decoder = self._decoder(g)
+            torch.cuda.synchronize(self.device)
+
+    def _conv_bn(self, g, prefix):
+        w = g(prefix + ".0.weight")
+        scale, shift = ops.fold_batchnorm(g(prefix + ".1.weight"), g(prefix + ".1.bias"), g(prefix + ".1.running_mean"),
+                                          g(prefix + ".1.running_var"), BN_EPS)
+        c = ConvPack()
+        c.cout, c.cin, c.k = w.shape
+        c.wp = ops.pack_conv1d_weight(w, scale)
+        c.bias = shift
+        return c
+
+    def _predictor(self, g, prefix, layers):
+        p = PredictorPack()
+        p.convs, p.ln = [], []
+        for i in range(layers):
+            w = g("%s.conv.%d.0.weight" % (prefix, i))
+            c = ConvPack()
+            c.cout, c.cin, c.k = w.shape
+            c.wp = ops.pack_conv1d_weight(w, None)
+            c.bias = g("%s.conv.%d.0.bias" % (prefix, i))
+            p.convs.append(c)
+            p.ln.append((g("%s.conv.%d.2.weight" % (prefix, i)), g("%s.conv.%d.2.bias" % (prefix, i))))
+        p.lin_w = g(prefix + ".linear.weight").reshape(-1).contiguous()
+        p.lin_b = g(prefix + ".linear.bias")
+        return p
+
+    def _decoder(self, g):
+        hp = self.hp
+        C, P, U, O = hp.eunits, hp.prenet_units, hp.dunits, hp.odim
+        d = DecoderPack()
+        s = d.struct
+        s.c, s.p, s.u, s.odim = C, P, U, O
+        w_ih0 = g("dec.lstm.0.cell.weight_ih")  # [4U, C + P + 1] = [att_c | prenet | position]
+        wf = g("dec.feat_out.weight")  # [odim, U + C]      = [lstm | att_c]
+        t = dict(
+            prenet_w0=g("dec.prenet.prenet.0.0.weight"), prenet_b0=g("dec.prenet.prenet.0.0.bias"),
+            prenet_w1=g("dec.prenet.prenet.1.0.weight"), prenet_b1=g("dec.prenet.prenet.1.0.bias"),
+            w0_att=ops.copy_cols(w_ih0, 0, C), w0_pre=ops.copy_cols(w_ih0, C, P), w0_pos=ops.copy_cols(w_ih0, C + P, 1).reshape(-1),
+            w0_hh=g("dec.lstm.0.cell.weight_hh"),
+            b0=ops.add_vec(g("dec.lstm.0.cell.bias_ih"), g("dec.lstm.0.cell.bias_hh")),
+            w1_ih=g("dec.lstm.1.cell.weight_ih"), w1_hh=g("dec.lstm.1.cell.weight_hh"),
+            b1=ops.add_vec(g("dec.lstm.1.cell.bias_ih"), g("dec.lstm.1.cell.bias_hh")),
+            wf_h=ops.copy_cols(wf, 0, U), wf_att=ops.copy_cols(wf, U, C),
+        )
+        for k, v in t.items():
+            setattr(s, k, v.data_ptr())
+            d.keep.append(v)
+        s.zoneout_rate = float(hp.zoneout_rate)
+        s.prenet_dropout = float(hp.dropout_rate)
+        return d

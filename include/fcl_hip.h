@@ -1,0 +1,157 @@
+/* fcl_hip.h — C ABI of libfcl_hip.so: the MI355X (gfx950) FCL-taco2 mel-synthesis hot path.
+ *
+ * The reference (Wendison/FCL-taco2) has no FFI: its plug-in point is the Python class path
+ * `--model-module pkg.mod:Class` (tts_train.py:103-109).  This header is the boundary this build puts
+ * UNDER that class: every entry point replaces a block of stock torch ops inside the reference's
+ * nets/ modules (cited per function; paths relative to the reference root).  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless the name ends in `_host`;
+ *   - all activations are fp32, row-major, "channels-last": a sequence tensor is [rows, C] with
+ *     rows = (utterance, time) flattened;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 on success, a negative FCL_ERR_* otherwise; fcl_last_error() gives the message for the
+ *     calling thread.  Nothing throws across the boundary.  Calls are re-entrant; the only global
+ *     state is the thread-local error string.  The caller owns every buffer, workspaces included.
+ */
+#ifndef FCL_HIP_H_
+#define FCL_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fcl_stream_t;
+
+enum { FCL_OK = 0, FCL_ERR_INVALID = -1, FCL_ERR_SHAPE = -2, FCL_ERR_ALIGN = -3, FCL_ERR_HIP = -4, FCL_ERR_WORKSPACE = -5 };
+enum { FCL_ACT_NONE = 0, FCL_ACT_RELU = 1, FCL_ACT_TANH = 2 };
+enum { FCL_DROP_NONE = 0, FCL_DROP_MASK = 1, FCL_DROP_RNG = 2 };
+
+const char* fcl_last_error(void);
+int fcl_version(void);
+
+/* ---- plan-time weight packing (run once per checkpoint) ------------------------------------------ */
+
+/* torch Conv1d weight [Cout, Cin, k] -> tap-major [k, Cout, Cin], each output channel optionally
+ * multiplied by scale[Cout] (eval BatchNorm folded into the conv; encoder_sa.py:61-78,
+ * decoder_sa.py:199-263). */
+int fcl_pack_conv1d_weight(const float* w, const float* scale, float* out, int cout, int cin, int k, fcl_stream_t stream);
+
+/* Eval BatchNorm1d -> per-channel scale = gamma/sqrt(var+eps), shift = beta - mean*scale. */
+int fcl_fold_batchnorm(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                       float* scale, float* shift, int c, fcl_stream_t stream);
+
+/* dst[r, 0:cols] = src[r, 0:cols] (strided 2-D copy; splits LSTMCell.weight_ih / feat_out.weight into
+ * their att_c / prenet / position column blocks, decoder_sa.py:357-369,397-398). */
+int fcl_copy2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, fcl_stream_t stream);
+
+/* out = a + b (bias_ih + bias_hh). */
+int fcl_add_vec(const float* a, const float* b, float* out, int n, fcl_stream_t stream);
+
+/* ---- H1: Encoder.embed (encoder_sa.py:58,134) ------------------------------------------------------ */
+/* out[m, :] = table[ids[m], :]; ids outside [0, V) produce a zero row. */
+int fcl_embedding_fwd(const int64_t* ids, const float* table, float* out, int m, int v, int e, fcl_stream_t stream);
+
+/* ---- H6/H8 + every nn.Linear: y = act(x . w^T + bias) --------------------------------------------- */
+/* x [M, K] (lda), w [N, K] (torch layout, ldw), y [M, N] (ldy).  K, lda, ldw multiples of 4. */
+int fcl_linear_fwd(const float* x, int lda, const float* w, int ldw, const float* bias, float* y, int ldy,
+                   int m, int n, int k, int act, fcl_stream_t stream);
+
+/* ---- H2/H4/H5/H11: Conv1d over channels-last rows (encoder_sa.py:136-140, decoder_sa.py:284-286,
+ *      variance_predictor.py:86-88) ------------------------------------------------------------------ */
+/* y[m, :] = act( sum_j x[m + j - (k-1)/2, :] . wp[j]^T + bias ) (+ residual), with rows outside
+ * [seg_lo[m], seg_hi[m]) contributing zero (zero padding at utterance edges).  wp is the packed
+ * [k, Cout, Cin] weight.  residual (optional, [M, Cout]) is added after the activation. */
+int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
+                   const float* residual, float* y, int m, int cin, int cout, int k, int act, fcl_stream_t stream);
+
+/* ---- H4/H5: channel LayerNorm (+ the predictor's Linear(C->1) and masked_fill) ---------------------- */
+/* y[m,:] = LN(x[m,:]) * gamma + beta (y may be NULL).  If lin_w != NULL:
+ * scalar[m] = pad_mask[m] ? 0 : (y[m,:] . lin_w + lin_b[0])   (variance_predictor.py:90-93). */
+int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y,
+                      const float* lin_w, const float* lin_b, const uint8_t* pad_mask, float* scalar,
+                      int m, int c, fcl_stream_t stream);
+
+/* ---- H4: DurationPredictor.inference rounding (ESPnet; call site ..._kd_student.py:825) ------------- */
+/* out = pad_mask ? 0 : (int64) max(rint(linear_domain ? x : exp(x) - offset), 0); rint = half-to-even. */
+int fcl_duration_round_fwd(const float* x, int64_t* out, int n, int linear_domain, float offset,
+                           const uint8_t* pad_mask, fcl_stream_t stream);
+
+/* ---- H5: pitch_embed + energy_embed + the decoder's `hs + p_embs + e_embs`
+ *      (..._kd_student.py:837-838, decoder_sa_kd.py:734) ---------------------------------------------- */
+/* out[m,c] = hs[m,c] + bp[c] + sum_j wp[c,j]*p[m+j-k/2] + be[c] + sum_j we[c,j]*e[m+j-k/2]; p_emb/e_emb
+ * (optional) receive the two embeddings separately. */
+int fcl_variance_embed_add_fwd(const float* hs, const float* p, const float* e, const float* wp, const float* bp,
+                               const float* we, const float* be, const int32_t* seg_lo, const int32_t* seg_hi,
+                               float* out, float* p_emb, float* e_emb, int m, int c, int k, fcl_stream_t stream);
+
+/* ---- H10: position table (..._kd_student.py:845-851): pos[n, t] = t < dur[n] ? (float)t/(float)dur[n] : 0 */
+int fcl_position_table_fwd(const int32_t* dur, float* pos, int n, int lmax, fcl_stream_t stream);
+
+/* ---- H9: row gather (decoder_sa.py:467: hs[non_zero_lens_mask.eq(1)], plus the duration sort) -------- */
+int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n, int c, fcl_stream_t stream);
+
+/* ---- H3: Encoder.blstm over packed sequences (encoder_sa.py:98-100,143-146) -------------------------- */
+/* x [B*T, C]; lens [B] int32 (device); w_ih_* [4H, C], w_hh_* [4H, H], b_* [4H] (= bias_ih + bias_hh);
+ * out [B*T, 2H] = fwd | bwd, zero past each length.  algo: 0 auto, 1 per-step launches, 2 persistent
+ * register-resident recurrence (H in {8,16,32,64,128}). */
+size_t fcl_bilstm_workspace_bytes(int b, int t, int h);
+int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
+                   const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,
+                   int algo, void* workspace, size_t workspace_bytes, fcl_stream_t stream);
+
+/* ---- H6-H8 (+H9/H10 scatter): the per-phoneme-parallel decoder loop
+ *      (Decoder.inference decoder_sa_kd.py:742-790; Decoder.forward :572-655) ------------------------- */
+typedef struct {
+    int c;     /* att_c width (= eunits) */
+    int p;     /* prenet units */
+    int u;     /* dunits */
+    int odim;  /* mel bins */
+    const float* prenet_w0; /* [P, odim] */
+    const float* prenet_b0; /* [P] */
+    const float* prenet_w1; /* [P, P] */
+    const float* prenet_b1; /* [P] */
+    const float* w0_att;    /* [4U, C]  lstm.0.cell.weight_ih[:, :C]      */
+    const float* w0_pre;    /* [4U, P]  lstm.0.cell.weight_ih[:, C:C+P]   */
+    const float* w0_pos;    /* [4U]     lstm.0.cell.weight_ih[:, C+P]     */
+    const float* w0_hh;     /* [4U, U] */
+    const float* b0;        /* [4U]     bias_ih + bias_hh */
+    const float* w1_ih;     /* [4U, U] */
+    const float* w1_hh;     /* [4U, U] */
+    const float* b1;        /* [4U] */
+    const float* wf_h;      /* [odim, U] feat_out.weight[:, :U] */
+    const float* wf_att;    /* [odim, C] feat_out.weight[:, U:] */
+    float zoneout_rate;     /* eval-form zoneout (decoder_sa.py:96) */
+    float prenet_dropout;   /* always-on prenet dropout rate (decoder_sa.py:156-158) */
+} fcl_decoder_weights_t;
+
+typedef struct {
+    int n;                      /* phoneme rows, SORTED by duration descending */
+    int lmax;                   /* = dur[0] */
+    const float* att_c;         /* [N, C]: hs + p_embs + e_embs, compacted + sorted rows */
+    const int32_t* dur;         /* [N] device, > 0 */
+    const int32_t* live_rows_host; /* [Lmax] HOST: rows with dur > t (non-increasing) */
+    const int32_t* frame_off;   /* [N] device: output frame index of (row, t = 0) */
+    const float* teacher_ys;    /* NULL = free running; else [N, Lmax, odim] teacher-forced inputs */
+    int dropout_mode;           /* FCL_DROP_* for the prenet */
+    const uint8_t* prenet_keep; /* FCL_DROP_MASK: [Lmax, 2, N, P] keep masks (sorted row order) */
+    uint32_t seed;              /* FCL_DROP_RNG */
+    float* before;              /* [F, odim] frame-major decoder output (pre-postnet), F = sum(dur) */
+    float* tap_prenet;          /* optional [F, P]  (KD taps, decoder_sa_kd.py:627-637) */
+    float* tap_lstm0;           /* optional [F, U] */
+    float* tap_lstm1;           /* optional [F, U] */
+    void* workspace;
+    size_t workspace_bytes;
+} fcl_decoder_io_t;
+
+size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n);
+int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, fcl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCL_HIP_H_ */

@@ -1,0 +1,84 @@
+"""CPU-only checks of the drop-in boundary: libfcl_hip.so loads, exports every symbol include/fcl_hip.h
+declares (and nothing undeclared), and rejects bad arguments with an error code + message — all without
+touching a GPU (argument validation returns before any HIP call)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HDR = os.path.join(ROOT, "include", "fcl_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+
+    ge.build()
+    from fcl_taco2_amd import _lib
+
+    return _lib.load()
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fcl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from fcl_taco2_amd import _lib
+
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.SIGNATURES) == names  # the ctypes table mirrors the header one to one
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = sorted(set(re.findall(r"\bT (fcl_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == names  # nothing undeclared leaks out of the C ABI
+
+
+def test_version_and_error_string(lib):
+    assert lib.fcl_version() >= 100
+    rc = lib.fcl_linear_fwd(None, 4, None, 4, None, None, 4, 1, 4, 4, 0, None)
+    assert rc == -1 and b"null" in lib.fcl_last_error()
+    rc = lib.fcl_conv1d_fwd(1, 1, None, 1, 1, None, 2, 4, 4, 4, 4, 0, None)  # even kernel size
+    assert rc == -2 and b"odd" in lib.fcl_last_error()
+    assert lib.fcl_bilstm_workspace_bytes(32, 100, 128) >= 4 * (2 * 32 * 100 * 512 + 6 * 32 * 128)
+
+
+def test_decoder_loop_argument_validation(lib):
+    from fcl_taco2_amd import _lib
+
+    w = _lib.DecoderWeights()
+    io = _lib.DecoderIO()
+    w.c, w.p, w.u, w.odim = 256, 256, 256, 81  # odim not a multiple of 4
+    assert lib.fcl_decoder_loop_fwd(C.byref(w), C.byref(io), None) == -2
+    w.odim = 80
+    assert lib.fcl_decoder_loop_fwd(C.byref(w), C.byref(io), None) == -1  # null weights
+    assert lib.fcl_decoder_loop_workspace_bytes(C.byref(w), 2500) > 2500 * 4 * (1024 + 80 + 512 + 6 * 256 + 80)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from fcl_taco2_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libfcl_hip.so")
+    with pytest.raises(_lib.FclError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_plan_refuses_cpu_device():
+    import numpy as np
+    from fcl_taco2_amd import _lib, hparams as HP, synthetic as SYN
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    hp = HP.student_hparams()
+    with pytest.raises(_lib.FclError, match="GPU"):
+        SynthesisPlan(SYN.closed_form_state_dict(HP.param_spec(hp)), hp, "cpu")
+    with pytest.raises(NotImplementedError):
+        HP.student_hparams(reduction_factor=2).check_supported()

@@ -1,0 +1,353 @@
+"""-m gpu: HIP path (through the C ABI) vs the CPU oracle and vs the reference's own goldens.
+
+Tolerances: fp32 everywhere; 1e-3 max-abs on mel frames is the north-star bar, the tests hold the
+kernels to much tighter figures (written next to each assert).  Integer / index work is bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import TINY_S, TINY_T, max_abs, np_state_dict, torch_state_dict
+
+pytestmark = pytest.mark.gpu
+
+from fcl_taco2_amd import hparams as HP  # noqa: E402
+from fcl_taco2_amd import synthetic as SYN  # noqa: E402
+from oracle import fcl_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from fcl_taco2_amd import _lib, ops as _ops
+
+    _lib.load()  # the HIP extension must be the thing that runs
+    return _ops
+
+
+def dev(a, dtype=None):
+    if isinstance(a, np.ndarray) and a.dtype == np.float64:
+        a = a.astype(np.float32)
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def rnd(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------ kernels
+@pytest.mark.parametrize("m,n,k", [(1, 4, 4), (7, 5, 8), (64, 64, 32), (65, 67, 36), (200, 256, 80), (2500, 80, 256),
+                                   (513, 1024, 256), (33, 384, 768), (3000, 256, 256), (17, 1024, 512)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear(ops, m, n, k, act):
+    rng = np.random.RandomState(m * 7 + n)
+    x, w, b = rnd(rng, m, k), (rnd(rng, n, k) / np.sqrt(k)).astype(np.float32), rnd(rng, n)
+    y = ops.linear(dev(x), dev(w), dev(b), act).cpu()
+    ref = F.linear(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b))
+    ref = [ref, torch.relu(ref), torch.tanh(ref)][act]
+    assert max_abs(y, ref) < 2e-5
+
+
+def _conv_ref(x, w, b, lo, hi, act):
+    """Per-segment F.conv1d on CPU."""
+    out = torch.zeros(x.shape[0], w.shape[0])
+    segs = sorted(set(zip(lo.tolist(), hi.tolist())))
+    for s, e in segs:
+        if e > s:
+            out[s:e] = F.conv1d(x[s:e].t().unsqueeze(0), w, b, 1, (w.shape[2] - 1) // 2)[0].t()
+    return [out, torch.relu(out), torch.tanh(out)][act]
+
+
+@pytest.mark.parametrize("cin,cout,k,act", [(16, 16, 5, 1), (80, 128, 5, 2), (128, 80, 5, 0), (256, 384, 3, 1), (256, 256, 5, 1), (12, 8, 5, 0)])
+def test_conv1d_segments(ops, cin, cout, k, act):
+    rng = np.random.RandomState(cin + cout)
+    seg_lens = [1, 2, 3, 40, 77, 5, 130]
+    M = sum(seg_lens) + 6  # 6 trailing rows belong to an empty segment (lo == hi): must come out as bias-only
+    lo, hi, s = [], [], 0
+    for L in seg_lens:
+        lo += [s] * L
+        hi += [s + L] * L
+        s += L
+    lo += [s] * 6
+    hi += [s] * 6
+    lo, hi = np.array(lo, np.int32), np.array(hi, np.int32)
+    x, w, b = rnd(rng, M, cin), (rnd(rng, cout, cin, k) / np.sqrt(cin * k)).astype(np.float32), rnd(rng, cout)
+    wp = ops.pack_conv1d_weight(dev(w))
+    assert np.array_equal(wp.cpu().numpy(), np.ascontiguousarray(w.transpose(2, 0, 1)))  # packing is a pure permutation
+    res = rnd(rng, M, cout)
+    y = ops.conv1d(dev(x), wp, dev(b), dev(lo), dev(hi), act, residual=dev(res)).cpu()
+    ref = _conv_ref(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), lo, hi, act)
+    ref[s:] = [lambda v: v, torch.relu, torch.tanh][act](torch.from_numpy(b)).expand(6, cout)
+    assert max_abs(y, ref + torch.from_numpy(res)) < 2e-5
+
+
+def test_fold_batchnorm_and_conv_bn(ops):
+    rng = np.random.RandomState(3)
+    c = 128
+    g, b, rm, rv = 1 + 0.1 * rnd(rng, c), rnd(rng, c), rnd(rng, c), 0.5 + rng.rand(c).astype(np.float32)
+    scale, shift = ops.fold_batchnorm(dev(g), dev(b), dev(rm), dev(rv), 1e-5)
+    s_ref = g / np.sqrt(rv + 1e-5)
+    assert max_abs(scale.cpu(), s_ref) < 1e-6 and max_abs(shift.cpu(), b - rm * s_ref) < 1e-6
+
+
+@pytest.mark.parametrize("c", [20, 64, 384, 1000])
+def test_layernorm_and_scalar_head(ops, c):
+    rng = np.random.RandomState(c)
+    m = 301
+    x, g, b, lw, lb = 3 * rnd(rng, m, c) + 1, rnd(rng, c), rnd(rng, c), (rnd(rng, c) / np.sqrt(c)).astype(np.float32), rnd(rng, 1)
+    pad = (rng.rand(m) < 0.2).astype(np.uint8)
+    y, sc = ops.layernorm(dev(x), dev(g), dev(b), 1e-12, True, dev(lw), dev(lb), dev(pad))
+    ref = F.layer_norm(torch.from_numpy(x), (c,), torch.from_numpy(g), torch.from_numpy(b), 1e-12)
+    assert max_abs(y.cpu(), ref) < 2e-5
+    ref_s = (ref @ torch.from_numpy(lw) + float(lb[0])).masked_fill(torch.from_numpy(pad).bool(), 0.0)
+    assert max_abs(sc.cpu(), ref_s) < 5e-5
+
+
+def test_duration_round_bit_exact(ops, golden):
+    g = golden("g4_integer")
+    out = ops.duration_round(dev(g["lin"]), linear_domain=True).cpu().numpy()
+    assert np.array_equal(out, g["lin_round"])  # half-to-even ties, clamp of negatives
+    # log-domain path away from ties: identical integers to the reference
+    out = ops.duration_round(dev(g["logits"]), linear_domain=False).cpu().numpy()
+    lin = np.exp(g["logits"].astype(np.float64)) - 1.0
+    safe = np.abs(lin - np.floor(lin) - 0.5) > 1e-3
+    assert np.array_equal(out[safe], g["logits_round"][safe])
+    pad = np.zeros(len(g["logits"]), np.uint8)
+    pad[-2:] = 1
+    out = ops.duration_round(dev(g["logits"]), False, 1.0, dev(pad)).cpu().numpy()
+    assert out[-1] == 0 and out[-2] == 0
+
+
+def test_position_table_bit_exact(ops, golden):
+    g = golden("g4_integer")
+    d = g["out2_ds_nonzeros"].astype(np.int32)
+    pos = ops.position_table(dev(d), int(d.max())).cpu().numpy()
+    assert np.array_equal(pos, g["out2_position"])  # fp32 divide must match torch's bit for bit
+    d = np.arange(1, 201, dtype=np.int32)
+    pos = ops.position_table(dev(d), 200).cpu().numpy()
+    assert np.array_equal(pos, O.position_table(torch.from_numpy(d)).numpy())
+
+
+def test_gather_and_embedding(ops):
+    rng = np.random.RandomState(0)
+    table = rnd(rng, 80, 256)
+    ids = rng.randint(0, 80, size=333).astype(np.int64)
+    assert np.array_equal(ops.embedding(dev(ids), dev(table)).cpu().numpy(), table[ids])
+    idx = rng.randint(0, 80, size=77).astype(np.int32)
+    assert np.array_equal(ops.gather_rows(dev(table), dev(idx)).cpu().numpy(), table[idx])
+    t2 = rnd(rng, 12, 18)  # non-multiple-of-4 width path
+    assert np.array_equal(ops.gather_rows(dev(t2), dev(idx % 12)).cpu().numpy(), t2[idx % 12])
+
+
+def test_variance_embed_add(ops):
+    rng = np.random.RandomState(1)
+    hp = HP.student_hparams()
+    sd = torch_state_dict(hp)
+    lens = [9, 1, 30]
+    T = 30
+    M = len(lens) * T
+    hs = rnd(rng, M, hp.eunits)
+    p, e = rnd(rng, M), rnd(rng, M)
+    lo = np.repeat(np.arange(3) * T, T).astype(np.int32)
+    hi = (lo + np.repeat(lens, T)).astype(np.int32)
+    out, pe, ee = ops.variance_embed_add(dev(hs), dev(p), dev(e), dev(sd["pitch_embed.0.weight"].reshape(hp.eunits, -1)),
+                                         dev(sd["pitch_embed.0.bias"]), dev(sd["energy_embed.0.weight"].reshape(hp.eunits, -1)),
+                                         dev(sd["energy_embed.0.bias"]), dev(lo), dev(hi), want_embs=True)
+    for b, L in enumerate(lens):
+        s = b * T
+        rp = O.variance_embed(sd, "pitch", torch.from_numpy(p[s : s + L]).reshape(1, L, 1))[0]
+        re = O.variance_embed(sd, "energy", torch.from_numpy(e[s : s + L]).reshape(1, L, 1))[0]
+        assert max_abs(pe[s : s + L].cpu(), rp) < 1e-5 and max_abs(ee[s : s + L].cpu(), re) < 1e-5
+        assert max_abs(out[s : s + L].cpu(), torch.from_numpy(hs[s : s + L]) + rp + re) < 1e-5
+
+
+@pytest.mark.parametrize("hp", [TINY_S, TINY_T, HP.student_hparams(), HP.teacher_hparams()], ids=["tinyS", "tinyT", "S", "T"])
+def test_bilstm_both_algorithms(ops, hp):
+    rng = np.random.RandomState(2)
+    sd = torch_state_dict(hp)
+    lens = [23, 17, 17, 4, 1]
+    B, T, C, H = len(lens), 23, hp.econv_chans, hp.eunits // 2
+    x = rnd(rng, B, T, C)
+    ref = O.blstm_packed(sd, torch.from_numpy(x), lens)
+    args = [dev(sd["enc.blstm." + k]) for k in ("weight_ih_l0", "weight_hh_l0")]
+    b_f = dev(sd["enc.blstm.bias_ih_l0"] + sd["enc.blstm.bias_hh_l0"])
+    args_r = [dev(sd["enc.blstm." + k + "_reverse"]) for k in ("weight_ih_l0", "weight_hh_l0")]
+    b_r = dev(sd["enc.blstm.bias_ih_l0_reverse"] + sd["enc.blstm.bias_hh_l0_reverse"])
+    algos = [1, 2] if H in (8, 16, 32, 64, 128) else [1]
+    for algo in algos:
+        out = ops.bilstm(dev(x.reshape(B * T, C)), dev(np.array(lens, np.int32)), args[0], args[1], b_f, args_r[0], args_r[1], b_r, B, T, algo)
+        assert max_abs(out.cpu().reshape(B, T, 2 * H), ref) < 2e-5, algo
+
+
+def _decoder_case(ops, hp, n_rows, seed, teacher_forced, masked):
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    rng = np.random.RandomState(seed)
+    sd = torch_state_dict(hp)
+    plan = SynthesisPlan(np_state_dict(hp), hp, DEV)
+    dur = np.sort(np.clip(rng.poisson(6, n_rows), 1, 30))[::-1].astype(np.int32).copy()
+    lmax = int(dur[0])
+    att = rnd(rng, n_rows, hp.eunits)
+    foff = np.concatenate([[0], np.cumsum(dur)[:-1]]).astype(np.int32)
+    F_ = int(dur.sum())
+    live = np.ascontiguousarray((dur[None, :] > np.arange(lmax)[:, None]).sum(1).astype(np.int32))
+    ys = rnd(rng, n_rows, lmax, hp.odim) if teacher_forced else None
+    keep = SYN.closed_form_keep_mask((lmax, 2, n_rows, hp.prenet_units), seed) if masked else None
+    before, taps = ops.decoder_loop(plan.decoder, dev(att), dev(dur), live, dev(foff), F_,
+                                    teacher_ys=dev(ys) if ys is not None else None,
+                                    dropout_mode=ops.DROP_MASK if masked else ops.DROP_NONE,
+                                    prenet_keep=dev(keep) if masked else None, want_taps=True)
+    pos = O.position_table(torch.from_numpy(dur))
+    with torch.no_grad():
+        outs, pres, l0, l1 = O.decoder_loop(sd, hp, torch.from_numpy(att), pos, lmax,
+                                            torch.from_numpy(ys) if ys is not None else None,
+                                            torch.from_numpy(keep) if masked else None)
+    mask = torch.from_numpy(dur[:, None] > np.arange(lmax)[None, :])
+    return (before.cpu(), [t.cpu() for t in taps]), (outs.transpose(1, 2)[mask], [pres[mask], l0[mask], l1[mask]])
+
+
+@pytest.mark.parametrize("hp,n_rows", [(TINY_S, 37), (TINY_T, 5), (HP.student_hparams(dropout_rate=0.0), 300),
+                                       (HP.student_hparams(), 97), (HP.teacher_hparams(), 70)], ids=["tinyS", "tinyT", "S_nodrop", "S_mask", "T_mask"])
+@pytest.mark.parametrize("teacher_forced", [False, True])
+def test_decoder_loop_vs_oracle(ops, hp, n_rows, teacher_forced):
+    masked = hp.dropout_rate > 0
+    (before, taps), (ref_before, ref_taps) = _decoder_case(ops, hp, n_rows, 5, teacher_forced, masked)
+    assert max_abs(before, ref_before) < 1e-4  # frame-major scatter (H10) + H6-H8 maths
+    for a, b in zip(taps, ref_taps):
+        assert max_abs(a, b) < 1e-4
+
+
+def test_decoder_rng_dropout_statistics(ops):
+    """Production mode (on-device counter-hash Bernoulli): keep rate ~ 1-p and outputs differ per seed."""
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    hp = HP.student_hparams()
+    plan = SynthesisPlan(np_state_dict(hp), hp, DEV)
+    n, lmax = 256, 4
+    dur = np.full(n, lmax, np.int32)
+    att = dev(rnd(np.random.RandomState(0), n, hp.eunits))
+    foff = (np.arange(n) * lmax).astype(np.int32)
+    live = np.full(lmax, n, np.int32)
+    outs = []
+    for seed in (1, 2):
+        before, taps = ops.decoder_loop(plan.decoder, att, dev(dur), live, dev(foff), n * lmax, dropout_mode=ops.DROP_RNG, seed=seed, want_taps=True)
+        frac = float((taps[0] == 0).float().mean())
+        assert 0.6 < frac < 0.9  # relu zeros (~50%) then dropout p=0.5 -> ~75% zeros
+        outs.append(before.cpu())
+    assert max_abs(outs[0], outs[1]) > 1e-6
+
+
+# ------------------------------------------------------------------------------------------ end to end
+def _plan(hp, thp=None, share=True):
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    return SynthesisPlan(np_state_dict(hp, thp, share), hp, DEV)
+
+
+@pytest.mark.parametrize("tag,hp,thp", [("student_share", TINY_S, TINY_T), ("teacher", TINY_T, None)])
+def test_g1_tiny_inference_vs_reference(ops, golden, tag, hp, thp):
+    from fcl_taco2_amd import engine
+
+    g = golden("g1_infer_" + tag)
+    plan = _plan(hp, thp)
+    for algo in (1, 2):
+        mels, it = engine.synthesize(plan, [g["x"]], [g["dur"]], return_intermediates=True, bilstm_algo=algo)
+        T = it["T"]
+        assert max_abs(it["hs"].cpu()[:T], g["h"]) < 1e-5
+        assert max_abs(it["p_outs"].cpu()[:T], g["p_outs"][:, 0]) < 1e-5
+        assert max_abs(it["e_outs"].cpu()[:T], g["e_outs"][:, 0]) < 1e-5
+        assert max_abs(it["p_embs"].cpu()[:T], g["p_embs"]) < 1e-5
+        assert max_abs(it["before"].cpu(), g["before"]) < 2e-5
+        assert max_abs(mels[0].cpu(), g["after"]) < 2e-5
+    # predicted durations: the integer output of the duration predictor is bit-exact vs the reference
+    hs, lo, hi, pad = engine.encode(plan, dev(g["x"].reshape(1, -1)), [len(g["x"])])
+    d_log = engine._predictor_scalar(plan.duration, hs, lo, hi, None)
+    assert max_abs(d_log.cpu(), g["d_log"]) < 1e-5
+    assert np.array_equal(ops.duration_round(d_log, False, 1.0, pad).cpu().numpy(), g["d_int"])
+
+
+def test_g2_student_c1_mel_vs_reference(ops, golden):
+    from fcl_taco2_amd import engine
+
+    g = golden("g2_student_c1")
+    plan = _plan(HP.student_hparams(dropout_rate=0.0))
+    mels, it = engine.synthesize(plan, [g["x"]], [g["dur"]], return_intermediates=True)
+    assert max_abs(it["hs"].cpu(), g["h"]) < 1e-4
+    assert max_abs(it["before"].cpu(), g["before"]) < 1e-3
+    assert mels[0].shape == g["after"].shape
+    err = max_abs(mels[0].cpu(), g["after"])
+    print("G2 mel max-abs vs reference: %.3e" % err)
+    assert err < 1e-3  # the north-star tolerance, against the real reference's output
+
+
+def test_g2t_teacher_c1_mel_vs_reference(ops, golden):
+    from fcl_taco2_amd import engine
+
+    g = golden("g2t_teacher_c1")
+    plan = _plan(HP.teacher_hparams(dropout_rate=0.0))
+    mels = engine.synthesize(plan, [g["x"]], [g["dur"]])
+    err = max_abs(mels[0].cpu(), g["after"])
+    print("G2T mel max-abs vs reference: %.3e" % err)
+    assert err < 1e-3
+
+
+def test_g3_injected_dropout_vs_reference(ops, golden):
+    from fcl_taco2_amd import engine
+
+    g = golden("g3_student_c1_masked")
+    hp = HP.student_hparams()
+    plan = _plan(hp)
+    d = g["dur"]
+    keep = SYN.closed_form_keep_mask((int(d.max()), 2, int((d > 0).sum()), hp.prenet_units), int(g["keep_seed"]))
+    mels = engine.synthesize(plan, [g["x"]], [d], dropout_mode=ops.DROP_MASK, prenet_keep=keep)
+    err = max_abs(mels[0].cpu(), g["after"])
+    print("G3 mel max-abs vs reference: %.3e" % err)
+    assert err < 1e-3
+
+
+def test_g2b_batched_equals_per_utterance_reference(ops, golden):
+    """D6: one batched call == the reference's per-utterance inference() (no padding leak, any order)."""
+    from fcl_taco2_amd import engine
+
+    g = golden("g2b_student_batch3")
+    plan = _plan(HP.student_hparams(dropout_rate=0.0))
+    xs, ds = [g["x%d" % i] for i in range(3)], [g["dur%d" % i] for i in range(3)]
+    for perm in ([0, 1, 2], [2, 0, 1]):
+        mels = engine.synthesize(plan, [xs[i] for i in perm], [ds[i] for i in perm])
+        for j, i in enumerate(perm):
+            assert max_abs(mels[j].cpu(), g["after%d" % i]) < 1e-3
+
+
+def test_zero_duration_raises_like_reference(ops):
+    from fcl_taco2_amd import engine
+
+    plan = _plan(TINY_T)
+    with pytest.raises(AssertionError):
+        engine.synthesize(plan, [np.array([3, 4, 5, 6, 7])], [np.array([2, 0, 1, 3, 1])])
+
+
+def test_c2_full_size_properties(ops):
+    """BASELINE config 2 (B=32, ~80 phonemes, ~800 frames/utt): size-independent properties.
+    (a) batched == each utterance alone (row independence + no leak), (b) frame counts == sum(dur),
+    (c) oracle parity on two utterances of the batch."""
+    from fcl_taco2_amd import engine
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    plan = _plan(hp)
+    xs, ds = SYN.batch_c2(hp.idim)
+    mels = engine.synthesize(plan, xs, ds)
+    assert [m.shape[0] for m in mels] == [int(d.sum()) for d in ds]
+    assert all(torch.isfinite(m).all() for m in mels)
+    for i in (0, 13, 31):
+        alone = engine.synthesize(plan, [xs[i]], [ds[i]])[0]
+        assert max_abs(alone.cpu(), mels[i].cpu()) < 1e-4
+    sd = torch_state_dict(hp)
+    for i in (5, 31):
+        with torch.no_grad():
+            ref = O.inference(sd, hp, torch.from_numpy(xs[i]), dur=torch.from_numpy(ds[i]))["after"]
+        assert max_abs(mels[i].cpu(), ref) < 1e-3
