@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — mel-frames/sec of the FCL-taco2-S synthesis hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (encoder -> predictors -> per-phoneme-parallel decoder loop -> postnet)
+over one synthetic LJSpeech-shape batch (32 utterances, 60..100 phonemes each, forced
+durations clip(Poisson(10),1,50), ~25.6 k mel frames), inputs already resident in HBM (engine.prepare runs
+before the clock starts), prenet dropout on in its production (on-device RNG) mode, fp32 arithmetic.
+Utterances are independent, so N ranks run N independent batches (different seeds; weak scaling, no
+data-path collective); the clock is barrier + synchronize on both sides, MAX over ranks; `value` is the
+whole-job frames / that time.  Rank 0 additionally reports (N=1 only) the live roofline figures of the
+dominant kernel (HIP events on the launching stream, via fcl_prof_*) and a bounded CPU baseline (the
+oracle = this build's CPU restatement of the reference, "port").  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= fp32 vector peak)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--model", choices=["student", "teacher"], default="student")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import __graft_entry__ as ge
+
+    ge.build() if rank == 0 and not os.path.exists(os.path.join(ROOT, "fcl-taco2_amd", "libfcl_hip.so")) else None
+    if dist is not None:
+        dist.barrier()
+    import fcl_taco2_amd  # noqa: F401
+    from fcl_taco2_amd import _lib, engine, hparams as HP, ops, synthetic as SYN
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    hp = HP.student_hparams() if args.model == "student" else HP.teacher_hparams()
+    sd_np = SYN.closed_form_state_dict(HP.param_spec(hp))
+    plan = SynthesisPlan(sd_np, hp, dev)
+    xs, ds = SYN.batch_c2(hp.idim, batch=args.batch, seed=1234 + rank)
+    prep = engine.prepare(plan, xs, ds)
+    frames = int(sum(int(d.sum()) for d in ds))
+    n_rows = int(sum(len(d) for d in ds))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        engine.run(plan, prep, ops.DROP_RNG, seed=i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        engine.run(plan, prep, ops.DROP_RNG, seed=1000 + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    tot = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        tmax = tot[0:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        fsum = tot[1:2].clone()
+        dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
+        dt, frames_all = float(tmax.item()), float(fsum.item())
+    else:
+        frames_all = float(frames)
+    value = frames_all * args.steps / dt
+
+    out = {
+        "metric": "mel-frames/sec (FCL-taco2-%s forward, batch=%d, 80-mel)" % ("S" if args.model == "student" else "T", args.batch),
+        "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: FCL-taco2-%s free-running synthesis, batch=%d/GPU, 60-100 phonemes/utt, forced "
+                               "durations clip(Poisson(10),1,50), %d frames / %d phoneme rows per batch, prenet dropout on (device RNG), "
+                               "closed-form weights" % ("S" if args.model == "student" else "T", args.batch, frames, n_rows),
+                   "parallelism": "%d independent replicas (utterance-sharded, no collective)" % world},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- PCIe-inclusive figure (prepare + run), reported beside `value`, never as it
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(5):
+            engine.run(plan, engine.prepare(plan, xs, ds), ops.DROP_RNG, seed=i)
+        torch.cuda.synchronize()
+        out["value_including_host_prepare"] = frames * 5 / (time.perf_counter() - t1)
+
+        # ---- live roofline of the dominant kernel: HIP events around every launch of one profiled pass
+        _lib.prof_enable(True)
+        for i in range(3):
+            engine.run(plan, prep, ops.DROP_RNG, seed=i)
+        torch.cuda.synchronize()
+        prof = _lib.prof_collect()
+        _lib.prof_enable(False)
+        tot_ms = sum(v["ms"] for v in prof.values()) or 1.0
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        d = prof[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "avg_launch_us": 1e3 * d["ms"] / d["launches"], "launches_per_step": d["launches"] / 3.0,
+            "flops_per_launch": d["flops"] / d["launches"], "share_of_kernel_time": d["ms"] / tot_ms,
+            "note": "fp32-in MFMA (exact f32) peak; FLOPs = executed 2*M*N*K of the kernel's launches (no credit for hoisted "
+                    "att_c terms or padded rows); durations from HIP events on the launch stream",
+        }
+        out["kernels"] = {k: {"ms_per_step": v["ms"] / 3.0, "launches_per_step": v["launches"] / 3.0,
+                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0} for k, v in sorted(prof.items())}
+
+        # ---- CPU baseline: the oracle ("port" of the reference's per-utterance inference) on the host cores
+        if not args.no_cpu_baseline:
+            from oracle import fcl_oracle as O
+
+            # host cores this process may use (cgroup/affinity aware), capped: the oracle's per-step ops are small and
+            # stop scaling (then thrash) well before a 256-thread pool
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            ncores = max(1, min(avail, args.cpu_threads))
+            torch.set_num_threads(ncores)
+            sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+            txs = [torch.from_numpy(x) for x in xs]
+            tds = [torch.from_numpy(d_) for d_ in ds]
+            done_frames, n_utts, t2 = 0, 0, time.perf_counter()
+            with torch.no_grad():
+                O.inference(sd, hp, txs[0], dur=tds[0], prenet_keep="rng")  # warm-up
+                t2 = time.perf_counter()
+                while time.perf_counter() - t2 < args.cpu_seconds:
+                    i = n_utts % len(txs)
+                    done_frames += int(O.inference(sd, hp, txs[i], dur=tds[i], prenet_keep="rng")["after"].shape[0])
+                    n_utts += 1
+            cpu_dt = time.perf_counter() - t2
+            out["cpu_baseline"] = {
+                "value": done_frames / cpu_dt, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "%d sequential per-utterance inference() calls of the same batch (%d frames, %.1f s) through oracle/fcl_oracle.py "
+                          "(torch %s CPU fp32, prenet dropout on)" % (n_utts, done_frames, cpu_dt, torch.__version__),
+            }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,10 @@ class DecoderIO(C.Structure):
                 ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
+
+
 SIGNATURES = {
     "fcl_last_error": (C.c_char_p, []),
     "fcl_version": (_I, []),
@@ -48,6 +52,8 @@ SIGNATURES = {
     "fcl_bilstm_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P, _Z, _P]),
     "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
     "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
+    "fcl_prof_enable": (_I, [_I]),
+    "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
@@ -76,6 +82,19 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def prof_enable(on):
+    check(load().fcl_prof_enable(int(on)))
+
+
+def prof_collect():
+    """{kernel name: dict(launches, ms, flops, rows)} for the launches since prof_enable(True)."""
+    buf = (ProfEntry * 32)()
+    n = load().fcl_prof_collect(buf, 32)
+    if n < 0:
+        check(n)
+    return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops, rows=buf[i].rows) for i in range(n)}
 
 
 def check(rc):

@@ -114,6 +114,7 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     if (algo == 0) algo = can_persist ? 2 : 1;
     FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);
     if (algo == 2) {
+        ProfScope ps("bilstm_persistent_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
         dim3 grid(b, 2);
 #define FCL_BILSTM_CASE(HH) \
     case HH: hipLaunchKernelGGL((bilstm_persistent_kernel<HH>), grid, dim3(4 * HH), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t); break;

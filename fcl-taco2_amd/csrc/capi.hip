@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <vector>
+
 #include "fcl_common.h"
 
 namespace fcl {
@@ -20,6 +22,20 @@ int check_hip(hipError_t e, const char* what) {
     set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
     return FCL_ERR_HIP;
 }
+
+// ---- profiling records ------------------------------------------------------------------------------
+bool g_prof_on = false;
+struct ProfRec { const char* name; double flops, rows; hipEvent_t a, b; };
+static std::vector<ProfRec> g_prof;
+
+void prof_begin(const char* name, double flops, double rows, hipStream_t s) {
+    ProfRec r{name, flops, rows, nullptr, nullptr};
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+void prof_end(hipStream_t s) { (void)hipEventRecord(g_prof.back().b, s); }
 
 __global__ void zero_kernel(float* p, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
@@ -103,6 +119,37 @@ int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int
     g.Y = y;
     g.ldy = cout;
     return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fcl_prof_enable(int on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries) {
+    FCL_REQUIRE(out && max_entries > 0, FCL_ERR_INVALID, "prof_collect: bad arguments");
+    int n = 0;
+    for (auto& r : g_prof) {
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        int i = 0;
+        for (; i < n; ++i)
+            if (strcmp(out[i].name, r.name) == 0) break;
+        if (i == n) {
+            if (n == max_entries) continue;
+            memset(&out[n], 0, sizeof(out[n]));
+            strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
+            ++n;
+        }
+        out[i].launches += 1;
+        out[i].ms += ms;
+        out[i].flops += r.flops;
+        out[i].rows += r.rows;
+    }
+    return n;
 }
 
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n) {

@@ -101,6 +101,21 @@ struct LstmStepArgs {
     int out2_col_off;
 };
 
+// ---- profiling hook (capi.hip) ----------------------------------------------------------------------
+extern bool g_prof_on;
+void prof_begin(const char* name, double flops, double rows, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(const char* name, double flops, double rows, hipStream_t st) : s(st), on(g_prof_on) {
+        if (on) prof_begin(name, flops, rows, s);
+    }
+    ~ProfScope() {
+        if (on) prof_end(s);
+    }
+};
+
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 

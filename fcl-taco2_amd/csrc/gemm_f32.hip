@@ -280,15 +280,21 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     FCL_REQUIRE(a.Y, FCL_ERR_INVALID, "gemm: null output");
     FCL_REQUIRE(a.drop_mode != 1 || a.keep, FCL_ERR_INVALID, "gemm: drop_mode 1 needs a keep mask");
     FCL_REQUIRE(!a.Y2 || a.y2_row_base, FCL_ERR_INVALID, "gemm: Y2 needs y2_row_base");
+    double ksum = 0;
+    for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
+    const double flops = 2.0 * a.M * (double)a.N * ksum;
     // 64x64 tiles while they fill the chip (>= 256 workgroups), else 32x128 / 16x256 to get more row tiles.
     const long long wg64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
     if (wg64 >= 256 || a.N <= 64) {
+        ProfScope ps("gemm_kernel<4,1>", flops, a.M, s);
         dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
         hipLaunchKernelGGL((gemm_kernel<4, 1>), grid, dim3(256), 0, s, a);
     } else if (a.N <= 128 || (long long)((a.M + 31) / 32) * ((a.N + 127) / 128) >= 256) {
+        ProfScope ps("gemm_kernel<2,2>", flops, a.M, s);
         dim3 grid((a.N + 127) / 128, (a.M + 31) / 32);
         hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, s, a);
     } else {
+        ProfScope ps("gemm_kernel<1,4>", flops, a.M, s);
         dim3 grid((a.N + 255) / 256, (a.M + 15) / 16);
         hipLaunchKernelGGL((gemm_kernel<1, 4>), grid, dim3(256), 0, s, a);
     }
@@ -303,14 +309,20 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     FCL_REQUIRE(a.h_in && a.h_out && a.c && a.h_in != a.h_out, FCL_ERR_INVALID, "lstm_step: h_in/h_out/c must be set and h_out must not alias h_in");
     FCL_REQUIRE(!a.rank1_w || a.dur, FCL_ERR_INVALID, "lstm_step: rank1_w needs dur");
     FCL_REQUIRE((a.zone_keep_h == nullptr) == (a.zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_step: zoneout masks come in pairs");
+    double ksum = 0;
+    for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
+    const double flops = 2.0 * a.M * 4.0 * a.U * ksum;
     const long long wg64 = (long long)((a.M + 63) / 64) * ((a.U + 15) / 16);
     if (wg64 >= 256 || a.U <= 16) {
+        ProfScope ps("lstm_step_kernel<4,1>", flops, a.M, s);
         dim3 grid((a.U + 15) / 16, (a.M + 63) / 64);
         hipLaunchKernelGGL((lstm_step_kernel<4, 1>), grid, dim3(256), 0, s, a);
     } else if (a.U <= 32 || (long long)((a.M + 31) / 32) * ((a.U + 31) / 32) >= 192) {
+        ProfScope ps("lstm_step_kernel<2,2>", flops, a.M, s);
         dim3 grid((a.U + 31) / 32, (a.M + 31) / 32);
         hipLaunchKernelGGL((lstm_step_kernel<2, 2>), grid, dim3(256), 0, s, a);
     } else {
+        ProfScope ps("lstm_step_kernel<1,4>", flops, a.M, s);
         dim3 grid((a.U + 63) / 64, (a.M + 15) / 16);
         hipLaunchKernelGGL((lstm_step_kernel<1, 4>), grid, dim3(256), 0, s, a);
     }

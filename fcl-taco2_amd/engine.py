@@ -69,23 +69,106 @@ def _predictor_scalar(pp, hs, seg_lo, seg_hi, pad_mask_u8):
     return out
 
 
-def encode(plan, ids_padded, lens, bilstm_algo=0):
-    """H1-H3 for a padded id matrix [B, T] (device int64): returns hs [B*T, C], seg_lo/seg_hi, pad mask."""
-    B, T = ids_padded.shape
+class PreparedBatch(object):
+    """Everything `run` needs, resident in HBM: padded ids, segment bounds, and (forced durations) row maps."""
+    __slots__ = ("B", "T", "lens", "ids", "seg_lo", "seg_hi", "pad", "lens_dev", "f0e", "maps", "src_rows", "dur", "frame_off",
+                 "frame_lo", "frame_hi")
+
+
+def _upload_maps(prep, maps, dev):
+    prep.maps = maps
+    prep.src_rows = torch.from_numpy(maps.src_rows).to(dev)
+    prep.dur = torch.from_numpy(maps.dur_sorted).to(dev)
+    prep.frame_off = torch.from_numpy(maps.frame_off_sorted).to(dev)
+    prep.frame_lo = torch.from_numpy(maps.frame_lo).to(dev)
+    prep.frame_hi = torch.from_numpy(maps.frame_hi).to(dev)
+
+
+def prepare(plan, xs, durs=None, f0=None, energy=None):
+    """Input hand-over: pad + upload phoneme ids, build the integer segment bounds, and — when durations are
+    forced — the row maps.  This is the host batch layout step (the reference's loader/converter side)."""
     dev = plan.device
-    lens_np = np.asarray(lens, dtype=np.int64)
-    rows = np.arange(B * T, dtype=np.int64)
+    p = PreparedBatch()
+    p.B = len(xs)
+    p.lens = [int(len(x)) for x in xs]
+    p.T = T = max(p.lens)
+    ids = np.zeros((p.B, T), dtype=np.int64)
+    for b, x in enumerate(xs):
+        ids[b, : p.lens[b]] = x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+    lens_np = np.asarray(p.lens, dtype=np.int64)
+    rows = np.arange(p.B * T, dtype=np.int64)
     b_of = rows // T
-    seg_lo = torch.from_numpy((b_of * T).astype(np.int32)).to(dev)
-    seg_hi = torch.from_numpy((b_of * T + lens_np[b_of]).astype(np.int32)).to(dev)
-    pad = torch.from_numpy(((rows % T) >= lens_np[b_of]).astype(np.uint8)).to(dev)
-    x = ops.embedding(ids_padded.reshape(-1), plan.embed)
+    with torch.cuda.device(dev):
+        p.ids = torch.from_numpy(ids.reshape(-1)).to(dev)
+        p.seg_lo = torch.from_numpy((b_of * T).astype(np.int32)).to(dev)
+        p.seg_hi = torch.from_numpy((b_of * T + lens_np[b_of]).astype(np.int32)).to(dev)
+        p.pad = torch.from_numpy(((rows % T) >= lens_np[b_of]).astype(np.uint8)).to(dev)
+        p.lens_dev = torch.from_numpy(lens_np.astype(np.int32)).to(dev)
+        p.f0e = None
+        if f0 is not None:
+            pe = np.zeros((2, p.B, T), dtype=np.float32)
+            for b in range(p.B):
+                pe[0, b, : p.lens[b]] = np.asarray(f0[b]).reshape(-1)
+                pe[1, b, : p.lens[b]] = np.asarray(energy[b]).reshape(-1)
+            p.f0e = torch.from_numpy(pe.reshape(2, -1)).to(dev)
+        p.maps = None
+        if durs is not None:
+            _upload_maps(p, build_row_maps(p.lens, durs, T), dev)
+    return p
+
+
+def encode(plan, prep, bilstm_algo=0):
+    """H1-H3: embedding -> 3 x conv/BN/ReLU -> packed BiLSTM.  Returns hs [B*T, C]."""
+    x = ops.embedding(prep.ids, plan.embed)
     for cv in plan.enc_convs:
-        x = ops.conv1d(x, cv.wp, cv.bias, seg_lo, seg_hi, ops.ACT_RELU)
-    lens_dev = torch.from_numpy(lens_np.astype(np.int32)).to(dev)
+        x = ops.conv1d(x, cv.wp, cv.bias, prep.seg_lo, prep.seg_hi, ops.ACT_RELU)
     bl = plan.blstm
-    hs = ops.bilstm(x, lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], B, T, bilstm_algo)
-    return hs, seg_lo, seg_hi, pad
+    return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo)
+
+
+def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_algo=0, return_intermediates=False):
+    """One pass of the hot path over a prepared batch.  Returns the packed mel [F, odim] (after postnet) and
+    the per-utterance frame counts; with forced durations nothing here touches the host."""
+    hp, dev = plan.hp, plan.device
+    with torch.cuda.device(dev):
+        hs = encode(plan, prep, bilstm_algo)
+        inter = {"hs": hs, "T": prep.T} if return_intermediates else None
+        rm = prep  # holder of the row maps
+        if prep.maps is None:  # predicted durations: maps depend on this pass's predictor output, never cached
+            d_log = _predictor_scalar(plan.duration, hs, prep.seg_lo, prep.seg_hi, None)
+            d_int = ops.duration_round(d_log, False, 1.0, prep.pad)
+            d_host = d_int.cpu().numpy().reshape(prep.B, prep.T)  # the one host sync of the predicted-duration path
+            rm = PreparedBatch()
+            _upload_maps(rm, build_row_maps(prep.lens, [d_host[b, : prep.lens[b]] for b in range(prep.B)], prep.T), dev)
+            if inter is not None:
+                inter["d_log"], inter["d_int"] = d_log, d_int
+        if prep.f0e is None:
+            p = _predictor_scalar(plan.pitch, hs, prep.seg_lo, prep.seg_hi, prep.pad)
+            e = _predictor_scalar(plan.energy, hs, prep.seg_lo, prep.seg_hi, prep.pad)
+        else:
+            p, e = prep.f0e[0], prep.f0e[1]
+        att, p_emb, e_emb = ops.variance_embed_add(hs, p, e, plan.pitch_embed_w, plan.pitch_embed_b, plan.energy_embed_w,
+                                                   plan.energy_embed_b, prep.seg_lo, prep.seg_hi, want_embs=return_intermediates)
+        maps = rm.maps
+        att_c = ops.gather_rows(att, rm.src_rows)
+        keep_dev = None
+        if hp.dropout_rate <= 0.0:
+            dropout_mode = ops.DROP_NONE
+        if dropout_mode == ops.DROP_MASK:
+            keep = np.ascontiguousarray(np.asarray(prenet_keep)[: maps.lmax][:, :, maps.order, :])  # to sorted row order
+            keep_dev = torch.from_numpy(keep).to(dev)
+        before = ops.decoder_loop(plan.decoder, att_c, rm.dur, maps.live_rows, rm.frame_off, maps.n_frames,
+                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed)
+        x = before
+        n_post = len(plan.postnet)
+        for i, cv in enumerate(plan.postnet):
+            last = i == n_post - 1
+            x = ops.conv1d(x, cv.wp, cv.bias, rm.frame_lo, rm.frame_hi, ops.ACT_NONE if last else ops.ACT_TANH,
+                           residual=before if last else None)
+        if inter is not None:
+            inter.update(p_outs=p, e_outs=e, p_embs=p_emb, e_embs=e_emb, before=before, after=x, maps=maps)
+            return x, maps.utt_frames, inter
+        return x, maps.utt_frames
 
 
 def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0,
@@ -94,62 +177,11 @@ def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_
     f0/energy: optional lists of [T] arrays replacing the predictors (inference(f0=..., energy=...)).
     prenet_keep: optional uint8 [Lmax, 2, N, P] in (utterance, phoneme) row order (FCL_DROP_MASK).
     Returns a list of mel tensors [L_b, odim] (views into one packed device buffer)."""
-    hp, dev = plan.hp, plan.device
-    B = len(xs)
-    lens = [int(len(x)) for x in xs]
-    T = max(lens)
-    ids = np.zeros((B, T), dtype=np.int64)
-    for b, x in enumerate(xs):
-        ids[b, : lens[b]] = x.cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
-    with torch.cuda.device(dev):
-        ids_dev = torch.from_numpy(ids).to(dev)
-        hs, seg_lo, seg_hi, pad = encode(plan, ids_dev, lens, bilstm_algo)
-        inter = {"hs": hs} if return_intermediates else None
-        if durs is None:
-            d_log = _predictor_scalar(plan.duration, hs, seg_lo, seg_hi, None)
-            d_int = ops.duration_round(d_log, False, 1.0, pad)
-            d_host = d_int.cpu().numpy().reshape(B, T)  # the one host sync of the predicted-duration path
-            durs = [d_host[b, : lens[b]] for b in range(B)]
-            if inter is not None:
-                inter["d_log"], inter["d_int"] = d_log, d_int
-        if f0 is None:
-            p = _predictor_scalar(plan.pitch, hs, seg_lo, seg_hi, pad)
-            e = _predictor_scalar(plan.energy, hs, seg_lo, seg_hi, pad)
-        else:
-            pe = np.zeros((2, B, T), dtype=np.float32)
-            for b in range(B):
-                pe[0, b, : lens[b]] = np.asarray(f0[b]).reshape(-1)
-                pe[1, b, : lens[b]] = np.asarray(energy[b]).reshape(-1)
-            pe = torch.from_numpy(pe).to(dev)
-            p, e = pe[0].reshape(-1).contiguous(), pe[1].reshape(-1).contiguous()
-        att, p_emb, e_emb = ops.variance_embed_add(hs, p, e, plan.pitch_embed_w, plan.pitch_embed_b, plan.energy_embed_w,
-                                                   plan.energy_embed_b, seg_lo, seg_hi, want_embs=return_intermediates)
-        if inter is not None:
-            inter.update(p_outs=p, e_outs=e, p_embs=p_emb, e_embs=e_emb)
-        maps = build_row_maps(lens, durs, T)
-        att_c = ops.gather_rows(att, torch.from_numpy(maps.src_rows).to(dev))
-        dur_dev = torch.from_numpy(maps.dur_sorted).to(dev)
-        foff_dev = torch.from_numpy(maps.frame_off_sorted).to(dev)
-        keep_dev = None
-        if hp.dropout_rate <= 0.0:
-            dropout_mode = ops.DROP_NONE
-        if dropout_mode == ops.DROP_MASK:
-            keep = np.ascontiguousarray(np.asarray(prenet_keep)[: maps.lmax][:, :, maps.order, :])  # to sorted row order
-            keep_dev = torch.from_numpy(keep).to(dev)
-        before = ops.decoder_loop(plan.decoder, att_c, dur_dev, maps.live_rows, foff_dev, maps.n_frames,
-                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed)
-        f_lo, f_hi = torch.from_numpy(maps.frame_lo).to(dev), torch.from_numpy(maps.frame_hi).to(dev)
-        x = before
-        n_post = len(plan.postnet)
-        for i, cv in enumerate(plan.postnet):
-            last = i == n_post - 1
-            x = ops.conv1d(x, cv.wp, cv.bias, f_lo, f_hi, ops.ACT_NONE if last else ops.ACT_TANH, residual=before if last else None)
-        after = x
-        mels, s = [], 0
-        for n in maps.utt_frames:
-            mels.append(after[s : s + n])
-            s += n
-        if inter is not None:
-            inter.update(before=before, after=after, maps=maps, T=T)
-            return mels, inter
-        return mels
+    prep = prepare(plan, xs, durs, f0, energy)
+    out = run(plan, prep, dropout_mode, prenet_keep, seed, bilstm_algo, return_intermediates)
+    after, utt_frames = out[0], out[1]
+    mels, s = [], 0
+    for n in utt_frames:
+        mels.append(after[s : s + n])
+        s += n
+    return (mels, out[2]) if return_intermediates else mels

@@ -151,6 +151,21 @@ typedef struct {
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n);
 int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, fcl_stream_t stream);
 
+/* ---- measurement hook (bench.py's live roofline figures) ------------------------------- */
+/* While enabled, every GEMM / LSTM-step / BiLSTM launch is bracketed by HIP events on the stream it is
+ * launched on.  fcl_prof_collect synchronises those events and returns one entry per kernel instantiation:
+ * launches, summed duration, summed executed FLOPs (2*M*N*sum(K); no credit for hoisted or padded work) and
+ * summed rows.  Off by default; never enabled inside a timed region. */
+typedef struct {
+    char name[56];
+    int launches;
+    double ms;
+    double flops;
+    double rows;
+} fcl_prof_entry_t;
+int fcl_prof_enable(int on);
+int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,7 +193,7 @@ def prenet(sd, x, keep_pair=None, p=0.5):
     keep_pair: None = dropout disabled (rate 0), else two {0,1} masks [N, P]."""
     for l in range(2):
         x = torch.relu(F.linear(x, sd["dec.prenet.prenet.%d.0.weight" % l], sd["dec.prenet.prenet.%d.0.bias" % l]))
-        if keep_pair is not None:
+        if keep_pair is not None and p > 0:
             x = _drop(x, keep_pair[l], p)
     return x
 
@@ -241,7 +241,11 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
     prev = att_c.new_zeros(N, hp.odim)
     outs, pres, l0, l1 = [], [], [], []
     for t in range(n_steps):
-        pre = prenet(sd, prev, None if prenet_keep is None else prenet_keep[t])
+        if isinstance(prenet_keep, str):  # "rng": the reference's always-on F.dropout with fresh Bernoulli masks
+            kp = [(torch.rand(N, hp.prenet_units) >= hp.dropout_rate) for _ in range(2)] if hp.dropout_rate > 0 else None
+        else:
+            kp = None if prenet_keep is None else prenet_keep[t]
+        pre = prenet(sd, prev, kp, hp.dropout_rate if kp is not None else 0.5)
         pres.append(pre)
         xs = torch.cat([att_c, pre, position[:, t].reshape(-1, 1)], dim=1)
         for l in range(2):

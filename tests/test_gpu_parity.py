@@ -265,10 +265,11 @@ def test_g1_tiny_inference_vs_reference(ops, golden, tag, hp, thp):
         assert max_abs(it["before"].cpu(), g["before"]) < 2e-5
         assert max_abs(mels[0].cpu(), g["after"]) < 2e-5
     # predicted durations: the integer output of the duration predictor is bit-exact vs the reference
-    hs, lo, hi, pad = engine.encode(plan, dev(g["x"].reshape(1, -1)), [len(g["x"])])
-    d_log = engine._predictor_scalar(plan.duration, hs, lo, hi, None)
+    prep = engine.prepare(plan, [g["x"]])
+    hs = engine.encode(plan, prep)
+    d_log = engine._predictor_scalar(plan.duration, hs, prep.seg_lo, prep.seg_hi, None)
     assert max_abs(d_log.cpu(), g["d_log"]) < 1e-5
-    assert np.array_equal(ops.duration_round(d_log, False, 1.0, pad).cpu().numpy(), g["d_int"])
+    assert np.array_equal(ops.duration_round(d_log, False, 1.0, prep.pad).cpu().numpy(), g["d_int"])
 
 
 def test_g2_student_c1_mel_vs_reference(ops, golden):
