@@ -25,7 +25,7 @@ class DecoderWeights(C.Structure):
 
 class DecoderIO(C.Structure):
     _fields_ = [("n", _I), ("lmax", _I), ("att_c", _P), ("dur", _P), ("live_rows_host", _P), ("frame_off", _P),
-                ("teacher_ys", _P), ("dropout_mode", _I), ("prenet_keep", _P), ("seed", C.c_uint32), ("before", _P),
+                ("teacher_ys", _P), ("dropout_mode", _I), ("prenet_keep", _P), ("seed", C.c_uint32), ("seed_dev", _P), ("before", _P),
                 ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z)]
 
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     "fcl_fold_batchnorm": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "fcl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "fcl_add_vec": (_I, [_P, _P, _P, _I, _P]),
+    "fcl_u32_add": (_I, [_P, C.c_uint32, _P]),
     "fcl_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcl_conv1d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -1,5 +1,6 @@
 // capi.hip — extern "C" surface of libfcl_hip.so: error plumbing, GEMM-backed ops, the decoder loop.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -21,6 +22,13 @@ int check_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
     set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
     return FCL_ERR_HIP;
+}
+
+int tunable(const char* name, int dflt) {
+    char key[64];
+    snprintf(key, sizeof(key), "FCL_%s", name);
+    const char* v = getenv(key);
+    return v && *v ? atoi(v) : dflt;
 }
 
 // ---- profiling records ------------------------------------------------------------------------------
@@ -207,27 +215,55 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
     }
     const float keep_scale = 1.0f / (1.0f - w->prenet_dropout);
     const int drop_mode = (w->prenet_dropout > 0.f) ? io->dropout_mode : FCL_DROP_NONE;
+    static const int fused = tunable("FUSED_PRENET", 1);
     int cur = 0;
-    for (int t = 0; t < io->lmax; ++t) {
-        const int n = io->live_rows_host[t];
-        // H6 prenet: 2 x {Linear -> ReLU -> dropout (always on)}
-        GemmArgs p0 = {};
-        if (io->teacher_ys && t > 0) p0.term[0] = GemmTerm{io->teacher_ys + (size_t)(t - 1) * O, w->prenet_w0, io->lmax * O, O, O, 0};
-        else p0.term[0] = GemmTerm{ws.prev, w->prenet_w0, O, O, O, 0};
-        p0.nterms = 1; p0.M = n; p0.N = P; p0.bias = w->prenet_b0; p0.act = FCL_ACT_RELU; p0.Y = ws.pre_a; p0.ldy = P;
-        p0.drop_mode = drop_mode; p0.keep_scale = keep_scale; p0.drop_p = w->prenet_dropout;
-        if (drop_mode == FCL_DROP_MASK) { p0.keep = io->prenet_keep + ((size_t)(t * 2 + 0) * N) * P; p0.ldkeep = P; }
-        p0.rng_seed = io->seed * 2654435761u + (unsigned)(t * 2 + 0);
-        int rc = launch_gemm(p0, s);
-        if (rc) return rc;
-        GemmArgs p1 = p0;
-        p1.term[0] = GemmTerm{ws.pre_a, w->prenet_w1, P, P, P, 0};
-        p1.bias = w->prenet_b1; p1.Y = ws.pre_b;
-        if (drop_mode == FCL_DROP_MASK) p1.keep = io->prenet_keep + ((size_t)(t * 2 + 1) * N) * P;
-        p1.rng_seed = io->seed * 2654435761u + (unsigned)(t * 2 + 1);
-        if (io->tap_prenet) { p1.Y2 = io->tap_prenet; p1.ldy2 = P; p1.y2_row_base = io->frame_off; p1.y2_row_add = t; }
-        rc = launch_gemm(p1, s);
-        if (rc) return rc;
+    for (int t = 0; t <= io->lmax; ++t) {
+        const int n = t < io->lmax ? io->live_rows_host[t] : 0;        // rows live at step t
+        const int n_prev = t > 0 ? io->live_rows_host[t - 1] : 0;      // rows whose feat_out(t-1) is due
+        const uint8_t* keep0 = drop_mode == FCL_DROP_MASK && t < io->lmax ? io->prenet_keep + ((size_t)(t * 2 + 0) * N) * P : nullptr;
+        const uint8_t* keep1 = drop_mode == FCL_DROP_MASK && t < io->lmax ? io->prenet_keep + ((size_t)(t * 2 + 1) * N) * P : nullptr;
+        const unsigned seed0 = io->seed * 2654435761u + (unsigned)(t * 2 + 0), seed1 = seed0 + 1;
+        const float* teacher_in = (io->teacher_ys && t > 0) ? io->teacher_ys + (size_t)(t - 1) * O : nullptr;
+        int rc;
+        if (fused) {
+            // H8 feat_out(t-1) [+ H10 scatter] -> H6 prenet(t), one launch
+            FeatPrenetArgs fp = {};
+            fp.M_feat = n_prev; fp.M_pre = n; fp.U = U; fp.O = O; fp.P = P;
+            fp.h1 = t > 0 ? ws.h1[cur] : nullptr; fp.wf_h = w->wf_h; fp.F0 = ws.F0;
+            fp.before = io->before; fp.frame_off = io->frame_off; fp.t_prev = t - 1; fp.t_cur = t;
+            fp.teacher_in = teacher_in; fp.teacher_ld = io->lmax * O;
+            if (t < io->lmax) { fp.w0 = w->prenet_w0; fp.b0 = w->prenet_b0; fp.w1 = w->prenet_w1; fp.b1 = w->prenet_b1; }
+            fp.drop_mode = drop_mode; fp.keep0 = keep0; fp.keep1 = keep1; fp.keep_scale = keep_scale; fp.drop_p = w->prenet_dropout;
+            fp.seed0 = seed0; fp.seed1 = seed1; fp.seed_dev = io->seed_dev; fp.pre_out = ws.pre_b; fp.tap_prenet = io->tap_prenet;
+            rc = launch_feat_prenet(fp, s);
+            if (rc) return rc;
+        } else {
+            if (t > 0) {  // H8 feat_out(t-1) (+ H10 scatter): out = h1 . Wf_h^T + F0
+                GemmArgs f = {};
+                f.term[0] = GemmTerm{ws.h1[cur], w->wf_h, U, U, U, 0};
+                f.nterms = 1; f.M = n_prev; f.N = O; f.C0 = ws.F0; f.ldc0 = O; f.Y = ws.prev; f.ldy = O;
+                f.Y2 = io->before; f.ldy2 = O; f.y2_row_base = io->frame_off; f.y2_row_add = t - 1;
+                rc = launch_gemm(f, s);
+                if (rc) return rc;
+            }
+            if (t < io->lmax) {  // H6 prenet: 2 x {Linear -> ReLU -> dropout (always on)}
+                GemmArgs p0 = {};
+                if (teacher_in) p0.term[0] = GemmTerm{teacher_in, w->prenet_w0, io->lmax * O, O, O, 0};
+                else p0.term[0] = GemmTerm{ws.prev, w->prenet_w0, O, O, O, 0};
+                p0.nterms = 1; p0.M = n; p0.N = P; p0.bias = w->prenet_b0; p0.act = FCL_ACT_RELU; p0.Y = ws.pre_a; p0.ldy = P;
+                p0.drop_mode = drop_mode; p0.keep_scale = keep_scale; p0.drop_p = w->prenet_dropout;
+                p0.keep = keep0; p0.ldkeep = P; p0.rng_seed = seed0; p0.seed_dev = io->seed_dev;
+                rc = launch_gemm(p0, s);
+                if (rc) return rc;
+                GemmArgs p1 = p0;
+                p1.term[0] = GemmTerm{ws.pre_a, w->prenet_w1, P, P, P, 0};
+                p1.bias = w->prenet_b1; p1.Y = ws.pre_b; p1.keep = keep1; p1.rng_seed = seed1;
+                if (io->tap_prenet) { p1.Y2 = io->tap_prenet; p1.ldy2 = P; p1.y2_row_base = io->frame_off; p1.y2_row_add = t; }
+                rc = launch_gemm(p1, s);
+                if (rc) return rc;
+            }
+        }
+        if (t == io->lmax) break;
         // H7 layer 0: gates = G0 + prenet . W_pre^T + pos * w_pos + h0 . W_hh^T ; cell ; zoneout
         LstmStepArgs l0 = {};
         l0.term[0] = GemmTerm{ws.pre_b, w->w0_pre, P, P, P, 0};
@@ -246,13 +282,6 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
         l1.h_in = ws.h1[cur]; l1.h_out = ws.h1[cur ^ 1]; l1.c = ws.c1; l1.zoneout = w->zoneout_rate;
         if (io->tap_lstm1) { l1.out2 = io->tap_lstm1; l1.out2_row_base = io->frame_off; l1.out2_row_add = t; l1.ld2 = U; }
         rc = launch_lstm_step(l1, s);
-        if (rc) return rc;
-        // H8 feat_out (+ H10 scatter to the frame-major output): out = h1 . Wf_h^T + F0
-        GemmArgs f = {};
-        f.term[0] = GemmTerm{ws.h1[cur ^ 1], w->wf_h, U, U, U, 0};
-        f.nterms = 1; f.M = n; f.N = O; f.C0 = ws.F0; f.ldc0 = O; f.Y = ws.prev; f.ldy = O;
-        f.Y2 = io->before; f.ldy2 = O; f.y2_row_base = io->frame_off; f.y2_row_add = t;
-        rc = launch_gemm(f, s);
         if (rc) return rc;
         cur ^= 1;
     }

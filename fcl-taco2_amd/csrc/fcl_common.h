@@ -59,6 +59,7 @@ struct GemmArgs {
     int ldkeep;
     float keep_scale;
     unsigned int rng_seed;  // drop_mode 2: counter-hash Bernoulli(keep 1-p) instead of a mask
+    const unsigned int* seed_dev;  // optional device word added to the seed
     float drop_p;
     int drop_mode;  // 0 none, 1 mask, 2 rng
     const float* R;  // optional residual added after act/dropout
@@ -116,8 +117,34 @@ struct ProfScope {
     }
 };
 
+// ---- fused feat_out(t-1) -> prenet(t) row-tile kernel (decoder_step.hip) -----------------------------
+struct FeatPrenetArgs {
+    int M_feat;  // rows live at step t-1 (feat_out part);  h1 == null => no feat part (t = 0, prev_out = 0)
+    int M_pre;   // rows live at step t (prenet part);       w0 == null => feat only (after the last step)
+    int U, O, P;
+    const float* h1;    // [M_feat, U]
+    const float* wf_h;  // [O, U]
+    const float* F0;    // [*, O] hoisted att_c share of feat_out
+    float* before;      // [F, O] frame-major output; row = frame_off[m] + t_prev
+    const int* frame_off;
+    int t_prev, t_cur;
+    const float* teacher_in;  // optional [*, teacher_ld]: prenet input rows (teacher forcing)
+    int teacher_ld;
+    const float *w0, *b0, *w1, *b1;
+    int drop_mode;  // FCL_DROP_*
+    const uint8_t *keep0, *keep1;  // [*, P] masks of the two layers
+    float keep_scale, drop_p;
+    unsigned int seed0, seed1;
+    const unsigned int* seed_dev;  // optional device word added to both seeds
+    float* pre_out;     // [M_pre, P]
+    float* tap_prenet;  // optional [F, P]; row = frame_off[m] + t_cur
+};
+
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
+int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
+int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s);
+int tunable(const char* name, int dflt);  // FCL_<NAME> environment override, read once
 
 // counter hash shared by the rng-dropout epilogue (and mirrored nowhere on the host: rng mode is the
 // production mode and is not bit-reproducible against the reference's torch RNG stream by design).

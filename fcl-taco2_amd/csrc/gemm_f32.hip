@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, rq = lane >> 4;
-    const unsigned int seed = hash_u32(a.rng_seed);
+    const unsigned int seed = hash_u32(a.rng_seed + (a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + col;
@@ -285,11 +285,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const double flops = 2.0 * a.M * (double)a.N * ksum;
     // 64x64 tiles while they fill the chip (>= 256 workgroups), else 32x128 / 16x256 to get more row tiles.
     const long long wg64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-    if (wg64 >= 256 || a.N <= 64) {
+    static const int force = tunable("GEMM_CFG", 0);  // experiments only: 1 -> <4,1>, 2 -> <2,2>, 3 -> <1,4>
+    if (force == 1 || (force == 0 && (wg64 >= 256 || a.N <= 64))) {
         ProfScope ps("gemm_kernel<4,1>", flops, a.M, s);
         dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
         hipLaunchKernelGGL((gemm_kernel<4, 1>), grid, dim3(256), 0, s, a);
-    } else if (a.N <= 128 || (long long)((a.M + 31) / 32) * ((a.N + 127) / 128) >= 256) {
+    } else if (force == 2 || (force == 0 && (a.N <= 128 || (long long)((a.M + 31) / 32) * ((a.N + 127) / 128) >= 256))) {
         ProfScope ps("gemm_kernel<2,2>", flops, a.M, s);
         dim3 grid((a.N + 127) / 128, (a.M + 31) / 32);
         hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, s, a);
@@ -309,6 +310,8 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     FCL_REQUIRE(a.h_in && a.h_out && a.c && a.h_in != a.h_out, FCL_ERR_INVALID, "lstm_step: h_in/h_out/c must be set and h_out must not alias h_in");
     FCL_REQUIRE(!a.rank1_w || a.dur, FCL_ERR_INVALID, "lstm_step: rank1_w needs dur");
     FCL_REQUIRE((a.zone_keep_h == nullptr) == (a.zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_step: zoneout masks come in pairs");
+    static const int small_m = tunable("LSTM_SMALL_M", 1024);
+    if (a.M <= small_m) return launch_lstm_small(a, s);
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * 4.0 * a.U * ksum;

@@ -38,6 +38,10 @@ __global__ void copy2d_kernel(float* dst, int ld_dst, const float* src, int ld_s
     }
 }
 
+__global__ void u32_add_kernel(unsigned int* p, unsigned int v) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *p += v;
+}
+
 __global__ void add_vec_kernel(const float* a, const float* b, float* out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
@@ -198,6 +202,12 @@ int fcl_copy2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, i
     FCL_REQUIRE(dst && src && rows > 0 && cols > 0 && ld_dst >= cols && ld_src >= cols, FCL_ERR_INVALID, "copy2d: bad arguments");
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src, rows, cols);
     return check_hip(hipGetLastError(), "copy2d");
+}
+
+int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream) {
+    FCL_REQUIRE(p, FCL_ERR_INVALID, "u32_add: null pointer");
+    hipLaunchKernelGGL(u32_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);
+    return check_hip(hipGetLastError(), "u32_add");
 }
 
 int fcl_add_vec(const float* a, const float* b, float* out, int n, fcl_stream_t stream) {

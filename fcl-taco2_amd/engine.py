@@ -126,7 +126,7 @@ def encode(plan, prep, bilstm_algo=0):
     return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo)
 
 
-def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_algo=0, return_intermediates=False):
+def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_algo=0, return_intermediates=False, seed_dev=None):
     """One pass of the hot path over a prepared batch.  Returns the packed mel [F, odim] (after postnet) and
     the per-utterance frame counts; with forced durations nothing here touches the host."""
     hp, dev = plan.hp, plan.device
@@ -158,7 +158,7 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
             keep = np.ascontiguousarray(np.asarray(prenet_keep)[: maps.lmax][:, :, maps.order, :])  # to sorted row order
             keep_dev = torch.from_numpy(keep).to(dev)
         before = ops.decoder_loop(plan.decoder, att_c, rm.dur, maps.live_rows, rm.frame_off, maps.n_frames,
-                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed)
+                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed, seed_dev=seed_dev)
         x = before
         n_post = len(plan.postnet)
         for i, cv in enumerate(plan.postnet):
@@ -185,3 +185,31 @@ def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_
         mels.append(after[s : s + n])
         s += n
     return (mels, out[2]) if return_intermediates else mels
+
+
+class GraphRunner(object):
+    """One pass of `run` over a prepared (forced-duration) batch captured as a hipGraph (guide: capture
+    launch-bound inner loops in graphs).  Every buffer of the pass lives in the graph's private pool, so a
+    replay is one host call; the prenet-dropout seed is a device word the graph itself advances, so each
+    replay draws fresh masks.  Several runners on different streams keep several batches in flight."""
+
+    def __init__(self, plan, prep, stream=None, dropout_mode=ops.DROP_RNG, seed=0):
+        if prep.maps is None:
+            raise ValueError("GraphRunner needs forced durations (predicted durations require a host round trip)")
+        self.plan, self.prep = plan, prep
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=plan.device)
+        with torch.cuda.device(plan.device):
+            self.seed_word = torch.zeros(1, dtype=torch.int32, device=plan.device)
+            with torch.cuda.stream(self.stream):  # warm-up outside capture (lazy one-time setup in the library)
+                run(plan, prep, dropout_mode, seed=seed, seed_dev=self.seed_word)
+            self.stream.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                ops.u32_add(self.seed_word, 1)
+                self.mel, self.utt_frames = run(plan, prep, dropout_mode, seed=seed, seed_dev=self.seed_word)
+
+    def replay(self):
+        """Enqueue one pass on this runner's stream; returns the static output tensor [F, odim]."""
+        with torch.cuda.stream(self.stream):
+            self.graph.replay()
+        return self.mel

@@ -128,8 +128,13 @@ def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0):
     return out
 
 
+def u32_add(word_i32, v=1):
+    """*word += v on the current stream (word: 1-element int32 device tensor used as a uint32)."""
+    check(_lib.load().fcl_u32_add(_p(word_i32, torch.int32), v, _stream()))
+
+
 def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher_ys=None, dropout_mode=DROP_NONE,
-                 prenet_keep=None, seed=0, want_taps=False):
+                 prenet_keep=None, seed=0, want_taps=False, seed_dev=None):
     """dw: plan.DecoderPack (holds the ctypes DecoderWeights + the tensors it points to).
     live_rows: host numpy int32 [Lmax].  Returns before [F, odim] (+ taps)."""
     lib = _lib.load()
@@ -145,7 +150,7 @@ def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher
     io = _lib.DecoderIO(
         n=n, lmax=lmax, att_c=_p(att_c), dur=_p(dur_i32, torch.int32), live_rows_host=live_rows.ctypes.data,
         frame_off=_p(frame_off_i32, torch.int32), teacher_ys=_p(teacher_ys), dropout_mode=dropout_mode,
-        prenet_keep=_p(prenet_keep, torch.uint8), seed=seed & 0xFFFFFFFF, before=_p(before),
+        prenet_keep=_p(prenet_keep, torch.uint8), seed=seed & 0xFFFFFFFF, seed_dev=_p(seed_dev, torch.int32), before=_p(before),
         tap_prenet=_p(taps[0]) if taps else None, tap_lstm0=_p(taps[1]) if taps else None, tap_lstm1=_p(taps[2]) if taps else None,
         workspace=ws.data_ptr(), workspace_bytes=nbytes)
     check(lib.fcl_decoder_loop_fwd(C.byref(dw.struct), C.byref(io), _stream()))

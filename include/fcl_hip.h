@@ -49,6 +49,9 @@ int fcl_fold_batchnorm(const float* gamma, const float* beta, const float* mean,
  * their att_c / prenet / position column blocks, decoder_sa.py:357-369,397-398). */
 int fcl_copy2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, fcl_stream_t stream);
 
+/* *p += v on the stream (a graph-capturable way to advance the dropout seed word). */
+int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream);
+
 /* out = a + b (bias_ih + bias_hh). */
 int fcl_add_vec(const float* a, const float* b, float* out, int n, fcl_stream_t stream);
 
@@ -140,6 +143,8 @@ typedef struct {
     int dropout_mode;           /* FCL_DROP_* for the prenet */
     const uint8_t* prenet_keep; /* FCL_DROP_MASK: [Lmax, 2, N, P] keep masks (sorted row order) */
     uint32_t seed;              /* FCL_DROP_RNG */
+    const uint32_t* seed_dev;   /* optional device word added to `seed` at run time (lets a captured hipGraph
+                                   draw fresh dropout masks on every replay; bump it with fcl_u32_add) */
     float* before;              /* [F, odim] frame-major decoder output (pre-postnet), F = sum(dur) */
     float* tap_prenet;          /* optional [F, P]  (KD taps, decoder_sa_kd.py:627-637) */
     float* tap_lstm0;           /* optional [F, U] */
