@@ -105,15 +105,9 @@ def main():
         one_pass(i, 1000 + i)
     barrier()
     dt = time.perf_counter() - t0
-    tot = torch.tensor([dt, float(frames)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        tmax = tot[0:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        fsum = tot[1:2].clone()
-        dist.all_reduce(fsum, op=dist.ReduceOp.SUM)
-        dt, frames_all = float(tmax.item()), float(fsum.item())
-    else:
-        frames_all = float(frames)
+    from fcl_taco2_amd import sharding
+
+    dt, frames_all = sharding.aggregate_throughput(dt, frames, dist, dev)  # MAX time, SUM frames over ranks
     value = frames_all * args.steps / dt
 
     out = {

@@ -49,6 +49,8 @@ class SynthesisPlan(object):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.FclError("fcl-taco2_amd: SynthesisPlan needs a GPU device (no CPU fallback)")
+        if not torch.cuda.is_available():
+            raise _lib.FclError("fcl-taco2_amd: no HIP GPU is available and the product path has no CPU fallback")
         missing = [k for k in param_spec(hp) if k not in state_dict]
         if missing:
             raise KeyError("state_dict is missing reference keys: %s ..." % missing[:4])

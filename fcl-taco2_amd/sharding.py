@@ -1,0 +1,42 @@
+"""Multi-GPU: the synthesis path shards by UTTERANCE with no data-path collective.
+
+One process per GPU; every rank holds a full replica of the weights and synthesises its own utterances
+(decoder rows are independent phonemes, the postnet couples frames only inside one utterance).  The only
+exchanges are the timing/bookkeeping reductions below, which work on any torch.distributed backend
+(RCCL on the GPU box, gloo in the CPU tests)."""
+import numpy as np
+
+
+def shard_utterances(frame_counts, world_size):
+    """Greedy longest-first partition of utterances over ranks, balanced by total output frames (sum of
+    durations).  Returns a list (per rank) of utterance-index lists; deterministic on every rank."""
+    loads = [0] * world_size
+    parts = [[] for _ in range(world_size)]
+    order = sorted(range(len(frame_counts)), key=lambda i: (-int(frame_counts[i]), i))
+    for i in order:
+        r = min(range(world_size), key=lambda j: (loads[j], j))
+        parts[r].append(i)
+        loads[r] += int(frame_counts[i])
+    return [sorted(p) for p in parts]
+
+
+def aggregate_throughput(seconds, frames, dist=None, device="cpu"):
+    """bench.py's reduction: MAX over ranks of the wall time, SUM over ranks of the frames produced."""
+    import torch
+
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(seconds), float(frames)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    f = torch.tensor([float(frames)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(f.item())
+
+
+def gather_frame_counts(local_counts, dist=None):
+    """All ranks learn every rank's per-utterance frame counts (optional final bookkeeping gather)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(map(int, local_counts))]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, list(map(int, local_counts)))
+    return out

@@ -384,3 +384,22 @@ def test_graph_replay_draws_fresh_dropout(ops):
     b = r.replay().clone()
     torch.cuda.synchronize()
     assert torch.isfinite(a).all() and not torch.equal(a, b)  # the device seed word advanced inside the graph
+
+
+def test_model_class_inference_matches_reference_golden(ops, golden):
+    """The reference's own call: model_class(idim, odim, args, com_args, teacher_args); load_state_dict;
+    model.inference(x, args, dur=...) -> (L, odim) — against the reference's output (G2)."""
+    import argparse
+
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa
+
+    g = golden("g2_student_c1")
+    S = dict(embed_dim=256, eunits=256, econv_chans=256, dunits=256, postnet_chans=128, use_residual=False, use_masking=True, dropout_rate=0.0)
+    com = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
+                             distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=True, share_proj=True)
+    m = Tacotron2_sa(80, 80, argparse.Namespace(**S), com, argparse.Namespace(use_residual=False, use_masking=True))
+    m.load_state_dict(torch_state_dict(HP.student_hparams(), HP.teacher_hparams()))
+    m.eval().to(DEV)
+    out = m.inference(torch.from_numpy(g["x"]).to(DEV), None, dur=torch.from_numpy(g["dur"]).to(DEV))
+    assert out.is_cuda and out.shape == g["after"].shape
+    assert max_abs(out.cpu(), g["after"]) < 1e-3

@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the utterance sharding and the bench reductions
+(the data path itself has no collective)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fcl_taco2_amd  # noqa: F401
+from fcl_taco2_amd import sharding, synthetic as SYN
+
+
+def test_shard_utterances_is_a_balanced_partition():
+    xs, ds = SYN.batch_c2(batch=32)
+    frames = [int(d.sum()) for d in ds]
+    for world in (1, 2, 4, 8):
+        parts = sharding.shard_utterances(frames, world)
+        assert sorted(i for p in parts for i in p) == list(range(32))  # exact partition, nothing dropped or duplicated
+        loads = [sum(frames[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(frames)  # greedy LPT bound
+    assert sharding.shard_utterances([5, 5], 4) == [[0], [1], [], []]  # more ranks than utterances: empty shards are legal
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    xs, ds = SYN.batch_c2(batch=8, seed=5)
+    frames = [int(d.sum()) for d in ds]
+    mine = sharding.shard_utterances(frames, world)[rank]
+    local_frames = sum(frames[i] for i in mine)
+    t, f = sharding.aggregate_throughput(1.0 + rank, local_frames, dist)
+    counts = sharding.gather_frame_counts([frames[i] for i in mine], dist)
+    q.put((rank, mine, t, f, counts))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_reduction():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xs, ds = SYN.batch_c2(batch=8, seed=5)
+    total = sum(int(d.sum()) for d in ds)
+    (r0, m0, t0, f0, c0), (r1, m1, t1, f1, c1) = res
+    assert sorted(m0 + m1) == list(range(8)) and not set(m0) & set(m1)
+    assert t0 == t1 == 2.0  # MAX over ranks
+    assert f0 == f1 == float(total)  # SUM over ranks
+    assert c0 == c1 and sum(sum(c) for c in c0) == total
