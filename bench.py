@@ -28,6 +28,31 @@ if ROOT not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= fp32 vector peak)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/*pmc_fetch_size.csv and
+    *pmc_write_size.csv, separate --pmc passes of this same command): 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B,
+    MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes.  None when no profile of that kernel is committed."""
+    import csv
+    import glob
+
+    def norm(n):
+        return n.replace(" ", "").replace("fcl::", "").replace("void", "")
+
+    vals = {}
+    for tag in ("fetch", "write"):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_%s_size.csv" % tag)))
+        if not files:
+            return None, None
+        with open(files[-1]) as f:
+            rows = list(csv.reader(f))
+        for r in rows[2:]:
+            if len(r) >= 3 and norm(r[0]) == norm(kernel):
+                vals[tag] = (float(r[2]), os.path.basename(files[-1]))
+    if len(vals) != 2:
+        return None, None
+    return (2.0 * vals["fetch"][0] + vals["write"][0]) * 1024.0, "%s + %s" % (vals["fetch"][1], vals["write"][1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,9 +167,10 @@ def main():
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic(dom)
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": 1e3 * d["ms"] / d["launches"], "launches_per_step": d["launches"] / 3.0,
             "flops_per_launch": d["flops"] / d["launches"], "share_of_kernel_time": d["ms"] / tot_ms,
             "note": "fp32-in MFMA (exact f32) peak; FLOPs = executed 2*M*N*K of the kernel's launches (no credit for hoisted "
