@@ -15,11 +15,12 @@ def main(path):
             name = r["Counter_Name"]
             agg[k][0] += 1
             agg[k][1] += float(r["Counter_Value"])
-    print("counter,%s" % name)
-    print("kernel,launches,mean_KiB_per_launch,mean_MB_per_launch,mean_MB_x2")
+    w = csv.writer(sys.stdout)
+    w.writerow(["counter", name])
+    w.writerow(["kernel", "launches", "mean_KiB_per_launch", "mean_MB_per_launch", "mean_MB_x2"])
     for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         kib = v / n
-        print("%s,%d,%.1f,%.3f,%.3f" % (k, n, kib, kib * 1024 / 1e6, 2 * kib * 1024 / 1e6))
+        w.writerow([k, n, "%.1f" % kib, "%.3f" % (kib * 1024 / 1e6), "%.3f" % (2 * kib * 1024 / 1e6)])
 
 
 if __name__ == "__main__":
