@@ -24,6 +24,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# one hardware queue per in-flight pass (the HIP default of 4 makes a 4th stream share a queue); must be set
+# before the HIP runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak (= fp32 vector peak)
 
@@ -60,7 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", choices=["student", "teacher"], default="student")
-    ap.add_argument("--streams", type=int, default=3, help="batches in flight per GPU (independent passes on separate HIP streams)")
+    ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (independent passes on separate HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)

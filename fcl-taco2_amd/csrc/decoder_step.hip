@@ -10,47 +10,80 @@
 //   * lstm_small_kernel  : one wave per gate (16 rows x 16 units each), gates exchanged through LDS, the
 //                          LSTMCell + zoneout epilogue one (row, unit) per thread.
 #include "fcl_common.h"
+#include "lstm_epilogue.h"
 
 namespace fcl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-// acc += A_l[16 x K] . W[16 rows x K]^T ; A_l row stride lda_l floats (LDS), wrow = &W[(n0 + r16) * ldw] or null.
-__device__ __forceinline__ f32x4 rowtile_mma(const float* A_l, int lda_l, const float* wrow, int K, int r16, int kq) {
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+// acc[t] = A_l[16 x K] . W_t[16 rows x K]^T for NT column tiles that share the A fragments.
+// A_l: LDS, row stride lda_l floats.  wrow[t] = &W[(n_t + r16) * ldw] — ALWAYS a valid row (callers clamp the row
+// index and discard the surplus columns), so every load is unconditional and stays in flight (guide §5 trap (c)).
+// W fragments are fetched one 64-k chunk ahead of the MFMAs that consume them.
+template <int NT>
+__device__ __forceinline__ void rowtile_mma(const float* A_l, int lda_l, const float* const (&wrow)[NT], int K, int r16, int kq,
+                                            f32x4 (&out)[NT]) {
+    f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc0[t] = acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* ap = A_l + r16 * lda_l + kq * 4;
-    const float* wp = wrow ? wrow + kq * 4 : nullptr;
-    int k = 0;
-    for (; k + 64 <= K; k += 64) {  // 4 W fragments in flight per lane
-        f32x4 b[4], a[4];
+    const float* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wp[t] = wrow[t] + kq * 4;
+    const int nfull = K >> 6;  // whole 64-k chunks
+    f32x4 bn[NT][4];
+    if (nfull > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bn[t][i] = *reinterpret_cast<const f32x4*>(wp[t] + i * 16);
+    }
+    for (int c = 0; c < nfull; ++c) {
+        const int k = c << 6;
+        f32x4 b[NT][4], a[4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) b[t][i] = bn[t][i];
+        if (c + 1 < nfull) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bn[t][i] = *reinterpret_cast<const f32x4*>(wp[t] + k + 64 + i * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + k + i * 16);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's W loads ABOVE this chunk's MFMAs (hipcc sinks them otherwise)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            b[i] = wp ? *reinterpret_cast<const f32x4*>(wp + k + i * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            a[i] = *reinterpret_cast<const f32x4*>(ap + k + i * 16);
-        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0], b[i][0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][1], b[i][1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][2], b[i][2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][3], b[i][3], acc1, 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0], b[t][i][0], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][1], b[t][i][1], acc1[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][2], b[t][i][2], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][3], b[t][i][3], acc1[t], 0, 0, 0);
+            }
         }
     }
-    for (; k < K; k += 16) {
-        const bool in = k + kq * 4 < K;  // K % 4 == 0
-        f32x4 b = {0.f, 0.f, 0.f, 0.f}, a = {0.f, 0.f, 0.f, 0.f};
-        if (in) {
-            if (wp) b = *reinterpret_cast<const f32x4*>(wp + k);
-            a = *reinterpret_cast<const f32x4*>(ap + k);
+    for (int k = nfull << 6; k < K; k += 16) {  // tail: K % 4 == 0, lanes past K contribute zeros
+        const bool in = k + kq * 4 < K;
+        const int kk = in ? k : 0;  // keep the address valid, zero the operand instead of skipping the load
+        f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk);
+        if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(wp[t] + kk);
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bb[0], acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bb[1], acc1[t], 0, 0, 0);
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bb[2], acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bb[3], acc1[t], 0, 0, 0);
         }
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
     }
-    return acc0 + acc1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t] = acc0[t] + acc1[t];
 }
 
 // cooperative load of a [16 x K] row tile (rows m0.., zero beyond M) into LDS with row stride ld_l
@@ -58,9 +91,8 @@ __device__ __forceinline__ void load_rowtile(float* dst, int ld_l, const float* 
     const int per_row = K >> 2;
     for (int i = threadIdx.x; i < 16 * per_row; i += blockDim.x) {
         const int r = i / per_row, c = (i - r * per_row) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m0 + r < M) v = *reinterpret_cast<const f32x4*>(src + (size_t)(m0 + r) * ld + c);
-        *reinterpret_cast<f32x4*>(dst + r * ld_l + c) = v;
+        const int m = min(m0 + r, M - 1);  // clamp (M >= 1): rows past M are computed on a copy and never stored
+        *reinterpret_cast<f32x4*>(dst + r * ld_l + c) = *reinterpret_cast<const f32x4*>(src + (size_t)m * ld + c);
     }
 }
 
@@ -92,16 +124,26 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
         load_rowtile(A1, ldU, a.h1, a.U, a.U, m0, a.M_feat);
         __syncthreads();
         for (int tile = wave; tile * 16 < a.O; tile += nwaves) {
-            const int n = tile * 16 + r16;
-            const f32x4 acc = rowtile_mma(A1, ldU, n < a.O ? a.wf_h + (size_t)n * a.U : nullptr, a.U, r16, kq);
-            const int nc = tile * 16 + col;
+            const float* const wr[1] = {a.wf_h + (size_t)min(tile * 16 + r16, a.O - 1) * a.U};
+            const int nc = tile * 16 + col, ncc = min(nc, a.O - 1);
+            float f0v[4];
+            int fo[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {  // epilogue operands fetched before the MFMA chain (clamped, unconditional)
+                const int mc = min(m0 + rq * 4 + r, a.M_feat - 1);
+                f0v[r] = a.F0[(size_t)mc * a.O + ncc];
+                fo[r] = a.frame_off[mc];
+            }
+            f32x4 accv[1];
+            rowtile_mma<1>(A1, ldU, wr, a.U, r16, kq, accv);
+            const f32x4 acc = accv[0];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rq * 4 + r, m = m0 + row;
                 float v = 0.f;
                 if (m < a.M_feat && nc < a.O) {
-                    v = acc[r] + a.F0[(size_t)m * a.O + nc];
-                    a.before[(size_t)(a.frame_off[m] + a.t_prev) * a.O + nc] = v;
+                    v = acc[r] + f0v[r];
+                    a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
                 }
                 if (nc < a.O) A2[row * ldO + nc] = v;
             }
@@ -116,37 +158,47 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
         __syncthreads();
     }
     // ---- H6 prenet layer 0 ---------------------------------------------------------------------------
-    for (int tile = wave; tile * 16 < a.P; tile += nwaves) {
-        const int n = tile * 16 + r16;
-        const f32x4 acc = rowtile_mma(A2, ldO, n < a.P ? a.w0 + (size_t)n * a.O : nullptr, a.O, r16, kq);
-        const int nc = tile * 16 + col;
-        if (nc < a.P) {
-            const float bn = a.b0[nc];
+    for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
+        const int tile2 = tile + nwaves;
+        const float* const wr[2] = {a.w0 + (size_t)min(tile * 16 + r16, a.P - 1) * a.O, a.w0 + (size_t)min(tile2 * 16 + r16, a.P - 1) * a.O};
+        f32x4 accv[2];
+        rowtile_mma<2>(A2, ldO, wr, a.O, r16, kq, accv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = rq * 4 + r, m = m0 + row;
-                float v = fmaxf(acc[r] + bn, 0.f);
-                if (m < a.M_pre) v = drop_apply(v, a.drop_mode, a.keep0, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed0);
-                A3[row * ldP + nc] = v;
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? tile2 : tile) * 16 + col;
+            if (nc < a.P) {
+                const float bn = a.b0[nc];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rq * 4 + r, m = m0 + row;
+                    float v = fmaxf(accv[tt][r] + bn, 0.f);
+                    if (m < a.M_pre) v = drop_apply(v, a.drop_mode, a.keep0, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed0);
+                    A3[row * ldP + nc] = v;
+                }
             }
         }
     }
     __syncthreads();
     // ---- H6 prenet layer 1 -> global (+ KD tap) --------------------------------------------------------
-    for (int tile = wave; tile * 16 < a.P; tile += nwaves) {
-        const int n = tile * 16 + r16;
-        const f32x4 acc = rowtile_mma(A3, ldP, n < a.P ? a.w1 + (size_t)n * a.P : nullptr, a.P, r16, kq);
-        const int nc = tile * 16 + col;
-        if (nc < a.P) {
-            const float bn = a.b1[nc];
+    for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
+        const int tile2 = tile + nwaves;
+        const float* const wr[2] = {a.w1 + (size_t)min(tile * 16 + r16, a.P - 1) * a.P, a.w1 + (size_t)min(tile2 * 16 + r16, a.P - 1) * a.P};
+        f32x4 accv[2];
+        rowtile_mma<2>(A3, ldP, wr, a.P, r16, kq, accv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + rq * 4 + r;
-                if (m >= a.M_pre) continue;
-                float v = fmaxf(acc[r] + bn, 0.f);
-                v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
-                a.pre_out[(size_t)m * a.P + nc] = v;
-                if (a.tap_prenet) a.tap_prenet[(size_t)(a.frame_off[m] + a.t_cur) * a.P + nc] = v;
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? tile2 : tile) * 16 + col;
+            if (nc < a.P) {
+                const float bn = a.b1[nc];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + rq * 4 + r;
+                    if (m >= a.M_pre) continue;
+                    float v = fmaxf(accv[tt][r] + bn, 0.f);
+                    v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
+                    a.pre_out[(size_t)m * a.P + nc] = v;
+                    if (a.tap_prenet) a.tap_prenet[(size_t)(a.frame_off[m] + a.t_cur) * a.P + nc] = v;
+                }
             }
         }
     }
@@ -170,8 +222,10 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(const LstmStepArgs a) {
             __syncthreads();  // previous chunk fully consumed
             load_rowtile(A_l, kc + 4, T.A + k0, T.lda, kc, m0, a.M);
             __syncthreads();
-            const float* wrow = u < a.U ? T.W + (size_t)(g * a.U + u) * T.ldw + k0 : nullptr;
-            acc += rowtile_mma(A_l, kc + 4, wrow, kc, r16, kq);
+            const float* const wr[1] = {T.W + (size_t)(g * a.U + min(u, a.U - 1)) * T.ldw + k0};
+            f32x4 part[1];
+            rowtile_mma<1>(A_l, kc + 4, wr, kc, r16, kq, part);
+            acc += part[0];
         }
     }
     {
@@ -184,40 +238,156 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(const LstmStepArgs a) {
     const int row = threadIdx.x >> 4, uc = threadIdx.x & 15;
     const int m = m0 + row, uu = u0 + uc;
     if (m >= a.M || uu >= a.U) return;
-    float pre[4];
+    const CellIn ci = cell_prefetch(a, m, uu);
+    const float pre[4] = {g_l[0][row][uc], g_l[1][row][uc], g_l[2][row][uc], g_l[3][row][uc]};
+    cell_finish(a, m, uu, pre, ci);
+}
+
+// ---- weights-stationary LSTM step (U <= 256-class models: the 64 x Kt weight slice of 16 units lives in LDS) ----
+// grid = (U/16 unit slices) x (R row groups) ~ 256 workgroups = one per CU; 4 waves split K in quarters, so a
+// workgroup's work is balanced to the MFMA instead of quantised in 64-row tiles.  Wave q loads ITS K-quarter of the
+// slice into LDS itself and only ever reads that quarter back, so the weight fill needs no workgroup barrier; A
+// fragments stream from L2 straight into registers one row tile ahead; the 4 partial sums meet in LDS.
+constexpr int WRES_KT = 512;
+constexpr int WRES_LD = WRES_KT + 4;  // row stride = 2064 B = 16 (mod 256): conflict-free ds_read_b128 across 16 rows
+
+template <int MODE>
+__global__ __launch_bounds__(256) void lstm_wres_kernel(const LstmStepArgs a, int rows_per_group) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* W_l = smem;                   // [64][WRES_LD]
+    float* red = smem + 64 * WRES_LD;    // [4 waves][4 gates][16 rows][16 units]
+    constexpr int KQ = WRES_KT / 4;      // 128 k per wave
+    constexpr int NJ = KQ / 16;          // 8 float4 A fragments per lane per row tile
+    const int u0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    // which source term this wave's K-quarter lives in (terms are quarter-aligned; checked by the launcher)
+    const int kbase = q * KQ;
+    const int t = kbase < a.term[0].K ? 0 : 1;
+    const GemmTerm T = a.term[t];
+    const int koff = kbase - (t ? a.term[0].K : 0);
+
+    // ---- fill this wave's quarter of the weight slice: 64 rows x 128 k, 16 loads in flight per lane ------
+    {
+        const int c4 = (lane & 31) * 4, rsub = lane >> 5;  // 32 lanes cover 128 k of a row; 2 rows per pass
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pre[q] = g_l[q][row][uc] + (a.bias ? a.bias[q * a.U + uu] : 0.f);
-    if (a.G) {
-        const float* gr = a.G + (size_t)((long long)m * a.g_row_mul + a.g_row_add) * (4 * a.U);
+        for (int half = 0; half < 2; ++half) {
+            f32x4 tmp[16];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pre[q] += gr[q * a.U + uu];
-    }
-    if (a.rank1_w) {
-        const float pos = (float)a.step / (float)a.dur[m];
+            for (int i = 0; i < 16; ++i) {
+                const int r = half * 32 + i * 2 + rsub;
+                const int g = r >> 4, u = u0 + (r & 15);
+                tmp[i] = *reinterpret_cast<const f32x4*>(T.W + (size_t)(g * a.U + u) * T.ldw + koff + c4);  // U % 16 == 0
+            }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pre[q] += pos * a.rank1_w[q * a.U + uu];
+            for (int i = 0; i < 16; ++i) {
+                const int r = half * 32 + i * 2 + rsub;
+                *reinterpret_cast<f32x4*>(W_l + r * WRES_LD + kbase + c4) = tmp[i];
+            }
+        }
     }
-    const size_t off = (size_t)m * a.U + uu;
-    const float h_old = a.h_in[off], c_old = a.c[off];
-    const float ig = sigm_(pre[0]), fg = sigm_(pre[1]), gg = tanhf(pre[2]), og = sigm_(pre[3]);
-    const float c_new = fg * c_old + ig * gg;
-    const float h_new = og * tanhf(c_new);
-    float h_o, c_o;
-    if (a.zone_keep_h) {
-        h_o = a.zone_keep_h[off] ? h_old : h_new;
-        c_o = a.zone_keep_c[off] ? c_old : c_new;
-    } else {
-        h_o = a.zoneout * h_old + (1.0f - a.zoneout) * h_new;
-        c_o = a.zoneout * c_old + (1.0f - a.zoneout) * c_new;
+    const int m_lo = blockIdx.y * rows_per_group;
+    const int m_hi = min(a.M, m_lo + rows_per_group);
+    if (m_lo >= m_hi) return;
+    const float* a_src = T.A + koff + kq * 4;
+
+    f32x4 af[NJ];
+    auto load_a = [&](int m0) {
+        const int m = m0 + r16;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_hi) v = *reinterpret_cast<const f32x4*>(a_src + (size_t)m * T.lda + j * 16);
+            af[j] = v;
+        }
+    };
+    load_a(m_lo);
+    const float* wl = W_l + r16 * WRES_LD + kbase + kq * 4;
+    const int erow = threadIdx.x >> 4, euc = threadIdx.x & 15;  // epilogue role: one (row, unit) per thread
+    for (int m0 = m_lo; m0 < m_hi; m0 += 16) {
+        // epilogue inputs for this tile, fetched before the MFMA block
+        const int em = m0 + erow, eu = u0 + euc;
+        const bool evalid = em < m_hi && eu < a.U;
+        CellIn ci;
+        if (evalid) ci = cell_prefetch<MODE>(a, em, eu);
+        f32x4 cur[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cur[j] = af[j];
+        if (m0 + 16 < m_hi) load_a(m0 + 16);  // next tile's A in flight during this tile's MFMAs
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {   // B fragments are read one k-step ahead of the MFMAs that consume them
+            f32x4 b[2][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) b[0][g] = *reinterpret_cast<const f32x4*>(wl + g * 16 * WRES_LD);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 1 < NJ) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) b[(j + 1) & 1][g] = *reinterpret_cast<const f32x4*>(wl + g * 16 * WRES_LD + (j + 1) * 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j][e], b[j & 1][g][e], acc[g], 0, 0, 0);
+                }
+            }
+        }
+        // partial sums -> LDS: red[q][g][row][col]
+        {
+            const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[((q * 4 + g) * 16 + rq * 4 + r) * 16 + col] = acc[g][r];
+        }
+        __syncthreads();
+        if (evalid) {
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) s += red[((w * 4 + g) * 16 + erow) * 16 + euc];
+                pre[g] = s;
+            }
+            cell_finish(a, em, eu, pre, ci);
+        }
+        __syncthreads();  // red is reused by the next tile
     }
-    bool live = true;
-    if (a.row_len) live = a.step < a.row_len[m];
-    a.h_out[off] = live ? h_o : h_old;
-    a.c[off] = live ? c_o : c_old;
-    if (a.out2) {
-        const long long orow = (a.out2_row_base ? (long long)a.out2_row_base[m] : (long long)m * a.out2_row_mul) + a.out2_row_add;
-        a.out2[(size_t)orow * a.ld2 + a.out2_col_off + uu] = live ? h_o : 0.f;
-    }
+}
+
+static bool wres_applicable(const LstmStepArgs& a) {
+    // latency mode: ~10 % faster for a single pass in flight, but its 156 KB of LDS per workgroup blocks the
+    // co-residency that several passes in flight rely on (bench default), so it is opt-in: FCL_LSTM_WRES=1
+    static const int on = tunable("LSTM_WRES", 0);
+    if (!on || a.nterms != 2) return false;
+    const int k0 = a.term[0].K, k1 = a.term[1].K;
+    return k0 + k1 == WRES_KT && (k0 % (WRES_KT / 4)) == 0 && a.U % 16 == 0 && a.U <= 1024;
+}
+
+int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled) {
+    *handled = false;
+    if (!wres_applicable(a)) return 0;
+    *handled = true;
+    const size_t lds = sizeof(float) * (64 * WRES_LD + 4 * 4 * 256);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wres_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wres_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wres_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                        (void)hipGetLastError(), true);
+    (void)once;
+    const int slices = a.U / 16;
+    int groups = 256 / slices;
+    if (groups < 1) groups = 1;
+    int rpg = ((a.M + groups - 1) / groups + 15) / 16 * 16;  // rows per group, whole 16-row tiles
+    groups = (a.M + rpg - 1) / rpg;
+    ProfScope ps("lstm_wres_kernel", 2.0 * a.M * 4.0 * a.U * WRES_KT, a.M, s);
+    const bool plain = !a.zone_keep_h && !a.row_len;
+    if (plain && a.G && a.rank1_w && !a.bias) hipLaunchKernelGGL(lstm_wres_kernel<0>, dim3(slices, groups), dim3(256), lds, s, a, rpg);
+    else if (plain && a.bias && !a.G && !a.rank1_w) hipLaunchKernelGGL(lstm_wres_kernel<1>, dim3(slices, groups), dim3(256), lds, s, a, rpg);
+    else hipLaunchKernelGGL(lstm_wres_kernel<-1>, dim3(slices, groups), dim3(256), lds, s, a, rpg);
+    return check_hip(hipGetLastError(), "lstm_wres launch");
 }
 
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s) {

@@ -143,8 +143,10 @@ struct FeatPrenetArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
+int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled);
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s);
 int tunable(const char* name, int dflt);  // FCL_<NAME> environment override, read once
+
 
 // counter hash shared by the rng-dropout epilogue (and mirrored nowhere on the host: rng mode is the
 // production mode and is not bit-reproducible against the reference's torch RNG stream by design).

@@ -14,6 +14,7 @@
 // f32-in MFMA is an exact fmaf chain (guide §3), so results differ from the CPU reference only by
 // summation order.
 #include "fcl_common.h"
+#include "lstm_epilogue.h"
 
 namespace fcl {
 
@@ -21,8 +22,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;          // k-chunk (floats): one 128-B line per row
 constexpr int LDS_LD = BK + 4;  // padded LDS row stride (floats); 144 B keeps float4 alignment
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <int WM, int WN, bool LSTM>
 struct Geo {
@@ -212,51 +211,31 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
     const int u = u0 + wn * 16 + (lane & 15);
     const int rq = lane >> 4;
     if (u >= a.U) return;
-    float bg[4], pw[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        bg[g] = a.bias ? a.bias[g * a.U + u] : 0.f;
-        pw[g] = a.rank1_w ? a.rank1_w[g * a.U + u] : 0.f;
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 16 + rq * 4 + r;
         if (m >= a.M) continue;
-        float pre[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = acc[g][r] + bg[g];
-        if (a.G) {
-            const float* gr = a.G + (size_t)((long long)m * a.g_row_mul + a.g_row_add) * (4 * a.U);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] += gr[g * a.U + u];
-        }
-        if (a.rank1_w) {
-            const float pos = (float)a.step / (float)a.dur[m];  // reference: arange(d).float() / d
-#pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] += pos * pw[g];
-        }
-        const size_t off = (size_t)m * a.U + u;
-        const float h_old = a.h_in[off], c_old = a.c[off];
-        const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
-        const float c_new = fg * c_old + ig * gg;
-        const float h_new = og * tanhf(c_new);
-        float h_o, c_o;
-        if (a.zone_keep_h) {  // train-form zoneout: mask=1 keeps the old state
-            h_o = a.zone_keep_h[off] ? h_old : h_new;
-            c_o = a.zone_keep_c[off] ? c_old : c_new;
-        } else {  // eval form (rate 0 => plain cell): rate*old + (1-rate)*new
-            h_o = a.zoneout * h_old + (1.0f - a.zoneout) * h_new;
-            c_o = a.zoneout * c_old + (1.0f - a.zoneout) * c_new;
-        }
-        bool live = true;
-        if (a.row_len) live = a.step < a.row_len[m];
-        a.h_out[off] = live ? h_o : h_old;
-        a.c[off] = live ? c_o : c_old;
-        if (a.out2) {
-            const long long row = (a.out2_row_base ? (long long)a.out2_row_base[m] : (long long)m * a.out2_row_mul) + a.out2_row_add;
-            a.out2[(size_t)row * a.ld2 + a.out2_col_off + u] = live ? h_o : 0.f;
-        }
+        const CellIn ci = cell_prefetch(a, m, u);
+        const float pre[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        cell_finish(a, m, u, pre, ci);
     }
+}
+
+// --------------------------------------------------------------------------------------------------
+template <int WM, int WN>
+static void launch_gemm_cfg(const GemmArgs& a, hipStream_t s, const char* name, double flops) {
+    using G = Geo<WM, WN, false>;
+    dim3 grid((a.N + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
+    ProfScope ps(name, flops, a.M, s);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN>), grid, dim3(G::THREADS), 0, s, a);
+}
+
+template <int WM, int WN>
+static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* name, double flops) {
+    using G = Geo<WM, WN, true>;
+    dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
+    ProfScope ps(name, flops, a.M, s);
+    hipLaunchKernelGGL((lstm_step_kernel<WM, WN>), grid, dim3(G::THREADS), 0, s, a);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -287,17 +266,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     const long long wg64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
     static const int force = tunable("GEMM_CFG", 0);  // experiments only: 1 -> <4,1>, 2 -> <2,2>, 3 -> <1,4>
     if (force == 1 || (force == 0 && (wg64 >= 256 || a.N <= 64))) {
-        ProfScope ps("gemm_kernel<4,1>", flops, a.M, s);
-        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
-        hipLaunchKernelGGL((gemm_kernel<4, 1>), grid, dim3(256), 0, s, a);
+        launch_gemm_cfg<4, 1>(a, s, "gemm_kernel<4,1>", flops);
     } else if (force == 2 || (force == 0 && (a.N <= 128 || (long long)((a.M + 31) / 32) * ((a.N + 127) / 128) >= 256))) {
-        ProfScope ps("gemm_kernel<2,2>", flops, a.M, s);
-        dim3 grid((a.N + 127) / 128, (a.M + 31) / 32);
-        hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, s, a);
+        launch_gemm_cfg<2, 2>(a, s, "gemm_kernel<2,2>", flops);
     } else {
-        ProfScope ps("gemm_kernel<1,4>", flops, a.M, s);
-        dim3 grid((a.N + 255) / 256, (a.M + 15) / 16);
-        hipLaunchKernelGGL((gemm_kernel<1, 4>), grid, dim3(256), 0, s, a);
+        launch_gemm_cfg<1, 4>(a, s, "gemm_kernel<1,4>", flops);
     }
     return check_hip(hipGetLastError(), "gemm launch");
 }
@@ -310,6 +283,11 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     FCL_REQUIRE(a.h_in && a.h_out && a.c && a.h_in != a.h_out, FCL_ERR_INVALID, "lstm_step: h_in/h_out/c must be set and h_out must not alias h_in");
     FCL_REQUIRE(!a.rank1_w || a.dur, FCL_ERR_INVALID, "lstm_step: rank1_w needs dur");
     FCL_REQUIRE((a.zone_keep_h == nullptr) == (a.zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_step: zoneout masks come in pairs");
+    {
+        bool handled = false;
+        rc = launch_lstm_wres(a, s, &handled);
+        if (handled) return rc;
+    }
     static const int small_m = tunable("LSTM_SMALL_M", 1024);
     if (a.M <= small_m) return launch_lstm_small(a, s);
     double ksum = 0;
@@ -317,17 +295,11 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     const double flops = 2.0 * a.M * 4.0 * a.U * ksum;
     const long long wg64 = (long long)((a.M + 63) / 64) * ((a.U + 15) / 16);
     if (wg64 >= 256 || a.U <= 16) {
-        ProfScope ps("lstm_step_kernel<4,1>", flops, a.M, s);
-        dim3 grid((a.U + 15) / 16, (a.M + 63) / 64);
-        hipLaunchKernelGGL((lstm_step_kernel<4, 1>), grid, dim3(256), 0, s, a);
+        launch_lstm_cfg<4, 1>(a, s, "lstm_step_kernel<4,1>", flops);
     } else if (a.U <= 32 || (long long)((a.M + 31) / 32) * ((a.U + 31) / 32) >= 192) {
-        ProfScope ps("lstm_step_kernel<2,2>", flops, a.M, s);
-        dim3 grid((a.U + 31) / 32, (a.M + 31) / 32);
-        hipLaunchKernelGGL((lstm_step_kernel<2, 2>), grid, dim3(256), 0, s, a);
+        launch_lstm_cfg<2, 2>(a, s, "lstm_step_kernel<2,2>", flops);
     } else {
-        ProfScope ps("lstm_step_kernel<1,4>", flops, a.M, s);
-        dim3 grid((a.U + 63) / 64, (a.M + 15) / 16);
-        hipLaunchKernelGGL((lstm_step_kernel<1, 4>), grid, dim3(256), 0, s, a);
+        launch_lstm_cfg<1, 4>(a, s, "lstm_step_kernel<1,4>", flops);
     }
     return check_hip(hipGetLastError(), "lstm_step launch");
 }

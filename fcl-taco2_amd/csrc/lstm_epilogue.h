@@ -1,0 +1,71 @@
+// lstm_epilogue.h — the LSTMCell + zoneout epilogue shared by every LSTM-step kernel.
+// Reference maths: torch.nn.LSTMCell (gate order i,f,g,o) inside ZoneOutCell (decoder_sa.py:63-96).
+#pragma once
+#include "fcl_common.h"
+
+namespace fcl {
+
+// v_exp_f32 / v_rcp_f32 based gates: ~1e-7 absolute error (1-2 ulp each), an order of magnitude below the fp32
+// summation-order noise of the gate pre-activations, and ~10x fewer VALU issues than ocml expf/tanhf in the
+// latency-critical epilogue.
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+
+// everything one (row m, unit u) needs besides the MFMA partial sums, fetched early to hide latency
+struct CellIn {
+    float add[4];  // bias + G + pos*w  per gate
+    float h_old, c_old;
+    bool live;
+};
+
+// MODE -1: every optional input tested at run time; MODE 0: decoder layer 0 (G + position, no bias);
+// MODE 1: decoder layer 1 (bias only).  The fixed modes issue their loads unconditionally, so hipcc keeps
+// them all in flight instead of branching + waiting around each one (guide §5 trap (c)).
+template <int MODE = -1>
+__device__ __forceinline__ CellIn cell_prefetch(const LstmStepArgs& a, int m, int u) {
+    CellIn ci;
+    const bool has_bias = MODE < 0 ? a.bias != nullptr : MODE == 1;
+    const bool has_g = MODE < 0 ? a.G != nullptr : MODE == 0;
+    const bool has_pos = MODE < 0 ? a.rank1_w != nullptr : MODE == 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ci.add[g] = has_bias ? a.bias[g * a.U + u] : 0.f;
+    if (has_g) {
+        const float* gr = a.G + (size_t)((long long)m * a.g_row_mul + a.g_row_add) * (4 * a.U);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ci.add[g] += gr[g * a.U + u];
+    }
+    if (has_pos) {
+        const float pos = (float)a.step / (float)a.dur[m];  // reference: arange(d).float() / d
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ci.add[g] += pos * a.rank1_w[g * a.U + u];
+    }
+    const size_t off = (size_t)m * a.U + u;
+    ci.h_old = a.h_in[off];
+    ci.c_old = a.c[off];
+    ci.live = a.row_len ? (a.step < a.row_len[m]) : true;
+    return ci;
+}
+
+__device__ __forceinline__ void cell_finish(const LstmStepArgs& a, int m, int u, const float (&acc)[4], const CellIn& ci) {
+    const float ig = sigmoid_f(acc[0] + ci.add[0]), fg = sigmoid_f(acc[1] + ci.add[1]);
+    const float gg = tanh_f(acc[2] + ci.add[2]), og = sigmoid_f(acc[3] + ci.add[3]);
+    const float c_new = fg * ci.c_old + ig * gg;
+    const float h_new = og * tanh_f(c_new);
+    const size_t off = (size_t)m * a.U + u;
+    float h_o, c_o;
+    if (a.zone_keep_h) {  // train-form zoneout: mask = 1 keeps the OLD state
+        h_o = a.zone_keep_h[off] ? ci.h_old : h_new;
+        c_o = a.zone_keep_c[off] ? ci.c_old : c_new;
+    } else {  // eval form (rate 0 => plain cell): rate*old + (1-rate)*new
+        h_o = a.zoneout * ci.h_old + (1.0f - a.zoneout) * h_new;
+        c_o = a.zoneout * ci.c_old + (1.0f - a.zoneout) * c_new;
+    }
+    a.h_out[off] = ci.live ? h_o : ci.h_old;
+    a.c[off] = ci.live ? c_o : ci.c_old;
+    if (a.out2) {
+        const long long row = (a.out2_row_base ? (long long)a.out2_row_base[m] : (long long)m * a.out2_row_mul) + a.out2_row_add;
+        a.out2[(size_t)row * a.ld2 + a.out2_col_off + u] = ci.live ? h_o : 0.f;
+    }
+}
+
+}  // namespace fcl
