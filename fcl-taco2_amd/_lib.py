@@ -53,6 +53,7 @@ SIGNATURES = {
     "fcl_bilstm_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P, _Z, _P]),
     "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
     "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
+    "fcl_masked_l1_mse_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
     "fcl_prof_enable": (_I, [_I]),
     "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }

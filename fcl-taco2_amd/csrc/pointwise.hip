@@ -171,6 +171,34 @@ __global__ void position_table_kernel(const int* __restrict__ dur, float* __rest
     }
 }
 
+// ---- H12 masked loss sums ---------------------------------------------------------------------------
+__global__ void masked_l1_mse_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                     const uint8_t* __restrict__ valid, int m, int c, int b_log, float off, double* out) {
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    const long long total = (long long)m * c;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c), j = (int)(i - (long long)r * c);
+        if (valid && !valid[r]) continue;
+        float bv = b[(size_t)r * ldb + j];
+        if (b_log) bv = logf(bv + off);
+        const float d = a[(size_t)r * lda + j] - bv;
+        s1 += fabsf(d);
+        s2 += (double)d * d;
+        cnt += 1.0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + 0, s1);
+        atomicAdd(out + 1, s2);
+        atomicAdd(out + 2, cnt);
+    }
+}
+
 static inline int grid_for(long long total, int block) {
     long long g = (total + block - 1) / block;
     if (g > 2048) g = 2048;
@@ -267,6 +295,15 @@ int fcl_variance_embed_add_fwd(const float* hs, const float* p, const float* e, 
     hipLaunchKernelGGL(variance_embed_add_kernel, dim3(m), dim3(c >= 256 ? 256 : 64), 0, (hipStream_t)stream, hs, p, e, wp, bp, we, be,
                        seg_lo, seg_hi, out, p_emb, e_emb, m, c, k);
     return check_hip(hipGetLastError(), "variance_embed_add_fwd");
+}
+
+int fcl_masked_l1_mse_fwd(const float* a, int lda, const float* b, int ldb, const uint8_t* row_valid, int m, int c, int b_log,
+                          float b_log_offset, double* out, fcl_stream_t stream) {
+    FCL_REQUIRE(a && b && out && m >= 0 && c > 0 && lda >= c && ldb >= c, FCL_ERR_INVALID, "masked_l1_mse_fwd: bad arguments");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(masked_l1_mse_kernel, dim3(grid_for((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
+                       row_valid, m, c, b_log, b_log_offset, out);
+    return check_hip(hipGetLastError(), "masked_l1_mse_fwd");
 }
 
 int fcl_position_table_fwd(const int32_t* dur, float* pos, int n, int lmax, fcl_stream_t stream) {

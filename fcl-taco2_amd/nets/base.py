@@ -266,10 +266,38 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
                                  None if f0s is None else [cpu(f) for f in f0s], None if energies is None else [cpu(e) for e in energies],
                                  dropout_mode=dropout_mode, prenet_keep=prenet_keep, seed=seed)
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "fcl-taco2_amd: the teacher-forced training forward()/backward on the HIP path is a later hot-path row "
-            "(SURVEY.md §8a H12/H13); this build covers synthesis (inference / inference_batch).")
+    def forward(self, xs, ilens, ys, olens, spembs=None, extras=None, new_ys=None, non_zero_lens_mask=None, ds_nonzeros=None,
+                output_masks=None, position=None, f0=None, energy=None, teacher_knowledge=None, *args, **kwargs):
+        """Teacher-forced forward on the HIP path, EVALUATION mode (what the reference's CustomEvaluator runs,
+        tts.py:76-108): returns the scalar loss (kd_teacher: the 5-tuple) and reports the named losses.  Same keyword
+        batch as the reference (tts.py:277-305); `output_masks` / `position` are accepted and recomputed on device
+        (make_non_pad_mask(ds_nonzeros); t/d in-kernel).  Train-mode forward/backward is a later hot-path row."""
+        if self.training:
+            raise NotImplementedError(
+                "fcl-taco2_amd: train-mode forward()/backward is not on the HIP path yet (SURVEY.md §8a H13); call .eval() "
+                "for the evaluation forward.")
+        if spembs is not None:
+            raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
+        from .. import teacher_forced as TF
+
+        batch = dict(xs=xs, ilens=ilens, ys=ys, olens=olens, extras=extras, new_ys=new_ys, non_zero_lens_mask=non_zero_lens_mask,
+                     ds_nonzeros=ds_nonzeros, f0=f0, energy=energy)
+        plan = self.plan(xs.device if xs.is_cuda else None)
+        kw = dict(seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        kw.update({k: kwargs[k] for k in ("dropout_mode", "prenet_keep", "seed") if k in kwargs})
+        with torch.no_grad():
+            if self.role == "kd_teacher":
+                return TF.knowledge_tuple(TF.forward_pass(plan, batch, **kw))
+            if self.role == "student":
+                rep, _ = TF.student_forward(plan, batch, teacher_knowledge, self.share_proj,
+                                            (self.distill_output_knowledge, self.distill_encoder_knowledge,
+                                             self.distill_decoder_knowledge, self.distill_prosody_knowledge), **kw)
+            else:
+                rep, _ = TF.teacher_forward(plan, batch, **kw)
+        order = ["l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss", "encoder_loss",
+                 "decoder_loss", "prosody_loss", "loss"]
+        self.reporter.report([{k: float(rep[k])} for k in order if k in rep])
+        return torch.tensor(float(rep["loss"]), dtype=torch.float32, device=plan.device)
 
     @property
     def base_plot_keys(self):

@@ -128,13 +128,21 @@ def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0):
     return out
 
 
+def masked_l1_mse(a, b, row_valid, out_f64, b_log_offset=None):
+    """Accumulate sum|a-b'|, sum(a-b')^2, count into out_f64[0:3] (device float64, caller-zeroed)."""
+    m, c = a.shape
+    assert b.shape == a.shape and out_f64.dtype == torch.float64 and out_f64.numel() >= 3
+    check(_lib.load().fcl_masked_l1_mse_fwd(_p(a), c, _p(b), c, _p(row_valid, torch.uint8), m, c, int(b_log_offset is not None),
+                                            float(b_log_offset or 0.0), out_f64.data_ptr(), _stream()))
+
+
 def u32_add(word_i32, v=1):
     """*word += v on the current stream (word: 1-element int32 device tensor used as a uint32)."""
     check(_lib.load().fcl_u32_add(_p(word_i32, torch.int32), v, _stream()))
 
 
 def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher_ys=None, dropout_mode=DROP_NONE,
-                 prenet_keep=None, seed=0, want_taps=False, seed_dev=None):
+                 prenet_keep=None, seed=0, want_taps=False, seed_dev=None, zero_init=False):
     """dw: plan.DecoderPack (holds the ctypes DecoderWeights + the tensors it points to).
     live_rows: host numpy int32 [Lmax].  Returns before [F, odim] (+ taps)."""
     lib = _lib.load()
@@ -142,11 +150,13 @@ def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher
     lmax = int(live_rows.shape[0])
     nbytes = lib.fcl_decoder_loop_workspace_bytes(C.byref(dw.struct), n)
     ws = torch.empty(nbytes, device=att_c.device, dtype=torch.uint8)
-    before = torch.empty(n_frames, dw.struct.odim, device=att_c.device, dtype=torch.float32)
+    alloc = torch.zeros if zero_init else torch.empty  # zero_init: frames no (row, t) maps to stay 0 (padded [B, Lmax] layout)
+    before = alloc(n_frames, dw.struct.odim, device=att_c.device, dtype=torch.float32)
     taps = None
     if want_taps:
-        taps = (torch.empty(n_frames, dw.struct.p, device=att_c.device), torch.empty(n_frames, dw.struct.u, device=att_c.device),
-                torch.empty(n_frames, dw.struct.u, device=att_c.device))
+        taps = (alloc(n_frames, dw.struct.p, device=att_c.device, dtype=torch.float32),
+                alloc(n_frames, dw.struct.u, device=att_c.device, dtype=torch.float32),
+                alloc(n_frames, dw.struct.u, device=att_c.device, dtype=torch.float32))
     io = _lib.DecoderIO(
         n=n, lmax=lmax, att_c=_p(att_c), dur=_p(dur_i32, torch.int32), live_rows_host=live_rows.ctypes.data,
         frame_off=_p(frame_off_i32, torch.int32), teacher_ys=_p(teacher_ys), dropout_mode=dropout_mode,

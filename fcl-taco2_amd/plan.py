@@ -72,6 +72,9 @@ class SynthesisPlan(object):
             self.energy_embed_b = g("energy_embed.0.bias")
             self.postnet = [self._conv_bn(g, "dec.postnet.postnet.%d" % i) for i in range(hp.postnet_layers)]
             self.decoder = self._decoder(g)
+            # student KD projections (bias-free Linear student->teacher width), present only in KD-training state_dicts
+            self.proj = {k[: -len(".weight")]: g(k) for k in state_dict
+                         if k.endswith("_proj.weight") or ".convs_proj." in k}
             torch.cuda.synchronize(self.device)
 
     def _conv_bn(self, g, prefix):

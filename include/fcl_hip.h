@@ -156,6 +156,15 @@ typedef struct {
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n);
 int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, fcl_stream_t stream);
 
+/* ---- H12: masked L1 / MSE loss sums (Tacotron2Loss ..._sa.py:26-82, Knowledge_loss ..._kd_student.py:134-179,
+ *      DurationPredictorLoss) ------------------------------------------------------------------------ */
+/* Over the rows with row_valid[m] != 0 (NULL = every row) and all c columns:
+ *   out[0] += sum |a - b'|, out[1] += sum (a - b')^2, out[2] += number of elements,
+ * with b' = b, or log(b + b_log_offset) when b_log != 0 (the duration target).  out: 3 doubles in device memory,
+ * accumulated with atomics (the caller zeroes them); the masked means are out[0]/out[2] and out[1]/out[2]. */
+int fcl_masked_l1_mse_fwd(const float* a, int lda, const float* b, int ldb, const uint8_t* row_valid, int m, int c,
+                          int b_log, float b_log_offset, double* out, fcl_stream_t stream);
+
 /* ---- measurement hook (bench.py's live roofline figures) ------------------------------- */
 /* While enabled, every GEMM / LSTM-step / BiLSTM launch is bracketed by HIP events on the stream it is
  * launched on.  fcl_prof_collect synchronises those events and returns one entry per kernel instantiation:

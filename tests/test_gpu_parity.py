@@ -432,3 +432,83 @@ def test_weights_stationary_lstm_kernel_matches(ops):
         outs.append(np.load(path))
     assert outs[0].shape == outs[1].shape
     assert float(np.abs(outs[0] - outs[1]).max()) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ teacher-forced forward
+def _conv_batch(golden):
+    from fcl_taco2_amd.converter import CustomConverter
+
+    g = golden("g4_integer")
+    raw = ([g["in_xs%d" % i] for i in range(4)], [g["in_ys%d" % i] for i in range(4)], None, [g["in_ds%d" % i] for i in range(4)],
+           [g["in_f0%d" % i] for i in range(4)], [g["in_en%d" % i] for i in range(4)])
+    return CustomConverter(1, True, True)([raw])
+
+
+def test_masked_l1_mse_kernel(ops):
+    rng = np.random.RandomState(0)
+    a, b = rnd(rng, 333, 20), np.abs(rnd(rng, 333, 20))
+    valid = (rng.rand(333) < 0.7).astype(np.uint8)
+    out = torch.zeros(3, dtype=torch.float64, device=DEV)
+    ops.masked_l1_mse(dev(a), dev(b), dev(valid), out, b_log_offset=1.0)
+    d = (a - np.log(b + 1.0))[valid.astype(bool)]
+    ref = np.array([np.abs(d).sum(), (d.astype(np.float64) ** 2).sum(), d.size])
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-5)
+
+
+def test_forward_eval_losses_vs_reference(ops, golden):
+    """H9/H12/H14: eval-mode forward() of teacher, KD teacher and student (share_proj on/off) on the HIP path vs the
+    REAL reference's numbers (G1 forward: losses, and the KD teacher's 5-tuple)."""
+    from fcl_taco2_amd import teacher_forced as TF
+
+    g = golden("g1_forward")
+    b = _conv_batch(golden)
+    plan_t = _plan(TINY_T)
+    rep, r = TF.teacher_forward(plan_t, b, dropout_mode=ops.DROP_NONE)
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"):
+        assert abs(rep[k] - float(g["teacher_" + k])) < 1e-4 * max(1.0, abs(float(g["teacher_" + k]))), k
+    know = TF.knowledge_tuple(r)
+    assert max_abs(know[0].cpu(), g["t_after"]) < 1e-4 and max_abs(know[1].cpu(), g["t_before"]) < 1e-4
+    for grp, items in (("t_enc", know[2]), ("t_dec", know[3]), ("t_pro", know[4])):
+        for i, it in enumerate(items):
+            assert max_abs(it.cpu(), g["%s%d" % (grp, i)]) < 1e-4, (grp, i)
+    ref_know = (torch.from_numpy(g["t_after"]), torch.from_numpy(g["t_before"]), [torch.from_numpy(g["t_enc%d" % i]) for i in range(5)],
+                [torch.from_numpy(g["t_dec%d" % i]) for i in range(8)], [torch.from_numpy(g["t_pro%d" % i]) for i in range(5)])
+    for share in (True, False):
+        tag = "student_%s_" % ("share" if share else "noshare")
+        plan_s = _plan(TINY_S, TINY_T, share)
+        rep, _ = TF.student_forward(plan_s, b, ref_know, share, dropout_mode=ops.DROP_NONE)
+        for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss",
+                  "encoder_loss", "decoder_loss", "prosody_loss"):
+            assert abs(rep[k] - float(g[tag + k])) < 1e-4 * max(1.0, abs(float(g[tag + k]))), (share, k, rep[k], float(g[tag + k]))
+
+
+def test_model_forward_eval_via_plugin_classes(ops, golden):
+    """The reference's KD evaluation call sequence through the plug-in classes: teacher_knowledge = teacher(**x);
+    loss = student(**x, teacher_knowledge) (tts_distill.py:159-161), eval mode."""
+    import argparse
+
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
+
+    def ns(hp):
+        return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits,
+                                  prenet_units=hp.prenet_units, postnet_chans=hp.postnet_chans, use_residual=False, use_masking=True,
+                                  dropout_rate=0.0, duration_predictor_chans=hp.duration_predictor_chans)
+
+    com = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
+                             distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=True, share_proj=True)
+    g = golden("g1_forward")
+    b = _conv_batch(golden)
+    teacher = KDTeacher(TINY_T.idim, TINY_T.odim, ns(TINY_T), com)
+    teacher.load_state_dict(torch_state_dict(TINY_T))
+    student = Student(TINY_S.idim, TINY_S.odim, ns(TINY_S), com, ns(TINY_T))
+    student.load_state_dict(torch_state_dict(TINY_S, TINY_T, True))
+    teacher.eval().to(DEV)
+    student.eval().to(DEV)
+    x = {k: (v.to(DEV) if k in ("xs", "ys", "new_ys", "ilens", "olens") else v) for k, v in b.items()}
+    know = teacher(**x)
+    loss = student(teacher_knowledge=know, **x)
+    assert loss.is_cuda and abs(float(loss) - float(g["student_share_loss"])) < 1e-4 * max(1.0, float(g["student_share_loss"]))
+    assert abs(student.reporter.last["decoder_loss"] - float(g["student_share_decoder_loss"])) < 1e-4
+    with pytest.raises(NotImplementedError):
+        student.train()(teacher_knowledge=know, **x)
