@@ -20,16 +20,22 @@ namespace fcl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;          // k-chunk (floats): one 128-B line per row
-constexpr int LDS_LD = BK + 4;  // padded LDS row stride (floats); 144 B keeps float4 alignment
+#ifndef FCL_BK
+#define FCL_BK 32
+#endif
+constexpr int BK = FCL_BK;      // k-chunk (floats): 32 = one 128-B line per row
+constexpr int F4 = BK / 4;      // float4 per row per chunk
+constexpr int F4_SHIFT = F4 == 8 ? 3 : 2;
+static_assert(BK == 32 || BK == 16, "BK must be 16 or 32");
+constexpr int LDS_LD = BK + 4;  // padded LDS row stride (floats); keeps float4 alignment and spreads rows over banks
 
 template <int WM, int WN, bool LSTM>
 struct Geo {
     static constexpr int BM = 16 * WM;
     static constexpr int BN = 64 * WN;
     static constexpr int THREADS = 64 * WM * WN;
-    static constexpr int NA = (BM * 8 + THREADS - 1) / THREADS;  // float4 loads of A per thread per chunk
-    static constexpr int NB = (BN * 8 + THREADS - 1) / THREADS;
+    static constexpr int NA = (BM * F4 + THREADS - 1) / THREADS;  // float4 loads of A per thread per chunk
+    static constexpr int NB = (BN * F4 + THREADS - 1) / THREADS;
     static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDS_LD;
 };
 
@@ -50,9 +56,9 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
 #pragma unroll
     for (int i = 0; i < G::NA; ++i) {
         const int idx = tid + i * G::THREADS;
-        const int row = idx >> 3;
+        const int row = idx >> F4_SHIFT;
         const int m = m0 + row;
-        a_ok[i] = (idx < G::BM * 8) && (m < M);
+        a_ok[i] = (idx < G::BM * F4) && (m < M);
         a_row[i] = m;
         a_lo[i] = 0;
         a_hi[i] = 0x7fffffff;
@@ -65,9 +71,9 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
 #pragma unroll
     for (int i = 0; i < G::NB; ++i) {
         const int idx = tid + i * G::THREADS;
-        const int row = idx >> 3;  // tile column 0..BN-1
+        const int row = idx >> F4_SHIFT;  // tile column 0..BN-1
         long long wr = -1;
-        if (idx < G::BN * 8) {
+        if (idx < G::BN * F4) {
             if (LSTM) {
                 const int u = n0 + (row >> 6) * 16 + (row & 15);
                 const int g = (row >> 4) & 3;
@@ -79,7 +85,7 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
         }
         b_row[i] = wr;
     }
-    const int c4 = (tid & 7) * 4;  // idx & 7 is the same for every i because THREADS % 8 == 0
+    const int c4 = (tid & (F4 - 1)) * 4;  // idx & (F4-1) is the same for every i because THREADS % F4 == 0
 
     f32x4 ra[G::NA], rb[G::NB];
     auto fetch = [&](int t, int k0) {
@@ -107,12 +113,12 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
 #pragma unroll
         for (int i = 0; i < G::NA; ++i) {
             const int idx = tid + i * G::THREADS;
-            if (idx < G::BM * 8) *reinterpret_cast<f32x4*>(A_l + (idx >> 3) * LDS_LD + c4) = ra[i];
+            if (idx < G::BM * F4) *reinterpret_cast<f32x4*>(A_l + (idx >> F4_SHIFT) * LDS_LD + c4) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < G::NB; ++i) {
             const int idx = tid + i * G::THREADS;
-            if (idx < G::BN * 8) *reinterpret_cast<f32x4*>(B_l + (idx >> 3) * LDS_LD + c4) = rb[i];
+            if (idx < G::BN * F4) *reinterpret_cast<f32x4*>(B_l + (idx >> F4_SHIFT) * LDS_LD + c4) = rb[i];
         }
     };
 
@@ -131,7 +137,7 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
         const float* A_l = lds + buf * (G::BM + G::BN) * LDS_LD;
         const float* B_l = A_l + G::BM * LDS_LD;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BK / 16; ++s) {
             const f32x4 af = *reinterpret_cast<const f32x4*>(A_l + (wm * 16 + r16) * LDS_LD + s * 16 + kq * 4);
             f32x4 bf[4];
 #pragma unroll
@@ -196,28 +202,32 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int MODE>
 __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepArgs a) {
     using G = Geo<WM, WN, true>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
     const int m0 = blockIdx.y * G::BM, u0 = blockIdx.x * (16 * WN);
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, true>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);
     const int rq = lane >> 4;
+    // epilogue operands (G0 / bias / position / old state) are requested BEFORE the K loop so their latency hides
+    // under the MFMAs; rows / units past the edge read a clamped, valid address and are never stored.
+    CellIn ci[4];
+    const int uc = min(u, a.U - 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ci[r] = cell_prefetch<MODE>(a, min(m0 + wm * 16 + rq * 4 + r, a.M - 1), uc);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<WM, WN, true>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
     if (u >= a.U) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 16 + rq * 4 + r;
         if (m >= a.M) continue;
-        const CellIn ci = cell_prefetch(a, m, u);
         const float pre[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        cell_finish(a, m, u, pre, ci);
+        cell_finish(a, m, u, pre, ci[r]);
     }
 }
 
@@ -235,7 +245,10 @@ static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* na
     using G = Geo<WM, WN, true>;
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     ProfScope ps(name, flops, a.M, s);
-    hipLaunchKernelGGL((lstm_step_kernel<WM, WN>), grid, dim3(G::THREADS), 0, s, a);
+    const bool plain = !a.zone_keep_h && !a.row_len;
+    if (plain && a.G && a.rank1_w && !a.bias) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0>), grid, dim3(G::THREADS), 0, s, a);
+    else if (plain && a.bias && !a.G && !a.rank1_w) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1>), grid, dim3(G::THREADS), 0, s, a);
+    else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1>), grid, dim3(G::THREADS), 0, s, a);
 }
 
 // --------------------------------------------------------------------------------------------------
