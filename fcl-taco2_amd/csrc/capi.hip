@@ -33,11 +33,14 @@ int tunable(const char* name, int dflt) {
 
 // ---- profiling records ------------------------------------------------------------------------------
 bool g_prof_on = false;
-struct ProfRec { const char* name; double flops, rows; hipEvent_t a, b; };
+struct ProfRec { char name[56]; double flops, rows; hipEvent_t a, b; };
 static std::vector<ProfRec> g_prof;
 
 void prof_begin(const char* name, double flops, double rows, hipStream_t s) {
-    ProfRec r{name, flops, rows, nullptr, nullptr};
+    ProfRec r{};
+    strncpy(r.name, name, sizeof(r.name) - 1);
+    r.flops = flops;
+    r.rows = rows;
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, s);

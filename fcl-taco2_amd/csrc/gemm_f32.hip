@@ -13,6 +13,8 @@
 // MFMAs of a float4 cover k = {4q+e}; A and W use the same assignment, hence the sum over k is complete.
 // f32-in MFMA is an exact fmaf chain (guide §3), so results differ from the CPU reference only by
 // summation order.
+#include <string.h>
+
 #include "fcl_common.h"
 #include "lstm_epilogue.h"
 
@@ -244,10 +246,13 @@ template <int WM, int WN>
 static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* name, double flops) {
     using G = Geo<WM, WN, true>;
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
-    ProfScope ps(name, flops, a.M, s);
     const bool plain = !a.zone_keep_h && !a.row_len;
-    if (plain && a.G && a.rank1_w && !a.bias) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0>), grid, dim3(G::THREADS), 0, s, a);
-    else if (plain && a.bias && !a.G && !a.rank1_w) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1>), grid, dim3(G::THREADS), 0, s, a);
+    const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
+    static thread_local char full[64];
+    snprintf(full, sizeof(full), "%.*s,%d>", (int)strlen(name) - 1, name, mode);  // "lstm_step_kernel<4,1>" -> "...<4,1,0>"
+    ProfScope ps(full, flops, a.M, s);
+    if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0>), grid, dim3(G::THREADS), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1>), grid, dim3(G::THREADS), 0, s, a);
     else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1>), grid, dim3(G::THREADS), 0, s, a);
 }
 
