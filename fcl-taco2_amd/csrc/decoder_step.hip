@@ -20,9 +20,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // A_l: LDS, row stride lda_l floats.  wrow[t] = &W[(n_t + r16) * ldw] — ALWAYS a valid row (callers clamp the row
 // index and discard the surplus columns), so every load is unconditional and stays in flight (guide §5 trap (c)).
 // W fragments are fetched one 64-k chunk ahead of the MFMAs that consume them.
+// rot: workgroups start the K walk at different 64-k chunks (chunk index rotated by rot) so that the ~150 workgroups
+// of a launch do not all request the same weight lines from the same L2 channels at the same moment.
 template <int NT>
 __device__ __forceinline__ void rowtile_mma(const float* A_l, int lda_l, const float* const (&wrow)[NT], int K, int r16, int kq,
-                                            f32x4 (&out)[NT]) {
+                                            f32x4 (&out)[NT], int rot = 0) {
     f32x4 acc0[NT], acc1[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc0[t] = acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -32,14 +34,16 @@ __device__ __forceinline__ void rowtile_mma(const float* A_l, int lda_l, const f
     for (int t = 0; t < NT; ++t) wp[t] = wrow[t] + kq * 4;
     const int nfull = K >> 6;  // whole 64-k chunks
     f32x4 bn[NT][4];
+    int cc = nfull > 0 ? rot % nfull : 0;
     if (nfull > 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bn[t][i] = *reinterpret_cast<const f32x4*>(wp[t] + i * 16);
+            for (int i = 0; i < 4; ++i) bn[t][i] = *reinterpret_cast<const f32x4*>(wp[t] + (cc << 6) + i * 16);
     }
     for (int c = 0; c < nfull; ++c) {
-        const int k = c << 6;
+        const int k = cc << 6;
+        const int cn = cc + 1 == nfull ? 0 : cc + 1;
         f32x4 b[NT][4], a[4];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -49,8 +53,9 @@ __device__ __forceinline__ void rowtile_mma(const float* A_l, int lda_l, const f
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) bn[t][i] = *reinterpret_cast<const f32x4*>(wp[t] + k + 64 + i * 16);
+                for (int i = 0; i < 4; ++i) bn[t][i] = *reinterpret_cast<const f32x4*>(wp[t] + (cn << 6) + i * 16);
         }
+        cc = cn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(ap + k + i * 16);
         __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's W loads ABOVE this chunk's MFMAs (hipcc sinks them otherwise)
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
                 fo[r] = a.frame_off[mc];
             }
             f32x4 accv[1];
-            rowtile_mma<1>(A1, ldU, wr, a.U, r16, kq, accv);
+            rowtile_mma<1>(A1, ldU, wr, a.U, r16, kq, accv, blockIdx.x);
             const f32x4 acc = accv[0];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
         const int tile2 = tile + nwaves;
         const float* const wr[2] = {a.w0 + (size_t)min(tile * 16 + r16, a.P - 1) * a.O, a.w0 + (size_t)min(tile2 * 16 + r16, a.P - 1) * a.O};
         f32x4 accv[2];
-        rowtile_mma<2>(A2, ldO, wr, a.O, r16, kq, accv);
+        rowtile_mma<2>(A2, ldO, wr, a.O, r16, kq, accv, blockIdx.x);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? tile2 : tile) * 16 + col;
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
         const int tile2 = tile + nwaves;
         const float* const wr[2] = {a.w1 + (size_t)min(tile * 16 + r16, a.P - 1) * a.P, a.w1 + (size_t)min(tile2 * 16 + r16, a.P - 1) * a.P};
         f32x4 accv[2];
-        rowtile_mma<2>(A3, ldP, wr, a.P, r16, kq, accv);
+        rowtile_mma<2>(A3, ldP, wr, a.P, r16, kq, accv, blockIdx.x);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? tile2 : tile) * 16 + col;
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(const LstmStepArgs a) {
             __syncthreads();
             const float* const wr[1] = {T.W + (size_t)(g * a.U + min(u, a.U - 1)) * T.ldw + k0};
             f32x4 part[1];
-            rowtile_mma<1>(A_l, kc + 4, wr, kc, r16, kq, part);
+            rowtile_mma<1>(A_l, kc + 4, wr, kc, r16, kq, part, blockIdx.y);
             acc += part[0];
         }
     }

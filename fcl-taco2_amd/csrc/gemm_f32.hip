@@ -38,11 +38,30 @@ struct Geo {
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int NA = (BM * F4 + THREADS - 1) / THREADS;  // float4 loads of A per thread per chunk
     static constexpr int NB = (BN * F4 + THREADS - 1) / THREADS;
-    static constexpr int LDS_FLOATS = 2 * (BM + BN) * LDS_LD;
+    // per row: fp32 path 36 floats (32 + pad); bf16x3 path two bf16 planes of 40 elements (32 + 8 pad) = 40 floats
+    static constexpr int LDS_FLOATS = 2 * (BM + BN) * 40;
 };
 
+// ---- bf16x3 operand split (PREC 1): x = hi + lo, hi = bf16_rn(x), lo = bf16_rn(x - hi);  a.b ~= ah.bh + ah.bl + al.bh
+// with fp32 accumulation on the bf16 MFMA pipe (16x the fp32-MFMA rate, 3 MFMAs per product => 5.3x), error ~2^-16
+// relative per product: 8.6e-6 max-abs on the mel end to end in emulation, 100x inside the 1e-3 parity bar.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr int LDK = BK + 8;  // bf16 elements per LDS plane row: 80 B stride -> conflict-free b128 fragment reads
+
+__device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
+    const float r0 = v[0] - __builtin_bit_cast(float, h01 << 16), r1 = v[1] - __builtin_bit_cast(float, h01 & 0xFFFF0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, h23 << 16), r3 = v[3] - __builtin_bit_cast(float, h23 & 0xFFFF0000u);
+    hi = make_uint2(h01, h23);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t)));
+}
+
 // Shared main loop.  n0: first output column (generic) or first hidden unit (LSTM).  NU: N (generic) or U.
-template <int WM, int WN, bool LSTM>
+template <int WM, int WN, bool LSTM, int PREC = 0>
 __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0,
                                          int NU, const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
                                          float* lds, f32x4 (&acc)[4]) {
@@ -109,18 +128,45 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
             rb[i] = v;
         }
     };
+    static_assert(PREC == 0 || BK == 32, "the bf16x3 path consumes one 32-k MFMA step per chunk");
+    constexpr int BUF_FLOATS = (G::BM + G::BN) * 40;
     auto stash = [&](int buf) {
-        float* A_l = lds + buf * (G::BM + G::BN) * LDS_LD;
-        float* B_l = A_l + G::BM * LDS_LD;
+        if constexpr (PREC == 0) {
+            float* A_l = lds + buf * BUF_FLOATS;
+            float* B_l = A_l + G::BM * LDS_LD;
 #pragma unroll
-        for (int i = 0; i < G::NA; ++i) {
-            const int idx = tid + i * G::THREADS;
-            if (idx < G::BM * F4) *reinterpret_cast<f32x4*>(A_l + (idx >> F4_SHIFT) * LDS_LD + c4) = ra[i];
-        }
+            for (int i = 0; i < G::NA; ++i) {
+                const int idx = tid + i * G::THREADS;
+                if (idx < G::BM * F4) *reinterpret_cast<f32x4*>(A_l + (idx >> F4_SHIFT) * LDS_LD + c4) = ra[i];
+            }
 #pragma unroll
-        for (int i = 0; i < G::NB; ++i) {
-            const int idx = tid + i * G::THREADS;
-            if (idx < G::BN * F4) *reinterpret_cast<f32x4*>(B_l + (idx >> F4_SHIFT) * LDS_LD + c4) = rb[i];
+            for (int i = 0; i < G::NB; ++i) {
+                const int idx = tid + i * G::THREADS;
+                if (idx < G::BN * F4) *reinterpret_cast<f32x4*>(B_l + (idx >> F4_SHIFT) * LDS_LD + c4) = rb[i];
+            }
+        } else {  // planes: [A hi][A lo][B hi][B lo], rows of LDK bf16
+            unsigned short* P = reinterpret_cast<unsigned short*>(lds + buf * BUF_FLOATS);
+            unsigned short* Ah = P, *Al = P + G::BM * LDK, *Bh = P + 2 * G::BM * LDK, *Bl = Bh + G::BN * LDK;
+#pragma unroll
+            for (int i = 0; i < G::NA; ++i) {
+                const int idx = tid + i * G::THREADS;
+                if (idx < G::BM * F4) {
+                    uint2 hi, lo;
+                    split4(ra[i], hi, lo);
+                    *reinterpret_cast<uint2*>(Ah + (idx >> F4_SHIFT) * LDK + c4) = hi;
+                    *reinterpret_cast<uint2*>(Al + (idx >> F4_SHIFT) * LDK + c4) = lo;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < G::NB; ++i) {
+                const int idx = tid + i * G::THREADS;
+                if (idx < G::BN * F4) {
+                    uint2 hi, lo;
+                    split4(rb[i], hi, lo);
+                    *reinterpret_cast<uint2*>(Bh + (idx >> F4_SHIFT) * LDK + c4) = hi;
+                    *reinterpret_cast<uint2*>(Bl + (idx >> F4_SHIFT) * LDK + c4) = lo;
+                }
+            }
         }
     };
 
@@ -136,21 +182,41 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
         const bool has_next = tn < nterms;
         if (has_next) fetch(tn, kn);
 
-        const float* A_l = lds + buf * (G::BM + G::BN) * LDS_LD;
-        const float* B_l = A_l + G::BM * LDS_LD;
+        if constexpr (PREC == 0) {
+            const float* A_l = lds + buf * BUF_FLOATS;
+            const float* B_l = A_l + G::BM * LDS_LD;
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(A_l + (wm * 16 + r16) * LDS_LD + s * 16 + kq * 4);
-            f32x4 bf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(B_l + (wn * 64 + j * 16 + r16) * LDS_LD + s * 16 + kq * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int s = 0; s < BK / 16; ++s) {
+                const f32x4 af = *reinterpret_cast<const f32x4*>(A_l + (wm * 16 + r16) * LDS_LD + s * 16 + kq * 4);
+                f32x4 bf[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
+                    bf[j] = *reinterpret_cast<const f32x4*>(B_l + (wn * 64 + j * 16 + r16) * LDS_LD + s * 16 + kq * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
+                }
             }
+        } else {  // one v_mfma_f32_16x16x32_bf16 k-step per chunk: lane (r16, kq) feeds 8 consecutive k of row r16
+            const unsigned short* P = reinterpret_cast<const unsigned short*>(lds + buf * BUF_FLOATS);
+            const unsigned short* Ah = P, *Al = P + G::BM * LDK, *Bh = P + 2 * G::BM * LDK, *Bl = Bh + G::BN * LDK;
+            const int ao = (wm * 16 + r16) * LDK + kq * 8;
+            const s16x8 ah = *reinterpret_cast<const s16x8*>(Ah + ao), al = *reinterpret_cast<const s16x8*>(Al + ao);
+            s16x8 bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int bo = (wn * 64 + j * 16 + r16) * LDK + kq * 8;
+                bh[j] = *reinterpret_cast<const s16x8*>(Bh + bo);
+                bl[j] = *reinterpret_cast<const s16x8*>(Bl + bo);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
         }
         if (!has_next) break;
         stash(buf ^ 1);
@@ -162,7 +228,7 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
 }
 
 // --------------------------------------------------------------------------------------------------
-template <int WM, int WN>
+template <int WM, int WN, int PREC>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     using G = Geo<WM, WN, false>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
@@ -170,7 +236,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, false>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, lds, acc);
+    mainloop<WM, WN, false, PREC>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -204,7 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     }
 }
 
-template <int WM, int WN, int MODE>
+template <int WM, int WN, int MODE, int PREC>
 __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepArgs a) {
     using G = Geo<WM, WN, true>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
@@ -222,7 +288,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, true>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
+    mainloop<WM, WN, true, PREC>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
     if (u >= a.U) return;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -234,12 +300,22 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
 }
 
 // --------------------------------------------------------------------------------------------------
+// FCL_PRECISION: 1 (default) = bf16x3 split operands on the bf16 MFMA pipe, fp32 accumulate: ~1e-5 relative error,
+// 1.4x the end-to-end throughput of 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), which stays available for audits.
+static int precision() {
+    static const int p = tunable("PRECISION", 1);
+    return p;
+}
+
 template <int WM, int WN>
 static void launch_gemm_cfg(const GemmArgs& a, hipStream_t s, const char* name, double flops) {
     using G = Geo<WM, WN, false>;
     dim3 grid((a.N + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
-    ProfScope ps(name, flops, a.M, s);
-    hipLaunchKernelGGL((gemm_kernel<WM, WN>), grid, dim3(G::THREADS), 0, s, a);
+    char full[64];
+    snprintf(full, sizeof(full), "%s%s", name, precision() ? "/bf16x3" : "");
+    ProfScope ps(full, flops, a.M, s);
+    if (precision()) hipLaunchKernelGGL((gemm_kernel<WM, WN, 1>), grid, dim3(G::THREADS), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, 0>), grid, dim3(G::THREADS), 0, s, a);
 }
 
 template <int WM, int WN>
@@ -248,12 +324,18 @@ static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* na
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     const bool plain = !a.zone_keep_h && !a.row_len;
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
-    static thread_local char full[64];
-    snprintf(full, sizeof(full), "%.*s,%d>", (int)strlen(name) - 1, name, mode);  // "lstm_step_kernel<4,1>" -> "...<4,1,0>"
+    char full[64];
+    snprintf(full, sizeof(full), "%.*s,%d>%s", (int)strlen(name) - 1, name, mode, precision() ? "/bf16x3" : "");  // "...<4,1>" -> "...<4,1,0>"
     ProfScope ps(full, flops, a.M, s);
-    if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0>), grid, dim3(G::THREADS), 0, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1>), grid, dim3(G::THREADS), 0, s, a);
-    else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1>), grid, dim3(G::THREADS), 0, s, a);
+    if (precision()) {
+        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 1>), grid, dim3(G::THREADS), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 1>), grid, dim3(G::THREADS), 0, s, a);
+        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 1>), grid, dim3(G::THREADS), 0, s, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 0>), grid, dim3(G::THREADS), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 0>), grid, dim3(G::THREADS), 0, s, a);
+        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 0>), grid, dim3(G::THREADS), 0, s, a);
+    }
 }
 
 // --------------------------------------------------------------------------------------------------

