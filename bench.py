@@ -41,8 +41,12 @@ def pmc_traffic(kernel):
 
     def norm(n):
         n = n.replace(" ", "").replace("fcl::", "").replace("void", "")
-        if n.endswith("/bf16x3"):  # bench label -> the template instantiation rocprof reports (last argument PREC = 1)
-            n = n[: -len("/bf16x3")].rstrip(">") + ",1>"
+        x3 = n.endswith("/bf16x3")
+        n = n[: -len("/bf16x3")] if x3 else n
+        if "<" in n and n.count(",") < (3 if n.startswith("lstm_step") else 2):  # bench label -> rocprof's instantiation (+ PREC)
+            n = n.rstrip(">") + (",1>" if x3 else ",0>")
+        elif x3 and "<" not in n:
+            n = n.replace("_kernel", "_x3_kernel")
         return n
 
     vals = {}

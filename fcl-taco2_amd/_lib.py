@@ -20,7 +20,8 @@ class DecoderWeights(C.Structure):
     _fields_ = [("c", _I), ("p", _I), ("u", _I), ("odim", _I)] + [
         (n, _P) for n in ("prenet_w0", "prenet_b0", "prenet_w1", "prenet_b1", "w0_att", "w0_pre", "w0_pos", "w0_hh", "b0",
                           "w1_ih", "w1_hh", "b1", "wf_h", "wf_att")
-    ] + [("zoneout_rate", _F), ("prenet_dropout", _F)]
+    ] + [("zoneout_rate", _F), ("prenet_dropout", _F)] + [
+        (n + sfx, _P) for n in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h") for sfx in ("_hi", "_lo")]
 
 
 class DecoderIO(C.Structure):
@@ -39,6 +40,7 @@ SIGNATURES = {
     "fcl_pack_conv1d_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_fold_batchnorm": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "fcl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "fcl_split_bf16": (_I, [_P, _P, _P, _Z, _P]),
     "fcl_add_vec": (_I, [_P, _P, _P, _I, _P]),
     "fcl_u32_add": (_I, [_P, C.c_uint32, _P]),
     "fcl_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

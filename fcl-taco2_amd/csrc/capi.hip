@@ -236,6 +236,8 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             fp.before = io->before; fp.frame_off = io->frame_off; fp.t_prev = t - 1; fp.t_cur = t;
             fp.teacher_in = teacher_in; fp.teacher_ld = io->lmax * O;
             if (t < io->lmax) { fp.w0 = w->prenet_w0; fp.b0 = w->prenet_b0; fp.w1 = w->prenet_w1; fp.b1 = w->prenet_b1; }
+            fp.wf_hi = w->wf_h_hi; fp.wf_lo = w->wf_h_lo; fp.w0_hi = w->prenet_w0_hi; fp.w0_lo = w->prenet_w0_lo;
+            fp.w1_hi = w->prenet_w1_hi; fp.w1_lo = w->prenet_w1_lo;
             fp.drop_mode = drop_mode; fp.keep0 = keep0; fp.keep1 = keep1; fp.keep_scale = keep_scale; fp.drop_p = w->prenet_dropout;
             fp.seed0 = seed0; fp.seed1 = seed1; fp.seed_dev = io->seed_dev; fp.pre_out = ws.pre_b; fp.tap_prenet = io->tap_prenet;
             rc = launch_feat_prenet(fp, s);
@@ -269,8 +271,8 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
         if (t == io->lmax) break;
         // H7 layer 0: gates = G0 + prenet . W_pre^T + pos * w_pos + h0 . W_hh^T ; cell ; zoneout
         LstmStepArgs l0 = {};
-        l0.term[0] = GemmTerm{ws.pre_b, w->w0_pre, P, P, P, 0};
-        l0.term[1] = GemmTerm{ws.h0[cur], w->w0_hh, U, U, U, 0};
+        l0.term[0] = GemmTerm{ws.pre_b, w->w0_pre, P, P, P, 0, w->w0_pre_hi, w->w0_pre_lo};
+        l0.term[1] = GemmTerm{ws.h0[cur], w->w0_hh, U, U, U, 0, w->w0_hh_hi, w->w0_hh_lo};
         l0.nterms = 2; l0.M = n; l0.U = U; l0.G = ws.G0; l0.g_row_mul = 1; l0.g_row_add = 0;
         l0.rank1_w = w->w0_pos; l0.dur = io->dur; l0.step = t;
         l0.h_in = ws.h0[cur]; l0.h_out = ws.h0[cur ^ 1]; l0.c = ws.c0; l0.zoneout = w->zoneout_rate;
@@ -279,8 +281,8 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
         if (rc) return rc;
         // H7 layer 1
         LstmStepArgs l1 = {};
-        l1.term[0] = GemmTerm{ws.h0[cur ^ 1], w->w1_ih, U, U, U, 0};
-        l1.term[1] = GemmTerm{ws.h1[cur], w->w1_hh, U, U, U, 0};
+        l1.term[0] = GemmTerm{ws.h0[cur ^ 1], w->w1_ih, U, U, U, 0, w->w1_ih_hi, w->w1_ih_lo};
+        l1.term[1] = GemmTerm{ws.h1[cur], w->w1_hh, U, U, U, 0, w->w1_hh_hi, w->w1_hh_lo};
         l1.nterms = 2; l1.M = n; l1.U = U; l1.bias = w->b1; l1.step = t;
         l1.h_in = ws.h1[cur]; l1.h_out = ws.h1[cur ^ 1]; l1.c = ws.c1; l1.zoneout = w->zoneout_rate;
         if (io->tap_lstm1) { l1.out2 = io->tap_lstm1; l1.out2_row_base = io->frame_off; l1.out2_row_add = t; l1.ld2 = U; }

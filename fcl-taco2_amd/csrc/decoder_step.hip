@@ -209,6 +209,229 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
     }
 }
 
+// =====================================================================================================
+// bf16x3 variants of the two small-tile kernels: activations are split (hi/lo bf16 planes) when they enter LDS,
+// weights arrive pre-split (fcl_split_bf16 at plan time) and stream from L2 straight into 16x16x32 bf16 MFMA fragments:
+// 3 MFMAs of 16 cycles per 32-k step instead of 8 fp32 MFMAs of 32 cycles, same fp32 accumulators and epilogues.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ void split1(float x, u16& hi, u16& lo) {
+    const __bf16 h = (__bf16)x;
+    hi = __builtin_bit_cast(u16, h);
+    lo = __builtin_bit_cast(u16, (__bf16)(x - (float)h));
+}
+
+// A planes: Ah/Al [16][ldk] bf16 in LDS.  whi/wlo[t]: plane row pointers of the W rows feeding column tile t (always valid).
+template <int NT>
+__device__ __forceinline__ void rowtile_mma_x3(const u16* Ah, const u16* Al, int ldk, const u16* const (&whi)[NT], const u16* const (&wlo)[NT],
+                                               int K, int r16, int kq, f32x4 (&out)[NT]) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u16* ah = Ah + r16 * ldk + kq * 8;
+    const u16* al = Al + r16 * ldk + kq * 8;
+    const int nsteps = (K + 31) >> 5;  // K % 8 == 0; lanes past K feed a zero A fragment
+    s16x8 bhn[NT], bln[NT];
+    {
+        const int kk = kq * 8 < K ? 0 : -(kq * 8);  // keep the address inside the row
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bhn[t] = *reinterpret_cast<const s16x8*>(whi[t] + kq * 8 + kk);
+            bln[t] = *reinterpret_cast<const s16x8*>(wlo[t] + kq * 8 + kk);
+        }
+    }
+    for (int st = 0; st < nsteps; ++st) {
+        const int k = st << 5;
+        const bool in = k + kq * 8 < K;
+        s16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { bh[t] = bhn[t]; bl[t] = bln[t]; }
+        if (st + 1 < nsteps) {
+            const int kn = (k + 32 + kq * 8 < K) ? k + 32 + kq * 8 : 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bhn[t] = *reinterpret_cast<const s16x8*>(whi[t] + kn);
+                bln[t] = *reinterpret_cast<const s16x8*>(wlo[t] + kn);
+            }
+        }
+        s16x8 a_hi = {0, 0, 0, 0, 0, 0, 0, 0}, a_lo = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (in) {
+            a_hi = *reinterpret_cast<const s16x8*>(ah + k);
+            a_lo = *reinterpret_cast<const s16x8*>(al + k);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // next step's W loads stay above this step's MFMAs
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, bh[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bl[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, bh[t], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t] = acc[t];
+}
+
+// cooperative load of a [16 x K] fp32 row tile, split into the two LDS planes (rows clamped to M-1)
+__device__ __forceinline__ void load_rowtile_split(u16* Ah, u16* Al, int ldk, const float* src, int ld, int K, int m0, int M) {
+    const int per_row = K >> 2;
+    for (int i = threadIdx.x; i < 16 * per_row; i += blockDim.x) {
+        const int r = i / per_row, c = (i - r * per_row) * 4;
+        const int m = min(m0 + r, M - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)m * ld + c);
+        u16 h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split1(v[e], h[e], l[e]);
+        *reinterpret_cast<uint2*>(Ah + r * ldk + c) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2*>(Al + r * ldk + c) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+}
+
+__global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ldU = a.U + 8, ldO = a.O + 8, ldP = a.P + 8;  // bf16 elements per plane row
+    u16* A1h = reinterpret_cast<u16*>(smem);
+    u16* A1l = A1h + 16 * ldU;
+    u16* A2h = A1l + 16 * ldU;
+    u16* A2l = A2h + 16 * ldO;
+    u16* A3h = A2l + 16 * ldO;
+    u16* A3l = A3h + 16 * ldP;
+    const int m0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int col = lane & 15, rq = lane >> 4;
+    const unsigned int sbump = a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u;
+    const unsigned int seed0 = hash_u32(a.seed0 + sbump), seed1 = hash_u32(a.seed1 + sbump);
+
+    if (a.h1) {
+        load_rowtile_split(A1h, A1l, ldU, a.h1, a.U, a.U, m0, a.M_feat);
+        __syncthreads();
+        for (int tile = wave; tile * 16 < a.O; tile += nwaves) {
+            const size_t wr = (size_t)min(tile * 16 + r16, a.O - 1) * a.U;
+            const u16* const wh[1] = {a.wf_hi + wr};
+            const u16* const wl[1] = {a.wf_lo + wr};
+            const int nc = tile * 16 + col, ncc = min(nc, a.O - 1);
+            float f0v[4];
+            int fo[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mc = min(m0 + rq * 4 + r, a.M_feat - 1);
+                f0v[r] = a.F0[(size_t)mc * a.O + ncc];
+                fo[r] = a.frame_off[mc];
+            }
+            f32x4 accv[1];
+            rowtile_mma_x3<1>(A1h, A1l, ldU, wh, wl, a.U, r16, kq, accv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rq * 4 + r, m = m0 + row;
+                float v = 0.f;
+                if (m < a.M_feat && nc < a.O) {
+                    v = accv[0][r] + f0v[r];
+                    a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
+                }
+                if (nc < a.O) split1(v, A2h[row * ldO + nc], A2l[row * ldO + nc]);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < 16 * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }  // prev_out = 0 at t = 0
+    }
+    if (!a.w0 || m0 >= a.M_pre) return;
+    __syncthreads();
+    if (a.teacher_in) {
+        load_rowtile_split(A2h, A2l, ldO, a.teacher_in, a.teacher_ld, a.O, m0, a.M_pre);
+        __syncthreads();
+    }
+    for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
+        const int tile2 = tile + nwaves;
+        const size_t w0r = (size_t)min(tile * 16 + r16, a.P - 1) * a.O, w1r = (size_t)min(tile2 * 16 + r16, a.P - 1) * a.O;
+        const u16* const wh[2] = {a.w0_hi + w0r, a.w0_hi + w1r};
+        const u16* const wl[2] = {a.w0_lo + w0r, a.w0_lo + w1r};
+        f32x4 accv[2];
+        rowtile_mma_x3<2>(A2h, A2l, ldO, wh, wl, a.O, r16, kq, accv);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? tile2 : tile) * 16 + col;
+            if (nc < a.P) {
+                const float bn = a.b0[nc];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rq * 4 + r, m = m0 + row;
+                    float v = fmaxf(accv[tt][r] + bn, 0.f);
+                    if (m < a.M_pre) v = drop_apply(v, a.drop_mode, a.keep0, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed0);
+                    split1(v, A3h[row * ldP + nc], A3l[row * ldP + nc]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
+        const int tile2 = tile + nwaves;
+        const size_t w0r = (size_t)min(tile * 16 + r16, a.P - 1) * a.P, w1r = (size_t)min(tile2 * 16 + r16, a.P - 1) * a.P;
+        const u16* const wh[2] = {a.w1_hi + w0r, a.w1_hi + w1r};
+        const u16* const wl[2] = {a.w1_lo + w0r, a.w1_lo + w1r};
+        f32x4 accv[2];
+        rowtile_mma_x3<2>(A3h, A3l, ldP, wh, wl, a.P, r16, kq, accv);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? tile2 : tile) * 16 + col;
+            if (nc < a.P) {
+                const float bn = a.b1[nc];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + rq * 4 + r;
+                    if (m >= a.M_pre) continue;
+                    float v = fmaxf(accv[tt][r] + bn, 0.f);
+                    v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
+                    a.pre_out[(size_t)m * a.P + nc] = v;
+                    if (a.tap_prenet) a.tap_prenet[(size_t)(a.frame_off[m] + a.t_cur) * a.P + nc] = v;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a) {
+    constexpr int KC = 512;
+    __shared__ __attribute__((aligned(16))) u16 A_h[16 * (KC + 8)];
+    __shared__ __attribute__((aligned(16))) u16 A_lo[16 * (KC + 8)];
+    __shared__ float g_l[4][16][17];
+    const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int u = min(u0 + r16, a.U - 1);
+    // epilogue operands first (latency hides under the K walk)
+    const int erow = threadIdx.x >> 4, euc = threadIdx.x & 15;
+    const int em = m0 + erow, eu = u0 + euc;
+    const bool evalid = em < a.M && eu < a.U;
+    CellIn ci;
+    if (evalid) ci = cell_prefetch(a, em, eu);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < a.nterms; ++t) {
+        const GemmTerm T = a.term[t];
+        for (int k0 = 0; k0 < T.K; k0 += KC) {
+            const int kc = min(KC, T.K - k0);
+            __syncthreads();
+            load_rowtile_split(A_h, A_lo, kc + 8, T.A + k0, T.lda, kc, m0, a.M);
+            __syncthreads();
+            const size_t wr = (size_t)(g * a.U + u) * T.ldw + k0;
+            const u16* const wh[1] = {T.Whi + wr};
+            const u16* const wl[1] = {T.Wlo + wr};
+            f32x4 part[1];
+            rowtile_mma_x3<1>(A_h, A_lo, kc + 8, wh, wl, kc, r16, kq, part);
+            acc += part[0];
+        }
+    }
+    {
+        const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g_l[g][rq * 4 + r][col] = acc[r];
+    }
+    __syncthreads();
+    if (!evalid) return;
+    const float pre[4] = {g_l[0][erow][euc], g_l[1][erow][euc], g_l[2][erow][euc], g_l[3][erow][euc]};
+    cell_finish(a, em, eu, pre, ci);
+}
+
 // ---- small-M LSTM step: wave g owns gate g of 16 units x 16 rows ------------------------------------
 constexpr int SMALL_KC = 512;  // K chunk resident in LDS
 
@@ -398,9 +621,16 @@ int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled) {
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s) {
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
-    ProfScope ps("lstm_small_kernel", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
     dim3 grid((a.U + 15) / 16, (a.M + 15) / 16);
-    hipLaunchKernelGGL(lstm_small_kernel, grid, dim3(256), 0, s, a);
+    bool planes = true;
+    for (int i = 0; i < a.nterms; ++i) planes = planes && a.term[i].Whi && a.term[i].Wlo && (a.term[i].K & 7) == 0 && (a.term[i].ldw & 7) == 0;
+    if (planes) {
+        ProfScope ps("lstm_small_kernel/bf16x3", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
+        hipLaunchKernelGGL(lstm_small_x3_kernel, grid, dim3(256), 0, s, a);
+    } else {
+        ProfScope ps("lstm_small_kernel", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
+        hipLaunchKernelGGL(lstm_small_kernel, grid, dim3(256), 0, s, a);
+    }
     return check_hip(hipGetLastError(), "lstm_small launch");
 }
 
@@ -418,8 +648,20 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
     double fl = 0;
     if (a.h1) fl += 2.0 * a.M_feat * a.O * a.U;
     if (a.w0) fl += 2.0 * a.M_pre * ((double)a.P * a.O + (double)a.P * a.P);
-    ProfScope ps("feat_prenet_kernel", fl, rows, s);
-    hipLaunchKernelGGL(feat_prenet_kernel, dim3((rows + 15) / 16), dim3(512), lds, s, a);
+    const bool planes = a.wf_hi && a.wf_lo && a.w0_hi && a.w0_lo && a.w1_hi && a.w1_lo && !(a.U & 7) && !(a.O & 7) && !(a.P & 7);
+    if (planes) {
+        const size_t lds3 = 2 * sizeof(unsigned short) * 16 * ((size_t)(a.U + 8) + (a.O + 8) + (a.P + 8));
+        static bool attr3 = false;
+        if (!attr3) {
+            FCL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feat_prenet_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr3 = true;
+        }
+        ProfScope ps("feat_prenet_kernel/bf16x3", fl, rows, s);
+        hipLaunchKernelGGL(feat_prenet_x3_kernel, dim3((rows + 15) / 16), dim3(512), lds3, s, a);
+    } else {
+        ProfScope ps("feat_prenet_kernel", fl, rows, s);
+        hipLaunchKernelGGL(feat_prenet_kernel, dim3((rows + 15) / 16), dim3(512), lds, s, a);
+    }
     return check_hip(hipGetLastError(), "feat_prenet launch");
 }
 

@@ -38,6 +38,8 @@ struct GemmTerm {
     int ldw;    // floats between W rows   (multiple of 4)
     int K;      // multiple of 4
     int shift;  // row shift (conv tap offset), 0 for linear terms
+    const unsigned short* Whi;  // optional pre-split bf16x3 planes of W (same layout); used by the small-tile kernels
+    const unsigned short* Wlo;
 };
 
 enum { FCL_MAX_TERMS = 9 };
@@ -131,6 +133,7 @@ struct FeatPrenetArgs {
     const float* teacher_in;  // optional [*, teacher_ld]: prenet input rows (teacher forcing)
     int teacher_ld;
     const float *w0, *b0, *w1, *b1;
+    const unsigned short *wf_hi, *wf_lo, *w0_hi, *w0_lo, *w1_hi, *w1_lo;  // optional bf16x3 planes (all or none)
     int drop_mode;  // FCL_DROP_*
     const uint8_t *keep0, *keep1;  // [*, P] masks of the two layers
     float keep_scale, drop_p;

@@ -38,6 +38,16 @@ __global__ void copy2d_kernel(float* dst, int ld_dst, const float* src, int ld_s
     }
 }
 
+__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = src[i];
+        const __bf16 h = (__bf16)x;
+        const __bf16 l = (__bf16)(x - (float)h);
+        hi[i] = __builtin_bit_cast(unsigned short, h);
+        lo[i] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
 __global__ void u32_add_kernel(unsigned int* p, unsigned int v) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *p += v;
 }
@@ -230,6 +240,12 @@ int fcl_copy2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, i
     FCL_REQUIRE(dst && src && rows > 0 && cols > 0 && ld_dst >= cols && ld_src >= cols, FCL_ERR_INVALID, "copy2d: bad arguments");
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src, rows, cols);
     return check_hip(hipGetLastError(), "copy2d");
+}
+
+int fcl_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, fcl_stream_t stream) {
+    FCL_REQUIRE(src && hi && lo && n > 0, FCL_ERR_INVALID, "split_bf16: bad arguments");
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, src, hi, lo, n);
+    return check_hip(hipGetLastError(), "split_bf16");
 }
 
 int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream) {

@@ -44,6 +44,14 @@ def copy_cols(src, col0, ncols):
     return dst
 
 
+def split_bf16(w):
+    """bf16x3 planes (hi, lo) of a float32 tensor, as int16 tensors of the same shape."""
+    hi = torch.empty(w.shape, device=w.device, dtype=torch.int16)
+    lo = torch.empty(w.shape, device=w.device, dtype=torch.int16)
+    check(_lib.load().fcl_split_bf16(_p(w), _p(hi, torch.int16), _p(lo, torch.int16), w.numel(), _stream()))
+    return hi, lo
+
+
 def add_vec(a, b):
     out = torch.empty_like(a)
     check(_lib.load().fcl_add_vec(_p(a), _p(b), _p(out), a.numel(), _stream()))
