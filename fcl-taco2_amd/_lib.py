@@ -40,7 +40,8 @@ SIGNATURES = {
     "fcl_pack_conv1d_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_fold_batchnorm": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "fcl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
-    "fcl_split_bf16": (_I, [_P, _P, _P, _Z, _P]),
+    "fcl_frag_bf16_elems": (_Z, [_I, _I]),
+    "fcl_pack_frag_bf16": (_I, [_P, _I, _I, _P, _P, _P]),
     "fcl_add_vec": (_I, [_P, _P, _P, _I, _P]),
     "fcl_u32_add": (_I, [_P, C.c_uint32, _P]),
     "fcl_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -222,41 +222,37 @@ __device__ __forceinline__ void split1(float x, u16& hi, u16& lo) {
     lo = __builtin_bit_cast(u16, (__bf16)(x - (float)h));
 }
 
-// A planes: Ah/Al [16][ldk] bf16 in LDS.  whi/wlo[t]: plane row pointers of the W rows feeding column tile t (always valid).
+// A planes: Ah/Al [16][ldk] bf16 in LDS.  fhi/flo[t]: this lane's slot in the first fragment block of column tile t
+// (fragment-major planes, fcl_pack_frag_bf16): step st lives 512 elements further, zero-padded past K.
 template <int NT>
-__device__ __forceinline__ void rowtile_mma_x3(const u16* Ah, const u16* Al, int ldk, const u16* const (&whi)[NT], const u16* const (&wlo)[NT],
+__device__ __forceinline__ void rowtile_mma_x3(const u16* Ah, const u16* Al, int ldk, const u16* const (&fhi)[NT], const u16* const (&flo)[NT],
                                                int K, int r16, int kq, f32x4 (&out)[NT]) {
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const u16* ah = Ah + r16 * ldk + kq * 8;
     const u16* al = Al + r16 * ldk + kq * 8;
-    const int nsteps = (K + 31) >> 5;  // K % 8 == 0; lanes past K feed a zero A fragment
+    const int nsteps = (K + 31) >> 5;
     s16x8 bhn[NT], bln[NT];
-    {
-        const int kk = kq * 8 < K ? 0 : -(kq * 8);  // keep the address inside the row
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            bhn[t] = *reinterpret_cast<const s16x8*>(whi[t] + kq * 8 + kk);
-            bln[t] = *reinterpret_cast<const s16x8*>(wlo[t] + kq * 8 + kk);
-        }
+    for (int t = 0; t < NT; ++t) {
+        bhn[t] = *reinterpret_cast<const s16x8*>(fhi[t]);
+        bln[t] = *reinterpret_cast<const s16x8*>(flo[t]);
     }
     for (int st = 0; st < nsteps; ++st) {
         const int k = st << 5;
-        const bool in = k + kq * 8 < K;
         s16x8 bh[NT], bl[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) { bh[t] = bhn[t]; bl[t] = bln[t]; }
         if (st + 1 < nsteps) {
-            const int kn = (k + 32 + kq * 8 < K) ? k + 32 + kq * 8 : 0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                bhn[t] = *reinterpret_cast<const s16x8*>(whi[t] + kn);
-                bln[t] = *reinterpret_cast<const s16x8*>(wlo[t] + kn);
+                bhn[t] = *reinterpret_cast<const s16x8*>(fhi[t] + (size_t)(st + 1) * 512);
+                bln[t] = *reinterpret_cast<const s16x8*>(flo[t] + (size_t)(st + 1) * 512);
             }
         }
         s16x8 a_hi = {0, 0, 0, 0, 0, 0, 0, 0}, a_lo = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (in) {
+        if (k + kq * 8 < K) {  // K % 8 == 0; the LDS row holds exactly K valid elements
             a_hi = *reinterpret_cast<const s16x8*>(ah + k);
             a_lo = *reinterpret_cast<const s16x8*>(al + k);
         }
@@ -271,6 +267,46 @@ __device__ __forceinline__ void rowtile_mma_x3(const u16* Ah, const u16* Al, int
 #pragma unroll
     for (int t = 0; t < NT; ++t) out[t] = acc[t];
 }
+
+// Register-resident W fragments: the weights do not depend on the activation chain, so a wave can request ALL the
+// fragments it will need (NS 32-k steps x NT column tiles x 2 planes) up front and pay the L2/Infinity-Cache latency
+// once per kernel instead of once per k-step; the MFMAs then issue back to back from registers.
+template <int NT, int NS>
+struct WFrag {
+    s16x8 hi[NT][NS], lo[NT][NS];
+    __device__ __forceinline__ void load(const u16* const (&fhi)[NT], const u16* const (&flo)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {  // every wave-wide load is one contiguous 1 KB fragment block
+                hi[t][st] = *reinterpret_cast<const s16x8*>(fhi[t] + st * 512);
+                lo[t][st] = *reinterpret_cast<const s16x8*>(flo[t] + st * 512);
+            }
+    }
+    __device__ __forceinline__ void mma(const u16* Ah, const u16* Al, int ldk, int K, int r16, int kq, f32x4 (&out)[NT]) const {
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const u16* ah = Ah + r16 * ldk + kq * 8;
+        const u16* al = Al + r16 * ldk + kq * 8;
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            s16x8 a_hi = {0, 0, 0, 0, 0, 0, 0, 0}, a_lo = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (st * 32 + kq * 8 < K) {
+                a_hi = *reinterpret_cast<const s16x8*>(ah + st * 32);
+                a_lo = *reinterpret_cast<const s16x8*>(al + st * 32);
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo, hi[t][st], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, lo[t][st], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi, hi[t][st], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) out[t] = acc[t];
+    }
+};
 
 // cooperative load of a [16 x K] fp32 row tile, split into the two LDS planes (rows clamped to M-1)
 __device__ __forceinline__ void load_rowtile_split(u16* Ah, u16* Al, int ldk, const float* src, int ld, int K, int m0, int M) {
@@ -287,6 +323,8 @@ __device__ __forceinline__ void load_rowtile_split(u16* Ah, u16* Al, int ldk, co
     }
 }
 
+// SU/SO/SP = compile-time 32-k step counts of U/O/P (weights preloaded into registers); 0 = generic streaming loops.
+template <int SU, int SO, int SP>
 __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ldU = a.U + 8, ldO = a.O + 8, ldP = a.P + 8;  // bf16 elements per plane row
@@ -303,13 +341,32 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     const unsigned int sbump = a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u;
     const unsigned int seed0 = hash_u32(a.seed0 + sbump), seed1 = hash_u32(a.seed1 + sbump);
 
+    constexpr bool PRE = SU > 0;
+    // weight fragments for the prenet layers are requested first thing: they are consumed two barriers later
+    WFrag<2, PRE ? SO : 1> f0;
+    WFrag<2, PRE ? SP : 1> f1;
+    const bool has_pre = a.w0 && m0 < a.M_pre;
+    const int ptile = wave, ptile2 = wave + nwaves;  // P/16 <= 2*nwaves is checked by the launcher for the PRE path
+    const int nsU = (a.U + 31) >> 5, nsO = (a.O + 31) >> 5, nsP = (a.P + 31) >> 5, ptmax = ((a.P + 15) >> 4) - 1;
+    const size_t lane8 = (size_t)lane * 8;
+    auto frag = [&](const u16* base, int tile, int ns) { return base + (size_t)tile * ns * 512 + lane8; };
+    if (PRE && has_pre) {
+        const u16* const wh0[2] = {frag(a.w0_hi, ptile, nsO), frag(a.w0_hi, min(ptile2, ptmax), nsO)};
+        const u16* const wl0[2] = {frag(a.w0_lo, ptile, nsO), frag(a.w0_lo, min(ptile2, ptmax), nsO)};
+        f0.load(wh0, wl0);
+    }
     if (a.h1) {
+        WFrag<1, PRE ? SU : 1> ff;
+        if (PRE && wave * 16 < a.O) {
+            const u16* const wh[1] = {frag(a.wf_hi, wave, nsU)};
+            const u16* const wl[1] = {frag(a.wf_lo, wave, nsU)};
+            ff.load(wh, wl);
+        }
         load_rowtile_split(A1h, A1l, ldU, a.h1, a.U, a.U, m0, a.M_feat);
         __syncthreads();
         for (int tile = wave; tile * 16 < a.O; tile += nwaves) {
-            const size_t wr = (size_t)min(tile * 16 + r16, a.O - 1) * a.U;
-            const u16* const wh[1] = {a.wf_hi + wr};
-            const u16* const wl[1] = {a.wf_lo + wr};
+            const u16* const wh[1] = {frag(a.wf_hi, tile, nsU)};
+            const u16* const wl[1] = {frag(a.wf_lo, tile, nsU)};
             const int nc = tile * 16 + col, ncc = min(nc, a.O - 1);
             float f0v[4];
             int fo[4];
@@ -320,7 +377,8 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
                 fo[r] = a.frame_off[mc];
             }
             f32x4 accv[1];
-            rowtile_mma_x3<1>(A1h, A1l, ldU, wh, wl, a.U, r16, kq, accv);
+            if (PRE) ff.mma(A1h, A1l, ldU, a.U, r16, kq, accv);
+            else rowtile_mma_x3<1>(A1h, A1l, ldU, wh, wl, a.U, r16, kq, accv);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rq * 4 + r, m = m0 + row;
@@ -335,7 +393,12 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     } else {
         for (int i = threadIdx.x; i < 16 * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }  // prev_out = 0 at t = 0
     }
-    if (!a.w0 || m0 >= a.M_pre) return;
+    if (!has_pre) return;
+    if (PRE) {  // layer-1 fragments: in flight while layer 0 computes
+        const u16* const wh1[2] = {frag(a.w1_hi, ptile, nsP), frag(a.w1_hi, min(ptile2, ptmax), nsP)};
+        const u16* const wl1[2] = {frag(a.w1_lo, ptile, nsP), frag(a.w1_lo, min(ptile2, ptmax), nsP)};
+        f1.load(wh1, wl1);
+    }
     __syncthreads();
     if (a.teacher_in) {
         load_rowtile_split(A2h, A2l, ldO, a.teacher_in, a.teacher_ld, a.O, m0, a.M_pre);
@@ -343,11 +406,11 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     }
     for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
         const int tile2 = tile + nwaves;
-        const size_t w0r = (size_t)min(tile * 16 + r16, a.P - 1) * a.O, w1r = (size_t)min(tile2 * 16 + r16, a.P - 1) * a.O;
-        const u16* const wh[2] = {a.w0_hi + w0r, a.w0_hi + w1r};
-        const u16* const wl[2] = {a.w0_lo + w0r, a.w0_lo + w1r};
+        const u16* const wh[2] = {frag(a.w0_hi, tile, nsO), frag(a.w0_hi, min(tile2, ptmax), nsO)};
+        const u16* const wl[2] = {frag(a.w0_lo, tile, nsO), frag(a.w0_lo, min(tile2, ptmax), nsO)};
         f32x4 accv[2];
-        rowtile_mma_x3<2>(A2h, A2l, ldO, wh, wl, a.O, r16, kq, accv);
+        if (PRE) f0.mma(A2h, A2l, ldO, a.O, r16, kq, accv);
+        else rowtile_mma_x3<2>(A2h, A2l, ldO, wh, wl, a.O, r16, kq, accv);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? tile2 : tile) * 16 + col;
@@ -366,11 +429,11 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     __syncthreads();
     for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
         const int tile2 = tile + nwaves;
-        const size_t w0r = (size_t)min(tile * 16 + r16, a.P - 1) * a.P, w1r = (size_t)min(tile2 * 16 + r16, a.P - 1) * a.P;
-        const u16* const wh[2] = {a.w1_hi + w0r, a.w1_hi + w1r};
-        const u16* const wl[2] = {a.w1_lo + w0r, a.w1_lo + w1r};
+        const u16* const wh[2] = {frag(a.w1_hi, tile, nsP), frag(a.w1_hi, min(tile2, ptmax), nsP)};
+        const u16* const wl[2] = {frag(a.w1_lo, tile, nsP), frag(a.w1_lo, min(tile2, ptmax), nsP)};
         f32x4 accv[2];
-        rowtile_mma_x3<2>(A3h, A3l, ldP, wh, wl, a.P, r16, kq, accv);
+        if (PRE) f1.mma(A3h, A3l, ldP, a.P, r16, kq, accv);
+        else rowtile_mma_x3<2>(A3h, A3l, ldP, wh, wl, a.P, r16, kq, accv);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? tile2 : tile) * 16 + col;
@@ -390,6 +453,8 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     }
 }
 
+// PRE: both terms have K = 256 (the student's decoder LSTMs) -> all 2 x 8 weight fragments are requested at kernel entry.
+template <bool PRE>
 __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a) {
     constexpr int KC = 512;
     __shared__ __attribute__((aligned(16))) u16 A_h[16 * (KC + 8)];
@@ -406,16 +471,35 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
     CellIn ci;
     if (evalid) ci = cell_prefetch(a, em, eu);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < a.nterms; ++t) {
+    WFrag<1, 8> wf[2];
+    if (PRE) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {  // W rows g*U + u0.. form fragment tile (g*U + u0)/16 (U % 16 == 0); 8 steps per row tile
+            const size_t fo = (size_t)((g * a.U + u0) >> 4) * 8 * 512 + (size_t)lane * 8;
+            const u16* const wh[1] = {a.term[t].Whi + fo};
+            const u16* const wl[1] = {a.term[t].Wlo + fo};
+            wf[t].load(wh, wl);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t) __syncthreads();
+            load_rowtile_split(A_h, A_lo, 256 + 8, a.term[t].A, a.term[t].lda, 256, m0, a.M);
+            __syncthreads();
+            f32x4 part[1];
+            wf[t].mma(A_h, A_lo, 256 + 8, 256, r16, kq, part);
+            acc += part[0];
+        }
+    }
+    for (int t = 0; t < (PRE ? 0 : a.nterms); ++t) {
         const GemmTerm T = a.term[t];
         for (int k0 = 0; k0 < T.K; k0 += KC) {
             const int kc = min(KC, T.K - k0);
             __syncthreads();
             load_rowtile_split(A_h, A_lo, kc + 8, T.A + k0, T.lda, kc, m0, a.M);
             __syncthreads();
-            const size_t wr = (size_t)(g * a.U + u) * T.ldw + k0;
-            const u16* const wh[1] = {T.Whi + wr};
-            const u16* const wl[1] = {T.Wlo + wr};
+            const size_t fo = ((size_t)((g * a.U + u0) >> 4) * ((T.K + 31) >> 5) + (k0 >> 5)) * 512 + (size_t)lane * 8;
+            const u16* const wh[1] = {T.Whi + fo};
+            const u16* const wl[1] = {T.Wlo + fo};
             f32x4 part[1];
             rowtile_mma_x3<1>(A_h, A_lo, kc + 8, wh, wl, kc, r16, kq, part);
             acc += part[0];
@@ -623,10 +707,12 @@ int launch_lstm_small(const LstmStepArgs& a, hipStream_t s) {
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     dim3 grid((a.U + 15) / 16, (a.M + 15) / 16);
     bool planes = true;
-    for (int i = 0; i < a.nterms; ++i) planes = planes && a.term[i].Whi && a.term[i].Wlo && (a.term[i].K & 7) == 0 && (a.term[i].ldw & 7) == 0;
+    for (int i = 0; i < a.nterms; ++i) planes = planes && a.term[i].Whi && a.term[i].Wlo && (a.term[i].K & 7) == 0 && a.term[i].ldw == a.term[i].K;
+    planes = planes && (a.U & 15) == 0;
     if (planes) {
         ProfScope ps("lstm_small_kernel/bf16x3", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
-        hipLaunchKernelGGL(lstm_small_x3_kernel, grid, dim3(256), 0, s, a);
+        if (a.nterms == 2 && a.term[0].K == 256 && a.term[1].K == 256) hipLaunchKernelGGL(lstm_small_x3_kernel<true>, grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(lstm_small_x3_kernel<false>, grid, dim3(256), 0, s, a);
     } else {
         ProfScope ps("lstm_small_kernel", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
         hipLaunchKernelGGL(lstm_small_kernel, grid, dim3(256), 0, s, a);
@@ -653,11 +739,12 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
         const size_t lds3 = 2 * sizeof(unsigned short) * 16 * ((size_t)(a.U + 8) + (a.O + 8) + (a.P + 8));
         static bool attr3 = false;
         if (!attr3) {
-            FCL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feat_prenet_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            FCL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feat_prenet_x3_kernel<0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr3 = true;
         }
         ProfScope ps("feat_prenet_kernel/bf16x3", fl, rows, s);
-        hipLaunchKernelGGL(feat_prenet_x3_kernel, dim3((rows + 15) / 16), dim3(512), lds3, s, a);
+        if (a.U == 256 && a.O == 80 && a.P == 256) hipLaunchKernelGGL((feat_prenet_x3_kernel<8, 3, 8>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
+        else hipLaunchKernelGGL((feat_prenet_x3_kernel<0, 0, 0>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
     } else {
         ProfScope ps("feat_prenet_kernel", fl, rows, s);
         hipLaunchKernelGGL(feat_prenet_kernel, dim3((rows + 15) / 16), dim3(512), lds, s, a);

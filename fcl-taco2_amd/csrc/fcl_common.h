@@ -38,7 +38,7 @@ struct GemmTerm {
     int ldw;    // floats between W rows   (multiple of 4)
     int K;      // multiple of 4
     int shift;  // row shift (conv tap offset), 0 for linear terms
-    const unsigned short* Whi;  // optional pre-split bf16x3 planes of W (same layout); used by the small-tile kernels
+    const unsigned short* Whi;  // optional fragment-major bf16x3 planes of W (fcl_pack_frag_bf16); used by the small-tile kernels
     const unsigned short* Wlo;
 };
 

@@ -38,13 +38,17 @@ __global__ void copy2d_kernel(float* dst, int ld_dst, const float* src, int ld_s
     }
 }
 
-__global__ void split_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, size_t n) {
+__global__ void pack_frag_bf16_kernel(const float* __restrict__ w, int rows, int cols, int nsteps, unsigned short* __restrict__ hi,
+                                      unsigned short* __restrict__ lo, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = src[i];
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const size_t blk = i >> 9;
+        const int step = (int)(blk % nsteps), tile = (int)(blk / nsteps);
+        const int r = tile * 16 + (lane & 15), c = step * 32 + (lane >> 4) * 8 + e;
+        const float x = (r < rows && c < cols) ? w[(size_t)r * cols + c] : 0.f;
         const __bf16 h = (__bf16)x;
-        const __bf16 l = (__bf16)(x - (float)h);
         hi[i] = __builtin_bit_cast(unsigned short, h);
-        lo[i] = __builtin_bit_cast(unsigned short, l);
+        lo[i] = __builtin_bit_cast(unsigned short, (__bf16)(x - (float)h));
     }
 }
 
@@ -242,10 +246,17 @@ int fcl_copy2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, i
     return check_hip(hipGetLastError(), "copy2d");
 }
 
-int fcl_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, fcl_stream_t stream) {
-    FCL_REQUIRE(src && hi && lo && n > 0, FCL_ERR_INVALID, "split_bf16: bad arguments");
-    hipLaunchKernelGGL(split_bf16_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, src, hi, lo, n);
-    return check_hip(hipGetLastError(), "split_bf16");
+size_t fcl_frag_bf16_elems(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)((rows + 15) / 16) * ((cols + 31) / 32) * 512;
+}
+
+int fcl_pack_frag_bf16(const float* w, int rows, int cols, uint16_t* hi, uint16_t* lo, fcl_stream_t stream) {
+    FCL_REQUIRE(w && hi && lo && rows > 0 && cols > 0, FCL_ERR_INVALID, "pack_frag_bf16: bad arguments");
+    const size_t n = fcl_frag_bf16_elems(rows, cols);
+    hipLaunchKernelGGL(pack_frag_bf16_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
+                       (cols + 31) / 32, hi, lo, n);
+    return check_hip(hipGetLastError(), "pack_frag_bf16");
 }
 
 int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream) {

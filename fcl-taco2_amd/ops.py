@@ -44,11 +44,13 @@ def copy_cols(src, col0, ncols):
     return dst
 
 
-def split_bf16(w):
-    """bf16x3 planes (hi, lo) of a float32 tensor, as int16 tensors of the same shape."""
-    hi = torch.empty(w.shape, device=w.device, dtype=torch.int16)
-    lo = torch.empty(w.shape, device=w.device, dtype=torch.int16)
-    check(_lib.load().fcl_split_bf16(_p(w), _p(hi, torch.int16), _p(lo, torch.int16), w.numel(), _stream()))
+def pack_frag_bf16(w):
+    """Fragment-major bf16x3 planes (hi, lo) of a float32 matrix [rows, cols] (see include/fcl_hip.h)."""
+    rows, cols = w.shape
+    n = _lib.load().fcl_frag_bf16_elems(rows, cols)
+    hi = torch.empty(n, device=w.device, dtype=torch.int16)
+    lo = torch.empty(n, device=w.device, dtype=torch.int16)
+    check(_lib.load().fcl_pack_frag_bf16(_p(w), rows, cols, _p(hi, torch.int16), _p(lo, torch.int16), _stream()))
     return hi, lo
 
 

@@ -123,11 +123,11 @@ class SynthesisPlan(object):
         for k, v in t.items():
             setattr(s, k, v.data_ptr())
             d.keep.append(v)
-        # bf16x3 planes for the small-tile decoder kernels (K must be a multiple of 8 for 16-byte bf16 fragments)
+        # fragment-major bf16x3 planes for the small-tile decoder kernels
         import os
-        if os.environ.get("FCL_PRECISION", "1") != "0" and all(x % 8 == 0 for x in (C, P, U, O)):
+        if os.environ.get("FCL_PRECISION", "1") != "0" and U % 16 == 0 and all(x % 8 == 0 for x in (C, P, O)):
             for k in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h"):
-                hi, lo = ops.split_bf16(t[k])
+                hi, lo = ops.pack_frag_bf16(t[k])
                 setattr(s, k + "_hi", hi.data_ptr())
                 setattr(s, k + "_lo", lo.data_ptr())
                 d.keep += [hi, lo]

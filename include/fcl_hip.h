@@ -52,9 +52,13 @@ int fcl_copy2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, i
 /* *p += v on the stream (a graph-capturable way to advance the dropout seed word). */
 int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream);
 
-/* bf16x3 operand planes of a weight matrix: hi = bf16_rn(x), lo = bf16_rn(x - hi) (same [rows, cols] layout, 2 bytes each).
- * Optional plan-time step: the decoder's small-tile kernels stream pre-split weights straight into bf16 MFMA fragments. */
-int fcl_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, size_t n, fcl_stream_t stream);
+/* bf16x3 operand planes of a weight matrix w [rows, cols] in MFMA-FRAGMENT-MAJOR order: hi = bf16_rn(x), lo = bf16_rn(x - hi),
+ * stored as blocks (tile = row/16, step = col/32) of 64 lanes x 8 bf16, lane (r = lane&15, q = lane>>4) holding
+ * w[tile*16 + r][step*32 + q*8 .. +7] (zero past rows/cols): element index ((tile*nsteps + step)*64 + lane)*8, nsteps =
+ * ceil(cols/32).  One wave-wide 16-byte load then reads 1 KB contiguous = exactly one v_mfma_f32_16x16x32_bf16 B operand.
+ * fcl_frag_bf16_elems() gives the plane length in uint16 elements.  Optional plan-time step for the decoder's small tiles. */
+size_t fcl_frag_bf16_elems(int rows, int cols);
+int fcl_pack_frag_bf16(const float* w, int rows, int cols, uint16_t* hi, uint16_t* lo, fcl_stream_t stream);
 
 /* out = a + b (bias_ih + bias_hh). */
 int fcl_add_vec(const float* a, const float* b, float* out, int n, fcl_stream_t stream);
@@ -134,7 +138,7 @@ typedef struct {
     const float* wf_att;    /* [odim, C] feat_out.weight[:, U:] */
     float zoneout_rate;     /* eval-form zoneout (decoder_sa.py:96) */
     float prenet_dropout;   /* always-on prenet dropout rate (decoder_sa.py:156-158) */
-    /* optional bf16x3 planes (fcl_split_bf16) of the matrices above, same shapes; all NULL = exact-fp32 small tiles */
+    /* optional fragment-major bf16x3 planes (fcl_pack_frag_bf16) of the matrices above; all NULL = exact-fp32 small tiles */
     const uint16_t *prenet_w0_hi, *prenet_w0_lo, *prenet_w1_hi, *prenet_w1_lo;
     const uint16_t *w0_pre_hi, *w0_pre_lo, *w0_hh_hi, *w0_hh_lo, *w1_ih_hi, *w1_ih_lo, *w1_hh_hi, *w1_hh_lo;
     const uint16_t *wf_h_hi, *wf_h_lo;
