@@ -10,12 +10,12 @@
 //   algo 1 "steps": one fused LSTM-step GEMM launch (gemm_f32.hip) per time step and direction, rows =
 //          utterances, packed-sequence semantics via row_len.  Any H; also the cross-check of algo 2.
 #include "fcl_common.h"
+#include "lstm_epilogue.h"
 
 namespace fcl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <int H>
 __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
         g_s[j] = gcur + ((a0 + a1) + (a2 + a3));
         __syncthreads();
         if (j < H) {
-            const float ig = sigm(g_s[j]), fg = sigm(g_s[H + j]), gg = tanhf(g_s[2 * H + j]), og = sigm(g_s[3 * H + j]);
+            const float ig = sigmoid_f(g_s[j]), fg = sigmoid_f(g_s[H + j]), gg = tanh_f(g_s[2 * H + j]), og = sigmoid_f(g_s[3 * H + j]);
             c = fg * c + ig * gg;
-            const float h = og * tanhf(c);
+            const float h = og * tanh_f(c);
             h_s[j] = h;
             out[((size_t)b * T + t) * (2 * H) + dir * H + j] = h;
         }

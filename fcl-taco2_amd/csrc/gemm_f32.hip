@@ -362,12 +362,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * (double)a.N * ksum;
-    // 64x64 tiles while they fill the chip (>= 256 workgroups), else 32x128 / 16x256 to get more row tiles.
-    const long long wg64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+    // 64x64 tiles measured best for every GEMM of the path (the 32x128 / 16x256 variants only win for a single 16/32-row tile)
     static const int force = tunable("GEMM_CFG", 0);  // experiments only: 1 -> <4,1>, 2 -> <2,2>, 3 -> <1,4>
-    if (force == 1 || (force == 0 && (wg64 >= 256 || a.N <= 64))) {
+    if (force == 1 || (force == 0 && a.M > 32)) {
         launch_gemm_cfg<4, 1>(a, s, "gemm_kernel<4,1>", flops);
-    } else if (force == 2 || (force == 0 && (a.N <= 128 || (long long)((a.M + 31) / 32) * ((a.N + 127) / 128) >= 256))) {
+    } else if (force == 2 || (force == 0 && a.M > 16)) {
         launch_gemm_cfg<2, 2>(a, s, "gemm_kernel<2,2>", flops);
     } else {
         launch_gemm_cfg<1, 4>(a, s, "gemm_kernel<1,4>", flops);
