@@ -1,0 +1,43 @@
+"""N1/N3 host glue: Kaldi ark/scp round trip and model.json / checkpoint parsing (CPU)."""
+import json
+
+import numpy as np
+import torch
+
+import fcl_taco2_amd  # noqa: F401
+from fcl_taco2_amd import decode as D
+from fcl_taco2_amd.kaldi_io import ArkScpWriter, read_scp
+
+
+def test_ark_scp_roundtrip(tmp_path):
+    rng = np.random.RandomState(0)
+    mats = {"LJ001-0001": rng.randn(7, 80).astype(np.float32), "utt_b": rng.randn(1, 80).astype(np.float32), "c": np.zeros((0, 80), np.float32)}
+    with ArkScpWriter(str(tmp_path / "feats")) as w:
+        for k, m in mats.items():
+            w[k] = m
+    back = read_scp(str(tmp_path / "feats.scp"))
+    assert list(back) == list(mats)
+    for k in mats:
+        assert back[k].shape == mats[k].shape and np.array_equal(back[k], mats[k])
+    raw = open(tmp_path / "feats.ark", "rb").read()
+    assert raw.startswith(b"LJ001-0001 \0BFM \x04\x07\x00\x00\x00\x04\x50\x00\x00\x00")  # Kaldi binary FloatMatrix header
+
+
+def test_model_conf_manifest_and_checkpoint_formats(tmp_path):
+    conf = tmp_path / "model.json"
+    args = dict(model_module="nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student:Tacotron2_sa", embed_dim=256, eunits=256,
+                share_proj=True)
+    conf.write_text(json.dumps([80, 80, args]))
+    idim, odim, ns = D.get_model_conf(str(conf))
+    assert (idim, odim, ns.embed_dim) == (80, 80, 256)
+    cls = D.dynamic_import(ns.model_module)  # reference class path -> this package's class
+    assert cls.__module__.startswith("fcl_taco2_amd.nets.knowledge_distillation") and cls.role == "student"
+    sd = {"enc.embed.weight": torch.zeros(2, 2)}
+    for name, obj in (("snapshot.ep.1", {"model": sd, "optimizer": {}}), ("amp_checkpoint_10.pt", {"model": sd, "optimizer": {}, "amp": {}}),
+                      ("model.loss.best", sd), ("dp.pt", {"module.enc.embed.weight": torch.zeros(2, 2)})):
+        torch.save(obj, tmp_path / name)
+        assert list(D.load_state_dict(str(tmp_path / name))) == ["enc.embed.weight"]
+    man = tmp_path / "data.json"
+    man.write_text(json.dumps({"utts": {"a": {"output": [{"tokenid": "3 4 5"}]}, "b": {"output": [{"tokenid": "7"}]}}}))
+    utts = D.read_manifest(str(man))
+    assert utts[0][0] == "a" and utts[0][1].tolist() == [3, 4, 5] and utts[1][1].tolist() == [7]

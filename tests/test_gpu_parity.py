@@ -524,3 +524,39 @@ def test_model_forward_eval_via_plugin_classes(ops, golden):
     assert abs(student.reporter.last["decoder_loss"] - float(g["student_share_decoder_loss"])) < tol(1e-4, 5e-4)
     with pytest.raises(NotImplementedError):
         student.train()(teacher_knowledge=know, **x)
+
+
+def test_decode_driver_end_to_end(ops, golden, tmp_path):
+    """N1/N3: model.json + ESPnet-style snapshot + data json -> ark/scp; the mel written for the G2 utterance equals the
+    reference's output (forced durations are not part of the decode CLI, so this runs the predicted-duration path on a
+    checkpoint whose duration predictor is rigged to a constant: linear.weight = 0, bias = log(3+1) -> 3 frames/phoneme)."""
+    import json
+
+    from fcl_taco2_amd import decode as D
+    from fcl_taco2_amd.kaldi_io import read_scp
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    sd = torch_state_dict(hp, HP.teacher_hparams(), True)
+    sd["duration_predictor.linear.weight"] = torch.zeros_like(sd["duration_predictor.linear.weight"])
+    sd["duration_predictor.linear.bias"] = torch.full((1,), float(np.log(4.0)))
+    torch.save({"model": sd, "optimizer": {}}, tmp_path / "snapshot.ep.1")
+    args = dict(model_module="nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student:Tacotron2_sa", embed_dim=256, eunits=256,
+                econv_chans=256, dunits=256, postnet_chans=128, use_residual=False, use_masking=True, dropout_rate=0.0, share_proj=True)
+    (tmp_path / "model.json").write_text(json.dumps([80, 80, args]))
+    (tmp_path / "teacher.json").write_text(json.dumps([80, 80, dict(use_residual=False)]))
+    g = golden("g2_student_c1")
+    rng = np.random.RandomState(3)
+    utts = {"u%02d" % i: {"output": [{"tokenid": " ".join(map(str, rng.randint(1, 80, size=rng.randint(5, 40))))}]} for i in range(5)}
+    utts["g2"] = {"output": [{"tokenid": " ".join(map(str, g["x"].tolist()))}]}
+    (tmp_path / "data.json").write_text(json.dumps({"utts": utts}))
+    frames, secs = D.main(["--model", str(tmp_path / "snapshot.ep.1"), "--model-conf", str(tmp_path / "model.json"), "--teacher-config",
+                           str(tmp_path / "teacher.json"), "--json", str(tmp_path / "data.json"), "--out", str(tmp_path / "feats"),
+                           "--batch-size", "4", "--verbose", "0"])
+    mels = read_scp(str(tmp_path / "feats.scp"))
+    assert sorted(mels) == sorted(utts) and frames == sum(m.shape[0] for m in mels.values())
+    for k, v in utts.items():
+        assert mels[k].shape == (3 * len(v["output"][0]["tokenid"].split()), 80)
+    # oracle for the rigged checkpoint on the G2 phoneme sequence (predicted durations = 3 everywhere)
+    with torch.no_grad():
+        ref = O.inference(sd, hp, torch.from_numpy(g["x"]))["after"]
+    assert max_abs(mels["g2"], ref) < 1e-3
