@@ -57,6 +57,16 @@ SIGNATURES = {
     "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
     "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
     "fcl_masked_l1_mse_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
+    "fcl_gemm_tn_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    "fcl_colsum_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fcl_act_bwd": (_I, [_P, _P, _P, _F, _P, _Z, _I, _P]),
+    "fcl_l1_mse_grad": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _F, C.c_double, _P, _I, _P]),
+    "fcl_layernorm_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
+    "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
+    "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),
+    "fcl_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _I, _P]),
     "fcl_prof_enable": (_I, [_I]),
     "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }

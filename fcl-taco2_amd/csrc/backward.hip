@@ -1,0 +1,403 @@
+// backward.hip — gradient primitives of the teacher-forced training step, gfx950.
+//
+// dX of every Linear / Conv1d reuses the forward multi-term GEMM (gemm_f32.hip) on transposed weights; what is new here:
+//   * gemm_tn_kernel   : dW[n, k] += sum_m dY[m, n] * X[row(m) + shift, k]  (contraction over ROWS, optional conv tap shift with
+//                        segment-bounded zero fill) — split over M across workgroups, fp32 atomics into the gradient buffer;
+//   * colsum           : bias / beta gradients and BatchNorm-fold parameter gradients (column reductions over rows);
+//   * act_bwd          : dz = dy * act'(y) (* dropout keep * scale);
+//   * l1_mse_grad      : gradient of the masked-mean L1 + MSE losses;
+//   * layernorm_bwd    : channel LayerNorm backward (+ the predictor's scalar head);
+//   * lstm_cell_bwd    : LSTMCell + zoneout backward for one step (gate pre-activation gradients);
+//   * scatter-add      : embedding gradient;  adam / sumsq: the optimizer.
+// Exact fp32 everywhere (gradients are accumulated over up to 25 k rows; the split-bf16 trick is not used here).
+#include "fcl_common.h"
+
+namespace fcl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C[n, k] += sum_{m in slice} A[m, n] * B[m + shift, k].  Tile 64(n) x 64(k) per workgroup, M walked in 32-row chunks;
+// both operands are staged TRANSPOSED into LDS ([col][m], m contiguous) so MFMA fragments are float4 reads along m.
+constexpr int TN_BM = 32;
+constexpr int TN_LD = TN_BM + 4;
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                      float* __restrict__ C, int ldc, int M, int N, int K, int shift,
+                                                      const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int rows_per_slice) {
+    __shared__ __attribute__((aligned(16))) float At[64 * TN_LD];  // [n][m]
+    __shared__ __attribute__((aligned(16))) float Bt[64 * TN_LD];  // [k][m]
+    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int m_lo = blockIdx.z * rows_per_slice, m_hi = min(M, m_lo + rows_per_slice);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    // wave w owns C rows (n) [w*16, w*16+16) x all 64 k columns: acc[j] = 16x16 tile j
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // loader: chunk = 32 rows x 64 cols per operand = 512 float4; thread handles float4 #tid and #tid+256
+    for (int mc = m_lo; mc < m_hi; mc += TN_BM) {
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int idx = tid + h * 256;
+            const int mr = idx >> 4, c4 = (idx & 15) * 4;  // row within chunk, first of 4 columns
+            const int m = mc + mr;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_hi) {
+                if (n0 + c4 < N) va = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + n0 + c4);  // N % 4 == 0
+                const int src = m + shift;
+                bool ok = k0 + c4 < K;
+                if (seg_lo) ok = ok && src >= seg_lo[m] && src < seg_hi[m];
+                else ok = ok && src >= 0 && src < M;
+                if (ok) vb = *reinterpret_cast<const f32x4*>(B + (size_t)src * ldb + k0 + c4);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                At[(c4 + e) * TN_LD + mr] = va[e];
+                Bt[(c4 + e) * TN_LD + mr] = vb[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TN_BM / 16; ++s) {
+            const f32x4 af = *reinterpret_cast<const f32x4*>(At + (wave * 16 + r16) * TN_LD + s * 16 + kq * 4);
+            f32x4 bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bt + (j * 16 + r16) * TN_LD + s * 16 + kq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
+        }
+    }
+    const int col = lane & 15, rq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j * 16 + col;
+        if (k >= K) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wave * 16 + rq * 4 + r;
+            if (n < N) atomicAdd(C + (size_t)n * ldc + k, acc[j][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out[c] += sum_m f(x[m, c]) ; mode 0: x ; 1: x * y[m, c] ; 2: x * (y[m,c] - b[c]) / g[c]   (BN-fold gamma gradient, xhat = (z - beta)/gamma)
+__global__ void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ b,
+                              float* __restrict__ out, int M, int C, int mode, int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
+    float s = 0.f;
+    for (int m = m_lo; m < m_hi; ++m) {
+        float v = x[(size_t)m * C + c];
+        if (mode == 1) v *= y[(size_t)m * C + c];
+        else if (mode == 2) v *= (y[(size_t)m * C + c] - b[c]) / g[c];
+        s += v;
+    }
+    atomicAdd(out + c, s);
+}
+
+// dz = dy * act'(y) * (keep ? keep*scale : 1)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const uint8_t* __restrict__ keep, float scale,
+                               float* __restrict__ dz, long long n, int act) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float g = dy[i];
+        if (keep) g = keep[i] ? g * scale : 0.f;
+        const float v = y[i];  // for dropout sites y is the PRE-dropout activation
+        if (act == FCL_ACT_RELU) g = v > 0.f ? g : 0.f;
+        else if (act == FCL_ACT_TANH) g *= 1.0f - v * v;
+        dz[i] = g;
+    }
+}
+
+// grad of  w1 * mean_valid|a - b'| + w2 * mean_valid (a - b')^2  w.r.t. a:   (w1*sign(d) + 2*w2*d) / count   on valid rows (+= when accumulate)
+__global__ void l1_mse_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ valid, int M, int C,
+                                   int b_log, float off, float w1, float w2, float inv_count, float* __restrict__ da, int accumulate) {
+    const long long total = (long long)M * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C);
+        float g = 0.f;
+        if (!valid || valid[r]) {
+            float bv = b[i];
+            if (b_log) bv = logf(bv + off);
+            const float d = a[i] - bv;
+            g = (w1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * w2 * d) * inv_count;
+        }
+        da[i] = accumulate ? da[i] + g : g;
+    }
+}
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LayerNorm backward, one wave per row.  Forward: xh = (x - mean) * rstd ; y = xh*gamma + beta ; (optional head) s = y.w + b0, masked.
+// Inputs: x (pre-LN), dy (grad of y, may be null when only the head contributes), ds (grad of the scalar head, may be null).
+template <int MAXPER>
+__global__ void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                     const float* __restrict__ dy, const float* __restrict__ lin_w, const float* __restrict__ ds,
+                                     const uint8_t* __restrict__ pad_mask, float* __restrict__ dx, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ dlin_w, float* __restrict__ dlin_b, int M, int C) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float v[MAXPER], gy[MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int j = lane + i * 64;
+        v[i] = j < C ? x[(size_t)row * C + j] : 0.f;
+        s += v[i];
+    }
+    const float mean = wsum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int j = lane + i * 64;
+        const float d = j < C ? v[i] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wsum(q) / (float)C + eps);
+    float dsr = 0.f;
+    if (ds) dsr = (pad_mask && pad_mask[row]) ? 0.f : ds[row];
+    float a1 = 0.f, a2 = 0.f;  // sum(g*gamma), sum(g*gamma*xh)
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int j = lane + i * 64;
+        gy[i] = 0.f;
+        if (j < C) {
+            const float xh = (v[i] - mean) * rstd;
+            float g = dy ? dy[(size_t)row * C + j] : 0.f;
+            if (ds) {
+                g += dsr * lin_w[j];
+                if (dlin_w) atomicAdd(dlin_w + j, dsr * (xh * gamma[j] + beta[j]));
+            }
+            gy[i] = g;
+            atomicAdd(dgamma + j, g * xh);
+            atomicAdd(dbeta + j, g);
+            a1 += g * gamma[j];
+            a2 += g * gamma[j] * xh;
+        }
+    }
+    a1 = wsum(a1) / (float)C;
+    a2 = wsum(a2) / (float)C;
+    if (ds && dlin_b && lane == 0) atomicAdd(dlin_b, dsr);
+#pragma unroll
+    for (int i = 0; i < MAXPER; ++i) {
+        const int j = lane + i * 64;
+        if (j < C) {
+            const float xh = (v[i] - mean) * rstd;
+            dx[(size_t)row * C + j] = rstd * (gy[i] * gamma[j] - a1 - xh * a2);
+        }
+    }
+}
+
+// LSTMCell + zoneout backward for one step.  Saved from forward: gates act [M,4U] (i,f,g,o after their nonlinearity), c_old, c_new (raw cell, before
+// zoneout) -- see LstmStepArgs.save_*.  In: dh_out, dc_out (gradients w.r.t. the zoneout-ed outputs).  Out: dgates [M,4U] (pre-activation),
+// dh_old_direct / dc_old (the zoneout "keep old" path and the f-gate path), to which the caller adds dgates . W_hh.
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_old, const float* __restrict__ c_new,
+                                     const float* __restrict__ dh_out, const float* __restrict__ dc_out, float zoneout,
+                                     const uint8_t* __restrict__ zk_h, const uint8_t* __restrict__ zk_c, const int* __restrict__ row_len, int step,
+                                     float* __restrict__ dgates, float* __restrict__ dh_old, float* __restrict__ dc_old_out, int M, int U) {
+    const long long total = (long long)M * U;
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / U), u = (int)(idx - (long long)m * U);
+        const float dho = dh_out[idx], dco = dc_out ? dc_out[idx] : 0.f;
+        const bool live = row_len ? (step < row_len[m]) : true;
+        float dh_new, dc_new_z, dh_keep, dc_keep;
+        if (!live) {  // state passed through untouched
+            dh_new = 0.f; dc_new_z = 0.f; dh_keep = dho; dc_keep = dco;
+        } else if (zk_h) {
+            dh_new = zk_h[idx] ? 0.f : dho; dh_keep = zk_h[idx] ? dho : 0.f;
+            dc_new_z = zk_c[idx] ? 0.f : dco; dc_keep = zk_c[idx] ? dco : 0.f;
+        } else {
+            dh_new = (1.0f - zoneout) * dho; dh_keep = zoneout * dho;
+            dc_new_z = (1.0f - zoneout) * dco; dc_keep = zoneout * dco;
+        }
+        const float* gr = gates + (size_t)m * 4 * U;
+        const float ig = gr[u], fg = gr[U + u], gg = gr[2 * U + u], og = gr[3 * U + u];
+        const float tc = tanhf(c_new[idx]);
+        const float dc_new = dc_new_z + dh_new * og * (1.0f - tc * tc);
+        float* dg = dgates + (size_t)m * 4 * U;
+        dg[u] = dc_new * gg * ig * (1.0f - ig);
+        dg[U + u] = dc_new * c_old[idx] * fg * (1.0f - fg);
+        dg[2 * U + u] = dc_new * ig * (1.0f - gg * gg);
+        dg[3 * U + u] = dh_new * tc * og * (1.0f - og);
+        dh_old[idx] = dh_keep;
+        dc_old_out[idx] = dc_new * fg + dc_keep;
+    }
+}
+
+// dst[idx[m], :] += src[m, :]   (embedding gradient; rows with idx == skip contribute nothing: padding_idx)
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst, int M, int C,
+                                        long long skip) {
+    const long long total = (long long)M * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / C), c = (int)(i - (long long)m * C);
+        const long long r = idx[m];
+        if (r != skip) atomicAdd(dst + (size_t)r * C + c, src[i]);
+    }
+}
+
+__global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = bx + j, c = by + threadIdx.x;  // dst is [cols, rows]
+        if (r < cols && c < rows) dst[(size_t)r * rows + c] = tile[threadIdx.x][j];
+    }
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ x, long long n, double* __restrict__ out) {
+    double s = 0.0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += (double)x[i] * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+
+// Adam (torch.optim.Adam semantics, weight_decay 0, amsgrad off) with the clip coefficient and the NaN guard read from device memory:
+// ctrl[0] = total grad-norm^2 (double).  clip = min(1, max_norm / (norm + 1e-6)); non-finite norm => no update (tts.py:173-179).
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            const double* __restrict__ ctrl, float max_norm, float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+    const double norm = sqrt(ctrl[0]);
+    if (!(norm == norm) || norm > 1e300) return;  // NaN / inf guard: skip the step
+    const float clip = max_norm > 0.f ? fminf(1.0f, max_norm / ((float)norm + 1e-6f)) : 1.0f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr * (mi / bc1) / (sqrtf(vi) / sqrtf(bc2) + eps);
+    }
+}
+
+static inline int grid1d(long long total, int block) {
+    long long g = (total + block - 1) / block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace fcl
+
+using namespace fcl;
+
+extern "C" {
+
+int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift,
+                    const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream) {
+    FCL_REQUIRE(a && b && c && m >= 0 && n > 0 && k > 0, FCL_ERR_INVALID, "gemm_tn_fwd: bad arguments");
+    FCL_REQUIRE(!(n & 3) && !(k & 3) && !(lda & 3) && !(ldb & 3) && aligned16(a) && aligned16(b), FCL_ERR_ALIGN,
+                "gemm_tn_fwd: N, K, lda, ldb must be multiples of 4 and operands 16-byte aligned");
+    FCL_REQUIRE((seg_lo == nullptr) == (seg_hi == nullptr), FCL_ERR_INVALID, "gemm_tn_fwd: seg_lo/seg_hi come in pairs");
+    if (m == 0) return 0;
+    const int tiles = ((n + 63) / 64) * ((k + 63) / 64);
+    int slices = (1024 + tiles - 1) / tiles;  // ~1024 workgroups in flight
+    int rps = ((m + slices - 1) / slices + TN_BM - 1) / TN_BM * TN_BM;
+    if (rps < TN_BM) rps = TN_BM;
+    slices = (m + rps - 1) / rps;
+    dim3 grid((n + 63) / 64, (k + 63) / 64, slices);
+    ProfScope ps("gemm_tn_kernel", 2.0 * m * (double)n * k, m, (hipStream_t)stream);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift, seg_lo, seg_hi, rps);
+    return check_hip(hipGetLastError(), "gemm_tn_fwd");
+}
+
+int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream) {
+    FCL_REQUIRE(x && out && m >= 0 && c > 0 && mode >= 0 && mode <= 2, FCL_ERR_INVALID, "colsum_fwd: bad arguments");
+    FCL_REQUIRE(mode == 0 || y, FCL_ERR_INVALID, "colsum_fwd: mode needs y");
+    FCL_REQUIRE(mode != 2 || (g && b), FCL_ERR_INVALID, "colsum_fwd: mode 2 needs gamma and beta");
+    if (m == 0) return 0;
+    const int rpb = 128;
+    hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(64), 0, (hipStream_t)stream, x, y, g, b, out, m, c, mode, rpb);
+    return check_hip(hipGetLastError(), "colsum_fwd");
+}
+
+int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, size_t n, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(dy && dz && (y || act == FCL_ACT_NONE) && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "act_bwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y ? y : dy, keep, keep_scale, dz,
+                       (long long)n, act);
+    return check_hip(hipGetLastError(), "act_bwd");
+}
+
+int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1, float w_mse,
+                    double count, float* da, int accumulate, fcl_stream_t stream) {
+    FCL_REQUIRE(a && b && da && m >= 0 && c > 0 && count > 0, FCL_ERR_INVALID, "l1_mse_grad: bad arguments");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(l1_mse_grad_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, a, b, row_valid, m, c, b_log,
+                       b_log_offset, w_l1, w_mse, (float)(1.0 / count), da, accumulate);
+    return check_hip(hipGetLastError(), "l1_mse_grad");
+}
+
+int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,
+                      const uint8_t* pad_mask, float* dx, float* dgamma, float* dbeta, float* dlin_w, float* dlin_b, int m, int c,
+                      fcl_stream_t stream) {
+    FCL_REQUIRE(x && gamma && beta && dx && dgamma && dbeta && (dy || ds) && m >= 0 && c > 0 && c <= 1024, FCL_ERR_INVALID, "layernorm_bwd: bad arguments");
+    FCL_REQUIRE(!ds || lin_w, FCL_ERR_INVALID, "layernorm_bwd: ds needs lin_w");
+    if (m == 0) return 0;
+    dim3 grid((m + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define FCL_LNB(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), grid, block, 0, s, x, gamma, beta, eps, dy, lin_w, ds, pad_mask, dx, dgamma, dbeta, dlin_w, dlin_b, m, c)
+    if (c <= 64) FCL_LNB(1);
+    else if (c <= 256) FCL_LNB(4);
+    else if (c <= 512) FCL_LNB(8);
+    else FCL_LNB(16);
+#undef FCL_LNB
+    return check_hip(hipGetLastError(), "layernorm_bwd");
+}
+
+int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dc_out, float zoneout,
+                      const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step, float* dgates, float* dh_old,
+                      float* dc_old, int m, int u, fcl_stream_t stream) {
+    FCL_REQUIRE(gates && c_old && c_new && dh_out && dgates && dh_old && dc_old && m >= 0 && u > 0, FCL_ERR_INVALID, "lstm_cell_bwd: bad arguments");
+    FCL_REQUIRE((zone_keep_h == nullptr) == (zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_cell_bwd: zoneout masks come in pairs");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)m * u, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_old, c_new, dh_out, dc_out,
+                       zoneout, zone_keep_h, zone_keep_c, row_len, step, dgates, dh_old, dc_old, m, u);
+    return check_hip(hipGetLastError(), "lstm_cell_bwd");
+}
+
+int fcl_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int m, int c, int64_t skip, fcl_stream_t stream) {
+    FCL_REQUIRE(src && idx && dst && m >= 0 && c > 0, FCL_ERR_INVALID, "scatter_add_rows: bad arguments");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, m, c, (long long)skip);
+    return check_hip(hipGetLastError(), "scatter_add_rows");
+}
+
+int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream) {
+    FCL_REQUIRE(src && dst && rows > 0 && cols > 0 && src != dst, FCL_ERR_INVALID, "transpose2d: bad arguments");
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, src, dst, rows, cols);
+    return check_hip(hipGetLastError(), "transpose2d");
+}
+
+int fcl_sumsq_accum(const float* x, size_t n, double* out, fcl_stream_t stream) {
+    FCL_REQUIRE(x && out, FCL_ERR_INVALID, "sumsq_accum: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+    return check_hip(hipGetLastError(), "sumsq_accum");
+}
+
+int fcl_adam_step(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
+                  float beta2, float eps, int step, fcl_stream_t stream) {
+    FCL_REQUIRE(p && g && m && v && gradnorm_sq && step >= 1, FCL_ERR_INVALID, "adam_step: bad arguments");
+    if (n == 0) return 0;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, gradnorm_sq, max_norm, lr,
+                       beta1, beta2, eps, bc1, bc2);
+    return check_hip(hipGetLastError(), "adam_step");
+}
+
+}  // extern "C"

@@ -175,3 +175,75 @@ def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher
         workspace=ws.data_ptr(), workspace_bytes=nbytes)
     check(lib.fcl_decoder_loop_fwd(C.byref(dw.struct), C.byref(io), _stream()))
     return (before, taps) if want_taps else before
+
+
+# ---- gradient primitives (include/fcl_hip.h "H13") -------------------------------------------------------------------
+def gemm_tn(a, b, out, shift=0, seg_lo=None, seg_hi=None):
+    """out[n, k] += sum_m a[m, n] * b[m + shift, k]."""
+    m, n = a.shape
+    k = b.shape[1]
+    assert b.shape[0] == m and out.shape == (n, k)
+    check(_lib.load().fcl_gemm_tn_fwd(_p(a), n, _p(b), k, _p(out), k, m, n, k, shift, _p(seg_lo, torch.int32), _p(seg_hi, torch.int32), _stream()))
+    return out
+
+
+def colsum(x, out, y=None, gamma=None, beta=None, mode=0):
+    m, c = x.shape
+    check(_lib.load().fcl_colsum_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(out), m, c, mode, _stream()))
+    return out
+
+
+def act_bwd(dy, y, act, keep=None, keep_scale=1.0):
+    dz = torch.empty_like(dy)
+    check(_lib.load().fcl_act_bwd(_p(dy), _p(y), _p(keep, torch.uint8), keep_scale, _p(dz), dy.numel(), act, _stream()))
+    return dz
+
+
+def l1_mse_grad(a, b, row_valid, count, w_l1, w_mse, da=None, b_log_offset=None):
+    if a.dim() == 1:
+        a, b = a.reshape(-1, 1), b.reshape(-1, 1)
+    m, c = a.shape
+    acc = da is not None
+    if da is None:
+        da = torch.empty_like(a)
+    check(_lib.load().fcl_l1_mse_grad(_p(a), _p(b), _p(row_valid, torch.uint8), m, c, int(b_log_offset is not None), float(b_log_offset or 0.0),
+                                      w_l1, w_mse, float(count), _p(da), int(acc), _stream()))
+    return da
+
+
+def layernorm_bwd(x, gamma, beta, eps, dgamma, dbeta, dy=None, lin_w=None, ds=None, pad_mask=None, dlin_w=None, dlin_b=None):
+    m, c = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.load().fcl_layernorm_bwd(_p(x), _p(gamma), _p(beta), eps, _p(dy), _p(lin_w), _p(ds), _p(pad_mask, torch.uint8), _p(dx), _p(dgamma),
+                                        _p(dbeta), _p(dlin_w), _p(dlin_b), m, c, _stream()))
+    return dx
+
+
+def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None, zone_keep_c=None, row_len=None, step=0):
+    m, u = c_old.shape
+    dgates = torch.empty(m, 4 * u, device=gates.device, dtype=torch.float32)
+    dh_old, dc_old = torch.empty_like(c_old), torch.empty_like(c_old)
+    check(_lib.load().fcl_lstm_cell_bwd(_p(gates), _p(c_old), _p(c_new), _p(dh_out), _p(dc_out), zoneout, _p(zone_keep_h, torch.uint8),
+                                        _p(zone_keep_c, torch.uint8), _p(row_len, torch.int32), step, _p(dgates), _p(dh_old), _p(dc_old), m, u, _stream()))
+    return dgates, dh_old, dc_old
+
+
+def scatter_add_rows(src, idx_i64, dst, skip=-1):
+    m, c = src.shape
+    check(_lib.load().fcl_scatter_add_rows(_p(src), _p(idx_i64, torch.int64), _p(dst), m, c, skip, _stream()))
+    return dst
+
+
+def transpose2d(src):
+    rows, cols = src.shape
+    dst = torch.empty(cols, rows, device=src.device, dtype=torch.float32)
+    check(_lib.load().fcl_transpose2d(_p(src), _p(dst), rows, cols, _stream()))
+    return dst
+
+
+def sumsq_accum(x, out_f64):
+    check(_lib.load().fcl_sumsq_accum(_p(x), x.numel(), out_f64.data_ptr(), _stream()))
+
+
+def adam_step(p, g, m, v, gradnorm_sq_f64, max_norm, lr, beta1, beta2, eps, step):
+    check(_lib.load().fcl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), gradnorm_sq_f64.data_ptr(), max_norm, lr, beta1, beta2, eps, step, _stream()))

@@ -177,6 +177,39 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
 int fcl_masked_l1_mse_fwd(const float* a, int lda, const float* b, int ldb, const uint8_t* row_valid, int m, int c,
                           int b_log, float b_log_offset, double* out, fcl_stream_t stream);
 
+/* ---- H13: gradient primitives of the teacher-forced training step (tts.py:137-179; losses ..._sa.py:601-613).
+ *      dX of every Linear / Conv1d is the forward GEMM on transposed weights (fcl_transpose2d + fcl_linear_fwd / fcl_conv1d_fwd
+ *      with the taps reversed); the entries below are what the backward pass needs beyond that. ------------------------------- */
+/* dW: c[n, k] += sum_m a[m, n] * b[m + shift, k]  (rows of b outside [seg_lo[m], seg_hi[m]) — or outside [0, M) when the
+ * bounds are NULL — contribute zero).  Linear: shift 0; Conv1d tap j: shift = j - (k-1)/2, c = packed dW[j] ([Cout, Cin]).
+ * Accumulates with fp32 atomics (the caller zeroes c once per step: gradient accumulation is the natural mode). */
+int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift,
+                    const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream);
+/* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm). */
+int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream);
+/* dz = dy * act'(y) [* keep * keep_scale]   (y = the activation's OUTPUT before dropout; act = FCL_ACT_*). */
+int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, size_t n, int act, fcl_stream_t stream);
+/* da (+)= (w_l1 * sign(a - b') + 2 * w_mse * (a - b')) / count on the valid rows, 0 elsewhere  (b' as in fcl_masked_l1_mse_fwd). */
+int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1,
+                    float w_mse, double count, float* da, int accumulate, fcl_stream_t stream);
+/* Channel LayerNorm backward (+ the predictor's scalar head: ds = gradient of scalar[m]).  dgamma/dbeta/dlin_w/dlin_b accumulate. */
+int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,
+                      const uint8_t* pad_mask, float* dx, float* dgamma, float* dbeta, float* dlin_w, float* dlin_b, int m, int c,
+                      fcl_stream_t stream);
+/* LSTMCell + zoneout backward of one step from the forward's saved gate activations [M,4U] (i,f,g,o), c_old and c_new (raw):
+ * dgates [M,4U] (pre-activation), dh_old (zoneout keep path), dc_old.  The caller adds dgates . W_hh to dh_old. */
+int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dc_out, float zoneout,
+                      const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step, float* dgates, float* dh_old,
+                      float* dc_old, int m, int u, fcl_stream_t stream);
+/* dst[idx[m], :] += src[m, :]  (embedding gradient; idx == skip rows are dropped: padding_idx). */
+int fcl_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int m, int c, int64_t skip, fcl_stream_t stream);
+int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream);
+/* Optimizer (tts.py:173-182): *out += sum x^2 ; Adam step with clip_grad_norm_(max_norm) and the NaN guard taken from the
+ * device-resident squared gradient norm, so the whole step stays on the stream. */
+int fcl_sumsq_accum(const float* x, size_t n, double* out, fcl_stream_t stream);
+int fcl_adam_step(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
+                  float beta2, float eps, int step, fcl_stream_t stream);
+
 /* ---- measurement hook (bench.py's live roofline figures) ------------------------------- */
 /* While enabled, every GEMM / LSTM-step / BiLSTM launch is bracketed by HIP events on the stream it is
  * launched on.  fcl_prof_collect synchronises those events and returns one entry per kernel instantiation:

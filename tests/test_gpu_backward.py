@@ -1,0 +1,175 @@
+"""-m gpu: gradient primitives (H13) vs torch autograd on CPU, each in isolation; exact-fp32 kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import max_abs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    import fcl_taco2_amd  # noqa: F401
+    from fcl_taco2_amd import _lib, ops as _ops
+
+    _lib.load()
+    return _ops
+
+
+def dev(a):
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    return t.to(DEV).contiguous()
+
+
+def rnd(rng, *shape):
+    return rng.standard_normal(shape).astype(np.float32)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 4, 4), (33, 8, 12), (700, 80, 128), (2501, 256, 256), (5000, 384, 768), (64, 1024, 512)])
+def test_gemm_tn_linear_weight_grad(ops, m, n, k):
+    rng = np.random.RandomState(m + n)
+    dy, x = rnd(rng, m, n), rnd(rng, m, k)
+    out = torch.zeros(n, k, device=DEV)
+    ops.gemm_tn(dev(dy), dev(x), out)
+    ref = dy.astype(np.float64).T @ x.astype(np.float64)
+    assert max_abs(out.cpu().double(), ref) < 2e-4 * max(1.0, np.sqrt(m))
+    ops.gemm_tn(dev(dy), dev(x), out)  # accumulates
+    assert max_abs(out.cpu().double(), 2 * ref) < 4e-4 * max(1.0, np.sqrt(m))
+
+
+@pytest.mark.parametrize("cin,cout,ksz", [(16, 8, 5), (80, 128, 5), (256, 384, 3)])
+def test_conv1d_backward_vs_autograd(ops, cin, cout, ksz):
+    """dW per tap by gemm_tn with shifted, segment-bounded rows; dX by the forward conv on transposed, tap-reversed weights."""
+    rng = np.random.RandomState(cin)
+    seg_lens = [3, 1, 50, 17, 129]
+    M = sum(seg_lens)
+    lo = np.repeat(np.cumsum([0] + seg_lens[:-1]), seg_lens).astype(np.int32)
+    hi = (lo + np.repeat(seg_lens, seg_lens)).astype(np.int32)
+    x = torch.from_numpy(rnd(rng, M, cin)).requires_grad_(True)
+    w = torch.from_numpy((rnd(rng, cout, cin, ksz) / np.sqrt(cin * ksz)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rnd(rng, M, cout))
+    y = torch.cat([F.conv1d(x[s:e].t().unsqueeze(0), w, None, 1, (ksz - 1) // 2)[0].t() for s, e in zip(np.cumsum([0] + seg_lens[:-1]), np.cumsum(seg_lens))])
+    (y * dy).sum().backward()
+    pad = (ksz - 1) // 2
+    dwp = torch.zeros(ksz, cout, cin, device=DEV)
+    for j in range(ksz):
+        ops.gemm_tn(dev(dy), dev(x.detach()), dwp[j], shift=j - pad, seg_lo=dev(lo), seg_hi=dev(hi))
+    assert max_abs(dwp.cpu().permute(1, 2, 0), w.grad) < 2e-4
+    # dX: y[m] = sum_j x[m + j - pad] W_j  =>  dx[m] = sum_j dy[m - (j - pad)] W_j^T : a conv of dy with taps reversed, weights transposed
+    wp = ops.pack_conv1d_weight(dev(w.detach()))  # [k, Cout, Cin]
+    wt = torch.stack([ops.transpose2d(wp[ksz - 1 - j]) for j in range(ksz)])  # [k, Cin, Cout], tap order reversed
+    dx = ops.conv1d(dev(dy), wt.contiguous(), None, dev(lo), dev(hi))
+    assert max_abs(dx.cpu(), x.grad) < 2e-4
+
+
+def test_act_bwd_colsum_transpose(ops):
+    rng = np.random.RandomState(0)
+    y, dy = rnd(rng, 301, 40), rnd(rng, 301, 40)
+    keep = (rng.rand(301, 40) < 0.5).astype(np.uint8)
+    for act, fn in ((0, lambda v: v), (1, torch.relu), (2, torch.tanh)):
+        pre = torch.from_numpy(y).requires_grad_(True)
+        out = fn(pre) * torch.from_numpy(keep).float() * 2.0
+        out.backward(torch.from_numpy(dy))
+        act_out = fn(torch.from_numpy(y))
+        dz = ops.act_bwd(dev(dy), dev(act_out.numpy()), act, dev(keep), 2.0)
+        assert max_abs(dz.cpu(), pre.grad) < 1e-6
+    out = torch.zeros(40, device=DEV)
+    ops.colsum(dev(dy), out)
+    assert max_abs(out.cpu(), dy.sum(0)) < 1e-4
+    g, b = 1 + 0.1 * rnd(rng, 40), rnd(rng, 40)
+    out2 = torch.zeros(40, device=DEV)
+    ops.colsum(dev(dy), out2, y=dev(y), gamma=dev(g), beta=dev(b), mode=2)
+    assert max_abs(out2.cpu(), (dy * (y - b) / g).sum(0)) < 2e-3
+    t = ops.transpose2d(dev(y))
+    assert torch.equal(t.cpu(), torch.from_numpy(y).t().contiguous())
+
+
+def test_l1_mse_grad(ops):
+    rng = np.random.RandomState(1)
+    a0, b = rnd(rng, 100, 8), np.abs(rnd(rng, 100, 8))
+    valid = (rng.rand(100) < 0.6).astype(np.uint8)
+    for blog in (None, 1.0):
+        a = torch.from_numpy(a0).requires_grad_(True)
+        bt = torch.from_numpy(b) if blog is None else torch.log(torch.from_numpy(b) + blog)
+        mask = torch.from_numpy(valid).bool().unsqueeze(1).expand_as(a)
+        d = (a - bt).masked_select(mask)
+        (0.7 * d.abs().mean() + 1.3 * (d ** 2).mean()).backward()
+        da = ops.l1_mse_grad(dev(a0), dev(b), dev(valid), float(mask.sum()), 0.7, 1.3, b_log_offset=blog)
+        assert max_abs(da.cpu(), a.grad) < 1e-6
+
+
+@pytest.mark.parametrize("c", [20, 384])
+def test_layernorm_bwd_with_scalar_head(ops, c):
+    rng = np.random.RandomState(c)
+    m = 97
+    x0, g0, b0, lw0, lb0 = 2 * rnd(rng, m, c) + 0.5, 1 + 0.1 * rnd(rng, c), rnd(rng, c), (rnd(rng, c) / np.sqrt(c)).astype(np.float32), rnd(rng, 1)
+    dy, ds = rnd(rng, m, c), rnd(rng, m)
+    pad = (rng.rand(m) < 0.2).astype(np.uint8)
+    x, g, b, lw, lb = [torch.from_numpy(v).requires_grad_(True) for v in (x0, g0, b0, lw0, lb0)]
+    y = F.layer_norm(x, (c,), g, b, 1e-12)
+    s = (y @ lw + lb).masked_fill(torch.from_numpy(pad).bool(), 0.0)
+    ((y * torch.from_numpy(dy)).sum() + (s * torch.from_numpy(ds)).sum()).backward()
+    dg, db, dlw, dlb = (torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(1, device=DEV))
+    dx = ops.layernorm_bwd(dev(x0), dev(g0), dev(b0), 1e-12, dg, db, dy=dev(dy), lin_w=dev(lw0), ds=dev(ds), pad_mask=dev(pad), dlin_w=dlw, dlin_b=dlb)
+    assert max_abs(dx.cpu(), x.grad) < 2e-4
+    assert max_abs(dg.cpu(), g.grad) < 2e-4 and max_abs(db.cpu(), b.grad) < 2e-4
+    assert max_abs(dlw.cpu(), lw.grad) < 2e-4 and max_abs(dlb.cpu(), lb.grad) < 2e-4
+
+
+@pytest.mark.parametrize("masks", [False, True])
+def test_lstm_cell_bwd_vs_autograd(ops, masks):
+    rng = np.random.RandomState(5)
+    m, u, zr = 37, 24, 0.1
+    pre0, h0, c0 = rnd(rng, m, 4 * u), rnd(rng, m, u), rnd(rng, m, u)
+    dh, dc = rnd(rng, m, u), rnd(rng, m, u)
+    zh = (rng.rand(m, u) < 0.3).astype(np.uint8) if masks else None
+    zc = (rng.rand(m, u) < 0.3).astype(np.uint8) if masks else None
+    pre, h_old, c_old = [torch.from_numpy(v).requires_grad_(True) for v in (pre0, h0, c0)]
+    i, f, g, o = pre.chunk(4, 1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    c_new = f * c_old + i * g
+    h_new = o * torch.tanh(c_new)
+    if masks:
+        mh, mc = torch.from_numpy(zh).float(), torch.from_numpy(zc).float()
+        h_out, c_out = mh * h_old + (1 - mh) * h_new, mc * c_old + (1 - mc) * c_new
+    else:
+        h_out, c_out = zr * h_old + (1 - zr) * h_new, zr * c_old + (1 - zr) * c_new
+    ((h_out * torch.from_numpy(dh)).sum() + (c_out * torch.from_numpy(dc)).sum()).backward()
+    gates = torch.cat([i, f, g, o], 1).detach()
+    dgates, dh_old, dc_old = ops.lstm_cell_bwd(dev(gates), dev(c0), dev(c_new.detach()), dev(dh), dev(dc), zr,
+                                                dev(zh) if masks else None, dev(zc) if masks else None)
+    assert max_abs(dgates.cpu(), pre.grad) < 1e-5
+    assert max_abs(dh_old.cpu(), h_old.grad) < 1e-6 and max_abs(dc_old.cpu(), c_old.grad) < 1e-5
+
+
+def test_scatter_add_and_adam_step(ops):
+    rng = np.random.RandomState(2)
+    src, idx = rnd(rng, 500, 32), rng.randint(0, 12, size=500).astype(np.int64)
+    dst = torch.zeros(12, 32, device=DEV)
+    ops.scatter_add_rows(dev(src), dev(idx), dst, skip=0)
+    ref = np.zeros((12, 32), np.float64)
+    for r, i in zip(src, idx):
+        if i != 0:
+            ref[i] += r
+    assert max_abs(dst.cpu().double(), ref) < 1e-4
+    # Adam with clip_grad_norm_(1.0): two steps vs torch.optim.Adam on CPU
+    p0, grads = rnd(rng, 1000), [5 * rnd(rng, 1000), rnd(rng, 1000)]
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([pt], lr=1e-3, eps=1e-6, weight_decay=0.0)
+    p, m, v = dev(p0.copy()), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step, gnp in enumerate(grads, 1):
+        pt.grad = torch.from_numpy(gnp.copy())
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+        nsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.sumsq_accum(dev(gnp), nsq)
+        ops.adam_step(p, dev(gnp), m, v, nsq, 1.0, 1e-3, 0.9, 0.999, 1e-6, step)
+        assert max_abs(p.cpu(), pt.detach()) < 2e-6
+    nan = torch.full((1,), float("nan"), dtype=torch.float64, device=DEV)
+    before = p.clone()
+    ops.adam_step(p, dev(grads[0]), m, v, nan, 1.0, 1e-3, 0.9, 0.999, 1e-6, 3)  # NaN grad norm -> the step is skipped (tts.py:175-178)
+    assert torch.equal(p, before)
