@@ -30,6 +30,18 @@ class DecoderIO(C.Structure):
                 ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z)]
 
 
+class GemmTerm(C.Structure):
+    _fields_ = [("A", _P), ("W", _P), ("lda", _I), ("ldw", _I), ("K", _I), ("shift", _I), ("Whi", _P), ("Wlo", _P)]
+
+
+class LstmStep(C.Structure):
+    _fields_ = [("term", GemmTerm * 3), ("nterms", _I), ("M", _I), ("U", _I), ("G", _P), ("g_row_mul", C.c_longlong), ("g_row_add", C.c_longlong),
+                ("bias", _P), ("rank1_w", _P), ("dur", _P), ("step", _I), ("h_in", _P), ("h_out", _P), ("c", _P), ("zoneout", _F),
+                ("zone_keep_h", _P), ("zone_keep_c", _P), ("row_len", _P), ("out2", _P), ("out2_row_base", _P), ("out2_row_mul", C.c_longlong),
+                ("out2_row_add", C.c_longlong), ("ld2", _I), ("out2_col_off", _I), ("save_gates", _P), ("save_c_new", _P), ("save_c_old", _P),
+                ("save_h_old", _P)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
 
@@ -40,6 +52,7 @@ SIGNATURES = {
     "fcl_pack_conv1d_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_fold_batchnorm": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "fcl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "fcl_add2d": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _P]),
     "fcl_frag_bf16_elems": (_Z, [_I, _I]),
     "fcl_pack_frag_bf16": (_I, [_P, _I, _I, _P, _P, _P]),
     "fcl_add_vec": (_I, [_P, _P, _P, _I, _P]),
@@ -59,6 +72,8 @@ SIGNATURES = {
     "fcl_masked_l1_mse_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
     "fcl_gemm_tn_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "fcl_colsum_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fcl_act_fwd": (_I, [_P, _P, _F, _P, _Z, _I, _P]),
+    "fcl_unpack_conv1d_grad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_act_bwd": (_I, [_P, _P, _P, _F, _P, _Z, _I, _P]),
     "fcl_l1_mse_grad": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _F, C.c_double, _P, _I, _P]),
     "fcl_layernorm_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
@@ -67,6 +82,7 @@ SIGNATURES = {
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),
     "fcl_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "fcl_lstm_step_fwd": (_I, [C.POINTER(LstmStep), _P]),
     "fcl_prof_enable": (_I, [_I]),
     "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }

@@ -114,6 +114,24 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     }
 }
 
+__global__ void act_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep, float scale, float* __restrict__ y, long long n, int act) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == FCL_ACT_TANH) v = tanhf(v);
+        if (keep) v = keep[i] ? v * scale : 0.f;
+        y[i] = v;
+    }
+}
+
+__global__ void unpack_conv_grad_kernel(const float* __restrict__ dwp, const float* __restrict__ scale, float* __restrict__ dw, int cout, int cin, int k) {
+    const long long total = (long long)k * cout * cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin), co = (int)((i / cin) % cout), j = (int)(i / ((long long)cin * cout));
+        dw[((size_t)co * cin + ci) * k + j] += dwp[i] * (scale ? scale[co] : 1.0f);
+    }
+}
+
 // grad of  w1 * mean_valid|a - b'| + w2 * mean_valid (a - b')^2  w.r.t. a:   (w1*sign(d) + 2*w2*d) / count   on valid rows (+= when accumulate)
 __global__ void l1_mse_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ valid, int M, int C,
                                    int b_log, float off, float w1, float w2, float inv_count, float* __restrict__ da, int accumulate) {
@@ -245,6 +263,17 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, const int
     }
 }
 
+// dst[r, 0:cols] += alpha * src[r, 0:cols] for rows with row_valid[r] != 0 (all rows when row_valid is null); strided on both sides
+__global__ void add2d_kernel(float* __restrict__ dst, int ld_dst, const float* __restrict__ src, int ld_src, int rows, int cols, float alpha,
+                             const uint8_t* __restrict__ row_valid) {
+    const long long total = (long long)rows * cols;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+        if (row_valid && !row_valid[r]) continue;
+        dst[(size_t)r * ld_dst + c] += alpha * src[(size_t)r * ld_src + c];
+    }
+}
+
 __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -333,6 +362,19 @@ int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep
     return check_hip(hipGetLastError(), "act_bwd");
 }
 
+int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y, size_t n, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(x && y && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "act_fwd: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, x, keep, keep_scale, y, (long long)n, act);
+    return check_hip(hipGetLastError(), "act_fwd");
+}
+
+int fcl_unpack_conv1d_grad(const float* dwp, const float* scale, float* dw, int cout, int cin, int k, fcl_stream_t stream) {
+    FCL_REQUIRE(dwp && dw && cout > 0 && cin > 0 && k > 0, FCL_ERR_INVALID, "unpack_conv1d_grad: bad arguments");
+    hipLaunchKernelGGL(unpack_conv_grad_kernel, dim3(grid1d((long long)k * cout * cin, 256)), dim3(256), 0, (hipStream_t)stream, dwp, scale, dw, cout, cin, k);
+    return check_hip(hipGetLastError(), "unpack_conv1d_grad");
+}
+
 int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1, float w_mse,
                     double count, float* da, int accumulate, fcl_stream_t stream) {
     FCL_REQUIRE(a && b && da && m >= 0 && c > 0 && count > 0, FCL_ERR_INVALID, "l1_mse_grad: bad arguments");
@@ -375,6 +417,14 @@ int fcl_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int m
     if (m == 0) return 0;
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, m, c, (long long)skip);
     return check_hip(hipGetLastError(), "scatter_add_rows");
+}
+
+int fcl_add2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, float alpha, const uint8_t* row_valid, fcl_stream_t stream) {
+    FCL_REQUIRE(dst && src && rows >= 0 && cols > 0 && ld_dst >= cols && ld_src >= cols, FCL_ERR_INVALID, "add2d: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(add2d_kernel, dim3(grid1d((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src, rows, cols,
+                       alpha, row_valid);
+    return check_hip(hipGetLastError(), "add2d");
 }
 
 int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream) {

@@ -132,6 +132,13 @@ int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int fcl_lstm_step_fwd(const fcl_lstm_step_t* args, fcl_stream_t stream) {
+    FCL_REQUIRE(args, FCL_ERR_INVALID, "lstm_step_fwd: null argument");
+    FCL_REQUIRE(!args->save_gates || (args->save_c_new && args->save_c_old && args->save_h_old), FCL_ERR_INVALID,
+                "lstm_step_fwd: save_gates needs save_c_new / save_c_old / save_h_old");
+    return launch_lstm_step(*args, (hipStream_t)stream);
+}
+
 int fcl_prof_enable(int on) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();

@@ -31,16 +31,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ---- fused multi-term GEMM (gemm_f32.hip) ---------------------------------------------------------
 // Y[m, n] = epi( sum_t sum_k A_t[row_t(m), k] * W_t[n, k] )    A_t, W_t are K-contiguous (row-major)
 // row_t(m) = (a_row_map ? a_row_map[m] : m) + shift_t, contributing 0 outside [seg_lo[m], seg_hi[m]).
-struct GemmTerm {
-    const float* A;
-    const float* W;
-    int lda;    // floats between A rows   (multiple of 4)
-    int ldw;    // floats between W rows   (multiple of 4)
-    int K;      // multiple of 4
-    int shift;  // row shift (conv tap offset), 0 for linear terms
-    const unsigned short* Whi;  // optional fragment-major bf16x3 planes of W (fcl_pack_frag_bf16); used by the small-tile kernels
-    const unsigned short* Wlo;
-};
+typedef fcl_gemm_term_t GemmTerm;  // public C struct (include/fcl_hip.h)
 
 enum { FCL_MAX_TERMS = 9 };
 
@@ -74,35 +65,8 @@ struct GemmArgs {
     int y2_row_add;
 };
 
-// ---- fused LSTM step (gemm_f32.hip) ----------------------------------------------------------------
-// gates[m, g*U+u] = sum_t A_t[m,:] . W_t[g*U+u,:] + G[m*g_row_mul + g_row_add, g*U+u] | bias + rank1
-// then the LSTMCell + zoneout epilogue, all four gates of a unit held by one lane.
-struct LstmStepArgs {
-    GemmTerm term[3];
-    int nterms;
-    int M, U;
-    const float* G;  // optional pre-activation init [*, 4U]
-    long long g_row_mul;
-    long long g_row_add;
-    const float* bias;  // optional [4U]
-    const float* rank1_w;  // optional [4U] with position computed in-kernel: pos = step / dur[m]
-    const int* dur;        // [M] (rank1 only)
-    int step;
-    const float* h_in;  // [M, U] previous hidden (also usually a term's A)
-    float* h_out;       // [M, U] (must not alias h_in)
-    float* c;           // [M, U] in place
-    float zoneout;      // eval-form rate (0 = plain LSTMCell)
-    const uint8_t* zone_keep_h;  // optional train-form masks [M, U] (1 keeps the OLD state)
-    const uint8_t* zone_keep_c;
-    const int* row_len;  // optional: row live iff step < row_len[m] (packed BiLSTM semantics)
-    float* out2;         // optional: out2[row*ld2 + col_off + u] = live ? h_new : 0, with
-                         // row = (out2_row_base ? out2_row_base[m] : m*out2_row_mul) + out2_row_add
-    const int* out2_row_base;
-    long long out2_row_mul;
-    long long out2_row_add;
-    int ld2;
-    int out2_col_off;
-};
+// ---- fused LSTM step (gemm_f32.hip / decoder_step.hip): the argument block is the public fcl_lstm_step_t ----------
+typedef fcl_lstm_step_t LstmStepArgs;
 
 // ---- profiling hook (capi.hip) ----------------------------------------------------------------------
 extern bool g_prof_on;

@@ -62,6 +62,13 @@ __device__ __forceinline__ void cell_finish(const LstmStepArgs& a, int m, int u,
     }
     a.h_out[off] = ci.live ? h_o : ci.h_old;
     a.c[off] = ci.live ? c_o : ci.c_old;
+    if (a.save_gates) {  // training forward: what fcl_lstm_cell_bwd needs
+        float* sg = a.save_gates + (size_t)m * 4 * a.U;
+        sg[u] = ig; sg[a.U + u] = fg; sg[2 * a.U + u] = gg; sg[3 * a.U + u] = og;
+        a.save_c_new[off] = c_new;
+        a.save_c_old[off] = ci.c_old;
+        a.save_h_old[off] = ci.h_old;
+    }
     if (a.out2) {
         const long long row = (a.out2_row_base ? (long long)a.out2_row_base[m] : (long long)m * a.out2_row_mul) + a.out2_row_add;
         a.out2[(size_t)row * a.ld2 + a.out2_col_off + u] = ci.live ? h_o : 0.f;

@@ -44,6 +44,14 @@ def copy_cols(src, col0, ncols):
     return dst
 
 
+def copy2d(dst, src):
+    """dst[:, :] = src[:, :] for 2-D views with unit column stride."""
+    rows, cols = src.shape
+    assert dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1 and dst.dtype == src.dtype == torch.float32 and dst.is_cuda
+    check(_lib.load().fcl_copy2d(dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), rows, cols, _stream()))
+    return dst
+
+
 def pack_frag_bf16(w):
     """Fragment-major bf16x3 planes (hi, lo) of a float32 matrix [rows, cols] (see include/fcl_hip.h)."""
     rows, cols = w.shape
@@ -68,10 +76,10 @@ def embedding(ids, table):
     return out
 
 
-def linear(x, w, bias=None, act=ACT_NONE):
+def linear(x, w, bias=None, act=ACT_NONE, out=None):
     m, k = x.shape
     n = w.shape[0]
-    y = torch.empty(m, n, device=x.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty(m, n, device=x.device, dtype=torch.float32)
     check(_lib.load().fcl_linear_fwd(_p(x), k, _p(w), w.shape[1], _p(bias), _p(y), n, m, n, k, act, _stream()))
     return y
 
@@ -182,8 +190,8 @@ def gemm_tn(a, b, out, shift=0, seg_lo=None, seg_hi=None):
     """out[n, k] += sum_m a[m, n] * b[m + shift, k]."""
     m, n = a.shape
     k = b.shape[1]
-    assert b.shape[0] == m and out.shape == (n, k)
-    check(_lib.load().fcl_gemm_tn_fwd(_p(a), n, _p(b), k, _p(out), k, m, n, k, shift, _p(seg_lo, torch.int32), _p(seg_hi, torch.int32), _stream()))
+    assert b.shape[0] == m and out.shape == (n, k) and out.stride(1) == 1 and out.dtype == torch.float32 and out.is_cuda
+    check(_lib.load().fcl_gemm_tn_fwd(_p(a), n, _p(b), k, out.data_ptr(), out.stride(0), m, n, k, shift, _p(seg_lo, torch.int32), _p(seg_hi, torch.int32), _stream()))
     return out
 
 
@@ -219,10 +227,13 @@ def layernorm_bwd(x, gamma, beta, eps, dgamma, dbeta, dy=None, lin_w=None, ds=No
     return dx
 
 
-def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None, zone_keep_c=None, row_len=None, step=0):
+def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None, zone_keep_c=None, row_len=None, step=0, out=None):
     m, u = c_old.shape
-    dgates = torch.empty(m, 4 * u, device=gates.device, dtype=torch.float32)
-    dh_old, dc_old = torch.empty_like(c_old), torch.empty_like(c_old)
+    if out is not None:
+        dgates, dh_old, dc_old = out
+    else:
+        dgates = torch.empty(m, 4 * u, device=gates.device, dtype=torch.float32)
+        dh_old, dc_old = torch.empty_like(c_old), torch.empty_like(c_old)
     check(_lib.load().fcl_lstm_cell_bwd(_p(gates), _p(c_old), _p(c_new), _p(dh_out), _p(dc_out), zoneout, _p(zone_keep_h, torch.uint8),
                                         _p(zone_keep_c, torch.uint8), _p(row_len, torch.int32), step, _p(dgates), _p(dh_old), _p(dc_old), m, u, _stream()))
     return dgates, dh_old, dc_old
@@ -231,6 +242,14 @@ def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None
 def scatter_add_rows(src, idx_i64, dst, skip=-1):
     m, c = src.shape
     check(_lib.load().fcl_scatter_add_rows(_p(src), _p(idx_i64, torch.int64), _p(dst), m, c, skip, _stream()))
+    return dst
+
+
+def add2d(dst, src, alpha=1.0, row_valid=None):
+    """dst += alpha * src on valid rows.  dst / src may be column-block VIEWS of row-major matrices (stride(1) == 1)."""
+    rows, cols = src.shape
+    assert dst.shape == src.shape and dst.stride(1) == 1 and src.stride(1) == 1 and dst.dtype == src.dtype == torch.float32 and dst.is_cuda
+    check(_lib.load().fcl_add2d(dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), rows, cols, alpha, _p(row_valid, torch.uint8), _stream()))
     return dst
 
 
@@ -247,3 +266,35 @@ def sumsq_accum(x, out_f64):
 
 def adam_step(p, g, m, v, gradnorm_sq_f64, max_norm, lr, beta1, beta2, eps, step):
     check(_lib.load().fcl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), gradnorm_sq_f64.data_ptr(), max_norm, lr, beta1, beta2, eps, step, _stream()))
+
+
+def act_fwd(x, act, keep=None, keep_scale=1.0):
+    y = torch.empty_like(x)
+    check(_lib.load().fcl_act_fwd(_p(x), _p(keep, torch.uint8), keep_scale, _p(y), x.numel(), act, _stream()))
+    return y
+
+
+def unpack_conv1d_grad(dwp, dw, scale=None):
+    k, cout, cin = dwp.shape
+    check(_lib.load().fcl_unpack_conv1d_grad(_p(dwp), _p(scale), _p(dw), cout, cin, k, _stream()))
+    return dw
+
+
+def lstm_step(terms, M, U, h_in, h_out, c, G=None, g_row_mul=1, g_row_add=0, bias=None, rank1_w=None, dur=None, step=0, zoneout=0.0,
+              zone_keep_h=None, zone_keep_c=None, row_len=None, out2=None, out2_row_mul=0, out2_row_add=0, ld2=0, out2_col_off=0, save=None):
+    """One LSTMCell(+zoneout) step through fcl_lstm_step_fwd.  terms: [(A, W, K)] with A [M, >=K] and W [4U, K] contiguous rows.
+    save: optional (gates [M,4U], c_new, c_old, h_old) tensors for the backward pass."""
+    a = _lib.LstmStep()
+    a.nterms = len(terms)
+    for i, (A, W, K) in enumerate(terms):
+        a.term[i] = _lib.GemmTerm(A.data_ptr(), W.data_ptr(), A.stride(0), W.stride(0), K, 0, None, None)
+    a.M, a.U = M, U
+    a.G, a.g_row_mul, a.g_row_add = _p(G), g_row_mul, g_row_add
+    a.bias, a.rank1_w, a.dur, a.step = _p(bias), _p(rank1_w), _p(dur, torch.int32), step
+    a.h_in, a.h_out, a.c, a.zoneout = h_in.data_ptr(), h_out.data_ptr(), c.data_ptr(), zoneout
+    a.zone_keep_h, a.zone_keep_c, a.row_len = _p(zone_keep_h, torch.uint8), _p(zone_keep_c, torch.uint8), _p(row_len, torch.int32)
+    if out2 is not None:
+        a.out2, a.out2_row_mul, a.out2_row_add, a.ld2, a.out2_col_off = out2.data_ptr(), out2_row_mul, out2_row_add, ld2, out2_col_off
+    if save is not None:
+        a.save_gates, a.save_c_new, a.save_c_old, a.save_h_old = [t.data_ptr() for t in save]
+    check(_lib.load().fcl_lstm_step_fwd(C.byref(a), _stream()))

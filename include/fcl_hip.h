@@ -115,6 +115,46 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
                    const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,
                    int algo, void* workspace, size_t workspace_bytes, fcl_stream_t stream);
 
+/* ---- H7 as a single step: one LSTMCell (+ zoneout) update of M rows — the building block of the decoder loop, of the per-step
+ *      BiLSTM, and of the TRAINING forward, which also saves what the backward pass needs (decoder_sa.py:63-96, 500-504) ------ */
+typedef struct {
+    const float* A;  /* [M, K] activations (lda) */
+    const float* W;  /* [4U (or N), K] weights, torch layout (ldw) */
+    int lda, ldw, K; /* multiples of 4 */
+    int shift;       /* conv tap row shift (GEMM terms only; 0 here) */
+    const uint16_t* Whi; /* optional fragment-major bf16x3 planes of W (fcl_pack_frag_bf16) */
+    const uint16_t* Wlo;
+} fcl_gemm_term_t;
+
+typedef struct {
+    fcl_gemm_term_t term[3]; /* gates[m, g*U+u] = sum_t A_t[m,:] . W_t[g*U+u,:] + ... */
+    int nterms;
+    int M, U;
+    const float* G;          /* optional pre-activation init [*, 4U]; row = m*g_row_mul + g_row_add */
+    long long g_row_mul, g_row_add;
+    const float* bias;       /* optional [4U] */
+    const float* rank1_w;    /* optional [4U]: + (step / dur[m]) * rank1_w  (the decoder's position input) */
+    const int32_t* dur;
+    int step;
+    const float* h_in;       /* [M, U] previous hidden state */
+    float* h_out;            /* [M, U], must not alias h_in */
+    float* c;                /* [M, U] cell state, in place */
+    float zoneout;           /* expectation-form rate (0 = plain LSTMCell) */
+    const uint8_t* zone_keep_h; /* optional sampled zoneout masks [M, U] (1 keeps the OLD state), in pairs */
+    const uint8_t* zone_keep_c;
+    const int32_t* row_len;  /* optional: row live iff step < row_len[m] (packed-sequence semantics) */
+    float* out2;             /* optional copy of h: row = (out2_row_base ? out2_row_base[m] : m*out2_row_mul) + out2_row_add */
+    const int32_t* out2_row_base;
+    long long out2_row_mul, out2_row_add;
+    int ld2, out2_col_off;
+    float* save_gates;       /* optional, training: activated gates i,f,g,o [M, 4U] */
+    float* save_c_new;       /* optional: raw new cell (before zoneout) [M, U] */
+    float* save_c_old;       /* optional: incoming cell / hidden state [M, U] */
+    float* save_h_old;
+} fcl_lstm_step_t;
+
+int fcl_lstm_step_fwd(const fcl_lstm_step_t* args, fcl_stream_t stream);
+
 /* ---- H6-H8 (+H9/H10 scatter): the per-phoneme-parallel decoder loop
  *      (Decoder.inference decoder_sa_kd.py:742-790; Decoder.forward :572-655) ------------------------- */
 typedef struct {
@@ -187,6 +227,13 @@ int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, 
                     const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream);
 /* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm). */
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream);
+/* dst[r, 0:cols] += alpha * src[r, 0:cols] on rows with row_valid[r] != 0 (null: every row).  Strided on both sides: accumulates a
+ * gradient block into a column range of weight_ih / feat_out.weight, adds residual-path gradients, masks padded rows. */
+int fcl_add2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, float alpha, const uint8_t* row_valid, fcl_stream_t stream);
+/* y = act(x) [* keep * keep_scale]   (elementwise; the training forward keeps pre-activations for the BatchNorm gradients). */
+int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y, size_t n, int act, fcl_stream_t stream);
+/* dw[co, ci, j] += dwp[j, co, ci] * (scale ? scale[co] : 1): packed tap-major conv gradient back to the torch Conv1d layout. */
+int fcl_unpack_conv1d_grad(const float* dwp, const float* scale, float* dw, int cout, int cin, int k, fcl_stream_t stream);
 /* dz = dy * act'(y) [* keep * keep_scale]   (y = the activation's OUTPUT before dropout; act = FCL_ACT_*). */
 int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, size_t n, int act, fcl_stream_t stream);
 /* da (+)= (w_l1 * sign(a - b') + 2 * w_mse * (a - b')) / count on the valid rows, 0 elsewhere  (b' as in fcl_masked_l1_mse_fwd). */
