@@ -60,7 +60,7 @@ SIGNATURES = {
     "fcl_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcl_conv1d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "fcl_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "fcl_duration_round_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P]),
     "fcl_variance_embed_add_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "fcl_position_table_fwd": (_I, [_P, _P, _I, _I, _P]),
@@ -76,7 +76,11 @@ SIGNATURES = {
     "fcl_unpack_conv1d_grad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_act_bwd": (_I, [_P, _P, _P, _F, _P, _Z, _I, _P]),
     "fcl_l1_mse_grad": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _F, C.c_double, _P, _I, _P]),
-    "fcl_layernorm_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_layernorm_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_bn_stats_fwd": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "fcl_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
+    "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_bernoulli_u8": (_I, [_P, _Z, _F, C.c_uint32, _P, _P]),
     "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),

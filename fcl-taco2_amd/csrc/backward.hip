@@ -96,6 +96,7 @@ __global__ void colsum_kernel(const float* __restrict__ x, const float* __restri
         float v = x[(size_t)m * C + c];
         if (mode == 1) v *= y[(size_t)m * C + c];
         else if (mode == 2) v *= (y[(size_t)m * C + c] - b[c]) / g[c];
+        else if (mode == 3) v *= (y[(size_t)m * C + c] - b[c]) * g[c];
         s += v;
     }
     atomicAdd(out + c, s);
@@ -160,7 +161,8 @@ __device__ __forceinline__ float wsum(float v) {
 template <int MAXPER>
 __global__ void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                      const float* __restrict__ dy, const float* __restrict__ lin_w, const float* __restrict__ ds,
-                                     const uint8_t* __restrict__ pad_mask, float* __restrict__ dx, float* __restrict__ dgamma,
+                                     const uint8_t* __restrict__ pad_mask, const uint8_t* __restrict__ keep, float keep_scale,
+                                     float* __restrict__ dx, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, float* __restrict__ dlin_w, float* __restrict__ dlin_b, int M, int C) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -192,10 +194,12 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ x, const float* _
         if (j < C) {
             const float xh = (v[i] - mean) * rstd;
             float g = dy ? dy[(size_t)row * C + j] : 0.f;
+            const float ks = keep ? (keep[(size_t)row * C + j] ? keep_scale : 0.f) : 1.f;  // dropout between the LayerNorm and its consumers
             if (ds) {
                 g += dsr * lin_w[j];
-                if (dlin_w) atomicAdd(dlin_w + j, dsr * (xh * gamma[j] + beta[j]));
+                if (dlin_w) atomicAdd(dlin_w + j, dsr * (xh * gamma[j] + beta[j]) * ks);
             }
+            g *= ks;
             gy[i] = g;
             atomicAdd(dgamma + j, g * xh);
             atomicAdd(dbeta + j, g);
@@ -274,6 +278,73 @@ __global__ void add2d_kernel(float* __restrict__ dst, int ld_dst, const float* _
     }
 }
 
+// ---- train-mode BatchNorm1d over rows (the reference normalises over ALL B x T positions of the padded batch, padding included) ----------------
+// pass 1: per-column sum and sum of squares in fp64 (ws[0:C], ws[C:2C], zeroed by the caller of the kernel)
+__global__ void bn_stats_kernel(const float* __restrict__ z, int M, int C, int rows_per_block, double* __restrict__ ws) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
+    double s = 0.0, q = 0.0;
+    for (int m = m_lo; m < m_hi; ++m) {
+        const double v = (double)z[(size_t)m * C + c];
+        s += v;
+        q += v * v;
+    }
+    atomicAdd(ws + c, s);
+    atomicAdd(ws + C + c, q);
+}
+
+// pass 2: mean, 1/sqrt(biased var + eps); running statistics as torch (momentum m: r = (1-m) r + m stat, variance unbiased)
+__global__ void bn_finalize_kernel(const double* __restrict__ ws, int M, int C, float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = ws[c] / M;
+    double var = ws[C + c] / M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// y_act = act(gamma * (z - mean) * invstd + beta) ; y_drop = y_act * keep * scale (optional second output)
+__global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, const uint8_t* __restrict__ keep, float scale, float* __restrict__ y_act,
+                                  float* __restrict__ y_drop, long long total, int C, int act) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == FCL_ACT_TANH) v = tanhf(v);
+        y_act[i] = v;
+        if (y_drop) y_drop[i] = keep ? (keep[i] ? v * scale : 0.f) : v;
+    }
+}
+
+// dz = gamma * invstd * (dy - dbeta/M - zhat * dgamma/M), dbeta = sum dy, dgamma = sum dy*zhat (this batch's sums)
+__global__ void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                              const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float* __restrict__ dz,
+                              long long total, int C, float inv_m) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float zh = (z[i] - mean[c]) * invstd[c];
+        dz[i] = gamma[c] * invstd[c] * (dy[i] - dbeta[c] * inv_m - zh * dgamma[c] * inv_m);
+    }
+}
+
+// keep[i] = 1 with probability p_one (counter hash of (seed, i): the production source of dropout / zoneout masks in training)
+__global__ void bernoulli_u8_kernel(uint8_t* __restrict__ out, long long n, unsigned int thresh, unsigned int seed, const unsigned int* __restrict__ seed_dev) {
+    const unsigned int s = hash_u32(seed + (seed_dev ? seed_dev[0] : 0u));
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned int h = hash_u32(hash_u32((unsigned int)i ^ s) + (unsigned int)(i >> 32) * 0x9e3779b9U);
+        out[i] = (h >> 8) < thresh ? 1 : 0;
+    }
+}
+
 __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -345,9 +416,9 @@ int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, 
 }
 
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream) {
-    FCL_REQUIRE(x && out && m >= 0 && c > 0 && mode >= 0 && mode <= 2, FCL_ERR_INVALID, "colsum_fwd: bad arguments");
+    FCL_REQUIRE(x && out && m >= 0 && c > 0 && mode >= 0 && mode <= 3, FCL_ERR_INVALID, "colsum_fwd: bad arguments");
     FCL_REQUIRE(mode == 0 || y, FCL_ERR_INVALID, "colsum_fwd: mode needs y");
-    FCL_REQUIRE(mode != 2 || (g && b), FCL_ERR_INVALID, "colsum_fwd: mode 2 needs gamma and beta");
+    FCL_REQUIRE(mode < 2 || (g && b), FCL_ERR_INVALID, "colsum_fwd: modes 2 and 3 need g and b");
     if (m == 0) return 0;
     const int rpb = 128;
     hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(64), 0, (hipStream_t)stream, x, y, g, b, out, m, c, mode, rpb);
@@ -385,14 +456,14 @@ int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, in
 }
 
 int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,
-                      const uint8_t* pad_mask, float* dx, float* dgamma, float* dbeta, float* dlin_w, float* dlin_b, int m, int c,
-                      fcl_stream_t stream) {
+                      const uint8_t* pad_mask, const uint8_t* keep, float keep_scale, float* dx, float* dgamma, float* dbeta, float* dlin_w,
+                      float* dlin_b, int m, int c, fcl_stream_t stream) {
     FCL_REQUIRE(x && gamma && beta && dx && dgamma && dbeta && (dy || ds) && m >= 0 && c > 0 && c <= 1024, FCL_ERR_INVALID, "layernorm_bwd: bad arguments");
     FCL_REQUIRE(!ds || lin_w, FCL_ERR_INVALID, "layernorm_bwd: ds needs lin_w");
     if (m == 0) return 0;
     dim3 grid((m + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define FCL_LNB(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), grid, block, 0, s, x, gamma, beta, eps, dy, lin_w, ds, pad_mask, dx, dgamma, dbeta, dlin_w, dlin_b, m, c)
+#define FCL_LNB(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), grid, block, 0, s, x, gamma, beta, eps, dy, lin_w, ds, pad_mask, keep, keep_scale, dx, dgamma, dbeta, dlin_w, dlin_b, m, c)
     if (c <= 64) FCL_LNB(1);
     else if (c <= 256) FCL_LNB(4);
     else if (c <= 512) FCL_LNB(8);
@@ -425,6 +496,45 @@ int fcl_add2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, in
     hipLaunchKernelGGL(add2d_kernel, dim3(grid1d((long long)rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, src, ld_src, rows, cols,
                        alpha, row_valid);
     return check_hip(hipGetLastError(), "add2d");
+}
+
+int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                     double* workspace, fcl_stream_t stream) {
+    FCL_REQUIRE(z && mean && invstd && workspace && m > 0 && c > 0, FCL_ERR_INVALID, "bn_stats_fwd: bad arguments");
+    FCL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FCL_ERR_INVALID, "bn_stats_fwd: running statistics come in pairs");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, 2 * sizeof(double) * (size_t)c, s) != hipSuccess) return check_hip(hipGetLastError(), "bn_stats_fwd memset");
+    const int rpb = std::max(64, (m + 255) / 256);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(64), 0, s, z, m, c, rpb, workspace);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, workspace, m, c, eps, momentum, mean, invstd, running_mean, running_var);
+    return check_hip(hipGetLastError(), "bn_stats_fwd");
+}
+
+int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
+                   float* y_act, float* y_drop, int m, int c, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(z && mean && invstd && gamma && beta && y_act && m >= 0 && c > 0 && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID,
+                "bn_act_fwd: bad arguments");
+    FCL_REQUIRE(!keep || y_drop, FCL_ERR_INVALID, "bn_act_fwd: a keep mask needs y_drop");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta, keep, keep_scale,
+                       y_act, y_drop, (long long)m * c, c, act);
+    return check_hip(hipGetLastError(), "bn_act_fwd");
+}
+
+int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
+               float* dz, int m, int c, fcl_stream_t stream) {
+    FCL_REQUIRE(dy && z && mean && invstd && gamma && dbeta && dgamma && dz && m > 0 && c > 0, FCL_ERR_INVALID, "bn_bwd: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, dy, z, mean, invstd, gamma, dbeta, dgamma, dz,
+                       (long long)m * c, c, 1.0f / (float)m);
+    return check_hip(hipGetLastError(), "bn_bwd");
+}
+
+int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const uint32_t* seed_dev, fcl_stream_t stream) {
+    FCL_REQUIRE(out && p_one >= 0.f && p_one <= 1.f, FCL_ERR_INVALID, "bernoulli_u8: bad arguments");
+    if (n == 0) return 0;
+    const unsigned int thresh = (unsigned int)((double)p_one * 16777216.0 + 0.5);  // 24-bit uniform
+    hipLaunchKernelGGL(bernoulli_u8_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, thresh, seed, seed_dev);
+    return check_hip(hipGetLastError(), "bernoulli_u8");
 }
 
 int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream) {

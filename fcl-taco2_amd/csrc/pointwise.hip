@@ -94,7 +94,7 @@ template <int MAXPER>
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                  float eps, float* __restrict__ y, const float* __restrict__ lin_w,
                                  const float* __restrict__ lin_b, const uint8_t* __restrict__ pad_mask,
-                                 float* __restrict__ scalar, int m, int c) {
+                                 const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ scalar, int m, int c) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (row >= m) return;
@@ -120,7 +120,8 @@ __global__ void layernorm_kernel(const float* __restrict__ x, const float* __res
     for (int i = 0; i < MAXPER; ++i) {
         const int j = lane + i * 64;
         if (j < c) {
-            const float o = (v[i] - mean) * rstd * gamma[j] + beta[j];
+            float o = (v[i] - mean) * rstd * gamma[j] + beta[j];
+            if (keep) o = keep[(size_t)row * c + j] ? o * keep_scale : 0.f;  // training: Dropout after the LayerNorm
             if (y) y[(size_t)row * c + j] = o;
             if (lin_w) dot += o * lin_w[j];
         }
@@ -288,7 +289,8 @@ int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n,
 }
 
 int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, const float* lin_w,
-                      const float* lin_b, const uint8_t* pad_mask, float* scalar, int m, int c, fcl_stream_t stream) {
+                      const float* lin_b, const uint8_t* pad_mask, const uint8_t* keep, float keep_scale, float* scalar, int m, int c,
+                      fcl_stream_t stream) {
     FCL_REQUIRE(x && gamma && beta && m >= 0 && c > 0, FCL_ERR_INVALID, "layernorm_fwd: bad arguments");
     FCL_REQUIRE(y || lin_w, FCL_ERR_INVALID, "layernorm_fwd: nothing to compute (y and lin_w both NULL)");
     FCL_REQUIRE(!lin_w || (lin_b && scalar), FCL_ERR_INVALID, "layernorm_fwd: lin_w needs lin_b and scalar");
@@ -296,10 +298,10 @@ int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
     if (m == 0) return 0;
     dim3 grid((m + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (c <= 64) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
-    else if (c <= 256) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
-    else if (c <= 512) hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
-    else hipLaunchKernelGGL((layernorm_kernel<16>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, scalar, m, c);
+    if (c <= 64) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
+    else if (c <= 256) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
+    else if (c <= 512) hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
+    else hipLaunchKernelGGL((layernorm_kernel<16>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
     return check_hip(hipGetLastError(), "layernorm_fwd");
 }
 

@@ -94,12 +94,12 @@ def conv1d(x, wp, bias, seg_lo, seg_hi, act=ACT_NONE, residual=None):
     return y
 
 
-def layernorm(x, gamma, beta, eps, want_y=True, lin_w=None, lin_b=None, pad_mask=None):
+def layernorm(x, gamma, beta, eps, want_y=True, lin_w=None, lin_b=None, pad_mask=None, keep=None, keep_scale=1.0):
     m, c = x.shape
     y = torch.empty_like(x) if want_y else None
     scalar = torch.empty(m, device=x.device, dtype=torch.float32) if lin_w is not None else None
-    check(_lib.load().fcl_layernorm_fwd(_p(x), _p(gamma), _p(beta), eps, _p(y), _p(lin_w), _p(lin_b), _p(pad_mask, torch.uint8), _p(scalar),
-                                        m, c, _stream()))
+    check(_lib.load().fcl_layernorm_fwd(_p(x), _p(gamma), _p(beta), eps, _p(y), _p(lin_w), _p(lin_b), _p(pad_mask, torch.uint8),
+                                        _p(keep, torch.uint8), keep_scale, _p(scalar), m, c, _stream()))
     return y, scalar
 
 
@@ -219,12 +219,45 @@ def l1_mse_grad(a, b, row_valid, count, w_l1, w_mse, da=None, b_log_offset=None)
     return da
 
 
-def layernorm_bwd(x, gamma, beta, eps, dgamma, dbeta, dy=None, lin_w=None, ds=None, pad_mask=None, dlin_w=None, dlin_b=None):
+def layernorm_bwd(x, gamma, beta, eps, dgamma, dbeta, dy=None, lin_w=None, ds=None, pad_mask=None, dlin_w=None, dlin_b=None, keep=None,
+                  keep_scale=1.0):
     m, c = x.shape
     dx = torch.empty_like(x)
-    check(_lib.load().fcl_layernorm_bwd(_p(x), _p(gamma), _p(beta), eps, _p(dy), _p(lin_w), _p(ds), _p(pad_mask, torch.uint8), _p(dx), _p(dgamma),
-                                        _p(dbeta), _p(dlin_w), _p(dlin_b), m, c, _stream()))
+    check(_lib.load().fcl_layernorm_bwd(_p(x), _p(gamma), _p(beta), eps, _p(dy), _p(lin_w), _p(ds), _p(pad_mask, torch.uint8), _p(keep, torch.uint8),
+                                        keep_scale, _p(dx), _p(dgamma), _p(dbeta), _p(dlin_w), _p(dlin_b), m, c, _stream()))
     return dx
+
+
+def bn_stats(z, eps, momentum=0.1, running_mean=None, running_var=None):
+    """Train-mode BatchNorm statistics over the rows of z: returns (mean, invstd); updates the running buffers in place."""
+    m, c = z.shape
+    mean, invstd = torch.empty(c, device=z.device), torch.empty(c, device=z.device)
+    ws = torch.empty(2 * c, device=z.device, dtype=torch.float64)
+    check(_lib.load().fcl_bn_stats_fwd(_p(z), m, c, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var), ws.data_ptr(), _stream()))
+    return mean, invstd
+
+
+def bn_act(z, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0):
+    """Returns (y_act, y_drop); y_drop is y_act when there is no keep mask."""
+    m, c = z.shape
+    y_act = torch.empty_like(z)
+    y_drop = torch.empty_like(z) if keep is not None else None
+    check(_lib.load().fcl_bn_act_fwd(_p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(keep, torch.uint8), keep_scale, _p(y_act), _p(y_drop), m, c, act,
+                                     _stream()))
+    return y_act, (y_drop if keep is not None else y_act)
+
+
+def bn_bwd(dy, z, mean, invstd, gamma, dbeta, dgamma):
+    m, c = z.shape
+    dz = torch.empty_like(z)
+    check(_lib.load().fcl_bn_bwd(_p(dy), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), m, c, _stream()))
+    return dz
+
+
+def bernoulli_u8(shape, p_one, seed, device, seed_dev=None):
+    out = torch.empty(shape, device=device, dtype=torch.uint8)
+    check(_lib.load().fcl_bernoulli_u8(_p(out, torch.uint8), out.numel(), float(p_one), seed & 0xFFFFFFFF, _p(seed_dev, torch.int32), _stream()))
+    return out
 
 
 def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None, zone_keep_c=None, row_len=None, step=0, out=None):

@@ -82,10 +82,11 @@ int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int
 
 /* ---- H4/H5: channel LayerNorm (+ the predictor's Linear(C->1) and masked_fill) ---------------------- */
 /* y[m,:] = LN(x[m,:]) * gamma + beta (y may be NULL).  If lin_w != NULL:
- * scalar[m] = pad_mask[m] ? 0 : (y[m,:] . lin_w + lin_b[0])   (variance_predictor.py:90-93). */
+ * scalar[m] = pad_mask[m] ? 0 : (y[m,:] . lin_w + lin_b[0])   (variance_predictor.py:90-93).
+ * keep != NULL (training): the Dropout after the LayerNorm, y *= keep[m,c] * keep_scale before it is stored / fed to the head. */
 int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y,
-                      const float* lin_w, const float* lin_b, const uint8_t* pad_mask, float* scalar,
-                      int m, int c, fcl_stream_t stream);
+                      const float* lin_w, const float* lin_b, const uint8_t* pad_mask, const uint8_t* keep, float keep_scale,
+                      float* scalar, int m, int c, fcl_stream_t stream);
 
 /* ---- H4: DurationPredictor.inference rounding (ESPnet; call site ..._kd_student.py:825) ------------- */
 /* out = pad_mask ? 0 : (int64) max(rint(linear_domain ? x : exp(x) - offset), 0); rint = half-to-even. */
@@ -225,7 +226,8 @@ int fcl_masked_l1_mse_fwd(const float* a, int lda, const float* b, int ldb, cons
  * Accumulates with fp32 atomics (the caller zeroes c once per step: gradient accumulation is the natural mode). */
 int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift,
                     const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream);
-/* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm). */
+/* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm)
+ * | x*(y - b[c])*g[c] (mode 3: b = batch mean, g = invstd: gamma gradient of a train-mode BatchNorm). */
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream);
 /* dst[r, 0:cols] += alpha * src[r, 0:cols] on rows with row_valid[r] != 0 (null: every row).  Strided on both sides: accumulates a
  * gradient block into a column range of weight_ih / feat_out.weight, adds residual-path gradients, masks padded rows. */
@@ -241,8 +243,21 @@ int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, in
                     float w_mse, double count, float* da, int accumulate, fcl_stream_t stream);
 /* Channel LayerNorm backward (+ the predictor's scalar head: ds = gradient of scalar[m]).  dgamma/dbeta/dlin_w/dlin_b accumulate. */
 int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,
-                      const uint8_t* pad_mask, float* dx, float* dgamma, float* dbeta, float* dlin_w, float* dlin_b, int m, int c,
-                      fcl_stream_t stream);
+                      const uint8_t* pad_mask, const uint8_t* keep, float keep_scale, float* dx, float* dgamma, float* dbeta, float* dlin_w,
+                      float* dlin_b, int m, int c, fcl_stream_t stream);
+/* Train-mode BatchNorm1d over the rows of z [M, C] (encoder_sa.py:61-78, decoder_sa.py:199-263 under model.train(): statistics over every
+ * position of the padded batch).  stats: mean / 1/sqrt(biased var + eps) accumulated in fp64 (workspace: 2*C doubles), running statistics
+ * updated as torch (momentum 0.1, unbiased variance) when given.  act: y_act = act(gamma*zhat + beta), y_drop = y_act*keep*keep_scale.
+ * bwd: dz = gamma*invstd*(dy - dbeta/M - zhat*dgamma/M) with THIS batch's dbeta = sum dy, dgamma = sum dy*zhat (fcl_colsum_fwd modes 0 / 3). */
+int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                     double* workspace, fcl_stream_t stream);
+int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
+                   float* y_act, float* y_drop, int m, int c, int act, fcl_stream_t stream);
+int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
+               float* dz, int m, int c, fcl_stream_t stream);
+/* out[i] = 1 with probability p_one: counter hash of (seed + *seed_dev, i).  The training path's source of dropout keep masks
+ * (p_one = 1 - p) and zoneout keep-old masks (p_one = zoneout rate); not bit-compatible with torch's Philox stream by design. */
+int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const uint32_t* seed_dev, fcl_stream_t stream);
 /* LSTMCell + zoneout backward of one step from the forward's saved gate activations [M,4U] (i,f,g,o), c_old and c_new (raw):
  * dgates [M,4U] (pre-activation), dh_old (zoneout keep path), dc_old.  The caller adds dgates . W_hh to dh_old. */
 int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dc_out, float zoneout,

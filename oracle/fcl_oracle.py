@@ -62,6 +62,10 @@ def batch_norm_train(y, sd, p):
     return (y - mean) / torch.sqrt(var + BN_EPS) * g[None, :, None] + b[None, :, None]
 
 
+def _t(a):
+    return a if torch.is_tensor(a) else torch.from_numpy(a)
+
+
 def _drop(x, keep, p):
     """Inverted dropout with an explicit {0,1} keep mask (same maths as F.dropout(training=True))."""
     if keep is None:
@@ -124,11 +128,13 @@ def blstm_packed(sd, x_btc, ilens, prefix="enc.blstm"):
     return torch.cat(outs, dim=2)
 
 
-def encoder_forward(sd, hp, xs, ilens, bn_train=False):
+def encoder_forward(sd, hp, xs, ilens, bn_train=False, keeps=None):
     """Batched Encoder.forward (encoder_sa_kd.py:144-197): returns (enc_out [B,T,C], taps) where taps =
-    [embed, conv0, conv1, conv2] as [B,T,C] (un-projected; student projections are applied by callers)."""
+    [embed, conv0, conv1, conv2] as [B,T,C] (un-projected; student projections are applied by callers).
+    keeps: optional per-layer dropout keep masks [B,T,C] (train form)."""
     emb = F.embedding(xs, sd["enc.embed.weight"], padding_idx=0)  # H1
-    taps = encoder_convs(sd, emb.transpose(1, 2), hp.econv_layers, bn_train)
+    kt = None if keeps is None else [_t(k).transpose(1, 2) for k in keeps]
+    taps = encoder_convs(sd, emb.transpose(1, 2), hp.econv_layers, bn_train, kt, hp.dropout_rate)
     enc = blstm_packed(sd, taps[-1].transpose(1, 2), ilens)
     return enc, [emb] + [t.transpose(1, 2) for t in taps]
 
@@ -152,10 +158,11 @@ def predictor_trunk(sd, prefix, hs_btc, n_layers, keeps=None, p=0.0):
     return F.linear(x.transpose(1, 2), sd[prefix + ".linear.weight"], sd[prefix + ".linear.bias"])  # [B,T,1]
 
 
-def duration_predictor(sd, hp, hs_btc, pad_mask, inference=False):
+def duration_predictor(sd, hp, hs_btc, pad_mask, inference=False, keeps=None):
     """H4 — ESPnet DurationPredictor.forward / .inference (call sites ..._kd_student.py:716,825).
     inference: clamp(round(exp(x) - 1.0), min=0).long(); torch.round is half-to-even."""
-    y = predictor_trunk(sd, "duration_predictor", hs_btc, hp.duration_predictor_layers).squeeze(-1)
+    kt = None if keeps is None else [_t(k).transpose(1, 2) for k in keeps]
+    y = predictor_trunk(sd, "duration_predictor", hs_btc, hp.duration_predictor_layers, kt, hp.duration_predictor_dropout_rate).squeeze(-1)
     if inference:
         y = torch.clamp(torch.round(y.exp() - 1.0), min=0).long()
     if pad_mask is not None:
@@ -168,18 +175,19 @@ def duration_round(logits):
     return torch.clamp(torch.round(logits.exp() - 1.0), min=0).long()
 
 
-def variance_predictor(sd, hp, name, hs_btc, pad_mask):
+def variance_predictor(sd, hp, name, hs_btc, pad_mask, keeps=None):
     """H5 — VariancePredictor.forward (variance_predictor.py:74-95): [B,T,1], masked_fill 0."""
-    y = predictor_trunk(sd, name + "_predictor", hs_btc, hp.variance_predictor_layers)
+    kt = None if keeps is None else [_t(k).transpose(1, 2) for k in keeps]
+    y = predictor_trunk(sd, name + "_predictor", hs_btc, hp.variance_predictor_layers, kt, hp.variance_predictor_dropout_rate)
     if pad_mask is not None:
         y = y.masked_fill(pad_mask.unsqueeze(-1), 0.0)
     return y
 
 
-def variance_embed(sd, name, v_bt1):
+def variance_embed(sd, name, v_bt1, keep=None, p=0.5):
     """pitch_embed / energy_embed: Conv1d(1->C, k9, pad 4, bias) (+Dropout in train) — ..._kd_student.py:567-600."""
     w, b = sd[name + "_embed.0.weight"], sd[name + "_embed.0.bias"]
-    return F.conv1d(v_bt1.transpose(1, 2), w, b, 1, (w.shape[2] - 1) // 2).transpose(1, 2)
+    return _drop(F.conv1d(v_bt1.transpose(1, 2), w, b, 1, (w.shape[2] - 1) // 2).transpose(1, 2), None if keep is None else _t(keep), p)
 
 
 def position_table(ds_nonzero):
@@ -244,7 +252,7 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
         if isinstance(prenet_keep, str):  # "rng": the reference's always-on F.dropout with fresh Bernoulli masks
             kp = [(torch.rand(N, hp.prenet_units) >= hp.dropout_rate) for _ in range(2)] if hp.dropout_rate > 0 else None
         else:
-            kp = None if prenet_keep is None else prenet_keep[t]
+            kp = None if prenet_keep is None else [_t(k) for k in prenet_keep[t]]
         pre = prenet(sd, prev, kp, hp.dropout_rate if kp is not None else 0.5)
         pres.append(pre)
         xs = torch.cat([att_c, pre, position[:, t].reshape(-1, 1)], dim=1)
@@ -346,7 +354,7 @@ def convert_batch(xs, ys, ds, f0, energy):
 
 # ----------------------------------------------------------------------------- teacher-forced forward
 def decoder_forward(sd, hp, hs, olens, new_ys, non_zero_lens_mask, ds_nonzeros, output_masks, position,
-                    p_embs, e_embs, prenet_keep=None, zone_keep=None, bn_train=False):
+                    p_embs, e_embs, prenet_keep=None, zone_keep=None, bn_train=False, post_keeps=None):
     """Decoder.forward (decoder_sa_kd.py:523-704), un-projected taps.
 
     Returns after [B,L,odim], before [B,L,odim], taps = [prenet [B,L,P], lstm0, lstm1 [B,L,U],
@@ -366,7 +374,8 @@ def decoder_forward(sd, hp, hs, olens, new_ys, non_zero_lens_mask, ds_nonzeros, 
         return pad_list(segs, 0)
 
     before = regroup(outs.transpose(1, 2))  # [B, L, odim]
-    post = postnet(sd, hp, before.transpose(1, 2), bn_train)
+    post = postnet(sd, hp, before.transpose(1, 2), bn_train, None if post_keeps is None else [_t(k).transpose(1, 2) for k in post_keeps],
+                   hp.dropout_rate)
     after = before + post[-1].transpose(1, 2)
     taps = [regroup(pres), regroup(l0), regroup(l1)] + [p.transpose(1, 2) for p in post]
     return after, before, taps
@@ -394,31 +403,67 @@ def knowledge_loss(student, teacher, lens):
     return loss
 
 
+def masks_from_sequence(seq, hp):
+    """Names the keep masks a train-mode forward() of the reference consumes, in its call order (..._sa.py:553-590, decoder_sa.py:472-531):
+    encoder conv dropouts, duration / pitch / energy predictor dropouts, pitch / energy embed dropouts, then per decoder step
+    {prenet x2, zoneout layer0 (h, c), layer1 (h, c)}, then the postnet dropouts.  seq: list of uint8 arrays in the reference's own
+    layouts ([B,C,T] for conv-side masks); returned in row-major [B,T,C] layouts."""
+    import numpy as np
+
+    it = iter(seq)
+    bct = lambda: np.ascontiguousarray(np.transpose(next(it), (0, 2, 1)))
+    m = {"enc.convs": [bct() for _ in range(hp.econv_layers)] if hp.dropout_rate > 0 else None}
+    m["duration_predictor"] = [bct() for _ in range(hp.duration_predictor_layers)]
+    m["pitch_predictor"] = [bct() for _ in range(hp.variance_predictor_layers)]
+    m["energy_predictor"] = [bct() for _ in range(hp.variance_predictor_layers)]
+    m["pitch_embed"], m["energy_embed"] = bct(), bct()
+    rest = list(it)
+    n_post = hp.postnet_layers if hp.dropout_rate > 0 else 0
+    dec, post = rest[: len(rest) - n_post], rest[len(rest) - n_post:]
+    per = (2 if hp.dropout_rate > 0 else 0) + 4
+    assert len(dec) % per == 0
+    steps = len(dec) // per
+    pk, zk = [], []
+    for t in range(steps):
+        g = dec[t * per : (t + 1) * per]
+        if hp.dropout_rate > 0:
+            pk.append(np.stack(g[:2]))
+            g = g[2:]
+        zk.append(np.stack([np.stack(g[0:2]), np.stack(g[2:4])]))
+    m["prenet"] = np.stack(pk) if pk else None  # [steps, 2, N, P]
+    m["zoneout"] = np.stack(zk)  # [steps, layer, (h, c), N, U]
+    m["postnet"] = [np.ascontiguousarray(np.transpose(a, (0, 2, 1))) for a in post] if n_post else None
+    return m
+
+
 def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher_knowledge=None,
-                  prenet_keep=None, bn_train=False):
-    """Tacotron2_sa.forward in eval-dropout-off mode (all nn.Dropout inactive, zoneout eval form).
+                  prenet_keep=None, bn_train=False, masks=None):
+    """Tacotron2_sa.forward.  Default: eval-dropout-off mode (all nn.Dropout inactive, zoneout eval form).
+    masks (see masks_from_sequence) + bn_train=True: the train-mode graph with every Bernoulli draw injected.
 
     role: "teacher" (..._sa.py:520-622 -> dict of named losses), "kd_teacher"
     (..._kd_teacher.py:521-603 -> 5-tuple), "student" (..._kd_student.py:673-802 -> dict of losses)."""
     xs, ilens, ys, olens = batch["xs"], batch["ilens"], batch["ys"], batch["olens"]
     xs = xs[:, : int(max(ilens))]
     ys = ys[:, : int(max(olens))]
-    hs, enc_taps = encoder_forward(sd, hp, xs, ilens, bn_train)
+    mk = masks or {}
+    hs, enc_taps = encoder_forward(sd, hp, xs, ilens, bn_train, mk.get("enc.convs"))
     ds = batch["extras"].squeeze(-1)
     pad = make_pad_mask(ilens)
-    d_outs = duration_predictor(sd, hp, hs, pad)  # log domain, masked_fill 0
+    d_outs = duration_predictor(sd, hp, hs, pad, keeps=mk.get("duration_predictor"))  # log domain, masked_fill 0
     nonpad = ~pad
     dur_loss = ((d_outs.masked_select(nonpad) - torch.log(ds.masked_select(nonpad).float() + 1.0)) ** 2).mean()
-    p_outs = variance_predictor(sd, hp, "pitch", hs, pad)
-    e_outs = variance_predictor(sd, hp, "energy", hs, pad)
+    p_outs = variance_predictor(sd, hp, "pitch", hs, pad, mk.get("pitch_predictor"))
+    e_outs = variance_predictor(sd, hp, "energy", hs, pad, mk.get("energy_predictor"))
     m1 = nonpad.unsqueeze(-1)
     pitch_loss = _masked_mean_l1_mse(p_outs, batch["f0"], m1)[1]
     energy_loss = _masked_mean_l1_mse(e_outs, batch["energy"], m1)[1]
-    p_embs = variance_embed(sd, "pitch", batch["f0"])  # ground-truth f0/energy feed the embeds in forward()
-    e_embs = variance_embed(sd, "energy", batch["energy"])
+    p_embs = variance_embed(sd, "pitch", batch["f0"], mk.get("pitch_embed"), hp.variance_embed_dropout_rate)  # ground-truth f0/energy feed the embeds
+    e_embs = variance_embed(sd, "energy", batch["energy"], mk.get("energy_embed"), hp.variance_embed_dropout_rate)
     after, before, dec_taps = decoder_forward(
         sd, hp, hs, olens, batch["new_ys"], batch["non_zero_lens_mask"], batch["ds_nonzeros"],
-        batch["output_masks"], batch["position"], p_embs, e_embs, prenet_keep, None, bn_train)
+        batch["output_masks"], batch["position"], p_embs, e_embs, prenet_keep if masks is None else mk.get("prenet"),
+        None if mk.get("zoneout") is None else _t(mk["zoneout"]), bn_train, mk.get("postnet"))
     if role == "kd_teacher":
         return after, before, enc_taps + [hs], dec_taps, [d_outs.unsqueeze(-1), p_outs, e_outs, p_embs, e_embs]
     l1, mse = taco2_loss(after, before, ys, olens)

@@ -363,6 +363,119 @@ def gen_g6(rec):
     print("records.json", rec)
 
 
+@contextlib.contextmanager
+def injected_randomness(log):
+    """Train-mode goldens: every Bernoulli draw of a training forward -- F.dropout (nn.Dropout and the prenet) and ZoneOutCell's
+    `h.new(...).bernoulli_(p)` (decoder_sa.py:93) -- is replaced by closed_form_keep_mask(shape, seed=<draw counter>) and appended to `log`,
+    so the reference, the oracle and the HIP path consume identical masks."""
+    import torch.nn.functional as F
+
+    orig_drop, orig_bern = F.dropout, torch.Tensor.bernoulli_
+
+    def fake_dropout(x, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return x
+        keep = SYN.closed_form_keep_mask(tuple(x.shape), 1000 + len(log))
+        log.append(keep)
+        return x * torch.from_numpy(keep).to(x.dtype) * (1.0 / (1.0 - p))
+
+    def fake_bernoulli_(self, p=0.5, generator=None):
+        keep = SYN.closed_form_keep_mask(tuple(self.shape), 1000 + len(log))
+        log.append(keep)
+        self.copy_(torch.from_numpy(keep).to(self.dtype))
+        return self
+
+    F.dropout, torch.Tensor.bernoulli_ = fake_dropout, fake_bernoulli_
+    try:
+        yield
+    finally:
+        F.dropout, torch.Tensor.bernoulli_ = orig_drop, orig_bern
+
+
+GRAD_KEYS = ["dec.feat_out.weight", "enc.embed.weight", "duration_predictor.linear.weight", "dec.lstm.0.cell.weight_hh",
+             "dec.prenet.prenet.0.0.bias", "pitch_embed.0.weight", "dec.postnet.postnet.4.0.weight", "enc.blstm.weight_hh_l0_reverse",
+             "enc.convs.1.1.weight", "dec.postnet.postnet.0.1.bias", "energy_predictor.conv.1.2.weight", "dec.lstm.1.cell.bias_ih"]
+KD_KEYS = ["enc.embed_proj.weight", "enc.convs_proj.0.weight", "enc.blstm_proj.weight", "dec.prenet_proj.weight", "dec.lstm_proj.weight",
+           "dec.post_proj.weight", "pemb_proj.weight", "eemb_proj.weight"]
+
+
+def _grads(model, keys, d):
+    named = dict(model.named_parameters())
+    for k in keys:
+        d["grad:" + k] = t2n(named[k].grad).copy()
+    gn = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.requires_grad], 1.0)
+    d["grad_norm"] = np.float32(float(gn))
+
+
+def _named_losses(model, d, prefix=""):
+    for item in model.reporter.last:
+        for k, v in item.items():
+            d[prefix + k] = np.float32(v)
+
+
+def gen_g7_g8_g9():
+    """G7: teacher step in TRAIN mode (batch-stat BatchNorm, every dropout and zoneout draw injected) -- loss, gradients, running statistics.
+    G8: student KD step, eval form (teacher knowledge from the eval-mode KD teacher): loss and gradients incl. the projections.
+    G9: the reference's KD update (tts_distill.py:159-161) in train mode: frozen train-mode teacher -> student forward/backward."""
+    T7 = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20,
+                            duration_predictor_chans=20, dropout_rate=0.5)
+    S7 = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12,
+                            duration_predictor_chans=20, dropout_rate=0.5)
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    # ---- G7
+    te, _ = build("teacher", T7)
+    te.train()
+    log = []
+    with injected_randomness(log):
+        loss = te(**b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), n_masks=np.int64(len(log)))
+    _named_losses(te, d)
+    _grads(te, GRAD_KEYS, d)
+    sd = te.state_dict()
+    for k in ("enc.convs.0.1.running_mean", "enc.convs.0.1.running_var", "dec.postnet.postnet.4.1.running_mean", "dec.postnet.postnet.4.1.running_var",
+              "enc.convs.0.1.num_batches_tracked"):
+        if k in sd:
+            d["buf:" + k] = t2n(sd[k]).copy()
+    for i, mk in enumerate(log):
+        d["mask%03d" % i] = mk
+    save("g7_teacher_train_mode", **d)
+    # ---- G8
+    kt, _ = build("kd_teacher", TINY_T)
+    with torch.no_grad():
+        know = kt(**b)
+    st, _ = build("student", TINY_S, TINY_T, True)
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(st, d)
+    _grads(st, [k for k in GRAD_KEYS] + KD_KEYS, d)
+    save("g8_student_kd_eval", **d)
+    # ---- G9
+    kt, _ = build("kd_teacher", T7)
+    for p in kt.parameters():
+        p.requires_grad = False  # tts_distill.py:398
+    kt.train()
+    st, _ = build("student", S7, T7, True)
+    st.train()
+    tlog, slog = [], []
+    with injected_randomness(tlog):
+        know = kt(**b)
+    with injected_randomness(slog):
+        loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), n_tmasks=np.int64(len(tlog)), n_smasks=np.int64(len(slog)), t_after=t2n(know[0]),
+             t_dec1=t2n(know[3][1]), t_pro3=t2n(know[4][3]))
+    _named_losses(st, d)
+    _grads(st, [k for k in GRAD_KEYS] + KD_KEYS, d)
+    d["buf:teacher.enc.convs.0.1.running_mean"] = t2n(kt.state_dict()["enc.convs.0.1.running_mean"]).copy()
+    for i, mk in enumerate(tlog):
+        d["tmask%03d" % i] = mk
+    for i, mk in enumerate(slog):
+        d["smask%03d" % i] = mk
+    save("g9_kd_step_train_mode", **d)
+
+
 def main():
     assert os.path.isdir(REF), "gen_golden.py needs /root/reference (survey container only)"
     os.makedirs(OUT, exist_ok=True)
@@ -373,6 +486,7 @@ def main():
     gen_g4()
     gen_g5()
     gen_g6(rec)
+    gen_g7_g8_g9()
 
 
 if __name__ == "__main__":

@@ -10,6 +10,11 @@ TINY_S = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chan
                             postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0)
 TINY_T = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                             postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0)
+# the train-mode goldens (G7, G9) use the same shapes (hence the same closed-form weights) with the shipped dropout rate
+TINY_S7 = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20,
+                             postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.5)
+TINY_T7 = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
+                             postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.5)
 
 
 def np_state_dict(hp, thp=None, share_proj=True):

@@ -162,6 +162,71 @@ def test_g5_training_gradients(golden):
     assert abs(float(gn) - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
 
 
+def _grad_sd(hp, thp=None, share=True):
+    return {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v)
+            for k, v in torch_state_dict(hp, thp, share).items()}
+
+
+def _check_grads(sd, g, tol=1e-4):
+    n = 0
+    for k in g:
+        if k.startswith("grad:"):
+            n += 1
+            ref = g[k]
+            assert max_abs(sd[k[5:]].grad, ref) < tol * max(1.0, float(np.abs(ref).max())), k
+    params = [v for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad and v.grad is not None]
+    gn = torch.sqrt(sum((p.grad ** 2).sum() for p in params))
+    assert abs(float(gn) - float(g["grad_norm"])) < 1e-3 * float(g["grad_norm"])
+    return n
+
+
+def test_g7_teacher_train_mode_with_injected_masks(golden):
+    """The oracle's TRAIN form (batch-statistics BatchNorm, every dropout / zoneout draw injected) vs the real reference in model.train()."""
+    from helpers import TINY_T7
+
+    g4, g = golden("g4_integer"), golden("g7_teacher_train_mode")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    masks = O.masks_from_sequence([g["mask%03d" % i] for i in range(int(g["n_masks"]))], TINY_T7)
+    sd = _grad_sd(TINY_T7)
+    rep = O.model_forward(sd, TINY_T7, b, "teacher", bn_train=True, masks=masks)
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), k
+    assert _check_grads(sd, g) >= 12
+
+
+def test_g8_student_kd_gradients_eval_form(golden):
+    g4, g1, g = golden("g4_integer"), golden("g1_forward"), golden("g8_student_kd_eval")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    know = (torch.from_numpy(g1["t_after"]), torch.from_numpy(g1["t_before"]), [torch.from_numpy(g1["t_enc%d" % i]) for i in range(5)],
+            [torch.from_numpy(g1["t_dec%d" % i]) for i in range(8)], [torch.from_numpy(g1["t_pro%d" % i]) for i in range(5)])
+    sd = _grad_sd(TINY_S, TINY_T, True)
+    rep = O.model_forward(sd, TINY_S, b, "student", TINY_T, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "output_l1_loss", "output_mse_loss", "encoder_loss", "decoder_loss", "prosody_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), k
+    assert _check_grads(sd, g) >= 20
+
+
+def test_g9_kd_step_train_mode(golden):
+    """tts_distill.py:159-161 in train mode: frozen train-mode teacher (its own masks) -> student forward/backward (its masks)."""
+    from helpers import TINY_S7, TINY_T7
+
+    g4, g = golden("g4_integer"), golden("g9_kd_step_train_mode")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    tm = O.masks_from_sequence([g["tmask%03d" % i] for i in range(int(g["n_tmasks"]))], TINY_T7)
+    sm = O.masks_from_sequence([g["smask%03d" % i] for i in range(int(g["n_smasks"]))], TINY_S7)
+    with torch.no_grad():
+        know = O.model_forward(torch_state_dict(TINY_T7), TINY_T7, b, "kd_teacher", bn_train=True, masks=tm)
+    assert max_abs(know[0], g["t_after"]) < TOL_STAGE and max_abs(know[3][1], g["t_dec1"]) < TOL_STAGE and max_abs(know[4][3], g["t_pro3"]) < TOL_STAGE
+    sd = _grad_sd(TINY_S7, TINY_T7, True)
+    rep = O.model_forward(sd, TINY_S7, b, "student", TINY_T7, True, know, bn_train=True, masks=sm)
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "output_l1_loss", "output_mse_loss", "encoder_loss", "decoder_loss", "prosody_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), k
+    assert _check_grads(sd, g) >= 20
+
+
 def test_g6_padding_leak_and_zero_duration(golden):
     g = golden("g6_padding_leak")
     rec = json.load(open(os.path.join(GOLDEN, "records.json")))
