@@ -80,6 +80,7 @@ SIGNATURES = {
     "fcl_bn_stats_fwd": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "fcl_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
     "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_scale": (_I, [_P, _Z, _F, _P]),
     "fcl_bernoulli_u8": (_I, [_P, _Z, _F, C.c_uint32, _P, _P]),
     "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),

@@ -345,6 +345,10 @@ __global__ void bernoulli_u8_kernel(uint8_t* __restrict__ out, long long n, unsi
     }
 }
 
+__global__ void scale_kernel(float* __restrict__ x, long long n, float alpha) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= alpha;
+}
+
 __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -535,6 +539,13 @@ int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const u
     const unsigned int thresh = (unsigned int)((double)p_one * 16777216.0 + 0.5);  // 24-bit uniform
     hipLaunchKernelGGL(bernoulli_u8_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, thresh, seed, seed_dev);
     return check_hip(hipGetLastError(), "bernoulli_u8");
+}
+
+int fcl_scale(float* x, size_t n, float alpha, fcl_stream_t stream) {
+    FCL_REQUIRE(x, FCL_ERR_INVALID, "scale: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scale_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, alpha);
+    return check_hip(hipGetLastError(), "scale");
 }
 
 int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream) {

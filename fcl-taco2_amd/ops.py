@@ -254,6 +254,11 @@ def bn_bwd(dy, z, mean, invstd, gamma, dbeta, dgamma):
     return dz
 
 
+def scale_(x, alpha):
+    check(_lib.load().fcl_scale(_p(x), x.numel(), float(alpha), _stream()))
+    return x
+
+
 def bernoulli_u8(shape, p_one, seed, device, seed_dev=None):
     out = torch.empty(shape, device=device, dtype=torch.uint8)
     check(_lib.load().fcl_bernoulli_u8(_p(out, torch.uint8), out.numel(), float(p_one), seed & 0xFFFFFFFF, _p(seed_dev, torch.int32), _stream()))

@@ -1,47 +1,142 @@
-"""Teacher-forced training step on the HIP path: forward with saved activations, backward, clip + Adam.
+"""The training step on the HIP path: forward with saved activations, backward, clip + Adam, data-parallel all-reduce.
 
-Restates the reference's `CustomUpdater.update_core` (tts.py:137-179; KD: tts_distill.py:143-182):
-    loss = model(**batch).mean() / accum_grad ; loss.backward() ; clip_grad_norm_(params, grad_clip) ; skip if NaN ; Adam.step()
-with every FLOP in libfcl_hip.so (forward GEMMs reuse the synthesis kernels; gradients use the primitives of backward.hip).
-torch supplies device memory only; there is no autograd graph.
+Restates the reference's update (teacher: tts.py:137-179; KD: tts_distill.py:143-182):
+    [teacher_knowledge = teacher(**x)]  loss = model(**x).mean() / accum_grad ; loss.backward()
+    clip_grad_norm_(params, grad_clip) ; skip if NaN ; Adam.step() ; zero_grad()
+with every FLOP in libfcl_hip.so (forward GEMMs reuse the synthesis kernels; gradients use backward.hip).  torch supplies device memory,
+streams and torch.distributed only; there is no autograd graph.
 
-Regulariser semantics implemented so far — the EVALUATION form of every stochastic layer, i.e. exactly the graph the
-reference builds under `model.eval()` (BatchNorm = affine map with running statistics, nn.Dropout off, zoneout in its
-expectation form decoder_sa.py:96, prenet dropout through explicit masks or off).  This is the configuration the real
-reference's gradients are pinned on (tests/golden/g5_teacher_train.npz).  Train-mode BatchNorm statistics and sampled
-dropout / zoneout masks are the next increment.
+Two forms of the stochastic layers, both pinned against the real reference (tests/golden/g5, g7, g8, g9):
+  mode="eval"   the graph the reference builds under model.eval(): BatchNorm = affine map of the running statistics, nn.Dropout off, zoneout in
+                its expectation form (decoder_sa.py:96); the prenet's dropout stays on whenever dropout_rate > 0 (decoder_sa.py:156-158);
+  mode="train"  model.train(): BatchNorm normalises with the statistics of ALL positions of the padded batch and updates the running buffers,
+                Dropout after every encoder / postnet conv block, after every predictor LayerNorm and after the pitch / energy embeds, zoneout
+                samples keep-old masks for h and c (decoder_sa.py:92-94).
+Every Bernoulli draw is either injected (`masks=`, the layouts of oracle.masks_from_sequence: how the goldens pin this path) or produced on the
+device by fcl_bernoulli_u8 (production; statistically, not bit-wise, torch's stream).
 
-Layouts: encoder rows (b, t) -> b*T + t, frame rows (b, l) -> b*L + l (both zero padded like the reference's batch), decoder
-cells in STEP-MAJOR order: phoneme rows sorted by duration (descending), cell (t, m) at offset[t] + m with offset[t] = sum of
-live rows of the earlier steps, so the live rows of every step are one contiguous slice of every saved tensor.
+Layouts: encoder rows (b, t) -> b*T + t, frame rows (b, l) -> b*L + l (zero padded like the reference's batch), decoder cells STEP-MAJOR: phoneme
+rows sorted by duration (descending), cell (t, m) at offset[t] + m, so the live rows of a step are one contiguous slice of every saved tensor.
+Gradients, Adam moments and (re-pointed) parameters live in three flat buffers ordered by when backward finishes them, so the optimizer is one
+launch and the all-reduce runs over contiguous buckets while backward is still producing the later ones.
 """
+import zlib
+
 import numpy as np
 import torch
 
 from . import ops
 from .plan import BN_EPS, LN_EPS
 
+BN_MOMENTUM = 0.1  # torch.nn.BatchNorm1d default
+
+# parameter groups in the order backward completes them (= all-reduce bucket order)
+_GROUPS = (("dec.postnet.", "dec.post_proj", "dec.post0_proj", "dec.post1_proj", "dec.post2_proj", "dec.post3_proj"),
+           ("dec.",),
+           ("pitch_embed.", "energy_embed.", "pemb_proj", "eemb_proj", "duration_predictor.", "pitch_predictor.", "energy_predictor."),
+           ("enc.",))
+
 
 def _i32(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
 
 
+def _u8(a, dev):
+    if torch.is_tensor(a):
+        return a.to(device=dev, dtype=torch.uint8).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8)).to(dev)
+
+
+def group_of(name):
+    for g, prefixes in enumerate(_GROUPS):
+        if any(name.startswith(p) for p in prefixes):
+            return g
+    return len(_GROUPS) - 1
+
+
+class GradBuckets(object):
+    """Bucketed gradient averaging over torch.distributed (RCCL on GPUs, gloo in the CPU tests).  launch(i) may be called as soon as bucket i
+    is final; the collective runs on the backend's own stream while the caller keeps producing the later buckets; finish() waits for all."""
+
+    def __init__(self, flat, bounds, group=None):
+        import torch.distributed as dist
+
+        self.flat, self.bounds, self.group, self.work = flat, bounds, group, []
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.avg = self.world > 1 and dist.get_backend(group) == "nccl"
+
+    def launch(self, i):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+
+        a, b = self.bounds[i], self.bounds[i + 1]
+        if b > a:
+            op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+            self.work.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
+
+    def finish(self, scale_fn=None):
+        for w in self.work:
+            w.wait()
+        self.work = []
+        if self.world > 1 and not self.avg:
+            (scale_fn or (lambda t, s: t.mul_(s)))(self.flat, 1.0 / self.world)
+
+
+def flat_layout(names_sizes):
+    """Order parameters by backward-completion group; returns (ordered names, offsets [n+1], bucket bounds [len(_GROUPS)+1])."""
+    order = sorted(range(len(names_sizes)), key=lambda i: (group_of(names_sizes[i][0]), i))
+    names = [names_sizes[i][0] for i in order]
+    sizes = [(names_sizes[i][1] + 63) // 64 * 64 for i in order]  # 256-byte aligned slots (kernels want 16-byte aligned rows); padding stays 0
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    bounds = [0]
+    for g in range(len(_GROUPS)):
+        last = [j for j, n in enumerate(names) if group_of(n) <= g]
+        bounds.append(int(offs[last[-1] + 1]) if last else bounds[-1])
+    return names, offs, bounds
+
+
+class _Ctx(object):
+    pass
+
+
 class TrainEngine(object):
-    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0):
+    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("fcl-taco2_amd: TrainEngine needs the model on a GPU (no CPU fallback)")
-        if model.role != "teacher":
-            raise NotImplementedError("fcl-taco2_amd: TrainEngine covers the teacher step; the KD student step is the next increment")
-        self.model, self.hp, self.dev = model, model.hp, p0.device
-        self.P = {k: v.data for k, v in model.named_parameters()}  # master weights: the module's own storage
-        self.B = {k: v for k, v in model.named_buffers()}
-        self.G = {k: torch.zeros_like(v) for k, v in self.P.items()}
-        self.m = {k: torch.zeros_like(v) for k, v in self.P.items()}
-        self.v = {k: torch.zeros_like(v) for k, v in self.P.items()}
-        self.lr, self.eps, self.betas, self.grad_clip = lr, eps, betas, grad_clip
-        self.step_count = 0
+        self.model, self.hp, self.dev, self.role = model, model.hp, p0.device, model.role
+        self.share_proj = bool(getattr(model, "share_proj", True))
+        self.distill = tuple(bool(getattr(model, "distill_%s_knowledge" % k, True)) for k in ("output", "encoder", "decoder", "prosody"))
+        pd = dict(model.named_parameters())
+        names, offs, bounds = flat_layout([(k, v.numel()) for k, v in pd.items()])
+        total = int(offs[-1])
+        self.pflat = torch.empty(total, device=self.dev)
+        self.gflat, self.mflat, self.vflat = (torch.zeros(total, device=self.dev) for _ in range(3))
+        self.P, self.G = {}, {}
+        for k, o in zip(names, offs[:-1]):
+            n = pd[k].numel()
+            view = self.pflat[o : o + n].view(pd[k].shape)
+            view.copy_(pd[k].data)
+            pd[k].data = view  # the module's parameters now live in the flat buffer: state_dict() / plan() see every update
+            self.P[k] = view
+            self.G[k] = self.gflat[o : o + n].view(pd[k].shape)
+        self.buckets = GradBuckets(self.gflat, bounds, group)
+        self.B = dict(model.named_buffers())
+        self.lr, self.eps, self.betas, self.grad_clip, self.accum_grad = lr, eps, betas, grad_clip, int(accum_grad)
+        self.step_count, self.forward_count, self.seed = 0, 0, int(seed)
         self.gn_sq = torch.zeros(1, dtype=torch.float64, device=self.dev)
+
+    # ------------------------------------------------------------------------------------------------ randomness
+    def _keep(self, c, name, shape, p_one):
+        """uint8 mask [shape] with P(1) = p_one: injected (c.masks) or drawn on the device."""
+        if c.masks is not None:
+            m = c.masks
+            for part in name:
+                m = m[part]
+            return _u8(m, self.dev).reshape(shape)
+        tag = zlib.crc32(repr(name).encode()) & 0x7FFFFFFF
+        return ops.bernoulli_u8(shape, p_one, self.seed * 7919 + c.draw * 104729 + tag, self.dev)
 
     # ------------------------------------------------------------------------------------------------ layers
     def _wt(self, w):
@@ -53,64 +148,84 @@ class TrainEngine(object):
         wt = torch.stack([ops.transpose2d(wp[k - 1 - j]) for j in range(k)]).contiguous()  # [k, Cin, Cout], taps reversed
         return wp, wt
 
-    def _conv_bn_fwd(self, x, prefix, lo, hi, act):
-        """Conv1d(no bias) -> eval BatchNorm folded -> act.  Keeps z (pre-activation) for the gamma gradient."""
+    def _conv_bn_fwd(self, c, x, prefix, lo, hi, act, keep):
+        """Conv1d(no bias) -> BatchNorm -> act -> Dropout.  Returns (block output, cache)."""
         P, B = self.P, self.B
+        ks = 1.0 / (1.0 - self.hp.dropout_rate) if keep is not None else 1.0
+        if c.train:
+            wp, wt = self._conv_pack(P[prefix + ".0.weight"])
+            z = ops.conv1d(x, wp, None, lo, hi, ops.ACT_NONE)
+            mean, invstd = ops.bn_stats(z, BN_EPS, BN_MOMENTUM, B[prefix + ".1.running_mean"], B[prefix + ".1.running_var"])
+            if prefix + ".1.num_batches_tracked" in B:
+                B[prefix + ".1.num_batches_tracked"].add_(1)  # integer bookkeeping buffer of torch's BatchNorm
+            y_act, y = ops.bn_act(z, mean, invstd, P[prefix + ".1.weight"], P[prefix + ".1.bias"], act, keep, ks)
+            return y, dict(x=x, z=z, y_act=y_act, wt=wt, mean=mean, invstd=invstd, prefix=prefix, act=act, lo=lo, hi=hi, keep=keep, ks=ks)
         scale, shift = ops.fold_batchnorm(P[prefix + ".1.weight"], P[prefix + ".1.bias"], B[prefix + ".1.running_mean"], B[prefix + ".1.running_var"], BN_EPS)
         wp, wt = self._conv_pack(P[prefix + ".0.weight"], scale)
         z = ops.conv1d(x, wp, shift, lo, hi, ops.ACT_NONE)
         y = ops.act_fwd(z, act) if act != ops.ACT_NONE else z
-        return y, dict(x=x, z=z, y=y, wt=wt, scale=scale, prefix=prefix, act=act, lo=lo, hi=hi)
+        return y, dict(x=x, z=z, y_act=y, wt=wt, scale=scale, prefix=prefix, act=act, lo=lo, hi=hi, keep=None, ks=1.0)
 
-    def _conv_bn_bwd(self, dy, c):
+    def _conv_bn_bwd(self, c, dy, cc):
         G, P = self.G, self.P
-        pre = c["prefix"]
-        dz = ops.act_bwd(dy, c["y"], c["act"]) if c["act"] != ops.ACT_NONE else dy
-        ops.colsum(dz, G[pre + ".1.bias"])
-        ops.colsum(dz, G[pre + ".1.weight"], y=c["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
-        w = P[pre + ".0.weight"]
-        cout, cin, k = w.shape
+        pre = cc["prefix"]
+        dz = ops.act_bwd(dy, cc["y_act"], cc["act"], cc["keep"], cc["ks"]) if (cc["act"] != ops.ACT_NONE or cc["keep"] is not None) else dy
+        cout, cin, k = P[pre + ".0.weight"].shape
+        if c.train:
+            dbeta, dgamma = torch.zeros(cout, device=self.dev), torch.zeros(cout, device=self.dev)
+            ops.colsum(dz, dbeta)
+            ops.colsum(dz, dgamma, y=cc["z"], gamma=cc["invstd"], beta=cc["mean"], mode=3)
+            ops.add2d(G[pre + ".1.bias"].reshape(1, -1), dbeta.reshape(1, -1))
+            ops.add2d(G[pre + ".1.weight"].reshape(1, -1), dgamma.reshape(1, -1))
+            dz = ops.bn_bwd(dz, cc["z"], cc["mean"], cc["invstd"], P[pre + ".1.weight"], dbeta, dgamma)
+            scale = None
+        else:
+            ops.colsum(dz, G[pre + ".1.bias"])
+            ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
+            scale = cc["scale"]
         dwp = torch.zeros(k, cout, cin, device=self.dev)
         for j in range(k):
-            ops.gemm_tn(dz, c["x"], dwp[j], shift=j - (k - 1) // 2, seg_lo=c["lo"], seg_hi=c["hi"])
-        ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], c["scale"])
-        return ops.conv1d(dz, c["wt"], None, c["lo"], c["hi"])
+            ops.gemm_tn(dz, cc["x"], dwp[j], shift=j - (k - 1) // 2, seg_lo=cc["lo"], seg_hi=cc["hi"])
+        ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
+        return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
     def _conv_bias_relu_fwd(self, x, prefix, lo, hi):
         wp, wt = self._conv_pack(self.P[prefix + ".weight"])
         y = ops.conv1d(x, wp, self.P[prefix + ".bias"], lo, hi, ops.ACT_RELU)
         return y, dict(x=x, y=y, wt=wt, prefix=prefix, lo=lo, hi=hi)
 
-    def _conv_bias_relu_bwd(self, dy, c):
+    def _conv_bias_relu_bwd(self, dy, cc):
         G = self.G
-        pre = c["prefix"]
-        dz = ops.act_bwd(dy, c["y"], ops.ACT_RELU)
+        pre = cc["prefix"]
+        dz = ops.act_bwd(dy, cc["y"], ops.ACT_RELU)
         ops.colsum(dz, G[pre + ".bias"])
         cout, cin, k = self.P[pre + ".weight"].shape
         dwp = torch.zeros(k, cout, cin, device=self.dev)
         for j in range(k):
-            ops.gemm_tn(dz, c["x"], dwp[j], shift=j - (k - 1) // 2, seg_lo=c["lo"], seg_hi=c["hi"])
+            ops.gemm_tn(dz, cc["x"], dwp[j], shift=j - (k - 1) // 2, seg_lo=cc["lo"], seg_hi=cc["hi"])
         ops.unpack_conv1d_grad(dwp, G[pre + ".weight"])
-        return ops.conv1d(dz, c["wt"], None, c["lo"], c["hi"])
+        return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
-    def _predictor_fwd(self, hs, name, layers, lo, hi, pad):
-        caches, x = [], hs
+    def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad):
+        caches, x, out = [], hs, None
         for i in range(layers):
             y, cc = self._conv_bias_relu_fwd(x, "%s.conv.%d.0" % (name, i), lo, hi)
             last = i == layers - 1
+            keep = self._keep(c, (name, i), tuple(y.shape), 1.0 - p_drop) if (c.train and p_drop > 0) else None
+            ks = 1.0 / (1.0 - p_drop) if keep is not None else 1.0
             g, b = self.P["%s.conv.%d.2.weight" % (name, i)], self.P["%s.conv.%d.2.bias" % (name, i)]
             ln, out = ops.layernorm(y, g, b, LN_EPS, want_y=not last, lin_w=self.P[name + ".linear.weight"].reshape(-1) if last else None,
-                                    lin_b=self.P[name + ".linear.bias"] if last else None, pad_mask=pad if last else None)
-            caches.append((cc, y, i, last))
+                                    lin_b=self.P[name + ".linear.bias"] if last else None, pad_mask=pad if last else None, keep=keep, keep_scale=ks)
+            caches.append((cc, y, i, last, keep, ks))
             x = ln
         return out, caches
 
     def _predictor_bwd(self, d_out, name, caches, pad):
         G, P = self.G, self.P
         dx = None
-        for cc, y, i, last in reversed(caches):
+        for cc, y, i, last, keep, ks in reversed(caches):
             g, b = P["%s.conv.%d.2.weight" % (name, i)], P["%s.conv.%d.2.bias" % (name, i)]
-            kw = dict(dgamma=G["%s.conv.%d.2.weight" % (name, i)], dbeta=G["%s.conv.%d.2.bias" % (name, i)])
+            kw = dict(dgamma=G["%s.conv.%d.2.weight" % (name, i)], dbeta=G["%s.conv.%d.2.bias" % (name, i)], keep=keep, keep_scale=ks)
             if last:
                 dy = ops.layernorm_bwd(y, g, b, LN_EPS, lin_w=P[name + ".linear.weight"].reshape(-1), ds=d_out, pad_mask=pad,
                                        dlin_w=G[name + ".linear.weight"].reshape(-1), dlin_b=G[name + ".linear.bias"], **kw)
@@ -118,13 +233,6 @@ class TrainEngine(object):
                 dy = ops.layernorm_bwd(y, g, b, LN_EPS, dy=dx, **kw)
             dx = self._conv_bias_relu_bwd(dy, cc)
         return dx
-
-    def _linear_bwd(self, dz, x, wname, bname=None):
-        """dW += dz^T x ; db += colsum(dz) ; returns dz . W."""
-        ops.gemm_tn(dz, x, self.G[wname])
-        if bname:
-            ops.colsum(dz, self.G[bname])
-        return ops.linear(dz, self._wt(self.P[wname]))
 
     # ------------------------------------------------------------------------------------------------ BiLSTM (per-step, saved)
     def _bilstm_fwd(self, x, lens_dev, B, T):
@@ -137,12 +245,12 @@ class TrainEngine(object):
             bias = ops.add_vec(P["enc.blstm.bias_ih_l0" + sfx], P["enc.blstm.bias_hh_l0" + sfx])
             gx = ops.linear(x, w_ih, bias)  # [B*T, 4H]
             h = [torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)]
-            c = torch.zeros(B, H, device=dev)
+            cst = torch.zeros(B, H, device=dev)
             sv = [torch.empty(T, B, 4 * H, device=dev)] + [torch.empty(T, B, H, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
             cur = 0
             order = range(T) if d == 0 else range(T - 1, -1, -1)
             for t in order:
-                ops.lstm_step([(h[cur], w_hh, H)], B, H, h[cur], h[cur ^ 1], c, G=gx, g_row_mul=T, g_row_add=t, step=t, row_len=lens_dev,
+                ops.lstm_step([(h[cur], w_hh, H)], B, H, h[cur], h[cur ^ 1], cst, G=gx, g_row_mul=T, g_row_add=t, step=t, row_len=lens_dev,
                               out2=out, out2_row_mul=T, out2_row_add=t, ld2=2 * H, out2_col_off=d * H, save=[s[t] for s in sv])
                 cur ^= 1
             cache.append((sv, order))
@@ -158,8 +266,8 @@ class TrainEngine(object):
             w_ih, w_hh = P["enc.blstm.weight_ih_l0" + sfx], P["enc.blstm.weight_hh_l0" + sfx]
             whh_t = self._wt(w_hh)  # [H, 4H]
             dgx = torch.zeros(B * T, 4 * H, device=dev)
-            dh_carry, dc_carry = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
             dgx3 = dgx.reshape(B, T, 4 * H)
+            dh_carry, dc_carry = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
             for t in reversed(list(order)):
                 ops.add2d(dh_carry, d3[:, t, d * H : (d + 1) * H])  # d_out is already zero on padded rows (masked by the caller)
                 dgates, dh_old, dc_old = ops.lstm_cell_bwd(sv[0][t], sv[2][t], sv[1][t], dh_carry, dc_carry, 0.0, row_len=c["lens"], step=t)
@@ -173,251 +281,428 @@ class TrainEngine(object):
             ops.add2d(dx, ops.linear(dgx, self._wt(w_ih)))
         return dx
 
-    # ------------------------------------------------------------------------------------------------ the step
-    def zero_grad(self):
-        for g in self.G.values():
-            g.zero_()
-
-    def forward_backward(self, batch, prenet_keep=None):
-        """Teacher loss (…_sa.py:601-613) and all parameter gradients into self.G.  Returns the named losses (floats)."""
-        hp, dev, P, G = self.hp, self.dev, self.P, self.G
+    # ------------------------------------------------------------------------------------------------ index maps (host, integers)
+    def _maps(self, c, batch):
+        dev = self.dev
         ilens = [int(v) for v in batch["ilens"]]
         olens = [int(v) for v in batch["olens"]]
         B, T, L = len(ilens), max(ilens), max(olens)
-        O, U, Pn, C = hp.odim, hp.dunits, hp.prenet_units, hp.eunits
-        drop_p = hp.dropout_rate if prenet_keep is not None else 0.0
-        kscale = 1.0 / (1.0 - drop_p) if drop_p > 0 else 1.0
-        with torch.cuda.device(dev):
-            self.zero_grad()
-            # ---- index maps (host, integers) ---------------------------------------------------------------
-            rows = np.arange(B * T)
-            b_of = rows // T
-            lens_np = np.asarray(ilens)
-            e_lo, e_hi = _i32(b_of * T, dev), _i32(b_of * T + T, dev)
-            pad_np = (rows % T) >= lens_np[b_of]
-            enc_pad = torch.from_numpy(pad_np.astype(np.uint8)).to(dev)
-            enc_valid = torch.from_numpy((~pad_np).astype(np.uint8)).to(dev)
-            frows = np.arange(B * L)
-            f_lo, f_hi = _i32((frows // L) * L, dev), _i32((frows // L) * L + L, dev)
-            fvalid_np = (frows % L) < np.asarray(olens)[frows // L]
-            frame_valid = torch.from_numpy(fvalid_np.astype(np.uint8)).to(dev)
-            nzm = np.asarray(batch["non_zero_lens_mask"])[:, :T] != 0
-            dsn = np.asarray(batch["ds_nonzeros"]).astype(np.int64)
-            src = np.flatnonzero(nzm.reshape(-1))
-            N = src.shape[0]
-            b_row = src // T
-            excl = np.cumsum(dsn) - dsn
-            first = np.concatenate([[0], np.cumsum(np.bincount(b_row, minlength=B))[:-1]])
-            foff = b_row * L + (excl - excl[first[b_row]])
-            order = np.argsort(-dsn, kind="stable")
-            dur_s = dsn[order]
-            foff_s = foff[order]
-            lmax = int(dur_s[0])
-            live = (dur_s[None, :] > np.arange(lmax)[:, None]).sum(1)
-            offs = np.concatenate([[0], np.cumsum(live)])  # step-major cell offsets
-            F = int(offs[-1])
-            cell_row = np.concatenate([np.arange(n) for n in live])  # sorted-row index of every cell
-            cell_t = np.repeat(np.arange(lmax), live)
-            cell_frame = foff_s[cell_row] + cell_t  # frame row (b*L + l) of every cell
-            frame_cell = np.full(B * L, -1, dtype=np.int64)
-            frame_cell[cell_frame] = np.arange(F)
-            prev_frame = np.where(cell_t > 0, cell_frame - 1, -1)  # teacher-forced input y_{t-1}; zero row at t = 0
+        c.B, c.T, c.L = B, T, L
+        rows = np.arange(B * T)
+        b_of = rows // T
+        lens_np = np.asarray(ilens)
+        c.lens_dev = _i32(lens_np, dev)
+        c.e_lo, c.e_hi = _i32(b_of * T, dev), _i32(b_of * T + T, dev)
+        pad_np = (rows % T) >= lens_np[b_of]
+        c.enc_pad, c.enc_valid = _u8(pad_np, dev), _u8(~pad_np, dev)
+        c.n_enc = float((~pad_np).sum())
+        frows = np.arange(B * L)
+        c.f_lo, c.f_hi = _i32((frows // L) * L, dev), _i32((frows // L) * L + L, dev)
+        fvalid_np = (frows % L) < np.asarray(olens)[frows // L]
+        c.frame_valid = _u8(fvalid_np, dev)
+        c.n_frames = float(fvalid_np.sum())
+        nzm = np.asarray(batch["non_zero_lens_mask"])[:, :T] != 0
+        dsn = np.asarray(batch["ds_nonzeros"]).astype(np.int64)
+        src = np.flatnonzero(nzm.reshape(-1))
+        assert src.shape[0] == dsn.shape[0], "hs.shape[0] != len(ds_nonzeros)"  # decoder_sa.py:468
+        N = src.shape[0]
+        b_row = src // T
+        excl = np.cumsum(dsn) - dsn
+        first = np.concatenate([[0], np.cumsum(np.bincount(b_row, minlength=B))[:-1]])
+        foff = b_row * L + (excl - excl[first[b_row]])
+        order = np.argsort(-dsn, kind="stable")
+        dur_s, foff_s = dsn[order], foff[order]
+        lmax = int(dur_s[0])
+        live = (dur_s[None, :] > np.arange(lmax)[:, None]).sum(1)
+        offs = np.concatenate([[0], np.cumsum(live)])  # step-major cell offsets
+        cell_row = np.concatenate([np.arange(n) for n in live])  # sorted-row index of every cell
+        cell_t = np.repeat(np.arange(lmax), live)
+        cell_frame = foff_s[cell_row] + cell_t  # frame row (b*L + l) of every cell
+        F = int(offs[-1])
+        assert F == int(fvalid_np.sum()), "sum of durations != olens"
+        frame_cell = np.full(B * L, -1, dtype=np.int64)
+        frame_cell[cell_frame] = np.arange(F)
+        inv = np.full(B * T, -1, dtype=np.int64)
+        inv[src[order]] = np.arange(N)
+        c.N, c.F, c.lmax, c.live, c.offs, c.order = N, F, lmax, live, offs, order
+        c.cell_row, c.cell_t, c.dur_s = cell_row, cell_t, dur_s
+        c.src_sorted = _i32(src[order], dev)
+        c.row_of_enc = _i32(inv, dev)
+        c.cell_frame, c.frame_cell = _i32(cell_frame, dev), _i32(frame_cell, dev)
+        c.prev_frame = _i32(np.where(cell_t > 0, cell_frame - 1, -1), dev)  # teacher-forced input y_{t-1}; zero row at t = 0
+        c.cell_row_i32 = _i32(cell_row, dev)
+        c.cell_row_i64 = torch.from_numpy(cell_row.astype(np.int64)).to(dev)
+        c.dur_dev = _i32(dur_s, dev)
 
-            # ---- encoder ---------------------------------------------------------------------------------------
-            xs = batch["xs"][:, :T].to(dev).to(torch.int64).reshape(-1).contiguous()
-            emb = ops.embedding(xs, P["enc.embed.weight"])
-            x, conv_c = emb, []
-            for i in range(hp.econv_layers):
-                x, cc = self._conv_bn_fwd(x, "enc.convs.%d" % i, e_lo, e_hi, ops.ACT_RELU)
-                conv_c.append(cc)
-            lens_dev = _i32(lens_np, dev)
-            hs, bl_c = self._bilstm_fwd(x, lens_dev, B, T)
-            # ---- predictors + embeds -----------------------------------------------------------------------------
-            d_outs, dur_c = self._predictor_fwd(hs, "duration_predictor", hp.duration_predictor_layers, e_lo, e_hi, enc_pad)
-            p_outs, pit_c = self._predictor_fwd(hs, "pitch_predictor", hp.variance_predictor_layers, e_lo, e_hi, enc_pad)
-            e_outs, en_c = self._predictor_fwd(hs, "energy_predictor", hp.variance_predictor_layers, e_lo, e_hi, enc_pad)
-            f0 = batch["f0"][:, :T].to(dev).float().reshape(-1).contiguous()
-            en = batch["energy"][:, :T].to(dev).float().reshape(-1).contiguous()
-            ds = batch["extras"][:, :T].to(dev).float().reshape(-1).contiguous()
-            kk = hp.variance_embed_kernel_size
-            att, _, _ = ops.variance_embed_add(hs, f0, en, P["pitch_embed.0.weight"].reshape(C, kk), P["pitch_embed.0.bias"],
-                                               P["energy_embed.0.weight"].reshape(C, kk), P["energy_embed.0.bias"], e_lo, e_hi)
-            # ---- decoder, teacher forced, step-major cells ---------------------------------------------------------
-            att_c = ops.gather_rows(att, _i32(src[order], dev))  # [N, C] sorted rows
-            ys = batch["ys"][:, :L].to(dev).float().reshape(B * L, O).contiguous()
-            pre_in = ops.gather_rows(ys, _i32(prev_frame, dev))  # [F, O]; idx -1 -> zero row
-            k0 = k1 = None
-            if prenet_keep is not None:  # [lmax, 2, N(compact order), P] -> cells
-                pk = np.asarray(prenet_keep)[:lmax][:, :, order, :]
-                k0 = torch.from_numpy(np.ascontiguousarray(np.concatenate([pk[t, 0, : live[t]] for t in range(lmax)]))).to(dev)
-                k1 = torch.from_numpy(np.ascontiguousarray(np.concatenate([pk[t, 1, : live[t]] for t in range(lmax)]))).to(dev)
-            w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
-            p0 = ops.linear(pre_in, P[w0n], P[b0n], ops.ACT_RELU)  # pre-dropout activations are kept
-            p0d = ops.act_fwd(p0, ops.ACT_NONE, k0, kscale) if k0 is not None else p0
-            p1 = ops.linear(p0d, P[w1n], P[b1n], ops.ACT_RELU)
-            p1d = ops.act_fwd(p1, ops.ACT_NONE, k1, kscale) if k1 is not None else p1
-            w_ih0 = P["dec.lstm.0.cell.weight_ih"]
-            w0_att, w0_pre = ops.copy_cols(w_ih0, 0, C), ops.copy_cols(w_ih0, C, Pn)
-            w0_pos = ops.copy_cols(w_ih0, C + Pn, 1).reshape(-1)
-            w0_hh = P["dec.lstm.0.cell.weight_hh"]
-            b0s = ops.add_vec(P["dec.lstm.0.cell.bias_ih"], P["dec.lstm.0.cell.bias_hh"])
-            w1_ih, w1_hh = P["dec.lstm.1.cell.weight_ih"], P["dec.lstm.1.cell.weight_hh"]
-            b1s = ops.add_vec(P["dec.lstm.1.cell.bias_ih"], P["dec.lstm.1.cell.bias_hh"])
-            wf = P["dec.feat_out.weight"]
-            wf_h, wf_att = ops.copy_cols(wf, 0, U), ops.copy_cols(wf, U, C)
-            G0 = ops.linear(att_c, w0_att, b0s)  # hoisted att_c share of the layer-0 gates
-            F0 = ops.linear(att_c, wf_att)
-            dur_dev = _i32(dur_s, dev)
-            S0 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
-            S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
-            h0_all, h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
-            h0 = [torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)]
-            h1 = [torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)]
-            c0, c1 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)
-            zr = float(hp.zoneout_rate)
-            cur = 0
-            for t in range(lmax):
-                n, o = int(live[t]), int(offs[t])
-                sl = slice(o, o + n)
-                ops.lstm_step([(p1d[sl], w0_pre, Pn), (h0[cur], w0_hh, U)], n, U, h0[cur], h0[cur ^ 1], c0, G=G0, rank1_w=w0_pos, dur=dur_dev,
-                              step=t, zoneout=zr, out2=h0_all[sl], out2_row_mul=1, ld2=U, save=[s[sl] for s in S0])
-                ops.lstm_step([(h0[cur ^ 1], w1_ih, U), (h1[cur], w1_hh, U)], n, U, h1[cur], h1[cur ^ 1], c1, bias=b1s, step=t, zoneout=zr,
-                              out2=h1_all[sl], out2_row_mul=1, ld2=U, save=[s[sl] for s in S1])
-                cur ^= 1
-            cell_row_dev = _i32(cell_row, dev)
-            F0_cells = ops.gather_rows(F0, cell_row_dev)
-            out_cells = ops.linear(h1_all, wf_h)
-            ops.add2d(out_cells, F0_cells)
-            before = ops.gather_rows(out_cells, _i32(frame_cell, dev))  # [B*L, O], zero where no cell maps (padding)
-            # ---- postnet ----------------------------------------------------------------------------------------------
-            x, post_c = before, []
-            n_post = hp.postnet_layers
-            for i in range(n_post):
-                x, cc = self._conv_bn_fwd(x, "dec.postnet.postnet.%d" % i, f_lo, f_hi, ops.ACT_NONE if i == n_post - 1 else ops.ACT_TANH)
-                post_c.append(cc)
-            after = ops.add_vec(before, x)
-            # ---- losses (Tacotron2Loss + duration + pitch + energy) -----------------------------------------------------
-            nf, ne = float(fvalid_np.sum()) * O, float((~pad_np).sum())
-            sums = torch.zeros(5, 3, dtype=torch.float64, device=dev)
-            ops.masked_l1_mse(after, ys, frame_valid, sums[0])
-            ops.masked_l1_mse(before, ys, frame_valid, sums[1])
-            ops.masked_l1_mse(d_outs.reshape(-1, 1), ds.reshape(-1, 1), enc_valid, sums[2], b_log_offset=1.0)
-            ops.masked_l1_mse(p_outs.reshape(-1, 1), f0.reshape(-1, 1), enc_valid, sums[3])
-            ops.masked_l1_mse(e_outs.reshape(-1, 1), en.reshape(-1, 1), enc_valid, sums[4])
-            # ================================================= backward =================================================
-            d_after = ops.l1_mse_grad(after, ys, frame_valid, nf, 1.0, 1.0)
-            d_before = ops.l1_mse_grad(before, ys, frame_valid, nf, 1.0, 1.0)
-            ops.add2d(d_before, d_after)  # residual path of after = before + postnet(before)
-            dx = d_after
-            for cc in reversed(post_c):
-                dx = self._conv_bn_bwd(dx, cc)
-            ops.add2d(d_before, dx)
-            # ---- decoder BPTT ----------------------------------------------------------------------------------------------
-            d_out_cells = ops.gather_rows(d_before, _i32(cell_frame, dev))  # [F, O]
-            g_wf = G["dec.feat_out.weight"]
-            ops.gemm_tn(d_out_cells, h1_all, g_wf[:, :U])  # column blocks of the [odim, U + C] gradient are written in place
-            dh1_all = ops.linear(d_out_cells, self._wt(wf_h))  # [F, U]
-            dF0 = torch.zeros(N, O, device=dev)
-            cell_row64 = torch.from_numpy(cell_row.astype(np.int64)).to(dev)
-            ops.scatter_add_rows(d_out_cells, cell_row64, dF0)
-            ops.gemm_tn(dF0, att_c, g_wf[:, U:])
-            d_att_c = ops.linear(dF0, self._wt(wf_att))
-            w1ih_t, w1hh_t, w0hh_t, w0pre_t = self._wt(w1_ih), self._wt(w1_hh), self._wt(w0_hh), self._wt(w0_pre)
-            dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
-            dp1_all = torch.empty(F, Pn, device=dev)
-            ch0, cc0 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)  # carries: grads w.r.t. the state entering step t+1
-            ch1, cc1 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)
-            tmp_h, tmp_c = torch.empty(N, U, device=dev), torch.zeros(N, U, device=dev)
-            for t in range(lmax - 1, -1, -1):  # live rows only grow as t falls, so carries of newly-live rows are still zero
-                n, o = int(live[t]), int(offs[t])
-                sl = slice(o, o + n)
-                ops.add2d(ch1[:n], dh1_all[sl])
-                ops.lstm_cell_bwd(S1[0][sl], S1[2][sl], S1[1][sl], ch1[:n], cc1[:n], zr, out=(dg1_all[sl], tmp_h[:n], tmp_c[:n]))
-                ops.linear(dg1_all[sl], w1hh_t, out=ch1[:n])
-                ops.add2d(ch1[:n], tmp_h[:n])
-                cc1, tmp_c = tmp_c, cc1
-                ops.add2d(ch0[:n], ops.linear(dg1_all[sl], w1ih_t))
-                ops.lstm_cell_bwd(S0[0][sl], S0[2][sl], S0[1][sl], ch0[:n], cc0[:n], zr, out=(dg0_all[sl], tmp_h[:n], tmp_c[:n]))
-                ops.linear(dg0_all[sl], w0hh_t, out=ch0[:n])
-                ops.add2d(ch0[:n], tmp_h[:n])
-                cc0, tmp_c = tmp_c, cc0
-                ops.linear(dg0_all[sl], w0pre_t, out=dp1_all[sl])
-            # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
-            ops.gemm_tn(dg1_all, h0_all, G["dec.lstm.1.cell.weight_ih"])
-            ops.gemm_tn(dg1_all, S1[3], G["dec.lstm.1.cell.weight_hh"])
-            for nm in ("bias_ih", "bias_hh"):
-                ops.colsum(dg1_all, G["dec.lstm.1.cell." + nm])
-                ops.colsum(dg0_all, G["dec.lstm.0.cell." + nm])
-            ops.gemm_tn(dg0_all, S0[3], G["dec.lstm.0.cell.weight_hh"])
-            g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
-            ops.gemm_tn(dg0_all, p1d, g_ih0[:, C : C + Pn])
-            pos_np = np.zeros((F, 4), dtype=np.float32)
-            pos_np[:, 0] = cell_t.astype(np.float32) / dur_s[cell_row].astype(np.float32)  # the position input t/d, padded to 4 columns
-            dw0_pos4 = torch.zeros(4 * U, 4, device=dev)
-            ops.gemm_tn(dg0_all, torch.from_numpy(pos_np).to(dev), dw0_pos4)
-            ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
-            dG0 = torch.zeros(N, 4 * U, device=dev)
-            ops.scatter_add_rows(dg0_all, cell_row64, dG0)
-            ops.gemm_tn(dG0, att_c, g_ih0[:, :C])
-            ops.add2d(d_att_c, ops.linear(dG0, self._wt(w0_att)))
-            # prenet (batched over all cells)
-            dz1 = ops.act_bwd(dp1_all, p1, ops.ACT_RELU, k1, kscale)
-            dp0 = self._linear_bwd(dz1, p0d, w1n, b1n)
-            dz0 = ops.act_bwd(dp0, p0, ops.ACT_RELU, k0, kscale)
-            ops.gemm_tn(dz0, pre_in, G[w0n])
-            ops.colsum(dz0, G[b0n])
-            # ---- att = hs + p_emb + e_emb -----------------------------------------------------------------------------------
-            inv = np.full(B * T, -1, dtype=np.int64)
-            inv[src[order]] = np.arange(N)
-            d_att = ops.gather_rows(d_att_c, _i32(inv, dev))  # scatter back to (b, t) rows; rows without a phoneme get 0
-            d_hs = d_att.clone()
-            for nm, sig in (("pitch", f0), ("energy", en)):
-                ops.colsum(d_att, G[nm + "_embed.0.bias"])
-                sig4 = torch.zeros(B * T, 4, device=dev)
-                ops.copy2d(sig4[:, :1], sig.reshape(-1, 1))
-                gw = G[nm + "_embed.0.weight"].reshape(C, kk)
-                for j in range(kk):
-                    tmp = torch.zeros(C, 4, device=dev)
-                    ops.gemm_tn(d_att, sig4, tmp, shift=j - (kk - 1) // 2, seg_lo=e_lo, seg_hi=e_hi)
-                    ops.add2d(gw[:, j : j + 1], tmp[:, :1])
-            # ---- predictors ----------------------------------------------------------------------------------------------------
-            d_d = ops.l1_mse_grad(d_outs, ds, enc_valid, ne, 0.0, 1.0, b_log_offset=1.0).reshape(-1)
-            d_p = ops.l1_mse_grad(p_outs, f0, enc_valid, ne, 0.0, 1.0).reshape(-1)
-            d_e = ops.l1_mse_grad(e_outs, en, enc_valid, ne, 0.0, 1.0).reshape(-1)
-            ops.add2d(d_hs, self._predictor_bwd(d_d, "duration_predictor", dur_c, enc_pad))
-            ops.add2d(d_hs, self._predictor_bwd(d_p, "pitch_predictor", pit_c, enc_pad))
-            ops.add2d(d_hs, self._predictor_bwd(d_e, "energy_predictor", en_c, enc_pad))
-            # ---- encoder -----------------------------------------------------------------------------------------------------------
-            d_hs_live = ops.add2d(torch.zeros_like(d_hs), d_hs, row_valid=enc_valid)  # pad_packed_sequence: padded outputs are constants
-            dx = self._bilstm_bwd(d_hs_live, bl_c)
-            for cc in reversed(conv_c):
-                dx = self._conv_bn_bwd(dx, cc)
-            ops.scatter_add_rows(dx, xs, G["enc.embed.weight"], skip=0)  # padding_idx = 0 gets no gradient
-            host = sums.cpu().numpy()
-        l1 = host[0, 0] / host[0, 2] + host[1, 0] / host[1, 2]
-        mse = host[0, 1] / host[0, 2] + host[1, 1] / host[1, 2]
-        rep = dict(l1_loss=l1, mse_loss=mse, dur_loss=host[2, 1] / host[2, 2], pitch_loss=host[3, 1] / host[3, 2], energy_loss=host[4, 1] / host[4, 2])
-        rep["loss"] = sum(rep.values())
+    def _cells(self, c, arr):
+        """[lmax, N(compact order), X] injected decoder masks -> step-major cells [F, X]."""
+        a = np.asarray(arr)[: c.lmax][:, c.order]
+        return _u8(np.concatenate([a[t, : c.live[t]] for t in range(c.lmax)]), self.dev)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def _forward(self, c, batch):
+        hp, dev, P = self.hp, self.dev, self.P
+        B, T, L = c.B, c.T, c.L
+        O, U, Pn, C = hp.odim, hp.dunits, hp.prenet_units, hp.eunits
+        p_conv = hp.dropout_rate
+        drop_conv = c.train and p_conv > 0
+        # ---- encoder
+        c.xs = batch["xs"][:, :T].to(dev).to(torch.int64).reshape(-1).contiguous()
+        c.emb = ops.embedding(c.xs, P["enc.embed.weight"])
+        x, c.conv_c, c.enc_taps = c.emb, [], [c.emb]
+        for i in range(hp.econv_layers):
+            keep = self._keep(c, ("enc.convs", i), (B * T, hp.econv_chans), 1.0 - p_conv) if drop_conv else None
+            x, cc = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep)
+            c.conv_c.append(cc)
+            c.enc_taps.append(x)
+        c.hs, c.bl_c = self._bilstm_fwd(x, c.lens_dev, B, T)
+        # ---- predictors + embeds
+        c.d_outs, c.dur_c = self._predictor_fwd(c, c.hs, "duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_dropout_rate,
+                                                c.e_lo, c.e_hi, c.enc_pad)
+        c.p_outs, c.pit_c = self._predictor_fwd(c, c.hs, "pitch_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
+                                                c.e_lo, c.e_hi, c.enc_pad)
+        c.e_outs, c.en_c = self._predictor_fwd(c, c.hs, "energy_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
+                                               c.e_lo, c.e_hi, c.enc_pad)
+        c.f0 = batch["f0"][:, :T].to(dev).float().reshape(-1).contiguous()
+        c.en = batch["energy"][:, :T].to(dev).float().reshape(-1).contiguous()
+        c.ds = batch["extras"][:, :T].to(dev).float().reshape(-1).contiguous()
+        kk = hp.variance_embed_kernel_size
+        att, pe, ee = ops.variance_embed_add(c.hs, c.f0, c.en, P["pitch_embed.0.weight"].reshape(C, kk), P["pitch_embed.0.bias"],
+                                             P["energy_embed.0.weight"].reshape(C, kk), P["energy_embed.0.bias"], c.e_lo, c.e_hi, want_embs=True)
+        p_emb = hp.variance_embed_dropout_rate
+        c.emb_keep, c.emb_ks = (None, None), 1.0
+        if c.train and p_emb > 0:
+            c.emb_keep = (self._keep(c, ("pitch_embed",), (B * T, C), 1.0 - p_emb), self._keep(c, ("energy_embed",), (B * T, C), 1.0 - p_emb))
+            c.emb_ks = 1.0 / (1.0 - p_emb)
+            pe, ee = ops.act_fwd(pe, ops.ACT_NONE, c.emb_keep[0], c.emb_ks), ops.act_fwd(ee, ops.ACT_NONE, c.emb_keep[1], c.emb_ks)
+            att = ops.add2d(ops.add2d(c.hs.clone(), pe), ee)
+        c.p_embs, c.e_embs = pe, ee
+        # ---- decoder, teacher forced, step-major cells
+        N, F, lmax, live, offs = c.N, c.F, c.lmax, c.live, c.offs
+        c.att_c = ops.gather_rows(att, c.src_sorted)  # [N, C] sorted rows
+        c.ys = batch["ys"][:, :L].to(dev).float().reshape(B * L, O).contiguous()
+        c.pre_in = ops.gather_rows(c.ys, c.prev_frame)  # [F, O]; idx -1 -> zero row
+        c.k0 = c.k1 = None
+        c.pks = 1.0
+        if hp.dropout_rate > 0:  # the prenet's dropout is on in BOTH modes (decoder_sa.py:156-158)
+            c.pks = 1.0 / (1.0 - hp.dropout_rate)
+            if c.masks is not None:
+                pk = np.asarray(c.masks["prenet"])
+                c.k0, c.k1 = self._cells(c, pk[:, 0]), self._cells(c, pk[:, 1])
+            else:
+                c.k0 = self._keep(c, ("prenet", 0), (F, Pn), 1.0 - hp.dropout_rate)
+                c.k1 = self._keep(c, ("prenet", 1), (F, Pn), 1.0 - hp.dropout_rate)
+        w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
+        c.p0 = ops.linear(c.pre_in, P[w0n], P[b0n], ops.ACT_RELU)  # pre-dropout activations are kept
+        c.p0d = ops.act_fwd(c.p0, ops.ACT_NONE, c.k0, c.pks) if c.k0 is not None else c.p0
+        c.p1 = ops.linear(c.p0d, P[w1n], P[b1n], ops.ACT_RELU)
+        c.p1d = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks) if c.k1 is not None else c.p1
+        w_ih0 = P["dec.lstm.0.cell.weight_ih"]
+        c.w0_att, c.w0_pre = ops.copy_cols(w_ih0, 0, C), ops.copy_cols(w_ih0, C, Pn)
+        w0_pos = ops.copy_cols(w_ih0, C + Pn, 1).reshape(-1)
+        c.w0_hh = P["dec.lstm.0.cell.weight_hh"]
+        b0s = ops.add_vec(P["dec.lstm.0.cell.bias_ih"], P["dec.lstm.0.cell.bias_hh"])
+        c.w1_ih, c.w1_hh = P["dec.lstm.1.cell.weight_ih"], P["dec.lstm.1.cell.weight_hh"]
+        b1s = ops.add_vec(P["dec.lstm.1.cell.bias_ih"], P["dec.lstm.1.cell.bias_hh"])
+        wf = P["dec.feat_out.weight"]
+        c.wf_h, c.wf_att = ops.copy_cols(wf, 0, U), ops.copy_cols(wf, U, C)
+        G0 = ops.linear(c.att_c, c.w0_att, b0s)  # hoisted att_c share of the layer-0 gates
+        F0 = ops.linear(c.att_c, c.wf_att)
+        c.zr = float(hp.zoneout_rate)
+        c.zk = None
+        if c.train and c.zr > 0:  # sampled zoneout: mask = 1 keeps the OLD state, P(1) = rate; [layer][h, c] -> [F, U]
+            if c.masks is not None:
+                zm = np.asarray(c.masks["zoneout"])
+                c.zk = [[self._cells(c, zm[:, l, j]) for j in range(2)] for l in range(2)]
+            else:
+                c.zk = [[self._keep(c, ("zoneout", l, j), (F, U), c.zr) for j in range(2)] for l in range(2)]
+        c.S0 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
+        c.S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
+        c.h0_all, c.h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
+        h0 = [torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)]
+        h1 = [torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)]
+        c0, c1 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)
+        cur = 0
+        for t in range(lmax):
+            n, o = int(live[t]), int(offs[t])
+            sl = slice(o, o + n)
+            z0 = dict(zone_keep_h=c.zk[0][0][sl], zone_keep_c=c.zk[0][1][sl]) if c.zk else {}
+            z1 = dict(zone_keep_h=c.zk[1][0][sl], zone_keep_c=c.zk[1][1][sl]) if c.zk else {}
+            ops.lstm_step([(c.p1d[sl], c.w0_pre, Pn), (h0[cur], c.w0_hh, U)], n, U, h0[cur], h0[cur ^ 1], c0, G=G0, rank1_w=w0_pos, dur=c.dur_dev,
+                          step=t, zoneout=c.zr, out2=c.h0_all[sl], out2_row_mul=1, ld2=U, save=[s[sl] for s in c.S0], **z0)
+            ops.lstm_step([(h0[cur ^ 1], c.w1_ih, U), (h1[cur], c.w1_hh, U)], n, U, h1[cur], h1[cur ^ 1], c1, bias=b1s, step=t, zoneout=c.zr,
+                          out2=c.h1_all[sl], out2_row_mul=1, ld2=U, save=[s[sl] for s in c.S1], **z1)
+            cur ^= 1
+        out_cells = ops.linear(c.h1_all, c.wf_h)
+        ops.add2d(out_cells, ops.gather_rows(F0, c.cell_row_i32))
+        c.before = ops.gather_rows(out_cells, c.frame_cell)  # [B*L, O], zero where no cell maps (padding)
+        # ---- postnet
+        x, c.post_c, c.post_taps = c.before, [], []
+        n_post = hp.postnet_layers
+        for i in range(n_post):
+            cout = hp.odim if i == n_post - 1 else hp.postnet_chans
+            keep = self._keep(c, ("postnet", i), (B * L, cout), 1.0 - p_conv) if drop_conv else None
+            x, cc = self._conv_bn_fwd(c, x, "dec.postnet.postnet.%d" % i, c.f_lo, c.f_hi, ops.ACT_NONE if i == n_post - 1 else ops.ACT_TANH, keep)
+            c.post_c.append(cc)
+            c.post_taps.append(x)
+        c.after = ops.add_vec(c.before, x)
+
+    def _knowledge(self, c):
+        """The KD teacher's 5-tuple (..._kd_teacher.py:597-603), shaped as the reference's."""
+        B, T, L = c.B, c.T, c.L
+        e = lambda x: x.reshape(B, T, -1)
+        f = lambda x: x.reshape(B, L, -1)
+        cells = [ops.gather_rows(x, c.frame_cell) for x in (c.p1d, c.h0_all, c.h1_all)]
+        return (f(c.after), f(c.before), [e(t) for t in c.enc_taps] + [e(c.hs)], [f(t) for t in cells + c.post_taps],
+                [e(c.d_outs), e(c.p_outs), e(c.e_outs), e(c.p_embs), e(c.e_embs)])
+
+    # ------------------------------------------------------------------------------------------------ losses and their gradients
+    def _losses(self, c, teacher_knowledge):
+        """Named losses into one device buffer + the gradient every loss term injects at its tap (c.inj[name])."""
+        dev, P, G, hp = self.dev, self.P, self.G, self.hp
+        nf, ne = c.n_frames * hp.odim, c.n_enc
+        sums = torch.zeros(48, 3, dtype=torch.float64, device=dev)
+        names = []
+
+        def term(name, a, b, valid, count, w_l1, w_mse, b_log=None, da=None):
+            a2, b2 = (a.reshape(-1, 1), b.reshape(-1, 1)) if a.dim() == 1 else (a, b)
+            ops.masked_l1_mse(a2, b2, valid, sums[len(names)], b_log_offset=b_log)
+            names.append(name)
+            return ops.l1_mse_grad(a2, b2, valid, count * self.accum_grad, w_l1, w_mse, da=da, b_log_offset=b_log)  # d(loss / accum_grad)
+
+        inj = c.inj = {}
+        inj["after"] = term("after", c.after, c.ys, c.frame_valid, nf, 1.0, 1.0)
+        inj["before"] = term("before", c.before, c.ys, c.frame_valid, nf, 1.0, 1.0)
+        inj["d_outs"] = term("dur", c.d_outs, c.ds, c.enc_valid, ne, 0.0, 1.0, b_log=1.0)
+        inj["p_outs"] = term("pitch", c.p_outs, c.f0, c.enc_valid, ne, 0.0, 1.0)
+        inj["e_outs"] = term("energy", c.e_outs, c.en, c.enc_valid, ne, 0.0, 1.0)
+        if self.role == "student":
+            t_after, t_before, t_enc, t_dec, t_pro = teacher_knowledge
+            flat = lambda t: t.to(device=dev, dtype=torch.float32).reshape(-1, t.shape[-1]).contiguous()
+            if self.share_proj:
+                cp, lp, pp = ["enc.convs_proj.0"] * 3, ["dec.lstm_proj"] * 2, ["dec.post_proj"] * 4
+            else:
+                cp = ["enc.convs_proj.%d" % i for i in range(3)]
+                lp, pp = ["dec.lstm0_proj", "dec.lstm1_proj"], ["dec.post%d_proj" % i for i in range(4)]
+
+            def kd(name, s_in, proj, t, valid, nvalid):
+                """MSE(s_in . W^T, t) over valid rows: accumulates dW, returns the gradient w.r.t. s_in."""
+                w = P[proj + ".weight"]
+                s = ops.linear(s_in, w)
+                ds_ = term(name, s, t, valid, nvalid * s.shape[1], 0.0, 1.0)
+                ops.gemm_tn(ds_, s_in, G[proj + ".weight"])
+                return ops.linear(ds_, self._wt(w))
+
+            if self.distill[0]:
+                term("o_after", c.after, flat(t_after), c.frame_valid, nf, 1.0, 1.0, da=inj["after"])
+                term("o_before", c.before, flat(t_before), c.frame_valid, nf, 1.0, 1.0, da=inj["before"])
+            if self.distill[1]:
+                inj["enc0"] = kd("enc0", c.enc_taps[0], "enc.embed_proj", flat(t_enc[0]), c.enc_valid, ne)
+                for i in range(3):
+                    inj["enc%d" % (i + 1)] = kd("enc%d" % (i + 1), c.enc_taps[1 + i], cp[i], flat(t_enc[1 + i]), c.enc_valid, ne)
+                inj["hs"] = kd("enc4", c.hs, "enc.blstm_proj", flat(t_enc[4]), c.enc_valid, ne)
+            if self.distill[2]:
+                cellv = torch.ones(c.F, dtype=torch.uint8, device=dev)  # every cell is a valid frame
+                tc = lambda t: ops.gather_rows(flat(t), c.cell_frame)
+                inj["p1d"] = kd("dec0", c.p1d, "dec.prenet_proj", tc(t_dec[0]), cellv, c.n_frames)
+                inj["h0"] = kd("dec1", c.h0_all, lp[0], tc(t_dec[1]), cellv, c.n_frames)
+                inj["h1"] = kd("dec2", c.h1_all, lp[1], tc(t_dec[2]), cellv, c.n_frames)
+                for i in range(4):
+                    inj["post%d" % i] = kd("dec%d" % (3 + i), c.post_taps[i], pp[i], flat(t_dec[3 + i]), c.frame_valid, c.n_frames)
+                inj["post4"] = term("dec7", c.post_taps[4], flat(t_dec[7]), c.frame_valid, nf, 0.0, 1.0)
+            if self.distill[3]:
+                term("pro0", c.d_outs, flat(t_pro[0]).reshape(-1), c.enc_valid, ne, 0.0, 1.0, da=inj["d_outs"])
+                term("pro1", c.p_outs, flat(t_pro[1]).reshape(-1), c.enc_valid, ne, 0.0, 1.0, da=inj["p_outs"])
+                term("pro2", c.e_outs, flat(t_pro[2]).reshape(-1), c.enc_valid, ne, 0.0, 1.0, da=inj["e_outs"])
+                inj["p_embs"] = kd("pro3", c.p_embs, "pemb_proj", flat(t_pro[3]), c.enc_valid, ne)
+                inj["e_embs"] = kd("pro4", c.e_embs, "eemb_proj", flat(t_pro[4]), c.enc_valid, ne)
+        c.sums, c.loss_names = sums, names
+
+    def _report(self, c):
+        host = c.sums[: len(c.loss_names)].cpu().numpy()
+        m = {n: (host[i, 0] / host[i, 2], host[i, 1] / host[i, 2]) for i, n in enumerate(c.loss_names)}
+        rep = dict(l1_loss=m["after"][0] + m["before"][0], mse_loss=m["after"][1] + m["before"][1], dur_loss=m["dur"][1], pitch_loss=m["pitch"][1],
+                   energy_loss=m["energy"][1])
+        rep["loss"] = rep["l1_loss"] + rep["mse_loss"] + rep["dur_loss"] + rep["pitch_loss"] + rep["energy_loss"]
+        if "o_after" in m:
+            rep["output_l1_loss"] = m["o_after"][0] + m["o_before"][0]
+            rep["output_mse_loss"] = m["o_after"][1] + m["o_before"][1]
+            rep["loss"] += rep["output_l1_loss"] + rep["output_mse_loss"]
+        for key, pre, n in (("encoder_loss", "enc", 5), ("decoder_loss", "dec", 8), ("prosody_loss", "pro", 5)):
+            if pre + "0" in m:
+                rep[key] = sum(m["%s%d" % (pre, i)][1] for i in range(n))
+                rep["loss"] += rep[key]
         return rep
 
-    def optimizer_step(self):
-        """clip_grad_norm_(grad_clip) + NaN guard + Adam, all on the stream (tts.py:173-182).  Returns the step count."""
+    # ------------------------------------------------------------------------------------------------ backward
+    def _backward(self, c):
+        hp, dev, P, G, inj = self.hp, self.dev, self.P, self.G, c.inj
+        B, T = c.B, c.T
+        U, Pn, C = hp.dunits, hp.prenet_units, hp.eunits
+        N, F, lmax, live, offs = c.N, c.F, c.lmax, c.live, c.offs
+        # ---- postnet: after = before + postnet(before)
+        d_before = inj["before"]
+        ops.add2d(d_before, inj["after"])
+        dx = inj["after"]
+        for i in range(len(c.post_c) - 1, -1, -1):
+            if "post%d" % i in inj:
+                ops.add2d(dx, inj["post%d" % i])
+            dx = self._conv_bn_bwd(c, dx, c.post_c[i])
+        ops.add2d(d_before, dx)
+        self.buckets.launch(0)
+        # ---- decoder BPTT
+        d_out_cells = ops.gather_rows(d_before, c.cell_frame)  # [F, O]
+        g_wf = G["dec.feat_out.weight"]
+        ops.gemm_tn(d_out_cells, c.h1_all, g_wf[:, :U])  # column blocks of the [odim, U + C] gradient are written in place
+        dh1_all = ops.linear(d_out_cells, self._wt(c.wf_h))  # [F, U]
+        if "h1" in inj:
+            ops.add2d(dh1_all, inj["h1"])
+        dF0 = torch.zeros(N, hp.odim, device=dev)
+        ops.scatter_add_rows(d_out_cells, c.cell_row_i64, dF0)
+        ops.gemm_tn(dF0, c.att_c, g_wf[:, U:])
+        d_att_c = ops.linear(dF0, self._wt(c.wf_att))
+        w1ih_t, w1hh_t, w0hh_t, w0pre_t = self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh), self._wt(c.w0_pre)
+        dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
+        dp1_all = torch.empty(F, Pn, device=dev)
+        ch0, cc0 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)  # carries: grads w.r.t. the state entering step t+1
+        ch1, cc1 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)
+        tmp_h, tmp_c = torch.empty(N, U, device=dev), torch.zeros(N, U, device=dev)
+        S0, S1 = c.S0, c.S1
+        for t in range(lmax - 1, -1, -1):  # live rows only grow as t falls, so carries of newly-live rows are still zero
+            n, o = int(live[t]), int(offs[t])
+            sl = slice(o, o + n)
+            z0 = dict(zone_keep_h=c.zk[0][0][sl], zone_keep_c=c.zk[0][1][sl]) if c.zk else {}
+            z1 = dict(zone_keep_h=c.zk[1][0][sl], zone_keep_c=c.zk[1][1][sl]) if c.zk else {}
+            ops.add2d(ch1[:n], dh1_all[sl])
+            ops.lstm_cell_bwd(S1[0][sl], S1[2][sl], S1[1][sl], ch1[:n], cc1[:n], c.zr, out=(dg1_all[sl], tmp_h[:n], tmp_c[:n]), **z1)
+            ops.linear(dg1_all[sl], w1hh_t, out=ch1[:n])
+            ops.add2d(ch1[:n], tmp_h[:n])
+            cc1, tmp_c = tmp_c, cc1
+            ops.add2d(ch0[:n], ops.linear(dg1_all[sl], w1ih_t))
+            if "h0" in inj:
+                ops.add2d(ch0[:n], inj["h0"][sl])
+            ops.lstm_cell_bwd(S0[0][sl], S0[2][sl], S0[1][sl], ch0[:n], cc0[:n], c.zr, out=(dg0_all[sl], tmp_h[:n], tmp_c[:n]), **z0)
+            ops.linear(dg0_all[sl], w0hh_t, out=ch0[:n])
+            ops.add2d(ch0[:n], tmp_h[:n])
+            cc0, tmp_c = tmp_c, cc0
+            ops.linear(dg0_all[sl], w0pre_t, out=dp1_all[sl])
+        # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
+        ops.gemm_tn(dg1_all, c.h0_all, G["dec.lstm.1.cell.weight_ih"])
+        ops.gemm_tn(dg1_all, S1[3], G["dec.lstm.1.cell.weight_hh"])
+        for nm in ("bias_ih", "bias_hh"):
+            ops.colsum(dg1_all, G["dec.lstm.1.cell." + nm])
+            ops.colsum(dg0_all, G["dec.lstm.0.cell." + nm])
+        ops.gemm_tn(dg0_all, S0[3], G["dec.lstm.0.cell.weight_hh"])
+        g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
+        ops.gemm_tn(dg0_all, c.p1d, g_ih0[:, C : C + Pn])
+        pos_np = np.zeros((F, 4), dtype=np.float32)
+        pos_np[:, 0] = c.cell_t.astype(np.float32) / c.dur_s[c.cell_row].astype(np.float32)  # the position input t/d, padded to 4 columns
+        dw0_pos4 = torch.zeros(4 * U, 4, device=dev)
+        ops.gemm_tn(dg0_all, torch.from_numpy(pos_np).to(dev), dw0_pos4)
+        ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
+        dG0 = torch.zeros(N, 4 * U, device=dev)
+        ops.scatter_add_rows(dg0_all, c.cell_row_i64, dG0)
+        ops.gemm_tn(dG0, c.att_c, g_ih0[:, :C])
+        ops.add2d(d_att_c, ops.linear(dG0, self._wt(c.w0_att)))
+        # prenet (batched over all cells)
+        w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
+        if "p1d" in inj:
+            ops.add2d(dp1_all, inj["p1d"])
+        dz1 = ops.act_bwd(dp1_all, c.p1, ops.ACT_RELU, c.k1, c.pks)
+        ops.gemm_tn(dz1, c.p0d, G[w1n])
+        ops.colsum(dz1, G[b1n])
+        dp0 = ops.linear(dz1, self._wt(P[w1n]))
+        dz0 = ops.act_bwd(dp0, c.p0, ops.ACT_RELU, c.k0, c.pks)
+        ops.gemm_tn(dz0, c.pre_in, G[w0n])
+        ops.colsum(dz0, G[b0n])
+        self.buckets.launch(1)
+        # ---- att = hs + p_embs + e_embs
+        d_att = ops.gather_rows(d_att_c, c.row_of_enc)  # back to (b, t) rows; rows without a phoneme get 0
+        d_hs = d_att.clone()
+        kk = hp.variance_embed_kernel_size
+        for nm, sig, tap, keep in (("pitch", c.f0, "p_embs", c.emb_keep[0]), ("energy", c.en, "e_embs", c.emb_keep[1])):
+            d_e = d_att
+            if tap in inj:
+                d_e = ops.add2d(d_att.clone(), inj[tap])
+            if keep is not None:
+                d_e = ops.act_bwd(d_e, None, ops.ACT_NONE, keep, c.emb_ks)
+            ops.colsum(d_e, G[nm + "_embed.0.bias"])
+            sig4 = torch.zeros(B * T, 4, device=dev)
+            ops.copy2d(sig4[:, :1], sig.reshape(-1, 1))
+            gw = G[nm + "_embed.0.weight"].reshape(C, kk)
+            for j in range(kk):
+                tmp = torch.zeros(C, 4, device=dev)
+                ops.gemm_tn(d_e, sig4, tmp, shift=j - (kk - 1) // 2, seg_lo=c.e_lo, seg_hi=c.e_hi)
+                ops.add2d(gw[:, j : j + 1], tmp[:, :1])
+        # ---- predictors
+        ops.add2d(d_hs, self._predictor_bwd(inj["d_outs"].reshape(-1), "duration_predictor", c.dur_c, c.enc_pad))
+        ops.add2d(d_hs, self._predictor_bwd(inj["p_outs"].reshape(-1), "pitch_predictor", c.pit_c, c.enc_pad))
+        ops.add2d(d_hs, self._predictor_bwd(inj["e_outs"].reshape(-1), "energy_predictor", c.en_c, c.enc_pad))
+        self.buckets.launch(2)
+        # ---- encoder
+        if "hs" in inj:
+            ops.add2d(d_hs, inj["hs"])
+        d_hs_live = ops.add2d(torch.zeros_like(d_hs), d_hs, row_valid=c.enc_valid)  # pad_packed_sequence: padded outputs are constants
+        dx = self._bilstm_bwd(d_hs_live, c.bl_c)
+        for i in range(len(c.conv_c) - 1, -1, -1):
+            if "enc%d" % (i + 1) in inj:
+                ops.add2d(dx, inj["enc%d" % (i + 1)])
+            dx = self._conv_bn_bwd(c, dx, c.conv_c[i])
+        if "enc0" in inj:
+            ops.add2d(dx, inj["enc0"])
+        ops.scatter_add_rows(dx, c.xs, G["enc.embed.weight"], skip=0)  # padding_idx = 0 gets no gradient
+        self.buckets.launch(3)
+
+    # ------------------------------------------------------------------------------------------------ public API
+    def zero_grad(self):
+        self.gflat.zero_()
+
+    def _ctx(self, batch, mode, masks):
+        if mode not in ("eval", "train"):
+            raise ValueError("mode must be 'eval' or 'train'")
+        c = _Ctx()
+        c.train, c.masks = mode == "train", masks
+        self.forward_count += 1
+        c.draw = self.forward_count
+        self._maps(c, batch)
+        return c
+
+    def knowledge(self, batch, mode="train", masks=None):
+        """Forward only: the frozen KD teacher's 5-tuple (tts_distill.py:159; the reference leaves the teacher in train mode)."""
         with torch.cuda.device(self.dev):
+            c = self._ctx(batch, mode, masks)
+            self._forward(c, batch)
+            return self._knowledge(c)
+
+    def forward_backward(self, batch, teacher_knowledge=None, mode="eval", masks=None):
+        """One micro-batch: named losses (floats) and d(loss / accum_grad) accumulated into the flat gradient buffer."""
+        if self.role == "student" and teacher_knowledge is None:
+            raise ValueError("the student step needs teacher_knowledge (tts_distill.py:159-161)")
+        with torch.cuda.device(self.dev):
+            c = self._ctx(batch, mode, masks)
+            self._forward(c, batch)
+            self._losses(c, teacher_knowledge)
+            self._backward(c)
+            return self._report(c)
+
+    def optimizer_step(self):
+        """all-reduce (if distributed) + clip_grad_norm_(grad_clip) + NaN guard + Adam on the flat buffers (tts.py:173-182)."""
+        with torch.cuda.device(self.dev):
+            self.buckets.finish(lambda t, s: ops.scale_(t, s))
             self.gn_sq.zero_()
-            for g in self.G.values():
-                ops.sumsq_accum(g.reshape(-1), self.gn_sq)
+            ops.sumsq_accum(self.gflat, self.gn_sq)
             self.step_count += 1
-            for k, p in self.P.items():
-                ops.adam_step(p.reshape(-1), self.G[k].reshape(-1), self.m[k].reshape(-1), self.v[k].reshape(-1), self.gn_sq, self.grad_clip, self.lr,
-                              self.betas[0], self.betas[1], self.eps, self.step_count)
+            ops.adam_step(self.pflat, self.gflat, self.mflat, self.vflat, self.gn_sq, self.grad_clip, self.lr, self.betas[0], self.betas[1], self.eps,
+                          self.step_count)
             self.model.refresh_plan()
         return self.step_count
 
     def grad_norm(self):
         return float(torch.sqrt(self.gn_sq).item())
 
-    def train_step(self, batch, prenet_keep=None):
-        rep = self.forward_backward(batch, prenet_keep)
+    def train_step(self, batch, teacher_knowledge=None, mode="eval", masks=None):
+        self.zero_grad()
+        rep = self.forward_backward(batch, teacher_knowledge, mode, masks)
         self.optimizer_step()
         rep["grad_norm"] = self.grad_norm()
         return rep

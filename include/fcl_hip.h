@@ -255,6 +255,8 @@ int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const
                    float* y_act, float* y_drop, int m, int c, int act, fcl_stream_t stream);
 int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
                float* dz, int m, int c, fcl_stream_t stream);
+/* x *= alpha (gradient averaging after a SUM all-reduce on backends without AVG). */
+int fcl_scale(float* x, size_t n, float alpha, fcl_stream_t stream);
 /* out[i] = 1 with probability p_one: counter hash of (seed + *seed_dev, i).  The training path's source of dropout keep masks
  * (p_one = 1 - p) and zoneout keep-old masks (p_one = zoneout rate); not bit-compatible with torch's Philox stream by design. */
 int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const uint32_t* seed_dev, fcl_stream_t stream);

@@ -1,5 +1,6 @@
 """-m gpu: the H13 training step on the HIP path (fcl_taco2_amd.training.TrainEngine) vs
-  * the REAL reference's loss / gradients / grad-norm pinned in tests/golden/g5_teacher_train.npz, and
+  * the REAL reference's losses / gradients / grad-norm / BatchNorm buffers pinned in tests/golden/g5 (teacher, eval form), g7 (teacher, train
+    form with every dropout / zoneout draw injected), g8 (student KD, eval form) and g9 (the full KD update in train form), and
   * the oracle's autograd for EVERY parameter (oracle/fcl_oracle.py restates the reference's forward in differentiable torch-CPU).
 Forward GEMMs run in the default bf16x3 mode (or exact fp32 under FCL_PRECISION=0); gradient kernels are exact fp32."""
 import argparse
@@ -10,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import TINY_T, max_abs, torch_state_dict
+from helpers import TINY_S, TINY_S7, TINY_T, TINY_T7, max_abs, torch_state_dict
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import fcl_oracle as O  # noqa: E402
@@ -18,69 +19,180 @@ import fcl_oracle as O  # noqa: E402
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+COM = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
+                         distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=True, share_proj=True)
 
 
-def _teacher(hp):
-    from fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa
+def _ns(hp):
+    return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
+                              postnet_chans=hp.postnet_chans, use_residual=False, use_masking=True, dropout_rate=hp.dropout_rate,
+                              duration_predictor_chans=hp.duration_predictor_chans)
 
-    ns = argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
-                            postnet_chans=hp.postnet_chans, use_residual=False, use_masking=True, dropout_rate=hp.dropout_rate,
-                            duration_predictor_chans=hp.duration_predictor_chans)
-    m = Tacotron2_sa(hp.idim, hp.odim, ns, argparse.Namespace(use_fe_condition=True, append_position=True))
-    m.load_state_dict(torch_state_dict(hp))
+
+def _model(role, hp, thp=None):
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
+    from fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa as Teacher
+
+    if role == "student":
+        m = Student(hp.idim, hp.odim, _ns(hp), COM, _ns(thp))
+        m.load_state_dict(torch_state_dict(hp, thp, True))
+    else:
+        m = (Teacher if role == "teacher" else KDTeacher)(hp.idim, hp.odim, _ns(hp), COM)
+        m.load_state_dict(torch_state_dict(hp))
     return m.to(DEV)
+
+
+def _golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
 def _batch():
     from fcl_taco2_amd.converter import CustomConverter
 
-    g = dict(np.load(os.path.join(GOLDEN, "g4_integer.npz")))
+    g = _golden("g4_integer")
     raw = ([g["in_xs%d" % i] for i in range(4)], [g["in_ys%d" % i] for i in range(4)], None, [g["in_ds%d" % i] for i in range(4)],
            [g["in_f0%d" % i] for i in range(4)], [g["in_en%d" % i] for i in range(4)])
     return CustomConverter(1, True, True)([raw])
 
 
-def _oracle_grads(hp, batch):
-    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in torch_state_dict(hp).items()}
-    b = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
-    rep = O.model_forward(sd, hp, b, "teacher")
-    rep["loss"].backward()
-    return rep, {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad}
+def _cpu(batch):
+    return {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def _grad_sd(hp, thp=None):
+    return {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in torch_state_dict(hp, thp, True).items()}
+
+
+def _check_vs_golden(eng, rep, g, loss_keys, tol=5e-4):
+    for k in loss_keys:
+        assert abs(rep[k] - float(g[k])) < tol * max(1.0, abs(float(g[k]))), (k, rep[k], float(g[k]))
+    n = 0
+    for k, ref in g.items():
+        if k.startswith("grad:"):
+            n += 1
+            assert max_abs(eng.G[k[5:]].cpu(), ref) < tol * max(1.0, float(np.abs(ref).max())), k
+    from fcl_taco2_amd import ops
+
+    eng.gn_sq.zero_()
+    ops.sumsq_accum(eng.gflat, eng.gn_sq)
+    assert abs(eng.grad_norm() - float(g["grad_norm"])) < 2e-3 * float(g["grad_norm"])
+    return n
+
+
+def _check_vs_oracle(eng, sd, tol=5e-4):
+    og = {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad}
+    assert set(og) == set(eng.G)
+    bad = {}
+    for k, ref in og.items():
+        ref = torch.zeros_like(eng.P[k]).cpu() if ref is None else ref
+        err = max_abs(eng.G[k].cpu(), ref) / max(1.0, float(ref.abs().max()))
+        if err > tol:
+            bad[k] = err
+    assert not bad, bad
 
 
 def test_teacher_step_gradients_vs_reference_and_oracle():
+    """G5: teacher, eval form (running-stat BatchNorm, dropout off, expectation zoneout)."""
     from fcl_taco2_amd.training import TrainEngine
 
-    model = _teacher(TINY_T)
-    eng = TrainEngine(model)
+    eng = TrainEngine(_model("teacher", TINY_T))
     batch = _batch()
     rep = eng.forward_backward(batch)
-    g5 = dict(np.load(os.path.join(GOLDEN, "g5_teacher_train.npz")))
-    assert abs(rep["loss"] - float(g5["loss"])) < 5e-4 * max(1.0, abs(float(g5["loss"])))
-    # the real reference's gradients (8 parameters spread over encoder / predictors / decoder / postnet)
-    n_ref = 0
-    for k, ref in g5.items():
-        if k.startswith("grad:"):
-            n_ref += 1
-            assert max_abs(eng.G[k[5:]].cpu(), ref) < 5e-4 * max(1.0, float(np.abs(ref).max())), k
-    assert n_ref >= 8
-    # every parameter vs the oracle's autograd
-    orep, og = _oracle_grads(TINY_T, batch)
+    assert _check_vs_golden(eng, rep, _golden("g5_teacher_train"), ["loss"]) >= 8
+    sd = _grad_sd(TINY_T)
+    orep = O.model_forward(sd, TINY_T, _cpu(batch), "teacher")
+    orep["loss"].backward()
     assert abs(rep["loss"] - float(orep["loss"])) < 5e-4
-    assert set(og) == set(eng.G)
-    worst = {}
-    for k, ref in og.items():
-        ref = torch.zeros_like(eng.P[k]).cpu() if ref is None else ref
-        worst[k] = max_abs(eng.G[k].cpu(), ref) / max(1.0, float(ref.abs().max()))
-    bad = {k: v for k, v in worst.items() if v > 5e-4}
-    assert not bad, bad
-    # clip_grad_norm_'s total norm
-    eng.gn_sq.zero_()
-    from fcl_taco2_amd import ops
+    _check_vs_oracle(eng, sd)
 
-    for gt in eng.G.values():
-        ops.sumsq_accum(gt.reshape(-1), eng.gn_sq)
-    assert abs(eng.grad_norm() - float(g5["grad_norm"])) < 2e-3 * float(g5["grad_norm"])
+
+def test_teacher_train_mode_step_vs_reference_g7():
+    """G7: model.train() — batch-statistics BatchNorm (+ running-buffer update), Dropout at every site, sampled zoneout; all draws injected."""
+    from fcl_taco2_amd.training import TrainEngine
+
+    g = _golden("g7_teacher_train_mode")
+    masks = O.masks_from_sequence([g["mask%03d" % i] for i in range(int(g["n_masks"]))], TINY_T7)
+    model = _model("teacher", TINY_T7)
+    eng = TrainEngine(model)
+    batch = _batch()
+    rep = eng.forward_backward(batch, mode="train", masks=masks)
+    assert _check_vs_golden(eng, rep, g, ["loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"]) >= 12
+    sdm = model.state_dict()
+    for k in g:
+        if k.startswith("buf:"):
+            assert max_abs(sdm[k[4:]].cpu().double(), g[k].astype(np.float64)) < 1e-4, k
+    sd = _grad_sd(TINY_T7)
+    orep = O.model_forward(sd, TINY_T7, _cpu(batch), "teacher", bn_train=True, masks=masks)
+    orep["loss"].backward()
+    _check_vs_oracle(eng, sd)
+
+
+def _g1_knowledge():
+    g1 = _golden("g1_forward")
+    return (torch.from_numpy(g1["t_after"]), torch.from_numpy(g1["t_before"]), [torch.from_numpy(g1["t_enc%d" % i]) for i in range(5)],
+            [torch.from_numpy(g1["t_dec%d" % i]) for i in range(8)], [torch.from_numpy(g1["t_pro%d" % i]) for i in range(5)])
+
+
+KD_KEYS = ["loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss", "encoder_loss", "decoder_loss",
+           "prosody_loss"]
+
+
+def test_student_kd_step_eval_form_vs_reference_g8():
+    """G8: student loss incl. the four KD terms through the shared projections; gradients of 20 parameters pinned by the reference."""
+    from fcl_taco2_amd.training import TrainEngine
+
+    know = _g1_knowledge()
+    eng = TrainEngine(_model("student", TINY_S, TINY_T))
+    batch = _batch()
+    rep = eng.forward_backward(batch, teacher_knowledge=know)
+    assert _check_vs_golden(eng, rep, _golden("g8_student_kd_eval"), KD_KEYS) >= 20
+    sd = _grad_sd(TINY_S, TINY_T)
+    orep = O.model_forward(sd, TINY_S, _cpu(batch), "student", TINY_T, True, know)
+    orep["loss"].backward()
+    _check_vs_oracle(eng, sd)
+
+
+def test_kd_update_train_mode_vs_reference_g9():
+    """G9: tts_distill.py:159-161 — frozen teacher left in train mode produces the knowledge on the HIP path, the student takes a train-mode
+    forward/backward; every draw of both models injected; teacher's BatchNorm buffers move although it is frozen."""
+    from fcl_taco2_amd.training import TrainEngine
+
+    g = _golden("g9_kd_step_train_mode")
+    tm = O.masks_from_sequence([g["tmask%03d" % i] for i in range(int(g["n_tmasks"]))], TINY_T7)
+    sm = O.masks_from_sequence([g["smask%03d" % i] for i in range(int(g["n_smasks"]))], TINY_S7)
+    batch = _batch()
+    teacher = _model("kd_teacher", TINY_T7)
+    teng = TrainEngine(teacher)
+    know = teng.knowledge(batch, mode="train", masks=tm)
+    assert max_abs(know[0].cpu(), g["t_after"]) < 3e-4 and max_abs(know[3][1].cpu(), g["t_dec1"]) < 3e-4 and max_abs(know[4][3].cpu(), g["t_pro3"]) < 3e-4
+    assert max_abs(teacher.state_dict()["enc.convs.0.1.running_mean"].cpu(), g["buf:teacher.enc.convs.0.1.running_mean"]) < 1e-5
+    eng = TrainEngine(_model("student", TINY_S7, TINY_T7))
+    rep = eng.forward_backward(batch, teacher_knowledge=know, mode="train", masks=sm)
+    assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
+    with torch.no_grad():
+        oknow = O.model_forward(torch_state_dict(TINY_T7), TINY_T7, _cpu(batch), "kd_teacher", bn_train=True, masks=tm)
+    sd = _grad_sd(TINY_S7, TINY_T7)
+    orep = O.model_forward(sd, TINY_S7, _cpu(batch), "student", TINY_T7, True, oknow, bn_train=True, masks=sm)
+    orep["loss"].backward()
+    _check_vs_oracle(eng, sd, tol=1e-3)
+
+
+def test_device_rng_masks_statistics_and_repeatability():
+    """Production masks come from fcl_bernoulli_u8: right rates, different draws per site / per step, same seed -> same step."""
+    from fcl_taco2_amd import ops
+    from fcl_taco2_amd.training import TrainEngine
+
+    a = ops.bernoulli_u8((1 << 20,), 0.1, 7, DEV).float().mean().item()
+    b = ops.bernoulli_u8((1 << 20,), 0.5, 7, DEV)
+    c = ops.bernoulli_u8((1 << 20,), 0.5, 8, DEV)
+    assert abs(a - 0.1) < 2e-3 and abs(b.float().mean().item() - 0.5) < 2e-3 and 0.45 < (b != c).float().mean().item() < 0.55
+    batch = _batch()
+    reps = []
+    for seed in (3, 3, 4):
+        eng = TrainEngine(_model("teacher", TINY_T7), seed=seed)
+        reps.append(eng.forward_backward(batch, mode="train")["loss"])
+    assert reps[0] == reps[1] and reps[0] != reps[2] and all(np.isfinite(reps))
 
 
 def test_teacher_train_steps_track_torch_adam():
@@ -88,11 +200,11 @@ def test_teacher_train_steps_track_torch_adam():
     against the oracle + torch.optim.Adam on CPU: losses and the final weights agree."""
     from fcl_taco2_amd.training import TrainEngine
 
-    model = _teacher(TINY_T)
+    model = _model("teacher", TINY_T)
     eng = TrainEngine(model, lr=1e-3, eps=1e-6, grad_clip=1.0)
     batch = _batch()
-    b = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
-    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in torch_state_dict(TINY_T).items()}
+    b = _cpu(batch)
+    sd = _grad_sd(TINY_T)
     params = [v for v in sd.values() if v.dtype.is_floating_point and v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3, eps=1e-6)
     for it in range(3):
@@ -111,3 +223,17 @@ def test_teacher_train_steps_track_torch_adam():
     assert max(float(d.max()) for d in diffs) <= 2 * 1e-3 * 3  # the sign-flip bound: 2 * lr per step
     # the module's own parameters are the master weights: a plan built after training sees the updated values
     assert dict(model.named_parameters())["dec.feat_out.weight"].data_ptr() == eng.P["dec.feat_out.weight"].data_ptr()
+    assert max_abs(model.state_dict()["dec.feat_out.weight"].cpu(), sd["dec.feat_out.weight"].detach()) < 6e-3
+
+
+def test_accum_grad_two_micro_batches_equal_one_scaled_sum():
+    """loss / accum_grad per micro-batch, gradients accumulate until the optimizer step (tts.py:160-171)."""
+    from fcl_taco2_amd.training import TrainEngine
+
+    batch = _batch()
+    e1 = TrainEngine(_model("teacher", TINY_T))
+    e1.forward_backward(batch)
+    e2 = TrainEngine(_model("teacher", TINY_T), accum_grad=2)
+    e2.forward_backward(batch)
+    e2.forward_backward(batch)
+    assert max_abs(e1.gflat.cpu(), e2.gflat.cpu()) < 1e-5 * max(1.0, float(e1.gflat.abs().max()))
