@@ -42,6 +42,28 @@ class LstmStep(C.Structure):
                 ("save_h_old", _P)]
 
 
+class DecoderTrain(C.Structure):  # fcl_decoder_train_t
+    _fields_ = [("n", _I), ("lmax", _I), ("u", _I), ("p", _I), ("live_rows_host", _P), ("p1d", _P), ("g0", _P), ("w0_pre", _P), ("w0_hh", _P),
+                ("w0_pos", _P), ("dur", _P), ("w1_ih", _P), ("w1_hh", _P), ("b1", _P), ("zoneout", _F), ("zk_h0", _P), ("zk_c0", _P), ("zk_h1", _P),
+                ("zk_c1", _P), ("s0", _P * 4), ("s1", _P * 4), ("h0_all", _P), ("h1_all", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+
+
+class DecoderBptt(C.Structure):  # fcl_decoder_bptt_t
+    _fields_ = [("n", _I), ("lmax", _I), ("u", _I), ("live_rows_host", _P), ("s0", _P * 3), ("s1", _P * 3), ("zoneout", _F), ("zk_h0", _P),
+                ("zk_c0", _P), ("zk_h1", _P), ("zk_c1", _P), ("dh1_all", _P), ("dh0_all", _P), ("w1_ih_t", _P), ("w1_hh_t", _P), ("w0_hh_t", _P),
+                ("dg0_all", _P), ("dg1_all", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+
+
+class BilstmTrain(C.Structure):  # fcl_bilstm_train_t
+    _fields_ = [("b", _I), ("t", _I), ("h", _I), ("reverse", _I), ("lens", _P), ("gx", _P), ("w_hh", _P), ("out", _P), ("ld_out", _I), ("col_off", _I),
+                ("s", _P * 4), ("workspace", _P), ("workspace_bytes", _Z)]
+
+
+class BilstmBptt(C.Structure):  # fcl_bilstm_bptt_t
+    _fields_ = [("b", _I), ("t", _I), ("h", _I), ("reverse", _I), ("lens", _P), ("s", _P * 3), ("d_out", _P), ("ld_dout", _I), ("col_off", _I),
+                ("w_hh_t", _P), ("dg", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
 
@@ -82,12 +104,18 @@ SIGNATURES = {
     "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scale": (_I, [_P, _Z, _F, _P]),
     "fcl_bernoulli_u8": (_I, [_P, _Z, _F, C.c_uint32, _P, _P]),
-    "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),
     "fcl_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _I, _P]),
     "fcl_lstm_step_fwd": (_I, [C.POINTER(LstmStep), _P]),
+    "fcl_decoder_train_workspace_bytes": (_Z, [_I, _I]),
+    "fcl_decoder_train_fwd": (_I, [C.POINTER(DecoderTrain), _P]),
+    "fcl_decoder_bptt": (_I, [C.POINTER(DecoderBptt), _P]),
+    "fcl_bilstm_train_workspace_bytes": (_Z, [_I, _I]),
+    "fcl_bilstm_train_fwd": (_I, [C.POINTER(BilstmTrain), _P]),
+    "fcl_bilstm_bptt": (_I, [C.POINTER(BilstmBptt), _P]),
     "fcl_prof_enable": (_I, [_I]),
     "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }

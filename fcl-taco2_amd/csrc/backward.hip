@@ -224,13 +224,14 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ x, const float* _
 // zoneout) -- see LstmStepArgs.save_*.  In: dh_out, dc_out (gradients w.r.t. the zoneout-ed outputs).  Out: dgates [M,4U] (pre-activation),
 // dh_old_direct / dc_old (the zoneout "keep old" path and the f-gate path), to which the caller adds dgates . W_hh.
 __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_old, const float* __restrict__ c_new,
-                                     const float* __restrict__ dh_out, const float* __restrict__ dc_out, float zoneout,
+                                     const float* __restrict__ dh_out, const float* __restrict__ dh_out2, int ld_dh2,
+                                     const float* __restrict__ dc_out, float zoneout,
                                      const uint8_t* __restrict__ zk_h, const uint8_t* __restrict__ zk_c, const int* __restrict__ row_len, int step,
                                      float* __restrict__ dgates, float* __restrict__ dh_old, float* __restrict__ dc_old_out, int M, int U) {
     const long long total = (long long)M * U;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx / U), u = (int)(idx - (long long)m * U);
-        const float dho = dh_out[idx], dco = dc_out ? dc_out[idx] : 0.f;
+        const float dho = dh_out[idx] + (dh_out2 ? dh_out2[(size_t)m * ld_dh2 + u] : 0.f), dco = dc_out ? dc_out[idx] : 0.f;
         const bool live = row_len ? (step < row_len[m]) : true;
         float dh_new, dc_new_z, dh_keep, dc_keep;
         if (!live) {  // state passed through untouched
@@ -476,13 +477,15 @@ int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, flo
     return check_hip(hipGetLastError(), "layernorm_bwd");
 }
 
-int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dc_out, float zoneout,
+int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dh_out2, int ld_dh2,
+                      const float* dc_out, float zoneout,
                       const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step, float* dgates, float* dh_old,
                       float* dc_old, int m, int u, fcl_stream_t stream) {
     FCL_REQUIRE(gates && c_old && c_new && dh_out && dgates && dh_old && dc_old && m >= 0 && u > 0, FCL_ERR_INVALID, "lstm_cell_bwd: bad arguments");
     FCL_REQUIRE((zone_keep_h == nullptr) == (zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_cell_bwd: zoneout masks come in pairs");
     if (m == 0) return 0;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)m * u, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_old, c_new, dh_out, dc_out,
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)m * u, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_old, c_new, dh_out, dh_out2,
+                       ld_dh2, dc_out,
                        zoneout, zone_keep_h, zone_keep_c, row_len, step, dgates, dh_old, dc_old, m, u);
     return check_hip(hipGetLastError(), "lstm_cell_bwd");
 }

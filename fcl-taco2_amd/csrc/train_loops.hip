@@ -1,0 +1,215 @@
+// train_loops.hip — the time loops of the training step, run on the host side of the C ABI so that one call enqueues a whole recurrence
+// (hundreds of launches) instead of one Python round trip per kernel.  Every kernel is one of the library's own entry points.
+//   fcl_decoder_train_fwd  : teacher-forced decoder LSTM stack over step-major cells, saving what BPTT needs (decoder_sa.py:472-515)
+//   fcl_decoder_bptt       : its reverse-time pass (gate gradients of both layers for every cell)
+//   fcl_bilstm_train_fwd   : one direction of the packed encoder BiLSTM with saved gates (encoder_sa.py:98-100,143-146)
+//   fcl_bilstm_bptt        : its reverse pass
+#include "fcl_common.h"
+
+using namespace fcl;
+
+namespace {
+
+inline GemmArgs lin(const float* x, int lda, const float* w, int ldw, int k, float* y, int ldy, int m, int n, const float* residual, int ldr) {
+    GemmArgs g = {};
+    g.term[0] = GemmTerm{x, w, lda, ldw, k, 0, nullptr, nullptr};
+    g.nterms = 1;
+    g.M = m;
+    g.N = n;
+    g.act = FCL_ACT_NONE;
+    g.R = residual;
+    g.ldr = ldr;
+    g.Y = y;
+    g.ldy = ldy;
+    return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t fcl_decoder_train_workspace_bytes(int n, int u) { return (n > 0 && u > 0) ? sizeof(float) * 6 * (size_t)n * u : 0; }
+
+int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
+    FCL_REQUIRE(a && a->live_rows_host && a->p1d && a->g0 && a->w0_pre && a->w0_hh && a->w0_pos && a->dur && a->w1_ih && a->w1_hh && a->b1,
+                FCL_ERR_INVALID, "decoder_train_fwd: null argument");
+    FCL_REQUIRE(a->n > 0 && a->lmax > 0 && a->u > 0 && a->p > 0, FCL_ERR_SHAPE, "decoder_train_fwd: bad sizes");
+    FCL_REQUIRE(a->h0_all && a->h1_all && a->s0[0] && a->s1[0], FCL_ERR_INVALID, "decoder_train_fwd: outputs missing");
+    FCL_REQUIRE((a->zk_h0 == nullptr) == (a->zk_c0 == nullptr) && (a->zk_h0 == nullptr) == (a->zk_h1 == nullptr) &&
+                    (a->zk_h0 == nullptr) == (a->zk_c1 == nullptr), FCL_ERR_INVALID, "decoder_train_fwd: the four zoneout masks come together");
+    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_decoder_train_workspace_bytes(a->n, a->u), FCL_ERR_WORKSPACE, "decoder_train_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t NU = (size_t)a->n * a->u;
+    const int U = a->u;
+    float* ws = (float*)a->workspace;
+    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 6 * NU, s));
+    float *h0[2] = {ws, ws + NU}, *h1[2] = {ws + 2 * NU, ws + 3 * NU}, *c0 = ws + 4 * NU, *c1 = ws + 5 * NU;
+    int cur = 0;
+    size_t off = 0;
+    int prev = a->n;
+    for (int t = 0; t < a->lmax; ++t) {
+        const int n = a->live_rows_host[t];
+        FCL_REQUIRE(n > 0 && n <= prev, FCL_ERR_SHAPE, "decoder_train_fwd: live_rows must be positive and non-increasing");
+        prev = n;
+        LstmStepArgs l0 = {};
+        l0.term[0] = GemmTerm{a->p1d + off * a->p, a->w0_pre, a->p, a->p, a->p, 0, nullptr, nullptr};
+        l0.term[1] = GemmTerm{h0[cur], a->w0_hh, U, U, U, 0, nullptr, nullptr};
+        l0.nterms = 2;
+        l0.M = n;
+        l0.U = U;
+        l0.G = a->g0;
+        l0.g_row_mul = 1;
+        l0.rank1_w = a->w0_pos;
+        l0.dur = a->dur;
+        l0.step = t;
+        l0.h_in = h0[cur];
+        l0.h_out = h0[cur ^ 1];
+        l0.c = c0;
+        l0.zoneout = a->zoneout;
+        if (a->zk_h0) { l0.zone_keep_h = a->zk_h0 + off * U; l0.zone_keep_c = a->zk_c0 + off * U; }
+        l0.out2 = a->h0_all + off * U;
+        l0.out2_row_mul = 1;
+        l0.ld2 = U;
+        l0.save_gates = a->s0[0] + off * 4 * U;
+        l0.save_c_new = a->s0[1] + off * U;
+        l0.save_c_old = a->s0[2] + off * U;
+        l0.save_h_old = a->s0[3] + off * U;
+        int rc = launch_lstm_step(l0, s);
+        if (rc) return rc;
+        LstmStepArgs l1 = {};
+        l1.term[0] = GemmTerm{h0[cur ^ 1], a->w1_ih, U, U, U, 0, nullptr, nullptr};
+        l1.term[1] = GemmTerm{h1[cur], a->w1_hh, U, U, U, 0, nullptr, nullptr};
+        l1.nterms = 2;
+        l1.M = n;
+        l1.U = U;
+        l1.bias = a->b1;
+        l1.step = t;
+        l1.h_in = h1[cur];
+        l1.h_out = h1[cur ^ 1];
+        l1.c = c1;
+        l1.zoneout = a->zoneout;
+        if (a->zk_h1) { l1.zone_keep_h = a->zk_h1 + off * U; l1.zone_keep_c = a->zk_c1 + off * U; }
+        l1.out2 = a->h1_all + off * U;
+        l1.out2_row_mul = 1;
+        l1.ld2 = U;
+        l1.save_gates = a->s1[0] + off * 4 * U;
+        l1.save_c_new = a->s1[1] + off * U;
+        l1.save_c_old = a->s1[2] + off * U;
+        l1.save_h_old = a->s1[3] + off * U;
+        rc = launch_lstm_step(l1, s);
+        if (rc) return rc;
+        cur ^= 1;
+        off += (size_t)n;
+    }
+    return 0;
+}
+
+int fcl_decoder_bptt(const fcl_decoder_bptt_t* a, fcl_stream_t stream) {
+    FCL_REQUIRE(a && a->live_rows_host && a->s0[0] && a->s0[1] && a->s0[2] && a->s1[0] && a->s1[1] && a->s1[2] && a->dh1_all && a->w1_ih_t &&
+                    a->w1_hh_t && a->w0_hh_t && a->dg0_all && a->dg1_all, FCL_ERR_INVALID, "decoder_bptt: null argument");
+    FCL_REQUIRE(a->n > 0 && a->lmax > 0 && a->u > 0, FCL_ERR_SHAPE, "decoder_bptt: bad sizes");
+    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_decoder_train_workspace_bytes(a->n, a->u), FCL_ERR_WORKSPACE, "decoder_bptt: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t NU = (size_t)a->n * a->u;
+    const int U = a->u, G4 = 4 * a->u;
+    float* ws = (float*)a->workspace;
+    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 6 * NU, s));  // rows that only become live at earlier steps must see zero carries
+    float *ch0 = ws, *ch1 = ws + NU, *cc0 = ws + 2 * NU, *cc1 = ws + 3 * NU, *tmp_h = ws + 4 * NU, *tmp_c = ws + 5 * NU;
+    size_t total = 0;
+    for (int t = 0; t < a->lmax; ++t) total += (size_t)a->live_rows_host[t];
+    size_t off = total;
+    for (int t = a->lmax - 1; t >= 0; --t) {
+        const int n = a->live_rows_host[t];
+        off -= (size_t)n;
+        // layer 1
+        int rc = fcl_lstm_cell_bwd(a->s1[0] + off * G4, a->s1[2] + off * U, a->s1[1] + off * U, ch1, a->dh1_all + off * U, U, cc1, a->zoneout,
+                                   a->zk_h1 ? a->zk_h1 + off * U : nullptr, a->zk_c1 ? a->zk_c1 + off * U : nullptr, nullptr, t, a->dg1_all + off * G4,
+                                   tmp_h, tmp_c, n, U, stream);
+        if (rc) return rc;
+        std::swap(cc1, tmp_c);
+        rc = launch_gemm(lin(a->dg1_all + off * G4, G4, a->w1_hh_t, G4, G4, ch1, U, n, U, tmp_h, U), s);  // ch1 = dg1 . W1_hh + zoneout keep path
+        if (rc) return rc;
+        rc = launch_gemm(lin(a->dg1_all + off * G4, G4, a->w1_ih_t, G4, G4, ch0, U, n, U, ch0, U), s);  // ch0 += dg1 . W1_ih
+        if (rc) return rc;
+        // layer 0
+        rc = fcl_lstm_cell_bwd(a->s0[0] + off * G4, a->s0[2] + off * U, a->s0[1] + off * U, ch0, a->dh0_all ? a->dh0_all + off * U : nullptr, U, cc0,
+                               a->zoneout, a->zk_h0 ? a->zk_h0 + off * U : nullptr, a->zk_c0 ? a->zk_c0 + off * U : nullptr, nullptr, t,
+                               a->dg0_all + off * G4, tmp_h, tmp_c, n, U, stream);
+        if (rc) return rc;
+        std::swap(cc0, tmp_c);
+        rc = launch_gemm(lin(a->dg0_all + off * G4, G4, a->w0_hh_t, G4, G4, ch0, U, n, U, tmp_h, U), s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+size_t fcl_bilstm_train_workspace_bytes(int b, int h) { return (b > 0 && h > 0) ? sizeof(float) * 4 * (size_t)b * h : 0; }
+
+int fcl_bilstm_train_fwd(const fcl_bilstm_train_t* a, fcl_stream_t stream) {
+    FCL_REQUIRE(a && a->lens && a->gx && a->w_hh && a->out && a->s[0] && a->s[1] && a->s[2] && a->s[3], FCL_ERR_INVALID, "bilstm_train_fwd: null argument");
+    FCL_REQUIRE(a->b > 0 && a->t > 0 && a->h > 0 && a->ld_out >= a->col_off + a->h, FCL_ERR_SHAPE, "bilstm_train_fwd: bad sizes");
+    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(a->b, a->h), FCL_ERR_WORKSPACE, "bilstm_train_fwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = a->b, T = a->t, H = a->h;
+    const size_t BH = (size_t)B * H;
+    float* ws = (float*)a->workspace;
+    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 3 * BH, s));
+    float *h[2] = {ws, ws + BH}, *c = ws + 2 * BH;
+    int cur = 0;
+    for (int i = 0; i < T; ++i) {
+        const int t = a->reverse ? T - 1 - i : i;
+        LstmStepArgs l = {};
+        l.term[0] = GemmTerm{h[cur], a->w_hh, H, H, H, 0, nullptr, nullptr};
+        l.nterms = 1;
+        l.M = B;
+        l.U = H;
+        l.G = a->gx;
+        l.g_row_mul = T;
+        l.g_row_add = t;
+        l.step = t;
+        l.h_in = h[cur];
+        l.h_out = h[cur ^ 1];
+        l.c = c;
+        l.row_len = a->lens;
+        l.out2 = a->out;
+        l.out2_row_mul = T;
+        l.out2_row_add = t;
+        l.ld2 = a->ld_out;
+        l.out2_col_off = a->col_off;
+        l.save_gates = a->s[0] + (size_t)t * B * 4 * H;
+        l.save_c_new = a->s[1] + (size_t)t * BH;
+        l.save_c_old = a->s[2] + (size_t)t * BH;
+        l.save_h_old = a->s[3] + (size_t)t * BH;
+        int rc = launch_lstm_step(l, s);
+        if (rc) return rc;
+        cur ^= 1;
+    }
+    return 0;
+}
+
+int fcl_bilstm_bptt(const fcl_bilstm_bptt_t* a, fcl_stream_t stream) {
+    FCL_REQUIRE(a && a->lens && a->s[0] && a->s[1] && a->s[2] && a->d_out && a->w_hh_t && a->dg, FCL_ERR_INVALID, "bilstm_bptt: null argument");
+    FCL_REQUIRE(a->b > 0 && a->t > 0 && a->h > 0 && a->ld_dout >= a->col_off + a->h, FCL_ERR_SHAPE, "bilstm_bptt: bad sizes");
+    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(a->b, a->h), FCL_ERR_WORKSPACE, "bilstm_bptt: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = a->b, T = a->t, H = a->h, G4 = 4 * a->h;
+    const size_t BH = (size_t)B * H;
+    float* ws = (float*)a->workspace;
+    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 4 * BH, s));
+    float *dh = ws, *tmp_h = ws + BH, *dc = ws + 2 * BH, *tmp_c = ws + 3 * BH;
+    for (int i = T - 1; i >= 0; --i) {  // reverse of the forward visiting order
+        const int t = a->reverse ? T - 1 - i : i;
+        float* dg = a->dg + (size_t)t * B * G4;
+        // output gradient of step t: rows (b, t) of d_out, i.e. row stride T * ld_dout
+        int rc = fcl_lstm_cell_bwd(a->s[0] + (size_t)t * B * G4, a->s[2] + (size_t)t * BH, a->s[1] + (size_t)t * BH, dh,
+                                   a->d_out + (size_t)t * a->ld_dout + a->col_off, T * a->ld_dout, dc, 0.f, nullptr, nullptr, a->lens, t, dg, tmp_h, tmp_c,
+                                   B, H, stream);
+        if (rc) return rc;
+        std::swap(dc, tmp_c);
+        rc = launch_gemm(lin(dg, G4, a->w_hh_t, G4, G4, dh, H, B, H, tmp_h, H), s);  // dh = dgates . W_hh + pass-through of dead rows
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -160,6 +160,19 @@ class _Decoder(torch.nn.Module):
                 torch.nn.init.xavier_uniform_(m.weight, torch.nn.init.calculate_gain("tanh"))
 
 
+class _HipLoss(torch.autograd.Function):
+    """loss value computed by the HIP engine; backward returns the engine's gradients (scaled by the incoming grad)."""
+
+    @staticmethod
+    def forward(ctx, value, grads, *params):
+        ctx.grads = grads
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return (None, None) + tuple(g * grad_out for g in ctx.grads)
+
+
 class Tacotron2Base(TTSInterface, torch.nn.Module):
     """role: "teacher" | "kd_teacher" | "student"."""
 
@@ -268,20 +281,24 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
 
     def forward(self, xs, ilens, ys, olens, spembs=None, extras=None, new_ys=None, non_zero_lens_mask=None, ds_nonzeros=None,
                 output_masks=None, position=None, f0=None, energy=None, teacher_knowledge=None, *args, **kwargs):
-        """Teacher-forced forward on the HIP path, EVALUATION mode (what the reference's CustomEvaluator runs,
-        tts.py:76-108): returns the scalar loss (kd_teacher: the 5-tuple) and reports the named losses.  Same keyword
-        batch as the reference (tts.py:277-305); `output_masks` / `position` are accepted and recomputed on device
-        (make_non_pad_mask(ds_nonzeros); t/d in-kernel).  Train-mode forward/backward is a later hot-path row."""
+        """Teacher-forced forward on the HIP path: returns the scalar loss (kd_teacher: the 5-tuple) and reports the named losses.  Same
+        keyword batch as the reference (tts.py:277-305); `output_masks` / `position` are accepted and recomputed on device
+        (make_non_pad_mask(ds_nonzeros); t/d in-kernel).
+          .eval()   what the reference's CustomEvaluator runs (tts.py:76-108): no gradients;
+          .train()  what CustomUpdater runs (tts.py:156-161, tts_distill.py:159-161): forward AND backward run fused in libfcl_hip.so
+                    (fcl_taco2_amd.training.TrainEngine, train-form BatchNorm / dropout / zoneout, masks drawn on the device); the returned
+                    loss is attached to the parameters through a torch.autograd.Function whose backward hands the HIP-computed gradients
+                    to autograd, so the reference's `loss.backward(); clip_grad_norm_(model.parameters()); optimizer.step()` works as is."""
+        if spembs is not None:
+            raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
+        batch = dict(xs=xs, ilens=ilens, ys=ys, olens=olens, extras=extras, new_ys=new_ys, non_zero_lens_mask=non_zero_lens_mask,
+                     ds_nonzeros=ds_nonzeros, f0=f0, energy=energy)
         if self.training:
-            raise NotImplementedError(
-                "fcl-taco2_amd: train-mode forward()/backward is not on the HIP path yet (SURVEY.md §8a H13); call .eval() "
-                "for the evaluation forward.")
+            return self._forward_train(batch, teacher_knowledge, kwargs.get("masks"))
         if spembs is not None:
             raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
         from .. import teacher_forced as TF
 
-        batch = dict(xs=xs, ilens=ilens, ys=ys, olens=olens, extras=extras, new_ys=new_ys, non_zero_lens_mask=non_zero_lens_mask,
-                     ds_nonzeros=ds_nonzeros, f0=f0, energy=energy)
         plan = self.plan(xs.device if xs.is_cuda else None)
         kw = dict(seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
         kw.update({k: kwargs[k] for k in ("dropout_mode", "prenet_keep", "seed") if k in kwargs})
@@ -298,6 +315,35 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
                  "decoder_loss", "prosody_loss", "loss"]
         self.reporter.report([{k: float(rep[k])} for k in order if k in rep])
         return torch.tensor(float(rep["loss"]), dtype=torch.float32, device=plan.device)
+
+    def train_engine(self, **kw):
+        """The fused forward/backward engine bound to this module's parameters (created on first use; parameters are re-pointed into its
+        flat buffer, so torch optimizers and state_dict() keep working on the same storage)."""
+        if getattr(self, "_engine", None) is None:
+            from ..training import TrainEngine
+
+            self._engine = TrainEngine(self, **kw)
+        return self._engine
+
+    def _forward_train(self, batch, teacher_knowledge, masks=None):
+        eng = self.train_engine()
+        self._plan = None  # weights are about to move
+        if self.role == "kd_teacher":
+            with torch.no_grad():
+                return eng.knowledge(batch, mode="train", masks=masks)
+        eng.zero_grad()  # accumulation across micro-batches is autograd's job on this path (p.grad += ...)
+        accum, eng.accum_grad = eng.accum_grad, 1
+        try:
+            rep = eng.forward_backward(batch, teacher_knowledge, mode="train", masks=masks)
+        finally:
+            eng.accum_grad = accum
+        order = ["l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss", "encoder_loss",
+                 "decoder_loss", "prosody_loss", "loss"]
+        self.reporter.report([{k: float(rep[k])} for k in order if k in rep])
+        names = [k for k, p in self.named_parameters() if p.requires_grad]
+        params = [p for _, p in self.named_parameters() if p.requires_grad]
+        value = torch.tensor(float(rep["loss"]), dtype=torch.float32, device=eng.dev)
+        return _HipLoss.apply(value, [eng.G[k] for k in names], *params)
 
     @property
     def base_plot_keys(self):

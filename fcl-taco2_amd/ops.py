@@ -265,14 +265,15 @@ def bernoulli_u8(shape, p_one, seed, device, seed_dev=None):
     return out
 
 
-def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None, zone_keep_c=None, row_len=None, step=0, out=None):
+def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None, zone_keep_c=None, row_len=None, step=0, out=None, dh_out2=None):
     m, u = c_old.shape
     if out is not None:
         dgates, dh_old, dc_old = out
     else:
         dgates = torch.empty(m, 4 * u, device=gates.device, dtype=torch.float32)
         dh_old, dc_old = torch.empty_like(c_old), torch.empty_like(c_old)
-    check(_lib.load().fcl_lstm_cell_bwd(_p(gates), _p(c_old), _p(c_new), _p(dh_out), _p(dc_out), zoneout, _p(zone_keep_h, torch.uint8),
+    check(_lib.load().fcl_lstm_cell_bwd(_p(gates), _p(c_old), _p(c_new), _p(dh_out), None if dh_out2 is None else dh_out2.data_ptr(),
+                                        0 if dh_out2 is None else dh_out2.stride(0), _p(dc_out), zoneout, _p(zone_keep_h, torch.uint8),
                                         _p(zone_keep_c, torch.uint8), _p(row_len, torch.int32), step, _p(dgates), _p(dh_old), _p(dc_old), m, u, _stream()))
     return dgates, dh_old, dc_old
 
@@ -336,3 +337,65 @@ def lstm_step(terms, M, U, h_in, h_out, c, G=None, g_row_mul=1, g_row_add=0, bia
     if save is not None:
         a.save_gates, a.save_c_new, a.save_c_old, a.save_h_old = [t.data_ptr() for t in save]
     check(_lib.load().fcl_lstm_step_fwd(C.byref(a), _stream()))
+
+
+# ---- the training step's time loops: one call enqueues a whole recurrence (csrc/train_loops.hip) ---------------------------------------------
+def _ptrs(ctype_array, tensors):
+    for i, t in enumerate(tensors):
+        ctype_array[i] = _p(t)
+
+
+def decoder_train_fwd(live_rows, p1d, g0, w0_pre, w0_hh, w0_pos, dur_i32, w1_ih, w1_hh, b1, zoneout, zk, s0, s1, h0_all, h1_all):
+    """live_rows: host int32 [lmax]; zk: None or [[h0, c0], [h1, c1]] uint8 [F, U]; s0/s1: (gates, c_new, c_old, h_old) outputs."""
+    lib = _lib.load()
+    n, u = g0.shape[0], h0_all.shape[1]
+    a = _lib.DecoderTrain(n=n, lmax=int(live_rows.shape[0]), u=u, p=p1d.shape[1], live_rows_host=live_rows.ctypes.data, p1d=_p(p1d), g0=_p(g0),
+                          w0_pre=_p(w0_pre), w0_hh=_p(w0_hh), w0_pos=_p(w0_pos), dur=_p(dur_i32, torch.int32), w1_ih=_p(w1_ih), w1_hh=_p(w1_hh), b1=_p(b1),
+                          zoneout=zoneout, h0_all=_p(h0_all), h1_all=_p(h1_all))
+    if zk is not None:
+        a.zk_h0, a.zk_c0, a.zk_h1, a.zk_c1 = [_p(t, torch.uint8) for t in (zk[0][0], zk[0][1], zk[1][0], zk[1][1])]
+    _ptrs(a.s0, s0)
+    _ptrs(a.s1, s1)
+    nbytes = lib.fcl_decoder_train_workspace_bytes(n, u)
+    ws = torch.empty(nbytes, device=g0.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.fcl_decoder_train_fwd(C.byref(a), _stream()))
+
+
+def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all):
+    lib = _lib.load()
+    u = dh1_all.shape[1]
+    a = _lib.DecoderBptt(n=n, lmax=int(live_rows.shape[0]), u=u, live_rows_host=live_rows.ctypes.data, zoneout=zoneout, dh1_all=_p(dh1_all),
+                         dh0_all=_p(dh0_all), w1_ih_t=_p(w1_ih_t), w1_hh_t=_p(w1_hh_t), w0_hh_t=_p(w0_hh_t), dg0_all=_p(dg0_all), dg1_all=_p(dg1_all))
+    if zk is not None:
+        a.zk_h0, a.zk_c0, a.zk_h1, a.zk_c1 = [_p(t, torch.uint8) for t in (zk[0][0], zk[0][1], zk[1][0], zk[1][1])]
+    _ptrs(a.s0, s0[:3])
+    _ptrs(a.s1, s1[:3])
+    nbytes = lib.fcl_decoder_train_workspace_bytes(n, u)
+    ws = torch.empty(nbytes, device=dh1_all.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.fcl_decoder_bptt(C.byref(a), _stream()))
+
+
+def bilstm_train_fwd(gx, w_hh, lens_i32, b, t, reverse, out, col_off, s):
+    lib = _lib.load()
+    h = w_hh.shape[1]
+    a = _lib.BilstmTrain(b=b, t=t, h=h, reverse=int(reverse), lens=_p(lens_i32, torch.int32), gx=_p(gx), w_hh=_p(w_hh), out=_p(out), ld_out=out.shape[1],
+                         col_off=col_off)
+    _ptrs(a.s, s)
+    nbytes = lib.fcl_bilstm_train_workspace_bytes(b, h)
+    ws = torch.empty(nbytes, device=gx.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.fcl_bilstm_train_fwd(C.byref(a), _stream()))
+
+
+def bilstm_bptt(s, lens_i32, b, t, reverse, d_out, col_off, w_hh_t, dg):
+    lib = _lib.load()
+    h = w_hh_t.shape[0]
+    a = _lib.BilstmBptt(b=b, t=t, h=h, reverse=int(reverse), lens=_p(lens_i32, torch.int32), d_out=_p(d_out), ld_dout=d_out.shape[1], col_off=col_off,
+                        w_hh_t=_p(w_hh_t), dg=_p(dg))
+    _ptrs(a.s, s[:3])
+    nbytes = lib.fcl_bilstm_train_workspace_bytes(b, h)
+    ws = torch.empty(nbytes, device=d_out.device, dtype=torch.uint8)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
+    check(lib.fcl_bilstm_bptt(C.byref(a), _stream()))

@@ -238,43 +238,31 @@ class TrainEngine(object):
     def _bilstm_fwd(self, x, lens_dev, B, T):
         P, dev = self.P, self.dev
         H = self.hp.eunits // 2
-        out = torch.zeros(B * T, 2 * H, device=dev)
+        out = torch.empty(B * T, 2 * H, device=dev)
         cache = []
         for d, sfx in enumerate(("", "_reverse")):
             w_ih, w_hh = P["enc.blstm.weight_ih_l0" + sfx], P["enc.blstm.weight_hh_l0" + sfx]
             bias = ops.add_vec(P["enc.blstm.bias_ih_l0" + sfx], P["enc.blstm.bias_hh_l0" + sfx])
             gx = ops.linear(x, w_ih, bias)  # [B*T, 4H]
-            h = [torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)]
-            cst = torch.zeros(B, H, device=dev)
-            sv = [torch.empty(T, B, 4 * H, device=dev)] + [torch.empty(T, B, H, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
-            cur = 0
-            order = range(T) if d == 0 else range(T - 1, -1, -1)
-            for t in order:
-                ops.lstm_step([(h[cur], w_hh, H)], B, H, h[cur], h[cur ^ 1], cst, G=gx, g_row_mul=T, g_row_add=t, step=t, row_len=lens_dev,
-                              out2=out, out2_row_mul=T, out2_row_add=t, ld2=2 * H, out2_col_off=d * H, save=[s[t] for s in sv])
-                cur ^= 1
-            cache.append((sv, order))
+            sv = [torch.empty(T, B, 4 * H, device=dev)] + [torch.empty(T, B, H, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old (t-major)
+            ops.bilstm_train_fwd(gx, w_hh, lens_dev, B, T, d == 1, out, d * H, sv)
+            cache.append(sv)
         return out, dict(x=x, dirs=cache, B=B, T=T, lens=lens_dev)
 
     def _bilstm_bwd(self, d_out, c):
         P, G, dev = self.P, self.G, self.dev
         B, T, H = c["B"], c["T"], self.hp.eunits // 2
         dx = torch.zeros_like(c["x"])
-        d3 = d_out.reshape(B, T, 2 * H)
+        if c.get("perm") is None:  # (b, t) row -> t-major row of the saved / gradient tensors
+            c["perm"] = _i32((np.arange(B * T) % T) * B + np.arange(B * T) // T, dev)
         for d, sfx in enumerate(("", "_reverse")):
-            sv, order = c["dirs"][d]
+            sv = c["dirs"][d]
             w_ih, w_hh = P["enc.blstm.weight_ih_l0" + sfx], P["enc.blstm.weight_hh_l0" + sfx]
-            whh_t = self._wt(w_hh)  # [H, 4H]
-            dgx = torch.zeros(B * T, 4 * H, device=dev)
-            dgx3 = dgx.reshape(B, T, 4 * H)
-            dh_carry, dc_carry = torch.zeros(B, H, device=dev), torch.zeros(B, H, device=dev)
-            for t in reversed(list(order)):
-                ops.add2d(dh_carry, d3[:, t, d * H : (d + 1) * H])  # d_out is already zero on padded rows (masked by the caller)
-                dgates, dh_old, dc_old = ops.lstm_cell_bwd(sv[0][t], sv[2][t], sv[1][t], dh_carry, dc_carry, 0.0, row_len=c["lens"], step=t)
-                dh_carry = ops.add2d(ops.linear(dgates, whh_t), dh_old)
-                dc_carry = dc_old
-                ops.gemm_tn(dgates, sv[3][t], G["enc.blstm.weight_hh_l0" + sfx])
-                ops.copy2d(dgx3[:, t], dgates)  # Gx rows are (b, t)
+            dg = torch.empty(T, B, 4 * H, device=dev)  # d_out is already zero on padded rows (masked by the caller); dead cells get dg = 0
+            ops.bilstm_bptt(sv, c["lens"], B, T, d == 1, d_out, d * H, self._wt(w_hh), dg)
+            dg2 = dg.reshape(T * B, 4 * H)
+            ops.gemm_tn(dg2, sv[3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
+            dgx = ops.gather_rows(dg2, c["perm"])  # back to (b, t) rows like x
             ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
             ops.colsum(dgx, G["enc.blstm.bias_ih_l0" + sfx])
             ops.colsum(dgx, G["enc.blstm.bias_hh_l0" + sfx])
@@ -419,20 +407,9 @@ class TrainEngine(object):
         c.S0 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
         c.S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
         c.h0_all, c.h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
-        h0 = [torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)]
-        h1 = [torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)]
-        c0, c1 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)
-        cur = 0
-        for t in range(lmax):
-            n, o = int(live[t]), int(offs[t])
-            sl = slice(o, o + n)
-            z0 = dict(zone_keep_h=c.zk[0][0][sl], zone_keep_c=c.zk[0][1][sl]) if c.zk else {}
-            z1 = dict(zone_keep_h=c.zk[1][0][sl], zone_keep_c=c.zk[1][1][sl]) if c.zk else {}
-            ops.lstm_step([(c.p1d[sl], c.w0_pre, Pn), (h0[cur], c.w0_hh, U)], n, U, h0[cur], h0[cur ^ 1], c0, G=G0, rank1_w=w0_pos, dur=c.dur_dev,
-                          step=t, zoneout=c.zr, out2=c.h0_all[sl], out2_row_mul=1, ld2=U, save=[s[sl] for s in c.S0], **z0)
-            ops.lstm_step([(h0[cur ^ 1], c.w1_ih, U), (h1[cur], c.w1_hh, U)], n, U, h1[cur], h1[cur ^ 1], c1, bias=b1s, step=t, zoneout=c.zr,
-                          out2=c.h1_all[sl], out2_row_mul=1, ld2=U, save=[s[sl] for s in c.S1], **z1)
-            cur ^= 1
+        c.live_i32 = np.ascontiguousarray(live, dtype=np.int32)
+        ops.decoder_train_fwd(c.live_i32, c.p1d, G0, c.w0_pre, c.w0_hh, w0_pos, c.dur_dev, c.w1_ih, c.w1_hh, b1s, c.zr, c.zk, c.S0, c.S1, c.h0_all,
+                              c.h1_all)
         out_cells = ops.linear(c.h1_all, c.wf_h)
         ops.add2d(out_cells, ops.gather_rows(F0, c.cell_row_i32))
         c.before = ops.gather_rows(out_cells, c.frame_cell)  # [B*L, O], zero where no cell maps (padding)
@@ -561,31 +538,11 @@ class TrainEngine(object):
         ops.scatter_add_rows(d_out_cells, c.cell_row_i64, dF0)
         ops.gemm_tn(dF0, c.att_c, g_wf[:, U:])
         d_att_c = ops.linear(dF0, self._wt(c.wf_att))
-        w1ih_t, w1hh_t, w0hh_t, w0pre_t = self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh), self._wt(c.w0_pre)
         dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
-        dp1_all = torch.empty(F, Pn, device=dev)
-        ch0, cc0 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)  # carries: grads w.r.t. the state entering step t+1
-        ch1, cc1 = torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)
-        tmp_h, tmp_c = torch.empty(N, U, device=dev), torch.zeros(N, U, device=dev)
+        ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh),
+                         dg0_all, dg1_all)
+        dp1_all = ops.linear(dg0_all, self._wt(c.w0_pre))  # [F, P]: gradient w.r.t. the prenet output of every cell
         S0, S1 = c.S0, c.S1
-        for t in range(lmax - 1, -1, -1):  # live rows only grow as t falls, so carries of newly-live rows are still zero
-            n, o = int(live[t]), int(offs[t])
-            sl = slice(o, o + n)
-            z0 = dict(zone_keep_h=c.zk[0][0][sl], zone_keep_c=c.zk[0][1][sl]) if c.zk else {}
-            z1 = dict(zone_keep_h=c.zk[1][0][sl], zone_keep_c=c.zk[1][1][sl]) if c.zk else {}
-            ops.add2d(ch1[:n], dh1_all[sl])
-            ops.lstm_cell_bwd(S1[0][sl], S1[2][sl], S1[1][sl], ch1[:n], cc1[:n], c.zr, out=(dg1_all[sl], tmp_h[:n], tmp_c[:n]), **z1)
-            ops.linear(dg1_all[sl], w1hh_t, out=ch1[:n])
-            ops.add2d(ch1[:n], tmp_h[:n])
-            cc1, tmp_c = tmp_c, cc1
-            ops.add2d(ch0[:n], ops.linear(dg1_all[sl], w1ih_t))
-            if "h0" in inj:
-                ops.add2d(ch0[:n], inj["h0"][sl])
-            ops.lstm_cell_bwd(S0[0][sl], S0[2][sl], S0[1][sl], ch0[:n], cc0[:n], c.zr, out=(dg0_all[sl], tmp_h[:n], tmp_c[:n]), **z0)
-            ops.linear(dg0_all[sl], w0hh_t, out=ch0[:n])
-            ops.add2d(ch0[:n], tmp_h[:n])
-            cc0, tmp_c = tmp_c, cc0
-            ops.linear(dg0_all[sl], w0pre_t, out=dp1_all[sl])
         # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
         ops.gemm_tn(dg1_all, c.h0_all, G["dec.lstm.1.cell.weight_ih"])
         ops.gemm_tn(dg1_all, S1[3], G["dec.lstm.1.cell.weight_hh"])

@@ -255,14 +255,77 @@ int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const
                    float* y_act, float* y_drop, int m, int c, int act, fcl_stream_t stream);
 int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
                float* dz, int m, int c, fcl_stream_t stream);
+/* ---- the training step's time loops, enqueued by ONE call each (H13; decoder_sa.py:472-515, encoder_sa.py:143-146) ----------------------------
+ * Cells are step-major: rows sorted by duration descending, cell (t, m) at offset(t) + m with offset(t) = sum_{t' < t} live_rows[t'].
+ * s0 / s1 (decoder layers) and s (BiLSTM direction) are the saved tensors {gates [.,4U], c_new, c_old, h_old [.,U]} fcl_lstm_cell_bwd needs. */
+typedef struct {
+    int n, lmax, u, p;              /* sorted rows, steps, dunits, prenet units */
+    const int32_t* live_rows_host;  /* [lmax] HOST */
+    const float* p1d;               /* [F, P] prenet output per cell (after dropout) */
+    const float* g0;                /* [N, 4U] att_c . W0_att^T + b0 (hoisted out of the loop) */
+    const float *w0_pre, *w0_hh, *w0_pos;
+    const int32_t* dur;             /* [N] device */
+    const float *w1_ih, *w1_hh, *b1;
+    float zoneout;
+    const uint8_t *zk_h0, *zk_c0, *zk_h1, *zk_c1; /* optional sampled zoneout masks [F, U] (1 keeps the old state), all or none */
+    float* s0[4];
+    float* s1[4];
+    float *h0_all, *h1_all;         /* [F, U] zoneout-ed outputs of both layers */
+    void* workspace;
+    size_t workspace_bytes;         /* fcl_decoder_train_workspace_bytes(n, u) */
+} fcl_decoder_train_t;
+typedef struct {
+    int n, lmax, u;
+    const int32_t* live_rows_host;
+    const float* s0[3];             /* gates, c_new, c_old of layer 0 (as saved by the forward) */
+    const float* s1[3];
+    float zoneout;
+    const uint8_t *zk_h0, *zk_c0, *zk_h1, *zk_c1;
+    const float* dh1_all;           /* [F, U] gradient w.r.t. layer-1 outputs (feat_out path + KD tap) */
+    const float* dh0_all;           /* optional [F, U] extra gradient w.r.t. layer-0 outputs (KD tap) */
+    const float *w1_ih_t, *w1_hh_t, *w0_hh_t; /* transposed weights [U, 4U] */
+    float *dg0_all, *dg1_all;       /* out [F, 4U]: gate pre-activation gradients of every cell */
+    void* workspace;
+    size_t workspace_bytes;
+} fcl_decoder_bptt_t;
+typedef struct {
+    int b, t, h, reverse;
+    const int32_t* lens;            /* [B] device */
+    const float* gx;                /* [B*T, 4H] x . W_ih^T + bias_ih + bias_hh of this direction, rows (b, t) */
+    const float* w_hh;              /* [4H, H] */
+    float* out;                     /* [B*T, ld_out]; this direction writes columns [col_off, col_off + H), zeros past each length */
+    int ld_out, col_off;
+    float* s[4];                    /* saved, t-major: gates [T, B, 4H], c_new, c_old, h_old [T, B, H] */
+    void* workspace;
+    size_t workspace_bytes;         /* fcl_bilstm_train_workspace_bytes(b, h) */
+} fcl_bilstm_train_t;
+typedef struct {
+    int b, t, h, reverse;
+    const int32_t* lens;
+    const float* s[3];              /* gates, c_new, c_old */
+    const float* d_out;             /* [B*T, ld_dout] gradient w.r.t. the layer output (zero on padded rows), columns [col_off, col_off + H) */
+    int ld_dout, col_off;
+    const float* w_hh_t;            /* [H, 4H] */
+    float* dg;                      /* out, t-major [T, B, 4H] */
+    void* workspace;
+    size_t workspace_bytes;
+} fcl_bilstm_bptt_t;
+size_t fcl_decoder_train_workspace_bytes(int n, int u);
+int fcl_decoder_train_fwd(const fcl_decoder_train_t* args, fcl_stream_t stream);
+int fcl_decoder_bptt(const fcl_decoder_bptt_t* args, fcl_stream_t stream);
+size_t fcl_bilstm_train_workspace_bytes(int b, int h);
+int fcl_bilstm_train_fwd(const fcl_bilstm_train_t* args, fcl_stream_t stream);
+int fcl_bilstm_bptt(const fcl_bilstm_bptt_t* args, fcl_stream_t stream);
 /* x *= alpha (gradient averaging after a SUM all-reduce on backends without AVG). */
 int fcl_scale(float* x, size_t n, float alpha, fcl_stream_t stream);
 /* out[i] = 1 with probability p_one: counter hash of (seed + *seed_dev, i).  The training path's source of dropout keep masks
  * (p_one = 1 - p) and zoneout keep-old masks (p_one = zoneout rate); not bit-compatible with torch's Philox stream by design. */
 int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const uint32_t* seed_dev, fcl_stream_t stream);
 /* LSTMCell + zoneout backward of one step from the forward's saved gate activations [M,4U] (i,f,g,o), c_old and c_new (raw):
- * dgates [M,4U] (pre-activation), dh_old (zoneout keep path), dc_old.  The caller adds dgates . W_hh to dh_old. */
-int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dc_out, float zoneout,
+ * dgates [M,4U] (pre-activation), dh_old (zoneout keep path), dc_old.  The caller adds dgates . W_hh to dh_old.
+ * dh_out2 (optional, row stride ld_dh2) is added to dh_out: the per-step output gradient next to the recurrent carry. */
+int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dh_out2, int ld_dh2,
+                      const float* dc_out, float zoneout,
                       const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step, float* dgates, float* dh_old,
                       float* dc_old, int m, int u, fcl_stream_t stream);
 /* dst[idx[m], :] += src[m, :]  (embedding gradient; idx == skip rows are dropped: padding_idx). */

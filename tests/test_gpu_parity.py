@@ -522,8 +522,24 @@ def test_model_forward_eval_via_plugin_classes(ops, golden):
     loss = student(teacher_knowledge=know, **x)
     assert loss.is_cuda and abs(float(loss) - float(g["student_share_loss"])) < tol(1e-4, 5e-4) * max(1.0, float(g["student_share_loss"]))
     assert abs(student.reporter.last["decoder_loss"] - float(g["student_share_decoder_loss"])) < tol(1e-4, 5e-4)
-    with pytest.raises(NotImplementedError):
-        student.train()(teacher_knowledge=know, **x)
+    # train mode: the reference's update sequence works unchanged on the plug-in classes (tts_distill.py:159-177)
+    teacher.train()
+    student.train()
+    opt = torch.optim.Adam(student.parameters(), lr=1e-3, eps=1e-6)
+    w0 = student.state_dict()["dec.feat_out.weight"].clone()
+    rm0 = teacher.state_dict()["enc.convs.0.1.running_mean"].clone()
+    know = teacher(**x)
+    loss = student(teacher_knowledge=know, **x).mean() / 1
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(student.parameters(), 1.0)
+    assert np.isfinite(float(gn)) and float(gn) > 0 and all(p.grad is not None for p in student.parameters())
+    opt.step()
+    opt.zero_grad()
+    assert max_abs(student.state_dict()["dec.feat_out.weight"], w0) > 1e-4  # weights moved
+    assert max_abs(teacher.state_dict()["enc.convs.0.1.running_mean"], rm0) > 0  # the frozen train-mode teacher still updates its BN buffers
+    assert set(student.reporter.last) >= {"loss", "encoder_loss", "decoder_loss", "prosody_loss"}
+    student.eval()
+    assert np.isfinite(float(student(teacher_knowledge=know, **x)))  # eval forward after the step sees the updated weights through a fresh plan
 
 
 def test_decode_driver_end_to_end(ops, golden, tmp_path):

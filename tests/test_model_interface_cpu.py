@@ -70,7 +70,7 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True)), com())
     m = cls(80, 80, argparse.Namespace(**T_ARGS), com())
-    with pytest.raises(NotImplementedError):  # train-mode forward/backward is not on the HIP path yet
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # train-mode forward runs the fused HIP engine: needs the model on a GPU
         m.train().forward(torch.zeros(1, 3, dtype=torch.long), [3], torch.zeros(1, 3, 80), [3])
     m.eval()
     from fcl_taco2_amd import _lib

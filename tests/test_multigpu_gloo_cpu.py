@@ -58,3 +58,52 @@ def test_two_rank_gloo_reduction():
     assert t0 == t1 == 2.0  # MAX over ranks
     assert f0 == f1 == float(total)  # SUM over ranks
     assert c0 == c1 and sum(sum(c) for c in c0) == total
+
+
+# ---- training: the gradient exchange step (one all-reduce per iteration, bucketed, overlapped with backward) ----------------
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fcl_taco2_amd import hparams as HP
+    from fcl_taco2_amd.training import GradBuckets, flat_layout
+
+    spec = HP.param_spec(HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12,
+                                            duration_predictor_chans=20),
+                         HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20,
+                                            duration_predictor_chans=20), True)
+    names, offs, bounds = flat_layout([(k, int(np.prod(v))) for k, v in spec.items() if "running" not in k and "num_batches" not in k])
+    flat = torch.from_numpy(np.random.RandomState(100 + rank).randn(int(offs[-1])).astype(np.float32))
+    mine = flat.clone()
+    b = GradBuckets(flat, bounds)
+    for i in range(len(bounds) - 1):  # the engine launches bucket i when backward has finished group i
+        b.launch(i)
+    b.finish()
+    q.put((rank, bounds, mine.numpy(), flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_buckets_average():
+    from fcl_taco2_amd.training import _GROUPS, flat_layout, group_of
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, bounds, g0, avg0), (_, _, g1, avg1) = res
+    assert bounds[0] == 0 and bounds[-1] == g0.shape[0] and all(a <= b for a, b in zip(bounds, bounds[1:])) and len(bounds) == len(_GROUPS) + 1
+    assert np.array_equal(avg0, avg1)  # every rank ends with the same gradients -> same grad-norm -> all skip / step together (tts.py:173-178)
+    assert np.allclose(avg0, (g0 + g1) / 2, atol=1e-7)
+    # layout: parameters are grouped by when backward finishes them, slots 256-byte aligned
+    names, offs, b2 = flat_layout([("enc.embed.weight", 7), ("dec.postnet.postnet.0.0.weight", 5), ("dec.feat_out.weight", 3), ("pitch_embed.0.bias", 2)])
+    assert names == ["dec.postnet.postnet.0.0.weight", "dec.feat_out.weight", "pitch_embed.0.bias", "enc.embed.weight"]
+    assert list(offs) == [0, 64, 128, 192, 256] and b2 == [0, 64, 128, 192, 256] and [group_of(n) for n in names] == [0, 1, 2, 3]

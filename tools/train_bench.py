@@ -1,0 +1,73 @@
+"""KD / teacher training step timing on one GPU: python tools/train_bench.py [--role student|teacher] [--batch 32] [--steps 5]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import fcl_taco2_amd  # noqa: E402,F401
+from fcl_taco2_amd import _lib, hparams as HP, synthetic as SYN  # noqa: E402
+from fcl_taco2_amd.converter import CustomConverter  # noqa: E402
+from fcl_taco2_amd.training import TrainEngine  # noqa: E402
+
+
+def ns(hp):
+    return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
+                              postnet_chans=hp.postnet_chans, use_residual=False, use_masking=True, dropout_rate=hp.dropout_rate,
+                              duration_predictor_chans=hp.duration_predictor_chans)
+
+
+def build(role, hp, thp=None, dev="cuda:0"):
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
+    from fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa as Teacher
+
+    com = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
+                             distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=True, share_proj=True)
+    if role == "student":
+        m = Student(hp.idim, hp.odim, ns(hp), com, ns(thp))
+        spec = HP.param_spec(hp, thp, True)
+    else:
+        m = (Teacher if role == "teacher" else KDTeacher)(hp.idim, hp.odim, ns(hp), com)
+        spec = HP.param_spec(hp)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in SYN.closed_form_state_dict(spec).items()})
+    return m.to(dev)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--role", default="student")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    a = ap.parse_args()
+    S, T = HP.student_hparams(), HP.teacher_hparams()
+    xs, ys, ds, f0, en = SYN.training_batch(80, S.idim, batch=a.batch, t_lo=60, t_hi=100, seed=1234, zero_frac=0.03, lam=10.0, hi=50)
+    batch = CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)])
+    frames = int(sum(y.shape[0] for y in ys))
+    if a.role == "student":
+        teng = TrainEngine(build("kd_teacher", T))
+        eng = TrainEngine(build("student", S, T))
+    else:
+        teng, eng = None, TrainEngine(build("teacher", T))
+
+    def step():
+        know = teng.knowledge(batch, mode="train") if teng else None
+        return eng.train_step(batch, know, mode="train")
+
+    for _ in range(a.warmup):
+        rep = step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(a.steps):
+        rep = step()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / a.steps
+    print("role %s  B=%d frames=%d  step %.1f ms  (%.0f frames/s)  loss %.4f gn %.3f" % (a.role, a.batch, frames, dt * 1e3, frames / dt, rep["loss"], rep["grad_norm"]))
+
+
+if __name__ == "__main__":
+    main()
