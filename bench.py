@@ -64,6 +64,66 @@ def pmc_traffic(kernel):
     return (2.0 * vals["fetch"][0] + vals["write"][0]) * 1024.0, "%s + %s" % (vals["fetch"][1], vals["write"][1])
 
 
+def train_workload(args, rank, world, dev, dist):
+    """KD step (frozen train-mode FCL-taco2-T forward -> FCL-taco2-S forward / backward / all-reduce / clip / Adam, tts_distill.py:143-182) or the
+    teacher's own training step (tts.py:137-179), train-form regularisers, masks drawn on the device.  One process per GPU; gradients are
+    averaged over ranks in buckets overlapped with backward (RCCL).  `value` = ms per step (MAX over ranks)."""
+    import numpy as np
+    import torch
+
+    from fcl_taco2_amd import hparams as HP, sharding, synthetic as SYN
+    from fcl_taco2_amd.converter import CustomConverter
+    from fcl_taco2_amd.training import TrainEngine
+
+    S, T = HP.student_hparams(), HP.teacher_hparams()
+    kd = args.workload == "kd_step"
+    B = args.batch if (kd or args.batch != 32) else 16  # shipped recipes: 32 / GPU for KD, 16 / GPU for the teacher (SURVEY.md §8d C3/C4)
+    xs, ys, ds, f0, en = SYN.training_batch(80, S.idim, batch=B, t_lo=60, t_hi=100, seed=1234 + rank, zero_frac=0.03, lam=10.0, hi=50)
+    batch = CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)])
+    frames = int(sum(y.shape[0] for y in ys))
+    teng = TrainEngine(SYN.build_model("kd_teacher", T, None, dev)) if kd else None
+    eng = TrainEngine(SYN.build_model("student", S, T, dev) if kd else SYN.build_model("teacher", T, None, dev), seed=rank)
+
+    def step():
+        know = teng.knowledge(batch, mode="train") if kd else None
+        return eng.train_step(batch, know, mode="train")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    steps, warmup = args.steps, args.warmup
+    for _ in range(warmup):
+        rep = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rep = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    dt, frames_all = sharding.aggregate_throughput(dt, frames, dist, dev)
+    ms = 1e3 * dt / steps
+    # algorithmic FLOPs per frame per step (SURVEY.md §8d): KD = teacher fwd 42.3 + 3 x (student 4.29 + projections 1.89) = 61 MFLOP; teacher = 3 x 42.3
+    mflop = 61.0 if kd else 127.0
+    achieved = mflop * 1e6 * frames / (dt / steps) / 1e12
+    name = "KD step" if kd else "teacher training step"
+    return {
+        "metric": "%s time (ms) (%s, batch=%d/GPU, 80-mel)" % (name, "FCL-taco2-T frozen teacher fwd + FCL-taco2-S fwd/bwd/Adam" if kd else "FCL-taco2-T fwd/bwd/Adam", B),
+        "value": ms, "unit": "ms/step", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (forward GEMMs bf16x3-split MFMA operands, fp32 accumulate; gradients exact fp32 MFMA)", "data": "synthetic",
+        "frames_per_s": frames_all * steps / dt, "loss": rep["loss"], "grad_norm": rep["grad_norm"],
+        "config": {"workload": "SURVEY §8d %s: %d utterances/GPU, 60-100 phonemes, durations clip(Poisson(10),1,50) with 3%% zero-duration phonemes, "
+                               "%d frames/GPU-batch, train-form BatchNorm / dropout / zoneout (device RNG), Adam lr 1e-3 eps 1e-6, clip 1.0, "
+                               "closed-form weights" % ("C3" if kd else "C4", B, frames),
+                   "parallelism": "dp%d: one process per GPU, gradient all-reduce (AVG) in 4 buckets overlapped with backward" % world},
+        "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "note": "algorithmic %.0f MFLOP per frame per step (SURVEY.md §8d) x frames / measured step time (per GPU)" % mflop},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +131,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", choices=["student", "teacher"], default="student")
+    ap.add_argument("--workload", choices=["synthesis", "kd_step", "teacher_step"], default="synthesis",
+                    help="synthesis = BASELINE.json's headline metric (default); kd_step / teacher_step = the training step (SURVEY.md §8d C3/C4)")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (independent passes on separate HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,6 +167,13 @@ def main():
     from fcl_taco2_amd import _lib, engine, hparams as HP, ops, synthetic as SYN
     from fcl_taco2_amd.plan import SynthesisPlan
 
+    if args.workload != "synthesis":
+        out = train_workload(args, rank, world, dev, dist)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     hp = HP.student_hparams() if args.model == "student" else HP.teacher_hparams()
     sd_np = SYN.closed_form_state_dict(HP.param_spec(hp))
     plan = SynthesisPlan(sd_np, hp, dev)

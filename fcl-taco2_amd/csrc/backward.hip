@@ -10,6 +10,7 @@
 //   * lstm_cell_bwd    : LSTMCell + zoneout backward for one step (gate pre-activation gradients);
 //   * scatter-add      : embedding gradient;  adam / sumsq: the optimizer.
 // Exact fp32 everywhere (gradients are accumulated over up to 25 k rows; the split-bf16 trick is not used here).
+#include <algorithm>
 #include "fcl_common.h"
 
 namespace fcl {
@@ -164,60 +165,82 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ x, const float* _
                                      const uint8_t* __restrict__ pad_mask, const uint8_t* __restrict__ keep, float keep_scale,
                                      float* __restrict__ dx, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, float* __restrict__ dlin_w, float* __restrict__ dlin_b, int M, int C) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (row >= M) return;
-    float v[MAXPER], gy[MAXPER];
-    float s = 0.f;
+    const int wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    // parameter gradients of this wave's rows stay in registers; one atomic per (wave, column) at the end instead of one per (row, column)
+    float gam[MAXPER], bet[MAXPER], lw[MAXPER], acc_g[MAXPER], acc_b[MAXPER], acc_w[MAXPER];
 #pragma unroll
     for (int i = 0; i < MAXPER; ++i) {
         const int j = lane + i * 64;
-        v[i] = j < C ? x[(size_t)row * C + j] : 0.f;
-        s += v[i];
+        gam[i] = j < C ? gamma[j] : 0.f;
+        bet[i] = j < C ? beta[j] : 0.f;
+        lw[i] = (ds && j < C) ? lin_w[j] : 0.f;
+        acc_g[i] = acc_b[i] = acc_w[i] = 0.f;
     }
-    const float mean = wsum(s) / (float)C;
-    float q = 0.f;
+    float acc_lb = 0.f;
+    for (int row = wave0; row < M; row += nwaves) {
+        float v[MAXPER], gy[MAXPER];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) {
-        const int j = lane + i * 64;
-        const float d = j < C ? v[i] - mean : 0.f;
-        q += d * d;
-    }
-    const float rstd = 1.0f / sqrtf(wsum(q) / (float)C + eps);
-    float dsr = 0.f;
-    if (ds) dsr = (pad_mask && pad_mask[row]) ? 0.f : ds[row];
-    float a1 = 0.f, a2 = 0.f;  // sum(g*gamma), sum(g*gamma*xh)
+        for (int i = 0; i < MAXPER; ++i) {
+            const int j = lane + i * 64;
+            v[i] = j < C ? x[(size_t)row * C + j] : 0.f;
+            s += v[i];
+        }
+        const float mean = wsum(s) / (float)C;
+        float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXPER; ++i) {
-        const int j = lane + i * 64;
-        gy[i] = 0.f;
-        if (j < C) {
-            const float xh = (v[i] - mean) * rstd;
-            float g = dy ? dy[(size_t)row * C + j] : 0.f;
-            const float ks = keep ? (keep[(size_t)row * C + j] ? keep_scale : 0.f) : 1.f;  // dropout between the LayerNorm and its consumers
-            if (ds) {
-                g += dsr * lin_w[j];
-                if (dlin_w) atomicAdd(dlin_w + j, dsr * (xh * gamma[j] + beta[j]) * ks);
+        for (int i = 0; i < MAXPER; ++i) {
+            const int j = lane + i * 64;
+            const float d = j < C ? v[i] - mean : 0.f;
+            q += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wsum(q) / (float)C + eps);
+        float dsr = 0.f;
+        if (ds) dsr = (pad_mask && pad_mask[row]) ? 0.f : ds[row];
+        acc_lb += dsr;
+        float a1 = 0.f, a2 = 0.f;  // sum(g*gamma), sum(g*gamma*xh)
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) {
+            const int j = lane + i * 64;
+            gy[i] = 0.f;
+            if (j < C) {
+                const float xh = (v[i] - mean) * rstd;
+                float g = dy ? dy[(size_t)row * C + j] : 0.f;
+                const float ks = keep ? (keep[(size_t)row * C + j] ? keep_scale : 0.f) : 1.f;  // dropout between the LayerNorm and its consumers
+                if (ds) {
+                    g += dsr * lw[i];
+                    acc_w[i] += dsr * (xh * gam[i] + bet[i]) * ks;
+                }
+                g *= ks;
+                gy[i] = g;
+                acc_g[i] += g * xh;
+                acc_b[i] += g;
+                a1 += g * gam[i];
+                a2 += g * gam[i] * xh;
             }
-            g *= ks;
-            gy[i] = g;
-            atomicAdd(dgamma + j, g * xh);
-            atomicAdd(dbeta + j, g);
-            a1 += g * gamma[j];
-            a2 += g * gamma[j] * xh;
+        }
+        a1 = wsum(a1) / (float)C;
+        a2 = wsum(a2) / (float)C;
+#pragma unroll
+        for (int i = 0; i < MAXPER; ++i) {
+            const int j = lane + i * 64;
+            if (j < C) {
+                const float xh = (v[i] - mean) * rstd;
+                dx[(size_t)row * C + j] = rstd * (gy[i] * gam[i] - a1 - xh * a2);
+            }
         }
     }
-    a1 = wsum(a1) / (float)C;
-    a2 = wsum(a2) / (float)C;
-    if (ds && dlin_b && lane == 0) atomicAdd(dlin_b, dsr);
 #pragma unroll
     for (int i = 0; i < MAXPER; ++i) {
         const int j = lane + i * 64;
         if (j < C) {
-            const float xh = (v[i] - mean) * rstd;
-            dx[(size_t)row * C + j] = rstd * (gy[i] * gamma[j] - a1 - xh * a2);
+            atomicAdd(dgamma + j, acc_g[i]);
+            atomicAdd(dbeta + j, acc_b[i]);
+            if (ds && dlin_w) atomicAdd(dlin_w + j, acc_w[i]);
         }
     }
+    if (ds && dlin_b && lane == 0) atomicAdd(dlin_b, acc_lb);
 }
 
 // LSTMCell + zoneout backward for one step.  Saved from forward: gates act [M,4U] (i,f,g,o after their nonlinearity), c_old, c_new (raw cell, before
@@ -466,7 +489,7 @@ int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, flo
     FCL_REQUIRE(x && gamma && beta && dx && dgamma && dbeta && (dy || ds) && m >= 0 && c > 0 && c <= 1024, FCL_ERR_INVALID, "layernorm_bwd: bad arguments");
     FCL_REQUIRE(!ds || lin_w, FCL_ERR_INVALID, "layernorm_bwd: ds needs lin_w");
     if (m == 0) return 0;
-    dim3 grid((m + 3) / 4), block(256);
+    dim3 grid(std::min((m + 3) / 4, 256)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define FCL_LNB(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), grid, block, 0, s, x, gamma, beta, eps, dy, lin_w, ds, pad_mask, keep, keep_scale, dx, dgamma, dbeta, dlin_w, dlin_b, m, c)
     if (c <= 64) FCL_LNB(1);

@@ -112,3 +112,31 @@ def training_batch(hp_odim=80, vocab=80, batch=4, t_lo=5, t_hi=9, seed=7, zero_f
         f0.append(p)
         en.append(rng.randn(n, 1).astype(np.float32))
     return xs, ys, ds, f0, en
+
+
+def build_model(role, hp, thp=None, device="cuda:0", share_proj=True):
+    """A plug-in model ("teacher" | "kd_teacher" | "student") with closed-form weights, the way bench / tools / smoke build one."""
+    import argparse
+
+    import torch
+
+    from . import hparams as HP
+    from .nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+    from .nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
+    from .nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa as Teacher
+
+    def ns(h):
+        return argparse.Namespace(embed_dim=h.embed_dim, eunits=h.eunits, econv_chans=h.econv_chans, dunits=h.dunits, prenet_units=h.prenet_units,
+                                  postnet_chans=h.postnet_chans, use_residual=False, use_masking=True, dropout_rate=h.dropout_rate,
+                                  duration_predictor_chans=h.duration_predictor_chans)
+
+    com = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
+                             distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=True, share_proj=share_proj)
+    if role == "student":
+        m = Student(hp.idim, hp.odim, ns(hp), com, ns(thp))
+        spec = HP.param_spec(hp, thp, share_proj)
+    else:
+        m = (Teacher if role == "teacher" else KDTeacher)(hp.idim, hp.odim, ns(hp), com)
+        spec = HP.param_spec(hp)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in closed_form_state_dict(spec).items()})
+    return m.to(device)

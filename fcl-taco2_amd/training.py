@@ -235,9 +235,14 @@ class TrainEngine(object):
         return dx
 
     # ------------------------------------------------------------------------------------------------ BiLSTM (per-step, saved)
-    def _bilstm_fwd(self, x, lens_dev, B, T):
+    def _bilstm_fwd(self, x, lens_dev, B, T, save=True):
         P, dev = self.P, self.dev
         H = self.hp.eunits // 2
+        if not save:  # forward only (the frozen KD teacher): the persistent register-resident kernel of the synthesis path
+            g = lambda k: P["enc.blstm." + k]
+            return ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), ops.add_vec(g("bias_ih_l0"), g("bias_hh_l0")),
+                              g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), ops.add_vec(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
+                              B, T), None
         out = torch.empty(B * T, 2 * H, device=dev)
         cache = []
         for d, sfx in enumerate(("", "_reverse")):
@@ -264,8 +269,10 @@ class TrainEngine(object):
             ops.gemm_tn(dg2, sv[3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
             dgx = ops.gather_rows(dg2, c["perm"])  # back to (b, t) rows like x
             ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
-            ops.colsum(dgx, G["enc.blstm.bias_ih_l0" + sfx])
-            ops.colsum(dgx, G["enc.blstm.bias_hh_l0" + sfx])
+            db = torch.zeros(1, 4 * H, device=dev)
+            ops.colsum(dgx, db.reshape(-1))
+            ops.add2d(G["enc.blstm.bias_ih_l0" + sfx].reshape(1, -1), db)
+            ops.add2d(G["enc.blstm.bias_hh_l0" + sfx].reshape(1, -1), db)
             ops.add2d(dx, ops.linear(dgx, self._wt(w_ih)))
         return dx
 
@@ -343,7 +350,7 @@ class TrainEngine(object):
             x, cc = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep)
             c.conv_c.append(cc)
             c.enc_taps.append(x)
-        c.hs, c.bl_c = self._bilstm_fwd(x, c.lens_dev, B, T)
+        c.hs, c.bl_c = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save)
         # ---- predictors + embeds
         c.d_outs, c.dur_c = self._predictor_fwd(c, c.hs, "duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_dropout_rate,
                                                 c.e_lo, c.e_hi, c.enc_pad)
@@ -546,9 +553,11 @@ class TrainEngine(object):
         # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
         ops.gemm_tn(dg1_all, c.h0_all, G["dec.lstm.1.cell.weight_ih"])
         ops.gemm_tn(dg1_all, S1[3], G["dec.lstm.1.cell.weight_hh"])
-        for nm in ("bias_ih", "bias_hh"):
-            ops.colsum(dg1_all, G["dec.lstm.1.cell." + nm])
-            ops.colsum(dg0_all, G["dec.lstm.0.cell." + nm])
+        for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
+            db = torch.zeros(1, 4 * U, device=dev)
+            ops.colsum(dg, db.reshape(-1))
+            ops.add2d(G["dec.lstm.%d.cell.bias_ih" % l].reshape(1, -1), db)
+            ops.add2d(G["dec.lstm.%d.cell.bias_hh" % l].reshape(1, -1), db)
         ops.gemm_tn(dg0_all, S0[3], G["dec.lstm.0.cell.weight_hh"])
         g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
         ops.gemm_tn(dg0_all, c.p1d, g_ih0[:, C : C + Pn])
@@ -614,11 +623,11 @@ class TrainEngine(object):
     def zero_grad(self):
         self.gflat.zero_()
 
-    def _ctx(self, batch, mode, masks):
+    def _ctx(self, batch, mode, masks, save=True):
         if mode not in ("eval", "train"):
             raise ValueError("mode must be 'eval' or 'train'")
         c = _Ctx()
-        c.train, c.masks = mode == "train", masks
+        c.train, c.masks, c.save = mode == "train", masks, save
         self.forward_count += 1
         c.draw = self.forward_count
         self._maps(c, batch)
@@ -627,7 +636,7 @@ class TrainEngine(object):
     def knowledge(self, batch, mode="train", masks=None):
         """Forward only: the frozen KD teacher's 5-tuple (tts_distill.py:159; the reference leaves the teacher in train mode)."""
         with torch.cuda.device(self.dev):
-            c = self._ctx(batch, mode, masks)
+            c = self._ctx(batch, mode, masks, save=False)
             self._forward(c, batch)
             return self._knowledge(c)
 
