@@ -55,13 +55,13 @@ class DecoderBptt(C.Structure):  # fcl_decoder_bptt_t
 
 
 class BilstmTrain(C.Structure):  # fcl_bilstm_train_t
-    _fields_ = [("b", _I), ("t", _I), ("h", _I), ("reverse", _I), ("lens", _P), ("gx", _P), ("w_hh", _P), ("out", _P), ("ld_out", _I), ("col_off", _I),
-                ("s", _P * 4), ("workspace", _P), ("workspace_bytes", _Z)]
+    _fields_ = [("b", _I), ("t", _I), ("h", _I), ("lens", _P), ("gx", _P * 2), ("w_hh", _P * 2), ("out", _P), ("s", (_P * 4) * 2), ("workspace", _P),
+                ("workspace_bytes", _Z)]
 
 
 class BilstmBptt(C.Structure):  # fcl_bilstm_bptt_t
-    _fields_ = [("b", _I), ("t", _I), ("h", _I), ("reverse", _I), ("lens", _P), ("s", _P * 3), ("d_out", _P), ("ld_dout", _I), ("col_off", _I),
-                ("w_hh_t", _P), ("dg", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+    _fields_ = [("b", _I), ("t", _I), ("h", _I), ("lens", _P), ("s", (_P * 3) * 2), ("d_out", _P), ("ld_dout", _I), ("w_hh_t", _P * 2), ("dg", _P * 2),
+                ("workspace", _P), ("workspace_bytes", _Z)]
 
 
 class ProfEntry(C.Structure):

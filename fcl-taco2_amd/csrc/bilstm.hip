@@ -17,10 +17,10 @@ namespace fcl {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-template <int H>
+template <int H, bool SAVE = false>
 __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
                                                                    const float* __restrict__ whh_f, const float* __restrict__ whh_r,
-                                                                   const int* __restrict__ lens, float* __restrict__ out, int T) {
+                                                                   const int* __restrict__ lens, float* __restrict__ out, int T, BilstmSave sv = BilstmSave()) {
     __shared__ __attribute__((aligned(16))) float h_s[H];
     __shared__ float g_s[4 * H];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
@@ -60,12 +60,73 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
         __syncthreads();
         if (j < H) {
             const float ig = sigmoid_f(g_s[j]), fg = sigmoid_f(g_s[H + j]), gg = tanh_f(g_s[2 * H + j]), og = sigmoid_f(g_s[3 * H + j]);
+            if (SAVE) {
+                const size_t cell = (size_t)t * sv.B + b;
+                float* sg = sv.gates[dir] + cell * (4 * H);
+                sg[j] = ig; sg[H + j] = fg; sg[2 * H + j] = gg; sg[3 * H + j] = og;
+                sv.c_old[dir][cell * H + j] = c;
+                sv.h_old[dir][cell * H + j] = h_s[j];
+            }
             c = fg * c + ig * gg;
+            if (SAVE) sv.c_new[dir][((size_t)t * sv.B + b) * H + j] = c;
             const float h = og * tanh_f(c);
             h_s[j] = h;
             out[((size_t)b * T + t) * (2 * H) + dir * H + j] = h;
         }
         __syncthreads();
+    }
+}
+
+// Reverse pass of one (utterance, direction): thread (q, k) = (j / H, j % H) keeps the H weights W_hh[qH .. qH+H, k] (read from the transposed
+// matrix, contiguous) in registers; per step the first H threads do the cell backward, all 4H threads a quarter of dh = dgates . W_hh, the quarters
+// meet in LDS.  Visits only live cells, in the reverse of the forward's order; the dead tail of dg is zeroed here.
+template <int H>
+__global__ __launch_bounds__(4 * H) void bilstm_bptt_persistent_kernel(BilstmBwd a, const int* __restrict__ lens, int T) {
+    __shared__ __attribute__((aligned(16))) float dg_s[4 * H];
+    __shared__ float p_s[4][H];
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    const int q = j / H, k = j % H;
+    const int len = lens[b];
+    float w[H];
+    const float* wt = a.whh_t[dir] + (size_t)k * (4 * H) + q * H;
+#pragma unroll
+    for (int r = 0; r < H; r += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wt + r);
+        w[r] = v[0]; w[r + 1] = v[1]; w[r + 2] = v[2]; w[r + 3] = v[3];
+    }
+    float* dg = a.dg[dir];
+    for (int t = len; t < T; ++t) dg[((size_t)t * a.B + b) * (4 * H) + j] = 0.f;  // dead cells contribute nothing to the weight gradients
+    float dh = 0.f, dc = 0.f;  // carries (threads j < H)
+    int t = dir ? 0 : len - 1;  // reverse of the forward visiting order
+    const int dt = dir ? 1 : -1;
+    for (int s = 0; s < len; ++s, t += dt) {
+        const size_t cell = (size_t)t * a.B + b;
+        if (j < H) {
+            const float* g = a.gates[dir] + cell * (4 * H);
+            const float ig = g[j], fg = g[H + j], gg = g[2 * H + j], og = g[3 * H + j];
+            const float dho = dh + a.d_out[((size_t)b * T + t) * a.ld + dir * H + j];
+            const float tc = tanhf(a.c_new[dir][cell * H + j]);
+            const float dcn = dc + dho * og * (1.0f - tc * tc);
+            const float d0 = dcn * gg * ig * (1.0f - ig), d1 = dcn * a.c_old[dir][cell * H + j] * fg * (1.0f - fg);
+            const float d2 = dcn * ig * (1.0f - gg * gg), d3 = dho * tc * og * (1.0f - og);
+            dg_s[j] = d0; dg_s[H + j] = d1; dg_s[2 * H + j] = d2; dg_s[3 * H + j] = d3;
+            float* o = dg + cell * (4 * H);
+            o[j] = d0; o[H + j] = d1; o[2 * H + j] = d2; o[3 * H + j] = d3;
+            dc = dcn * fg;
+        }
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < H; r += 4) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(&dg_s[q * H + r]);  // wave-uniform address (H >= 64) or 64/H addresses: broadcast
+            a0 = fmaf(w[r], dv[0], a0);
+            a1 = fmaf(w[r + 1], dv[1], a1);
+            a2 = fmaf(w[r + 2], dv[2], a2);
+            a3 = fmaf(w[r + 3], dv[3], a3);
+        }
+        p_s[q][k] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (j < H) dh = (p_s[0][j] + p_s[1][j]) + (p_s[2][j] + p_s[3][j]);
     }
 }
 
@@ -76,6 +137,42 @@ __global__ void fill_kernel(float* p, long long n, float v) {
 }  // namespace fcl
 
 using namespace fcl;
+
+namespace fcl {
+
+// both directions of the training forward / reverse pass in one launch each; false = H unsupported (the caller falls back to per-step launches)
+bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T,
+                                    int H, const BilstmSave& sv, hipStream_t s) {
+    dim3 grid(B, 2);
+#define FCL_BILSTM_CASE(HH) \
+    case HH: hipLaunchKernelGGL((bilstm_persistent_kernel<HH, true>), grid, dim3(4 * HH), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, sv); return true;
+    switch (H) {
+        FCL_BILSTM_CASE(8)
+        FCL_BILSTM_CASE(16)
+        FCL_BILSTM_CASE(32)
+        FCL_BILSTM_CASE(64)
+        FCL_BILSTM_CASE(128)
+    }
+#undef FCL_BILSTM_CASE
+    return false;
+}
+
+bool launch_bilstm_bptt_persistent(const BilstmBwd& a, const int* lens, int B, int T, int H, hipStream_t s) {
+    dim3 grid(B, 2);
+#define FCL_BILSTM_CASE(HH) \
+    case HH: hipLaunchKernelGGL((bilstm_bptt_persistent_kernel<HH>), grid, dim3(4 * HH), 0, s, a, lens, T); return true;
+    switch (H) {
+        FCL_BILSTM_CASE(8)
+        FCL_BILSTM_CASE(16)
+        FCL_BILSTM_CASE(32)
+        FCL_BILSTM_CASE(64)
+        FCL_BILSTM_CASE(128)
+    }
+#undef FCL_BILSTM_CASE
+    return false;
+}
+
+}  // namespace fcl
 
 extern "C" {
 

@@ -107,6 +107,30 @@ struct FeatPrenetArgs {
     float* tap_prenet;  // optional [F, P]; row = frame_off[m] + t_cur
 };
 
+// ---- persistent BiLSTM training kernels (bilstm.hip) ---------------------------------------------------
+// training forward: what bilstm_bptt_persistent_kernel needs, t-major ([T, B, .]); only live cells are written
+struct BilstmSave {
+    float* gates[2];  // per direction: activated i,f,g,o [T, B, 4H]
+    float* c_new[2];  // [T, B, H]
+    float* c_old[2];
+    float* h_old[2];
+    int B;
+};
+
+struct BilstmBwd {
+    const float* gates[2];
+    const float* c_new[2];
+    const float* c_old[2];
+    const float* whh_t[2];  // [H, 4H]
+    float* dg[2];           // [T, B, 4H]
+    const float* d_out;     // [B*T, ld], direction d in columns [d*H, d*H + H)
+    int ld, B;
+};
+
+bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T,
+                                    int H, const BilstmSave& sv, hipStream_t s);
+bool launch_bilstm_bptt_persistent(const BilstmBwd& a, const int* lens, int B, int T, int H, hipStream_t s);
+
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);

@@ -146,68 +146,91 @@ int fcl_decoder_bptt(const fcl_decoder_bptt_t* a, fcl_stream_t stream) {
 size_t fcl_bilstm_train_workspace_bytes(int b, int h) { return (b > 0 && h > 0) ? sizeof(float) * 4 * (size_t)b * h : 0; }
 
 int fcl_bilstm_train_fwd(const fcl_bilstm_train_t* a, fcl_stream_t stream) {
-    FCL_REQUIRE(a && a->lens && a->gx && a->w_hh && a->out && a->s[0] && a->s[1] && a->s[2] && a->s[3], FCL_ERR_INVALID, "bilstm_train_fwd: null argument");
-    FCL_REQUIRE(a->b > 0 && a->t > 0 && a->h > 0 && a->ld_out >= a->col_off + a->h, FCL_ERR_SHAPE, "bilstm_train_fwd: bad sizes");
-    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(a->b, a->h), FCL_ERR_WORKSPACE, "bilstm_train_fwd: workspace too small");
+    FCL_REQUIRE(a && a->lens && a->gx[0] && a->gx[1] && a->w_hh[0] && a->w_hh[1] && a->out, FCL_ERR_INVALID, "bilstm_train_fwd: null argument");
+    for (int d = 0; d < 2; ++d)
+        for (int i = 0; i < 4; ++i) FCL_REQUIRE(a->s[d][i], FCL_ERR_INVALID, "bilstm_train_fwd: save buffers missing");
+    FCL_REQUIRE(a->b > 0 && a->t > 0 && a->h > 0 && (a->h & 3) == 0, FCL_ERR_SHAPE, "bilstm_train_fwd: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const int B = a->b, T = a->t, H = a->h;
+    if (!tunable("BILSTM_TRAIN_STEPS", 0)) {  // one persistent launch for both directions (H in {8,16,32,64,128})
+        BilstmSave sv;
+        for (int d = 0; d < 2; ++d) { sv.gates[d] = a->s[d][0]; sv.c_new[d] = a->s[d][1]; sv.c_old[d] = a->s[d][2]; sv.h_old[d] = a->s[d][3]; }
+        sv.B = B;
+        if (launch_bilstm_train_persistent(a->gx[0], a->gx[1], a->w_hh[0], a->w_hh[1], a->lens, a->out, B, T, H, sv, s))
+            return check_hip(hipGetLastError(), "bilstm_train_fwd persistent launch");
+    }
+    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(B, H), FCL_ERR_WORKSPACE, "bilstm_train_fwd: workspace too small");
     const size_t BH = (size_t)B * H;
     float* ws = (float*)a->workspace;
-    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 3 * BH, s));
-    float *h[2] = {ws, ws + BH}, *c = ws + 2 * BH;
-    int cur = 0;
-    for (int i = 0; i < T; ++i) {
-        const int t = a->reverse ? T - 1 - i : i;
-        LstmStepArgs l = {};
-        l.term[0] = GemmTerm{h[cur], a->w_hh, H, H, H, 0, nullptr, nullptr};
-        l.nterms = 1;
-        l.M = B;
-        l.U = H;
-        l.G = a->gx;
-        l.g_row_mul = T;
-        l.g_row_add = t;
-        l.step = t;
-        l.h_in = h[cur];
-        l.h_out = h[cur ^ 1];
-        l.c = c;
-        l.row_len = a->lens;
-        l.out2 = a->out;
-        l.out2_row_mul = T;
-        l.out2_row_add = t;
-        l.ld2 = a->ld_out;
-        l.out2_col_off = a->col_off;
-        l.save_gates = a->s[0] + (size_t)t * B * 4 * H;
-        l.save_c_new = a->s[1] + (size_t)t * BH;
-        l.save_c_old = a->s[2] + (size_t)t * BH;
-        l.save_h_old = a->s[3] + (size_t)t * BH;
-        int rc = launch_lstm_step(l, s);
-        if (rc) return rc;
-        cur ^= 1;
+    for (int d = 0; d < 2; ++d) {
+        FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 3 * BH, s));
+        float *h[2] = {ws, ws + BH}, *c = ws + 2 * BH;
+        int cur = 0;
+        for (int i = 0; i < T; ++i) {
+            const int t = d ? T - 1 - i : i;
+            LstmStepArgs l = {};
+            l.term[0] = GemmTerm{h[cur], a->w_hh[d], H, H, H, 0, nullptr, nullptr};
+            l.nterms = 1;
+            l.M = B;
+            l.U = H;
+            l.G = a->gx[d];
+            l.g_row_mul = T;
+            l.g_row_add = t;
+            l.step = t;
+            l.h_in = h[cur];
+            l.h_out = h[cur ^ 1];
+            l.c = c;
+            l.row_len = a->lens;
+            l.out2 = a->out;
+            l.out2_row_mul = T;
+            l.out2_row_add = t;
+            l.ld2 = 2 * H;
+            l.out2_col_off = d * H;
+            l.save_gates = a->s[d][0] + (size_t)t * B * 4 * H;
+            l.save_c_new = a->s[d][1] + (size_t)t * BH;
+            l.save_c_old = a->s[d][2] + (size_t)t * BH;
+            l.save_h_old = a->s[d][3] + (size_t)t * BH;
+            int rc = launch_lstm_step(l, s);
+            if (rc) return rc;
+            cur ^= 1;
+        }
     }
     return 0;
 }
 
 int fcl_bilstm_bptt(const fcl_bilstm_bptt_t* a, fcl_stream_t stream) {
-    FCL_REQUIRE(a && a->lens && a->s[0] && a->s[1] && a->s[2] && a->d_out && a->w_hh_t && a->dg, FCL_ERR_INVALID, "bilstm_bptt: null argument");
-    FCL_REQUIRE(a->b > 0 && a->t > 0 && a->h > 0 && a->ld_dout >= a->col_off + a->h, FCL_ERR_SHAPE, "bilstm_bptt: bad sizes");
-    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(a->b, a->h), FCL_ERR_WORKSPACE, "bilstm_bptt: workspace too small");
+    FCL_REQUIRE(a && a->lens && a->d_out && a->w_hh_t[0] && a->w_hh_t[1] && a->dg[0] && a->dg[1], FCL_ERR_INVALID, "bilstm_bptt: null argument");
+    for (int d = 0; d < 2; ++d)
+        for (int i = 0; i < 3; ++i) FCL_REQUIRE(a->s[d][i], FCL_ERR_INVALID, "bilstm_bptt: saved tensors missing");
+    FCL_REQUIRE(a->b > 0 && a->t > 0 && a->h > 0 && (a->h & 3) == 0 && a->ld_dout >= 2 * a->h, FCL_ERR_SHAPE, "bilstm_bptt: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const int B = a->b, T = a->t, H = a->h, G4 = 4 * a->h;
+    if (!tunable("BILSTM_TRAIN_STEPS", 0)) {
+        BilstmBwd bw;
+        for (int d = 0; d < 2; ++d) { bw.gates[d] = a->s[d][0]; bw.c_new[d] = a->s[d][1]; bw.c_old[d] = a->s[d][2]; bw.whh_t[d] = a->w_hh_t[d]; bw.dg[d] = a->dg[d]; }
+        bw.d_out = a->d_out;
+        bw.ld = a->ld_dout;
+        bw.B = B;
+        if (launch_bilstm_bptt_persistent(bw, a->lens, B, T, H, s)) return check_hip(hipGetLastError(), "bilstm_bptt persistent launch");
+    }
+    FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(B, H), FCL_ERR_WORKSPACE, "bilstm_bptt: workspace too small");
     const size_t BH = (size_t)B * H;
     float* ws = (float*)a->workspace;
-    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 4 * BH, s));
-    float *dh = ws, *tmp_h = ws + BH, *dc = ws + 2 * BH, *tmp_c = ws + 3 * BH;
-    for (int i = T - 1; i >= 0; --i) {  // reverse of the forward visiting order
-        const int t = a->reverse ? T - 1 - i : i;
-        float* dg = a->dg + (size_t)t * B * G4;
-        // output gradient of step t: rows (b, t) of d_out, i.e. row stride T * ld_dout
-        int rc = fcl_lstm_cell_bwd(a->s[0] + (size_t)t * B * G4, a->s[2] + (size_t)t * BH, a->s[1] + (size_t)t * BH, dh,
-                                   a->d_out + (size_t)t * a->ld_dout + a->col_off, T * a->ld_dout, dc, 0.f, nullptr, nullptr, a->lens, t, dg, tmp_h, tmp_c,
-                                   B, H, stream);
-        if (rc) return rc;
-        std::swap(dc, tmp_c);
-        rc = launch_gemm(lin(dg, G4, a->w_hh_t, G4, G4, dh, H, B, H, tmp_h, H), s);  // dh = dgates . W_hh + pass-through of dead rows
-        if (rc) return rc;
+    for (int d = 0; d < 2; ++d) {
+        FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 4 * BH, s));
+        float *dh = ws, *tmp_h = ws + BH, *dc = ws + 2 * BH, *tmp_c = ws + 3 * BH;
+        for (int i = T - 1; i >= 0; --i) {  // reverse of the forward visiting order
+            const int t = d ? T - 1 - i : i;
+            float* dg = a->dg[d] + (size_t)t * B * G4;
+            // output gradient of step t: rows (b, t) of d_out, i.e. row stride T * ld_dout; dead cells (row_len) pass the carries through with dg = 0
+            int rc = fcl_lstm_cell_bwd(a->s[d][0] + (size_t)t * B * G4, a->s[d][2] + (size_t)t * BH, a->s[d][1] + (size_t)t * BH, dh,
+                                       a->d_out + (size_t)t * a->ld_dout + d * H, T * a->ld_dout, dc, 0.f, nullptr, nullptr, a->lens, t, dg, tmp_h, tmp_c,
+                                       B, H, stream);
+            if (rc) return rc;
+            std::swap(dc, tmp_c);
+            rc = launch_gemm(lin(dg, G4, a->w_hh_t[d], G4, G4, dh, H, B, H, tmp_h, H), s);  // dh = dgates . W_hh + pass-through of dead rows
+            if (rc) return rc;
+        }
     }
     return 0;
 }

@@ -377,24 +377,27 @@ def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w
     check(lib.fcl_decoder_bptt(C.byref(a), _stream()))
 
 
-def bilstm_train_fwd(gx, w_hh, lens_i32, b, t, reverse, out, col_off, s):
+def bilstm_train_fwd(gx, w_hh, lens_i32, b, t, out, s):
+    """Both directions: gx / w_hh: (forward, reverse) pairs; s: per direction (gates, c_new, c_old, h_old), t-major."""
     lib = _lib.load()
-    h = w_hh.shape[1]
-    a = _lib.BilstmTrain(b=b, t=t, h=h, reverse=int(reverse), lens=_p(lens_i32, torch.int32), gx=_p(gx), w_hh=_p(w_hh), out=_p(out), ld_out=out.shape[1],
-                         col_off=col_off)
-    _ptrs(a.s, s)
+    h = w_hh[0].shape[1]
+    a = _lib.BilstmTrain(b=b, t=t, h=h, lens=_p(lens_i32, torch.int32), out=_p(out))
+    for d in range(2):
+        a.gx[d], a.w_hh[d] = _p(gx[d]), _p(w_hh[d])
+        _ptrs(a.s[d], s[d])
     nbytes = lib.fcl_bilstm_train_workspace_bytes(b, h)
-    ws = torch.empty(nbytes, device=gx.device, dtype=torch.uint8)
+    ws = torch.empty(nbytes, device=out.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     check(lib.fcl_bilstm_train_fwd(C.byref(a), _stream()))
 
 
-def bilstm_bptt(s, lens_i32, b, t, reverse, d_out, col_off, w_hh_t, dg):
+def bilstm_bptt(s, lens_i32, b, t, d_out, w_hh_t, dg):
     lib = _lib.load()
-    h = w_hh_t.shape[0]
-    a = _lib.BilstmBptt(b=b, t=t, h=h, reverse=int(reverse), lens=_p(lens_i32, torch.int32), d_out=_p(d_out), ld_dout=d_out.shape[1], col_off=col_off,
-                        w_hh_t=_p(w_hh_t), dg=_p(dg))
-    _ptrs(a.s, s[:3])
+    h = w_hh_t[0].shape[0]
+    a = _lib.BilstmBptt(b=b, t=t, h=h, lens=_p(lens_i32, torch.int32), d_out=_p(d_out), ld_dout=d_out.shape[1])
+    for d in range(2):
+        a.w_hh_t[d], a.dg[d] = _p(w_hh_t[d]), _p(dg[d])
+        _ptrs(a.s[d], s[d][:3])
     nbytes = lib.fcl_bilstm_train_workspace_bytes(b, h)
     ws = torch.empty(nbytes, device=d_out.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes

@@ -244,36 +244,34 @@ class TrainEngine(object):
                               g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), ops.add_vec(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
                               B, T), None
         out = torch.empty(B * T, 2 * H, device=dev)
-        cache = []
-        for d, sfx in enumerate(("", "_reverse")):
-            w_ih, w_hh = P["enc.blstm.weight_ih_l0" + sfx], P["enc.blstm.weight_hh_l0" + sfx]
+        gx, whh, sv = [], [], []
+        for sfx in ("", "_reverse"):
             bias = ops.add_vec(P["enc.blstm.bias_ih_l0" + sfx], P["enc.blstm.bias_hh_l0" + sfx])
-            gx = ops.linear(x, w_ih, bias)  # [B*T, 4H]
-            sv = [torch.empty(T, B, 4 * H, device=dev)] + [torch.empty(T, B, H, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old (t-major)
-            ops.bilstm_train_fwd(gx, w_hh, lens_dev, B, T, d == 1, out, d * H, sv)
-            cache.append(sv)
-        return out, dict(x=x, dirs=cache, B=B, T=T, lens=lens_dev)
+            gx.append(ops.linear(x, P["enc.blstm.weight_ih_l0" + sfx], bias))  # [B*T, 4H]
+            whh.append(P["enc.blstm.weight_hh_l0" + sfx])
+            # gates, c_new, c_old, h_old (t-major); zero-filled: dead cells are never written but are read by the batched weight-gradient GEMM
+            sv.append([torch.zeros(T, B, 4 * H, device=dev)] + [torch.zeros(T, B, H, device=dev) for _ in range(3)])
+        ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv)
+        return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev)
 
     def _bilstm_bwd(self, d_out, c):
         P, G, dev = self.P, self.G, self.dev
         B, T, H = c["B"], c["T"], self.hp.eunits // 2
         dx = torch.zeros_like(c["x"])
-        if c.get("perm") is None:  # (b, t) row -> t-major row of the saved / gradient tensors
-            c["perm"] = _i32((np.arange(B * T) % T) * B + np.arange(B * T) // T, dev)
-        for d, sfx in enumerate(("", "_reverse")):
-            sv = c["dirs"][d]
-            w_ih, w_hh = P["enc.blstm.weight_ih_l0" + sfx], P["enc.blstm.weight_hh_l0" + sfx]
-            dg = torch.empty(T, B, 4 * H, device=dev)  # d_out is already zero on padded rows (masked by the caller); dead cells get dg = 0
-            ops.bilstm_bptt(sv, c["lens"], B, T, d == 1, d_out, d * H, self._wt(w_hh), dg)
-            dg2 = dg.reshape(T * B, 4 * H)
-            ops.gemm_tn(dg2, sv[3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
-            dgx = ops.gather_rows(dg2, c["perm"])  # back to (b, t) rows like x
+        perm = _i32((np.arange(B * T) % T) * B + np.arange(B * T) // T, dev)  # (b, t) row -> t-major row of the saved / gradient tensors
+        sfxs = ("", "_reverse")
+        dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in sfxs]  # d_out is already zero on padded rows (masked by the caller); dead cells get dg = 0
+        ops.bilstm_bptt(c["dirs"], c["lens"], B, T, d_out, [self._wt(P["enc.blstm.weight_hh_l0" + sfx]) for sfx in sfxs], dgs)
+        for d, sfx in enumerate(sfxs):
+            dg2 = dgs[d].reshape(T * B, 4 * H)
+            ops.gemm_tn(dg2, c["dirs"][d][3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
+            dgx = ops.gather_rows(dg2, perm)  # back to (b, t) rows like x
             ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
             db = torch.zeros(1, 4 * H, device=dev)
             ops.colsum(dgx, db.reshape(-1))
             ops.add2d(G["enc.blstm.bias_ih_l0" + sfx].reshape(1, -1), db)
             ops.add2d(G["enc.blstm.bias_hh_l0" + sfx].reshape(1, -1), db)
-            ops.add2d(dx, ops.linear(dgx, self._wt(w_ih)))
+            ops.add2d(dx, ops.linear(dgx, self._wt(P["enc.blstm.weight_ih_l0" + sfx])))
         return dx
 
     # ------------------------------------------------------------------------------------------------ index maps (host, integers)

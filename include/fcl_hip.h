@@ -289,24 +289,23 @@ typedef struct {
     size_t workspace_bytes;
 } fcl_decoder_bptt_t;
 typedef struct {
-    int b, t, h, reverse;
+    int b, t, h;
     const int32_t* lens;            /* [B] device */
-    const float* gx;                /* [B*T, 4H] x . W_ih^T + bias_ih + bias_hh of this direction, rows (b, t) */
-    const float* w_hh;              /* [4H, H] */
-    float* out;                     /* [B*T, ld_out]; this direction writes columns [col_off, col_off + H), zeros past each length */
-    int ld_out, col_off;
-    float* s[4];                    /* saved, t-major: gates [T, B, 4H], c_new, c_old, h_old [T, B, H] */
-    void* workspace;
-    size_t workspace_bytes;         /* fcl_bilstm_train_workspace_bytes(b, h) */
+    const float* gx[2];             /* per direction (0 forward, 1 reverse): x . W_ih^T + bias_ih + bias_hh, [B*T, 4H], rows (b, t) */
+    const float* w_hh[2];           /* [4H, H] */
+    float* out;                     /* [B*T, 2H]: direction d writes columns [d*H, d*H + H), zeros past each length */
+    float* s[2][4];                 /* saved, t-major: gates [T, B, 4H], c_new, c_old, h_old [T, B, H]; only live cells are written */
+    void* workspace;                /* fcl_bilstm_train_workspace_bytes(b, h): used by the per-step fallback (H not in {8,16,32,64,128}) */
+    size_t workspace_bytes;
 } fcl_bilstm_train_t;
 typedef struct {
-    int b, t, h, reverse;
+    int b, t, h;
     const int32_t* lens;
-    const float* s[3];              /* gates, c_new, c_old */
-    const float* d_out;             /* [B*T, ld_dout] gradient w.r.t. the layer output (zero on padded rows), columns [col_off, col_off + H) */
-    int ld_dout, col_off;
-    const float* w_hh_t;            /* [H, 4H] */
-    float* dg;                      /* out, t-major [T, B, 4H] */
+    const float* s[2][3];           /* gates, c_new, c_old of each direction */
+    const float* d_out;             /* [B*T, ld_dout] gradient w.r.t. the layer output, ZERO on padded rows; direction d in columns [d*H, d*H + H) */
+    int ld_dout;
+    const float* w_hh_t[2];         /* [H, 4H] */
+    float* dg[2];                   /* out, t-major [T, B, 4H]; dead cells are written as 0 */
     void* workspace;
     size_t workspace_bytes;
 } fcl_bilstm_bptt_t;
