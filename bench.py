@@ -81,6 +81,8 @@ def train_workload(args, rank, world, dev, dist):
     xs, ys, ds, f0, en = SYN.training_batch(80, S.idim, batch=B, t_lo=60, t_hi=100, seed=1234 + rank, zero_frac=0.03, lam=10.0, hi=50)
     batch = CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)])
     frames = int(sum(y.shape[0] for y in ys))
+    for k in ("xs", "ys", "extras", "f0", "energy"):  # inputs resident in HBM when the timed region starts; the integer layout tensors stay on the host
+        batch[k] = batch[k].to(dev)
     teng = TrainEngine(SYN.build_model("kd_teacher", T, None, dev)) if kd else None
     eng = TrainEngine(SYN.build_model("student", S, T, dev) if kd else SYN.build_model("teacher", T, None, dev), seed=rank)
 

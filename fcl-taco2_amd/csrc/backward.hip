@@ -24,12 +24,16 @@ constexpr int TN_BM = 32;
 constexpr int TN_LD = TN_BM + 4;
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                      float* __restrict__ C, int ldc, int M, int N, int K, int shift,
-                                                      const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int rows_per_slice) {
+                                                      float* __restrict__ C, int ldc, int M, int N, int K, int shift0,
+                                                      const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int rows_per_slice, int ntaps,
+                                                      long long c_tap_stride) {
     __shared__ __attribute__((aligned(16))) float At[64 * TN_LD];  // [n][m]
     __shared__ __attribute__((aligned(16))) float Bt[64 * TN_LD];  // [k][m]
     const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-    const int m_lo = blockIdx.z * rows_per_slice, m_hi = min(M, m_lo + rows_per_slice);
+    const int tap = blockIdx.z % ntaps, slice = blockIdx.z / ntaps;  // conv weight gradients: all taps of a layer in one launch
+    const int shift = shift0 + tap;
+    C += (size_t)tap * c_tap_stride;
+    const int m_lo = slice * rows_per_slice, m_hi = min(M, m_lo + rows_per_slice);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     // wave w owns C rows (n) [w*16, w*16+16) x all 64 k columns: acc[j] = 16x16 tile j
@@ -87,20 +91,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // out[c] += sum_m f(x[m, c]) ; mode 0: x ; 1: x * y[m, c] ; 2: x * (y[m,c] - b[c]) / g[c]   (BN-fold gamma gradient, xhat = (z - beta)/gamma)
-__global__ void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ b,
-                              float* __restrict__ out, int M, int C, int mode, int rows_per_block) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float* __restrict__ out, int M, int C, int mode, int rows_per_block) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // a wave reads 64 consecutive columns of one row: 256-byte coalesced
+    const int c = blockIdx.x * 64 + tx;
     const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
     float s = 0.f;
-    for (int m = m_lo; m < m_hi; ++m) {
-        float v = x[(size_t)m * C + c];
-        if (mode == 1) v *= y[(size_t)m * C + c];
-        else if (mode == 2) v *= (y[(size_t)m * C + c] - b[c]) / g[c];
-        else if (mode == 3) v *= (y[(size_t)m * C + c] - b[c]) * g[c];
-        s += v;
+    if (c < C) {
+        const float bc = mode >= 2 ? b[c] : 0.f, gc = mode == 2 ? 1.0f / g[c] : (mode == 3 ? g[c] : 1.f);
+        for (int m = m_lo + ty; m < m_hi; m += 4) {
+            float v = x[(size_t)m * C + c];
+            if (mode == 1) v *= y[(size_t)m * C + c];
+            else if (mode >= 2) v *= (y[(size_t)m * C + c] - bc) * gc;
+            s += v;
+        }
     }
-    atomicAdd(out + c, s);
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) atomicAdd(out + c, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
 }
 
 // dz = dy * act'(y) * (keep ? keep*scale : 1)
@@ -148,6 +157,54 @@ __global__ void l1_mse_grad_kernel(const float* __restrict__ a, const float* __r
             g = (w1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * w2 * d) * inv_count;
         }
         da[i] = accumulate ? da[i] + g : g;
+    }
+}
+
+// the loss sums of fcl_masked_l1_mse_fwd and the gradient of fcl_l1_mse_grad in one pass over a and b (the KD terms read 100 MB teacher taps)
+__global__ __launch_bounds__(256) void l1_mse_loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ valid,
+                                                               int M, int C, int b_log, float off, float w1, float w2, float inv_count,
+                                                               float* __restrict__ da, int accumulate, double* __restrict__ sums) {
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    const int c4 = C >> 2;  // C % 4 == 0: one float4 per thread-iteration
+    const long long total = (long long)M * c4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c4);
+        const bool ok = !valid || valid[r];
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const f32x4 av = reinterpret_cast<const f32x4*>(a)[i];
+            f32x4 bv = reinterpret_cast<const f32x4*>(b)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (b_log) bv[e] = logf(bv[e] + off);
+                const float d = av[e] - bv[e];
+                s1 += fabsf(d);
+                s2 += (double)d * d;
+                g[e] = (w1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * w2 * d) * inv_count;
+            }
+            cnt += 4.0;
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(da) + i;
+        if (accumulate) {
+            const f32x4 old = *o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += old[e];
+        }
+        *o = g;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+        cnt += __shfl_xor(cnt, o);
+    }
+    __shared__ double part[4][3];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[wave][0] = s1; part[wave][1] = s2; part[wave][2] = cnt; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (v != 0.0) atomicAdd(sums + threadIdx.x, v);
     }
 }
 
@@ -425,22 +482,28 @@ using namespace fcl;
 
 extern "C" {
 
-int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift,
-                    const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream) {
-    FCL_REQUIRE(a && b && c && m >= 0 && n > 0 && k > 0, FCL_ERR_INVALID, "gemm_tn_fwd: bad arguments");
+int fcl_gemm_tn_taps_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift0, int ntaps,
+                         size_t c_tap_stride, const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream) {
+    FCL_REQUIRE(a && b && c && m >= 0 && n > 0 && k > 0 && ntaps >= 1, FCL_ERR_INVALID, "gemm_tn_fwd: bad arguments");
     FCL_REQUIRE(!(n & 3) && !(k & 3) && !(lda & 3) && !(ldb & 3) && aligned16(a) && aligned16(b), FCL_ERR_ALIGN,
                 "gemm_tn_fwd: N, K, lda, ldb must be multiples of 4 and operands 16-byte aligned");
     FCL_REQUIRE((seg_lo == nullptr) == (seg_hi == nullptr), FCL_ERR_INVALID, "gemm_tn_fwd: seg_lo/seg_hi come in pairs");
     if (m == 0) return 0;
-    const int tiles = ((n + 63) / 64) * ((k + 63) / 64);
-    int slices = (1024 + tiles - 1) / tiles;  // ~1024 workgroups in flight
+    const int tiles = ((n + 63) / 64) * ((k + 63) / 64) * ntaps;
+    int slices = (1024 + tiles - 1) / tiles;  // ~1024 workgroups in flight, but at least 128 rows each: every slice ends in 4096 atomics per tile
     int rps = ((m + slices - 1) / slices + TN_BM - 1) / TN_BM * TN_BM;
-    if (rps < TN_BM) rps = TN_BM;
+    if (rps < 4 * TN_BM) rps = 4 * TN_BM;
     slices = (m + rps - 1) / rps;
-    dim3 grid((n + 63) / 64, (k + 63) / 64, slices);
-    ProfScope ps("gemm_tn_kernel", 2.0 * m * (double)n * k, m, (hipStream_t)stream);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift, seg_lo, seg_hi, rps);
+    dim3 grid((n + 63) / 64, (k + 63) / 64, slices * ntaps);
+    ProfScope ps("gemm_tn_kernel", 2.0 * m * (double)n * k * ntaps, m, (hipStream_t)stream);
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift0, seg_lo, seg_hi, rps, ntaps,
+                       (long long)c_tap_stride);
     return check_hip(hipGetLastError(), "gemm_tn_fwd");
+}
+
+int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift,
+                    const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream) {
+    return fcl_gemm_tn_taps_fwd(a, lda, b, ldb, c, ldc, m, n, k, shift, 1, 0, seg_lo, seg_hi, stream);
 }
 
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream) {
@@ -448,8 +511,8 @@ int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* 
     FCL_REQUIRE(mode == 0 || y, FCL_ERR_INVALID, "colsum_fwd: mode needs y");
     FCL_REQUIRE(mode < 2 || (g && b), FCL_ERR_INVALID, "colsum_fwd: modes 2 and 3 need g and b");
     if (m == 0) return 0;
-    const int rpb = 128;
-    hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(64), 0, (hipStream_t)stream, x, y, g, b, out, m, c, mode, rpb);
+    const int rpb = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, y, g, b, out, m, c, mode, rpb);
     return check_hip(hipGetLastError(), "colsum_fwd");
 }
 
@@ -481,6 +544,17 @@ int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, in
     hipLaunchKernelGGL(l1_mse_grad_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, a, b, row_valid, m, c, b_log,
                        b_log_offset, w_l1, w_mse, (float)(1.0 / count), da, accumulate);
     return check_hip(hipGetLastError(), "l1_mse_grad");
+}
+
+int fcl_l1_mse_loss_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1, float w_mse,
+                         double count, float* da, int accumulate, double* sums, fcl_stream_t stream) {
+    FCL_REQUIRE(a && b && da && sums && m >= 0 && c > 0 && count > 0, FCL_ERR_INVALID, "l1_mse_loss_grad: bad arguments");
+    FCL_REQUIRE(!(c & 3) && aligned16(a) && aligned16(b) && aligned16(da), FCL_ERR_ALIGN, "l1_mse_loss_grad: C %% 4 == 0 and 16-byte aligned operands required");
+    if (m == 0) return 0;
+    const int grid = std::min(grid1d((long long)m * (c / 4), 256), 1024);
+    hipLaunchKernelGGL(l1_mse_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, row_valid, m, c, b_log, b_log_offset, w_l1, w_mse,
+                       (float)(1.0 / count), da, accumulate, sums);
+    return check_hip(hipGetLastError(), "l1_mse_loss_grad");
 }
 
 int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,

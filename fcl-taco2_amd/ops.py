@@ -195,6 +195,32 @@ def gemm_tn(a, b, out, shift=0, seg_lo=None, seg_hi=None):
     return out
 
 
+def gemm_tn_taps(a, b, out, shift0, seg_lo=None, seg_hi=None):
+    """out[j, n, k] += sum_m a[m, n] * b[m + shift0 + j, k] for every tap j of out [ntaps, N, K] (contiguous)."""
+    m, n = a.shape
+    ntaps, n2, k = out.shape
+    assert b.shape == (m, k) and n2 == n and out.is_contiguous()
+    check(_lib.load().fcl_gemm_tn_taps_fwd(_p(a), n, _p(b), k, _p(out), k, m, n, k, shift0, ntaps, n * k, _p(seg_lo, torch.int32), _p(seg_hi, torch.int32),
+                                           _stream()))
+    return out
+
+
+def l1_mse_loss_grad(a, b, row_valid, count, w_l1, w_mse, sums_f64, da=None, b_log_offset=None):
+    """Loss sums (into sums_f64[0:3]) and gradient in one pass; falls back to the two separate kernels when C % 4 != 0."""
+    if a.dim() == 1:
+        a, b = a.reshape(-1, 1), b.reshape(-1, 1)
+    m, c = a.shape
+    if c % 4:
+        masked_l1_mse(a, b, row_valid, sums_f64, b_log_offset)
+        return l1_mse_grad(a, b, row_valid, count, w_l1, w_mse, da=da, b_log_offset=b_log_offset)
+    acc = da is not None
+    if da is None:
+        da = torch.empty_like(a)
+    check(_lib.load().fcl_l1_mse_loss_grad(_p(a), _p(b), _p(row_valid, torch.uint8), m, c, int(b_log_offset is not None), float(b_log_offset or 0.0),
+                                           w_l1, w_mse, float(count), _p(da), int(acc), sums_f64.data_ptr(), _stream()))
+    return da
+
+
 def colsum(x, out, y=None, gamma=None, beta=None, mode=0):
     m, c = x.shape
     check(_lib.load().fcl_colsum_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(out), m, c, mode, _stream()))

@@ -184,8 +184,7 @@ class TrainEngine(object):
             ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
             scale = cc["scale"]
         dwp = torch.zeros(k, cout, cin, device=self.dev)
-        for j in range(k):
-            ops.gemm_tn(dz, cc["x"], dwp[j], shift=j - (k - 1) // 2, seg_lo=cc["lo"], seg_hi=cc["hi"])
+        ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
         ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
         return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
@@ -201,8 +200,7 @@ class TrainEngine(object):
         ops.colsum(dz, G[pre + ".bias"])
         cout, cin, k = self.P[pre + ".weight"].shape
         dwp = torch.zeros(k, cout, cin, device=self.dev)
-        for j in range(k):
-            ops.gemm_tn(dz, cc["x"], dwp[j], shift=j - (k - 1) // 2, seg_lo=cc["lo"], seg_hi=cc["hi"])
+        ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
         ops.unpack_conv1d_grad(dwp, G[pre + ".weight"])
         return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
@@ -235,7 +233,7 @@ class TrainEngine(object):
         return dx
 
     # ------------------------------------------------------------------------------------------------ BiLSTM (per-step, saved)
-    def _bilstm_fwd(self, x, lens_dev, B, T, save=True):
+    def _bilstm_fwd(self, x, lens_dev, B, T, save=True, perm=None):
         P, dev = self.P, self.dev
         H = self.hp.eunits // 2
         if not save:  # forward only (the frozen KD teacher): the persistent register-resident kernel of the synthesis path
@@ -252,13 +250,13 @@ class TrainEngine(object):
             # gates, c_new, c_old, h_old (t-major); zero-filled: dead cells are never written but are read by the batched weight-gradient GEMM
             sv.append([torch.zeros(T, B, 4 * H, device=dev)] + [torch.zeros(T, B, H, device=dev) for _ in range(3)])
         ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv)
-        return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev)
+        return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev, perm=perm)
 
     def _bilstm_bwd(self, d_out, c):
         P, G, dev = self.P, self.G, self.dev
         B, T, H = c["B"], c["T"], self.hp.eunits // 2
         dx = torch.zeros_like(c["x"])
-        perm = _i32((np.arange(B * T) % T) * B + np.arange(B * T) // T, dev)  # (b, t) row -> t-major row of the saved / gradient tensors
+        perm = c["perm"]  # (b, t) row -> t-major row of the saved / gradient tensors
         sfxs = ("", "_reverse")
         dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in sfxs]  # d_out is already zero on padded rows (masked by the caller); dead cells get dg = 0
         ops.bilstm_bptt(c["dirs"], c["lens"], B, T, d_out, [self._wt(P["enc.blstm.weight_hh_l0" + sfx]) for sfx in sfxs], dgs)
@@ -276,24 +274,22 @@ class TrainEngine(object):
 
     # ------------------------------------------------------------------------------------------------ index maps (host, integers)
     def _maps(self, c, batch):
+        """Integer index maps of one batch (host numpy), shipped to the device in TWO transfers (int32 block, uint8 block) and cached on the
+        batch dict: the frozen teacher and the student of a KD step share them."""
         dev = self.dev
+        cache = batch.get("_fcl_maps") if isinstance(batch, dict) else None
+        if cache is not None and cache[0] == str(dev):
+            c.__dict__.update(cache[1])
+            return
         ilens = [int(v) for v in batch["ilens"]]
         olens = [int(v) for v in batch["olens"]]
         B, T, L = len(ilens), max(ilens), max(olens)
-        c.B, c.T, c.L = B, T, L
         rows = np.arange(B * T)
         b_of = rows // T
         lens_np = np.asarray(ilens)
-        c.lens_dev = _i32(lens_np, dev)
-        c.e_lo, c.e_hi = _i32(b_of * T, dev), _i32(b_of * T + T, dev)
         pad_np = (rows % T) >= lens_np[b_of]
-        c.enc_pad, c.enc_valid = _u8(pad_np, dev), _u8(~pad_np, dev)
-        c.n_enc = float((~pad_np).sum())
         frows = np.arange(B * L)
-        c.f_lo, c.f_hi = _i32((frows // L) * L, dev), _i32((frows // L) * L + L, dev)
         fvalid_np = (frows % L) < np.asarray(olens)[frows // L]
-        c.frame_valid = _u8(fvalid_np, dev)
-        c.n_frames = float(fvalid_np.sum())
         nzm = np.asarray(batch["non_zero_lens_mask"])[:, :T] != 0
         dsn = np.asarray(batch["ds_nonzeros"]).astype(np.int64)
         src = np.flatnonzero(nzm.reshape(-1))
@@ -317,15 +313,32 @@ class TrainEngine(object):
         frame_cell[cell_frame] = np.arange(F)
         inv = np.full(B * T, -1, dtype=np.int64)
         inv[src[order]] = np.arange(N)
-        c.N, c.F, c.lmax, c.live, c.offs, c.order = N, F, lmax, live, offs, order
-        c.cell_row, c.cell_t, c.dur_s = cell_row, cell_t, dur_s
-        c.src_sorted = _i32(src[order], dev)
-        c.row_of_enc = _i32(inv, dev)
-        c.cell_frame, c.frame_cell = _i32(cell_frame, dev), _i32(frame_cell, dev)
-        c.prev_frame = _i32(np.where(cell_t > 0, cell_frame - 1, -1), dev)  # teacher-forced input y_{t-1}; zero row at t = 0
-        c.cell_row_i32 = _i32(cell_row, dev)
-        c.cell_row_i64 = torch.from_numpy(cell_row.astype(np.int64)).to(dev)
-        c.dur_dev = _i32(dur_s, dev)
+        i32 = dict(lens_dev=lens_np, e_lo=b_of * T, e_hi=b_of * T + T, f_lo=(frows // L) * L, f_hi=(frows // L) * L + L, src_sorted=src[order],
+                   row_of_enc=inv, cell_frame=cell_frame, frame_cell=frame_cell, prev_frame=np.where(cell_t > 0, cell_frame - 1, -1),
+                   cell_row_i32=cell_row, dur_dev=dur_s, perm_tb=(rows % T) * B + rows // T)
+        u8 = dict(enc_pad=pad_np, enc_valid=~pad_np, frame_valid=fvalid_np)
+        m = dict(B=B, T=T, L=L, N=N, F=F, lmax=lmax, live=live, offs=offs, order=order, cell_row=cell_row, cell_t=cell_t, dur_s=dur_s,
+                 n_enc=float((~pad_np).sum()), n_frames=float(fvalid_np.sum()), live_i32=np.ascontiguousarray(live, dtype=np.int32))
+        for block, dtype in ((i32, np.int32), (u8, np.uint8)):
+            sizes = [(k, (v.size + 15) // 16 * 16) for k, v in block.items()]  # 64-byte aligned slots
+            host = np.zeros(sum(n for _, n in sizes), dtype=dtype)
+            o = 0
+            for (k, n), v in zip(sizes, block.values()):
+                host[o : o + v.size] = v
+                o += n
+            devbuf = torch.from_numpy(host).to(dev)
+            o = 0
+            for (k, n), v in zip(sizes, block.values()):
+                m[k] = devbuf[o : o + v.size]
+                o += n
+        m["cell_row_i64"] = m["cell_row_i32"].to(torch.int64)
+        pos = np.zeros((F, 4), dtype=np.float32)
+        pos[:, 0] = cell_t.astype(np.float32) / dur_s[cell_row].astype(np.float32)  # the position input t/d, padded to 4 columns (TN-GEMM operand)
+        m["pos4"] = torch.from_numpy(pos).to(dev)
+        m["cell_valid"] = torch.ones(F, dtype=torch.uint8, device=dev)  # every cell is a valid frame
+        if isinstance(batch, dict):
+            batch["_fcl_maps"] = (str(dev), m)
+        c.__dict__.update(m)
 
     def _cells(self, c, arr):
         """[lmax, N(compact order), X] injected decoder masks -> step-major cells [F, X]."""
@@ -348,7 +361,7 @@ class TrainEngine(object):
             x, cc = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep)
             c.conv_c.append(cc)
             c.enc_taps.append(x)
-        c.hs, c.bl_c = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save)
+        c.hs, c.bl_c = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save, perm=c.perm_tb)
         # ---- predictors + embeds
         c.d_outs, c.dur_c = self._predictor_fwd(c, c.hs, "duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_dropout_rate,
                                                 c.e_lo, c.e_hi, c.enc_pad)
@@ -412,7 +425,6 @@ class TrainEngine(object):
         c.S0 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
         c.S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
         c.h0_all, c.h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
-        c.live_i32 = np.ascontiguousarray(live, dtype=np.int32)
         ops.decoder_train_fwd(c.live_i32, c.p1d, G0, c.w0_pre, c.w0_hh, w0_pos, c.dur_dev, c.w1_ih, c.w1_hh, b1s, c.zr, c.zk, c.S0, c.S1, c.h0_all,
                               c.h1_all)
         out_cells = ops.linear(c.h1_all, c.wf_h)
@@ -448,9 +460,9 @@ class TrainEngine(object):
 
         def term(name, a, b, valid, count, w_l1, w_mse, b_log=None, da=None):
             a2, b2 = (a.reshape(-1, 1), b.reshape(-1, 1)) if a.dim() == 1 else (a, b)
-            ops.masked_l1_mse(a2, b2, valid, sums[len(names)], b_log_offset=b_log)
             names.append(name)
-            return ops.l1_mse_grad(a2, b2, valid, count * self.accum_grad, w_l1, w_mse, da=da, b_log_offset=b_log)  # d(loss / accum_grad)
+            return ops.l1_mse_loss_grad(a2, b2, valid, count * self.accum_grad, w_l1, w_mse, sums[len(names) - 1], da=da,
+                                        b_log_offset=b_log)  # loss sums + d(loss / accum_grad) in one pass
 
         inj = c.inj = {}
         inj["after"] = term("after", c.after, c.ys, c.frame_valid, nf, 1.0, 1.0)
@@ -484,7 +496,7 @@ class TrainEngine(object):
                     inj["enc%d" % (i + 1)] = kd("enc%d" % (i + 1), c.enc_taps[1 + i], cp[i], flat(t_enc[1 + i]), c.enc_valid, ne)
                 inj["hs"] = kd("enc4", c.hs, "enc.blstm_proj", flat(t_enc[4]), c.enc_valid, ne)
             if self.distill[2]:
-                cellv = torch.ones(c.F, dtype=torch.uint8, device=dev)  # every cell is a valid frame
+                cellv = c.cell_valid
                 tc = lambda t: ops.gather_rows(flat(t), c.cell_frame)
                 inj["p1d"] = kd("dec0", c.p1d, "dec.prenet_proj", tc(t_dec[0]), cellv, c.n_frames)
                 inj["h0"] = kd("dec1", c.h0_all, lp[0], tc(t_dec[1]), cellv, c.n_frames)
@@ -559,10 +571,8 @@ class TrainEngine(object):
         ops.gemm_tn(dg0_all, S0[3], G["dec.lstm.0.cell.weight_hh"])
         g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
         ops.gemm_tn(dg0_all, c.p1d, g_ih0[:, C : C + Pn])
-        pos_np = np.zeros((F, 4), dtype=np.float32)
-        pos_np[:, 0] = c.cell_t.astype(np.float32) / c.dur_s[c.cell_row].astype(np.float32)  # the position input t/d, padded to 4 columns
         dw0_pos4 = torch.zeros(4 * U, 4, device=dev)
-        ops.gemm_tn(dg0_all, torch.from_numpy(pos_np).to(dev), dw0_pos4)
+        ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
         ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
         dG0 = torch.zeros(N, 4 * U, device=dev)
         ops.scatter_add_rows(dg0_all, c.cell_row_i64, dG0)

@@ -226,6 +226,9 @@ int fcl_masked_l1_mse_fwd(const float* a, int lda, const float* b, int ldb, cons
  * Accumulates with fp32 atomics (the caller zeroes c once per step: gradient accumulation is the natural mode). */
 int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift,
                     const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream);
+/* The same for NTAPS consecutive shifts in one launch: c + j*c_tap_stride gets shift0 + j (all taps of a Conv1d weight gradient, tap-major). */
+int fcl_gemm_tn_taps_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift0, int ntaps,
+                         size_t c_tap_stride, const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream);
 /* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm)
  * | x*(y - b[c])*g[c] (mode 3: b = batch mean, g = invstd: gamma gradient of a train-mode BatchNorm). */
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream);
@@ -241,6 +244,9 @@ int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep
 /* da (+)= (w_l1 * sign(a - b') + 2 * w_mse * (a - b')) / count on the valid rows, 0 elsewhere  (b' as in fcl_masked_l1_mse_fwd). */
 int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1,
                     float w_mse, double count, float* da, int accumulate, fcl_stream_t stream);
+/* fcl_masked_l1_mse_fwd (sums[0:3] += sum|d|, sum d^2, count) and fcl_l1_mse_grad in ONE pass over a and b (C % 4 == 0). */
+int fcl_l1_mse_loss_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1,
+                         float w_mse, double count, float* da, int accumulate, double* sums, fcl_stream_t stream);
 /* Channel LayerNorm backward (+ the predictor's scalar head: ds = gradient of scalar[m]).  dgamma/dbeta/dlin_w/dlin_b accumulate. */
 int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,
                       const uint8_t* pad_mask, const uint8_t* keep, float keep_scale, float* dx, float* dgamma, float* dbeta, float* dlin_w,
