@@ -173,3 +173,16 @@ def test_scatter_add_and_adam_step(ops):
     before = p.clone()
     ops.adam_step(p, dev(grads[0]), m, v, nan, 1.0, 1e-3, 0.9, 0.999, 1e-6, 3)  # NaN grad norm -> the step is skipped (tts.py:175-178)
     assert torch.equal(p, before)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 16, 256), (7, 100, 260), (16, 256, 1024), (33, 256, 1024), (64, 1024, 512)])
+def test_small_m_split_k_gemm(ops, m, n, k):
+    """The split-K kernel launch_gemm picks for M <= 64, K >= 256 (the per-step GEMMs of the BPTT recurrences; their residual epilogue is covered by
+    the training-step parity tests under FCL_BILSTM_TRAIN_STEPS=1)."""
+    rng = np.random.RandomState(m + k)
+    x, w, b = rnd(rng, m, k), rnd(rng, n, k) / np.sqrt(k), rnd(rng, n)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    y = ops.linear(dev(x), dev(w.astype(np.float32)), dev(b))
+    assert max_abs(y.cpu().double(), ref) < 2e-5
+    y2 = ops.linear(dev(x), dev(w.astype(np.float32)))  # no bias
+    assert max_abs(y2.cpu().double(), ref - b) < 2e-5
