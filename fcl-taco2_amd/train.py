@@ -1,0 +1,277 @@
+"""Training driver on the HIP path — the role of the reference's `tts_train.py` + `tts.train` / `tts_distill.train`
+(tts.py:309-603, tts_distill.py:312-624) reduced to what the hot path needs, with the reference's flag names, inputs and artefacts:
+
+  inputs   `--train-json/--valid-json` data manifests (preprocess.py:199-241: per utterance input1 mel [L,80], input2 durations [T,1],
+           input3 f0 [T,1], input4 energy [T,1] as .npy paths, output tokenid string); for KD `--teacher-conf model.json --teacher-model
+           amp_checkpoint_*.pt | snapshot` (tts_distill.py:367-398: the teacher is frozen and LEFT IN TRAIN MODE);
+  batching `--batch-size`, `--batch-sort-key shuffle|input|output` (shuffle = the shipped recipes: fixed-size random batches), every batch
+           sorted by descending phoneme count (io_utils_fcl.py:316-318), laid out by the bit-exact vectorised CustomConverter (tts.py:215-306);
+  step     fcl_taco2_amd.training.TrainEngine: forward/backward on the HIP path, `--accum-grad`, bucketed gradient all-reduce when launched
+           under torch.distributed.run (one process per GPU, batches sharded round-robin), clip `--grad-clip`, NaN guard, Adam `--lr --eps`;
+  outputs  `outdir/model.json` (`[idim, odim, vars(args)]`, tts.py:341-348), `outdir/snapshot.ep.N` ({"model", "optimizer", "epoch",
+           "iteration"}), `outdir/amp_checkpoint_ep{N}.pt` ({"model", "optimizer" (torch.optim.Adam layout), "amp": None}, tts.py:193-198 —
+           the file the reference's KD recipe loads its teacher from), `outdir/model.loss.best` (bare state_dict of the best validation
+           loss, ESPnet torch_save), `outdir/log` (JSON list of per-epoch means of every reported loss, main/ and validation/main/ prefixed).
+Not here: chainer extensions (plots, tensorboard), sortagrad, apex AMP, early stopping.
+"""
+import argparse
+import json
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+
+from .converter import CustomConverter
+from .decode import build_model, dynamic_import, load_state_dict
+
+
+# ---- data ------------------------------------------------------------------------------------------------------------------------------
+def read_train_manifest(path):
+    with open(path, "rb") as f:
+        utts = json.load(f)["utts"]
+    out = []
+    for uid, info in utts.items():
+        inputs = {i["name"]: i for i in info["input"]}
+        out.append(dict(id=uid, tokenid=info["output"][0]["tokenid"], mel=inputs["input1"]["feat"], dur=inputs["input2"]["feat"],
+                        f0=inputs["input3"]["feat"], energy=inputs["input4"]["feat"], ilen=int(info["output"][0]["shape"][0]),
+                        olen=int(inputs["input1"]["shape"][0]), num_phns=int(info["output"][0]["shape"][1])))
+    return out
+
+
+def make_batchset(utts, batch_size, sort_key="shuffle", seed=1, min_batch_size=1):
+    """batchfy_fcl.make_batchset reduced to count="seq": "shuffle" = random fixed-size batches (the shipped recipes), "input"/"output" =
+    sort by that length (descending) and cut; batches smaller than min_batch_size (= ranks) are dropped like the reference does for ngpu > 1."""
+    idx = list(range(len(utts)))
+    if sort_key == "shuffle":
+        np.random.RandomState(seed).shuffle(idx)
+    elif sort_key in ("input", "output"):
+        idx.sort(key=lambda i: -(utts[i]["ilen"] if sort_key == "input" else utts[i]["olen"]))
+    else:
+        raise ValueError("batch-sort-key must be shuffle, input or output")
+    batches = [[utts[i] for i in idx[s : s + batch_size]] for s in range(0, len(idx), batch_size)]
+    return [b for b in batches if len(b) >= min_batch_size]
+
+
+def load_batch(batch, cache=None):
+    """LoadInputsAndTargets(mode="tts", use_second_target=True) for one batch: lists sorted by descending phoneme count."""
+    def get(p):
+        if cache is not None and p in cache:
+            return cache[p]
+        a = np.load(p)
+        if cache is not None:
+            cache[p] = a
+        return a
+
+    rows = []
+    for u in batch:
+        x = np.fromiter(map(int, u["tokenid"].split()), dtype=np.int64)
+        if len(x) == 0:
+            continue
+        rows.append((x, get(u["mel"]).astype(np.float32), np.asarray(get(u["dur"]), dtype=np.float32).reshape(-1, 1),
+                     np.asarray(get(u["f0"]), dtype=np.float32).reshape(-1, 1), np.asarray(get(u["energy"]), dtype=np.float32).reshape(-1, 1)))
+    rows.sort(key=lambda r: -len(r[0]))
+    xs, ys, ds, f0, en = (list(c) for c in zip(*rows))
+    return xs, ys, None, ds, f0, en
+
+
+# ---- checkpoints -----------------------------------------------------------------------------------------------------------------------
+def adam_state_dict(engine):
+    """The engine's flat Adam moments in torch.optim.Adam.state_dict() layout (parameters in model.parameters() order)."""
+    names = [k for k, _ in engine.model.named_parameters()]
+    offs = engine.param_offsets()
+    state = {}
+    for i, k in enumerate(names):
+        o, n, shape = offs[k]
+        state[i] = {"step": torch.tensor(float(engine.step_count)), "exp_avg": engine.mflat[o : o + n].view(shape).detach().cpu().clone(),
+                    "exp_avg_sq": engine.vflat[o : o + n].view(shape).detach().cpu().clone()}
+    group = {"lr": engine.lr, "betas": tuple(engine.betas), "eps": engine.eps, "weight_decay": 0, "amsgrad": False, "params": list(range(len(names)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def load_adam_state_dict(engine, sd):
+    names = [k for k, _ in engine.model.named_parameters()]
+    offs = engine.param_offsets()
+    for i, k in enumerate(names):
+        st = sd["state"].get(i)
+        if st is None:
+            continue
+        o, n, shape = offs[k]
+        engine.mflat[o : o + n].view(shape).copy_(st["exp_avg"])
+        engine.vflat[o : o + n].view(shape).copy_(st["exp_avg_sq"])
+        engine.step_count = int(float(st["step"]))
+    g = sd["param_groups"][0]
+    engine.lr, engine.eps, engine.betas = g["lr"], g["eps"], tuple(g["betas"])
+
+
+def save_checkpoints(outdir, engine, epoch, iteration, valid_loss, best):
+    model_sd = {k: v.detach().cpu().clone() for k, v in engine.model.state_dict().items()}
+    opt = adam_state_dict(engine)
+    torch.save({"model": model_sd, "optimizer": opt, "epoch": epoch, "iteration": iteration}, os.path.join(outdir, "snapshot.ep.%d" % epoch))
+    torch.save({"model": model_sd, "optimizer": opt, "amp": None}, os.path.join(outdir, "amp_checkpoint_ep%d.pt" % epoch))
+    if valid_loss is not None and valid_loss < best:
+        torch.save(model_sd, os.path.join(outdir, "model.loss.best"))
+        return valid_loss
+    return best
+
+
+# ---- the loop ----------------------------------------------------------------------------------------------------------------------------
+def get_parser():
+    p = argparse.ArgumentParser(description="Train FCL-taco2 (teacher or KD student) on the MI355X HIP path")
+    p.add_argument("--outdir", required=True)
+    p.add_argument("--train-json", required=True)
+    p.add_argument("--valid-json", default=None)
+    p.add_argument("--model-module", default="fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa:Tacotron2_sa")
+    p.add_argument("--teacher-conf", default=None, help="KD: the teacher's model.json")
+    p.add_argument("--teacher-model", default=None, help="KD: the teacher's amp_checkpoint_*.pt / snapshot")
+    p.add_argument("--resume", "-r", default=None, help="snapshot.ep.N to continue from")
+    p.add_argument("--batch-size", "-b", default=32, type=int)
+    p.add_argument("--batch-sort-key", default="shuffle", choices=["shuffle", "input", "output"])
+    p.add_argument("--epochs", "-e", default=30, type=int)
+    p.add_argument("--lr", default=1e-3, type=float)
+    p.add_argument("--eps", default=1e-6, type=float)
+    p.add_argument("--weight-decay", default=0.0, type=float)
+    p.add_argument("--grad-clip", default=1.0, type=float)
+    p.add_argument("--accum-grad", default=1, type=int)
+    p.add_argument("--seed", default=1, type=int)
+    p.add_argument("--save-interval-epochs", default=1, type=int)
+    p.add_argument("--eval-interval-epochs", default=1, type=int)
+    p.add_argument("--report-interval-iters", default=100, type=int)
+    p.add_argument("--keep-all-data-on-mem", action="store_true")
+    p.add_argument("--use-fe-condition", default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
+    p.add_argument("--append-position", default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
+    for k in ("output", "encoder", "decoder", "prosody"):
+        p.add_argument("--distill-%s-knowledge" % k, default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
+    p.add_argument("--share-proj", default=False, type=lambda s: str(s).lower() in ("1", "true", "yes"))
+    p.add_argument("--is-train", default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
+    return p
+
+
+def _mean_reports(reps):
+    keys = sorted({k for r in reps for k in r})
+    return {k: float(np.mean([r[k] for r in reps if k in r])) for k in keys}
+
+
+def train(argv=None):
+    parser = get_parser()
+    args, _ = parser.parse_known_args(argv)
+    cls = dynamic_import(args.model_module)
+    cls.add_arguments(parser)
+    args = parser.parse_args(argv)
+    if args.weight_decay != 0.0:
+        raise NotImplementedError("fcl-taco2_amd: weight decay is 0 in every shipped recipe and is not implemented on the HIP path")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = "cuda:%d" % local_rank
+    if not torch.cuda.is_available():
+        raise RuntimeError("fcl-taco2_amd: training needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+    from .training import TrainEngine
+
+    train_utts = read_train_manifest(args.train_json)
+    valid_utts = read_train_manifest(args.valid_json) if args.valid_json else []
+    idim, odim = train_utts[0]["num_phns"], int(np.load(train_utts[0]["mel"]).shape[1])
+    os.makedirs(args.outdir, exist_ok=True)
+    if rank == 0:
+        with open(os.path.join(args.outdir, "model.json"), "wb") as f:
+            f.write(json.dumps((idim, odim, vars(args)), indent=4, ensure_ascii=False, sort_keys=True).encode("utf_8"))
+    kd = cls.role == "student"
+    if kd:
+        if not (args.teacher_conf and args.teacher_model):
+            raise ValueError("KD training needs --teacher-conf and --teacher-model (tts_distill.py:370-371)")
+        from .decode import get_model_conf
+
+        teacher = build_model(args.teacher_model, args.teacher_conf, None, dev)
+        if teacher.role != "kd_teacher":  # a teacher trained with the plain class: same parameter tree, KD class returns the knowledge tuple
+            from .nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
+
+            t_idim, t_odim, targs = get_model_conf(args.teacher_conf)
+            kt = KDTeacher(t_idim, t_odim, targs, argparse.Namespace(use_fe_condition=True, append_position=True))
+            kt.load_state_dict(teacher.state_dict())
+            teacher = kt.to(dev)
+        for p_ in teacher.parameters():
+            p_.requires_grad = False  # tts_distill.py:397-398
+        teacher.train()  # the reference never puts the teacher in eval mode
+        teng = TrainEngine(teacher)
+        model = cls(idim, odim, args, args, get_model_conf(args.teacher_conf)[2])
+    else:
+        teng = None
+        model = cls(idim, odim, args, args)
+    torch.manual_seed(args.seed)
+    model = model.to(dev)
+    eng = TrainEngine(model, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip, accum_grad=args.accum_grad, seed=args.seed * 1000 + rank)
+    epoch0, iteration = 0, 0
+    if args.resume:
+        snap = torch.load(args.resume, map_location="cpu", weights_only=False)
+        model.load_state_dict(load_state_dict(args.resume))
+        if "optimizer" in snap:
+            load_adam_state_dict(eng, snap["optimizer"])
+        epoch0, iteration = int(snap.get("epoch", 0)), int(snap.get("iteration", 0))
+    conv = CustomConverter(1, args.use_fe_condition, args.append_position)
+    cache = {} if args.keep_all_data_on_mem else None
+    log, best = [], float("inf")
+    for epoch in range(epoch0 + 1, args.epochs + 1):
+        batches = make_batchset(train_utts, args.batch_size, args.batch_sort_key, seed=args.seed + epoch, min_batch_size=1)
+        n_iter = len(batches) // world  # every rank takes the same number of steps: collectives stay matched
+        reps, t0, frames = [], time.time(), 0
+        micro = 0
+        for it in range(n_iter):
+            batch = conv([load_batch(batches[it * world + rank], cache)])
+            know = teng.knowledge(batch, mode="train") if kd else None
+            if micro == 0:
+                eng.zero_grad()
+            rep = eng.forward_backward(batch, know, mode="train")
+            micro += 1
+            if micro == eng.accum_grad:  # tts.py:166-171
+                eng.optimizer_step()
+                micro = 0
+                iteration += 1
+            reps.append(rep)
+            frames += int(sum(int(v) for v in batch["olens"]))
+            if rank == 0 and args.report_interval_iters and (it + 1) % args.report_interval_iters == 0:
+                m = _mean_reports(reps[-args.report_interval_iters:])
+                logging.info("epoch %d iter %d/%d loss %.4f (%.0f frames/s/GPU)", epoch, it + 1, n_iter, m["loss"], frames / (time.time() - t0))
+        torch.cuda.synchronize()
+        entry = {"epoch": epoch, "iteration": iteration, "elapsed_time": time.time() - t0}
+        entry.update({"main/" + k: v for k, v in _mean_reports(reps).items()})
+        valid_loss = None
+        if valid_utts and epoch % args.eval_interval_epochs == 0 and rank == 0:
+            model.eval()  # CustomEvaluator: student in eval mode, teacher untouched (tts_distill.py:91-111)
+            vreps = []
+            with torch.no_grad():
+                for vb in make_batchset(valid_utts, args.batch_size, "input"):
+                    batch = conv([load_batch(vb, cache)])
+                    kw = dict(teacher_knowledge=teng.knowledge(batch, mode="train")) if kd else {}
+                    model(**{k: v for k, v in batch.items() if not k.startswith("_")}, **kw)
+                    vreps.append(dict(model.reporter.last))
+            model.train()
+            vm = _mean_reports(vreps)
+            entry.update({"validation/main/" + k: v for k, v in vm.items()})
+            valid_loss = vm.get("loss")
+        if rank == 0:
+            log.append(entry)
+            with open(os.path.join(args.outdir, "log"), "w") as f:
+                json.dump(log, f, indent=4)
+            if epoch % args.save_interval_epochs == 0 or epoch == args.epochs:
+                best = save_checkpoints(args.outdir, eng, epoch, iteration, valid_loss, best)
+            logging.info("epoch %d done: %s", epoch, json.dumps(entry))
+        if world > 1:
+            dist.barrier()
+    if world > 1:
+        dist.destroy_process_group()
+    return log
+
+
+def main(argv=None):
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
+    train(argv)
+
+
+if __name__ == "__main__":
+    main()

@@ -113,8 +113,9 @@ class TrainEngine(object):
         total = int(offs[-1])
         self.pflat = torch.empty(total, device=self.dev)
         self.gflat, self.mflat, self.vflat = (torch.zeros(total, device=self.dev) for _ in range(3))
-        self.P, self.G = {}, {}
+        self.P, self.G, self._offsets = {}, {}, {}
         for k, o in zip(names, offs[:-1]):
+            self._offsets[k] = (int(o), pd[k].numel(), tuple(pd[k].shape))
             n = pd[k].numel()
             view = self.pflat[o : o + n].view(pd[k].shape)
             view.copy_(pd[k].data)
@@ -126,6 +127,10 @@ class TrainEngine(object):
         self.lr, self.eps, self.betas, self.grad_clip, self.accum_grad = lr, eps, betas, grad_clip, int(accum_grad)
         self.step_count, self.forward_count, self.seed = 0, 0, int(seed)
         self.gn_sq = torch.zeros(1, dtype=torch.float64, device=self.dev)
+
+    def param_offsets(self):
+        """{parameter name: (offset, numel, shape)} into pflat / gflat / mflat / vflat (checkpoint writers)."""
+        return dict(self._offsets)
 
     # ------------------------------------------------------------------------------------------------ randomness
     def _keep(self, c, name, shape, p_one):
