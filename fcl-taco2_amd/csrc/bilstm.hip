@@ -130,6 +130,173 @@ __global__ __launch_bounds__(4 * H) void bilstm_bptt_persistent_kernel(BilstmBwd
     }
 }
 
+// ---- H = 256 (FCL-taco2-T): one CU's register file (512 KB) cannot hold the 1 MB of W_hh, so an (utterance, direction) recurrence is shared by
+// P = H/64 = 4 workgroups, each owning 64 units (all four gates, 256 weight rows, 128 weights per thread in registers).  Per step the workgroups
+// exchange their slices of h through global memory and meet at a counter barrier (release fence -> device-scope atomic -> spin -> acquire fence).
+// Group members have adjacent block ids, the grid is at most 8 B workgroups of 512 threads (one per CU), so partially resident groups only wait for
+// running ones; a bounded spin turns any scheduling surprise into an error flag instead of a hang.
+struct GroupSync {
+    unsigned int* flag;  // [groups] zeroed before the launch
+    unsigned int* error;
+};
+
+// No fences: an agent-scope release / acquire on gfx942-class parts writes back / invalidates the whole L2 (measured 45 us per step here).  The
+// exchanged words are instead written and read with agent-scope RELAXED atomics (write-through / L2-bypassing accesses), the writers drain their
+// store counters before the workgroup barrier, and only then is the arrival counted.
+__device__ __forceinline__ void xchg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float xchg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool group_barrier(const GroupSync& gs, int group, unsigned int target) {
+    __builtin_amdgcn_s_waitcnt(0);  // this thread's write-through stores have been acknowledged
+    __syncthreads();
+    __shared__ int ok_s;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(gs.flag + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (long long spin = 0; spin < (1ll << 24); ++spin) {
+            if (__hip_atomic_load(gs.flag + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+        }
+        if (!ok) atomicExch(gs.error, 1u);
+        ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+
+template <int H, bool SAVE>
+__global__ __launch_bounds__(512) void bilstm_group_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r, const float* __restrict__ whh_f,
+                                                           const float* __restrict__ whh_r, const int* __restrict__ lens, float* __restrict__ out, int T,
+                                                           float* __restrict__ hbuf /* [groups][2][H] */, GroupSync gs, BilstmSave sv) {
+    static_assert(H == 256, "4 workgroups x 64 units x 2 K-halves");
+    constexpr int P = H / 64;
+    __shared__ __attribute__((aligned(16))) float h_s[H];
+    __shared__ float g_s[2][256];
+    const int p = blockIdx.x % P, group = blockIdx.x / P;  // group = b * 2 + dir
+    const int b = group >> 1, dir = group & 1;
+    const int j = threadIdx.x, row = j & 255, kh = j >> 8;  // row = gate * 64 + unit of this workgroup's slice
+    const int gate = row >> 6, unit = p * 64 + (row & 63);
+    const float* gx = (dir ? gx_r : gx_f) + (size_t)b * T * (4 * H);
+    const float* whh = (dir ? whh_r : whh_f) + (size_t)(gate * H + unit) * H + kh * 128;
+    const int len = lens[b];
+    float w[128];
+#pragma unroll
+    for (int k = 0; k < 128; k += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(whh + k);
+        w[k] = v[0]; w[k + 1] = v[1]; w[k + 2] = v[2]; w[k + 3] = v[3];
+    }
+    if (j < H) h_s[j] = 0.f;
+    float c = 0.f;
+    if (j < 64)
+        for (int t = len; t < T; ++t) out[((size_t)b * T + t) * (2 * H) + dir * H + p * 64 + j] = 0.f;  // padded tail of this slice
+    __syncthreads();
+    int t = dir ? len - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float* hb = hbuf + (size_t)group * 2 * H;
+    for (int s = 0; s < len; ++s, t += dt) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 128; k += 4) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(&h_s[kh * 128 + k]);
+            a0 = fmaf(w[k], hv[0], a0);
+            a1 = fmaf(w[k + 1], hv[1], a1);
+            a2 = fmaf(w[k + 2], hv[2], a2);
+            a3 = fmaf(w[k + 3], hv[3], a3);
+        }
+        g_s[kh][row] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (j < 64) {
+            const float* gr = gx + (size_t)t * (4 * H) + p * 64 + j;
+            const float ig = sigmoid_f(gr[0] + g_s[0][j] + g_s[1][j]), fg = sigmoid_f(gr[H] + g_s[0][64 + j] + g_s[1][64 + j]);
+            const float gg = tanh_f(gr[2 * H] + g_s[0][128 + j] + g_s[1][128 + j]), og = sigmoid_f(gr[3 * H] + g_s[0][192 + j] + g_s[1][192 + j]);
+            const int u = p * 64 + j;
+            if (SAVE) {
+                const size_t cell = (size_t)t * sv.B + b;
+                float* sg = sv.gates[dir] + cell * (4 * H);
+                sg[u] = ig; sg[H + u] = fg; sg[2 * H + u] = gg; sg[3 * H + u] = og;
+                sv.c_old[dir][cell * H + u] = c;
+                sv.h_old[dir][cell * H + u] = h_s[u];
+            }
+            c = fg * c + ig * gg;
+            if (SAVE) sv.c_new[dir][((size_t)t * sv.B + b) * H + u] = c;
+            const float h = og * tanh_f(c);
+            out[((size_t)b * T + t) * (2 * H) + dir * H + u] = h;
+            xchg_store(hb + (s & 1) * H + u, h);
+        }
+        if (!group_barrier(gs, group, (unsigned int)(P * (s + 1)))) return;
+        if (j < H) h_s[j] = xchg_load(hb + (s & 1) * H + j);
+        __syncthreads();
+    }
+}
+
+// reverse pass, same grouping: workgroup p does the cell backward of its 64 units, then its 256 gate rows' share of dh = dgates . W_hh for ALL H columns
+// (thread (k, rh): 128 weights W_hh[rows of half rh, k] from the transposed matrix); the P partial vectors are exchanged and summed per unit slice.
+template <int H>
+__global__ __launch_bounds__(512) void bilstm_bptt_group_kernel(BilstmBwd a, const int* __restrict__ lens, int T, float* __restrict__ part /* [groups][2][P][H] */,
+                                                                GroupSync gs) {
+    static_assert(H == 256, "4 workgroups x 64 units");
+    constexpr int P = H / 64;
+    __shared__ __attribute__((aligned(16))) float dg_s[256];  // this workgroup's gate-row gradients, (gate, unit-in-slice) order
+    __shared__ float p_s[2][H];
+    const int p = blockIdx.x % P, group = blockIdx.x / P;
+    const int b = group >> 1, dir = group & 1;
+    const int j = threadIdx.x, k = j & 255, rh = j >> 8;
+    const int len = lens[b];
+    float w[128];  // W_hh[(2rh + seg) * H + 64p + r, k] for seg in {0, 1}, r in 0..63
+    const float* wt = a.whh_t[dir] + (size_t)k * (4 * H);
+#pragma unroll
+    for (int seg = 0; seg < 2; ++seg)
+#pragma unroll
+        for (int r = 0; r < 64; r += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(wt + (2 * rh + seg) * H + p * 64 + r);
+            w[seg * 64 + r] = v[0]; w[seg * 64 + r + 1] = v[1]; w[seg * 64 + r + 2] = v[2]; w[seg * 64 + r + 3] = v[3];
+        }
+    float* dg = a.dg[dir];
+    if (j < 256)
+        for (int t = len; t < T; ++t) dg[((size_t)t * a.B + b) * (4 * H) + (j >> 6) * H + p * 64 + (j & 63)] = 0.f;  // dead cells of this slice
+    float dh = 0.f, dc = 0.f;
+    int t = dir ? 0 : len - 1;
+    const int dt = dir ? 1 : -1;
+    float* pb = part + (size_t)group * 2 * P * H;
+    for (int s = 0; s < len; ++s, t += dt) {
+        const size_t cell = (size_t)t * a.B + b;
+        if (j < 64) {
+            const int u = p * 64 + j;
+            const float* g = a.gates[dir] + cell * (4 * H);
+            const float ig = g[u], fg = g[H + u], gg = g[2 * H + u], og = g[3 * H + u];
+            const float dho = dh + a.d_out[((size_t)b * T + t) * a.ld + dir * H + u];
+            const float tc = tanhf(a.c_new[dir][cell * H + u]);
+            const float dcn = dc + dho * og * (1.0f - tc * tc);
+            const float d0 = dcn * gg * ig * (1.0f - ig), d1 = dcn * a.c_old[dir][cell * H + u] * fg * (1.0f - fg);
+            const float d2 = dcn * ig * (1.0f - gg * gg), d3 = dho * tc * og * (1.0f - og);
+            dg_s[j] = d0; dg_s[64 + j] = d1; dg_s[128 + j] = d2; dg_s[192 + j] = d3;
+            float* o = dg + cell * (4 * H);
+            o[u] = d0; o[H + u] = d1; o[2 * H + u] = d2; o[3 * H + u] = d3;
+            dc = dcn * fg;
+        }
+        __syncthreads();
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 128; r += 4) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(&dg_s[rh * 128 + r]);
+            a0 = fmaf(w[r], dv[0], a0);
+            a1 = fmaf(w[r + 1], dv[1], a1);
+            a2 = fmaf(w[r + 2], dv[2], a2);
+            a3 = fmaf(w[r + 3], dv[3], a3);
+        }
+        p_s[rh][k] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (j < H) xchg_store(pb + ((s & 1) * P + p) * H + j, p_s[0][j] + p_s[1][j]);
+        if (!group_barrier(gs, group, (unsigned int)(P * (s + 1)))) return;
+        if (j < 64) {
+            const float* q = pb + (s & 1) * P * H + p * 64 + j;
+            float v = 0.f;
+#pragma unroll
+            for (int pp = 0; pp < P; ++pp) v += xchg_load(q + pp * H);
+            dh = v;
+        }
+    }
+}
+
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -141,6 +308,37 @@ using namespace fcl;
 namespace fcl {
 
 // both directions of the training forward / reverse pass in one launch each; false = H unsupported (the caller falls back to per-step launches)
+// H = 256: groups of 4 workgroups.  ws: [2B] flags + 1 error word (zeroed here) followed by the exchange buffer.
+size_t bilstm_group_workspace_bytes(int B, int H) { return 1024 + sizeof(unsigned int) * 2 * (size_t)B + sizeof(float) * 2 * (size_t)B * 2 * 4 * H; }
+
+static bool group_ok(int B, int H, void* ws, size_t ws_bytes) {
+    static const int enabled = tunable("BILSTM_GROUP", 1);
+    return enabled && H == 256 && ws && ws_bytes >= bilstm_group_workspace_bytes(B, H);
+}
+
+bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T, int H,
+                         const BilstmSave* sv, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!group_ok(B, H, ws, ws_bytes)) return false;
+    unsigned int* flags = (unsigned int*)ws;
+    if (hipMemsetAsync(flags, 0, 1024 + sizeof(unsigned int) * 2 * (size_t)B, s) != hipSuccess) return false;
+    GroupSync gs{flags + 256, flags};
+    float* hbuf = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
+    dim3 grid(2 * B * 4);
+    if (sv) hipLaunchKernelGGL((bilstm_group_kernel<256, true>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, hbuf, gs, *sv);
+    else hipLaunchKernelGGL((bilstm_group_kernel<256, false>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, hbuf, gs, BilstmSave());
+    return true;
+}
+
+bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!group_ok(B, H, ws, ws_bytes)) return false;
+    unsigned int* flags = (unsigned int*)ws;
+    if (hipMemsetAsync(flags, 0, 1024 + sizeof(unsigned int) * 2 * (size_t)B, s) != hipSuccess) return false;
+    GroupSync gs{flags + 256, flags};
+    float* part = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
+    hipLaunchKernelGGL((bilstm_bptt_group_kernel<256>), dim3(2 * B * 4), dim3(512), 0, s, a, lens, T, part, gs);
+    return true;
+}
+
 bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T,
                                     int H, const BilstmSave& sv, hipStream_t s) {
     dim3 grid(B, 2);
@@ -179,7 +377,7 @@ extern "C" {
 // workspace: Gx_f [B*T,4H] | Gx_r [B*T,4H] | h[2][2 dirs][B,H] | c[2 dirs][B,H]
 size_t fcl_bilstm_workspace_bytes(int b, int t, int h) {
     if (b <= 0 || t <= 0 || h <= 0) return 0;
-    return sizeof(float) * ((size_t)2 * b * t * 4 * h + (size_t)6 * b * h) + 256;
+    return sizeof(float) * ((size_t)2 * b * t * 4 * h + (size_t)6 * b * h) + 256 + (h == 256 ? bilstm_group_workspace_bytes(b, h) : 0);
 }
 
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
@@ -208,7 +406,17 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
         if (rc) return rc;
     }
     const bool can_persist = (h == 8 || h == 16 || h == 32 || h == 64 || h == 128);
-    if (algo == 0) algo = can_persist ? 2 : 1;
+    // algo 3 (H = 256, FCL-taco2-T): 4 cooperating workgroups per (utterance, direction).  Opt-in: it is 2.6x faster than 2T per-step launches on an
+    // otherwise idle GPU (the training step), but its 8B spinning workgroups own every CU for the whole recurrence, which costs 9 % of throughput when
+    // several synthesis passes are in flight on other streams (3.52 vs 3.85 M frames/s) — so algo 0 keeps the per-step launches there.
+    static const int group_infer = tunable("BILSTM_GROUP_INFER", 0);
+    if (h == 256 && (algo == 3 || (algo == 0 && group_infer))) {
+        void* gws = hbuf;  // the Gx buffers are final, so the tail of the workspace (per-step state of algo 1) is free for the flags and the exchange buffer
+        const size_t gbytes = workspace_bytes - sizeof(float) * ((size_t)2 * b * t * 4 * h);
+        ProfScope ps("bilstm_group_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
+        if (launch_bilstm_group(gx_f, gx_r, w_hh_f, w_hh_r, lens, out, b, t, h, nullptr, gws, gbytes, s)) return check_hip(hipGetLastError(), "bilstm group launch");
+    }
+    if (algo == 0 || algo == 3) algo = can_persist ? 2 : 1;
     FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);
     if (algo == 2) {
         ProfScope ps("bilstm_persistent_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);

@@ -130,6 +130,10 @@ struct BilstmBwd {
 bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T,
                                     int H, const BilstmSave& sv, hipStream_t s);
 bool launch_bilstm_bptt_persistent(const BilstmBwd& a, const int* lens, int B, int T, int H, hipStream_t s);
+size_t bilstm_group_workspace_bytes(int B, int H);
+bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T, int H,
+                         const BilstmSave* sv, void* ws, size_t ws_bytes, hipStream_t s);
+bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, hipStream_t s);
 
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);

@@ -245,7 +245,7 @@ class TrainEngine(object):
             g = lambda k: P["enc.blstm." + k]
             return ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), ops.add_vec(g("bias_ih_l0"), g("bias_hh_l0")),
                               g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), ops.add_vec(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
-                              B, T), None
+                              B, T, algo=3 if H == 256 else 0), None  # single stream here: the 4-workgroup group kernel for FCL-taco2-T
         out = torch.empty(B * T, 2 * H, device=dev)
         gx, whh, sv = [], [], []
         for sfx in ("", "_reverse"):

@@ -110,7 +110,8 @@ int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n,
 /* ---- H3: Encoder.blstm over packed sequences (encoder_sa.py:98-100,143-146) -------------------------- */
 /* x [B*T, C]; lens [B] int32 (device); w_ih_* [4H, C], w_hh_* [4H, H], b_* [4H] (= bias_ih + bias_hh);
  * out [B*T, 2H] = fwd | bwd, zero past each length.  algo: 0 auto, 1 per-step launches, 2 persistent
- * register-resident recurrence (H in {8,16,32,64,128}). */
+ * register-resident recurrence (H in {8,16,32,64,128}), 3 (H = 256) four cooperating workgroups per (utterance, direction)
+ * exchanging h through global memory — fastest on an idle GPU, not the default when other streams are in flight. */
 size_t fcl_bilstm_workspace_bytes(int b, int t, int h);
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
                    const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,

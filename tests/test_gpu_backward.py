@@ -186,3 +186,49 @@ def test_small_m_split_k_gemm(ops, m, n, k):
     assert max_abs(y.cpu().double(), ref) < 2e-5
     y2 = ops.linear(dev(x), dev(w.astype(np.float32)))  # no bias
     assert max_abs(y2.cpu().double(), ref - b) < 2e-5
+
+
+@pytest.mark.parametrize("H,lens", [(16, [19, 19, 12, 5, 1]), (128, [19, 19, 12, 5, 1]), (256, [19, 19, 12, 5, 1]), (24, [19, 19, 12, 5, 1]),
+                                    (256, sorted(np.random.RandomState(9).randint(40, 81, 32).tolist(), reverse=True))])
+def test_bilstm_train_forward_and_bptt_vs_torch_lstm(ops, H, lens):
+    """fcl_bilstm_train_fwd / fcl_bilstm_bptt (persistent kernels for H <= 128, the 4-workgroup group kernels for H = 256, the per-step fallback for
+    any other H) against torch.nn.LSTM over packed sequences: outputs, and — through the saved gates — the gradients of W_hh, W_ih and x.
+    The inference entry (ops.bilstm, algo 0) takes the same kernels without saving and must agree too."""
+    rng = np.random.RandomState(H)
+    B, T, C = len(lens), max(lens), 32  # the last case fills all 256 CUs with 32 x 2 groups of 4 workgroups
+    lstm = torch.nn.LSTM(C, H, 1, batch_first=True, bidirectional=True)
+    x = torch.from_numpy(rnd(rng, B, T, C)).requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True)
+    ref, _ = torch.nn.utils.rnn.pad_packed_sequence(lstm(packed)[0], batch_first=True, total_length=T)
+    d_out = rnd(rng, B, T, 2 * H)
+    for b, l in enumerate(lens):
+        d_out[b, l:] = 0.0
+    (ref * torch.from_numpy(d_out)).sum().backward()
+    sd = {k: v.detach() for k, v in lstm.named_parameters()}
+    lens_dev = dev(np.array(lens, np.int32))
+    xd = dev(x.detach().reshape(B * T, C))
+    sfxs = ("", "_reverse")
+    gx = [ops.linear(xd, dev(sd["weight_ih_l0" + s]), dev(sd["bias_ih_l0" + s] + sd["bias_hh_l0" + s])) for s in sfxs]
+    whh = [dev(sd["weight_hh_l0" + s]) for s in sfxs]
+    sv = [[torch.zeros(T, B, 4 * H, device=DEV)] + [torch.zeros(T, B, H, device=DEV) for _ in range(3)] for _ in sfxs]
+    out = torch.empty(B * T, 2 * H, device=DEV)
+    ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv)
+    assert max_abs(out.cpu().reshape(B, T, 2 * H), ref.detach()) < 2e-5
+    inf = ops.bilstm(xd, lens_dev, dev(sd["weight_ih_l0"]), whh[0], dev(sd["bias_ih_l0"] + sd["bias_hh_l0"]), dev(sd["weight_ih_l0_reverse"]), whh[1],
+                     dev(sd["bias_ih_l0_reverse"] + sd["bias_hh_l0_reverse"]), B, T)
+    assert max_abs(inf.cpu().reshape(B, T, 2 * H), ref.detach()) < 2e-5
+    dgs = [torch.empty(T, B, 4 * H, device=DEV) for _ in sfxs]
+    ops.bilstm_bptt(sv, lens_dev, B, T, dev(d_out.reshape(B * T, 2 * H)), [ops.transpose2d(w) for w in whh], dgs)
+    perm = dev(((np.arange(B * T) % T) * B + np.arange(B * T) // T).astype(np.int32))
+    dx = torch.zeros(B * T, C, device=DEV)
+    for d, s in enumerate(sfxs):
+        dg2 = dgs[d].reshape(T * B, 4 * H)
+        g_hh = torch.zeros(4 * H, H, device=DEV)
+        ops.gemm_tn(dg2, sv[d][3].reshape(T * B, H), g_hh)
+        assert max_abs(g_hh.cpu(), dict(lstm.named_parameters())["weight_hh_l0" + s].grad) < 2e-4, s
+        dgx = ops.gather_rows(dg2, perm)
+        g_ih = torch.zeros(4 * H, C, device=DEV)
+        ops.gemm_tn(dgx, xd, g_ih)
+        assert max_abs(g_ih.cpu(), dict(lstm.named_parameters())["weight_ih_l0" + s].grad) < 2e-4, s
+        ops.add2d(dx, ops.linear(dgx, ops.transpose2d(dev(sd["weight_ih_l0" + s]))))
+    assert max_abs(dx.cpu().reshape(B, T, C), x.grad) < 2e-4 * max(1.0, float(x.grad.abs().max()))
