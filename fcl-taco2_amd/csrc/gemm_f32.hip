@@ -31,9 +31,11 @@ constexpr int F4_SHIFT = F4 == 8 ? 3 : 2;
 static_assert(BK == 32 || BK == 16, "BK must be 16 or 32");
 constexpr int LDS_LD = BK + 4;  // padded LDS row stride (floats); keeps float4 alignment and spreads rows over banks
 
-template <int WM, int WN, bool LSTM>
+// TM = 16-row MFMA tiles per wave along M.  TM = 1: a wave reads 10 operand fragments from LDS per 12 MFMAs (bf16x3) and the kernel is LDS-bound;
+// TM = 2 (32 x 64 per wave, 64 x 128 per workgroup with WM = WN = 2): 12 fragments per 24 MFMAs, LDS and MFMA time balance.
+template <int WM, int WN, bool LSTM, int TM = 1>
 struct Geo {
-    static constexpr int BM = 16 * WM;
+    static constexpr int BM = 16 * WM * TM;
     static constexpr int BN = 64 * WN;
     static constexpr int THREADS = 64 * WM * WN;
     static constexpr int NA = (BM * F4 + THREADS - 1) / THREADS;  // float4 loads of A per thread per chunk
@@ -61,11 +63,11 @@ __device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
 }
 
 // Shared main loop.  n0: first output column (generic) or first hidden unit (LSTM).  NU: N (generic) or U.
-template <int WM, int WN, bool LSTM, int PREC = 0>
+template <int WM, int WN, bool LSTM, int PREC = 0, int TM = 1>
 __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0,
                                          int NU, const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
-                                         float* lds, f32x4 (&acc)[4]) {
-    using G = Geo<WM, WN, LSTM>;
+                                         float* lds, f32x4 (&acc)[TM][4]) {
+    using G = Geo<WM, WN, LSTM, TM>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -187,7 +189,10 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
             const float* B_l = A_l + G::BM * LDS_LD;
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
-                const f32x4 af = *reinterpret_cast<const f32x4*>(A_l + (wm * 16 + r16) * LDS_LD + s * 16 + kq * 4);
+                f32x4 af[TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    af[tm] = *reinterpret_cast<const f32x4*>(A_l + ((wm * TM + tm) * 16 + r16) * LDS_LD + s * 16 + kq * 4);
                 f32x4 bf[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -195,15 +200,22 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tm][e], bf[j][e], acc[tm][j], 0, 0, 0);
                 }
             }
         } else {  // one v_mfma_f32_16x16x32_bf16 k-step per chunk: lane (r16, kq) feeds 8 consecutive k of row r16
             const unsigned short* P = reinterpret_cast<const unsigned short*>(lds + buf * BUF_FLOATS);
             const unsigned short* Ah = P, *Al = P + G::BM * LDK, *Bh = P + 2 * G::BM * LDK, *Bl = Bh + G::BN * LDK;
-            const int ao = (wm * 16 + r16) * LDK + kq * 8;
-            const s16x8 ah = *reinterpret_cast<const s16x8*>(Ah + ao), al = *reinterpret_cast<const s16x8*>(Al + ao);
+            s16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int ao = ((wm * TM + tm) * 16 + r16) * LDK + kq * 8;
+                ah[tm] = *reinterpret_cast<const s16x8*>(Ah + ao);
+                al[tm] = *reinterpret_cast<const s16x8*>(Al + ao);
+            }
             s16x8 bh[4], bl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -212,11 +224,14 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
                 bl[j] = *reinterpret_cast<const s16x8*>(Bl + bo);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[j], 0, 0, 0);
+            for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[j], acc[tm][j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[j], acc[tm][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[j], acc[tm][j], 0, 0, 0);
+            }
         }
         if (!has_next) break;
         stash(buf ^ 1);
@@ -228,20 +243,24 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
 }
 
 // --------------------------------------------------------------------------------------------------
-template <int WM, int WN, int PREC>
+template <int WM, int WN, int PREC, int TM = 1>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
-    using G = Geo<WM, WN, false>;
+    using G = Geo<WM, WN, false, TM>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
     const int m0 = blockIdx.y * G::BM, n0 = blockIdx.x * G::BN;
-    f32x4 acc[4];
+    f32x4 acc[TM][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, false, PREC>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, lds, acc);
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<WM, WN, false, PREC, TM>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, lds, acc);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, rq = lane >> 4;
     const unsigned int seed = hash_u32(a.rng_seed + (a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u));
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + col;
@@ -250,9 +269,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
         const float r1w = a.rank1_w ? a.rank1_w[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm * 16 + rq * 4 + r;
+            const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
             if (m >= a.M) continue;
-            float v = acc[j][r] + bn;
+            float v = acc[tm][j][r] + bn;
             if (a.rank1_a) v += a.rank1_a[(size_t)m * a.rank1_lda] * r1w;
             if (a.C0) v += a.C0[(size_t)m * a.ldc0 + n];
             if (a.act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
@@ -270,9 +289,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     }
 }
 
-template <int WM, int WN, int MODE, int PREC>
+template <int WM, int WN, int MODE, int PREC, int TM = 1>
 __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepArgs a) {
-    using G = Geo<WM, WN, true>;
+    using G = Geo<WM, WN, true, TM>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
     const int m0 = blockIdx.y * G::BM, u0 = blockIdx.x * (16 * WN);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -281,27 +300,38 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
     const int rq = lane >> 4;
     // epilogue operands (G0 / bias / position / old state) are requested BEFORE the K loop so their latency hides
     // under the MFMAs; rows / units past the edge read a clamped, valid address and are never stored.
-    CellIn ci[4];
+    CellIn ci[TM][4];
     const int uc = min(u, a.U - 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ci[r] = cell_prefetch<MODE>(a, min(m0 + wm * 16 + rq * 4 + r, a.M - 1), uc);
-    f32x4 acc[4];
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, true, PREC>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
+        for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, a.M - 1), uc);
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mainloop<WM, WN, true, PREC, TM>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
     if (u >= a.U) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 16 + rq * 4 + r;
-        if (m >= a.M) continue;
-        const float pre[4] = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        cell_finish(a, m, u, pre, ci[r]);
-    }
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
+            if (m >= a.M) continue;
+            const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+            cell_finish(a, m, u, pre, ci[tm][r]);
+        }
 }
 
 // --------------------------------------------------------------------------------------------------
 // FCL_PRECISION: 1 (default) = bf16x3 split operands on the bf16 MFMA pipe, fp32 accumulate: ~1e-5 relative error,
 // 1.4x the end-to-end throughput of 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32), which stays available for audits.
+static int tm2_min_wg() {
+    static const int v = tunable("GEMM_TM2_MIN_WG", 128);
+    return v;
+}
+
 static int precision() {
     static const int p = tunable("PRECISION", 1);
     return p;
@@ -351,20 +381,20 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restric
     }
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int TM = 1>
 static void launch_gemm_cfg(const GemmArgs& a, hipStream_t s, const char* name, double flops) {
-    using G = Geo<WM, WN, false>;
+    using G = Geo<WM, WN, false, TM>;
     dim3 grid((a.N + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
     char full[64];
     snprintf(full, sizeof(full), "%s%s", name, precision() ? "/bf16x3" : "");
     ProfScope ps(full, flops, a.M, s);
-    if (precision()) hipLaunchKernelGGL((gemm_kernel<WM, WN, 1>), grid, dim3(G::THREADS), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<WM, WN, 0>), grid, dim3(G::THREADS), 0, s, a);
+    if (precision()) hipLaunchKernelGGL((gemm_kernel<WM, WN, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int TM = 1>
 static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* name, double flops) {
-    using G = Geo<WM, WN, true>;
+    using G = Geo<WM, WN, true, TM>;
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     const bool plain = !a.zone_keep_h && !a.row_len;
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
@@ -372,13 +402,13 @@ static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* na
     snprintf(full, sizeof(full), "%.*s,%d>%s", (int)strlen(name) - 1, name, mode, precision() ? "/bf16x3" : "");  // "...<4,1>" -> "...<4,1,0>"
     ProfScope ps(full, flops, a.M, s);
     if (precision()) {
-        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 1>), grid, dim3(G::THREADS), 0, s, a);
-        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 1>), grid, dim3(G::THREADS), 0, s, a);
-        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 1>), grid, dim3(G::THREADS), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
+        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 0>), grid, dim3(G::THREADS), 0, s, a);
-        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 0>), grid, dim3(G::THREADS), 0, s, a);
-        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 0>), grid, dim3(G::THREADS), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
+        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
+        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
     }
 }
 
@@ -417,7 +447,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     }
     // 64x64 tiles measured best for every GEMM of the path (the 32x128 / 16x256 variants only win for a single 16/32-row tile)
     static const int force = tunable("GEMM_CFG", 0);  // experiments only: 1 -> <4,1>, 2 -> <2,2>, 3 -> <1,4>
-    if (force == 1 || (force == 0 && a.M > 32)) {
+    static const int tm2 = tunable("GEMM_TM2", 1);    // 64 x 128 workgroup tiles with 32 x 64 per wave where the grid still fills the chip
+    if (force == 0 && tm2 && a.N >= 128 && (long long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= tm2_min_wg()) {
+        launch_gemm_cfg<2, 2, 2>(a, s, "gemm_kernel<2,2,tm2>", flops);
+    } else if (force == 1 || (force == 0 && a.M > 32)) {
         launch_gemm_cfg<4, 1>(a, s, "gemm_kernel<4,1>", flops);
     } else if (force == 2 || (force == 0 && a.M > 16)) {
         launch_gemm_cfg<2, 2>(a, s, "gemm_kernel<2,2>", flops);
@@ -446,7 +479,10 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * 4.0 * a.U * ksum;
     const long long wg64 = (long long)((a.M + 63) / 64) * ((a.U + 15) / 16);
-    if (wg64 >= 256 || a.U <= 16) {
+    static const int tm2 = tunable("GEMM_TM2", 1);
+    if (tm2 && a.U >= 32 && (long long)((a.M + 63) / 64) * ((a.U + 31) / 32) >= tm2_min_wg()) {
+        launch_lstm_cfg<2, 2, 2>(a, s, "lstm_step_kernel<2,2,tm2>", flops);
+    } else if (wg64 >= 256 || a.U <= 16) {
         launch_lstm_cfg<4, 1>(a, s, "lstm_step_kernel<4,1>", flops);
     } else if (a.U <= 32 || (long long)((a.M + 31) / 32) * ((a.U + 31) / 32) >= 192) {
         launch_lstm_cfg<2, 2>(a, s, "lstm_step_kernel<2,2>", flops);
