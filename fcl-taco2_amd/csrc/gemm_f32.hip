@@ -29,6 +29,10 @@ constexpr int BK = FCL_BK;      // k-chunk (floats): 32 = one 128-B line per row
 constexpr int F4 = BK / 4;      // float4 per row per chunk
 constexpr int F4_SHIFT = F4 == 8 ? 3 : 2;
 static_assert(BK == 32 || BK == 16, "BK must be 16 or 32");
+#ifndef FCL_NBUF
+#define FCL_NBUF 2
+#endif
+constexpr int NBUF = FCL_NBUF;  // LDS buffers per workgroup: 2 = one barrier per chunk; 1 = half the LDS (more workgroups per CU), two barriers
 constexpr int LDS_LD = BK + 4;  // padded LDS row stride (floats); keeps float4 alignment and spreads rows over banks
 
 // TM = 16-row MFMA tiles per wave along M.  TM = 1: a wave reads 10 operand fragments from LDS per 12 MFMAs (bf16x3) and the kernel is LDS-bound;
@@ -41,7 +45,7 @@ struct Geo {
     static constexpr int NA = (BM * F4 + THREADS - 1) / THREADS;  // float4 loads of A per thread per chunk
     static constexpr int NB = (BN * F4 + THREADS - 1) / THREADS;
     // per row: fp32 path 36 floats (32 + pad); bf16x3 path two bf16 planes of 40 elements (32 + 8 pad) = 40 floats
-    static constexpr int LDS_FLOATS = 2 * (BM + BN) * 40;
+    static constexpr int LDS_FLOATS = NBUF * (BM + BN) * 40;
 };
 
 // ---- bf16x3 operand split (PREC 1): x = hi + lo, hi = bf16_rn(x), lo = bf16_rn(x - hi);  a.b ~= ah.bh + ah.bl + al.bh
@@ -234,9 +238,14 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
             }
         }
         if (!has_next) break;
-        stash(buf ^ 1);
+        if constexpr (NBUF == 1) {
+            __syncthreads();  // every wave is done reading the only buffer
+            stash(0);
+        } else {
+            stash(buf ^ 1);
+            buf ^= 1;
+        }
         __syncthreads();
-        buf ^= 1;
         t = tn;
         k0 = kn;
     }
