@@ -341,6 +341,11 @@ static int tm2_min_wg() {
     return v;
 }
 
+static int half_tile_wg() {
+    static const int v = tunable("GEMM_HALF_TILE_WG", 0);  // measured: 32 x 64 tiles lose (39 vs 47 TFLOP/s) even when 64 x 64 leaves CUs idle; off
+    return v;
+}
+
 static int precision() {
     static const int p = tunable("PRECISION", 1);
     return p;
@@ -459,6 +464,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     static const int tm2 = tunable("GEMM_TM2", 1);    // 64 x 128 workgroup tiles with 32 x 64 per wave where the grid still fills the chip
     if (force == 0 && tm2 && a.N >= 128 && (long long)((a.M + 63) / 64) * ((a.N + 127) / 128) >= tm2_min_wg()) {
         launch_gemm_cfg<2, 2, 2>(a, s, "gemm_kernel<2,2,tm2>", flops);
+    } else if (force == 0 && a.M > 32 && (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) < half_tile_wg()) {
+        launch_gemm_cfg<2, 1>(a, s, "gemm_kernel<2,1>", flops);  // too few 64 x 64 tiles to fill 256 CUs: 32 x 64 tiles, twice the workgroups
     } else if (force == 1 || (force == 0 && a.M > 32)) {
         launch_gemm_cfg<4, 1>(a, s, "gemm_kernel<4,1>", flops);
     } else if (force == 2 || (force == 0 && a.M > 16)) {
