@@ -153,6 +153,36 @@ def test_student_kd_step_eval_form_vs_reference_g8():
     _check_vs_oracle(eng, sd)
 
 
+@pytest.mark.parametrize("share,flags", [(False, (True, True, True, True)), (True, (True, False, True, False)), (False, (False, True, False, True))])
+def test_student_kd_variants_vs_oracle(share, flags):
+    """--share-proj false (one projection per tap) and subsets of the four --distill-*-knowledge flags (..._kd_student.py:778-797): every gradient vs the
+    oracle's autograd, eval form; unused projections keep a zero gradient (the reference leaves their .grad None and Adam skips them)."""
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+    from fcl_taco2_amd.training import TrainEngine
+
+    com = argparse.Namespace(**dict(vars(COM), share_proj=share, distill_output_knowledge=flags[0], distill_encoder_knowledge=flags[1],
+                                    distill_decoder_knowledge=flags[2], distill_prosody_knowledge=flags[3]))
+    m = Student(TINY_S.idim, TINY_S.odim, _ns(TINY_S), com, _ns(TINY_T))
+    m.load_state_dict(torch_state_dict(TINY_S, TINY_T, share))
+    eng = TrainEngine(m.to(DEV))
+    know = _g1_knowledge()
+    batch = _batch()
+    rep = eng.forward_backward(batch, teacher_knowledge=know)
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in torch_state_dict(TINY_S, TINY_T, share).items()}
+    full = O.model_forward(sd, TINY_S, _cpu(batch), "student", TINY_T, share, know)
+    loss = full["l1_loss"] + full["mse_loss"] + full["dur_loss"] + full["pitch_loss"] + full["energy_loss"]
+    for on, keys in zip(flags, (("output_l1_loss", "output_mse_loss"), ("encoder_loss",), ("decoder_loss",), ("prosody_loss",))):
+        for k in keys:
+            if on:
+                loss = loss + full[k]
+                assert abs(rep[k] - float(full[k])) < 5e-4 * max(1.0, abs(float(full[k]))), k
+            else:
+                assert k not in rep
+    loss.backward()
+    assert abs(rep["loss"] - float(loss)) < 5e-4 * max(1.0, abs(float(loss)))
+    _check_vs_oracle(eng, sd)
+
+
 def test_kd_update_train_mode_vs_reference_g9():
     """G9: tts_distill.py:159-161 — frozen teacher left in train mode produces the knowledge on the HIP path, the student takes a train-mode
     forward/backward; every draw of both models injected; teacher's BatchNorm buffers move although it is frozen."""
