@@ -86,7 +86,18 @@ def train_workload(args, rank, world, dev, dist):
     teng = TrainEngine(SYN.build_model("kd_teacher", T, None, dev)) if kd else None
     eng = TrainEngine(SYN.build_model("student", S, T, dev) if kd else SYN.build_model("teacher", T, None, dev), seed=rank)
 
+    from fcl_taco2_amd.training import KDPipeline
+
+    # a second batch object with the same content: the pipeline keys its look-ahead on the batch identity, as a data loader would present it
+    batches = [batch, dict(batch)]
+    pipe = KDPipeline(teng, eng) if (kd and not args.no_overlap) else None
+    counter = [0]
+
     def step():
+        i = counter[0]
+        counter[0] += 1
+        if pipe is not None:  # teacher of step i+1 overlaps the student update of step i
+            return pipe.step(batches[i % 2], batches[(i + 1) % 2])
         know = teng.knowledge(batch, mode="train") if kd else None
         return eng.train_step(batch, know, mode="train")
 
@@ -119,7 +130,9 @@ def train_workload(args, rank, world, dev, dist):
         "config": {"workload": "SURVEY §8d %s: %d utterances/GPU, 60-100 phonemes, durations clip(Poisson(10),1,50) with 3%% zero-duration phonemes, "
                                "%d frames/GPU-batch, train-form BatchNorm / dropout / zoneout (device RNG), Adam lr 1e-3 eps 1e-6, clip 1.0, "
                                "closed-form weights" % ("C3" if kd else "C4", B, frames),
-                   "parallelism": "dp%d: one process per GPU, gradient all-reduce (AVG) in 4 buckets overlapped with backward" % world},
+                   "parallelism": "dp%d: one process per GPU, gradient all-reduce (AVG) in 4 buckets overlapped with backward" % world,
+                   "pipeline": ("frozen teacher one batch ahead on a second HIP stream (steady-state time per update)" if pipe is not None else
+                                "teacher forward and update back to back on one stream")},
         "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                      "note": "algorithmic %.0f MFLOP per frame per step (SURVEY.md §8d) x frames / measured step time (per GPU)" % mflop},
@@ -138,6 +151,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (independent passes on separate HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="kd_step: run teacher forward and student update back to back on one stream")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
     args = ap.parse_args()

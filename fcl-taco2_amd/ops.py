@@ -9,7 +9,15 @@ from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, DROP_MASK, DROP_NONE, DROP_RNG, check  # noqa: F401
 
 
+try:  # raw handle of the current stream without building a torch.cuda.Stream object per call (7 us -> 0.3 us; a training step issues ~1000 ops)
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:  # pragma: no cover - older/newer torch without the private accessors
+    _raw_stream = _cur_device = None
+
+
 def _stream():
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -172,7 +172,7 @@ def train(argv=None):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
-    from .training import TrainEngine
+    from .training import KDPipeline, TrainEngine
 
     train_utts = read_train_manifest(args.train_json)
     valid_utts = read_train_manifest(args.valid_json) if args.valid_json else []
@@ -221,17 +221,24 @@ def train(argv=None):
         n_iter = len(batches) // world  # every rank takes the same number of steps: collectives stay matched
         reps, t0, frames = [], time.time(), 0
         micro = 0
+        pipe = KDPipeline(teng, eng) if (kd and eng.accum_grad == 1) else None  # frozen teacher one batch ahead on a second stream
+        nxt = conv([load_batch(batches[rank], cache)]) if n_iter else None
         for it in range(n_iter):
-            batch = conv([load_batch(batches[it * world + rank], cache)])
-            know = teng.knowledge(batch, mode="train") if kd else None
-            if micro == 0:
-                eng.zero_grad()
-            rep = eng.forward_backward(batch, know, mode="train")
-            micro += 1
-            if micro == eng.accum_grad:  # tts.py:166-171
-                eng.optimizer_step()
-                micro = 0
+            batch = nxt
+            nxt = conv([load_batch(batches[(it + 1) * world + rank], cache)]) if it + 1 < n_iter else None
+            if pipe is not None:
+                rep = pipe.step(batch, nxt)
                 iteration += 1
+            else:
+                know = teng.knowledge(batch, mode="train") if kd else None
+                if micro == 0:
+                    eng.zero_grad()
+                rep = eng.forward_backward(batch, know, mode="train")
+                micro += 1
+                if micro == eng.accum_grad:  # tts.py:166-171
+                    eng.optimizer_step()
+                    micro = 0
+                    iteration += 1
             reps.append(rep)
             frames += int(sum(int(v) for v in batch["olens"]))
             if rank == 0 and args.report_interval_iters and (it + 1) % args.report_interval_iters == 0:

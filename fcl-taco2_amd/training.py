@@ -100,6 +100,77 @@ class _Ctx(object):
     pass
 
 
+class LossReport(dict):
+    """The named losses of a step.  The fp64 loss sums are copied to pinned host memory asynchronously; the dict fills itself on first access, so a
+    training loop that only logs every N steps never stalls the CPU on the GPU (the .cpu() read-back used to cost a full pipeline drain per step)."""
+
+    def __init__(self, sums_dev, names, extra=None):
+        super().__init__()
+        self._names = list(names)
+        self._host = torch.empty((len(names), 3), dtype=torch.float64, pin_memory=True)
+        self._host.copy_(sums_dev[: len(names)], non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._extra = dict(extra or {})
+        self._done = False
+
+    def resolve(self):
+        if self._done:
+            return self
+        self._event.synchronize()
+        host = self._host.numpy()
+        m = {n: (host[i, 0] / host[i, 2], host[i, 1] / host[i, 2]) for i, n in enumerate(self._names)}
+        rep = dict(l1_loss=m["after"][0] + m["before"][0], mse_loss=m["after"][1] + m["before"][1], dur_loss=m["dur"][1], pitch_loss=m["pitch"][1],
+                   energy_loss=m["energy"][1])
+        rep["loss"] = rep["l1_loss"] + rep["mse_loss"] + rep["dur_loss"] + rep["pitch_loss"] + rep["energy_loss"]
+        if "o_after" in m:
+            rep["output_l1_loss"] = m["o_after"][0] + m["o_before"][0]
+            rep["output_mse_loss"] = m["o_after"][1] + m["o_before"][1]
+            rep["loss"] += rep["output_l1_loss"] + rep["output_mse_loss"]
+        for key, pre, n in (("encoder_loss", "enc", 5), ("decoder_loss", "dec", 8), ("prosody_loss", "pro", 5)):
+            if pre + "0" in m:
+                rep[key] = sum(m["%s%d" % (pre, i)][1] for i in range(n))
+                rep["loss"] += rep[key]
+        for k, v in self._extra.items():
+            rep[k] = v() if callable(v) else v
+        self._done = True
+        super().update(rep)
+        return self
+
+    def __getitem__(self, k):
+        return dict.__getitem__(self.resolve(), k)
+
+    def __contains__(self, k):
+        return dict.__contains__(self.resolve(), k)
+
+    def __iter__(self):
+        return dict.__iter__(self.resolve())
+
+    def keys(self):
+        return dict.keys(self.resolve())
+
+    def items(self):
+        return dict.items(self.resolve())
+
+    def values(self):
+        return dict.values(self.resolve())
+
+    def get(self, k, d=None):
+        return dict.get(self.resolve(), k, d)
+
+    def __len__(self):
+        return dict.__len__(self.resolve())
+
+    def __repr__(self):
+        return dict.__repr__(self.resolve())
+
+    def __setitem__(self, k, v):
+        if self._done:
+            dict.__setitem__(self, k, v)
+        else:
+            self._extra[k] = v
+
+
 class TrainEngine(object):
     def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None):
         p0 = next(model.parameters())
@@ -111,7 +182,7 @@ class TrainEngine(object):
         pd = dict(model.named_parameters())
         names, offs, bounds = flat_layout([(k, v.numel()) for k, v in pd.items()])
         total = int(offs[-1])
-        self.pflat = torch.empty(total, device=self.dev)
+        self.pflat = torch.zeros(total, device=self.dev)  # zeros: the 256-byte alignment padding between parameters must stay inert
         self.gflat, self.mflat, self.vflat = (torch.zeros(total, device=self.dev) for _ in range(3))
         self.P, self.G, self._offsets = {}, {}, {}
         for k, o in zip(names, offs[:-1]):
@@ -518,20 +589,7 @@ class TrainEngine(object):
         c.sums, c.loss_names = sums, names
 
     def _report(self, c):
-        host = c.sums[: len(c.loss_names)].cpu().numpy()
-        m = {n: (host[i, 0] / host[i, 2], host[i, 1] / host[i, 2]) for i, n in enumerate(c.loss_names)}
-        rep = dict(l1_loss=m["after"][0] + m["before"][0], mse_loss=m["after"][1] + m["before"][1], dur_loss=m["dur"][1], pitch_loss=m["pitch"][1],
-                   energy_loss=m["energy"][1])
-        rep["loss"] = rep["l1_loss"] + rep["mse_loss"] + rep["dur_loss"] + rep["pitch_loss"] + rep["energy_loss"]
-        if "o_after" in m:
-            rep["output_l1_loss"] = m["o_after"][0] + m["o_before"][0]
-            rep["output_mse_loss"] = m["o_after"][1] + m["o_before"][1]
-            rep["loss"] += rep["output_l1_loss"] + rep["output_mse_loss"]
-        for key, pre, n in (("encoder_loss", "enc", 5), ("decoder_loss", "dec", 8), ("prosody_loss", "pro", 5)):
-            if pre + "0" in m:
-                rep[key] = sum(m["%s%d" % (pre, i)][1] for i in range(n))
-                rep["loss"] += rep[key]
-        return rep
+        return LossReport(c.sums, c.loss_names)
 
     # ------------------------------------------------------------------------------------------------ backward
     def _backward(self, c):
@@ -683,5 +741,44 @@ class TrainEngine(object):
         self.zero_grad()
         rep = self.forward_backward(batch, teacher_knowledge, mode, masks)
         self.optimizer_step()
-        rep["grad_norm"] = self.grad_norm()
+        gn_host = torch.empty(1, dtype=torch.float64, pin_memory=True)  # this step's norm, read back without stalling (gn_sq is reused next step)
+        gn_host.copy_(self.gn_sq, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        rep["grad_norm"] = lambda: (ev.synchronize(), float(np.sqrt(gn_host.numpy()[0])))[1]
         return rep
+
+
+class KDPipeline(object):
+    """The KD update with the frozen teacher one batch ahead on its own HIP stream: teacher(batch i+1) has no dependency on student(batch i)
+    (the teacher is frozen; its BatchNorm buffers still advance in batch order), and neither fills the GPU alone, so the two overlap.  The student's
+    stream waits on an event recorded after the teacher's forward; the knowledge tensors are handed over with record_stream so the caching
+    allocator does not recycle them while the student still reads them.  step() is call-compatible with the sequential pair
+    `know = teacher.knowledge(batch); student.train_step(batch, know)`."""
+
+    def __init__(self, teacher_engine, student_engine, mode="train"):
+        self.teng, self.eng, self.mode = teacher_engine, student_engine, mode
+        self.side = torch.cuda.Stream(device=student_engine.dev)
+        self.pending = None  # (batch id, knowledge, event)
+
+    def _launch_teacher(self, batch):
+        main = torch.cuda.current_stream(self.eng.dev)
+        c = _Ctx()
+        self.teng._maps(c, batch)  # index maps are allocated and uploaded on the main stream (both engines use them), then cached on the batch
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            know = self.teng.knowledge(batch, mode=self.mode)
+            for t in (know[0], know[1], *know[2], *know[3], *know[4]):
+                t.record_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        return id(batch), know, ev
+
+    def step(self, batch, next_batch=None):
+        """One student update on `batch`; `next_batch` (if given) starts its teacher forward now, concurrently with this update."""
+        if self.pending is None or self.pending[0] != id(batch):
+            self.pending = self._launch_teacher(batch)
+        _, know, ev = self.pending
+        self.pending = self._launch_teacher(next_batch) if next_batch is not None else None
+        torch.cuda.current_stream(self.eng.dev).wait_event(ev)
+        return self.eng.train_step(batch, know, mode=self.mode)

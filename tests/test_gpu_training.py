@@ -267,3 +267,32 @@ def test_accum_grad_two_micro_batches_equal_one_scaled_sum():
     e2.forward_backward(batch)
     e2.forward_backward(batch)
     assert max_abs(e1.gflat.cpu(), e2.gflat.cpu()) < 1e-5 * max(1.0, float(e1.gflat.abs().max()))
+
+
+def test_kd_pipeline_equals_sequential_updates():
+    """KDPipeline (teacher one batch ahead on a second stream) takes the updates of the sequential loop: same device seeds, same batches -> the
+    same losses and weights after three steps, up to the summation-order noise of the atomically accumulated gradients (a missing stream
+    dependency or a recycled knowledge buffer would show up as O(1) differences)."""
+    from fcl_taco2_amd.training import KDPipeline, TrainEngine
+
+    b1, b2 = _batch(), _batch()
+
+    def run(pipelined):
+        teng = TrainEngine(_model("kd_teacher", TINY_T7), seed=11)
+        eng = TrainEngine(_model("student", TINY_S7, TINY_T7), seed=5)
+        losses = []
+        seq = [b1, b2, b1]
+        if pipelined:
+            pipe = KDPipeline(teng, eng)
+            for i, b in enumerate(seq):
+                losses.append(pipe.step(b, seq[i + 1] if i + 1 < len(seq) else None)["loss"])
+        else:
+            for b in seq:
+                losses.append(eng.train_step(b, teng.knowledge(b, mode="train"), mode="train")["loss"])
+        torch.cuda.synchronize()
+        return losses, eng.pflat.clone()
+
+    l_seq, w_seq = run(False)
+    l_pipe, w_pipe = run(True)
+    assert l_seq[0] == pytest.approx(l_pipe[0], rel=1e-9) and l_seq == pytest.approx(l_pipe, rel=1e-4)
+    assert max_abs(w_seq.cpu(), w_pipe.cpu()) <= 2 * 1e-3 * 3 and float((w_seq - w_pipe).abs().mean()) < 1e-5  # sign-flip bound / mean, as in the Adam test
