@@ -141,6 +141,10 @@ def load():
         raise FclError(
             "fcl-taco2_amd: %s not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C fcl-taco2_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    # torch first: device memory and streams come from torch, so libfcl_hip.so must bind to the HIP runtime torch has loaded.  Loading the .so
+    # before torch pulls in /opt/rocm's libamdhip64 and torch then finds "no ROCm-capable device" in the same process (seen with build(); smoke()).
+    import torch  # noqa: F401
+
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
