@@ -489,8 +489,8 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
         rc = launch_lstm_wres(a, s, &handled);
         if (handled) return rc;
     }
-    static const int small_m = tunable("LSTM_SMALL_M", 1024);
-    if (a.M <= small_m) return launch_lstm_small(a, s);
+    static const int small_m = tunable("LSTM_SMALL_M", 0);  // 0 = by width: the wave-per-gate small-tile kernel re-streams W per 16-row tile,
+    if (a.M <= (small_m ? small_m : (a.U >= 512 ? 256 : 1024))) return launch_lstm_small(a, s);  // which stops paying earlier at U = 1024 (FCL-taco2-T)
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * 4.0 * a.U * ksum;
