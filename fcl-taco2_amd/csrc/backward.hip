@@ -23,6 +23,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TN_BM = 32;
 constexpr int TN_LD = TN_BM + 4;
 
+// PREC 0: exact fp32 MFMAs.  PREC 1: each lane splits its 8 consecutive m of a fragment into bf16 hi / lo in registers and issues the three bf16 MFMAs
+// of the bf16x3 scheme (one 32-row MFMA step per chunk instead of eight 4-row ones; ~2^-16 relative error per product, fp32 accumulation).
+// The next chunk's global loads are issued before the MFMAs of the current one and only consumed after the next barrier.
+template <int PREC>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                       float* __restrict__ C, int ldc, int M, int N, int K, int shift0,
                                                       const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int rows_per_slice, int ntaps,
@@ -41,39 +45,71 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // loader: chunk = 32 rows x 64 cols per operand = 512 float4; thread handles float4 #tid and #tid+256
-    for (int mc = m_lo; mc < m_hi; mc += TN_BM) {
-        __syncthreads();
+    f32x4 va[2], vb[2];
+    auto fetch = [&](int mc) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int idx = tid + h * 256;
             const int mr = idx >> 4, c4 = (idx & 15) * 4;  // row within chunk, first of 4 columns
             const int m = mc + mr;
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            va[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            vb[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (m < m_hi) {
-                if (n0 + c4 < N) va = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + n0 + c4);  // N % 4 == 0
+                if (n0 + c4 < N) va[h] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + n0 + c4);  // N % 4 == 0
                 const int src = m + shift;
                 bool ok = k0 + c4 < K;
                 if (seg_lo) ok = ok && src >= seg_lo[m] && src < seg_hi[m];
                 else ok = ok && src >= 0 && src < M;
-                if (ok) vb = *reinterpret_cast<const f32x4*>(B + (size_t)src * ldb + k0 + c4);
+                if (ok) vb[h] = *reinterpret_cast<const f32x4*>(B + (size_t)src * ldb + k0 + c4);
             }
+        }
+    };
+    if (m_lo < m_hi) fetch(m_lo);
+    for (int mc = m_lo; mc < m_hi; mc += TN_BM) {
+        __syncthreads();  // every wave is done with the previous chunk
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int idx = tid + h * 256;
+            const int mr = idx >> 4, c4 = (idx & 15) * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                At[(c4 + e) * TN_LD + mr] = va[e];
-                Bt[(c4 + e) * TN_LD + mr] = vb[e];
+                At[(c4 + e) * TN_LD + mr] = va[h][e];
+                Bt[(c4 + e) * TN_LD + mr] = vb[h][e];
             }
         }
         __syncthreads();
+        if (mc + TN_BM < m_hi) fetch(mc + TN_BM);  // in flight under the MFMAs below
+        if constexpr (PREC == 0) {
 #pragma unroll
-        for (int s = 0; s < TN_BM / 16; ++s) {
-            const f32x4 af = *reinterpret_cast<const f32x4*>(At + (wave * 16 + r16) * TN_LD + s * 16 + kq * 4);
-            f32x4 bf[4];
+            for (int s = 0; s < TN_BM / 16; ++s) {
+                const f32x4 af = *reinterpret_cast<const f32x4*>(At + (wave * 16 + r16) * TN_LD + s * 16 + kq * 4);
+                f32x4 bf[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bt + (j * 16 + r16) * TN_LD + s * 16 + kq * 4);
+                for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bt + (j * 16 + r16) * TN_LD + s * 16 + kq * 4);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
+            }
+        } else {
+            static_assert(TN_BM == 32, "one 32-row bf16 MFMA step per chunk");
+            auto frag = [&](const float* base, s16x8& hi, s16x8& lo) {  // 8 consecutive m of one column -> bf16 hi / lo operand registers
+                uint2 h0, l0, h1, l1;
+                split4(*reinterpret_cast<const f32x4*>(base), h0, l0);
+                split4(*reinterpret_cast<const f32x4*>(base + 4), h1, l1);
+                hi = __builtin_bit_cast(s16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                lo = __builtin_bit_cast(s16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            };
+            s16x8 ah, al;
+            frag(At + (wave * 16 + r16) * TN_LD + kq * 8, ah, al);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s16x8 bh, bl;
+                frag(Bt + (j * 16 + r16) * TN_LD + kq * 8, bh, bl);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
+            }
         }
     }
     const int col = lane & 15, rq = lane >> 4;
@@ -89,8 +125,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// out[c] += sum_m f(x[m, c]) ; mode 0: x ; 1: x * y[m, c] ; 2: x * (y[m,c] - b[c]) / g[c]   (BN-fold gamma gradient, xhat = (z - beta)/gamma)
+// ---- bias / BatchNorm-affine gradients: column sums over rows --------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
                                                      const float* __restrict__ b, float* __restrict__ out, int M, int C, int mode, int rows_per_block) {
     __shared__ float part[4][64];
@@ -496,8 +531,11 @@ int fcl_gemm_tn_taps_fwd(const float* a, int lda, const float* b, int ldb, float
     slices = (m + rps - 1) / rps;
     dim3 grid((n + 63) / 64, (k + 63) / 64, slices * ntaps);
     ProfScope ps("gemm_tn_kernel", 2.0 * m * (double)n * k * ntaps, m, (hipStream_t)stream);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift0, seg_lo, seg_hi, rps, ntaps,
-                       (long long)c_tap_stride);
+    static const int prec = tunable("PRECISION", 1);  // as the forward GEMMs: 1 = bf16x3 operands, 0 = exact fp32 MFMA
+    if (prec) hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift0, seg_lo, seg_hi, rps,
+                                 ntaps, (long long)c_tap_stride);
+    else hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift0, seg_lo, seg_hi, rps,
+                            ntaps, (long long)c_tap_stride);
     return check_hip(hipGetLastError(), "gemm_tn_fwd");
 }
 

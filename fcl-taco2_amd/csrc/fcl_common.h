@@ -107,6 +107,23 @@ struct FeatPrenetArgs {
     float* tap_prenet;  // optional [F, P]; row = frame_off[m] + t_cur
 };
 
+// ---- bf16x3 operand split shared by the big-tile GEMMs (gemm_f32.hip) and the weight-gradient GEMM (backward.hip) ------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split4(const f32x4_t v, uint2& hi, uint2& lo) {
+    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t));
+    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
+    const float r0 = v[0] - __builtin_bit_cast(float, h01 << 16), r1 = v[1] - __builtin_bit_cast(float, h01 & 0xFFFF0000u);
+    const float r2 = v[2] - __builtin_bit_cast(float, h23 << 16), r3 = v[3] - __builtin_bit_cast(float, h23 & 0xFFFF0000u);
+    hi = make_uint2(h01, h23);
+    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t)),
+                    __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t)));
+}
+
+
 // ---- persistent BiLSTM training kernels (bilstm.hip) ---------------------------------------------------
 // training forward: what bilstm_bptt_persistent_kernel needs, t-major ([T, B, .]); only live cells are written
 struct BilstmSave {

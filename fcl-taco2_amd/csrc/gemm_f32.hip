@@ -51,20 +51,7 @@ struct Geo {
 // ---- bf16x3 operand split (PREC 1): x = hi + lo, hi = bf16_rn(x), lo = bf16_rn(x - hi);  a.b ~= ah.bh + ah.bl + al.bh
 // with fp32 accumulation on the bf16 MFMA pipe (16x the fp32-MFMA rate, 3 MFMAs per product => 5.3x), error ~2^-16
 // relative per product: 8.6e-6 max-abs on the mel end to end in emulation, 100x inside the 1e-3 parity bar.
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int LDK = BK + 8;  // bf16 elements per LDS plane row: 80 B stride -> conflict-free b128 fragment reads
-
-__device__ __forceinline__ void split4(const f32x4 v, uint2& hi, uint2& lo) {
-    const unsigned h01 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t));
-    const unsigned h23 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
-    const float r0 = v[0] - __builtin_bit_cast(float, h01 << 16), r1 = v[1] - __builtin_bit_cast(float, h01 & 0xFFFF0000u);
-    const float r2 = v[2] - __builtin_bit_cast(float, h23 << 16), r3 = v[3] - __builtin_bit_cast(float, h23 & 0xFFFF0000u);
-    hi = make_uint2(h01, h23);
-    lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r0, r1}, bf16x2_t)),
-                    __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){r2, r3}, bf16x2_t)));
-}
 
 // Shared main loop.  n0: first output column (generic) or first hidden unit (LSTM).  NU: N (generic) or U.
 template <int WM, int WN, bool LSTM, int PREC = 0, int TM = 1>

@@ -25,6 +25,13 @@ def dev(a):
     return t.to(DEV).contiguous()
 
 
+def close(a, ref, atol=2e-4, rtol=3e-5):
+    """max-abs within atol + rtol * max|ref|: the weight-gradient GEMM runs bf16x3-split operands by default (2^-16 relative per product,
+    fp32 accumulation; exact fp32 MFMA under FCL_PRECISION=0), so sums over hundreds of O(1) products are compared relative to their size."""
+    ref_t = ref.detach().cpu() if hasattr(ref, "detach") else torch.as_tensor(ref)
+    return max_abs(a, ref_t) < atol + rtol * float(ref_t.abs().max())
+
+
 def rnd(rng, *shape):
     return rng.standard_normal(shape).astype(np.float32)
 
@@ -58,7 +65,7 @@ def test_conv1d_backward_vs_autograd(ops, cin, cout, ksz):
     dwp = torch.zeros(ksz, cout, cin, device=DEV)
     for j in range(ksz):
         ops.gemm_tn(dev(dy), dev(x.detach()), dwp[j], shift=j - pad, seg_lo=dev(lo), seg_hi=dev(hi))
-    assert max_abs(dwp.cpu().permute(1, 2, 0), w.grad) < 2e-4
+    assert close(dwp.cpu().permute(1, 2, 0), w.grad)
     # dX: y[m] = sum_j x[m + j - pad] W_j  =>  dx[m] = sum_j dy[m - (j - pad)] W_j^T : a conv of dy with taps reversed, weights transposed
     wp = ops.pack_conv1d_weight(dev(w.detach()))  # [k, Cout, Cin]
     wt = torch.stack([ops.transpose2d(wp[ksz - 1 - j]) for j in range(ksz)])  # [k, Cin, Cout], tap order reversed
@@ -225,10 +232,10 @@ def test_bilstm_train_forward_and_bptt_vs_torch_lstm(ops, H, lens):
         dg2 = dgs[d].reshape(T * B, 4 * H)
         g_hh = torch.zeros(4 * H, H, device=DEV)
         ops.gemm_tn(dg2, sv[d][3].reshape(T * B, H), g_hh)
-        assert max_abs(g_hh.cpu(), dict(lstm.named_parameters())["weight_hh_l0" + s].grad) < 2e-4, s
+        assert close(g_hh.cpu(), dict(lstm.named_parameters())["weight_hh_l0" + s].grad), s
         dgx = ops.gather_rows(dg2, perm)
         g_ih = torch.zeros(4 * H, C, device=DEV)
         ops.gemm_tn(dgx, xd, g_ih)
-        assert max_abs(g_ih.cpu(), dict(lstm.named_parameters())["weight_ih_l0" + s].grad) < 2e-4, s
+        assert close(g_ih.cpu(), dict(lstm.named_parameters())["weight_ih_l0" + s].grad), s
         ops.add2d(dx, ops.linear(dgx, ops.transpose2d(dev(sd["weight_ih_l0" + s]))))
     assert max_abs(dx.cpu().reshape(B, T, C), x.grad) < 2e-4 * max(1.0, float(x.grad.abs().max()))
