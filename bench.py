@@ -125,7 +125,7 @@ def train_workload(args, rank, world, dev, dist):
     return {
         "metric": "%s time (ms) (%s, batch=%d/GPU, 80-mel)" % (name, "FCL-taco2-T frozen teacher fwd + FCL-taco2-S fwd/bwd/Adam" if kd else "FCL-taco2-T fwd/bwd/Adam", B),
         "value": ms, "unit": "ms/step", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (forward GEMMs bf16x3-split MFMA operands, fp32 accumulate; gradients exact fp32 MFMA)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (GEMMs on bf16x3-split MFMA operands, fp32 accumulate; FCL_PRECISION=0 = exact fp32 MFMA)", "data": "synthetic",
         "frames_per_s": frames_all * steps / dt, "loss": rep["loss"], "grad_norm": rep["grad_norm"],
         "config": {"workload": "SURVEY §8d %s: %d utterances/GPU, 60-100 phonemes, durations clip(Poisson(10),1,50) with 3%% zero-duration phonemes, "
                                "%d frames/GPU-batch, train-form BatchNorm / dropout / zoneout (device RNG), Adam lr 1e-3 eps 1e-6, clip 1.0, "

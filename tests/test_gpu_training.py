@@ -2,7 +2,7 @@
   * the REAL reference's losses / gradients / grad-norm / BatchNorm buffers pinned in tests/golden/g5 (teacher, eval form), g7 (teacher, train
     form with every dropout / zoneout draw injected), g8 (student KD, eval form) and g9 (the full KD update in train form), and
   * the oracle's autograd for EVERY parameter (oracle/fcl_oracle.py restates the reference's forward in differentiable torch-CPU).
-Forward GEMMs run in the default bf16x3 mode (or exact fp32 under FCL_PRECISION=0); gradient kernels are exact fp32."""
+All GEMMs (forward, input- and weight-gradient) run in the default bf16x3 mode, or exact fp32 MFMA under FCL_PRECISION=0; both pass."""
 import argparse
 import os
 import sys
