@@ -56,14 +56,17 @@ def group_of(name):
 
 class GradBuckets(object):
     """Bucketed gradient averaging over torch.distributed (RCCL on GPUs, gloo in the CPU tests).  launch(i) may be called as soon as bucket i
-    is final; the collective runs on the backend's own stream while the caller keeps producing the later buckets; finish() waits for all."""
+    is final; the collective runs on the backend's own stream while the caller keeps producing the later buckets; finish() waits for all.
+    gloo + device tensors (the 2-processes-on-one-GPU test): buckets are staged through host memory in finish(), without overlap."""
 
     def __init__(self, flat, bounds, group=None):
         import torch.distributed as dist
 
-        self.flat, self.bounds, self.group, self.work = flat, bounds, group, []
+        self.flat, self.bounds, self.group, self.work, self.staged = flat, bounds, group, [], []
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        self.avg = self.world > 1 and dist.get_backend(group) == "nccl"
+        backend = dist.get_backend(group) if self.world > 1 else None
+        self.avg = backend == "nccl"
+        self.stage_host = backend == "gloo" and flat.is_cuda
 
     def launch(self, i):
         if self.world == 1:
@@ -71,11 +74,22 @@ class GradBuckets(object):
         import torch.distributed as dist
 
         a, b = self.bounds[i], self.bounds[i + 1]
-        if b > a:
-            op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
-            self.work.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
+        if b <= a:
+            return
+        if self.stage_host:
+            self.staged.append((a, b))
+            return
+        op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
+        self.work.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
 
     def finish(self, scale_fn=None):
+        import torch.distributed as dist
+
+        for a, b in self.staged:
+            host = self.flat[a:b].cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat[a:b].copy_(host)
+        self.staged = []
         for w in self.work:
             w.wait()
         self.work = []
