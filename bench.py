@@ -40,14 +40,19 @@ def pmc_traffic(kernel):
     import glob
 
     def norm(n):
-        n = n.replace(" ", "").replace("fcl::", "").replace("void", "")
+        """(base name, template args or None): bench labels are "gemm_kernel<2,2,1,2>/bf16x3" or "feat_prenet_kernel/bf16x3", rocprofv3 rows
+        "fcl::gemm_kernel<2, 2, 1, 2>" or "fcl::feat_prenet_x3_kernel<8, 3, 8>"."""
+        n = n.split("(")[0].replace(" ", "").replace("fcl::", "").replace("void", "")
         x3 = n.endswith("/bf16x3")
         n = n[: -len("/bf16x3")] if x3 else n
-        if "<" in n and n.count(",") < (3 if n.startswith("lstm_step") else 2):  # bench label -> rocprof's instantiation (+ PREC)
-            n = n.rstrip(">") + (",1>" if x3 else ",0>")
-        elif x3 and "<" not in n:
-            n = n.replace("_kernel", "_x3_kernel")
-        return n
+        base, _, targs = n.partition("<")
+        if x3 and not targs and "_x3_" not in base:
+            base = base.replace("_kernel", "_x3_kernel")
+        return base, (targs.rstrip(">") or None)
+
+    def same(a, b):
+        (ba, ta), (bb, tb) = norm(a), norm(b)
+        return ba == bb and (ta is None or tb is None or ta == tb)
 
     vals = {}
     for tag in ("fetch", "write"):
@@ -57,7 +62,7 @@ def pmc_traffic(kernel):
         with open(files[-1]) as f:
             rows = list(csv.reader(f))
         for r in rows[2:]:
-            if len(r) >= 3 and norm(r[0]) == norm(kernel):
+            if len(r) >= 3 and same(r[0], kernel):
                 vals[tag] = (float(r[2]), os.path.basename(files[-1]))
     if len(vals) != 2:
         return None, None

@@ -386,8 +386,9 @@ template <int WM, int WN, int TM = 1>
 static void launch_gemm_cfg(const GemmArgs& a, hipStream_t s, const char* name, double flops) {
     using G = Geo<WM, WN, false, TM>;
     dim3 grid((a.N + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
-    char full[64];
-    snprintf(full, sizeof(full), "%s%s", name, precision() ? "/bf16x3" : "");
+    char full[64];  // the rocprofv3 instantiation name <WM, WN, PREC, TM>, so HIP-event and rocprof / PMC rows can be joined by name
+    snprintf(full, sizeof(full), "gemm_kernel<%d,%d,%d,%d>%s", WM, WN, precision() ? 1 : 0, TM, precision() ? "/bf16x3" : "");
+    (void)name;
     ProfScope ps(full, flops, a.M, s);
     if (precision()) hipLaunchKernelGGL((gemm_kernel<WM, WN, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<WM, WN, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
@@ -399,8 +400,9 @@ static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* na
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     const bool plain = !a.zone_keep_h && !a.row_len;
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
-    char full[64];
-    snprintf(full, sizeof(full), "%.*s,%d>%s", (int)strlen(name) - 1, name, mode, precision() ? "/bf16x3" : "");  // "...<4,1>" -> "...<4,1,0>"
+    char full[64];  // <WM, WN, MODE, PREC, TM> as rocprofv3 prints the instantiation
+    snprintf(full, sizeof(full), "lstm_step_kernel<%d,%d,%d,%d,%d>%s", WM, WN, mode, precision() ? 1 : 0, TM, precision() ? "/bf16x3" : "");
+    (void)name;
     ProfScope ps(full, flops, a.M, s);
     if (precision()) {
         if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
