@@ -413,3 +413,32 @@ def test_full_size_kd_step_properties():
     eng.optimizer_step()
     assert 0 < float((eng.pflat - w_before).abs().max()) <= 1e-5 + 2e-7  # + half an ulp of the largest weights
     assert np.isfinite(before)
+
+
+@pytest.mark.parametrize("case", ["single_phoneme", "ragged_with_zeros", "long_durations"])
+def test_training_step_edge_shapes_vs_oracle(case):
+    """Edge shapes of the training batch: one utterance of one phoneme; ragged lengths with zero-duration phonemes (dropped rows) next to
+    1-frame phonemes; durations far beyond the manifest filter's 50 (the kernels accept any Lmax).  Every gradient vs the oracle's autograd."""
+    from fcl_taco2_amd.converter import CustomConverter
+    from fcl_taco2_amd.training import TrainEngine
+
+    rng = np.random.RandomState(len(case))
+    if case == "single_phoneme":
+        durs = [[3]]
+    elif case == "ragged_with_zeros":
+        durs = [[2, 0, 1, 4, 0, 1], [1, 1, 0, 2], [5]]
+    else:
+        durs = [[70, 1, 33], [2, 64]]
+    xs = [rng.randint(1, TINY_T.idim, size=len(d)).astype(np.int64) for d in durs]
+    ds = [np.asarray(d, np.float32).reshape(-1, 1) for d in durs]
+    ys = [rng.randn(int(sum(d)), TINY_T.odim).astype(np.float32) for d in durs]
+    f0 = [rng.randn(len(d), 1).astype(np.float32) for d in durs]
+    en = [rng.randn(len(d), 1).astype(np.float32) for d in durs]
+    batch = CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)])
+    eng = TrainEngine(_model("teacher", TINY_T))
+    rep = eng.forward_backward(batch)
+    sd = _grad_sd(TINY_T)
+    orep = O.model_forward(sd, TINY_T, _cpu(batch), "teacher")
+    orep["loss"].backward()
+    assert abs(rep["loss"] - float(orep["loss"])) < 5e-4 * max(1.0, abs(float(orep["loss"])))
+    _check_vs_oracle(eng, sd)
