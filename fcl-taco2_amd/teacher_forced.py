@@ -8,7 +8,7 @@ off, zoneout takes its expectation form (decoder_sa.py:96), the prenet's dropout
   student     nets/knowledge_distillation/e2e_tts_tacotron2_sa_kd_student.py:673-802 -> named losses incl. the KD terms
 Batched `forward()` keeps the reference's padding semantics: convolutions run over the zero-padded [B, Tmax] /
 [B, Lmax] rows WITHOUT masking between layers (the padding leak of SURVEY.md §7), unlike the synthesis path.
-Training-mode forward (batch-statistics BN, dropout everywhere) and backward are not on the HIP path yet.
+The train-mode forward (batch-statistics BN, dropout everywhere, sampled zoneout) and the backward pass live in training.py (TrainEngine).
 """
 import numpy as np
 import torch
