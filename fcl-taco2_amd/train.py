@@ -161,6 +161,8 @@ def train(argv=None):
     args = parser.parse_args(argv)
     if args.weight_decay != 0.0:
         raise NotImplementedError("fcl-taco2_amd: weight decay is 0 in every shipped recipe and is not implemented on the HIP path")
+    torch.manual_seed(args.seed)  # before any module is built: initial weights depend on --seed only (set_deterministic_pytorch, tts.py:321)
+    np.random.seed(args.seed)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev = "cuda:%d" % local_rank
@@ -203,7 +205,6 @@ def train(argv=None):
     else:
         teng = None
         model = cls(idim, odim, args, args)
-    torch.manual_seed(args.seed)
     model = model.to(dev)
     eng = TrainEngine(model, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip, accum_grad=args.accum_grad, seed=args.seed * 1000 + rank)
     epoch0, iteration = 0, 0
