@@ -127,7 +127,52 @@ def train_workload(args, rank, world, dev, dist):
     mflop = 61.0 if kd else 127.0
     achieved = mflop * 1e6 * frames / (dt / steps) / 1e12
     name = "KD step" if kd else "teacher training step"
-    return {
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # ---- CPU baseline ("port"): the same update through the oracle's differentiable restatement + torch autograd + torch.optim.Adam on a bounded
+        # sample (the first 2 utterances of the batch; the reference's own 32-utterance CPU step took ~38 s in the survey container)
+        from oracle import fcl_oracle as O
+
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(avail, args.cpu_threads)))
+        n = 2
+        sb = O.convert_batch(xs[:n], ys[:n], ds[:n], f0[:n], en[:n])
+        sframes = int(sum(y.shape[0] for y in ys[:n]))
+        f = lambda spec: {k: torch.from_numpy(np.asarray(v)) for k, v in SYN.closed_form_state_dict(spec).items()}
+        if kd:
+            tsd = f(HP.param_spec(T))
+            ssd = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in f(HP.param_spec(S, T, True)).items()}
+        else:
+            ssd = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in f(HP.param_spec(T)).items()}
+        params = [v for v in ssd.values() if v.dtype.is_floating_point and v.requires_grad]
+        opt = torch.optim.Adam(params, lr=1e-3, eps=1e-6)
+
+        def cpu_step():
+            opt.zero_grad()
+            if kd:
+                with torch.no_grad():
+                    know = O.model_forward(tsd, T, sb, "kd_teacher", bn_train=True)
+                out = O.model_forward(ssd, S, sb, "student", T, True, know, bn_train=True)
+            else:
+                out = O.model_forward(ssd, T, sb, "teacher", bn_train=True)
+            out["loss"].backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+
+        cpu_step()
+        t1, reps = time.perf_counter(), 0
+        while time.perf_counter() - t1 < args.cpu_seconds and reps < 20:
+            cpu_step()
+            reps += 1
+        cdt = (time.perf_counter() - t1) / max(reps, 1)
+        cpu = {"value": 1e3 * cdt * frames / sframes, "unit": "ms/step (scaled to the full batch by frames)", "cores": torch.get_num_threads(), "kind": "port",
+               "frames_per_s": sframes / cdt,
+               "sample": "%d updates on the first %d utterances (%d frames) of the batch through oracle/fcl_oracle.py + torch autograd + torch.optim.Adam "
+                         "(torch %s CPU fp32, batch-statistics BatchNorm, dropout off), %.2f s each" % (reps, n, sframes, torch.__version__, cdt)}
+    out = {
         "metric": "%s time (ms) (%s, batch=%d/GPU, 80-mel)" % (name, "FCL-taco2-T frozen teacher fwd + FCL-taco2-S fwd/bwd/Adam" if kd else "FCL-taco2-T fwd/bwd/Adam", B),
         "value": ms, "unit": "ms/step", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32 (GEMMs on bf16x3-split MFMA operands, fp32 accumulate; FCL_PRECISION=0 = exact fp32 MFMA)", "data": "synthetic",
@@ -142,6 +187,9 @@ def train_workload(args, rank, world, dev, dist):
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                      "note": "algorithmic %.0f MFLOP per frame per step (SURVEY.md §8d) x frames / measured step time (per GPU)" % mflop},
     }
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
 
 
 def main():
