@@ -4,7 +4,6 @@ One process per GPU; every rank holds a full replica of the weights and synthesi
 (decoder rows are independent phonemes, the postnet couples frames only inside one utterance).  The only
 exchanges are the timing/bookkeeping reductions below, which work on any torch.distributed backend
 (RCCL on the GPU box, gloo in the CPU tests)."""
-import numpy as np
 
 
 def shard_utterances(frame_counts, world_size):

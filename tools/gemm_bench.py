@@ -1,14 +1,12 @@
 """Micro-benchmark of the fp32-MFMA GEMM / LSTM-step kernels (developer tool; run on the GPU box)."""
 import os
 import sys
-import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fcl_taco2_amd  # noqa
-from fcl_taco2_amd import _lib, ops
+from fcl_taco2_amd import ops
 
 
 def bench(fn, n=20):

@@ -4,7 +4,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import fcl_taco2_amd  # noqa
-from fcl_taco2_amd import engine, hparams as HP, ops, synthetic as SYN
+from fcl_taco2_amd import engine, hparams as HP, synthetic as SYN
 from fcl_taco2_amd.plan import SynthesisPlan
 
 hp = HP.student_hparams()
