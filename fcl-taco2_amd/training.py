@@ -186,7 +186,7 @@ class LossReport(dict):
 
 
 class TrainEngine(object):
-    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None):
+    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None, overlap_dw=True):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("fcl-taco2_amd: TrainEngine needs the model on a GPU (no CPU fallback)")
@@ -212,6 +212,32 @@ class TrainEngine(object):
         self.lr, self.eps, self.betas, self.grad_clip, self.accum_grad = lr, eps, betas, grad_clip, int(accum_grad)
         self.step_count, self.forward_count, self.seed = 0, 0, int(seed)
         self.gn_sq = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        # weight gradients are off the critical path of backward (only the input-gradient chain is sequential): they are enqueued on a side
+        # stream and joined at the end of backward / before a bucket's all-reduce
+        self.overlap_dw = overlap_dw
+        self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
+        self._dw_keep = []
+
+    def _dw(self, fn):
+        """Run a weight-gradient closure on the side stream, after everything enqueued on the main stream so far.  The closure (and through it
+        every tensor it reads) is kept alive until the streams are joined."""
+        if self.side is None:
+            fn()
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.side):
+            fn()
+        self._dw_keep.append(fn)
+
+    def _join_dw(self):
+        if self.side is not None and self._dw_keep:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self._dw_keep.clear()  # main-stream reuse of these buffers is ordered after the join
+
+    def _launch_bucket(self, i):
+        if self.buckets.world > 1:
+            self._join_dw()
+        self.buckets.launch(i)
 
     def param_offsets(self):
         """{parameter name: (offset, numel, shape)} into pflat / gflat / mflat / vflat (checkpoint writers)."""
@@ -270,12 +296,17 @@ class TrainEngine(object):
             dz = ops.bn_bwd(dz, cc["z"], cc["mean"], cc["invstd"], P[pre + ".1.weight"], dbeta, dgamma)
             scale = None
         else:
-            ops.colsum(dz, G[pre + ".1.bias"])
-            ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
             scale = cc["scale"]
-        dwp = torch.zeros(k, cout, cin, device=self.dev)
-        ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
-        ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
+
+        def dw(dz=dz, scale=scale, eval_affine=not c.train):
+            if eval_affine:
+                ops.colsum(dz, G[pre + ".1.bias"])
+                ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
+            dwp = torch.zeros(k, cout, cin, device=self.dev)
+            ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
+            ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
+
+        self._dw(dw)
         return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
     def _conv_bias_relu_fwd(self, x, prefix, lo, hi):
@@ -287,11 +318,15 @@ class TrainEngine(object):
         G = self.G
         pre = cc["prefix"]
         dz = ops.act_bwd(dy, cc["y"], ops.ACT_RELU)
-        ops.colsum(dz, G[pre + ".bias"])
         cout, cin, k = self.P[pre + ".weight"].shape
-        dwp = torch.zeros(k, cout, cin, device=self.dev)
-        ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
-        ops.unpack_conv1d_grad(dwp, G[pre + ".weight"])
+
+        def dw():
+            ops.colsum(dz, G[pre + ".bias"])
+            dwp = torch.zeros(k, cout, cin, device=self.dev)
+            ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
+            ops.unpack_conv1d_grad(dwp, G[pre + ".weight"])
+
+        self._dw(dw)
         return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
     def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad):
@@ -352,13 +387,17 @@ class TrainEngine(object):
         ops.bilstm_bptt(c["dirs"], c["lens"], B, T, d_out, [self._wt(P["enc.blstm.weight_hh_l0" + sfx]) for sfx in sfxs], dgs)
         for d, sfx in enumerate(sfxs):
             dg2 = dgs[d].reshape(T * B, 4 * H)
-            ops.gemm_tn(dg2, c["dirs"][d][3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
             dgx = ops.gather_rows(dg2, perm)  # back to (b, t) rows like x
-            ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
-            db = torch.zeros(1, 4 * H, device=dev)
-            ops.colsum(dgx, db.reshape(-1))
-            ops.add2d(G["enc.blstm.bias_ih_l0" + sfx].reshape(1, -1), db)
-            ops.add2d(G["enc.blstm.bias_hh_l0" + sfx].reshape(1, -1), db)
+
+            def dw(dg2=dg2, dgx=dgx, d=d, sfx=sfx):
+                ops.gemm_tn(dg2, c["dirs"][d][3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
+                ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
+                db = torch.zeros(1, 4 * H, device=dev)
+                ops.colsum(dgx, db.reshape(-1))
+                ops.add2d(G["enc.blstm.bias_ih_l0" + sfx].reshape(1, -1), db)
+                ops.add2d(G["enc.blstm.bias_hh_l0" + sfx].reshape(1, -1), db)
+
+            self._dw(dw)
             ops.add2d(dx, ops.linear(dgx, self._wt(P["enc.blstm.weight_ih_l0" + sfx])))
         return dx
 
@@ -574,7 +613,7 @@ class TrainEngine(object):
                 w = P[proj + ".weight"]
                 s = ops.linear(s_in, w)
                 ds_ = term(name, s, t, valid, nvalid * s.shape[1], 0.0, 1.0)
-                ops.gemm_tn(ds_, s_in, G[proj + ".weight"])
+                self._dw(lambda: ops.gemm_tn(ds_, s_in, G[proj + ".weight"]))
                 return ops.linear(ds_, self._wt(w))
 
             if self.distill[0]:
@@ -620,53 +659,54 @@ class TrainEngine(object):
                 ops.add2d(dx, inj["post%d" % i])
             dx = self._conv_bn_bwd(c, dx, c.post_c[i])
         ops.add2d(d_before, dx)
-        self.buckets.launch(0)
+        self._launch_bucket(0)
         # ---- decoder BPTT
         d_out_cells = ops.gather_rows(d_before, c.cell_frame)  # [F, O]
         g_wf = G["dec.feat_out.weight"]
-        ops.gemm_tn(d_out_cells, c.h1_all, g_wf[:, :U])  # column blocks of the [odim, U + C] gradient are written in place
+        self._dw(lambda: ops.gemm_tn(d_out_cells, c.h1_all, g_wf[:, :U]))  # column blocks of the [odim, U + C] gradient are written in place
         dh1_all = ops.linear(d_out_cells, self._wt(c.wf_h))  # [F, U]
         if "h1" in inj:
             ops.add2d(dh1_all, inj["h1"])
         dF0 = torch.zeros(N, hp.odim, device=dev)
         ops.scatter_add_rows(d_out_cells, c.cell_row_i64, dF0)
-        ops.gemm_tn(dF0, c.att_c, g_wf[:, U:])
+        self._dw(lambda: ops.gemm_tn(dF0, c.att_c, g_wf[:, U:]))
         d_att_c = ops.linear(dF0, self._wt(c.wf_att))
         dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
         ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh),
                          dg0_all, dg1_all)
         dp1_all = ops.linear(dg0_all, self._wt(c.w0_pre))  # [F, P]: gradient w.r.t. the prenet output of every cell
         S0, S1 = c.S0, c.S1
-        # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
-        ops.gemm_tn(dg1_all, c.h0_all, G["dec.lstm.1.cell.weight_ih"])
-        ops.gemm_tn(dg1_all, S1[3], G["dec.lstm.1.cell.weight_hh"])
-        for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
-            db = torch.zeros(1, 4 * U, device=dev)
-            ops.colsum(dg, db.reshape(-1))
-            ops.add2d(G["dec.lstm.%d.cell.bias_ih" % l].reshape(1, -1), db)
-            ops.add2d(G["dec.lstm.%d.cell.bias_hh" % l].reshape(1, -1), db)
-        ops.gemm_tn(dg0_all, S0[3], G["dec.lstm.0.cell.weight_hh"])
         g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
-        ops.gemm_tn(dg0_all, c.p1d, g_ih0[:, C : C + Pn])
-        dw0_pos4 = torch.zeros(4 * U, 4, device=dev)
-        ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
-        ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
+
+        def dw_cells():  # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
+            ops.gemm_tn(dg1_all, c.h0_all, G["dec.lstm.1.cell.weight_ih"])
+            ops.gemm_tn(dg1_all, S1[3], G["dec.lstm.1.cell.weight_hh"])
+            for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
+                db = torch.zeros(1, 4 * U, device=dev)
+                ops.colsum(dg, db.reshape(-1))
+                ops.add2d(G["dec.lstm.%d.cell.bias_ih" % l].reshape(1, -1), db)
+                ops.add2d(G["dec.lstm.%d.cell.bias_hh" % l].reshape(1, -1), db)
+            ops.gemm_tn(dg0_all, S0[3], G["dec.lstm.0.cell.weight_hh"])
+            ops.gemm_tn(dg0_all, c.p1d, g_ih0[:, C : C + Pn])
+            dw0_pos4 = torch.zeros(4 * U, 4, device=dev)
+            ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
+            ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
+
+        self._dw(dw_cells)
         dG0 = torch.zeros(N, 4 * U, device=dev)
         ops.scatter_add_rows(dg0_all, c.cell_row_i64, dG0)
-        ops.gemm_tn(dG0, c.att_c, g_ih0[:, :C])
+        self._dw(lambda: ops.gemm_tn(dG0, c.att_c, g_ih0[:, :C]))
         ops.add2d(d_att_c, ops.linear(dG0, self._wt(c.w0_att)))
         # prenet (batched over all cells)
         w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
         if "p1d" in inj:
             ops.add2d(dp1_all, inj["p1d"])
         dz1 = ops.act_bwd(dp1_all, c.p1, ops.ACT_RELU, c.k1, c.pks)
-        ops.gemm_tn(dz1, c.p0d, G[w1n])
-        ops.colsum(dz1, G[b1n])
+        self._dw(lambda: (ops.gemm_tn(dz1, c.p0d, G[w1n]), ops.colsum(dz1, G[b1n])))
         dp0 = ops.linear(dz1, self._wt(P[w1n]))
         dz0 = ops.act_bwd(dp0, c.p0, ops.ACT_RELU, c.k0, c.pks)
-        ops.gemm_tn(dz0, c.pre_in, G[w0n])
-        ops.colsum(dz0, G[b0n])
-        self.buckets.launch(1)
+        self._dw(lambda: (ops.gemm_tn(dz0, c.pre_in, G[w0n]), ops.colsum(dz0, G[b0n])))
+        self._launch_bucket(1)
         # ---- att = hs + p_embs + e_embs
         d_att = ops.gather_rows(d_att_c, c.row_of_enc)  # back to (b, t) rows; rows without a phoneme get 0
         d_hs = d_att.clone()
@@ -677,19 +717,22 @@ class TrainEngine(object):
                 d_e = ops.add2d(d_att.clone(), inj[tap])
             if keep is not None:
                 d_e = ops.act_bwd(d_e, None, ops.ACT_NONE, keep, c.emb_ks)
-            ops.colsum(d_e, G[nm + "_embed.0.bias"])
-            sig4 = torch.zeros(B * T, 4, device=dev)
-            ops.copy2d(sig4[:, :1], sig.reshape(-1, 1))
-            gw = G[nm + "_embed.0.weight"].reshape(C, kk)
-            for j in range(kk):
-                tmp = torch.zeros(C, 4, device=dev)
-                ops.gemm_tn(d_e, sig4, tmp, shift=j - (kk - 1) // 2, seg_lo=c.e_lo, seg_hi=c.e_hi)
-                ops.add2d(gw[:, j : j + 1], tmp[:, :1])
+            def dw_embed(nm=nm, sig=sig, d_e=d_e):
+                ops.colsum(d_e, G[nm + "_embed.0.bias"])
+                sig4 = torch.zeros(B * T, 4, device=dev)
+                ops.copy2d(sig4[:, :1], sig.reshape(-1, 1))
+                gw = G[nm + "_embed.0.weight"].reshape(C, kk)
+                for j in range(kk):
+                    tmp = torch.zeros(C, 4, device=dev)
+                    ops.gemm_tn(d_e, sig4, tmp, shift=j - (kk - 1) // 2, seg_lo=c.e_lo, seg_hi=c.e_hi)
+                    ops.add2d(gw[:, j : j + 1], tmp[:, :1])
+
+            self._dw(dw_embed)
         # ---- predictors
         ops.add2d(d_hs, self._predictor_bwd(inj["d_outs"].reshape(-1), "duration_predictor", c.dur_c, c.enc_pad))
         ops.add2d(d_hs, self._predictor_bwd(inj["p_outs"].reshape(-1), "pitch_predictor", c.pit_c, c.enc_pad))
         ops.add2d(d_hs, self._predictor_bwd(inj["e_outs"].reshape(-1), "energy_predictor", c.en_c, c.enc_pad))
-        self.buckets.launch(2)
+        self._launch_bucket(2)
         # ---- encoder
         if "hs" in inj:
             ops.add2d(d_hs, inj["hs"])
@@ -701,8 +744,9 @@ class TrainEngine(object):
             dx = self._conv_bn_bwd(c, dx, c.conv_c[i])
         if "enc0" in inj:
             ops.add2d(dx, inj["enc0"])
-        ops.scatter_add_rows(dx, c.xs, G["enc.embed.weight"], skip=0)  # padding_idx = 0 gets no gradient
-        self.buckets.launch(3)
+        self._dw(lambda: ops.scatter_add_rows(dx, c.xs, G["enc.embed.weight"], skip=0))  # padding_idx = 0 gets no gradient
+        self._join_dw()
+        self._launch_bucket(3)
 
     # ------------------------------------------------------------------------------------------------ public API
     def zero_grad(self):
