@@ -76,6 +76,14 @@ def load_batch(batch, cache=None):
     return xs, ys, None, ds, f0, en
 
 
+def to_device(batch, dev):
+    """Hand the float / id tensors of a converted batch to the GPU through pinned memory without blocking the host (the integer layout tensors stay
+    on the host: the engine builds its index maps from them).  Inputs are then resident when the step's kernels reach them."""
+    for k in ("xs", "ys", "extras", "f0", "energy"):
+        batch[k] = batch[k].pin_memory().to(dev, non_blocking=True)
+    return batch
+
+
 # ---- checkpoints -----------------------------------------------------------------------------------------------------------------------
 def adam_state_dict(engine):
     """The engine's flat Adam moments in torch.optim.Adam.state_dict() layout (parameters in model.parameters() order)."""
@@ -223,10 +231,10 @@ def train(argv=None):
         reps, t0, frames = [], time.time(), 0
         micro = 0
         pipe = KDPipeline(teng, eng) if (kd and eng.accum_grad == 1) else None  # frozen teacher one batch ahead on a second stream
-        nxt = conv([load_batch(batches[rank], cache)]) if n_iter else None
+        nxt = to_device(conv([load_batch(batches[rank], cache)]), dev) if n_iter else None
         for it in range(n_iter):
             batch = nxt
-            nxt = conv([load_batch(batches[(it + 1) * world + rank], cache)]) if it + 1 < n_iter else None
+            nxt = to_device(conv([load_batch(batches[(it + 1) * world + rank], cache)]), dev) if it + 1 < n_iter else None
             if pipe is not None:
                 rep = pipe.step(batch, nxt)
                 iteration += 1
