@@ -23,16 +23,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TN_BM = 32;
 constexpr int TN_LD = TN_BM + 4;
 
-// PREC 0: exact fp32 MFMAs.  PREC 1: each lane splits its 8 consecutive m of a fragment into bf16 hi / lo in registers and issues the three bf16 MFMAs
-// of the bf16x3 scheme (one 32-row MFMA step per chunk instead of eight 4-row ones; ~2^-16 relative error per product, fp32 accumulation).
-// The next chunk's global loads are issued before the MFMAs of the current one and only consumed after the next barrier.
+// PREC 0: exact fp32 MFMAs on fp32 tiles staged transposed ([col][m]) in LDS.
+// PREC 1: bf16x3.  The transposition comes for free from the loader: lane = column, wave w loads rows 8w..8w+7 of the chunk (coalesced 256-byte row
+// segments), so every lane ends up with 8 consecutive m of ITS column in registers, splits them once into bf16 hi / lo and stores one 16-byte
+// vector per plane; the MFMA phase reads ready-made bf16 fragments (one 32-row MFMA step per chunk, three MFMAs per product).
+// Both: the next chunk's global loads are issued before the MFMAs of the current one and consumed after the next barrier.
+constexpr int TN_LDK = TN_BM + 8;  // bf16 elements per plane row: 80 B stride, conflict-free b128 reads and writes
+
 template <int PREC>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                       float* __restrict__ C, int ldc, int M, int N, int K, int shift0,
                                                       const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int rows_per_slice, int ntaps,
                                                       long long c_tap_stride) {
-    __shared__ __attribute__((aligned(16))) float At[64 * TN_LD];  // [n][m]
-    __shared__ __attribute__((aligned(16))) float Bt[64 * TN_LD];  // [k][m]
+    constexpr int LDS_BYTES = PREC == 0 ? 2 * 64 * TN_LD * 4 : 4 * 64 * TN_LDK * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
     const int tap = blockIdx.z % ntaps, slice = blockIdx.z / ntaps;  // conv weight gradients: all taps of a layer in one launch
     const int shift = shift0 + tap;
@@ -44,42 +48,44 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // loader: chunk = 32 rows x 64 cols per operand = 512 float4; thread handles float4 #tid and #tid+256
-    f32x4 va[2], vb[2];
-    auto fetch = [&](int mc) {
+    if constexpr (PREC == 0) {
+        float* At = reinterpret_cast<float*>(lds_raw);  // [n][m]
+        float* Bt = At + 64 * TN_LD;                    // [k][m]
+        // loader: chunk = 32 rows x 64 cols per operand = 512 float4; thread handles float4 #tid and #tid+256
+        f32x4 va[2], vb[2];
+        auto fetch = [&](int mc) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int idx = tid + h * 256;
-            const int mr = idx >> 4, c4 = (idx & 15) * 4;  // row within chunk, first of 4 columns
-            const int m = mc + mr;
-            va[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            vb[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (m < m_hi) {
-                if (n0 + c4 < N) va[h] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + n0 + c4);  // N % 4 == 0
-                const int src = m + shift;
-                bool ok = k0 + c4 < K;
-                if (seg_lo) ok = ok && src >= seg_lo[m] && src < seg_hi[m];
-                else ok = ok && src >= 0 && src < M;
-                if (ok) vb[h] = *reinterpret_cast<const f32x4*>(B + (size_t)src * ldb + k0 + c4);
+            for (int h = 0; h < 2; ++h) {
+                const int idx = tid + h * 256;
+                const int mr = idx >> 4, c4 = (idx & 15) * 4;  // row within chunk, first of 4 columns
+                const int m = mc + mr;
+                va[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                vb[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (m < m_hi) {
+                    if (n0 + c4 < N) va[h] = *reinterpret_cast<const f32x4*>(A + (size_t)m * lda + n0 + c4);  // N % 4 == 0
+                    const int src = m + shift;
+                    bool ok = k0 + c4 < K;
+                    if (seg_lo) ok = ok && src >= seg_lo[m] && src < seg_hi[m];
+                    else ok = ok && src >= 0 && src < M;
+                    if (ok) vb[h] = *reinterpret_cast<const f32x4*>(B + (size_t)src * ldb + k0 + c4);
+                }
             }
-        }
-    };
-    if (m_lo < m_hi) fetch(m_lo);
-    for (int mc = m_lo; mc < m_hi; mc += TN_BM) {
-        __syncthreads();  // every wave is done with the previous chunk
+        };
+        if (m_lo < m_hi) fetch(m_lo);
+        for (int mc = m_lo; mc < m_hi; mc += TN_BM) {
+            __syncthreads();  // every wave is done with the previous chunk
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int idx = tid + h * 256;
-            const int mr = idx >> 4, c4 = (idx & 15) * 4;
+            for (int h = 0; h < 2; ++h) {
+                const int idx = tid + h * 256;
+                const int mr = idx >> 4, c4 = (idx & 15) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                At[(c4 + e) * TN_LD + mr] = va[h][e];
-                Bt[(c4 + e) * TN_LD + mr] = vb[h][e];
+                for (int e = 0; e < 4; ++e) {
+                    At[(c4 + e) * TN_LD + mr] = va[h][e];
+                    Bt[(c4 + e) * TN_LD + mr] = vb[h][e];
+                }
             }
-        }
-        __syncthreads();
-        if (mc + TN_BM < m_hi) fetch(mc + TN_BM);  // in flight under the MFMAs below
-        if constexpr (PREC == 0) {
+            __syncthreads();
+            if (mc + TN_BM < m_hi) fetch(mc + TN_BM);  // in flight under the MFMAs below
 #pragma unroll
             for (int s = 0; s < TN_BM / 16; ++s) {
                 const f32x4 af = *reinterpret_cast<const f32x4*>(At + (wave * 16 + r16) * TN_LD + s * 16 + kq * 4);
@@ -91,21 +97,62 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[j][e], acc[j], 0, 0, 0);
             }
-        } else {
-            static_assert(TN_BM == 32, "one 32-row bf16 MFMA step per chunk");
-            auto frag = [&](const float* base, s16x8& hi, s16x8& lo) {  // 8 consecutive m of one column -> bf16 hi / lo operand registers
-                uint2 h0, l0, h1, l1;
-                split4(*reinterpret_cast<const f32x4*>(base), h0, l0);
-                split4(*reinterpret_cast<const f32x4*>(base + 4), h1, l1);
-                hi = __builtin_bit_cast(s16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-                lo = __builtin_bit_cast(s16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-            };
-            s16x8 ah, al;
-            frag(At + (wave * 16 + r16) * TN_LD + kq * 8, ah, al);
+        }
+    } else {
+        static_assert(TN_BM == 32, "one 32-row bf16 MFMA step per chunk; 4 waves x 8 rows");
+        unsigned short* Ath = reinterpret_cast<unsigned short*>(lds_raw);  // [n][m] planes
+        unsigned short *Atl = Ath + 64 * TN_LDK, *Bth = Atl + 64 * TN_LDK, *Btl = Bth + 64 * TN_LDK;
+        const bool a_col = n0 + lane < N, b_col = k0 + lane < K;
+        const float* ap = A + n0 + (a_col ? lane : 0);
+        const float* bp = B + k0 + (b_col ? lane : 0);
+        float ra[8], rb[8];
+        unsigned okb = 0;  // validity bits of the 8 B rows of the stage in flight (applied at the split, so no load result is consumed early)
+        auto fetch = [&](int mc) {
+            okb = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int m = mc + wave * 8 + e;
+                const int mcl = min(m, M - 1);
+                ra[e] = ap[(size_t)mcl * lda];
+                const int src = m + shift;
+                bool ok = m < m_hi;
+                if (seg_lo) ok = ok && src >= seg_lo[mcl] && src < seg_hi[mcl];
+                else ok = ok && src >= 0 && src < M;
+                rb[e] = bp[(size_t)(ok ? src : mcl) * ldb];
+                okb |= ok ? (1u << e) : 0u;
+            }
+        };
+        auto stash = [&](int mc) {
+            f32x4 a0, a1, b0, b1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a0[e] = (a_col && mc + wave * 8 + e < m_hi) ? ra[e] : 0.f;
+                a1[e] = (a_col && mc + wave * 8 + 4 + e < m_hi) ? ra[4 + e] : 0.f;
+                b0[e] = (b_col && ((okb >> e) & 1u)) ? rb[e] : 0.f;
+                b1[e] = (b_col && ((okb >> (4 + e)) & 1u)) ? rb[4 + e] : 0.f;
+            }
+            uint2 h0, l0, h1, l1;
+            split4(a0, h0, l0);
+            split4(a1, h1, l1);
+            *reinterpret_cast<uint4*>(Ath + lane * TN_LDK + wave * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(Atl + lane * TN_LDK + wave * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            split4(b0, h0, l0);
+            split4(b1, h1, l1);
+            *reinterpret_cast<uint4*>(Bth + lane * TN_LDK + wave * 8) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(Btl + lane * TN_LDK + wave * 8) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        };
+        if (m_lo < m_hi) fetch(m_lo);
+        for (int mc = m_lo; mc < m_hi; mc += TN_BM) {
+            __syncthreads();  // every wave is done with the previous chunk
+            stash(mc);
+            __syncthreads();
+            if (mc + TN_BM < m_hi) fetch(mc + TN_BM);  // in flight under the MFMAs below
+            const int ao = (wave * 16 + r16) * TN_LDK + kq * 8;
+            const s16x8 ah = *reinterpret_cast<const s16x8*>(Ath + ao), al = *reinterpret_cast<const s16x8*>(Atl + ao);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s16x8 bh, bl;
-                frag(Bt + (j * 16 + r16) * TN_LD + kq * 8, bh, bl);
+                const int bo = (j * 16 + r16) * TN_LDK + kq * 8;
+                const s16x8 bh = *reinterpret_cast<const s16x8*>(Bth + bo), bl = *reinterpret_cast<const s16x8*>(Btl + bo);
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
