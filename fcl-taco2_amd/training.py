@@ -258,8 +258,10 @@ class TrainEngine(object):
     def _wt(self, w):
         return ops.transpose2d(w.contiguous())
 
-    def _conv_pack(self, w, scale=None):
+    def _conv_pack(self, w, scale=None, need_t=True):
         wp = ops.pack_conv1d_weight(w, scale)  # [k, Cout, Cin]
+        if not need_t:  # forward only (the frozen teacher): the transposed taps are the backward's operand
+            return wp, None
         k = wp.shape[0]
         wt = torch.stack([ops.transpose2d(wp[k - 1 - j]) for j in range(k)]).contiguous()  # [k, Cin, Cout], taps reversed
         return wp, wt
@@ -269,7 +271,7 @@ class TrainEngine(object):
         P, B = self.P, self.B
         ks = 1.0 / (1.0 - self.hp.dropout_rate) if keep is not None else 1.0
         if c.train:
-            wp, wt = self._conv_pack(P[prefix + ".0.weight"])
+            wp, wt = self._conv_pack(P[prefix + ".0.weight"], need_t=c.save)
             z = ops.conv1d(x, wp, None, lo, hi, ops.ACT_NONE)
             mean, invstd = ops.bn_stats(z, BN_EPS, BN_MOMENTUM, B[prefix + ".1.running_mean"], B[prefix + ".1.running_var"])
             if prefix + ".1.num_batches_tracked" in B:
@@ -277,7 +279,7 @@ class TrainEngine(object):
             y_act, y = ops.bn_act(z, mean, invstd, P[prefix + ".1.weight"], P[prefix + ".1.bias"], act, keep, ks)
             return y, dict(x=x, z=z, y_act=y_act, wt=wt, mean=mean, invstd=invstd, prefix=prefix, act=act, lo=lo, hi=hi, keep=keep, ks=ks)
         scale, shift = ops.fold_batchnorm(P[prefix + ".1.weight"], P[prefix + ".1.bias"], B[prefix + ".1.running_mean"], B[prefix + ".1.running_var"], BN_EPS)
-        wp, wt = self._conv_pack(P[prefix + ".0.weight"], scale)
+        wp, wt = self._conv_pack(P[prefix + ".0.weight"], scale, need_t=c.save)
         z = ops.conv1d(x, wp, shift, lo, hi, ops.ACT_NONE)
         y = ops.act_fwd(z, act) if act != ops.ACT_NONE else z
         return y, dict(x=x, z=z, y_act=y, wt=wt, scale=scale, prefix=prefix, act=act, lo=lo, hi=hi, keep=None, ks=1.0)
@@ -309,8 +311,8 @@ class TrainEngine(object):
         self._dw(dw)
         return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
-    def _conv_bias_relu_fwd(self, x, prefix, lo, hi):
-        wp, wt = self._conv_pack(self.P[prefix + ".weight"])
+    def _conv_bias_relu_fwd(self, x, prefix, lo, hi, need_t=True):
+        wp, wt = self._conv_pack(self.P[prefix + ".weight"], need_t=need_t)
         y = ops.conv1d(x, wp, self.P[prefix + ".bias"], lo, hi, ops.ACT_RELU)
         return y, dict(x=x, y=y, wt=wt, prefix=prefix, lo=lo, hi=hi)
 
@@ -332,7 +334,7 @@ class TrainEngine(object):
     def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad):
         caches, x, out = [], hs, None
         for i in range(layers):
-            y, cc = self._conv_bias_relu_fwd(x, "%s.conv.%d.0" % (name, i), lo, hi)
+            y, cc = self._conv_bias_relu_fwd(x, "%s.conv.%d.0" % (name, i), lo, hi, need_t=c.save)
             last = i == layers - 1
             keep = self._keep(c, (name, i), tuple(y.shape), 1.0 - p_drop) if (c.train and p_drop > 0) else None
             ks = 1.0 / (1.0 - p_drop) if keep is not None else 1.0
