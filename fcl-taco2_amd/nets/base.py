@@ -343,7 +343,9 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
         names = [k for k, p in self.named_parameters() if p.requires_grad]
         params = [p for _, p in self.named_parameters() if p.requires_grad]
         value = torch.tensor(float(rep["loss"]), dtype=torch.float32, device=eng.dev)
-        return _HipLoss.apply(value, [eng.G[k] for k in names], *params)
+        snap = eng.gflat.clone()  # this forward's gradients: a later forward() (before this loss's backward()) must not overwrite them
+        offs = eng.param_offsets()
+        return _HipLoss.apply(value, [snap[offs[k][0] : offs[k][0] + offs[k][1]].view(offs[k][2]) for k in names], *params)
 
     @property
     def base_plot_keys(self):
