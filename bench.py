@@ -80,6 +80,7 @@ def train_workload(args, rank, world, dev, dist):
     from fcl_taco2_amd.converter import CustomConverter
     from fcl_taco2_amd.training import TrainEngine
 
+    torch.set_num_threads(4)  # the step is ~1000 launches from this thread; a 256-thread intra-op pool spinning after small CPU ops slows them (train.py)
     S, T = HP.student_hparams(), HP.teacher_hparams()
     kd = args.workload == "kd_step"
     B = args.batch if (kd or args.batch != 32) else 16  # shipped recipes: 32 / GPU for KD, 16 / GPU for the teacher

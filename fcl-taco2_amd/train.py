@@ -76,12 +76,46 @@ def load_batch(batch, cache=None):
     return xs, ys, None, ds, f0, en
 
 
+PINNED = ("xs", "ys", "extras", "f0", "energy")
+_ring = None
+
+
 def to_device(batch, dev):
-    """Hand the float / id tensors of a converted batch to the GPU through pinned memory without blocking the host (the integer layout tensors stay
-    on the host: the engine builds its index maps from them).  Inputs are then resident when the step's kernels reach them."""
-    for k in ("xs", "ys", "extras", "f0", "energy"):
-        batch[k] = batch[k].pin_memory().to(dev, non_blocking=True)
+    """Hand the float / id tensors of a converted batch to the GPU through fixed pinned staging buffers without blocking the host (the integer
+    layout tensors stay on the host: the engine builds its index maps from them).  Inputs are resident when the step's kernels reach them."""
+    global _ring
+    if _ring is None:
+        from .training import PinnedRing
+
+        _ring = PinnedRing()
+    batch.update(_ring.upload({k: batch[k] for k in PINNED}, dev))
     return batch
+
+
+class _BatchDataset(torch.utils.data.Dataset):
+    """One item = one converted batch incl. the host half of the engine's index maps: everything numpy-heavy happens in the loader processes
+    (the role of the reference's ChainerDataLoader workers, tts.py:509-528; --num-iter-processes)."""
+
+    def __init__(self, batches, conv, cache):
+        self.batches, self.conv, self.cache = batches, conv, cache
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __getitem__(self, i):
+        from .training import build_maps_host
+
+        b = self.conv([load_batch(self.batches[i], self.cache)])
+        b["_fcl_maps_host"] = build_maps_host(b)
+        return b
+
+
+def batch_feed(batches, conv, cache, workers):
+    """Iterator of converted batches in order; workers > 0 = forked loader processes (they never touch the GPU), 0 = inline."""
+    ds = _BatchDataset(batches, conv, cache)
+    if workers <= 0 or len(batches) == 0:
+        return (ds[i] for i in range(len(ds)))
+    return iter(torch.utils.data.DataLoader(ds, batch_size=None, shuffle=False, num_workers=workers, prefetch_factor=2, persistent_workers=False))
 
 
 # ---- checkpoints -----------------------------------------------------------------------------------------------------------------------
@@ -147,6 +181,9 @@ def get_parser():
     p.add_argument("--eval-interval-epochs", default=1, type=int)
     p.add_argument("--report-interval-iters", default=100, type=int)
     p.add_argument("--keep-all-data-on-mem", action="store_true")
+    p.add_argument("--num-iter-processes", default=0, type=int, help="loader processes (npy reads, converter, host index maps); 0 = inline, "
+                   "which keeps the loop GPU-bound at the shipped batch sizes (converter + maps ~4 ms per batch)")
+    p.add_argument("--host-threads", default=4, type=int, help="torch intra-op CPU threads of the training process (see train())")
     p.add_argument("--use-fe-condition", default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
     p.add_argument("--append-position", default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
     for k in ("output", "encoder", "decoder", "prosody"):
@@ -169,6 +206,9 @@ def train(argv=None):
     args = parser.parse_args(argv)
     if args.weight_decay != 0.0:
         raise NotImplementedError("fcl-taco2_amd: weight decay is 0 in every shipped recipe and is not implemented on the HIP path")
+    # The host side of a step is ~1000 kernel launches issued from this thread.  torch's default intra-op pool (one thread per core: 256 on an
+    # MI355X host) spins after every small CPU op of the converter and slows those launches 4x (46 vs 16 ms per KD update, measured); cap it.
+    torch.set_num_threads(max(1, args.host_threads))
     torch.manual_seed(args.seed)  # before any module is built: initial weights depend on --seed only (set_deterministic_pytorch, tts.py:321)
     np.random.seed(args.seed)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -231,10 +271,14 @@ def train(argv=None):
         reps, t0, frames = [], time.time(), 0
         micro = 0
         pipe = KDPipeline(teng, eng) if (kd and eng.accum_grad == 1) else None  # frozen teacher one batch ahead on a second stream
-        nxt = to_device(conv([load_batch(batches[rank], cache)]), dev) if n_iter else None
+        feed = batch_feed([batches[it * world + rank] for it in range(n_iter)], conv, cache, args.num_iter_processes)
+        nxt = next(feed, None)
+        nxt = to_device(nxt, dev) if nxt is not None else None
         for it in range(n_iter):
             batch = nxt
-            nxt = to_device(conv([load_batch(batches[(it + 1) * world + rank], cache)]), dev) if it + 1 < n_iter else None
+            nxt = next(feed, None)
+            if nxt is not None:
+                nxt = to_device(nxt, dev)
             if pipe is not None:
                 rep = pipe.step(batch, nxt)
                 iteration += 1

@@ -110,6 +110,103 @@ def flat_layout(names_sizes):
     return names, offs, bounds
 
 
+class PinnedRing(object):
+    """A few fixed page-locked staging buffers, reused round-robin: host -> device hand-over without touching the pinned-memory allocator in the
+    training loop (its blocks are only recycled once their copy has completed, i.e. a step later, so per-batch pin_memory() keeps calling
+    hipHostMalloc, which is slow and serialises with the GPU).  A slot is rewritten only after the event recorded behind its last copy."""
+
+    def __init__(self, depth=4):
+        self.depth, self.slots, self.i = depth, {}, 0
+
+    def stage(self, key, t):
+        """Copy the CPU tensor `t` into the next pinned slot of `key`; returns (pinned view, slot) — call done(slot) after enqueuing the copy."""
+        ring = self.slots.setdefault(key, [None] * self.depth)
+        j = self.i % self.depth
+        slot = ring[j]
+        need = t.numel() * t.element_size()
+        if slot is None or slot["buf"].numel() < need:
+            slot = ring[j] = {"buf": torch.empty(max(need * 3 // 2, 1 << 16), dtype=torch.uint8, pin_memory=True), "ev": None}
+        elif slot["ev"] is not None:
+            slot["ev"].synchronize()  # the copy that last read this slot (depth steps ago): long done in steady state
+        view = slot["buf"][:need].view(t.dtype).view(t.shape)
+        view.copy_(t)
+        return view, slot
+
+    def upload(self, items, dev):
+        """{key: cpu tensor} -> {key: device tensor}, non-blocking, one ring position per call."""
+        out, used = {}, []
+        for k, t in items.items():
+            view, slot = self.stage(k, t.contiguous())
+            out[k] = view.to(dev, non_blocking=True)
+            used.append(slot)
+        ev = torch.cuda.Event()
+        ev.record()
+        for slot in used:
+            slot["ev"] = ev
+        self.i += 1
+        return out
+
+
+def build_maps_host(batch):
+    """The host half of the index maps (SURVEY.md H9/H10 for the teacher-forced layout): pure numpy on the converter's integer tensors, safe to run
+    in a loader process.  Returns scalars, two packed blocks (int32, uint8) with their {name: (offset, size)} layouts, and the position column."""
+    ilens = [int(v) for v in batch["ilens"]]
+    olens = [int(v) for v in batch["olens"]]
+    B, T, L = len(ilens), max(ilens), max(olens)
+    rows = np.arange(B * T)
+    b_of = rows // T
+    lens_np = np.asarray(ilens)
+    pad_np = (rows % T) >= lens_np[b_of]
+    frows = np.arange(B * L)
+    fvalid_np = (frows % L) < np.asarray(olens)[frows // L]
+    nzm = np.asarray(batch["non_zero_lens_mask"])[:, :T] != 0
+    dsn = np.asarray(batch["ds_nonzeros"]).astype(np.int64)
+    src = np.flatnonzero(nzm.reshape(-1))
+    assert src.shape[0] == dsn.shape[0], "hs.shape[0] != len(ds_nonzeros)"  # decoder_sa.py:468
+    N = src.shape[0]
+    b_row = src // T
+    excl = np.cumsum(dsn) - dsn
+    first = np.concatenate([[0], np.cumsum(np.bincount(b_row, minlength=B))[:-1]])
+    foff = b_row * L + (excl - excl[first[b_row]])
+    order = np.argsort(-dsn, kind="stable")
+    dur_s, foff_s = dsn[order], foff[order]
+    lmax = int(dur_s[0])
+    live = (dur_s[None, :] > np.arange(lmax)[:, None]).sum(1)
+    offs = np.concatenate([[0], np.cumsum(live)])  # step-major cell offsets
+    cell_row = np.concatenate([np.arange(n) for n in live])  # sorted-row index of every cell
+    cell_t = np.repeat(np.arange(lmax), live)
+    cell_frame = foff_s[cell_row] + cell_t  # frame row (b*L + l) of every cell
+    F = int(offs[-1])
+    assert F == int(fvalid_np.sum()), "sum of durations != olens"
+    frame_cell = np.full(B * L, -1, dtype=np.int64)
+    frame_cell[cell_frame] = np.arange(F)
+    inv = np.full(B * T, -1, dtype=np.int64)
+    inv[src[order]] = np.arange(N)
+    i32 = dict(lens_dev=lens_np, e_lo=b_of * T, e_hi=b_of * T + T, f_lo=(frows // L) * L, f_hi=(frows // L) * L + L, src_sorted=src[order],
+               row_of_enc=inv, cell_frame=cell_frame, frame_cell=frame_cell, prev_frame=np.where(cell_t > 0, cell_frame - 1, -1),
+               cell_row_i32=cell_row, dur_dev=dur_s, perm_tb=(rows % T) * B + rows // T)
+    u8 = dict(enc_pad=pad_np, enc_valid=~pad_np, frame_valid=fvalid_np)
+    out = dict(scalars=dict(B=B, T=T, L=L, N=N, F=F, lmax=lmax, live=live, offs=offs, order=order, cell_row=cell_row, cell_t=cell_t, dur_s=dur_s,
+                            n_enc=float((~pad_np).sum()), n_frames=float(fvalid_np.sum()), live_i32=np.ascontiguousarray(live, dtype=np.int32)))
+    for name, block, dtype in (("i32", i32, np.int32), ("u8", u8, np.uint8)):
+        layout, o = {}, 0
+        for k, v in block.items():
+            layout[k] = (o, int(v.size))
+            o += (v.size + 15) // 16 * 16  # 64-byte aligned slots
+        host = np.zeros(o, dtype=dtype)
+        for k, v in block.items():
+            host[layout[k][0] : layout[k][0] + v.size] = v
+        out[name] = torch.from_numpy(host)
+        out[name + "_layout"] = layout
+    pos = np.zeros((F, 4), dtype=np.float32)
+    pos[:, 0] = cell_t.astype(np.float32) / dur_s[cell_row].astype(np.float32)  # the position input t/d, padded to 4 columns (TN-GEMM operand)
+    out["pos4"] = torch.from_numpy(pos)
+    return out
+
+
+_RING = PinnedRing()  # staging of the index maps (one process = one GPU)
+
+
 class _Ctx(object):
     pass
 
@@ -405,68 +502,24 @@ class TrainEngine(object):
 
     # ------------------------------------------------------------------------------------------------ index maps (host, integers)
     def _maps(self, c, batch):
-        """Integer index maps of one batch (host numpy), shipped to the device in TWO transfers (int32 block, uint8 block) and cached on the
-        batch dict: the frozen teacher and the student of a KD step share them."""
+        """Integer index maps of one batch: built on the host (build_maps_host: pure numpy, possibly already done by a loader thread), shipped to
+        the device in three non-blocking copies from pinned memory and cached on the batch dict (the frozen teacher and the student share them)."""
         dev = self.dev
         cache = batch.get("_fcl_maps") if isinstance(batch, dict) else None
         if cache is not None and cache[0] == str(dev):
             c.__dict__.update(cache[1])
             return
-        ilens = [int(v) for v in batch["ilens"]]
-        olens = [int(v) for v in batch["olens"]]
-        B, T, L = len(ilens), max(ilens), max(olens)
-        rows = np.arange(B * T)
-        b_of = rows // T
-        lens_np = np.asarray(ilens)
-        pad_np = (rows % T) >= lens_np[b_of]
-        frows = np.arange(B * L)
-        fvalid_np = (frows % L) < np.asarray(olens)[frows // L]
-        nzm = np.asarray(batch["non_zero_lens_mask"])[:, :T] != 0
-        dsn = np.asarray(batch["ds_nonzeros"]).astype(np.int64)
-        src = np.flatnonzero(nzm.reshape(-1))
-        assert src.shape[0] == dsn.shape[0], "hs.shape[0] != len(ds_nonzeros)"  # decoder_sa.py:468
-        N = src.shape[0]
-        b_row = src // T
-        excl = np.cumsum(dsn) - dsn
-        first = np.concatenate([[0], np.cumsum(np.bincount(b_row, minlength=B))[:-1]])
-        foff = b_row * L + (excl - excl[first[b_row]])
-        order = np.argsort(-dsn, kind="stable")
-        dur_s, foff_s = dsn[order], foff[order]
-        lmax = int(dur_s[0])
-        live = (dur_s[None, :] > np.arange(lmax)[:, None]).sum(1)
-        offs = np.concatenate([[0], np.cumsum(live)])  # step-major cell offsets
-        cell_row = np.concatenate([np.arange(n) for n in live])  # sorted-row index of every cell
-        cell_t = np.repeat(np.arange(lmax), live)
-        cell_frame = foff_s[cell_row] + cell_t  # frame row (b*L + l) of every cell
-        F = int(offs[-1])
-        assert F == int(fvalid_np.sum()), "sum of durations != olens"
-        frame_cell = np.full(B * L, -1, dtype=np.int64)
-        frame_cell[cell_frame] = np.arange(F)
-        inv = np.full(B * T, -1, dtype=np.int64)
-        inv[src[order]] = np.arange(N)
-        i32 = dict(lens_dev=lens_np, e_lo=b_of * T, e_hi=b_of * T + T, f_lo=(frows // L) * L, f_hi=(frows // L) * L + L, src_sorted=src[order],
-                   row_of_enc=inv, cell_frame=cell_frame, frame_cell=frame_cell, prev_frame=np.where(cell_t > 0, cell_frame - 1, -1),
-                   cell_row_i32=cell_row, dur_dev=dur_s, perm_tb=(rows % T) * B + rows // T)
-        u8 = dict(enc_pad=pad_np, enc_valid=~pad_np, frame_valid=fvalid_np)
-        m = dict(B=B, T=T, L=L, N=N, F=F, lmax=lmax, live=live, offs=offs, order=order, cell_row=cell_row, cell_t=cell_t, dur_s=dur_s,
-                 n_enc=float((~pad_np).sum()), n_frames=float(fvalid_np.sum()), live_i32=np.ascontiguousarray(live, dtype=np.int32))
-        for block, dtype in ((i32, np.int32), (u8, np.uint8)):
-            sizes = [(k, (v.size + 15) // 16 * 16) for k, v in block.items()]  # 64-byte aligned slots
-            host = np.zeros(sum(n for _, n in sizes), dtype=dtype)
-            o = 0
-            for (k, n), v in zip(sizes, block.values()):
-                host[o : o + v.size] = v
-                o += n
-            devbuf = torch.from_numpy(host).to(dev)
-            o = 0
-            for (k, n), v in zip(sizes, block.values()):
-                m[k] = devbuf[o : o + v.size]
-                o += n
+        host = batch.get("_fcl_maps_host") if isinstance(batch, dict) else None
+        if host is None:
+            host = build_maps_host(batch)
+        m = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in host["scalars"].items()}  # a DataLoader hands numpy arrays over as tensors
+        up = _RING.upload({"i32": host["i32"], "u8": host["u8"], "pos4": host["pos4"]}, dev)  # pinned staging: the CPU keeps running ahead
+        for name in ("i32", "u8"):
+            for k, (o, n) in host[name + "_layout"].items():
+                m[k] = up[name][o : o + n]
         m["cell_row_i64"] = m["cell_row_i32"].to(torch.int64)
-        pos = np.zeros((F, 4), dtype=np.float32)
-        pos[:, 0] = cell_t.astype(np.float32) / dur_s[cell_row].astype(np.float32)  # the position input t/d, padded to 4 columns (TN-GEMM operand)
-        m["pos4"] = torch.from_numpy(pos).to(dev)
-        m["cell_valid"] = torch.ones(F, dtype=torch.uint8, device=dev)  # every cell is a valid frame
+        m["pos4"] = up["pos4"]
+        m["cell_valid"] = torch.ones(m["F"], dtype=torch.uint8, device=dev)  # every cell is a valid frame
         if isinstance(batch, dict):
             batch["_fcl_maps"] = (str(dev), m)
         c.__dict__.update(m)
