@@ -219,6 +219,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.set_num_threads(4)  # launches are issued from this thread: keep torch's 256-thread intra-op pool from spinning next to it
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None

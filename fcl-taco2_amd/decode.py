@@ -104,6 +104,7 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=137)
     ap.add_argument("--verbose", type=int, default=1)
     args = ap.parse_args(argv)
+    torch.set_num_threads(4)  # kernels are launched from this thread; a one-thread-per-core intra-op pool spinning beside it slows them
     logging.basicConfig(level=logging.INFO if args.verbose else logging.WARN, format="%(asctime)s %(levelname)s: %(message)s")
     dev = "cuda:%d" % (args.job % max(torch.cuda.device_count(), 1))
     model = build_model(args.model, args.model_conf, args.teacher_config, dev)
