@@ -102,6 +102,11 @@ def test_train_teacher_then_kd_student_then_decode(tmp_path):
                     + common + STUDENT_FLAGS)
     assert len(plog) == 2 and plog[-1]["iteration"] == 4 and all(np.isfinite(e["main/loss"]) and np.isfinite(e["validation/main/loss"]) for e in plog)
     assert plog[-1]["main/decoder_loss"] < plog[0]["main/decoder_loss"]  # the distillation terms go down from the first epoch on
+    # loader processes (--num-iter-processes): converter + host index maps in a forked worker, same artefacts
+    wlog = TR.train(["--outdir", tdir + "_workers", "--epochs", "1", "--num-iter-processes", "1",
+                     "--model-module", "fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa:Tacotron2_sa"] + common + TEACHER_FLAGS)
+    assert len(wlog) == 1 and wlog[0]["iteration"] == 2 and np.isfinite(wlog[0]["main/loss"])
+    assert abs(wlog[0]["main/loss"] - log[0]["main/loss"]) < 1e-3 * abs(log[0]["main/loss"])  # same seed, same batches: the same first epoch
     # the decode driver reads what the train driver wrote
     model = D.build_model(os.path.join(sdir, "model.loss.best"), os.path.join(sdir, "model.json"), os.path.join(tdir, "model.json"))
     mel = model.inference(torch.tensor([3, 5, 2, 7]), None, dur=torch.tensor([2, 1, 3, 2]))
