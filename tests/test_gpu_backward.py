@@ -239,3 +239,19 @@ def test_bilstm_train_forward_and_bptt_vs_torch_lstm(ops, H, lens):
         assert close(g_ih.cpu(), dict(lstm.named_parameters())["weight_ih_l0" + s].grad), s
         ops.add2d(dx, ops.linear(dgx, ops.transpose2d(dev(sd["weight_ih_l0" + s]))))
     assert max_abs(dx.cpu().reshape(B, T, C), x.grad) < 2e-4 * max(1.0, float(x.grad.abs().max()))
+
+
+def test_bilstm_group_kernel_more_workgroups_than_cus(ops):
+    """H = 256 group kernel with 8 B = 768 workgroups on a 256-CU part: groups are dispatched in id order, partially resident groups wait for running
+    ones to retire (bounded spins), results equal the per-step algorithm."""
+    B, T, C, H = 96, 40, 64, 256
+    rng = np.random.RandomState(0)
+    x = dev(rnd(rng, B * T, C))
+    lens_np = np.sort(rng.randint(5, T + 1, B))[::-1].astype(np.int32).copy()
+    lens_np[0] = T
+    lens = dev(lens_np)
+    w = lambda *s: dev((rnd(rng, *s) / np.sqrt(s[-1])).astype(np.float32))
+    a = [w(4 * H, C), w(4 * H, H), w(4 * H), w(4 * H, C), w(4 * H, H), w(4 * H)]
+    ref = ops.bilstm(x, lens, *a, B, T, 1)
+    out = ops.bilstm(x, lens, *a, B, T, 3)
+    assert max_abs(out.cpu(), ref.cpu()) < 1e-5
