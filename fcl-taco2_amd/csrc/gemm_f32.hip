@@ -238,12 +238,26 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
     }
 }
 
+// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs by linear id (x fastest), each XCD with its own L2; the N tiles of
+// one M-tile share the A rows, so with the natural order every XCD fetches every A tile.  Remap: the workgroups one XCD receives (ids = xcd mod 8)
+// walk a CONTIGUOUS range of tiles (bijective for any grid size), so the N tiles of an M-tile meet in one L2; W is read by every XCD either way.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+    const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * nx + blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    by = t / nx;
+    bx = t - by * nx;
+}
+
 // --------------------------------------------------------------------------------------------------
 template <int WM, int WN, int PREC, int TM = 1>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     using G = Geo<WM, WN, false, TM>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
-    const int m0 = blockIdx.y * G::BM, n0 = blockIdx.x * G::BN;
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = by * G::BM, n0 = bx * G::BN;
     f32x4 acc[TM][4];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -289,7 +303,9 @@ template <int WM, int WN, int MODE, int PREC, int TM = 1>
 __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepArgs a) {
     using G = Geo<WM, WN, true, TM>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
-    const int m0 = blockIdx.y * G::BM, u0 = blockIdx.x * (16 * WN);
+    int bx, by;
+    xcd_tile(bx, by);
+    const int m0 = by * G::BM, u0 = bx * (16 * WN);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);
