@@ -37,8 +37,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       long long c_tap_stride) {
     constexpr int LDS_BYTES = PREC == 0 ? 2 * 64 * TN_LD * 4 : 4 * 64 * TN_LDK * 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
-    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-    const int tap = blockIdx.z % ntaps, slice = blockIdx.z / ntaps;  // conv weight gradients: all taps of a layer in one launch
+    // XCD-aware order (as in gemm_f32.hip): the ids one XCD receives walk a contiguous range of (slice, tap, k tile, n tile), so the tiles that
+    // read the same M slice of A and B meet in one L2 instead of all eight
+    const int nx = gridDim.x, nxy = gridDim.x * gridDim.y, nwg = nxy * gridDim.z;
+    const int orig = (blockIdx.z * gridDim.y + blockIdx.y) * nx + blockIdx.x;
+    const int xcd = orig & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int tl = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int bz = tl / nxy, by = (tl - bz * nxy) / nx, bx = tl - bz * nxy - by * nx;
+    const int n0 = bx * 64, k0 = by * 64;
+    const int tap = bz % ntaps, slice = bz / ntaps;  // conv weight gradients: all taps of a layer in one launch
     const int shift = shift0 + tap;
     C += (size_t)tap * c_tap_stride;
     const int m_lo = slice * rows_per_slice, m_hi = min(M, m_lo + rows_per_slice);
