@@ -21,3 +21,12 @@ def golden():
         return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """A checkout without the in-tree libfcl_hip.so (it is git-ignored): compile it once per session before any test needs it."""
+    if not os.path.exists(os.path.join(ROOT, "fcl-taco2_amd", "libfcl_hip.so")):
+        import __graft_entry__ as ge
+
+        ge.build()
