@@ -463,7 +463,6 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
     const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int u = min(u0 + r16, a.U - 1);
     // epilogue operands first (latency hides under the K walk)
     const int erow = threadIdx.x >> 4, euc = threadIdx.x & 15;
     const int em = m0 + erow, eu = u0 + euc;
