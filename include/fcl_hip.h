@@ -224,7 +224,8 @@ int fcl_masked_l1_mse_fwd(const float* a, int lda, const float* b, int ldb, cons
  *      with the taps reversed); the entries below are what the backward pass needs beyond that. ------------------------------- */
 /* dW: c[n, k] += sum_m a[m, n] * b[m + shift, k]  (rows of b outside [seg_lo[m], seg_hi[m]) — or outside [0, M) when the
  * bounds are NULL — contribute zero).  Linear: shift 0; Conv1d tap j: shift = j - (k-1)/2, c = packed dW[j] ([Cout, Cin]).
- * Accumulates with fp32 atomics (the caller zeroes c once per step: gradient accumulation is the natural mode). */
+ * Accumulates with fp32 atomics (the caller zeroes c once per step: gradient accumulation is the natural mode).
+ * Arithmetic follows FCL_PRECISION like the forward GEMMs: bf16x3-split operands with fp32 accumulation (default) or exact fp32 MFMA (0). */
 int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift,
                     const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream);
 /* The same for NTAPS consecutive shifts in one launch: c + j*c_tap_stride gets shift0 + j (all taps of a Conv1d weight gradient, tap-major). */
