@@ -56,12 +56,12 @@ class DecoderBptt(C.Structure):  # fcl_decoder_bptt_t
 
 class BilstmTrain(C.Structure):  # fcl_bilstm_train_t
     _fields_ = [("b", _I), ("t", _I), ("h", _I), ("lens", _P), ("gx", _P * 2), ("w_hh", _P * 2), ("out", _P), ("s", (_P * 4) * 2), ("workspace", _P),
-                ("workspace_bytes", _Z)]
+                ("workspace_bytes", _Z), ("status", _P)]
 
 
 class BilstmBptt(C.Structure):  # fcl_bilstm_bptt_t
     _fields_ = [("b", _I), ("t", _I), ("h", _I), ("lens", _P), ("s", (_P * 3) * 2), ("d_out", _P), ("ld_dout", _I), ("w_hh_t", _P * 2), ("dg", _P * 2),
-                ("workspace", _P), ("workspace_bytes", _Z)]
+                ("workspace", _P), ("workspace_bytes", _Z), ("status", _P)]
 
 
 class ProfEntry(C.Structure):
@@ -88,7 +88,7 @@ SIGNATURES = {
     "fcl_position_table_fwd": (_I, [_P, _P, _I, _I, _P]),
     "fcl_gather_rows_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
     "fcl_bilstm_workspace_bytes": (_Z, [_I, _I, _I]),
-    "fcl_bilstm_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P, _Z, _P]),
+    "fcl_bilstm_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
     "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
     "fcl_masked_l1_mse_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
@@ -110,7 +110,7 @@ SIGNATURES = {
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),
-    "fcl_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "fcl_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P, _P, _P]),
     "fcl_lstm_step_fwd": (_I, [C.POINTER(LstmStep), _P]),
     "fcl_decoder_train_workspace_bytes": (_Z, [_I, _I]),
     "fcl_decoder_train_fwd": (_I, [C.POINTER(DecoderTrain), _P]),
@@ -124,6 +124,7 @@ SIGNATURES = {
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 DROP_NONE, DROP_MASK, DROP_RNG = 0, 1, 2
+STATUS_GROUP_TIMEOUT = 1  # FCL_STATUS_* bits of a device status word
 
 _lib = None
 

@@ -543,10 +543,19 @@ __global__ void sumsq_kernel(const float* __restrict__ x, long long n, double* _
 
 // Adam (torch.optim.Adam semantics, weight_decay 0, amsgrad off) with the clip coefficient and the NaN guard read from device memory:
 // ctrl[0] = total grad-norm^2 (double).  clip = min(1, max_norm / (norm + 1e-6)); non-finite norm => no update (tts.py:173-179).
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                            const double* __restrict__ ctrl, float max_norm, float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+// skip = NaN / inf gradient norm (tts.py:173-179 skips optimizer.step() on NaN; inf: see include/fcl_hip.h) or a non-zero status word
+__device__ __forceinline__ bool adam_skip(const double* ctrl, const unsigned int* status) {
     const double norm = sqrt(ctrl[0]);
-    if (!(norm == norm) || norm > 1e300) return;  // NaN / inf guard: skip the step
+    return !(norm == norm) || norm > 1e300 || (status && *status != 0u);
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                            const double* __restrict__ ctrl, float max_norm, float lr, float beta1, float beta2, float eps, const int* __restrict__ step_dev,
+                            const unsigned int* __restrict__ status) {
+    if (adam_skip(ctrl, status)) return;
+    const double norm = sqrt(ctrl[0]);
+    const float t = (float)(*step_dev + 1);  // the counter is advanced by adam_commit_kernel, after every block has read it
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     const float clip = max_norm > 0.f ? fminf(1.0f, max_norm / ((float)norm + 1e-6f)) : 1.0f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * clip;
@@ -556,6 +565,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         v[i] = vi;
         p[i] -= lr * (mi / bc1) / (sqrtf(vi) / sqrtf(bc2) + eps);
     }
+}
+
+__global__ void adam_commit_kernel(const double* __restrict__ ctrl, int* __restrict__ step_dev, const unsigned int* __restrict__ status) {
+    if (!adam_skip(ctrl, status)) *step_dev += 1;
 }
 
 static inline int grid1d(long long total, int block) {
@@ -754,12 +767,12 @@ int fcl_sumsq_accum(const float* x, size_t n, double* out, fcl_stream_t stream) 
 }
 
 int fcl_adam_step(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
-                  float beta2, float eps, int step, fcl_stream_t stream) {
-    FCL_REQUIRE(p && g && m && v && gradnorm_sq && step >= 1, FCL_ERR_INVALID, "adam_step: bad arguments");
+                  float beta2, float eps, int32_t* step_dev, const uint32_t* status, fcl_stream_t stream) {
+    FCL_REQUIRE(p && g && m && v && gradnorm_sq && step_dev, FCL_ERR_INVALID, "adam_step: bad arguments");
     if (n == 0) return 0;
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, gradnorm_sq, max_norm, lr,
-                       beta1, beta2, eps, bc1, bc2);
+                       beta1, beta2, eps, step_dev, status);
+    hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gradnorm_sq, step_dev, status);
     return check_hip(hipGetLastError(), "adam_step");
 }
 

@@ -133,11 +133,14 @@ __global__ __launch_bounds__(4 * H) void bilstm_bptt_persistent_kernel(BilstmBwd
 // ---- H = 256 (FCL-taco2-T): one CU's register file (512 KB) cannot hold the 1 MB of W_hh, so an (utterance, direction) recurrence is shared by
 // P = H/64 = 4 workgroups, each owning 64 units (all four gates, 256 weight rows, 128 weights per thread in registers).  Per step the workgroups
 // exchange their slices of h through global memory and meet at a counter barrier (release fence -> device-scope atomic -> spin -> acquire fence).
-// Group members have adjacent block ids, the grid is at most 8 B workgroups of 512 threads (one per CU), so partially resident groups only wait for
-// running ones; a bounded spin turns any scheduling surprise into an error flag instead of a hang.
+// Group members have adjacent block ids and the grid (8 B workgroups of 512 threads) is refused unless it fits the device one workgroup per CU, so
+// with ONE such kernel in flight every group is resident.  Two group kernels in flight on different streams can each hold CUs the other's missing
+// members need, so the path is SINGLE-STREAM ONLY; the spin is bounded and a timeout is reported, never silent: the kernel ORs
+// FCL_STATUS_GROUP_TIMEOUT into the caller's device status word (the launchers refuse the path without one), which fcl_adam_step tests before
+// touching the parameters and the host reads back next to the losses.
 struct GroupSync {
     unsigned int* flag;  // [groups] zeroed before the launch
-    unsigned int* error;
+    unsigned int* error; // the caller's status word (never reset here)
 };
 
 // No fences: an agent-scope release / acquire on gfx942-class parts writes back / invalidates the whole L2 (measured 45 us per step here).  The
@@ -156,7 +159,7 @@ __device__ __forceinline__ bool group_barrier(const GroupSync& gs, int group, un
         for (long long spin = 0; spin < (1ll << 24); ++spin) {
             if (__hip_atomic_load(gs.flag + group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
         }
-        if (!ok) atomicExch(gs.error, 1u);
+        if (!ok) atomicOr(gs.error, (unsigned int)FCL_STATUS_GROUP_TIMEOUT);
         ok_s = ok;
     }
     __syncthreads();
@@ -311,17 +314,20 @@ namespace fcl {
 // H = 256: groups of 4 workgroups.  ws: [2B] flags + 1 error word (zeroed here) followed by the exchange buffer.
 size_t bilstm_group_workspace_bytes(int B, int H) { return 1024 + sizeof(unsigned int) * 2 * (size_t)B + sizeof(float) * 2 * (size_t)B * 2 * 4 * H; }
 
-static bool group_ok(int B, int H, void* ws, size_t ws_bytes) {
+static bool group_ok(int B, int H, void* ws, size_t ws_bytes, const unsigned int* status) {
     static const int enabled = tunable("BILSTM_GROUP", 1);
-    return enabled && H == 256 && ws && ws_bytes >= bilstm_group_workspace_bytes(B, H);
+    if (!enabled || H != 256 || !ws || ws_bytes < bilstm_group_workspace_bytes(B, H) || !status) return false;  // no status word, no spinning kernel
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    return 2 * B * 4 <= cus;  // every workgroup of the grid resident (one 512-thread workgroup per CU): groups never wait for unscheduled members
 }
 
 bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T, int H,
-                         const BilstmSave* sv, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!group_ok(B, H, ws, ws_bytes)) return false;
+                         const BilstmSave* sv, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s) {
+    if (!group_ok(B, H, ws, ws_bytes, status)) return false;
     unsigned int* flags = (unsigned int*)ws;
     if (hipMemsetAsync(flags, 0, 1024 + sizeof(unsigned int) * 2 * (size_t)B, s) != hipSuccess) return false;
-    GroupSync gs{flags + 256, flags};
+    GroupSync gs{flags + 256, status};
     float* hbuf = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
     dim3 grid(2 * B * 4);
     if (sv) hipLaunchKernelGGL((bilstm_group_kernel<256, true>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, hbuf, gs, *sv);
@@ -329,11 +335,11 @@ bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_
     return true;
 }
 
-bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, hipStream_t s) {
-    if (!group_ok(B, H, ws, ws_bytes)) return false;
+bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s) {
+    if (!group_ok(B, H, ws, ws_bytes, status)) return false;
     unsigned int* flags = (unsigned int*)ws;
     if (hipMemsetAsync(flags, 0, 1024 + sizeof(unsigned int) * 2 * (size_t)B, s) != hipSuccess) return false;
-    GroupSync gs{flags + 256, flags};
+    GroupSync gs{flags + 256, status};
     float* part = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
     hipLaunchKernelGGL((bilstm_bptt_group_kernel<256>), dim3(2 * B * 4), dim3(512), 0, s, a, lens, T, part, gs);
     return true;
@@ -382,7 +388,7 @@ size_t fcl_bilstm_workspace_bytes(int b, int t, int h) {
 
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
                    const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,
-                   int algo, void* workspace, size_t workspace_bytes, fcl_stream_t stream) {
+                   int algo, void* workspace, size_t workspace_bytes, uint32_t* status, fcl_stream_t stream) {
     FCL_REQUIRE(x && lens && w_ih_f && w_hh_f && b_f && w_ih_r && w_hh_r && b_r && out, FCL_ERR_INVALID, "bilstm_fwd: null argument");
     FCL_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && (c & 3) == 0 && (h & 3) == 0, FCL_ERR_SHAPE, "bilstm_fwd: bad sizes B=%d T=%d C=%d H=%d", b, t, c, h);
     FCL_REQUIRE(workspace && workspace_bytes >= fcl_bilstm_workspace_bytes(b, t, h), FCL_ERR_WORKSPACE, "bilstm_fwd: workspace too small");
@@ -410,11 +416,12 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     // otherwise idle GPU (the training step), but its 8B spinning workgroups own every CU for the whole recurrence, which costs 9 % of throughput when
     // several synthesis passes are in flight on other streams (3.52 vs 3.85 M frames/s) — so algo 0 keeps the per-step launches there.
     static const int group_infer = tunable("BILSTM_GROUP_INFER", 0);
-    if (h == 256 && (algo == 3 || (algo == 0 && group_infer))) {
+    FCL_REQUIRE(algo != 3 || status, FCL_ERR_INVALID, "bilstm_fwd: algo 3 (cooperating workgroups) needs a device status word");
+    if (h == 256 && status && (algo == 3 || (algo == 0 && group_infer))) {
         void* gws = hbuf;  // the Gx buffers are final, so the tail of the workspace (per-step state of algo 1) is free for the flags and the exchange buffer
         const size_t gbytes = workspace_bytes - sizeof(float) * ((size_t)2 * b * t * 4 * h);
         ProfScope ps("bilstm_group_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
-        if (launch_bilstm_group(gx_f, gx_r, w_hh_f, w_hh_r, lens, out, b, t, h, nullptr, gws, gbytes, s)) return check_hip(hipGetLastError(), "bilstm group launch");
+        if (launch_bilstm_group(gx_f, gx_r, w_hh_f, w_hh_r, lens, out, b, t, h, nullptr, gws, gbytes, status, s)) return check_hip(hipGetLastError(), "bilstm group launch");
     }
     if (algo == 0 || algo == 3) algo = can_persist ? 2 : 1;
     FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);

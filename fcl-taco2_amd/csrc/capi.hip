@@ -3,6 +3,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "fcl_common.h"
@@ -29,6 +32,19 @@ int tunable(const char* name, int dflt) {
     snprintf(key, sizeof(key), "FCL_%s", name);
     const char* v = getenv(key);
     return v && *v ? atoi(v) : dflt;
+}
+
+int ensure_dyn_lds(const void* func, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> granted;  // (kernel, device) -> bytes already opted in
+    int dev = 0;
+    FCL_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    int& have = granted[std::make_pair(func, dev)];
+    if (have >= bytes) return 0;
+    FCL_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+    return 0;
 }
 
 // ---- profiling records ------------------------------------------------------------------------------

@@ -683,11 +683,11 @@ int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled) {
     if (!wres_applicable(a)) return 0;
     *handled = true;
     const size_t lds = sizeof(float) * (64 * WRES_LD + 4 * 4 * 256);
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wres_kernel<-1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wres_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_wres_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                        (void)hipGetLastError(), true);
-    (void)once;
+    for (const void* f : {reinterpret_cast<const void*>(lstm_wres_kernel<-1>), reinterpret_cast<const void*>(lstm_wres_kernel<0>),
+                          reinterpret_cast<const void*>(lstm_wres_kernel<1>)}) {
+        const int rc = ensure_dyn_lds(f, (int)lds);
+        if (rc) return rc;
+    }
     const int slices = a.U / 16;
     int groups = 256 / slices;
     if (groups < 1) groups = 1;
@@ -725,10 +725,9 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
     FCL_REQUIRE(!(a.U & 3) && !(a.O & 3) && !(a.P & 3), FCL_ERR_SHAPE, "feat_prenet: U/O/P must be multiples of 4");
     const size_t lds = sizeof(float) * 16 * ((size_t)(a.U + 4) + (a.O + 4) + (a.P + 4));
     FCL_REQUIRE(lds <= 160 * 1024, FCL_ERR_SHAPE, "feat_prenet: tile does not fit LDS (%zu B)", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        FCL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feat_prenet_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    {
+        const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(feat_prenet_kernel), 160 * 1024);
+        if (rc) return rc;
     }
     double fl = 0;
     if (a.h1) fl += 2.0 * a.M_feat * a.O * a.U;
@@ -736,10 +735,9 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
     const bool planes = a.wf_hi && a.wf_lo && a.w0_hi && a.w0_lo && a.w1_hi && a.w1_lo && !(a.U & 7) && !(a.O & 7) && !(a.P & 7);
     if (planes) {
         const size_t lds3 = 2 * sizeof(unsigned short) * 16 * ((size_t)(a.U + 8) + (a.O + 8) + (a.P + 8));
-        static bool attr3 = false;
-        if (!attr3) {
-            FCL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(feat_prenet_x3_kernel<0, 0, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr3 = true;
+        {
+            const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(feat_prenet_x3_kernel<0, 0, 0>), 160 * 1024);
+            if (rc) return rc;
         }
         ProfScope ps("feat_prenet_kernel/bf16x3", fl, rows, s);
         if (a.U == 256 && a.O == 80 && a.P == 256) hipLaunchKernelGGL((feat_prenet_x3_kernel<8, 3, 8>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);

@@ -149,8 +149,8 @@ bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const 
 bool launch_bilstm_bptt_persistent(const BilstmBwd& a, const int* lens, int B, int T, int H, hipStream_t s);
 size_t bilstm_group_workspace_bytes(int B, int H);
 bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T, int H,
-                         const BilstmSave* sv, void* ws, size_t ws_bytes, hipStream_t s);
-bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, hipStream_t s);
+                         const BilstmSave* sv, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s);
+bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s);
 
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
@@ -158,6 +158,9 @@ int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
 int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled);
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s);
 int tunable(const char* name, int dflt);  // FCL_<NAME> environment override, read once
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: opt the CURRENT device in for `bytes` of dynamic LDS the first time
+// `func` is launched on it (thread-safe; every later call is a map lookup).  Returns 0 or FCL_ERR_HIP.
+int ensure_dyn_lds(const void* func, int bytes);
 
 
 // counter hash shared by the rng-dropout epilogue (and mirrored nowhere on the host: rng mode is the

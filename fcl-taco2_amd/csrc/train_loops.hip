@@ -160,7 +160,7 @@ int fcl_bilstm_train_fwd(const fcl_bilstm_train_t* a, fcl_stream_t stream) {
         sv.B = B;
         if (launch_bilstm_train_persistent(a->gx[0], a->gx[1], a->w_hh[0], a->w_hh[1], a->lens, a->out, B, T, H, sv, s))
             return check_hip(hipGetLastError(), "bilstm_train_fwd persistent launch");
-        if (launch_bilstm_group(a->gx[0], a->gx[1], a->w_hh[0], a->w_hh[1], a->lens, a->out, B, T, H, &sv, a->workspace, a->workspace_bytes, s))
+        if (launch_bilstm_group(a->gx[0], a->gx[1], a->w_hh[0], a->w_hh[1], a->lens, a->out, B, T, H, &sv, a->workspace, a->workspace_bytes, a->status, s))
             return check_hip(hipGetLastError(), "bilstm_train_fwd group launch");
     }
     FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(B, H), FCL_ERR_WORKSPACE, "bilstm_train_fwd: workspace too small");
@@ -216,7 +216,7 @@ int fcl_bilstm_bptt(const fcl_bilstm_bptt_t* a, fcl_stream_t stream) {
         bw.ld = a->ld_dout;
         bw.B = B;
         if (launch_bilstm_bptt_persistent(bw, a->lens, B, T, H, s)) return check_hip(hipGetLastError(), "bilstm_bptt persistent launch");
-        if (launch_bilstm_bptt_group(bw, a->lens, B, T, H, a->workspace, a->workspace_bytes, s)) return check_hip(hipGetLastError(), "bilstm_bptt group launch");
+        if (launch_bilstm_bptt_group(bw, a->lens, B, T, H, a->workspace, a->workspace_bytes, a->status, s)) return check_hip(hipGetLastError(), "bilstm_bptt group launch");
     }
     FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_bilstm_train_workspace_bytes(B, H), FCL_ERR_WORKSPACE, "bilstm_bptt: workspace too small");
     const size_t BH = (size_t)B * H;

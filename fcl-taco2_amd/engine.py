@@ -179,6 +179,10 @@ def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_
     Returns a list of mel tensors [L_b, odim] (views into one packed device buffer)."""
     prep = prepare(plan, xs, durs, f0, energy)
     out = run(plan, prep, dropout_mode, prenet_keep, seed, bilstm_algo, return_intermediates)
+    import os
+
+    if bilstm_algo == 3 or os.environ.get("FCL_BILSTM_GROUP_INFER", "0") not in ("", "0"):
+        ops.check_status(plan.device)  # the cooperating-workgroup BiLSTM (opt-in, single-stream only) reports a timeout here, never silently
     after, utt_frames = out[0], out[1]
     mels, s = [], 0
     for n in utt_frames:

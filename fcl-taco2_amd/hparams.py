@@ -44,7 +44,20 @@ class HParams:
     variance_embed_dropout_rate: float = 0.5
     use_fe_condition: bool = True
     append_position: bool = True
-    use_masking: bool = True
+    use_masking: bool = True  # the shipped recipes (conf/*.yaml:25); the reference's argparse default is False (..._sa.py:251-262)
+    use_weighted_masking: bool = False
+
+    def check_loss_supported(self):
+        """The training / evaluation LOSSES on the HIP path are the masked means of the shipped recipes (Tacotron2Loss with use_masking,
+        ..._sa.py:60-70; prosody_criterions :122-126).  use_masking=False averages over padded positions as well and use_weighted_masking
+        re-weights per utterance: both are different objectives, so they fail loudly here instead of silently training the masked one.
+        Synthesis (inference / decode) does not depend on either flag and is not gated."""
+        bad = []
+        if not self.use_masking: bad.append("use_masking False (pass --use-masking true, as conf/*.yaml does)")
+        if self.use_weighted_masking: bad.append("use_weighted_masking True")
+        if bad:
+            raise NotImplementedError("fcl-taco2_amd HIP path: unsupported loss configuration: " + ", ".join(bad))
+        return self
 
     def check_supported(self):
         """The HIP path covers the shipped recipe only; anything else fails loudly."""

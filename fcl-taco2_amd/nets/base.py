@@ -72,7 +72,8 @@ def hparams_from_args(idim, odim, args):
         duration_predictor_layers=args.duration_predictor_layers, duration_predictor_chans=args.duration_predictor_chans,
         duration_predictor_kernel_size=args.duration_predictor_kernel_size,
         duration_predictor_dropout_rate=args.duration_predictor_dropout_rate,
-        use_fe_condition=args.use_fe_condition, append_position=args.append_position, use_masking=args.use_masking,
+        use_fe_condition=args.use_fe_condition, append_position=args.append_position, use_masking=bool(args.use_masking),
+        use_weighted_masking=bool(getattr(args, "use_weighted_masking", False)),
     ).check_supported()
 
 
@@ -334,7 +335,9 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
         eng.zero_grad()  # accumulation across micro-batches is autograd's job on this path (p.grad += ...)
         accum, eng.accum_grad = eng.accum_grad, 1
         try:
-            rep = eng.forward_backward(batch, teacher_knowledge, mode="train", masks=masks)
+            # reduce=False: on this path the gradients go to autograd (p.grad), so averaging them across ranks is the caller's optimizer-side
+            # job, exactly as with the reference's own updater; the engine's buckets stay idle
+            rep = eng.forward_backward(batch, teacher_knowledge, mode="train", masks=masks, reduce=False)
         finally:
             eng.accum_grad = accum
         order = ["l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss", "encoder_loss",

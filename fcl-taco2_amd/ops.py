@@ -142,7 +142,41 @@ def gather_rows(src, idx_i32):
     return dst
 
 
-def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0):
+_STATUS = {}
+
+
+def status_word(device):
+    """The per-device status word (int32 tensor used as a uint32; include/fcl_hip.h FCL_STATUS_*): kernels that can only detect a failure
+    while they run (the cooperating-workgroup BiLSTM's bounded spin) OR a bit into it; check_status() raises on it."""
+    key = str(torch.device(device))
+    w = _STATUS.get(key)
+    if w is None:
+        w = _STATUS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def status_message(bits):
+    msgs = []
+    if bits & _lib.STATUS_GROUP_TIMEOUT:
+        msgs.append("a cooperating-workgroup BiLSTM kernel timed out waiting for a group member (its outputs are partial); "
+                    "it is single-stream only — run one at a time or set FCL_BILSTM_GROUP=0")
+    if bits & ~_lib.STATUS_GROUP_TIMEOUT:
+        msgs.append("unknown status bits 0x%x" % (bits & ~_lib.STATUS_GROUP_TIMEOUT))
+    return "; ".join(msgs)
+
+
+def check_status(device, reset=True):
+    """Synchronising read of the device status word; raises FclError when a kernel reported a failure."""
+    w = status_word(device)
+    bits = int(w.item()) & 0xFFFFFFFF
+    if bits:
+        if reset:
+            w.zero_()
+        raise _lib.FclError("fcl-taco2_amd: device status 0x%x: %s" % (bits, status_message(bits)))
+
+
+def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0, status=None):
+    """status: device status word for algo 3 (default: the per-device word of status_word(); callers check it at their next sync point)."""
     c = x.shape[1]
     h = w_hh_f.shape[1]
     lib = _lib.load()
@@ -150,7 +184,7 @@ def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0):
     ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
     out = torch.empty(b * t, 2 * h, device=x.device, dtype=torch.float32)
     check(lib.fcl_bilstm_fwd(_p(x), _p(lens_i32, torch.int32), _p(w_ih_f), _p(w_hh_f), _p(b_f), _p(w_ih_r), _p(w_hh_r), _p(b_r), _p(out),
-                             b, t, c, h, algo, ws.data_ptr(), nbytes, _stream()))
+                             b, t, c, h, algo, ws.data_ptr(), nbytes, _p(status if status is not None else status_word(x.device), torch.int32), _stream()))
     return out
 
 
@@ -337,8 +371,10 @@ def sumsq_accum(x, out_f64):
     check(_lib.load().fcl_sumsq_accum(_p(x), x.numel(), out_f64.data_ptr(), _stream()))
 
 
-def adam_step(p, g, m, v, gradnorm_sq_f64, max_norm, lr, beta1, beta2, eps, step):
-    check(_lib.load().fcl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), gradnorm_sq_f64.data_ptr(), max_norm, lr, beta1, beta2, eps, step, _stream()))
+def adam_step(p, g, m, v, gradnorm_sq_f64, max_norm, lr, beta1, beta2, eps, step_i32, status=None):
+    """step_i32: device int32 count of APPLIED updates (advanced on the device only when this update is applied); status: device status word."""
+    check(_lib.load().fcl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), gradnorm_sq_f64.data_ptr(), max_norm, lr, beta1, beta2, eps,
+                                    _p(step_i32, torch.int32), _p(status, torch.int32), _stream()))
 
 
 def act_fwd(x, act, keep=None, keep_scale=1.0):
@@ -411,11 +447,12 @@ def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w
     check(lib.fcl_decoder_bptt(C.byref(a), _stream()))
 
 
-def bilstm_train_fwd(gx, w_hh, lens_i32, b, t, out, s):
-    """Both directions: gx / w_hh: (forward, reverse) pairs; s: per direction (gates, c_new, c_old, h_old), t-major."""
+def bilstm_train_fwd(gx, w_hh, lens_i32, b, t, out, s, status=None):
+    """Both directions: gx / w_hh: (forward, reverse) pairs; s: per direction (gates, c_new, c_old, h_old), t-major.
+    status: device status word (None: the cooperating-workgroup kernel for H = 256 is not used)."""
     lib = _lib.load()
     h = w_hh[0].shape[1]
-    a = _lib.BilstmTrain(b=b, t=t, h=h, lens=_p(lens_i32, torch.int32), out=_p(out))
+    a = _lib.BilstmTrain(b=b, t=t, h=h, lens=_p(lens_i32, torch.int32), out=_p(out), status=_p(status, torch.int32))
     for d in range(2):
         a.gx[d], a.w_hh[d] = _p(gx[d]), _p(w_hh[d])
         _ptrs(a.s[d], s[d])
@@ -425,10 +462,10 @@ def bilstm_train_fwd(gx, w_hh, lens_i32, b, t, out, s):
     check(lib.fcl_bilstm_train_fwd(C.byref(a), _stream()))
 
 
-def bilstm_bptt(s, lens_i32, b, t, d_out, w_hh_t, dg):
+def bilstm_bptt(s, lens_i32, b, t, d_out, w_hh_t, dg, status=None):
     lib = _lib.load()
     h = w_hh_t[0].shape[0]
-    a = _lib.BilstmBptt(b=b, t=t, h=h, lens=_p(lens_i32, torch.int32), d_out=_p(d_out), ld_dout=d_out.shape[1])
+    a = _lib.BilstmBptt(b=b, t=t, h=h, lens=_p(lens_i32, torch.int32), d_out=_p(d_out), ld_dout=d_out.shape[1], status=_p(status, torch.int32))
     for d in range(2):
         a.w_hh_t[d], a.dg[d] = _p(w_hh_t[d]), _p(dg[d])
         _ptrs(a.s[d], s[d][:3])

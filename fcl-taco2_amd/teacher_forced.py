@@ -154,6 +154,7 @@ def finish_base(m):
 
 
 def teacher_forward(plan, batch, **kw):
+    plan.hp.check_loss_supported()  # masked means only (use_masking True): anything else raises instead of silently computing this objective
     r = forward_pass(plan, batch, **kw)
     acc = LossAccumulator(plan.device)
     base_losses(acc, r)
@@ -171,6 +172,7 @@ def knowledge_tuple(r):
 
 def student_forward(plan, batch, teacher_knowledge, share_proj=True, distill=(True, True, True, True), **kw):
     """distill = (output, encoder, decoder, prosody) flags (..._kd_student.py:778-797)."""
+    plan.hp.check_loss_supported()
     r = forward_pass(plan, batch, **kw)
     dev = plan.device
     acc = LossAccumulator(dev, 48)

@@ -286,7 +286,7 @@ def train(argv=None):
                 know = teng.knowledge(batch, mode="train") if kd else None
                 if micro == 0:
                     eng.zero_grad()
-                rep = eng.forward_backward(batch, know, mode="train")
+                rep = eng.forward_backward(batch, know, mode="train", reduce=micro == eng.accum_grad - 1)  # all-reduce on the last micro-batch only
                 micro += 1
                 if micro == eng.accum_grad:  # tts.py:166-171
                     eng.optimizer_step()

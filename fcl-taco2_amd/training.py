@@ -62,17 +62,22 @@ class GradBuckets(object):
     def __init__(self, flat, bounds, group=None):
         import torch.distributed as dist
 
-        self.flat, self.bounds, self.group, self.work, self.staged = flat, bounds, group, [], []
+        self.flat, self.bounds, self.group, self.work, self.staged, self.launched = flat, bounds, group, [], [], set()
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         backend = dist.get_backend(group) if self.world > 1 else None
         self.avg = backend == "nccl"
         self.stage_host = backend == "gloo" and flat.is_cuda
 
     def launch(self, i):
+        """Start averaging bucket i.  Once per optimizer step: with gradient accumulation only the LAST micro-batch may launch (an in-flight
+        all-reduce must not overlap the next micro-batch's writes into the same gradient memory), so a second launch before finish() raises."""
         if self.world == 1:
             return
         import torch.distributed as dist
 
+        if i in self.launched:
+            raise RuntimeError("GradBuckets: bucket %d launched twice before finish() — reduce only on the last micro-batch of an accumulation" % i)
+        self.launched.add(i)
         a, b = self.bounds[i], self.bounds[i + 1]
         if b <= a:
             return
@@ -93,6 +98,9 @@ class GradBuckets(object):
         for w in self.work:
             w.wait()
         self.work = []
+        reduced, self.launched = bool(self.launched), set()
+        if not reduced:
+            return
         if self.world > 1 and not self.avg:
             (scale_fn or (lambda t, s: t.mul_(s)))(self.flat, 1.0 / self.world)
 
@@ -215,11 +223,15 @@ class LossReport(dict):
     """The named losses of a step.  The fp64 loss sums are copied to pinned host memory asynchronously; the dict fills itself on first access, so a
     training loop that only logs every N steps never stalls the CPU on the GPU (the .cpu() read-back used to cost a full pipeline drain per step)."""
 
-    def __init__(self, sums_dev, names, extra=None):
+    def __init__(self, sums_dev, names, extra=None, status_dev=None):
         super().__init__()
         self._names = list(names)
         self._host = torch.empty((len(names), 3), dtype=torch.float64, pin_memory=True)
         self._host.copy_(sums_dev[: len(names)], non_blocking=True)
+        self._status = None
+        if status_dev is not None:  # the device status word rides along: 4 bytes on the same stream
+            self._status = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            self._status.copy_(status_dev, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
         self._extra = dict(extra or {})
@@ -229,6 +241,13 @@ class LossReport(dict):
         if self._done:
             return self
         self._event.synchronize()
+        if self._status is not None:
+            bits = int(self._status.numpy()[0]) & 0xFFFFFFFF
+            if bits:
+                from ._lib import FclError
+
+                raise FclError("fcl-taco2_amd: device status 0x%x during this step (the parameter update was skipped on the device): %s"
+                               % (bits, ops.status_message(bits)))
         host = self._host.numpy()
         m = {n: (host[i, 0] / host[i, 2], host[i, 1] / host[i, 2]) for i, n in enumerate(self._names)}
         rep = dict(l1_loss=m["after"][0] + m["before"][0], mse_loss=m["after"][1] + m["before"][1], dur_loss=m["dur"][1], pitch_loss=m["pitch"][1],
@@ -288,6 +307,8 @@ class TrainEngine(object):
         if not p0.is_cuda:
             raise RuntimeError("fcl-taco2_amd: TrainEngine needs the model on a GPU (no CPU fallback)")
         self.model, self.hp, self.dev, self.role = model, model.hp, p0.device, model.role
+        if self.role != "kd_teacher":  # the frozen KD teacher computes no loss
+            self.hp.check_loss_supported()
         self.share_proj = bool(getattr(model, "share_proj", True))
         self.distill = tuple(bool(getattr(model, "distill_%s_knowledge" % k, True)) for k in ("output", "encoder", "decoder", "prosody"))
         pd = dict(model.named_parameters())
@@ -307,13 +328,25 @@ class TrainEngine(object):
         self.buckets = GradBuckets(self.gflat, bounds, group)
         self.B = dict(model.named_buffers())
         self.lr, self.eps, self.betas, self.grad_clip, self.accum_grad = lr, eps, betas, grad_clip, int(accum_grad)
-        self.step_count, self.forward_count, self.seed = 0, 0, int(seed)
+        self.forward_count, self.seed = 0, int(seed)
+        self.update_calls = 0  # optimizer_step() calls (host side; no sync)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)  # APPLIED updates = torch.optim.Adam's per-parameter `step`
+        self.status = ops.status_word(self.dev)  # shared per device: a failure reported by the frozen teacher's kernels stops this update too
         self.gn_sq = torch.zeros(1, dtype=torch.float64, device=self.dev)
         # weight gradients are off the critical path of backward (only the input-gradient chain is sequential): they are enqueued on a side
         # stream and joined at the end of backward / before a bucket's all-reduce
         self.overlap_dw = overlap_dw
         self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
         self._dw_keep = []
+
+    @property
+    def step_count(self):
+        """Updates actually applied (skipped NaN / failed steps do not count: tts.py:173-179).  Synchronising read of the device counter."""
+        return int(self.step_dev.item())
+
+    @step_count.setter
+    def step_count(self, v):
+        self.step_dev.fill_(int(v))
 
     def _dw(self, fn):
         """Run a weight-gradient closure on the side stream, after everything enqueued on the main stream so far.  The closure (and through it
@@ -331,7 +364,9 @@ class TrainEngine(object):
             torch.cuda.current_stream(self.dev).wait_stream(self.side)
             self._dw_keep.clear()  # main-stream reuse of these buffers is ordered after the join
 
-    def _launch_bucket(self, i):
+    def _launch_bucket(self, c, i):
+        if not c.reduce:  # a micro-batch that is not the last of its accumulation (or the autograd path): gradients stay local
+            return
         if self.buckets.world > 1:
             self._join_dw()
         self.buckets.launch(i)
@@ -464,7 +499,7 @@ class TrainEngine(object):
             g = lambda k: P["enc.blstm." + k]
             return ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), ops.add_vec(g("bias_ih_l0"), g("bias_hh_l0")),
                               g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), ops.add_vec(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
-                              B, T, algo=3 if H == 256 else 0), None  # single stream here: the 4-workgroup group kernel for FCL-taco2-T
+                              B, T, algo=3 if H == 256 else 0, status=self.status), None  # one group kernel at a time (this engine's stream)
         out = torch.empty(B * T, 2 * H, device=dev)
         gx, whh, sv = [], [], []
         for sfx in ("", "_reverse"):
@@ -473,7 +508,7 @@ class TrainEngine(object):
             whh.append(P["enc.blstm.weight_hh_l0" + sfx])
             # gates, c_new, c_old, h_old (t-major); zero-filled: dead cells are never written but are read by the batched weight-gradient GEMM
             sv.append([torch.zeros(T, B, 4 * H, device=dev)] + [torch.zeros(T, B, H, device=dev) for _ in range(3)])
-        ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv)
+        ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv, status=self.status)
         return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev, perm=perm)
 
     def _bilstm_bwd(self, d_out, c):
@@ -483,7 +518,7 @@ class TrainEngine(object):
         perm = c["perm"]  # (b, t) row -> t-major row of the saved / gradient tensors
         sfxs = ("", "_reverse")
         dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in sfxs]  # d_out is already zero on padded rows (masked by the caller); dead cells get dg = 0
-        ops.bilstm_bptt(c["dirs"], c["lens"], B, T, d_out, [self._wt(P["enc.blstm.weight_hh_l0" + sfx]) for sfx in sfxs], dgs)
+        ops.bilstm_bptt(c["dirs"], c["lens"], B, T, d_out, [self._wt(P["enc.blstm.weight_hh_l0" + sfx]) for sfx in sfxs], dgs, status=self.status)
         for d, sfx in enumerate(sfxs):
             dg2 = dgs[d].reshape(T * B, 4 * H)
             dgx = ops.gather_rows(dg2, perm)  # back to (b, t) rows like x
@@ -697,7 +732,7 @@ class TrainEngine(object):
         c.sums, c.loss_names = sums, names
 
     def _report(self, c):
-        return LossReport(c.sums, c.loss_names)
+        return LossReport(c.sums, c.loss_names, status_dev=self.status)
 
     # ------------------------------------------------------------------------------------------------ backward
     def _backward(self, c):
@@ -714,7 +749,7 @@ class TrainEngine(object):
                 ops.add2d(dx, inj["post%d" % i])
             dx = self._conv_bn_bwd(c, dx, c.post_c[i])
         ops.add2d(d_before, dx)
-        self._launch_bucket(0)
+        self._launch_bucket(c, 0)
         # ---- decoder BPTT
         d_out_cells = ops.gather_rows(d_before, c.cell_frame)  # [F, O]
         g_wf = G["dec.feat_out.weight"]
@@ -761,7 +796,7 @@ class TrainEngine(object):
         dp0 = ops.linear(dz1, self._wt(P[w1n]))
         dz0 = ops.act_bwd(dp0, c.p0, ops.ACT_RELU, c.k0, c.pks)
         self._dw(lambda: (ops.gemm_tn(dz0, c.pre_in, G[w0n]), ops.colsum(dz0, G[b0n])))
-        self._launch_bucket(1)
+        self._launch_bucket(c, 1)
         # ---- att = hs + p_embs + e_embs
         d_att = ops.gather_rows(d_att_c, c.row_of_enc)  # back to (b, t) rows; rows without a phoneme get 0
         d_hs = d_att.clone()
@@ -787,7 +822,7 @@ class TrainEngine(object):
         ops.add2d(d_hs, self._predictor_bwd(inj["d_outs"].reshape(-1), "duration_predictor", c.dur_c, c.enc_pad))
         ops.add2d(d_hs, self._predictor_bwd(inj["p_outs"].reshape(-1), "pitch_predictor", c.pit_c, c.enc_pad))
         ops.add2d(d_hs, self._predictor_bwd(inj["e_outs"].reshape(-1), "energy_predictor", c.en_c, c.enc_pad))
-        self._launch_bucket(2)
+        self._launch_bucket(c, 2)
         # ---- encoder
         if "hs" in inj:
             ops.add2d(d_hs, inj["hs"])
@@ -801,17 +836,17 @@ class TrainEngine(object):
             ops.add2d(dx, inj["enc0"])
         self._dw(lambda: ops.scatter_add_rows(dx, c.xs, G["enc.embed.weight"], skip=0))  # padding_idx = 0 gets no gradient
         self._join_dw()
-        self._launch_bucket(3)
+        self._launch_bucket(c, 3)
 
     # ------------------------------------------------------------------------------------------------ public API
     def zero_grad(self):
         self.gflat.zero_()
 
-    def _ctx(self, batch, mode, masks, save=True):
+    def _ctx(self, batch, mode, masks, save=True, reduce=True):
         if mode not in ("eval", "train"):
             raise ValueError("mode must be 'eval' or 'train'")
         c = _Ctx()
-        c.train, c.masks, c.save = mode == "train", masks, save
+        c.train, c.masks, c.save, c.reduce = mode == "train", masks, save, reduce
         self.forward_count += 1
         c.draw = self.forward_count
         self._maps(c, batch)
@@ -824,12 +859,15 @@ class TrainEngine(object):
             self._forward(c, batch)
             return self._knowledge(c)
 
-    def forward_backward(self, batch, teacher_knowledge=None, mode="eval", masks=None):
-        """One micro-batch: named losses (floats) and d(loss / accum_grad) accumulated into the flat gradient buffer."""
+    def forward_backward(self, batch, teacher_knowledge=None, mode="eval", masks=None, reduce=True):
+        """One micro-batch: named losses (floats) and d(loss / accum_grad) accumulated into the flat gradient buffer.
+        reduce: launch the data-parallel gradient all-reduce buckets as backward completes them.  With accum_grad > 1 pass True only for the
+        LAST micro-batch of an update (the earlier ones would race the in-flight collective and multiply the traffic); False keeps the
+        gradients local (optimizer_step() then averages nothing)."""
         if self.role == "student" and teacher_knowledge is None:
             raise ValueError("the student step needs teacher_knowledge (tts_distill.py:159-161)")
         with torch.cuda.device(self.dev):
-            c = self._ctx(batch, mode, masks)
+            c = self._ctx(batch, mode, masks, reduce=reduce)
             self._forward(c, batch)
             self._losses(c, teacher_knowledge)
             self._backward(c)
@@ -841,11 +879,11 @@ class TrainEngine(object):
             self.buckets.finish(lambda t, s: ops.scale_(t, s))
             self.gn_sq.zero_()
             ops.sumsq_accum(self.gflat, self.gn_sq)
-            self.step_count += 1
+            self.update_calls += 1
             ops.adam_step(self.pflat, self.gflat, self.mflat, self.vflat, self.gn_sq, self.grad_clip, self.lr, self.betas[0], self.betas[1], self.eps,
-                          self.step_count)
+                          self.step_dev, self.status)  # skipped on the device (counter included) on a NaN / inf norm or a non-zero status word
             self.model.refresh_plan()
-        return self.step_count
+        return self.update_calls
 
     def grad_norm(self):
         return float(torch.sqrt(self.gn_sq).item())

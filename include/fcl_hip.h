@@ -30,6 +30,10 @@ typedef void* fcl_stream_t;
 enum { FCL_OK = 0, FCL_ERR_INVALID = -1, FCL_ERR_SHAPE = -2, FCL_ERR_ALIGN = -3, FCL_ERR_HIP = -4, FCL_ERR_WORKSPACE = -5 };
 enum { FCL_ACT_NONE = 0, FCL_ACT_RELU = 1, FCL_ACT_TANH = 2 };
 enum { FCL_DROP_NONE = 0, FCL_DROP_MASK = 1, FCL_DROP_RNG = 2 };
+/* Bits of a DEVICE status word (uint32, caller-owned, zeroed by the caller): failures a kernel can only detect while it runs are OR-ed into
+ * it instead of being lost.  fcl_adam_step refuses to update the parameters while the word is non-zero; the host reads it back next to the
+ * losses (one 4-byte copy) and raises. */
+enum { FCL_STATUS_GROUP_TIMEOUT = 1 /* a cooperating-workgroup BiLSTM kernel gave up waiting for a group member: its outputs are partial */ };
 
 const char* fcl_last_error(void);
 int fcl_version(void);
@@ -111,11 +115,14 @@ int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n,
 /* x [B*T, C]; lens [B] int32 (device); w_ih_* [4H, C], w_hh_* [4H, H], b_* [4H] (= bias_ih + bias_hh);
  * out [B*T, 2H] = fwd | bwd, zero past each length.  algo: 0 auto, 1 per-step launches, 2 persistent
  * register-resident recurrence (H in {8,16,32,64,128}), 3 (H = 256) four cooperating workgroups per (utterance, direction)
- * exchanging h through global memory — fastest on an idle GPU, not the default when other streams are in flight. */
+ * exchanging h through global memory — fastest on an idle GPU, not the default when other streams are in flight.
+ * algo 3 is SINGLE-STREAM ONLY (two such kernels in flight can starve each other's groups) and needs `status`, a device status word
+ * (FCL_STATUS_*): a group that times out reports there and its outputs are partial.  It is refused (per-step launches instead) when
+ * 8*B workgroups do not fit the device one per CU.  status may be NULL for the other algorithms. */
 size_t fcl_bilstm_workspace_bytes(int b, int t, int h);
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
                    const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,
-                   int algo, void* workspace, size_t workspace_bytes, fcl_stream_t stream);
+                   int algo, void* workspace, size_t workspace_bytes, uint32_t* status, fcl_stream_t stream);
 
 /* ---- H7 as a single step: one LSTMCell (+ zoneout) update of M rows — the building block of the decoder loop, of the per-step
  *      BiLSTM, and of the TRAINING forward, which also saves what the backward pass needs (decoder_sa.py:63-96, 500-504) ------ */
@@ -305,6 +312,7 @@ typedef struct {
     float* s[2][4];                 /* saved, t-major: gates [T, B, 4H], c_new, c_old, h_old [T, B, H]; only live cells are written */
     void* workspace;                /* fcl_bilstm_train_workspace_bytes(b, h): used by the per-step fallback (H not in {8,16,32,64,128}) */
     size_t workspace_bytes;
+    uint32_t* status;               /* device status word (FCL_STATUS_*); NULL = never use the cooperating-workgroup kernel (H = 256) */
 } fcl_bilstm_train_t;
 typedef struct {
     int b, t, h;
@@ -316,6 +324,7 @@ typedef struct {
     float* dg[2];                   /* out, t-major [T, B, 4H]; dead cells are written as 0 */
     void* workspace;
     size_t workspace_bytes;
+    uint32_t* status;               /* as in fcl_bilstm_train_t */
 } fcl_bilstm_bptt_t;
 size_t fcl_decoder_train_workspace_bytes(int n, int u);
 int fcl_decoder_train_fwd(const fcl_decoder_train_t* args, fcl_stream_t stream);
@@ -339,10 +348,15 @@ int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new
 int fcl_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int m, int c, int64_t skip, fcl_stream_t stream);
 int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream);
 /* Optimizer (tts.py:173-182): *out += sum x^2 ; Adam step with clip_grad_norm_(max_norm) and the NaN guard taken from the
- * device-resident squared gradient norm, so the whole step stays on the stream. */
+ * device-resident squared gradient norm, so the whole step stays on the stream.
+ * step_dev: device int32 = number of updates APPLIED so far (torch's per-parameter `step`); the bias corrections use *step_dev + 1 and the
+ * counter advances only when the update is applied, exactly like the reference, which does not call optimizer.step() on a NaN norm
+ * (tts.py:173-179).  Deliberate deviation: an INFINITE norm is skipped as well — the reference would scale the gradients by 0, turn the
+ * overflowed entries into NaN (inf * 0) and write them into the parameters.  status (optional): the update is also skipped while the device
+ * status word is non-zero (a kernel of this step reported partial outputs). */
 int fcl_sumsq_accum(const float* x, size_t n, double* out, fcl_stream_t stream);
 int fcl_adam_step(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
-                  float beta2, float eps, int step, fcl_stream_t stream);
+                  float beta2, float eps, int32_t* step_dev, const uint32_t* status, fcl_stream_t stream);
 
 /* ---- measurement hook (bench.py's live roofline figures) ------------------------------- */
 /* While enabled, every GEMM / LSTM-step / BiLSTM launch is bracketed by HIP events on the stream it is

@@ -269,6 +269,43 @@ def test_accum_grad_two_micro_batches_equal_one_scaled_sum():
     assert max_abs(e1.gflat.cpu(), e2.gflat.cpu()) < 1e-5 * max(1.0, float(e1.gflat.abs().max()))
 
 
+def test_skipped_update_does_not_advance_adam_and_status_word_is_surfaced():
+    """tts.py:173-179: a NaN gradient norm skips optimizer.step(), so torch's per-parameter `step` (the bias-correction exponent, saved in
+    checkpoints) does not advance; same on the device counter.  A non-zero device status word (FCL_STATUS_*: a kernel reported partial
+    outputs) skips the update as well and raises when the step's report is read."""
+    from fcl_taco2_amd import ops
+    from fcl_taco2_amd._lib import FclError
+    from fcl_taco2_amd.training import TrainEngine
+
+    eng = TrainEngine(_model("teacher", TINY_T))
+    batch = _batch()
+    eng.train_step(batch)
+    assert eng.step_count == 1
+    w1 = eng.pflat.clone()
+    eng.zero_grad()
+    eng.forward_backward(batch)
+    eng.gflat[5] = float("nan")
+    eng.optimizer_step()
+    assert eng.step_count == 1 and torch.equal(eng.pflat, w1)  # skipped: counter and weights untouched
+    rep = eng.train_step(batch)
+    float(rep["loss"])
+    assert eng.step_count == 2 and not torch.equal(eng.pflat, w1)
+    w2 = eng.pflat.clone()
+    eng.status.fill_(1)  # what a timed-out group kernel does (FCL_STATUS_GROUP_TIMEOUT)
+    try:
+        rep = eng.train_step(batch)
+        with pytest.raises(FclError):
+            float(rep["loss"])
+        assert eng.step_count == 2 and torch.equal(eng.pflat, w2)
+        with pytest.raises(FclError):
+            ops.check_status(eng.dev)  # resets the word
+    finally:
+        eng.status.zero_()
+    ops.check_status(eng.dev)
+    eng.train_step(batch)
+    assert eng.step_count == 3
+
+
 def test_kd_pipeline_equals_sequential_updates():
     """KDPipeline (teacher one batch ahead on a second stream) takes the updates of the sequential loop: same device seeds, same batches -> the
     same losses and weights after three steps, up to the summation-order noise of the atomically accumulated gradients (a missing stream
@@ -314,11 +351,12 @@ def _ddp_worker(rank, world, port, q):
 
     ref = TrainEngine(_model("teacher", TINY_T))  # built before init_process_group: world 1, no exchange
     parts = []
-    for r in range(world):
+    for r in range(world + 2):
         ref.zero_grad()
         ref.forward_backward(batch_of(r))
         parts.append(ref.gflat.clone())
-    want = sum(parts) / world
+    want = sum(parts[:world]) / world
+    want_acc = sum((parts[r] + parts[r + 2]) / 2 for r in range(world)) / world  # accum_grad = 2: each micro-batch contributes loss / 2
     dist.init_process_group("gloo", rank=rank, world_size=world)
     eng = TrainEngine(_model("teacher", TINY_T))
     assert eng.buckets.world == world and eng.buckets.stage_host
@@ -332,6 +370,14 @@ def _ddp_worker(rank, world, port, q):
 
     eng2.buckets.finish(lambda t, s: ops.scale_(t, s))
     err = float((eng2.gflat - want).abs().max() / want.abs().max())
+    # accum_grad = 2 under data parallelism: only the LAST micro-batch launches the buckets (no collective in flight while the next
+    # micro-batch writes the gradient buffer, and the host-staged path must not collect a bucket twice)
+    eng3 = TrainEngine(_model("teacher", TINY_T), accum_grad=2)
+    eng3.zero_grad()
+    eng3.forward_backward(batch_of(rank), reduce=False)
+    eng3.forward_backward(batch_of(rank + 2), reduce=True)
+    eng3.buckets.finish(lambda t, s: ops.scale_(t, s))
+    err = max(err, float((eng3.gflat - want_acc).abs().max() / want_acc.abs().max()))
     gathered = [torch.zeros_like(w_after.cpu()) for _ in range(world)]
     dist.all_gather(gathered, w_after.cpu())
     same = all(torch.equal(gathered[0], g) for g in gathered)

@@ -76,3 +76,18 @@ def test_unsupported_configurations_fail_loudly():
     from fcl_taco2_amd import _lib
     with pytest.raises(_lib.FclError):  # no GPU here: inference must not fall back to torch CPU ops
         m.inference(torch.tensor([1, 2, 3]), None, dur=torch.tensor([1, 1, 1]))
+
+
+def test_loss_configuration_is_gated_loudly():
+    """ADVICE r1: use_masking=False (the reference's argparse default, ..._sa.py:251-262) and use_weighted_masking are different objectives;
+    the HIP path computes the masked means of the shipped recipes (conf/*.yaml:25) and must refuse the others instead of silently ignoring them.
+    Synthesis does not depend on the flags: check_supported() (plan building) still passes."""
+    import pytest
+
+    from fcl_taco2_amd import hparams as HP
+
+    HP.student_hparams().check_supported().check_loss_supported()
+    for kw in (dict(use_masking=False), dict(use_weighted_masking=True, use_masking=False), dict(use_weighted_masking=True)):
+        hp = HP.student_hparams(**kw).check_supported()
+        with pytest.raises(NotImplementedError):
+            hp.check_loss_supported()

@@ -78,7 +78,23 @@ def _grad_worker(rank, world, port, q):
     for i in range(len(bounds) - 1):  # the engine launches bucket i when backward has finished group i
         b.launch(i)
     b.finish()
-    q.put((rank, bounds, mine.numpy(), flat.numpy()))
+    # gradient accumulation (accum_grad = 2): micro-batch 1 only accumulates, the buckets are launched by the LAST micro-batch, once each
+    rs = np.random.RandomState(200 + rank)
+    m1, m2 = (torch.from_numpy(rs.randn(int(offs[-1])).astype(np.float32)) for _ in range(2))
+    acc = torch.zeros(int(offs[-1]))
+    b2 = GradBuckets(acc, bounds)
+    acc += m1  # micro-batch 1: reduce=False, nothing launched
+    acc += m2  # micro-batch 2 ...
+    for i in range(len(bounds) - 1):
+        b2.launch(i)  # ... launches as its backward completes each group
+    twice = False
+    try:
+        b2.launch(0)  # a second launch before finish() is the race ADVICE r1 describes: it must be loud
+    except RuntimeError:
+        twice = True
+    b2.finish()
+    b2.finish()  # nothing launched since: must not rescale again
+    q.put((rank, bounds, mine.numpy(), flat.numpy(), (m1 + m2).numpy(), acc.numpy(), twice))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -99,7 +115,9 @@ def test_two_rank_gradient_buckets_average():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, bounds, g0, avg0), (_, _, g1, avg1) = res
+    (_, bounds, g0, avg0, s0, acc0, tw0), (_, _, g1, avg1, s1, acc1, tw1) = res
+    assert tw0 and tw1  # double launch raises
+    assert np.array_equal(acc0, acc1) and np.allclose(acc0, (s0 + s1) / 2, atol=1e-6)  # accum_grad=2: mean over ranks of the accumulated sums, once
     assert bounds[0] == 0 and bounds[-1] == g0.shape[0] and all(a <= b for a, b in zip(bounds, bounds[1:])) and len(bounds) == len(_GROUPS) + 1
     assert np.array_equal(avg0, avg1)  # every rank ends with the same gradients -> same grad-norm -> all skip / step together (tts.py:173-178)
     assert np.allclose(avg0, (g0 + g1) / 2, atol=1e-7)
