@@ -168,18 +168,23 @@ def test_scatter_add_and_adam_step(ops):
     pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
     opt = torch.optim.Adam([pt], lr=1e-3, eps=1e-6, weight_decay=0.0)
     p, m, v = dev(p0.copy()), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=DEV)  # applied updates, advanced on the device
     for step, gnp in enumerate(grads, 1):
         pt.grad = torch.from_numpy(gnp.copy())
         torch.nn.utils.clip_grad_norm_([pt], 1.0)
         opt.step()
         nsq = torch.zeros(1, dtype=torch.float64, device=DEV)
         ops.sumsq_accum(dev(gnp), nsq)
-        ops.adam_step(p, dev(gnp), m, v, nsq, 1.0, 1e-3, 0.9, 0.999, 1e-6, step)
-        assert max_abs(p.cpu(), pt.detach()) < 2e-6
+        ops.adam_step(p, dev(gnp), m, v, nsq, 1.0, 1e-3, 0.9, 0.999, 1e-6, step_dev)
+        assert max_abs(p.cpu(), pt.detach()) < 2e-6 and int(step_dev.item()) == step
     nan = torch.full((1,), float("nan"), dtype=torch.float64, device=DEV)
     before = p.clone()
-    ops.adam_step(p, dev(grads[0]), m, v, nan, 1.0, 1e-3, 0.9, 0.999, 1e-6, 3)  # NaN grad norm -> the step is skipped (tts.py:175-178)
-    assert torch.equal(p, before)
+    ops.adam_step(p, dev(grads[0]), m, v, nan, 1.0, 1e-3, 0.9, 0.999, 1e-6, step_dev)  # NaN grad norm -> the step is skipped (tts.py:175-178)
+    assert torch.equal(p, before) and int(step_dev.item()) == 2  # ... and does not count (torch's per-parameter `step` would not advance either)
+    status = torch.ones(1, dtype=torch.int32, device=DEV)
+    nsq = torch.ones(1, dtype=torch.float64, device=DEV)
+    ops.adam_step(p, dev(grads[0]), m, v, nsq, 1.0, 1e-3, 0.9, 0.999, 1e-6, step_dev, status)  # non-zero device status word -> skipped as well
+    assert torch.equal(p, before) and int(step_dev.item()) == 2
 
 
 @pytest.mark.parametrize("m,n,k", [(1, 16, 256), (7, 100, 260), (16, 256, 1024), (33, 256, 1024), (64, 1024, 512)])
