@@ -21,24 +21,26 @@ class DecoderWeights(C.Structure):
         (n, _P) for n in ("prenet_w0", "prenet_b0", "prenet_w1", "prenet_b1", "w0_att", "w0_pre", "w0_pos", "w0_hh", "b0",
                           "w1_ih", "w1_hh", "b1", "wf_h", "wf_att")
     ] + [("zoneout_rate", _F), ("prenet_dropout", _F)] + [
-        (n + sfx, _P) for n in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h") for sfx in ("_hi", "_lo")]
+        (n + sfx, _P) for n in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h") for sfx in ("_hi", "_lo")] + [
+        (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")]
 
 
 class DecoderIO(C.Structure):
     _fields_ = [("n", _I), ("lmax", _I), ("att_c", _P), ("dur", _P), ("live_rows_host", _P), ("frame_off", _P),
                 ("teacher_ys", _P), ("dropout_mode", _I), ("prenet_keep", _P), ("seed", C.c_uint32), ("seed_dev", _P), ("before", _P),
-                ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+                ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z), ("att_c_p", _P), ("before_p", _P)]
 
 
 class GemmTerm(C.Structure):
-    _fields_ = [("A", _P), ("W", _P), ("lda", _I), ("ldw", _I), ("K", _I), ("shift", _I), ("Whi", _P), ("Wlo", _P)]
+    _fields_ = [("A", _P), ("W", _P), ("lda", _I), ("ldw", _I), ("K", _I), ("shift", _I), ("Whi", _P), ("Wlo", _P), ("Ap", _P), ("Wp", _P),
+                ("lda_p", _I), ("ldw_p", _I)]
 
 
 class LstmStep(C.Structure):
     _fields_ = [("term", GemmTerm * 3), ("nterms", _I), ("M", _I), ("U", _I), ("G", _P), ("g_row_mul", C.c_longlong), ("g_row_add", C.c_longlong),
                 ("bias", _P), ("rank1_w", _P), ("dur", _P), ("step", _I), ("h_in", _P), ("h_out", _P), ("c", _P), ("zoneout", _F),
                 ("zone_keep_h", _P), ("zone_keep_c", _P), ("row_len", _P), ("out2", _P), ("out2_row_base", _P), ("out2_row_mul", C.c_longlong),
-                ("out2_row_add", C.c_longlong), ("ld2", _I), ("out2_col_off", _I), ("save_gates", _P), ("save_c_new", _P), ("save_c_old", _P),
+                ("out2_row_add", C.c_longlong), ("ld2", _I), ("out2_col_off", _I), ("h_out_p", _P), ("ld_hp", _I), ("save_gates", _P), ("save_c_new", _P), ("save_c_old", _P),
                 ("save_h_old", _P)]
 
 
@@ -79,16 +81,20 @@ SIGNATURES = {
     "fcl_pack_frag_bf16": (_I, [_P, _I, _I, _P, _P, _P]),
     "fcl_add_vec": (_I, [_P, _P, _P, _I, _P]),
     "fcl_u32_add": (_I, [_P, C.c_uint32, _P]),
-    "fcl_embedding_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "fcl_planes_elems": (_Z, [_I, _I]),
+    "fcl_pack_planes": (_I, [_P, _I, _I, _I, _P, _P]),
+    "fcl_linear_planes_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "fcl_conv1d_planes_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "fcl_embedding_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "fcl_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcl_conv1d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "fcl_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
+    "fcl_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "fcl_duration_round_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P]),
     "fcl_variance_embed_add_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "fcl_position_table_fwd": (_I, [_P, _P, _I, _I, _P]),
-    "fcl_gather_rows_fwd": (_I, [_P, _P, _P, _I, _I, _P]),
+    "fcl_gather_rows_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "fcl_bilstm_workspace_bytes": (_Z, [_I, _I, _I]),
-    "fcl_bilstm_fwd": (_I, [_P] * 9 + [_I, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    "fcl_bilstm_fwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _Z, _P, _P]),
     "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
     "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
     "fcl_masked_l1_mse_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),

@@ -20,7 +20,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int H, bool SAVE = false>
 __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
                                                                    const float* __restrict__ whh_f, const float* __restrict__ whh_r,
-                                                                   const int* __restrict__ lens, float* __restrict__ out, int T, BilstmSave sv = BilstmSave()) {
+                                                                   const int* __restrict__ lens, float* __restrict__ out, int T, BilstmSave sv = BilstmSave(),
+                                                                   unsigned short* __restrict__ out_p = nullptr /* optional P32 planes of out */) {
     __shared__ __attribute__((aligned(16))) float h_s[H];
     __shared__ float g_s[4 * H];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
@@ -37,8 +38,10 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
     if (j < H) h_s[j] = 0.f;
     float c = 0.f;
     // zero the padded tail of this direction's half of the output rows
-    for (int t = len + (j / H); t < T; t += 4)
+    for (int t = len + (j / H); t < T; t += 4) {
         out[((size_t)b * T + t) * (2 * H) + dir * H + (j % H)] = 0.f;
+        if (out_p) store_p32(out_p, (2 * H + 31) >> 5, b * T + t, dir * H + (j % H), 0.f);
+    }
     __syncthreads();
 
     int t = dir ? len - 1 : 0;
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
             const float h = og * tanh_f(c);
             h_s[j] = h;
             out[((size_t)b * T + t) * (2 * H) + dir * H + j] = h;
+            if (out_p) store_p32(out_p, (2 * H + 31) >> 5, b * T + t, dir * H + j, h);
         }
         __syncthreads();
     }
@@ -387,9 +391,13 @@ size_t fcl_bilstm_workspace_bytes(int b, int t, int h) {
 }
 
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
-                   const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,
+                   const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, uint16_t* out_p, const uint16_t* x_p,
+                   const uint16_t* w_ih_f_p, const uint16_t* w_ih_r_p, int b, int t, int c, int h,
                    int algo, void* workspace, size_t workspace_bytes, uint32_t* status, fcl_stream_t stream) {
-    FCL_REQUIRE(x && lens && w_ih_f && w_hh_f && b_f && w_ih_r && w_hh_r && b_r && out, FCL_ERR_INVALID, "bilstm_fwd: null argument");
+    FCL_REQUIRE((x || x_p) && lens && w_ih_f && w_hh_f && b_f && w_ih_r && w_hh_r && b_r && out, FCL_ERR_INVALID, "bilstm_fwd: null argument");
+    FCL_REQUIRE((x_p == nullptr) == (w_ih_f_p == nullptr) && (x_p == nullptr) == (w_ih_r_p == nullptr), FCL_ERR_INVALID,
+                "bilstm_fwd: x_p / w_ih_f_p / w_ih_r_p come together");
+    FCL_REQUIRE(x || x_p, FCL_ERR_INVALID, "bilstm_fwd: no input");
     FCL_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && (c & 3) == 0 && (h & 3) == 0, FCL_ERR_SHAPE, "bilstm_fwd: bad sizes B=%d T=%d C=%d H=%d", b, t, c, h);
     FCL_REQUIRE(workspace && workspace_bytes >= fcl_bilstm_workspace_bytes(b, t, h), FCL_ERR_WORKSPACE, "bilstm_fwd: workspace too small");
     FCL_REQUIRE(aligned16(workspace) && aligned16(out), FCL_ERR_ALIGN, "bilstm_fwd: 16-byte alignment required");
@@ -402,6 +410,11 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     for (int d = 0; d < 2; ++d) {
         GemmArgs g = {};
         g.term[0] = GemmTerm{x, d ? w_ih_r : w_ih_f, c, c, c, 0};
+        if (x_p && w_ih_f_p && w_ih_r_p) {  // pre-split operands of the input projection (written by the last encoder convolution / at plan time)
+            g.term[0].Ap = x_p;
+            g.term[0].Wp = d ? w_ih_r_p : w_ih_f_p;
+            g.term[0].lda_p = g.term[0].ldw_p = (c + 31) / 32;
+        }
         g.nterms = 1;
         g.M = b * t;
         g.N = 4 * h;
@@ -421,7 +434,10 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
         void* gws = hbuf;  // the Gx buffers are final, so the tail of the workspace (per-step state of algo 1) is free for the flags and the exchange buffer
         const size_t gbytes = workspace_bytes - sizeof(float) * ((size_t)2 * b * t * 4 * h);
         ProfScope ps("bilstm_group_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
-        if (launch_bilstm_group(gx_f, gx_r, w_hh_f, w_hh_r, lens, out, b, t, h, nullptr, gws, gbytes, status, s)) return check_hip(hipGetLastError(), "bilstm group launch");
+        if (launch_bilstm_group(gx_f, gx_r, w_hh_f, w_hh_r, lens, out, b, t, h, nullptr, gws, gbytes, status, s)) {
+            FCL_HIP(hipGetLastError());
+            return out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0;
+        }
     }
     if (algo == 0 || algo == 3) algo = can_persist ? 2 : 1;
     FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);
@@ -429,7 +445,7 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
         ProfScope ps("bilstm_persistent_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
         dim3 grid(b, 2);
 #define FCL_BILSTM_CASE(HH) \
-    case HH: hipLaunchKernelGGL((bilstm_persistent_kernel<HH>), grid, dim3(4 * HH), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t); break;
+    case HH: hipLaunchKernelGGL((bilstm_persistent_kernel<HH>), grid, dim3(4 * HH), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t, BilstmSave(), out_p); break;
         switch (h) {
             FCL_BILSTM_CASE(8)
             FCL_BILSTM_CASE(16)
@@ -471,7 +487,7 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
             cur ^= 1;
         }
     }
-    return 0;
+    return out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0;  // the per-step path writes fp32 only: split once at the end
 }
 
 }  // extern "C"

@@ -68,12 +68,18 @@ __global__ void zero_kernel(float* p, long long n) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
 
-static inline size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
+static inline size_t align_up(size_t x) { return (x + 127) & ~(size_t)127; }  // P32 planes want 128-byte lines
 
 struct DecoderWs {
     float *G0, *F0, *pre_a, *pre_b, *h0[2], *c0, *h1[2], *c1, *prev;
-    size_t bytes;
+    unsigned short *h0_p[2], *h1_p[2], *pre_p;  // P32 planes of the recurrent states / the prenet output (the LSTM steps' pre-split operands)
+    size_t bytes, state_bytes;                  // state_bytes: h0 .. h1_p, zeroed before the loop
 };
+
+// P32 planes are used by the decoder loop when the plan provides them and the widths are whole 32-column lines
+static bool decoder_planes(const fcl_decoder_weights_t* w) {
+    return w->w0_att_p && w->wf_att_p && w->w0_pre_p && w->w0_hh_p && w->w1_ih_p && w->w1_hh_p && !(w->c & 31) && !(w->p & 31) && !(w->u & 31);
+}
 
 static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
     DecoderWs ws;
@@ -96,6 +102,11 @@ static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
     ws.h1[1] = take(N * w->u);
     ws.c1 = take(N * w->u);
     ws.prev = take(N * w->odim);
+    // planes of the states: as many bytes as their fp32 form (2 x 2 bytes per element); contiguous with the states so one kernel zeroes all
+    for (int i = 0; i < 2; ++i) ws.h0_p[i] = reinterpret_cast<unsigned short*>(take(N * w->u));
+    for (int i = 0; i < 2; ++i) ws.h1_p[i] = reinterpret_cast<unsigned short*>(take(N * w->u));
+    ws.state_bytes = off - (size_t)(reinterpret_cast<char*>(ws.h0[0]) - reinterpret_cast<char*>(base));
+    ws.pre_p = reinterpret_cast<unsigned short*>(take(N * w->p));
     ws.bytes = off;
     return ws;
 }
@@ -145,6 +156,46 @@ int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int
     g.ldr = cout;
     g.Y = y;
     g.ldy = cout;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fcl_linear_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, float* y, int ldy, uint16_t* yp,
+                          int m, int n, int k, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(xp && wpp && (y || yp), FCL_ERR_INVALID, "linear_planes_fwd: null argument");
+    FCL_REQUIRE(act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "linear_planes_fwd: bad act %d", act);
+    FCL_REQUIRE(ldxp * 32 >= k && (!y || ldy >= n), FCL_ERR_SHAPE, "linear_planes_fwd: leading dimensions too small");
+    GemmArgs g = {};
+    g.term[0].K = k;
+    g.term[0].Ap = xp; g.term[0].lda_p = ldxp;
+    g.term[0].Wp = wpp; g.term[0].ldw_p = (k + 31) / 32;
+    g.nterms = 1;
+    g.M = m; g.N = n; g.bias = bias; g.act = act;
+    g.Y = y; g.ldy = ldy;
+    g.Yp = yp; g.ldyp = (n + 31) / 32;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
+                          const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(xp && wpp && (y || yp) && seg_lo && seg_hi, FCL_ERR_INVALID, "conv1d_planes_fwd: null argument");
+    FCL_REQUIRE(k >= 1 && (k & 1) && k <= FCL_MAX_TERMS, FCL_ERR_SHAPE, "conv1d_planes_fwd: kernel size %d must be odd and <= %d", k, FCL_MAX_TERMS);
+    FCL_REQUIRE(act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "conv1d_planes_fwd: bad act %d", act);
+    FCL_REQUIRE(ldxp * 32 >= cin, FCL_ERR_SHAPE, "conv1d_planes_fwd: input planes narrower than Cin");
+    const int ldw = (cin + 31) / 32;
+    GemmArgs g = {};
+    for (int j = 0; j < k; ++j) {
+        g.term[j].K = cin;
+        g.term[j].shift = j - (k - 1) / 2;
+        g.term[j].Ap = xp; g.term[j].lda_p = ldxp;
+        g.term[j].Wp = wpp + (size_t)j * cout * ldw * 64; g.term[j].ldw_p = ldw;
+    }
+    g.nterms = k;
+    g.M = m; g.N = cout;
+    g.seg_lo = seg_lo; g.seg_hi = seg_hi;
+    g.bias = bias; g.act = act;
+    g.R = residual; g.ldr = cout;
+    g.Y = y; g.ldy = cout;
+    g.Yp = yp; g.ldyp = (cout + 31) / 32;
     return launch_gemm(g, (hipStream_t)stream);
 }
 
@@ -200,7 +251,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
                 FCL_ERR_INVALID, "decoder_loop_fwd: null weight pointer");
     FCL_REQUIRE(io->n >= 0 && io->lmax >= 0, FCL_ERR_SHAPE, "decoder_loop_fwd: bad N=%d Lmax=%d", io->n, io->lmax);
     if (io->n == 0 || io->lmax == 0) return 0;
-    FCL_REQUIRE(io->att_c && io->dur && io->live_rows_host && io->frame_off && io->before, FCL_ERR_INVALID, "decoder_loop_fwd: null io pointer");
+    FCL_REQUIRE((io->att_c || io->att_c_p) && io->dur && io->live_rows_host && io->frame_off && io->before, FCL_ERR_INVALID, "decoder_loop_fwd: null io pointer");
     FCL_REQUIRE(io->dropout_mode >= FCL_DROP_NONE && io->dropout_mode <= FCL_DROP_RNG, FCL_ERR_INVALID, "decoder_loop_fwd: bad dropout_mode");
     FCL_REQUIRE(io->dropout_mode != FCL_DROP_MASK || io->prenet_keep, FCL_ERR_INVALID, "decoder_loop_fwd: FCL_DROP_MASK needs prenet_keep");
     FCL_REQUIRE(w->prenet_dropout >= 0.f && w->prenet_dropout < 1.f, FCL_ERR_INVALID, "decoder_loop_fwd: bad prenet_dropout");
@@ -220,21 +271,28 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
     DecoderWs ws = carve(w, N, io->workspace);
 
     // zero recurrent state (h0[2], c0, h1[2], c1 are contiguous) and prev_out
+    static const bool planes_on = tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0;
+    const bool planes = decoder_planes(w) && io->att_c_p != nullptr && planes_on;
+    FCL_REQUIRE(planes || io->att_c, FCL_ERR_INVALID, "decoder_loop_fwd: att_c is required when the P32 path is off");
+    FCL_REQUIRE(!io->before_p || planes, FCL_ERR_INVALID, "decoder_loop_fwd: before_p needs the P32 weight planes and att_c_p");
     {
-        const long long n_state = (long long)((char*)ws.prev - (char*)ws.h0[0]) / 4 + (long long)N * O;
-        hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, ws.h0[0], n_state);
+        hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, ws.h0[0], (long long)(ws.state_bytes / 4));
         FCL_HIP(hipGetLastError());
     }
+    const int ldc = C / 32, ldp = P / 32, ldu = U / 32;  // plane strides in 128-byte lines (planes mode: whole lines)
+    auto small_step = [&](int m) { return lstm_step_is_small(m, U); };  // launch_lstm_step's own choice: small steps read the fp32 operands
     // loop-invariant hoists: att_c is constant across steps, so its share of the LSTM-0
     // gate pre-activations and of feat_out is one GEMM each instead of Lmax of them.
     {
         GemmArgs g = {};
         g.term[0] = GemmTerm{io->att_c, w->w0_att, C, C, C, 0};
+        if (planes) { g.term[0].Ap = io->att_c_p; g.term[0].Wp = w->w0_att_p; g.term[0].lda_p = g.term[0].ldw_p = ldc; }
         g.nterms = 1; g.M = N; g.N = 4 * U; g.bias = w->b0; g.Y = ws.G0; g.ldy = 4 * U;
         int rc = launch_gemm(g, s);
         if (rc) return rc;
         GemmArgs f = {};
         f.term[0] = GemmTerm{io->att_c, w->wf_att, C, C, C, 0};
+        if (planes) { f.term[0].Ap = io->att_c_p; f.term[0].Wp = w->wf_att_p; f.term[0].lda_p = f.term[0].ldw_p = ldc; }
         f.nterms = 1; f.M = N; f.N = O; f.Y = ws.F0; f.ldy = O;
         rc = launch_gemm(f, s);
         if (rc) return rc;
@@ -263,6 +321,10 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             fp.w1_hi = w->prenet_w1_hi; fp.w1_lo = w->prenet_w1_lo;
             fp.drop_mode = drop_mode; fp.keep0 = keep0; fp.keep1 = keep1; fp.keep_scale = keep_scale; fp.drop_p = w->prenet_dropout;
             fp.seed0 = seed0; fp.seed1 = seed1; fp.seed_dev = io->seed_dev; fp.pre_out = ws.pre_b; fp.tap_prenet = io->tap_prenet;
+            if (planes) {
+                fp.before_p = io->before_p;
+                if (!small_step(n)) { fp.pre_out_p = ws.pre_p; fp.pre_out = nullptr; }  // the big-tile LSTM step reads planes only
+            }
             rc = launch_feat_prenet(fp, s);
             if (rc) return rc;
         } else {
@@ -294,8 +356,15 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
         if (t == io->lmax) break;
         // H7 layer 0: gates = G0 + prenet . W_pre^T + pos * w_pos + h0 . W_hh^T ; cell ; zoneout
         LstmStepArgs l0 = {};
+        const bool big = planes && !small_step(n);  // big steps: pre-split operands through the LDS-DMA kernels; their outputs feed the next step's
+        const bool next_big = planes && t + 1 < io->lmax && !small_step(io->live_rows_host[t + 1]);
         l0.term[0] = GemmTerm{ws.pre_b, w->w0_pre, P, P, P, 0, w->w0_pre_hi, w->w0_pre_lo};
         l0.term[1] = GemmTerm{ws.h0[cur], w->w0_hh, U, U, U, 0, w->w0_hh_hi, w->w0_hh_lo};
+        if (big) {
+            l0.term[0].Ap = ws.pre_p; l0.term[0].Wp = w->w0_pre_p; l0.term[0].lda_p = l0.term[0].ldw_p = ldp;
+            l0.term[1].Ap = ws.h0_p[cur]; l0.term[1].Wp = w->w0_hh_p; l0.term[1].lda_p = l0.term[1].ldw_p = ldu;
+            l0.h_out_p = ws.h0_p[cur ^ 1]; l0.ld_hp = ldu;  // read by layer 1 now and by layer 0 of the next step
+        }
         l0.nterms = 2; l0.M = n; l0.U = U; l0.G = ws.G0; l0.g_row_mul = 1; l0.g_row_add = 0;
         l0.rank1_w = w->w0_pos; l0.dur = io->dur; l0.step = t;
         l0.h_in = ws.h0[cur]; l0.h_out = ws.h0[cur ^ 1]; l0.c = ws.c0; l0.zoneout = w->zoneout_rate;
@@ -306,6 +375,11 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
         LstmStepArgs l1 = {};
         l1.term[0] = GemmTerm{ws.h0[cur ^ 1], w->w1_ih, U, U, U, 0, w->w1_ih_hi, w->w1_ih_lo};
         l1.term[1] = GemmTerm{ws.h1[cur], w->w1_hh, U, U, U, 0, w->w1_hh_hi, w->w1_hh_lo};
+        if (big) {
+            l1.term[0].Ap = ws.h0_p[cur ^ 1]; l1.term[0].Wp = w->w1_ih_p; l1.term[0].lda_p = l1.term[0].ldw_p = ldu;
+            l1.term[1].Ap = ws.h1_p[cur]; l1.term[1].Wp = w->w1_hh_p; l1.term[1].lda_p = l1.term[1].ldw_p = ldu;
+            if (next_big) { l1.h_out_p = ws.h1_p[cur ^ 1]; l1.ld_hp = ldu; }
+        }
         l1.nterms = 2; l1.M = n; l1.U = U; l1.bias = w->b1; l1.step = t;
         l1.h_in = ws.h1[cur]; l1.h_out = ws.h1[cur ^ 1]; l1.c = ws.c1; l1.zoneout = w->zoneout_rate;
         if (io->tap_lstm1) { l1.out2 = io->tap_lstm1; l1.out2_row_base = io->frame_off; l1.out2_row_add = t; l1.ld2 = U; }

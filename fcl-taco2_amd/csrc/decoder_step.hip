@@ -386,8 +386,16 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
                 if (m < a.M_feat && nc < a.O) {
                     v = accv[0][r] + f0v[r];
                     a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
+                    if (a.before_p) store_p32(a.before_p, (a.O + 31) >> 5, fo[r] + a.t_prev, nc, v);
                 }
                 if (nc < a.O) split1(v, A2h[row * ldO + nc], A2l[row * ldO + nc]);
+            }
+        }
+        if (a.before_p && (a.O & 31)) {  // zero padding of the last 32-column line of this tile's frames
+            const int padc = 32 - (a.O & 31);
+            for (int i = threadIdx.x; i < 16 * padc; i += blockDim.x) {
+                const int m = m0 + i / padc;
+                if (m < a.M_feat) store_p32(a.before_p, (a.O + 31) >> 5, a.frame_off[m] + a.t_prev, a.O + i % padc, 0.f);
             }
         }
     } else {
@@ -445,7 +453,8 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
                     if (m >= a.M_pre) continue;
                     float v = fmaxf(accv[tt][r] + bn, 0.f);
                     v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
-                    a.pre_out[(size_t)m * a.P + nc] = v;
+                    if (a.pre_out) a.pre_out[(size_t)m * a.P + nc] = v;
+                    if (a.pre_out_p) store_p32(a.pre_out_p, (a.P + 31) >> 5, m, nc, v);
                     if (a.tap_prenet) a.tap_prenet[(size_t)(a.frame_off[m] + a.t_cur) * a.P + nc] = v;
                 }
             }
@@ -733,6 +742,9 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
     if (a.h1) fl += 2.0 * a.M_feat * a.O * a.U;
     if (a.w0) fl += 2.0 * a.M_pre * ((double)a.P * a.O + (double)a.P * a.P);
     const bool planes = a.wf_hi && a.wf_lo && a.w0_hi && a.w0_lo && a.w1_hi && a.w1_lo && !(a.U & 7) && !(a.O & 7) && !(a.P & 7);
+    FCL_REQUIRE(planes || (!a.pre_out_p && !a.before_p), FCL_ERR_INVALID, "feat_prenet: P32 outputs need the bf16x3 weight planes");
+    FCL_REQUIRE(!a.w0 || a.pre_out || a.pre_out_p, FCL_ERR_INVALID, "feat_prenet: no prenet output buffer");
+    FCL_REQUIRE(!a.pre_out_p || !(a.P & 31), FCL_ERR_SHAPE, "feat_prenet: P32 prenet output needs P %% 32 == 0");
     if (planes) {
         const size_t lds3 = 2 * sizeof(unsigned short) * 16 * ((size_t)(a.U + 8) + (a.O + 8) + (a.P + 8));
         {

@@ -63,6 +63,8 @@ struct GemmArgs {
     int ldy2;
     const int* y2_row_base;
     int y2_row_add;
+    unsigned short* Yp;  // optional P32 planes of the output (ldyp lines per row, written up to the padded width); Y may then be null
+    int ldyp;
 };
 
 // ---- fused LSTM step (gemm_f32.hip / decoder_step.hip): the argument block is the public fcl_lstm_step_t ----------
@@ -103,8 +105,10 @@ struct FeatPrenetArgs {
     float keep_scale, drop_p;
     unsigned int seed0, seed1;
     const unsigned int* seed_dev;  // optional device word added to both seeds
-    float* pre_out;     // [M_pre, P]
+    float* pre_out;     // [M_pre, P] (optional when pre_out_p is given)
     float* tap_prenet;  // optional [F, P]; row = frame_off[m] + t_cur
+    unsigned short* pre_out_p;  // optional P32 planes of pre_out (ceil(P/32) lines per row): the next LSTM step's pre-split operand
+    unsigned short* before_p;   // optional P32 planes of `before` (ceil(O/32) lines per row, zero past O): the postnet's pre-split operand
 };
 
 // ---- bf16x3 operand split shared by the big-tile GEMMs (gemm_f32.hip) and the weight-gradient GEMM (backward.hip) ------------------
@@ -152,8 +156,19 @@ bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_
                          const BilstmSave* sv, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s);
 bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s);
 
+// P32 planes (include/fcl_hip.h "bf16x3 operand planes"): element (row m, column n) of a buffer with ld lines per row
+__device__ __forceinline__ void store_p32(unsigned short* __restrict__ p, int ld, int m, int n, float v) {
+    const __bf16 h = (__bf16)v;
+    unsigned short* line = p + ((size_t)m * ld + (n >> 5)) * 64 + (n & 31);
+    line[0] = __builtin_bit_cast(unsigned short, h);
+    line[32] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+}
+bool planes_ok(const GemmTerm* t, int n);                  // every term carries A and W planes (and FCL_PLANES != 0)
+int launch_gemm_planes(const GemmArgs& a, hipStream_t s);  // gemm_planes.hip
+int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s);
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
+bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wave-per-gate kernel (fp32 operands) rather than a big-tile kernel
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
 int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled);
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s);

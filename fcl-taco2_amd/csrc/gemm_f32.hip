@@ -435,10 +435,19 @@ static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* na
 static int check_terms(const GemmTerm* t, int n, int maxn, bool need_seg, const int* lo) {
     FCL_REQUIRE(n >= 1 && n <= maxn, FCL_ERR_INVALID, "gemm: nterms %d out of range [1,%d]", n, maxn);
     for (int i = 0; i < n; ++i) {
-        FCL_REQUIRE(t[i].A && t[i].W, FCL_ERR_INVALID, "gemm: term %d has a null operand", i);
         FCL_REQUIRE(t[i].K > 0 && (t[i].K & 3) == 0, FCL_ERR_SHAPE, "gemm: term %d K=%d must be a positive multiple of 4", i, t[i].K);
-        FCL_REQUIRE((t[i].lda & 3) == 0 && (t[i].ldw & 3) == 0, FCL_ERR_SHAPE, "gemm: term %d lda=%d/ldw=%d must be multiples of 4", i, t[i].lda, t[i].ldw);
-        FCL_REQUIRE(aligned16(t[i].A) && aligned16(t[i].W), FCL_ERR_ALIGN, "gemm: term %d operands must be 16-byte aligned", i);
+        const bool planes = t[i].Ap && t[i].Wp;  // pre-split P32 operands: the fp32 pointers are optional then
+        if (planes) {
+            FCL_REQUIRE(t[i].lda_p * 32 >= t[i].K && t[i].ldw_p * 32 >= t[i].K, FCL_ERR_SHAPE, "gemm: term %d plane strides %d/%d lines are narrower than K=%d", i,
+                        t[i].lda_p, t[i].ldw_p, t[i].K);
+            FCL_REQUIRE(((reinterpret_cast<uintptr_t>(t[i].Ap) | reinterpret_cast<uintptr_t>(t[i].Wp)) & 127u) == 0, FCL_ERR_ALIGN,
+                        "gemm: term %d planes must be 128-byte aligned", i);
+        }
+        if (!planes || (t[i].A && t[i].W)) {  // the fp32 pair is optional next to planes (either pointer alone is ignored then)
+            FCL_REQUIRE(t[i].A && t[i].W, FCL_ERR_INVALID, "gemm: term %d has a null operand", i);
+            FCL_REQUIRE((t[i].lda & 3) == 0 && (t[i].ldw & 3) == 0, FCL_ERR_SHAPE, "gemm: term %d lda=%d/ldw=%d must be multiples of 4", i, t[i].lda, t[i].ldw);
+            FCL_REQUIRE(aligned16(t[i].A) && aligned16(t[i].W), FCL_ERR_ALIGN, "gemm: term %d operands must be 16-byte aligned", i);
+        }
         if (t[i].shift != 0) FCL_REQUIRE(need_seg && lo, FCL_ERR_INVALID, "gemm: shifted term %d needs seg_lo/seg_hi", i);
     }
     return 0;
@@ -449,9 +458,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M == 0) return 0;
     int rc = check_terms(a.term, a.nterms, FCL_MAX_TERMS, true, a.seg_lo);
     if (rc) return rc;
-    FCL_REQUIRE(a.Y, FCL_ERR_INVALID, "gemm: null output");
+    FCL_REQUIRE(a.Y || a.Yp, FCL_ERR_INVALID, "gemm: null output");
     FCL_REQUIRE(a.drop_mode != 1 || a.keep, FCL_ERR_INVALID, "gemm: drop_mode 1 needs a keep mask");
     FCL_REQUIRE(!a.Y2 || a.y2_row_base, FCL_ERR_INVALID, "gemm: Y2 needs y2_row_base");
+    if (precision() && planes_ok(a.term, a.nterms)) return launch_gemm_planes(a, s);  // pre-split operands: the LDS-DMA kernels
+    FCL_REQUIRE(a.Y && !a.Yp, FCL_ERR_INVALID, "gemm: the fp32-operand kernels write fp32 outputs only (planes output needs planes inputs)");
+    for (int i = 0; i < a.nterms; ++i) FCL_REQUIRE(a.term[i].A && a.term[i].W, FCL_ERR_INVALID, "gemm: term %d has no fp32 operands for the fp32-operand kernels", i);
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * (double)a.N * ksum;
@@ -481,6 +493,11 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     return check_hip(hipGetLastError(), "gemm launch");
 }
 
+bool lstm_step_is_small(int M, int U) {
+    static const int small_m = tunable("LSTM_SMALL_M", 0);  // 0 = by width: the wave-per-gate small-tile kernel re-streams W per 16-row tile,
+    return M <= (small_m ? small_m : (U >= 512 ? 256 : 1024));  // which stops paying earlier at U = 1024 (FCL-taco2-T)
+}
+
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     FCL_REQUIRE(a.M >= 0 && a.U > 0, FCL_ERR_SHAPE, "lstm_step: bad M=%d U=%d", a.M, a.U);
     if (a.M == 0) return 0;
@@ -494,8 +511,12 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
         rc = launch_lstm_wres(a, s, &handled);
         if (handled) return rc;
     }
-    static const int small_m = tunable("LSTM_SMALL_M", 0);  // 0 = by width: the wave-per-gate small-tile kernel re-streams W per 16-row tile,
-    if (a.M <= (small_m ? small_m : (a.U >= 512 ? 256 : 1024))) return launch_lstm_small(a, s);  // which stops paying earlier at U = 1024 (FCL-taco2-T)
+    const bool small = lstm_step_is_small(a.M, a.U);
+    bool has_f32 = true;
+    for (int i = 0; i < a.nterms; ++i) has_f32 = has_f32 && a.term[i].A && a.term[i].W;
+    if (precision() && planes_ok(a.term, a.nterms) && (!small || !has_f32)) return launch_lstm_planes(a, s);  // pre-split operands, LDS-DMA ring
+    FCL_REQUIRE(has_f32, FCL_ERR_INVALID, "lstm_step: the fp32-operand kernels need A and W of every term");
+    if (small) return launch_lstm_small(a, s);
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * 4.0 * a.U * ksum;

@@ -1,0 +1,389 @@
+// gemm_planes.hip — the bf16x3 GEMM / LSTM-step core on PRE-SPLIT operand planes, gfx950.
+//
+// Same contractions as gemm_f32.hip, different data path.  gemm_f32.hip loads fp32 operands, splits them into
+// bf16 hi / lo in registers and writes them to LDS every k-chunk: a serial chain (global load -> wait -> ~14 VALU per float4 -> ds_write ->
+// barrier) that left the MFMA pipe idle 7/8 of the time at the path's GEMM sizes.  Here every operand arrives already split, in the "P32"
+// layout written once by its producer (weights at plan time, activations by the epilogue / pointwise kernel that creates them):
+//     P32 of X [R, K]: uint16 [R][ld lines][2][32]: per row and 32-k block ONE 128-byte line = 32 bf16 hi | 32 bf16 lo, zero past K.
+// A k-chunk of a tile is then a set of whole 128-byte lines that go global -> LDS by direct LDS-DMA (global_load_lds_dwordx4: no VGPR staging,
+// no VALU), through an NST-deep ring with COUNTED vmcnt waits and one raw s_barrier per chunk (guide §5 "Pipelining across barriers").
+// LDS image of a chunk: rows of 128 B; the 16-byte piece c = plane*4 + k/8 of row r sits at position c ^ ((r >> 1) & 7), which makes the
+// MFMA fragment reads (ds_read_b128: lane (r16, kq) -> row r16, pieces kq and 4+kq) bank-conflict free for the documented lane groups.
+// LDS-DMA writes lane-linear, so the permutation is applied to the per-lane SOURCE address (guide §5.4 rule 21: linear destination,
+// permuted source, the same permutation on the read).  Rows outside the matrix / outside a conv segment read a static all-zero line.
+// Numerics: a.b ~= al.bh + ah.bl + ah.bh on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, exactly the products of the in-kernel split.
+#include <string.h>
+
+#include "fcl_common.h"
+#include "lstm_epilogue.h"
+
+namespace fcl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+__device__ __attribute__((aligned(128))) unsigned int g_zero_line[32];  // 128 bytes of zeros (static device memory is zero-initialised)
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// XCD-aware tile order (see gemm_f32.hip): the workgroups one XCD receives walk a contiguous range of tiles.
+__device__ __forceinline__ void xcd_tile_p(int& bx, int& by) {
+    const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int orig = blockIdx.y * nx + blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    by = t / nx;
+    bx = t - by * nx;
+}
+
+template <int WM, int WN, int TM, int TN, int NST>
+struct PGeo {
+    static constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN, THREADS = 64 * NW;
+    static constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, GPW = GA + GB;  // LDS-DMA row groups (8 rows = 1 KB) per wave per chunk
+    static constexpr int STAGE = (BM + BN) * 128;
+    static constexpr int LDS_BYTES = NST * STAGE;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && (NW % 2) == 0, "tile rows must split evenly over the waves");
+    static_assert(NST == 3 || NST == 4, "ring depth");
+};
+
+// The shared main loop.  LSTM: tile column c of the wave strip wn is gate (c >> 4) & 3 of unit u0 + wn*16 + (c & 15), i.e. W row g*NU + u
+// (TN must be 4); generic: W row n0 + c.  NU = N (generic) or U.
+template <int WM, int WN, int TM, int TN, int NST, bool LSTM>
+__device__ __forceinline__ void pmainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0, int NU, const int* __restrict__ seg_lo,
+                                          const int* __restrict__ seg_hi, u8* smem, f32x4 (&acc)[TM][TN]) {
+    using G = PGeo<WM, WN, TM, TN, NST>;
+    static_assert(!LSTM || TN == 4, "LSTM tiles keep the four gates of a unit in one lane");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- loader coordinates: group g = j*NW + wave covers rows g*8 .. g*8+7 of its region; lane -> (row = lane >> 3, LDS piece = lane & 7)
+    const unsigned coff = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);  // SOURCE piece for this lane's LDS slot
+    const u8* zline = reinterpret_cast<const u8*>(g_zero_line) + coff;
+    int am[G::GA], alo[G::GA];
+    unsigned alen[G::GA];
+#pragma unroll
+    for (int j = 0; j < G::GA; ++j) {
+        const int m = m0 + (j * G::NW + wave) * 8 + (lane >> 3);
+        am[j] = m;
+        alo[j] = 0;
+        alen[j] = m < M ? (unsigned)M : 0u;  // rows past M: empty segment -> zero line
+        if (seg_lo != nullptr && m < M) {
+            alo[j] = seg_lo[m];
+            alen[j] = (unsigned)(seg_hi[m] - alo[j]);
+        }
+    }
+    long long brow[G::GB];  // W row index, -1 = zero line
+#pragma unroll
+    for (int j = 0; j < G::GB; ++j) {
+        const int c = (j * G::NW + wave) * 8 + (lane >> 3);  // tile column
+        long long wr = -1;
+        if (LSTM) {
+            const int u = n0 + (c >> 6) * 16 + (c & 15);
+            const int g = (c >> 4) & 3;
+            if (u < NU) wr = (long long)g * NU + u;
+        } else {
+            if (n0 + c < NU) wr = n0 + c;
+        }
+        brow[j] = wr;
+    }
+    // issue-side state: per-lane source pointers, advanced one 128-byte line per chunk (zero-line pointers do not move)
+    const u8* pa[G::GA];
+    const u8* pb[G::GB];
+    unsigned ia[G::GA], ib[G::GB];
+    int rem = 0, it = 0;
+    auto setup_term = [&](int t) {
+        const GemmTerm T = terms[t];
+        const u8* Ab = reinterpret_cast<const u8*>(T.Ap);
+        const u8* Wb = reinterpret_cast<const u8*>(T.Wp);
+#pragma unroll
+        for (int j = 0; j < G::GA; ++j) {
+            const int src = am[j] + T.shift;
+            const bool ok = (unsigned)(src - alo[j]) < alen[j];
+            pa[j] = ok ? Ab + (size_t)src * ((size_t)T.lda_p * 128) + coff : zline;
+            ia[j] = ok ? 128u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < G::GB; ++j) {
+            const bool ok = brow[j] >= 0;
+            pb[j] = ok ? Wb + (size_t)brow[j] * ((size_t)T.ldw_p * 128) + coff : zline;
+            ib[j] = ok ? 128u : 0u;
+        }
+        rem = (T.K + 31) >> 5;
+    };
+    auto issue = [&](int stage) {
+        u8* sbase = smem + stage * G::STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < G::GA; ++j) {
+            glds16(pa[j], sbase + j * G::NW * 1024);
+            pa[j] += ia[j];
+        }
+#pragma unroll
+        for (int j = 0; j < G::GB; ++j) {
+            glds16(pb[j], sbase + G::BM * 128 + j * G::NW * 1024);
+            pb[j] += ib[j];
+        }
+    };
+    auto step_term = [&]() {
+        if (--rem == 0 && ++it < nterms) setup_term(it);  // rare, wave-uniform
+    };
+
+    // ---- fragment read offsets (bytes within a stage)
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int sw = r16 >> 1;
+    const int a_hi = (wm * TM * 16 + r16) * 128 + ((kq ^ sw) << 4);
+    const int a_lo = (wm * TM * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+    const int b_hi = G::BM * 128 + (wn * TN * 16 + r16) * 128 + ((kq ^ sw) << 4);
+    const int b_lo = G::BM * 128 + (wn * TN * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+
+    auto compute = [&](int stage) {
+        const u8* sb = smem + stage * G::STAGE;
+        s16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            ah[tm] = *reinterpret_cast<const s16x8*>(sb + a_hi + tm * 16 * 128);
+            al[tm] = *reinterpret_cast<const s16x8*>(sb + a_lo + tm * 16 * 128);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            bh[tn] = *reinterpret_cast<const s16x8*>(sb + b_hi + tn * 16 * 128);
+            bl[tn] = *reinterpret_cast<const s16x8*>(sb + b_lo + tn * 16 * 128);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        }
+    };
+
+    int nchunks = 0;
+    for (int t = 0; t < nterms; ++t) nchunks += (terms[t].K + 31) >> 5;
+    setup_term(0);
+    int issued = 0;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) {
+        if (issued < nchunks) { issue(p); ++issued; step_term(); }
+    }
+    int cs = 0, is = NST - 1;
+    for (int i = 0; i < nchunks; ++i) {  // chunk i is consumed while chunks i+1 .. i+NST-2 stay in flight and chunk i+NST-1 is issued
+        const int left = nchunks - 1 - i;
+        if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
+        else if (left >= 1) wait_vm<G::GPW>();
+        else wait_vm<0>();
+        asm volatile("s_barrier" ::: "memory");  // chunk i has landed for every wave; every wave is done reading the buffer refilled now
+        if (left >= NST - 1) {
+            issue(is);
+            step_term();
+            is = is + 1 == NST ? 0 : is + 1;
+        }
+        compute(cs);
+        cs = cs + 1 == NST ? 0 : cs + 1;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int NST>
+__global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
+    using G = PGeo<WM, WN, TM, TN, NST>;
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    int bx, by;
+    xcd_tile_p(bx, by);
+    const int m0 = by * G::BM, n0 = bx * G::BN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    pmainloop<WM, WN, TM, TN, NST, false>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 15, rq = lane >> 4;
+    const unsigned int seed = hash_u32(a.rng_seed + (a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u));
+    const int np = a.Yp ? a.ldyp * 32 : a.N;  // planes are written up to their padded width (zeros past N)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + (wn * TN + tn) * 16 + col;
+            if (n >= np) continue;
+            const bool nin = n < a.N;
+            const float bn = (a.bias && nin) ? a.bias[n] : 0.f;
+            const float r1w = (a.rank1_w && nin) ? a.rank1_w[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
+                if (m >= a.M) continue;
+                float v = 0.f;
+                if (nin) {
+                    v = acc[tm][tn][r] + bn;
+                    if (a.rank1_a) v += a.rank1_a[(size_t)m * a.rank1_lda] * r1w;
+                    if (a.C0) v += a.C0[(size_t)m * a.ldc0 + n];
+                    if (a.act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (a.act == FCL_ACT_TANH) v = tanhf(v);
+                    if (a.drop_mode == 1) {
+                        v = a.keep[(size_t)m * a.ldkeep + n] ? v * a.keep_scale : 0.f;
+                    } else if (a.drop_mode == 2) {
+                        const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)a.N + (unsigned int)n) ^ seed);
+                        v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
+                    }
+                    if (a.R) v += a.R[(size_t)m * a.ldr + n];
+                    if (a.Y) a.Y[(size_t)m * a.ldy + n] = v;
+                    if (a.Y2) a.Y2[(size_t)(a.y2_row_base[m] + a.y2_row_add) * a.ldy2 + n] = v;
+                }
+                if (a.Yp) store_p32(a.Yp, a.ldyp, m, n, v);
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int NST, int MODE>
+__global__ __launch_bounds__(64 * WM * WN) void plstm_kernel(const LstmStepArgs a) {
+    using G = PGeo<WM, WN, TM, 4, NST>;
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    int bx, by;
+    xcd_tile_p(bx, by);
+    const int m0 = by * G::BM, u0 = bx * (16 * WN);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int u = u0 + wn * 16 + (lane & 15);
+    const int rq = lane >> 4;
+    // epilogue operands (G0 / bias / position / old state) are requested BEFORE the K loop (plain loads: they are older than every LDS-DMA
+    // piece, so the counted vmcnt waits of the loop cover them and their latency hides under it)
+    CellIn ci[TM][4];
+    const int uc = min(u, a.U - 1);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, a.M - 1), uc);
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    pmainloop<WM, WN, TM, 4, NST, true>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, smem, acc);
+    if (u >= a.U) return;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
+            if (m >= a.M) continue;
+            const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+            cell_finish(a, m, u, pre, ci[tm][r]);
+        }
+}
+
+// --------------------------------------------------------------------------------------------------------------------------------------
+bool planes_ok(const GemmTerm* t, int n) {
+    static const int on = tunable("PLANES", 1);
+    if (!on) return false;
+    for (int i = 0; i < n; ++i)
+        if (!t[i].Ap || !t[i].Wp || t[i].lda_p * 32 < t[i].K || t[i].ldw_p * 32 < t[i].K) return false;
+    return true;
+}
+
+template <int WM, int WN, int TM, int TN, int NST>
+static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
+    using G = PGeo<WM, WN, TM, TN, NST>;
+    auto k = pgemm_kernel<WM, WN, TM, TN, NST>;
+    const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(k), G::LDS_BYTES);
+    if (rc) return rc;
+    const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;  // the tiles also cover the zero padding of the output planes
+    dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
+    char full[64];
+    snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, NST);
+    ProfScope ps(full, flops, a.M, s);
+    hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    return check_hip(hipGetLastError(), "pgemm launch");
+}
+
+int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
+    double ksum = 0;
+    for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
+    const double flops = 2.0 * a.M * (double)a.N * ksum;
+    static const int force = tunable("PGEMM_CFG", 0);
+    const long long t64x128 = (long long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+    const long long t128x128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    // measured on MI355X (tools/probe/planes_gemm_probe): 8-wave 128 x 128 tiles where they still give >= ~150 workgroups, 64 x 128 with three
+    // stages (two workgroups per CU) down to ~250, 64 x 64 below that (the encoder-side GEMMs: M = 3 200, N = 256-384)
+    if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
+    if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pgemm_cfg<2, 2, 2, 4, 3>(a, s, flops);
+    return launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
+}
+
+template <int WM, int WN, int TM, int NST>
+static int launch_plstm_cfg(const LstmStepArgs& a, hipStream_t s, double flops) {
+    using G = PGeo<WM, WN, TM, 4, NST>;
+    const bool plain = !a.zone_keep_h && !a.row_len;
+    const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
+    dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
+    char full[64];
+    snprintf(full, sizeof(full), "plstm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, NST, mode);
+    const void* fn = mode == 0 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 0>)
+                   : mode == 1 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 1>)
+                               : reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, -1>);
+    const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
+    if (rc) return rc;
+    ProfScope ps(full, flops, a.M, s);
+    if (mode == 0) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 0>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 1>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, -1>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    return check_hip(hipGetLastError(), "plstm launch");
+}
+
+int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
+    double ksum = 0;
+    for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
+    const double flops = 2.0 * a.M * 4.0 * a.U * ksum;
+    static const int force = tunable("PLSTM_CFG", 0);
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.U + 31) / 32);
+    const long long t64 = (long long)((a.M + 63) / 64) * ((a.U + 31) / 32);
+    if (force == 1 || (force == 0 && t128 >= 150)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
+    if (force == 2 || (force == 0 && t64 >= 200)) return launch_plstm_cfg<2, 2, 2, 3>(a, s, flops);
+    return launch_plstm_cfg<2, 1, 2, 4>(a, s, flops);  // 32 x 64 gate-column tiles (16 units): M <~ 1600 at U = 256
+}
+
+// --------------------------------------------------------------------------------------------------------------------------------------
+__global__ void pack_planes_kernel(const float* __restrict__ x, int ld, int rows, int cols, u16* __restrict__ out, int ldp) {
+    const long long total = (long long)rows * ldp * 32;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (ldp * 32)), k = (int)(i - (long long)r * (ldp * 32));
+        store_p32(out, ldp, r, k, k < cols ? x[(size_t)r * ld + k] : 0.f);
+    }
+}
+
+}  // namespace fcl
+
+using namespace fcl;
+
+extern "C" {
+
+size_t fcl_planes_elems(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)rows * ((cols + 31) / 32) * 64;
+}
+
+int fcl_pack_planes(const float* x, int ld, int rows, int cols, uint16_t* out, fcl_stream_t stream) {
+    FCL_REQUIRE(x && out && rows >= 0 && cols > 0 && ld >= cols, FCL_ERR_INVALID, "pack_planes: bad arguments");
+    FCL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 127u) == 0, FCL_ERR_ALIGN, "pack_planes: the plane buffer must be 128-byte aligned");
+    if (rows == 0) return 0;
+    const int ldp = (cols + 31) / 32;
+    long long blocks = ((long long)rows * ldp * 32 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, ldp);
+    return check_hip(hipGetLastError(), "pack_planes");
+}
+
+}  // extern "C"

@@ -60,7 +60,9 @@ __device__ __forceinline__ void cell_finish(const LstmStepArgs& a, int m, int u,
         h_o = a.zoneout * ci.h_old + (1.0f - a.zoneout) * h_new;
         c_o = a.zoneout * ci.c_old + (1.0f - a.zoneout) * c_new;
     }
-    a.h_out[off] = ci.live ? h_o : ci.h_old;
+    const float h_w = ci.live ? h_o : ci.h_old;
+    a.h_out[off] = h_w;
+    if (a.h_out_p) store_p32(a.h_out_p, a.ld_hp, m, u, h_w);  // the same state as the next step's pre-split GEMM operand
     a.c[off] = ci.live ? c_o : ci.c_old;
     if (a.save_gates) {  // training forward: what fcl_lstm_cell_bwd needs
         float* sg = a.save_gates + (size_t)m * 4 * a.U;

@@ -64,22 +64,35 @@ __global__ void add_vec_kernel(const float* a, const float* b, float* out, int n
 
 // ---- H1 embedding / H9 row gather -------------------------------------------------------------------
 // one wave per row, float4 lanes
+// dst_p (optional): the gathered rows as P32 planes (ceil(c / 32) lines per row, zero past c) for the GEMM that consumes them; dst may then be null
 template <typename IdxT>
 __global__ void gather_rows_kernel(const float* __restrict__ src, const IdxT* __restrict__ idx, float* __restrict__ dst,
-                                   int n, int c, long long src_rows) {
+                                   int n, int c, long long src_rows, unsigned short* __restrict__ dst_p) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (wave >= n) return;
     const long long r = (long long)idx[wave];
     const bool ok = r >= 0 && (src_rows < 0 || r < src_rows);
+    const int ldp = (c + 31) >> 5;
     if ((c & 3) == 0) {
-        for (int j = lane * 4; j < c; j += 256) {
+        for (int j = lane * 4; j < ldp * 32; j += 256) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(src + (size_t)r * c + j);
-            *reinterpret_cast<f32x4*>(dst + (size_t)wave * c + j) = v;
+            if (ok && j < c) v = *reinterpret_cast<const f32x4*>(src + (size_t)r * c + j);
+            if (dst && j < c) *reinterpret_cast<f32x4*>(dst + (size_t)wave * c + j) = v;
+            if (dst_p) {
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                unsigned short* line = dst_p + ((size_t)wave * ldp + (j >> 5)) * 64 + (j & 31);
+                *reinterpret_cast<uint2*>(line) = hi;
+                *reinterpret_cast<uint2*>(line + 32) = lo;
+            }
         }
     } else {
-        for (int j = lane; j < c; j += 64) dst[(size_t)wave * c + j] = ok ? src[(size_t)r * c + j] : 0.f;
+        for (int j = lane; j < ldp * 32; j += 64) {
+            const float v = (ok && j < c) ? src[(size_t)r * c + j] : 0.f;
+            if (dst && j < c) dst[(size_t)wave * c + j] = v;
+            if (dst_p) store_p32(dst_p, ldp, wave, j, v);
+        }
     }
 }
 
@@ -93,7 +106,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 template <int MAXPER>
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                 float eps, float* __restrict__ y, const float* __restrict__ lin_w,
+                                 float eps, float* __restrict__ y, unsigned short* __restrict__ yp, const float* __restrict__ lin_w,
                                  const float* __restrict__ lin_b, const uint8_t* __restrict__ pad_mask,
                                  const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ scalar, int m, int c) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -124,7 +137,10 @@ __global__ void layernorm_kernel(const float* __restrict__ x, const float* __res
             float o = (v[i] - mean) * rstd * gamma[j] + beta[j];
             if (keep) o = keep[(size_t)row * c + j] ? o * keep_scale : 0.f;  // training: Dropout after the LayerNorm
             if (y) y[(size_t)row * c + j] = o;
+            if (yp) store_p32(yp, (c + 31) >> 5, row, j, o);
             if (lin_w) dot += o * lin_w[j];
+        } else if (yp && j < ((c + 31) & ~31)) {
+            store_p32(yp, (c + 31) >> 5, row, j, 0.f);  // zero padding of the last 32-column line
         }
     }
     if (lin_w) {
@@ -282,36 +298,39 @@ int fcl_add_vec(const float* a, const float* b, float* out, int n, fcl_stream_t 
     return check_hip(hipGetLastError(), "add_vec");
 }
 
-int fcl_embedding_fwd(const int64_t* ids, const float* table, float* out, int m, int v, int e, fcl_stream_t stream) {
-    FCL_REQUIRE(ids && table && out && m >= 0 && v > 0 && e > 0, FCL_ERR_INVALID, "embedding_fwd: bad arguments");
+int fcl_embedding_fwd(const int64_t* ids, const float* table, float* out, uint16_t* out_p, int m, int v, int e, fcl_stream_t stream) {
+    FCL_REQUIRE(ids && table && (out || out_p) && m >= 0 && v > 0 && e > 0, FCL_ERR_INVALID, "embedding_fwd: bad arguments");
     if (m == 0) return 0;
     FCL_REQUIRE((e & 3) != 0 || (aligned16(table) && aligned16(out)), FCL_ERR_ALIGN, "embedding_fwd: 16-byte alignment required");
-    hipLaunchKernelGGL((gather_rows_kernel<int64_t>), dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, out, m, e, (long long)v);
+    FCL_REQUIRE((reinterpret_cast<uintptr_t>(out_p) & 127u) == 0, FCL_ERR_ALIGN, "embedding_fwd: planes must be 128-byte aligned");
+    hipLaunchKernelGGL((gather_rows_kernel<int64_t>), dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ids, out, m, e, (long long)v, out_p);
     return check_hip(hipGetLastError(), "embedding_fwd");
 }
 
-int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n, int c, fcl_stream_t stream) {
-    FCL_REQUIRE(src && idx && dst && n >= 0 && c > 0, FCL_ERR_INVALID, "gather_rows_fwd: bad arguments");
+int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, uint16_t* dst_p, int n, int c, fcl_stream_t stream) {
+    FCL_REQUIRE(src && idx && (dst || dst_p) && n >= 0 && c > 0, FCL_ERR_INVALID, "gather_rows_fwd: bad arguments");
     if (n == 0) return 0;
     FCL_REQUIRE((c & 3) != 0 || (aligned16(src) && aligned16(dst)), FCL_ERR_ALIGN, "gather_rows_fwd: 16-byte alignment required");
-    hipLaunchKernelGGL((gather_rows_kernel<int32_t>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, c, -1LL);
+    FCL_REQUIRE((reinterpret_cast<uintptr_t>(dst_p) & 127u) == 0, FCL_ERR_ALIGN, "gather_rows_fwd: planes must be 128-byte aligned");
+    hipLaunchKernelGGL((gather_rows_kernel<int32_t>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, c, -1LL, dst_p);
     return check_hip(hipGetLastError(), "gather_rows_fwd");
 }
 
-int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, const float* lin_w,
+int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, uint16_t* yp, const float* lin_w,
                       const float* lin_b, const uint8_t* pad_mask, const uint8_t* keep, float keep_scale, float* scalar, int m, int c,
                       fcl_stream_t stream) {
     FCL_REQUIRE(x && gamma && beta && m >= 0 && c > 0, FCL_ERR_INVALID, "layernorm_fwd: bad arguments");
-    FCL_REQUIRE(y || lin_w, FCL_ERR_INVALID, "layernorm_fwd: nothing to compute (y and lin_w both NULL)");
+    FCL_REQUIRE(y || yp || lin_w, FCL_ERR_INVALID, "layernorm_fwd: nothing to compute (y, yp and lin_w all NULL)");
+    FCL_REQUIRE((reinterpret_cast<uintptr_t>(yp) & 127u) == 0, FCL_ERR_ALIGN, "layernorm_fwd: planes must be 128-byte aligned");
     FCL_REQUIRE(!lin_w || (lin_b && scalar), FCL_ERR_INVALID, "layernorm_fwd: lin_w needs lin_b and scalar");
     FCL_REQUIRE(c <= 1024, FCL_ERR_SHAPE, "layernorm_fwd: C=%d > 1024 unsupported", c);
     if (m == 0) return 0;
     dim3 grid((m + 3) / 4), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (c <= 64) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
-    else if (c <= 256) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
-    else if (c <= 512) hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
-    else hipLaunchKernelGGL((layernorm_kernel<16>), grid, block, 0, s, x, gamma, beta, eps, y, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
+    if (c <= 64) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, s, x, gamma, beta, eps, y, yp, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
+    else if (c <= 256) hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, s, x, gamma, beta, eps, y, yp, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
+    else if (c <= 512) hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, gamma, beta, eps, y, yp, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
+    else hipLaunchKernelGGL((layernorm_kernel<16>), grid, block, 0, s, x, gamma, beta, eps, y, yp, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
     return check_hip(hipGetLastError(), "layernorm_fwd");
 }
 

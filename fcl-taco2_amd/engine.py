@@ -69,6 +69,30 @@ def _predictor_scalar(pp, hs, seg_lo, seg_hi, pad_mask_u8):
     return out
 
 
+def _predictor_scalar_planes(pp, hs_p, seg_lo, seg_hi, pad_mask_u8):
+    """The same predictor on pre-split operands: the conv reads P32 planes and writes fp32 (the LayerNorm's input), the LayerNorm writes the
+    next conv's planes."""
+    xp = hs_p
+    n = len(pp.convs)
+    out = None
+    for i, cv in enumerate(pp.convs):
+        y, _ = ops.conv1d_planes(xp, cv, seg_lo, seg_hi, ops.ACT_RELU, want_f32=True, want_planes=False)
+        last = i == n - 1
+        if last:
+            _, out = ops.layernorm(y, pp.ln[i][0], pp.ln[i][1], LN_EPS, want_y=False, lin_w=pp.lin_w, lin_b=pp.lin_b, pad_mask=pad_mask_u8)
+        else:
+            _, _, xp = ops.layernorm(y, pp.ln[i][0], pp.ln[i][1], LN_EPS, want_y=False, want_planes=True)
+    return out
+
+
+def use_planes(plan):
+    """Pre-split (P32) operands end to end: on by default (FCL_PRECISION=0 / FCL_PLANES=0 turn it off), needs whole 32-column lines."""
+    hp = plan.hp
+    return (ops.planes_enabled() and plan.enc_convs[0].wpp is not None and plan.decoder.struct.w0_att_p is not None
+            and all(x % 32 == 0 for x in (hp.embed_dim, hp.econv_chans, hp.eunits, hp.postnet_chans, hp.duration_predictor_chans,
+                                          hp.variance_predictor_chans)))
+
+
 class PreparedBatch(object):
     """Everything `run` needs, resident in HBM: padded ids, segment bounds, and (forced durations) row maps."""
     __slots__ = ("B", "T", "lens", "ids", "seg_lo", "seg_hi", "pad", "lens_dev", "f0e", "maps", "src_rows", "dur", "frame_off",
@@ -117,12 +141,18 @@ def prepare(plan, xs, durs=None, f0=None, energy=None):
     return p
 
 
-def encode(plan, prep, bilstm_algo=0):
-    """H1-H3: embedding -> 3 x conv/BN/ReLU -> packed BiLSTM.  Returns hs [B*T, C]."""
+def encode(plan, prep, bilstm_algo=0, planes=False):
+    """H1-H3: embedding -> 3 x conv/BN/ReLU -> packed BiLSTM.  Returns hs [B*T, C] (planes: (hs, P32 planes of hs))."""
+    bl = plan.blstm
+    if planes:  # every GEMM operand travels pre-split: embedding -> planes, conv -> planes, ..., BiLSTM -> fp32 + planes
+        _, xp = ops.embedding(prep.ids, plan.embed, want_f32=False, want_planes=True)
+        for cv in plan.enc_convs:
+            _, xp = ops.conv1d_planes(xp, cv, prep.seg_lo, prep.seg_hi, ops.ACT_RELU)
+        return ops.bilstm(None, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo,
+                          x_p=xp, w_ih_p=(bl["w_ih_p_f"], bl["w_ih_p_r"]), want_planes=True)
     x = ops.embedding(prep.ids, plan.embed)
     for cv in plan.enc_convs:
         x = ops.conv1d(x, cv.wp, cv.bias, prep.seg_lo, prep.seg_hi, ops.ACT_RELU)
-    bl = plan.blstm
     return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo)
 
 
@@ -131,11 +161,18 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
     the per-utterance frame counts; with forced durations nothing here touches the host."""
     hp, dev = plan.hp, plan.device
     with torch.cuda.device(dev):
-        hs = encode(plan, prep, bilstm_algo)
+        planes = use_planes(plan)
+        hs_p = None
+        if planes:
+            hs, hs_p = encode(plan, prep, bilstm_algo, planes=True)
+            predictor = lambda pp, pad: _predictor_scalar_planes(pp, hs_p, prep.seg_lo, prep.seg_hi, pad)
+        else:
+            hs = encode(plan, prep, bilstm_algo)
+            predictor = lambda pp, pad: _predictor_scalar(pp, hs, prep.seg_lo, prep.seg_hi, pad)
         inter = {"hs": hs, "T": prep.T} if return_intermediates else None
         rm = prep  # holder of the row maps
         if prep.maps is None:  # predicted durations: maps depend on this pass's predictor output, never cached
-            d_log = _predictor_scalar(plan.duration, hs, prep.seg_lo, prep.seg_hi, None)
+            d_log = predictor(plan.duration, None)
             d_int = ops.duration_round(d_log, False, 1.0, prep.pad)
             d_host = d_int.cpu().numpy().reshape(prep.B, prep.T)  # the one host sync of the predicted-duration path
             rm = PreparedBatch()
@@ -143,14 +180,14 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
             if inter is not None:
                 inter["d_log"], inter["d_int"] = d_log, d_int
         if prep.f0e is None:
-            p = _predictor_scalar(plan.pitch, hs, prep.seg_lo, prep.seg_hi, prep.pad)
-            e = _predictor_scalar(plan.energy, hs, prep.seg_lo, prep.seg_hi, prep.pad)
+            p = predictor(plan.pitch, prep.pad)
+            e = predictor(plan.energy, prep.pad)
         else:
             p, e = prep.f0e[0], prep.f0e[1]
         att, p_emb, e_emb = ops.variance_embed_add(hs, p, e, plan.pitch_embed_w, plan.pitch_embed_b, plan.energy_embed_w,
                                                    plan.energy_embed_b, prep.seg_lo, prep.seg_hi, want_embs=return_intermediates)
         maps = rm.maps
-        att_c = ops.gather_rows(att, rm.src_rows)
+        att_c, att_c_p = (ops.gather_rows(att, rm.src_rows, want_f32=False, want_planes=True) if planes else (ops.gather_rows(att, rm.src_rows), None))
         keep_dev = None
         if hp.dropout_rate <= 0.0:
             dropout_mode = ops.DROP_NONE
@@ -158,13 +195,20 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
             keep = np.ascontiguousarray(np.asarray(prenet_keep)[: maps.lmax][:, :, maps.order, :])  # to sorted row order
             keep_dev = torch.from_numpy(keep).to(dev)
         before = ops.decoder_loop(plan.decoder, att_c, rm.dur, maps.live_rows, rm.frame_off, maps.n_frames,
-                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed, seed_dev=seed_dev)
-        x = before
+                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed, seed_dev=seed_dev, att_c_p=att_c_p, want_before_p=planes)
         n_post = len(plan.postnet)
-        for i, cv in enumerate(plan.postnet):
-            last = i == n_post - 1
-            x = ops.conv1d(x, cv.wp, cv.bias, rm.frame_lo, rm.frame_hi, ops.ACT_NONE if last else ops.ACT_TANH,
-                           residual=before if last else None)
+        if planes:
+            before, xp = before
+            for i, cv in enumerate(plan.postnet):
+                last = i == n_post - 1
+                x, xp = ops.conv1d_planes(xp, cv, rm.frame_lo, rm.frame_hi, ops.ACT_NONE if last else ops.ACT_TANH, residual=before if last else None,
+                                          want_f32=last, want_planes=not last)
+        else:
+            x = before
+            for i, cv in enumerate(plan.postnet):
+                last = i == n_post - 1
+                x = ops.conv1d(x, cv.wp, cv.bias, rm.frame_lo, rm.frame_hi, ops.ACT_NONE if last else ops.ACT_TANH,
+                               residual=before if last else None)
         if inter is not None:
             inter.update(p_outs=p, e_outs=e, p_embs=p_emb, e_embs=e_emb, before=before, after=x, maps=maps)
             return x, maps.utt_frames, inter

@@ -70,18 +70,43 @@ def pack_frag_bf16(w):
     return hi, lo
 
 
+def planes_enabled():
+    """The pre-split (P32) operand path is on unless exact-fp32 arithmetic (FCL_PRECISION=0) or FCL_PLANES=0 is requested."""
+    import os
+
+    return os.environ.get("FCL_PRECISION", "1") != "0" and os.environ.get("FCL_PLANES", "1") != "0"
+
+
+def planes_empty(rows, cols, device):
+    """Uninitialised P32 plane buffer of a [rows, cols] matrix (include/fcl_hip.h): int16 [rows, ceil(cols/32) * 64], 128-byte aligned rows."""
+    t = torch.empty(max(rows, 1), (cols + 31) // 32 * 64, device=device, dtype=torch.int16)
+    assert t.data_ptr() % 128 == 0
+    return t
+
+
+def pack_planes(x):
+    """P32 planes of a float32 matrix [rows, cols] (plan-time weight packing; activations get theirs from their producers)."""
+    rows, cols = x.shape
+    assert x.stride(1) == 1
+    out = planes_empty(rows, cols, x.device)
+    check(_lib.load().fcl_pack_planes(x.data_ptr(), x.stride(0), rows, cols, _p(out, torch.int16), _stream()))
+    return out
+
+
 def add_vec(a, b):
     out = torch.empty_like(a)
     check(_lib.load().fcl_add_vec(_p(a), _p(b), _p(out), a.numel(), _stream()))
     return out
 
 
-def embedding(ids, table):
+def embedding(ids, table, want_f32=True, want_planes=False):
+    """Returns the fp32 rows, or (fp32 or None, P32 planes) when want_planes."""
     m = ids.numel()
     v, e = table.shape
-    out = torch.empty(m, e, device=table.device, dtype=torch.float32)
-    check(_lib.load().fcl_embedding_fwd(_p(ids, torch.int64), _p(table), _p(out), m, v, e, _stream()))
-    return out
+    out = torch.empty(m, e, device=table.device, dtype=torch.float32) if want_f32 else None
+    outp = planes_empty(m, e, table.device) if want_planes else None
+    check(_lib.load().fcl_embedding_fwd(_p(ids, torch.int64), _p(table), _p(out), _p(outp, torch.int16), m, v, e, _stream()))
+    return (out, outp) if want_planes else out
 
 
 def linear(x, w, bias=None, act=ACT_NONE, out=None):
@@ -102,13 +127,27 @@ def conv1d(x, wp, bias, seg_lo, seg_hi, act=ACT_NONE, residual=None):
     return y
 
 
-def layernorm(x, gamma, beta, eps, want_y=True, lin_w=None, lin_b=None, pad_mask=None, keep=None, keep_scale=1.0):
+def conv1d_planes(xp, cv, seg_lo, seg_hi, act=ACT_NONE, residual=None, want_f32=False, want_planes=True):
+    """Conv1d on pre-split operands: xp = P32 planes of x [m, cin]; cv: a plan ConvPack with .wpp (planes of the packed taps).
+    Returns (y fp32 or None, y planes or None)."""
+    m = xp.shape[0]
+    ldxp = xp.shape[1] // 64
+    y = torch.empty(m, cv.cout, device=xp.device, dtype=torch.float32) if want_f32 else None
+    yp = planes_empty(m, cv.cout, xp.device) if want_planes else None
+    check(_lib.load().fcl_conv1d_planes_fwd(_p(xp, torch.int16), ldxp, _p(cv.wpp, torch.int16), _p(cv.bias), _p(seg_lo, torch.int32),
+                                            _p(seg_hi, torch.int32), _p(residual), _p(y), _p(yp, torch.int16), m, cv.cin, cv.cout, cv.k, act, _stream()))
+    return y, yp
+
+
+def layernorm(x, gamma, beta, eps, want_y=True, lin_w=None, lin_b=None, pad_mask=None, keep=None, keep_scale=1.0, want_planes=False):
+    """Returns (y, scalar); with want_planes (y or None, scalar, P32 planes of y)."""
     m, c = x.shape
     y = torch.empty_like(x) if want_y else None
+    yp = planes_empty(m, c, x.device) if want_planes else None
     scalar = torch.empty(m, device=x.device, dtype=torch.float32) if lin_w is not None else None
-    check(_lib.load().fcl_layernorm_fwd(_p(x), _p(gamma), _p(beta), eps, _p(y), _p(lin_w), _p(lin_b), _p(pad_mask, torch.uint8),
+    check(_lib.load().fcl_layernorm_fwd(_p(x), _p(gamma), _p(beta), eps, _p(y), _p(yp, torch.int16), _p(lin_w), _p(lin_b), _p(pad_mask, torch.uint8),
                                         _p(keep, torch.uint8), keep_scale, _p(scalar), m, c, _stream()))
-    return y, scalar
+    return (y, scalar, yp) if want_planes else (y, scalar)
 
 
 def duration_round(x, linear_domain=False, offset=1.0, pad_mask=None):
@@ -135,11 +174,13 @@ def position_table(dur_i32, lmax):
     return pos
 
 
-def gather_rows(src, idx_i32):
+def gather_rows(src, idx_i32, want_f32=True, want_planes=False):
+    """Returns the gathered fp32 rows, or (fp32 or None, P32 planes) when want_planes."""
     n, c = idx_i32.numel(), src.shape[1]
-    dst = torch.empty(n, c, device=src.device, dtype=torch.float32)
-    check(_lib.load().fcl_gather_rows_fwd(_p(src), _p(idx_i32, torch.int32), _p(dst), n, c, _stream()))
-    return dst
+    dst = torch.empty(n, c, device=src.device, dtype=torch.float32) if want_f32 else None
+    dstp = planes_empty(n, c, src.device) if want_planes else None
+    check(_lib.load().fcl_gather_rows_fwd(_p(src), _p(idx_i32, torch.int32), _p(dst), _p(dstp, torch.int16), n, c, _stream()))
+    return (dst, dstp) if want_planes else dst
 
 
 _STATUS = {}
@@ -175,17 +216,22 @@ def check_status(device, reset=True):
         raise _lib.FclError("fcl-taco2_amd: device status 0x%x: %s" % (bits, status_message(bits)))
 
 
-def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0, status=None):
-    """status: device status word for algo 3 (default: the per-device word of status_word(); callers check it at their next sync point)."""
-    c = x.shape[1]
+def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0, status=None, x_p=None, w_ih_p=None, want_planes=False):
+    """status: device status word for algo 3 (default: the per-device word of status_word(); callers check it at their next sync point).
+    x_p / w_ih_p = (forward, reverse): pre-split P32 operands of the input projection (x may then be None); want_planes: also return the
+    output as P32 planes."""
+    c, dev = w_ih_f.shape[1], w_ih_f.device
     h = w_hh_f.shape[1]
     lib = _lib.load()
     nbytes = lib.fcl_bilstm_workspace_bytes(b, t, h)
-    ws = torch.empty(nbytes, device=x.device, dtype=torch.uint8)
-    out = torch.empty(b * t, 2 * h, device=x.device, dtype=torch.float32)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    out = torch.empty(b * t, 2 * h, device=dev, dtype=torch.float32)
+    outp = planes_empty(b * t, 2 * h, dev) if want_planes else None
+    wf_p, wr_p = w_ih_p if (x_p is not None and w_ih_p is not None) else (None, None)
     check(lib.fcl_bilstm_fwd(_p(x), _p(lens_i32, torch.int32), _p(w_ih_f), _p(w_hh_f), _p(b_f), _p(w_ih_r), _p(w_hh_r), _p(b_r), _p(out),
-                             b, t, c, h, algo, ws.data_ptr(), nbytes, _p(status if status is not None else status_word(x.device), torch.int32), _stream()))
-    return out
+                             _p(outp, torch.int16), _p(x_p if wf_p is not None else None, torch.int16), _p(wf_p, torch.int16), _p(wr_p, torch.int16),
+                             b, t, c, h, algo, ws.data_ptr(), nbytes, _p(status if status is not None else status_word(dev), torch.int32), _stream()))
+    return (out, outp) if want_planes else out
 
 
 def masked_l1_mse(a, b, row_valid, out_f64, b_log_offset=None):
@@ -202,29 +248,35 @@ def u32_add(word_i32, v=1):
 
 
 def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher_ys=None, dropout_mode=DROP_NONE,
-                 prenet_keep=None, seed=0, want_taps=False, seed_dev=None, zero_init=False):
+                 prenet_keep=None, seed=0, want_taps=False, seed_dev=None, zero_init=False, att_c_p=None, want_before_p=False):
     """dw: plan.DecoderPack (holds the ctypes DecoderWeights + the tensors it points to).
-    live_rows: host numpy int32 [Lmax].  Returns before [F, odim] (+ taps)."""
+    live_rows: host numpy int32 [Lmax].  Returns before [F, odim] (+ taps).  att_c_p: P32 planes of att_c (att_c may then be None);
+    want_before_p: also return `before` as P32 planes (appended to the result)."""
     lib = _lib.load()
-    n = att_c.shape[0]
+    dev = att_c.device if att_c is not None else att_c_p.device
+    n = att_c.shape[0] if att_c is not None else att_c_p.shape[0]
     lmax = int(live_rows.shape[0])
     nbytes = lib.fcl_decoder_loop_workspace_bytes(C.byref(dw.struct), n)
-    ws = torch.empty(nbytes, device=att_c.device, dtype=torch.uint8)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     alloc = torch.zeros if zero_init else torch.empty  # zero_init: frames no (row, t) maps to stay 0 (padded [B, Lmax] layout)
-    before = alloc(n_frames, dw.struct.odim, device=att_c.device, dtype=torch.float32)
+    before = alloc(n_frames, dw.struct.odim, device=dev, dtype=torch.float32)
+    before_p = planes_empty(n_frames, dw.struct.odim, dev) if want_before_p else None
     taps = None
     if want_taps:
-        taps = (alloc(n_frames, dw.struct.p, device=att_c.device, dtype=torch.float32),
-                alloc(n_frames, dw.struct.u, device=att_c.device, dtype=torch.float32),
-                alloc(n_frames, dw.struct.u, device=att_c.device, dtype=torch.float32))
+        taps = (alloc(n_frames, dw.struct.p, device=dev, dtype=torch.float32),
+                alloc(n_frames, dw.struct.u, device=dev, dtype=torch.float32),
+                alloc(n_frames, dw.struct.u, device=dev, dtype=torch.float32))
     io = _lib.DecoderIO(
         n=n, lmax=lmax, att_c=_p(att_c), dur=_p(dur_i32, torch.int32), live_rows_host=live_rows.ctypes.data,
         frame_off=_p(frame_off_i32, torch.int32), teacher_ys=_p(teacher_ys), dropout_mode=dropout_mode,
         prenet_keep=_p(prenet_keep, torch.uint8), seed=seed & 0xFFFFFFFF, seed_dev=_p(seed_dev, torch.int32), before=_p(before),
         tap_prenet=_p(taps[0]) if taps else None, tap_lstm0=_p(taps[1]) if taps else None, tap_lstm1=_p(taps[2]) if taps else None,
-        workspace=ws.data_ptr(), workspace_bytes=nbytes)
+        workspace=ws.data_ptr(), workspace_bytes=nbytes, att_c_p=_p(att_c_p, torch.int16), before_p=_p(before_p, torch.int16))
     check(lib.fcl_decoder_loop_fwd(C.byref(dw.struct), C.byref(io), _stream()))
-    return (before, taps) if want_taps else before
+    res = (before, taps) if want_taps else before
+    if want_before_p:
+        return (res + (before_p,)) if want_taps else (res, before_p)
+    return res
 
 
 # ---- gradient primitives (include/fcl_hip.h "H13") -------------------------------------------------------------------
@@ -396,7 +448,7 @@ def lstm_step(terms, M, U, h_in, h_out, c, G=None, g_row_mul=1, g_row_add=0, bia
     a = _lib.LstmStep()
     a.nterms = len(terms)
     for i, (A, W, K) in enumerate(terms):
-        a.term[i] = _lib.GemmTerm(A.data_ptr(), W.data_ptr(), A.stride(0), W.stride(0), K, 0, None, None)
+        a.term[i] = _lib.GemmTerm(A.data_ptr(), W.data_ptr(), A.stride(0), W.stride(0), K, 0, None, None, None, None, 0, 0)
     a.M, a.U = M, U
     a.G, a.g_row_mul, a.g_row_add = _p(G), g_row_mul, g_row_add
     a.bias, a.rank1_w, a.dur, a.step = _p(bias), _p(rank1_w), _p(dur, torch.int32), step

@@ -19,7 +19,12 @@ LN_EPS = 1e-12
 
 
 class ConvPack(object):
-    __slots__ = ("wp", "bias", "k", "cin", "cout")
+    __slots__ = ("wp", "bias", "k", "cin", "cout", "wpp")  # wpp: P32 planes of the packed taps viewed as [k*Cout, Cin] (None: fp32 path only)
+
+
+def _conv_planes(c):
+    c.wpp = ops.pack_planes(c.wp.reshape(c.k * c.cout, c.cin)) if ops.planes_enabled() else None
+    return c
 
 
 class PredictorPack(object):
@@ -63,6 +68,7 @@ class SynthesisPlan(object):
                 self.blstm["w_ih_" + tag] = g("enc.blstm.weight_ih_l0" + sfx)
                 self.blstm["w_hh_" + tag] = g("enc.blstm.weight_hh_l0" + sfx)
                 self.blstm["b_" + tag] = ops.add_vec(g("enc.blstm.bias_ih_l0" + sfx), g("enc.blstm.bias_hh_l0" + sfx))
+                self.blstm["w_ih_p_" + tag] = ops.pack_planes(self.blstm["w_ih_" + tag]) if ops.planes_enabled() else None
             self.duration = self._predictor(g, "duration_predictor", hp.duration_predictor_layers)
             self.pitch = self._predictor(g, "pitch_predictor", hp.variance_predictor_layers)
             self.energy = self._predictor(g, "energy_predictor", hp.variance_predictor_layers)
@@ -85,7 +91,7 @@ class SynthesisPlan(object):
         c.cout, c.cin, c.k = w.shape
         c.wp = ops.pack_conv1d_weight(w, scale)
         c.bias = shift
-        return c
+        return _conv_planes(c)
 
     def _predictor(self, g, prefix, layers):
         p = PredictorPack()
@@ -96,7 +102,7 @@ class SynthesisPlan(object):
             c.cout, c.cin, c.k = w.shape
             c.wp = ops.pack_conv1d_weight(w, None)
             c.bias = g("%s.conv.%d.0.bias" % (prefix, i))
-            p.convs.append(c)
+            p.convs.append(_conv_planes(c))
             p.ln.append((g("%s.conv.%d.2.weight" % (prefix, i)), g("%s.conv.%d.2.bias" % (prefix, i))))
         p.lin_w = g(prefix + ".linear.weight").reshape(-1).contiguous()
         p.lin_b = g(prefix + ".linear.bias")
@@ -131,6 +137,11 @@ class SynthesisPlan(object):
                 setattr(s, k + "_hi", hi.data_ptr())
                 setattr(s, k + "_lo", lo.data_ptr())
                 d.keep += [hi, lo]
+            if ops.planes_enabled() and all(x % 32 == 0 for x in (C, P, U)):  # P32 planes for the LDS-DMA GEMM / LSTM-step kernels
+                for k in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh"):
+                    pl = ops.pack_planes(t[k])
+                    setattr(s, k + "_p", pl.data_ptr())
+                    d.keep.append(pl)
         s.zoneout_rate = float(hp.zoneout_rate)
         s.prenet_dropout = float(hp.dropout_rate)
         return d

@@ -64,12 +64,23 @@ int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream);
 size_t fcl_frag_bf16_elems(int rows, int cols);
 int fcl_pack_frag_bf16(const float* w, int rows, int cols, uint16_t* hi, uint16_t* lo, fcl_stream_t stream);
 
+/* ---- bf16x3 operand planes ("P32" layout) -----------------------------------------------------------------------------------------
+ * The default arithmetic computes a.b as a_lo.b_hi + a_hi.b_lo + a_hi.b_hi on the bf16 MFMA pipe with fp32 accumulation, hi = bf16_rn(x),
+ * lo = bf16_rn(x - hi).  Operands that are consumed by a GEMM are therefore kept ALREADY SPLIT next to (or instead of) their fp32 form:
+ *     P32 planes of X [R, K]: uint16 [R][ld][2][32] — per row and per block of 32 columns one 128-byte line = 32 hi | 32 lo, zeros past K;
+ *     ld >= ceil(K / 32) lines per row; the buffer must be 128-byte aligned.
+ * Weights are packed once at plan time (fcl_pack_planes); activations are written in this form by the kernel that produces them (the `*_p`
+ * outputs below), so the GEMM main loops move whole lines global -> LDS by LDS-DMA with no register staging and no conversion work. */
+size_t fcl_planes_elems(int rows, int cols); /* uint16 elements of a dense plane buffer: rows * ceil(cols / 32) * 64 */
+int fcl_pack_planes(const float* x, int ld, int rows, int cols, uint16_t* out, fcl_stream_t stream);
+
 /* out = a + b (bias_ih + bias_hh). */
 int fcl_add_vec(const float* a, const float* b, float* out, int n, fcl_stream_t stream);
 
 /* ---- H1: Encoder.embed (encoder_sa.py:58,134) ------------------------------------------------------ */
-/* out[m, :] = table[ids[m], :]; ids outside [0, V) produce a zero row. */
-int fcl_embedding_fwd(const int64_t* ids, const float* table, float* out, int m, int v, int e, fcl_stream_t stream);
+/* out[m, :] = table[ids[m], :]; ids outside [0, V) produce a zero row.  out_p (optional): the same rows as P32 planes (ceil(e/32) lines per
+ * row) for the convolution that consumes them; out may then be NULL. */
+int fcl_embedding_fwd(const int64_t* ids, const float* table, float* out, uint16_t* out_p, int m, int v, int e, fcl_stream_t stream);
 
 /* ---- H6/H8 + every nn.Linear: y = act(x . w^T + bias) --------------------------------------------- */
 /* x [M, K] (lda), w [N, K] (torch layout, ldw), y [M, N] (ldy).  K, lda, ldw multiples of 4. */
@@ -84,11 +95,19 @@ int fcl_linear_fwd(const float* x, int lda, const float* w, int ldw, const float
 int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
                    const float* residual, float* y, int m, int cin, int cout, int k, int act, fcl_stream_t stream);
 
+/* The same two on pre-split operands: xp = P32 planes of x (ldxp lines per row), wpp = P32 planes of the weight (Linear: [N, K]; Conv1d: the
+ * packed taps as one [k*Cout, Cin] matrix, i.e. fcl_pack_planes of fcl_pack_conv1d_weight's output).  y (fp32) and / or yp (P32 planes, dense:
+ * ceil(N/32) lines per row, zero past N) receive the result; residual / bias as above. */
+int fcl_linear_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, float* y, int ldy, uint16_t* yp,
+                          int m, int n, int k, int act, fcl_stream_t stream);
+int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
+                          const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, fcl_stream_t stream);
+
 /* ---- H4/H5: channel LayerNorm (+ the predictor's Linear(C->1) and masked_fill) ---------------------- */
 /* y[m,:] = LN(x[m,:]) * gamma + beta (y may be NULL).  If lin_w != NULL:
  * scalar[m] = pad_mask[m] ? 0 : (y[m,:] . lin_w + lin_b[0])   (variance_predictor.py:90-93).
  * keep != NULL (training): the Dropout after the LayerNorm, y *= keep[m,c] * keep_scale before it is stored / fed to the head. */
-int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y,
+int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, uint16_t* yp /* optional P32 planes of y */,
                       const float* lin_w, const float* lin_b, const uint8_t* pad_mask, const uint8_t* keep, float keep_scale,
                       float* scalar, int m, int c, fcl_stream_t stream);
 
@@ -109,7 +128,8 @@ int fcl_variance_embed_add_fwd(const float* hs, const float* p, const float* e, 
 int fcl_position_table_fwd(const int32_t* dur, float* pos, int n, int lmax, fcl_stream_t stream);
 
 /* ---- H9: row gather (decoder_sa.py:467: hs[non_zero_lens_mask.eq(1)], plus the duration sort) -------- */
-int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n, int c, fcl_stream_t stream);
+/* dst_p (optional): the gathered rows as P32 planes (ceil(c/32) lines per row); dst may then be NULL. */
+int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, uint16_t* dst_p, int n, int c, fcl_stream_t stream);
 
 /* ---- H3: Encoder.blstm over packed sequences (encoder_sa.py:98-100,143-146) -------------------------- */
 /* x [B*T, C]; lens [B] int32 (device); w_ih_* [4H, C], w_hh_* [4H, H], b_* [4H] (= bias_ih + bias_hh);
@@ -118,10 +138,13 @@ int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, int n,
  * exchanging h through global memory — fastest on an idle GPU, not the default when other streams are in flight.
  * algo 3 is SINGLE-STREAM ONLY (two such kernels in flight can starve each other's groups) and needs `status`, a device status word
  * (FCL_STATUS_*): a group that times out reports there and its outputs are partial.  It is refused (per-step launches instead) when
- * 8*B workgroups do not fit the device one per CU.  status may be NULL for the other algorithms. */
+ * 8*B workgroups do not fit the device one per CU.  status may be NULL for the other algorithms.
+ * Optional P32 planes: out_p receives out as planes (for the predictor convolutions); x_p / w_ih_f_p / w_ih_r_p (all or none) are the
+ * pre-split operands of the input projection, in which case x may be NULL. */
 size_t fcl_bilstm_workspace_bytes(int b, int t, int h);
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
-                   const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, int b, int t, int c, int h,
+                   const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, uint16_t* out_p, const uint16_t* x_p,
+                   const uint16_t* w_ih_f_p, const uint16_t* w_ih_r_p, int b, int t, int c, int h,
                    int algo, void* workspace, size_t workspace_bytes, uint32_t* status, fcl_stream_t stream);
 
 /* ---- H7 as a single step: one LSTMCell (+ zoneout) update of M rows — the building block of the decoder loop, of the per-step
@@ -133,6 +156,9 @@ typedef struct {
     int shift;       /* conv tap row shift (GEMM terms only; 0 here) */
     const uint16_t* Whi; /* optional fragment-major bf16x3 planes of W (fcl_pack_frag_bf16) */
     const uint16_t* Wlo;
+    const uint16_t* Ap;  /* optional P32 planes of A and of W (fcl_pack_planes layout; see "bf16x3 operand planes" above): when EVERY term of a */
+    const uint16_t* Wp;  /* call carries both, the contraction runs on the LDS-DMA kernels of gemm_planes.hip and A / W may be NULL */
+    int lda_p, ldw_p;    /* row strides of the planes in 128-byte lines (>= ceil(K / 32)) */
 } fcl_gemm_term_t;
 
 typedef struct {
@@ -156,6 +182,8 @@ typedef struct {
     const int32_t* out2_row_base;
     long long out2_row_mul, out2_row_add;
     int ld2, out2_col_off;
+    uint16_t* h_out_p;       /* optional P32 planes of h_out (ld_hp lines per row): the next step's GEMM operand, written by the same epilogue */
+    int ld_hp;
     float* save_gates;       /* optional, training: activated gates i,f,g,o [M, 4U] */
     float* save_c_new;       /* optional: raw new cell (before zoneout) [M, U] */
     float* save_c_old;       /* optional: incoming cell / hidden state [M, U] */
@@ -191,6 +219,9 @@ typedef struct {
     const uint16_t *prenet_w0_hi, *prenet_w0_lo, *prenet_w1_hi, *prenet_w1_lo;
     const uint16_t *w0_pre_hi, *w0_pre_lo, *w0_hh_hi, *w0_hh_lo, *w1_ih_hi, *w1_ih_lo, *w1_hh_hi, *w1_hh_lo;
     const uint16_t *wf_h_hi, *wf_h_lo;
+    /* optional P32 planes (fcl_pack_planes) of the GEMM-sized matrices: with all six set (and C, P, U multiples of 32) the hoists and the
+     * LSTM steps with more than ~1000 live rows run on the LDS-DMA kernels, states and prenet outputs travelling between them pre-split */
+    const uint16_t *w0_att_p, *wf_att_p, *w0_pre_p, *w0_hh_p, *w1_ih_p, *w1_hh_p;
 } fcl_decoder_weights_t;
 
 typedef struct {
@@ -212,6 +243,8 @@ typedef struct {
     float* tap_lstm1;           /* optional [F, U] */
     void* workspace;
     size_t workspace_bytes;
+    const uint16_t* att_c_p;    /* optional P32 planes of att_c (C/32 lines per row; fcl_gather_rows_fwd writes them); att_c may then be NULL */
+    uint16_t* before_p;         /* optional out: P32 planes of `before` (ceil(odim/32) lines per row), the postnet's pre-split operand */
 } fcl_decoder_io_t;
 
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n);

@@ -33,6 +33,7 @@ struct PTerm {
     const u16* Wp;  // P32 planes of W [N, K]
     int lda_b, ldw_b;  // row strides in BYTES (= Kp * 4)
     int K, shift;
+    int a_zrow;  // index of the all-zero row of the A plane buffer (= its row count); W planes: row N is the zero row
 };
 struct PArgs {
     PTerm term[9];
@@ -45,7 +46,7 @@ struct PArgs {
     const u16* zero;  // >= 128 bytes of zeros
 };
 
-__global__ void pack_p32_kernel(const float* __restrict__ x, int ld, int rows, int K, u16* __restrict__ out) {
+__global__ void pack_p32_kernel(const float* __restrict__ x, int ld, int rows, int K, u16* __restrict__ out, int ldp) {
     const int Kp = (K + 31) & ~31;
     const long long total = (long long)rows * Kp;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -53,7 +54,7 @@ __global__ void pack_p32_kernel(const float* __restrict__ x, int ld, int rows, i
         const float v = k < K ? x[(size_t)r * ld + k] : 0.f;
         const __bf16 h = (__bf16)v;
         const __bf16 l = (__bf16)(v - (float)h);
-        u16* line = out + ((size_t)r * (Kp / 32) + (k >> 5)) * 64;
+        u16* line = out + ((size_t)r * ldp + (k >> 5)) * 64;
         line[k & 31] = __builtin_bit_cast(u16, h);
         line[32 + (k & 31)] = __builtin_bit_cast(u16, l);
     }
@@ -80,7 +81,8 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, int NST>
+// VAR (ablation): 0 = full kernel; 1 = LDS-DMA pipeline only (no fragment reads / MFMAs); 2 = no loads (MFMAs on whatever LDS holds); 3 = no output stores
+template <int WM, int WN, int TM, int TN, int NST, int VAR = 0>
 __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN;
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // LDS-DMA row groups (8 rows = 1 KB) per wave per chunk
@@ -97,42 +99,59 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
 
     // ---- loader coordinates: group g = j * NW + wave covers rows g*8 .. g*8+7 of its region; lane -> (row = lane >> 3, piece = lane & 7)
     const unsigned coff = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);  // source piece for this lane's LDS slot
-    int am[GA], alo[GA], ahi[GA];
+    int am[GA], alo[GA];
+    unsigned alen[GA];
 #pragma unroll
     for (int j = 0; j < GA; ++j) {
         const int m = m0 + (j * NW + wave) * 8 + (lane >> 3);
         am[j] = m;
         alo[j] = 0;
-        ahi[j] = m < a.M ? 0x7fffffff : -0x7fffffff;  // rows past M: empty segment -> zero line
+        alen[j] = m < a.M ? (unsigned)a.M : 0u;  // rows past M: empty segment -> zero row
         if (a.seg_lo != nullptr && m < a.M) {
             alo[j] = a.seg_lo[m];
-            ahi[j] = a.seg_hi[m];
+            alen[j] = (unsigned)(a.seg_hi[m] - alo[j]);
         }
     }
     int bn[GB];
 #pragma unroll
     for (int j = 0; j < GB; ++j) {
         const int n = n0 + (j * NW + wave) * 8 + (lane >> 3);
-        bn[j] = n < a.N ? n : -1;
+        bn[j] = n < a.N ? n : a.N;  // row N of every W plane buffer is the all-zero row
     }
-    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.zero) + coff;
-
-    auto fetch = [&](int stage, int t, int kb) {
+    // issue-side state: 32-bit byte offsets from the term's (uniform) base pointers, advanced by 128 B per chunk
+    unsigned oa[GA], ob[GB];
+    const unsigned char *baseA = nullptr, *baseW = nullptr;
+    int rem = 0, it = 0;
+    auto setup_term = [&](int t) {
         const PTerm T = a.term[t];
-        unsigned char* sbase = smem + stage * STAGE + wave * 1024;
-        const size_t koff = (size_t)kb * 128 + coff;
+        baseA = reinterpret_cast<const unsigned char*>(T.Ap);
+        baseW = reinterpret_cast<const unsigned char*>(T.Wp);
 #pragma unroll
         for (int j = 0; j < GA; ++j) {
             const int src = am[j] + T.shift;
-            const bool ok = src >= alo[j] && src < ahi[j];
-            const unsigned char* p = ok ? reinterpret_cast<const unsigned char*>(T.Ap) + (size_t)src * T.lda_b + koff : zsrc;
-            glds16(p, sbase + j * NW * 1024);
+            const int row = (unsigned)(src - alo[j]) < alen[j] ? src : T.a_zrow;
+            oa[j] = (unsigned)row * (unsigned)T.lda_b + coff;
+        }
+#pragma unroll
+        for (int j = 0; j < GB; ++j) ob[j] = (unsigned)bn[j] * (unsigned)T.ldw_b + coff;
+        rem = (T.K + 31) >> 5;
+    };
+    auto issue = [&](int stage) {
+        if (VAR == 2) return;
+        unsigned char* sbase = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < GA; ++j) {
+            glds16(baseA + oa[j], sbase + j * NW * 1024);
+            oa[j] += 128;
         }
 #pragma unroll
         for (int j = 0; j < GB; ++j) {
-            const unsigned char* p = bn[j] >= 0 ? reinterpret_cast<const unsigned char*>(T.Wp) + (size_t)bn[j] * T.ldw_b + koff : zsrc;
-            glds16(p, sbase + BM * 128 + j * NW * 1024);
+            glds16(baseW + ob[j], sbase + BM * 128 + j * NW * 1024);
+            ob[j] += 128;
         }
+    };
+    auto step_term = [&]() {
+        if (--rem == 0 && ++it < a.nterms) setup_term(it);  // rare, wave-uniform
     };
 
     // ---- fragment read offsets (bytes within a stage)
@@ -149,30 +168,8 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int nchunks = 0;
-    for (int t = 0; t < a.nterms; ++t) nchunks += (a.term[t].K + 31) >> 5;
-    int it = 0, ikb = 0;  // issue cursor
-    auto advance = [&]() {
-        if (++ikb >= ((a.term[it].K + 31) >> 5)) { ikb = 0; ++it; }
-    };
-    int issued = 0;
-#pragma unroll
-    for (int p = 0; p < NST - 1; ++p) {
-        if (issued < nchunks) { fetch(p, it, ikb); advance(); ++issued; }
-    }
-    int stage = 0, istage = NST - 1;
-    for (int i = 0; i < nchunks; ++i) {
-        const int ahead = issued - (i + 1);  // chunks that may stay in flight while chunk i is consumed
-        if (NST >= 4 && ahead >= 2) wait_vm<2 * GPW>();
-        else if (NST >= 3 && ahead >= 1) wait_vm<GPW>();
-        else wait_vm<0>();
-        asm volatile("s_barrier" ::: "memory");  // chunk i has landed for every wave; everyone is done reading the buffer refilled next
-        if (issued < nchunks) {
-            fetch(istage, it, ikb);
-            advance();
-            ++issued;
-            istage = istage + 1 == NST ? 0 : istage + 1;
-        }
+    auto compute = [&](int stage) {
+        if (VAR == 1) return;
         const unsigned char* sb = smem + stage * STAGE;
         s16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
@@ -194,7 +191,30 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
         }
-        stage = stage + 1 == NST ? 0 : stage + 1;
+    };
+
+    int nchunks = 0;
+    for (int t = 0; t < a.nterms; ++t) nchunks += (a.term[t].K + 31) >> 5;
+    setup_term(0);
+    int issued = 0;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) {
+        if (issued < nchunks) { issue(p); ++issued; step_term(); }
+    }
+    int cs = 0, is = NST - 1;
+    for (int i = 0; i < nchunks; ++i) {  // chunk i is consumed while chunks i+1 .. i+NST-2 stay in flight and chunk i+NST-1 is issued
+        const int left = nchunks - 1 - i;
+        if (NST >= 4 && left >= 2) wait_vm<2 * GPW>();
+        else if (NST >= 3 && left >= 1) wait_vm<GPW>();
+        else wait_vm<0>();
+        asm volatile("s_barrier" ::: "memory");  // chunk i has landed for every wave; everyone is done reading the buffer refilled now
+        if (left >= NST - 1) {
+            issue(is);
+            step_term();
+            is = is + 1 == NST ? 0 : is + 1;
+        }
+        compute(cs);
+        cs = cs + 1 == NST ? 0 : cs + 1;
     }
 
     const int col = lane & 15, rq = lane >> 4;
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
-                if (m < a.M) a.Y[(size_t)m * a.ldy + n] = acc[tm][tn][r] + bv;
+                if (m < a.M && (VAR == 0 || acc[tm][tn][r] == 12345.678f)) a.Y[(size_t)m * a.ldy + n] = acc[tm][tn][r] + bv;
             }
         }
 }
@@ -218,14 +238,16 @@ struct Mat {
     std::vector<float> h;
     float* d = nullptr;
     u16* p = nullptr;
-    int rows, K, Kp;
+    int rows, K, Kp, ldp;  // ldp: row stride in 128-byte blocks
 };
 
+static int g_pad = 0;
 static Mat make(int rows, int K, unsigned seed, float scale) {
     Mat m;
     m.rows = rows;
     m.K = K;
     m.Kp = (K + 31) & ~31;
+    m.ldp = m.Kp / 32 + g_pad;
     m.h.resize((size_t)rows * K);
     unsigned s = seed * 2654435761u + 12345u;
     for (auto& v : m.h) {
@@ -234,8 +256,9 @@ static Mat make(int rows, int K, unsigned seed, float scale) {
     }
     CK(hipMalloc(&m.d, m.h.size() * 4));
     CK(hipMemcpy(m.d, m.h.data(), m.h.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&m.p, (size_t)rows * m.Kp * 4 + 256));
-    hipLaunchKernelGGL(pack_p32_kernel, dim3(1024), dim3(256), 0, 0, m.d, K, rows, K, m.p);
+    CK(hipMalloc(&m.p, (size_t)(rows + 1) * m.ldp * 128 + 256));
+    CK(hipMemset(m.p, 0, (size_t)(rows + 1) * m.ldp * 128 + 256));
+    hipLaunchKernelGGL(pack_p32_kernel, dim3(1024), dim3(256), 0, 0, m.d, K, rows, K, m.p, m.ldp);
     CK(hipDeviceSynchronize());
     return m;
 }
@@ -243,11 +266,11 @@ static Mat make(int rows, int K, unsigned seed, float scale) {
 typedef int (*linear_fn)(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, void*);
 typedef int (*conv_fn)(const float*, const float*, const float*, const int*, const int*, const float*, float*, int, int, int, int, int, void*);
 
-template <int WM, int WN, int TM, int TN, int NST>
+template <int WM, int WN, int TM, int TN, int NST, int VAR = 0>
 static float run_cfg(const PArgs& a, int iters, const char* tag, double flops) {
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
     const size_t lds = (size_t)NST * (BM + BN) * 128;
-    auto k = pgemm_kernel<WM, WN, TM, TN, NST>;
+    auto k = pgemm_kernel<WM, WN, TM, TN, NST, VAR>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(64 * WM * WN), lds, 0, a);
@@ -268,6 +291,8 @@ static float run_cfg(const PArgs& a, int iters, const char* tag, double flops) {
 
 int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 50;
+    g_pad = argc > 2 ? atoi(argv[2]) : 0;
+    printf("row pad: %d x 128 B\n", g_pad);
     void* lib = dlopen("fcl-taco2_amd/libfcl_hip.so", RTLD_NOW);
     linear_fn lin = lib ? (linear_fn)dlsym(lib, "fcl_linear_fwd") : nullptr;
     conv_fn conv = lib ? (conv_fn)dlsym(lib, "fcl_conv1d_fwd") : nullptr;
@@ -302,7 +327,7 @@ int main(int argc, char** argv) {
         a.nterms = taps; a.M = M; a.N = N; a.Y = Y; a.ldy = N; a.zero = zero;
         for (int t = 0; t < taps; ++t) {
             const Mat& am = is_conv ? A[0] : A[t];
-            a.term[t] = PTerm{am.p, W[t].p, am.Kp * 4, W[t].Kp * 4, K, is_conv ? t - taps / 2 : 0};
+            a.term[t] = PTerm{am.p, W[t].p, am.ldp * 128, W[t].ldp * 128, K, is_conv ? t - taps / 2 : 0, M};
         }
         if (is_conv) { a.seg_lo = dlo; a.seg_hi = dhi; }
         const double flops = 2.0 * M * N * (double)K * taps;
@@ -331,12 +356,16 @@ int main(int argc, char** argv) {
         printf("  max |err| over 4000 samples: %.3e (max |ref| %.3f)  %s\n", worst, scale, worst < 2e-5 * fmax(1.0, scale) ? "OK" : "**** MISMATCH ****");
         // timing: new configurations
         run_cfg<2, 2, 2, 4, 3>(a, iters, "new <2,2,2,4> 3st", flops);
-        run_cfg<2, 2, 2, 4, 4>(a, iters, "new <2,2,2,4> 4st", flops);
-        run_cfg<2, 2, 4, 4, 3>(a, iters, "new <2,2,4,4> 3st", flops);
-        run_cfg<2, 2, 4, 4, 4>(a, iters, "new <2,2,4,4> 4st", flops);
+        run_cfg<2, 2, 2, 4, 3, 1>(a, iters, "  ... DMA pipeline only", flops);
+        run_cfg<2, 2, 2, 4, 3, 2>(a, iters, "  ... no loads", flops);
+        run_cfg<2, 2, 2, 4, 3, 3>(a, iters, "  ... no stores", flops);
         run_cfg<2, 2, 2, 2, 4>(a, iters, "new <2,2,2,2> 4st", flops);
+        run_cfg<2, 2, 2, 2, 4, 1>(a, iters, "  ... DMA pipeline only", flops);
+        run_cfg<2, 2, 2, 2, 4, 2>(a, iters, "  ... no loads", flops);
         run_cfg<4, 2, 2, 4, 3>(a, iters, "new <4,2,2,4> 3st 8 waves", flops);
-        run_cfg<2, 4, 4, 2, 3>(a, iters, "new <2,4,4,2> 3st 8 waves", flops);
+        run_cfg<4, 2, 2, 4, 3, 1>(a, iters, "  ... DMA pipeline only", flops);
+        run_cfg<4, 2, 2, 4, 3, 2>(a, iters, "  ... no loads", flops);
+        run_cfg<4, 2, 2, 4, 3, 3>(a, iters, "  ... no stores", flops);
         // old kernel through the library
         if (lin && conv) {
             hipEvent_t e0, e1;
