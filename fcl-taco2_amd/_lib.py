@@ -47,7 +47,8 @@ class LstmStep(C.Structure):
 class DecoderTrain(C.Structure):  # fcl_decoder_train_t
     _fields_ = [("n", _I), ("lmax", _I), ("u", _I), ("p", _I), ("live_rows_host", _P), ("p1d", _P), ("g0", _P), ("w0_pre", _P), ("w0_hh", _P),
                 ("w0_pos", _P), ("dur", _P), ("w1_ih", _P), ("w1_hh", _P), ("b1", _P), ("zoneout", _F), ("zk_h0", _P), ("zk_c0", _P), ("zk_h1", _P),
-                ("zk_c1", _P), ("s0", _P * 4), ("s1", _P * 4), ("h0_all", _P), ("h1_all", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+                ("zk_c1", _P), ("s0", _P * 4), ("s1", _P * 4), ("h0_all", _P), ("h1_all", _P), ("workspace", _P), ("workspace_bytes", _Z),
+                ("p1d_p", _P), ("w0_pre_p", _P), ("w0_hh_p", _P), ("w1_ih_p", _P), ("w1_hh_p", _P)]
 
 
 class DecoderBptt(C.Structure):  # fcl_decoder_bptt_t

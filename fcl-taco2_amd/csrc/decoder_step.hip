@@ -350,6 +350,17 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     const int nsU = (a.U + 31) >> 5, nsO = (a.O + 31) >> 5, nsP = (a.P + 31) >> 5, ptmax = ((a.P + 15) >> 4) - 1;
     const size_t lane8 = (size_t)lane * 8;
     auto frag = [&](const u16* base, int tile, int ns) { return base + (size_t)tile * ns * 512 + lane8; };
+    // epilogue biases of this wave's two prenet column tiles: requested now, consumed two / three barriers later (they used to be dependent
+    // global loads behind each layer's MFMA chain: ~1 us of exposed latency each on the step's critical path)
+    float pb0[2] = {0.f, 0.f}, pb1[2] = {0.f, 0.f};
+    if (has_pre) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = min((tt ? ptile2 : ptile) * 16 + col, a.P - 1);
+            pb0[tt] = a.b0[nc];
+            pb1[tt] = a.b1[nc];
+        }
+    }
     if (PRE && has_pre) {
         const u16* const wh0[2] = {frag(a.w0_hi, ptile, nsO), frag(a.w0_hi, min(ptile2, ptmax), nsO)};
         const u16* const wl0[2] = {frag(a.w0_lo, ptile, nsO), frag(a.w0_lo, min(ptile2, ptmax), nsO)};
@@ -423,7 +434,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? tile2 : tile) * 16 + col;
             if (nc < a.P) {
-                const float bn = a.b0[nc];
+                const float bn = tile == ptile ? pb0[tt] : a.b0[nc];  // first pass of the tile loop: the prefetched value
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int row = rq * 4 + r, m = m0 + row;
@@ -446,7 +457,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? tile2 : tile) * 16 + col;
             if (nc < a.P) {
-                const float bn = a.b1[nc];
+                const float bn = tile == ptile ? pb1[tt] : a.b1[nc];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + rq * 4 + r;

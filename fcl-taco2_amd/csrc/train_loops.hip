@@ -28,7 +28,8 @@ inline GemmArgs lin(const float* x, int lda, const float* w, int ldw, int k, flo
 
 extern "C" {
 
-size_t fcl_decoder_train_workspace_bytes(int n, int u) { return (n > 0 && u > 0) ? sizeof(float) * 6 * (size_t)n * u : 0; }
+// 6 fp32 state buffers [N, U] + 4 plane buffers of the same byte size (h0 / h1 ping-pong as P32 planes), all 128-byte aligned when N*U*4 is
+size_t fcl_decoder_train_workspace_bytes(int n, int u) { return (n > 0 && u > 0) ? sizeof(float) * 10 * (size_t)n * u + 128 : 0; }
 
 int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
     FCL_REQUIRE(a && a->live_rows_host && a->p1d && a->g0 && a->w0_pre && a->w0_hh && a->w0_pos && a->dur && a->w1_ih && a->w1_hh && a->b1,
@@ -41,9 +42,13 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const size_t NU = (size_t)a->n * a->u;
     const int U = a->u;
-    float* ws = (float*)a->workspace;
-    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * 6 * NU, s));
+    float* ws = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(a->workspace) + 127) & ~(uintptr_t)127);
+    const bool planes = a->p1d_p && a->w0_pre_p && a->w0_hh_p && a->w1_ih_p && a->w1_hh_p && !(a->p & 31) && !(U & 31) && !((NU * 4) & 127);
+    FCL_HIP(hipMemsetAsync(ws, 0, sizeof(float) * (planes ? 10 : 6) * NU, s));
     float *h0[2] = {ws, ws + NU}, *h1[2] = {ws + 2 * NU, ws + 3 * NU}, *c0 = ws + 4 * NU, *c1 = ws + 5 * NU;
+    unsigned short* h0p[2] = {reinterpret_cast<unsigned short*>(ws + 6 * NU), reinterpret_cast<unsigned short*>(ws + 7 * NU)};
+    unsigned short* h1p[2] = {reinterpret_cast<unsigned short*>(ws + 8 * NU), reinterpret_cast<unsigned short*>(ws + 9 * NU)};
+    const int ldp = a->p / 32, ldu = U / 32;
     int cur = 0;
     size_t off = 0;
     int prev = a->n;
@@ -51,9 +56,15 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
         const int n = a->live_rows_host[t];
         FCL_REQUIRE(n > 0 && n <= prev, FCL_ERR_SHAPE, "decoder_train_fwd: live_rows must be positive and non-increasing");
         prev = n;
+        const bool big = planes && !lstm_step_is_small(n, U);  // pre-split operands for the big-tile steps (their h planes feed the next big step)
         LstmStepArgs l0 = {};
         l0.term[0] = GemmTerm{a->p1d + off * a->p, a->w0_pre, a->p, a->p, a->p, 0, nullptr, nullptr};
         l0.term[1] = GemmTerm{h0[cur], a->w0_hh, U, U, U, 0, nullptr, nullptr};
+        if (big) {
+            l0.term[0].Ap = a->p1d_p + off * (size_t)ldp * 64; l0.term[0].Wp = a->w0_pre_p; l0.term[0].lda_p = l0.term[0].ldw_p = ldp;
+            l0.term[1].Ap = h0p[cur]; l0.term[1].Wp = a->w0_hh_p; l0.term[1].lda_p = l0.term[1].ldw_p = ldu;
+            l0.h_out_p = h0p[cur ^ 1]; l0.ld_hp = ldu;
+        }
         l0.nterms = 2;
         l0.M = n;
         l0.U = U;
@@ -79,6 +90,11 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
         LstmStepArgs l1 = {};
         l1.term[0] = GemmTerm{h0[cur ^ 1], a->w1_ih, U, U, U, 0, nullptr, nullptr};
         l1.term[1] = GemmTerm{h1[cur], a->w1_hh, U, U, U, 0, nullptr, nullptr};
+        if (big) {
+            l1.term[0].Ap = h0p[cur ^ 1]; l1.term[0].Wp = a->w1_ih_p; l1.term[0].lda_p = l1.term[0].ldw_p = ldu;
+            l1.term[1].Ap = h1p[cur]; l1.term[1].Wp = a->w1_hh_p; l1.term[1].lda_p = l1.term[1].ldw_p = ldu;
+            l1.h_out_p = h1p[cur ^ 1]; l1.ld_hp = ldu;
+        }
         l1.nterms = 2;
         l1.M = n;
         l1.U = U;

@@ -467,8 +467,9 @@ def _ptrs(ctype_array, tensors):
         ctype_array[i] = _p(t)
 
 
-def decoder_train_fwd(live_rows, p1d, g0, w0_pre, w0_hh, w0_pos, dur_i32, w1_ih, w1_hh, b1, zoneout, zk, s0, s1, h0_all, h1_all):
-    """live_rows: host int32 [lmax]; zk: None or [[h0, c0], [h1, c1]] uint8 [F, U]; s0/s1: (gates, c_new, c_old, h_old) outputs."""
+def decoder_train_fwd(live_rows, p1d, g0, w0_pre, w0_hh, w0_pos, dur_i32, w1_ih, w1_hh, b1, zoneout, zk, s0, s1, h0_all, h1_all, planes=None):
+    """live_rows: host int32 [lmax]; zk: None or [[h0, c0], [h1, c1]] uint8 [F, U]; s0/s1: (gates, c_new, c_old, h_old) outputs.
+    planes: optional (p1d_p, w0_pre_p, w0_hh_p, w1_ih_p, w1_hh_p) P32 planes -> the big steps run on the LDS-DMA kernels."""
     lib = _lib.load()
     n, u = g0.shape[0], h0_all.shape[1]
     a = _lib.DecoderTrain(n=n, lmax=int(live_rows.shape[0]), u=u, p=p1d.shape[1], live_rows_host=live_rows.ctypes.data, p1d=_p(p1d), g0=_p(g0),
@@ -478,6 +479,8 @@ def decoder_train_fwd(live_rows, p1d, g0, w0_pre, w0_hh, w0_pos, dur_i32, w1_ih,
         a.zk_h0, a.zk_c0, a.zk_h1, a.zk_c1 = [_p(t, torch.uint8) for t in (zk[0][0], zk[0][1], zk[1][0], zk[1][1])]
     _ptrs(a.s0, s0)
     _ptrs(a.s1, s1)
+    if planes is not None:
+        a.p1d_p, a.w0_pre_p, a.w0_hh_p, a.w1_ih_p, a.w1_hh_p = [_p(t, torch.int16) for t in planes]
     nbytes = lib.fcl_decoder_train_workspace_bytes(n, u)
     ws = torch.empty(nbytes, device=g0.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes

@@ -338,6 +338,7 @@ class TrainEngine(object):
         self.overlap_dw = overlap_dw
         self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
         self._dw_keep = []
+        self._plane_cache = {}
 
     @property
     def step_count(self):
@@ -347,6 +348,18 @@ class TrainEngine(object):
     @step_count.setter
     def step_count(self, v):
         self.step_dev.fill_(int(v))
+
+    def _wplanes(self, key, w):
+        """P32 planes of a weight matrix (ops.pack_planes), cached until the next optimizer step: the frozen KD teacher packs once, a model in
+        training once per update.  None when the pre-split path is off."""
+        if not ops.planes_enabled():
+            return None
+        hit = self._plane_cache.get(key)
+        if hit is not None and hit[0] == self.update_calls and hit[1] == w.data_ptr():
+            return hit[2]
+        pl = ops.pack_planes(w.reshape(w.shape[0], -1) if w.dim() != 2 else w)
+        self._plane_cache[key] = (self.update_calls, w.data_ptr(), pl)
+        return pl
 
     def _dw(self, fn):
         """Run a weight-gradient closure on the side stream, after everything enqueued on the main stream so far.  The closure (and through it
@@ -644,8 +657,12 @@ class TrainEngine(object):
         c.S0 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
         c.S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
         c.h0_all, c.h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
+        dec_planes = None
+        if ops.planes_enabled() and Pn % 32 == 0 and U % 32 == 0 and (N * U * 4) % 128 == 0:  # big steps on the LDS-DMA kernels (pre-split operands)
+            dec_planes = (ops.pack_planes(c.p1d), self._wplanes("w0_pre", c.w0_pre), self._wplanes("w0_hh", c.w0_hh),
+                          self._wplanes("w1_ih", c.w1_ih), self._wplanes("w1_hh", c.w1_hh))
         ops.decoder_train_fwd(c.live_i32, c.p1d, G0, c.w0_pre, c.w0_hh, w0_pos, c.dur_dev, c.w1_ih, c.w1_hh, b1s, c.zr, c.zk, c.S0, c.S1, c.h0_all,
-                              c.h1_all)
+                              c.h1_all, planes=dec_planes)
         out_cells = ops.linear(c.h1_all, c.wf_h)
         ops.add2d(out_cells, ops.gather_rows(F0, c.cell_row_i32))
         c.before = ops.gather_rows(out_cells, c.frame_cell)  # [B*L, O], zero where no cell maps (padding)

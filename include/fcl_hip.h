@@ -321,6 +321,9 @@ typedef struct {
     float *h0_all, *h1_all;         /* [F, U] zoneout-ed outputs of both layers */
     void* workspace;
     size_t workspace_bytes;         /* fcl_decoder_train_workspace_bytes(n, u) */
+    /* optional P32 planes (all five or none; P and U multiples of 32): the prenet output per cell [F, P/32 lines] and the four weight matrices;
+     * the steps with more than ~1000 live rows (~250 at U >= 512) then run on the LDS-DMA kernels, the states travelling pre-split */
+    const uint16_t *p1d_p, *w0_pre_p, *w0_hh_p, *w1_ih_p, *w1_hh_p;
 } fcl_decoder_train_t;
 typedef struct {
     int n, lmax, u;
