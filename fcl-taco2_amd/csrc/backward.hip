@@ -214,13 +214,16 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
     }
 }
 
-__global__ void act_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep, float scale, float* __restrict__ y, long long n, int act) {
+// yp (optional): the result as P32 planes of a [n / cols, cols] matrix (cols % 32 == 0) for the GEMM that consumes it
+__global__ void act_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ keep, float scale, float* __restrict__ y, long long n, int act,
+                               unsigned short* __restrict__ yp, int cols) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = x[i];
         if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
         else if (act == FCL_ACT_TANH) v = tanhf(v);
         if (keep) v = keep[i] ? v * scale : 0.f;
-        y[i] = v;
+        if (y) y[i] = v;
+        if (yp) store_p32(yp, cols >> 5, (int)(i / cols), (int)(i % cols), v);
     }
 }
 
@@ -484,14 +487,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int M, int C, 
 // y_act = act(gamma * (z - mean) * invstd + beta) ; y_drop = y_act * keep * scale (optional second output)
 __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, const uint8_t* __restrict__ keep, float scale, float* __restrict__ y_act,
-                                  float* __restrict__ y_drop, long long total, int C, int act) {
+                                  float* __restrict__ y_drop, long long total, int C, int act, unsigned short* __restrict__ yp) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
         if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
         else if (act == FCL_ACT_TANH) v = tanhf(v);
         y_act[i] = v;
-        if (y_drop) y_drop[i] = keep ? (keep[i] ? v * scale : 0.f) : v;
+        const float vd = keep ? (keep[i] ? v * scale : 0.f) : v;
+        if (y_drop) y_drop[i] = vd;
+        if (yp) store_p32(yp, C >> 5, (int)(i / C), c, vd);  // the block's output (after dropout) as the next conv's pre-split operand
     }
 }
 
@@ -629,10 +634,12 @@ int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep
     return check_hip(hipGetLastError(), "act_bwd");
 }
 
-int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y, size_t n, int act, fcl_stream_t stream) {
-    FCL_REQUIRE(x && y && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "act_fwd: bad arguments");
+int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y, uint16_t* yp, int cols, size_t n, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(x && (y || yp) && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "act_fwd: bad arguments");
+    FCL_REQUIRE(!yp || (cols > 0 && (cols & 31) == 0 && n % (size_t)cols == 0 && (reinterpret_cast<uintptr_t>(yp) & 127u) == 0), FCL_ERR_SHAPE,
+                "act_fwd: planes need cols %% 32 == 0, n %% cols == 0 and a 128-byte aligned buffer");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, x, keep, keep_scale, y, (long long)n, act);
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, x, keep, keep_scale, y, (long long)n, act, yp, cols);
     return check_hip(hipGetLastError(), "act_fwd");
 }
 
@@ -720,13 +727,14 @@ int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, fl
 }
 
 int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
-                   float* y_act, float* y_drop, int m, int c, int act, fcl_stream_t stream) {
+                   float* y_act, float* y_drop, uint16_t* yp, int m, int c, int act, fcl_stream_t stream) {
     FCL_REQUIRE(z && mean && invstd && gamma && beta && y_act && m >= 0 && c > 0 && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID,
                 "bn_act_fwd: bad arguments");
     FCL_REQUIRE(!keep || y_drop, FCL_ERR_INVALID, "bn_act_fwd: a keep mask needs y_drop");
+    FCL_REQUIRE(!yp || ((c & 31) == 0 && (reinterpret_cast<uintptr_t>(yp) & 127u) == 0), FCL_ERR_SHAPE, "bn_act_fwd: planes need C %% 32 == 0, 128-byte aligned");
     if (m == 0) return 0;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, z, mean, invstd, gamma, beta, keep, keep_scale,
-                       y_act, y_drop, (long long)m * c, c, act);
+                       y_act, y_drop, (long long)m * c, c, act, yp);
     return check_hip(hipGetLastError(), "bn_act_fwd");
 }
 

@@ -237,11 +237,16 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
     # ---- plan management --------------------------------------------------------------------------
     def _load_from_state_dict(self, *a, **k):  # any (re)load invalidates the packed device weights
         self._plan = None
+        if getattr(self, "_engine", None) is not None:
+            self._engine.invalidate_planes()
         return super()._load_from_state_dict(*a, **k)
 
     def load_state_dict(self, *a, **k):
         self._plan = None
-        return super().load_state_dict(*a, **k)
+        r = super().load_state_dict(*a, **k)
+        if getattr(self, "_engine", None) is not None:
+            self._engine.invalidate_planes()
+        return r
 
     def plan(self, device=None):
         """Packed device weights for the HIP path (rebuilt after load_state_dict / refresh_plan())."""

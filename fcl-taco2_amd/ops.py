@@ -357,14 +357,16 @@ def bn_stats(z, eps, momentum=0.1, running_mean=None, running_var=None):
     return mean, invstd
 
 
-def bn_act(z, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0):
-    """Returns (y_act, y_drop); y_drop is y_act when there is no keep mask."""
+def bn_act(z, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0, want_planes=False):
+    """Returns (y_act, y_drop); y_drop is y_act when there is no keep mask.  want_planes: (+ P32 planes of y_drop)."""
     m, c = z.shape
     y_act = torch.empty_like(z)
     y_drop = torch.empty_like(z) if keep is not None else None
-    check(_lib.load().fcl_bn_act_fwd(_p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(keep, torch.uint8), keep_scale, _p(y_act), _p(y_drop), m, c, act,
-                                     _stream()))
-    return y_act, (y_drop if keep is not None else y_act)
+    yp = planes_empty(m, c, z.device) if want_planes else None
+    check(_lib.load().fcl_bn_act_fwd(_p(z), _p(mean), _p(invstd), _p(gamma), _p(beta), _p(keep, torch.uint8), keep_scale, _p(y_act), _p(y_drop),
+                                     _p(yp, torch.int16), m, c, act, _stream()))
+    res = (y_act, (y_drop if keep is not None else y_act))
+    return res + (yp,) if want_planes else res
 
 
 def bn_bwd(dy, z, mean, invstd, gamma, dbeta, dgamma):
@@ -429,10 +431,22 @@ def adam_step(p, g, m, v, gradnorm_sq_f64, max_norm, lr, beta1, beta2, eps, step
                                     _p(step_i32, torch.int32), _p(status, torch.int32), _stream()))
 
 
-def act_fwd(x, act, keep=None, keep_scale=1.0):
+def act_fwd(x, act, keep=None, keep_scale=1.0, want_planes=False):
+    """y = act(x) [* keep * keep_scale]; want_planes (2-D x, width % 32 == 0): returns (y, P32 planes of y)."""
     y = torch.empty_like(x)
-    check(_lib.load().fcl_act_fwd(_p(x), _p(keep, torch.uint8), keep_scale, _p(y), x.numel(), act, _stream()))
-    return y
+    yp = planes_empty(x.shape[0], x.shape[1], x.device) if want_planes else None
+    check(_lib.load().fcl_act_fwd(_p(x), _p(keep, torch.uint8), keep_scale, _p(y), _p(yp, torch.int16), x.shape[-1] if want_planes else 0, x.numel(), act,
+                                  _stream()))
+    return (y, yp) if want_planes else y
+
+
+def linear_planes(xp, wpp, n, k, bias=None, act=ACT_NONE, want_f32=True, want_planes=False):
+    """Linear on pre-split operands: xp = P32 planes of x [m, k], wpp = P32 planes of the weight [n, k].  Returns (y or None, planes or None)."""
+    m, ldxp = xp.shape[0], xp.shape[1] // 64
+    y = torch.empty(m, n, device=xp.device, dtype=torch.float32) if want_f32 else None
+    yp = planes_empty(m, n, xp.device) if want_planes else None
+    check(_lib.load().fcl_linear_planes_fwd(_p(xp, torch.int16), ldxp, _p(wpp, torch.int16), _p(bias), _p(y), n, _p(yp, torch.int16), m, n, k, act, _stream()))
+    return y, yp
 
 
 def unpack_conv1d_grad(dwp, dw, scale=None):

@@ -219,6 +219,14 @@ class _Ctx(object):
     pass
 
 
+class _ConvP(object):
+    """What ops.conv1d_planes needs from a convolution: P32 planes of the packed taps, bias, sizes."""
+    __slots__ = ("wpp", "bias", "cin", "cout", "k")
+
+    def __init__(self, wpp, bias, cout, cin, k):
+        self.wpp, self.bias, self.cout, self.cin, self.k = wpp, bias, cout, cin, k
+
+
 class LossReport(dict):
     """The named losses of a step.  The fp64 loss sums are copied to pinned host memory asynchronously; the dict fills itself on first access, so a
     training loop that only logs every N steps never stalls the CPU on the GPU (the .cpu() read-back used to cost a full pipeline drain per step)."""
@@ -339,6 +347,10 @@ class TrainEngine(object):
         self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
         self._dw_keep = []
         self._plane_cache = {}
+        try:
+            model._engine = self  # load_state_dict() on the module reaches invalidate_planes() through this back-reference
+        except Exception:  # pragma: no cover - a module that refuses attributes only loses the cache invalidation hook
+            pass
 
     @property
     def step_count(self):
@@ -349,17 +361,26 @@ class TrainEngine(object):
     def step_count(self, v):
         self.step_dev.fill_(int(v))
 
-    def _wplanes(self, key, w):
-        """P32 planes of a weight matrix (ops.pack_planes), cached until the next optimizer step: the frozen KD teacher packs once, a model in
-        training once per update.  None when the pre-split path is off."""
+    def _wplanes(self, key, w, cache=True):
+        """P32 planes of a weight matrix (ops.pack_planes).  cache: `w` is a function of the PARAMETERS only, so its planes stay valid until
+        the next optimizer step (the frozen KD teacher packs once, a model in training once per update; load_state_dict clears the cache).
+        Matrices that also depend on buffers (eval-mode BatchNorm folds) pass cache=False.  None when the pre-split path is off."""
         if not ops.planes_enabled():
             return None
-        hit = self._plane_cache.get(key)
-        if hit is not None and hit[0] == self.update_calls and hit[1] == w.data_ptr():
-            return hit[2]
+        # validity stamp: optimizer steps (raw-pointer kernels) + torch's version counter of the flat buffer, which every in-place write through
+        # any parameter view bumps (load_state_dict, p.data.copy_(), torch optimizers on the autograd path)
+        stamp = (self.update_calls, self.pflat._version, tuple(w.shape))
+        hit = self._plane_cache.get(key) if cache else None
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
         pl = ops.pack_planes(w.reshape(w.shape[0], -1) if w.dim() != 2 else w)
-        self._plane_cache[key] = (self.update_calls, w.data_ptr(), pl)
+        if cache:
+            self._plane_cache[key] = (stamp, pl)
         return pl
+
+    def invalidate_planes(self):
+        """Parameters were overwritten in place (load_state_dict): cached weight planes are stale."""
+        self._plane_cache.clear()
 
     def _dw(self, fn):
         """Run a weight-gradient closure on the side stream, after everything enqueued on the main stream so far.  The closure (and through it
@@ -411,23 +432,42 @@ class TrainEngine(object):
         wt = torch.stack([ops.transpose2d(wp[k - 1 - j]) for j in range(k)]).contiguous()  # [k, Cin, Cout], taps reversed
         return wp, wt
 
-    def _conv_bn_fwd(self, c, x, prefix, lo, hi, act, keep):
-        """Conv1d(no bias) -> BatchNorm -> act -> Dropout.  Returns (block output, cache)."""
+    def _conv_bn_fwd(self, c, x, prefix, lo, hi, act, keep, xp=None, want_planes=False):
+        """Conv1d(no bias) -> BatchNorm -> act -> Dropout.  Returns (block output, cache[, P32 planes of the output]).
+        xp: P32 planes of x -> the convolution runs on the pre-split-operand kernels (its weight planes are cached per update)."""
         P, B = self.P, self.B
         ks = 1.0 / (1.0 - self.hp.dropout_rate) if keep is not None else 1.0
+        cout, cin, k = P[prefix + ".0.weight"].shape
+        use_p = xp is not None
+        want_planes = want_planes and cout % 32 == 0
+
+        def conv(wp, bias):
+            if use_p:
+                wpp = self._wplanes(prefix, wp.reshape(k * cout, cin), cache=c.train)  # eval mode folds the running statistics into the taps
+                return ops.conv1d_planes(xp, _ConvP(wpp, bias, cout, cin, k), lo, hi, ops.ACT_NONE, want_f32=True, want_planes=False)[0]
+            return ops.conv1d(x, wp, bias, lo, hi, ops.ACT_NONE)
+
         if c.train:
             wp, wt = self._conv_pack(P[prefix + ".0.weight"], need_t=c.save)
-            z = ops.conv1d(x, wp, None, lo, hi, ops.ACT_NONE)
+            z = conv(wp, None)
             mean, invstd = ops.bn_stats(z, BN_EPS, BN_MOMENTUM, B[prefix + ".1.running_mean"], B[prefix + ".1.running_var"])
             if prefix + ".1.num_batches_tracked" in B:
                 B[prefix + ".1.num_batches_tracked"].add_(1)  # integer bookkeeping buffer of torch's BatchNorm
-            y_act, y = ops.bn_act(z, mean, invstd, P[prefix + ".1.weight"], P[prefix + ".1.bias"], act, keep, ks)
-            return y, dict(x=x, z=z, y_act=y_act, wt=wt, mean=mean, invstd=invstd, prefix=prefix, act=act, lo=lo, hi=hi, keep=keep, ks=ks)
+            res = ops.bn_act(z, mean, invstd, P[prefix + ".1.weight"], P[prefix + ".1.bias"], act, keep, ks, want_planes=want_planes)
+            y_act, y = res[0], res[1]
+            cache = dict(x=x, z=z, y_act=y_act, wt=wt, mean=mean, invstd=invstd, prefix=prefix, act=act, lo=lo, hi=hi, keep=keep, ks=ks)
+            return (y, cache, res[2]) if want_planes else (y, cache)
         scale, shift = ops.fold_batchnorm(P[prefix + ".1.weight"], P[prefix + ".1.bias"], B[prefix + ".1.running_mean"], B[prefix + ".1.running_var"], BN_EPS)
         wp, wt = self._conv_pack(P[prefix + ".0.weight"], scale, need_t=c.save)
-        z = ops.conv1d(x, wp, shift, lo, hi, ops.ACT_NONE)
-        y = ops.act_fwd(z, act) if act != ops.ACT_NONE else z
-        return y, dict(x=x, z=z, y_act=y, wt=wt, scale=scale, prefix=prefix, act=act, lo=lo, hi=hi, keep=None, ks=1.0)
+        z = conv(wp, shift)
+        yp = None
+        if act != ops.ACT_NONE or want_planes:
+            r = ops.act_fwd(z, act, want_planes=want_planes)
+            y, yp = r if want_planes else (r, None)
+        else:
+            y = z
+        cache = dict(x=x, z=z, y_act=y, wt=wt, scale=scale, prefix=prefix, act=act, lo=lo, hi=hi, keep=None, ks=1.0)
+        return (y, cache, yp) if want_planes else (y, cache)
 
     def _conv_bn_bwd(self, c, dy, cc):
         G, P = self.G, self.P
@@ -456,9 +496,14 @@ class TrainEngine(object):
         self._dw(dw)
         return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
-    def _conv_bias_relu_fwd(self, x, prefix, lo, hi, need_t=True):
+    def _conv_bias_relu_fwd(self, x, prefix, lo, hi, need_t=True, xp=None):
         wp, wt = self._conv_pack(self.P[prefix + ".weight"], need_t=need_t)
-        y = ops.conv1d(x, wp, self.P[prefix + ".bias"], lo, hi, ops.ACT_RELU)
+        k, cout, cin = wp.shape
+        if xp is not None:
+            wpp = self._wplanes(prefix, wp.reshape(k * cout, cin))
+            y = ops.conv1d_planes(xp, _ConvP(wpp, self.P[prefix + ".bias"], cout, cin, k), lo, hi, ops.ACT_RELU, want_f32=True, want_planes=False)[0]
+        else:
+            y = ops.conv1d(x, wp, self.P[prefix + ".bias"], lo, hi, ops.ACT_RELU)
         return y, dict(x=x, y=y, wt=wt, prefix=prefix, lo=lo, hi=hi)
 
     def _conv_bias_relu_bwd(self, dy, cc):
@@ -476,16 +521,21 @@ class TrainEngine(object):
         self._dw(dw)
         return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
 
-    def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad):
-        caches, x, out = [], hs, None
+    def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad, hs_p=None):
+        caches, x, xp, out = [], hs, hs_p, None
         for i in range(layers):
-            y, cc = self._conv_bias_relu_fwd(x, "%s.conv.%d.0" % (name, i), lo, hi, need_t=c.save)
+            y, cc = self._conv_bias_relu_fwd(x, "%s.conv.%d.0" % (name, i), lo, hi, need_t=c.save, xp=xp)
             last = i == layers - 1
             keep = self._keep(c, (name, i), tuple(y.shape), 1.0 - p_drop) if (c.train and p_drop > 0) else None
             ks = 1.0 / (1.0 - p_drop) if keep is not None else 1.0
             g, b = self.P["%s.conv.%d.2.weight" % (name, i)], self.P["%s.conv.%d.2.bias" % (name, i)]
-            ln, out = ops.layernorm(y, g, b, LN_EPS, want_y=not last, lin_w=self.P[name + ".linear.weight"].reshape(-1) if last else None,
-                                    lin_b=self.P[name + ".linear.bias"] if last else None, pad_mask=pad if last else None, keep=keep, keep_scale=ks)
+            wantp = hs_p is not None and not last and y.shape[1] % 32 == 0
+            res = ops.layernorm(y, g, b, LN_EPS, want_y=(not last) and (c.save or not wantp),
+                                lin_w=self.P[name + ".linear.weight"].reshape(-1) if last else None,
+                                lin_b=self.P[name + ".linear.bias"] if last else None, pad_mask=pad if last else None, keep=keep, keep_scale=ks,
+                                want_planes=wantp)
+            ln, out = res[0], res[1]
+            xp = res[2] if wantp else None
             caches.append((cc, y, i, last, keep, ks))
             x = ln
         return out, caches
@@ -505,24 +555,32 @@ class TrainEngine(object):
         return dx
 
     # ------------------------------------------------------------------------------------------------ BiLSTM (per-step, saved)
-    def _bilstm_fwd(self, x, lens_dev, B, T, save=True, perm=None):
+    def _bilstm_fwd(self, x, lens_dev, B, T, save=True, perm=None, xp=None):
+        """Returns (out, cache, P32 planes of out or None).  xp: P32 planes of x (the input projections then run on the pre-split kernels)."""
         P, dev = self.P, self.dev
         H = self.hp.eunits // 2
+        use_p = xp is not None and x.shape[1] % 32 == 0 and (2 * H) % 32 == 0
+        wip = [self._wplanes("enc.blstm.weight_ih_l0" + sfx, P["enc.blstm.weight_ih_l0" + sfx]) for sfx in ("", "_reverse")] if use_p else None
         if not save:  # forward only (the frozen KD teacher): the persistent register-resident kernel of the synthesis path
             g = lambda k: P["enc.blstm." + k]
-            return ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), ops.add_vec(g("bias_ih_l0"), g("bias_hh_l0")),
-                              g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), ops.add_vec(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
-                              B, T, algo=3 if H == 256 else 0, status=self.status), None  # one group kernel at a time (this engine's stream)
+            r = ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), ops.add_vec(g("bias_ih_l0"), g("bias_hh_l0")),
+                           g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), ops.add_vec(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
+                           B, T, algo=3 if H == 256 else 0, status=self.status,  # one group kernel at a time (this engine's stream)
+                           x_p=xp if use_p else None, w_ih_p=wip, want_planes=use_p)
+            return (r[0], None, r[1]) if use_p else (r, None, None)
         out = torch.empty(B * T, 2 * H, device=dev)
         gx, whh, sv = [], [], []
-        for sfx in ("", "_reverse"):
+        for d, sfx in enumerate(("", "_reverse")):
             bias = ops.add_vec(P["enc.blstm.bias_ih_l0" + sfx], P["enc.blstm.bias_hh_l0" + sfx])
-            gx.append(ops.linear(x, P["enc.blstm.weight_ih_l0" + sfx], bias))  # [B*T, 4H]
+            if use_p:
+                gx.append(ops.linear_planes(xp, wip[d], 4 * H, x.shape[1], bias)[0])
+            else:
+                gx.append(ops.linear(x, P["enc.blstm.weight_ih_l0" + sfx], bias))  # [B*T, 4H]
             whh.append(P["enc.blstm.weight_hh_l0" + sfx])
             # gates, c_new, c_old, h_old (t-major); zero-filled: dead cells are never written but are read by the batched weight-gradient GEMM
             sv.append([torch.zeros(T, B, 4 * H, device=dev)] + [torch.zeros(T, B, H, device=dev) for _ in range(3)])
         ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv, status=self.status)
-        return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev, perm=perm)
+        return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev, perm=perm), (ops.pack_planes(out) if use_p else None)
 
     def _bilstm_bwd(self, d_out, c):
         P, G, dev = self.P, self.G, self.dev
@@ -586,21 +644,27 @@ class TrainEngine(object):
         drop_conv = c.train and p_conv > 0
         # ---- encoder
         c.xs = batch["xs"][:, :T].to(dev).to(torch.int64).reshape(-1).contiguous()
-        c.emb = ops.embedding(c.xs, P["enc.embed.weight"])
+        pl = ops.planes_enabled()  # forward GEMM operands travel pre-split (P32 planes) next to the fp32 tensors the backward pass keeps
+        xp = None
+        if pl:
+            c.emb, xp = ops.embedding(c.xs, P["enc.embed.weight"], want_planes=True)
+        else:
+            c.emb = ops.embedding(c.xs, P["enc.embed.weight"])
         x, c.conv_c, c.enc_taps = c.emb, [], [c.emb]
         for i in range(hp.econv_layers):
             keep = self._keep(c, ("enc.convs", i), (B * T, hp.econv_chans), 1.0 - p_conv) if drop_conv else None
-            x, cc = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep)
+            r = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep, xp=xp, want_planes=pl)
+            x, cc, xp = r if len(r) == 3 else (r[0], r[1], None)
             c.conv_c.append(cc)
             c.enc_taps.append(x)
-        c.hs, c.bl_c = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save, perm=c.perm_tb)
+        c.hs, c.bl_c, hs_p = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save, perm=c.perm_tb, xp=xp)
         # ---- predictors + embeds
         c.d_outs, c.dur_c = self._predictor_fwd(c, c.hs, "duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_dropout_rate,
-                                                c.e_lo, c.e_hi, c.enc_pad)
+                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p)
         c.p_outs, c.pit_c = self._predictor_fwd(c, c.hs, "pitch_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
-                                                c.e_lo, c.e_hi, c.enc_pad)
+                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p)
         c.e_outs, c.en_c = self._predictor_fwd(c, c.hs, "energy_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
-                                               c.e_lo, c.e_hi, c.enc_pad)
+                                               c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p)
         c.f0 = batch["f0"][:, :T].to(dev).float().reshape(-1).contiguous()
         c.en = batch["energy"][:, :T].to(dev).float().reshape(-1).contiguous()
         c.ds = batch["extras"][:, :T].to(dev).float().reshape(-1).contiguous()
@@ -617,9 +681,17 @@ class TrainEngine(object):
         c.p_embs, c.e_embs = pe, ee
         # ---- decoder, teacher forced, step-major cells
         N, F, lmax, live, offs = c.N, c.F, c.lmax, c.live, c.offs
-        c.att_c = ops.gather_rows(att, c.src_sorted)  # [N, C] sorted rows
+        dpl = pl and all(v % 32 == 0 for v in (C, Pn, U))  # decoder-side GEMMs on pre-split operands (whole 32-column lines)
+        att_p = pre_in_p = None
+        if dpl:
+            c.att_c, att_p = ops.gather_rows(att, c.src_sorted, want_planes=True)  # [N, C] sorted rows
+        else:
+            c.att_c = ops.gather_rows(att, c.src_sorted)
         c.ys = batch["ys"][:, :L].to(dev).float().reshape(B * L, O).contiguous()
-        c.pre_in = ops.gather_rows(c.ys, c.prev_frame)  # [F, O]; idx -1 -> zero row
+        if dpl:
+            c.pre_in, pre_in_p = ops.gather_rows(c.ys, c.prev_frame, want_planes=True)  # [F, O]; idx -1 -> zero row
+        else:
+            c.pre_in = ops.gather_rows(c.ys, c.prev_frame)
         c.k0 = c.k1 = None
         c.pks = 1.0
         if hp.dropout_rate > 0:  # the prenet's dropout is on in BOTH modes (decoder_sa.py:156-158)
@@ -631,10 +703,17 @@ class TrainEngine(object):
                 c.k0 = self._keep(c, ("prenet", 0), (F, Pn), 1.0 - hp.dropout_rate)
                 c.k1 = self._keep(c, ("prenet", 1), (F, Pn), 1.0 - hp.dropout_rate)
         w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
-        c.p0 = ops.linear(c.pre_in, P[w0n], P[b0n], ops.ACT_RELU)  # pre-dropout activations are kept
-        c.p0d = ops.act_fwd(c.p0, ops.ACT_NONE, c.k0, c.pks) if c.k0 is not None else c.p0
-        c.p1 = ops.linear(c.p0d, P[w1n], P[b1n], ops.ACT_RELU)
-        c.p1d = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks) if c.k1 is not None else c.p1
+        p1d_p = None
+        if dpl:
+            c.p0 = ops.linear_planes(pre_in_p, self._wplanes(w0n, P[w0n]), Pn, O, P[b0n], ops.ACT_RELU)[0]  # pre-dropout activations are kept
+            c.p0d, p0d_p = ops.act_fwd(c.p0, ops.ACT_NONE, c.k0, c.pks, want_planes=True)
+            c.p1 = ops.linear_planes(p0d_p, self._wplanes(w1n, P[w1n]), Pn, Pn, P[b1n], ops.ACT_RELU)[0]
+            c.p1d, p1d_p = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks, want_planes=True)
+        else:
+            c.p0 = ops.linear(c.pre_in, P[w0n], P[b0n], ops.ACT_RELU)  # pre-dropout activations are kept
+            c.p0d = ops.act_fwd(c.p0, ops.ACT_NONE, c.k0, c.pks) if c.k0 is not None else c.p0
+            c.p1 = ops.linear(c.p0d, P[w1n], P[b1n], ops.ACT_RELU)
+            c.p1d = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks) if c.k1 is not None else c.p1
         w_ih0 = P["dec.lstm.0.cell.weight_ih"]
         c.w0_att, c.w0_pre = ops.copy_cols(w_ih0, 0, C), ops.copy_cols(w_ih0, C, Pn)
         w0_pos = ops.copy_cols(w_ih0, C + Pn, 1).reshape(-1)
@@ -644,8 +723,12 @@ class TrainEngine(object):
         b1s = ops.add_vec(P["dec.lstm.1.cell.bias_ih"], P["dec.lstm.1.cell.bias_hh"])
         wf = P["dec.feat_out.weight"]
         c.wf_h, c.wf_att = ops.copy_cols(wf, 0, U), ops.copy_cols(wf, U, C)
-        G0 = ops.linear(c.att_c, c.w0_att, b0s)  # hoisted att_c share of the layer-0 gates
-        F0 = ops.linear(c.att_c, c.wf_att)
+        if dpl:
+            G0 = ops.linear_planes(att_p, self._wplanes("w0_att", c.w0_att), 4 * U, C, b0s)[0]  # hoisted att_c share of the layer-0 gates
+            F0 = ops.linear_planes(att_p, self._wplanes("wf_att", c.wf_att), O, C)[0]
+        else:
+            G0 = ops.linear(c.att_c, c.w0_att, b0s)
+            F0 = ops.linear(c.att_c, c.wf_att)
         c.zr = float(hp.zoneout_rate)
         c.zk = None
         if c.train and c.zr > 0:  # sampled zoneout: mask = 1 keeps the OLD state, P(1) = rate; [layer][h, c] -> [F, U]
@@ -658,21 +741,30 @@ class TrainEngine(object):
         c.S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
         c.h0_all, c.h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
         dec_planes = None
-        if ops.planes_enabled() and Pn % 32 == 0 and U % 32 == 0 and (N * U * 4) % 128 == 0:  # big steps on the LDS-DMA kernels (pre-split operands)
-            dec_planes = (ops.pack_planes(c.p1d), self._wplanes("w0_pre", c.w0_pre), self._wplanes("w0_hh", c.w0_hh),
+        if dpl and (N * U * 4) % 128 == 0:  # big steps on the LDS-DMA kernels (pre-split operands)
+            dec_planes = (p1d_p, self._wplanes("w0_pre", c.w0_pre), self._wplanes("w0_hh", c.w0_hh),
                           self._wplanes("w1_ih", c.w1_ih), self._wplanes("w1_hh", c.w1_hh))
         ops.decoder_train_fwd(c.live_i32, c.p1d, G0, c.w0_pre, c.w0_hh, w0_pos, c.dur_dev, c.w1_ih, c.w1_hh, b1s, c.zr, c.zk, c.S0, c.S1, c.h0_all,
                               c.h1_all, planes=dec_planes)
-        out_cells = ops.linear(c.h1_all, c.wf_h)
+        if dpl:
+            out_cells = ops.linear_planes(ops.pack_planes(c.h1_all), self._wplanes("wf_h", c.wf_h), O, U)[0]
+        else:
+            out_cells = ops.linear(c.h1_all, c.wf_h)
         ops.add2d(out_cells, ops.gather_rows(F0, c.cell_row_i32))
-        c.before = ops.gather_rows(out_cells, c.frame_cell)  # [B*L, O], zero where no cell maps (padding)
+        xp = None
+        if pl:
+            c.before, xp = ops.gather_rows(out_cells, c.frame_cell, want_planes=True)  # [B*L, O], zero where no cell maps (padding)
+        else:
+            c.before = ops.gather_rows(out_cells, c.frame_cell)
         # ---- postnet
         x, c.post_c, c.post_taps = c.before, [], []
         n_post = hp.postnet_layers
         for i in range(n_post):
             cout = hp.odim if i == n_post - 1 else hp.postnet_chans
             keep = self._keep(c, ("postnet", i), (B * L, cout), 1.0 - p_conv) if drop_conv else None
-            x, cc = self._conv_bn_fwd(c, x, "dec.postnet.postnet.%d" % i, c.f_lo, c.f_hi, ops.ACT_NONE if i == n_post - 1 else ops.ACT_TANH, keep)
+            r = self._conv_bn_fwd(c, x, "dec.postnet.postnet.%d" % i, c.f_lo, c.f_hi, ops.ACT_NONE if i == n_post - 1 else ops.ACT_TANH, keep,
+                                  xp=xp, want_planes=pl and i < n_post - 1)
+            x, cc, xp = r if len(r) == 3 else (r[0], r[1], None)
             c.post_c.append(cc)
             c.post_taps.append(x)
         c.after = ops.add_vec(c.before, x)

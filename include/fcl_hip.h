@@ -277,8 +277,9 @@ int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* 
 /* dst[r, 0:cols] += alpha * src[r, 0:cols] on rows with row_valid[r] != 0 (null: every row).  Strided on both sides: accumulates a
  * gradient block into a column range of weight_ih / feat_out.weight, adds residual-path gradients, masks padded rows. */
 int fcl_add2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, float alpha, const uint8_t* row_valid, fcl_stream_t stream);
-/* y = act(x) [* keep * keep_scale]   (elementwise; the training forward keeps pre-activations for the BatchNorm gradients). */
-int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y, size_t n, int act, fcl_stream_t stream);
+/* y = act(x) [* keep * keep_scale]   (elementwise; the training forward keeps pre-activations for the BatchNorm gradients).
+ * yp (optional): the result as P32 planes of the [n / cols, cols] matrix (cols % 32 == 0); y may then be NULL. */
+int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y, uint16_t* yp, int cols, size_t n, int act, fcl_stream_t stream);
 /* dw[co, ci, j] += dwp[j, co, ci] * (scale ? scale[co] : 1): packed tap-major conv gradient back to the torch Conv1d layout. */
 int fcl_unpack_conv1d_grad(const float* dwp, const float* scale, float* dw, int cout, int cin, int k, fcl_stream_t stream);
 /* dz = dy * act'(y) [* keep * keep_scale]   (y = the activation's OUTPUT before dropout; act = FCL_ACT_*). */
@@ -300,7 +301,8 @@ int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, flo
 int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                      double* workspace, fcl_stream_t stream);
 int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
-                   float* y_act, float* y_drop, int m, int c, int act, fcl_stream_t stream);
+                   float* y_act, float* y_drop, uint16_t* yp /* optional P32 planes of the block output (after dropout), C % 32 == 0 */, int m, int c, int act,
+                   fcl_stream_t stream);
 int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
                float* dz, int m, int c, fcl_stream_t stream);
 /* ---- the training step's time loops, enqueued by ONE call each (H13; decoder_sa.py:472-515, encoder_sa.py:143-146) ----------------------------
