@@ -283,6 +283,8 @@ struct WFrag {
                 lo[t][st] = *reinterpret_cast<const s16x8*>(flo[t] + st * 512);
             }
     }
+    // CHECK = false: the LDS rows hold NS * 32 valid (or zero-padded) elements, so no lane needs masking and the loop is branch-free
+    template <bool CHECK = true>
     __device__ __forceinline__ void mma(const u16* Ah, const u16* Al, int ldk, int K, int r16, int kq, f32x4 (&out)[NT]) const {
         f32x4 acc[NT];
 #pragma unroll
@@ -292,7 +294,7 @@ struct WFrag {
 #pragma unroll
         for (int st = 0; st < NS; ++st) {
             s16x8 a_hi = {0, 0, 0, 0, 0, 0, 0, 0}, a_lo = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (st * 32 + kq * 8 < K) {
+            if (!CHECK || st * 32 + kq * 8 < K) {
                 a_hi = *reinterpret_cast<const s16x8*>(ah + st * 32);
                 a_lo = *reinterpret_cast<const s16x8*>(al + st * 32);
             }
@@ -322,6 +324,10 @@ __device__ __forceinline__ void load_rowtile_split(u16* Ah, u16* Al, int ldk, co
         *reinterpret_cast<uint2*>(Al + r * ldk + c) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
     }
 }
+
+// Workgroup barrier for data exchanged through LDS only: LDS accesses retired (lgkmcnt), then s_barrier.  Unlike __syncthreads() it leaves
+// global loads in flight (vmcnt untouched) — the register-resident weight fragments requested ahead of their phase.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // SU/SO/SP = compile-time 32-k step counts of U/O/P (weights preloaded into registers); 0 = generic streaming loops.
 template <int SU, int SO, int SP>
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
         }
         load_rowtile_split(A1h, A1l, ldU, a.h1, a.U, a.U, m0, a.M_feat);
         __syncthreads();
+        if (a.dbg_phase == 1) return;
         for (int tile = wave; tile * 16 < a.O; tile += nwaves) {
             const u16* const wh[1] = {frag(a.wf_hi, tile, nsU)};
             const u16* const wl[1] = {frag(a.wf_lo, tile, nsU)};
@@ -412,13 +419,13 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     } else {
         for (int i = threadIdx.x; i < 16 * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }  // prev_out = 0 at t = 0
     }
-    if (!has_pre) return;
+    if (!has_pre || a.dbg_phase == 2) return;
     if (PRE) {  // layer-1 fragments: in flight while layer 0 computes
         const u16* const wh1[2] = {frag(a.w1_hi, ptile, nsP), frag(a.w1_hi, min(ptile2, ptmax), nsP)};
         const u16* const wl1[2] = {frag(a.w1_lo, ptile, nsP), frag(a.w1_lo, min(ptile2, ptmax), nsP)};
         f1.load(wh1, wl1);
     }
-    __syncthreads();
+    lds_barrier();  // NOT __syncthreads(): its vmcnt(0) would park every wave until the 32 fragment loads just issued have landed
     if (a.teacher_in) {
         load_rowtile_split(A2h, A2l, ldO, a.teacher_in, a.teacher_ld, a.O, m0, a.M_pre);
         __syncthreads();
@@ -445,7 +452,8 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    if (a.dbg_phase == 3) return;
     for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
         const int tile2 = tile + nwaves;
         const u16* const wh[2] = {frag(a.w1_hi, tile, nsP), frag(a.w1_hi, min(tile2, ptmax), nsP)};
@@ -468,6 +476,165 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
                     if (a.pre_out_p) store_p32(a.pre_out_p, (a.P + 31) >> 5, m, nc, v);
                     if (a.tap_prenet) a.tap_prenet[(size_t)(a.frame_off[m] + a.t_cur) * a.P + nc] = v;
                 }
+            }
+        }
+    }
+}
+
+// ---- the same chain, specialised and straightened for the shapes that fit registers (U = 32 SU, P = 32 SP <= 256, O <= 32 SO): every weight
+// fragment, bias, hoisted operand and (mask mode) keep byte is REQUESTED at kernel entry or one phase ahead, the three MFMA chains are
+// branch-free (LDS tiles are zero-padded to whole 32-k steps), the dropout mode is a template argument, and the two inner barriers are LDS-only
+// (lds_barrier) so the fragment loads of the next phase stay in flight across them.  The generic kernel above had a conditional global load +
+// s_waitcnt vmcnt(0) in every epilogue, which drained the 32 in-flight fragment loads of the next layer: +3.3 us per layer on a ~5 us kernel.
+template <int SU, int SO, int SP, int DROP>
+__global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetArgs a) {
+    constexpr int U = SU * 32, OP = SO * 32, P = SP * 32;
+    constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8;
+    static_assert(2 * SP <= 16, "two prenet column tiles per wave, 8 waves");
+    __shared__ __attribute__((aligned(16))) u16 A1h[16 * ldU], A1l[16 * ldU], A2h[16 * ldO], A2l[16 * ldO], A3h[16 * ldP], A3l[16 * ldP];
+    const int O = a.O;
+    const int m0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int col = lane & 15, rq = lane >> 4;
+    const bool has_feat = a.h1 != nullptr, has_pre = a.w0 != nullptr && m0 < a.M_pre;
+    const bool feat_wave = has_feat && wave * 16 < O;
+    const size_t lane8 = (size_t)lane * 8;
+    auto frag = [&](const u16* base, int tile, int ns) { return base + (size_t)tile * ns * 512 + lane8; };
+    const int t0 = wave, t1 = wave + 8;  // this wave's prenet column tiles
+
+    // ---- everything the epilogues need, requested now ---------------------------------------------------------------------------
+    unsigned int seed0 = 0, seed1 = 0;
+    if (DROP == 2) {
+        const unsigned int sbump = a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u;
+        seed0 = hash_u32(a.seed0 + sbump);
+        seed1 = hash_u32(a.seed1 + sbump);
+    }
+    float pb0[2] = {0.f, 0.f}, pb1[2] = {0.f, 0.f};
+    uint8_t k0[2][4], k1[2][4];
+    if (has_pre) {
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + col;
+            pb0[tt] = a.b0[nc];
+            pb1[tt] = a.b1[nc];
+            if (DROP == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mc = min(m0 + rq * 4 + r, a.M_pre - 1);
+                    k0[tt][r] = a.keep0[(size_t)mc * P + nc];
+                    k1[tt][r] = a.keep1[(size_t)mc * P + nc];
+                }
+            }
+        }
+    }
+    float f0v[4] = {0.f, 0.f, 0.f, 0.f};
+    int fo[4] = {0, 0, 0, 0};
+    const int fnc = wave * 16 + col;
+    if (feat_wave) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mc = min(m0 + rq * 4 + r, a.M_feat - 1);
+            f0v[r] = a.F0[(size_t)mc * O + min(fnc, O - 1)];
+            fo[r] = a.frame_off[mc];
+        }
+    }
+    WFrag<1, SU> ff;
+    WFrag<2, SO> f0;
+    WFrag<2, SP> f1;
+    if (feat_wave) {
+        const u16* const wh[1] = {frag(a.wf_hi, wave, SU)};
+        const u16* const wl[1] = {frag(a.wf_lo, wave, SU)};
+        ff.load(wh, wl);
+    }
+    if (has_pre) {
+        const u16* const wh0[2] = {frag(a.w0_hi, t0, SO), frag(a.w0_hi, t1, SO)};
+        const u16* const wl0[2] = {frag(a.w0_lo, t0, SO), frag(a.w0_lo, t1, SO)};
+        f0.load(wh0, wl0);
+    }
+    // ---- phase 0: h1 tile -> LDS planes; prenet-input tile zeroed (prev_out = 0 at t = 0; zero padding past O otherwise) ------------------
+    for (int i = threadIdx.x; i < 16 * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }
+    if (has_feat) load_rowtile_split(A1h, A1l, ldU, a.h1, U, U, m0, a.M_feat);
+    __syncthreads();
+    if (a.dbg_phase == 1) return;
+    // ---- phase 1: H8 feat_out of the previous step (+ H10 scatter) ---------------------------------------------------------------------
+    if (feat_wave) {
+        f32x4 accv[1];
+        ff.template mma<false>(A1h, A1l, ldU, U, r16, kq, accv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rq * 4 + r, m = m0 + row;
+            if (fnc < O) {
+                float v = 0.f;
+                if (m < a.M_feat) {
+                    v = accv[0][r] + f0v[r];
+                    a.before[(size_t)(fo[r] + a.t_prev) * O + fnc] = v;
+                    if (a.before_p) store_p32(a.before_p, (O + 31) >> 5, fo[r] + a.t_prev, fnc, v);
+                }
+                split1(v, A2h[row * ldO + fnc], A2l[row * ldO + fnc]);
+            }
+        }
+    }
+    if (has_feat && a.before_p && (O & 31)) {  // zero padding of the last 32-column line of this tile's frames
+        const int padc = 32 - (O & 31);
+        for (int i = threadIdx.x; i < 16 * padc; i += blockDim.x) {
+            const int m = m0 + i / padc;
+            if (m < a.M_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
+        }
+    }
+    if (!has_pre || a.dbg_phase == 2) return;
+    {   // layer-1 fragments: in flight across the next two phases
+        const u16* const wh1[2] = {frag(a.w1_hi, t0, SP), frag(a.w1_hi, t1, SP)};
+        const u16* const wl1[2] = {frag(a.w1_lo, t0, SP), frag(a.w1_lo, t1, SP)};
+        f1.load(wh1, wl1);
+    }
+    lds_barrier();
+    if (a.teacher_in) {  // teacher forcing: prenet input is y_{t-1}, not the decoder's own output
+        load_rowtile_split(A2h, A2l, ldO, a.teacher_in, a.teacher_ld, O, m0, a.M_pre);
+        __syncthreads();
+    }
+    // ---- phase 2: H6 prenet layer 0 ---------------------------------------------------------------------------------------------------------
+    {
+        f32x4 accv[2];
+        f0.template mma<false>(A2h, A2l, ldO, OP, r16, kq, accv);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rq * 4 + r, m = m0 + row;
+                float v = fmaxf(accv[tt][r] + pb0[tt], 0.f);
+                if (DROP == 1) v = k0[tt][r] ? v * a.keep_scale : 0.f;
+                if (DROP == 2) {
+                    const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)P + (unsigned int)nc) ^ seed0);
+                    v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
+                }
+                split1(v, A3h[row * ldP + nc], A3l[row * ldP + nc]);
+            }
+        }
+    }
+    lds_barrier();
+    if (a.dbg_phase == 3) return;
+    // ---- phase 3: H6 prenet layer 1 -> global (+ KD tap, + P32 planes) ------------------------------------------------------------------------
+    {
+        f32x4 accv[2];
+        f1.template mma<false>(A3h, A3l, ldP, P, r16, kq, accv);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + col;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + rq * 4 + r;
+                if (m >= a.M_pre) continue;
+                float v = fmaxf(accv[tt][r] + pb1[tt], 0.f);
+                if (DROP == 1) v = k1[tt][r] ? v * a.keep_scale : 0.f;
+                if (DROP == 2) {
+                    const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)P + (unsigned int)nc) ^ seed1);
+                    v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
+                }
+                if (a.pre_out) a.pre_out[(size_t)m * P + nc] = v;
+                if (a.pre_out_p) store_p32(a.pre_out_p, SP, m, nc, v);
+                if (a.tap_prenet) a.tap_prenet[(size_t)(a.frame_off[m] + a.t_cur) * P + nc] = v;
             }
         }
     }
@@ -752,6 +919,8 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
     double fl = 0;
     if (a.h1) fl += 2.0 * a.M_feat * a.O * a.U;
     if (a.w0) fl += 2.0 * a.M_pre * ((double)a.P * a.O + (double)a.P * a.P);
+    static const int dbg = tunable("FP_DBG", 0);
+    const_cast<FeatPrenetArgs&>(a).dbg_phase = dbg;
     const bool planes = a.wf_hi && a.wf_lo && a.w0_hi && a.w0_lo && a.w1_hi && a.w1_lo && !(a.U & 7) && !(a.O & 7) && !(a.P & 7);
     FCL_REQUIRE(planes || (!a.pre_out_p && !a.before_p), FCL_ERR_INVALID, "feat_prenet: P32 outputs need the bf16x3 weight planes");
     FCL_REQUIRE(!a.w0 || a.pre_out || a.pre_out_p, FCL_ERR_INVALID, "feat_prenet: no prenet output buffer");
@@ -763,8 +932,17 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
             if (rc) return rc;
         }
         ProfScope ps("feat_prenet_kernel/bf16x3", fl, rows, s);
-        if (a.U == 256 && a.O == 80 && a.P == 256) hipLaunchKernelGGL((feat_prenet_x3_kernel<8, 3, 8>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
-        else hipLaunchKernelGGL((feat_prenet_x3_kernel<0, 0, 0>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
+        static const int fast = tunable("FEAT_PRENET_FAST", 1);
+        if (fast && a.U == 256 && a.O > 64 && a.O <= 96 && a.P == 256) {
+            const dim3 g((rows + 15) / 16), b(512);
+            if (a.drop_mode == 1) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 1>), g, b, 0, s, a);
+            else if (a.drop_mode == 2) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 2>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 0>), g, b, 0, s, a);
+        } else if (a.U == 256 && a.O == 80 && a.P == 256) {
+            hipLaunchKernelGGL((feat_prenet_x3_kernel<8, 3, 8>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
+        } else {
+            hipLaunchKernelGGL((feat_prenet_x3_kernel<0, 0, 0>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
+        }
     } else {
         ProfScope ps("feat_prenet_kernel", fl, rows, s);
         hipLaunchKernelGGL(feat_prenet_kernel, dim3((rows + 15) / 16), dim3(512), lds, s, a);

@@ -109,6 +109,7 @@ struct FeatPrenetArgs {
     float* tap_prenet;  // optional [F, P]; row = frame_off[m] + t_cur
     unsigned short* pre_out_p;  // optional P32 planes of pre_out (ceil(P/32) lines per row): the next LSTM step's pre-split operand
     unsigned short* before_p;   // optional P32 planes of `before` (ceil(O/32) lines per row, zero past O): the postnet's pre-split operand
+    int dbg_phase;              // developer timing aid (FCL_FP_DBG): 1..3 = return after the loads / feat / prenet-0 phase (results are then garbage)
 };
 
 // ---- bf16x3 operand split shared by the big-tile GEMMs (gemm_f32.hip) and the weight-gradient GEMM (backward.hip) ------------------
