@@ -212,22 +212,26 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, rq = lane >> 4;
     const unsigned int seed = hash_u32(a.rng_seed + (a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u));
-    const int np = a.Yp ? a.ldyp * 32 : a.N;  // planes are written up to their padded width (zeros past N)
+    // Epilogue through LDS: the MFMA accumulator layout gives every lane ONE column of four rows, i.e. 4-byte (fp32) or 2-byte (planes) stores,
+    // 32 - 64 store instructions per lane.  The finished tile is staged as fp32 in the (now idle) ring and written out row-wise: 16 bytes per
+    // lane, whole 128-byte lines for the planes (hi | lo of 32 columns), a quarter / an eighth of the store instructions.
+    constexpr int LDT = G::BN + 4;  // staging row stride (floats): keeps float4 alignment, spreads rows over banks
+    static_assert(G::BM * LDT * 4 <= G::LDS_BYTES, "the staging tile must fit the ring");
+    float* tile = reinterpret_cast<float*>(smem);
+    __syncthreads();  // every wave is done with the last chunk
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + (wn * TN + tn) * 16 + col;
-            if (n >= np) continue;
+            const int cn = (wn * TN + tn) * 16 + col, n = n0 + cn;
             const bool nin = n < a.N;
             const float bn = (a.bias && nin) ? a.bias[n] : 0.f;
             const float r1w = (a.rank1_w && nin) ? a.rank1_w[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
-                if (m >= a.M) continue;
+                const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + rm;
                 float v = 0.f;
-                if (nin) {
+                if (nin && m < a.M) {
                     v = acc[tm][tn][r] + bn;
                     if (a.rank1_a) v += a.rank1_a[(size_t)m * a.rank1_lda] * r1w;
                     if (a.C0) v += a.C0[(size_t)m * a.ldc0 + n];
@@ -240,12 +244,43 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
                         v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
                     }
                     if (a.R) v += a.R[(size_t)m * a.ldr + n];
-                    if (a.Y) a.Y[(size_t)m * a.ldy + n] = v;
                     if (a.Y2) a.Y2[(size_t)(a.y2_row_base[m] + a.y2_row_add) * a.ldy2 + n] = v;
                 }
-                if (a.Yp) store_p32(a.Yp, a.ldyp, m, n, v);
+                tile[rm * LDT + cn] = v;  // zeros past N / M: the planes' padding
             }
         }
+    __syncthreads();
+    const int rows = min(G::BM, a.M - m0);
+    if (a.Y) {
+        const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
+        for (int i = threadIdx.x; i < rows * (G::BN / 4); i += G::THREADS) {
+            const int rm = i / (G::BN / 4), c4 = (i - rm * (G::BN / 4)) * 4, n = n0 + c4;
+            if (n >= a.N) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c4);
+            float* dst = a.Y + (size_t)(m0 + rm) * a.ldy + n;
+            if (vec && n + 3 < a.N) {
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < a.N) dst[e] = v[e];
+            }
+        }
+    }
+    if (a.Yp) {  // item = (row, 32-column line, quarter q): 8 values -> 16 bytes of hi at piece q and 16 bytes of lo at piece 4 + q
+        const int np = a.ldyp * 32;
+        for (int i = threadIdx.x; i < rows * (G::BN / 8); i += G::THREADS) {
+            const int rm = i / (G::BN / 8), c8 = (i - rm * (G::BN / 8)) * 8, n = n0 + c8;
+            if (n >= np) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8), v1 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8 + 4);
+            uint2 h0, l0, h1, l1;
+            split4(v0, h0, l0);
+            split4(v1, h1, l1);
+            u16* line = a.Yp + ((size_t)(m0 + rm) * a.ldyp + (n >> 5)) * 64 + (n & 31);
+            *reinterpret_cast<uint4*>(line) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(line + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+    }
 }
 
 template <int WM, int WN, int TM, int NST, int MODE>
