@@ -308,16 +308,56 @@ __global__ __launch_bounds__(64 * WM * WN) void plstm_kernel(const LstmStepArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     pmainloop<WM, WN, TM, 4, NST, true>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, smem, acc);
-    if (u >= a.U) return;
+    // Epilogue through LDS (see pgemm_kernel): the new h and c of the tile are staged as [row][unit] fp32 and written out row-wise, 16 bytes
+    // per lane; the tile's 16 WN units are (part of) ONE 128-byte P32 line per row, so the planes of h go out as whole 16-byte pieces too.
+    constexpr int UW = 16 * WN, LDT = UW + 4;
+    static_assert(2 * G::BM * LDT * 4 <= G::LDS_BYTES, "the staging tiles must fit the ring");
+    float* th = reinterpret_cast<float*>(smem);
+    float* tc = th + G::BM * LDT;
+    __syncthreads();  // every wave is done with the last chunk
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
-            if (m >= a.M) continue;
-            const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
-            cell_finish(a, m, u, pre, ci[tm][r]);
+            const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + rm;
+            float h_w = 0.f, c_w = 0.f;
+            if (m < a.M && u < a.U) {
+                const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
+                cell_math(a, m, u, pre, ci[tm][r], h_w, c_w);
+            }
+            th[rm * LDT + wn * 16 + (lane & 15)] = h_w;
+            tc[rm * LDT + wn * 16 + (lane & 15)] = c_w;
         }
+    __syncthreads();
+    const int rows = min(G::BM, a.M - m0);
+    const bool vec = (a.U & 3) == 0;
+    for (int i = threadIdx.x; i < rows * (UW / 4); i += G::THREADS) {
+        const int rm = i / (UW / 4), c4 = (i - rm * (UW / 4)) * 4, uu = u0 + c4;
+        if (uu >= a.U) continue;
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(th + rm * LDT + c4), cv = *reinterpret_cast<const f32x4*>(tc + rm * LDT + c4);
+        const size_t off = (size_t)(m0 + rm) * a.U + uu;
+        if (vec && uu + 3 < a.U) {
+            *reinterpret_cast<f32x4*>(a.h_out + off) = hv;
+            *reinterpret_cast<f32x4*>(a.c + off) = cv;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (uu + e < a.U) { a.h_out[off + e] = hv[e]; a.c[off + e] = cv[e]; }
+        }
+    }
+    if (a.h_out_p) {  // U % 32 == 0 (whole lines): item = (row, 8 units) -> 16 bytes of hi and 16 bytes of lo
+        for (int i = threadIdx.x; i < rows * (UW / 8); i += G::THREADS) {
+            const int rm = i / (UW / 8), c8 = (i - rm * (UW / 8)) * 8, uu = u0 + c8;
+            if (uu >= a.U) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(th + rm * LDT + c8), v1 = *reinterpret_cast<const f32x4*>(th + rm * LDT + c8 + 4);
+            uint2 h0, l0, h1, l1;
+            split4(v0, h0, l0);
+            split4(v1, h1, l1);
+            u16* line = a.h_out_p + ((size_t)(m0 + rm) * a.ld_hp + (uu >> 5)) * 64 + (uu & 31);
+            *reinterpret_cast<uint4*>(line) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(line + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------------------------------------------------
@@ -379,6 +419,8 @@ static int launch_plstm_cfg(const LstmStepArgs& a, hipStream_t s, double flops) 
 }
 
 int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
+    FCL_REQUIRE(!a.h_out_p || ((a.U & 31) == 0 && a.ld_hp * 32 >= a.U && (reinterpret_cast<uintptr_t>(a.h_out_p) & 127u) == 0), FCL_ERR_SHAPE,
+                "lstm_step: h_out_p needs U %% 32 == 0, ld_hp >= U / 32 and a 128-byte aligned buffer");
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * 4.0 * a.U * ksum;

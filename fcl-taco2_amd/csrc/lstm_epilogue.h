@@ -46,7 +46,9 @@ __device__ __forceinline__ CellIn cell_prefetch(const LstmStepArgs& a, int m, in
     return ci;
 }
 
-__device__ __forceinline__ void cell_finish(const LstmStepArgs& a, int m, int u, const float (&acc)[4], const CellIn& ci) {
+// the cell + zoneout update of one (row m, unit u): new hidden / cell state in h_w / c_w; the training-only side outputs (saved gates, out2 tap)
+// are stored here, the states themselves by the caller (directly: cell_finish; or staged through LDS for row-wise stores: plstm_kernel)
+__device__ __forceinline__ void cell_math(const LstmStepArgs& a, int m, int u, const float (&acc)[4], const CellIn& ci, float& h_w, float& c_w) {
     const float ig = sigmoid_f(acc[0] + ci.add[0]), fg = sigmoid_f(acc[1] + ci.add[1]);
     const float gg = tanh_f(acc[2] + ci.add[2]), og = sigmoid_f(acc[3] + ci.add[3]);
     const float c_new = fg * ci.c_old + ig * gg;
@@ -60,10 +62,8 @@ __device__ __forceinline__ void cell_finish(const LstmStepArgs& a, int m, int u,
         h_o = a.zoneout * ci.h_old + (1.0f - a.zoneout) * h_new;
         c_o = a.zoneout * ci.c_old + (1.0f - a.zoneout) * c_new;
     }
-    const float h_w = ci.live ? h_o : ci.h_old;
-    a.h_out[off] = h_w;
-    if (a.h_out_p) store_p32(a.h_out_p, a.ld_hp, m, u, h_w);  // the same state as the next step's pre-split GEMM operand
-    a.c[off] = ci.live ? c_o : ci.c_old;
+    h_w = ci.live ? h_o : ci.h_old;
+    c_w = ci.live ? c_o : ci.c_old;
     if (a.save_gates) {  // training forward: what fcl_lstm_cell_bwd needs
         float* sg = a.save_gates + (size_t)m * 4 * a.U;
         sg[u] = ig; sg[a.U + u] = fg; sg[2 * a.U + u] = gg; sg[3 * a.U + u] = og;
@@ -75,6 +75,15 @@ __device__ __forceinline__ void cell_finish(const LstmStepArgs& a, int m, int u,
         const long long row = (a.out2_row_base ? (long long)a.out2_row_base[m] : (long long)m * a.out2_row_mul) + a.out2_row_add;
         a.out2[(size_t)row * a.ld2 + a.out2_col_off + u] = ci.live ? h_o : 0.f;
     }
+}
+
+__device__ __forceinline__ void cell_finish(const LstmStepArgs& a, int m, int u, const float (&acc)[4], const CellIn& ci) {
+    float h_w, c_w;
+    cell_math(a, m, u, acc, ci, h_w, c_w);
+    const size_t off = (size_t)m * a.U + u;
+    a.h_out[off] = h_w;
+    if (a.h_out_p) store_p32(a.h_out_p, a.ld_hp, m, u, h_w);  // the same state as the next step's pre-split GEMM operand
+    a.c[off] = c_w;
 }
 
 }  // namespace fcl
