@@ -495,7 +495,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 
 bool lstm_step_is_small(int M, int U) {
     static const int small_m = tunable("LSTM_SMALL_M", 0);  // 0 = by width: the wave-per-gate small-tile kernel re-streams W per 16-row tile,
-    return M <= (small_m ? small_m : (U >= 512 ? 256 : 1024));  // which stops paying earlier at U = 1024 (FCL-taco2-T)
+    // which stops paying earlier at U = 1024 (FCL-taco2-T); with the pre-split operand kernels available (32-row tiles) at ~500 rows for U = 256
+    static const bool planes_on = tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0;
+    return M <= (small_m ? small_m : (U >= 512 ? 256 : (planes_on ? 512 : 1024)));
 }
 
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {

@@ -429,7 +429,9 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     const long long t64 = (long long)((a.M + 63) / 64) * ((a.U + 31) / 32);
     if (force == 1 || (force == 0 && t128 >= 150)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
     if (force == 2 || (force == 0 && t64 >= 200)) return launch_plstm_cfg<2, 2, 2, 3>(a, s, flops);
-    return launch_plstm_cfg<2, 1, 2, 4>(a, s, flops);  // 32 x 64 gate-column tiles (16 units): M <~ 1600 at U = 256
+    static const int row32_m = tunable("PLSTM_ROW32_M", 1100);
+    if (force == 4 || (force == 0 && a.M <= row32_m)) return launch_plstm_cfg<2, 2, 1, 4>(a, s, flops);  // 32 x 128 tiles: M = 500 .. 1100 (measured)
+    return launch_plstm_cfg<2, 1, 2, 4>(a, s, flops);  // 64 x 64 gate-column tiles (16 units): M <~ 1600 at U = 256
 }
 
 // --------------------------------------------------------------------------------------------------------------------------------------

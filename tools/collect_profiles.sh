@@ -1,0 +1,17 @@
+# Collects the round's profile evidence on the GPU box into gpurun_out/prof_$1/ (copy the summaries to profiles/ afterwards):
+#   default bench JSON, rocprofv3 kernel stats (hipGraph x 4 streams = the default command; eager x 1 stream), PMC FETCH_SIZE / WRITE_SIZE (separate passes)
+TAG=${1:-r2}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+rocprofv3 --kernel-trace --stats -d $OUT/graph4 -o g --output-format csv -- python3 bench.py --no-cpu-baseline > $OUT/graph4_bench.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $OUT/eager1 -o e --output-format csv -- python3 bench.py --streams 1 --eager --no-cpu-baseline > $OUT/eager1_bench.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- python3 bench.py --streams 1 --eager --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- python3 bench.py --streams 1 --eager --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS -d $OUT/pmc_sq -o s --output-format csv -- python3 bench.py --streams 1 --eager --no-cpu-baseline --steps 6 --warmup 2 > /dev/null 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_fetch/f_counter_collection.csv > $OUT/pmc_fetch_size.csv
+python3 tools/pmc_summary.py $OUT/pmc_write/w_counter_collection.csv > $OUT/pmc_write_size.csv
+python3 tools/pmc_multi.py $OUT/pmc_sq/s_counter_collection.csv > $OUT/pmc_sq_counters.csv 2>/dev/null
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq   # raw per-dispatch rows are large; the summaries are what gets committed
+ls -la $OUT $OUT/graph4 | head -30

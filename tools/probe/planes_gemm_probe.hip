@@ -82,13 +82,14 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // VAR (ablation): 0 = full kernel; 1 = LDS-DMA pipeline only (no fragment reads / MFMAs); 2 = no loads (MFMAs on whatever LDS holds); 3 = no output stores
-template <int WM, int WN, int TM, int TN, int NST, int VAR = 0>
+template <int WM, int WN, int TM, int TN, int NST, int VAR = 0, int KS = 1>
 __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN;
     constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // LDS-DMA row groups (8 rows = 1 KB) per wave per chunk
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && (NW % 2) == 0, "tile rows must split evenly over the waves");
-    constexpr int GPW = GA + GB;
-    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int GPW = (GA + GB) * KS;
+    constexpr int SUB = (BM + BN) * 128;  // one 32-k chunk
+    constexpr int STAGE = SUB * KS;       // KS chunks per ring stage: one wait + barrier per KS * 32 k
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,20 +139,24 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
     };
     auto issue = [&](int stage) {
         if (VAR == 2) return;
-        unsigned char* sbase = smem + stage * STAGE + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < GA; ++j) {
-            glds16(baseA + oa[j], sbase + j * NW * 1024);
-            oa[j] += 128;
-        }
+        for (int ks = 0; ks < KS; ++ks) {  // (terms are whole multiples of KS chunks in this probe)
+            unsigned char* sbase = smem + stage * STAGE + ks * SUB + wave * 1024;
 #pragma unroll
-        for (int j = 0; j < GB; ++j) {
-            glds16(baseW + ob[j], sbase + BM * 128 + j * NW * 1024);
-            ob[j] += 128;
+            for (int j = 0; j < GA; ++j) {
+                glds16(baseA + oa[j], sbase + j * NW * 1024);
+                oa[j] += 128;
+            }
+#pragma unroll
+            for (int j = 0; j < GB; ++j) {
+                glds16(baseW + ob[j], sbase + BM * 128 + j * NW * 1024);
+                ob[j] += 128;
+            }
         }
     };
     auto step_term = [&]() {
-        if (--rem == 0 && ++it < a.nterms) setup_term(it);  // rare, wave-uniform
+        rem -= KS;
+        if (rem <= 0 && ++it < a.nterms) setup_term(it);  // rare, wave-uniform
     };
 
     // ---- fragment read offsets (bytes within a stage)
@@ -170,7 +175,9 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
 
     auto compute = [&](int stage) {
         if (VAR == 1) return;
-        const unsigned char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+        const unsigned char* sb = smem + stage * STAGE + ks * SUB;
         s16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
@@ -191,10 +198,11 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const PArgs a) {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
         }
+        }
     };
 
     int nchunks = 0;
-    for (int t = 0; t < a.nterms; ++t) nchunks += (a.term[t].K + 31) >> 5;
+    for (int t = 0; t < a.nterms; ++t) nchunks += ((a.term[t].K + 31) >> 5) / KS;
     setup_term(0);
     int issued = 0;
 #pragma unroll
@@ -411,11 +419,11 @@ static Mat make(int rows, int K, unsigned seed, float scale) {
 typedef int (*linear_fn)(const float*, int, const float*, int, const float*, float*, int, int, int, int, int, void*);
 typedef int (*conv_fn)(const float*, const float*, const float*, const int*, const int*, const float*, float*, int, int, int, int, int, void*);
 
-template <int WM, int WN, int TM, int TN, int NST, int VAR = 0>
+template <int WM, int WN, int TM, int TN, int NST, int VAR = 0, int KS = 1>
 static float run_cfg(const PArgs& a, int iters, const char* tag, double flops) {
     constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN;
-    const size_t lds = (size_t)NST * (BM + BN) * 128;
-    auto k = pgemm_kernel<WM, WN, TM, TN, NST, VAR>;
+    const size_t lds = (size_t)NST * (BM + BN) * 128 * KS;
+    auto k = pgemm_kernel<WM, WN, TM, TN, NST, VAR, KS>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM);
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k, grid, dim3(64 * WM * WN), lds, 0, a);
@@ -535,6 +543,10 @@ int main(int argc, char** argv) {
         run_cfg<4, 2, 2, 4, 3, 1>(a, iters, "  ... DMA pipeline only", flops);
         run_cfg<4, 2, 2, 4, 3, 2>(a, iters, "  ... no loads", flops);
         run_cfg<4, 2, 2, 4, 3, 3>(a, iters, "  ... no stores", flops);
+        run_cfg<2, 2, 2, 2, 3, 0, 2>(a, iters, "BK64 <2,2,2,2> 3st", flops);
+        run_cfg<2, 2, 2, 2, 4, 0, 2>(a, iters, "BK64 <2,2,2,2> 4st", flops);
+        run_cfg<2, 2, 2, 4, 3, 0, 2>(a, iters, "BK64 <2,2,2,4> 3st", flops);
+        run_cfg<4, 2, 2, 4, 2, 0, 2>(a, iters, "BK64 <4,2,2,4> 2st", flops);
         run_ls<4, 2, 2, 4, 3, 2>(a, iters, "LS <4,2,2,4> 3st +2 loaders", flops);
         run_ls<4, 2, 2, 4, 4, 2>(a, iters, "LS <4,2,2,4> 4st +2 loaders", flops);
         run_ls<2, 2, 2, 4, 3, 2>(a, iters, "LS <2,2,2,4> 3st +2 loaders", flops);
