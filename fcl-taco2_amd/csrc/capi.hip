@@ -94,18 +94,20 @@ static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
     ws.F0 = take(N * w->odim);
     ws.pre_a = take(N * w->p);
     ws.pre_b = take(N * w->p);
-    // recurrent state is contiguous so one kernel zeroes it
+    // what the loop READS before it writes — the states entering step 0 (fp32 and, for the pre-split path, planes) and prev_out — is contiguous, so
+    // one kernel zeroes exactly that; the ping-pong partners are written by step 0 before anything reads them
     ws.h0[0] = take(N * w->u);
-    ws.h0[1] = take(N * w->u);
     ws.c0 = take(N * w->u);
     ws.h1[0] = take(N * w->u);
-    ws.h1[1] = take(N * w->u);
     ws.c1 = take(N * w->u);
+    ws.h0_p[0] = reinterpret_cast<unsigned short*>(take(N * w->u));  // as many bytes as the fp32 form (2 x 2 bytes per element)
+    ws.h1_p[0] = reinterpret_cast<unsigned short*>(take(N * w->u));
     ws.prev = take(N * w->odim);
-    // planes of the states: as many bytes as their fp32 form (2 x 2 bytes per element); contiguous with the states so one kernel zeroes all
-    for (int i = 0; i < 2; ++i) ws.h0_p[i] = reinterpret_cast<unsigned short*>(take(N * w->u));
-    for (int i = 0; i < 2; ++i) ws.h1_p[i] = reinterpret_cast<unsigned short*>(take(N * w->u));
     ws.state_bytes = off - (size_t)(reinterpret_cast<char*>(ws.h0[0]) - reinterpret_cast<char*>(base));
+    ws.h0[1] = take(N * w->u);
+    ws.h1[1] = take(N * w->u);
+    ws.h0_p[1] = reinterpret_cast<unsigned short*>(take(N * w->u));
+    ws.h1_p[1] = reinterpret_cast<unsigned short*>(take(N * w->u));
     ws.pre_p = reinterpret_cast<unsigned short*>(take(N * w->p));
     ws.bytes = off;
     return ws;
