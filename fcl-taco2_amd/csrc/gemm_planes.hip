@@ -44,159 +44,196 @@ __device__ __forceinline__ void xcd_tile_p(int& bx, int& by) {
     bx = t - by * nx;
 }
 
-template <int WM, int WN, int TM, int TN, int NST>
-struct PGeo {
-    static constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN, THREADS = 64 * NW;
-    static constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW, GPW = GA + GB;  // LDS-DMA row groups (8 rows = 1 KB) per wave per chunk
-    static constexpr int STAGE = (BM + BN) * 128;
-    static constexpr int LDS_BYTES = NST * STAGE;
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0 && (NW % 2) == 0, "tile rows must split evenly over the waves");
-    static_assert(NST == 3 || NST == 4, "ring depth");
-};
-
-// The shared main loop.  LSTM: tile column c of the wave strip wn is gate (c >> 4) & 3 of unit u0 + wn*16 + (c & 15), i.e. W row g*NU + u
-// (TN must be 4); generic: W row n0 + c.  NU = N (generic) or U.
-template <int WM, int WN, int TM, int TN, int NST, bool LSTM>
-__device__ __forceinline__ void pmainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0, int NU, const int* __restrict__ seg_lo,
-                                          const int* __restrict__ seg_hi, u8* smem, f32x4 (&acc)[TM][TN]) {
-    using G = PGeo<WM, WN, TM, TN, NST>;
-    static_assert(!LSTM || TN == 4, "LSTM tiles keep the four gates of a unit in one lane");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    // ---- loader coordinates: group g = j*NW + wave covers rows g*8 .. g*8+7 of its region; lane -> (row = lane >> 3, LDS piece = lane & 7)
-    const unsigned coff = (unsigned)(((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) * 16);  // SOURCE piece for this lane's LDS slot
-    const u8* zline = reinterpret_cast<const u8*>(g_zero_line) + coff;
-    int am[G::GA], alo[G::GA];
-    unsigned alen[G::GA];
+// one 32-k chunk of a wave's TM x TN tiles: fragment reads (bank-conflict free by the piece permutation) and 3 bf16 MFMAs per tile pair
+template <int TM, int TN>
+__device__ __forceinline__ void pchunk_mma(const u8* sb, int a_hi, int a_lo, int b_hi, int b_lo, f32x4 (&acc)[TM][TN]) {
+    s16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-    for (int j = 0; j < G::GA; ++j) {
-        const int m = m0 + (j * G::NW + wave) * 8 + (lane >> 3);
-        am[j] = m;
-        alo[j] = 0;
-        alen[j] = m < M ? (unsigned)M : 0u;  // rows past M: empty segment -> zero line
-        if (seg_lo != nullptr && m < M) {
-            alo[j] = seg_lo[m];
-            alen[j] = (unsigned)(seg_hi[m] - alo[j]);
-        }
+    for (int tm = 0; tm < TM; ++tm) {
+        ah[tm] = *reinterpret_cast<const s16x8*>(sb + a_hi + tm * 16 * 128);
+        al[tm] = *reinterpret_cast<const s16x8*>(sb + a_lo + tm * 16 * 128);
     }
-    long long brow[G::GB];  // W row index, -1 = zero line
 #pragma unroll
-    for (int j = 0; j < G::GB; ++j) {
-        const int c = (j * G::NW + wave) * 8 + (lane >> 3);  // tile column
-        long long wr = -1;
-        if (LSTM) {
-            const int u = n0 + (c >> 6) * 16 + (c & 15);
-            const int g = (c >> 4) & 3;
-            if (u < NU) wr = (long long)g * NU + u;
-        } else {
-            if (n0 + c < NU) wr = n0 + c;
-        }
-        brow[j] = wr;
+    for (int tn = 0; tn < TN; ++tn) {
+        bh[tn] = *reinterpret_cast<const s16x8*>(sb + b_hi + tn * 16 * 128);
+        bl[tn] = *reinterpret_cast<const s16x8*>(sb + b_lo + tn * 16 * 128);
     }
-    // issue-side state: per-lane source pointers, advanced one 128-byte line per chunk (zero-line pointers do not move)
-    const u8* pa[G::GA];
-    const u8* pb[G::GB];
-    unsigned ia[G::GA], ib[G::GB];
-    int rem = 0, it = 0;
-    auto setup_term = [&](int t) {
-        const GemmTerm T = terms[t];
-        const u8* Ab = reinterpret_cast<const u8*>(T.Ap);
-        const u8* Wb = reinterpret_cast<const u8*>(T.Wp);
 #pragma unroll
-        for (int j = 0; j < G::GA; ++j) {
-            const int src = am[j] + T.shift;
-            const bool ok = (unsigned)(src - alo[j]) < alen[j];
-            pa[j] = ok ? Ab + (size_t)src * ((size_t)T.lda_p * 128) + coff : zline;
-            ia[j] = ok ? 128u : 0u;
-        }
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-        for (int j = 0; j < G::GB; ++j) {
-            const bool ok = brow[j] >= 0;
-            pb[j] = ok ? Wb + (size_t)brow[j] * ((size_t)T.ldw_p * 128) + coff : zline;
-            ib[j] = ok ? 128u : 0u;
-        }
-        rem = (T.K + 31) >> 5;
-    };
-    auto issue = [&](int stage) {
-        u8* sbase = smem + stage * G::STAGE + wave * 1024;
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < G::GA; ++j) {
-            glds16(pa[j], sbase + j * G::NW * 1024);
-            pa[j] += ia[j];
-        }
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < G::GB; ++j) {
-            glds16(pb[j], sbase + G::BM * 128 + j * G::NW * 1024);
-            pb[j] += ib[j];
-        }
-    };
-    auto step_term = [&]() {
-        if (--rem == 0 && ++it < nterms) setup_term(it);  // rare, wave-uniform
-    };
-
-    // ---- fragment read offsets (bytes within a stage)
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int sw = r16 >> 1;
-    const int a_hi = (wm * TM * 16 + r16) * 128 + ((kq ^ sw) << 4);
-    const int a_lo = (wm * TM * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
-    const int b_hi = G::BM * 128 + (wn * TN * 16 + r16) * 128 + ((kq ^ sw) << 4);
-    const int b_lo = G::BM * 128 + (wn * TN * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
-
-    auto compute = [&](int stage) {
-        const u8* sb = smem + stage * G::STAGE;
-        s16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            ah[tm] = *reinterpret_cast<const s16x8*>(sb + a_hi + tm * 16 * 128);
-            al[tm] = *reinterpret_cast<const s16x8*>(sb + a_lo + tm * 16 * 128);
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            bh[tn] = *reinterpret_cast<const s16x8*>(sb + b_hi + tn * 16 * 128);
-            bl[tn] = *reinterpret_cast<const s16x8*>(sb + b_lo + tn * 16 * 128);
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-        }
-    };
-
-    int nchunks = 0;
-    for (int t = 0; t < nterms; ++t) nchunks += (terms[t].K + 31) >> 5;
-    setup_term(0);
-    int issued = 0;
-#pragma unroll
-    for (int p = 0; p < NST - 1; ++p) {
-        if (issued < nchunks) { issue(p); ++issued; step_term(); }
-    }
-    int cs = 0, is = NST - 1;
-    for (int i = 0; i < nchunks; ++i) {  // chunk i is consumed while chunks i+1 .. i+NST-2 stay in flight and chunk i+NST-1 is issued
-        const int left = nchunks - 1 - i;
-        if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
-        else if (left >= 1) wait_vm<G::GPW>();
-        else wait_vm<0>();
-        asm volatile("s_barrier" ::: "memory");  // chunk i has landed for every wave; every wave is done reading the buffer refilled now
-        if (left >= NST - 1) {
-            issue(is);
-            step_term();
-            is = is + 1 == NST ? 0 : is + 1;
-        }
-        compute(cs);
-        cs = cs + 1 == NST ? 0 : cs + 1;
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
     }
 }
 
+// LW = 0: every wave loads its share of a chunk and computes.  LW = 2: two extra LOADER waves per workgroup do nothing but the LDS-DMA of all row
+// groups (and the counted waits), the WM x WN compute waves nothing but fragment reads and MFMAs; one barrier per chunk joins them.  A wave that
+// issues its own global_load_lds cannot issue MFMAs meanwhile (in-order issue), so with ~1 workgroup per CU the two phases used to alternate.
+template <int WM, int WN, int TM, int TN, int NST, int LW = 0>
+struct PGeo {
+    static constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN, THREADS = 64 * (NW + LW), CTHREADS = 64 * NW;
+    static constexpr int NL = LW > 0 ? LW : NW;                              // waves that issue LDS-DMA
+    static constexpr int GA = BM / 8 / NL, GB = BN / 8 / NL, GPW = GA + GB;  // LDS-DMA row groups (8 rows = 1 KB) per loading wave per chunk
+    static constexpr int STAGE = (BM + BN) * 128;
+    static constexpr int LDS_BYTES = NST * STAGE;
+    static_assert((BM / 8) % NL == 0 && (BN / 8) % NL == 0 && (NL % 2) == 0, "tile rows must split evenly over the loading waves");
+    static_assert(NST == 3 || NST == 4, "ring depth");
+    static_assert(2 * GPW <= 60, "s_waitcnt vmcnt is a 6-bit field");
+};
+
+// The shared main loop.  LSTM: tile column c of the wave strip wn is gate (c >> 4) & 3 of unit u0 + wn*16 + (c & 15), i.e. W row g*NU + u
+// (TN must be 4); generic: W row n0 + c.  NU = N (generic) or U.  Returns false in a loader wave (LW > 0), which is done and must return.
+template <int WM, int WN, int TM, int TN, int NST, bool LSTM, int LW>
+__device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0, int NU, const int* __restrict__ seg_lo,
+                                          const int* __restrict__ seg_hi, u8* smem, f32x4 (&acc)[TM][TN]) {
+    using G = PGeo<WM, WN, TM, TN, NST, LW>;
+    static_assert(!LSTM || TN == 4, "LSTM tiles keep the four gates of a unit in one lane");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW > 0 && wave >= G::NW;
+    const int lw = LW > 0 ? wave - G::NW : wave;  // index among the loading waves
+    const int wm = wave / WN, wn = wave % WN;
+    int nchunks = 0;
+    for (int t = 0; t < nterms; ++t) nchunks += (terms[t].K + 31) >> 5;
+
+    if (LW == 0 || loader) {
+        // ---- loader coordinates: group g = j*NL + lw covers rows g*8 .. g*8+7 of its region; lane -> (row = lane >> 3, LDS piece = lane & 7)
+        const unsigned coff = (unsigned)(((lane & 7) ^ (((lw & 1) << 2) | (lane >> 4))) * 16);  // SOURCE piece for this lane's LDS slot
+        const u8* zline = reinterpret_cast<const u8*>(g_zero_line) + coff;
+        int am[G::GA], alo[G::GA];
+        unsigned alen[G::GA];
+#pragma unroll
+        for (int j = 0; j < G::GA; ++j) {
+            const int m = m0 + (j * G::NL + lw) * 8 + (lane >> 3);
+            am[j] = m;
+            alo[j] = 0;
+            alen[j] = m < M ? (unsigned)M : 0u;  // rows past M: empty segment -> zero line
+            if (seg_lo != nullptr && m < M) {
+                alo[j] = seg_lo[m];
+                alen[j] = (unsigned)(seg_hi[m] - alo[j]);
+            }
+        }
+        long long brow[G::GB];  // W row index, -1 = zero line
+#pragma unroll
+        for (int j = 0; j < G::GB; ++j) {
+            const int c = (j * G::NL + lw) * 8 + (lane >> 3);  // tile column
+            long long wr = -1;
+            if (LSTM) {
+                const int u = n0 + (c >> 6) * 16 + (c & 15);
+                const int g = (c >> 4) & 3;
+                if (u < NU) wr = (long long)g * NU + u;
+            } else {
+                if (n0 + c < NU) wr = n0 + c;
+            }
+            brow[j] = wr;
+        }
+        // issue-side state: per-lane source pointers, advanced one 128-byte line per chunk (zero-line pointers do not move)
+        const u8* pa[G::GA];
+        const u8* pb[G::GB];
+        unsigned ia[G::GA], ib[G::GB];
+        int rem = 0, it = 0;
+        auto setup_term = [&](int t) {
+            const GemmTerm T = terms[t];
+            const u8* Ab = reinterpret_cast<const u8*>(T.Ap);
+            const u8* Wb = reinterpret_cast<const u8*>(T.Wp);
+#pragma unroll
+            for (int j = 0; j < G::GA; ++j) {
+                const int src = am[j] + T.shift;
+                const bool ok = (unsigned)(src - alo[j]) < alen[j];
+                pa[j] = ok ? Ab + (size_t)src * ((size_t)T.lda_p * 128) + coff : zline;
+                ia[j] = ok ? 128u : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < G::GB; ++j) {
+                const bool ok = brow[j] >= 0;
+                pb[j] = ok ? Wb + (size_t)brow[j] * ((size_t)T.ldw_p * 128) + coff : zline;
+                ib[j] = ok ? 128u : 0u;
+            }
+            rem = (T.K + 31) >> 5;
+        };
+        auto issue = [&](int stage) {
+            u8* sbase = smem + stage * G::STAGE + lw * 1024;
+#pragma unroll
+            for (int j = 0; j < G::GA; ++j) {
+                glds16(pa[j], sbase + j * G::NL * 1024);
+                pa[j] += ia[j];
+            }
+#pragma unroll
+            for (int j = 0; j < G::GB; ++j) {
+                glds16(pb[j], sbase + G::BM * 128 + j * G::NL * 1024);
+                pb[j] += ib[j];
+            }
+            if (--rem == 0 && ++it < nterms) setup_term(it);  // rare, wave-uniform
+        };
+        setup_term(0);
+        int issued = 0;
+#pragma unroll
+        for (int p = 0; p < NST - 1; ++p) {
+            if (issued < nchunks) { issue(p); ++issued; }
+        }
+        if (LW > 0) {  // loader wave: waits + barriers + refills only
+            int is = NST - 1;
+            for (int i = 0; i < nchunks; ++i) {
+                const int left = nchunks - 1 - i;
+                if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
+                else if (left >= 1) wait_vm<G::GPW>();
+                else wait_vm<0>();
+                asm volatile("s_barrier" ::: "memory");
+                if (left >= NST - 1) {
+                    issue(is);
+                    is = is + 1 == NST ? 0 : is + 1;
+                }
+            }
+            return false;
+        }
+        // ---- LW == 0: the same waves also compute
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int sw = r16 >> 1;
+        const int a_hi = (wm * TM * 16 + r16) * 128 + ((kq ^ sw) << 4);
+        const int a_lo = (wm * TM * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+        const int b_hi = G::BM * 128 + (wn * TN * 16 + r16) * 128 + ((kq ^ sw) << 4);
+        const int b_lo = G::BM * 128 + (wn * TN * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+        int cs = 0, is = NST - 1;
+        for (int i = 0; i < nchunks; ++i) {  // chunk i is consumed while chunks i+1 .. i+NST-2 stay in flight and chunk i+NST-1 is issued
+            const int left = nchunks - 1 - i;
+            if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
+            else if (left >= 1) wait_vm<G::GPW>();
+            else wait_vm<0>();
+            asm volatile("s_barrier" ::: "memory");  // chunk i has landed for every wave; every wave is done reading the buffer refilled now
+            if (left >= NST - 1) {
+                issue(is);
+                is = is + 1 == NST ? 0 : is + 1;
+            }
+            pchunk_mma<TM, TN>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
+            cs = cs + 1 == NST ? 0 : cs + 1;
+        }
+        return true;
+    }
+    // ---- compute wave of a loader-specialised workgroup
+    {
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int sw = r16 >> 1;
+        const int a_hi = (wm * TM * 16 + r16) * 128 + ((kq ^ sw) << 4);
+        const int a_lo = (wm * TM * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+        const int b_hi = G::BM * 128 + (wn * TN * 16 + r16) * 128 + ((kq ^ sw) << 4);
+        const int b_lo = G::BM * 128 + (wn * TN * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+        int cs = 0;
+        for (int i = 0; i < nchunks; ++i) {
+            asm volatile("s_barrier" ::: "memory");  // the loader waves have seen chunk i land before they arrive here
+            pchunk_mma<TM, TN>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
+            cs = cs + 1 == NST ? 0 : cs + 1;
+        }
+    }
+    return true;
+}
+
 // --------------------------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int NST>
-__global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
-    using G = PGeo<WM, WN, TM, TN, NST>;
+template <int WM, int WN, int TM, int TN, int NST, int LW>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmArgs a) {
+    using G = PGeo<WM, WN, TM, TN, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
     xcd_tile_p(bx, by);
@@ -206,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    pmainloop<WM, WN, TM, TN, NST, false>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc);
+    if (!pmainloop<WM, WN, TM, TN, NST, false, LW>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc)) return;  // loader wave
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -253,7 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
     const int rows = min(G::BM, a.M - m0);
     if (a.Y) {
         const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
-        for (int i = threadIdx.x; i < rows * (G::BN / 4); i += G::THREADS) {
+        for (int i = threadIdx.x; i < rows * (G::BN / 4); i += G::CTHREADS) {
             const int rm = i / (G::BN / 4), c4 = (i - rm * (G::BN / 4)) * 4, n = n0 + c4;
             if (n >= a.N) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c4);
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
     }
     if (a.Yp) {  // item = (row, 32-column line, quarter q): 8 values -> 16 bytes of hi at piece q and 16 bytes of lo at piece 4 + q
         const int np = a.ldyp * 32;
-        for (int i = threadIdx.x; i < rows * (G::BN / 8); i += G::THREADS) {
+        for (int i = threadIdx.x; i < rows * (G::BN / 8); i += G::CTHREADS) {
             const int rm = i / (G::BN / 8), c8 = (i - rm * (G::BN / 8)) * 8, n = n0 + c8;
             if (n >= np) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8), v1 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8 + 4);
@@ -283,9 +320,9 @@ __global__ __launch_bounds__(64 * WM * WN) void pgemm_kernel(const GemmArgs a) {
     }
 }
 
-template <int WM, int WN, int TM, int NST, int MODE>
-__global__ __launch_bounds__(64 * WM * WN) void plstm_kernel(const LstmStepArgs a) {
-    using G = PGeo<WM, WN, TM, 4, NST>;
+template <int WM, int WN, int TM, int NST, int MODE, int LW>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmStepArgs a) {
+    using G = PGeo<WM, WN, TM, 4, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
     xcd_tile_p(bx, by);
@@ -298,16 +335,18 @@ __global__ __launch_bounds__(64 * WM * WN) void plstm_kernel(const LstmStepArgs 
     // piece, so the counted vmcnt waits of the loop cover them and their latency hides under it)
     CellIn ci[TM][4];
     const int uc = min(u, a.U - 1);
+    if (LW == 0 || wave < G::NW) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+        for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, a.M - 1), uc);
+            for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, a.M - 1), uc);
+    }
     f32x4 acc[TM][4];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    pmainloop<WM, WN, TM, 4, NST, true>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, smem, acc);
+    if (!pmainloop<WM, WN, TM, 4, NST, true, LW>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, smem, acc)) return;  // loader wave
     // Epilogue through LDS (see pgemm_kernel): the new h and c of the tile are staged as [row][unit] fp32 and written out row-wise, 16 bytes
     // per lane; the tile's 16 WN units are (part of) ONE 128-byte P32 line per row, so the planes of h go out as whole 16-byte pieces too.
     constexpr int UW = 16 * WN, LDT = UW + 4;
@@ -331,7 +370,7 @@ __global__ __launch_bounds__(64 * WM * WN) void plstm_kernel(const LstmStepArgs 
     __syncthreads();
     const int rows = min(G::BM, a.M - m0);
     const bool vec = (a.U & 3) == 0;
-    for (int i = threadIdx.x; i < rows * (UW / 4); i += G::THREADS) {
+    for (int i = threadIdx.x; i < rows * (UW / 4); i += G::CTHREADS) {
         const int rm = i / (UW / 4), c4 = (i - rm * (UW / 4)) * 4, uu = u0 + c4;
         if (uu >= a.U) continue;
         const f32x4 hv = *reinterpret_cast<const f32x4*>(th + rm * LDT + c4), cv = *reinterpret_cast<const f32x4*>(tc + rm * LDT + c4);
@@ -346,7 +385,7 @@ __global__ __launch_bounds__(64 * WM * WN) void plstm_kernel(const LstmStepArgs 
         }
     }
     if (a.h_out_p) {  // U % 32 == 0 (whole lines): item = (row, 8 units) -> 16 bytes of hi and 16 bytes of lo
-        for (int i = threadIdx.x; i < rows * (UW / 8); i += G::THREADS) {
+        for (int i = threadIdx.x; i < rows * (UW / 8); i += G::CTHREADS) {
             const int rm = i / (UW / 8), c8 = (i - rm * (UW / 8)) * 8, uu = u0 + c8;
             if (uu >= a.U) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(th + rm * LDT + c8), v1 = *reinterpret_cast<const f32x4*>(th + rm * LDT + c8 + 4);
@@ -369,19 +408,29 @@ bool planes_ok(const GemmTerm* t, int n) {
     return true;
 }
 
-template <int WM, int WN, int TM, int TN, int NST>
-static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
-    using G = PGeo<WM, WN, TM, TN, NST>;
-    auto k = pgemm_kernel<WM, WN, TM, TN, NST>;
+static int loader_waves() {
+    static const int v = tunable("PLANES_LOADERS", 2) ? 2 : 0;  // 2 dedicated LDS-DMA waves per workgroup (0: every wave loads and computes)
+    return v;
+}
+
+template <int WM, int WN, int TM, int TN, int NST, int LW>
+static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
+    using G = PGeo<WM, WN, TM, TN, NST, LW>;
+    auto k = pgemm_kernel<WM, WN, TM, TN, NST, LW>;
     const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(k), G::LDS_BYTES);
     if (rc) return rc;
     const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;  // the tiles also cover the zero padding of the output planes
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
     char full[64];
-    snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, TN, NST);
+    snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, TM, TN, NST, LW);
     ProfScope ps(full, flops, a.M, s);
     hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     return check_hip(hipGetLastError(), "pgemm launch");
+}
+
+template <int WM, int WN, int TM, int TN, int NST>
+static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
+    return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0>(a, s, flops);
 }
 
 int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
@@ -398,24 +447,29 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     return launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
 }
 
-template <int WM, int WN, int TM, int NST>
-static int launch_plstm_cfg(const LstmStepArgs& a, hipStream_t s, double flops) {
-    using G = PGeo<WM, WN, TM, 4, NST>;
+template <int WM, int WN, int TM, int NST, int LW>
+static int launch_plstm_lw(const LstmStepArgs& a, hipStream_t s, double flops) {
+    using G = PGeo<WM, WN, TM, 4, NST, LW>;
     const bool plain = !a.zone_keep_h && !a.row_len;
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     char full[64];
-    snprintf(full, sizeof(full), "plstm_kernel<%d,%d,%d,%d,%d>", WM, WN, TM, NST, mode);
-    const void* fn = mode == 0 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 0>)
-                   : mode == 1 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 1>)
-                               : reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, -1>);
+    snprintf(full, sizeof(full), "plstm_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, TM, NST, mode, LW);
+    const void* fn = mode == 0 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 0, LW>)
+                   : mode == 1 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 1, LW>)
+                               : reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, -1, LW>);
     const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
     if (rc) return rc;
     ProfScope ps(full, flops, a.M, s);
-    if (mode == 0) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 0>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 1>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, -1>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    if (mode == 0) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 0, LW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 1, LW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, -1, LW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     return check_hip(hipGetLastError(), "plstm launch");
+}
+
+template <int WM, int WN, int TM, int NST>
+static int launch_plstm_cfg(const LstmStepArgs& a, hipStream_t s, double flops) {
+    return loader_waves() ? launch_plstm_lw<WM, WN, TM, NST, 2>(a, s, flops) : launch_plstm_lw<WM, WN, TM, NST, 0>(a, s, flops);
 }
 
 int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
