@@ -54,7 +54,8 @@ class DecoderTrain(C.Structure):  # fcl_decoder_train_t
 class DecoderBptt(C.Structure):  # fcl_decoder_bptt_t
     _fields_ = [("n", _I), ("lmax", _I), ("u", _I), ("live_rows_host", _P), ("s0", _P * 3), ("s1", _P * 3), ("zoneout", _F), ("zk_h0", _P),
                 ("zk_c0", _P), ("zk_h1", _P), ("zk_c1", _P), ("dh1_all", _P), ("dh0_all", _P), ("w1_ih_t", _P), ("w1_hh_t", _P), ("w0_hh_t", _P),
-                ("dg0_all", _P), ("dg1_all", _P), ("workspace", _P), ("workspace_bytes", _Z)]
+                ("dg0_all", _P), ("dg1_all", _P), ("workspace", _P), ("workspace_bytes", _Z), ("w1_ih_t_p", _P), ("w1_hh_t_p", _P), ("w0_hh_t_p", _P),
+                ("dg0_all_p", _P), ("dg1_all_p", _P)]
 
 
 class BilstmTrain(C.Structure):  # fcl_bilstm_train_t
@@ -113,7 +114,7 @@ SIGNATURES = {
     "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scale": (_I, [_P, _Z, _F, _P]),
     "fcl_bernoulli_u8": (_I, [_P, _Z, _F, C.c_uint32, _P, _P]),
-    "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _P, _I, _P, _P, _P, _I, _I, _P]),
+    "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),

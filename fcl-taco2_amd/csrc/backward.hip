@@ -399,7 +399,8 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const floa
                                      const float* __restrict__ dh_out, const float* __restrict__ dh_out2, int ld_dh2,
                                      const float* __restrict__ dc_out, float zoneout,
                                      const uint8_t* __restrict__ zk_h, const uint8_t* __restrict__ zk_c, const int* __restrict__ row_len, int step,
-                                     float* __restrict__ dgates, float* __restrict__ dh_old, float* __restrict__ dc_old_out, int M, int U) {
+                                     float* __restrict__ dgates, float* __restrict__ dh_old, float* __restrict__ dc_old_out, int M, int U,
+                                     unsigned short* __restrict__ dgates_p) {
     const long long total = (long long)M * U;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx / U), u = (int)(idx - (long long)m * U);
@@ -420,10 +421,19 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const floa
         const float tc = tanhf(c_new[idx]);
         const float dc_new = dc_new_z + dh_new * og * (1.0f - tc * tc);
         float* dg = dgates + (size_t)m * 4 * U;
-        dg[u] = dc_new * gg * ig * (1.0f - ig);
-        dg[U + u] = dc_new * c_old[idx] * fg * (1.0f - fg);
-        dg[2 * U + u] = dc_new * ig * (1.0f - gg * gg);
-        dg[3 * U + u] = dh_new * tc * og * (1.0f - og);
+        const float d0 = dc_new * gg * ig * (1.0f - ig), d1 = dc_new * c_old[idx] * fg * (1.0f - fg);
+        const float d2 = dc_new * ig * (1.0f - gg * gg), d3 = dh_new * tc * og * (1.0f - og);
+        dg[u] = d0;
+        dg[U + u] = d1;
+        dg[2 * U + u] = d2;
+        dg[3 * U + u] = d3;
+        if (dgates_p) {  // the same gate gradients as the pre-split operand of the recurrence / input-gradient GEMMs (4U % 32 == 0)
+            const int ld = (4 * U) >> 5;
+            store_p32(dgates_p, ld, m, u, d0);
+            store_p32(dgates_p, ld, m, U + u, d1);
+            store_p32(dgates_p, ld, m, 2 * U + u, d2);
+            store_p32(dgates_p, ld, m, 3 * U + u, d3);
+        }
         dh_old[idx] = dh_keep;
         dc_old_out[idx] = dc_new * fg + dc_keep;
     }
@@ -689,13 +699,15 @@ int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, flo
 int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dh_out2, int ld_dh2,
                       const float* dc_out, float zoneout,
                       const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step, float* dgates, float* dh_old,
-                      float* dc_old, int m, int u, fcl_stream_t stream) {
+                      float* dc_old, uint16_t* dgates_p, int m, int u, fcl_stream_t stream) {
     FCL_REQUIRE(gates && c_old && c_new && dh_out && dgates && dh_old && dc_old && m >= 0 && u > 0, FCL_ERR_INVALID, "lstm_cell_bwd: bad arguments");
+    FCL_REQUIRE(!dgates_p || (((4 * u) & 31) == 0 && (reinterpret_cast<uintptr_t>(dgates_p) & 127u) == 0), FCL_ERR_SHAPE,
+                "lstm_cell_bwd: planes need 4U %% 32 == 0 and a 128-byte aligned buffer");
     FCL_REQUIRE((zone_keep_h == nullptr) == (zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_cell_bwd: zoneout masks come in pairs");
     if (m == 0) return 0;
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)m * u, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_old, c_new, dh_out, dh_out2,
                        ld_dh2, dc_out,
-                       zoneout, zone_keep_h, zone_keep_c, row_len, step, dgates, dh_old, dc_old, m, u);
+                       zoneout, zone_keep_h, zone_keep_c, row_len, step, dgates, dh_old, dc_old, m, u, dgates_p);
     return check_hip(hipGetLastError(), "lstm_cell_bwd");
 }
 

@@ -133,27 +133,37 @@ int fcl_decoder_bptt(const fcl_decoder_bptt_t* a, fcl_stream_t stream) {
     float *ch0 = ws, *ch1 = ws + NU, *cc0 = ws + 2 * NU, *cc1 = ws + 3 * NU, *tmp_h = ws + 4 * NU, *tmp_c = ws + 5 * NU;
     size_t total = 0;
     for (int t = 0; t < a->lmax; ++t) total += (size_t)a->live_rows_host[t];
+    const bool planes = a->w1_ih_t_p && a->w1_hh_t_p && a->w0_hh_t_p && a->dg0_all_p && a->dg1_all_p && !(G4 & 31);
+    const int ldg = G4 / 32;  // plane lines per gate-gradient row
+    static const int planes_min_rows = tunable("BPTT_PLANES_MIN_M", 256);  // below: the split-K small-M kernel on the fp32 operands is faster
+    auto linp = [&](const float* dg, const unsigned short* dgp, const float* wt, const unsigned short* wtp, float* y, int n, const float* residual) {
+        GemmArgs g = lin(dg, G4, wt, G4, G4, y, U, n, U, residual, U);
+        if (planes && n > planes_min_rows) { g.term[0].Ap = dgp; g.term[0].Wp = wtp; g.term[0].lda_p = g.term[0].ldw_p = ldg; }
+        return g;
+    };
     size_t off = total;
     for (int t = a->lmax - 1; t >= 0; --t) {
         const int n = a->live_rows_host[t];
         off -= (size_t)n;
+        unsigned short* dg1p = planes ? a->dg1_all_p + off * (size_t)ldg * 64 : nullptr;
+        unsigned short* dg0p = planes ? a->dg0_all_p + off * (size_t)ldg * 64 : nullptr;
         // layer 1
         int rc = fcl_lstm_cell_bwd(a->s1[0] + off * G4, a->s1[2] + off * U, a->s1[1] + off * U, ch1, a->dh1_all + off * U, U, cc1, a->zoneout,
                                    a->zk_h1 ? a->zk_h1 + off * U : nullptr, a->zk_c1 ? a->zk_c1 + off * U : nullptr, nullptr, t, a->dg1_all + off * G4,
-                                   tmp_h, tmp_c, n, U, stream);
+                                   tmp_h, tmp_c, dg1p, n, U, stream);
         if (rc) return rc;
         std::swap(cc1, tmp_c);
-        rc = launch_gemm(lin(a->dg1_all + off * G4, G4, a->w1_hh_t, G4, G4, ch1, U, n, U, tmp_h, U), s);  // ch1 = dg1 . W1_hh + zoneout keep path
+        rc = launch_gemm(linp(a->dg1_all + off * G4, dg1p, a->w1_hh_t, a->w1_hh_t_p, ch1, n, tmp_h), s);  // ch1 = dg1 . W1_hh + zoneout keep path
         if (rc) return rc;
-        rc = launch_gemm(lin(a->dg1_all + off * G4, G4, a->w1_ih_t, G4, G4, ch0, U, n, U, ch0, U), s);  // ch0 += dg1 . W1_ih
+        rc = launch_gemm(linp(a->dg1_all + off * G4, dg1p, a->w1_ih_t, a->w1_ih_t_p, ch0, n, ch0), s);  // ch0 += dg1 . W1_ih
         if (rc) return rc;
         // layer 0
         rc = fcl_lstm_cell_bwd(a->s0[0] + off * G4, a->s0[2] + off * U, a->s0[1] + off * U, ch0, a->dh0_all ? a->dh0_all + off * U : nullptr, U, cc0,
                                a->zoneout, a->zk_h0 ? a->zk_h0 + off * U : nullptr, a->zk_c0 ? a->zk_c0 + off * U : nullptr, nullptr, t,
-                               a->dg0_all + off * G4, tmp_h, tmp_c, n, U, stream);
+                               a->dg0_all + off * G4, tmp_h, tmp_c, dg0p, n, U, stream);
         if (rc) return rc;
         std::swap(cc0, tmp_c);
-        rc = launch_gemm(lin(a->dg0_all + off * G4, G4, a->w0_hh_t, G4, G4, ch0, U, n, U, tmp_h, U), s);
+        rc = launch_gemm(linp(a->dg0_all + off * G4, dg0p, a->w0_hh_t, a->w0_hh_t_p, ch0, n, tmp_h), s);
         if (rc) return rc;
     }
     return 0;
@@ -246,7 +256,7 @@ int fcl_bilstm_bptt(const fcl_bilstm_bptt_t* a, fcl_stream_t stream) {
             // output gradient of step t: rows (b, t) of d_out, i.e. row stride T * ld_dout; dead cells (row_len) pass the carries through with dg = 0
             int rc = fcl_lstm_cell_bwd(a->s[d][0] + (size_t)t * B * G4, a->s[d][2] + (size_t)t * BH, a->s[d][1] + (size_t)t * BH, dh,
                                        a->d_out + (size_t)t * a->ld_dout + d * H, T * a->ld_dout, dc, 0.f, nullptr, nullptr, a->lens, t, dg, tmp_h, tmp_c,
-                                       B, H, stream);
+                                       nullptr, B, H, stream);
             if (rc) return rc;
             std::swap(dc, tmp_c);
             rc = launch_gemm(lin(dg, G4, a->w_hh_t[d], G4, G4, dh, H, B, H, tmp_h, H), s);  // dh = dgates . W_hh + pass-through of dead rows

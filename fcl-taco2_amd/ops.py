@@ -396,7 +396,7 @@ def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None
         dh_old, dc_old = torch.empty_like(c_old), torch.empty_like(c_old)
     check(_lib.load().fcl_lstm_cell_bwd(_p(gates), _p(c_old), _p(c_new), _p(dh_out), None if dh_out2 is None else dh_out2.data_ptr(),
                                         0 if dh_out2 is None else dh_out2.stride(0), _p(dc_out), zoneout, _p(zone_keep_h, torch.uint8),
-                                        _p(zone_keep_c, torch.uint8), _p(row_len, torch.int32), step, _p(dgates), _p(dh_old), _p(dc_old), m, u, _stream()))
+                                        _p(zone_keep_c, torch.uint8), _p(row_len, torch.int32), step, _p(dgates), _p(dh_old), _p(dc_old), None, m, u, _stream()))
     return dgates, dh_old, dc_old
 
 
@@ -501,7 +501,9 @@ def decoder_train_fwd(live_rows, p1d, g0, w0_pre, w0_hh, w0_pos, dur_i32, w1_ih,
     check(lib.fcl_decoder_train_fwd(C.byref(a), _stream()))
 
 
-def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all):
+def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=None):
+    """planes: optional (w1_ih_t_p, w1_hh_t_p, w0_hh_t_p, dg0_all_p, dg1_all_p): P32 planes of the transposed weights (in) and of the gate
+    gradients of every cell (out) -> the recurrence's GEMMs of the steps with enough live rows run on the pre-split-operand kernels."""
     lib = _lib.load()
     u = dh1_all.shape[1]
     a = _lib.DecoderBptt(n=n, lmax=int(live_rows.shape[0]), u=u, live_rows_host=live_rows.ctypes.data, zoneout=zoneout, dh1_all=_p(dh1_all),
@@ -510,6 +512,8 @@ def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w
         a.zk_h0, a.zk_c0, a.zk_h1, a.zk_c1 = [_p(t, torch.uint8) for t in (zk[0][0], zk[0][1], zk[1][0], zk[1][1])]
     _ptrs(a.s0, s0[:3])
     _ptrs(a.s1, s1[:3])
+    if planes is not None:
+        a.w1_ih_t_p, a.w1_hh_t_p, a.w0_hh_t_p, a.dg0_all_p, a.dg1_all_p = [_p(t, torch.int16) for t in planes]
     nbytes = lib.fcl_decoder_train_workspace_bytes(n, u)
     ws = torch.empty(nbytes, device=dh1_all.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes

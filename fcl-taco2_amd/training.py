@@ -871,9 +871,16 @@ class TrainEngine(object):
         self._dw(lambda: ops.gemm_tn(dF0, c.att_c, g_wf[:, U:]))
         d_att_c = ops.linear(dF0, self._wt(c.wf_att))
         dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
-        ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh),
-                         dg0_all, dg1_all)
-        dp1_all = ops.linear(dg0_all, self._wt(c.w0_pre))  # [F, P]: gradient w.r.t. the prenet output of every cell
+        w1_ih_t, w1_hh_t, w0_hh_t, w0_pre_t = self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh), self._wt(c.w0_pre)
+        bpl = None
+        if ops.planes_enabled() and U % 8 == 0:  # the recurrence's GEMMs on pre-split operands: the cell-backward kernel writes dgates as planes too
+            dg0_p, dg1_p = ops.planes_empty(F, 4 * U, dev), ops.planes_empty(F, 4 * U, dev)
+            bpl = (self._wplanes("w1_ih_t", w1_ih_t), self._wplanes("w1_hh_t", w1_hh_t), self._wplanes("w0_hh_t", w0_hh_t), dg0_p, dg1_p)
+        ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=bpl)
+        if bpl is not None:  # [F, P]: gradient w.r.t. the prenet output of every cell
+            dp1_all = ops.linear_planes(bpl[3], self._wplanes("w0_pre_t", w0_pre_t), Pn, 4 * U)[0]
+        else:
+            dp1_all = ops.linear(dg0_all, w0_pre_t)
         S0, S1 = c.S0, c.S1
         g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
 

@@ -340,6 +340,10 @@ typedef struct {
     float *dg0_all, *dg1_all;       /* out [F, 4U]: gate pre-activation gradients of every cell */
     void* workspace;
     size_t workspace_bytes;
+    /* optional P32 planes (all five or none; U % 8 == 0): the transposed weights, and out: the gate gradients of every cell as planes
+     * [F, 4U/32 lines].  The recurrence's three GEMMs per step then run on the pre-split-operand kernels for steps with enough live rows. */
+    const uint16_t *w1_ih_t_p, *w1_hh_t_p, *w0_hh_t_p;
+    uint16_t *dg0_all_p, *dg1_all_p;
 } fcl_decoder_bptt_t;
 typedef struct {
     int b, t, h;
@@ -381,7 +385,7 @@ int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const u
 int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, const float* dh_out2, int ld_dh2,
                       const float* dc_out, float zoneout,
                       const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step, float* dgates, float* dh_old,
-                      float* dc_old, int m, int u, fcl_stream_t stream);
+                      float* dc_old, uint16_t* dgates_p /* optional P32 planes of dgates (4U/32 lines per row) */, int m, int u, fcl_stream_t stream);
 /* dst[idx[m], :] += src[m, :]  (embedding gradient; idx == skip rows are dropped: padding_idx). */
 int fcl_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int m, int c, int64_t skip, fcl_stream_t stream);
 int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream);
