@@ -105,13 +105,13 @@ SIGNATURES = {
     "fcl_colsum_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fcl_act_fwd": (_I, [_P, _P, _F, _P, _P, _I, _Z, _I, _P]),
     "fcl_unpack_conv1d_grad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "fcl_act_bwd": (_I, [_P, _P, _P, _F, _P, _Z, _I, _P]),
+    "fcl_act_bwd": (_I, [_P, _P, _P, _F, _P, _P, _I, _Z, _I, _P]),
     "fcl_l1_mse_grad": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _F, C.c_double, _P, _I, _P]),
     "fcl_l1_mse_loss_grad": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _F, C.c_double, _P, _I, _P, _P]),
     "fcl_layernorm_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_bn_stats_fwd": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "fcl_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
-    "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scale": (_I, [_P, _Z, _F, _P]),
     "fcl_bernoulli_u8": (_I, [_P, _Z, _F, C.c_uint32, _P, _P]),
     "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P]),

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 // dz = dy * act'(y) * (keep ? keep*scale : 1)
 __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const uint8_t* __restrict__ keep, float scale,
-                               float* __restrict__ dz, long long n, int act) {
+                               float* __restrict__ dz, long long n, int act, unsigned short* __restrict__ dzp, int cols) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float g = dy[i];
         if (keep) g = keep[i] ? g * scale : 0.f;
@@ -211,6 +211,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
         if (act == FCL_ACT_RELU) g = v > 0.f ? g : 0.f;
         else if (act == FCL_ACT_TANH) g *= 1.0f - v * v;
         dz[i] = g;
+        if (dzp) store_p32(dzp, cols >> 5, (int)(i / cols), (int)(i % cols), g);  // pre-split operand of the input-gradient GEMM
     }
 }
 
@@ -513,11 +514,13 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __re
 // dz = gamma * invstd * (dy - dbeta/M - zhat * dgamma/M), dbeta = sum dy, dgamma = sum dy*zhat (this batch's sums)
 __global__ void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
                               const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float* __restrict__ dz,
-                              long long total, int C, float inv_m) {
+                              long long total, int C, float inv_m, unsigned short* __restrict__ dzp) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const float zh = (z[i] - mean[c]) * invstd[c];
-        dz[i] = gamma[c] * invstd[c] * (dy[i] - dbeta[c] * inv_m - zh * dgamma[c] * inv_m);
+        const float g = gamma[c] * invstd[c] * (dy[i] - dbeta[c] * inv_m - zh * dgamma[c] * inv_m);
+        dz[i] = g;
+        if (dzp) store_p32(dzp, C >> 5, (int)(i / C), c, g);
     }
 }
 
@@ -636,11 +639,14 @@ int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* 
     return check_hip(hipGetLastError(), "colsum_fwd");
 }
 
-int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, size_t n, int act, fcl_stream_t stream) {
+int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, uint16_t* dzp, int cols, size_t n, int act,
+                fcl_stream_t stream) {
     FCL_REQUIRE(dy && dz && (y || act == FCL_ACT_NONE) && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "act_bwd: bad arguments");
+    FCL_REQUIRE(!dzp || (cols > 0 && (cols & 31) == 0 && n % (size_t)cols == 0 && (reinterpret_cast<uintptr_t>(dzp) & 127u) == 0), FCL_ERR_SHAPE,
+                "act_bwd: planes need cols %% 32 == 0, n %% cols == 0 and a 128-byte aligned buffer");
     if (n == 0) return 0;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y ? y : dy, keep, keep_scale, dz,
-                       (long long)n, act);
+                       (long long)n, act, dzp, cols);
     return check_hip(hipGetLastError(), "act_bwd");
 }
 
@@ -751,10 +757,11 @@ int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const
 }
 
 int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
-               float* dz, int m, int c, fcl_stream_t stream) {
+               float* dz, uint16_t* dzp, int m, int c, fcl_stream_t stream) {
     FCL_REQUIRE(dy && z && mean && invstd && gamma && dbeta && dgamma && dz && m > 0 && c > 0, FCL_ERR_INVALID, "bn_bwd: bad arguments");
+    FCL_REQUIRE(!dzp || ((c & 31) == 0 && (reinterpret_cast<uintptr_t>(dzp) & 127u) == 0), FCL_ERR_SHAPE, "bn_bwd: planes need C %% 32 == 0, 128-byte aligned");
     hipLaunchKernelGGL(bn_bwd_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, dy, z, mean, invstd, gamma, dbeta, dgamma, dz,
-                       (long long)m * c, c, 1.0f / (float)m);
+                       (long long)m * c, c, 1.0f / (float)m, dzp);
     return check_hip(hipGetLastError(), "bn_bwd");
 }
 

@@ -321,10 +321,13 @@ def colsum(x, out, y=None, gamma=None, beta=None, mode=0):
     return out
 
 
-def act_bwd(dy, y, act, keep=None, keep_scale=1.0):
+def act_bwd(dy, y, act, keep=None, keep_scale=1.0, want_planes=False):
+    """dz = dy * act'(y) [* keep * keep_scale]; want_planes (2-D, width % 32 == 0): returns (dz, P32 planes of dz)."""
     dz = torch.empty_like(dy)
-    check(_lib.load().fcl_act_bwd(_p(dy), _p(y), _p(keep, torch.uint8), keep_scale, _p(dz), dy.numel(), act, _stream()))
-    return dz
+    dzp = planes_empty(dy.shape[0], dy.shape[1], dy.device) if want_planes else None
+    check(_lib.load().fcl_act_bwd(_p(dy), _p(y), _p(keep, torch.uint8), keep_scale, _p(dz), _p(dzp, torch.int16), dy.shape[-1] if want_planes else 0,
+                                  dy.numel(), act, _stream()))
+    return (dz, dzp) if want_planes else dz
 
 
 def l1_mse_grad(a, b, row_valid, count, w_l1, w_mse, da=None, b_log_offset=None):
@@ -369,11 +372,12 @@ def bn_act(z, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0, want_pl
     return res + (yp,) if want_planes else res
 
 
-def bn_bwd(dy, z, mean, invstd, gamma, dbeta, dgamma):
+def bn_bwd(dy, z, mean, invstd, gamma, dbeta, dgamma, want_planes=False):
     m, c = z.shape
     dz = torch.empty_like(z)
-    check(_lib.load().fcl_bn_bwd(_p(dy), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), m, c, _stream()))
-    return dz
+    dzp = planes_empty(m, c, z.device) if want_planes else None
+    check(_lib.load().fcl_bn_bwd(_p(dy), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), _p(dzp, torch.int16), m, c, _stream()))
+    return (dz, dzp) if want_planes else dz
 
 
 def scale_(x, alpha):

@@ -469,21 +469,39 @@ class TrainEngine(object):
         cache = dict(x=x, z=z, y_act=y, wt=wt, scale=scale, prefix=prefix, act=act, lo=lo, hi=hi, keep=None, ks=1.0)
         return (y, cache, yp) if want_planes else (y, cache)
 
+    def _conv_dx(self, dz, dzp, wt, key, lo, hi):
+        """Input gradient of a Conv1d = the forward conv of dz with taps reversed and W_j transposed (wt [k, Cin, Cout]); on pre-split operands
+        when the producer of dz also wrote its planes."""
+        if dzp is not None:
+            k, cin, cout = wt.shape
+            wpp = self._wplanes(key + ".t", wt.reshape(k * cin, cout))
+            return ops.conv1d_planes(dzp, _ConvP(wpp, None, cin, cout, k), lo, hi, ops.ACT_NONE, want_f32=True, want_planes=False)[0]
+        return ops.conv1d(dz, wt, None, lo, hi)
+
     def _conv_bn_bwd(self, c, dy, cc):
         G, P = self.G, self.P
         pre = cc["prefix"]
-        dz = ops.act_bwd(dy, cc["y_act"], cc["act"], cc["keep"], cc["ks"]) if (cc["act"] != ops.ACT_NONE or cc["keep"] is not None) else dy
         cout, cin, k = P[pre + ".0.weight"].shape
+        pl = ops.planes_enabled() and cout % 32 == 0
+        dzp = None
+        if cc["act"] != ops.ACT_NONE or cc["keep"] is not None:
+            r = ops.act_bwd(dy, cc["y_act"], cc["act"], cc["keep"], cc["ks"], want_planes=pl and not c.train)
+            dz, dzp = r if (pl and not c.train) else (r, None)
+        else:
+            dz = dy
         if c.train:
             dbeta, dgamma = torch.zeros(cout, device=self.dev), torch.zeros(cout, device=self.dev)
             ops.colsum(dz, dbeta)
             ops.colsum(dz, dgamma, y=cc["z"], gamma=cc["invstd"], beta=cc["mean"], mode=3)
             ops.add2d(G[pre + ".1.bias"].reshape(1, -1), dbeta.reshape(1, -1))
             ops.add2d(G[pre + ".1.weight"].reshape(1, -1), dgamma.reshape(1, -1))
-            dz = ops.bn_bwd(dz, cc["z"], cc["mean"], cc["invstd"], P[pre + ".1.weight"], dbeta, dgamma)
+            r = ops.bn_bwd(dz, cc["z"], cc["mean"], cc["invstd"], P[pre + ".1.weight"], dbeta, dgamma, want_planes=pl)
+            dz, dzp = r if pl else (r, None)
             scale = None
         else:
             scale = cc["scale"]
+            if pl and dzp is None:
+                dzp = ops.pack_planes(dz)
 
         def dw(dz=dz, scale=scale, eval_affine=not c.train):
             if eval_affine:
@@ -494,7 +512,12 @@ class TrainEngine(object):
             ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
 
         self._dw(dw)
-        return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
+        # eval mode folds the running statistics into the taps: those transposed taps are not a function of the parameters alone (no caching)
+        if dzp is not None and not c.train:
+            kk, ci, co = cc["wt"].shape
+            wpp = ops.pack_planes(cc["wt"].reshape(kk * ci, co))
+            return ops.conv1d_planes(dzp, _ConvP(wpp, None, ci, co, kk), cc["lo"], cc["hi"], ops.ACT_NONE, want_f32=True, want_planes=False)[0]
+        return self._conv_dx(dz, dzp, cc["wt"], pre, cc["lo"], cc["hi"])
 
     def _conv_bias_relu_fwd(self, x, prefix, lo, hi, need_t=True, xp=None):
         wp, wt = self._conv_pack(self.P[prefix + ".weight"], need_t=need_t)
@@ -509,8 +532,10 @@ class TrainEngine(object):
     def _conv_bias_relu_bwd(self, dy, cc):
         G = self.G
         pre = cc["prefix"]
-        dz = ops.act_bwd(dy, cc["y"], ops.ACT_RELU)
         cout, cin, k = self.P[pre + ".weight"].shape
+        pl = ops.planes_enabled() and cout % 32 == 0
+        r = ops.act_bwd(dy, cc["y"], ops.ACT_RELU, want_planes=pl)
+        dz, dzp = r if pl else (r, None)
 
         def dw():
             ops.colsum(dz, G[pre + ".bias"])
@@ -519,7 +544,7 @@ class TrainEngine(object):
             ops.unpack_conv1d_grad(dwp, G[pre + ".weight"])
 
         self._dw(dw)
-        return ops.conv1d(dz, cc["wt"], None, cc["lo"], cc["hi"])
+        return self._conv_dx(dz, dzp, cc["wt"], pre, cc["lo"], cc["hi"])
 
     def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad, hs_p=None):
         caches, x, xp, out = [], hs, hs_p, None
@@ -907,9 +932,15 @@ class TrainEngine(object):
         w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
         if "p1d" in inj:
             ops.add2d(dp1_all, inj["p1d"])
-        dz1 = ops.act_bwd(dp1_all, c.p1, ops.ACT_RELU, c.k1, c.pks)
+        if bpl is not None and Pn % 32 == 0:
+            dz1, dz1_p = ops.act_bwd(dp1_all, c.p1, ops.ACT_RELU, c.k1, c.pks, want_planes=True)
+        else:
+            dz1, dz1_p = ops.act_bwd(dp1_all, c.p1, ops.ACT_RELU, c.k1, c.pks), None
         self._dw(lambda: (ops.gemm_tn(dz1, c.p0d, G[w1n]), ops.colsum(dz1, G[b1n])))
-        dp0 = ops.linear(dz1, self._wt(P[w1n]))
+        if dz1_p is not None:
+            dp0 = ops.linear_planes(dz1_p, self._wplanes(w1n + ".t", self._wt(P[w1n])), Pn, Pn)[0]
+        else:
+            dp0 = ops.linear(dz1, self._wt(P[w1n]))
         dz0 = ops.act_bwd(dp0, c.p0, ops.ACT_RELU, c.k0, c.pks)
         self._dw(lambda: (ops.gemm_tn(dz0, c.pre_in, G[w0n]), ops.colsum(dz0, G[b0n])))
         self._launch_bucket(c, 1)

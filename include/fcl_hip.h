@@ -283,7 +283,8 @@ int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y,
 /* dw[co, ci, j] += dwp[j, co, ci] * (scale ? scale[co] : 1): packed tap-major conv gradient back to the torch Conv1d layout. */
 int fcl_unpack_conv1d_grad(const float* dwp, const float* scale, float* dw, int cout, int cin, int k, fcl_stream_t stream);
 /* dz = dy * act'(y) [* keep * keep_scale]   (y = the activation's OUTPUT before dropout; act = FCL_ACT_*). */
-int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, size_t n, int act, fcl_stream_t stream);
+int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, uint16_t* dzp /* optional P32 planes of dz */,
+                int cols /* row width for the planes, % 32 == 0 */, size_t n, int act, fcl_stream_t stream);
 /* da (+)= (w_l1 * sign(a - b') + 2 * w_mse * (a - b')) / count on the valid rows, 0 elsewhere  (b' as in fcl_masked_l1_mse_fwd). */
 int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1,
                     float w_mse, double count, float* da, int accumulate, fcl_stream_t stream);
@@ -304,7 +305,7 @@ int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const
                    float* y_act, float* y_drop, uint16_t* yp /* optional P32 planes of the block output (after dropout), C % 32 == 0 */, int m, int c, int act,
                    fcl_stream_t stream);
 int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
-               float* dz, int m, int c, fcl_stream_t stream);
+               float* dz, uint16_t* dzp /* optional P32 planes of dz, C % 32 == 0 */, int m, int c, fcl_stream_t stream);
 /* ---- the training step's time loops, enqueued by ONE call each (H13; decoder_sa.py:472-515, encoder_sa.py:143-146) ----------------------------
  * Cells are step-major: rows sorted by duration descending, cell (t, m) at offset(t) + m with offset(t) = sum_{t' < t} live_rows[t'].
  * s0 / s1 (decoder layers) and s (BiLSTM direction) are the saved tensors {gates [.,4U], c_new, c_old, h_old [.,U]} fcl_lstm_cell_bwd needs. */
