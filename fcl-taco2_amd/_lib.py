@@ -68,6 +68,11 @@ class BilstmBptt(C.Structure):  # fcl_bilstm_bptt_t
                 ("workspace", _P), ("workspace_bytes", _Z), ("status", _P)]
 
 
+class Derive(C.Structure):  # fcl_derive_t
+    _fields_ = [("src", _P), ("src2", _P), ("dst", _P), ("dst_p", _P), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("sa", C.c_int32),
+                ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
 
@@ -117,6 +122,8 @@ SIGNATURES = {
     "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
+    "fcl_derive_blocks": (_I, [_I, _I, _I]),
+    "fcl_derive_batch": (_I, [_P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),
     "fcl_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P, _P, _P]),
     "fcl_lstm_step_fwd": (_I, [C.POINTER(LstmStep), _P]),

@@ -247,6 +247,45 @@ static inline int grid_for(long long total, int block) {
     return (int)g;
 }
 
+// Batched operand forms of the parameters (fcl_derive_batch): one 32x32 output tile per workgroup, any number of matrices per launch.
+// out[(a*B + b), c] = src[a*sa + b*sb + c*sc] (+ src2[same]) ; fp32 and / or P32 planes out.
+__global__ void __launch_bounds__(256) derive_batch_kernel(const fcl_derive_t* __restrict__ descs, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;  // last descriptor whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const fcl_derive_t d = descs[lo];
+    const int R = d.a * d.b, tiles_c = (d.c + 31) >> 5;
+    const int t = (int)blockIdx.x - d.first_block;
+    const int r0 = (t / tiles_c) << 5, c0 = (t % tiles_c) << 5;
+    const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
+    const bool along_c = d.sc == 1 || d.sc == -1 || (d.sb != 1 && d.sb != -1);  // lanes follow the unit-stride direction of the SOURCE
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = i0 + 8 * p;
+        const int r = along_c ? r0 + i : r0 + j, c = along_c ? c0 + j : c0 + i;
+        float v = 0.f;
+        if (r < R && c < d.c) {
+            const long long off = (long long)(r / d.b) * d.sa + (long long)(r % d.b) * d.sb + (long long)c * d.sc;
+            v = d.src[off];
+            if (d.src2) v += d.src2[off];
+        }
+        if (along_c) tile[i][j] = v; else tile[j][i] = v;
+    }
+    __syncthreads();
+    const int ldp = tiles_c;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = i0 + 8 * p, r = r0 + i, c = c0 + j;
+        if (r >= R) continue;
+        const float v = tile[i][j];  // zero past column C: plane lines are zero-padded
+        if (d.dst && c < d.c) d.dst[(size_t)r * d.c + c] = v;
+        if (d.dst_p) store_p32(d.dst_p, ldp, r, c, v);
+    }
+}
+
 }  // namespace fcl
 
 using namespace fcl;
@@ -369,6 +408,19 @@ int fcl_position_table_fwd(const int32_t* dur, float* pos, int n, int lmax, fcl_
     if (n == 0) return 0;
     hipLaunchKernelGGL(position_table_kernel, dim3(grid_for((long long)n * lmax, 256)), dim3(256), 0, (hipStream_t)stream, dur, pos, n, lmax);
     return check_hip(hipGetLastError(), "position_table_fwd");
+}
+
+int fcl_derive_blocks(int a, int b, int c) {
+    if (a <= 0 || b <= 0 || c <= 0) return 0;
+    const long long n = (((long long)a * b + 31) / 32) * ((c + 31) / 32);
+    return n > 0x7fffffffLL ? -1 : (int)n;
+}
+
+int fcl_derive_batch(const fcl_derive_t* descs_dev, int n, int total_blocks, fcl_stream_t stream) {
+    FCL_REQUIRE(n >= 0 && total_blocks >= 0 && (n == 0 || descs_dev), FCL_ERR_INVALID, "derive_batch: bad arguments");
+    if (n == 0 || total_blocks == 0) return 0;
+    hipLaunchKernelGGL(derive_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
+    return check_hip(hipGetLastError(), "derive_batch");
 }
 
 }  // extern "C"

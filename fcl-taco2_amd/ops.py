@@ -425,6 +425,76 @@ def transpose2d(src):
     return dst
 
 
+class DerivedForms(object):
+    """Operand forms that are functions of the PARAMETERS alone (packed Conv1d taps, transposes for the input-gradient GEMMs, column blocks of
+    the decoder's LSTM weights, bias sums; fp32 and / or P32 planes), all refreshed by ONE fcl_derive_batch launch per optimizer update instead
+    of one small launch each (a KD update used to spend ~150 launches on them).  A form is registered the first time it is asked for (and
+    computed on the spot by a one-entry table); from the next refresh() on it is part of the batched table.  Outputs keep their addresses for
+    the life of the object, so the table is uploaded only when a new form appears."""
+
+    def __init__(self, device):
+        self.device = device
+        self.forms = {}  # key -> dict(sig, desc fields, out, outp, keep-alive sources)
+        self.order = []
+        self.table = None  # (device uint8 tensor, n, total_blocks) or None = rebuild
+        self.stamp = None
+
+    def _table(self, forms):
+        arr = (_lib.Derive * len(forms))()
+        first = 0
+        for i, f in enumerate(forms):
+            d = arr[i]
+            d.src, d.src2, d.dst, d.dst_p = f["src_ptr"], f["src2_ptr"], f["dst_ptr"], f["dstp_ptr"]
+            d.a, d.b, d.c, d.sa, d.sb, d.sc = f["geom"]
+            d.first_block = first
+            first += f["blocks"]
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        return host.to(self.device), len(forms), first
+
+    def _run(self, table):
+        dev, n, blocks = table
+        check(_lib.load().fcl_derive_batch(dev.data_ptr(), n, blocks, _stream()))
+
+    def refresh(self, stamp):
+        """Recompute every registered form (call when the parameters changed: once per update)."""
+        if self.order:
+            if self.table is None:
+                self.table = self._table([self.forms[k] for k in self.order])
+            self._run(self.table)
+        self.stamp = stamp
+
+    def get(self, stamp, key, src, geom, base=0, src2=None, f32=True, planes=False):
+        """geom = (a, b, c, sa, sb, sc) over `src` (a contiguous fp32 parameter tensor) starting at element `base`; see fcl_derive_batch.
+        Returns (fp32 [a*b, c] or None, P32 planes or None)."""
+        if stamp != self.stamp:
+            self.refresh(stamp)
+        a, b, c = geom[:3]
+        sig = (src.data_ptr() + 4 * base, None if src2 is None else src2.data_ptr() + 4 * base, tuple(geom), bool(f32), bool(planes))
+        f = self.forms.get(key)
+        if f is not None and f["sig"] == sig:
+            return f["out"], f["outp"]
+        out = torch.empty(a * b, c, device=self.device, dtype=torch.float32) if f32 else None
+        outp = planes_empty(a * b, c, self.device) if planes else None
+        blocks = _lib.load().fcl_derive_blocks(a, b, c)
+        if blocks <= 0:
+            raise _lib.FclError("fcl-taco2_amd: bad derived-form geometry %r" % (geom,))
+        f = dict(sig=sig, src_ptr=_p(src) + 4 * base, src2_ptr=None if src2 is None else _p(src2) + 4 * base, dst_ptr=_p(out), dstp_ptr=_p(outp, torch.int16),
+                 geom=tuple(int(v) for v in geom), blocks=blocks, out=out, outp=outp, keep=(src, src2))
+        if key not in self.forms:
+            self.order.append(key)
+        self.forms[key] = f
+        self.table = None  # rebuilt (and uploaded) at the next refresh
+        one = self._table([f])
+        self._run(one)
+        f["first_table"] = one[0]  # the one-entry table must outlive its launch
+        return out, outp
+
+    def clear(self):
+        self.forms.clear()
+        del self.order[:]
+        self.table, self.stamp = None, None
+
+
 def sumsq_accum(x, out_f64):
     check(_lib.load().fcl_sumsq_accum(_p(x), x.numel(), out_f64.data_ptr(), _stream()))
 

@@ -347,6 +347,15 @@ class TrainEngine(object):
         self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
         self._dw_keep = []
         self._plane_cache = {}
+        # operand forms of the parameters (packed taps, transposes, column blocks, bias sums, their P32 planes): one batched launch per update
+        self._forms = ops.DerivedForms(self.dev)
+        self._recipe = {}  # data_ptr of a derived fp32 form -> (key, src, geom, base, src2): lets _wplanes / _wt derive further forms from the source
+        self._param_ptr = {v.data_ptr(): k for k, v in self.P.items()}
+        nbt = [k for k in self.B if k.endswith("num_batches_tracked")]
+        self._nbt_flat = torch.zeros(len(nbt), dtype=torch.int64, device=self.dev) if nbt else None  # one add_ per forward instead of one per layer
+        for i, k in enumerate(nbt):
+            self._nbt_flat[i] = self.B[k].to(self.dev)
+            self.B[k].data = self._nbt_flat[i]
         try:
             model._engine = self  # load_state_dict() on the module reaches invalidate_planes() through this back-reference
         except Exception:  # pragma: no cover - a module that refuses attributes only loses the cache invalidation hook
@@ -367,6 +376,9 @@ class TrainEngine(object):
         Matrices that also depend on buffers (eval-mode BatchNorm folds) pass cache=False.  None when the pre-split path is off."""
         if not ops.planes_enabled():
             return None
+        rec = self._recipe_of(w) if cache else None
+        if rec is not None:  # a parameter or a form derived from one: its planes come from the source in the batched per-update launch
+            return self._forms.get(self._stamp(), ("p",) + rec[0], rec[1], rec[2], rec[3], rec[4], f32=False, planes=True)[1]
         # validity stamp: optimizer steps (raw-pointer kernels) + torch's version counter of the flat buffer, which every in-place write through
         # any parameter view bumps (load_state_dict, p.data.copy_(), torch optimizers on the autograd path)
         stamp = (self.update_calls, self.pflat._version, tuple(w.shape))
@@ -381,6 +393,38 @@ class TrainEngine(object):
     def invalidate_planes(self):
         """Parameters were overwritten in place (load_state_dict): cached weight planes are stale."""
         self._plane_cache.clear()
+        self._forms.stamp = None
+
+    def _stamp(self):
+        return (self.update_calls, self.pflat._version)
+
+    def _recipe_of(self, w):
+        """(key, src, geom, base, src2) when `w` is a whole parameter seen as a 2-D matrix, or a derived form of one; else None."""
+        ptr = w.data_ptr()
+        rec = self._recipe.get(ptr)
+        if rec is not None:
+            a, b, c = rec[2][:3]
+            return rec if w.numel() == a * b * c and w.shape[-1] == c else None
+        name = self._param_ptr.get(ptr)
+        if name is not None and w.dim() == 2 and w.is_contiguous() and w.numel() == self.P[name].numel():
+            rows, cols = w.shape
+            return ((name, "w", rows), self.P[name], (1, rows, cols, 0, cols, 1), 0, None)
+        return None
+
+    def _form(self, key, src, geom, base=0, src2=None):
+        """fp32 form [a*b, c] of a parameter (ops.DerivedForms / fcl_derive_batch), refreshed with all the others once per update."""
+        out = self._forms.get(self._stamp(), ("f",) + key, src, geom, base, src2, f32=True, planes=False)[0]
+        self._recipe[out.data_ptr()] = (key, src, geom, base, src2)
+        return out
+
+    def _cols(self, w, col0, n):
+        """Contiguous copy of the parameter block w[:, col0:col0+n]."""
+        rows, ld = w.shape
+        return self._form((self._param_ptr[w.data_ptr()], "c", col0, n), w, (1, rows, n, 0, ld, 1), base=col0)
+
+    def _bsum(self, b1, b2):
+        """bias_ih + bias_hh."""
+        return self._form((self._param_ptr[b1.data_ptr()], "bs"), b1, (1, 1, b1.numel(), 0, 0, 1), src2=b2).reshape(-1)
 
     def _dw(self, fn):
         """Run a weight-gradient closure on the side stream, after everything enqueued on the main stream so far.  The closure (and through it
@@ -422,9 +466,19 @@ class TrainEngine(object):
 
     # ------------------------------------------------------------------------------------------------ layers
     def _wt(self, w):
+        rec = self._recipe_of(w)
+        if rec is not None and rec[2][0] == 1 and rec[4] is None:  # transpose of a parameter (block): swap the roles of b and c
+            key, src, (a, b, c, sa, sb, sc), base, _ = rec
+            return self._form(key + ("t",), src, (1, c, b, 0, sc, sb), base=base)
         return ops.transpose2d(w.contiguous())
 
     def _conv_pack(self, w, scale=None, need_t=True):
+        name = self._param_ptr.get(w.data_ptr())
+        if scale is None and name is not None:  # a function of the parameter alone: part of the batched per-update launch
+            cout, cin, k = w.shape
+            wp = self._form((name, "cp"), w, (k, cout, cin, 1, cin * k, k)).view(k, cout, cin)
+            wt = self._form((name, "ct"), w, (k, cin, cout, -1, k, cin * k), base=k - 1).view(k, cin, cout) if need_t else None
+            return wp, wt
         wp = ops.pack_conv1d_weight(w, scale)  # [k, Cout, Cin]
         if not need_t:  # forward only (the frozen teacher): the transposed taps are the backward's operand
             return wp, None
@@ -452,7 +506,7 @@ class TrainEngine(object):
             z = conv(wp, None)
             mean, invstd = ops.bn_stats(z, BN_EPS, BN_MOMENTUM, B[prefix + ".1.running_mean"], B[prefix + ".1.running_var"])
             if prefix + ".1.num_batches_tracked" in B:
-                B[prefix + ".1.num_batches_tracked"].add_(1)  # integer bookkeeping buffer of torch's BatchNorm
+                c.bn_run.append(prefix + ".1.num_batches_tracked")  # torch's integer bookkeeping buffer: all layers advance in one add_ (_forward)
             res = ops.bn_act(z, mean, invstd, P[prefix + ".1.weight"], P[prefix + ".1.bias"], act, keep, ks, want_planes=want_planes)
             y_act, y = res[0], res[1]
             cache = dict(x=x, z=z, y_act=y_act, wt=wt, mean=mean, invstd=invstd, prefix=prefix, act=act, lo=lo, hi=hi, keep=keep, ks=ks)
@@ -588,15 +642,15 @@ class TrainEngine(object):
         wip = [self._wplanes("enc.blstm.weight_ih_l0" + sfx, P["enc.blstm.weight_ih_l0" + sfx]) for sfx in ("", "_reverse")] if use_p else None
         if not save:  # forward only (the frozen KD teacher): the persistent register-resident kernel of the synthesis path
             g = lambda k: P["enc.blstm." + k]
-            r = ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), ops.add_vec(g("bias_ih_l0"), g("bias_hh_l0")),
-                           g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), ops.add_vec(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
+            r = ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), self._bsum(g("bias_ih_l0"), g("bias_hh_l0")),
+                           g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), self._bsum(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
                            B, T, algo=3 if H == 256 else 0, status=self.status,  # one group kernel at a time (this engine's stream)
                            x_p=xp if use_p else None, w_ih_p=wip, want_planes=use_p)
             return (r[0], None, r[1]) if use_p else (r, None, None)
         out = torch.empty(B * T, 2 * H, device=dev)
         gx, whh, sv = [], [], []
         for d, sfx in enumerate(("", "_reverse")):
-            bias = ops.add_vec(P["enc.blstm.bias_ih_l0" + sfx], P["enc.blstm.bias_hh_l0" + sfx])
+            bias = self._bsum(P["enc.blstm.bias_ih_l0" + sfx], P["enc.blstm.bias_hh_l0" + sfx])
             if use_p:
                 gx.append(ops.linear_planes(xp, wip[d], 4 * H, x.shape[1], bias)[0])
             else:
@@ -663,6 +717,7 @@ class TrainEngine(object):
     # ------------------------------------------------------------------------------------------------ forward
     def _forward(self, c, batch):
         hp, dev, P = self.hp, self.dev, self.P
+        c.bn_run = []
         B, T, L = c.B, c.T, c.L
         O, U, Pn, C = hp.odim, hp.dunits, hp.prenet_units, hp.eunits
         p_conv = hp.dropout_rate
@@ -740,14 +795,14 @@ class TrainEngine(object):
             c.p1 = ops.linear(c.p0d, P[w1n], P[b1n], ops.ACT_RELU)
             c.p1d = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks) if c.k1 is not None else c.p1
         w_ih0 = P["dec.lstm.0.cell.weight_ih"]
-        c.w0_att, c.w0_pre = ops.copy_cols(w_ih0, 0, C), ops.copy_cols(w_ih0, C, Pn)
-        w0_pos = ops.copy_cols(w_ih0, C + Pn, 1).reshape(-1)
+        c.w0_att, c.w0_pre = self._cols(w_ih0, 0, C), self._cols(w_ih0, C, Pn)
+        w0_pos = self._cols(w_ih0, C + Pn, 1).reshape(-1)
         c.w0_hh = P["dec.lstm.0.cell.weight_hh"]
-        b0s = ops.add_vec(P["dec.lstm.0.cell.bias_ih"], P["dec.lstm.0.cell.bias_hh"])
+        b0s = self._bsum(P["dec.lstm.0.cell.bias_ih"], P["dec.lstm.0.cell.bias_hh"])
         c.w1_ih, c.w1_hh = P["dec.lstm.1.cell.weight_ih"], P["dec.lstm.1.cell.weight_hh"]
-        b1s = ops.add_vec(P["dec.lstm.1.cell.bias_ih"], P["dec.lstm.1.cell.bias_hh"])
+        b1s = self._bsum(P["dec.lstm.1.cell.bias_ih"], P["dec.lstm.1.cell.bias_hh"])
         wf = P["dec.feat_out.weight"]
-        c.wf_h, c.wf_att = ops.copy_cols(wf, 0, U), ops.copy_cols(wf, U, C)
+        c.wf_h, c.wf_att = self._cols(wf, 0, U), self._cols(wf, U, C)
         if dpl:
             G0 = ops.linear_planes(att_p, self._wplanes("w0_att", c.w0_att), 4 * U, C, b0s)[0]  # hoisted att_c share of the layer-0 gates
             F0 = ops.linear_planes(att_p, self._wplanes("wf_att", c.wf_att), O, C)[0]
@@ -793,6 +848,12 @@ class TrainEngine(object):
             c.post_c.append(cc)
             c.post_taps.append(x)
         c.after = ops.add_vec(c.before, x)
+        if c.bn_run:
+            if self._nbt_flat is not None and len(c.bn_run) == self._nbt_flat.numel():
+                self._nbt_flat.add_(1)
+            else:
+                for k in c.bn_run:
+                    self.B[k].add_(1)
 
     def _knowledge(self, c):
         """The KD teacher's 5-tuple (..._kd_teacher.py:597-603), shaped as the reference's."""

@@ -390,6 +390,27 @@ int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new
 /* dst[idx[m], :] += src[m, :]  (embedding gradient; idx == skip rows are dropped: padding_idx). */
 int fcl_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int m, int c, int64_t skip, fcl_stream_t stream);
 int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream);
+/* Batched operand forms of the parameters, one launch for any number of matrices (a training step re-derives every packed / transposed /
+ * pre-split weight once per optimizer update; the frozen KD teacher once).  Descriptor i produces the [a*b, c] matrix
+ *     out[(ia*b + ib), ic] = src[ia*sa + ib*sb + ic*sc]  (+ src2[same offset] when src2 != NULL)        (strides in floats, may be negative)
+ * as fp32 (dst, dense, row stride c; optional) and / or as P32 planes (dst_p, ceil(c/32) lines per row, zero past c, 128-byte aligned;
+ * optional).  Examples: transpose of W[r, c]: a=1, b=c, c=r, sb=1, sc=c; columns [c0, c0+n) of W: src=W+c0, b=r, c=n, sb=ld, sc=1; Conv1d taps
+ * [Cout, Cin, k] -> [k, Cout, Cin]: a=k, b=Cout, c=Cin, sa=1, sb=Cin*k, sc=k; the backward's reversed, transposed taps [k, Cin, Cout]:
+ * src=W+k-1, a=k, b=Cin, c=Cout, sa=-1, sb=k, sc=Cin*k; bias_ih + bias_hh: src2.
+ * The table lives in DEVICE memory (the caller uploads it once and replays it); first_block = sum of fcl_derive_blocks(a, b, c) of the
+ * descriptors before it, total_blocks = the sum over all.  Pointers inside the table cannot be checked here. */
+typedef struct {
+    const float* src;
+    const float* src2;
+    float* dst;
+    uint16_t* dst_p;
+    int32_t a, b, c;
+    int32_t sa, sb, sc;
+    int32_t first_block;
+    int32_t reserved;
+} fcl_derive_t;
+int fcl_derive_blocks(int a, int b, int c);
+int fcl_derive_batch(const fcl_derive_t* descs_dev, int n, int total_blocks, fcl_stream_t stream);
 /* Optimizer (tts.py:173-182): *out += sum x^2 ; Adam step with clip_grad_norm_(max_norm) and the NaN guard taken from the
  * device-resident squared gradient norm, so the whole step stays on the stream.
  * step_dev: device int32 = number of updates APPLIED so far (torch's per-parameter `step`); the bias corrections use *step_dev + 1 and the

@@ -215,3 +215,52 @@ def test_synthesis_with_and_without_planes_agree(ops):
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
         outs.append(np.load(path))
     assert outs[0].shape == outs[1].shape and np.max(np.abs(outs[0] - outs[1])) < 5e-5
+
+
+def test_derived_forms_batch_is_bit_exact_and_follows_parameter_updates(ops):
+    """fcl_derive_batch (one launch for all operand forms of the parameters): every form equals the one-at-a-time kernels bit for bit, both the
+    fp32 output and the planes; a refresh after an in-place parameter change reproduces them from the new values with the same buffers."""
+    rng = np.random.RandomState(5)
+    W = dev(rnd(rng, 96, 77))       # Linear-like [rows, ld], odd ld
+    Cw = dev(rnd(rng, 40, 24, 5))   # Conv1d weight [Cout, Cin, k]
+    b1, b2 = dev(rnd(rng, 130)), dev(rnd(rng, 130))
+    forms = ops.DerivedForms(torch.device(DEV))
+
+    def ask(stamp):
+        out = {}
+        out["t"] = forms.get(stamp, ("t",), W, (1, 77, 96, 0, 1, 77), f32=True, planes=True)
+        out["c"] = forms.get(stamp, ("c",), W, (1, 96, 33, 0, 77, 1), base=40, f32=True, planes=True)
+        out["ct"] = forms.get(stamp, ("ct",), W, (1, 33, 96, 0, 1, 77), base=40, f32=True, planes=True)
+        out["col"] = forms.get(stamp, ("col",), W, (1, 96, 1, 0, 77, 1), base=76, f32=True, planes=False)
+        out["cp"] = forms.get(stamp, ("cp",), Cw, (5, 40, 24, 1, 120, 5), f32=True, planes=True)
+        out["cr"] = forms.get(stamp, ("cr",), Cw, (5, 24, 40, -1, 5, 120), base=4, f32=True, planes=True)
+        out["bs"] = forms.get(stamp, ("bs",), b1, (1, 1, 130, 0, 0, 1), src2=b2, f32=True, planes=False)
+        out["p"] = forms.get(stamp, ("p",), W, (1, 96, 77, 0, 77, 1), f32=False, planes=True)
+        return out
+
+    def expect():
+        wp = Cw.permute(2, 0, 1).contiguous()  # [k, Cout, Cin]
+        return {
+            "t": W.t().contiguous(), "c": W[:, 40:73].contiguous(), "ct": W[:, 40:73].t().contiguous(), "col": W[:, 76:77].contiguous(),
+            "cp": wp.reshape(5 * 40, 24), "cr": torch.stack([wp[4 - j].t() for j in range(5)]).reshape(5 * 24, 40).contiguous(), "bs": (b1 + b2).reshape(1, -1),
+            "p": W,
+        }
+
+    def check(out):
+        for k, ref in expect().items():
+            f32, pl = out[k]
+            if f32 is not None:
+                assert torch.equal(f32, ref), k
+            if pl is not None:
+                assert torch.equal(pl, ops.pack_planes(ref)), k
+
+    first = ask(0)  # registered and computed one by one
+    check(first)
+    ptrs = {k: tuple(None if t is None else t.data_ptr() for t in v) for k, v in first.items()}
+    W.mul_(1.5).add_(0.25)
+    Cw.neg_()
+    b2.add_(1.0)
+    second = ask(1)  # one batched launch refreshes all eight
+    assert forms.table is not None and forms.table[1] == 8
+    assert {k: tuple(None if t is None else t.data_ptr() for t in v) for k, v in second.items()} == ptrs
+    check(second)
