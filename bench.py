@@ -71,6 +71,47 @@ def pmc_traffic(kernel):
     return (2.0 * vals["fetch"][0] + vals["write"][0]) * 1024.0, "%s + %s" % (vals["fetch"][1], vals["write"][1])
 
 
+def forward_tf_workload(args, rank, world, dev, dist, batch, frames, S, T):
+    """the student's teacher-forced `forward()` under eval() + no_grad() (what the reference's CustomEvaluator runs every epoch,
+    tts_distill.py:91-111): H1-H12 incl. the distillation terms against a teacher 5-tuple computed once, outside the timed region."""
+    import torch
+
+    from fcl_taco2_amd import sharding, synthetic as SYN
+    from fcl_taco2_amd.training import TrainEngine
+
+    teng = TrainEngine(SYN.build_model("kd_teacher", T, None, dev))
+    know = teng.knowledge(batch, mode="train")
+    model = SYN.build_model("student", S, T, dev)
+    model.eval()
+    kw = {k: v for k, v in batch.items() if not k.startswith("_")}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            loss = model(teacher_knowledge=know, **kw)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = model(teacher_knowledge=know, **kw)
+        barrier()
+        dt = time.perf_counter() - t0
+    dt, frames_all = sharding.aggregate_throughput(dt, frames, dist, dev)
+    return {
+        "metric": "mel-frames/sec (FCL-taco2-S teacher-forced forward(), eval + no_grad, batch=%d, 80-mel)" % args.batch,
+        "value": frames_all * args.steps / dt, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 (GEMMs on bf16x3-split MFMA operands, fp32 accumulate; FCL_PRECISION=0 = exact fp32 MFMA)", "data": "synthetic", "loss": float(loss),
+        "config": {"workload": "SURVEY §8d C2(ii): %d utterances/GPU, %d frames/GPU-batch, ys ~ N(0,1), named losses incl. the four distillation terms "
+                               "against a resident teacher 5-tuple, eager launches (shapes change per batch)" % (args.batch, frames),
+                   "parallelism": "%d independent replicas (utterance-sharded, no collective)" % world},
+    }
+
+
 def train_workload(args, rank, world, dev, dist):
     """KD step (frozen train-mode FCL-taco2-T forward -> FCL-taco2-S forward / backward / all-reduce / clip / Adam, tts_distill.py:143-182) or the
     teacher's own training step (tts.py:137-179), train-form regularisers, masks drawn on the device.  One process per GPU; gradients are
@@ -85,12 +126,14 @@ def train_workload(args, rank, world, dev, dist):
     torch.set_num_threads(4)  # the step is ~1000 launches from this thread; a 256-thread intra-op pool spinning after small CPU ops slows them (train.py)
     S, T = HP.student_hparams(), HP.teacher_hparams()
     kd = args.workload == "kd_step"
-    B = args.batch if (kd or args.batch != 32) else 16  # shipped recipes: 32 / GPU for KD, 16 / GPU for the teacher
+    B = args.batch if (kd or args.batch != 32 or args.workload == "forward_tf") else 16  # shipped recipes: 32 / GPU for KD, 16 / GPU for the teacher
     xs, ys, ds, f0, en = SYN.training_batch(80, S.idim, batch=B, t_lo=60, t_hi=100, seed=1234 + rank, zero_frac=0.03, lam=10.0, hi=50)
     batch = CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)])
     frames = int(sum(y.shape[0] for y in ys))
     for k in ("xs", "ys", "extras", "f0", "energy"):  # inputs resident in HBM when the timed region starts; the integer layout tensors stay on the host
         batch[k] = batch[k].to(dev)
+    if args.workload == "forward_tf":
+        return forward_tf_workload(args, rank, world, dev, dist, batch, frames, S, T)
     teng = TrainEngine(SYN.build_model("kd_teacher", T, None, dev)) if kd else None
     eng = TrainEngine(SYN.build_model("student", S, T, dev) if kd else SYN.build_model("teacher", T, None, dev), seed=rank)
 
@@ -202,7 +245,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", choices=["student", "teacher"], default="student")
-    ap.add_argument("--workload", choices=["synthesis", "kd_step", "teacher_step"], default="synthesis",
+    ap.add_argument("--workload", choices=["synthesis", "kd_step", "teacher_step", "forward_tf"], default="synthesis",
                     help="synthesis = BASELINE.json's headline metric (default); kd_step / teacher_step = the training step (SURVEY.md §8d C3/C4)")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (independent passes on separate HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
