@@ -134,8 +134,9 @@ def train_workload(args, rank, world, dev, dist):
         batch[k] = batch[k].to(dev)
     if args.workload == "forward_tf":
         return forward_tf_workload(args, rank, world, dev, dist, batch, frames, S, T)
-    teng = TrainEngine(SYN.build_model("kd_teacher", T, None, dev)) if kd else None
-    eng = TrainEngine(SYN.build_model("student", S, T, dev) if kd else SYN.build_model("teacher", T, None, dev), seed=rank)
+    amp = None if args.amp == "none" else args.amp
+    teng = TrainEngine(SYN.build_model("kd_teacher", T, None, dev), amp=amp) if kd else None
+    eng = TrainEngine(SYN.build_model("student", S, T, dev) if kd else SYN.build_model("teacher", T, None, dev), seed=rank, amp=amp)
 
     from fcl_taco2_amd.training import KDPipeline
 
@@ -221,7 +222,8 @@ def train_workload(args, rank, world, dev, dist):
     out = {
         "metric": "%s time (ms) (%s, batch=%d/GPU, 80-mel)" % (name, "FCL-taco2-T frozen teacher fwd + FCL-taco2-S fwd/bwd/Adam" if kd else "FCL-taco2-T fwd/bwd/Adam", B),
         "value": ms, "unit": "ms/step", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms, "higher_is_better": False, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (GEMMs on bf16x3-split MFMA operands, fp32 accumulate; FCL_PRECISION=0 = exact fp32 MFMA)", "data": "synthetic",
+        "vs_baseline": None, "dtype": ("bf16 GEMM operands (rounded), fp32 accumulate / master weights / norms / losses / Adam (--amp bf16)" if amp else
+                                       "f32 (GEMMs on bf16x3-split MFMA operands, fp32 accumulate; FCL_PRECISION=0 = exact fp32 MFMA)"), "data": "synthetic",
         "frames_per_s": frames_all * steps / dt, "loss": rep["loss"], "grad_norm": rep["grad_norm"],
         "config": {"workload": "SURVEY §8d %s: %d utterances/GPU, 60-100 phonemes, durations clip(Poisson(10),1,50) with 3%% zero-duration phonemes, "
                                "%d frames/GPU-batch, train-form BatchNorm / dropout / zoneout (device RNG), Adam lr 1e-3 eps 1e-6, clip 1.0, "
@@ -229,8 +231,8 @@ def train_workload(args, rank, world, dev, dist):
                    "parallelism": "dp%d: one process per GPU, gradient all-reduce (AVG) in 4 buckets overlapped with backward" % world,
                    "pipeline": ("frozen teacher one batch ahead on a second HIP stream (steady-state time per update)" if pipe is not None else
                                 "teacher forward and update back to back on one stream")},
-        "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+        "roofline": {"bound": "mfma", "kernel": "whole step", "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS if amp else PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16_MFMA_TFLOPS if amp else PEAK_F32_MFMA_TFLOPS), "traffic": None,
                      "note": "algorithmic %.0f MFLOP per frame per step (SURVEY.md §8d) x frames / measured step time (per GPU)" % mflop},
     }
     if cpu is not None:
@@ -247,6 +249,8 @@ def main():
     ap.add_argument("--model", choices=["student", "teacher"], default="student")
     ap.add_argument("--workload", choices=["synthesis", "kd_step", "teacher_step", "forward_tf"], default="synthesis",
                     help="synthesis = BASELINE.json's headline metric (default); kd_step / teacher_step = the training step (SURVEY.md §8d C3/C4)")
+    ap.add_argument("--amp", choices=["none", "bf16"], default="none", help="kd_step / teacher_step: the mixed-precision variant (bf16-rounded GEMM operands, "
+                    "fp32 accumulate / master weights / optimizer) of the reference's --use-amp recipes")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (independent passes on separate HIP streams)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -68,6 +68,9 @@ class BilstmBptt(C.Structure):  # fcl_bilstm_bptt_t
                 ("workspace", _P), ("workspace_bytes", _Z), ("status", _P)]
 
 
+GEMM_F32, GEMM_BF16 = 0, 1
+
+
 class Derive(C.Structure):  # fcl_derive_t
     _fields_ = [("src", _P), ("src2", _P), ("dst", _P), ("dst_p", _P), ("a", C.c_int32), ("b", C.c_int32), ("c", C.c_int32), ("sa", C.c_int32),
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
@@ -80,6 +83,8 @@ class ProfEntry(C.Structure):
 SIGNATURES = {
     "fcl_last_error": (C.c_char_p, []),
     "fcl_version": (_I, []),
+    "fcl_set_gemm_mode": (_I, [_I]),
+    "fcl_get_gemm_mode": (_I, []),
     "fcl_pack_conv1d_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "fcl_fold_batchnorm": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "fcl_copy2d": (_I, [_P, _I, _P, _I, _I, _I, _P]),
@@ -122,6 +127,8 @@ SIGNATURES = {
     "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
+    "fcl_pack_planes_t": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "fcl_gemm_tn_planes": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _Z, _P]),
     "fcl_derive_blocks": (_I, [_I, _I, _I]),
     "fcl_derive_batch": (_I, [_P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),

@@ -34,7 +34,7 @@ template <int PREC>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                       float* __restrict__ C, int ldc, int M, int N, int K, int shift0,
                                                       const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int rows_per_slice, int ntaps,
-                                                      long long c_tap_stride) {
+                                                      long long c_tap_stride, const int hi_only) {
     constexpr int LDS_BYTES = PREC == 0 ? 2 * 64 * TN_LD * 4 : 4 * 64 * TN_LDK * 2;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     // XCD-aware order (as in gemm_f32.hip): the ids one XCD receives walk a contiguous range of (slice, tap, k tile, n tile), so the tiles that
@@ -160,8 +160,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             for (int j = 0; j < 4; ++j) {
                 const int bo = (j * 16 + r16) * TN_LDK + kq * 8;
                 const s16x8 bh = *reinterpret_cast<const s16x8*>(Bth + bo), bl = *reinterpret_cast<const s16x8*>(Btl + bo);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[j], 0, 0, 0);
+                if (!hi_only) {  // FCL_GEMM_BF16: bf16-rounded operands, the hi.hi product alone
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[j], 0, 0, 0);
+                }
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[j], 0, 0, 0);
             }
         }
@@ -615,12 +617,13 @@ int fcl_gemm_tn_taps_fwd(const float* a, int lda, const float* b, int ldb, float
     if (rps < 4 * TN_BM) rps = 4 * TN_BM;
     slices = (m + rps - 1) / rps;
     dim3 grid((n + 63) / 64, (k + 63) / 64, slices * ntaps);
-    ProfScope ps("gemm_tn_kernel", 2.0 * m * (double)n * k * ntaps, m, (hipStream_t)stream);
     static const int prec = tunable("PRECISION", 1);  // as the forward GEMMs: 1 = bf16x3 operands, 0 = exact fp32 MFMA
+    const int hi_only = prec && fcl::gemm_mode() == FCL_GEMM_BF16;
+    ProfScope ps(hi_only ? "gemm_tn_kernel/bf16" : "gemm_tn_kernel", 2.0 * m * (double)n * k * ntaps, m, (hipStream_t)stream);
     if (prec) hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift0, seg_lo, seg_hi, rps,
-                                 ntaps, (long long)c_tap_stride);
+                                 ntaps, (long long)c_tap_stride, hi_only);
     else hipLaunchKernelGGL(gemm_tn_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, m, n, k, shift0, seg_lo, seg_hi, rps,
-                            ntaps, (long long)c_tap_stride);
+                            ntaps, (long long)c_tap_stride, 0);
     return check_hip(hipGetLastError(), "gemm_tn_fwd");
 }
 

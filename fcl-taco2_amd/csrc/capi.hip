@@ -13,6 +13,7 @@
 namespace fcl {
 
 static thread_local char g_err[512] = "";
+static thread_local int g_gemm_mode = FCL_GEMM_F32;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -26,6 +27,8 @@ int check_hip(hipError_t e, const char* what) {
     set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
     return FCL_ERR_HIP;
 }
+
+int gemm_mode() { return g_gemm_mode; }
 
 int tunable(const char* name, int dflt) {
     char key[64];
@@ -121,6 +124,15 @@ extern "C" {
 
 const char* fcl_last_error(void) { return g_err; }
 int fcl_version(void) { return 100; }
+
+int fcl_set_gemm_mode(int mode) {
+    FCL_REQUIRE(mode == FCL_GEMM_F32 || mode == FCL_GEMM_BF16, FCL_ERR_INVALID, "set_gemm_mode: unknown mode %d", mode);
+    FCL_REQUIRE(mode == FCL_GEMM_F32 || tunable("PRECISION", 1) != 0, FCL_ERR_INVALID,
+                "set_gemm_mode: FCL_GEMM_BF16 needs the bf16 MFMA path (FCL_PRECISION=0 selects exact fp32 MFMAs)");
+    g_gemm_mode = mode;
+    return 0;
+}
+int fcl_get_gemm_mode(void) { return g_gemm_mode; }
 
 int fcl_linear_fwd(const float* x, int lda, const float* w, int ldw, const float* bias, float* y, int ldy, int m, int n,
                    int k, int act, fcl_stream_t stream) {

@@ -65,6 +65,13 @@ struct GemmArgs {
     int y2_row_add;
     unsigned short* Yp;  // optional P32 planes of the output (ldyp lines per row, written up to the padded width); Y may then be null
     int ldyp;
+    int hi_only;  // set by the launchers from gemm_mode(): operands rounded to bf16 (one MFMA per product) instead of the bf16x3 split
+    // planes kernels only (the weight-gradient GEMM, fcl_gemm_tn_planes): split of the contraction over gridDim.z (chunks of 32 per slice, single
+    // term), atomic accumulation into Y, and an output made of column blocks (column n -> Y + (n / nblk) * blk_stride + m * ldy + n % nblk)
+    int ksplit_chunks;
+    int accumulate;
+    int nblk;
+    long long blk_stride;
 };
 
 // ---- fused LSTM step (gemm_f32.hip / decoder_step.hip): the argument block is the public fcl_lstm_step_t ----------
@@ -173,6 +180,7 @@ bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wa
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
 int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled);
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s);
+int gemm_mode();  // capi.hip: the calling thread's fcl_set_gemm_mode() value (FCL_GEMM_F32 / FCL_GEMM_BF16)
 int tunable(const char* name, int dflt);  // FCL_<NAME> environment override, read once
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: opt the CURRENT device in for `bytes` of dynamic LDS the first time
 // `func` is launched on it (thread-safe; every later call is a map lookup).  Returns 0 or FCL_ERR_HIP.

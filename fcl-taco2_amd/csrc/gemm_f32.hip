@@ -57,7 +57,7 @@ constexpr int LDK = BK + 8;  // bf16 elements per LDS plane row: 80 B stride -> 
 template <int WM, int WN, bool LSTM, int PREC = 0, int TM = 1>
 __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0,
                                          int NU, const int* __restrict__ seg_lo, const int* __restrict__ seg_hi,
-                                         float* lds, f32x4 (&acc)[TM][4]) {
+                                         float* lds, f32x4 (&acc)[TM][4], bool hi_only = false) {
     using G = Geo<WM, WN, LSTM, TM>;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -216,10 +216,12 @@ __device__ __forceinline__ void mainloop(const GemmTerm* __restrict__ terms, int
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
+                if (!hi_only) {  // FCL_GEMM_BF16: bf16-rounded operands, the hi.hi product alone
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[j], acc[tm][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[j], acc[tm][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[j], acc[tm][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[j], acc[tm][j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[tm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[j], acc[tm][j], 0, 0, 0);
             }
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, false, PREC, TM>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, lds, acc);
+    mainloop<WM, WN, false, PREC, TM>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, lds, acc, PREC != 0 && a.hi_only != 0);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
 }
 
 template <int WM, int WN, int MODE, int PREC, int TM = 1>
-__global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepArgs a, const int hi_only) {
     using G = Geo<WM, WN, true, TM>;
     __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
     int bx, by;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, true, PREC, TM>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc);
+    mainloop<WM, WN, true, PREC, TM>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc, PREC != 0 && hi_only != 0);
     if (u >= a.U) return;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
@@ -403,11 +405,13 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t s, const char* name, 
     using G = Geo<WM, WN, false, TM>;
     dim3 grid((a.N + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
     char full[64];  // the rocprofv3 instantiation name <WM, WN, PREC, TM>, so HIP-event and rocprof / PMC rows can be joined by name
-    snprintf(full, sizeof(full), "gemm_kernel<%d,%d,%d,%d>%s", WM, WN, precision() ? 1 : 0, TM, precision() ? "/bf16x3" : "");
+    GemmArgs b = a;
+    b.hi_only = precision() && gemm_mode() == FCL_GEMM_BF16;
+    snprintf(full, sizeof(full), "gemm_kernel<%d,%d,%d,%d>%s", WM, WN, precision() ? 1 : 0, TM, b.hi_only ? "/bf16" : precision() ? "/bf16x3" : "");
     (void)name;
     ProfScope ps(full, flops, a.M, s);
-    if (precision()) hipLaunchKernelGGL((gemm_kernel<WM, WN, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<WM, WN, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
+    if (precision()) hipLaunchKernelGGL((gemm_kernel<WM, WN, 1, TM>), grid, dim3(G::THREADS), 0, s, b);
+    else hipLaunchKernelGGL((gemm_kernel<WM, WN, 0, TM>), grid, dim3(G::THREADS), 0, s, b);
 }
 
 template <int WM, int WN, int TM = 1>
@@ -417,17 +421,18 @@ static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* na
     const bool plain = !a.zone_keep_h && !a.row_len;
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
     char full[64];  // <WM, WN, MODE, PREC, TM> as rocprofv3 prints the instantiation
-    snprintf(full, sizeof(full), "lstm_step_kernel<%d,%d,%d,%d,%d>%s", WM, WN, mode, precision() ? 1 : 0, TM, precision() ? "/bf16x3" : "");
+    const int hi_only = precision() && gemm_mode() == FCL_GEMM_BF16;
+    snprintf(full, sizeof(full), "lstm_step_kernel<%d,%d,%d,%d,%d>%s", WM, WN, mode, precision() ? 1 : 0, TM, hi_only ? "/bf16" : precision() ? "/bf16x3" : "");
     (void)name;
     ProfScope ps(full, flops, a.M, s);
     if (precision()) {
-        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
-        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
-        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 1, TM>), grid, dim3(G::THREADS), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 1, TM>), grid, dim3(G::THREADS), 0, s, a, hi_only);
+        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 1, TM>), grid, dim3(G::THREADS), 0, s, a, hi_only);
+        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 1, TM>), grid, dim3(G::THREADS), 0, s, a, hi_only);
     } else {
-        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
-        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
-        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 0, TM>), grid, dim3(G::THREADS), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 0, 0, TM>), grid, dim3(G::THREADS), 0, s, a, hi_only);
+        else if (mode == 1) hipLaunchKernelGGL((lstm_step_kernel<WM, WN, 1, 0, TM>), grid, dim3(G::THREADS), 0, s, a, hi_only);
+        else hipLaunchKernelGGL((lstm_step_kernel<WM, WN, -1, 0, TM>), grid, dim3(G::THREADS), 0, s, a, hi_only);
     }
 }
 

@@ -45,9 +45,20 @@ __device__ __forceinline__ void xcd_tile_p(int& bx, int& by) {
 }
 
 // one 32-k chunk of a wave's TM x TN tiles: fragment reads (bank-conflict free by the piece permutation) and 3 bf16 MFMAs per tile pair
-template <int TM, int TN>
+template <int TM, int TN, bool HI>
 __device__ __forceinline__ void pchunk_mma(const u8* sb, int a_hi, int a_lo, int b_hi, int b_lo, f32x4 (&acc)[TM][TN]) {
     s16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    if constexpr (HI) {  // FCL_GEMM_BF16 (autocast): operands rounded to bf16 = the hi plane alone, one MFMA per product, fp32 accumulation
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) ah[tm] = *reinterpret_cast<const s16x8*>(sb + a_hi + tm * 16 * 128);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) bh[tn] = *reinterpret_cast<const s16x8*>(sb + b_hi + tn * 16 * 128);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         ah[tm] = *reinterpret_cast<const s16x8*>(sb + a_hi + tm * 16 * 128);
@@ -86,9 +97,9 @@ struct PGeo {
 
 // The shared main loop.  LSTM: tile column c of the wave strip wn is gate (c >> 4) & 3 of unit u0 + wn*16 + (c & 15), i.e. W row g*NU + u
 // (TN must be 4); generic: W row n0 + c.  NU = N (generic) or U.  Returns false in a loader wave (LW > 0), which is done and must return.
-template <int WM, int WN, int TM, int TN, int NST, bool LSTM, int LW>
+template <int WM, int WN, int TM, int TN, int NST, bool LSTM, int LW, bool HI>
 __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0, int NU, const int* __restrict__ seg_lo,
-                                          const int* __restrict__ seg_hi, u8* smem, f32x4 (&acc)[TM][TN]) {
+                                          const int* __restrict__ seg_hi, u8* smem, f32x4 (&acc)[TM][TN], int ksplit_chunks = 0) {
     using G = PGeo<WM, WN, TM, TN, NST, LW>;
     static_assert(!LSTM || TN == 4, "LSTM tiles keep the four gates of a unit in one lane");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,6 +109,11 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
     const int wm = wave / WN, wn = wave % WN;
     int nchunks = 0;
     for (int t = 0; t < nterms; ++t) nchunks += (terms[t].K + 31) >> 5;
+    int kskip = 0;  // split contraction (single term): slice blockIdx.z owns chunks [kskip, kskip + nchunks)
+    if (ksplit_chunks > 0) {
+        kskip = (int)blockIdx.z * ksplit_chunks;
+        nchunks = max(0, min(ksplit_chunks, nchunks - kskip));
+    }
 
     if (LW == 0 || loader) {
         // ---- loader coordinates: group g = j*NL + lw covers rows g*8 .. g*8+7 of its region; lane -> (row = lane >> 3, LDS piece = lane & 7)
@@ -143,16 +159,16 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
             for (int j = 0; j < G::GA; ++j) {
                 const int src = am[j] + T.shift;
                 const bool ok = (unsigned)(src - alo[j]) < alen[j];
-                pa[j] = ok ? Ab + (size_t)src * ((size_t)T.lda_p * 128) + coff : zline;
+                pa[j] = ok ? Ab + ((size_t)src * (size_t)T.lda_p + kskip) * 128 + coff : zline;
                 ia[j] = ok ? 128u : 0u;
             }
 #pragma unroll
             for (int j = 0; j < G::GB; ++j) {
                 const bool ok = brow[j] >= 0;
-                pb[j] = ok ? Wb + (size_t)brow[j] * ((size_t)T.ldw_p * 128) + coff : zline;
+                pb[j] = ok ? Wb + ((size_t)brow[j] * (size_t)T.ldw_p + kskip) * 128 + coff : zline;
                 ib[j] = ok ? 128u : 0u;
             }
-            rem = (T.K + 31) >> 5;
+            rem = ((T.K + 31) >> 5) - kskip;
         };
         auto issue = [&](int stage) {
             u8* sbase = smem + stage * G::STAGE + lw * 1024;
@@ -207,7 +223,7 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
                 issue(is);
                 is = is + 1 == NST ? 0 : is + 1;
             }
-            pchunk_mma<TM, TN>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
+            pchunk_mma<TM, TN, HI>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
             cs = cs + 1 == NST ? 0 : cs + 1;
         }
         return true;
@@ -223,7 +239,7 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
         int cs = 0;
         for (int i = 0; i < nchunks; ++i) {
             asm volatile("s_barrier" ::: "memory");  // the loader waves have seen chunk i land before they arrive here
-            pchunk_mma<TM, TN>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
+            pchunk_mma<TM, TN, HI>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
             cs = cs + 1 == NST ? 0 : cs + 1;
         }
     }
@@ -231,7 +247,7 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
 }
 
 // --------------------------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int NST, int LW>
+template <int WM, int WN, int TM, int TN, int NST, int LW, bool HI>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmArgs a) {
     using G = PGeo<WM, WN, TM, TN, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!pmainloop<WM, WN, TM, TN, NST, false, LW>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc)) return;  // loader wave
+    if (!pmainloop<WM, WN, TM, TN, NST, false, LW, HI>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc, a.ksplit_chunks)) return;  // loader wave
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -288,6 +304,17 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
         }
     __syncthreads();
     const int rows = min(G::BM, a.M - m0);
+    if (a.accumulate) {  // weight gradients (split contraction, accumulation over micro-batches): one float per lane, consecutive lanes on
+                         // consecutive addresses, so a wave's atomic instruction touches two cache lines
+        for (int i = threadIdx.x; i < rows * G::BN; i += G::CTHREADS) {
+            const int rm = i / G::BN, cn = i - rm * G::BN, n = n0 + cn;
+            if (n >= a.N) continue;
+            float* dst = a.nblk > 0 ? a.Y + (size_t)(n / a.nblk) * a.blk_stride + (size_t)(m0 + rm) * a.ldy + (n % a.nblk)
+                                    : a.Y + (size_t)(m0 + rm) * a.ldy + n;
+            atomicAdd(dst, tile[rm * LDT + cn]);
+        }
+        return;
+    }
     if (a.Y) {
         const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
         for (int i = threadIdx.x; i < rows * (G::BN / 4); i += G::CTHREADS) {
@@ -320,7 +347,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
     }
 }
 
-template <int WM, int WN, int TM, int NST, int MODE, int LW>
+template <int WM, int WN, int TM, int NST, int MODE, int LW, bool HI>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmStepArgs a) {
     using G = PGeo<WM, WN, TM, 4, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!pmainloop<WM, WN, TM, 4, NST, true, LW>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, smem, acc)) return;  // loader wave
+    if (!pmainloop<WM, WN, TM, 4, NST, true, LW, HI>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, smem, acc)) return;  // loader wave
     // Epilogue through LDS (see pgemm_kernel): the new h and c of the tile are staged as [row][unit] fp32 and written out row-wise, 16 bytes
     // per lane; the tile's 16 WN units are (part of) ONE 128-byte P32 line per row, so the planes of h go out as whole 16-byte pieces too.
     constexpr int UW = 16 * WN, LDT = UW + 4;
@@ -413,24 +440,36 @@ static int loader_waves() {
     return v;
 }
 
-template <int WM, int WN, int TM, int TN, int NST, int LW>
+template <int WM, int WN, int TM, int TN, int NST, int LW, bool HI>
 static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
     using G = PGeo<WM, WN, TM, TN, NST, LW>;
-    auto k = pgemm_kernel<WM, WN, TM, TN, NST, LW>;
+    auto k = pgemm_kernel<WM, WN, TM, TN, NST, LW, HI>;
     const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(k), G::LDS_BYTES);
     if (rc) return rc;
     const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;  // the tiles also cover the zero padding of the output planes
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
     char full[64];
-    snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, TM, TN, NST, LW);
+    snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NST, LW, HI ? "/bf16" : "", a.accumulate ? "/dW" : "");
     ProfScope ps(full, flops, a.M, s);
+    if (a.accumulate && a.nterms == 1) {  // weight gradient: few output tiles, long contraction -> slices of the contraction over gridDim.z, ~512 workgroups
+        GemmArgs b = a;
+        const int total = (a.term[0].K + 31) >> 5, tiles = (int)(grid.x * grid.y);
+        static const int wg_target = tunable("DW_WORKGROUPS", 256), min_chunks = tunable("DW_MIN_CHUNKS", 16);
+        int splits = std::max(1, std::min(wg_target / std::max(tiles, 1), total / std::max(min_chunks, 1)));
+        b.ksplit_chunks = (total + splits - 1) / splits;
+        grid.z = (unsigned)((total + b.ksplit_chunks - 1) / b.ksplit_chunks);
+        hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+        return check_hip(hipGetLastError(), "pgemm launch");
+    }
     hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     return check_hip(hipGetLastError(), "pgemm launch");
 }
 
 template <int WM, int WN, int TM, int TN, int NST>
 static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
-    return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0>(a, s, flops);
+    if (gemm_mode() == FCL_GEMM_BF16)  // autocast: bf16-rounded operands (the hi planes alone), one MFMA per product
+        return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2, true>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0, true>(a, s, flops);
+    return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2, false>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0, false>(a, s, flops);
 }
 
 int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
@@ -442,34 +481,38 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     const long long t128x128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     // measured on MI355X (tools/probe/planes_gemm_probe): 8-wave 128 x 128 tiles where they still give >= ~150 workgroups, 64 x 128 with three
     // stages (two workgroups per CU) down to ~250, 64 x 64 below that (the encoder-side GEMMs: M = 3 200, N = 256-384)
+    if (a.accumulate && force == 0)  // split contraction fills the device whatever the tile count: the largest tiles that fit the output
+        return (a.M >= 128 && a.N >= 128) ? launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops) : launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
     if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
     if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pgemm_cfg<2, 2, 2, 4, 3>(a, s, flops);
     return launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
 }
 
-template <int WM, int WN, int TM, int NST, int LW>
+template <int WM, int WN, int TM, int NST, int LW, bool HI>
 static int launch_plstm_lw(const LstmStepArgs& a, hipStream_t s, double flops) {
     using G = PGeo<WM, WN, TM, 4, NST, LW>;
     const bool plain = !a.zone_keep_h && !a.row_len;
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     char full[64];
-    snprintf(full, sizeof(full), "plstm_kernel<%d,%d,%d,%d,%d,%d>", WM, WN, TM, NST, mode, LW);
-    const void* fn = mode == 0 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 0, LW>)
-                   : mode == 1 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 1, LW>)
-                               : reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, -1, LW>);
+    snprintf(full, sizeof(full), "plstm_kernel<%d,%d,%d,%d,%d,%d>%s", WM, WN, TM, NST, mode, LW, HI ? "/bf16" : "");
+    const void* fn = mode == 0 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 0, LW, HI>)
+                   : mode == 1 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 1, LW, HI>)
+                               : reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, -1, LW, HI>);
     const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
     if (rc) return rc;
     ProfScope ps(full, flops, a.M, s);
-    if (mode == 0) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 0, LW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else if (mode == 1) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 1, LW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, -1, LW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    if (mode == 0) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 0, LW, HI>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 1, LW, HI>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, -1, LW, HI>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     return check_hip(hipGetLastError(), "plstm launch");
 }
 
 template <int WM, int WN, int TM, int NST>
 static int launch_plstm_cfg(const LstmStepArgs& a, hipStream_t s, double flops) {
-    return loader_waves() ? launch_plstm_lw<WM, WN, TM, NST, 2>(a, s, flops) : launch_plstm_lw<WM, WN, TM, NST, 0>(a, s, flops);
+    if (gemm_mode() == FCL_GEMM_BF16)
+        return loader_waves() ? launch_plstm_lw<WM, WN, TM, NST, 2, true>(a, s, flops) : launch_plstm_lw<WM, WN, TM, NST, 0, true>(a, s, flops);
+    return loader_waves() ? launch_plstm_lw<WM, WN, TM, NST, 2, false>(a, s, flops) : launch_plstm_lw<WM, WN, TM, NST, 0, false>(a, s, flops);
 }
 
 int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
@@ -497,6 +540,38 @@ __global__ void pack_planes_kernel(const float* __restrict__ x, int ld, int rows
     }
 }
 
+// Transposed planes (P32T) of x [rows, cols]: one plane row per COLUMN, 32 consecutive rows m per 128-byte line (hi | lo) -- the operand layout
+// of the weight-gradient GEMM (contraction over rows).  Tap t (grid.z) reads row m + shift0 + t, zero outside [seg_lo[m], seg_hi[m]) (or outside
+// [0, rows)) and past `rows`; plane row = t * cols + c.  One 32 x 32 tile per workgroup through LDS: coalesced reads along c, whole lines out.
+__global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restrict__ x, int ld, int rows, int cols, int shift0,
+                                                            const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, u16* __restrict__ out, int ldp) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tap = blockIdx.z, shift = shift0 + tap;
+    const int j = threadIdx.x & 31, i0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = i0 + 8 * p, m = m0 + i, c = c0 + j;
+        float v = 0.f;
+        if (m < rows && c < cols) {
+            const int src = m + shift;
+            const bool ok = seg_lo ? (src >= seg_lo[m] && src < seg_hi[m]) : (src >= 0 && src < rows);
+            if (ok) v = x[(size_t)src * ld + c];
+        }
+        tile[i][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int i = i0 + 8 * p, c = c0 + i;  // plane row = column c; lane j = row m0 + j of the source
+        if (c >= cols) continue;
+        const float v = tile[j][i];
+        const __bf16 h = (__bf16)v;
+        u16* line = out + (((size_t)tap * cols + c) * ldp + blockIdx.x) * 64 + j;
+        line[0] = __builtin_bit_cast(u16, h);
+        line[32] = __builtin_bit_cast(u16, (__bf16)(v - (float)h));
+    }
+}
+
 }  // namespace fcl
 
 using namespace fcl;
@@ -506,6 +581,40 @@ extern "C" {
 size_t fcl_planes_elems(int rows, int cols) {
     if (rows <= 0 || cols <= 0) return 0;
     return (size_t)rows * ((cols + 31) / 32) * 64;
+}
+
+int fcl_pack_planes_t(const float* x, int ld, int rows, int cols, int ntaps, int shift0, const int32_t* seg_lo, const int32_t* seg_hi, uint16_t* out,
+                      fcl_stream_t stream) {
+    FCL_REQUIRE(x && out && rows > 0 && cols > 0 && ld >= cols && ntaps >= 1, FCL_ERR_INVALID, "pack_planes_t: bad arguments");
+    FCL_REQUIRE((seg_lo == nullptr) == (seg_hi == nullptr), FCL_ERR_INVALID, "pack_planes_t: seg_lo/seg_hi come in pairs");
+    FCL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 127u) == 0, FCL_ERR_ALIGN, "pack_planes_t: the plane buffer must be 128-byte aligned");
+    const int ldp = (rows + 31) / 32;
+    FCL_REQUIRE((cols + 31) / 32 <= 65535 && ntaps <= 65535, FCL_ERR_SHAPE, "pack_planes_t: too many columns / taps for one launch");
+    hipLaunchKernelGGL(pack_planes_t_kernel, dim3((unsigned)ldp, (unsigned)((cols + 31) / 32), (unsigned)ntaps), dim3(256), 0, (hipStream_t)stream, x, ld, rows,
+                       cols, shift0, seg_lo, seg_hi, out, ldp);
+    return check_hip(hipGetLastError(), "pack_planes_t");
+}
+
+int fcl_gemm_tn_planes(const uint16_t* ap_t, const uint16_t* bp_t, float* c, int ldc, int m, int n, int k, int nblk, size_t blk_stride,
+                       fcl_stream_t stream) {
+    FCL_REQUIRE(ap_t && bp_t && c && m > 0 && n > 0 && k > 0, FCL_ERR_INVALID, "gemm_tn_planes: bad arguments");
+    FCL_REQUIRE(((reinterpret_cast<uintptr_t>(ap_t) | reinterpret_cast<uintptr_t>(bp_t)) & 127u) == 0, FCL_ERR_ALIGN, "gemm_tn_planes: planes must be 128-byte aligned");
+    FCL_REQUIRE(nblk >= 0 && (nblk == 0 || ((nblk & 3) == 0 && k % nblk == 0)), FCL_ERR_SHAPE, "gemm_tn_planes: nblk must be a multiple of 4 dividing k");
+    FCL_REQUIRE(tunable("PRECISION", 1) != 0, FCL_ERR_INVALID, "gemm_tn_planes: the pre-split path is off under FCL_PRECISION=0 (use fcl_gemm_tn_fwd)");
+    GemmArgs g = {};
+    g.nterms = 1;
+    g.term[0].Ap = ap_t;
+    g.term[0].Wp = bp_t;
+    g.term[0].lda_p = g.term[0].ldw_p = (m + 31) / 32;
+    g.term[0].K = m;
+    g.M = n;
+    g.N = k;
+    g.Y = c;
+    g.ldy = ldc;
+    g.accumulate = 1;
+    g.nblk = nblk;
+    g.blk_stride = (long long)blk_stride;
+    return launch_gemm_planes(g, (hipStream_t)stream);
 }
 
 int fcl_pack_planes(const float* x, int ld, int rows, int cols, uint16_t* out, fcl_stream_t stream) {

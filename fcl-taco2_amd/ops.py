@@ -70,6 +70,28 @@ def pack_frag_bf16(w):
     return hi, lo
 
 
+class gemm_mode(object):
+    """Context manager for the calling thread's contraction arithmetic (include/fcl_hip.h fcl_set_gemm_mode): `with ops.gemm_mode("bf16"):` runs the
+    big-tile GEMMs inside on bf16-rounded operands (autocast); "f32" (default) is the fp32-equivalent bf16x3 split."""
+
+    MODES = {"f32": _lib.GEMM_F32, "bf16": _lib.GEMM_BF16, None: _lib.GEMM_F32}
+
+    def __init__(self, mode):
+        if mode not in self.MODES:
+            raise ValueError("gemm mode must be 'f32' or 'bf16', got %r" % (mode,))
+        self.mode = self.MODES[mode]
+
+    def __enter__(self):
+        lib = _lib.load()
+        self.prev = lib.fcl_get_gemm_mode()
+        check(lib.fcl_set_gemm_mode(self.mode))
+        return self
+
+    def __exit__(self, *exc):
+        check(_lib.load().fcl_set_gemm_mode(self.prev))
+        return False
+
+
 def planes_enabled():
     """The pre-split (P32) operand path is on unless exact-fp32 arithmetic (FCL_PRECISION=0) or FCL_PLANES=0 is requested."""
     import os
@@ -286,6 +308,31 @@ def gemm_tn(a, b, out, shift=0, seg_lo=None, seg_hi=None):
     k = b.shape[1]
     assert b.shape[0] == m and out.shape == (n, k) and out.stride(1) == 1 and out.dtype == torch.float32 and out.is_cuda
     check(_lib.load().fcl_gemm_tn_fwd(_p(a), n, _p(b), k, out.data_ptr(), out.stride(0), m, n, k, shift, _p(seg_lo, torch.int32), _p(seg_hi, torch.int32), _stream()))
+    return out
+
+
+def pack_planes_t(x, ntaps=1, shift0=0, seg_lo=None, seg_hi=None):
+    """Transposed P32 planes (include/fcl_hip.h fcl_pack_planes_t) of x [rows, cols]: int16 [ntaps * cols, ceil(rows/32) * 64]."""
+    rows, cols = x.shape
+    assert x.stride(1) == 1 and rows > 0
+    out = torch.empty(ntaps * cols, (rows + 31) // 32 * 64, device=x.device, dtype=torch.int16)
+    assert out.data_ptr() % 128 == 0
+    check(_lib.load().fcl_pack_planes_t(x.data_ptr(), x.stride(0), rows, cols, ntaps, shift0, _p(seg_lo, torch.int32), _p(seg_hi, torch.int32),
+                                        _p(out, torch.int16), _stream()))
+    return out
+
+
+def gemm_tn_planes(ap_t, bp_t, out, m):
+    """out[n, k] += sum_m a[m, n] * b[m, k] from transposed planes; out [n, k] (row stride free) or tap-major [ntaps, n, k / ntaps] (contiguous)."""
+    n = ap_t.shape[0]
+    k = bp_t.shape[0]
+    if out.dim() == 3:
+        ntaps, n2, kk = out.shape
+        assert n2 == n and ntaps * kk == k and out.is_contiguous()
+        check(_lib.load().fcl_gemm_tn_planes(_p(ap_t, torch.int16), _p(bp_t, torch.int16), out.data_ptr(), kk, m, n, k, kk, n * kk, _stream()))
+    else:
+        assert out.shape == (n, k) and out.stride(1) == 1
+        check(_lib.load().fcl_gemm_tn_planes(_p(ap_t, torch.int16), _p(bp_t, torch.int16), out.data_ptr(), out.stride(0), m, n, k, 0, 0, _stream()))
     return out
 
 

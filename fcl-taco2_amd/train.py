@@ -184,6 +184,9 @@ def get_parser():
     p.add_argument("--num-iter-processes", default=0, type=int, help="loader processes (npy reads, converter, host index maps); 0 = inline, "
                    "which keeps the loop GPU-bound at the shipped batch sizes (converter + maps ~4 ms per batch)")
     p.add_argument("--host-threads", default=4, type=int, help="torch intra-op CPU threads of the training process (see train())")
+    p.add_argument("--use-amp", default=False, type=lambda s: str(s).lower() in ("1", "true", "yes"),
+                   help="mixed precision as in the shipped recipes (teacher_parser.py:306, student_model_training.sh:29: apex O1): here bf16-rounded GEMM "
+                        "operands with fp32 accumulation, fp32 master weights / norms / losses / Adam, no loss scaling (TrainEngine(amp='bf16'))")
     p.add_argument("--use-fe-condition", default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
     p.add_argument("--append-position", default=True, type=lambda s: str(s).lower() in ("1", "true", "yes"))
     for k in ("output", "encoder", "decoder", "prosody"):
@@ -248,13 +251,14 @@ def train(argv=None):
         for p_ in teacher.parameters():
             p_.requires_grad = False  # tts_distill.py:397-398
         teacher.train()  # the reference never puts the teacher in eval mode
-        teng = TrainEngine(teacher)
+        teng = TrainEngine(teacher, amp="bf16" if args.use_amp else None)
         model = cls(idim, odim, args, args, get_model_conf(args.teacher_conf)[2])
     else:
         teng = None
         model = cls(idim, odim, args, args)
     model = model.to(dev)
-    eng = TrainEngine(model, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip, accum_grad=args.accum_grad, seed=args.seed * 1000 + rank)
+    eng = TrainEngine(model, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip, accum_grad=args.accum_grad, seed=args.seed * 1000 + rank,
+                      amp="bf16" if args.use_amp else None)
     epoch0, iteration = 0, 0
     if args.resume:
         snap = torch.load(args.resume, map_location="cpu", weights_only=False)

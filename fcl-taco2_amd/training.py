@@ -20,6 +20,7 @@ rows sorted by duration (descending), cell (t, m) at offset[t] + m, so the live 
 Gradients, Adam moments and (re-pointed) parameters live in three flat buffers ordered by when backward finishes them, so the optimizer is one
 launch and the all-reduce runs over contiguous buckets while backward is still producing the later ones.
 """
+import os
 import zlib
 
 import numpy as np
@@ -309,8 +310,14 @@ class LossReport(dict):
             self._extra[k] = v
 
 
+_DW_PLANES_MIN = int(os.environ.get("FCL_DW_PLANES_MIN", str(1 << 20)))  # output elements from which a weight gradient runs on transposed planes
+
+
 class TrainEngine(object):
-    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None, overlap_dw=True):
+    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None, overlap_dw=True, amp=None):
+        """amp: None = fp32-equivalent arithmetic; "bf16" = the mixed-precision form of the reference's `--use-amp True` recipe (apex O1,
+        tts.py:414-416) with bf16 in place of fp16: the big-tile forward / input-gradient / weight-gradient GEMMs take bf16-rounded operands and
+        accumulate in fp32 (ops.gemm_mode), master weights, norms, losses, gradients and Adam stay fp32, no loss scaling is needed."""
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise RuntimeError("fcl-taco2_amd: TrainEngine needs the model on a GPU (no CPU fallback)")
@@ -337,6 +344,9 @@ class TrainEngine(object):
         self.B = dict(model.named_buffers())
         self.lr, self.eps, self.betas, self.grad_clip, self.accum_grad = lr, eps, betas, grad_clip, int(accum_grad)
         self.forward_count, self.seed = 0, int(seed)
+        if amp not in (None, "bf16"):
+            raise ValueError("amp must be None or 'bf16'")
+        self.amp = amp
         self.update_calls = 0  # optimizer_step() calls (host side; no sync)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)  # APPLIED updates = torch.optim.Adam's per-parameter `step`
         self.status = ops.status_word(self.dev)  # shared per device: a failure reported by the frozen teacher's kernels stops this update too
@@ -436,6 +446,27 @@ class TrainEngine(object):
         with torch.cuda.stream(self.side):
             fn()
         self._dw_keep.append(fn)
+
+    def _dw_gemm(self, dz, pairs, taps=None):
+        """Weight gradients out += dz^T x for every (x, out) in pairs (dz [m, n], x [m, k], out [n, k]); taps = (ksz, seg_lo, seg_hi): one x and a
+        tap-major out [ksz, n, k] (Conv1d).  Large outputs run on transposed planes (fcl_pack_planes_t + fcl_gemm_tn_planes: the LDS-DMA GEMM,
+        2-3x the rate of the fp32-operand kernel; the transposing pass over dz is shared by the pairs), small ones on fcl_gemm_tn_fwd, whose
+        per-launch cost is lower than the two extra passes."""
+        m, n = dz.shape
+        outs = sum(out.numel() for _, out in pairs)
+        if ops.planes_enabled() and outs >= _DW_PLANES_MIN and all(x.shape[1] % 4 == 0 for x, _ in pairs) and m >= 512:
+            ap = ops.pack_planes_t(dz)
+            for x, out in pairs:
+                if taps is None:
+                    ops.gemm_tn_planes(ap, ops.pack_planes_t(x), out, m)
+                else:
+                    ops.gemm_tn_planes(ap, ops.pack_planes_t(x, ntaps=taps[0], shift0=-((taps[0] - 1) // 2), seg_lo=taps[1], seg_hi=taps[2]), out, m)
+            return
+        for x, out in pairs:
+            if taps is None:
+                ops.gemm_tn(dz, x, out)
+            else:
+                ops.gemm_tn_taps(dz, x, out, -((taps[0] - 1) // 2), seg_lo=taps[1], seg_hi=taps[2])  # all taps in one launch
 
     def _join_dw(self):
         if self.side is not None and self._dw_keep:
@@ -562,7 +593,7 @@ class TrainEngine(object):
                 ops.colsum(dz, G[pre + ".1.bias"])
                 ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
             dwp = torch.zeros(k, cout, cin, device=self.dev)
-            ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
+            self._dw_gemm(dz, [(cc["x"], dwp)], taps=(k, cc["lo"], cc["hi"]))
             ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
 
         self._dw(dw)
@@ -594,7 +625,7 @@ class TrainEngine(object):
         def dw():
             ops.colsum(dz, G[pre + ".bias"])
             dwp = torch.zeros(k, cout, cin, device=self.dev)
-            ops.gemm_tn_taps(dz, cc["x"], dwp, -((k - 1) // 2), seg_lo=cc["lo"], seg_hi=cc["hi"])  # all taps in one launch
+            self._dw_gemm(dz, [(cc["x"], dwp)], taps=(k, cc["lo"], cc["hi"]))
             ops.unpack_conv1d_grad(dwp, G[pre + ".weight"])
 
         self._dw(dw)
@@ -971,15 +1002,13 @@ class TrainEngine(object):
         g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
 
         def dw_cells():  # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
-            ops.gemm_tn(dg1_all, c.h0_all, G["dec.lstm.1.cell.weight_ih"])
-            ops.gemm_tn(dg1_all, S1[3], G["dec.lstm.1.cell.weight_hh"])
+            self._dw_gemm(dg1_all, [(c.h0_all, G["dec.lstm.1.cell.weight_ih"]), (S1[3], G["dec.lstm.1.cell.weight_hh"])])
             for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
                 db = torch.zeros(1, 4 * U, device=dev)
                 ops.colsum(dg, db.reshape(-1))
                 ops.add2d(G["dec.lstm.%d.cell.bias_ih" % l].reshape(1, -1), db)
                 ops.add2d(G["dec.lstm.%d.cell.bias_hh" % l].reshape(1, -1), db)
-            ops.gemm_tn(dg0_all, S0[3], G["dec.lstm.0.cell.weight_hh"])
-            ops.gemm_tn(dg0_all, c.p1d, g_ih0[:, C : C + Pn])
+            self._dw_gemm(dg0_all, [(S0[3], G["dec.lstm.0.cell.weight_hh"]), (c.p1d, g_ih0[:, C : C + Pn])])
             dw0_pos4 = torch.zeros(4 * U, 4, device=dev)
             ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
             ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
@@ -1062,7 +1091,7 @@ class TrainEngine(object):
 
     def knowledge(self, batch, mode="train", masks=None):
         """Forward only: the frozen KD teacher's 5-tuple (tts_distill.py:159; the reference leaves the teacher in train mode)."""
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), ops.gemm_mode(self.amp):
             c = self._ctx(batch, mode, masks, save=False)
             self._forward(c, batch)
             return self._knowledge(c)
@@ -1074,7 +1103,7 @@ class TrainEngine(object):
         gradients local (optimizer_step() then averages nothing)."""
         if self.role == "student" and teacher_knowledge is None:
             raise ValueError("the student step needs teacher_knowledge (tts_distill.py:159-161)")
-        with torch.cuda.device(self.dev):
+        with torch.cuda.device(self.dev), ops.gemm_mode(self.amp):
             c = self._ctx(batch, mode, masks, reduce=reduce)
             self._forward(c, batch)
             self._losses(c, teacher_knowledge)

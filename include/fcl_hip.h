@@ -35,8 +35,19 @@ enum { FCL_DROP_NONE = 0, FCL_DROP_MASK = 1, FCL_DROP_RNG = 2 };
  * losses (one 4-byte copy) and raises. */
 enum { FCL_STATUS_GROUP_TIMEOUT = 1 /* a cooperating-workgroup BiLSTM kernel gave up waiting for a group member: its outputs are partial */ };
 
+/* Arithmetic of the MFMA contractions (Linear / Conv1d / LSTM-step GEMMs and the weight-gradient GEMM) launched by the CALLING THREAD:
+ *   FCL_GEMM_F32  (default) fp32-equivalent: both operands split into bf16 hi + lo, three MFMAs per product (or exact fp32 MFMAs under FCL_PRECISION=0);
+ *   FCL_GEMM_BF16 the autocast form of mixed-precision training (the reference trains under apex AMP O1, tts.py:414-416; bf16 replaces its fp16 and
+ *                 needs no loss scaling): both operands ROUNDED to bf16 (round to nearest even = the hi plane), one MFMA per product, fp32
+ *                 accumulation, fp32 outputs.  Everything that is not a big-tile contraction keeps fp32: norms, activations, losses, the
+ *                 optimizer, and the latency-bound small-row kernels (BiLSTM recurrences, decoder steps with few live rows).
+ * The mode is thread-local, like torch.autocast.  Returns FCL_ERR_INVALID for an unknown mode, or for FCL_GEMM_BF16 under FCL_PRECISION=0. */
+enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
+
 const char* fcl_last_error(void);
 int fcl_version(void);
+int fcl_set_gemm_mode(int mode);
+int fcl_get_gemm_mode(void);
 
 /* ---- plan-time weight packing (run once per checkpoint) ------------------------------------------ */
 
@@ -271,6 +282,19 @@ int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, 
 /* The same for NTAPS consecutive shifts in one launch: c + j*c_tap_stride gets shift0 + j (all taps of a Conv1d weight gradient, tap-major). */
 int fcl_gemm_tn_taps_fwd(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift0, int ntaps,
                          size_t c_tap_stride, const int32_t* seg_lo, const int32_t* seg_hi, fcl_stream_t stream);
+/* The same contraction on pre-split operands: the LDS-DMA GEMM kernels (fcl_linear_planes_fwd's) with the roles of rows and columns exchanged.
+ * fcl_pack_planes_t writes TRANSPOSED planes (P32T) of x [rows, cols]: one plane row per column, ceil(rows/32) lines of 32 consecutive rows
+ * (hi | lo, zero past `rows`); with ntaps > 1 plane row t*cols + c holds column c read at row m + shift0 + t (zero outside
+ * [seg_lo[m], seg_hi[m]), or outside [0, rows) when the bounds are NULL): the shifted inputs of all taps of a Conv1d weight gradient.
+ * out: ntaps * cols * ceil(rows/32) * 64 uint16, 128-byte aligned.
+ * fcl_gemm_tn_planes: c[n_, k_] += sum_m a[m, n_] * b[m, k_] with ap_t = P32T of a [m, n] and bp_t = P32T of b [m, k] (k = ntaps * cols for
+ * a tap-stacked b).  The contraction is split over workgroup slices and accumulated with fp32 atomics (the caller zeroes c once per update).
+ * nblk > 0: output column k_ lands at c + (k_ / nblk) * blk_stride + n_ * ldc + k_ % nblk (nblk = Cin, blk_stride = Cout * Cin: tap-major
+ * [ntaps, Cout, Cin] like fcl_gemm_tn_taps_fwd); nblk = 0: plain [n, k] with row stride ldc.  Honours fcl_set_gemm_mode. */
+int fcl_pack_planes_t(const float* x, int ld, int rows, int cols, int ntaps, int shift0, const int32_t* seg_lo, const int32_t* seg_hi, uint16_t* out,
+                      fcl_stream_t stream);
+int fcl_gemm_tn_planes(const uint16_t* ap_t, const uint16_t* bp_t, float* c, int ldc, int m, int n, int k, int nblk, size_t blk_stride,
+                       fcl_stream_t stream);
 /* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm)
  * | x*(y - b[c])*g[c] (mode 3: b = batch mean, g = invstd: gamma gradient of a train-mode BatchNorm). */
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream);

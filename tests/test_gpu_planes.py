@@ -264,3 +264,104 @@ def test_derived_forms_batch_is_bit_exact_and_follows_parameter_updates(ops):
     assert forms.table is not None and forms.table[1] == 8
     assert {k: tuple(None if t is None else t.data_ptr() for t in v) for k, v in second.items()} == ptrs
     check(second)
+
+
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 96, 160), (2501, 1024, 256), (37, 40, 72)])
+def test_bf16_gemm_mode_rounds_both_operands_and_accumulates_in_fp32(ops, m, n, k):
+    """ops.gemm_mode("bf16") (fcl_set_gemm_mode: the autocast form for --use-amp training): the planes GEMM, the fp32-operand GEMM and the
+    weight-gradient GEMM equal the fp64 product of the bf16-ROUNDED operands (tolerance = fp32 accumulation only), differ from the fp32-equivalent
+    result at bf16 level, and the mode is restored on exit."""
+    from fcl_taco2_amd import _lib
+
+    rng = np.random.RandomState(m + n)
+    x, w, b = dev(rnd(rng, m, k)), dev(rnd(rng, n, k)), dev(rnd(rng, n))
+    ref = _bf16_round(x) @ _bf16_round(w).t() + b.double()
+    exact = x.double() @ w.double().t() + b.double()
+    scale = float(exact.abs().max())
+    xp, wp = ops.pack_planes(x), ops.pack_planes(w)
+    with ops.gemm_mode("bf16"):
+        assert _lib.load().fcl_get_gemm_mode() == _lib.GEMM_BF16
+        y_p = ops.linear_planes(xp, wp, n, k, b, want_f32=True, want_planes=False)[0]
+        y_f = ops.linear(x, w, b)
+    assert _lib.load().fcl_get_gemm_mode() == _lib.GEMM_F32
+    for y in (y_p, y_f):
+        assert max_abs(y.double(), ref) < 2e-5 * scale
+        assert max_abs(y.double(), exact) > 1e-4 * scale  # really the rounded operands
+    y3 = ops.linear_planes(xp, wp, n, k, b, want_f32=True, want_planes=False)[0]  # back to the fp32-equivalent split
+    assert max_abs(y3.double(), exact) < 2e-5 * scale
+    # weight gradient: c[n, k] += sum_m a[m, n] * b[m, k]
+    dy = dev(rnd(rng, m, n))
+    g = torch.zeros(n, k, device=DEV)
+    with ops.gemm_mode("bf16"):
+        ops.gemm_tn(dy, x, g)
+    gref = _bf16_round(dy).t() @ _bf16_round(x)
+    assert max_abs(g.double(), gref) < 3e-5 * float(gref.abs().max())
+
+
+def test_bf16_gemm_mode_lstm_step_on_planes(ops):
+    """The LDS-DMA LSTM-step kernel under ops.gemm_mode("bf16") = the cell evaluated in fp64 on bf16-rounded x, h and weights."""
+    import ctypes as C
+
+    from fcl_taco2_amd import _lib
+
+    rng = np.random.RandomState(11)
+    m, u, k0 = 700, 256, 256
+    x, h = dev(rnd(rng, m, k0)), dev(0.5 * rnd(rng, m, u))
+    c0 = dev(0.5 * rnd(rng, m, u))
+    w_ih, w_hh, b = dev(0.1 * rnd(rng, 4 * u, k0)), dev(0.1 * rnd(rng, 4 * u, u)), dev(0.1 * rnd(rng, 4 * u))
+    gates = _bf16_round(x) @ _bf16_round(w_ih).t() + _bf16_round(h) @ _bf16_round(w_hh).t() + b.double()
+    i, f, g, o = gates.split(u, dim=1)
+    c_ref = torch.sigmoid(f) * c0.double() + torch.sigmoid(i) * torch.tanh(g)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    a = _lib.LstmStep()
+    a.nterms, a.M, a.U = 2, m, u
+    planes = [ops.pack_planes(t) for t in (x, w_ih, h, w_hh)]
+    a.term[0] = _lib.GemmTerm(x.data_ptr(), w_ih.data_ptr(), k0, k0, k0, 0, None, None, planes[0].data_ptr(), planes[1].data_ptr(), k0 // 32, k0 // 32)
+    a.term[1] = _lib.GemmTerm(h.data_ptr(), w_hh.data_ptr(), u, u, u, 0, None, None, planes[2].data_ptr(), planes[3].data_ptr(), u // 32, u // 32)
+    a.bias = b.data_ptr()
+    c_io, h_out = c0.clone(), torch.empty(m, u, device=DEV)
+    a.h_in, a.h_out, a.c, a.zoneout = h.data_ptr(), h_out.data_ptr(), c_io.data_ptr(), 0.0
+    with ops.gemm_mode("bf16"):
+        _lib.check(_lib.load().fcl_lstm_step_fwd(C.byref(a), ops._stream()))
+    torch.cuda.synchronize()
+    assert max_abs(h_out.double(), h_ref) < 1e-5 and max_abs(c_io.double(), c_ref) < 1e-5
+    exact = x.double() @ w_ih.double().t() + h.double() @ w_hh.double().t() + b.double()
+    assert float((gates - exact).abs().max()) > 1e-3  # the rounding is visible at gate level
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 64, 96), (2501, 256, 128), (333, 40, 36), (4100, 1024, 256)])
+def test_weight_gradient_gemm_on_transposed_planes(ops, m, n, k):
+    """fcl_pack_planes_t + fcl_gemm_tn_planes: c[n, k] += sum_m a[m, n] b[m, k] equals the fp64 product (fp32-equivalent), accumulates into c,
+    handles contraction lengths that are not multiples of 32 and outputs that do not fill a tile; strided output rows."""
+    rng = np.random.RandomState(m)
+    a, b = dev(rnd(rng, m, n)), dev(rnd(rng, m, k))
+    ref = a.double().t() @ b.double()
+    base = dev(rnd(rng, n, k + 8))
+    out = base.clone()
+    ops.gemm_tn_planes(ops.pack_planes_t(a), ops.pack_planes_t(b), out[:, 4 : 4 + k], m)
+    torch.cuda.synchronize()
+    scale = float(ref.abs().max())
+    assert max_abs((out[:, 4 : 4 + k] - base[:, 4 : 4 + k]).double(), ref) < 3e-5 * scale
+    assert torch.equal(out[:, :4], base[:, :4]) and torch.equal(out[:, 4 + k :], base[:, 4 + k :])
+
+
+def test_conv_weight_gradient_taps_on_transposed_planes(ops):
+    """All taps of a Conv1d weight gradient in one GEMM: the shifted, segment-masked inputs stacked as plane rows; tap-major [k, Cout, Cin] output
+    equal to fcl_gemm_tn_taps_fwd's."""
+    rng = np.random.RandomState(3)
+    lens = [70, 41, 5, 1, 64]
+    m, cin, cout, ksz = sum(lens), 48, 72, 5
+    lo = np.concatenate([np.full(n, s, np.int32) for n, s in zip(lens, np.cumsum([0] + lens[:-1]))])
+    hi = np.concatenate([np.full(n, s + n, np.int32) for n, s in zip(lens, np.cumsum([0] + lens[:-1]))])
+    dz, x = dev(rnd(rng, m, cout)), dev(rnd(rng, m, cin))
+    lo_d, hi_d = dev(lo), dev(hi)
+    want = torch.zeros(ksz, cout, cin, device=DEV)
+    ops.gemm_tn_taps(dz, x, want, -2, seg_lo=lo_d, seg_hi=hi_d)
+    got = torch.zeros(ksz, cout, cin, device=DEV)
+    ops.gemm_tn_planes(ops.pack_planes_t(dz), ops.pack_planes_t(x, ntaps=ksz, shift0=-2, seg_lo=lo_d, seg_hi=hi_d), got, m)
+    torch.cuda.synchronize()
+    assert max_abs(got, want) < 3e-5 * float(want.abs().max())
