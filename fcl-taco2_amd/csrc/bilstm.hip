@@ -458,33 +458,48 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     }
     // algo 1: per-step launches
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, s, hbuf, (long long)6 * b * h, 0.f);
-    for (int d = 0; d < 2; ++d) {
+    auto step_args = [&](int d, int st, int cur) {
         float* hp[2] = {hbuf + (size_t)d * b * h, hbuf + (size_t)(2 + d) * b * h};
+        const int tt = d ? t - 1 - st : st;
+        LstmStepArgs a = {};
+        a.term[0] = GemmTerm{hp[cur], d ? w_hh_r : w_hh_f, h, h, h, 0};
+        a.nterms = 1;
+        a.M = b;
+        a.U = h;
+        a.G = d ? gx_r : gx_f;
+        a.g_row_mul = t;
+        a.g_row_add = tt;
+        a.step = tt;
+        a.h_in = hp[cur];
+        a.h_out = hp[cur ^ 1];
+        a.c = cbuf + (size_t)d * b * h;
+        a.zoneout = 0.f;
+        a.row_len = lens;
+        a.out2 = out;
+        a.out2_row_mul = t;
+        a.out2_row_add = tt;
+        a.ld2 = 2 * h;
+        a.out2_col_off = d * h;
+        return a;
+    };
+    // the two directions are independent recurrences: while a step is small enough for the wave-per-gate kernel both go out in ONE launch per time
+    // step (T dependent launches instead of 2T)
+    static const int pair = tunable("BILSTM_PAIR", 1);
+    if (pair && lstm_step_is_small(b, h)) {
         int cur = 0;
         for (int st = 0; st < t; ++st) {
-            const int tt = d ? t - 1 - st : st;
-            LstmStepArgs a = {};
-            a.term[0] = GemmTerm{hp[cur], d ? w_hh_r : w_hh_f, h, h, h, 0};
-            a.nterms = 1;
-            a.M = b;
-            a.U = h;
-            a.G = d ? gx_r : gx_f;
-            a.g_row_mul = t;
-            a.g_row_add = tt;
-            a.step = tt;
-            a.h_in = hp[cur];
-            a.h_out = hp[cur ^ 1];
-            a.c = cbuf + (size_t)d * b * h;
-            a.zoneout = 0.f;
-            a.row_len = lens;
-            a.out2 = out;
-            a.out2_row_mul = t;
-            a.out2_row_add = tt;
-            a.ld2 = 2 * h;
-            a.out2_col_off = d * h;
-            int rc = launch_lstm_step(a, s);
+            int rc = launch_lstm_small_pair(step_args(0, st, cur), step_args(1, st, cur), s);
             if (rc) return rc;
             cur ^= 1;
+        }
+    } else {
+        for (int d = 0; d < 2; ++d) {
+            int cur = 0;
+            for (int st = 0; st < t; ++st) {
+                int rc = launch_lstm_step(step_args(d, st, cur), s);
+                if (rc) return rc;
+                cur ^= 1;
+            }
         }
     }
     return out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0;  // the per-step path writes fp32 only: split once at the end

@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
 // ---- small-M LSTM step: wave g owns gate g of 16 units x 16 rows ------------------------------------
 constexpr int SMALL_KC = 512;  // K chunk resident in LDS
 
-__global__ __launch_bounds__(256) void lstm_small_kernel(const LstmStepArgs a) {
+__device__ __forceinline__ void lstm_small_body(const LstmStepArgs& a) {
     __shared__ __attribute__((aligned(16))) float A_l[16 * (SMALL_KC + 4)];
     __shared__ float g_l[4][16][17];
     const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
@@ -739,6 +739,15 @@ __global__ __launch_bounds__(256) void lstm_small_kernel(const LstmStepArgs a) {
     const CellIn ci = cell_prefetch(a, m, uu);
     const float pre[4] = {g_l[0][row][uc], g_l[1][row][uc], g_l[2][row][uc], g_l[3][row][uc]};
     cell_finish(a, m, uu, pre, ci);
+}
+
+__global__ __launch_bounds__(256) void lstm_small_kernel(const LstmStepArgs a) { lstm_small_body(a); }
+
+// Two independent steps of the same shape in one launch (blockIdx.z picks the problem): the forward and the backward direction of a BiLSTM time
+// step (bilstm.hip algo 1) -- half the dependent launches of the per-step path.
+__global__ __launch_bounds__(256) void lstm_small_pair_kernel(const LstmStepArgs a0, const LstmStepArgs a1) {
+    if (blockIdx.z == 0) lstm_small_body(a0);
+    else lstm_small_body(a1);
 }
 
 // ---- weights-stationary LSTM step (U <= 256-class models: the 64 x Kt weight slice of 16 units lives in LDS) ----
@@ -904,6 +913,15 @@ int launch_lstm_small(const LstmStepArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(lstm_small_kernel, grid, dim3(256), 0, s, a);
     }
     return check_hip(hipGetLastError(), "lstm_small launch");
+}
+
+int launch_lstm_small_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s) {
+    double ksum = 0;
+    for (int i = 0; i < a0.nterms; ++i) ksum += a0.term[i].K;
+    dim3 grid((a0.U + 15) / 16, (a0.M + 15) / 16, 2);
+    ProfScope ps("lstm_small_pair_kernel", 2.0 * 2.0 * a0.M * 4.0 * a0.U * ksum, 2 * a0.M, s);
+    hipLaunchKernelGGL(lstm_small_pair_kernel, grid, dim3(256), 0, s, a0, a1);
+    return check_hip(hipGetLastError(), "lstm_small_pair launch");
 }
 
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {

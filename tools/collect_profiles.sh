@@ -15,3 +15,12 @@ python3 tools/pmc_summary.py $OUT/pmc_write/w_counter_collection.csv > $OUT/pmc_
 python3 tools/pmc_multi.py $OUT/pmc_sq/s_counter_collection.csv > $OUT/pmc_sq_counters.csv 2>/dev/null
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq   # raw per-dispatch rows are large; the summaries are what gets committed
 ls -la $OUT $OUT/graph4 | head -30
+# training workloads: bench JSON (with the CPU baseline) in both arithmetic modes, kernel stats of the KD and teacher steps
+for w in kd_step teacher_step; do
+  python3 bench.py --workload $w > $OUT/bench_$w.json 2> /dev/null
+  python3 bench.py --workload $w --amp bf16 --no-cpu-baseline > $OUT/bench_${w}_bf16.json 2> /dev/null
+  rocprofv3 --kernel-trace --stats -d $OUT/$w -o t --output-format csv -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+done
+python3 bench.py --workload forward_tf > $OUT/bench_forward_tf.json 2> /dev/null
+python3 bench.py --batch 64 --no-cpu-baseline > $OUT/bench_b64.json 2> /dev/null
+python3 bench.py --model teacher --no-cpu-baseline > $OUT/bench_teacher_synthesis.json 2> /dev/null
