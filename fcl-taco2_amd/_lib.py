@@ -76,6 +76,11 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
+class PwgLayer(C.Structure):  # fcl_pwg_layer_t
+    _fields_ = [("m", C.c_int64), ("r", C.c_int32), ("aux", C.c_int32), ("ksize", C.c_int32), ("dilation", C.c_int32), ("first_layer", C.c_int32)] + [
+        (n, _P) for n in ("seg_lo", "seg_hi", "x", "xp", "cp", "w_conv_p", "b_conv", "w_aux_p", "w_os_p", "b_os", "skips", "z", "gp", "o")]
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
 
@@ -129,6 +134,11 @@ SIGNATURES = {
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "fcl_pack_planes_t": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "fcl_gemm_tn_planes": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _Z, _P]),
+    "fcl_pwg_upsample_stage": (_I, [_P, _P, _P, C.c_int64, _I, _I, _P, _P, _P, _I, _P]),
+    "fcl_pwg_noise": (_I, [_P, C.c_int64, C.c_uint32, _P]),
+    "fcl_pwg_first_conv": (_I, [_P, _P, _P, _P, _P, C.c_int64, _I, _P]),
+    "fcl_pwg_layer_fwd": (_I, [_P, _P]),
+    "fcl_pwg_last_fwd": (_I, [_P, _F, _P, _P, _P, _F, _P, _P, _P, C.c_int64, _I, _P]),
     "fcl_derive_blocks": (_I, [_I, _I, _I]),
     "fcl_derive_batch": (_I, [_P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),

@@ -1,0 +1,219 @@
+// pwg.hip — Parallel WaveGAN generator (BASELINE configs[4]: the stage the reference shells out to,
+// inference_student.sh:20-23).  gfx950 only.  Rows are SAMPLES (time-major, utterances concatenated, zero padding at utterance edges through
+// the GEMM's segment bounds); channels are the contiguous dimension, so every convolution of the residual stack is a K-term of the pre-split
+// operand GEMM (gemm_planes.hip):
+//     z[M, 128]  = x[t-d] W_0^T + x[t] W_1^T + x[t+d] W_2^T + c_up[t] W_aux^T + b          (4 terms: K = 3 x 64 + 80)
+//     g[M, 64]   = tanh(z[:, :64]) * sigmoid(z[:, 64:])                                     (pwg_gate_kernel, writes planes)
+//     o[M, 128]  = g [W_out ; W_skip]^T + [b_out ; b_skip]                                  (1 term: K = 64)
+//     x          = (o[:, :64] + x) * sqrt(0.5) ;  skips += o[:, 64:]                        (pwg_resid_kernel, writes fp32 + planes)
+// The upsampling network (nearest-neighbour stretch + 1 x (2s+1) smoothing, four times) and the 1 -> 64 / 64 -> 1 end convolutions are
+// HBM-bound row kernels.  Published architecture: kan-bayashi/ParallelWaveGAN, ParallelWaveGANGenerator (v1, LJSpeech); see oracle/pwg_oracle.py.
+#include <algorithm>
+
+#include "fcl_common.h"
+
+namespace fcl {
+
+typedef unsigned short u16;
+
+// ---- one stage of UpsampleNetwork: Stretch2d(scale, nearest) + Conv2d(1, 1, (1, 2*scale+1), padding (0, scale), no bias), per channel.
+// in: [frames * rate_in rows, C]; out: [frames * rate_in * scale rows, C] (fp32 and / or planes with ldp lines per row, zero past C).
+// A row's utterance comes from its frame: frame_utt[frame], bounds utt_off[u] .. utt_off[u+1] (in frames): the zero padding of the smoothing
+// convolution applies at UTTERANCE edges, as when each utterance is upsampled on its own.
+__global__ __launch_bounds__(256) void pwg_upsample_stage_kernel(const float* __restrict__ in, const int* __restrict__ frame_utt,
+                                                                 const int* __restrict__ utt_off, long long rows_out, int rate_in, int scale,
+                                                                 const float* __restrict__ w, float* __restrict__ out, u16* __restrict__ out_p, int ldp,
+                                                                 int C) {
+    const int cpad = out_p ? ldp * 32 : C;
+    const long long total = rows_out * cpad;
+    const int rate_out = rate_in * scale;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / cpad;
+        const int c = (int)(i - r * cpad);
+        float acc = 0.f;
+        if (c < C) {
+            const int u = frame_utt[r / rate_out];
+            const long long lo = (long long)utt_off[u] * rate_out, hi = (long long)utt_off[u + 1] * rate_out;
+            for (int j = -scale; j <= scale; ++j) {
+                const long long q = r + j;
+                if (q < lo || q >= hi) continue;
+                acc += w[j + scale] * in[(q / scale) * C + c];  // q / scale: row of the stage input (nearest-neighbour stretch); utterances start on multiples of scale
+            }
+            if (out) out[r * C + c] = acc;
+        }
+        if (out_p) store_p32(out_p + (size_t)r * ldp * 64, ldp, 0, c, acc);
+    }
+}
+
+// first_conv: x[m, ch] = w[ch] * z[m] + b[ch]  (Conv1d1x1(1 -> R))
+__global__ __launch_bounds__(256) void pwg_first_conv_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b,
+                                                             float* __restrict__ x, u16* __restrict__ xp, long long M, int R) {
+    const long long total = M * R;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / R;
+        const int ch = (int)(i - m * R);
+        const float v = w[ch] * z[m] + b[ch];
+        x[i] = v;
+        store_p32(xp + (size_t)m * (R >> 5) * 64, R >> 5, 0, ch, v);
+    }
+}
+
+// g = tanh(z[:, :H]) * sigmoid(z[:, H:])  -> planes [M, H]
+__global__ __launch_bounds__(256) void pwg_gate_kernel(const float* __restrict__ z, u16* __restrict__ gp, long long M, int H) {
+    const long long total = M * H;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / H;
+        const int ch = (int)(i - m * H);
+        const float a = z[m * 2 * H + ch], b = z[m * 2 * H + H + ch];
+        const float v = tanhf(a) * (1.0f / (1.0f + __expf(-b)));
+        store_p32(gp + (size_t)m * (H >> 5) * 64, H >> 5, 0, ch, v);
+    }
+}
+
+// x = (o[:, :R] + x) * sqrt(0.5) (fp32 + planes) ; skips += o[:, R:]
+__global__ __launch_bounds__(256) void pwg_resid_kernel(const float* __restrict__ o, float* __restrict__ x, u16* __restrict__ xp, float* __restrict__ skips,
+                                                        long long M, int R, int first) {
+    const long long total = M * R;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / R;
+        const int ch = (int)(i - m * R);
+        const float v = (o[m * 2 * R + ch] + x[i]) * 0.70710678118654752440f;
+        x[i] = v;
+        store_p32(xp + (size_t)m * (R >> 5) * 64, R >> 5, 0, ch, v);
+        const float s = o[m * 2 * R + R + ch];
+        skips[i] = first ? s : skips[i] + s;
+    }
+}
+
+// y = relu(skips * scale) -> planes [M, S]
+__global__ __launch_bounds__(256) void pwg_relu_scale_kernel(const float* __restrict__ skips, float scale, u16* __restrict__ yp, long long M, int S) {
+    const long long total = M * S;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / S;
+        const int ch = (int)(i - m * S);
+        store_p32(yp + (size_t)m * (S >> 5) * 64, S >> 5, 0, ch, fmaxf(skips[i] * scale, 0.f));
+    }
+}
+
+// wav[m] = sum_ch relu(h[m, ch]) * w[ch] + b   (last ReLU + Conv1d1x1(S -> 1)); one wave per 4 rows of S = 64 channels
+__global__ __launch_bounds__(256) void pwg_out_kernel(const float* __restrict__ h, const float* __restrict__ w, float b, float* __restrict__ wav, long long M,
+                                                      int S) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    for (long long m = wave; m < M; m += nwaves) {
+        float acc = 0.f;
+        for (int ch = lane; ch < S; ch += 64) acc += fmaxf(h[m * S + ch], 0.f) * w[ch];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) wav[m] = acc + b;
+    }
+}
+
+// z ~ N(0, 1): Box-Muller on two hashed 24-bit uniforms per element (counter-based: element i of a given seed is reproducible on any grid)
+__global__ __launch_bounds__(256) void pwg_noise_kernel(float* __restrict__ z, long long n, unsigned int seed) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned int lo = (unsigned int)i, hi = (unsigned int)(i >> 32);
+        const unsigned int h1 = hash_u32(lo ^ hash_u32(seed ^ (hi * 0x9E3779B9u))), h2 = hash_u32(h1 ^ 0x85EBCA6Bu ^ lo);
+        const float u1 = ((h1 >> 8) + 1) * (1.0f / 16777216.0f), u2 = (h2 >> 8) * (1.0f / 16777216.0f);  // u1 in (0, 1]
+        z[i] = sqrtf(-2.0f * __logf(u1)) * __cosf(6.28318530717958647692f * u2);
+    }
+}
+
+static unsigned grid_1d(long long n, int per_block) {
+    long long b = (n + per_block - 1) / per_block;
+    return (unsigned)std::min<long long>(std::max<long long>(b, 1), 1 << 20);
+}
+
+}  // namespace fcl
+
+using namespace fcl;
+
+extern "C" {
+
+int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int32_t* utt_off, int64_t frames, int rate_in, int scale, const float* w,
+                           float* out, uint16_t* out_p, int c, fcl_stream_t stream) {
+    FCL_REQUIRE(in && frame_utt && utt_off && w && (out || out_p) && frames > 0 && rate_in >= 1 && scale >= 1 && c > 0, FCL_ERR_INVALID,
+                "pwg_upsample_stage: bad arguments");
+    FCL_REQUIRE((reinterpret_cast<uintptr_t>(out_p) & 127u) == 0, FCL_ERR_ALIGN, "pwg_upsample_stage: planes must be 128-byte aligned");
+    const long long rows_out = (long long)frames * rate_in * scale;
+    const int ldp = (c + 31) / 32;
+    hipLaunchKernelGGL(pwg_upsample_stage_kernel, dim3(grid_1d(rows_out * (out_p ? ldp * 32 : c), 256)), dim3(256), 0, (hipStream_t)stream, in, frame_utt, utt_off,
+                       rows_out, rate_in, scale, w, out, out_p, ldp, c);
+    return check_hip(hipGetLastError(), "pwg_upsample_stage");
+}
+
+int fcl_pwg_noise(float* z, int64_t n, uint32_t seed, fcl_stream_t stream) {
+    FCL_REQUIRE(z && n > 0, FCL_ERR_INVALID, "pwg_noise: bad arguments");
+    hipLaunchKernelGGL(pwg_noise_kernel, dim3(grid_1d(n, 1024)), dim3(256), 0, (hipStream_t)stream, z, (long long)n, seed);
+    return check_hip(hipGetLastError(), "pwg_noise");
+}
+
+int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x, uint16_t* xp, int64_t m, int r, fcl_stream_t stream) {
+    FCL_REQUIRE(z && w && b && x && xp && m > 0 && r > 0 && (r & 31) == 0, FCL_ERR_INVALID, "pwg_first_conv: bad arguments (R must be a multiple of 32)");
+    hipLaunchKernelGGL(pwg_first_conv_kernel, dim3(grid_1d(m * r, 1024)), dim3(256), 0, (hipStream_t)stream, z, w, b, x, xp, (long long)m, r);
+    return check_hip(hipGetLastError(), "pwg_first_conv");
+}
+
+int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream) {
+    FCL_REQUIRE(a && a->m > 0 && a->x && a->xp && a->cp && a->w_conv_p && a->b_conv && a->w_aux_p && a->w_os_p && a->b_os && a->skips && a->seg_lo && a->seg_hi,
+                FCL_ERR_INVALID, "pwg_layer_fwd: null argument");
+    FCL_REQUIRE(a->r > 0 && (a->r & 31) == 0 && a->aux > 0 && a->dilation >= 1 && a->ksize >= 1 && (a->ksize & 1) && a->ksize + 1 <= FCL_MAX_TERMS, FCL_ERR_SHAPE,
+                "pwg_layer_fwd: residual channels must be a multiple of 32, kernel size odd and < %d", FCL_MAX_TERMS);
+    FCL_REQUIRE(a->z && a->gp && a->o, FCL_ERR_WORKSPACE, "pwg_layer_fwd: the unfused path needs the z / g / o workspaces");
+    FCL_REQUIRE(a->m <= 0x7fffffffLL, FCL_ERR_SHAPE, "pwg_layer_fwd: more than 2^31 samples in one call");
+    hipStream_t s = (hipStream_t)stream;
+    const int R = a->r, G = 2 * R, M = (int)a->m;
+    const int ldx = R / 32, ldc = (a->aux + 31) / 32;
+    GemmArgs g = {};
+    for (int j = 0; j < a->ksize; ++j) {
+        g.term[j].K = R;
+        g.term[j].shift = (j - (a->ksize - 1) / 2) * a->dilation;
+        g.term[j].Ap = a->xp; g.term[j].lda_p = ldx;
+        g.term[j].Wp = a->w_conv_p + (size_t)j * G * ldx * 64; g.term[j].ldw_p = ldx;
+    }
+    g.term[a->ksize].K = a->aux;
+    g.term[a->ksize].Ap = a->cp; g.term[a->ksize].lda_p = ldc;
+    g.term[a->ksize].Wp = a->w_aux_p; g.term[a->ksize].ldw_p = ldc;
+    g.nterms = a->ksize + 1;
+    g.M = M; g.N = G;
+    g.seg_lo = a->seg_lo; g.seg_hi = a->seg_hi;
+    g.bias = a->b_conv;
+    g.Y = a->z; g.ldy = G;
+    int rc = launch_gemm(g, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pwg_gate_kernel, dim3(grid_1d((long long)M * R, 1024)), dim3(256), 0, s, a->z, a->gp, (long long)M, R);
+    GemmArgs h = {};
+    h.term[0].K = R;
+    h.term[0].Ap = a->gp; h.term[0].lda_p = ldx;
+    h.term[0].Wp = a->w_os_p; h.term[0].ldw_p = ldx;
+    h.nterms = 1;
+    h.M = M; h.N = G;
+    h.bias = a->b_os;
+    h.Y = a->o; h.ldy = G;
+    rc = launch_gemm(h, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pwg_resid_kernel, dim3(grid_1d((long long)M * R, 1024)), dim3(256), 0, s, a->o, a->x, a->xp, a->skips, (long long)M, R, a->first_layer);
+    return check_hip(hipGetLastError(), "pwg_layer_fwd");
+}
+
+int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const float* b1, const float* w2, float b2, uint16_t* yp, float* h, float* wav,
+                     int64_t m, int s_ch, fcl_stream_t stream) {
+    FCL_REQUIRE(skips && w1p && b1 && w2 && yp && h && wav && m > 0 && m <= 0x7fffffffLL && s_ch > 0 && (s_ch & 31) == 0, FCL_ERR_INVALID,
+                "pwg_last_fwd: bad arguments (skip channels must be a multiple of 32)");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pwg_relu_scale_kernel, dim3(grid_1d(m * s_ch, 1024)), dim3(256), 0, s, skips, scale, yp, (long long)m, s_ch);
+    GemmArgs g = {};
+    g.term[0].K = s_ch;
+    g.term[0].Ap = yp; g.term[0].lda_p = s_ch / 32;
+    g.term[0].Wp = w1p; g.term[0].ldw_p = s_ch / 32;
+    g.nterms = 1;
+    g.M = (int)m; g.N = s_ch;
+    g.bias = b1;
+    g.Y = h; g.ldy = s_ch;
+    int rc = launch_gemm(g, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pwg_out_kernel, dim3(grid_1d(m, 16)), dim3(256), 0, s, h, w2, b2, wav, (long long)m, s_ch);
+    return check_hip(hipGetLastError(), "pwg_last_fwd");
+}
+
+}  // extern "C"

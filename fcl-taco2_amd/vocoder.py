@@ -1,0 +1,187 @@
+"""Parallel WaveGAN generator on the HIP path (BASELINE configs[4]): mel [T', 80] -> waveform [T' * 256].
+
+The reference hands its mels to the external `parallel-wavegan-decode --checkpoint vocoder/PWG/PWG.pkl` (inference_student.sh:20-23); this module
+is that stage, built from the published architecture (kan-bayashi/ParallelWaveGAN `ParallelWaveGANGenerator`, v1 / LJSpeech; restated in
+oracle/pwg_oracle.py — no source or vectors in the reference: parity unpinned).  State-dict names and the `inference(c, x=None)` call are that
+package's, so its checkpoints (`{"model": {"generator": ...}}`, with or without weight norm) load here.
+
+Batched: utterances are concatenated sample-major; every convolution of the 30-layer residual stack is a K-term of the pre-split-operand GEMM
+(csrc/pwg.hip).  No CPU fallback; needs the pre-split path (FCL_PRECISION / FCL_PLANES not 0)."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+CONFIG = dict(layers=30, stacks=3, residual_channels=64, gate_channels=128, skip_channels=64, aux_channels=80, aux_context_window=2,
+              kernel_size=3, upsample_scales=(4, 4, 4, 4))
+
+
+def param_spec(cfg=None):
+    """Ordered {state_dict name: shape}, weight norm folded (the generator after remove_weight_norm())."""
+    cfg = dict(CONFIG, **(cfg or {}))
+    R, G, S, A, k = cfg["residual_channels"], cfg["gate_channels"], cfg["skip_channels"], cfg["aux_channels"], cfg["kernel_size"]
+    spec = {"first_conv.weight": (R, 1, 1), "first_conv.bias": (R,), "upsample_net.conv_in.weight": (A, A, 2 * cfg["aux_context_window"] + 1)}
+    for i, s in enumerate(cfg["upsample_scales"]):
+        spec["upsample_net.upsample.up_layers.%d.weight" % (2 * i + 1)] = (1, 1, 1, 2 * s + 1)
+    for l in range(cfg["layers"]):
+        p = "conv_layers.%d." % l
+        spec[p + "conv.weight"], spec[p + "conv.bias"] = (G, R, k), (G,)
+        spec[p + "conv1x1_aux.weight"] = (G, A, 1)
+        spec[p + "conv1x1_out.weight"], spec[p + "conv1x1_out.bias"] = (R, G // 2, 1), (R,)
+        spec[p + "conv1x1_skip.weight"], spec[p + "conv1x1_skip.bias"] = (S, G // 2, 1), (S,)
+    spec["last_conv_layers.1.weight"], spec["last_conv_layers.1.bias"] = (S, S, 1), (S,)
+    spec["last_conv_layers.3.weight"], spec["last_conv_layers.3.bias"] = (1, S, 1), (1,)
+    return spec
+
+
+def fold_weight_norm(sd):
+    """weight_g / weight_v pairs (torch.nn.utils.weight_norm, norm over every dim but 0) -> plain weights; other entries pass through."""
+    out = {}
+    for k, v in sd.items():
+        v = np.asarray(v.detach().cpu().numpy() if torch.is_tensor(v) else v)
+        if k.endswith("weight_g"):
+            base = k[: -len("_g")]
+            vv = sd[base + "_v"]
+            vv = np.asarray(vv.detach().cpu().numpy() if torch.is_tensor(vv) else vv, dtype=np.float64)
+            norm = np.sqrt((vv.reshape(vv.shape[0], -1) ** 2).sum(axis=1)).reshape([-1] + [1] * (vv.ndim - 1))
+            out[base] = (v.astype(np.float64) * vv / norm).astype(np.float32)
+        elif not k.endswith("weight_v"):
+            out[k] = v
+    return out
+
+
+class PWGPlan(object):
+    """Device-resident, GEMM-ready weights of one generator: packed taps and their P32 planes, stacked out / skip projections."""
+
+    def __init__(self, state_dict, device, cfg=None):
+        if not ops.planes_enabled():
+            raise _lib.FclError("fcl-taco2_amd: the vocoder runs on the pre-split operand kernels only (FCL_PRECISION=0 / FCL_PLANES=0 is set)")
+        if not str(device).startswith("cuda"):
+            raise _lib.FclError("fcl-taco2_amd: PWGPlan needs a GPU device (no CPU fallback)")
+        self.cfg = cfg = dict(CONFIG, **(cfg or {}))
+        self.device = dev = torch.device(device)
+        if "model" in state_dict and "generator" in state_dict["model"]:  # a parallel_wavegan checkpoint
+            state_dict = state_dict["model"]["generator"]
+        sd = fold_weight_norm(state_dict)
+        for k, shp in param_spec(cfg).items():
+            if k not in sd or tuple(np.shape(sd[k])) != tuple(shp):
+                raise _lib.FclError("fcl-taco2_amd: generator state_dict lacks %s %r (got %r)" % (k, shp, None if k not in sd else np.shape(sd[k])))
+        self.R, self.A, self.S, self.k = cfg["residual_channels"], cfg["aux_channels"], cfg["skip_channels"], cfg["kernel_size"]
+        if cfg["gate_channels"] != 2 * self.R or self.S != self.R or self.R % 32:
+            raise _lib.FclError("fcl-taco2_amd: the vocoder kernels need gate = 2 x residual = 2 x skip channels, a multiple of 32")
+        self.hop = int(np.prod(cfg["upsample_scales"]))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        with torch.cuda.device(dev):
+            self.first_w, self.first_b = t(sd["first_conv.weight"].reshape(-1)), t(sd["first_conv.bias"])
+            self.conv_in = ops.pack_conv1d_weight(t(sd["upsample_net.conv_in.weight"]))  # [k, A, A]
+            self.up_w = [t(sd["upsample_net.upsample.up_layers.%d.weight" % (2 * i + 1)].reshape(-1)) for i in range(len(cfg["upsample_scales"]))]
+            self.layers = []
+            for l in range(cfg["layers"]):
+                p = "conv_layers.%d." % l
+                wp = ops.pack_conv1d_weight(t(sd[p + "conv.weight"]))  # [k, 2R, R]
+                w_os = np.concatenate([sd[p + "conv1x1_out.weight"].reshape(self.R, self.R), sd[p + "conv1x1_skip.weight"].reshape(self.S, self.R)])
+                self.layers.append(dict(
+                    dilation=2 ** (l % (cfg["layers"] // cfg["stacks"])),
+                    w_conv_p=ops.pack_planes(wp.reshape(self.k * 2 * self.R, self.R)), b_conv=t(sd[p + "conv.bias"]),
+                    w_aux_p=ops.pack_planes(t(sd[p + "conv1x1_aux.weight"].reshape(2 * self.R, self.A))),
+                    w_os_p=ops.pack_planes(t(w_os)), b_os=t(np.concatenate([sd[p + "conv1x1_out.bias"], sd[p + "conv1x1_skip.bias"]]))))
+            self.last_w1p = ops.pack_planes(t(sd["last_conv_layers.1.weight"].reshape(self.S, self.S)))
+            self.last_b1 = t(sd["last_conv_layers.1.bias"])
+            self.last_w2 = t(sd["last_conv_layers.3.weight"].reshape(-1))
+            self.last_b2 = float(np.asarray(sd["last_conv_layers.3.bias"]).reshape(-1)[0])
+
+
+class ParallelWaveGANGenerator(object):
+    """mel -> waveform.  `synthesize(mels)` is the batched entry; `inference(c, x=None)` mirrors the published single-utterance call."""
+
+    def __init__(self, plan):
+        self.plan = plan
+
+    # ---- feature side: replicate padding + conv_in at frame rate, then 4 x (stretch + smoothing) to sample rate --------------------------------
+    def _upsample(self, mel_rows, lens):
+        pl, dev = self.plan, self.plan.device
+        ctx, A = pl.cfg["aux_context_window"], pl.A
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        pad_idx, lo, hi, keep = [], [], [], []
+        for u, n in enumerate(lens):  # padded utterance = frames clamp(-ctx .. n-1+ctx); conv_in is 'valid', i.e. 'same' evaluated on the interior
+            base = len(pad_idx)
+            pad_idx.extend(offs[u] + np.clip(np.arange(-ctx, n + ctx), 0, n - 1))
+            lo.extend([base] * (n + 2 * ctx))
+            hi.extend([base + n + 2 * ctx] * (n + 2 * ctx))
+            keep.extend(range(base + ctx, base + ctx + n))
+        i32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(dev)
+        c_pad = ops.gather_rows(mel_rows, i32(pad_idx))
+        c_in = ops.conv1d(c_pad, pl.conv_in, None, i32(lo), i32(hi))
+        c = ops.gather_rows(c_in, i32(keep))  # [sum T', A]
+        frames = int(offs[-1])
+        frame_utt, utt_off = i32(np.repeat(np.arange(len(lens)), lens)), i32(offs)
+        rate, lib = 1, _lib.load()
+        n_st = len(pl.up_w)
+        cp = None
+        for i, s in enumerate(pl.cfg["upsample_scales"]):
+            last = i == n_st - 1
+            rows = frames * rate * s
+            out = None if last else torch.empty(rows, A, device=dev)
+            cp = ops.planes_empty(rows, A, dev) if last else None
+            _lib.check(lib.fcl_pwg_upsample_stage(c.data_ptr(), frame_utt.data_ptr(), utt_off.data_ptr(), frames, rate, s, pl.up_w[i].data_ptr(),
+                                                  None if out is None else out.data_ptr(), None if cp is None else cp.data_ptr(), A, ops._stream()))
+            c, rate = out, rate * s
+        return cp, offs
+
+    def synthesize(self, mels, noise=None, seed=0, return_intermediates=False):
+        """mels: list of [T'_i, aux] float tensors / arrays.  noise: optional list of [T'_i * hop] arrays (else drawn on the device from `seed`).
+        Returns a list of [T'_i * hop] float32 device tensors."""
+        pl, dev = self.plan, self.plan.device
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            lens = [int(m.shape[0]) for m in mels]
+            if min(lens) < 1:
+                raise _lib.FclError("fcl-taco2_amd: empty mel")
+            mel_rows = torch.cat([torch.as_tensor(m, dtype=torch.float32).to(dev) for m in mels]).contiguous()
+            if mel_rows.shape[1] != pl.A:
+                raise _lib.FclError("fcl-taco2_amd: expected %d mel channels, got %d" % (pl.A, mel_rows.shape[1]))
+            cp, offs = self._upsample(mel_rows, lens)
+            M, R = int(offs[-1]) * pl.hop, pl.R
+            if M >= 2 ** 31:
+                raise _lib.FclError("fcl-taco2_amd: more than 2^31 samples in one vocoder batch")
+            if noise is None:
+                z = torch.empty(M, device=dev)
+                _lib.check(lib.fcl_pwg_noise(z.data_ptr(), M, seed & 0xFFFFFFFF, ops._stream()))
+            else:
+                z = torch.cat([torch.as_tensor(n_, dtype=torch.float32).reshape(-1).to(dev) for n_ in noise]).contiguous()
+                if z.numel() != M:
+                    raise _lib.FclError("fcl-taco2_amd: noise must hold T' * %d samples per utterance" % pl.hop)
+            s_off = torch.from_numpy((offs * pl.hop).astype(np.int64)).to(dev)
+            reps = torch.from_numpy(np.asarray(lens, dtype=np.int64) * pl.hop).to(dev)
+            seg_lo = torch.repeat_interleave(s_off[:-1], reps).to(torch.int32)  # index maps (integers): sample range of each row's utterance
+            seg_hi = torch.repeat_interleave(s_off[1:], reps).to(torch.int32)
+            x, xp = torch.empty(M, R, device=dev), ops.planes_empty(M, R, dev)
+            _lib.check(lib.fcl_pwg_first_conv(z.data_ptr(), pl.first_w.data_ptr(), pl.first_b.data_ptr(), x.data_ptr(), xp.data_ptr(), M, R, ops._stream()))
+            skips = torch.empty(M, R, device=dev)
+            zbuf, obuf, gp = torch.empty(M, 2 * R, device=dev), torch.empty(M, 2 * R, device=dev), ops.planes_empty(M, R, dev)
+            taps = []
+            for l, L in enumerate(pl.layers):
+                a = _lib.PwgLayer()
+                a.m, a.r, a.aux, a.ksize, a.dilation, a.first_layer = M, R, pl.A, pl.k, L["dilation"], int(l == 0)
+                a.seg_lo, a.seg_hi = seg_lo.data_ptr(), seg_hi.data_ptr()
+                a.x, a.xp, a.cp = x.data_ptr(), xp.data_ptr(), cp.data_ptr()
+                a.w_conv_p, a.b_conv, a.w_aux_p = L["w_conv_p"].data_ptr(), L["b_conv"].data_ptr(), L["w_aux_p"].data_ptr()
+                a.w_os_p, a.b_os, a.skips = L["w_os_p"].data_ptr(), L["b_os"].data_ptr(), skips.data_ptr()
+                a.z, a.gp, a.o = zbuf.data_ptr(), gp.data_ptr(), obuf.data_ptr()
+                _lib.check(lib.fcl_pwg_layer_fwd(C.byref(a), ops._stream()))
+                if return_intermediates:
+                    taps.append(x.clone())
+            wav = torch.empty(M, device=dev)
+            _lib.check(lib.fcl_pwg_last_fwd(skips.data_ptr(), math.sqrt(1.0 / len(pl.layers)), pl.last_w1p.data_ptr(), pl.last_b1.data_ptr(),
+                                            pl.last_w2.data_ptr(), pl.last_b2, gp.data_ptr(), x.data_ptr(), wav.data_ptr(), M, pl.S, ops._stream()))
+            outs = [wav[int(offs[i]) * pl.hop : int(offs[i + 1]) * pl.hop] for i in range(len(lens))]
+            if return_intermediates:
+                return outs, dict(z=z, taps=taps, skips=skips, seg=(seg_lo, seg_hi))
+            return outs
+
+    def inference(self, c, x=None):
+        """ParallelWaveGANGenerator.inference(c, x): c [T', aux] (x: optional noise [T' * hop]) -> waveform [T' * hop, 1]."""
+        return self.synthesize([c], None if x is None else [x])[0].reshape(-1, 1)

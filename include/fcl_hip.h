@@ -461,6 +461,48 @@ typedef struct {
 int fcl_prof_enable(int on);
 int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries);
 
+/* ---- §8f N4 / BASELINE configs[4]: Parallel WaveGAN generator (mel -> waveform), the stage the reference delegates to the external
+ *      `parallel-wavegan-decode` (inference_student.sh:20-23).  No source in the reference: the architecture is the published
+ *      kan-bayashi/ParallelWaveGAN generator (v1, LJSpeech: 80 mels, hop 256 = 4*4*4*4, 30 layers / 3 stacks, 64 residual + skip channels,
+ *      128 gate channels, kernel 3), restated in oracle/pwg_oracle.py (parity unpinned).  Rows are SAMPLES, time-major, utterances concatenated;
+ *      seg_lo / seg_hi [M] give every row the sample range of its utterance (zero padding at utterance edges).  Needs the pre-split operand
+ *      path (refused under FCL_PRECISION=0 / FCL_PLANES=0). ------------------------------------------------------------------------------- */
+/* One stage of the upsampling network: nearest-neighbour stretch by `scale` + the 1 x (2*scale+1) smoothing convolution w (no bias), per channel.
+ * in [frames * rate_in, c] -> out [frames * rate_in * scale, c] fp32 and / or out_p (P32 planes, ceil(c/32) lines per row, zero past c).
+ * frame_utt [frames]: utterance of each mel frame; utt_off [n_utt + 1]: first frame of each utterance. */
+int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int32_t* utt_off, int64_t frames, int rate_in, int scale, const float* w,
+                           float* out, uint16_t* out_p, int c, fcl_stream_t stream);
+/* The generator's input noise z ~ N(0, 1) (ParallelWaveGANGenerator.inference draws torch.randn): counter-based, reproducible per (seed, index). */
+int fcl_pwg_noise(float* z, int64_t n, uint32_t seed, fcl_stream_t stream);
+/* first_conv (Conv1d1x1 1 -> r): x[m, ch] = w[ch] * z[m] + b[ch], written as fp32 and as planes. */
+int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x, uint16_t* xp, int64_t m, int r, fcl_stream_t stream);
+/* One residual block (ResidualBlock.forward): dilated Conv1d(r -> 2r, ksize, dilation) + conv1x1_aux(aux -> 2r) as ONE GEMM of ksize + 1 K-terms,
+ * tanh * sigmoid gate, conv1x1_out / conv1x1_skip as one GEMM, x = (out + x) * sqrt(0.5), skips += skip (= skip when first_layer). */
+typedef struct {
+    int64_t m;                 /* samples (rows) */
+    int32_t r, aux;            /* residual (= skip = gate/2) channels, multiple of 32; auxiliary channels */
+    int32_t ksize, dilation;
+    int32_t first_layer;       /* != 0: skips is written, not accumulated */
+    const int32_t* seg_lo;     /* [m] */
+    const int32_t* seg_hi;
+    float* x;                  /* [m, r] fp32, in / out */
+    uint16_t* xp;              /* its planes (r/32 lines per row), in / out */
+    const uint16_t* cp;        /* planes of the upsampled features [m, aux] (ceil(aux/32) lines per row) */
+    const uint16_t* w_conv_p;  /* planes of the taps, tap-major [ksize * 2r, r] (fcl_pack_conv1d_weight + fcl_pack_planes) */
+    const float* b_conv;       /* [2r] */
+    const uint16_t* w_aux_p;   /* planes of conv1x1_aux [2r, aux] */
+    const uint16_t* w_os_p;    /* planes of [conv1x1_out ; conv1x1_skip] stacked [2r, r] */
+    const float* b_os;         /* [2r] = [b_out ; b_skip] */
+    float* skips;              /* [m, r] */
+    float* z;                  /* workspaces: [m, 2r] fp32 */
+    uint16_t* gp;              /*             planes [m, r] */
+    float* o;                  /*             [m, 2r] fp32 */
+} fcl_pwg_layer_t;
+int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
+/* last_conv_layers: wav[m] = relu(relu(skips * scale) W1^T + b1) . w2 + b2.  yp: workspace planes [m, s_ch]; h: workspace fp32 [m, s_ch]. */
+int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const float* b1, const float* w2, float b2, uint16_t* yp, float* h, float* wav,
+                     int64_t m, int s_ch, fcl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

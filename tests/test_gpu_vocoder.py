@@ -1,0 +1,109 @@
+"""-m gpu: the Parallel WaveGAN generator on the HIP path (fcl_taco2_amd/vocoder.py, csrc/pwg.hip) against the CPU restatement of the published
+architecture (oracle/pwg_oracle.py; no vocoder source or vectors exist in the reference: parity unpinned).  Closed-form weights, explicit noise;
+full v1 configuration and a small irregular one (aux channels not a multiple of 32, scales 2 x 3, two stacks), batches of ragged utterances incl.
+a one-frame utterance (every dilation then reaches past both edges), per-layer taps, weight-normed checkpoints."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_abs
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def voc():
+    assert torch.cuda.is_available()
+    import fcl_taco2_amd  # noqa: F401
+    from fcl_taco2_amd import _lib, ops, vocoder
+
+    _lib.load()
+    if not ops.planes_enabled():
+        pytest.skip("FCL_PRECISION=0 / FCL_PLANES=0: the vocoder needs the pre-split operand path")
+    return vocoder
+
+
+def weights(voc, cfg=None):
+    from fcl_taco2_amd import synthetic as SYN
+
+    return {k: SYN.closed_form_tensor("pwg." + k, tuple(s)) for k, s in voc.param_spec(cfg).items()}
+
+
+def run_both(voc, cfg, lens, seed):
+    from oracle import pwg_oracle as O
+
+    rng = np.random.RandomState(seed)
+    sd = weights(voc, cfg)
+    full = dict(voc.CONFIG, **(cfg or {}))
+    hop = int(np.prod(full["upsample_scales"]))
+    mels = [rng.standard_normal((n, full["aux_channels"])).astype(np.float32) for n in lens]
+    noise = [rng.standard_normal(n * hop).astype(np.float32) for n in lens]
+    gen = voc.ParallelWaveGANGenerator(voc.PWGPlan(sd, DEV, cfg))
+    got, aux = gen.synthesize(mels, noise=noise, return_intermediates=True)
+    torch.cuda.synchronize()
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    want = [O.inference(tsd, m, z, cfg) for m, z in zip(mels, noise)]
+    return got, want, aux, (tsd, mels, noise, hop)
+
+
+def test_full_v1_generator_matches_the_oracle(voc):
+    got, want, aux, _ = run_both(voc, None, [5, 1, 3], 0)
+    for g, w in zip(got, want):
+        assert g.shape == w.shape
+        err = max_abs(g.cpu(), w) / float(w.abs().max())
+        print('rel err', err)
+        assert err < 1e-3  # relative to the waveform's peak (the closed-form generator's output is small)
+
+
+def test_small_irregular_generator_and_per_layer_taps(voc):
+    import torch.nn.functional as F
+
+    from oracle import pwg_oracle as O
+
+    cfg = dict(layers=4, stacks=2, residual_channels=32, gate_channels=64, skip_channels=32, aux_channels=20, upsample_scales=(2, 3))
+    got, want, aux, (tsd, mels, noise, hop) = run_both(voc, cfg, [7, 2, 1, 9], 1)
+    for g, w in zip(got, want):
+        assert max_abs(g.cpu(), w) < 1e-3 * float(w.abs().max())
+    # the residual stream after every layer, utterance 0
+    full = dict(O.CONFIG, **cfg)
+    c = torch.from_numpy(mels[0]).t().unsqueeze(0)
+    c = F.pad(c, (full["aux_context_window"],) * 2, mode="replicate")
+    with torch.no_grad():
+        _, taps, skips = O.generator_forward(tsd, torch.from_numpy(noise[0]).reshape(1, 1, -1), O.upsample(tsd, c, cfg), cfg, return_taps=True)
+    n0 = mels[0].shape[0] * hop
+    for l, t in enumerate(taps):
+        assert max_abs(aux["taps"][l][:n0].cpu(), t[0].t()) < 5e-5, l
+
+
+def test_weight_normed_checkpoint_and_published_call(voc):
+    """A parallel_wavegan checkpoint ({"model": {"generator": ...}} with weight_g / weight_v) gives the same waveform; inference(c, x) -> [T, 1];
+    device noise is reproducible per seed and differs between seeds."""
+    rng = np.random.RandomState(2)
+    cfg = dict(layers=2, stacks=1, residual_channels=32, gate_channels=64, skip_channels=32, aux_channels=16, upsample_scales=(4,))
+    sd = weights(voc, cfg)
+    wn = {}
+    for k, v in sd.items():
+        if k.endswith("weight"):
+            g = rng.uniform(0.5, 2.0, size=[v.shape[0]] + [1] * (v.ndim - 1)).astype(np.float32)
+            norm = np.sqrt((v.reshape(v.shape[0], -1).astype(np.float64) ** 2).sum(1)).reshape(g.shape)
+            wn[k + "_g"], wn[k + "_v"] = (norm * 1.0).astype(np.float32), (v * g).astype(np.float32)  # g * v / |v| with |g v| = g |v|: folds back to v
+        else:
+            wn[k] = v
+    mel, z = rng.standard_normal((4, 16)).astype(np.float32), rng.standard_normal(16).astype(np.float32)
+    a = voc.ParallelWaveGANGenerator(voc.PWGPlan(sd, DEV, cfg)).inference(mel, z)
+    b = voc.ParallelWaveGANGenerator(voc.PWGPlan({"model": {"generator": wn}}, DEV, cfg)).inference(mel, z)
+    assert a.shape == (16, 1) and max_abs(a.cpu(), b.cpu()) < 1e-5
+    gen = voc.ParallelWaveGANGenerator(voc.PWGPlan(sd, DEV, cfg))
+    w0, w0b, w1 = gen.synthesize([mel], seed=7)[0], gen.synthesize([mel], seed=7)[0], gen.synthesize([mel], seed=8)[0]
+    assert torch.equal(w0, w0b) and not torch.equal(w0, w1)
+
+
+def test_device_noise_is_standard_normal(voc):
+    from fcl_taco2_amd import _lib, ops
+
+    z = torch.empty(1 << 20, device=DEV)
+    _lib.check(_lib.load().fcl_pwg_noise(z.data_ptr(), z.numel(), 123, ops._stream()))
+    torch.cuda.synchronize()
+    assert abs(float(z.mean())) < 5e-3 and abs(float(z.std()) - 1.0) < 5e-3
+    assert abs(float((z.abs() < 1.0).float().mean()) - 0.6827) < 3e-3 and float(z.abs().max()) < 6.5

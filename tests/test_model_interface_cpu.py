@@ -91,3 +91,25 @@ def test_loss_configuration_is_gated_loudly():
         hp = HP.student_hparams(**kw).check_supported()
         with pytest.raises(NotImplementedError):
             hp.check_loss_supported()
+
+
+def test_vocoder_spec_matches_the_oracle_and_weight_norm_folds():
+    """CPU: the vocoder's state-dict manifest is the oracle's (published parallel_wavegan names); weight_g / weight_v fold to torch's weight_norm."""
+    import numpy as np
+    import torch
+
+    from fcl_taco2_amd import vocoder
+    from oracle import pwg_oracle as O
+
+    assert list(O.param_spec().items()) == list(vocoder.param_spec().items())
+    spec = vocoder.param_spec()
+    assert spec["conv_layers.29.conv.weight"] == (128, 64, 3) and spec["upsample_net.upsample.up_layers.7.weight"] == (1, 1, 1, 9) and len(spec) == 219
+    conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(4, 6, 3))
+    with torch.no_grad():
+        conv.weight_g.mul_(1.7)
+    w = conv.weight.detach()  # recomputed from g, v by the parametrisation hook on access
+    conv(torch.zeros(1, 4, 8))
+    folded = vocoder.fold_weight_norm(conv.state_dict())
+    assert np.abs(folded["weight"] - conv.weight.detach().numpy()).max() < 1e-6 and "weight_g" not in folded
+    assert float((O.fold_weight_norm(conv.state_dict())["weight"] - conv.weight.detach()).abs().max()) < 1e-6
+    del w
