@@ -103,7 +103,7 @@ def test_vocoder_spec_matches_the_oracle_and_weight_norm_folds():
 
     assert list(O.param_spec().items()) == list(vocoder.param_spec().items())
     spec = vocoder.param_spec()
-    assert spec["conv_layers.29.conv.weight"] == (128, 64, 3) and spec["upsample_net.upsample.up_layers.7.weight"] == (1, 1, 1, 9) and len(spec) == 219
+    assert spec["conv_layers.29.conv.weight"] == (128, 64, 3) and spec["upsample_net.upsample.up_layers.7.weight"] == (1, 1, 1, 9) and len(spec) == 221
     conv = torch.nn.utils.weight_norm(torch.nn.Conv1d(4, 6, 3))
     with torch.no_grad():
         conv.weight_g.mul_(1.7)
