@@ -78,7 +78,7 @@ class Derive(C.Structure):  # fcl_derive_t
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
     _fields_ = [("m", C.c_int64), ("r", C.c_int32), ("aux", C.c_int32), ("ksize", C.c_int32), ("dilation", C.c_int32), ("first_layer", C.c_int32)] + [
-        (n, _P) for n in ("seg_lo", "seg_hi", "x", "xp", "cp", "w_conv_p", "b_conv", "w_aux_p", "w_os_p", "b_os", "skips", "z", "gp", "o")]
+        (n, _P) for n in ("seg_lo", "seg_hi", "x", "xp", "cp", "w_conv_p", "b_conv", "w_aux_p", "w_os_p", "b_os", "skips", "z", "gp", "o", "xp_out")]
 
 
 class ProfEntry(C.Structure):

@@ -174,6 +174,7 @@ __device__ __forceinline__ void store_p32(unsigned short* __restrict__ p, int ld
 bool planes_ok(const GemmTerm* t, int n);                  // every term carries A and W planes (and FCL_PLANES != 0)
 int launch_gemm_planes(const GemmArgs& a, hipStream_t s);  // gemm_planes.hip
 int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s);
+int launch_pwg_layer_fused(const fcl_pwg_layer_t& a, hipStream_t s);  // one Parallel WaveGAN residual block in one launch (r = 64, ksize = 3, aux <= 96)
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wave-per-gate kernel (fp32 operands) rather than a big-tile kernel

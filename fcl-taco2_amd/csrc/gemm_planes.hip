@@ -532,6 +532,227 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
 }
 
 // --------------------------------------------------------------------------------------------------------------------------------------
+// One Parallel WaveGAN residual block in ONE launch (pwg.hip holds the unfused form and the algebra): 128 samples x 128 gate columns per workgroup.
+//   main loop  z = sum of ksize dilated taps of x + the auxiliary term (the shared LDS-DMA ring, 3 x 2 + 3 chunks for the v1 generator)
+//   epilogue 1 z + b -> LDS (fp32); g = tanh(z[:, :64]) * sigmoid(z[:, 64:]) -> LDS as pre-split A planes in the ring's swizzled chunk layout
+//   phase 2    o = g [W_out ; W_skip]^T  (2 chunks; W_os was staged in LDS by the compute waves while the loaders filled the ring)
+//   epilogue 2 x_out = (o[:, :64] + b_out + x) * sqrt(0.5) as planes (a SECOND buffer: neighbouring workgroups still read x for their taps),
+//              skips (+)= o[:, 64:] + b_skip.  HBM traffic per sample and layer: x 256 B in (+ halo) + 256 B out, aux 384 B, skips 512 B.
+struct PwgFusedArgs {
+    GemmTerm term[4];
+    int nterms, M;
+    const int *seg_lo, *seg_hi;
+    const float *b_conv, *b_os;
+    const u16 *w_os_p, *xp_in;
+    u16* xp_out;
+    float* skips;
+    int first;
+    int dbg;  // developer timing aid (FCL_PWG_DBG): 1 / 2 / 3 = return after the main loop / the gate / phase 2 (results are then garbage)
+};
+
+// WM = 4: 128-row tiles, W_os resident in LDS (160 KB, one workgroup per CU); WM = 2: 64-row tiles, W_os fragments straight from L2 into
+// registers, everything else inside the 72 KB ring (two workgroups per CU: one's epilogue overlaps the other's main loop).
+template <int WM, int NST, bool HI>
+__global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgFusedArgs a) {
+    using G = PGeo<WM, 2, 2, 4, NST, 2>;
+    constexpr int TM = 2, TN = 4, WN = 2, BM = G::BM;
+    constexpr bool WLDS = WM == 4 && NST == 3;
+    constexpr int LDT = 132, ZT_BYTES = BM * LDT * 4;
+    constexpr int WOS = G::LDS_BYTES;                                          // WLDS only: 32 KB after the ring
+    constexpr int GA = WLDS ? WOS + 32768 : (ZT_BYTES + 1023) / 1024 * 1024;    // gate planes: after W_os, or inside the ring behind the staging tile
+    static_assert(G::BN == 128 && ZT_BYTES <= G::LDS_BYTES && (WLDS || GA + BM * 256 <= G::LDS_BYTES), "tile geometry");
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    int bx, by;
+    xcd_tile_p(bx, by);
+    const int m0 = by * BM;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (WLDS && wave < G::NW) {  // W_os [128, 64] planes -> LDS, two 16 KB chunks in the ring's layout (piece p of row n at slot p ^ ((n >> 1) & 7))
+        for (int i = tid; i < 2048; i += G::CTHREADS) {
+            const int n = i >> 4, c = (i >> 3) & 1, p = i & 7;
+            const uint4 v = *reinterpret_cast<const uint4*>(a.w_os_p + ((size_t)(n * 2 + c) * 64 + p * 8));
+            *reinterpret_cast<uint4*>(smem + WOS + c * 16384 + n * 128 + ((p ^ ((n >> 1) & 7)) << 4)) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!pmainloop<WM, 2, TM, TN, NST, false, 2, HI>(a.term, a.nterms, a.M, m0, 0, 128, a.seg_lo, a.seg_hi, smem, acc)) return;  // loader wave
+
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 15, rq = lane >> 4;
+    const int r16 = lane & 15, kq = lane >> 4, sw = r16 >> 1;
+    s16x8 wh[2][TN], wl[2][TN];
+    if (!WLDS) {  // phase-2 B fragments (W_os rows wn*64 + tn*16 + r16, chunk c, pieces kq / 4 + kq): requested now, consumed after the gate
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const u16* w = a.w_os_p + ((size_t)((wn * TN + tn) * 16 + r16) * 2 + c) * 64 + kq * 8;
+                wh[c][tn] = *reinterpret_cast<const s16x8*>(w);
+                if (!HI) wl[c][tn] = *reinterpret_cast<const s16x8*>(w + 32);
+            }
+    }
+    float* zt = reinterpret_cast<float*>(smem);
+    if (a.dbg == 1) {
+        if (acc[0][0][0] == 12345.f) a.skips[0] = 1.f;
+        return;
+    }
+    __syncthreads();  // every compute wave is done with the ring
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int cn = (wn * TN + tn) * 16 + col;
+            const float b = a.b_conv[cn];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zt[((wm * TM + tm) * 16 + rq * 4 + r) * LDT + cn] = acc[tm][tn][r] + b;
+        }
+    __syncthreads();
+    for (int i = tid; i < BM * 8; i += G::CTHREADS) {  // gate: 8 columns per item -> one hi and one lo piece of the A planes
+        const int r = i >> 3, p = i & 7, c0 = p * 8;
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = tanhf(zt[r * LDT + c0 + e]) * (1.0f / (1.0f + __expf(-zt[r * LDT + 64 + c0 + e])));
+            v1[e] = tanhf(zt[r * LDT + c0 + 4 + e]) * (1.0f / (1.0f + __expf(-zt[r * LDT + 64 + c0 + 4 + e])));
+        }
+        uint2 h0, l0, h1, l1;
+        split4(v0, h0, l0);
+        split4(v1, h1, l1);
+        u8* base = smem + GA + (p >> 2) * (BM * 128) + r * 128;
+        const int sws = (r >> 1) & 7, piece = p & 3;
+        *reinterpret_cast<uint4*>(base + ((piece ^ sws) << 4)) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(base + (((4 + piece) ^ sws) << 4)) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+    __syncthreads();
+    if (a.dbg == 2) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const int ar = (wm * TM * 16 + r16) * 128, br = (wn * TN * 16 + r16) * 128;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if constexpr (WLDS) {
+                pchunk_mma<TM, TN, HI>(smem, GA + c * (BM * 128) + ar + ((kq ^ sw) << 4), GA + c * (BM * 128) + ar + (((4 + kq) ^ sw) << 4),
+                                       WOS + c * 16384 + br + ((kq ^ sw) << 4), WOS + c * 16384 + br + (((4 + kq) ^ sw) << 4), acc);
+            } else {
+                s16x8 ah[TM], al[TM];
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    ah[tm] = *reinterpret_cast<const s16x8*>(smem + GA + c * (BM * 128) + ar + tm * 2048 + ((kq ^ sw) << 4));
+                    if (!HI) al[tm] = *reinterpret_cast<const s16x8*>(smem + GA + c * (BM * 128) + ar + tm * 2048 + (((4 + kq) ^ sw) << 4));
+                }
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) {
+                        if (!HI) {
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], wh[c][tn], acc[tm][tn], 0, 0, 0);
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], wl[c][tn], acc[tm][tn], 0, 0, 0);
+                        }
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], wh[c][tn], acc[tm][tn], 0, 0, 0);
+                    }
+            }
+        }
+    }
+    if (a.dbg == 3) {
+        if (acc[0][0][0] == 12345.f) a.skips[0] = 1.f;
+        return;
+    }
+    if (!WLDS) __syncthreads();  // GA sits in the ring next to the staging tile's rows: everyone has read its fragments before o is staged
+    // (WLDS: zt is free since the gate pass, phase 2 reads GA / WOS only)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int cn = (wn * TN + tn) * 16 + col;
+            const float b = a.b_os[cn];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zt[((wm * TM + tm) * 16 + rq * 4 + r) * LDT + cn] = acc[tm][tn][r] + b;
+        }
+    __syncthreads();
+    const int rows = min(BM, a.M - m0);
+    for (int i = tid; i < rows * 8; i += G::CTHREADS) {
+        const int r = i >> 3, p = i & 7, c0 = p * 8;
+        const size_t m = (size_t)(m0 + r);
+        const size_t lo_off = (m * 2 + (c0 >> 5)) * 64 + (c0 & 31);
+        const uint4 xh = *reinterpret_cast<const uint4*>(a.xp_in + lo_off), xl = *reinterpret_cast<const uint4*>(a.xp_in + lo_off + 32);
+        const unsigned hw[4] = {xh.x, xh.y, xh.z, xh.w}, lw_[4] = {xl.x, xl.y, xl.z, xl.w};
+        f32x4 v0, v1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // element 2e (low half-word) and 2e + 1 (high half-word) of the piece
+            const float x0 = __builtin_bit_cast(float, hw[e] << 16) + __builtin_bit_cast(float, lw_[e] << 16);
+            const float x1 = __builtin_bit_cast(float, hw[e] & 0xFFFF0000u) + __builtin_bit_cast(float, lw_[e] & 0xFFFF0000u);
+            const float n0 = (zt[r * LDT + c0 + 2 * e] + x0) * 0.70710678118654752440f, n1 = (zt[r * LDT + c0 + 2 * e + 1] + x1) * 0.70710678118654752440f;
+            if (e < 2) { v0[2 * e] = n0; v0[2 * e + 1] = n1; } else { v1[2 * (e - 2)] = n0; v1[2 * (e - 2) + 1] = n1; }
+        }
+        uint2 h0, l0, h1, l1;
+        split4(v0, h0, l0);
+        split4(v1, h1, l1);
+        *reinterpret_cast<uint4*>(a.xp_out + lo_off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+        *reinterpret_cast<uint4*>(a.xp_out + lo_off + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        float* sk = a.skips + m * 64 + c0;
+        f32x4 s0 = *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0), s1 = *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0 + 4);
+        if (!a.first) {
+            s0 += *reinterpret_cast<const f32x4*>(sk);
+            s1 += *reinterpret_cast<const f32x4*>(sk + 4);
+        }
+        *reinterpret_cast<f32x4*>(sk) = s0;
+        *reinterpret_cast<f32x4*>(sk + 4) = s1;
+    }
+}
+
+template <int WM, int NST, bool HI>
+static int launch_pwg_cfg(const PwgFusedArgs& a, long long m, double flops, hipStream_t s) {
+    using G = PGeo<WM, 2, 2, 4, NST, 2>;
+    constexpr int LDS = G::LDS_BYTES + ((WM == 4 && NST == 3) ? 2 * 32768 : 0);
+    auto k = pwg_layer_kernel<WM, NST, HI>;
+    const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(k), LDS);
+    if (rc) return rc;
+    dim3 grid(1, (unsigned)((m + G::BM - 1) / G::BM));
+    char full[48];
+    snprintf(full, sizeof(full), "pwg_layer_kernel<%d,%d>%s", WM, NST, HI ? "/bf16" : "");
+    ProfScope ps(full, flops, (int)m, s);
+    hipLaunchKernelGGL(k, grid, dim3(G::THREADS), LDS, s, a);
+    return check_hip(hipGetLastError(), "pwg_layer launch");
+}
+
+int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
+    PwgFusedArgs a = {};
+    const int R = L.r, ldx = R / 32, ldc = (L.aux + 31) / 32;
+    for (int j = 0; j < L.ksize; ++j) {
+        a.term[j].K = R;
+        a.term[j].shift = (j - (L.ksize - 1) / 2) * L.dilation;
+        a.term[j].Ap = L.xp; a.term[j].lda_p = ldx;
+        a.term[j].Wp = L.w_conv_p + (size_t)j * 2 * R * ldx * 64; a.term[j].ldw_p = ldx;
+    }
+    a.term[L.ksize].K = L.aux;
+    a.term[L.ksize].Ap = L.cp; a.term[L.ksize].lda_p = ldc;
+    a.term[L.ksize].Wp = L.w_aux_p; a.term[L.ksize].ldw_p = ldc;
+    a.nterms = L.ksize + 1;
+    a.M = (int)L.m;
+    a.seg_lo = L.seg_lo; a.seg_hi = L.seg_hi;
+    a.b_conv = L.b_conv; a.b_os = L.b_os; a.w_os_p = L.w_os_p;
+    a.xp_in = L.xp; a.xp_out = L.xp_out; a.skips = L.skips; a.first = L.first_layer;
+    static const int dbg = tunable("PWG_DBG", 0);
+    a.dbg = dbg;
+    const bool hi = gemm_mode() == FCL_GEMM_BF16;
+    const double flops = 2.0 * (double)L.m * 2.0 * R * ((double)L.ksize * R + L.aux + R);
+    // measured on MI355X, 64 x 800 frames, ms per layer: 128-row tiles + 3-deep ring + W_os in LDS 7.07 (default); the same with a 4-deep ring and
+    // W_os fragments from L2 8.4 (the main loop alone is 4.05 either way: not bound by bytes in flight); 64-row tiles, two workgroups per CU 7.5
+    static const int cfg = tunable("PWG_CFG", 0);  // 1: 128 rows, 4-deep ring; 3: 64-row tiles, 3-deep; 4: 64-row tiles, 4-deep
+    if (cfg == 1) return hi ? launch_pwg_cfg<4, 4, true>(a, L.m, flops, s) : launch_pwg_cfg<4, 4, false>(a, L.m, flops, s);
+    if (cfg == 3) return hi ? launch_pwg_cfg<2, 3, true>(a, L.m, flops, s) : launch_pwg_cfg<2, 3, false>(a, L.m, flops, s);
+    if (cfg == 4) return hi ? launch_pwg_cfg<2, 4, true>(a, L.m, flops, s) : launch_pwg_cfg<2, 4, false>(a, L.m, flops, s);
+    return hi ? launch_pwg_cfg<4, 3, true>(a, L.m, flops, s) : launch_pwg_cfg<4, 3, false>(a, L.m, flops, s);
+}
+
+// --------------------------------------------------------------------------------------------------------------------------------------
 __global__ void pack_planes_kernel(const float* __restrict__ x, int ld, int rows, int cols, u16* __restrict__ out, int ldp) {
     const long long total = (long long)rows * ldp * 32;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

@@ -155,12 +155,17 @@ int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x,
 }
 
 int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream) {
-    FCL_REQUIRE(a && a->m > 0 && a->x && a->xp && a->cp && a->w_conv_p && a->b_conv && a->w_aux_p && a->w_os_p && a->b_os && a->skips && a->seg_lo && a->seg_hi,
+    FCL_REQUIRE(a && a->m > 0 && (a->x || a->xp_out) && a->xp && a->cp && a->w_conv_p && a->b_conv && a->w_aux_p && a->w_os_p && a->b_os && a->skips && a->seg_lo && a->seg_hi,
                 FCL_ERR_INVALID, "pwg_layer_fwd: null argument");
     FCL_REQUIRE(a->r > 0 && (a->r & 31) == 0 && a->aux > 0 && a->dilation >= 1 && a->ksize >= 1 && (a->ksize & 1) && a->ksize + 1 <= FCL_MAX_TERMS, FCL_ERR_SHAPE,
                 "pwg_layer_fwd: residual channels must be a multiple of 32, kernel size odd and < %d", FCL_MAX_TERMS);
-    FCL_REQUIRE(a->z && a->gp && a->o, FCL_ERR_WORKSPACE, "pwg_layer_fwd: the unfused path needs the z / g / o workspaces");
     FCL_REQUIRE(a->m <= 0x7fffffffLL, FCL_ERR_SHAPE, "pwg_layer_fwd: more than 2^31 samples in one call");
+    if (a->xp_out) {
+        FCL_REQUIRE(a->r == 64 && a->ksize == 3 && a->aux <= 96 && a->xp_out != a->xp, FCL_ERR_SHAPE,
+                    "pwg_layer_fwd: the one-launch block is built for r = 64, ksize = 3, aux <= 96 and needs xp_out != xp");
+        return launch_pwg_layer_fused(*a, (hipStream_t)stream);
+    }
+    FCL_REQUIRE(a->z && a->gp && a->o && a->x, FCL_ERR_WORKSPACE, "pwg_layer_fwd: the unfused path needs x and the z / g / o workspaces");
     hipStream_t s = (hipStream_t)stream;
     const int R = a->r, G = 2 * R, M = (int)a->m;
     const int ldx = R / 32, ldc = (a->aux + 31) / 32;

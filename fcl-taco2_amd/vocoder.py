@@ -9,6 +9,7 @@ Batched: utterances are concatenated sample-major; every convolution of the 30-l
 (csrc/pwg.hip).  No CPU fallback; needs the pre-split path (FCL_PRECISION / FCL_PLANES not 0)."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -51,6 +52,14 @@ def fold_weight_norm(sd):
         elif not k.endswith("weight_v"):
             out[k] = v
     return out
+
+
+def unpack_planes(p, cols):
+    """fp32 value hi + lo of a P32 plane buffer [rows, ceil(cols/32) * 64] (tests / debugging: plain tensor reshuffling, no arithmetic kernel of ours)."""
+    rows = p.shape[0]
+    v = p.reshape(rows, -1, 2, 32).to(torch.int32)
+    f = lambda t: (t << 16).view(torch.float32)
+    return (f(v[:, :, 0]) + f(v[:, :, 1])).reshape(rows, -1)[:, :cols].contiguous()
 
 
 class PWGPlan(object):
@@ -161,7 +170,11 @@ class ParallelWaveGANGenerator(object):
             x, xp = torch.empty(M, R, device=dev), ops.planes_empty(M, R, dev)
             _lib.check(lib.fcl_pwg_first_conv(z.data_ptr(), pl.first_w.data_ptr(), pl.first_b.data_ptr(), x.data_ptr(), xp.data_ptr(), M, R, ops._stream()))
             skips = torch.empty(M, R, device=dev)
-            zbuf, obuf, gp = torch.empty(M, 2 * R, device=dev), torch.empty(M, 2 * R, device=dev), ops.planes_empty(M, R, dev)
+            fused = R == 64 and pl.k == 3 and pl.A <= 96 and os.environ.get("FCL_PWG_FUSED", "1") != "0"  # one launch per residual block
+            gp = ops.planes_empty(M, R, dev)  # unfused: the gate's planes; fused: the second x buffer (blocks ping-pong between xp and gp)
+            zbuf = obuf = None
+            if not fused:
+                zbuf, obuf = torch.empty(M, 2 * R, device=dev), torch.empty(M, 2 * R, device=dev)
             taps = []
             for l, L in enumerate(pl.layers):
                 a = _lib.PwgLayer()
@@ -170,10 +183,15 @@ class ParallelWaveGANGenerator(object):
                 a.x, a.xp, a.cp = x.data_ptr(), xp.data_ptr(), cp.data_ptr()
                 a.w_conv_p, a.b_conv, a.w_aux_p = L["w_conv_p"].data_ptr(), L["b_conv"].data_ptr(), L["w_aux_p"].data_ptr()
                 a.w_os_p, a.b_os, a.skips = L["w_os_p"].data_ptr(), L["b_os"].data_ptr(), skips.data_ptr()
-                a.z, a.gp, a.o = zbuf.data_ptr(), gp.data_ptr(), obuf.data_ptr()
+                if fused:
+                    a.xp_out = gp.data_ptr()
+                else:
+                    a.z, a.gp, a.o = zbuf.data_ptr(), gp.data_ptr(), obuf.data_ptr()
                 _lib.check(lib.fcl_pwg_layer_fwd(C.byref(a), ops._stream()))
+                if fused:
+                    xp, gp = gp, xp
                 if return_intermediates:
-                    taps.append(x.clone())
+                    taps.append(unpack_planes(xp, R) if fused else x.clone())
             wav = torch.empty(M, device=dev)
             _lib.check(lib.fcl_pwg_last_fwd(skips.data_ptr(), math.sqrt(1.0 / len(pl.layers)), pl.last_w1p.data_ptr(), pl.last_b1.data_ptr(),
                                             pl.last_w2.data_ptr(), pl.last_b2, gp.data_ptr(), x.data_ptr(), wav.data_ptr(), M, pl.S, ops._stream()))

@@ -494,9 +494,11 @@ typedef struct {
     const uint16_t* w_os_p;    /* planes of [conv1x1_out ; conv1x1_skip] stacked [2r, r] */
     const float* b_os;         /* [2r] = [b_out ; b_skip] */
     float* skips;              /* [m, r] */
-    float* z;                  /* workspaces: [m, 2r] fp32 */
+    float* z;                  /* workspaces of the unfused path: [m, 2r] fp32 */
     uint16_t* gp;              /*             planes [m, r] */
     float* o;                  /*             [m, 2r] fp32 */
+    uint16_t* xp_out;          /* != NULL: the block runs as ONE launch (r = 64, ksize = 3, aux <= 96 only) that reads x from xp and writes the new
+                                * planes to xp_out (a different buffer: neighbouring tiles still read xp for their taps); x, z, gp, o are unused */
 } fcl_pwg_layer_t;
 int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
 /* last_conv_layers: wav[m] = relu(relu(skips * scale) W1^T + b1) . w2 + b2.  yp: workspace planes [m, s_ch]; h: workspace fp32 [m, s_ch]. */

@@ -99,6 +99,24 @@ def test_weight_normed_checkpoint_and_published_call(voc):
     assert torch.equal(w0, w0b) and not torch.equal(w0, w1)
 
 
+def test_fused_and_unfused_blocks_agree(voc, monkeypatch):
+    """The one-launch residual block (default for the v1 geometry) against the four-launch form of the same algebra."""
+    rng = np.random.RandomState(4)
+    sd = weights(voc)
+    mels = [rng.standard_normal((n, 80)).astype(np.float32) for n in (6, 2)]
+    noise = [rng.standard_normal(n * 256).astype(np.float32) for n in (6, 2)]
+    gen = voc.ParallelWaveGANGenerator(voc.PWGPlan(sd, DEV))
+    a, ia = gen.synthesize(mels, noise=noise, return_intermediates=True)
+    monkeypatch.setenv("FCL_PWG_FUSED", "0")
+    b, ib = gen.synthesize(mels, noise=noise, return_intermediates=True)
+    torch.cuda.synchronize()
+    for l in (0, 9, 29):
+        assert max_abs(ia["taps"][l].cpu(), ib["taps"][l].cpu()) < 1e-4, l
+    assert max_abs(ia["skips"].cpu(), ib["skips"].cpu()) < 1e-4
+    for x, y in zip(a, b):
+        assert max_abs(x.cpu(), y.cpu()) < 1e-3 * float(y.abs().max())
+
+
 def test_device_noise_is_standard_normal(voc):
     from fcl_taco2_amd import _lib, ops
 
