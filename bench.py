@@ -71,6 +71,111 @@ def pmc_traffic(kernel):
     return (2.0 * vals["fetch"][0] + vals["write"][0]) * 1024.0, "%s + %s" % (vals["fetch"][1], vals["write"][1])
 
 
+def e2e_workload(args, rank, world, dev, dist):
+    """BASELINE configs[4]: phoneme -> waveform, FCL-taco2-S (forced durations, as in the headline workload) + the Parallel WaveGAN generator, batch 64;
+    `--workload vocoder` times the generator alone on the same mels.  value = real-time factor = wall seconds per second of audio (22 050 Hz, hop 256)."""
+    import numpy as np
+    import torch
+
+    from fcl_taco2_amd import _lib, engine, hparams as HP, ops, sharding, synthetic as SYN, vocoder as V
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    e2e = args.workload == "tts_e2e"
+    B = 64 if args.batch == 32 else args.batch  # configs[4] is quoted on batch 64
+    hp = HP.student_hparams()
+    sd_np = SYN.closed_form_state_dict(HP.param_spec(hp))
+    plan = SynthesisPlan(sd_np, hp, dev)
+    xs, ds = SYN.batch_c2(hp.idim, batch=B, seed=1234 + rank)
+    prep = engine.prepare(plan, xs, ds)
+    vsd = {k: SYN.closed_form_tensor("pwg." + k, tuple(shp)) for k, shp in V.param_spec().items()}
+    gen = V.ParallelWaveGANGenerator(V.PWGPlan(vsd, dev))
+    runner = engine.GraphRunner(plan, prep, seed=77)
+    mel = runner.replay()
+    lens = [int(n) for n in runner.utt_frames]
+    frames = int(sum(lens))
+    samples = frames * gen.plan.hop
+    audio_s = samples / 22050.0
+
+    def step(i):
+        with torch.cuda.stream(runner.stream):
+            m = runner.replay() if e2e else mel
+            return gen.synthesize_packed(m, lens, seed=i)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        wavs = step(1000 + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    dt, samples_all = sharding.aggregate_throughput(dt, samples, dist, dev)
+    rtf = (dt / args.steps) / (samples_all / world / 22050.0)
+    out = {
+        "metric": ("phoneme -> waveform real-time factor (FCL-taco2-S + Parallel WaveGAN, batch=%d)" if e2e else
+                   "mel -> waveform real-time factor (Parallel WaveGAN generator, batch=%d)") % B,
+        "value": rtf, "unit": "wall s / audio s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 via bf16x3-split MFMA operands, fp32 accumulate", "data": "synthetic",
+        "samples_per_s": samples_all * args.steps / dt, "x_real_time": 1.0 / rtf,
+        "config": {"workload": "BASELINE configs[4]: %d utterances/GPU, %d mel frames = %.0f s of audio per batch; synthesis as in configs[1] (forced durations, "
+                               "hipGraph replay)%s; generator = published ParallelWaveGAN v1 (30 layers, 64/128 channels, hop 256), closed-form weights, "
+                               "device noise" % (B, frames, audio_s, "" if e2e else " OUTSIDE the timed region"),
+                   "parallelism": "%d independent replicas (utterance-sharded, no collective)" % world},
+    }
+    if rank == 0 and world == 1:
+        # ---- live roofline of the dominant kernel (the fused residual block): HBM bytes it must move per launch / its HIP-event duration
+        torch.cuda.synchronize()
+        _lib.prof_enable(True)
+        gen.synthesize_packed(mel, lens, seed=5)
+        torch.cuda.synchronize()
+        prof = _lib.prof_collect()
+        _lib.prof_enable(False)
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        d = prof[dom]
+        # algorithmic bytes per sample and layer: x planes in 256 + out 256, auxiliary planes 384 (96 padded columns, hi | lo), skips fp32 read + write 512
+        bytes_per_launch = 1408.0 * samples
+        achieved = bytes_per_launch * d["launches"] / (d["ms"] * 1e-3) / 1e9
+        traffic, src = pmc_traffic(dom)
+        out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                           "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * d["ms"] / d["launches"], "launches_per_step": d["launches"],
+                           "bytes_per_launch": bytes_per_launch, "share_of_kernel_time": d["ms"] / sum(v["ms"] for v in prof.values()),
+                           "fp32_equivalent_tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12,
+                           "note": "algorithmic 1408 B per sample per residual block (x 256 in + 256 out, aux 384, skips 512); 13 kFLOP per byte-row "
+                                   "would put the block on the MFMA side only below ~2 TB/s"}
+        if not args.no_cpu_baseline:
+            from oracle import fcl_oracle as O, pwg_oracle as PO
+
+            try:
+                avail = len(os.sched_getaffinity(0))
+            except AttributeError:
+                avail = os.cpu_count() or 1
+            torch.set_num_threads(max(1, min(avail, args.cpu_threads)))
+            sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+            tv = {k: torch.from_numpy(v) for k, v in vsd.items()}
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                cmel = O.inference(sd, hp, torch.from_numpy(xs[0]), dur=torch.from_numpy(ds[0]), prenet_keep="rng")["after"]
+                t_mel = time.perf_counter() - t1
+                nf = min(48, cmel.shape[0])
+                PO.inference(tv, cmel[:8].numpy())  # warm-up
+                t1 = time.perf_counter()
+                PO.inference(tv, cmel[:nf].numpy())
+                t_voc = (time.perf_counter() - t1) * cmel.shape[0] / nf
+            a_s = cmel.shape[0] * 256 / 22050.0
+            out["cpu_baseline"] = {"value": ((t_mel if e2e else 0.0) + t_voc) / a_s, "unit": "wall s / audio s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": "utterance 0 (%d frames): %s the generator through oracle/pwg_oracle.py on its first %d frames, scaled to the utterance "
+                                             "(%.1f s)" % (cmel.shape[0], "mel through oracle/fcl_oracle.py (%.2f s) +" % t_mel if e2e else "", nf, t_voc)}
+    del wavs
+    return out
+
+
 def forward_tf_workload(args, rank, world, dev, dist, batch, frames, S, T):
     """the student's teacher-forced `forward()` under eval() + no_grad() (what the reference's CustomEvaluator runs every epoch,
     tts_distill.py:91-111): H1-H12 incl. the distillation terms against a teacher 5-tuple computed once, outside the timed region."""
@@ -247,7 +352,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--model", choices=["student", "teacher"], default="student")
-    ap.add_argument("--workload", choices=["synthesis", "kd_step", "teacher_step", "forward_tf"], default="synthesis",
+    ap.add_argument("--workload", choices=["synthesis", "kd_step", "teacher_step", "forward_tf", "tts_e2e", "vocoder"], default="synthesis",
                     help="synthesis = BASELINE.json's headline metric (default); kd_step / teacher_step = the training step (SURVEY.md §8d C3/C4)")
     ap.add_argument("--amp", choices=["none", "bf16"], default="none", help="kd_step / teacher_step: the mixed-precision variant (bf16-rounded GEMM operands, "
                     "fp32 accumulate / master weights / optimizer) of the reference's --use-amp recipes")
@@ -287,6 +392,13 @@ def main():
     from fcl_taco2_amd import _lib, engine, hparams as HP, ops, synthetic as SYN
     from fcl_taco2_amd.plan import SynthesisPlan
 
+    if args.workload in ("tts_e2e", "vocoder"):
+        out = e2e_workload(args, rank, world, dev, dist)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.workload != "synthesis":
         out = train_workload(args, rank, world, dev, dist)
         if rank == 0:

@@ -33,7 +33,7 @@ class DecoderIO(C.Structure):
 
 class GemmTerm(C.Structure):
     _fields_ = [("A", _P), ("W", _P), ("lda", _I), ("ldw", _I), ("K", _I), ("shift", _I), ("Whi", _P), ("Wlo", _P), ("Ap", _P), ("Wp", _P),
-                ("lda_p", _I), ("ldw_p", _I)]
+                ("lda_p", _I), ("ldw_p", _I), ("a_chunk_stride", C.c_int64)]
 
 
 class LstmStep(C.Structure):
@@ -134,9 +134,9 @@ SIGNATURES = {
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),
     "fcl_pack_planes_t": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     "fcl_gemm_tn_planes": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _Z, _P]),
-    "fcl_pwg_upsample_stage": (_I, [_P, _P, _P, C.c_int64, _I, _I, _P, _P, _P, _I, _P]),
+    "fcl_pwg_upsample_stage": (_I, [_P, _P, _P, C.c_int64, _I, _I, _P, _P, _P, _I, _I, _P]),
     "fcl_pwg_noise": (_I, [_P, C.c_int64, C.c_uint32, _P]),
-    "fcl_pwg_first_conv": (_I, [_P, _P, _P, _P, _P, C.c_int64, _I, _P]),
+    "fcl_pwg_first_conv": (_I, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _P]),
     "fcl_pwg_layer_fwd": (_I, [_P, _P]),
     "fcl_pwg_last_fwd": (_I, [_P, _F, _P, _P, _P, _F, _P, _P, _P, C.c_int64, _I, _P]),
     "fcl_derive_blocks": (_I, [_I, _I, _I]),

@@ -159,8 +159,13 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
             for (int j = 0; j < G::GA; ++j) {
                 const int src = am[j] + T.shift;
                 const bool ok = (unsigned)(src - alo[j]) < alen[j];
-                pa[j] = ok ? Ab + ((size_t)src * (size_t)T.lda_p + kskip) * 128 + coff : zline;
-                ia[j] = ok ? 128u : 0u;
+                if (T.a_chunk_stride) {  // chunk-major A planes: consecutive rows of one chunk are consecutive 128-byte lines
+                    pa[j] = ok ? Ab + (size_t)src * 128 + (size_t)kskip * (size_t)T.a_chunk_stride + coff : zline;
+                    ia[j] = ok ? (unsigned)T.a_chunk_stride : 0u;
+                } else {
+                    pa[j] = ok ? Ab + ((size_t)src * (size_t)T.lda_p + kskip) * 128 + coff : zline;
+                    ia[j] = ok ? 128u : 0u;
+                }
             }
 #pragma unroll
             for (int j = 0; j < G::GB; ++j) {
@@ -538,6 +543,13 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
 //   phase 2    o = g [W_out ; W_skip]^T  (2 chunks; W_os was staged in LDS by the compute waves while the loaders filled the ring)
 //   epilogue 2 x_out = (o[:, :64] + b_out + x) * sqrt(0.5) as planes (a SECOND buffer: neighbouring workgroups still read x for their taps),
 //              skips (+)= o[:, 64:] + b_skip.  HBM traffic per sample and layer: x 256 B in (+ halo) + 256 B out, aux 384 B, skips 512 B.
+// tanh(a) * sigmoid(b) = (1 - e^-2a) / ((1 + e^-2a) (1 + e^-b)): two exponentials and one division (the clamp keeps e^-2a finite; tanh is +-1 to
+// fp32 precision beyond |a| = 10)
+__device__ __forceinline__ float pwg_gate(float a, float b) {
+    const float ea = __expf(-2.0f * fminf(fmaxf(a, -10.f), 10.f)), eb = __expf(-fmaxf(b, -80.f));
+    return __fdividef(1.0f - ea, (1.0f + ea) * (1.0f + eb));
+}
+
 struct PwgFusedArgs {
     GemmTerm term[4];
     int nterms, M;
@@ -546,6 +558,7 @@ struct PwgFusedArgs {
     const u16 *w_os_p, *xp_in;
     u16* xp_out;
     float* skips;
+    long long xcs;  // chunk stride of the x planes in uint16 elements (= M * 64): x is stored chunk-major
     int first;
     int dbg;  // developer timing aid (FCL_PWG_DBG): 1 / 2 / 3 = return after the main loop / the gate / phase 2 (results are then garbage)
 };
@@ -595,6 +608,28 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
                 if (!HI) wl[c][tn] = *reinterpret_cast<const s16x8*>(w + 32);
             }
     }
+    // final-epilogue operands (the old x planes and the skip accumulator of this thread's items) are requested NOW: their latency hides behind the
+    // gate and phase 2
+    constexpr int ITEMS = BM * 8 / G::CTHREADS;
+    const int rows = min(BM, a.M - m0);
+    uint4 pxh[ITEMS], pxl[ITEMS];
+    f32x4 ps0[ITEMS], ps1[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int i = tid + it * G::CTHREADS, r = i >> 3, c0 = (i & 7) * 8;
+        pxh[it] = pxl[it] = make_uint4(0, 0, 0, 0);
+        ps0[it] = ps1[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            const size_t m = (size_t)(m0 + r);
+            const size_t lo_off = (size_t)(c0 >> 5) * a.xcs + m * 64 + (c0 & 31);
+            pxh[it] = *reinterpret_cast<const uint4*>(a.xp_in + lo_off);
+            pxl[it] = *reinterpret_cast<const uint4*>(a.xp_in + lo_off + 32);
+            if (!a.first) {
+                ps0[it] = *reinterpret_cast<const f32x4*>(a.skips + m * 64 + c0);
+                ps1[it] = *reinterpret_cast<const f32x4*>(a.skips + m * 64 + c0 + 4);
+            }
+        }
+    }
     float* zt = reinterpret_cast<float*>(smem);
     if (a.dbg == 1) {
         if (acc[0][0][0] == 12345.f) a.skips[0] = 1.f;
@@ -614,10 +649,12 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
     for (int i = tid; i < BM * 8; i += G::CTHREADS) {  // gate: 8 columns per item -> one hi and one lo piece of the A planes
         const int r = i >> 3, p = i & 7, c0 = p * 8;
         f32x4 v0, v1;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(zt + r * LDT + c0), a1 = *reinterpret_cast<const f32x4*>(zt + r * LDT + c0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0), b1 = *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v0[e] = tanhf(zt[r * LDT + c0 + e]) * (1.0f / (1.0f + __expf(-zt[r * LDT + 64 + c0 + e])));
-            v1[e] = tanhf(zt[r * LDT + c0 + 4 + e]) * (1.0f / (1.0f + __expf(-zt[r * LDT + 64 + c0 + 4 + e])));
+            v0[e] = pwg_gate(a0[e], b0[e]);
+            v1[e] = pwg_gate(a1[e], b1[e]);
         }
         uint2 h0, l0, h1, l1;
         split4(v0, h0, l0);
@@ -676,13 +713,13 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
             for (int r = 0; r < 4; ++r) zt[((wm * TM + tm) * 16 + rq * 4 + r) * LDT + cn] = acc[tm][tn][r] + b;
         }
     __syncthreads();
-    const int rows = min(BM, a.M - m0);
-    for (int i = tid; i < rows * 8; i += G::CTHREADS) {
-        const int r = i >> 3, p = i & 7, c0 = p * 8;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int i = tid + it * G::CTHREADS, r = i >> 3, c0 = (i & 7) * 8;
+        if (r >= rows) continue;
         const size_t m = (size_t)(m0 + r);
-        const size_t lo_off = (m * 2 + (c0 >> 5)) * 64 + (c0 & 31);
-        const uint4 xh = *reinterpret_cast<const uint4*>(a.xp_in + lo_off), xl = *reinterpret_cast<const uint4*>(a.xp_in + lo_off + 32);
-        const unsigned hw[4] = {xh.x, xh.y, xh.z, xh.w}, lw_[4] = {xl.x, xl.y, xl.z, xl.w};
+        const size_t lo_off = (size_t)(c0 >> 5) * a.xcs + m * 64 + (c0 & 31);
+        const unsigned hw[4] = {pxh[it].x, pxh[it].y, pxh[it].z, pxh[it].w}, lw_[4] = {pxl[it].x, pxl[it].y, pxl[it].z, pxl[it].w};
         f32x4 v0, v1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {  // element 2e (low half-word) and 2e + 1 (high half-word) of the piece
@@ -697,13 +734,8 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
         *reinterpret_cast<uint4*>(a.xp_out + lo_off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
         *reinterpret_cast<uint4*>(a.xp_out + lo_off + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         float* sk = a.skips + m * 64 + c0;
-        f32x4 s0 = *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0), s1 = *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0 + 4);
-        if (!a.first) {
-            s0 += *reinterpret_cast<const f32x4*>(sk);
-            s1 += *reinterpret_cast<const f32x4*>(sk + 4);
-        }
-        *reinterpret_cast<f32x4*>(sk) = s0;
-        *reinterpret_cast<f32x4*>(sk + 4) = s1;
+        *reinterpret_cast<f32x4*>(sk) = ps0[it] + *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0);
+        *reinterpret_cast<f32x4*>(sk + 4) = ps1[it] + *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0 + 4);
     }
 }
 
@@ -728,19 +760,21 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
     for (int j = 0; j < L.ksize; ++j) {
         a.term[j].K = R;
         a.term[j].shift = (j - (L.ksize - 1) / 2) * L.dilation;
-        a.term[j].Ap = L.xp; a.term[j].lda_p = ldx;
+        a.term[j].Ap = L.xp; a.term[j].lda_p = ldx; a.term[j].a_chunk_stride = (int64_t)L.m * 128;  // the one-launch block keeps x and aux chunk-major
         a.term[j].Wp = L.w_conv_p + (size_t)j * 2 * R * ldx * 64; a.term[j].ldw_p = ldx;
     }
     a.term[L.ksize].K = L.aux;
-    a.term[L.ksize].Ap = L.cp; a.term[L.ksize].lda_p = ldc;
+    a.term[L.ksize].Ap = L.cp; a.term[L.ksize].lda_p = ldc; a.term[L.ksize].a_chunk_stride = (int64_t)L.m * 128;
     a.term[L.ksize].Wp = L.w_aux_p; a.term[L.ksize].ldw_p = ldc;
     a.nterms = L.ksize + 1;
     a.M = (int)L.m;
     a.seg_lo = L.seg_lo; a.seg_hi = L.seg_hi;
     a.b_conv = L.b_conv; a.b_os = L.b_os; a.w_os_p = L.w_os_p;
     a.xp_in = L.xp; a.xp_out = L.xp_out; a.skips = L.skips; a.first = L.first_layer;
-    static const int dbg = tunable("PWG_DBG", 0);
+    a.xcs = (long long)L.m * 64;
+    static const int dbg = tunable("PWG_DBG", 0), exp_terms = tunable("PWG_EXP_TERMS", 0);
     a.dbg = dbg;
+    if (exp_terms > 0) a.nterms = exp_terms;  // developer timing aid: fewer K-terms (results are then garbage)
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
     const double flops = 2.0 * (double)L.m * 2.0 * R * ((double)L.ksize * R + L.aux + R);
     // measured on MI355X, 64 x 800 frames, ms per layer: 128-row tiles + 3-deep ring + W_os in LDS 7.07 (default); the same with a 4-deep ring and

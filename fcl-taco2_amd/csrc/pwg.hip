@@ -23,7 +23,7 @@ typedef unsigned short u16;
 __global__ __launch_bounds__(256) void pwg_upsample_stage_kernel(const float* __restrict__ in, const int* __restrict__ frame_utt,
                                                                  const int* __restrict__ utt_off, long long rows_out, int rate_in, int scale,
                                                                  const float* __restrict__ w, float* __restrict__ out, u16* __restrict__ out_p, int ldp,
-                                                                 int C) {
+                                                                 int C, int chunk_major) {
     const int cpad = out_p ? ldp * 32 : C;
     const long long total = rows_out * cpad;
     const int rate_out = rate_in * scale;
@@ -41,20 +41,24 @@ __global__ __launch_bounds__(256) void pwg_upsample_stage_kernel(const float* __
             }
             if (out) out[r * C + c] = acc;
         }
-        if (out_p) store_p32(out_p + (size_t)r * ldp * 64, ldp, 0, c, acc);
+        if (out_p) {
+            if (chunk_major) store_p32(out_p + ((size_t)(c >> 5) * rows_out + r) * 64, 1, 0, c & 31, acc);  // line (chunk, row)
+            else store_p32(out_p + (size_t)r * ldp * 64, ldp, 0, c, acc);
+        }
     }
 }
 
 // first_conv: x[m, ch] = w[ch] * z[m] + b[ch]  (Conv1d1x1(1 -> R))
 __global__ __launch_bounds__(256) void pwg_first_conv_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b,
-                                                             float* __restrict__ x, u16* __restrict__ xp, long long M, int R) {
+                                                             float* __restrict__ x, u16* __restrict__ xp, long long M, int R, int chunk_major) {
     const long long total = M * R;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long m = i / R;
         const int ch = (int)(i - m * R);
         const float v = w[ch] * z[m] + b[ch];
-        x[i] = v;
-        store_p32(xp + (size_t)m * (R >> 5) * 64, R >> 5, 0, ch, v);
+        if (x) x[i] = v;
+        if (chunk_major) store_p32(xp + ((size_t)(ch >> 5) * M + m) * 64, 1, 0, ch & 31, v);
+        else store_p32(xp + (size_t)m * (R >> 5) * 64, R >> 5, 0, ch, v);
     }
 }
 
@@ -131,14 +135,14 @@ using namespace fcl;
 extern "C" {
 
 int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int32_t* utt_off, int64_t frames, int rate_in, int scale, const float* w,
-                           float* out, uint16_t* out_p, int c, fcl_stream_t stream) {
+                           float* out, uint16_t* out_p, int c, int chunk_major, fcl_stream_t stream) {
     FCL_REQUIRE(in && frame_utt && utt_off && w && (out || out_p) && frames > 0 && rate_in >= 1 && scale >= 1 && c > 0, FCL_ERR_INVALID,
                 "pwg_upsample_stage: bad arguments");
     FCL_REQUIRE((reinterpret_cast<uintptr_t>(out_p) & 127u) == 0, FCL_ERR_ALIGN, "pwg_upsample_stage: planes must be 128-byte aligned");
     const long long rows_out = (long long)frames * rate_in * scale;
     const int ldp = (c + 31) / 32;
     hipLaunchKernelGGL(pwg_upsample_stage_kernel, dim3(grid_1d(rows_out * (out_p ? ldp * 32 : c), 256)), dim3(256), 0, (hipStream_t)stream, in, frame_utt, utt_off,
-                       rows_out, rate_in, scale, w, out, out_p, ldp, c);
+                       rows_out, rate_in, scale, w, out, out_p, ldp, c, chunk_major);
     return check_hip(hipGetLastError(), "pwg_upsample_stage");
 }
 
@@ -148,9 +152,9 @@ int fcl_pwg_noise(float* z, int64_t n, uint32_t seed, fcl_stream_t stream) {
     return check_hip(hipGetLastError(), "pwg_noise");
 }
 
-int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x, uint16_t* xp, int64_t m, int r, fcl_stream_t stream) {
-    FCL_REQUIRE(z && w && b && x && xp && m > 0 && r > 0 && (r & 31) == 0, FCL_ERR_INVALID, "pwg_first_conv: bad arguments (R must be a multiple of 32)");
-    hipLaunchKernelGGL(pwg_first_conv_kernel, dim3(grid_1d(m * r, 1024)), dim3(256), 0, (hipStream_t)stream, z, w, b, x, xp, (long long)m, r);
+int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x, uint16_t* xp, int64_t m, int r, int chunk_major, fcl_stream_t stream) {
+    FCL_REQUIRE(z && w && b && xp && m > 0 && r > 0 && (r & 31) == 0, FCL_ERR_INVALID, "pwg_first_conv: bad arguments (R must be a multiple of 32)");
+    hipLaunchKernelGGL(pwg_first_conv_kernel, dim3(grid_1d(m * r, 1024)), dim3(256), 0, (hipStream_t)stream, z, w, b, x, xp, (long long)m, r, chunk_major);
     return check_hip(hipGetLastError(), "pwg_first_conv");
 }
 

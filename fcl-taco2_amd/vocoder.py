@@ -54,10 +54,11 @@ def fold_weight_norm(sd):
     return out
 
 
-def unpack_planes(p, cols):
-    """fp32 value hi + lo of a P32 plane buffer [rows, ceil(cols/32) * 64] (tests / debugging: plain tensor reshuffling, no arithmetic kernel of ours)."""
+def unpack_planes(p, cols, chunk_major=False):
+    """fp32 value hi + lo of a P32 plane buffer [rows, ceil(cols/32) * 64], row-major or chunk-major ([chunk][row] lines) (tests / debugging: plain
+    tensor reshuffling, no arithmetic kernel of ours)."""
     rows = p.shape[0]
-    v = p.reshape(rows, -1, 2, 32).to(torch.int32)
+    v = (p.reshape(-1, rows, 2, 32).permute(1, 0, 2, 3) if chunk_major else p.reshape(rows, -1, 2, 32)).to(torch.int32)
     f = lambda t: (t << 16).view(torch.float32)
     return (f(v[:, :, 0]) + f(v[:, :, 1])).reshape(rows, -1)[:, :cols].contiguous()
 
@@ -108,25 +109,46 @@ class ParallelWaveGANGenerator(object):
 
     def __init__(self, plan):
         self.plan = plan
+        self._maps_cache = {}
+
+    # ---- integer index maps of a batch shape (host-built once per tuple of utterance lengths, cached) -------------------------------------------
+    def _maps(self, lens):
+        key = tuple(lens)
+        hit = self._maps_cache.get(key)
+        if hit is not None:
+            return hit
+        pl, dev = self.plan, self.plan.device
+        ctx = pl.cfg["aux_context_window"]
+        lens_np = np.asarray(lens, dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens_np)]).astype(np.int64)
+        pad_idx, lo, hi, keep = [], [], [], []
+        base = 0
+        for u, n in enumerate(lens):  # padded utterance = frames clamp(-ctx .. n-1+ctx); conv_in is 'valid', i.e. 'same' evaluated on the interior
+            pad_idx.append(offs[u] + np.clip(np.arange(-ctx, n + ctx), 0, n - 1))
+            lo.append(np.full(n + 2 * ctx, base))
+            hi.append(np.full(n + 2 * ctx, base + n + 2 * ctx))
+            keep.append(np.arange(base + ctx, base + ctx + n))
+            base += n + 2 * ctx
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        m = dict(offs=offs, pad_idx=i32(np.concatenate(pad_idx)), lo=i32(np.concatenate(lo)), hi=i32(np.concatenate(hi)), keep=i32(np.concatenate(keep)),
+                 frame_utt=i32(np.repeat(np.arange(len(lens)), lens_np)), utt_off=i32(offs))
+        s_off = torch.from_numpy(offs * pl.hop).to(dev)
+        reps = torch.from_numpy(lens_np * pl.hop).to(dev)
+        m["seg_lo"] = torch.repeat_interleave(s_off[:-1], reps).to(torch.int32)  # sample range of each row's utterance (integers only)
+        m["seg_hi"] = torch.repeat_interleave(s_off[1:], reps).to(torch.int32)
+        if len(self._maps_cache) >= 4:
+            self._maps_cache.clear()
+        self._maps_cache[key] = m
+        return m
 
     # ---- feature side: replicate padding + conv_in at frame rate, then 4 x (stretch + smoothing) to sample rate --------------------------------
-    def _upsample(self, mel_rows, lens):
+    def _upsample(self, mel_rows, mp, chunk_major):
         pl, dev = self.plan, self.plan.device
-        ctx, A = pl.cfg["aux_context_window"], pl.A
-        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-        pad_idx, lo, hi, keep = [], [], [], []
-        for u, n in enumerate(lens):  # padded utterance = frames clamp(-ctx .. n-1+ctx); conv_in is 'valid', i.e. 'same' evaluated on the interior
-            base = len(pad_idx)
-            pad_idx.extend(offs[u] + np.clip(np.arange(-ctx, n + ctx), 0, n - 1))
-            lo.extend([base] * (n + 2 * ctx))
-            hi.extend([base + n + 2 * ctx] * (n + 2 * ctx))
-            keep.extend(range(base + ctx, base + ctx + n))
-        i32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(dev)
-        c_pad = ops.gather_rows(mel_rows, i32(pad_idx))
-        c_in = ops.conv1d(c_pad, pl.conv_in, None, i32(lo), i32(hi))
-        c = ops.gather_rows(c_in, i32(keep))  # [sum T', A]
-        frames = int(offs[-1])
-        frame_utt, utt_off = i32(np.repeat(np.arange(len(lens)), lens)), i32(offs)
+        A = pl.A
+        c_pad = ops.gather_rows(mel_rows, mp["pad_idx"])
+        c_in = ops.conv1d(c_pad, pl.conv_in, None, mp["lo"], mp["hi"])
+        c = ops.gather_rows(c_in, mp["keep"])  # [sum T', A]
+        frames = int(mp["offs"][-1])
         rate, lib = 1, _lib.load()
         n_st = len(pl.up_w)
         cp = None
@@ -135,25 +157,35 @@ class ParallelWaveGANGenerator(object):
             rows = frames * rate * s
             out = None if last else torch.empty(rows, A, device=dev)
             cp = ops.planes_empty(rows, A, dev) if last else None
-            _lib.check(lib.fcl_pwg_upsample_stage(c.data_ptr(), frame_utt.data_ptr(), utt_off.data_ptr(), frames, rate, s, pl.up_w[i].data_ptr(),
-                                                  None if out is None else out.data_ptr(), None if cp is None else cp.data_ptr(), A, ops._stream()))
+            _lib.check(lib.fcl_pwg_upsample_stage(c.data_ptr(), mp["frame_utt"].data_ptr(), mp["utt_off"].data_ptr(), frames, rate, s, pl.up_w[i].data_ptr(),
+                                                  None if out is None else out.data_ptr(), None if cp is None else cp.data_ptr(), A, int(chunk_major), ops._stream()))
             c, rate = out, rate * s
-        return cp, offs
+        return cp
 
     def synthesize(self, mels, noise=None, seed=0, return_intermediates=False):
         """mels: list of [T'_i, aux] float tensors / arrays.  noise: optional list of [T'_i * hop] arrays (else drawn on the device from `seed`).
         Returns a list of [T'_i * hop] float32 device tensors."""
+        dev = self.plan.device
+        with torch.cuda.device(dev):
+            lens = [int(m.shape[0]) for m in mels]
+            mel_rows = torch.cat([torch.as_tensor(m, dtype=torch.float32).to(dev) for m in mels]).contiguous()
+            return self.synthesize_packed(mel_rows, lens, noise, seed, return_intermediates)
+
+    def synthesize_packed(self, mel_rows, lens, noise=None, seed=0, return_intermediates=False):
+        """The same on utterances already packed row-wise ([sum T', aux] device tensor, e.g. engine.run's output) with their frame counts."""
         pl, dev = self.plan, self.plan.device
         lib = _lib.load()
         with torch.cuda.device(dev):
-            lens = [int(m.shape[0]) for m in mels]
-            if min(lens) < 1:
+            lens = [int(n) for n in lens]
+            if not lens or min(lens) < 1:
                 raise _lib.FclError("fcl-taco2_amd: empty mel")
-            mel_rows = torch.cat([torch.as_tensor(m, dtype=torch.float32).to(dev) for m in mels]).contiguous()
-            if mel_rows.shape[1] != pl.A:
-                raise _lib.FclError("fcl-taco2_amd: expected %d mel channels, got %d" % (pl.A, mel_rows.shape[1]))
-            cp, offs = self._upsample(mel_rows, lens)
+            if mel_rows.dim() != 2 or mel_rows.shape[1] != pl.A or mel_rows.shape[0] != sum(lens):
+                raise _lib.FclError("fcl-taco2_amd: expected [%d, %d] mel rows, got %r" % (sum(lens), pl.A, tuple(mel_rows.shape)))
+            mp = self._maps(lens)
+            offs = mp["offs"]
             M, R = int(offs[-1]) * pl.hop, pl.R
+            fused = R == 64 and pl.k == 3 and pl.A <= 96 and os.environ.get("FCL_PWG_FUSED", "1") != "0"  # one launch per residual block
+            cp = self._upsample(mel_rows, mp, fused)  # the one-launch block reads chunk-major planes (contiguous rows per 32-column chunk)
             if M >= 2 ** 31:
                 raise _lib.FclError("fcl-taco2_amd: more than 2^31 samples in one vocoder batch")
             if noise is None:
@@ -163,14 +195,11 @@ class ParallelWaveGANGenerator(object):
                 z = torch.cat([torch.as_tensor(n_, dtype=torch.float32).reshape(-1).to(dev) for n_ in noise]).contiguous()
                 if z.numel() != M:
                     raise _lib.FclError("fcl-taco2_amd: noise must hold T' * %d samples per utterance" % pl.hop)
-            s_off = torch.from_numpy((offs * pl.hop).astype(np.int64)).to(dev)
-            reps = torch.from_numpy(np.asarray(lens, dtype=np.int64) * pl.hop).to(dev)
-            seg_lo = torch.repeat_interleave(s_off[:-1], reps).to(torch.int32)  # index maps (integers): sample range of each row's utterance
-            seg_hi = torch.repeat_interleave(s_off[1:], reps).to(torch.int32)
+            seg_lo, seg_hi = mp["seg_lo"], mp["seg_hi"]
             x, xp = torch.empty(M, R, device=dev), ops.planes_empty(M, R, dev)
-            _lib.check(lib.fcl_pwg_first_conv(z.data_ptr(), pl.first_w.data_ptr(), pl.first_b.data_ptr(), x.data_ptr(), xp.data_ptr(), M, R, ops._stream()))
+            _lib.check(lib.fcl_pwg_first_conv(z.data_ptr(), pl.first_w.data_ptr(), pl.first_b.data_ptr(), x.data_ptr(), xp.data_ptr(), M, R, int(fused),
+                                              ops._stream()))
             skips = torch.empty(M, R, device=dev)
-            fused = R == 64 and pl.k == 3 and pl.A <= 96 and os.environ.get("FCL_PWG_FUSED", "1") != "0"  # one launch per residual block
             gp = ops.planes_empty(M, R, dev)  # unfused: the gate's planes; fused: the second x buffer (blocks ping-pong between xp and gp)
             zbuf = obuf = None
             if not fused:
@@ -191,7 +220,7 @@ class ParallelWaveGANGenerator(object):
                 if fused:
                     xp, gp = gp, xp
                 if return_intermediates:
-                    taps.append(unpack_planes(xp, R) if fused else x.clone())
+                    taps.append(unpack_planes(xp, R, chunk_major=True) if fused else x.clone())
             wav = torch.empty(M, device=dev)
             _lib.check(lib.fcl_pwg_last_fwd(skips.data_ptr(), math.sqrt(1.0 / len(pl.layers)), pl.last_w1p.data_ptr(), pl.last_b1.data_ptr(),
                                             pl.last_w2.data_ptr(), pl.last_b2, gp.data_ptr(), x.data_ptr(), wav.data_ptr(), M, pl.S, ops._stream()))

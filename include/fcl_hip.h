@@ -170,6 +170,9 @@ typedef struct {
     const uint16_t* Ap;  /* optional P32 planes of A and of W (fcl_pack_planes layout; see "bf16x3 operand planes" above): when EVERY term of a */
     const uint16_t* Wp;  /* call carries both, the contraction runs on the LDS-DMA kernels of gemm_planes.hip and A / W may be NULL */
     int lda_p, ldw_p;    /* row strides of the planes in 128-byte lines (>= ceil(K / 32)) */
+    int64_t a_chunk_stride; /* 0: Ap is row-major as above.  != 0: CHUNK-MAJOR planes of A -- line (row m, 32-column chunk c) at byte offset
+                             * c * a_chunk_stride + m * 128 (lda_p unused): a tile's rows of one chunk are one contiguous stream, which is what
+                             * the vocoder's sample-major activations use (DRAM-friendly: [chunk][row] instead of [row][chunk]) */
 } fcl_gemm_term_t;
 
 typedef struct {
@@ -471,11 +474,12 @@ int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries);
  * in [frames * rate_in, c] -> out [frames * rate_in * scale, c] fp32 and / or out_p (P32 planes, ceil(c/32) lines per row, zero past c).
  * frame_utt [frames]: utterance of each mel frame; utt_off [n_utt + 1]: first frame of each utterance. */
 int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int32_t* utt_off, int64_t frames, int rate_in, int scale, const float* w,
-                           float* out, uint16_t* out_p, int c, fcl_stream_t stream);
+                           float* out, uint16_t* out_p, int c, int chunk_major /* out_p as [chunk][row] lines (fcl_gemm_term_t.a_chunk_stride) */,
+                           fcl_stream_t stream);
 /* The generator's input noise z ~ N(0, 1) (ParallelWaveGANGenerator.inference draws torch.randn): counter-based, reproducible per (seed, index). */
 int fcl_pwg_noise(float* z, int64_t n, uint32_t seed, fcl_stream_t stream);
-/* first_conv (Conv1d1x1 1 -> r): x[m, ch] = w[ch] * z[m] + b[ch], written as fp32 and as planes. */
-int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x, uint16_t* xp, int64_t m, int r, fcl_stream_t stream);
+/* first_conv (Conv1d1x1 1 -> r): x[m, ch] = w[ch] * z[m] + b[ch], written as fp32 (optional) and as planes (row-major or chunk-major). */
+int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x, uint16_t* xp, int64_t m, int r, int chunk_major, fcl_stream_t stream);
 /* One residual block (ResidualBlock.forward): dilated Conv1d(r -> 2r, ksize, dilation) + conv1x1_aux(aux -> 2r) as ONE GEMM of ksize + 1 K-terms,
  * tanh * sigmoid gate, conv1x1_out / conv1x1_skip as one GEMM, x = (out + x) * sqrt(0.5), skips += skip (= skip when first_layer). */
 typedef struct {
@@ -498,7 +502,8 @@ typedef struct {
     uint16_t* gp;              /*             planes [m, r] */
     float* o;                  /*             [m, 2r] fp32 */
     uint16_t* xp_out;          /* != NULL: the block runs as ONE launch (r = 64, ksize = 3, aux <= 96 only) that reads x from xp and writes the new
-                                * planes to xp_out (a different buffer: neighbouring tiles still read xp for their taps); x, z, gp, o are unused */
+                                * planes to xp_out (a different buffer: neighbouring tiles still read xp for their taps); x, z, gp, o are unused.
+                                * In this form xp, xp_out and cp are CHUNK-MAJOR planes (line (chunk c, row m) at c * m_total * 128 + m * 128 bytes) */
 } fcl_pwg_layer_t;
 int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
 /* last_conv_layers: wav[m] = relu(relu(skips * scale) W1^T + b1) . w2 + b2.  yp: workspace planes [m, s_ch]; h: workspace fp32 [m, s_ch]. */
