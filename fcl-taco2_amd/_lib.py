@@ -88,6 +88,7 @@ class ProfEntry(C.Structure):
 SIGNATURES = {
     "fcl_last_error": (C.c_char_p, []),
     "fcl_version": (_I, []),
+    "fcl_debug_ptr": (_P, []),
     "fcl_set_gemm_mode": (_I, [_I]),
     "fcl_get_gemm_mode": (_I, []),
     "fcl_pack_conv1d_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),

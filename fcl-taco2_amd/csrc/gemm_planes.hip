@@ -550,6 +550,12 @@ __device__ __forceinline__ float pwg_gate(float a, float b) {
     return __fdividef(1.0f - ea, (1.0f + ea) * (1.0f + eb));
 }
 
+void* g_debug_ptr = nullptr;
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the epilogue operands prefetched
+// from global memory right after the main loop (their latency is meant to hide behind the gate and phase 2)
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct PwgFusedArgs {
     GemmTerm term[4];
     int nterms, M;
@@ -559,6 +565,7 @@ struct PwgFusedArgs {
     u16* xp_out;
     float* skips;
     long long xcs;  // chunk stride of the x planes in uint16 elements (= M * 64): x is stored chunk-major
+    long long* ts;  // developer aid (FCL_PWG_TS): 8 wall-clock stamps (10 ns units) per workgroup
     int first;
     int dbg;  // developer timing aid (FCL_PWG_DBG): 1 / 2 / 3 = return after the main loop / the gate / phase 2 (results are then garbage)
 };
@@ -579,6 +586,8 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
     xcd_tile_p(bx, by);
     const int m0 = by * BM;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define PWG_STAMP(k) do { if (a.ts && tid == 0) a.ts[(size_t)by * 8 + (k)] = (long long)wall_clock64(); } while (0)
+    PWG_STAMP(0);
     if (WLDS && wave < G::NW) {  // W_os [128, 64] planes -> LDS, two 16 KB chunks in the ring's layout (piece p of row n at slot p ^ ((n >> 1) & 7))
         for (int i = tid; i < 2048; i += G::CTHREADS) {
             const int n = i >> 4, c = (i >> 3) & 1, p = i & 7;
@@ -586,6 +595,14 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
             *reinterpret_cast<uint4*>(smem + WOS + c * 16384 + n * 128 + ((p ^ ((n >> 1) & 7)) << 4)) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    PWG_STAMP(1);
+    float bz[TN], bo[TN];  // this lane's bias columns of both GEMMs, requested before the main loop
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int cn = (((tid >> 6) % WN) * TN + tn) * 16 + (tid & 15);
+        bz[tn] = a.b_conv[cn];
+        bo[tn] = a.b_os[cn];
     }
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -630,22 +647,24 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
             }
         }
     }
+    PWG_STAMP(2);
     float* zt = reinterpret_cast<float*>(smem);
     if (a.dbg == 1) {
         if (acc[0][0][0] == 12345.f) a.skips[0] = 1.f;
         return;
     }
-    __syncthreads();  // every compute wave is done with the ring
+    lds_sync();  // every compute wave is done with the ring
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int cn = (wn * TN + tn) * 16 + col;
-            const float b = a.b_conv[cn];
+            const float b = bz[tn];
 #pragma unroll
             for (int r = 0; r < 4; ++r) zt[((wm * TM + tm) * 16 + rq * 4 + r) * LDT + cn] = acc[tm][tn][r] + b;
         }
-    __syncthreads();
+    lds_sync();
+    PWG_STAMP(6);
     for (int i = tid; i < BM * 8; i += G::CTHREADS) {  // gate: 8 columns per item -> one hi and one lo piece of the A planes
         const int r = i >> 3, p = i & 7, c0 = p * 8;
         f32x4 v0, v1;
@@ -664,7 +683,8 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
         *reinterpret_cast<uint4*>(base + ((piece ^ sws) << 4)) = make_uint4(h0.x, h0.y, h1.x, h1.y);
         *reinterpret_cast<uint4*>(base + (((4 + piece) ^ sws) << 4)) = make_uint4(l0.x, l0.y, l1.x, l1.y);
     }
-    __syncthreads();
+    lds_sync();
+    PWG_STAMP(3);
     if (a.dbg == 2) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -697,22 +717,23 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
             }
         }
     }
+    PWG_STAMP(4);
     if (a.dbg == 3) {
         if (acc[0][0][0] == 12345.f) a.skips[0] = 1.f;
         return;
     }
-    if (!WLDS) __syncthreads();  // GA sits in the ring next to the staging tile's rows: everyone has read its fragments before o is staged
+    if (!WLDS) lds_sync();  // GA sits in the ring next to the staging tile's rows: everyone has read its fragments before o is staged
     // (WLDS: zt is free since the gate pass, phase 2 reads GA / WOS only)
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int cn = (wn * TN + tn) * 16 + col;
-            const float b = a.b_os[cn];
+            const float b = bo[tn];
 #pragma unroll
             for (int r = 0; r < 4; ++r) zt[((wm * TM + tm) * 16 + rq * 4 + r) * LDT + cn] = acc[tm][tn][r] + b;
         }
-    __syncthreads();
+    lds_sync();
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int i = tid + it * G::CTHREADS, r = i >> 3, c0 = (i & 7) * 8;
@@ -737,6 +758,8 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
         *reinterpret_cast<f32x4*>(sk) = ps0[it] + *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0);
         *reinterpret_cast<f32x4*>(sk + 4) = ps1[it] + *reinterpret_cast<const f32x4*>(zt + r * LDT + 64 + c0 + 4);
     }
+    PWG_STAMP(5);
+#undef PWG_STAMP
 }
 
 template <int WM, int NST, bool HI>
@@ -772,8 +795,14 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
     a.b_conv = L.b_conv; a.b_os = L.b_os; a.w_os_p = L.w_os_p;
     a.xp_in = L.xp; a.xp_out = L.xp_out; a.skips = L.skips; a.first = L.first_layer;
     a.xcs = (long long)L.m * 64;
-    static const int dbg = tunable("PWG_DBG", 0), exp_terms = tunable("PWG_EXP_TERMS", 0);
+    static const int dbg = tunable("PWG_DBG", 0), exp_terms = tunable("PWG_EXP_TERMS", 0), want_ts = tunable("PWG_TS", 0);
     a.dbg = dbg;
+    static long long* ts_buf = nullptr;
+    if (want_ts) {  // developer aid: one stamp buffer for the process, dumped by tools/pwg_stamps.py through fcl_debug_ptr
+        if (!ts_buf && hipMalloc(&ts_buf, sizeof(long long) * 8 * ((L.m + 127) / 128 + 1)) != hipSuccess) ts_buf = nullptr;
+        a.ts = ts_buf;
+        g_debug_ptr = ts_buf;
+    }
     if (exp_terms > 0) a.nterms = exp_terms;  // developer timing aid: fewer K-terms (results are then garbage)
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
     const double flops = 2.0 * (double)L.m * 2.0 * R * ((double)L.ksize * R + L.aux + R);
@@ -837,6 +866,8 @@ size_t fcl_planes_elems(int rows, int cols) {
     if (rows <= 0 || cols <= 0) return 0;
     return (size_t)rows * ((cols + 31) / 32) * 64;
 }
+
+void* fcl_debug_ptr(void) { return fcl::g_debug_ptr; }
 
 int fcl_pack_planes_t(const float* x, int ld, int rows, int cols, int ntaps, int shift0, const int32_t* seg_lo, const int32_t* seg_hi, uint16_t* out,
                       fcl_stream_t stream) {

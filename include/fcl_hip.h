@@ -46,6 +46,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 
 const char* fcl_last_error(void);
 int fcl_version(void);
+void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
 int fcl_get_gemm_mode(void);
 
