@@ -82,3 +82,24 @@ def test_plan_refuses_cpu_device():
         SynthesisPlan(SYN.closed_form_state_dict(HP.param_spec(hp)), hp, "cpu")
     with pytest.raises(NotImplementedError):
         HP.student_hparams(reduction_factor=2).check_supported()
+
+
+def test_round2_entry_points_validate_arguments_without_a_gpu(lib):
+    """Argument validation of the round-2 entry points returns before any HIP call: GEMM arithmetic mode, batched operand forms, weight-gradient
+    GEMM on transposed planes, the vocoder block."""
+    from fcl_taco2_amd import _lib
+
+    assert lib.fcl_get_gemm_mode() == _lib.GEMM_F32
+    assert lib.fcl_set_gemm_mode(7) == -1 and b"unknown mode" in lib.fcl_last_error()
+    assert lib.fcl_set_gemm_mode(_lib.GEMM_BF16) == 0 and lib.fcl_get_gemm_mode() == _lib.GEMM_BF16
+    assert lib.fcl_set_gemm_mode(_lib.GEMM_F32) == 0
+    assert lib.fcl_derive_blocks(5, 40, 24) == ((5 * 40 + 31) // 32) * 1 and lib.fcl_derive_blocks(0, 4, 4) == 0
+    assert lib.fcl_derive_batch(None, 3, 10, None) == -1  # a table is required
+    assert lib.fcl_derive_batch(None, 0, 0, None) == 0    # nothing to do
+    assert lib.fcl_pack_planes_t(None, 4, 4, 4, 1, 0, None, None, None, None) == -1
+    assert lib.fcl_gemm_tn_planes(128, 128, 128, 8, 100, 8, 12, 5, 0, None) == -2 and b"nblk" in lib.fcl_last_error()  # nblk must be a multiple of 4 dividing k
+    a = _lib.PwgLayer()
+    assert lib.fcl_pwg_layer_fwd(C.byref(a), None) == -1
+    assert lib.fcl_pwg_noise(None, 16, 1, None) == -1
+    assert lib.fcl_pwg_first_conv(1, 1, 1, None, 128, 16, 48, 0, None) == -1 and b"multiple of 32" in lib.fcl_last_error()
+    assert lib.fcl_debug_ptr() is None
