@@ -762,6 +762,242 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
 #undef PWG_STAMP
 }
 
+// ---- persistent form of the block: one workgroup per CU walks a contiguous run of 128-sample tiles of its XCD.  What it buys over one workgroup per
+// tile: (1) the loader waves request the NEXT tile's segment bounds and first two chunks while the compute waves are still in the epilogue (the
+// 3.7 us of fixed latency in front of a tile's first MFMA disappear), (2) W_os and the biases are staged once per workgroup, not once per tile,
+// (3) no launch gap between tiles.  For (1) the epilogue must stay out of the ring: the gate runs in REGISTERS -- the W tile is loaded with its
+// rows permuted so that a lane holds tanh column c and sigmoid column c of the same sample (tn tiles alternate tanh / sigmoid) -- its result goes
+// straight into the 32 KB gate-plane buffer, and the second GEMM's result is staged in two 64-row halves through that same buffer once phase 2 has
+// read it.  LDS: ring 96 KB | W_os 32 KB | gate planes / o staging 32 KB.
+template <bool HI>
+__global__ __launch_bounds__(640) void pwg_layer_pkernel(const PwgFusedArgs a, const int ntiles) {
+    using G = PGeo<4, 2, 2, 4, 3, 2>;
+    constexpr int TM = 2, TN = 4, WN = 2, BM = 128, NST = 3, NCH = 9;
+    constexpr int WOS = G::LDS_BYTES, GA = WOS + 32768;
+    static_assert(G::BM == BM && G::BN == 128 && G::STAGE == 32768, "tile geometry");
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // tile schedule: XCD x (= workgroup id mod 8) owns a contiguous range of tiles, its workgroups stride through it -> a tile and its +-d
+    // neighbours meet in one L2
+    const int wg = blockIdx.x, nwg = gridDim.x, xcd = wg & 7;
+    const int q = ntiles >> 3, rr = ntiles & 7;
+    const int t_end = xcd * q + min(xcd, rr) + q + (xcd < rr ? 1 : 0);
+    const int per_x = (nwg - xcd + 7) >> 3;
+    int t = xcd * q + min(xcd, rr) + (wg >> 3);
+    if (t >= t_end) return;  // every wave of the workgroup takes the same exit
+
+    if (wave >= G::NW) {  // ------------------------------------------------------------------------------------------------ loader waves
+        const int lw = wave - G::NW;
+        const unsigned coff = (unsigned)(((lane & 7) ^ (((lw & 1) << 2) | (lane >> 4))) * 16);
+        const u8* zline = reinterpret_cast<const u8*>(g_zero_line) + coff;
+        long long brow[G::GB];
+#pragma unroll
+        for (int j = 0; j < G::GB; ++j) {  // tile column c = 64 wn + 16 tn + jj  <-  gate row (tn odd: sigmoid half) 32 wn + 16 (tn / 2) + jj
+            const int c = (j * G::NL + lw) * 8 + (lane >> 3);
+            brow[j] = ((c >> 4) & 1 ? 64 : 0) + 32 * (c >> 6) + 16 * ((c >> 5) & 1) + (c & 15);
+        }
+        int am[G::GA], alo[G::GA];
+        unsigned alen[G::GA];
+        const u8* pa[G::GA];
+        const u8* pb[G::GB];
+        unsigned ia[G::GA];
+        int rem = 0, it = 0, slot = 0;
+        auto setup_term = [&](int ti) {
+            const GemmTerm T = a.term[ti];
+            const u8* Ab = reinterpret_cast<const u8*>(T.Ap);
+            const u8* Wb = reinterpret_cast<const u8*>(T.Wp);
+#pragma unroll
+            for (int j = 0; j < G::GA; ++j) {
+                const int src = am[j] + T.shift;
+                const bool ok = (unsigned)(src - alo[j]) < alen[j];
+                pa[j] = ok ? Ab + (size_t)src * 128 + coff : zline;  // chunk-major A planes
+                ia[j] = ok ? (unsigned)T.a_chunk_stride : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < G::GB; ++j) pb[j] = Wb + (size_t)brow[j] * ((size_t)T.ldw_p * 128) + coff;
+            rem = (T.K + 31) >> 5;
+        };
+        auto begin_tile = [&](int m0) {
+#pragma unroll
+            for (int j = 0; j < G::GA; ++j) {
+                const int m = m0 + (j * G::NL + lw) * 8 + (lane >> 3);
+                am[j] = m;
+                alo[j] = 0;
+                alen[j] = 0u;
+                if (m < a.M) {
+                    alo[j] = a.seg_lo[m];
+                    alen[j] = (unsigned)(a.seg_hi[m] - alo[j]);
+                }
+            }
+            it = 0;
+            setup_term(0);
+        };
+        auto issue = [&]() {
+            u8* sbase = smem + slot * G::STAGE + lw * 1024;
+#pragma unroll
+            for (int j = 0; j < G::GA; ++j) {
+                glds16(pa[j], sbase + j * G::NL * 1024);
+                pa[j] += ia[j];
+            }
+#pragma unroll
+            for (int j = 0; j < G::GB; ++j) {
+                glds16(pb[j], sbase + BM * 128 + j * G::NL * 1024);
+                pb[j] += 128;
+            }
+            if (--rem == 0 && ++it < a.nterms) setup_term(it);
+            slot = slot + 1 == NST ? 0 : slot + 1;
+        };
+        begin_tile(t * BM);
+        issue();
+        issue();
+        while (true) {
+#pragma unroll 1
+            for (int i = 0; i < NCH; ++i) {
+                const int left = NCH - 1 - i;
+                if (left >= 1) wait_vm<G::GPW>();
+                else wait_vm<0>();
+                asm volatile("s_barrier" ::: "memory");
+                if (left >= NST - 1) issue();
+            }
+            const int tn_ = t + per_x;
+            const bool more = tn_ < t_end;
+            if (more) {  // the next tile's bounds and first two chunks travel while the compute waves run this tile's epilogue
+                begin_tile(tn_ * BM);
+                issue();
+                issue();
+            }
+#pragma unroll
+            for (int e = 0; e < 5; ++e) asm volatile("s_barrier" ::: "memory");  // the epilogue's five barriers
+            if (!more) return;
+            t = tn_;
+        }
+    }
+    // -------------------------------------------------------------------------------------------------------------------- compute waves
+    const int wm = wave / WN, wn = wave % WN;
+    const int col = lane & 15, rq = lane >> 4;
+    const int r16 = lane & 15, kq = lane >> 4, sw = r16 >> 1;
+    for (int i = tid; i < 2048; i += G::CTHREADS) {  // W_os [128, 64] planes -> LDS once per workgroup
+        const int n = i >> 4, c = (i >> 3) & 1, p = i & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(a.w_os_p + ((size_t)(n * 2 + c) * 64 + p * 8));
+        *reinterpret_cast<uint4*>(smem + WOS + c * 16384 + n * 128 + ((p ^ ((n >> 1) & 7)) << 4)) = v;
+    }
+    float bz[TN], bo[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        bz[tn] = a.b_conv[((tn & 1) ? 64 : 0) + 32 * wn + 16 * (tn >> 1) + col];  // the permuted gate row of this lane's column
+        bo[tn] = a.b_os[(wn * TN + tn) * 16 + col];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int a_hi = (wm * TM * 16 + r16) * 128 + ((kq ^ sw) << 4), a_lo = (wm * TM * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+    const int b_hi = BM * 128 + (wn * TN * 16 + r16) * 128 + ((kq ^ sw) << 4), b_lo = BM * 128 + (wn * TN * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+    float* ot = reinterpret_cast<float*>(smem + GA);  // o staging: 64 rows x 128 columns, column index XOR-ed with ((row >> 2) & 3) << 4
+    int cs = 0;
+    while (true) {
+        const int m0 = t * BM;
+        // this thread's two final-epilogue items (one per 64-row half): old x planes and skip accumulator, requested now
+        uint4 pxh[2], pxl[2];
+        f32x4 ps0[2], ps1[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + h * 64 + (tid >> 3), c0 = (tid & 7) * 8;
+            pxh[h] = pxl[h] = make_uint4(0, 0, 0, 0);
+            ps0[h] = ps1[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (m < a.M) {
+                const size_t off = (size_t)(c0 >> 5) * a.xcs + (size_t)m * 64 + (c0 & 31);
+                pxh[h] = *reinterpret_cast<const uint4*>(a.xp_in + off);
+                pxl[h] = *reinterpret_cast<const uint4*>(a.xp_in + off + 32);
+                if (!a.first) {
+                    ps0[h] = *reinterpret_cast<const f32x4*>(a.skips + (size_t)m * 64 + c0);
+                    ps1[h] = *reinterpret_cast<const f32x4*>(a.skips + (size_t)m * 64 + c0 + 4);
+                }
+            }
+        }
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int i = 0; i < NCH; ++i) {
+            asm volatile("s_barrier" ::: "memory");
+            pchunk_mma<TM, TN, HI>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
+            cs = cs + 1 == NST ? 0 : cs + 1;
+        }
+        // ---- gate in registers -> pre-split A planes of g (chunk wn, columns 16 u + col)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float g = pwg_gate(acc[tm][2 * u][r] + bz[2 * u], acc[tm][2 * u + 1][r] + bz[2 * u + 1]);
+                    const int R = (wm * TM + tm) * 16 + rq * 4 + r, k = 16 * u + col;
+                    const __bf16 gh = (__bf16)g;
+                    u8* line = smem + GA + wn * 16384 + R * 128 + (k & 7) * 2;
+                    const int sws = (R >> 1) & 7;
+                    *reinterpret_cast<u16*>(line + (((k >> 3) ^ sws) << 4)) = __builtin_bit_cast(u16, gh);
+                    if (!HI) *reinterpret_cast<u16*>(line + (((4 + (k >> 3)) ^ sws) << 4)) = __builtin_bit_cast(u16, (__bf16)(g - (float)gh));
+                }
+        lds_sync();  // B1: g complete
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const int ar = (wm * TM * 16 + r16) * 128, br = (wn * TN * 16 + r16) * 128;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                pchunk_mma<TM, TN, HI>(smem, GA + c * 16384 + ar + ((kq ^ sw) << 4), GA + c * 16384 + ar + (((4 + kq) ^ sw) << 4),
+                                       WOS + c * 16384 + br + ((kq ^ sw) << 4), WOS + c * 16384 + br + (((4 + kq) ^ sw) << 4), acc);
+        }
+        lds_sync();  // B2: every wave has read its g fragments; the buffer becomes the staging tile of o
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((wm >> 1) == h) {
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            ot[((wm & 1) * 32 + tm * 16 + rq * 4 + r) * 128 + (((wn * TN + tn) * 16 + col) ^ (rq << 4))] = acc[tm][tn][r] + bo[tn];
+            }
+            lds_sync();  // B3 / B5
+            {
+                const int rl = tid >> 3, c0 = (tid & 7) * 8, m = m0 + h * 64 + rl;
+                if (m < a.M) {
+                    const int cx = c0 ^ (((rl >> 2) & 3) << 4);
+                    const f32x4 o0 = *reinterpret_cast<const f32x4*>(ot + rl * 128 + cx), o1 = *reinterpret_cast<const f32x4*>(ot + rl * 128 + cx + 4);
+                    const f32x4 k0 = *reinterpret_cast<const f32x4*>(ot + rl * 128 + 64 + cx), k1 = *reinterpret_cast<const f32x4*>(ot + rl * 128 + 64 + cx + 4);
+                    const unsigned hw[4] = {pxh[h].x, pxh[h].y, pxh[h].z, pxh[h].w}, lw_[4] = {pxl[h].x, pxl[h].y, pxl[h].z, pxl[h].w};
+                    const float ov[8] = {o0[0], o0[1], o0[2], o0[3], o1[0], o1[1], o1[2], o1[3]};
+                    f32x4 v0, v1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = __builtin_bit_cast(float, hw[e] << 16) + __builtin_bit_cast(float, lw_[e] << 16);
+                        const float x1 = __builtin_bit_cast(float, hw[e] & 0xFFFF0000u) + __builtin_bit_cast(float, lw_[e] & 0xFFFF0000u);
+                        const float n0 = (ov[2 * e] + x0) * 0.70710678118654752440f, n1 = (ov[2 * e + 1] + x1) * 0.70710678118654752440f;
+                        if (e < 2) { v0[2 * e] = n0; v0[2 * e + 1] = n1; } else { v1[2 * (e - 2)] = n0; v1[2 * (e - 2) + 1] = n1; }
+                    }
+                    uint2 h0, l0, h1, l1;
+                    split4(v0, h0, l0);
+                    split4(v1, h1, l1);
+                    const size_t off = (size_t)(c0 >> 5) * a.xcs + (size_t)m * 64 + (c0 & 31);
+                    *reinterpret_cast<uint4*>(a.xp_out + off) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                    *reinterpret_cast<uint4*>(a.xp_out + off + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                    float* sk = a.skips + (size_t)m * 64 + c0;
+                    *reinterpret_cast<f32x4*>(sk) = ps0[h] + k0;
+                    *reinterpret_cast<f32x4*>(sk + 4) = ps1[h] + k1;
+                }
+            }
+            if (h == 0) lds_sync();  // B4: half 0 has been read out
+        }
+        t += per_x;
+        if (t >= t_end) return;
+    }
+}
+
 template <int WM, int NST, bool HI>
 static int launch_pwg_cfg(const PwgFusedArgs& a, long long m, double flops, hipStream_t s) {
     using G = PGeo<WM, 2, 2, 4, NST, 2>;
@@ -806,6 +1042,23 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
     if (exp_terms > 0) a.nterms = exp_terms;  // developer timing aid: fewer K-terms (results are then garbage)
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
     const double flops = 2.0 * (double)L.m * 2.0 * R * ((double)L.ksize * R + L.aux + R);
+    static const int persist = tunable("PWG_PERSIST", 1);
+    if (persist && !dbg && !want_ts && exp_terms <= 0 && L.aux > 64) {  // (the persistent kernel is written for 3 x 2 + 3 chunks: r = 64, ksize = 3, 64 < aux <= 96)
+        using G = PGeo<4, 2, 2, 4, 3, 2>;
+        constexpr int LDS = G::LDS_BYTES + 2 * 32768;
+        const void* fn = hi ? reinterpret_cast<const void*>(pwg_layer_pkernel<true>) : reinterpret_cast<const void*>(pwg_layer_pkernel<false>);
+        const int rc = ensure_dyn_lds(fn, LDS);
+        if (rc) return rc;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int ntiles = (int)((L.m + 127) / 128);
+        static const int wg_per_cu = tunable("PWG_PERSIST_WGS", 0);  // 0: one workgroup per CU (160 KB of LDS each)
+        int nwg = std::min(ntiles, wg_per_cu > 0 ? wg_per_cu : cus);
+        ProfScope ps(hi ? "pwg_layer_pkernel/bf16" : "pwg_layer_pkernel", flops, (int)L.m, s);
+        if (hi) hipLaunchKernelGGL(pwg_layer_pkernel<true>, dim3((unsigned)nwg), dim3(G::THREADS), LDS, s, a, ntiles);
+        else hipLaunchKernelGGL(pwg_layer_pkernel<false>, dim3((unsigned)nwg), dim3(G::THREADS), LDS, s, a, ntiles);
+        return check_hip(hipGetLastError(), "pwg_layer persistent launch");
+    }
     // measured on MI355X, 64 x 800 frames, ms per layer: 128-row tiles + 3-deep ring + W_os in LDS 7.07 (default); the same with a 4-deep ring and
     // W_os fragments from L2 8.4 (the main loop alone is 4.05 either way: not bound by bytes in flight); 64-row tiles, two workgroups per CU 7.5
     static const int cfg = tunable("PWG_CFG", 0);  // 1: 128 rows, 4-deep ring; 3: 64-row tiles, 3-deep; 4: 64-row tiles, 4-deep
