@@ -913,6 +913,8 @@ __global__ __launch_bounds__(640) void pwg_layer_pkernel(const PwgFusedArgs a, c
                 }
             }
         }
+#define PWG_PSTAMP(k) do { if (a.ts && tid == 0) a.ts[(size_t)t * 8 + (k)] = (long long)wall_clock64(); } while (0)
+        PWG_PSTAMP(0);
         f32x4 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -924,6 +926,7 @@ __global__ __launch_bounds__(640) void pwg_layer_pkernel(const PwgFusedArgs a, c
             pchunk_mma<TM, TN, HI>(smem + cs * G::STAGE, a_hi, a_lo, b_hi, b_lo, acc);
             cs = cs + 1 == NST ? 0 : cs + 1;
         }
+        PWG_PSTAMP(1);
         // ---- gate in registers -> pre-split A planes of g (chunk wn, columns 16 u + col)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -940,6 +943,7 @@ __global__ __launch_bounds__(640) void pwg_layer_pkernel(const PwgFusedArgs a, c
                     if (!HI) *reinterpret_cast<u16*>(line + (((4 + (k >> 3)) ^ sws) << 4)) = __builtin_bit_cast(u16, (__bf16)(g - (float)gh));
                 }
         lds_sync();  // B1: g complete
+        PWG_PSTAMP(2);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -952,6 +956,7 @@ __global__ __launch_bounds__(640) void pwg_layer_pkernel(const PwgFusedArgs a, c
                                        WOS + c * 16384 + br + ((kq ^ sw) << 4), WOS + c * 16384 + br + (((4 + kq) ^ sw) << 4), acc);
         }
         lds_sync();  // B2: every wave has read its g fragments; the buffer becomes the staging tile of o
+        PWG_PSTAMP(3);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if ((wm >> 1) == h) {
@@ -993,6 +998,8 @@ __global__ __launch_bounds__(640) void pwg_layer_pkernel(const PwgFusedArgs a, c
             }
             if (h == 0) lds_sync();  // B4: half 0 has been read out
         }
+        PWG_PSTAMP(4);
+#undef PWG_PSTAMP
         t += per_x;
         if (t >= t_end) return;
     }
@@ -1043,7 +1050,7 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
     const double flops = 2.0 * (double)L.m * 2.0 * R * ((double)L.ksize * R + L.aux + R);
     static const int persist = tunable("PWG_PERSIST", 1);
-    if (persist && !dbg && !want_ts && exp_terms <= 0 && L.aux > 64) {  // (the persistent kernel is written for 3 x 2 + 3 chunks: r = 64, ksize = 3, 64 < aux <= 96)
+    if (persist && !dbg && exp_terms <= 0 && L.aux > 64) {  // (the persistent kernel is written for 3 x 2 + 3 chunks: r = 64, ksize = 3, 64 < aux <= 96)
         using G = PGeo<4, 2, 2, 4, 3, 2>;
         constexpr int LDS = G::LDS_BYTES + 2 * 32768;
         const void* fn = hi ? reinterpret_cast<const void*>(pwg_layer_pkernel<true>) : reinterpret_cast<const void*>(pwg_layer_pkernel<false>);

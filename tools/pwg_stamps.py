@@ -27,6 +27,12 @@ hip = ctypes.CDLL("libamdhip64.so")
 hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 assert hip.hipMemcpy(ctypes.addressof(host), ptr, n * 64, 2) == 0
 raw = np.frombuffer(host, dtype=np.int64).reshape(n, 8).astype(np.float64) * 0.01  # us (100 MHz clock)
+if os.environ.get("FCL_PWG_PERSIST", "1") != "0":  # persistent kernel: 0 tile start, 1 main loop done, 2 gate + B1, 3 phase 2 + B2, 4 tile end
+    d = np.diff(raw[:, :5], axis=1)
+    for i, nm in enumerate(["main loop", "gate -> planes", "phase 2", "o staging + final (2 halves)"]):
+        print("%-30s median %6.2f us   p10 %6.2f   p90 %6.2f" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+    print("tile total median %.2f us; layer span %.2f ms" % (np.median(raw[:, 4] - raw[:, 0]), (raw[:, 4].max() - raw[:, 0].min()) / 1e3))
+    sys.exit(0)
 print("z staging (stamp 2 -> 6) median %.2f us, gate (6 -> 3) median %.2f us" % (np.median(raw[:, 6] - raw[:, 2]), np.median(raw[:, 3] - raw[:, 6])))
 ts = raw[:, :6]
 d = np.diff(ts, axis=1)
