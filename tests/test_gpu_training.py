@@ -488,3 +488,39 @@ def test_training_step_edge_shapes_vs_oracle(case):
     orep["loss"].backward()
     assert abs(rep["loss"] - float(orep["loss"])) < 5e-4 * max(1.0, abs(float(orep["loss"])))
     _check_vs_oracle(eng, sd)
+
+
+def test_bf16_autocast_step_tracks_the_fp32_equivalent_step():
+    """TrainEngine(amp="bf16") (the --use-amp recipes: bf16-rounded GEMM operands, fp32 accumulation / master weights / Adam) on full-size S / T dims:
+    same batch, same device-RNG draws; the named losses agree to bf16 level, the gradient keeps its direction (cosine; the same closed-form
+    student under real torch.autocast(bfloat16) on the CPU oracle is further from fp32 than this), the update is applied (no loss scaling, no
+    skipped step), and the calling thread's GEMM mode is back to fp32-equivalent afterwards."""
+    from fcl_taco2_amd import _lib, hparams as HP, ops, synthetic as SYN
+    from fcl_taco2_amd.converter import CustomConverter
+    from fcl_taco2_amd.training import TrainEngine
+
+    if not ops.planes_enabled():
+        pytest.skip("FCL_PRECISION=0: the bf16 mode needs the bf16 MFMA path")
+    S, T = HP.student_hparams(), HP.teacher_hparams()
+    xs, ys, ds, f0, en = SYN.training_batch(80, S.idim, batch=8, t_lo=60, t_hi=100, seed=5, zero_frac=0.03, lam=10.0, hi=50)
+    batch = CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)])
+    res = {}
+    for amp in (None, "bf16"):
+        teng = TrainEngine(SYN.build_model("kd_teacher", T, None, DEV), amp=amp)
+        know = teng.knowledge(batch, mode="train")
+        eng = TrainEngine(SYN.build_model("student", S, T, DEV), seed=0, amp=amp)
+        eng.zero_grad()
+        rep = eng.forward_backward(batch, know, mode="train")
+        g = eng.gflat.clone()
+        w0 = eng.pflat.clone()
+        eng.optimizer_step()
+        torch.cuda.synchronize()
+        assert eng.step_count == 1 and float((eng.pflat - w0).abs().max()) > 0
+        res[amp] = ({k: float(rep[k]) for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "decoder_loss")}, g.double())
+        assert _lib.load().fcl_get_gemm_mode() == _lib.GEMM_F32
+    (l32, g32), (l16, g16) = res[None], res["bf16"]
+    for k in l32:
+        assert abs(l16[k] - l32[k]) < 2e-2 * max(1.0, abs(l32[k])), (k, l16[k], l32[k])
+    assert any(l16[k] != l32[k] for k in l32)  # the mode really changed the arithmetic
+    cos = float((g32 * g16).sum() / g32.norm() / g16.norm())
+    assert cos > 0.99 and abs(float(g16.norm() / g32.norm()) - 1.0) < 0.05, cos
