@@ -136,6 +136,7 @@ class ParallelWaveGANGenerator(object):
         reps = torch.from_numpy(lens_np * pl.hop).to(dev)
         m["seg_lo"] = torch.repeat_interleave(s_off[:-1], reps).to(torch.int32)  # sample range of each row's utterance (integers only)
         m["seg_hi"] = torch.repeat_interleave(s_off[1:], reps).to(torch.int32)
+        torch.cuda.current_stream(dev).synchronize()  # the cached maps may be used from other streams later: finish building them first (once per shape)
         if len(self._maps_cache) >= 4:
             self._maps_cache.clear()
         self._maps_cache[key] = m
