@@ -414,6 +414,10 @@ class TrainEngine(object):
         rec = self._recipe.get(ptr)
         if rec is not None:
             a, b, c = rec[2][:3]
+            live = self._forms.forms.get(("f",) + rec[0])  # the address must still belong to that form (a freed form's address can be reused)
+            if live is None or live["out"] is None or live["out"].data_ptr() != ptr:
+                del self._recipe[ptr]
+                return None
             return rec if w.numel() == a * b * c and w.shape[-1] == c else None
         name = self._param_ptr.get(ptr)
         if name is not None and w.dim() == 2 and w.is_contiguous() and w.numel() == self.P[name].numel():
