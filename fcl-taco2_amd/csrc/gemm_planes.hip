@@ -441,7 +441,11 @@ bool planes_ok(const GemmTerm* t, int n) {
 }
 
 static int loader_waves() {
-    static const int v = tunable("PLANES_LOADERS", 2) ? 2 : 0;  // 2 dedicated LDS-DMA waves per workgroup (0: every wave loads and computes)
+    // dedicated LDS-DMA waves per workgroup (0: every wave loads and computes).  Measured: 2 loaders -9 % per isolated launch over 0; 4 loaders another
+    // +1.5 % (S, batch 32: 41.8 -> 42.4 M frames/s over 3 runs each) to +3.6 % (batch 64) on the whole pass -- the issue rate of global_load_lds per
+    // wave is part of the per-chunk time
+    static const int t = tunable("PLANES_LOADERS", 4);
+    static const int v = t >= 4 ? 4 : (t ? 2 : 0);
     return v;
 }
 
@@ -474,6 +478,7 @@ template <int WM, int WN, int TM, int TN, int NST>
 static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
     if (gemm_mode() == FCL_GEMM_BF16)  // autocast: bf16-rounded operands (the hi planes alone), one MFMA per product
         return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2, true>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0, true>(a, s, flops);
+    if (loader_waves() == 4) return launch_pgemm_lw<WM, WN, TM, TN, NST, 4, false>(a, s, flops);
     return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2, false>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0, false>(a, s, flops);
 }
 
@@ -517,6 +522,7 @@ template <int WM, int WN, int TM, int NST>
 static int launch_plstm_cfg(const LstmStepArgs& a, hipStream_t s, double flops) {
     if (gemm_mode() == FCL_GEMM_BF16)
         return loader_waves() ? launch_plstm_lw<WM, WN, TM, NST, 2, true>(a, s, flops) : launch_plstm_lw<WM, WN, TM, NST, 0, true>(a, s, flops);
+    if (loader_waves() == 4) return launch_plstm_lw<WM, WN, TM, NST, 4, false>(a, s, flops);
     return loader_waves() ? launch_plstm_lw<WM, WN, TM, NST, 2, false>(a, s, flops) : launch_plstm_lw<WM, WN, TM, NST, 0, false>(a, s, flops);
 }
 
@@ -769,9 +775,9 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
 // rows permuted so that a lane holds tanh column c and sigmoid column c of the same sample (tn tiles alternate tanh / sigmoid) -- its result goes
 // straight into the 32 KB gate-plane buffer, and the second GEMM's result is staged in two 64-row halves through that same buffer once phase 2 has
 // read it.  LDS: ring 96 KB | W_os 32 KB | gate planes / o staging 32 KB.
-template <bool HI>
-__global__ __launch_bounds__(640) void pwg_layer_pkernel(const PwgFusedArgs a, const int ntiles) {
-    using G = PGeo<4, 2, 2, 4, 3, 2>;
+template <bool HI, int LW>
+__global__ __launch_bounds__(64 * (8 + LW)) void pwg_layer_pkernel(const PwgFusedArgs a, const int ntiles) {
+    using G = PGeo<4, 2, 2, 4, 3, LW>;
     constexpr int TM = 2, TN = 4, WN = 2, BM = 128, NST = 3, NCH = 9;
     constexpr int WOS = G::LDS_BYTES, GA = WOS + 32768;
     static_assert(G::BM == BM && G::BN == 128 && G::STAGE == 32768, "tile geometry");
@@ -1051,9 +1057,10 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
     const double flops = 2.0 * (double)L.m * 2.0 * R * ((double)L.ksize * R + L.aux + R);
     static const int persist = tunable("PWG_PERSIST", 1);
     if (persist && !dbg && exp_terms <= 0 && L.aux > 64) {  // (the persistent kernel is written for 3 x 2 + 3 chunks: r = 64, ksize = 3, 64 < aux <= 96)
-        using G = PGeo<4, 2, 2, 4, 3, 2>;
-        constexpr int LDS = G::LDS_BYTES + 2 * 32768;
-        const void* fn = hi ? reinterpret_cast<const void*>(pwg_layer_pkernel<true>) : reinterpret_cast<const void*>(pwg_layer_pkernel<false>);
+        constexpr int LDS = PGeo<4, 2, 2, 4, 3, 2>::LDS_BYTES + 2 * 32768;
+        static const int plw = tunable("PWG_LOADERS", 4);  // 4 loader waves: 151.9 -> 145.1 ms per 30 blocks
+        const void* fn = plw >= 4 ? (hi ? reinterpret_cast<const void*>(pwg_layer_pkernel<true, 4>) : reinterpret_cast<const void*>(pwg_layer_pkernel<false, 4>))
+                                  : (hi ? reinterpret_cast<const void*>(pwg_layer_pkernel<true, 2>) : reinterpret_cast<const void*>(pwg_layer_pkernel<false, 2>));
         const int rc = ensure_dyn_lds(fn, LDS);
         if (rc) return rc;
         int dev = 0, cus = 256;
@@ -1062,8 +1069,14 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
         static const int wg_per_cu = tunable("PWG_PERSIST_WGS", 0);  // 0: one workgroup per CU (160 KB of LDS each)
         int nwg = std::min(ntiles, wg_per_cu > 0 ? wg_per_cu : cus);
         ProfScope ps(hi ? "pwg_layer_pkernel/bf16" : "pwg_layer_pkernel", flops, (int)L.m, s);
-        if (hi) hipLaunchKernelGGL(pwg_layer_pkernel<true>, dim3((unsigned)nwg), dim3(G::THREADS), LDS, s, a, ntiles);
-        else hipLaunchKernelGGL(pwg_layer_pkernel<false>, dim3((unsigned)nwg), dim3(G::THREADS), LDS, s, a, ntiles);
+        const dim3 blk(64 * (8 + (plw >= 4 ? 4 : 2)));
+        if (plw >= 4) {
+            if (hi) hipLaunchKernelGGL((pwg_layer_pkernel<true, 4>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
+            else hipLaunchKernelGGL((pwg_layer_pkernel<false, 4>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
+        } else {
+            if (hi) hipLaunchKernelGGL((pwg_layer_pkernel<true, 2>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
+            else hipLaunchKernelGGL((pwg_layer_pkernel<false, 2>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
+        }
         return check_hip(hipGetLastError(), "pwg_layer persistent launch");
     }
     // measured on MI355X, 64 x 800 frames, ms per layer: 128-row tiles + 3-deep ring + W_os in LDS 7.07 (default); the same with a 4-deep ring and
