@@ -486,14 +486,23 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
 // branch-free (LDS tiles are zero-padded to whole 32-k steps), the dropout mode is a template argument, and the two inner barriers are LDS-only
 // (lds_barrier) so the fragment loads of the next phase stay in flight across them.  The generic kernel above had a conditional global load +
 // s_waitcnt vmcnt(0) in every epilogue, which drained the 32 in-flight fragment loads of the next layer: +3.3 us per layer on a ~5 us kernel.
-template <int SU, int SO, int SP, int DROP>
+// RT = 16-row tiles a workgroup carries through every phase TOGETHER: each weight fragment set is fetched once (426 KB from L2 per workgroup) and
+// drives RT MFMA chains before it dies, so per row the L2 traffic and -- with several passes in flight, what bounds the throughput -- the
+// kernel's CU-time fall by RT (the fragment registers cannot stay resident ACROSS tiles: 240 VGPRs for the three sets).
+template <int SU, int SO, int SP, int DROP, int RT>
 __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetArgs a) {
     constexpr int U = SU * 32, OP = SO * 32, P = SP * 32;
-    constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8;
+    constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8, ROWS = 16 * RT;
     static_assert(2 * SP <= 16, "two prenet column tiles per wave, 8 waves");
-    __shared__ __attribute__((aligned(16))) u16 A1h[16 * ldU], A1l[16 * ldU], A2h[16 * ldO], A2l[16 * ldO], A3h[16 * ldP], A3l[16 * ldP];
+    extern __shared__ __attribute__((aligned(16))) u16 fp_lds[];
+    u16* A1h = fp_lds;
+    u16* A1l = A1h + ROWS * ldU;
+    u16* A2h = A1l + ROWS * ldU;
+    u16* A2l = A2h + ROWS * ldO;
+    u16* A3h = A2l + ROWS * ldO;
+    u16* A3l = A3h + ROWS * ldP;
     const int O = a.O;
-    const int m0 = blockIdx.x * 16;
+    const int m0 = blockIdx.x * ROWS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int col = lane & 15, rq = lane >> 4;
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
         seed1 = hash_u32(a.seed1 + sbump);
     }
     float pb0[2] = {0.f, 0.f}, pb1[2] = {0.f, 0.f};
-    uint8_t k0[2][4], k1[2][4];
+    uint8_t k0[RT][2][4], k1[RT][2][4];
     if (has_pre) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -520,25 +529,31 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
             pb1[tt] = a.b1[nc];
             if (DROP == 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int mc = min(m0 + rq * 4 + r, a.M_pre - 1);
-                    k0[tt][r] = a.keep0[(size_t)mc * P + nc];
-                    k1[tt][r] = a.keep1[(size_t)mc * P + nc];
-                }
+                for (int q = 0; q < RT; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int mc = min(m0 + q * 16 + rq * 4 + r, a.M_pre - 1);
+                        k0[q][tt][r] = a.keep0[(size_t)mc * P + nc];
+                        k1[q][tt][r] = a.keep1[(size_t)mc * P + nc];
+                    }
             }
         }
     }
-    float f0v[4] = {0.f, 0.f, 0.f, 0.f};
-    int fo[4] = {0, 0, 0, 0};
+    float f0v[RT][4];
+    int fo[RT][4];
     const int fnc = wave * 16 + col;
-    if (feat_wave) {
+#pragma unroll
+    for (int q = 0; q < RT; ++q)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int mc = min(m0 + rq * 4 + r, a.M_feat - 1);
-            f0v[r] = a.F0[(size_t)mc * O + min(fnc, O - 1)];
-            fo[r] = a.frame_off[mc];
+            f0v[q][r] = 0.f;
+            fo[q][r] = 0;
+            if (feat_wave) {
+                const int mc = min(m0 + q * 16 + rq * 4 + r, a.M_feat - 1);
+                f0v[q][r] = a.F0[(size_t)mc * O + min(fnc, O - 1)];
+                fo[q][r] = a.frame_off[mc];
+            }
         }
-    }
     WFrag<1, SU> ff;
     WFrag<2, SO> f0;
     WFrag<2, SP> f1;
@@ -552,32 +567,38 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
         const u16* const wl0[2] = {frag(a.w0_lo, t0, SO), frag(a.w0_lo, t1, SO)};
         f0.load(wh0, wl0);
     }
-    // ---- phase 0: h1 tile -> LDS planes; prenet-input tile zeroed (prev_out = 0 at t = 0; zero padding past O otherwise) ------------------
-    for (int i = threadIdx.x; i < 16 * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }
-    if (has_feat) load_rowtile_split(A1h, A1l, ldU, a.h1, U, U, m0, a.M_feat);
+    // ---- phase 0: h1 tiles -> LDS planes; prenet-input tiles zeroed (prev_out = 0 at t = 0; zero padding past O otherwise) ------------------
+    for (int i = threadIdx.x; i < ROWS * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }
+    if (has_feat) {
+#pragma unroll
+        for (int q = 0; q < RT; ++q) load_rowtile_split(A1h + q * 16 * ldU, A1l + q * 16 * ldU, ldU, a.h1, U, U, m0 + q * 16, a.M_feat);
+    }
     __syncthreads();
     if (a.dbg_phase == 1) return;
     // ---- phase 1: H8 feat_out of the previous step (+ H10 scatter) ---------------------------------------------------------------------
     if (feat_wave) {
-        f32x4 accv[1];
-        ff.template mma<false>(A1h, A1l, ldU, U, r16, kq, accv);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rq * 4 + r, m = m0 + row;
-            if (fnc < O) {
-                float v = 0.f;
-                if (m < a.M_feat) {
-                    v = accv[0][r] + f0v[r];
-                    a.before[(size_t)(fo[r] + a.t_prev) * O + fnc] = v;
-                    if (a.before_p) store_p32(a.before_p, (O + 31) >> 5, fo[r] + a.t_prev, fnc, v);
+        for (int q = 0; q < RT; ++q) {
+            f32x4 accv[1];
+            ff.template mma<false>(A1h + q * 16 * ldU, A1l + q * 16 * ldU, ldU, U, r16, kq, accv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 16 + rq * 4 + r, m = m0 + row;
+                if (fnc < O) {
+                    float v = 0.f;
+                    if (m < a.M_feat) {
+                        v = accv[0][r] + f0v[q][r];
+                        a.before[(size_t)(fo[q][r] + a.t_prev) * O + fnc] = v;
+                        if (a.before_p) store_p32(a.before_p, (O + 31) >> 5, fo[q][r] + a.t_prev, fnc, v);
+                    }
+                    split1(v, A2h[row * ldO + fnc], A2l[row * ldO + fnc]);
                 }
-                split1(v, A2h[row * ldO + fnc], A2l[row * ldO + fnc]);
             }
         }
     }
     if (has_feat && a.before_p && (O & 31)) {  // zero padding of the last 32-column line of this tile's frames
         const int padc = 32 - (O & 31);
-        for (int i = threadIdx.x; i < 16 * padc; i += blockDim.x) {
+        for (int i = threadIdx.x; i < ROWS * padc; i += blockDim.x) {
             const int m = m0 + i / padc;
             if (m < a.M_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
         }
@@ -590,21 +611,23 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     }
     lds_barrier();
     if (a.teacher_in) {  // teacher forcing: prenet input is y_{t-1}, not the decoder's own output
-        load_rowtile_split(A2h, A2l, ldO, a.teacher_in, a.teacher_ld, O, m0, a.M_pre);
+#pragma unroll
+        for (int q = 0; q < RT; ++q) load_rowtile_split(A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, a.teacher_in, a.teacher_ld, O, m0 + q * 16, a.M_pre);
         __syncthreads();
     }
     // ---- phase 2: H6 prenet layer 0 ---------------------------------------------------------------------------------------------------------
-    {
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
         f32x4 accv[2];
-        f0.template mma<false>(A2h, A2l, ldO, OP, r16, kq, accv);
+        f0.template mma<false>(A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, OP, r16, kq, accv);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? t1 : t0) * 16 + col;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = rq * 4 + r, m = m0 + row;
+                const int row = q * 16 + rq * 4 + r, m = m0 + row;
                 float v = fmaxf(accv[tt][r] + pb0[tt], 0.f);
-                if (DROP == 1) v = k0[tt][r] ? v * a.keep_scale : 0.f;
+                if (DROP == 1) v = k0[q][tt][r] ? v * a.keep_scale : 0.f;
                 if (DROP == 2) {
                     const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)P + (unsigned int)nc) ^ seed0);
                     v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
@@ -616,18 +639,19 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     lds_barrier();
     if (a.dbg_phase == 3) return;
     // ---- phase 3: H6 prenet layer 1 -> global (+ KD tap, + P32 planes) ------------------------------------------------------------------------
-    {
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
         f32x4 accv[2];
-        f1.template mma<false>(A3h, A3l, ldP, P, r16, kq, accv);
+        f1.template mma<false>(A3h + q * 16 * ldP, A3l + q * 16 * ldP, ldP, P, r16, kq, accv);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int nc = (tt ? t1 : t0) * 16 + col;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + rq * 4 + r;
+                const int m = m0 + q * 16 + rq * 4 + r;
                 if (m >= a.M_pre) continue;
                 float v = fmaxf(accv[tt][r] + pb1[tt], 0.f);
-                if (DROP == 1) v = k1[tt][r] ? v * a.keep_scale : 0.f;
+                if (DROP == 1) v = k1[q][tt][r] ? v * a.keep_scale : 0.f;
                 if (DROP == 2) {
                     const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)P + (unsigned int)nc) ^ seed1);
                     v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
@@ -952,10 +976,27 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
         ProfScope ps("feat_prenet_kernel/bf16x3", fl, rows, s);
         static const int fast = tunable("FEAT_PRENET_FAST", 1);
         if (fast && a.U == 256 && a.O > 64 && a.O <= 96 && a.P == 256) {
-            const dim3 g((rows + 15) / 16), b(512);
-            if (a.drop_mode == 1) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 1>), g, b, 0, s, a);
-            else if (a.drop_mode == 2) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 2>), g, b, 0, s, a);
-            else hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 0>), g, b, 0, s, a);
+            // RT row tiles per workgroup share one fetch of the weight fragments (see the kernel); few rows keep one tile per workgroup (latency)
+            static const int rt_max = tunable("FP_ROW_TILES", 2), rt_m = tunable("FP_ROW_TILES_M", 512);
+            const int rt = (rt_max >= 4 && rows >= 2 * rt_m) ? 4 : (rt_max >= 2 && rows >= rt_m) ? 2 : 1;
+            const dim3 b(512);
+#define FCL_FP_LAUNCH(RT_)                                                                                                               \
+    do {                                                                                                                                 \
+        constexpr size_t lds_rt = 2 * sizeof(unsigned short) * 16 * RT_ * ((256 + 8) + (96 + 8) + (256 + 8));                            \
+        const dim3 g((rows + 16 * RT_ - 1) / (16 * RT_));                                                                                \
+        const void* fn = a.drop_mode == 1   ? reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 1, RT_>)                      \
+                         : a.drop_mode == 2 ? reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 2, RT_>)                      \
+                                            : reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 0, RT_>);                     \
+        const int rc = ensure_dyn_lds(fn, (int)lds_rt);                                                                                  \
+        if (rc) return rc;                                                                                                               \
+        if (a.drop_mode == 1) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 1, RT_>), g, b, lds_rt, s, a);                        \
+        else if (a.drop_mode == 2) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 2, RT_>), g, b, lds_rt, s, a);                   \
+        else hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 0, RT_>), g, b, lds_rt, s, a);                                         \
+    } while (0)
+            if (rt == 4) FCL_FP_LAUNCH(4);
+            else if (rt == 2) FCL_FP_LAUNCH(2);
+            else FCL_FP_LAUNCH(1);
+#undef FCL_FP_LAUNCH
         } else if (a.U == 256 && a.O == 80 && a.P == 256) {
             hipLaunchKernelGGL((feat_prenet_x3_kernel<8, 3, 8>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
         } else {

@@ -535,6 +535,12 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     static const int force = tunable("PLSTM_CFG", 0);
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.U + 31) / 32);
     const long long t64 = (long long)((a.M + 63) / 64) * ((a.U + 31) / 32);
+    const long long t96 = (long long)((a.M + 95) / 96) * ((a.U + 31) / 32);
+    static const int use96 = tunable("PLSTM_TILE96", 0);
+    // 96-row tiles where they still fit one wave of workgroups and 128-row tiles would leave CUs idle: a workgroup's main loop takes
+    // (BM + BN) * K * 4 bytes / ~47 GB/s, so 96 + 128 instead of 128 + 128 rows is -12.5 % per workgroup
+    if ((force == 5 || (force == 0 && use96 && t128 >= 150 && t128 < 230 && t96 <= 256)) && loader_waves() > 0 && gemm_mode() != FCL_GEMM_BF16)
+        return loader_waves() == 4 ? launch_plstm_lw<3, 2, 2, 3, 4, false>(a, s, flops) : launch_plstm_lw<3, 2, 2, 3, 2, false>(a, s, flops);  // (6 compute waves: loader-specialised only)
     if (force == 1 || (force == 0 && t128 >= 150)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
     if (force == 2 || (force == 0 && t64 >= 200)) return launch_plstm_cfg<2, 2, 2, 3>(a, s, flops);
     static const int row32_m = tunable("PLSTM_ROW32_M", 1100);
