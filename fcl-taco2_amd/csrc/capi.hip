@@ -204,6 +204,7 @@ int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
         g.term[j].Wp = wpp + (size_t)j * cout * ldw * 64; g.term[j].ldw_p = ldw;
     }
     g.nterms = k;
+    g.conv_k = k;
     g.M = m; g.N = cout;
     g.seg_lo = seg_lo; g.seg_hi = seg_hi;
     g.bias = bias; g.act = act;

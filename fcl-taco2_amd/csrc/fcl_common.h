@@ -68,6 +68,8 @@ struct GemmArgs {
     int hi_only;  // set by the launchers from gemm_mode(): operands rounded to bf16 (one MFMA per product) instead of the bf16x3 split
     // planes kernels only (the weight-gradient GEMM, fcl_gemm_tn_planes): split of the contraction over gridDim.z (chunks of 32 per slice, single
     // term), atomic accumulation into Y, and an output made of column blocks (column n -> Y + (n / nblk) * blk_stride + m * ldy + n % nblk)
+    int conv_k;  // != 0 (set by fcl_conv1d_planes_fwd): the terms are the conv_k taps of ONE Conv1d -- same A planes, shifts -(k-1)/2 .. (k-1)/2, W tap-major
+                 // and contiguous -- so the stencil kernel (pconv_kernel) may load each A tile once and reuse it for every tap
     int ksplit_chunks;
     int accumulate;
     int nblk;

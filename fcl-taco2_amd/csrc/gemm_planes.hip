@@ -252,20 +252,9 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
 }
 
 // --------------------------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int NST, int LW, bool HI>
-__global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmArgs a) {
-    using G = PGeo<WM, WN, TM, TN, NST, LW>;
-    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
-    int bx, by;
-    xcd_tile_p(bx, by);
-    const int m0 = by * G::BM, n0 = bx * G::BN;
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!pmainloop<WM, WN, TM, TN, NST, false, LW, HI>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc, a.ksplit_chunks)) return;  // loader wave
-
+// The GEMM epilogue shared by pgemm_kernel and pconv_kernel (compute waves only; BM x BN tile at (m0, n0), accumulators in the MFMA layout).
+template <int WN, int TM, int TN, int BM, int BN, int CTHREADS, int LDS_BYTES>
+__device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[TM][TN], u8* smem, int m0, int n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, rq = lane >> 4;
@@ -273,8 +262,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
     // Epilogue through LDS: the MFMA accumulator layout gives every lane ONE column of four rows, i.e. 4-byte (fp32) or 2-byte (planes) stores,
     // 32 - 64 store instructions per lane.  The finished tile is staged as fp32 in the (now idle) ring and written out row-wise: 16 bytes per
     // lane, whole 128-byte lines for the planes (hi | lo of 32 columns), a quarter / an eighth of the store instructions.
-    constexpr int LDT = G::BN + 4;  // staging row stride (floats): keeps float4 alignment, spreads rows over banks
-    static_assert(G::BM * LDT * 4 <= G::LDS_BYTES, "the staging tile must fit the ring");
+    constexpr int LDT = BN + 4;  // staging row stride (floats): keeps float4 alignment, spreads rows over banks
+    static_assert(BM * LDT * 4 <= LDS_BYTES, "the staging tile must fit the ring");
     float* tile = reinterpret_cast<float*>(smem);
     __syncthreads();  // every wave is done with the last chunk
 #pragma unroll
@@ -308,11 +297,11 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
             }
         }
     __syncthreads();
-    const int rows = min(G::BM, a.M - m0);
+    const int rows = min(BM, a.M - m0);
     if (a.accumulate) {  // weight gradients (split contraction, accumulation over micro-batches): one float per lane, consecutive lanes on
                          // consecutive addresses, so a wave's atomic instruction touches two cache lines
-        for (int i = threadIdx.x; i < rows * G::BN; i += G::CTHREADS) {
-            const int rm = i / G::BN, cn = i - rm * G::BN, n = n0 + cn;
+        for (int i = threadIdx.x; i < rows * BN; i += CTHREADS) {
+            const int rm = i / BN, cn = i - rm * BN, n = n0 + cn;
             if (n >= a.N) continue;
             float* dst = a.nblk > 0 ? a.Y + (size_t)(n / a.nblk) * a.blk_stride + (size_t)(m0 + rm) * a.ldy + (n % a.nblk)
                                     : a.Y + (size_t)(m0 + rm) * a.ldy + n;
@@ -322,8 +311,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
     }
     if (a.Y) {
         const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
-        for (int i = threadIdx.x; i < rows * (G::BN / 4); i += G::CTHREADS) {
-            const int rm = i / (G::BN / 4), c4 = (i - rm * (G::BN / 4)) * 4, n = n0 + c4;
+        for (int i = threadIdx.x; i < rows * (BN / 4); i += CTHREADS) {
+            const int rm = i / (BN / 4), c4 = (i - rm * (BN / 4)) * 4, n = n0 + c4;
             if (n >= a.N) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c4);
             float* dst = a.Y + (size_t)(m0 + rm) * a.ldy + n;
@@ -338,8 +327,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
     }
     if (a.Yp) {  // item = (row, 32-column line, quarter q): 8 values -> 16 bytes of hi at piece q and 16 bytes of lo at piece 4 + q
         const int np = a.ldyp * 32;
-        for (int i = threadIdx.x; i < rows * (G::BN / 8); i += G::CTHREADS) {
-            const int rm = i / (G::BN / 8), c8 = (i - rm * (G::BN / 8)) * 8, n = n0 + c8;
+        for (int i = threadIdx.x; i < rows * (BN / 8); i += CTHREADS) {
+            const int rm = i / (BN / 8), c8 = (i - rm * (BN / 8)) * 8, n = n0 + c8;
             if (n >= np) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8), v1 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8 + 4);
             uint2 h0, l0, h1, l1;
@@ -350,6 +339,23 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
             *reinterpret_cast<uint4*>(line + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
     }
+}
+
+template <int WM, int WN, int TM, int TN, int NST, int LW, bool HI>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmArgs a) {
+    using G = PGeo<WM, WN, TM, TN, NST, LW>;
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    int bx, by;
+    xcd_tile_p(bx, by);
+    const int m0 = by * G::BM, n0 = bx * G::BN;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!pmainloop<WM, WN, TM, TN, NST, false, LW, HI>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc, a.ksplit_chunks)) return;  // loader wave
+
+    pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES>(a, acc, smem, m0, n0);
 }
 
 template <int WM, int WN, int TM, int NST, int MODE, int LW, bool HI>
@@ -482,6 +488,168 @@ static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
     return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2, false>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0, false>(a, s, flops);
 }
 
+// --------------------------------------------------------------------------------------------------------------------------------------
+// Conv1d as an LDS-tiled stencil on the same machinery.  pgemm_kernel treats the k taps as k independent K-terms: every tap re-fetches "its" A rows
+// (the same rows shifted by one) and a workgroup's main loop is bound by the bytes it pulls through LDS-DMA ((BM + BN) * Cin * k * 4 at ~47 GB/s
+// per CU).  Here a 32-column chunk of the input tile is loaded ONCE with a halo of 8 rows on either side (BM + 16 rows, double-buffered) and the
+// k taps read it at row offsets -pad .. +pad; only the W chunk changes per step: (BM + 16 + k * BN) * 128 B per channel chunk instead of
+// k * (BM + BN) * 128 B (-39 % for k = 5, 64 x 64 tiles).  Utterance edges: a row outside the segment of the OUTPUT row it contributes to is
+// zeroed per lane at fragment-read time (one shared tile serves rows of two utterances when a tile straddles a boundary).
+template <int WM, int WN, int TM, int TN>
+struct CGeo {
+    static constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN, NL = 2, THREADS = 64 * (NW + NL), CTHREADS = 64 * NW;
+    static constexpr int HALO = 8, AROWS = BM + 2 * HALO, A_BYTES = AROWS * 128, W_BYTES = BN * 128, NSTW = 3;
+    static constexpr int LDS_BYTES = 2 * A_BYTES + NSTW * W_BYTES;
+    static constexpr int GAH = AROWS / 8 / NL, GB = BN / 8 / NL;
+    static_assert((AROWS / 8) % NL == 0 && (BN / 8) % NL == 0, "tile rows must split evenly over the two loader waves");
+    static_assert(GAH + GB <= 60, "s_waitcnt vmcnt is a 6-bit field");
+};
+
+template <int WM, int WN, int TM, int TN, bool HI>
+__global__ __launch_bounds__(64 * (WM * WN + 2)) void pconv_kernel(const GemmArgs a) {
+    using G = CGeo<WM, WN, TM, TN>;
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    int bx, by;
+    xcd_tile_p(bx, by);
+    const int m0 = by * G::BM, n0 = bx * G::BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = a.conv_k, pad = (k - 1) >> 1;
+    const GemmTerm T0 = a.term[0];
+    const int cc = (T0.K + 31) >> 5, S = cc * k;  // channel chunks, steps (chunk-major, tap-minor)
+    u8* const wring = smem + 2 * G::A_BYTES;
+
+    if (wave >= G::NW) {  // ------------------------------------------------------------------------------------------------ loader waves
+        const int lw = wave - G::NW;
+        const unsigned coff = (unsigned)(((lane & 7) ^ (((lw & 1) << 2) | (lane >> 4))) * 16);
+        const u8* zline = reinterpret_cast<const u8*>(g_zero_line) + coff;
+        const u8* pa[G::GAH];   // chunk 0 of this lane's halo rows (zero line outside the matrix)
+        unsigned ia[G::GAH];
+#pragma unroll
+        for (int j = 0; j < G::GAH; ++j) {
+            const int row = m0 - G::HALO + (j * G::NL + lw) * 8 + (lane >> 3);
+            const bool ok = row >= 0 && row < a.M;
+            pa[j] = ok ? reinterpret_cast<const u8*>(T0.Ap) + (size_t)row * ((size_t)T0.lda_p * 128) + coff : zline;
+            ia[j] = ok ? 128u : 0u;
+        }
+        const u8* pw[G::GB];    // tap 0, chunk 0 of this lane's W rows
+        bool wok[G::GB];
+        const size_t tap_stride = (size_t)a.N * ((size_t)T0.ldw_p * 128);  // tap-major [k * Cout, Cin] planes
+#pragma unroll
+        for (int j = 0; j < G::GB; ++j) {
+            const int n = n0 + (j * G::NL + lw) * 8 + (lane >> 3);
+            wok[j] = n < a.N;
+            pw[j] = wok[j] ? reinterpret_cast<const u8*>(T0.Wp) + (size_t)n * ((size_t)T0.ldw_p * 128) + coff : zline;
+        }
+        int is = 0, ic = 0, ij = 0;  // next bundle to issue: step is = (chunk ic, tap ij)
+        auto issue = [&]() {  // bundle(is) = W chunk of the step, plus the A halo tile of the chunk on its first tap
+            if (ij == 0) {
+                u8* abase = smem + (ic & 1) * G::A_BYTES + lw * 1024;
+#pragma unroll
+                for (int j = 0; j < G::GAH; ++j) {
+                    glds16(pa[j], abase + j * G::NL * 1024);
+                    pa[j] += ia[j];
+                }
+            }
+            u8* wbase = wring + (is % G::NSTW) * G::W_BYTES + lw * 1024;
+            const size_t woff = (size_t)ij * tap_stride + (size_t)ic * 128;
+#pragma unroll
+            for (int j = 0; j < G::GB; ++j) glds16(wok[j] ? pw[j] + woff : pw[j], wbase + j * G::NL * 1024);
+            ++is;
+            if (++ij == k) { ij = 0; ++ic; }
+        };
+        issue();
+        if (S > 1) issue();
+        for (int s = 0; s < S; ++s) {
+            // everything but the newest bundle (step s + 1) has landed; that bundle carries an A tile when s + 1 opens a chunk
+            if (s + 1 < S) {
+                if ((s + 1) % k == 0) wait_vm<G::GB + G::GAH>();
+                else wait_vm<G::GB>();
+            } else {
+                wait_vm<0>();
+            }
+            asm volatile("s_barrier" ::: "memory");
+            if (s + 2 < S) issue();
+        }
+        return;
+    }
+    // -------------------------------------------------------------------------------------------------------------------- compute waves
+    const int wm = wave / WN, wn = wave % WN;
+    const int r16 = lane & 15, kq = lane >> 4, sw = r16 >> 1;
+    int lo_off[TM], hi_off[TM];  // segment of this lane's output rows, relative to the row: tap shift sh contributes iff lo_off <= sh < hi_off
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + (wm * TM + tm) * 16 + r16;
+        lo_off[tm] = hi_off[tm] = 0;
+        if (m < a.M) {
+            lo_off[tm] = a.seg_lo[m] - m;
+            hi_off[tm] = a.seg_hi[m] - m;
+        }
+    }
+    const int b_hi = (wn * TN * 16 + r16) * 128 + ((kq ^ sw) << 4), b_lo = (wn * TN * 16 + r16) * 128 + (((4 + kq) ^ sw) << 4);
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int c = 0, j = 0;
+    const s16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < S; ++s) {
+        asm volatile("s_barrier" ::: "memory");
+        const int sh = j - pad;
+        const u8* abase = smem + (c & 1) * G::A_BYTES;
+        const u8* wb = wring + (s % G::NSTW) * G::W_BYTES;
+        s16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int lr = (wm * TM + tm) * 16 + r16 + G::HALO + sh;
+            const int swz = (lr >> 1) & 7;
+            const bool ok = sh >= lo_off[tm] && sh < hi_off[tm];
+            ah[tm] = *reinterpret_cast<const s16x8*>(abase + lr * 128 + ((kq ^ swz) << 4));
+            if (!HI) al[tm] = *reinterpret_cast<const s16x8*>(abase + lr * 128 + (((4 + kq) ^ swz) << 4));
+            if (!ok) {
+                ah[tm] = zero8;
+                al[tm] = zero8;
+            }
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            bh[tn] = *reinterpret_cast<const s16x8*>(wb + b_hi + tn * 16 * 128);
+            if (!HI) bl[tn] = *reinterpret_cast<const s16x8*>(wb + b_lo + tn * 16 * 128);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            if (!HI) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (++j == k) { j = 0; ++c; }
+    }
+    pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES>(a, acc, smem, m0, n0);
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_pconv_cfg(const GemmArgs& a, hipStream_t s, double flops) {
+    using G = CGeo<WM, WN, TM, TN>;
+    const bool hi = gemm_mode() == FCL_GEMM_BF16;
+    const void* fn = hi ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, true>) : reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, false>);
+    const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
+    if (rc) return rc;
+    const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;
+    dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
+    char full[48];
+    snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d>%s", WM, WN, TM, TN, hi ? "/bf16" : "");
+    ProfScope ps(full, flops, a.M, s);
+    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    return check_hip(hipGetLastError(), "pconv launch");
+}
+
 int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
@@ -491,6 +659,12 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     const long long t128x128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     // measured on MI355X (tools/probe/planes_gemm_probe): 8-wave 128 x 128 tiles where they still give >= ~150 workgroups, 64 x 128 with three
     // stages (two workgroups per CU) down to ~250, 64 x 64 below that (the encoder-side GEMMs: M = 3 200, N = 256-384)
+    static const int pconv = tunable("PCONV", 1);
+    if (pconv && a.conv_k >= 3 && a.conv_k <= 2 * CGeo<2, 2, 2, 2>::HALO + 1 && !a.accumulate) {  // Conv1d: the stencil kernel (shared A halo tile)
+        if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pconv_cfg<4, 2, 2, 4>(a, s, flops);
+        if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pconv_cfg<2, 2, 2, 4>(a, s, flops);
+        return launch_pconv_cfg<2, 2, 2, 2>(a, s, flops);
+    }
     if (a.accumulate && force == 0)  // split contraction fills the device whatever the tile count: the largest tiles that fit the output
         return (a.M >= 128 && a.N >= 128) ? launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops) : launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
     if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
