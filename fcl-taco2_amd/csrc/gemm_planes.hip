@@ -495,19 +495,19 @@ static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
 // k taps read it at row offsets -pad .. +pad; only the W chunk changes per step: (BM + 16 + k * BN) * 128 B per channel chunk instead of
 // k * (BM + BN) * 128 B (-39 % for k = 5, 64 x 64 tiles).  Utterance edges: a row outside the segment of the OUTPUT row it contributes to is
 // zeroed per lane at fragment-read time (one shared tile serves rows of two utterances when a tile straddles a boundary).
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int NL_ = 2>
 struct CGeo {
-    static constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN, NL = 2, THREADS = 64 * (NW + NL), CTHREADS = 64 * NW;
-    static constexpr int HALO = 8, AROWS = BM + 2 * HALO, A_BYTES = AROWS * 128, W_BYTES = BN * 128, NSTW = 3;
+    static constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN, NL = NL_, THREADS = 64 * (NW + NL), CTHREADS = 64 * NW;
+    static constexpr int HALO = NL_ == 4 ? 16 : 8, AROWS = BM + 2 * HALO, A_BYTES = AROWS * 128, W_BYTES = BN * 128, NSTW = 3;
     static constexpr int LDS_BYTES = 2 * A_BYTES + NSTW * W_BYTES;
     static constexpr int GAH = AROWS / 8 / NL, GB = BN / 8 / NL;
-    static_assert((AROWS / 8) % NL == 0 && (BN / 8) % NL == 0, "tile rows must split evenly over the two loader waves");
+    static_assert((AROWS / 8) % NL == 0 && (BN / 8) % NL == 0, "tile rows must split evenly over the loader waves");
     static_assert(GAH + GB <= 60, "s_waitcnt vmcnt is a 6-bit field");
 };
 
-template <int WM, int WN, int TM, int TN, bool HI>
-__global__ __launch_bounds__(64 * (WM * WN + 2)) void pconv_kernel(const GemmArgs a) {
-    using G = CGeo<WM, WN, TM, TN>;
+template <int WM, int WN, int TM, int TN, bool HI, int NL>
+__global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmArgs a) {
+    using G = CGeo<WM, WN, TM, TN, NL>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
     xcd_tile_p(bx, by);
@@ -633,21 +633,27 @@ __global__ __launch_bounds__(64 * (WM * WN + 2)) void pconv_kernel(const GemmArg
     pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES>(a, acc, smem, m0, n0);
 }
 
-template <int WM, int WN, int TM, int TN>
-static int launch_pconv_cfg(const GemmArgs& a, hipStream_t s, double flops) {
-    using G = CGeo<WM, WN, TM, TN>;
+template <int WM, int WN, int TM, int TN, int NL>
+static int launch_pconv_nl(const GemmArgs& a, hipStream_t s, double flops) {
+    using G = CGeo<WM, WN, TM, TN, NL>;
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
-    const void* fn = hi ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, true>) : reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, false>);
+    const void* fn = hi ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, true, NL>) : reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, false, NL>);
     const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
     if (rc) return rc;
     const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
     char full[48];
-    snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d>%s", WM, WN, TM, TN, hi ? "/bf16" : "");
+    snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, NL, hi ? "/bf16" : "");
     ProfScope ps(full, flops, a.M, s);
-    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     return check_hip(hipGetLastError(), "pconv launch");
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_pconv_cfg(const GemmArgs& a, hipStream_t s, double flops) {
+    static const int nl = tunable("PCONV_LOADERS", 2);
+    return nl >= 4 ? launch_pconv_nl<WM, WN, TM, TN, 4>(a, s, flops) : launch_pconv_nl<WM, WN, TM, TN, 2>(a, s, flops);
 }
 
 int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
@@ -660,7 +666,7 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     // measured on MI355X (tools/probe/planes_gemm_probe): 8-wave 128 x 128 tiles where they still give >= ~150 workgroups, 64 x 128 with three
     // stages (two workgroups per CU) down to ~250, 64 x 64 below that (the encoder-side GEMMs: M = 3 200, N = 256-384)
     static const int pconv = tunable("PCONV", 1);
-    if (pconv && a.conv_k >= 3 && a.conv_k <= 2 * CGeo<2, 2, 2, 2>::HALO + 1 && !a.accumulate) {  // Conv1d: the stencil kernel (shared A halo tile)
+    if (pconv && a.conv_k >= 3 && a.conv_k <= 17 && !a.accumulate) {  // Conv1d: the stencil kernel (shared A halo tile)
         if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pconv_cfg<4, 2, 2, 4>(a, s, flops);
         if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pconv_cfg<2, 2, 2, 4>(a, s, flops);
         return launch_pconv_cfg<2, 2, 2, 2>(a, s, flops);
