@@ -666,7 +666,11 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     // measured on MI355X (tools/probe/planes_gemm_probe): 8-wave 128 x 128 tiles where they still give >= ~150 workgroups, 64 x 128 with three
     // stages (two workgroups per CU) down to ~250, 64 x 64 below that (the encoder-side GEMMs: M = 3 200, N = 256-384)
     static const int pconv = tunable("PCONV", 1);
-    if (pconv && a.conv_k >= 3 && a.conv_k <= 17 && !a.accumulate) {  // Conv1d: the stencil kernel (shared A halo tile)
+    // Conv1d: the stencil kernel (shared A halo tile).  In isolation it is within +-10 % of the K-term form (3 200 x 256 x 5 x 256: 20.7 vs 18.8 us;
+    // 25 026 x 128 x 5 x 128: 24.7 vs 25.6); its smaller LDS footprint (44 vs 64 KB, 86 vs 96 KB) and 10 instead of 12 waves are what raise the
+    // pass rate with several passes in flight (+1.7 ... +4 %, batch 64 +3.6 %).  At Cin >= 512 (FCL-taco2-T: 33.8 vs 28.0, 124 vs 115 us) the
+    // single-stream training step loses 2 % with it, so those keep the K-term form (PCONV=2 forces the stencil everywhere).
+    if (pconv && a.conv_k >= 3 && a.conv_k <= 17 && !a.accumulate && (a.term[0].K <= 384 || pconv >= 2)) {
         if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pconv_cfg<4, 2, 2, 4>(a, s, flops);
         if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pconv_cfg<2, 2, 2, 4>(a, s, flops);
         return launch_pconv_cfg<2, 2, 2, 2>(a, s, flops);
