@@ -15,6 +15,8 @@ import argparse
 import importlib
 import json
 import logging
+import queue
+import threading
 import time
 
 import numpy as np
@@ -72,22 +74,79 @@ def read_manifest(json_path):
 
 
 @torch.no_grad()
-def decode(model, utts, out_prefix, batch_size=32, seed=137):
-    """utts: [(utt_id, ids)].  Writes PREFIX.ark/.scp; returns (frames, seconds)."""
+def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=2):
+    """utts: [(utt_id, ids)].  Writes PREFIX.ark/.scp; returns (frames, seconds).
+    Pipelined: a batch's packed mel [F, odim] leaves the device in ONE non-blocking copy into pinned memory on a copy stream, and up to `depth`
+    batches are in flight, so the host prepares and enqueues batch i+1 (and writes batch i-1 to the ark) while the GPU runs batch i.  The clock
+    covers first submit -> last mel on the host (the only synchronisation points are the predicted-duration read-back inside a pass and the
+    copy-complete events)."""
     torch.manual_seed(seed)
     order = sorted(range(len(utts)), key=lambda i: -len(utts[i][1]))
-    frames, secs = 0, 0.0
-    with ArkScpWriter(out_prefix) as w:
-        for s in range(0, len(order), batch_size):
+    dev = next(model.parameters()).device
+    frames = 0
+    copy_stream = torch.cuda.Stream(device=dev)
+    pinned = [None] * (depth + 1)
+    pending = []
+
+    # the ark / scp file is written by a worker thread (file writes release the GIL): storage keeps up with the GPU instead of stalling the loop
+    wq = queue.Queue(maxsize=2 * (depth + 1))
+    werr = []
+
+    def writer(w):
+        while True:
+            item = wq.get()
+            if item is None:
+                return
+            try:
+                if not werr:
+                    for uid, arr in item:
+                        w[uid] = arr
+            except Exception as e:  # surfaced by the main thread after the join
+                werr.append(e)
+
+    def harvest(item):
+        chunk, host, counts, ev = item
+        ev.synchronize()
+        arr, s0, out = host.numpy().copy(), 0, []  # one copy out of the pinned slot, which is reused `depth + 1` batches later
+        for (uid, _), c in zip(chunk, counts):
+            out.append((uid, arr[s0 : s0 + c]))
+            s0 += c
+        wq.put(out)
+        return s0
+
+    with ArkScpWriter(out_prefix) as w, torch.cuda.device(dev):
+        th = threading.Thread(target=writer, args=(w,), daemon=True)
+        th.start()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for bi, s in enumerate(range(0, len(order), batch_size)):
             chunk = [utts[i] for i in order[s : s + batch_size]]
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            mels = model.inference_batch([x for _, x in chunk])
-            torch.cuda.synchronize()
-            secs += time.perf_counter() - t0
-            for (uid, _), mel in zip(chunk, mels):
-                frames += mel.shape[0]
-                w[uid] = mel.cpu().numpy()
+            mels = model.inference_batch([x for _, x in chunk])  # views into one packed device buffer, utterance-major
+            counts = [int(m.shape[0]) for m in mels]
+            total = sum(counts)
+            packed = mels[0]._base if mels[0]._base is not None else torch.cat(mels)
+            packed = packed[:total]
+            slot = bi % (depth + 1)
+            if pinned[slot] is None or pinned[slot].shape[0] < total:
+                pinned[slot] = torch.empty(max(total * 5 // 4, 1), packed.shape[1], dtype=torch.float32, pin_memory=True)
+            host = pinned[slot][:total]
+            copy_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(copy_stream):
+                host.copy_(packed, non_blocking=True)
+                packed.record_stream(copy_stream)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            pending.append((chunk, host, counts, ev))
+            while len(pending) > depth:  # the slot written `depth + 1` batches ago is free again only after its harvest
+                frames += harvest(pending.pop(0))
+        while pending:
+            frames += harvest(pending.pop(0))
+        wq.put(None)
+        th.join()
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
+        if werr:
+            raise werr[0]
     return frames, secs
 
 
