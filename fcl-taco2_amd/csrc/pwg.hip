@@ -24,26 +24,43 @@ __global__ __launch_bounds__(256) void pwg_upsample_stage_kernel(const float* __
                                                                  const int* __restrict__ utt_off, long long rows_out, int rate_in, int scale,
                                                                  const float* __restrict__ w, float* __restrict__ out, u16* __restrict__ out_p, int ldp,
                                                                  int C, int chunk_major) {
-    const int cpad = out_p ? ldp * 32 : C;
-    const long long total = rows_out * cpad;
+    // item = (output row, 4 channels).  The 2*scale+1 taps of a row fall on at most three rows of the stage input (nearest-neighbour stretch), so
+    // they collapse to three coefficients per row (sums of the taps that land on each input row and lie inside the utterance: the zero padding
+    // of the smoothing convolution); then 3 float4 loads and 12 FMAs per item.  C % 4 == 0.
+    const int cq = out_p ? ldp * 8 : C >> 2;  // channel quads per row (planes: the zero padding up to the last 32-column line is written too)
+    const long long total = rows_out * cq;
     const int rate_out = rate_in * scale;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / cpad;
-        const int c = (int)(i - r * cpad);
-        float acc = 0.f;
+        const long long r = i / cq;
+        const int c = (int)(i - r * cq) * 4;
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         if (c < C) {
             const int u = frame_utt[r / rate_out];
             const long long lo = (long long)utt_off[u] * rate_out, hi = (long long)utt_off[u + 1] * rate_out;
+            const long long i0 = r / scale;  // input row of the centre tap
+            float k[3] = {0.f, 0.f, 0.f};    // coefficients of input rows i0 - 1, i0, i0 + 1
             for (int j = -scale; j <= scale; ++j) {
                 const long long q = r + j;
                 if (q < lo || q >= hi) continue;
-                acc += w[j + scale] * in[(q / scale) * C + c];  // q / scale: row of the stage input (nearest-neighbour stretch); utterances start on multiples of scale
+                k[(int)(q / scale - i0) + 1] += w[j + scale];
             }
-            if (out) out[r * C + c] = acc;
+            const long long rows_in = rows_out / scale;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const long long ri = i0 + d - 1;
+                if (k[d] != 0.f && ri >= 0 && ri < rows_in) {
+                    const f32x4_t v = *reinterpret_cast<const f32x4_t*>(in + ri * C + c);
+                    acc += k[d] * v;
+                }
+            }
+            if (out) *reinterpret_cast<f32x4_t*>(out + r * C + c) = acc;
         }
         if (out_p) {
-            if (chunk_major) store_p32(out_p + ((size_t)(c >> 5) * rows_out + r) * 64, 1, 0, c & 31, acc);  // line (chunk, row)
-            else store_p32(out_p + (size_t)r * ldp * 64, ldp, 0, c, acc);
+            uint2 h, l;
+            split4(acc, h, l);
+            u16* line = chunk_major ? out_p + ((size_t)(c >> 5) * rows_out + r) * 64 + (c & 31) : out_p + ((size_t)r * ldp + (c >> 5)) * 64 + (c & 31);
+            *reinterpret_cast<uint2*>(line) = h;
+            *reinterpret_cast<uint2*>(line + 32) = l;
         }
     }
 }
@@ -136,12 +153,12 @@ extern "C" {
 
 int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int32_t* utt_off, int64_t frames, int rate_in, int scale, const float* w,
                            float* out, uint16_t* out_p, int c, int chunk_major, fcl_stream_t stream) {
-    FCL_REQUIRE(in && frame_utt && utt_off && w && (out || out_p) && frames > 0 && rate_in >= 1 && scale >= 1 && c > 0, FCL_ERR_INVALID,
-                "pwg_upsample_stage: bad arguments");
+    FCL_REQUIRE(in && frame_utt && utt_off && w && (out || out_p) && frames > 0 && rate_in >= 1 && scale >= 1 && c > 0 && (c & 3) == 0, FCL_ERR_INVALID,
+                "pwg_upsample_stage: bad arguments (channels must be a multiple of 4)");
     FCL_REQUIRE((reinterpret_cast<uintptr_t>(out_p) & 127u) == 0, FCL_ERR_ALIGN, "pwg_upsample_stage: planes must be 128-byte aligned");
     const long long rows_out = (long long)frames * rate_in * scale;
     const int ldp = (c + 31) / 32;
-    hipLaunchKernelGGL(pwg_upsample_stage_kernel, dim3(grid_1d(rows_out * (out_p ? ldp * 32 : c), 256)), dim3(256), 0, (hipStream_t)stream, in, frame_utt, utt_off,
+    hipLaunchKernelGGL(pwg_upsample_stage_kernel, dim3(grid_1d(rows_out * (out_p ? ldp * 8 : c / 4), 256)), dim3(256), 0, (hipStream_t)stream, in, frame_utt, utt_off,
                        rows_out, rate_in, scale, w, out, out_p, ldp, c, chunk_major);
     return check_hip(hipGetLastError(), "pwg_upsample_stage");
 }
