@@ -27,18 +27,21 @@ def build_row_maps(lens, durs, t_max):
     """lens [B]; durs: list of int arrays (len_b each).  Raises AssertionError on a zero duration, like the
     reference's `assert ds_nonzeros.shape[0] == hs.shape[0]` (decoder_sa_kd.py:739)."""
     B = len(lens)
-    src, dur, foff, utt_frames = [], [], [], []
-    base = 0
+    lens_np = np.asarray(lens, dtype=np.int64)
+    parts = [np.asarray(d).reshape(-1) for d in durs]
     for b in range(B):
-        d = np.asarray(durs[b]).reshape(-1).astype(np.int64)
-        assert d.shape[0] == lens[b], "duration count != phoneme count"
-        assert (d > 0).all(), "zero duration: ds_nonzeros.shape[0] != hs.shape[0]"
-        src.append(b * t_max + np.arange(lens[b], dtype=np.int64))
-        dur.append(d)
-        foff.append(base + np.concatenate([[0], np.cumsum(d)[:-1]]))  # exclusive cumsum (H10)
-        utt_frames.append(int(d.sum()))
-        base += utt_frames[-1]
-    src, dur, foff = np.concatenate(src), np.concatenate(dur), np.concatenate(foff)
+        assert parts[b].shape[0] == lens_np[b], "duration count != phoneme count"
+    dur = np.concatenate(parts).astype(np.int64) if B else np.zeros(0, dtype=np.int64)
+    assert (dur > 0).all(), "zero duration: ds_nonzeros.shape[0] != hs.shape[0]"
+    n = dur.shape[0]
+    starts = np.zeros(B + 1, dtype=np.int64)
+    np.cumsum(lens_np, out=starts[1:])
+    src = np.arange(n, dtype=np.int64) + np.repeat(np.arange(B, dtype=np.int64) * t_max - starts[:-1], lens_np)  # row b * t_max + position
+    csum = np.cumsum(dur)
+    foff = csum - dur  # exclusive cumsum over the whole batch = utterance base + exclusive cumsum inside the utterance (H10)
+    fstarts = np.zeros(B + 1, dtype=np.int64)
+    fstarts[1:] = csum[starts[1:] - 1]
+    utt = fstarts[1:] - fstarts[:-1]
     order = np.argsort(-dur, kind="stable")
     m = RowMaps()
     m.order = order
@@ -47,12 +50,11 @@ def build_row_maps(lens, durs, t_max):
     m.frame_off_sorted = foff[order].astype(np.int32)
     m.lmax = int(m.dur_sorted[0])
     # live_rows[t] = #rows with dur > t  (rows sorted descending => a prefix)
-    m.live_rows = np.ascontiguousarray((m.dur_sorted[None, :] > np.arange(m.lmax)[:, None]).sum(axis=1).astype(np.int32))
-    m.utt_frames = utt_frames
-    m.n_frames = base
-    starts = np.concatenate([[0], np.cumsum(utt_frames)])
-    m.frame_lo = np.repeat(starts[:-1], utt_frames).astype(np.int32)
-    m.frame_hi = np.repeat(starts[1:], utt_frames).astype(np.int32)
+    m.live_rows = np.ascontiguousarray((n - np.cumsum(np.bincount(dur, minlength=m.lmax + 1))[: m.lmax]).astype(np.int32))
+    m.utt_frames = [int(v) for v in utt]
+    m.n_frames = int(fstarts[-1])
+    m.frame_lo = np.repeat(fstarts[:-1], utt).astype(np.int32)
+    m.frame_hi = np.repeat(fstarts[1:], utt).astype(np.int32)
     return m
 
 
