@@ -156,6 +156,7 @@ int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int3
     FCL_REQUIRE(in && frame_utt && utt_off && w && (out || out_p) && frames > 0 && rate_in >= 1 && scale >= 1 && c > 0 && (c & 3) == 0, FCL_ERR_INVALID,
                 "pwg_upsample_stage: bad arguments (channels must be a multiple of 4)");
     FCL_REQUIRE((reinterpret_cast<uintptr_t>(out_p) & 127u) == 0, FCL_ERR_ALIGN, "pwg_upsample_stage: planes must be 128-byte aligned");
+    FCL_REQUIRE(aligned16(in) && aligned16(out), FCL_ERR_ALIGN, "pwg_upsample_stage: in / out must be 16-byte aligned");
     const long long rows_out = (long long)frames * rate_in * scale;
     const int ldp = (c + 31) / 32;
     hipLaunchKernelGGL(pwg_upsample_stage_kernel, dim3(grid_1d(rows_out * (out_p ? ldp * 8 : c / 4), 256)), dim3(256), 0, (hipStream_t)stream, in, frame_utt, utt_off,

@@ -473,7 +473,7 @@ int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries);
  *      path (refused under FCL_PRECISION=0 / FCL_PLANES=0). ------------------------------------------------------------------------------- */
 /* One stage of the upsampling network: nearest-neighbour stretch by `scale` + the 1 x (2*scale+1) smoothing convolution w (no bias), per channel.
  * in [frames * rate_in, c] -> out [frames * rate_in * scale, c] fp32 and / or out_p (P32 planes, ceil(c/32) lines per row, zero past c).
- * frame_utt [frames]: utterance of each mel frame; utt_off [n_utt + 1]: first frame of each utterance. */
+ * frame_utt [frames]: utterance of each mel frame; utt_off [n_utt + 1]: first frame of each utterance.  c % 4 == 0; in / out 16-byte aligned. */
 int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int32_t* utt_off, int64_t frames, int rate_in, int scale, const float* w,
                            float* out, uint16_t* out_p, int c, int chunk_major /* out_p as [chunk][row] lines (fcl_gemm_term_t.a_chunk_stride) */,
                            fcl_stream_t stream);
