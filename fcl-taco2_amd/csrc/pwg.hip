@@ -68,14 +68,19 @@ __global__ __launch_bounds__(256) void pwg_upsample_stage_kernel(const float* __
 // first_conv: x[m, ch] = w[ch] * z[m] + b[ch]  (Conv1d1x1(1 -> R))
 __global__ __launch_bounds__(256) void pwg_first_conv_kernel(const float* __restrict__ z, const float* __restrict__ w, const float* __restrict__ b,
                                                              float* __restrict__ x, u16* __restrict__ xp, long long M, int R, int chunk_major) {
-    const long long total = M * R;
+    const int rq = R >> 2;  // item = (sample, 4 channels): one 8-byte store per plane
+    const long long total = M * rq;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long m = i / R;
-        const int ch = (int)(i - m * R);
-        const float v = w[ch] * z[m] + b[ch];
-        if (x) x[i] = v;
-        if (chunk_major) store_p32(xp + ((size_t)(ch >> 5) * M + m) * 64, 1, 0, ch & 31, v);
-        else store_p32(xp + (size_t)m * (R >> 5) * 64, R >> 5, 0, ch, v);
+        const long long m = i / rq;
+        const int ch = (int)(i - m * rq) * 4;
+        const float zm = z[m];
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(w + ch) * zm + *reinterpret_cast<const f32x4_t*>(b + ch);
+        if (x) *reinterpret_cast<f32x4_t*>(x + m * R + ch) = v;
+        uint2 h, l;
+        split4(v, h, l);
+        u16* line = chunk_major ? xp + ((size_t)(ch >> 5) * M + m) * 64 + (ch & 31) : xp + ((size_t)m * (R >> 5) + (ch >> 5)) * 64 + (ch & 31);
+        *reinterpret_cast<uint2*>(line) = h;
+        *reinterpret_cast<uint2*>(line + 32) = l;
     }
 }
 
@@ -172,7 +177,9 @@ int fcl_pwg_noise(float* z, int64_t n, uint32_t seed, fcl_stream_t stream) {
 
 int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x, uint16_t* xp, int64_t m, int r, int chunk_major, fcl_stream_t stream) {
     FCL_REQUIRE(z && w && b && xp && m > 0 && r > 0 && (r & 31) == 0, FCL_ERR_INVALID, "pwg_first_conv: bad arguments (R must be a multiple of 32)");
-    hipLaunchKernelGGL(pwg_first_conv_kernel, dim3(grid_1d(m * r, 1024)), dim3(256), 0, (hipStream_t)stream, z, w, b, x, xp, (long long)m, r, chunk_major);
+    FCL_REQUIRE(aligned16(w) && aligned16(b) && aligned16(x) && (reinterpret_cast<uintptr_t>(xp) & 127u) == 0, FCL_ERR_ALIGN,
+                "pwg_first_conv: w / b / x must be 16-byte aligned, the planes 128-byte aligned");
+    hipLaunchKernelGGL(pwg_first_conv_kernel, dim3(grid_1d(m * (r / 4), 256)), dim3(256), 0, (hipStream_t)stream, z, w, b, x, xp, (long long)m, r, chunk_major);
     return check_hip(hipGetLastError(), "pwg_first_conv");
 }
 

@@ -197,9 +197,9 @@ class ParallelWaveGANGenerator(object):
                 if z.numel() != M:
                     raise _lib.FclError("fcl-taco2_amd: noise must hold T' * %d samples per utterance" % pl.hop)
             seg_lo, seg_hi = mp["seg_lo"], mp["seg_hi"]
-            x, xp = torch.empty(M, R, device=dev), ops.planes_empty(M, R, dev)
-            _lib.check(lib.fcl_pwg_first_conv(z.data_ptr(), pl.first_w.data_ptr(), pl.first_b.data_ptr(), x.data_ptr(), xp.data_ptr(), M, R, int(fused),
-                                              ops._stream()))
+            x, xp = torch.empty(M, R, device=dev), ops.planes_empty(M, R, dev)  # fused blocks carry x as planes only; x is then the last stage's scratch
+            _lib.check(lib.fcl_pwg_first_conv(z.data_ptr(), pl.first_w.data_ptr(), pl.first_b.data_ptr(), None if fused else x.data_ptr(), xp.data_ptr(),
+                                              M, R, int(fused), ops._stream()))
             skips = torch.empty(M, R, device=dev)
             gp = ops.planes_empty(M, R, dev)  # unfused: the gate's planes; fused: the second x buffer (blocks ping-pong between xp and gp)
             zbuf = obuf = None
