@@ -152,16 +152,19 @@ def e2e_workload(args, rank, world, dev, dist):
         _lib.prof_enable(False)
         dom = max(prof, key=lambda k: prof[k]["ms"])
         d = prof[dom]
-        # algorithmic bytes per sample and layer: x planes in 256 + out 256, auxiliary planes 384 (96 padded columns, hi | lo), skips fp32 read + write 512
-        bytes_per_launch = 1408.0 * samples
+        # algorithmic bytes per sample and layer: x planes in 256 + out 256, skips fp32 read + write 512, and the auxiliary term: one 128-byte
+        # coefficient line (frame-rate form, default) or 384 bytes of upsampled-feature planes (96 padded columns, hi | lo)
+        aux_b = 128 if V.aux_frame_rate(gen.plan) else 384
+        bytes_per_launch = (1024.0 + aux_b) * samples
         achieved = bytes_per_launch * d["launches"] / (d["ms"] * 1e-3) / 1e9
         traffic, src = pmc_traffic(dom)
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * d["ms"] / d["launches"], "launches_per_step": d["launches"],
                            "bytes_per_launch": bytes_per_launch, "share_of_kernel_time": d["ms"] / sum(v["ms"] for v in prof.values()),
                            "fp32_equivalent_tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12,
-                           "note": "algorithmic 1408 B per sample per residual block (x planes 256 in + 256 out, auxiliary planes 384, skip accumulator "
-                                   "512); the block's 86 kFLOP per sample (61 FLOP per byte) put it on the HBM side of the fp32-equivalent ridge"}
+                           "note": "algorithmic %d B per sample per residual block (x planes 256 in + 256 out, skip accumulator 512, auxiliary term %d: %s); "
+                                   "the block's 86 kFLOP per sample put it on the HBM side of the fp32-equivalent ridge"
+                                   % (1024 + aux_b, aux_b, "coefficient line of the frame-rate form" if aux_b == 128 else "planes of the upsampled features")}
         if not args.no_cpu_baseline:
             from oracle import fcl_oracle as O, pwg_oracle as PO
 

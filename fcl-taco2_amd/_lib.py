@@ -78,7 +78,8 @@ class Derive(C.Structure):  # fcl_derive_t
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
     _fields_ = [("m", C.c_int64), ("r", C.c_int32), ("aux", C.c_int32), ("ksize", C.c_int32), ("dilation", C.c_int32), ("first_layer", C.c_int32)] + [
-        (n, _P) for n in ("seg_lo", "seg_hi", "x", "xp", "cp", "w_conv_p", "b_conv", "w_aux_p", "w_os_p", "b_os", "skips", "z", "gp", "o", "xp_out")]
+        (n, _P) for n in ("seg_lo", "seg_hi", "x", "xp", "cp", "w_conv_p", "b_conv", "w_aux_p", "w_os_p", "b_os", "skips", "z", "gp", "o", "xp_out",
+                          "kp", "pt_a", "pt_b")] + [("ld_pt", C.c_int32), ("hop", C.c_int32)]
 
 
 class ProfEntry(C.Structure):
@@ -137,6 +138,7 @@ SIGNATURES = {
     "fcl_gemm_tn_planes": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _Z, _P]),
     "fcl_pwg_upsample_stage": (_I, [_P, _P, _P, C.c_int64, _I, _I, _P, _P, _P, _I, _I, _P]),
     "fcl_pwg_noise": (_I, [_P, C.c_int64, C.c_uint32, _P]),
+    "fcl_pwg_aux_coeff": (_I, [_P, C.c_int64, _I, C.c_int64, _P, _P]),
     "fcl_pwg_first_conv": (_I, [_P, _P, _P, _P, _P, C.c_int64, _I, _I, _P]),
     "fcl_pwg_layer_fwd": (_I, [_P, _P]),
     "fcl_pwg_last_fwd": (_I, [_P, _F, _P, _P, _P, _F, _P, _P, _P, C.c_int64, _I, _P]),

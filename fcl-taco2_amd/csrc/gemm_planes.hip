@@ -763,6 +763,8 @@ struct PwgFusedArgs {
     long long xcs;  // chunk stride of the x planes in uint16 elements (= M * 64): x is stored chunk-major
     long long* ts;  // developer aid (FCL_PWG_TS): 8 wall-clock stamps (10 ns units) per workgroup
     int first;
+    const u16 *pt_a, *pt_b;  // frame-rate auxiliary term (fcl_pwg_layer_t.kp): the last term's W tile is a frame window of pt_a / pt_b, chosen per tile
+    int hop;
     int dbg;  // developer timing aid (FCL_PWG_DBG): 1 / 2 / 3 = return after the main loop / the gate / phase 2 (results are then garbage)
 };
 
@@ -965,10 +967,12 @@ __global__ __launch_bounds__(64 * (WM * 2 + 2)) void pwg_layer_kernel(const PwgF
 // rows permuted so that a lane holds tanh column c and sigmoid column c of the same sample (tn tiles alternate tanh / sigmoid) -- its result goes
 // straight into the 32 KB gate-plane buffer, and the second GEMM's result is staged in two 64-row halves through that same buffer once phase 2 has
 // read it.  LDS: ring 96 KB | W_os 32 KB | gate planes / o staging 32 KB.
-template <bool HI, int LW>
+// AUXF: the auxiliary term at frame rate -- 3 x 2 + 1 chunks per tile instead of 3 x 2 + 3, the last one (coefficient lines x a 32-frame window of
+// the projected features) with a W tile that depends on the tile's frame.
+template <bool HI, int LW, bool AUXF>
 __global__ __launch_bounds__(64 * (8 + LW)) void pwg_layer_pkernel(const PwgFusedArgs a, const int ntiles) {
     using G = PGeo<4, 2, 2, 4, 3, LW>;
-    constexpr int TM = 2, TN = 4, WN = 2, BM = 128, NST = 3, NCH = 9;
+    constexpr int TM = 2, TN = 4, WN = 2, BM = 128, NST = 3, NCH = AUXF ? 7 : 9;
     constexpr int WOS = G::LDS_BYTES, GA = WOS + 32768;
     static_assert(G::BM == BM && G::BN == 128 && G::STAGE == 32768, "tile geometry");
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
@@ -999,10 +1003,11 @@ __global__ __launch_bounds__(64 * (8 + LW)) void pwg_layer_pkernel(const PwgFuse
         const u8* pb[G::GB];
         unsigned ia[G::GA];
         int rem = 0, it = 0, slot = 0;
+        const u8* wtile = nullptr;  // AUXF: this tile's frame window
         auto setup_term = [&](int ti) {
             const GemmTerm T = a.term[ti];
             const u8* Ab = reinterpret_cast<const u8*>(T.Ap);
-            const u8* Wb = reinterpret_cast<const u8*>(T.Wp);
+            const u8* Wb = AUXF && ti == a.nterms - 1 ? wtile : reinterpret_cast<const u8*>(T.Wp);
 #pragma unroll
             for (int j = 0; j < G::GA; ++j) {
                 const int src = am[j] + T.shift;
@@ -1025,6 +1030,11 @@ __global__ __launch_bounds__(64 * (8 + LW)) void pwg_layer_pkernel(const PwgFuse
                     alo[j] = a.seg_lo[m];
                     alen[j] = (unsigned)(a.seg_hi[m] - alo[j]);
                 }
+            }
+            if (AUXF) {  // window rule of fcl_pwg_aux_coeff
+                const int f = m0 / a.hop, r = f & 31;
+                const bool sel_a = r >= 2 && r <= 29;
+                wtile = reinterpret_cast<const u8*>(sel_a ? a.pt_a : a.pt_b) + (size_t)(sel_a ? f >> 5 : (f + 16) >> 5) * 128;
             }
             it = 0;
             setup_term(0);
@@ -1246,12 +1256,26 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
     const double flops = 2.0 * (double)L.m * 2.0 * R * ((double)L.ksize * R + L.aux + R);
     static const int persist = tunable("PWG_PERSIST", 1);
-    if (persist && !dbg && exp_terms <= 0 && L.aux > 64) {  // (the persistent kernel is written for 3 x 2 + 3 chunks: r = 64, ksize = 3, 64 < aux <= 96)
+    const bool auxf = L.kp != nullptr;
+    if (auxf) {  // one chunk: coefficient lines (one line per sample) x the tile's frame window
+        GemmTerm& T = a.term[L.ksize];
+        T.K = 32;
+        T.Ap = L.kp; T.lda_p = 1; T.a_chunk_stride = 0;
+        T.Wp = L.pt_a; T.ldw_p = L.ld_pt;
+        a.pt_a = L.pt_a; a.pt_b = L.pt_b; a.hop = L.hop;
+        FCL_REQUIRE(persist && !dbg && exp_terms <= 0, FCL_ERR_INVALID, "pwg_layer_fwd: the frame-rate auxiliary term runs on the persistent kernel only");
+    }
+    if (persist && !dbg && exp_terms <= 0 && (auxf || L.aux > 64)) {  // (the persistent kernel is written for 3 x 2 + 3 chunks: r = 64, ksize = 3, 64 < aux <= 96)
         constexpr int LDS = PGeo<4, 2, 2, 4, 3, 2>::LDS_BYTES + 2 * 32768;
         static const int plw = tunable("PWG_LOADERS", 4);  // 4 loader waves: 151.9 -> 145.1 ms per 30 blocks
-        const void* fn = plw >= 4 ? (hi ? reinterpret_cast<const void*>(pwg_layer_pkernel<true, 4>) : reinterpret_cast<const void*>(pwg_layer_pkernel<false, 4>))
-                                  : (hi ? reinterpret_cast<const void*>(pwg_layer_pkernel<true, 2>) : reinterpret_cast<const void*>(pwg_layer_pkernel<false, 2>));
-        const int rc = ensure_dyn_lds(fn, LDS);
+        const int lwv = plw >= 4 ? 4 : 2;
+        typedef void (*kern_t)(const PwgFusedArgs, const int);
+        static const kern_t table[2][2][2] = {{{pwg_layer_pkernel<false, 2, false>, pwg_layer_pkernel<false, 2, true>},
+                                               {pwg_layer_pkernel<false, 4, false>, pwg_layer_pkernel<false, 4, true>}},
+                                              {{pwg_layer_pkernel<true, 2, false>, pwg_layer_pkernel<true, 2, true>},
+                                               {pwg_layer_pkernel<true, 4, false>, pwg_layer_pkernel<true, 4, true>}}};
+        const kern_t fn = table[hi ? 1 : 0][lwv == 4 ? 1 : 0][auxf ? 1 : 0];
+        const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(fn), LDS);
         if (rc) return rc;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1259,14 +1283,7 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
         static const int wg_per_cu = tunable("PWG_PERSIST_WGS", 0);  // 0: one workgroup per CU (160 KB of LDS each)
         int nwg = std::min(ntiles, wg_per_cu > 0 ? wg_per_cu : cus);
         ProfScope ps(hi ? "pwg_layer_pkernel/bf16" : "pwg_layer_pkernel", flops, (int)L.m, s);
-        const dim3 blk(64 * (8 + (plw >= 4 ? 4 : 2)));
-        if (plw >= 4) {
-            if (hi) hipLaunchKernelGGL((pwg_layer_pkernel<true, 4>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
-            else hipLaunchKernelGGL((pwg_layer_pkernel<false, 4>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
-        } else {
-            if (hi) hipLaunchKernelGGL((pwg_layer_pkernel<true, 2>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
-            else hipLaunchKernelGGL((pwg_layer_pkernel<false, 2>), dim3((unsigned)nwg), blk, LDS, s, a, ntiles);
-        }
+        hipLaunchKernelGGL(fn, dim3((unsigned)nwg), dim3(64 * (8 + lwv)), LDS, s, a, ntiles);
         return check_hip(hipGetLastError(), "pwg_layer persistent launch");
     }
     // measured on MI355X, 64 x 800 frames, ms per layer: 128-row tiles + 3-deep ring + W_os in LDS 7.07 (default); the same with a 4-deep ring and

@@ -135,6 +135,46 @@ __global__ __launch_bounds__(256) void pwg_out_kernel(const float* __restrict__ 
     }
 }
 
+// coefficient lines of the frame-rate auxiliary term (include/fcl_hip.h: fcl_pwg_aux_coeff): one 128-byte line per sample
+__global__ __launch_bounds__(256) void pwg_aux_coeff_kernel(const float* __restrict__ kc, long long M, int hop, long long frames, u16* __restrict__ kp) {
+    for (long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x; m < M; m += (long long)gridDim.x * blockDim.x) {
+        const long long f = m / hop;
+        const int r = (int)(f & 31);
+        const long long w0 = (r >= 2 && r <= 29) ? (f >> 5) * 32 : ((f + 16) >> 5) * 32 - 16;
+        const f32x4_t k03 = *reinterpret_cast<const f32x4_t*>(kc + m * 8);
+        const float k4 = kc[m * 8 + 4];
+        const float kv[5] = {k03[0], k03[1], k03[2], k03[3], k4};
+        unsigned hw[16], lw[16];  // 32 columns, two bf16 per word
+#pragma unroll
+        for (int i = 0; i < 16; ++i) hw[i] = lw[i] = 0u;
+        const int p0 = (int)(f - 2 - w0);  // column of frame f - 2 (0 .. 27)
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+            const long long g = f - 2 + d;
+            if (g < 0 || g >= frames) continue;
+            float v = 0.f;
+            const int c = (int)(g % 5);
+#pragma unroll
+            for (int e = 0; e < 5; ++e) v = c == e ? kv[e] : v;
+            const __bf16 h = (__bf16)v;
+            const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)h));
+            const int col = p0 + d;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i == (col >> 1)) {
+                    hw[i] |= hb << ((col & 1) * 16);
+                    lw[i] |= lb << ((col & 1) * 16);
+                }
+        }
+        uint4* line = reinterpret_cast<uint4*>(kp + (size_t)m * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            line[i] = make_uint4(hw[4 * i], hw[4 * i + 1], hw[4 * i + 2], hw[4 * i + 3]);
+            line[4 + i] = make_uint4(lw[4 * i], lw[4 * i + 1], lw[4 * i + 2], lw[4 * i + 3]);
+        }
+    }
+}
+
 // z ~ N(0, 1): Box-Muller on two hashed 24-bit uniforms per element (counter-based: element i of a given seed is reproducible on any grid)
 __global__ __launch_bounds__(256) void pwg_noise_kernel(float* __restrict__ z, long long n, unsigned int seed) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -169,6 +209,13 @@ int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int3
     return check_hip(hipGetLastError(), "pwg_upsample_stage");
 }
 
+int fcl_pwg_aux_coeff(const float* kc, int64_t m, int hop, int64_t frames, uint16_t* kp, fcl_stream_t stream) {
+    FCL_REQUIRE(kc && kp && m > 0 && hop > 0 && frames > 0 && m <= frames * (int64_t)hop, FCL_ERR_INVALID, "pwg_aux_coeff: bad arguments");
+    FCL_REQUIRE(aligned16(kc) && (reinterpret_cast<uintptr_t>(kp) & 127u) == 0, FCL_ERR_ALIGN, "pwg_aux_coeff: kc must be 16-byte, kp 128-byte aligned");
+    hipLaunchKernelGGL(pwg_aux_coeff_kernel, dim3(grid_1d(m, 256)), dim3(256), 0, (hipStream_t)stream, kc, (long long)m, hop, (long long)frames, kp);
+    return check_hip(hipGetLastError(), "pwg_aux_coeff");
+}
+
 int fcl_pwg_noise(float* z, int64_t n, uint32_t seed, fcl_stream_t stream) {
     FCL_REQUIRE(z && n > 0, FCL_ERR_INVALID, "pwg_noise: bad arguments");
     hipLaunchKernelGGL(pwg_noise_kernel, dim3(grid_1d(n, 1024)), dim3(256), 0, (hipStream_t)stream, z, (long long)n, seed);
@@ -184,8 +231,16 @@ int fcl_pwg_first_conv(const float* z, const float* w, const float* b, float* x,
 }
 
 int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream) {
-    FCL_REQUIRE(a && a->m > 0 && (a->x || a->xp_out) && a->xp && a->cp && a->w_conv_p && a->b_conv && a->w_aux_p && a->w_os_p && a->b_os && a->skips && a->seg_lo && a->seg_hi,
+    FCL_REQUIRE(a && a->m > 0 && (a->x || a->xp_out) && a->xp && (a->kp || (a->cp && a->w_aux_p)) && a->w_conv_p && a->b_conv && a->w_os_p && a->b_os && a->skips &&
+                    a->seg_lo && a->seg_hi,
                 FCL_ERR_INVALID, "pwg_layer_fwd: null argument");
+    if (a->kp) {
+        FCL_REQUIRE(a->xp_out && a->pt_a && a->pt_b && a->ld_pt > 0 && a->hop > 0 && a->hop % 128 == 0, FCL_ERR_INVALID,
+                    "pwg_layer_fwd: the frame-rate auxiliary term needs the one-launch form (xp_out), pt_a / pt_b / ld_pt and a hop that is a multiple of 128");
+        FCL_REQUIRE(((reinterpret_cast<uintptr_t>(a->kp) | reinterpret_cast<uintptr_t>(a->pt_a) | reinterpret_cast<uintptr_t>(a->pt_b)) & 127u) == 0, FCL_ERR_ALIGN,
+                    "pwg_layer_fwd: kp / pt_a / pt_b must be 128-byte aligned");
+        FCL_REQUIRE((a->m + a->hop - 1) / a->hop + 16 <= (int64_t)a->ld_pt * 32, FCL_ERR_SHAPE, "pwg_layer_fwd: ld_pt does not cover the frames");
+    }
     FCL_REQUIRE(a->r > 0 && (a->r & 31) == 0 && a->aux > 0 && a->dilation >= 1 && a->ksize >= 1 && (a->ksize & 1) && a->ksize + 1 <= FCL_MAX_TERMS, FCL_ERR_SHAPE,
                 "pwg_layer_fwd: residual channels must be a multiple of 32, kernel size odd and < %d", FCL_MAX_TERMS);
     FCL_REQUIRE(a->m <= 0x7fffffffLL, FCL_ERR_SHAPE, "pwg_layer_fwd: more than 2^31 samples in one call");

@@ -98,10 +98,23 @@ class PWGPlan(object):
                     w_conv_p=ops.pack_planes(wp.reshape(self.k * 2 * self.R, self.R)), b_conv=t(sd[p + "conv.bias"]),
                     w_aux_p=ops.pack_planes(t(sd[p + "conv1x1_aux.weight"].reshape(2 * self.R, self.A))),
                     w_os_p=ops.pack_planes(t(w_os)), b_os=t(np.concatenate([sd[p + "conv1x1_out.bias"], sd[p + "conv1x1_skip.bias"]]))))
+            # every block's conv1x1_aux stacked [layers * 2R, A]: the frame-rate form of the auxiliary term projects the features once for all blocks
+            self.w_aux_all_p = ops.pack_planes(t(np.concatenate([sd["conv_layers.%d.conv1x1_aux.weight" % l].reshape(2 * self.R, self.A)
+                                                                 for l in range(cfg["layers"])])))
             self.last_w1p = ops.pack_planes(t(sd["last_conv_layers.1.weight"].reshape(self.S, self.S)))
             self.last_b1 = t(sd["last_conv_layers.1.bias"])
             self.last_w2 = t(sd["last_conv_layers.3.weight"].reshape(-1))
             self.last_b2 = float(np.asarray(sd["last_conv_layers.3.bias"]).reshape(-1)[0])
+
+
+def fused_block(plan):
+    """One launch per residual block: the published v1 geometry (64 residual channels, kernel 3, <= 96 auxiliary channels); FCL_PWG_FUSED=0 opts out."""
+    return plan.R == 64 and plan.k == 3 and plan.A <= 96 and os.environ.get("FCL_PWG_FUSED", "1") != "0"
+
+
+def aux_frame_rate(plan):
+    """The one-launch block with the auxiliary term evaluated at frame rate (default; FCL_PWG_AUX_FRAME_RATE=0 = planes of the upsampled features)."""
+    return fused_block(plan) and plan.hop % 128 == 0 and os.environ.get("FCL_PWG_AUX_FRAME_RATE", "1") != "0"
 
 
 class ParallelWaveGANGenerator(object):
@@ -143,25 +156,58 @@ class ParallelWaveGANGenerator(object):
         return m
 
     # ---- feature side: replicate padding + conv_in at frame rate, then 4 x (stretch + smoothing) to sample rate --------------------------------
-    def _upsample(self, mel_rows, mp, chunk_major):
-        pl, dev = self.plan, self.plan.device
-        A = pl.A
+    def _conv_in(self, mel_rows, mp):
+        """replicate padding + conv_in at frame rate -> [sum T', A]"""
         c_pad = ops.gather_rows(mel_rows, mp["pad_idx"])
-        c_in = ops.conv1d(c_pad, pl.conv_in, None, mp["lo"], mp["hi"])
-        c = ops.gather_rows(c_in, mp["keep"])  # [sum T', A]
+        c_in = ops.conv1d(c_pad, self.plan.conv_in, None, mp["lo"], mp["hi"])
+        return ops.gather_rows(c_in, mp["keep"])
+
+    def _cascade(self, c, mp, want_planes, chunk_major=False):
+        """The 4 x (stretch + smoothing) stages on c [frames, C] (C % 4 == 0): planes of the result (want_planes) or the fp32 result."""
+        pl, dev = self.plan, self.plan.device
+        C_ = c.shape[1]
         frames = int(mp["offs"][-1])
         rate, lib = 1, _lib.load()
         n_st = len(pl.up_w)
-        cp = None
         for i, s in enumerate(pl.cfg["upsample_scales"]):
             last = i == n_st - 1
             rows = frames * rate * s
-            out = None if last else torch.empty(rows, A, device=dev)
-            cp = ops.planes_empty(rows, A, dev) if last else None
+            as_planes = last and want_planes
+            out = ops.planes_empty(rows, C_, dev) if as_planes else torch.empty(rows, C_, device=dev)
             _lib.check(lib.fcl_pwg_upsample_stage(c.data_ptr(), mp["frame_utt"].data_ptr(), mp["utt_off"].data_ptr(), frames, rate, s, pl.up_w[i].data_ptr(),
-                                                  None if out is None else out.data_ptr(), None if cp is None else cp.data_ptr(), A, int(chunk_major), ops._stream()))
+                                                  None if as_planes else out.data_ptr(), out.data_ptr() if as_planes else None, C_, int(chunk_major),
+                                                  ops._stream()))
             c, rate = out, rate * s
-        return cp
+        return c
+
+    def _upsample(self, mel_rows, mp, chunk_major):
+        return self._cascade(self._conv_in(mel_rows, mp), mp, True, chunk_major)
+
+    def _aux_frame_rate(self, mel_rows, mp):
+        """The auxiliary term of every block at frame rate (fcl_pwg_layer_t.kp): the upsampling network is linear and a sample of frame f sees
+        frames f-2 .. f+2 only, so conv1x1_aux(upsample(c))[m] = sum_g k[m][g] (W_aux c_in[g]).  Returns (coefficient lines [M], planes of W_aux c_in^T
+        for all blocks in the two window alignments, lines per row)."""
+        pl, dev = self.plan, self.plan.device
+        lib = _lib.load()
+        frames = int(mp["offs"][-1])
+        M = frames * pl.hop
+        # k: response of the upsampling network (utterance edges included) to the colour basis e[g][c] = (g mod 5 == c)
+        g = torch.arange(frames, device=dev)
+        e = (g[:, None] % 5 == torch.arange(8, device=dev)[None, :]).to(torch.float32).contiguous()
+        kc = self._cascade(e, mp, False)
+        kp = ops.planes_empty(M, 32, dev)
+        _lib.check(lib.fcl_pwg_aux_coeff(kc.data_ptr(), M, pl.hop, frames, kp.data_ptr(), ops._stream()))
+        # projected features, gate-row major over frames: line q of pt_a = frames [32q, 32q + 32), of pt_b = frames [32q - 16, 32q + 16)
+        ld_pt = (frames + 16 + 31) // 32
+        n = ld_pt * 32
+        cfull = torch.zeros(16 + n, pl.A, device=dev)
+        cfull[16 : 16 + frames] = self._conv_in(mel_rows, mp)
+        cfull_p = ops.pack_planes(cfull)
+        rows = pl.w_aux_all_p.shape[0]
+        pt_a = ops.linear_planes(pl.w_aux_all_p, cfull_p[16:], n, pl.A, want_f32=False, want_planes=True)[1]
+        pt_b = ops.linear_planes(pl.w_aux_all_p, cfull_p, n, pl.A, want_f32=False, want_planes=True)[1]
+        assert pt_a.shape == (rows, ld_pt * 64)
+        return kp, pt_a, pt_b, ld_pt
 
     def synthesize(self, mels, noise=None, seed=0, return_intermediates=False):
         """mels: list of [T'_i, aux] float tensors / arrays.  noise: optional list of [T'_i * hop] arrays (else drawn on the device from `seed`).
@@ -185,8 +231,13 @@ class ParallelWaveGANGenerator(object):
             mp = self._maps(lens)
             offs = mp["offs"]
             M, R = int(offs[-1]) * pl.hop, pl.R
-            fused = R == 64 and pl.k == 3 and pl.A <= 96 and os.environ.get("FCL_PWG_FUSED", "1") != "0"  # one launch per residual block
-            cp = self._upsample(mel_rows, mp, fused)  # the one-launch block reads chunk-major planes (contiguous rows per 32-column chunk)
+            fused = fused_block(pl)
+            aux_fr = aux_frame_rate(pl)
+            if aux_fr:
+                cp = None
+                kp, pt_a, pt_b, ld_pt = self._aux_frame_rate(mel_rows, mp)
+            else:
+                cp = self._upsample(mel_rows, mp, fused)  # the one-launch block reads chunk-major planes (contiguous rows per 32-column chunk)
             if M >= 2 ** 31:
                 raise _lib.FclError("fcl-taco2_amd: more than 2^31 samples in one vocoder batch")
             if noise is None:
@@ -210,8 +261,14 @@ class ParallelWaveGANGenerator(object):
                 a = _lib.PwgLayer()
                 a.m, a.r, a.aux, a.ksize, a.dilation, a.first_layer = M, R, pl.A, pl.k, L["dilation"], int(l == 0)
                 a.seg_lo, a.seg_hi = seg_lo.data_ptr(), seg_hi.data_ptr()
-                a.x, a.xp, a.cp = x.data_ptr(), xp.data_ptr(), cp.data_ptr()
+                a.x, a.xp = x.data_ptr(), xp.data_ptr()
                 a.w_conv_p, a.b_conv, a.w_aux_p = L["w_conv_p"].data_ptr(), L["b_conv"].data_ptr(), L["w_aux_p"].data_ptr()
+                if aux_fr:
+                    row0 = l * 2 * R * ld_pt * 64  # this block's gate rows of the stacked projection (int16 elements)
+                    a.kp, a.pt_a, a.pt_b = kp.data_ptr(), pt_a.data_ptr() + 2 * row0, pt_b.data_ptr() + 2 * row0
+                    a.ld_pt, a.hop = ld_pt, pl.hop
+                else:
+                    a.cp = cp.data_ptr()
                 a.w_os_p, a.b_os, a.skips = L["w_os_p"].data_ptr(), L["b_os"].data_ptr(), skips.data_ptr()
                 if fused:
                     a.xp_out = gp.data_ptr()

@@ -477,6 +477,11 @@ int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries);
 int fcl_pwg_upsample_stage(const float* in, const int32_t* frame_utt, const int32_t* utt_off, int64_t frames, int rate_in, int scale, const float* w,
                            float* out, uint16_t* out_p, int c, int chunk_major /* out_p as [chunk][row] lines (fcl_gemm_term_t.a_chunk_stride) */,
                            fcl_stream_t stream);
+/* Coefficient lines of the frame-rate auxiliary term (fcl_pwg_layer_t.kp).  kc [m, 8]: the upsampling network's response to the colour basis
+ * e[g][c] = (g mod 5 == c) over the batch's frames (columns 5..7 unused), i.e. kc[m][g mod 5] is the weight of frame g in sample m for the five
+ * frames g = f-2 .. f+2 around the sample's own frame f = m / hop.  Line of sample m: that weight at column g - w0(f), zero elsewhere, where the
+ * window is w0 = 32 (f >> 5) (read from pt_a) when 2 <= f mod 32 <= 29 and w0 = 32 ((f + 16) >> 5) - 16 (read from pt_b) otherwise. */
+int fcl_pwg_aux_coeff(const float* kc, int64_t m, int hop, int64_t frames, uint16_t* kp, fcl_stream_t stream);
 /* The generator's input noise z ~ N(0, 1) (ParallelWaveGANGenerator.inference draws torch.randn): counter-based, reproducible per (seed, index). */
 int fcl_pwg_noise(float* z, int64_t n, uint32_t seed, fcl_stream_t stream);
 /* first_conv (Conv1d1x1 1 -> r): x[m, ch] = w[ch] * z[m] + b[ch], written as fp32 (optional) and as planes (row-major or chunk-major). */
@@ -505,6 +510,14 @@ typedef struct {
     uint16_t* xp_out;          /* != NULL: the block runs as ONE launch (r = 64, ksize = 3, aux <= 96 only) that reads x from xp and writes the new
                                 * planes to xp_out (a different buffer: neighbouring tiles still read xp for their taps); x, z, gp, o are unused.
                                 * In this form xp, xp_out and cp are CHUNK-MAJOR planes (line (chunk c, row m) at c * m_total * 128 + m * 128 bytes) */
+    /* one-launch form only, optional (kp != NULL; cp / w_aux_p are then unused): the auxiliary term evaluated at FRAME rate.  The upsampling network
+     * is linear and a sample of frame f sees frames f-2 .. f+2 only, so conv1x1_aux(upsample(c))[m] = sum_g k[m][g] * (W_aux c_in[g]): one K-chunk of 32
+     * (coefficient line of the sample x the frame window of the projected features) replaces the ceil(aux/32) chunks of upsampled features. */
+    const uint16_t* kp;        /* [m] coefficient lines (fcl_pwg_aux_coeff) */
+    const uint16_t* pt_a;      /* planes of (W_aux c_in^T) [2r, frames]: line q of a row = frames [32q, 32q + 32) */
+    const uint16_t* pt_b;      /* the same shifted by 16 frames: line q = frames [32q - 16, 32q + 16), zero where there is no frame */
+    int32_t ld_pt;             /* lines per row of pt_a / pt_b (>= (frames + 16 + 31) / 32) */
+    int32_t hop;               /* samples per frame: a multiple of 128 (a 128-sample tile lies inside one frame) */
 } fcl_pwg_layer_t;
 int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
 /* last_conv_layers: wav[m] = relu(relu(skips * scale) W1^T + b1) . w2 + b2.  yp: workspace planes [m, s_ch]; h: workspace fp32 [m, s_ch]. */

@@ -117,6 +117,25 @@ def test_fused_and_unfused_blocks_agree(voc, monkeypatch):
         assert max_abs(x.cpu(), y.cpu()) < 1e-3 * float(y.abs().max())
 
 
+def test_frame_rate_auxiliary_term_across_window_boundaries(voc, monkeypatch):
+    """The default one-launch block evaluates conv1x1_aux(upsample(c)) at frame rate (coefficient lines x a 32-frame window of W_aux c_in, two window
+    alignments).  70 frames in ragged utterances put tiles on every frame position mod 32, incl. the four that switch to the shifted windows and
+    utterance edges right at a window boundary; against the oracle and against the upsampled-feature form of the same block."""
+    lens = [29, 3, 1, 33, 2, 2]
+    got, want, aux, (tsd, mels, noise, hop) = run_both(voc, None, lens, 5)
+    for g, w in zip(got, want):
+        assert max_abs(g.cpu(), w) < 1e-3 * float(w.abs().max())
+    monkeypatch.setenv("FCL_PWG_AUX_FRAME_RATE", "0")
+    gen = voc.ParallelWaveGANGenerator(voc.PWGPlan(weights(voc), DEV))
+    ref, ir = gen.synthesize(mels, noise=noise, return_intermediates=True)
+    torch.cuda.synchronize()
+    for l in (0, 1, 15, 29):
+        assert max_abs(aux["taps"][l].cpu(), ir["taps"][l].cpu()) < 1e-4, l
+    assert max_abs(aux["skips"].cpu(), ir["skips"].cpu()) < 1e-4
+    for x, y in zip(got, ref):
+        assert max_abs(x.cpu(), y.cpu()) < 1e-3 * float(y.abs().max())
+
+
 def test_device_noise_is_standard_normal(voc):
     from fcl_taco2_amd import _lib, ops
 
