@@ -177,6 +177,8 @@ bool planes_ok(const GemmTerm* t, int n);                  // every term carries
 int launch_gemm_planes(const GemmArgs& a, hipStream_t s);  // gemm_planes.hip
 int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s);
 int launch_pwg_layer_fused(const fcl_pwg_layer_t& a, hipStream_t s);  // one Parallel WaveGAN residual block in one launch (r = 64, ksize = 3, aux <= 96)
+int launch_pwg_last_fused(const float* skips, float scale, const unsigned short* w1p, const float* b1, const float* w2, float b2, float* wav, long long m,
+                          hipStream_t s);  // last_conv_layers in one launch (64 skip channels)
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wave-per-gate kernel (fp32 operands) rather than a big-tile kernel

@@ -1295,6 +1295,89 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& L, hipStream_t s) {
     return hi ? launch_pwg_cfg<4, 3, true>(a, L.m, flops, s) : launch_pwg_cfg<4, 3, false>(a, L.m, flops, s);
 }
 
+// ---- the generator's last_conv_layers in one launch: wav[m] = relu(relu(skips[m] * scale) W1^T + b1) . w2 + b2  (64 skip channels).
+// A 128-sample tile of the skip accumulator is read ONCE (the kernel's only HBM traffic besides 4 bytes per sample out): ReLU * scale and the
+// bf16x3 split go straight into LDS in the fragment layout (swizzled 128-byte lines, one 32-column chunk after the other), W1's planes are
+// staged once per workgroup, the 64 x 64 GEMM runs on the MFMA pipe, and the 64 -> 1 projection is an in-register dot + a 16-lane reduction.
+template <bool HI>
+__global__ __launch_bounds__(256) void pwg_last_kernel(const float* __restrict__ skips, float scale, const u16* __restrict__ w1p, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, float b2, float* __restrict__ wav, int M, int ntiles) {
+    constexpr int TM = 2, TN = 4, AB = 0, WB = 32768;
+    __shared__ __attribute__((aligned(1024))) u8 smem[32768 + 16384];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 1024; i += 256) {  // W1 [64, 64] planes -> LDS, chunk-major
+        const int n = i >> 4, c = (i >> 3) & 1, p = i & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(w1p + ((size_t)(n * 2 + c) * 64 + p * 8));
+        *reinterpret_cast<uint4*>(smem + WB + c * 8192 + n * 128 + ((p ^ ((n >> 1) & 7)) << 4)) = v;
+    }
+    const int col = lane & 15, rq = lane >> 4, r16 = lane & 15, kq = lane >> 4, sw = r16 >> 1;
+    float bb[TN], ww[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        bb[tn] = b1[tn * 16 + col];
+        ww[tn] = w2[tn * 16 + col];
+    }
+    const int ar = (wave * TM * 16 + r16) * 128, br = r16 * 128;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int m0 = t * 128;
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j, row = i >> 4;
+            v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (m0 + row < M) v[j] = *reinterpret_cast<const f32x4*>(skips + (size_t)(m0 + row) * 64 + (i & 15) * 4);
+        }
+        __syncthreads();  // the previous tile's fragments have been read (first pass: W1 is staged)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j, row = i >> 4, c4 = (i & 15) * 4, k = c4 & 31;
+            f32x4_t y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(v[j][e] * scale, 0.f);
+            uint2 h, l;
+            split4(y, h, l);
+            u8* line = smem + AB + (c4 >> 5) * 16384 + row * 128 + (k & 7) * 2;
+            const int sws = (row >> 1) & 7;
+            *reinterpret_cast<uint2*>(line + (((k >> 3) ^ sws) << 4)) = h;
+            if (!HI) *reinterpret_cast<uint2*>(line + (((4 + (k >> 3)) ^ sws) << 4)) = l;
+        }
+        __syncthreads();
+        f32x4 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            pchunk_mma<TM, TN, HI>(smem, AB + c * 16384 + ar + ((kq ^ sw) << 4), AB + c * 16384 + ar + (((4 + kq) ^ sw) << 4),
+                                   WB + c * 8192 + br + ((kq ^ sw) << 4), WB + c * 8192 + br + (((4 + kq) ^ sw) << 4), acc);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sum = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) sum += fmaxf(acc[tm][tn][r] + bb[tn], 0.f) * ww[tn];
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+                const int m = m0 + (wave * TM + tm) * 16 + rq * 4 + r;
+                if (col == 0 && m < M) wav[m] = sum + b2;
+            }
+    }
+}
+
+int launch_pwg_last_fused(const float* skips, float scale, const u16* w1p, const float* b1, const float* w2, float b2, float* wav, long long m, hipStream_t s) {
+    const bool hi = gemm_mode() == FCL_GEMM_BF16;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int ntiles = (int)((m + 127) / 128);
+    const unsigned grid = (unsigned)std::min(ntiles, cus * 3);  // 48 KB of LDS: three workgroups per CU
+    ProfScope ps(hi ? "pwg_last_kernel/bf16" : "pwg_last_kernel", 2.0 * (double)m * 64 * 65, (int)m, s);
+    if (hi) hipLaunchKernelGGL(pwg_last_kernel<true>, dim3(grid), dim3(256), 0, s, skips, scale, w1p, b1, w2, b2, wav, (int)m, ntiles);
+    else hipLaunchKernelGGL(pwg_last_kernel<false>, dim3(grid), dim3(256), 0, s, skips, scale, w1p, b1, w2, b2, wav, (int)m, ntiles);
+    return check_hip(hipGetLastError(), "pwg_last launch");
+}
+
 // --------------------------------------------------------------------------------------------------------------------------------------
 __global__ void pack_planes_kernel(const float* __restrict__ x, int ld, int rows, int cols, u16* __restrict__ out, int ldp) {
     const long long total = (long long)rows * ldp * 32;

@@ -287,9 +287,13 @@ int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream) {
 
 int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const float* b1, const float* w2, float b2, uint16_t* yp, float* h, float* wav,
                      int64_t m, int s_ch, fcl_stream_t stream) {
-    FCL_REQUIRE(skips && w1p && b1 && w2 && yp && h && wav && m > 0 && m <= 0x7fffffffLL && s_ch > 0 && (s_ch & 31) == 0, FCL_ERR_INVALID,
+    FCL_REQUIRE(skips && w1p && b1 && w2 && wav && m > 0 && m <= 0x7fffffffLL && s_ch > 0 && (s_ch & 31) == 0, FCL_ERR_INVALID,
                 "pwg_last_fwd: bad arguments (skip channels must be a multiple of 32)");
     hipStream_t s = (hipStream_t)stream;
+    static const int fused = tunable("PWG_LAST_FUSED", 1);
+    if (s_ch == 64 && fused && aligned16(skips) && (reinterpret_cast<uintptr_t>(w1p) & 15u) == 0)  // one launch, skips read once; no workspaces
+        return launch_pwg_last_fused(skips, scale, w1p, b1, w2, b2, wav, m, s);
+    FCL_REQUIRE(yp && h, FCL_ERR_WORKSPACE, "pwg_last_fwd: this channel count needs the yp / h workspaces");
     hipLaunchKernelGGL(pwg_relu_scale_kernel, dim3(grid_1d(m * s_ch, 1024)), dim3(256), 0, s, skips, scale, yp, (long long)m, s_ch);
     GemmArgs g = {};
     g.term[0].K = s_ch;

@@ -248,7 +248,9 @@ class ParallelWaveGANGenerator(object):
                 if z.numel() != M:
                     raise _lib.FclError("fcl-taco2_amd: noise must hold T' * %d samples per utterance" % pl.hop)
             seg_lo, seg_hi = mp["seg_lo"], mp["seg_hi"]
-            x, xp = torch.empty(M, R, device=dev), ops.planes_empty(M, R, dev)  # fused blocks carry x as planes only; x is then the last stage's scratch
+            # the one-launch blocks carry x as planes only; fp32 x is then just the workspace of the general last stage (not needed for 64 channels)
+            x = None if fused and pl.S == 64 else torch.empty(M, R, device=dev)
+            xp = ops.planes_empty(M, R, dev)
             _lib.check(lib.fcl_pwg_first_conv(z.data_ptr(), pl.first_w.data_ptr(), pl.first_b.data_ptr(), None if fused else x.data_ptr(), xp.data_ptr(),
                                               M, R, int(fused), ops._stream()))
             skips = torch.empty(M, R, device=dev)
@@ -261,7 +263,7 @@ class ParallelWaveGANGenerator(object):
                 a = _lib.PwgLayer()
                 a.m, a.r, a.aux, a.ksize, a.dilation, a.first_layer = M, R, pl.A, pl.k, L["dilation"], int(l == 0)
                 a.seg_lo, a.seg_hi = seg_lo.data_ptr(), seg_hi.data_ptr()
-                a.x, a.xp = x.data_ptr(), xp.data_ptr()
+                a.x, a.xp = None if x is None else x.data_ptr(), xp.data_ptr()
                 a.w_conv_p, a.b_conv, a.w_aux_p = L["w_conv_p"].data_ptr(), L["b_conv"].data_ptr(), L["w_aux_p"].data_ptr()
                 if aux_fr:
                     row0 = l * 2 * R * ld_pt * 64  # this block's gate rows of the stacked projection (int16 elements)
@@ -281,7 +283,8 @@ class ParallelWaveGANGenerator(object):
                     taps.append(unpack_planes(xp, R, chunk_major=True) if fused else x.clone())
             wav = torch.empty(M, device=dev)
             _lib.check(lib.fcl_pwg_last_fwd(skips.data_ptr(), math.sqrt(1.0 / len(pl.layers)), pl.last_w1p.data_ptr(), pl.last_b1.data_ptr(),
-                                            pl.last_w2.data_ptr(), pl.last_b2, gp.data_ptr(), x.data_ptr(), wav.data_ptr(), M, pl.S, ops._stream()))
+                                            pl.last_w2.data_ptr(), pl.last_b2, gp.data_ptr(), None if x is None else x.data_ptr(), wav.data_ptr(), M, pl.S,
+                                            ops._stream()))
             outs = [wav[int(offs[i]) * pl.hop : int(offs[i + 1]) * pl.hop] for i in range(len(lens))]
             if return_intermediates:
                 return outs, dict(z=z, taps=taps, skips=skips, seg=(seg_lo, seg_hi))

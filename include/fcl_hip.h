@@ -520,7 +520,8 @@ typedef struct {
     int32_t hop;               /* samples per frame: a multiple of 128 (a 128-sample tile lies inside one frame) */
 } fcl_pwg_layer_t;
 int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
-/* last_conv_layers: wav[m] = relu(relu(skips * scale) W1^T + b1) . w2 + b2.  yp: workspace planes [m, s_ch]; h: workspace fp32 [m, s_ch]. */
+/* last_conv_layers: wav[m] = relu(relu(skips * scale) W1^T + b1) . w2 + b2.  yp: workspace planes [m, s_ch]; h: workspace fp32 [m, s_ch]
+ * (both unused, may be NULL, for s_ch = 64: one launch that reads skips once). */
 int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const float* b1, const float* w2, float b2, uint16_t* yp, float* h, float* wav,
                      int64_t m, int s_ch, fcl_stream_t stream);
 
