@@ -41,3 +41,34 @@ def test_model_conf_manifest_and_checkpoint_formats(tmp_path):
     man.write_text(json.dumps({"utts": {"a": {"output": [{"tokenid": "3 4 5"}]}, "b": {"output": [{"tokenid": "7"}]}}}))
     utts = D.read_manifest(str(man))
     assert utts[0][0] == "a" and utts[0][1].tolist() == [3, 4, 5] and utts[1][1].tolist() == [7]
+
+
+def test_vocoder_driver_host_side(tmp_path):
+    """parallel-wavegan-decode replacement, host parts: batch packing, config.yml -> generator geometry, 16-bit PCM writer, checkpoint nesting."""
+    import wave
+
+    from fcl_taco2_amd import vocoder_decode as VD
+
+    assert VD.make_batches([5, 9, 1, 7, 3], 10) == [[1], [3], [0, 4, 2]]  # longest first, at most 10 frames per batch
+    assert VD.make_batches([50], 10) == [[0]] and VD.make_batches([], 10) == []
+    ck = tmp_path / "ck.pkl"
+    torch.save({"model": {"generator": {"first_conv.bias": torch.ones(3)}, "discriminator": {"x": torch.zeros(1)}}, "optimizer": {}}, ck)
+    sd = VD.load_checkpoint(str(ck))
+    assert list(sd["model"]) == ["generator"] and isinstance(sd["model"]["generator"]["first_conv.bias"], np.ndarray)
+    assert VD.generator_config(str(ck)) == ({}, 22050)  # no config.yml beside the checkpoint: the published v1 geometry
+    (tmp_path / "config.yml").write_text("sampling_rate: 16000\ngenerator_params:\n  layers: 4\n  stacks: 2\n  aux_channels: 20\n"
+                                         "  upsample_params:\n    upsample_scales: [2, 3]\n")
+    cfg, rate = VD.generator_config(str(ck))
+    assert cfg == dict(layers=4, stacks=2, aux_channels=20, upsample_scales=(2, 3)) and rate == 16000
+    (tmp_path / "bad.yml").write_text("generator_params:\n  use_causal_conv: true\n")
+    try:
+        VD.generator_config(str(ck), str(tmp_path / "bad.yml"))
+        assert False
+    except NotImplementedError:
+        pass
+    x = np.array([0.0, 0.5, -0.5, 1.0, -1.0, 2.0, -2.0, 1e-5], dtype=np.float32)
+    VD.write_wav(str(tmp_path / "a.wav"), x, 22050)
+    with wave.open(str(tmp_path / "a.wav")) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 22050, 8)
+        pcm = np.frombuffer(w.readframes(8), dtype="<i2")
+    assert pcm.tolist() == [0, 16384, -16384, 32767, -32767, 32767, -32768, 0]

@@ -136,6 +136,39 @@ def test_frame_rate_auxiliary_term_across_window_boundaries(voc, monkeypatch):
         assert max_abs(x.cpu(), y.cpu()) < 1e-3 * float(y.abs().max())
 
 
+def test_decode_driver_writes_the_generators_waveforms(voc, tmp_path):
+    """`python -m fcl_taco2_amd.vocoder_decode --checkpoint --feats-scp --outdir` (the reference's `parallel-wavegan-decode` call,
+    inference_student.sh:20-23): feats.scp in, <utt>_gen.wav out; the PCM equals the generator's output for the same batches and seeds."""
+    import wave
+
+    from fcl_taco2_amd import vocoder_decode as VD
+    from fcl_taco2_amd.kaldi_io import ArkScpWriter
+
+    rng = np.random.RandomState(6)
+    sd = weights(voc)
+    torch.save({"model": {"generator": {k: torch.from_numpy(v) for k, v in sd.items()}}}, tmp_path / "PWG.pkl")
+    feats = {"utt_%d" % i: rng.standard_normal((n, 80)).astype(np.float32) for i, n in enumerate([4, 9, 2, 6, 1])}
+    with ArkScpWriter(str(tmp_path / "feats")) as w:
+        for k, m in feats.items():
+            w[k] = m
+    samples, _ = VD.main(["--checkpoint", str(tmp_path / "PWG.pkl"), "--feats-scp", str(tmp_path / "feats.scp"), "--outdir", str(tmp_path / "wav"),
+                          "--batch-frames", "10", "--seed", "3", "--verbose", "0"])
+    assert samples == 22 * 256
+    gen = voc.ParallelWaveGANGenerator(voc.PWGPlan(sd, DEV))
+    items = sorted(feats.items())
+    peak = 0.0
+    for bi, idx in enumerate(VD.make_batches([m.shape[0] for _, m in items], 10)):
+        want = gen.synthesize([items[i][1] for i in idx], seed=3 + bi)
+        for i, y in zip(idx, want):
+            with wave.open(str(tmp_path / "wav" / (items[i][0] + "_gen.wav"))) as f:
+                assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (1, 2, 22050, items[i][1].shape[0] * 256)
+                pcm = np.frombuffer(f.readframes(f.getnframes()), dtype="<i2").astype(np.float64)
+            ref = np.clip(np.rint(y.cpu().numpy().astype(np.float64) * 32767.0), -32768, 32767)
+            assert np.array_equal(pcm, ref)
+            peak = max(peak, float(np.abs(ref).max()))
+    assert peak > 0
+
+
 def test_device_noise_is_standard_normal(voc):
     from fcl_taco2_amd import _lib, ops
 
