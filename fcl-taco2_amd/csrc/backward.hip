@@ -12,6 +12,7 @@
 // Exact fp32 everywhere (gradients are accumulated over up to 25 k rows; the split-bf16 trick is not used here).
 #include <algorithm>
 #include "fcl_common.h"
+#include "lstm_epilogue.h"
 
 namespace fcl {
 
@@ -223,7 +224,7 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, const uint8_t* __res
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = x[i];
         if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (act == FCL_ACT_TANH) v = tanhf(v);
+        else if (act == FCL_ACT_TANH) v = tanh_f(v);
         if (keep) v = keep[i] ? v * scale : 0.f;
         if (y) y[i] = v;
         if (yp) store_p32(yp, cols >> 5, (int)(i / cols), (int)(i % cols), v);
@@ -421,7 +422,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const floa
         }
         const float* gr = gates + (size_t)m * 4 * U;
         const float ig = gr[u], fg = gr[U + u], gg = gr[2 * U + u], og = gr[3 * U + u];
-        const float tc = tanhf(c_new[idx]);
+        const float tc = tanh_f(c_new[idx]);
         const float dc_new = dc_new_z + dh_new * og * (1.0f - tc * tc);
         float* dg = dgates + (size_t)m * 4 * U;
         const float d0 = dc_new * gg * ig * (1.0f - ig), d1 = dc_new * c_old[idx] * fg * (1.0f - fg);
@@ -505,7 +506,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __re
         const int c = (int)(i % C);
         float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
         if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (act == FCL_ACT_TANH) v = tanhf(v);
+        else if (act == FCL_ACT_TANH) v = tanh_f(v);
         y_act[i] = v;
         const float vd = keep ? (keep[i] ? v * scale : 0.f) : v;
         if (y_drop) y_drop[i] = vd;

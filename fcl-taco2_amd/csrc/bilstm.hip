@@ -109,7 +109,7 @@ __global__ __launch_bounds__(4 * H) void bilstm_bptt_persistent_kernel(BilstmBwd
             const float* g = a.gates[dir] + cell * (4 * H);
             const float ig = g[j], fg = g[H + j], gg = g[2 * H + j], og = g[3 * H + j];
             const float dho = dh + a.d_out[((size_t)b * T + t) * a.ld + dir * H + j];
-            const float tc = tanhf(a.c_new[dir][cell * H + j]);
+            const float tc = tanh_f(a.c_new[dir][cell * H + j]);
             const float dcn = dc + dho * og * (1.0f - tc * tc);
             const float d0 = dcn * gg * ig * (1.0f - ig), d1 = dcn * a.c_old[dir][cell * H + j] * fg * (1.0f - fg);
             const float d2 = dcn * ig * (1.0f - gg * gg), d3 = dho * tc * og * (1.0f - og);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512) void bilstm_bptt_group_kernel(BilstmBwd a, con
             const float* g = a.gates[dir] + cell * (4 * H);
             const float ig = g[u], fg = g[H + u], gg = g[2 * H + u], og = g[3 * H + u];
             const float dho = dh + a.d_out[((size_t)b * T + t) * a.ld + dir * H + u];
-            const float tc = tanhf(a.c_new[dir][cell * H + u]);
+            const float tc = tanh_f(a.c_new[dir][cell * H + u]);
             const float dcn = dc + dho * og * (1.0f - tc * tc);
             const float d0 = dcn * gg * ig * (1.0f - ig), d1 = dcn * a.c_old[dir][cell * H + u] * fg * (1.0f - fg);
             const float d2 = dcn * ig * (1.0f - gg * gg), d3 = dho * tc * og * (1.0f - og);

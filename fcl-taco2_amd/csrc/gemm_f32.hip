@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
             if (a.rank1_a) v += a.rank1_a[(size_t)m * a.rank1_lda] * r1w;
             if (a.C0) v += a.C0[(size_t)m * a.ldc0 + n];
             if (a.act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (a.act == FCL_ACT_TANH) v = tanhf(v);
+            else if (a.act == FCL_ACT_TANH) v = tanh_f(v);
             if (a.drop_mode == 1) {
                 v = a.keep[(size_t)m * a.ldkeep + n] ? v * a.keep_scale : 0.f;
             } else if (a.drop_mode == 2) {
