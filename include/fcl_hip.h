@@ -517,7 +517,8 @@ typedef struct {
     const uint16_t* pt_a;      /* planes of (W_aux c_in^T) [2r, frames]: line q of a row = frames [32q, 32q + 32) */
     const uint16_t* pt_b;      /* the same shifted by 16 frames: line q = frames [32q - 16, 32q + 16), zero where there is no frame */
     int32_t ld_pt;             /* lines per row of pt_a / pt_b (>= (frames + 16 + 31) / 32) */
-    int32_t hop;               /* samples per frame: a multiple of 128 (a 128-sample tile lies inside one frame) */
+    int32_t hop;               /* samples per frame: a multiple of 128 (a 128-sample tile lies inside one frame); with kp, seg_lo / seg_hi may change
+                                * only at multiples of hop (utterances are whole frames): the kernel reads one pair of bounds per tile */
 } fcl_pwg_layer_t;
 int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
 /* last_conv_layers: wav[m] = relu(relu(skips * scale) W1^T + b1) . w2 + b2.  yp: workspace planes [m, s_ch]; h: workspace fp32 [m, s_ch]
