@@ -1008,10 +1008,11 @@ __global__ __launch_bounds__(64 * (8 + LW)) void pwg_layer_pkernel(const PwgFuse
         // scalar cache (lgkmcnt -- the vector-memory counter orders these loads with the LDS-DMA stream, and per-row bounds requested after the last
         // chunk held the loaders, and with them the epilogue's first barrier, for an HBM round trip: 3.2 -> 1.8 us for the gate phase)
         int blo = 0, bhi = 0;
+        typedef const int __attribute__((address_space(4))) cint_k;  // constant address space: uniform loads become s_load, waits are the compiler's
         auto fetch_bounds = [&](int m0) {
             if (AUXF) {
-                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(blo) : "s"(a.seg_lo + m0));
-                asm volatile("s_load_dword %0, %1, 0x0" : "=s"(bhi) : "s"(a.seg_hi + m0));
+                blo = *reinterpret_cast<cint_k*>(reinterpret_cast<uintptr_t>(a.seg_lo + m0));
+                bhi = *reinterpret_cast<cint_k*>(reinterpret_cast<uintptr_t>(a.seg_hi + m0));
             }
         };
         auto setup_term = [&](int ti) {
@@ -1030,7 +1031,6 @@ __global__ __launch_bounds__(64 * (8 + LW)) void pwg_layer_pkernel(const PwgFuse
             rem = (T.K + 31) >> 5;
         };
         auto begin_tile = [&](int m0) {
-            if (AUXF) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(blo), "+s"(bhi));
 #pragma unroll
             for (int j = 0; j < G::GA; ++j) {
                 const int m = m0 + (j * G::NL + lw) * 8 + (lane >> 3);
