@@ -102,4 +102,20 @@ def test_round2_entry_points_validate_arguments_without_a_gpu(lib):
     assert lib.fcl_pwg_layer_fwd(C.byref(a), None) == -1
     assert lib.fcl_pwg_noise(None, 16, 1, None) == -1
     assert lib.fcl_pwg_first_conv(1, 1, 1, None, 128, 16, 48, 0, None) == -1 and b"multiple of 32" in lib.fcl_last_error()
+    # the frame-rate form of the auxiliary term: coefficient lines need both buffers; the block needs the one-launch form, both window alignments
+    # and a hop that keeps a 128-sample tile inside one frame
+    assert lib.fcl_pwg_aux_coeff(None, 256, 256, 1, 128, None) == -1
+    assert lib.fcl_pwg_aux_coeff(16, 512, 256, 1, 128, None) == -1  # more samples than frames * hop
+    a = _lib.PwgLayer()
+    a.m, a.r, a.aux, a.ksize, a.dilation = 256, 64, 80, 3, 1
+    for f in ("seg_lo", "seg_hi", "xp", "w_conv_p", "b_conv", "w_os_p", "b_os", "skips", "kp", "pt_a", "pt_b"):
+        setattr(a, f, 128)
+    a.x, a.ld_pt, a.hop = 128, 1, 256
+    assert lib.fcl_pwg_layer_fwd(C.byref(a), None) == -1 and b"one-launch form" in lib.fcl_last_error()  # xp_out missing
+    a.xp_out, a.hop = 256, 192
+    assert lib.fcl_pwg_layer_fwd(C.byref(a), None) == -1 and b"multiple of 128" in lib.fcl_last_error()
+    a.hop, a.kp = 256, 130
+    assert lib.fcl_pwg_layer_fwd(C.byref(a), None) == -3 and b"128-byte aligned" in lib.fcl_last_error()
+    a.kp, a.ld_pt, a.m = 128, 1, 256 * 40
+    assert lib.fcl_pwg_layer_fwd(C.byref(a), None) == -2 and b"ld_pt" in lib.fcl_last_error()  # 40 frames + 16 > 32 columns
     assert lib.fcl_debug_ptr() is None
