@@ -129,6 +129,7 @@ class ParallelWaveGANGenerator(object):
         key = tuple(lens)
         hit = self._maps_cache.get(key)
         if hit is not None:
+            torch.cuda.current_stream(self.plan.device).wait_event(hit["ready"])  # built on another stream, possibly: order this one behind it
             return hit
         pl, dev = self.plan, self.plan.device
         ctx = pl.cfg["aux_context_window"]
@@ -149,7 +150,8 @@ class ParallelWaveGANGenerator(object):
         reps = torch.from_numpy(lens_np * pl.hop).to(dev)
         m["seg_lo"] = torch.repeat_interleave(s_off[:-1], reps).to(torch.int32)  # sample range of each row's utterance (integers only)
         m["seg_hi"] = torch.repeat_interleave(s_off[1:], reps).to(torch.int32)
-        torch.cuda.current_stream(dev).synchronize()  # the cached maps may be used from other streams later: finish building them first (once per shape)
+        m["ready"] = torch.cuda.Event()  # the cached maps may be used from other streams later: those wait for this event (no host synchronisation:
+        m["ready"].record(torch.cuda.current_stream(dev))  # a driver that sees a new batch shape every call keeps its batches pipelined)
         if len(self._maps_cache) >= 4:
             self._maps_cache.clear()
         self._maps_cache[key] = m
