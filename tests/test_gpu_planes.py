@@ -124,7 +124,8 @@ def test_conv1d_on_planes_vs_the_fp32_operand_kernel(ops, cin, cout, ksz):
     assert np.max(np.abs(val - y.cpu().numpy())) < 2.0 ** -15 * max(1.0, float(y.abs().max()))
 
 
-@pytest.mark.parametrize("m,u,k0,k1", [(2501, 256, 256, 256), (1100, 256, 256, 256), (300, 1024, 256, 1024), (70, 32, 32, 64)])
+@pytest.mark.parametrize("m,u,k0,k1", [(2501, 256, 256, 256), (1100, 256, 256, 256), (300, 1024, 256, 1024), (70, 32, 32, 64),
+                                       (2501, 1024, 256, 1024), (1190, 1024, 256, 1024)])  # T-size steps: more tiles than CUs
 def test_lstm_step_on_planes_vs_the_fp32_operand_kernels(ops, m, u, k0, k1):
     """Same step through the big-tile fp32-operand kernel (planes off for this call: no plane pointers) and through the LDS-DMA kernel:
     h, c and the h planes agree; decoder layer-0 form (hoisted G + position term) and layer-1 form (bias)."""
