@@ -366,6 +366,31 @@ def test_c2_full_size_properties(ops):
         assert max_abs(mels[i].cpu(), ref) < 1e-3
 
 
+def test_synthesis_edge_shapes_vs_oracle(ops):
+    """Ragged extremes of the batched path against the oracle, utterance by utterance: a one-phoneme utterance of one frame, a phoneme far beyond
+    the training cap of 50 frames (predicted durations are uncapped at inference, decoder_sa_kd.py:752-753), 1 and 130 phonemes in one batch."""
+    from fcl_taco2_amd import engine
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    plan = _plan(hp)
+    sd = torch_state_dict(hp)
+    rng = np.random.RandomState(9)
+    ids = lambda n: rng.randint(1, hp.idim, size=n).astype(np.int64)
+    cases = [
+        ([ids(1)], [np.array([1])]),
+        ([ids(3)], [np.array([2, 170, 1])]),
+        ([ids(130), ids(1), ids(17)], [rng.randint(1, 9, size=130), np.array([64]), rng.randint(1, 30, size=17)]),
+    ]
+    for xs, ds in cases:
+        ds = [np.asarray(d, dtype=np.int64) for d in ds]
+        mels = engine.synthesize(plan, xs, ds)
+        assert [m.shape[0] for m in mels] == [int(d.sum()) for d in ds]
+        for x, d, m in zip(xs, ds, mels):
+            with torch.no_grad():
+                ref = O.inference(sd, hp, torch.from_numpy(x), dur=torch.from_numpy(d))["after"]
+            assert max_abs(m.cpu(), ref) < 1e-3
+
+
 def test_graph_replay_equals_eager(ops):
     """hipGraph capture of a whole pass (engine.GraphRunner) reproduces the eager result bit for bit
     (dropout off => deterministic), replay after replay, and on two streams at once."""
