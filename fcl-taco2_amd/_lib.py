@@ -76,6 +76,9 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
+ABI_VERSION = 200  # FCL_ABI_VERSION of include/fcl_hip.h
+
+
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
     _fields_ = [("m", C.c_int64), ("r", C.c_int32), ("aux", C.c_int32), ("ksize", C.c_int32), ("dilation", C.c_int32), ("first_layer", C.c_int32)] + [
         (n, _P) for n in ("seg_lo", "seg_hi", "x", "xp", "cp", "w_conv_p", "b_conv", "w_aux_p", "w_os_p", "b_os", "skips", "z", "gp", "o", "xp_out",
@@ -186,6 +189,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    if lib.fcl_version() != ABI_VERSION:  # a stale in-tree build: the struct layouts mirrored here would not match
+        raise FclError("fcl-taco2_amd: %s has ABI revision %d, this package mirrors %d — rebuild it (`make -C fcl-taco2_amd/csrc`)"
+                       % (LIB_PATH, lib.fcl_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -123,7 +123,7 @@ using namespace fcl;
 extern "C" {
 
 const char* fcl_last_error(void) { return g_err; }
-int fcl_version(void) { return 100; }
+int fcl_version(void) { return FCL_ABI_VERSION; }
 
 int fcl_set_gemm_mode(int mode) {
     FCL_REQUIRE(mode == FCL_GEMM_F32 || mode == FCL_GEMM_BF16, FCL_ERR_INVALID, "set_gemm_mode: unknown mode %d", mode);

@@ -45,6 +45,9 @@ enum { FCL_STATUS_GROUP_TIMEOUT = 1 /* a cooperating-workgroup BiLSTM kernel gav
 enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 
 const char* fcl_last_error(void);
+/* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
+ * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
+#define FCL_ABI_VERSION 200
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);

@@ -43,7 +43,10 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.fcl_version() >= 100
+    from fcl_taco2_amd import _lib as L
+
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fcl_hip.h")).read()
+    assert "#define FCL_ABI_VERSION %d" % L.ABI_VERSION in header and lib.fcl_version() == L.ABI_VERSION
     rc = lib.fcl_linear_fwd(None, 4, None, 4, None, None, 4, 1, 4, 4, 0, None)
     assert rc == -1 and b"null" in lib.fcl_last_error()
     rc = lib.fcl_conv1d_fwd(1, 1, None, 1, 1, None, 2, 4, 4, 4, 4, 0, None)  # even kernel size
