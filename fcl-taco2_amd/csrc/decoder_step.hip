@@ -894,6 +894,10 @@ static bool wres_applicable(const LstmStepArgs& a) {
     // co-residency that several passes in flight rely on (bench default), so it is opt-in: FCL_LSTM_WRES=1
     static const int on = tunable("LSTM_WRES", 0);
     if (!on || a.nterms != 2) return false;
+    // the kernel reads the fp32 operands: a step whose producers wrote planes only (big decoder steps on the pre-split path set A = the buffer
+    // but never fill it; round-2 ADVICE) is not its to take
+    for (int i = 0; i < 2; ++i)
+        if (!a.term[i].A || !a.term[i].W || a.term[i].Ap) return false;
     const int k0 = a.term[0].K, k1 = a.term[1].K;
     return k0 + k1 == WRES_KT && (k0 % (WRES_KT / 4)) == 0 && a.U % 16 == 0 && a.U <= 1024;
 }

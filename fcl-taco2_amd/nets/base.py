@@ -334,6 +334,11 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
     def _forward_train(self, batch, teacher_knowledge, masks=None):
         eng = self.train_engine()
         self._plan = None  # weights are about to move
+        # on this path the optimizer is the CALLER's (torch.optim.*.step(), p.data.copy_(), ...): writes through the re-pointed parameter views do
+        # not bump the flat buffer's version counter, so the engine's stamp cannot see them -- every cached operand form of the parameters (packed
+        # conv taps, transposes, LSTM column blocks, P32 planes) is rebuilt per forward here (round-2 ADVICE; the native TrainEngine.train_step path
+        # knows its own updates and keeps the once-per-update cache)
+        eng.invalidate_planes()
         if self.role == "kd_teacher":
             with torch.no_grad():
                 return eng.knowledge(batch, mode="train", masks=masks)

@@ -355,8 +355,10 @@ class TrainEngine(object):
         rec = self._recipe_of(w) if cache else None
         if rec is not None:  # a parameter or a form derived from one: its planes come from the source in the batched per-update launch
             return self._forms.get(self._stamp(), ("p",) + rec[0], rec[1], rec[2], rec[3], rec[4], f32=False, planes=True)[1]
-        # validity stamp: optimizer steps (raw-pointer kernels) + torch's version counter of the flat buffer, which every in-place write through
-        # any parameter view bumps (load_state_dict, p.data.copy_(), torch optimizers on the autograd path)
+        # validity stamp: the engine's own optimizer steps (raw-pointer kernels) + torch's version counter of the flat buffer (in-place writes to
+        # pflat / the P[...] views: finite-difference tests, checkpoint loads through the engine).  Writes through the MODULE's parameters
+        # (p.data = view: torch optimizers, p.data.copy_()) do NOT bump that counter -- Tacotron2Base._forward_train and load_state_dict call
+        # invalidate_planes() instead
         stamp = (self.update_calls, self.pflat._version, tuple(w.shape))
         hit = self._plane_cache.get(key) if cache else None
         if hit is not None and hit[0] == stamp:

@@ -129,7 +129,13 @@ class ParallelWaveGANGenerator(object):
         key = tuple(lens)
         hit = self._maps_cache.get(key)
         if hit is not None:
-            torch.cuda.current_stream(self.plan.device).wait_event(hit["ready"])  # built on another stream, possibly: order this one behind it
+            cur = torch.cuda.current_stream(self.plan.device)
+            cur.wait_event(hit["ready"])  # built on another stream, possibly: order this one behind it
+            if cur.cuda_stream not in hit["streams"]:  # ... and tell the caching allocator that this stream reads the maps too: an eviction while
+                hit["streams"].add(cur.cuda_stream)    # its kernels are in flight must not hand the blocks back to the building stream
+                for v in hit.values():
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
             return hit
         pl, dev = self.plan, self.plan.device
         ctx = pl.cfg["aux_context_window"]
@@ -152,6 +158,7 @@ class ParallelWaveGANGenerator(object):
         m["seg_hi"] = torch.repeat_interleave(s_off[1:], reps).to(torch.int32)
         m["ready"] = torch.cuda.Event()  # the cached maps may be used from other streams later: those wait for this event (no host synchronisation:
         m["ready"].record(torch.cuda.current_stream(dev))  # a driver that sees a new batch shape every call keeps its batches pipelined)
+        m["streams"] = {torch.cuda.current_stream(dev).cuda_stream}
         if len(self._maps_cache) >= 4:
             self._maps_cache.clear()
         self._maps_cache[key] = m
@@ -230,6 +237,8 @@ class ParallelWaveGANGenerator(object):
                 raise _lib.FclError("fcl-taco2_amd: empty mel")
             if mel_rows.dim() != 2 or mel_rows.shape[1] != pl.A or mel_rows.shape[0] != sum(lens):
                 raise _lib.FclError("fcl-taco2_amd: expected [%d, %d] mel rows, got %r" % (sum(lens), pl.A, tuple(mel_rows.shape)))
+            if sum(lens) * pl.hop >= 2 ** 31:  # before any int32 index map is built or any kernel launched with the overflowing sizes
+                raise _lib.FclError("fcl-taco2_amd: more than 2^31 samples in one vocoder batch")
             mp = self._maps(lens)
             offs = mp["offs"]
             M, R = int(offs[-1]) * pl.hop, pl.R
@@ -240,8 +249,6 @@ class ParallelWaveGANGenerator(object):
                 kp, pt_a, pt_b, ld_pt = self._aux_frame_rate(mel_rows, mp)
             else:
                 cp = self._upsample(mel_rows, mp, fused)  # the one-launch block reads chunk-major planes (contiguous rows per 32-column chunk)
-            if M >= 2 ** 31:
-                raise _lib.FclError("fcl-taco2_amd: more than 2^31 samples in one vocoder batch")
             if noise is None:
                 z = torch.empty(M, device=dev)
                 _lib.check(lib.fcl_pwg_noise(z.data_ptr(), M, seed & 0xFFFFFFFF, ops._stream()))

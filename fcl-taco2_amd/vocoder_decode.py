@@ -45,13 +45,19 @@ def generator_config(checkpoint, config=None):
     cfg = {k: gp[k] for k in ("layers", "stacks", "residual_channels", "gate_channels", "skip_channels", "aux_channels", "aux_context_window", "kernel_size")
            if k in gp}
     up = gp.get("upsample_params", {})
+    bad_up = {k: up[k] for k, dflt in (("nonlinear_activation", None), ("interpolate_mode", "nearest"), ("use_causal_conv", False),
+                                       ("freq_axis_kernel_size", 1)) if up.get(k, dflt) != dflt}
+    if bad_up:  # they change the upsampling network's arithmetic; silently ignoring them would produce wrong audio
+        raise NotImplementedError("fcl-taco2_amd: upsample_params %r are not supported on the HIP path" % bad_up)
     if "upsample_scales" in up:
         cfg["upsample_scales"] = tuple(int(s) for s in up["upsample_scales"])
     return cfg, int(y.get("sampling_rate", 22050))
 
 
-def load_checkpoint(path):
-    """torch.load of a parallel_wavegan checkpoint ({"model": {"generator": sd}}, or a bare state dict) -> the same nesting with numpy arrays."""
+def load_checkpoint(path, allow_pickle=False):
+    """torch.load of a parallel_wavegan checkpoint ({"model": {"generator": sd}}, or a bare state dict) -> the same nesting with numpy arrays.
+    Loaded with weights_only=True (tensors and plain containers only); a checkpoint that needs the full unpickler — which executes whatever code
+    the file carries — is read only with allow_pickle=True (`--unsafe-pickle`), i.e. when the caller vouches for the file."""
     def conv(o):
         if torch.is_tensor(o):
             return o.detach().cpu().float().numpy()
@@ -59,7 +65,13 @@ def load_checkpoint(path):
             return {k: conv(v) for k, v in o.items()}
         return o
 
-    obj = torch.load(path, map_location="cpu", weights_only=False)
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        if not allow_pickle:
+            raise RuntimeError("fcl-taco2_amd: %s does not load with weights_only=True (%s); pass --unsafe-pickle / allow_pickle=True only for a "
+                               "checkpoint you trust" % (path, str(e).splitlines()[0] if str(e) else type(e).__name__))
+        obj = torch.load(path, map_location="cpu", weights_only=False)
     if isinstance(obj, dict) and "model" in obj and isinstance(obj["model"], dict) and "generator" in obj["model"]:
         return {"model": {"generator": conv(obj["model"]["generator"])}}  # (the discriminator / optimizer states are not needed)
     return conv(obj)
@@ -173,12 +185,14 @@ def main(argv=None):
     ap.add_argument("--job", type=int, default=0, help="this process's shard (0-based)")
     ap.add_argument("--seed", type=int, default=0, help="seed of the device noise")
     ap.add_argument("--verbose", type=int, default=1)
+    ap.add_argument("--unsafe-pickle", action="store_true", help="allow the full unpickler for checkpoints that weights_only=True rejects (runs code "
+                    "embedded in the file: trusted checkpoints only)")
     args = ap.parse_args(argv)
     torch.set_num_threads(4)
     logging.basicConfig(level=logging.INFO if args.verbose else logging.WARN, format="%(asctime)s %(levelname)s: %(message)s")
     dev = "cuda:%d" % (args.job % max(torch.cuda.device_count(), 1))
     cfg, rate = generator_config(args.checkpoint, args.config)
-    gen = ParallelWaveGANGenerator(PWGPlan(load_checkpoint(args.checkpoint), dev, cfg))
+    gen = ParallelWaveGANGenerator(PWGPlan(load_checkpoint(args.checkpoint, args.unsafe_pickle), dev, cfg))
     feats = sorted(kaldi_io.read_scp(args.feats_scp).items())
     aux = dict(CONFIG, **cfg)["aux_channels"]
     for uid, m in feats:

@@ -256,6 +256,42 @@ def test_teacher_train_steps_track_torch_adam():
     assert max_abs(model.state_dict()["dec.feat_out.weight"].cpu(), sd["dec.feat_out.weight"].detach()) < 6e-3
 
 
+def test_autograd_path_with_an_external_optimizer_sees_every_update():
+    """Round-2 ADVICE (high): on the documented path `loss = model(**batch); loss.backward(); optimizer.step()` the optimizer writes through the
+    module's parameter views, which the engine's cache stamp cannot see; the cached operand forms of the weights (packed conv taps, transposes,
+    LSTM column blocks, P32 planes) must not survive such a step.  Two autograd-path steps with torch's SGD (a large step, so stale forms would show
+    at O(1)) against two native forward_backward passes of a second engine with the same seed and the same updates applied to its flat buffer."""
+    from fcl_taco2_amd.training import TrainEngine
+
+    batch = _batch()
+    kw = {k: v for k, v in batch.items() if not k.startswith("_")}
+    lr = 0.05
+    ma = _model("teacher", TINY_T7).train()
+    ea = ma.train_engine(seed=3)
+    opt = torch.optim.SGD(ma.parameters(), lr=lr)
+    la, ga = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = ma(**kw)
+        loss.backward()
+        ga.append(torch.cat([p.grad.reshape(-1) for _, p in sorted(ma.named_parameters())]).clone())
+        opt.step()
+        la.append(float(loss))
+    eb = TrainEngine(_model("teacher", TINY_T7), seed=3)
+    lb, gb = [], []
+    for _ in range(3):
+        eb.zero_grad()
+        lb.append(eb.forward_backward(batch, mode="train", reduce=False)["loss"])
+        gb.append(torch.cat([eb.G[k].reshape(-1) for k in sorted(eb.G)]).clone())
+        eb.pflat.add_(eb.gflat, alpha=-lr)  # bumps pflat's version counter: the native engine's stamp sees it
+    assert la[0] == pytest.approx(lb[0], rel=1e-6)
+    assert abs(la[1] - la[0]) > 1e-3 * abs(la[0])  # the step really moved the loss, so a stale cache could not hide
+    for i in (1, 2):
+        assert la[i] == pytest.approx(lb[i], rel=2e-4), (i, la, lb)
+        assert max_abs(ga[i].cpu(), gb[i].cpu()) < 1e-3 * max(1.0, float(gb[i].abs().max())), i
+    assert ea is ma.train_engine()
+
+
 def test_accum_grad_two_micro_batches_equal_one_scaled_sum():
     """loss / accum_grad per micro-batch, gradients accumulate until the optimizer step (tts.py:160-171)."""
     from fcl_taco2_amd.training import TrainEngine
