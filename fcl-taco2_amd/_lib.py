@@ -202,8 +202,8 @@ def prof_enable(on):
 
 def prof_collect():
     """{kernel name: dict(launches, ms, flops, rows)} for the launches since prof_enable(True)."""
-    buf = (ProfEntry * 32)()
-    n = load().fcl_prof_collect(buf, 32)
+    buf = (ProfEntry * 256)()
+    n = load().fcl_prof_collect(buf, 256)
     if n < 0:
         check(n)
     return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops, rows=buf[i].rows) for i in range(n)}

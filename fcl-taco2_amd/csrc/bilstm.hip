@@ -334,6 +334,7 @@ bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_
     GroupSync gs{flags + 256, status};
     float* hbuf = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
     dim3 grid(2 * B * 4);
+    ProfScope ps(sv ? "bilstm_group_kernel<256>/train" : "bilstm_group_kernel<256>", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
     if (sv) hipLaunchKernelGGL((bilstm_group_kernel<256, true>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, hbuf, gs, *sv);
     else hipLaunchKernelGGL((bilstm_group_kernel<256, false>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, hbuf, gs, BilstmSave());
     return true;
@@ -345,6 +346,7 @@ bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T,
     if (hipMemsetAsync(flags, 0, 1024 + sizeof(unsigned int) * 2 * (size_t)B, s) != hipSuccess) return false;
     GroupSync gs{flags + 256, status};
     float* part = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
+    ProfScope ps("bilstm_bptt_group_kernel<256>", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
     hipLaunchKernelGGL((bilstm_bptt_group_kernel<256>), dim3(2 * B * 4), dim3(512), 0, s, a, lens, T, part, gs);
     return true;
 }
@@ -352,6 +354,8 @@ bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T,
 bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T,
                                     int H, const BilstmSave& sv, hipStream_t s) {
     dim3 grid(B, 2);
+    if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return false;
+    ProfScope ps("bilstm_persistent_kernel/train", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
 #define FCL_BILSTM_CASE(HH) \
     case HH: hipLaunchKernelGGL((bilstm_persistent_kernel<HH, true>), grid, dim3(4 * HH), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, sv); return true;
     switch (H) {
@@ -367,6 +371,8 @@ bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const 
 
 bool launch_bilstm_bptt_persistent(const BilstmBwd& a, const int* lens, int B, int T, int H, hipStream_t s) {
     dim3 grid(B, 2);
+    if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return false;
+    ProfScope ps("bilstm_bptt_persistent_kernel", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
 #define FCL_BILSTM_CASE(HH) \
     case HH: hipLaunchKernelGGL((bilstm_bptt_persistent_kernel<HH>), grid, dim3(4 * HH), 0, s, a, lens, T); return true;
     switch (H) {
@@ -433,7 +439,6 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     if (h == 256 && status && (algo == 3 || (algo == 0 && group_infer))) {
         void* gws = hbuf;  // the Gx buffers are final, so the tail of the workspace (per-step state of algo 1) is free for the flags and the exchange buffer
         const size_t gbytes = workspace_bytes - sizeof(float) * ((size_t)2 * b * t * 4 * h);
-        ProfScope ps("bilstm_group_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
         if (launch_bilstm_group(gx_f, gx_r, w_hh_f, w_hh_r, lens, out, b, t, h, nullptr, gws, gbytes, status, s)) {
             FCL_HIP(hipGetLastError());
             return out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0;
