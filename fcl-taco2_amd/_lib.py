@@ -28,7 +28,14 @@ class DecoderWeights(C.Structure):
 class DecoderIO(C.Structure):
     _fields_ = [("n", _I), ("lmax", _I), ("att_c", _P), ("dur", _P), ("live_rows_host", _P), ("frame_off", _P),
                 ("teacher_ys", _P), ("dropout_mode", _I), ("prenet_keep", _P), ("seed", C.c_uint32), ("seed_dev", _P), ("before", _P),
-                ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z), ("att_c_p", _P), ("before_p", _P)]
+                ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z), ("att_c_p", _P), ("before_p", _P),
+                ("live_rows", _P), ("status", _P)]
+
+
+class RowMaps(C.Structure):  # fcl_row_maps_t
+    _fields_ = [("b", _I), ("n", _I), ("lmax_cap", _I), ("frames_cap", _I), ("t_max", _I)] + [
+        (n, _P) for n in ("row_src", "utt_row0", "pad", "dur_i64", "dur_i32", "src_rows", "dur_sorted", "frame_off", "order", "live_rows", "utt_frame0",
+                          "frame_lo", "frame_hi", "totals", "status")]
 
 
 class GemmTerm(C.Structure):
@@ -41,7 +48,7 @@ class LstmStep(C.Structure):
                 ("bias", _P), ("rank1_w", _P), ("dur", _P), ("step", _I), ("h_in", _P), ("h_out", _P), ("c", _P), ("zoneout", _F),
                 ("zone_keep_h", _P), ("zone_keep_c", _P), ("row_len", _P), ("out2", _P), ("out2_row_base", _P), ("out2_row_mul", C.c_longlong),
                 ("out2_row_add", C.c_longlong), ("ld2", _I), ("out2_col_off", _I), ("h_out_p", _P), ("ld_hp", _I), ("save_gates", _P), ("save_c_new", _P), ("save_c_old", _P),
-                ("save_h_old", _P)]
+                ("save_h_old", _P), ("m_dev", _P)]
 
 
 class DecoderTrain(C.Structure):  # fcl_decoder_train_t
@@ -76,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 200  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 300  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -114,6 +121,7 @@ SIGNATURES = {
     "fcl_duration_round_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P]),
     "fcl_variance_embed_add_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "fcl_position_table_fwd": (_I, [_P, _P, _I, _I, _P]),
+    "fcl_row_maps_build": (_I, [C.POINTER(RowMaps), _P]),
     "fcl_gather_rows_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "fcl_bilstm_workspace_bytes": (_Z, [_I, _I, _I]),
     "fcl_bilstm_fwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _Z, _P, _P]),
@@ -162,7 +170,7 @@ SIGNATURES = {
 
 ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
 DROP_NONE, DROP_MASK, DROP_RNG = 0, 1, 2
-STATUS_GROUP_TIMEOUT = 1  # FCL_STATUS_* bits of a device status word
+STATUS_GROUP_TIMEOUT, STATUS_ZERO_DURATION, STATUS_LMAX_CAP, STATUS_FRAMES_CAP, STATUS_ROWS_CAP = 1, 2, 4, 8, 16  # FCL_STATUS_* bits of a device status word
 
 _lib = None
 

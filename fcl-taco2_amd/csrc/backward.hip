@@ -185,23 +185,25 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 // ---- bias / BatchNorm-affine gradients: column sums over rows --------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
                                                      const float* __restrict__ b, float* __restrict__ out, int M, int C, int mode, int rows_per_block) {
-    __shared__ float part[4][64];
+    // fp64 accumulation (the kernel is HBM-bound either way): these sums are the dbeta / dgamma that train-mode BatchNorm's backward SUBTRACTS from
+    // dy, i.e. operands of a cancellation; 7e-8 instead of 3e-7 relative at 1 600 rows
+    __shared__ double part[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // a wave reads 64 consecutive columns of one row: 256-byte coalesced
     const int c = blockIdx.x * 64 + tx;
     const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
-    float s = 0.f;
+    double s = 0.0;
     if (c < C) {
         const float bc = mode >= 2 ? b[c] : 0.f, gc = mode == 2 ? 1.0f / g[c] : (mode == 3 ? g[c] : 1.f);
         for (int m = m_lo + ty; m < m_hi; m += 4) {
             float v = x[(size_t)m * C + c];
             if (mode == 1) v *= y[(size_t)m * C + c];
             else if (mode >= 2) v *= (y[(size_t)m * C + c] - bc) * gc;
-            s += v;
+            s += (double)v;
         }
     }
     part[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && c < C) atomicAdd(out + c, (part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx]));
+    if (ty == 0 && c < C) atomicAdd(out + c, (float)((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
 }
 
 // dz = dy * act'(y) * (keep ? keep*scale : 1)

@@ -272,9 +272,11 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
     FCL_REQUIRE(w->prenet_dropout >= 0.f && w->prenet_dropout < 1.f, FCL_ERR_INVALID, "decoder_loop_fwd: bad prenet_dropout");
     FCL_REQUIRE(io->workspace && aligned16(io->workspace) && io->workspace_bytes >= fcl_decoder_loop_workspace_bytes(w, io->n), FCL_ERR_WORKSPACE,
                 "decoder_loop_fwd: workspace missing, misaligned or smaller than fcl_decoder_loop_workspace_bytes()");
+    FCL_REQUIRE(!io->live_rows || io->status, FCL_ERR_INVALID, "decoder_loop_fwd: device live_rows need a device status word");
     {
         int prev = io->n;
-        FCL_REQUIRE(io->live_rows_host[0] == io->n, FCL_ERR_INVALID, "decoder_loop_fwd: live_rows_host[0] must equal N (all durations > 0)");
+        // host counts are exact (every row is live at step 0: durations > 0) unless the device counts drive the loop: then they are upper bounds
+        FCL_REQUIRE(io->live_rows || io->live_rows_host[0] == io->n, FCL_ERR_INVALID, "decoder_loop_fwd: live_rows_host[0] must equal N (all durations > 0)");
         for (int t = 0; t < io->lmax; ++t) {
             FCL_REQUIRE(io->live_rows_host[t] > 0 && io->live_rows_host[t] <= prev, FCL_ERR_INVALID,
                         "decoder_loop_fwd: live_rows_host must be positive and non-increasing (rows sorted by duration descending)");
@@ -315,6 +317,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
     const float keep_scale = 1.0f / (1.0f - w->prenet_dropout);
     const int drop_mode = (w->prenet_dropout > 0.f) ? io->dropout_mode : FCL_DROP_NONE;
     static const int fused = tunable("FUSED_PRENET", 1);
+    FCL_REQUIRE(fused || !io->live_rows, FCL_ERR_INVALID, "decoder_loop_fwd: device live_rows need the fused feat/prenet kernel (FCL_FUSED_PRENET=1)");
     int cur = 0;
     for (int t = 0; t <= io->lmax; ++t) {
         const int n = t < io->lmax ? io->live_rows_host[t] : 0;        // rows live at step t
@@ -336,6 +339,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             fp.w1_hi = w->prenet_w1_hi; fp.w1_lo = w->prenet_w1_lo;
             fp.drop_mode = drop_mode; fp.keep0 = keep0; fp.keep1 = keep1; fp.keep_scale = keep_scale; fp.drop_p = w->prenet_dropout;
             fp.seed0 = seed0; fp.seed1 = seed1; fp.seed_dev = io->seed_dev; fp.pre_out = ws.pre_b; fp.tap_prenet = io->tap_prenet;
+            fp.live = io->live_rows; fp.status = io->status;
             if (planes) {
                 fp.before_p = io->before_p;
                 if (!small_step(n)) { fp.pre_out_p = ws.pre_p; fp.pre_out = nullptr; }  // the big-tile LSTM step reads planes only
@@ -381,6 +385,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             l0.h_out_p = ws.h0_p[cur ^ 1]; l0.ld_hp = ldu;  // read by layer 1 now and by layer 0 of the next step
         }
         l0.nterms = 2; l0.M = n; l0.U = U; l0.G = ws.G0; l0.g_row_mul = 1; l0.g_row_add = 0;
+        l0.m_dev = io->live_rows ? io->live_rows + t : nullptr;
         l0.rank1_w = w->w0_pos; l0.dur = io->dur; l0.step = t;
         l0.h_in = ws.h0[cur]; l0.h_out = ws.h0[cur ^ 1]; l0.c = ws.c0; l0.zoneout = w->zoneout_rate;
         if (io->tap_lstm0) { l0.out2 = io->tap_lstm0; l0.out2_row_base = io->frame_off; l0.out2_row_add = t; l0.ld2 = U; }
@@ -396,6 +401,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             if (next_big) { l1.h_out_p = ws.h1_p[cur ^ 1]; l1.ld_hp = ldu; }
         }
         l1.nterms = 2; l1.M = n; l1.U = U; l1.bias = w->b1; l1.step = t;
+        l1.m_dev = l0.m_dev;
         l1.h_in = ws.h1[cur]; l1.h_out = ws.h1[cur ^ 1]; l1.c = ws.c1; l1.zoneout = w->zoneout_rate;
         if (io->tap_lstm1) { l1.out2 = io->tap_lstm1; l1.out2_row_base = io->frame_off; l1.out2_row_add = t; l1.ld2 = U; }
         rc = launch_lstm_step(l1, s);

@@ -112,6 +112,11 @@ __device__ __forceinline__ float drop_apply(float v, int mode, const uint8_t* ke
 }
 
 __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a) {
+    // rows of this launch: the host's counts, or -- device-driven loop -- the smaller of the host's bounds and the device's live counts
+    const int M_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat;
+    const int M_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * (16) >= (a.h1 ? M_feat : M_pre)) return;  // tile beyond the live rows (uniform per workgroup, before any barrier)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ldU = a.U + 4, ldO = a.O + 4, ldP = a.P + 4;
     float* A1 = smem;            // [16, U]  h1 tile
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
 
     // ---- H8 feat_out of the previous step (+ H10 scatter) ------------------------------------------
     if (a.h1) {
-        load_rowtile(A1, ldU, a.h1, a.U, a.U, m0, a.M_feat);
+        load_rowtile(A1, ldU, a.h1, a.U, a.U, m0, M_feat);
         __syncthreads();
         for (int tile = wave; tile * 16 < a.O; tile += nwaves) {
             const float* const wr[1] = {a.wf_h + (size_t)min(tile * 16 + r16, a.O - 1) * a.U};
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
             int fo[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {  // epilogue operands fetched before the MFMA chain (clamped, unconditional)
-                const int mc = min(m0 + rq * 4 + r, a.M_feat - 1);
+                const int mc = min(m0 + rq * 4 + r, M_feat - 1);
                 f0v[r] = a.F0[(size_t)mc * a.O + ncc];
                 fo[r] = a.frame_off[mc];
             }
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
             for (int r = 0; r < 4; ++r) {
                 const int row = rq * 4 + r, m = m0 + row;
                 float v = 0.f;
-                if (m < a.M_feat && nc < a.O) {
+                if (m < M_feat && nc < a.O) {
                     v = acc[r] + f0v[r];
                     a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
                 }
@@ -156,10 +161,10 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
     } else {
         for (int i = threadIdx.x; i < 16 * ldO; i += blockDim.x) A2[i] = 0.f;  // prev_out = 0 at t = 0
     }
-    if (!a.w0 || m0 >= a.M_pre) return;  // last step: feat only / rows that just finished
+    if (!a.w0 || m0 >= M_pre) return;  // last step: feat only / rows that just finished
     __syncthreads();
     if (a.teacher_in) {  // teacher forcing: prenet input is y_{t-1}, not the decoder's own output
-        load_rowtile(A2, ldO, a.teacher_in, a.teacher_ld, a.O, m0, a.M_pre);
+        load_rowtile(A2, ldO, a.teacher_in, a.teacher_ld, a.O, m0, M_pre);
         __syncthreads();
     }
     // ---- H6 prenet layer 0 ---------------------------------------------------------------------------
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
                 for (int r = 0; r < 4; ++r) {
                     const int row = rq * 4 + r, m = m0 + row;
                     float v = fmaxf(accv[tt][r] + bn, 0.f);
-                    if (m < a.M_pre) v = drop_apply(v, a.drop_mode, a.keep0, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed0);
+                    if (m < M_pre) v = drop_apply(v, a.drop_mode, a.keep0, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed0);
                     A3[row * ldP + nc] = v;
                 }
             }
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + rq * 4 + r;
-                    if (m >= a.M_pre) continue;
+                    if (m >= M_pre) continue;
                     float v = fmaxf(accv[tt][r] + bn, 0.f);
                     v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
                     a.pre_out[(size_t)m * a.P + nc] = v;
@@ -332,6 +337,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // SU/SO/SP = compile-time 32-k step counts of U/O/P (weights preloaded into registers); 0 = generic streaming loops.
 template <int SU, int SO, int SP>
 __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArgs a) {
+    // rows of this launch: the host's counts, or -- device-driven loop -- the smaller of the host's bounds and the device's live counts
+    const int M_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat;
+    const int M_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * (16) >= (a.h1 ? M_feat : M_pre)) return;  // tile beyond the live rows (uniform per workgroup, before any barrier)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ldU = a.U + 8, ldO = a.O + 8, ldP = a.P + 8;  // bf16 elements per plane row
     u16* A1h = reinterpret_cast<u16*>(smem);
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     // weight fragments for the prenet layers are requested first thing: they are consumed two barriers later
     WFrag<2, PRE ? SO : 1> f0;
     WFrag<2, PRE ? SP : 1> f1;
-    const bool has_pre = a.w0 && m0 < a.M_pre;
+    const bool has_pre = a.w0 && m0 < M_pre;
     const int ptile = wave, ptile2 = wave + nwaves;  // P/16 <= 2*nwaves is checked by the launcher for the PRE path
     const int nsU = (a.U + 31) >> 5, nsO = (a.O + 31) >> 5, nsP = (a.P + 31) >> 5, ptmax = ((a.P + 15) >> 4) - 1;
     const size_t lane8 = (size_t)lane * 8;
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
             const u16* const wl[1] = {frag(a.wf_lo, wave, nsU)};
             ff.load(wh, wl);
         }
-        load_rowtile_split(A1h, A1l, ldU, a.h1, a.U, a.U, m0, a.M_feat);
+        load_rowtile_split(A1h, A1l, ldU, a.h1, a.U, a.U, m0, M_feat);
         __syncthreads();
         if (a.dbg_phase == 1) return;
         for (int tile = wave; tile * 16 < a.O; tile += nwaves) {
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
             int fo[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int mc = min(m0 + rq * 4 + r, a.M_feat - 1);
+                const int mc = min(m0 + rq * 4 + r, M_feat - 1);
                 f0v[r] = a.F0[(size_t)mc * a.O + ncc];
                 fo[r] = a.frame_off[mc];
             }
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
             for (int r = 0; r < 4; ++r) {
                 const int row = rq * 4 + r, m = m0 + row;
                 float v = 0.f;
-                if (m < a.M_feat && nc < a.O) {
+                if (m < M_feat && nc < a.O) {
                     v = accv[0][r] + f0v[r];
                     a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
                     if (a.before_p) store_p32(a.before_p, (a.O + 31) >> 5, fo[r] + a.t_prev, nc, v);
@@ -413,7 +423,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
             const int padc = 32 - (a.O & 31);
             for (int i = threadIdx.x; i < 16 * padc; i += blockDim.x) {
                 const int m = m0 + i / padc;
-                if (m < a.M_feat) store_p32(a.before_p, (a.O + 31) >> 5, a.frame_off[m] + a.t_prev, a.O + i % padc, 0.f);
+                if (m < M_feat) store_p32(a.before_p, (a.O + 31) >> 5, a.frame_off[m] + a.t_prev, a.O + i % padc, 0.f);
             }
         }
     } else {
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     }
     lds_barrier();  // NOT __syncthreads(): its vmcnt(0) would park every wave until the 32 fragment loads just issued have landed
     if (a.teacher_in) {
-        load_rowtile_split(A2h, A2l, ldO, a.teacher_in, a.teacher_ld, a.O, m0, a.M_pre);
+        load_rowtile_split(A2h, A2l, ldO, a.teacher_in, a.teacher_ld, a.O, m0, M_pre);
         __syncthreads();
     }
     for (int tile = wave; tile * 16 < a.P; tile += 2 * nwaves) {
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
                 for (int r = 0; r < 4; ++r) {
                     const int row = rq * 4 + r, m = m0 + row;
                     float v = fmaxf(accv[tt][r] + bn, 0.f);
-                    if (m < a.M_pre) v = drop_apply(v, a.drop_mode, a.keep0, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed0);
+                    if (m < M_pre) v = drop_apply(v, a.drop_mode, a.keep0, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed0);
                     split1(v, A3h[row * ldP + nc], A3l[row * ldP + nc]);
                 }
             }
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + rq * 4 + r;
-                    if (m >= a.M_pre) continue;
+                    if (m >= M_pre) continue;
                     float v = fmaxf(accv[tt][r] + bn, 0.f);
                     v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
                     if (a.pre_out) a.pre_out[(size_t)m * a.P + nc] = v;
@@ -491,6 +501,11 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
 // kernel's CU-time fall by RT (the fragment registers cannot stay resident ACROSS tiles: 240 VGPRs for the three sets).
 template <int SU, int SO, int SP, int DROP, int RT>
 __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetArgs a) {
+    // rows of this launch: the host's counts, or -- device-driven loop -- the smaller of the host's bounds and the device's live counts
+    const int M_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat;
+    const int M_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * (16 * RT) >= (a.h1 ? M_feat : M_pre)) return;  // tile beyond the live rows (uniform per workgroup, before any barrier)
     constexpr int U = SU * 32, OP = SO * 32, P = SP * 32;
     constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8, ROWS = 16 * RT;
     static_assert(2 * SP <= 16, "two prenet column tiles per wave, 8 waves");
@@ -506,7 +521,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int col = lane & 15, rq = lane >> 4;
-    const bool has_feat = a.h1 != nullptr, has_pre = a.w0 != nullptr && m0 < a.M_pre;
+    const bool has_feat = a.h1 != nullptr, has_pre = a.w0 != nullptr && m0 < M_pre;
     const bool feat_wave = has_feat && wave * 16 < O;
     const size_t lane8 = (size_t)lane * 8;
     auto frag = [&](const u16* base, int tile, int ns) { return base + (size_t)tile * ns * 512 + lane8; };
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
                 for (int q = 0; q < RT; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int mc = min(m0 + q * 16 + rq * 4 + r, a.M_pre - 1);
+                        const int mc = min(m0 + q * 16 + rq * 4 + r, M_pre - 1);
                         k0[q][tt][r] = a.keep0[(size_t)mc * P + nc];
                         k1[q][tt][r] = a.keep1[(size_t)mc * P + nc];
                     }
@@ -549,7 +564,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
             f0v[q][r] = 0.f;
             fo[q][r] = 0;
             if (feat_wave) {
-                const int mc = min(m0 + q * 16 + rq * 4 + r, a.M_feat - 1);
+                const int mc = min(m0 + q * 16 + rq * 4 + r, M_feat - 1);
                 f0v[q][r] = a.F0[(size_t)mc * O + min(fnc, O - 1)];
                 fo[q][r] = a.frame_off[mc];
             }
@@ -571,7 +586,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     for (int i = threadIdx.x; i < ROWS * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }
     if (has_feat) {
 #pragma unroll
-        for (int q = 0; q < RT; ++q) load_rowtile_split(A1h + q * 16 * ldU, A1l + q * 16 * ldU, ldU, a.h1, U, U, m0 + q * 16, a.M_feat);
+        for (int q = 0; q < RT; ++q) load_rowtile_split(A1h + q * 16 * ldU, A1l + q * 16 * ldU, ldU, a.h1, U, U, m0 + q * 16, M_feat);
     }
     __syncthreads();
     if (a.dbg_phase == 1) return;
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
                 const int row = q * 16 + rq * 4 + r, m = m0 + row;
                 if (fnc < O) {
                     float v = 0.f;
-                    if (m < a.M_feat) {
+                    if (m < M_feat) {
                         v = accv[0][r] + f0v[q][r];
                         a.before[(size_t)(fo[q][r] + a.t_prev) * O + fnc] = v;
                         if (a.before_p) store_p32(a.before_p, (O + 31) >> 5, fo[q][r] + a.t_prev, fnc, v);
@@ -600,7 +615,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
         const int padc = 32 - (O & 31);
         for (int i = threadIdx.x; i < ROWS * padc; i += blockDim.x) {
             const int m = m0 + i / padc;
-            if (m < a.M_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
+            if (m < M_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
         }
     }
     if (!has_pre || a.dbg_phase == 2) return;
@@ -612,7 +627,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     lds_barrier();
     if (a.teacher_in) {  // teacher forcing: prenet input is y_{t-1}, not the decoder's own output
 #pragma unroll
-        for (int q = 0; q < RT; ++q) load_rowtile_split(A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, a.teacher_in, a.teacher_ld, O, m0 + q * 16, a.M_pre);
+        for (int q = 0; q < RT; ++q) load_rowtile_split(A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, a.teacher_in, a.teacher_ld, O, m0 + q * 16, M_pre);
         __syncthreads();
     }
     // ---- phase 2: H6 prenet layer 0 ---------------------------------------------------------------------------------------------------------
@@ -649,7 +664,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + q * 16 + rq * 4 + r;
-                if (m >= a.M_pre) continue;
+                if (m >= M_pre) continue;
                 float v = fmaxf(accv[tt][r] + pb1[tt], 0.f);
                 if (DROP == 1) v = k1[q][tt][r] ? v * a.keep_scale : 0.f;
                 if (DROP == 2) {
@@ -667,6 +682,8 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
 // PRE: both terms have K = 256 (the student's decoder LSTMs) -> all 2 x 8 weight fragments are requested at kernel entry.
 template <bool PRE>
 __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a) {
+    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
+    if ((int)blockIdx.y * 16 >= M) return;      // tile beyond the live rows (uniform per workgroup, before any barrier)
     constexpr int KC = 512;
     __shared__ __attribute__((aligned(16))) u16 A_h[16 * (KC + 8)];
     __shared__ __attribute__((aligned(16))) u16 A_lo[16 * (KC + 8)];
@@ -677,7 +694,7 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
     // epilogue operands first (latency hides under the K walk)
     const int erow = threadIdx.x >> 4, euc = threadIdx.x & 15;
     const int em = m0 + erow, eu = u0 + euc;
-    const bool evalid = em < a.M && eu < a.U;
+    const bool evalid = em < M && eu < a.U;
     CellIn ci;
     if (evalid) ci = cell_prefetch(a, em, eu);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -693,7 +710,7 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (t) __syncthreads();
-            load_rowtile_split(A_h, A_lo, 256 + 8, a.term[t].A, a.term[t].lda, 256, m0, a.M);
+            load_rowtile_split(A_h, A_lo, 256 + 8, a.term[t].A, a.term[t].lda, 256, m0, M);
             __syncthreads();
             f32x4 part[1];
             wf[t].mma(A_h, A_lo, 256 + 8, 256, r16, kq, part);
@@ -705,7 +722,7 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
         for (int k0 = 0; k0 < T.K; k0 += KC) {
             const int kc = min(KC, T.K - k0);
             __syncthreads();
-            load_rowtile_split(A_h, A_lo, kc + 8, T.A + k0, T.lda, kc, m0, a.M);
+            load_rowtile_split(A_h, A_lo, kc + 8, T.A + k0, T.lda, kc, m0, M);
             __syncthreads();
             const size_t fo = ((size_t)((g * a.U + u0) >> 4) * ((T.K + 31) >> 5) + (k0 >> 5)) * 512 + (size_t)lane * 8;
             const u16* const wh[1] = {T.Whi + fo};
@@ -730,6 +747,8 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
 constexpr int SMALL_KC = 512;  // K chunk resident in LDS
 
 __device__ __forceinline__ void lstm_small_body(const LstmStepArgs& a) {
+    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
+    if ((int)blockIdx.y * 16 >= M) return;      // tile beyond the live rows (uniform per workgroup, before any barrier)
     __shared__ __attribute__((aligned(16))) float A_l[16 * (SMALL_KC + 4)];
     __shared__ float g_l[4][16][17];
     const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
@@ -742,7 +761,7 @@ __device__ __forceinline__ void lstm_small_body(const LstmStepArgs& a) {
         for (int k0 = 0; k0 < T.K; k0 += SMALL_KC) {
             const int kc = min(SMALL_KC, T.K - k0);
             __syncthreads();  // previous chunk fully consumed
-            load_rowtile(A_l, kc + 4, T.A + k0, T.lda, kc, m0, a.M);
+            load_rowtile(A_l, kc + 4, T.A + k0, T.lda, kc, m0, M);
             __syncthreads();
             const float* const wr[1] = {T.W + (size_t)(g * a.U + min(u, a.U - 1)) * T.ldw + k0};
             f32x4 part[1];
@@ -759,7 +778,7 @@ __device__ __forceinline__ void lstm_small_body(const LstmStepArgs& a) {
     // cell epilogue: thread -> (row, unit)
     const int row = threadIdx.x >> 4, uc = threadIdx.x & 15;
     const int m = m0 + row, uu = u0 + uc;
-    if (m >= a.M || uu >= a.U) return;
+    if (m >= M || uu >= a.U) return;
     const CellIn ci = cell_prefetch(a, m, uu);
     const float pre[4] = {g_l[0][row][uc], g_l[1][row][uc], g_l[2][row][uc], g_l[3][row][uc]};
     cell_finish(a, m, uu, pre, ci);
@@ -893,7 +912,7 @@ static bool wres_applicable(const LstmStepArgs& a) {
     // latency mode: ~10 % faster for a single pass in flight, but its 156 KB of LDS per workgroup blocks the
     // co-residency that several passes in flight rely on (bench default), so it is opt-in: FCL_LSTM_WRES=1
     static const int on = tunable("LSTM_WRES", 0);
-    if (!on || a.nterms != 2) return false;
+    if (!on || a.nterms != 2 || a.m_dev) return false;  // (device row counts: the grouped row split of this kernel is computed on the host)
     // the kernel reads the fp32 operands: a step whose producers wrote planes only (big decoder steps on the pre-split path set A = the buffer
     // but never fill it; round-2 ADVICE) is not its to take
     for (int i = 0; i < 2; ++i)

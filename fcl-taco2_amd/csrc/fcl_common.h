@@ -119,7 +119,12 @@ struct FeatPrenetArgs {
     unsigned short* pre_out_p;  // optional P32 planes of pre_out (ceil(P/32) lines per row): the next LSTM step's pre-split operand
     unsigned short* before_p;   // optional P32 planes of `before` (ceil(O/32) lines per row, zero past O): the postnet's pre-split operand
     int dbg_phase;              // developer timing aid (FCL_FP_DBG): 1..3 = return after the loads / feat / prenet-0 phase (results are then garbage)
+    const int* live;            // optional DEVICE live-row counts [*]: M_feat := min(M_feat, live[t_prev]), M_pre := min(M_pre, live[t_cur])
+    unsigned int* status;       // with `live`: FCL_STATUS_ROWS_CAP when live[t_cur] exceeds the host's bound M_pre
 };
+
+// rows a step kernel processes: the host's count, or (device-driven loops) the smaller of the host's bound and the device's count
+__device__ __forceinline__ int live_rows_of(int m_host, const int* m_dev) { return m_dev ? min(m_host, *m_dev) : m_host; }
 
 // ---- bf16x3 operand split shared by the big-tile GEMMs (gemm_f32.hip) and the weight-gradient GEMM (backward.hip) ------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

@@ -308,6 +308,8 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
     int bx, by;
     xcd_tile(bx, by);
     const int m0 = by * G::BM, u0 = bx * (16 * WN);
+    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
+    if (m0 >= M) return;                        // tile beyond the live rows (uniform per workgroup, before any barrier / LDS-DMA)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);
@@ -319,20 +321,20 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, a.M - 1), uc);
+        for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, M - 1), uc);
     f32x4 acc[TM][4];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mainloop<WM, WN, true, PREC, TM>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, lds, acc, PREC != 0 && hi_only != 0);
+    mainloop<WM, WN, true, PREC, TM>(a.term, a.nterms, M, m0, u0, a.U, nullptr, nullptr, lds, acc, PREC != 0 && hi_only != 0);
     if (u >= a.U) return;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
-            if (m >= a.M) continue;
+            if (m >= M) continue;
             const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
             cell_finish(a, m, u, pre, ci[tm][r]);
         }

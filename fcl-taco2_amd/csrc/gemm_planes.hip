@@ -365,6 +365,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
     int bx, by;
     xcd_tile_p(bx, by);
     const int m0 = by * G::BM, u0 = bx * (16 * WN);
+    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
+    if (m0 >= M) return;                        // tile beyond the live rows (uniform per workgroup, before any barrier / LDS-DMA)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);
@@ -377,14 +379,14 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, a.M - 1), uc);
+            for (int r = 0; r < 4; ++r) ci[tm][r] = cell_prefetch<MODE>(a, min(m0 + (wm * TM + tm) * 16 + rq * 4 + r, M - 1), uc);
     }
     f32x4 acc[TM][4];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[tm][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (!pmainloop<WM, WN, TM, 4, NST, true, LW, HI>(a.term, a.nterms, a.M, m0, u0, a.U, nullptr, nullptr, smem, acc)) return;  // loader wave
+    if (!pmainloop<WM, WN, TM, 4, NST, true, LW, HI>(a.term, a.nterms, M, m0, u0, a.U, nullptr, nullptr, smem, acc)) return;  // loader wave
     // Epilogue through LDS (see pgemm_kernel): the new h and c of the tile are staged as [row][unit] fp32 and written out row-wise, 16 bytes
     // per lane; the tile's 16 WN units are (part of) ONE 128-byte P32 line per row, so the planes of h go out as whole 16-byte pieces too.
     constexpr int UW = 16 * WN, LDT = UW + 4;
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
         for (int r = 0; r < 4; ++r) {
             const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + rm;
             float h_w = 0.f, c_w = 0.f;
-            if (m < a.M && u < a.U) {
+            if (m < M && u < a.U) {
                 const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
                 cell_math(a, m, u, pre, ci[tm][r], h_w, c_w);
             }
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
             tc[rm * LDT + wn * 16 + (lane & 15)] = c_w;
         }
     __syncthreads();
-    const int rows = min(G::BM, a.M - m0);
+    const int rows = min(G::BM, M - m0);
     const bool vec = (a.U & 3) == 0;
     for (int i = threadIdx.x; i < rows * (UW / 4); i += G::CTHREADS) {
         const int rm = i / (UW / 4), c4 = (i - rm * (UW / 4)) * 4, uu = u0 + c4;

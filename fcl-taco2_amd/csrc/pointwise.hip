@@ -286,6 +286,98 @@ __global__ void __launch_bounds__(256) derive_batch_kernel(const fcl_derive_t* _
     }
 }
 
+// ---- H10 on the device: row / frame maps of a batch from durations that live in HBM (fcl_row_maps_build) -----------------------------------
+// Every output element is a count or a prefix sum over the N compact rows, so each thread walks the durations once (staged through LDS in
+// chunks: broadcast reads): O(N) per thread, N/256 + a few workgroups -- ~10 us for a 32-utterance batch, no sort network, no atomics,
+// deterministic.  Role by workgroup: rows (stable descending rank + exclusive prefix sum), live-row counts, utterance frame starts / totals.
+constexpr int RM_CHUNK = 4096;
+constexpr int RM_DMAX = 65535;  // durations are clamped here (sum over <= 32 k rows stays inside int32); anything near it trips FCL_STATUS_LMAX_CAP
+
+__device__ __forceinline__ int rm_dur(const fcl_row_maps_t& a, int j) {
+    const long long d = a.dur_i32 ? (long long)a.dur_i32[j] : (long long)a.dur_i64[a.row_src ? a.row_src[j] : j];
+    const int v = (int)(d < 0 ? 0 : (d > RM_DMAX ? RM_DMAX : d));
+    return (a.pad && a.pad[j]) ? -1 - v : v;  // padding rows: tagged negative for the zero-duration test, counted as 0 everywhere else
+}
+
+__global__ __launch_bounds__(256) void row_maps_kernel(const fcl_row_maps_t a, int wg_rows, int wg_live) {
+    __shared__ int d_l[RM_CHUNK];
+    const int wg = blockIdx.x;
+    const int role = wg < wg_rows ? 0 : (wg < wg_rows + wg_live ? 1 : 2);
+    const int idx = (wg - (role == 0 ? 0 : (role == 1 ? wg_rows : wg_rows + wg_live))) * 256 + threadIdx.x;
+    const bool on = role == 0 ? idx < a.n : (role == 1 ? idx <= a.lmax_cap : idx <= a.b);
+    int my_d = 0, lim = 0;
+    if (role == 0 && on) my_d = max(rm_dur(a, idx), 0);
+    if (role == 2 && on) lim = a.utt_row0 ? a.utt_row0[idx] : idx * a.t_max;
+    int rank = 0, acc = 0, dmax = 0, zeros = 0;
+    for (int c0 = 0; c0 < a.n; c0 += RM_CHUNK) {
+        const int cn = min(RM_CHUNK, a.n - c0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cn; j += 256) d_l[j] = rm_dur(a, c0 + j);
+        __syncthreads();
+        if (!on) continue;
+        if (role == 0) {
+            for (int j = 0; j < cn; ++j) {
+                const int d = max(d_l[j], 0), gj = c0 + j;
+                rank += (d > my_d) || (d == my_d && gj < idx);  // stable: ties keep compact order (np.argsort(-dur, kind="stable"))
+                acc += gj < idx ? d : 0;                        // exclusive prefix sum = first output frame of the row (H10)
+            }
+        } else if (role == 1) {
+            for (int j = 0; j < cn; ++j) acc += d_l[j] > idx;   // rows still alive at step idx
+        } else {
+            for (int j = 0; j < cn; ++j) {
+                const int d = max(d_l[j], 0);
+                acc += (c0 + j) < lim ? d : 0;
+                dmax = max(dmax, d);
+                zeros += d_l[j] == 0;  // (padding rows are < 0 here)
+            }
+        }
+    }
+    if (!on) return;
+    if (role == 0) {
+        a.src_rows[rank] = a.row_src ? a.row_src[idx] : idx;
+        a.dur_sorted[rank] = my_d;
+        a.frame_off[rank] = acc;
+        if (a.order) a.order[rank] = idx;
+    } else if (role == 1) {
+        a.live_rows[idx] = acc;
+    } else {
+        a.utt_frame0[idx] = acc;
+        if (idx == a.b) {  // lim = N: acc is the total
+            a.totals[0] = acc;
+            a.totals[1] = dmax;
+            a.totals[2] = zeros;
+            a.totals[3] = 0;
+            unsigned int bits = 0;
+            if (zeros) bits |= FCL_STATUS_ZERO_DURATION;
+            if (dmax > a.lmax_cap) bits |= FCL_STATUS_LMAX_CAP;
+            if (acc > a.frames_cap) bits |= FCL_STATUS_FRAMES_CAP;
+            if (bits) atomicOr(a.status, bits);
+        }
+    }
+}
+
+// second launch (the totals are complete): frame -> utterance bounds, and -- on any violation -- no live rows at all, so that a decoder loop
+// driven by these maps neither runs past its launched steps nor scatters past the frame buffers
+__global__ __launch_bounds__(256) void row_maps_finish_kernel(const fcl_row_maps_t a) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int total = a.totals[0];
+    const bool bad = a.totals[2] > 0 || a.totals[1] > a.lmax_cap || total > a.frames_cap;
+    if (bad && f <= a.lmax_cap) a.live_rows[f] = 0;
+    if (f >= a.frames_cap) return;
+    int lo = 0, hi = 0;
+    if (!bad && f < total) {
+        int l = 0, r = a.b;  // utt_frame0[l] <= f < utt_frame0[r]
+        while (r - l > 1) {
+            const int mid = (l + r) >> 1;
+            if (a.utt_frame0[mid] <= f) l = mid; else r = mid;
+        }
+        lo = a.utt_frame0[l];
+        hi = a.utt_frame0[l + 1];
+    }
+    a.frame_lo[f] = lo;
+    a.frame_hi[f] = hi;
+}
+
 }  // namespace fcl
 
 using namespace fcl;
@@ -421,6 +513,25 @@ int fcl_derive_batch(const fcl_derive_t* descs_dev, int n, int total_blocks, fcl
     if (n == 0 || total_blocks == 0) return 0;
     hipLaunchKernelGGL(derive_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, descs_dev, n);
     return check_hip(hipGetLastError(), "derive_batch");
+}
+
+int fcl_row_maps_build(const fcl_row_maps_t* a, fcl_stream_t stream) {
+    FCL_REQUIRE(a, FCL_ERR_INVALID, "row_maps_build: null argument");
+    FCL_REQUIRE(a->b > 0 && a->n > 0 && a->lmax_cap > 0 && a->frames_cap > 0, FCL_ERR_SHAPE, "row_maps_build: bad sizes B=%d N=%d lmax_cap=%d frames_cap=%d",
+                a->b, a->n, a->lmax_cap, a->frames_cap);
+    FCL_REQUIRE(a->n <= 32768 && a->lmax_cap < RM_DMAX, FCL_ERR_SHAPE, "row_maps_build: at most 32768 rows and %d steps", RM_DMAX - 1);
+    FCL_REQUIRE((a->dur_i64 != nullptr) != (a->dur_i32 != nullptr), FCL_ERR_INVALID, "row_maps_build: exactly one of dur_i64 / dur_i32");
+    FCL_REQUIRE(a->utt_row0 || (a->t_max > 0 && a->n == a->b * a->t_max), FCL_ERR_SHAPE, "row_maps_build: without utt_row0 the rows are the padded [B, t_max] layout");
+    FCL_REQUIRE(a->src_rows && a->dur_sorted && a->frame_off && a->live_rows && a->utt_frame0 && a->frame_lo && a->frame_hi &&
+                    a->totals && a->status,
+                FCL_ERR_INVALID, "row_maps_build: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int wg_rows = (a->n + 255) / 256, wg_live = (a->lmax_cap + 1 + 255) / 256, wg_utt = (a->b + 1 + 255) / 256;
+    hipLaunchKernelGGL(row_maps_kernel, dim3(wg_rows + wg_live + wg_utt), dim3(256), 0, s, *a, wg_rows, wg_live);
+    FCL_HIP(hipGetLastError());
+    const int items = std::max(a->frames_cap, a->lmax_cap + 1);
+    hipLaunchKernelGGL(row_maps_finish_kernel, dim3((items + 255) / 256), dim3(256), 0, s, *a);
+    return check_hip(hipGetLastError(), "row_maps_build");
 }
 
 }  // extern "C"

@@ -223,8 +223,18 @@ def status_message(bits):
     if bits & _lib.STATUS_GROUP_TIMEOUT:
         msgs.append("a cooperating-workgroup BiLSTM kernel timed out waiting for a group member (its outputs are partial); "
                     "it is single-stream only — run one at a time or set FCL_BILSTM_GROUP=0")
-    if bits & ~_lib.STATUS_GROUP_TIMEOUT:
-        msgs.append("unknown status bits 0x%x" % (bits & ~_lib.STATUS_GROUP_TIMEOUT))
+    if bits & _lib.STATUS_ZERO_DURATION:
+        msgs.append("zero duration: ds_nonzeros.shape[0] != hs.shape[0] (the reference asserts on a non-padded phoneme of duration 0, "
+                    "decoder_sa_kd.py:739); nothing was decoded")
+    if bits & _lib.STATUS_LMAX_CAP:
+        msgs.append("a duration exceeds the number of decoder steps that were launched (lmax_cap); nothing was decoded -- rerun with a larger cap")
+    if bits & _lib.STATUS_FRAMES_CAP:
+        msgs.append("the batch has more frames than the frame buffers hold (frames_cap); nothing was decoded -- rerun with a larger cap")
+    if bits & _lib.STATUS_ROWS_CAP:
+        msgs.append("a decoder step had more live rows than the host's bound for it (rows beyond the bound were not computed)")
+    known = (_lib.STATUS_GROUP_TIMEOUT | _lib.STATUS_ZERO_DURATION | _lib.STATUS_LMAX_CAP | _lib.STATUS_FRAMES_CAP | _lib.STATUS_ROWS_CAP)
+    if bits & ~known:
+        msgs.append("unknown status bits 0x%x" % (bits & ~known))
     return "; ".join(msgs)
 
 
@@ -269,11 +279,47 @@ def u32_add(word_i32, v=1):
     check(_lib.load().fcl_u32_add(_p(word_i32, torch.int32), v, _stream()))
 
 
+def row_maps_build(n, b, lmax_cap, frames_cap, dur_i64=None, dur_i32=None, row_src=None, utt_row0=None, t_max=0, pad=None, want_order=False,
+                   status=None):
+    """Device-built row / frame maps (include/fcl_hip.h fcl_row_maps_build; bit-identical to engine.build_row_maps on the real rows).
+    Row universe: compact rows (row_src [N] / utt_row0 [B + 1] int32 device tensors that depend on the phoneme counts alone) or, with
+    row_src=None, the padded [B, t_max] layout (n = B * t_max; `pad` marks the padding rows).  Durations: int64 (fcl_duration_round_fwd's
+    output, read through row_src) or int32 per row.  Returns a dict of int32 device tensors: src_rows, dur, frame_off [n]; live_rows
+    [lmax_cap + 1]; utt_frame0 [B + 1]; frame_lo / frame_hi [frames_cap]; totals [4] = (frames, max duration, zero-duration rows, 0); order [n] on
+    request.  Violations (a zero duration, a duration > lmax_cap, more than frames_cap frames) set FCL_STATUS_* bits in the device status word
+    and zero live_rows."""
+    ref = dur_i64 if dur_i64 is not None else dur_i32
+    dev = ref.device
+    # one allocation for all the maps (a graph-private pool then holds one block; slices are 16-byte aligned)
+    sizes = dict(src_rows=n, dur=n, frame_off=n, live_rows=lmax_cap + 1, utt_frame0=b + 1, frame_lo=frames_cap, frame_hi=frames_cap, totals=4)
+    if want_order:
+        sizes["order"] = n
+    offs, tot = {}, 0
+    for k, v in sizes.items():
+        offs[k] = tot
+        tot += (v + 3) // 4 * 4
+    blk = torch.empty(tot, dtype=torch.int32, device=dev)
+    out = {k: blk[offs[k] : offs[k] + v] for k, v in sizes.items()}
+    st = status if status is not None else status_word(dev)
+    a = _lib.RowMaps(b=b, n=n, lmax_cap=lmax_cap, frames_cap=frames_cap, t_max=t_max, row_src=_p(row_src, torch.int32), utt_row0=_p(utt_row0, torch.int32),
+                     pad=_p(pad, torch.uint8), dur_i64=_p(dur_i64, torch.int64), dur_i32=_p(dur_i32, torch.int32), src_rows=_p(out["src_rows"], torch.int32),
+                     dur_sorted=_p(out["dur"], torch.int32), frame_off=_p(out["frame_off"], torch.int32),
+                     order=_p(out.get("order"), torch.int32), live_rows=_p(out["live_rows"], torch.int32), utt_frame0=_p(out["utt_frame0"], torch.int32),
+                     frame_lo=_p(out["frame_lo"], torch.int32), frame_hi=_p(out["frame_hi"], torch.int32), totals=_p(out["totals"], torch.int32),
+                     status=st.data_ptr())
+    check(_lib.load().fcl_row_maps_build(C.byref(a), _stream()))
+    return out
+
+
 def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher_ys=None, dropout_mode=DROP_NONE,
-                 prenet_keep=None, seed=0, want_taps=False, seed_dev=None, zero_init=False, att_c_p=None, want_before_p=False):
+                 prenet_keep=None, seed=0, want_taps=False, seed_dev=None, zero_init=False, att_c_p=None, want_before_p=False, live_rows_dev=None,
+                 status=None):
     """dw: plan.DecoderPack (holds the ctypes DecoderWeights + the tensors it points to).
     live_rows: host numpy int32 [Lmax].  Returns before [F, odim] (+ taps).  att_c_p: P32 planes of att_c (att_c may then be None);
-    want_before_p: also return `before` as P32 planes (appended to the result)."""
+    want_before_p: also return `before` as P32 planes (appended to the result).
+    live_rows_dev: device int32 [Lmax + 1] (row_maps_build): the loop is then driven by the DEVICE counts, `live_rows` are per-step upper bounds
+    (grid sizes, kernel selection) and n_frames is the capacity of the frame buffers (rows past the real total are never written; the
+    postnet's segment bounds of such rows are empty, so nothing reads them either)."""
     lib = _lib.load()
     dev = att_c.device if att_c is not None else att_c_p.device
     n = att_c.shape[0] if att_c is not None else att_c_p.shape[0]
@@ -283,6 +329,8 @@ def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher
     alloc = torch.zeros if zero_init else torch.empty  # zero_init: frames no (row, t) maps to stay 0 (padded [B, Lmax] layout)
     before = alloc(n_frames, dw.struct.odim, device=dev, dtype=torch.float32)
     before_p = planes_empty(n_frames, dw.struct.odim, dev) if want_before_p else None
+    if live_rows_dev is not None and status is None:
+        status = status_word(dev)
     taps = None
     if want_taps:
         taps = (alloc(n_frames, dw.struct.p, device=dev, dtype=torch.float32),
@@ -293,7 +341,8 @@ def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher
         frame_off=_p(frame_off_i32, torch.int32), teacher_ys=_p(teacher_ys), dropout_mode=dropout_mode,
         prenet_keep=_p(prenet_keep, torch.uint8), seed=seed & 0xFFFFFFFF, seed_dev=_p(seed_dev, torch.int32), before=_p(before),
         tap_prenet=_p(taps[0]) if taps else None, tap_lstm0=_p(taps[1]) if taps else None, tap_lstm1=_p(taps[2]) if taps else None,
-        workspace=ws.data_ptr(), workspace_bytes=nbytes, att_c_p=_p(att_c_p, torch.int16), before_p=_p(before_p, torch.int16))
+        workspace=ws.data_ptr(), workspace_bytes=nbytes, att_c_p=_p(att_c_p, torch.int16), before_p=_p(before_p, torch.int16),
+        live_rows=_p(live_rows_dev, torch.int32), status=None if live_rows_dev is None else status.data_ptr())
     check(lib.fcl_decoder_loop_fwd(C.byref(dw.struct), C.byref(io), _stream()))
     res = (before, taps) if want_taps else before
     if want_before_p:

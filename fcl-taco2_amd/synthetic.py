@@ -114,8 +114,10 @@ def training_batch(hp_odim=80, vocab=80, batch=4, t_lo=5, t_hi=9, seed=7, zero_f
     return xs, ys, ds, f0, en
 
 
-def build_model(role, hp, thp=None, device="cuda:0", share_proj=True):
-    """A plug-in model ("teacher" | "kd_teacher" | "student") with closed-form weights, the way bench / tools / smoke build one."""
+def build_model(role, hp, thp=None, device="cuda:0", share_proj=True, weights="closed_form", seed=0):
+    """A plug-in model ("teacher" | "kd_teacher" | "student"), the way bench / tools / smoke build one.  weights: "closed_form" (the goldens'
+    generator: a stiff, badly conditioned net -- fine for timing and forward parity) or "init" (the reference's own initialisation, i.e. what
+    training starts from: torch defaults + xavier on the convolutions, drawn from torch.manual_seed(seed))."""
     import argparse
 
     import torch
@@ -132,11 +134,17 @@ def build_model(role, hp, thp=None, device="cuda:0", share_proj=True):
 
     com = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
                              distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=True, share_proj=share_proj)
+    if weights == "init":
+        torch.manual_seed(seed)
+    elif weights != "closed_form":
+        raise ValueError("weights must be 'closed_form' or 'init'")
     if role == "student":
         m = Student(hp.idim, hp.odim, ns(hp), com, ns(thp))
         spec = HP.param_spec(hp, thp, share_proj)
     else:
         m = (Teacher if role == "teacher" else KDTeacher)(hp.idim, hp.odim, ns(hp), com)
         spec = HP.param_spec(hp)
+    if weights == "init":
+        return m.to(device)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in closed_form_state_dict(spec).items()})
     return m.to(device)

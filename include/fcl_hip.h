@@ -33,7 +33,15 @@ enum { FCL_DROP_NONE = 0, FCL_DROP_MASK = 1, FCL_DROP_RNG = 2 };
 /* Bits of a DEVICE status word (uint32, caller-owned, zeroed by the caller): failures a kernel can only detect while it runs are OR-ed into
  * it instead of being lost.  fcl_adam_step refuses to update the parameters while the word is non-zero; the host reads it back next to the
  * losses (one 4-byte copy) and raises. */
-enum { FCL_STATUS_GROUP_TIMEOUT = 1 /* a cooperating-workgroup BiLSTM kernel gave up waiting for a group member: its outputs are partial */ };
+enum {
+    FCL_STATUS_GROUP_TIMEOUT = 1, /* a cooperating-workgroup BiLSTM kernel gave up waiting for a group member: its outputs are partial */
+    /* device-built row maps (fcl_row_maps_build) and the decoder loop driven by them: */
+    FCL_STATUS_ZERO_DURATION = 2, /* a non-padded phoneme has duration 0: the reference's `assert ds_nonzeros.shape[0] == hs.shape[0]`
+                                   * (decoder_sa_kd.py:739) — the pass produced nothing valid */
+    FCL_STATUS_LMAX_CAP = 4,      /* max duration > lmax_cap: the loop would have needed more steps than were launched (nothing was decoded) */
+    FCL_STATUS_FRAMES_CAP = 8,    /* sum of durations > frames_cap: the frame-major buffers are too small (nothing was decoded) */
+    FCL_STATUS_ROWS_CAP = 16      /* live rows of a decoder step > the host's bound for that step (rows beyond the bound were not computed) */
+};
 
 /* Arithmetic of the MFMA contractions (Linear / Conv1d / LSTM-step GEMMs and the weight-gradient GEMM) launched by the CALLING THREAD:
  *   FCL_GEMM_F32  (default) fp32-equivalent: both operands split into bf16 hi + lo, three MFMAs per product (or exact fp32 MFMAs under FCL_PRECISION=0);
@@ -47,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 200
+#define FCL_ABI_VERSION 300
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -206,6 +214,8 @@ typedef struct {
     float* save_c_new;       /* optional: raw new cell (before zoneout) [M, U] */
     float* save_c_old;       /* optional: incoming cell / hidden state [M, U] */
     float* save_h_old;
+    const int32_t* m_dev;    /* optional DEVICE word: rows live in this step; the kernel processes min(M, *m_dev) rows (M then bounds the grid).
+                              * Lets a decoder loop whose durations were computed on the device run without a host round trip (fcl_decoder_io_t.live_rows) */
 } fcl_lstm_step_t;
 
 int fcl_lstm_step_fwd(const fcl_lstm_step_t* args, fcl_stream_t stream);
@@ -247,7 +257,8 @@ typedef struct {
     int lmax;                   /* = dur[0] */
     const float* att_c;         /* [N, C]: hs + p_embs + e_embs, compacted + sorted rows */
     const int32_t* dur;         /* [N] device, > 0 */
-    const int32_t* live_rows_host; /* [Lmax] HOST: rows with dur > t (non-increasing) */
+    const int32_t* live_rows_host; /* [Lmax] HOST: rows with dur > t (non-increasing).  Exact when live_rows is NULL; otherwise an UPPER BOUND per step,
+                                    * used for grid sizes and kernel selection only (never for correctness: see live_rows / status) */
     const int32_t* frame_off;   /* [N] device: output frame index of (row, t = 0) */
     const float* teacher_ys;    /* NULL = free running; else [N, Lmax, odim] teacher-forced inputs */
     int dropout_mode;           /* FCL_DROP_* for the prenet */
@@ -263,10 +274,54 @@ typedef struct {
     size_t workspace_bytes;
     const uint16_t* att_c_p;    /* optional P32 planes of att_c (C/32 lines per row; fcl_gather_rows_fwd writes them); att_c may then be NULL */
     uint16_t* before_p;         /* optional out: P32 planes of `before` (ceil(odim/32) lines per row), the postnet's pre-split operand */
+    const int32_t* live_rows;   /* optional [Lmax + 1] DEVICE: rows with dur > t as fcl_row_maps_build wrote them (entry Lmax and beyond: 0).  With it the
+                                 * loop needs nothing from the host about the durations: every step kernel processes min(live_rows_host[t], live_rows[t])
+                                 * rows, `lmax` is the number of steps LAUNCHED (>= the true maximum, else FCL_STATUS_LMAX_CAP was raised by the map
+                                 * builder), and a step with more live rows than its bound raises FCL_STATUS_ROWS_CAP in `status`.  NULL: host counts are exact */
+    uint32_t* status;           /* device status word (FCL_STATUS_*); required with live_rows */
 } fcl_decoder_io_t;
 
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n);
 int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, fcl_stream_t stream);
+
+/* ---- H10 on the device: the integer row / frame maps of a batch from durations that live in HBM (predicted by fcl_duration_round_fwd, or
+ *      forced and uploaded), with no host round trip.  Replaces the reference's host bookkeeping — `ds_nonzeros` filter + assert
+ *      (decoder_sa_kd.py:736-739), the per-phoneme position / trim / concat loops (..._kd_student.py:845-851, decoder_sa_kd.py:781-791) — and this
+ *      build's own numpy version (engine.build_row_maps), to which it is bit-identical (tests/test_gpu_rowmaps.py).
+ *      Rows are the non-padded (utterance, phoneme) pairs in row-major order (N = sum of phoneme counts, known to the host), or the whole padded
+ *      [B, t_max] layout (row_src == NULL).
+ *        dur_sorted[r], src_rows[r], frame_off[r] : rows STABLY sorted by duration descending; padded row index b*T + t; first output frame
+ *                                                   (exclusive cumsum of the durations in compact order = utterance base + offset inside it)
+ *        live_rows[t], t = 0 .. lmax_cap          : rows with duration > t
+ *        utt_frame0[b], b = 0 .. B                : first frame of utterance b; [B] = total frames
+ *        frame_lo / frame_hi [frames_cap]         : utterance frame range of every frame row (0, 0 beyond the total): the postnet's segment bounds
+ *        totals[0] = total frames, totals[1] = max duration, totals[2] = zero-duration rows
+ *      Violations are reported in *status (FCL_STATUS_ZERO_DURATION / LMAX_CAP / FRAMES_CAP) and live_rows is then zeroed, so a decoder loop
+ *      driven by these maps does nothing instead of writing out of bounds.  Two launches, O(N) work per thread (N <= ~1e5). */
+typedef struct {
+    int b, n;                   /* utterances; rows of the row universe (see row_src) */
+    int lmax_cap, frames_cap;
+    int t_max;                  /* with utt_row0 == NULL: utterance b owns rows [b * t_max, (b + 1) * t_max) */
+    const int32_t* row_src;     /* [N] device: padded row index b*T + t of compact row i (a function of the phoneme counts alone), or NULL: the row
+                                 * universe IS the padded [B, t_max] layout (n = B * t_max); padding rows carry duration 0, sort behind every real
+                                 * row and add nothing to the prefix sums, so the real rows get exactly the maps of the compact form -- this is the
+                                 * form whose every size is a capacity, i.e. the one a captured hipGraph can replay for any batch that fits */
+    const int32_t* utt_row0;    /* [B + 1] device: row range of every utterance, or NULL (t_max) */
+    const uint8_t* pad;         /* optional [N]: 1 = padding row (a duration of 0 there is not an error) */
+    const int64_t* dur_i64;     /* durations as int64 (fcl_duration_round_fwd's output), row i at dur[row_src ? row_src[i] : i]; or NULL */
+    const int32_t* dur_i32;     /* durations as int32 per ROW OF THE UNIVERSE (forced durations); exactly one of the two is set */
+    int32_t* src_rows;          /* [N] */
+    int32_t* dur_sorted;        /* [N] */
+    int32_t* frame_off;         /* [N] */
+    int32_t* order;             /* optional [N]: compact index of sorted row r (mask re-ordering, tests) */
+    int32_t* live_rows;         /* [lmax_cap + 1] */
+    int32_t* utt_frame0;        /* [B + 1] */
+    int32_t* frame_lo;          /* [frames_cap] */
+    int32_t* frame_hi;          /* [frames_cap] */
+    int32_t* totals;            /* [4] */
+    uint32_t* status;           /* device status word, OR-ed */
+} fcl_row_maps_t;
+int fcl_row_maps_build(const fcl_row_maps_t* maps, fcl_stream_t stream);
 
 /* ---- H12: masked L1 / MSE loss sums (Tacotron2Loss ..._sa.py:26-82, Knowledge_loss ..._kd_student.py:134-179,
  *      DurationPredictorLoss) ------------------------------------------------------------------------ */

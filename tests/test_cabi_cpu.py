@@ -122,3 +122,41 @@ def test_round2_entry_points_validate_arguments_without_a_gpu(lib):
     a.kp, a.ld_pt, a.m = 128, 1, 256 * 40
     assert lib.fcl_pwg_layer_fwd(C.byref(a), None) == -2 and b"ld_pt" in lib.fcl_last_error()  # 40 frames + 16 > 32 columns
     assert lib.fcl_debug_ptr() is None
+
+
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """The ctypes mirrors in _lib.py are laid out exactly like the structs of include/fcl_hip.h (sizeof and the offset of every mirrored field's
+    last member): a C program that includes the header prints them, gcc compiles it here."""
+    from fcl_taco2_amd import _lib
+
+    pairs = [("fcl_decoder_weights_t", _lib.DecoderWeights), ("fcl_decoder_io_t", _lib.DecoderIO), ("fcl_gemm_term_t", _lib.GemmTerm),
+             ("fcl_lstm_step_t", _lib.LstmStep), ("fcl_decoder_train_t", _lib.DecoderTrain), ("fcl_decoder_bptt_t", _lib.DecoderBptt),
+             ("fcl_bilstm_train_t", _lib.BilstmTrain), ("fcl_bilstm_bptt_t", _lib.BilstmBptt), ("fcl_derive_t", _lib.Derive),
+             ("fcl_pwg_layer_t", _lib.PwgLayer), ("fcl_prof_entry_t", _lib.ProfEntry), ("fcl_row_maps_t", _lib.RowMaps)]
+    body = ['#include <stdio.h>', '#include <stddef.h>', '#include "fcl_hip.h"', "int main(void) {"]
+    for cname, cls in pairs:
+        last = cls._fields_[-1][0]
+        body.append('  printf("%s %%zu %%zu\\n", sizeof(%s), offsetof(%s, %s));' % (cname, cname, cname, last))
+    body += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(body))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict((ln.split()[0], tuple(int(v) for v in ln.split()[1:])) for ln in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in pairs:
+        last = cls._fields_[-1][0]
+        assert out[cname] == (C.sizeof(cls), getattr(cls, last).offset), (cname, out[cname], C.sizeof(cls), getattr(cls, last).offset)
+
+
+def test_row_maps_argument_validation(lib):
+    from fcl_taco2_amd import _lib
+
+    a = _lib.RowMaps()
+    assert lib.fcl_row_maps_build(None, None) == -1
+    assert lib.fcl_row_maps_build(C.byref(a), None) == -2  # sizes
+    a.b, a.n, a.lmax_cap, a.frames_cap = 2, 10, 8, 64
+    assert lib.fcl_row_maps_build(C.byref(a), None) == -1 and b"exactly one" in lib.fcl_last_error()
+    a.dur_i32 = 128
+    assert lib.fcl_row_maps_build(C.byref(a), None) == -2 and b"padded" in lib.fcl_last_error()  # no utt_row0 and n != b * t_max
+    a.t_max = 5
+    assert lib.fcl_row_maps_build(C.byref(a), None) == -1 and b"null pointer" in lib.fcl_last_error()

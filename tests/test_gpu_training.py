@@ -259,37 +259,48 @@ def test_teacher_train_steps_track_torch_adam():
 def test_autograd_path_with_an_external_optimizer_sees_every_update():
     """Round-2 ADVICE (high): on the documented path `loss = model(**batch); loss.backward(); optimizer.step()` the optimizer writes through the
     module's parameter views, which the engine's cache stamp cannot see; the cached operand forms of the weights (packed conv taps, transposes,
-    LSTM column blocks, P32 planes) must not survive such a step.  Two autograd-path steps with torch's SGD (a large step, so stale forms would show
-    at O(1)) against two native forward_backward passes of a second engine with the same seed and the same updates applied to its flat buffer."""
+    LSTM column blocks, P32 planes) must not survive such a step.  An autograd-path step with torch's SGD, then a second forward / backward, against
+    two native passes of a second engine (same seed, same update applied to its flat buffer).  These closed-form tiny weights are a stiff system
+    (loss 12.4 -> 16.9 after one step of 2e-3), so only the FIRST post-update pass is compared tightly; the negative control — the same sequence with
+    the invalidation disabled — must miss by orders of magnitude more, which is what makes the comparison meaningful."""
     from fcl_taco2_amd.training import TrainEngine
 
     batch = _batch()
     kw = {k: v for k, v in batch.items() if not k.startswith("_")}
-    lr = 0.05
-    ma = _model("teacher", TINY_T7).train()
-    ea = ma.train_engine(seed=3)
-    opt = torch.optim.SGD(ma.parameters(), lr=lr)
-    la, ga = [], []
-    for _ in range(3):
-        opt.zero_grad()
-        loss = ma(**kw)
-        loss.backward()
-        ga.append(torch.cat([p.grad.reshape(-1) for _, p in sorted(ma.named_parameters())]).clone())
-        opt.step()
-        la.append(float(loss))
+    lr = 2e-3
+
+    def autograd_two_passes(disable_invalidation):
+        m = _model("teacher", TINY_T7).train()
+        eng = m.train_engine(seed=3)
+        if disable_invalidation:
+            eng.invalidate_planes = lambda: None
+        opt = torch.optim.SGD(m.parameters(), lr=lr)
+        losses, grads = [], []
+        for _ in range(2):
+            opt.zero_grad()
+            loss = m(**kw)
+            loss.backward()
+            grads.append(torch.cat([p.grad.reshape(-1) for _, p in sorted(m.named_parameters())]).double().cpu())
+            opt.step()
+            losses.append(float(loss))
+        assert eng is m.train_engine()
+        return losses, grads
+
+    la, ga = autograd_two_passes(False)
     eb = TrainEngine(_model("teacher", TINY_T7), seed=3)
     lb, gb = [], []
-    for _ in range(3):
+    for _ in range(2):
         eb.zero_grad()
         lb.append(eb.forward_backward(batch, mode="train", reduce=False)["loss"])
-        gb.append(torch.cat([eb.G[k].reshape(-1) for k in sorted(eb.G)]).clone())
+        gb.append(torch.cat([eb.G[k].reshape(-1) for k in sorted(eb.G)]).double().cpu())
         eb.pflat.add_(eb.gflat, alpha=-lr)  # bumps pflat's version counter: the native engine's stamp sees it
-    assert la[0] == pytest.approx(lb[0], rel=1e-6)
-    assert abs(la[1] - la[0]) > 1e-3 * abs(la[0])  # the step really moved the loss, so a stale cache could not hide
-    for i in (1, 2):
-        assert la[i] == pytest.approx(lb[i], rel=2e-4), (i, la, lb)
-        assert max_abs(ga[i].cpu(), gb[i].cpu()) < 1e-3 * max(1.0, float(gb[i].abs().max())), i
-    assert ea is ma.train_engine()
+    cos = lambda a, b: float((a * b).sum() / a.norm() / b.norm())
+    assert la[0] == pytest.approx(lb[0], rel=1e-6) and cos(ga[0], gb[0]) > 1.0 - 1e-9
+    assert abs(la[1] - la[0]) > 1e-2 * abs(la[0]), la  # the step really moved the loss, so a stale cache cannot hide
+    assert la[1] == pytest.approx(lb[1], rel=1e-4), (la, lb)  # measured 1.1e-5 (p.add_ vs the flat add_ round differently: 6e-8 on the weights)
+    assert cos(ga[1], gb[1]) > 1.0 - 1e-6, cos(ga[1], gb[1])  # measured 1 - 3e-9
+    ls, gs = autograd_two_passes(True)  # negative control: stale operand forms
+    assert abs(ls[1] - lb[1]) > 100 * abs(la[1] - lb[1]) and 1.0 - cos(gs[1], gb[1]) > 100 * (1.0 - cos(ga[1], gb[1]) + 1e-12), (ls, lb)
 
 
 def test_accum_grad_two_micro_batches_equal_one_scaled_sum():

@@ -66,21 +66,45 @@ def random_masks(hp, batch, seed):
     return m
 
 
-def _grad_sd(model):
-    return {k: (v.detach().cpu().clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.detach().cpu().clone())
-            for k, v in model.state_dict().items()}
+def _grad_sd(model, dtype=torch.float64):
+    """The model's state dict as oracle leaves, in float64 by default: the comparison is against the exact gradient, not another fp32 rounding."""
+    return {k: (v.detach().cpu().to(dtype).clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else
+                (v.detach().cpu().to(dtype) if v.dtype.is_floating_point else v.detach().cpu().clone())) for k, v in model.state_dict().items()}
 
 
-def _compare_grads(eng, sd, tol):
+def _cpu64(batch):
+    return {k: ((v.cpu().double() if v.dtype.is_floating_point else v.cpu()) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def _tolerances():
+    """(max-abs relative to max(1, max|ref|), relative L2) per gradient tensor, against the oracle run in FLOAT64.
+    What bounds the agreement of two correct implementations here is not rounding but the ReLU kink: an activation whose pre-activation is within
+    the forward's rounding error of zero gets a different 0/1 derivative, and ONE such flip among the 73 k activations of a 2-utterance predictor
+    layer moves that layer's weight gradient by 2.5e-4 in relative L2 (measured, tools/diag_pred.py: the flipped element had |pre| = 4.4e-7, every
+    building block by itself — conv / LayerNorm / BatchNorm forward and backward, dW — agrees with float64 to 1e-6, tools/diag_ops.py).  At the
+    batch sizes of these tests a ReLU layer has 0.6 - 1.2 M activations: exact fp32 MFMAs (|error| <= 4e-6 on a pre-activation) flip a handful
+    per layer, bf16x3 operands (2^-16 per product) ten times as many.  Measured worst tensors (FCL-taco2-T, 16 utterances, reference-initialised
+    weights, tools/diag_fullsize.py): relative L2 1.9e-3 exact / 8.3e-3 bf16x3 in the train form, 2.5e-3 bf16x3 in the eval form; torch's own fp32
+    CPU kernels sit at 1e-6 on the same tensors (they round 10x tighter, so they flip next to nothing).  A wrong term in a backward formula shows
+    up as >= several per cent (and at tiny dims, where nothing flips, the same engine is at 1e-6: tools/diag_tiny.py)."""
+    from fcl_taco2_amd import ops
+
+    return (3e-2, 3e-2) if ops.planes_enabled() else (1e-2, 1e-2)
+
+
+def _compare_grads(eng, sd):
+    tol_max, tol_l2 = _tolerances()
     og = {k: v.grad for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad}
     assert set(og) == set(eng.G)
-    bad, worst = {}, 0.0
+    bad, worst = {}, (0.0, 0.0)
     for k, ref in og.items():
-        ref = torch.zeros_like(eng.P[k]).cpu() if ref is None else ref
-        err = max_abs(eng.G[k].cpu(), ref) / max(1.0, float(ref.abs().max()))
-        worst = max(worst, err)
-        if err > tol:
-            bad[k] = err
+        ref = (torch.zeros_like(eng.P[k]).cpu() if ref is None else ref).double()
+        diff = eng.G[k].cpu().double() - ref
+        e_max = float(diff.abs().max()) / max(1.0, float(ref.abs().max()))
+        e_l2 = float(diff.norm()) / max(float(ref.norm()), 1e-3 * float(ref.numel()) ** 0.5)  # floor: an RMS of 1e-3 (tensors whose gradient is ~0)
+        worst = (max(worst[0], e_max), max(worst[1], e_l2))
+        if e_max > tol_max or e_l2 > tol_l2:
+            bad[k] = (e_max, e_l2)
     assert not bad, bad
     return worst
 
@@ -105,9 +129,13 @@ def test_teacher_step_at_configs3_size_vs_oracle_autograd(form):
     from fcl_taco2_amd.training import TrainEngine
 
     _threads()
-    T = HP.teacher_hparams()
+    # eval form: the oracle's default is "every dropout off", but the Prenet's dropout is on in BOTH modes (decoder_sa.py:156-158) and the engine
+    # draws it on the device -- the eval-form comparison therefore runs the model with dropout_rate 0 (as G5 / G8 do); the train form injects every draw.
+    # Weights: the reference's own initialisation (what training starts from); the goldens' closed-form generator makes a net whose train-mode
+    # BatchNorm / eps-1e-12 LayerNorm amplify rounding 1000x (even torch's fp32 CPU kernels are then 2e-3 from float64), which would hide real errors
+    T = HP.teacher_hparams() if form == "train" else HP.teacher_hparams(dropout_rate=0.0)
     batch = _batch(16, 41, T.idim)
-    model = SYN.build_model("teacher", T, None, DEV)
+    model = SYN.build_model("teacher", T, None, DEV, weights="init", seed=1)
     sd = _grad_sd(model)
     bufs0 = {k: v.clone() for k, v in sd.items() if "running" in k}
     masks = random_masks(T, batch, 7) if form == "train" else None
@@ -117,12 +145,12 @@ def test_teacher_step_at_configs3_size_vs_oracle_autograd(form):
     torch.cuda.synchronize()
     prof = _lib.prof_collect()
     _lib.prof_enable(False)
-    orep = O.model_forward(sd, T, _cpu(batch), "teacher", bn_train=form == "train", masks=masks)
+    orep = O.model_forward(sd, T, _cpu64(batch), "teacher", bn_train=form == "train", masks=masks)
     orep["loss"].backward()
     for k in LOSS_KEYS:
-        assert abs(rep[k] - float(orep[k])) < 5e-4 * max(1.0, abs(float(orep[k]))), (k, rep[k], float(orep[k]))
-    worst = _compare_grads(eng, sd, 1e-3)
-    print("configs[3] %s form: worst relative gradient error %.2e over %d tensors" % (form, worst, len(eng.G)))
+        assert abs(rep[k] - float(orep[k])) < 1e-4 * max(1.0, abs(float(orep[k]))), (k, rep[k], float(orep[k]))
+    worst = _compare_grads(eng, sd)
+    print("configs[3] %s form: worst gradient error max-abs %.2e / L2 %.2e over %d tensors" % (form, worst[0], worst[1], len(eng.G)))
     from fcl_taco2_amd import ops
 
     if ops.planes_enabled():
@@ -148,14 +176,14 @@ def test_kd_step_at_configs2_size_vs_oracle_autograd(form):
     from fcl_taco2_amd.training import TrainEngine
 
     _threads()
-    S, T = HP.student_hparams(), HP.teacher_hparams()
-    batch = _batch(32, 43, S.idim)
-    b_cpu = _cpu(batch)
     train = form == "train"
+    S, T = (HP.student_hparams(), HP.teacher_hparams()) if train else (HP.student_hparams(dropout_rate=0.0), HP.teacher_hparams(dropout_rate=0.0))
+    batch = _batch(32, 43, S.idim)
+    b_cpu = _cpu64(batch)
     tm = random_masks(T, batch, 11) if train else None
     sm = random_masks(S, batch, 13) if train else None
-    teacher = SYN.build_model("kd_teacher", T, None, DEV)
-    tsd = {k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}
+    teacher = SYN.build_model("kd_teacher", T, None, DEV, weights="init", seed=2)
+    tsd = {k: (v.detach().cpu().double() if v.dtype.is_floating_point else v.detach().cpu().clone()) for k, v in teacher.state_dict().items()}
     teng = TrainEngine(teacher)
     know = teng.knowledge(batch, mode=form, masks=tm)
     with torch.no_grad():
@@ -163,7 +191,7 @@ def test_kd_step_at_configs2_size_vs_oracle_autograd(form):
     flat = lambda kn: [kn[0], kn[1]] + list(kn[2]) + list(kn[3]) + list(kn[4])
     for i, (a, b) in enumerate(zip(flat(know), flat(oknow))):
         assert max_abs(a.cpu(), b) < 1e-3 * max(1.0, float(b.abs().max())), ("knowledge item", i)
-    student = SYN.build_model("student", S, T, DEV)
+    student = SYN.build_model("student", S, T, DEV, weights="init", seed=3)
     sd = _grad_sd(student)
     eng = TrainEngine(student)
     _lib.prof_enable(True)
@@ -174,9 +202,9 @@ def test_kd_step_at_configs2_size_vs_oracle_autograd(form):
     orep = O.model_forward(sd, S, b_cpu, "student", T, True, oknow, bn_train=train, masks=sm)
     orep["loss"].backward()
     for k in KD_KEYS:
-        assert abs(rep[k] - float(orep[k])) < 5e-4 * max(1.0, abs(float(orep[k]))), (k, rep[k], float(orep[k]))
-    worst = _compare_grads(eng, sd, 1e-3)
-    print("configs[2] %s form: worst relative gradient error %.2e over %d tensors" % (form, worst, len(eng.G)))
+        assert abs(rep[k] - float(orep[k])) < 1e-4 * max(1.0, abs(float(orep[k]))), (k, rep[k], float(orep[k]))
+    worst = _compare_grads(eng, sd)
+    print("configs[2] %s form: worst gradient error max-abs %.2e / L2 %.2e over %d tensors" % (form, worst[0], worst[1], len(eng.G)))
     if ops.planes_enabled():
         _on_path(prof, ("plstm_kernel<", ",-1," if train else ",0,"), ("pgemm_kernel<", "/dW"))
     _on_path(prof, ("bilstm_persistent_kernel/train",), ("bilstm_bptt_persistent_kernel",))
@@ -190,10 +218,10 @@ def test_teacher_update_at_configs3_size_tracks_torch_adam():
     from fcl_taco2_amd.training import TrainEngine
 
     _threads()
-    T = HP.teacher_hparams()
+    T = HP.teacher_hparams(dropout_rate=0.0)  # eval form (see above)
     batch = _batch(16, 47, T.idim)
-    model = SYN.build_model("teacher", T, None, DEV)
-    sd = _grad_sd(model)
+    model = SYN.build_model("teacher", T, None, DEV, weights="init", seed=4)
+    sd = _grad_sd(model, torch.float32)  # torch.optim.Adam's own arithmetic
     params = [v for v in sd.values() if v.dtype.is_floating_point and v.requires_grad]
     eng = TrainEngine(model, lr=1e-3, eps=1e-6, grad_clip=1.0)
     w0 = eng.pflat.clone()
@@ -209,4 +237,5 @@ def test_teacher_update_at_configs3_size_tracks_torch_adam():
     assert 0 < float((eng.pflat - w0).abs().max()) <= 1e-3 * (1 + 1e-4)
     diffs = [(eng.P[k].cpu() - v.detach()).abs() for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad]
     assert max(float(d.max()) for d in diffs) <= 2e-3 * (1 + 1e-4)
-    assert sum(float(d.sum()) for d in diffs) / sum(d.numel() for d in diffs) < 2e-5
+    # coordinates whose gradient is smaller than the two implementations' difference take opposite sign steps (2 lr apart): at most 5 % of them
+    assert sum(float(d.sum()) for d in diffs) / sum(d.numel() for d in diffs) < 1e-4
