@@ -253,7 +253,16 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
 
 // --------------------------------------------------------------------------------------------------------------------------------------
 // The GEMM epilogue shared by pgemm_kernel and pconv_kernel (compute waves only; BM x BN tile at (m0, n0), accumulators in the MFMA layout).
-template <int WN, int TM, int TN, int BM, int BN, int CTHREADS, int LDS_BYTES>
+// Row permutation of a 16-row MFMA tile used by the Conv1d stencil (pconv_kernel): MFMA row i of the fragment holds tile row rho16(i).
+// ds_read_b128 is serviced in four fixed 16-lane groups, each = eight rows read at k-piece a plus eight rows read at piece a ^ 1 ({0-3, 12-15} and
+// {4-11} of the 16 rows).  With the line swizzle piece ^ ((row >> 1) & 7) two such rows collide iff they have the same parity and sit in the same
+// aligned group of four rows -- never for a tile that starts at a multiple of 4 rows (every GEMM), but the stencil reads the SAME tile at row offsets
+// -pad .. +pad: 2 of 16 lanes collide for odd offsets, 4 for offsets = 2 (mod 4) (r2 profile: 27 % / 19 % of the LDS cycles of the two
+// instantiations).  rho16 hands the even rows to one piece-set and the odd rows to the other, so two rows of different sets always differ in
+// parity (address bit 7 = other half of the 64 banks) at EVERY offset: conflict-free by construction (all 16 alignments enumerated offline).
+__device__ __forceinline__ int rho16(int i) { return i < 4 ? 2 * i : (i < 12 ? 2 * (i - 4) + 1 : 2 * (i - 8)); }
+
+template <int WN, int TM, int TN, int BM, int BN, int CTHREADS, int LDS_BYTES, bool RP = false>
 __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[TM][TN], u8* smem, int m0, int n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -276,7 +285,7 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
             const float r1w = (a.rank1_w && nin) ? a.rank1_w[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + rm;
+                const int rm = (wm * TM + tm) * 16 + (RP ? rho16(rq * 4 + r) : rq * 4 + r), m = m0 + rm;
                 float v = 0.f;
                 if (nin && m < a.M) {
                     v = acc[tm][tn][r] + bn;
@@ -578,10 +587,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
     // -------------------------------------------------------------------------------------------------------------------- compute waves
     const int wm = wave / WN, wn = wave % WN;
     const int r16 = lane & 15, kq = lane >> 4, sw = r16 >> 1;
+    const int ar16 = rho16(r16);  // the A-tile row this lane's MFMA row holds (see rho16: conflict-free fragment reads at every tap offset)
     int lo_off[TM], hi_off[TM];  // segment of this lane's output rows, relative to the row: tap shift sh contributes iff lo_off <= sh < hi_off
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-        const int m = m0 + (wm * TM + tm) * 16 + r16;
+        const int m = m0 + (wm * TM + tm) * 16 + ar16;
         lo_off[tm] = hi_off[tm] = 0;
         if (m < a.M) {
             lo_off[tm] = a.seg_lo[m] - m;
@@ -604,7 +614,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
         s16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
-            const int lr = (wm * TM + tm) * 16 + r16 + G::HALO + sh;
+            const int lr = (wm * TM + tm) * 16 + ar16 + G::HALO + sh;
             const int swz = (lr >> 1) & 7;
             const bool ok = sh >= lo_off[tm] && sh < hi_off[tm];
             ah[tm] = *reinterpret_cast<const s16x8*>(abase + lr * 128 + ((kq ^ swz) << 4));
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
         }
         if (++j == k) { j = 0; ++c; }
     }
-    pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES>(a, acc, smem, m0, n0);
+    pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES, true>(a, acc, smem, m0, n0);
 }
 
 template <int WM, int WN, int TM, int TN, int NL>

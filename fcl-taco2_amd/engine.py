@@ -96,9 +96,49 @@ def use_planes(plan):
 
 
 class PreparedBatch(object):
-    """Everything `run` needs, resident in HBM: padded ids, segment bounds, and (forced durations) row maps."""
+    """Everything `run` needs, resident in HBM: padded ids, segment bounds, and (forced durations) row maps -- built on the host (`maps`), or
+    left to the device (`dur_pad`: the forced durations in the padded [B, T] layout; run() then needs `caps`)."""
     __slots__ = ("B", "T", "lens", "ids", "seg_lo", "seg_hi", "pad", "lens_dev", "f0e", "maps", "src_rows", "dur", "frame_off",
-                 "frame_lo", "frame_hi")
+                 "frame_lo", "frame_hi", "dur_pad")
+
+
+class Caps(object):
+    """Capacities of a pass whose row maps are built on the DEVICE (ops.row_maps_build): everything the host would otherwise have to know about the
+    durations.  lmax: decoder steps to launch; frames: rows of the frame-major buffers; bounds: int32 [lmax] upper bounds of the live rows per
+    step (grid sizes and kernel selection only).  None of them is trusted: a batch that exceeds one raises FCL_STATUS_* in the device status word
+    (read it with DeviceFrames.resolve() / ops.check_status) and decodes nothing."""
+    __slots__ = ("lmax", "frames", "bounds")
+
+    def __init__(self, lmax, frames, bounds):
+        self.lmax, self.frames = int(lmax), int(frames)
+        self.bounds = np.ascontiguousarray(np.asarray(bounds, dtype=np.int32))
+        assert self.bounds.shape == (self.lmax,) and self.lmax > 0 and self.frames > 0
+
+    @staticmethod
+    def from_maps(maps):
+        """Exact capacities of a batch whose host maps are known (calibration of a graph that replays THAT batch)."""
+        return Caps(maps.lmax, maps.n_frames, maps.live_rows)
+
+    @staticmethod
+    def generous(n_rows, lmax, frames):
+        """Capacities that hold for ANY durations up to lmax per phoneme and `frames` in total: every step may keep every row."""
+        return Caps(lmax, frames, np.full(lmax, n_rows, dtype=np.int32))
+
+
+class DeviceFrames(object):
+    """Frame bookkeeping of a device-driven pass: utterance frame starts [B + 1] and totals live in HBM until somebody needs them on the host."""
+
+    def __init__(self, maps, caps, device):
+        self.utt_frame0, self.totals, self.caps, self.device = maps["utt_frame0"], maps["totals"], caps, device
+        self._host = None
+
+    def resolve(self):
+        """Synchronising read: raises FclError when the pass violated a capacity or met a zero duration; returns the per-utterance frame counts."""
+        if self._host is None:
+            ops.check_status(self.device)
+            f0 = self.utt_frame0.cpu().numpy()
+            self._host = [int(v) for v in (f0[1:] - f0[:-1])]
+        return self._host
 
 
 _RING = None
@@ -130,11 +170,12 @@ def _upload_maps(holder, maps, dev):
         setattr(holder, k, up[o : o + n])
 
 
-def prepare(plan, xs, durs=None, f0=None, energy=None):
+def prepare(plan, xs, durs=None, f0=None, energy=None, device_maps=False):
     """Input hand-over: pad + upload phoneme ids, build the integer segment bounds, and — when durations are
     forced — the row maps.  This is the host batch layout step (the reference's loader/converter side).  Every integer array of the batch
     travels in ONE packed int32 block (plus the ids and the pad mask) through fixed pinned staging buffers, non-blocking: three copies per
-    batch instead of ten pageable ones."""
+    batch instead of ten pageable ones.  device_maps: forced durations are only uploaded (padded [B, T] int32); the maps are built by
+    ops.row_maps_build inside run(), which then needs `caps`."""
     dev = plan.device
     p = PreparedBatch()
     p.B = len(xs)
@@ -147,8 +188,15 @@ def prepare(plan, xs, durs=None, f0=None, energy=None):
     rows = np.arange(p.B * T, dtype=np.int64)
     b_of = rows // T
     blocks = {"seg_lo": (b_of * T).astype(np.int32), "seg_hi": (b_of * T + lens_np[b_of]).astype(np.int32), "lens_dev": lens_np.astype(np.int32)}
-    p.maps = None
-    if durs is not None:
+    p.maps, p.dur_pad = None, None
+    if durs is not None and device_maps:
+        dpad = np.zeros((p.B, T), dtype=np.int32)
+        for b in range(p.B):
+            d = np.asarray(durs[b]).reshape(-1)
+            assert d.shape[0] == p.lens[b], "duration count != phoneme count"
+            dpad[b, : p.lens[b]] = d
+        blocks["dur_pad"] = dpad.reshape(-1)
+    elif durs is not None:
         p.maps = m = build_row_maps(p.lens, durs, T)
         blocks.update(src_rows=m.src_rows, dur=m.dur_sorted, frame_off=m.frame_off_sorted, frame_lo=m.frame_lo, frame_hi=m.frame_hi)
     layout, off = {}, 0
@@ -189,9 +237,22 @@ def encode(plan, prep, bilstm_algo=0, planes=False):
     return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo)
 
 
-def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_algo=0, return_intermediates=False, seed_dev=None):
+class _DevMaps(object):
+    """The device-built maps of a pass behind the attribute names run() uses for host-built ones."""
+
+    def __init__(self, dm, caps):
+        self.src_rows, self.dur, self.frame_off, self.frame_lo, self.frame_hi = dm["src_rows"], dm["dur"], dm["frame_off"], dm["frame_lo"], dm["frame_hi"]
+        self.live_dev, self.live_rows, self.n_frames, self.lmax = dm["live_rows"], caps.bounds, caps.frames, caps.lmax
+        self.order = None
+
+
+def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_algo=0, return_intermediates=False, seed_dev=None, caps=None):
     """One pass of the hot path over a prepared batch.  Returns the packed mel [F, odim] (after postnet) and
-    the per-utterance frame counts; with forced durations nothing here touches the host."""
+    the per-utterance frame counts; with forced durations nothing here touches the host.
+    caps (engine.Caps): build the row maps on the DEVICE from the durations in HBM — predicted by this pass, or forced and uploaded by
+    prepare(device_maps=True) — so that no step waits for the host: the mel buffer then has caps.frames rows (the first total are valid) and
+    the frame counts come back as a DeviceFrames to resolve() when the caller synchronises anyway.  Without caps a pass with predicted durations
+    makes one host round trip (durations down, maps up)."""
     hp, dev = plan.hp, plan.device
     with torch.cuda.device(dev):
         planes = use_planes(plan)
@@ -204,14 +265,26 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
             predictor = lambda pp, pad: _predictor_scalar(pp, hs, prep.seg_lo, prep.seg_hi, pad)
         inter = {"hs": hs, "T": prep.T} if return_intermediates else None
         rm = prep  # holder of the row maps
-        if prep.maps is None:  # predicted durations: maps depend on this pass's predictor output, never cached
-            d_log = predictor(plan.duration, None)
-            d_int = ops.duration_round(d_log, False, 1.0, prep.pad)
-            d_host = d_int.cpu().numpy().reshape(prep.B, prep.T)  # the one host sync of the predicted-duration path
-            rm = PreparedBatch()
-            _upload_maps(rm, build_row_maps(prep.lens, [d_host[b, : prep.lens[b]] for b in range(prep.B)], prep.T), dev)
-            if inter is not None:
-                inter["d_log"], inter["d_int"] = d_log, d_int
+        frames_info = None
+        if prep.maps is None:  # maps depend on durations that live in HBM: predicted by this pass, or forced and uploaded
+            d_int = None
+            if prep.dur_pad is None:
+                d_log = predictor(plan.duration, None)
+                d_int = ops.duration_round(d_log, False, 1.0, prep.pad)
+                if inter is not None:
+                    inter["d_log"], inter["d_int"] = d_log, d_int
+            if caps is not None:  # device-built maps over the padded [B, T] row universe: no host round trip
+                dm = ops.row_maps_build(prep.B * prep.T, prep.B, caps.lmax, caps.frames, dur_i64=d_int, dur_i32=prep.dur_pad, t_max=prep.T, pad=prep.pad)
+                rm = PreparedBatch()
+                rm.maps = _DevMaps(dm, caps)
+                rm.src_rows, rm.dur, rm.frame_off, rm.frame_lo, rm.frame_hi = dm["src_rows"], dm["dur"], dm["frame_off"], dm["frame_lo"], dm["frame_hi"]
+                frames_info = DeviceFrames(dm, caps, dev)
+            else:
+                if d_int is None:
+                    raise ValueError("prepare(device_maps=True) leaves the row maps to the device: run() needs caps")
+                d_host = d_int.cpu().numpy().reshape(prep.B, prep.T)  # the one host sync of the predicted-duration path
+                rm = PreparedBatch()
+                _upload_maps(rm, build_row_maps(prep.lens, [d_host[b, : prep.lens[b]] for b in range(prep.B)], prep.T), dev)
         if prep.f0e is None:
             p = predictor(plan.pitch, prep.pad)
             e = predictor(plan.energy, prep.pad)
@@ -224,11 +297,14 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
         keep_dev = None
         if hp.dropout_rate <= 0.0:
             dropout_mode = ops.DROP_NONE
+        if dropout_mode == ops.DROP_MASK and maps.order is None:
+            raise ValueError("injected prenet masks are given in (utterance, phoneme) order: they need host-built row maps")
         if dropout_mode == ops.DROP_MASK:
             keep = np.ascontiguousarray(np.asarray(prenet_keep)[: maps.lmax][:, :, maps.order, :])  # to sorted row order
             keep_dev = torch.from_numpy(keep).to(dev)
         before = ops.decoder_loop(plan.decoder, att_c, rm.dur, maps.live_rows, rm.frame_off, maps.n_frames,
-                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed, seed_dev=seed_dev, att_c_p=att_c_p, want_before_p=planes)
+                                  dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed, seed_dev=seed_dev, att_c_p=att_c_p, want_before_p=planes,
+                                  live_rows_dev=getattr(maps, "live_dev", None))
         n_post = len(plan.postnet)
         if planes:
             before, xp = before
@@ -242,25 +318,28 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
                 last = i == n_post - 1
                 x = ops.conv1d(x, cv.wp, cv.bias, rm.frame_lo, rm.frame_hi, ops.ACT_NONE if last else ops.ACT_TANH,
                                residual=before if last else None)
+        utt_frames = frames_info if frames_info is not None else maps.utt_frames
         if inter is not None:
             inter.update(p_outs=p, e_outs=e, p_embs=p_emb, e_embs=e_emb, before=before, after=x, maps=maps)
-            return x, maps.utt_frames, inter
-        return x, maps.utt_frames
+            return x, utt_frames, inter
+        return x, utt_frames
 
 
 def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0,
-               bilstm_algo=0, return_intermediates=False):
+               bilstm_algo=0, return_intermediates=False, caps=None):
     """xs: list of 1-D int64 id arrays/tensors; durs: optional list of forced durations (else predicted).
     f0/energy: optional lists of [T] arrays replacing the predictors (inference(f0=..., energy=...)).
     prenet_keep: optional uint8 [Lmax, 2, N, P] in (utterance, phoneme) row order (FCL_DROP_MASK).
     Returns a list of mel tensors [L_b, odim] (views into one packed device buffer)."""
-    prep = prepare(plan, xs, durs, f0, energy)
-    out = run(plan, prep, dropout_mode, prenet_keep, seed, bilstm_algo, return_intermediates)
+    prep = prepare(plan, xs, durs, f0, energy, device_maps=caps is not None)
+    out = run(plan, prep, dropout_mode, prenet_keep, seed, bilstm_algo, return_intermediates, caps=caps)
     import os
 
     if bilstm_algo == 3 or os.environ.get("FCL_BILSTM_GROUP_INFER", "0") not in ("", "0"):
         ops.check_status(plan.device)  # the cooperating-workgroup BiLSTM (opt-in, single-stream only) reports a timeout here, never silently
     after, utt_frames = out[0], out[1]
+    if isinstance(utt_frames, DeviceFrames):
+        utt_frames = utt_frames.resolve()
     mels, s = [], 0
     for n in utt_frames:
         mels.append(after[s : s + n])
@@ -269,28 +348,44 @@ def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_
 
 
 class GraphRunner(object):
-    """One pass of `run` over a prepared (forced-duration) batch captured as a hipGraph (guide: capture
-    launch-bound inner loops in graphs).  Every buffer of the pass lives in the graph's private pool, so a
-    replay is one host call; the prenet-dropout seed is a device word the graph itself advances, so each
-    replay draws fresh masks.  Several runners on different streams keep several batches in flight."""
+    """One pass of `run` over a prepared batch captured as a hipGraph (guide: capture launch-bound inner loops in graphs).  Every buffer of the
+    pass lives in the graph's private pool, so a replay is one host call; the prenet-dropout seed is a device word the graph itself advances, so
+    each replay draws fresh masks.  Several runners on different streams keep several batches in flight.
+    Forced durations: the host-built maps of `prep` are baked in.  PREDICTED durations (prep built without durs): the graph contains the duration
+    predictor, the rounding and the device map builder, i.e. every replay recomputes the durations and the maps in HBM with no host round trip; the
+    capacities are calibrated once, eagerly, on this batch (the predictors are deterministic, so they are exact for every replay) and verified on
+    the device (a violated capacity raises in check())."""
 
-    def __init__(self, plan, prep, stream=None, dropout_mode=ops.DROP_RNG, seed=0):
-        if prep.maps is None:
-            raise ValueError("GraphRunner needs forced durations (predicted durations require a host round trip)")
+    def __init__(self, plan, prep, stream=None, dropout_mode=ops.DROP_RNG, seed=0, caps=None):
         self.plan, self.prep = plan, prep
         self.stream = stream if stream is not None else torch.cuda.Stream(device=plan.device)
         with torch.cuda.device(plan.device):
             self.seed_word = torch.zeros(1, dtype=torch.int32, device=plan.device)
+            self.caps = caps
             with torch.cuda.stream(self.stream):  # warm-up outside capture (lazy one-time setup in the library)
-                run(plan, prep, dropout_mode, seed=seed, seed_dev=self.seed_word)
+                if prep.maps is None and caps is None:  # calibration: one pass with the host round trip tells this batch's capacities
+                    _, _, inter = run(plan, prep, dropout_mode, seed=seed, seed_dev=self.seed_word, return_intermediates=True)
+                    self.caps = Caps.from_maps(inter["maps"])
+                    self.utt_frames = list(inter["maps"].utt_frames)
+                out = run(plan, prep, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=self.caps)
+                if isinstance(out[1], DeviceFrames):
+                    self.utt_frames = out[1].resolve()
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 ops.u32_add(self.seed_word, 1)
-                self.mel, self.utt_frames = run(plan, prep, dropout_mode, seed=seed, seed_dev=self.seed_word)
+                self.mel, frames = run(plan, prep, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=self.caps)
+            if isinstance(frames, DeviceFrames):
+                self.frames = frames  # device-resident frame starts of the LAST replay
+            else:
+                self.frames, self.utt_frames = None, frames
 
     def replay(self):
         """Enqueue one pass on this runner's stream; returns the static output tensor [F, odim]."""
         with torch.cuda.stream(self.stream):
             self.graph.replay()
         return self.mel
+
+    def check(self):
+        """Device-driven graphs: synchronising check of the status word (capacity violations, zero durations)."""
+        ops.check_status(self.plan.device)

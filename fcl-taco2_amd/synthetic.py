@@ -148,3 +148,14 @@ def build_model(role, hp, thp=None, device="cuda:0", share_proj=True, weights="c
         return m.to(device)
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in closed_form_state_dict(spec).items()})
     return m.to(device)
+
+
+def positive_duration_head(sd, mean_log=2.3, spread=0.35):
+    """A copy of a closed-form state dict whose duration predictor predicts usable durations: the closed-form head gives log-durations ~ N(0, 1),
+    i.e. mostly 0 frames ("random weights predict ~ 0 frames", and a predicted 0 is an error, D9).  Scaling the head's weight by
+    `spread` and setting its bias to `mean_log` gives log-durations ~ N(mean_log, spread): 4 .. 25 frames per phoneme, LJSpeech-like, never 0 --
+    so the predicted-duration path (predictor -> rounding -> device-built row maps -> decoder) can be exercised and timed with synthetic weights."""
+    out = OrderedDict((k, np.array(v, copy=True)) for k, v in sd.items())
+    out["duration_predictor.linear.weight"] = (out["duration_predictor.linear.weight"] * spread).astype(np.float32)
+    out["duration_predictor.linear.bias"] = np.full_like(out["duration_predictor.linear.bias"], mean_log)
+    return out

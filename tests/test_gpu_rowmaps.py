@@ -1,0 +1,161 @@
+"""-m gpu: the integer row / frame maps built ON THE DEVICE (fcl_row_maps_build) are bit-identical to the host maps (engine.build_row_maps, itself
+pinned to the reference's converter / inference bookkeeping by G4), and a synthesis pass driven by them — forced or PREDICTED durations, eager or
+as a replayed hipGraph — equals the pass with host-built maps.  Reference: ..._kd_student.py:821-851, decoder_sa_kd.py:736-791 (H10); a predicted
+duration of 0 is the reference's AssertionError (decoder_sa_kd.py:739) and must surface here as FCL_STATUS_ZERO_DURATION."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import max_abs, np_state_dict
+from fcl_taco2_amd import hparams as HP, synthetic as SYN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _dev_maps(lens, durs, lmax_cap, frames_cap, mode):
+    """mode "compact": rows = the non-padded phonemes (row_src / utt_row0 from the lengths); "padded": rows = the padded [B, T] layout."""
+    from fcl_taco2_amd import ops
+
+    B, T = len(lens), max(lens)
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    if mode == "compact":
+        starts = np.concatenate([[0], np.cumsum(lens)])
+        row_src = np.concatenate([b * T + np.arange(n) for b, n in enumerate(lens)])
+        d = np.concatenate([np.asarray(x).reshape(-1) for x in durs])
+        out = ops.row_maps_build(int(starts[-1]), B, lmax_cap, frames_cap, dur_i32=i32(d), row_src=i32(row_src), utt_row0=i32(starts), want_order=True, status=st)
+    else:
+        dpad = np.zeros((B, T), dtype=np.int64)
+        pad = np.ones((B, T), dtype=np.uint8)
+        for b, n in enumerate(lens):
+            dpad[b, :n] = np.asarray(durs[b]).reshape(-1)
+            pad[b, :n] = 0
+        out = ops.row_maps_build(B * T, B, lmax_cap, frames_cap, dur_i64=torch.from_numpy(dpad.reshape(-1)).to(DEV), t_max=T,
+                                 pad=torch.from_numpy(pad.reshape(-1)).to(DEV), want_order=True, status=st)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}, int(st.item()) & 0xFFFFFFFF
+
+
+def _check_equal(lens, durs, slack_l=0, slack_f=0):
+    from fcl_taco2_amd import engine
+
+    m = engine.build_row_maps(lens, durs, max(lens))
+    n = len(m.src_rows)
+    for mode in ("compact", "padded"):
+        d, status = _dev_maps(lens, durs, m.lmax + slack_l, m.n_frames + slack_f, mode)
+        assert status == 0, (mode, status)
+        assert np.array_equal(d["src_rows"][:n], m.src_rows) and np.array_equal(d["dur"][:n], m.dur_sorted), mode
+        assert np.array_equal(d["frame_off"][:n], m.frame_off_sorted), mode
+        assert np.array_equal(d["live_rows"][: m.lmax], m.live_rows) and not d["live_rows"][m.lmax :].any(), mode
+        assert np.array_equal(d["frame_lo"][: m.n_frames], m.frame_lo) and np.array_equal(d["frame_hi"][: m.n_frames], m.frame_hi), mode
+        assert not d["frame_lo"][m.n_frames :].any() and not d["frame_hi"][m.n_frames :].any(), mode
+        assert list(np.diff(d["utt_frame0"])) == m.utt_frames and tuple(d["totals"][:3]) == (m.n_frames, m.lmax, 0), mode
+        if mode == "compact":
+            assert np.array_equal(d["order"], m.order)
+        else:  # padding rows sort behind every real row, carry duration 0 and the total as their frame offset
+            assert not d["dur"][n:].any() and (d["frame_off"][n:] <= m.n_frames).all()
+
+
+def test_device_row_maps_equal_host_maps_on_g4_and_fuzz():
+    g = dict(np.load(os.path.join(GOLDEN, "g4_integer.npz")))
+    ds = [g["in_ds%d" % i].reshape(-1).astype(np.int64) for i in range(4)]
+    ds = [np.maximum(d, 1) for d in ds]  # (the converter's batch has zero-duration phonemes: inference would assert on them, see below)
+    _check_equal([len(d) for d in ds], ds)
+    rng = np.random.RandomState(0)
+    cases = [([1], [[1]]), ([1], [[50]]), ([3, 1], [[2, 2, 2], [2]]), ([5, 5], [[1, 1, 1, 1, 1], [7, 7, 7, 7, 7]])]
+    for trial in range(40):
+        B = int(rng.randint(1, 40))
+        lens = sorted(rng.randint(1, 130, size=B).tolist(), reverse=True)
+        hi = int(rng.choice([2, 5, 50, 300]))
+        cases.append((lens, [rng.randint(1, hi + 1, size=n) for n in lens]))
+    xs, c2 = SYN.batch_c2(80, batch=64, seed=11)  # the configs[4] batch: 5 k rows, > one LDS chunk of the builder
+    cases.append(([len(d) for d in c2], c2))
+    for i, (lens, durs) in enumerate(cases):
+        _check_equal(lens, durs, slack_l=(i % 3) * 5, slack_f=(i % 4) * 100)
+
+
+def test_device_row_maps_report_violations_and_decode_nothing():
+    from fcl_taco2_amd import _lib
+
+    lens, durs = [4, 3], [[3, 0, 2, 1], [1, 1, 9]]
+    d, status = _dev_maps(lens, durs, 16, 64, "padded")
+    assert status == _lib.STATUS_ZERO_DURATION and not d["live_rows"].any() and d["totals"][2] == 1  # the reference's AssertionError (D9)
+    durs = [[3, 1, 2, 1], [1, 1, 9]]
+    for mode in ("compact", "padded"):
+        d, status = _dev_maps(lens, durs, 8, 64, mode)  # max duration 9 > 8 launched steps
+        assert status == _lib.STATUS_LMAX_CAP and not d["live_rows"].any() and not d["frame_hi"].any()
+        d, status = _dev_maps(lens, durs, 9, 17, mode)  # 18 frames > 17
+        assert status == _lib.STATUS_FRAMES_CAP and not d["live_rows"].any()
+        d, status = _dev_maps(lens, durs, 9, 18, mode)
+        assert status == 0 and d["live_rows"][0] == 7 and d["totals"][0] == 18
+
+
+def _plan(hp, sd=None):
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    return SynthesisPlan(sd if sd is not None else np_state_dict(hp), hp, DEV)
+
+
+def test_forced_durations_through_device_maps_equal_host_maps():
+    """The same batch, forced durations: host-built maps vs device-built maps with exact capacities (same kernels per step -> bit-identical) and with
+    generous ones (every step may keep every row: other tile shapes -> fp32 summation order)."""
+    from fcl_taco2_amd import engine, ops
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    plan = _plan(hp)
+    xs, ds = SYN.batch_c2(hp.idim, batch=12, t_lo=40, t_hi=90, seed=21)
+    ref = torch.cat(engine.synthesize(plan, xs, ds))
+    maps = engine.build_row_maps([len(x) for x in xs], ds, max(len(x) for x in xs))
+    n_pad = len(xs) * max(len(x) for x in xs)
+    exact = torch.cat(engine.synthesize(plan, xs, ds, caps=engine.Caps.from_maps(maps)))
+    assert torch.equal(exact, ref)
+    gen = torch.cat(engine.synthesize(plan, xs, ds, caps=engine.Caps.generous(n_pad, maps.lmax + 7, maps.n_frames + 1000)))
+    assert gen.shape == ref.shape and max_abs(gen, ref) < 2e-5
+    ops.check_status(DEV)
+    # a step bound below the device's count is flagged, not silently wrong
+    tight = engine.Caps.from_maps(maps)
+    tight.bounds[3] -= 1
+    with pytest.raises(Exception, match="live rows"):
+        engine.synthesize(plan, xs, ds, caps=tight)
+    # a zero duration is the reference's AssertionError on either path
+    bad = [d.copy() for d in ds]
+    bad[1][2] = 0
+    with pytest.raises(AssertionError):
+        engine.synthesize(plan, xs, bad)
+    with pytest.raises(Exception, match="zero duration"):
+        engine.synthesize(plan, xs, bad, caps=engine.Caps.from_maps(maps))
+
+
+def test_predicted_durations_without_a_host_round_trip_and_as_a_graph():
+    """Predicted durations (the reference's inference() default): predictor -> clamp(round(exp(x) - 1), 0) -> row maps, all in HBM.  The eager pass
+    with the host round trip is the reference behaviour; the device-driven pass and a replayed hipGraph of it must give the same mel."""
+    from fcl_taco2_amd import engine, ops
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    plan = _plan(hp, SYN.positive_duration_head(np_state_dict(hp)))
+    xs, _ = SYN.batch_c2(hp.idim, batch=8, t_lo=30, t_hi=70, seed=33)
+    prep = engine.prepare(plan, xs)
+    mel_ref, frames_ref, inter = engine.run(plan, prep, return_intermediates=True)
+    torch.cuda.synchronize()
+    m = inter["maps"]
+    assert min(m.utt_frames) > 0 and 3 <= m.lmax <= 64 and m.dur_sorted.min() >= 1  # the synthetic duration head predicts usable durations
+    n_pad = prep.B * prep.T
+    mel_dev, frames = engine.run(plan, prep, caps=engine.Caps.generous(n_pad, m.lmax + 9, m.n_frames + 777))
+    assert frames.resolve() == list(m.utt_frames)
+    assert max_abs(mel_dev[: m.n_frames], mel_ref) < 2e-5
+    runner = engine.GraphRunner(plan, prep)  # calibrates, then captures predictor + rounding + device maps + decoder + postnet
+    for _ in range(3):
+        out = runner.replay()
+        torch.cuda.synchronize()
+        runner.check()
+        assert torch.equal(out[: m.n_frames], mel_ref) and runner.utt_frames == list(m.utt_frames)
+    assert np.array_equal(np.diff(runner.frames.utt_frame0.cpu().numpy()), np.asarray(m.utt_frames))
+    # other ids through the SAME graph would need other capacities: a violated capacity is reported, never silent
+    small = engine.Caps(2, 64, np.full(2, n_pad, dtype=np.int32))
+    engine.run(plan, prep, caps=small)
+    with pytest.raises(Exception, match="decoder steps|frames"):
+        ops.check_status(DEV)
