@@ -503,6 +503,10 @@ def main():
     ap.add_argument("--amp", choices=["none", "bf16"], default="none", help="kd_step / teacher_step: the mixed-precision variant (bf16-rounded GEMM operands, "
                     "fp32 accumulate / master weights / optimizer) of the reference's --use-amp recipes")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (independent passes on separate HIP streams)")
+    ap.add_argument("--feed", choices=["fresh", "replay"], default="fresh", help="synthesis: fresh = every pass takes a NEW batch through host packing + "
+                    "one H2D copy + one capacity graph with device-built row maps (default: what inference() times); replay = one prepared batch "
+                    "(host-built maps, outside the clock) replayed from a hipGraph (rounds 1-2)")
+    ap.add_argument("--batches", type=int, default=4, help="synthesis: distinct synthetic batches fed round-robin")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="kd_step: run teacher forward and student update back to back on one stream")
@@ -583,10 +587,15 @@ def main():
     hp = HP.student_hparams() if args.model == "student" else HP.teacher_hparams()
     sd_np = SYN.closed_form_state_dict(HP.param_spec(hp))
     plan = SynthesisPlan(sd_np, hp, dev)
-    xs, ds = SYN.batch_c2(hp.idim, batch=args.batch, seed=1234 + rank)
-    prep = engine.prepare(plan, xs, ds)
-    frames = int(sum(int(d.sum()) for d in ds))
+    # ---- the workload: `--batches` different synthetic batches of the configs[1] shape (other phoneme counts and durations each), fed round-robin;
+    # the first one is the batch the roofline / CPU-baseline legs use
+    T_CAP = 100
+    batches = [SYN.batch_c2(hp.idim, batch=args.batch, t_hi=T_CAP, seed=1234 + rank + 1000 * j) for j in range(max(1, args.batches))]
+    xs, ds = batches[0]
+    bframes = [int(sum(int(d.sum()) for d in b[1])) for b in batches]
+    frames = bframes[0]
     n_rows = int(sum(len(d) for d in ds))
+    prep = engine.prepare(plan, xs, ds)
 
     def barrier():
         torch.cuda.synchronize()
@@ -594,36 +603,66 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # `--streams` independent passes in flight, each a captured hipGraph on its own stream (fresh dropout
-    # masks per replay through the device seed word); --eager launches kernel by kernel instead.
+    # Default (`--feed fresh`): what the reference's inference() call covers per batch (tts.py:665-667) -- the host hand-over of a NEW batch (pack +
+    # one H2D copy of ids / lengths / durations), then the whole pass incl. the integer bookkeeping of the durations, which runs on the device
+    # inside the captured graph (engine.BatchRunner: capacities instead of a baked-in batch; ops.row_maps_build).  `--streams` runners keep as
+    # many batches in flight.  `--feed replay` = rounds 1-2: one prepared batch (host-built maps, outside the clock) replayed from a hipGraph;
+    # --eager launches that pass kernel by kernel.
+    host_maps = [engine.build_row_maps([len(x) for x in b[0]], b[1], T_CAP) for b in batches]
+    lmax_cap = max(m.lmax for m in host_maps) + 2
+    bounds = np.ones(lmax_cap, dtype=np.int32)
+    for m in host_maps:
+        bounds[: m.lmax] = np.maximum(bounds[: m.lmax], m.live_rows)
+    caps = engine.Caps(lmax_cap, (max(bframes) + 255) // 256 * 256, bounds)
+    fresh = args.feed == "fresh" and not args.eager
     if args.eager:
         streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [torch.cuda.current_stream()]
 
         def one_pass(i, seed):
             with torch.cuda.stream(streams[i % len(streams)]):
                 engine.run(plan, prep, ops.DROP_RNG, seed=seed)
+            return frames
+    elif fresh:
+        runners = [engine.BatchRunner(plan, args.batch, T_CAP, caps, forced=True, seed=77 + 1000 * j) for j in range(args.streams)]
+
+        def one_pass(i, seed):
+            r, j = runners[i % len(runners)], i % len(batches)
+            r.load(batches[j][0], batches[j][1])
+            r.replay()
+            return bframes[j]
     else:
         runners = [engine.GraphRunner(plan, prep, seed=77 + 1000 * j) for j in range(args.streams)]
 
         def one_pass(i, seed):
             runners[i % len(runners)].replay()
+            return frames
 
     for i in range(args.warmup):
         one_pass(i, i)
-    counter = [0]
+    counter, done, enq = [0], [0], []
 
     def region():
+        done[0] = 0
+        t_e = time.perf_counter()
         for _ in range(args.steps):
             counter[0] += 1
-            one_pass(counter[0], 1000 + counter[0])
+            done[0] += one_pass(counter[0], 1000 + counter[0])
+        enq.append(time.perf_counter() - t_e)  # host time to ENQUEUE the region's steps (the GPU is still running them)
 
     from fcl_taco2_amd import sharding
 
     # every region is reduced over the ranks (MAX time, SUM frames) before the median is taken, so all ranks report the same region
-    agg = [sharding.aggregate_throughput(t, frames, dist, dev) for t in timed_regions(region, barrier, max(1, args.regions))]
+    agg = []
+    for t in timed_regions(region, barrier, max(1, args.regions)):
+        agg.append(sharding.aggregate_throughput(t, done[0], dist, dev))
+    if fresh:  # every timed pass must have been a valid one: capacities held, frame counts as the host computes them
+        for r in runners:
+            got = r.frames()
+            assert sum(got) in bframes, "bench: a device-driven pass disagrees with the host's frame count"
+    rates = sorted(f / t for t, f in agg)
+    value = rates[len(rates) // 2] if len(rates) % 2 else 0.5 * (rates[len(rates) // 2 - 1] + rates[len(rates) // 2])
     dts = [a[0] for a in agg]
-    dt, frames_all = median(dts), agg[0][1]
-    value = frames_all * args.steps / dt
+    dt = median(dts)
 
     out = {
         "metric": "mel-frames/sec (FCL-taco2-%s forward, batch=%d, 80-mel)" % ("S" if args.model == "student" else "T", args.batch),
@@ -633,22 +672,67 @@ def main():
                  "f32 via bf16x3-split MFMA operands, fp32 accumulate (max-abs 8e-6 on mel vs the reference; FCL_PRECISION=0 = exact fp32 MFMA)",
         "data": "synthetic",
         "timing": {"statistic": "median over %d timed regions of exactly %d steps each (barrier + synchronize on both sides; MAX over ranks per region)"
-                                % (len(dts), args.steps), "region_ms": [round(1e3 * t, 4) for t in dts], "best_ms_per_step": 1e3 * min(dts) / args.steps},
+                                % (len(dts), args.steps), "region_ms": [round(1e3 * t, 4) for t in dts], "best_ms_per_step": 1e3 * min(dts) / args.steps,
+                   "host_enqueue_ms_per_step": 1e3 * median(enq) / args.steps},
         "config": {"workload": "BASELINE configs[1]: FCL-taco2-%s free-running synthesis, batch=%d/GPU, 60-100 phonemes/utt, forced "
-                               "durations clip(Poisson(10),1,50), %d frames / %d phoneme rows per batch, prenet dropout on (device RNG), "
-                               "closed-form weights" % ("S" if args.model == "student" else "T", args.batch, frames, n_rows),
+                               "durations clip(Poisson(10),1,50), %s frames / %d phoneme rows per batch, prenet dropout on (device RNG), "
+                               "closed-form weights" % ("S" if args.model == "student" else "T", args.batch,
+                                                        "/".join(str(f) for f in (bframes if fresh else [frames])), n_rows),
                    "parallelism": "%d independent replicas (utterance-sharded, no collective)" % world,
-                   "streams_per_gpu": args.streams, "launch": "eager" if args.eager else "hipGraph replay"},
+                   "streams_per_gpu": args.streams,
+                   "timed_per_step": ("host packing of a NEW batch (%d distinct batches round-robin) + one H2D copy (ids, lengths, durations) + one "
+                                      "hipGraph launch: encoder, predictors, device-built row maps (fcl_row_maps_build), decoder loop on device "
+                                      "live-row counts, postnet; capacities %d steps / %d frames, per-step row bounds = the batches' maximum"
+                                      % (len(batches), caps.lmax, caps.frames)) if fresh else
+                                     ("kernel-by-kernel launches of one prepared batch (host-built maps outside the clock)" if args.eager else
+                                      "hipGraph replay of one prepared batch (host-built maps outside the clock)")},
     }
 
     if rank == 0 and world == 1:
-        # ---- PCIe-inclusive figure (prepare + run), reported beside `value`, never as it
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(5):
-            engine.run(plan, engine.prepare(plan, xs, ds), ops.DROP_RNG, seed=i)
-        torch.cuda.synchronize()
-        out["value_including_host_prepare"] = frames * 5 / (time.perf_counter() - t1)
+        # ---- the same workload the way rounds 1-2 timed it (one prepared batch replayed, host maps outside the clock), and with PREDICTED durations
+        # (synthetic duration head, SYN.positive_duration_head: the closed-form head predicts ~0 frames) through the same kind of capacity graph
+        if fresh:
+            # (on the SAME streams: a second set would share hardware queues with the first, DESIGN.md "5+ streams are slower")
+            gr = [engine.GraphRunner(plan, prep, stream=runners[j].stream, seed=5 + j) for j in range(args.streams)]
+            for i in range(8):
+                gr[i % len(gr)].replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(40):
+                gr[i % len(gr)].replay()
+            torch.cuda.synchronize()
+            out["value_replay_only"] = frames * 40 / (time.perf_counter() - t1)
+            del gr
+            plan_p = SynthesisPlan(SYN.positive_duration_head(sd_np), hp, dev)
+            cal = [engine.run(plan_p, engine.prepare(plan_p, b[0]), ops.DROP_RNG, return_intermediates=True)[2]["maps"] for b in batches]
+            pl_cap = max(m.lmax for m in cal) + 2
+            pb = np.ones(pl_cap, dtype=np.int32)
+            for m in cal:
+                pb[: m.lmax] = np.maximum(pb[: m.lmax], m.live_rows)
+            pcaps = engine.Caps(pl_cap, (max(m.n_frames for m in cal) + 255) // 256 * 256, pb)
+            pr = [engine.BatchRunner(plan_p, args.batch, T_CAP, pcaps, forced=False, stream=runners[j].stream, seed=9 + j) for j in range(args.streams)]
+            pframes = [m.n_frames for m in cal]
+
+            def ppass(i):
+                r, j = pr[i % len(pr)], i % len(batches)
+                r.load(batches[j][0])
+                r.replay()
+                return pframes[j]
+
+            for i in range(8):
+                ppass(i)
+            torch.cuda.synchronize()
+            t1, tot = time.perf_counter(), 0
+            for i in range(40):
+                tot += ppass(i)
+            torch.cuda.synchronize()
+            pdt = time.perf_counter() - t1
+            for r in pr:
+                r.frames()  # raises on a violated capacity
+            out["predicted_durations"] = {"value": tot / pdt, "unit": "mel-frames/s", "ms_per_step": 1e3 * pdt / 40, "frames_per_batch": pframes,
+                                          "note": "same feed, durations PREDICTED inside the graph (duration predictor -> clamp(round(exp(x) - 1), 0) -> device "
+                                                  "row maps); synthetic duration head (log-durations ~ N(2.3, 0.35)) on the closed-form weights"}
+            del pr, plan_p
 
         # ---- live roofline of the dominant kernel: HIP events around every launch; 5 profiled passes, per-kernel MEDIAN over the passes
         # (one pass in ~10 shows a single launch stretched by whatever else the box is doing; a sum would let that outlier pick the "dominant" kernel)

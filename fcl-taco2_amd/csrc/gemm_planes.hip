@@ -285,7 +285,8 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
             const float r1w = (a.rank1_w && nin) ? a.rank1_w[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rm = (wm * TM + tm) * 16 + (RP ? rho16(rq * 4 + r) : rq * 4 + r), m = m0 + rm;
+                // staging row = MFMA row order (conflict-free ds_write pattern); RP: the tile row it holds is rho16 of it
+                const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + (RP ? (wm * TM + tm) * 16 + rho16(rq * 4 + r) : rm);
                 float v = 0.f;
                 if (nin && m < a.M) {
                     v = acc[tm][tn][r] + bn;
@@ -306,14 +307,15 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
             }
         }
     __syncthreads();
-    const int rows = min(BM, a.M - m0);
+    const int rows = RP ? BM : min(BM, a.M - m0);  // staging rows to write out; RP: staging row rm holds tile row (rm & ~15) + rho16(rm & 15)
+    auto trow = [&](int rm) { return RP ? (rm & ~15) + rho16(rm & 15) : rm; };
     if (a.accumulate) {  // weight gradients (split contraction, accumulation over micro-batches): one float per lane, consecutive lanes on
                          // consecutive addresses, so a wave's atomic instruction touches two cache lines
         for (int i = threadIdx.x; i < rows * BN; i += CTHREADS) {
-            const int rm = i / BN, cn = i - rm * BN, n = n0 + cn;
-            if (n >= a.N) continue;
-            float* dst = a.nblk > 0 ? a.Y + (size_t)(n / a.nblk) * a.blk_stride + (size_t)(m0 + rm) * a.ldy + (n % a.nblk)
-                                    : a.Y + (size_t)(m0 + rm) * a.ldy + n;
+            const int rm = i / BN, cn = i - rm * BN, n = n0 + cn, gm = m0 + trow(rm);
+            if (n >= a.N || gm >= a.M) continue;
+            float* dst = a.nblk > 0 ? a.Y + (size_t)(n / a.nblk) * a.blk_stride + (size_t)gm * a.ldy + (n % a.nblk)
+                                    : a.Y + (size_t)gm * a.ldy + n;
             atomicAdd(dst, tile[rm * LDT + cn]);
         }
         return;
@@ -321,10 +323,10 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
     if (a.Y) {
         const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
         for (int i = threadIdx.x; i < rows * (BN / 4); i += CTHREADS) {
-            const int rm = i / (BN / 4), c4 = (i - rm * (BN / 4)) * 4, n = n0 + c4;
-            if (n >= a.N) continue;
+            const int rm = i / (BN / 4), c4 = (i - rm * (BN / 4)) * 4, n = n0 + c4, gm = m0 + trow(rm);
+            if (n >= a.N || gm >= a.M) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c4);
-            float* dst = a.Y + (size_t)(m0 + rm) * a.ldy + n;
+            float* dst = a.Y + (size_t)gm * a.ldy + n;
             if (vec && n + 3 < a.N) {
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
@@ -337,13 +339,13 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
     if (a.Yp) {  // item = (row, 32-column line, quarter q): 8 values -> 16 bytes of hi at piece q and 16 bytes of lo at piece 4 + q
         const int np = a.ldyp * 32;
         for (int i = threadIdx.x; i < rows * (BN / 8); i += CTHREADS) {
-            const int rm = i / (BN / 8), c8 = (i - rm * (BN / 8)) * 8, n = n0 + c8;
-            if (n >= np) continue;
+            const int rm = i / (BN / 8), c8 = (i - rm * (BN / 8)) * 8, n = n0 + c8, gm = m0 + trow(rm);
+            if (n >= np || gm >= a.M) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8), v1 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8 + 4);
             uint2 h0, l0, h1, l1;
             split4(v0, h0, l0);
             split4(v1, h1, l1);
-            u16* line = a.Yp + ((size_t)(m0 + rm) * a.ldyp + (n >> 5)) * 64 + (n & 31);
+            u16* line = a.Yp + ((size_t)gm * a.ldyp + (n >> 5)) * 64 + (n & 31);
             *reinterpret_cast<uint4*>(line) = make_uint4(h0.x, h0.y, h1.x, h1.y);
             *reinterpret_cast<uint4*>(line + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }

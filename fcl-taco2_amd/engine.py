@@ -389,3 +389,109 @@ class GraphRunner(object):
     def check(self):
         """Device-driven graphs: synchronising check of the status word (capacity violations, zero durations)."""
         ops.check_status(self.plan.device)
+
+
+class BatchRunner(object):
+    """A captured pass whose every size is a CAPACITY: one hipGraph replays for any batch of at most `batch` utterances, `t_cap` phonemes each and
+    `caps` (decoder steps, frames, live rows per step).  Per batch the host does three things: pack ids / lengths / pad mask (/ forced durations)
+    into ONE pinned block, enqueue ONE host-to-device copy, launch ONE graph.  Everything the reference's inference() does per utterance on the
+    host -- the `ds_nonzeros` filter, the position table, the per-phoneme trim and concat loops (..._kd_student.py:821-851,
+    decoder_sa_kd.py:736-791) -- and this build's own numpy row maps run on the device inside the graph (ops.row_maps_build over the padded
+    [batch, t_cap] row universe), with predicted OR forced durations.  Nothing about the durations is known to the host until it reads the mels
+    back (`frames()`): capacities are verified on the device (FCL_STATUS_*), a batch that does not fit is reported, never silently truncated.
+    forced=True: the graph takes uploaded durations (load(xs, durs)); forced=False: it contains the duration predictor + rounding."""
+
+    def __init__(self, plan, batch, t_cap, caps, forced=True, stream=None, dropout_mode=ops.DROP_RNG, seed=0, depth=3):
+        dev = plan.device
+        self.plan, self.B, self.T, self.caps, self.forced = plan, int(batch), int(t_cap), caps, bool(forced)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        n = self.B * self.T
+        # one byte block: ids int64 [n] | seg_lo, seg_hi int32 [n] each | dur int32 [n] | lens int32 [B, padded to 4] | pad uint8 [n]
+        self._off = {}
+        off = 0
+        for name, nbytes in (("ids", 8 * n), ("seg_lo", 4 * n), ("seg_hi", 4 * n), ("dur", 4 * n), ("lens", 4 * ((self.B + 3) // 4 * 4)), ("pad", n)):
+            self._off[name] = (off, nbytes)
+            off += (nbytes + 15) // 16 * 16
+        self._nbytes = off
+        self._host = [torch.zeros(off, dtype=torch.uint8).pin_memory() for _ in range(depth)]
+        self._host_ev = [None] * depth
+        self._slot = 0
+        with torch.cuda.device(dev):
+            self._dev = torch.zeros(off, dtype=torch.uint8, device=dev)
+            view = lambda name, dt: self._dev[self._off[name][0] : self._off[name][0] + self._off[name][1]].view(dt)
+            p = PreparedBatch()
+            p.B, p.T, p.lens = self.B, self.T, None
+            p.ids, p.seg_lo, p.seg_hi = view("ids", torch.int64), view("seg_lo", torch.int32), view("seg_hi", torch.int32)
+            p.lens_dev, p.pad = view("lens", torch.int32)[: self.B], view("pad", torch.uint8)
+            p.dur_pad = view("dur", torch.int32) if self.forced else None
+            p.f0e, p.maps = None, None
+            self.prep = p
+            self.seed_word = torch.zeros(1, dtype=torch.int32, device=dev)
+            # warm-up on a minimal valid batch (one phoneme of duration 1 per utterance), then capture
+            self.load([np.ones(1, dtype=np.int64)] * self.B, [np.ones(1, dtype=np.int64)] * self.B if self.forced else None)
+            with torch.cuda.stream(self.stream):
+                run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps)
+            self.stream.synchronize()
+            if self.forced:
+                ops.check_status(dev)
+            else:
+                ops.status_word(dev).zero_()  # (the warm-up ids need not predict valid durations)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                ops.u32_add(self.seed_word, 1)
+                self.mel, self._frames = run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps)
+        self.n_loaded = 0
+
+    def load(self, xs, durs=None):
+        """Hand one batch to the graph's input block: host packing + ONE non-blocking copy on this runner's stream (ordered before the next replay)."""
+        nb = len(xs)
+        if nb > self.B or nb == 0:
+            raise ValueError("BatchRunner: %d utterances, capacity %d" % (nb, self.B))
+        if (durs is not None) != self.forced:
+            raise ValueError("BatchRunner(forced=%s): durations %s" % (self.forced, "missing" if self.forced else "not taken (the graph predicts them)"))
+        B, T, n = self.B, self.T, self.B * self.T
+        j = self._slot % len(self._host)
+        self._slot += 1
+        if self._host_ev[j] is not None:
+            self._host_ev[j].synchronize()  # the copy that last read this staging buffer (depth loads ago)
+        hb = self._host[j].numpy()
+        seg = lambda name, dt: hb[self._off[name][0] : self._off[name][0] + self._off[name][1]].view(dt)
+        ids, dur, lens = seg("ids", np.int64).reshape(B, T), seg("dur", np.int32).reshape(B, T), seg("lens", np.int32)
+        ids[:] = 0
+        dur[:] = 0
+        lens[:] = 0
+        for b in range(nb):
+            x = xs[b].cpu().numpy() if torch.is_tensor(xs[b]) else np.asarray(xs[b])
+            k = x.shape[0]
+            if k > T or k == 0:
+                raise ValueError("BatchRunner: utterance of %d phonemes, capacity %d" % (k, T))
+            ids[b, :k] = x
+            lens[b] = k
+            if durs is not None:
+                d = np.asarray(durs[b]).reshape(-1)
+                if d.shape[0] != k:
+                    raise ValueError("duration count != phoneme count")
+                dur[b, :k] = d
+        rows = np.arange(n, dtype=np.int32)
+        b_of = rows // T
+        seg("seg_lo", np.int32)[:] = b_of * T
+        seg("seg_hi", np.int32)[:] = b_of * T + lens[:B][b_of]
+        seg("pad", np.uint8)[:] = (rows - b_of * T) >= lens[:B][b_of]
+        with torch.cuda.stream(self.stream):
+            self._dev.copy_(self._host[j], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._host_ev[j] = ev
+        self.n_loaded = nb
+
+    def replay(self):
+        """Enqueue one pass over the loaded batch; returns the static mel buffer [caps.frames, odim] (rows past the batch's total are not valid)."""
+        with torch.cuda.stream(self.stream):
+            self.graph.replay()
+        return self.mel
+
+    def frames(self):
+        """Synchronising: per-utterance frame counts of the last replay (raises FclError on a violated capacity / zero duration)."""
+        self.stream.synchronize()
+        self._frames._host = None
+        return self._frames.resolve()[: self.n_loaded]

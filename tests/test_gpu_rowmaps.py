@@ -159,3 +159,48 @@ def test_predicted_durations_without_a_host_round_trip_and_as_a_graph():
     engine.run(plan, prep, caps=small)
     with pytest.raises(Exception, match="decoder steps|frames"):
         ops.check_status(DEV)
+
+
+def test_batch_runner_one_graph_for_many_batches():
+    """engine.BatchRunner: ONE captured graph, capacities instead of a baked-in batch.  Different batches (other lengths, other durations, fewer
+    utterances than the capacity) go through load() + replay() and must equal the plain eager synthesis of each batch; a batch that does not fit
+    is reported."""
+    from fcl_taco2_amd import engine
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    plan = _plan(hp)
+    B, T_cap = 8, 64
+    batches = [SYN.batch_c2(hp.idim, batch=B, t_lo=20, t_hi=T_cap, seed=s) for s in (1, 2, 3)]
+    batches.append(tuple(v[:5] for v in SYN.batch_c2(hp.idim, batch=B, t_lo=10, t_hi=30, seed=4)))  # fewer utterances than the capacity
+    maps = [engine.build_row_maps([len(x) for x in xs], ds, T_cap) for xs, ds in batches]
+    lmax = max(m.lmax for m in maps) + 2
+    bounds = np.zeros(lmax, dtype=np.int32)
+    for m in maps:
+        bounds[: m.lmax] = np.maximum(bounds[: m.lmax], m.live_rows)
+    bounds = np.maximum(bounds, 1)
+    caps = engine.Caps(lmax, max(m.n_frames for m in maps) + 100, bounds)
+    runner = engine.BatchRunner(plan, B, T_cap, caps, forced=True)
+    for (xs, ds), m in zip(batches + batches[:1], maps + maps[:1]):  # (and the first batch again: nothing of the previous one may linger)
+        runner.load(xs, ds)
+        mel = runner.replay()
+        assert runner.frames() == list(m.utt_frames)
+        ref = torch.cat(engine.synthesize(plan, xs, ds))
+        assert max_abs(mel[: m.n_frames], ref) < 2e-5
+    xs, ds = batches[0]
+    bad = [d.copy() for d in ds]
+    bad[0][0] = lmax + 1
+    runner.load(xs, bad)
+    runner.replay()
+    with pytest.raises(Exception, match="decoder steps"):
+        runner.frames()
+    with pytest.raises(ValueError):
+        runner.load(xs + xs, ds + ds)
+    # predicted durations through one graph
+    plan2 = _plan(hp, SYN.positive_duration_head(np_state_dict(hp)))
+    r2 = engine.BatchRunner(plan2, B, T_cap, engine.Caps.generous(B * T_cap, 64, B * T_cap * 24), forced=False)
+    for xs, _ in batches[:2]:
+        r2.load(xs)
+        mel = r2.replay()
+        fr = r2.frames()
+        ref = engine.synthesize(plan2, xs)
+        assert fr == [int(m_.shape[0]) for m_ in ref] and max_abs(mel[: sum(fr)], torch.cat(ref)) < 2e-5
