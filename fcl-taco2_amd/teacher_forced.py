@@ -137,13 +137,15 @@ class LossAccumulator(object):
         return {n: (host[i, 0] / host[i, 2], host[i, 1] / host[i, 2]) for i, n in enumerate(self.names)}
 
 
-def base_losses(acc, r):
-    """Tacotron2Loss + duration + pitch + energy (..._sa.py:601-613)."""
-    acc.add("after", r.after, r.ys, r.frame_valid)
-    acc.add("before", r.before, r.ys, r.frame_valid)
+def base_losses(acc, r, use_masking=True):
+    """Tacotron2Loss + duration + pitch + energy (..._sa.py:601-613).  use_masking False: the mel and prosody terms run over the padded tensors
+    (row_valid None = every row); the duration loss is masked regardless (..._sa.py:561-565)."""
+    fv, ev = (r.frame_valid, r.enc_valid) if use_masking else (None, None)
+    acc.add("after", r.after, r.ys, fv)
+    acc.add("before", r.before, r.ys, fv)
     acc.add("dur", r.d_outs, r.ds, r.enc_valid, b_log_offset=1.0)  # DurationPredictorLoss: MSE vs log(d + 1)
-    acc.add("pitch", r.p_outs, r.f0, r.enc_valid)
-    acc.add("energy", r.e_outs, r.energy, r.enc_valid)
+    acc.add("pitch", r.p_outs, r.f0, ev)
+    acc.add("energy", r.e_outs, r.energy, ev)
 
 
 def finish_base(m):
@@ -154,10 +156,10 @@ def finish_base(m):
 
 
 def teacher_forward(plan, batch, **kw):
-    plan.hp.check_loss_supported()  # masked means only (use_masking True): anything else raises instead of silently computing this objective
+    plan.hp.check_loss_supported()  # (use_weighted_masking raises instead of silently computing another objective)
     r = forward_pass(plan, batch, **kw)
     acc = LossAccumulator(plan.device)
-    base_losses(acc, r)
+    base_losses(acc, r, plan.hp.use_masking)
     return finish_base(acc.means()), r
 
 
@@ -176,7 +178,7 @@ def student_forward(plan, batch, teacher_knowledge, share_proj=True, distill=(Tr
     r = forward_pass(plan, batch, **kw)
     dev = plan.device
     acc = LossAccumulator(dev, 48)
-    base_losses(acc, r)
+    base_losses(acc, r, plan.hp.use_masking)
     t_after, t_before, t_enc, t_dec, t_pro = teacher_knowledge
     flat = lambda t: _dev(t, dev, torch.float32).reshape(-1, t.shape[-1])
     P = plan.proj
@@ -187,8 +189,9 @@ def student_forward(plan, batch, teacher_knowledge, share_proj=True, distill=(Tr
         cp = ["enc.convs_proj.%d" % i for i in range(3)]
         lp, pp = ["dec.lstm0_proj", "dec.lstm1_proj"], ["dec.post%d_proj" % i for i in range(4)]
     if distill[0]:
-        acc.add("o_after", r.after, flat(t_after), r.frame_valid)
-        acc.add("o_before", r.before, flat(t_before), r.frame_valid)
+        fv = r.frame_valid if plan.hp.use_masking else None  # Tacotron2Loss_KD follows use_masking too (..._kd_student.py:120-125)
+        acc.add("o_after", r.after, flat(t_after), fv)
+        acc.add("o_before", r.before, flat(t_before), fv)
     if distill[1]:
         s_enc = [lin(r.enc_taps[0], "enc.embed_proj")] + [lin(r.enc_taps[1 + i], cp[i]) for i in range(3)] + [lin(r.hs, "enc.blstm_proj")]
         for i, (s, t) in enumerate(zip(s_enc, t_enc)):

@@ -882,11 +882,17 @@ class TrainEngine(object):
                                         b_log_offset=b_log)  # loss sums + d(loss / accum_grad) in one pass
 
         inj = c.inj = {}
-        inj["after"] = term("after", c.after, c.ys, c.frame_valid, nf, 1.0, 1.0)
-        inj["before"] = term("before", c.before, c.ys, c.frame_valid, nf, 1.0, 1.0)
+        # use_masking False (the reference's argparse default): Tacotron2Loss, Tacotron2Loss_KD and prosody_criterions average over the PADDED
+        # tensors -- every (b, l) / (b, t) row counts, padded targets are 0, `before` is 0 there and `after` is whatever the postnet makes of the
+        # zero padding (..._sa.py:60-70, 122-126); the duration loss and Knowledge_loss are masked regardless (..._kd_student.py:719, 165-176)
+        um = not hp.use_masking
+        fv, nfm = (None, c.after.shape[0] * hp.odim) if um else (c.frame_valid, nf)
+        ev, nem = (None, c.p_outs.numel()) if um else (c.enc_valid, ne)
+        inj["after"] = term("after", c.after, c.ys, fv, nfm, 1.0, 1.0)
+        inj["before"] = term("before", c.before, c.ys, fv, nfm, 1.0, 1.0)
         inj["d_outs"] = term("dur", c.d_outs, c.ds, c.enc_valid, ne, 0.0, 1.0, b_log=1.0)
-        inj["p_outs"] = term("pitch", c.p_outs, c.f0, c.enc_valid, ne, 0.0, 1.0)
-        inj["e_outs"] = term("energy", c.e_outs, c.en, c.enc_valid, ne, 0.0, 1.0)
+        inj["p_outs"] = term("pitch", c.p_outs, c.f0, ev, nem, 0.0, 1.0)
+        inj["e_outs"] = term("energy", c.e_outs, c.en, ev, nem, 0.0, 1.0)
         if self.role == "student":
             t_after, t_before, t_enc, t_dec, t_pro = teacher_knowledge
             flat = lambda t: t.to(device=dev, dtype=torch.float32).reshape(-1, t.shape[-1]).contiguous()
@@ -905,8 +911,8 @@ class TrainEngine(object):
                 return ops.linear(ds_, self._wt(w))
 
             if self.distill[0]:
-                term("o_after", c.after, flat(t_after), c.frame_valid, nf, 1.0, 1.0, da=inj["after"])
-                term("o_before", c.before, flat(t_before), c.frame_valid, nf, 1.0, 1.0, da=inj["before"])
+                term("o_after", c.after, flat(t_after), fv, nfm, 1.0, 1.0, da=inj["after"])
+                term("o_before", c.before, flat(t_before), fv, nfm, 1.0, 1.0, da=inj["before"])
             if self.distill[1]:
                 inj["enc0"] = kd("enc0", c.enc_taps[0], "enc.embed_proj", flat(t_enc[0]), c.enc_valid, ne)
                 for i in range(3):

@@ -382,13 +382,14 @@ def decoder_forward(sd, hp, hs, olens, new_ys, non_zero_lens_mask, ds_nonzeros, 
 
 
 def _masked_mean_l1_mse(a, b, mask):
-    a, b = a.masked_select(mask), b.masked_select(mask)
+    if mask is not None:
+        a, b = a.masked_select(mask), b.masked_select(mask)
     return (a - b).abs().mean(), ((a - b) ** 2).mean()
 
 
-def taco2_loss(after, before, ys, olens):
-    """Tacotron2Loss (..._sa.py:26-82) with use_masking: L1(after)+L1(before), MSE(after)+MSE(before)."""
-    m = make_non_pad_mask(olens).unsqueeze(-1)
+def taco2_loss(after, before, ys, olens, use_masking=True):
+    """Tacotron2Loss (..._sa.py:26-82): L1(after)+L1(before), MSE(after)+MSE(before); use_masking False = means over the padded tensors."""
+    m = make_non_pad_mask(olens).unsqueeze(-1) if use_masking else None
     l1a, ma = _masked_mean_l1_mse(after, ys, m)
     l1b, mb = _masked_mean_l1_mse(before, ys, m)
     return l1a + l1b, ma + mb
@@ -455,9 +456,9 @@ def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher
     dur_loss = ((d_outs.masked_select(nonpad) - torch.log(ds.masked_select(nonpad).float() + 1.0)) ** 2).mean()
     p_outs = variance_predictor(sd, hp, "pitch", hs, pad, mk.get("pitch_predictor"))
     e_outs = variance_predictor(sd, hp, "energy", hs, pad, mk.get("energy_predictor"))
-    m1 = nonpad.unsqueeze(-1)
-    pitch_loss = _masked_mean_l1_mse(p_outs, batch["f0"], m1)[1]
-    energy_loss = _masked_mean_l1_mse(e_outs, batch["energy"], m1)[1]
+    m1 = nonpad.unsqueeze(-1) if hp.use_masking else None  # prosody_criterions follows use_masking (..._sa.py:122-126); the duration loss does not
+    pitch_loss = _masked_mean_l1_mse(p_outs, batch["f0"][:, : int(max(ilens))], m1)[1]
+    energy_loss = _masked_mean_l1_mse(e_outs, batch["energy"][:, : int(max(ilens))], m1)[1]
     p_embs = variance_embed(sd, "pitch", batch["f0"], mk.get("pitch_embed"), hp.variance_embed_dropout_rate)  # ground-truth f0/energy feed the embeds
     e_embs = variance_embed(sd, "energy", batch["energy"], mk.get("energy_embed"), hp.variance_embed_dropout_rate)
     after, before, dec_taps = decoder_forward(
@@ -466,7 +467,7 @@ def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher
         None if mk.get("zoneout") is None else _t(mk["zoneout"]), bn_train, mk.get("postnet"))
     if role == "kd_teacher":
         return after, before, enc_taps + [hs], dec_taps, [d_outs.unsqueeze(-1), p_outs, e_outs, p_embs, e_embs]
-    l1, mse = taco2_loss(after, before, ys, olens)
+    l1, mse = taco2_loss(after, before, ys, olens, hp.use_masking)
     rep = dict(l1_loss=l1, mse_loss=mse, dur_loss=dur_loss, pitch_loss=pitch_loss, energy_loss=energy_loss)
     loss = l1 + mse + dur_loss + pitch_loss + energy_loss
     if role == "student":
@@ -485,7 +486,7 @@ def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher
         s_dec = [lin(dec_taps[0], "dec.prenet_proj.weight"), lin(dec_taps[1], lp[0]), lin(dec_taps[2], lp[1])] \
             + [lin(dec_taps[3 + i], pp[i]) for i in range(4)] + [dec_taps[7]]
         s_pro = [d_outs.unsqueeze(-1), p_outs, e_outs, lin(p_embs, "pemb_proj.weight"), lin(e_embs, "eemb_proj.weight")]
-        mo = make_non_pad_mask(olens).unsqueeze(-1)
+        mo = make_non_pad_mask(olens).unsqueeze(-1) if hp.use_masking else None  # Tacotron2Loss_KD (..._kd_student.py:120-125)
         o_l1 = _masked_mean_l1_mse(after, t_after, mo)[0] + _masked_mean_l1_mse(before, t_before, mo)[0]
         o_mse = _masked_mean_l1_mse(after, t_after, mo)[1] + _masked_mean_l1_mse(before, t_before, mo)[1]
         enc_l = knowledge_loss(s_enc, t_enc, ilens)

@@ -476,10 +476,58 @@ def gen_g7_g8_g9():
     save("g9_kd_step_train_mode", **d)
 
 
+def gen_g10():
+    """G10: the loss variants of `--use-masking False` (the reference's argparse default, ..._sa.py:251-262; the shipped yaml sets True): mel L1 / MSE
+    and the prosody MSEs over the PADDED tensors, the output-KD term likewise; the duration loss and the encoder / decoder / prosody KD terms stay
+    masked (..._kd_student.py:719, 134-179).  Teacher step and student KD step, eval form: named losses + gradients.  Also records what the
+    reference does with `--use-weighted-masking True` (unreduced duration / prosody losses of different shapes are added: it fails)."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, use_masking=False)
+    TU = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **kw)
+    SU = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, **kw)
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    te, _ = build("teacher", TU)
+    assert te.taco2_loss.use_masking is False
+    loss = te(**b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(te, d)
+    _grads(te, GRAD_KEYS, d)
+    save("g10_teacher_unmasked", **d)
+    kt, _ = build("kd_teacher", TINY_T)
+    with torch.no_grad():
+        know = kt(**b)
+    st, _ = build("student", SU, TU, True)
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(st, d)
+    _grads(st, [k for k in GRAD_KEYS] + KD_KEYS, d)
+    save("g10_student_kd_unmasked", **d)
+    rec_path = os.path.join(OUT, "records.json")
+    rec = json.load(open(rec_path)) if os.path.exists(rec_path) else {}
+    try:
+        from nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa as Teacher
+
+        tw = _quiet(Teacher, TU.idim, TU.odim, ns(TU, use_weighted_masking=True), argparse.Namespace(share_proj=True, **COM))
+        tw.eval()
+        float(tw(**b).mean())
+        rec["use_weighted_masking"] = "runs"
+    except Exception as e:  # noqa: BLE001 - the record is the exception itself
+        rec["use_weighted_masking"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:160])
+    with open(rec_path, "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print("records.json use_weighted_masking ->", rec["use_weighted_masking"])
+
+
 def main():
     assert os.path.isdir(REF), "gen_golden.py needs /root/reference (survey container only)"
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
+    only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
+    if only:
+        assert only <= {"g10"}, only
+        gen_g10()
+        return
     gen_manifest()
     gen_g1()
     rec = gen_g2_g3()
@@ -487,6 +535,7 @@ def main():
     gen_g5()
     gen_g6(rec)
     gen_g7_g8_g9()
+    gen_g10()
 
 
 if __name__ == "__main__":

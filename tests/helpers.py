@@ -30,3 +30,9 @@ def max_abs(a, b):
     b = b.detach().cpu().numpy() if hasattr(b, "detach") else np.asarray(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+
+# the `--use-masking False` loss variant (G10): same shapes / weights as TINY_S / TINY_T
+TINY_SU = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20,
+                             postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0, use_masking=False)
+TINY_TU = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
+                             postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, use_masking=False)

@@ -25,7 +25,7 @@ COM = argparse.Namespace(use_fe_condition=True, append_position=True, distill_ou
 
 def _ns(hp):
     return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
-                              postnet_chans=hp.postnet_chans, use_residual=False, use_masking=True, dropout_rate=hp.dropout_rate,
+                              postnet_chans=hp.postnet_chans, use_residual=False, use_masking=hp.use_masking, dropout_rate=hp.dropout_rate,
                               duration_predictor_chans=hp.duration_predictor_chans)
 
 
@@ -206,6 +206,32 @@ def test_kd_update_train_mode_vs_reference_g9():
     orep = O.model_forward(sd, TINY_S7, _cpu(batch), "student", TINY_T7, True, oknow, bn_train=True, masks=sm)
     orep["loss"].backward()
     _check_vs_oracle(eng, sd, tol=1e-3)
+
+
+def test_unmasked_loss_variant_vs_reference_g10():
+    """G10: `--use-masking False` on the HIP path -- the teacher step and the student KD step against the real reference's losses and gradients
+    (mel / prosody / output-KD means over the padded tensors), and every other gradient against the oracle's autograd."""
+    from helpers import TINY_SU, TINY_TU
+    from fcl_taco2_amd.training import TrainEngine
+
+    batch = _batch()
+    g = _golden("g10_teacher_unmasked")
+    m = _model("teacher", TINY_TU)
+    assert m.hp.use_masking is False
+    eng = TrainEngine(m)
+    rep = eng.forward_backward(batch)
+    assert _check_vs_golden(eng, rep, g, ["loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"]) >= 12
+    sd = _grad_sd(TINY_TU)
+    O.model_forward(sd, TINY_TU, _cpu(batch), "teacher")["loss"].backward()
+    _check_vs_oracle(eng, sd)
+    m.eval()
+    with torch.no_grad():
+        loss = m(**{k: v for k, v in batch.items() if not k.startswith("_")})  # the evaluator's forward() (teacher_forced.py)
+    assert abs(float(loss) - float(g["loss"])) < 5e-4 * abs(float(g["loss"]))
+    g = _golden("g10_student_kd_unmasked")
+    eng = TrainEngine(_model("student", TINY_SU, TINY_TU))
+    rep = eng.forward_backward(batch, teacher_knowledge=_g1_knowledge())
+    assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
 
 
 def test_device_rng_masks_statistics_and_repeatability():

@@ -79,15 +79,16 @@ def test_unsupported_configurations_fail_loudly():
 
 
 def test_loss_configuration_is_gated_loudly():
-    """ADVICE r1: use_masking=False (the reference's argparse default, ..._sa.py:251-262) and use_weighted_masking are different objectives;
-    the HIP path computes the masked means of the shipped recipes (conf/*.yaml:25) and must refuse the others instead of silently ignoring them.
-    Synthesis does not depend on the flags: check_supported() (plan building) still passes."""
+    """Loss variants: use_masking True (shipped recipes) and False (the reference's argparse default, round 3: G10) are both computed;
+    use_weighted_masking is refused -- the reference's own forward() raises on it (tests/golden/records.json), so refusing IS the parity.
+    Synthesis does not depend on the flags: check_supported() (plan building) passes for all of them."""
     import pytest
 
     from fcl_taco2_amd import hparams as HP
 
     HP.student_hparams().check_supported().check_loss_supported()
-    for kw in (dict(use_masking=False), dict(use_weighted_masking=True, use_masking=False), dict(use_weighted_masking=True)):
+    HP.student_hparams(use_masking=False).check_supported().check_loss_supported()
+    for kw in (dict(use_weighted_masking=True, use_masking=False), dict(use_weighted_masking=True)):
         hp = HP.student_hparams(**kw).check_supported()
         with pytest.raises(NotImplementedError):
             hp.check_loss_supported()

@@ -227,6 +227,37 @@ def test_g9_kd_step_train_mode(golden):
     assert _check_grads(sd, g) >= 20
 
 
+def test_g10_unmasked_loss_variant(golden):
+    """`--use-masking False` (the reference's argparse default): mel / prosody / output-KD means over the padded tensors; duration loss and the
+    encoder / decoder / prosody KD terms masked as ever.  Teacher step and student KD step vs the real reference (losses + gradients)."""
+    from helpers import TINY_SU, TINY_TU
+
+    g4, g1 = golden("g4_integer"), golden("g1_forward")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden("g10_teacher_unmasked")
+    sd = _grad_sd(TINY_TU)
+    rep = O.model_forward(sd, TINY_TU, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 12
+    assert abs(float(g["l1_loss"]) - float(golden("g5_teacher_train")["loss"])) > 1e-2  # (it IS a different objective than the masked one)
+    g = golden("g10_student_kd_unmasked")
+    know = (torch.from_numpy(g1["t_after"]), torch.from_numpy(g1["t_before"]), [torch.from_numpy(g1["t_enc%d" % i]) for i in range(5)],
+            [torch.from_numpy(g1["t_dec%d" % i]) for i in range(8)], [torch.from_numpy(g1["t_pro%d" % i]) for i in range(5)])
+    sd = _grad_sd(TINY_SU, TINY_TU, True)
+    rep = O.model_forward(sd, TINY_SU, b, "student", TINY_TU, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss", "encoder_loss", "decoder_loss",
+              "prosody_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 20
+    import json
+
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "records.json")))
+    assert rec["use_weighted_masking"].startswith("RuntimeError")  # the reference itself cannot run that variant: refusing it is parity
+
+
 def test_g6_padding_leak_and_zero_duration(golden):
     g = golden("g6_padding_leak")
     rec = json.load(open(os.path.join(GOLDEN, "records.json")))
