@@ -73,23 +73,74 @@ def read_manifest(json_path):
     return [(k, np.array(list(map(int, v["output"][0]["tokenid"].split())), dtype=np.int64)) for k, v in js.items()]
 
 
+class _Slot(object):
+    """One pinned landing area of a runner's outputs (mel buffer, frame starts, status word); `free` is set by the writer thread once the ark
+    holds its utterances, and waited on before the next device-to-host copy may overwrite it."""
+
+    def __init__(self, frames_cap, odim, batch):
+        self.mel = torch.empty(frames_cap, odim, dtype=torch.float32, pin_memory=True)
+        self.f0 = torch.empty(batch + 1, dtype=torch.int32, pin_memory=True)
+        self.st = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self.free = threading.Event()
+        self.free.set()
+
+
+class _Pool(object):
+    """The capacity graphs of one phoneme-length bucket: BatchRunners (predicted durations, created on first use) sharing the bucket's
+    capacities; kept on the plan, so later decode() calls on the same model replay the graphs captured by earlier ones."""
+
+    def __init__(self, plan, batch, t_cap, caps, streams, seed):
+        self.plan, self.batch, self.caps, self.t_cap, self.streams, self.seed = plan, batch, caps, t_cap, streams, seed
+        self.runners, self.slots, self.next, self.grow = [None] * len(streams), [None] * len(streams), 0, None
+
+    def runner(self, j):
+        from . import engine
+
+        if self.runners[j] is None:
+            r = self.runners[j] = engine.BatchRunner(self.plan, self.batch, self.t_cap, self.caps, forced=False, stream=self.streams[j], seed=self.seed + 7919 * j)
+            self.slots[j] = [_Slot(self.caps.frames, r.mel.shape[1], self.batch) for _ in range(2)]
+        return self.runners[j]
+
+
+def _grown_caps(engine, maps, n_rows, scale=1.3):
+    """Capacities for the batches that follow the one whose exact maps are `maps` (they are no longer than it): some slack on every count."""
+    lmax = max(16, int(maps.lmax * 1.5) + 4)
+    bounds = np.full(lmax, 1, dtype=np.int32)
+    live = np.minimum(n_rows, (maps.live_rows.astype(np.float64) * scale).astype(np.int64) + 32)
+    bounds[: maps.lmax] = live
+    bounds[maps.lmax :] = live[-1]
+    bounds = np.maximum.accumulate(bounds[::-1])[::-1].astype(np.int32)  # non-increasing, as the loop requires
+    return engine.Caps(lmax, (int(maps.n_frames * scale) + 255) // 256 * 256, bounds)
+
+
 @torch.no_grad()
-def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=2):
-    """utts: [(utt_id, ids)].  Writes PREFIX.ark/.scp; returns (frames, seconds).
-    Pipelined: a batch's packed mel [F, odim] leaves the device in ONE non-blocking copy into pinned memory on a copy stream, and up to `depth`
-    batches are in flight, so the host prepares and enqueues batch i+1 (and writes batch i-1 to the ark) while the GPU runs batch i.  The clock
-    covers first submit -> last mel on the host (the only synchronisation points are the predicted-duration read-back inside a pass and the
-    copy-complete events)."""
+def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None):
+    """utts: [(utt_id, ids)].  Writes PREFIX.ark/.scp (out_prefix None: nothing is written); returns (frames, seconds).
+    Every batch runs as ONE captured graph with predicted durations (engine.BatchRunner): the host packs the phoneme ids, enqueues one H2D
+    copy, one graph launch and one D2H copy of the mel buffer + the per-utterance frame starts, and only synchronises on a batch when it
+    harvests it `depth` batches later -- no read-back of the predicted durations in the middle of a pass (rounds 1-2 did one per batch).  The
+    mels go from the pinned landing buffer straight into the ark on a writer thread (no intermediate copy on the submitting thread).
+    Utterances are sorted by length and bucketed by padded phoneme count (multiples of 16); the first batch of a bucket runs eagerly with the
+    host round trip, which both produces its mels and calibrates the bucket's capacities (decoder steps, frames, live rows per step, with
+    slack); a later batch that exceeds them is reported by the device (FCL_STATUS_*), re-run eagerly, and the bucket's capacities grow.  The
+    captured graphs stay with the model's plan: a second decode() on the same model replays them.
+    stats (dict, optional): receives `device_seconds` — first submit -> last batch complete on the GPU, excluding the ark writing."""
+    from . import engine, ops
+
     torch.manual_seed(seed)
     order = sorted(range(len(utts)), key=lambda i: -len(utts[i][1]))
     dev = next(model.parameters()).device
+    plan = model.plan(dev)
     frames = 0
-    copy_stream = torch.cuda.Stream(device=dev)
-    pinned = [None] * (depth + 1)
+    depth = max(1, int(depth))
+    cache = plan.__dict__.setdefault("_decode_cache", {})
+    streams = cache.setdefault(("streams", depth), [torch.cuda.Stream(device=dev) for _ in range(depth)])
+    pools = cache.setdefault(("pools", batch_size, depth), {})
     pending = []
+    n_eager = n_graph = n_redo = 0
 
     # the ark / scp file is written by a worker thread (file writes release the GIL): storage keeps up with the GPU instead of stalling the loop
-    wq = queue.Queue(maxsize=2 * (depth + 1))
+    wq = queue.Queue(maxsize=4 * (depth + 1))
     werr = []
 
     def writer(w):
@@ -97,56 +148,105 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=2):
             item = wq.get()
             if item is None:
                 return
+            chunk, arr, counts, slot = item
             try:
                 if not werr:
-                    for uid, arr in item:
-                        w[uid] = arr
+                    s0 = 0
+                    for (uid, _), c in zip(chunk, counts):
+                        w[uid] = arr[s0 : s0 + c]
+                        s0 += c
             except Exception as e:  # surfaced by the main thread after the join
                 werr.append(e)
+            finally:
+                if slot is not None:
+                    slot.free.set()
+
+    def eager(chunk):
+        """Host-round-trip pass (calibration / fallback): exact maps of THIS batch."""
+        prep = engine.prepare(plan, [x for _, x in chunk])
+        mel, utt_frames, inter = engine.run(plan, prep, ops.DROP_RNG, seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), return_intermediates=True)
+        arr = mel.cpu().numpy()
+        wq.put((chunk, arr, list(utt_frames), None))
+        return int(arr.shape[0]), inter["maps"]
 
     def harvest(item):
-        chunk, host, counts, ev = item
+        nonlocal n_redo
+        pool, j, chunk, slot, ev = item
         ev.synchronize()
-        arr, s0, out = host.numpy().copy(), 0, []  # one copy out of the pinned slot, which is reused `depth + 1` batches later
-        for (uid, _), c in zip(chunk, counts):
-            out.append((uid, arr[s0 : s0 + c]))
-            s0 += c
-        wq.put(out)
-        return s0
+        if int(slot.st[0]) != 0:  # a capacity of the bucket did not hold for this batch (or a phoneme got duration 0: eager() then raises like the reference)
+            pool.runners[j].status.zero_()
+            slot.free.set()
+            n_redo += 1
+            got, pool.grow = eager(chunk)
+            return got
+        f0 = slot.f0.numpy()
+        total = int(f0[len(chunk)])
+        wq.put((chunk, slot.mel.numpy()[:total], [int(v) for v in np.diff(f0[: len(chunk) + 1])], slot))
+        return total
 
-    with ArkScpWriter(out_prefix) as w, torch.cuda.device(dev):
+    class _Discard(dict):  # out_prefix None: synthesis + device-to-host hand-over only (benchmarks)
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def __setitem__(self, k, v):
+            pass
+
+    with (ArkScpWriter(out_prefix) if out_prefix is not None else _Discard()) as w, torch.cuda.device(dev):
         th = threading.Thread(target=writer, args=(w,), daemon=True)
         th.start()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for bi, s in enumerate(range(0, len(order), batch_size)):
             chunk = [utts[i] for i in order[s : s + batch_size]]
-            mels = model.inference_batch([x for _, x in chunk])  # views into one packed device buffer, utterance-major
-            counts = [int(m.shape[0]) for m in mels]
-            total = sum(counts)
-            packed = mels[0]._base if mels[0]._base is not None else torch.cat(mels)
-            packed = packed[:total]
-            slot = bi % (depth + 1)
-            if pinned[slot] is None or pinned[slot].shape[0] < total:
-                pinned[slot] = torch.empty(max(total * 5 // 4, 1), packed.shape[1], dtype=torch.float32, pin_memory=True)
-            host = pinned[slot][:total]
-            copy_stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(copy_stream):
-                host.copy_(packed, non_blocking=True)
-                packed.record_stream(copy_stream)
+            t_cap = (max(len(x) for _, x in chunk) + 15) // 16 * 16
+            pool = pools.get(t_cap)
+            if pool is not None and pool.grow is not None:  # a batch overflowed this bucket: drain it, widen the capacities, capture anew
+                for it in [p_ for p_ in pending if p_[0] is pool]:
+                    pending.remove(it)
+                    frames += harvest(it)
+                g = _grown_caps(engine, pool.grow, batch_size * t_cap, scale=1.6)
+                lmax = max(g.lmax, pool.caps.lmax)
+                caps = engine.Caps(lmax, max(g.frames, pool.caps.frames), np.full(lmax, batch_size * t_cap, np.int32))
+                pool = pools[t_cap] = _Pool(plan, batch_size, t_cap, caps, streams, seed + 31 * bi)
+            if pool is None:  # first batch of the bucket: eager pass = its result + the bucket's calibration
+                got, maps = eager(chunk)
+                frames += got
+                n_eager += 1
+                pools[t_cap] = _Pool(plan, batch_size, t_cap, _grown_caps(engine, maps, batch_size * t_cap), streams, seed + 31 * bi)
+                continue
+            j = pool.next % len(streams)
+            pool.next += 1
+            for it in [p_ for p_ in pending if p_[1] == j]:  # stream j's previous batch (of any bucket) must have left the runner's static buffers
+                pending.remove(it)
+                frames += harvest(it)
+            r = pool.runner(j)
+            slot = pool.slots[j][(pool.next // len(streams)) % 2]
+            slot.free.wait()  # the writer thread is done with what this landing buffer held
+            slot.free.clear()
+            r.load([x for _, x in chunk])
+            r.replay()
+            with torch.cuda.stream(r.stream):
+                slot.mel.copy_(r.mel, non_blocking=True)
+                slot.f0.copy_(r._frames.utt_frame0, non_blocking=True)
+                slot.st.copy_(r.status, non_blocking=True)
                 ev = torch.cuda.Event()
-                ev.record(copy_stream)
-            pending.append((chunk, host, counts, ev))
-            while len(pending) > depth:  # the slot written `depth + 1` batches ago is free again only after its harvest
-                frames += harvest(pending.pop(0))
+                ev.record(r.stream)
+            pending.append((pool, j, chunk, slot, ev))
+            n_graph += 1
         while pending:
             frames += harvest(pending.pop(0))
+        torch.cuda.synchronize()
+        dev_secs = time.perf_counter() - t0
         wq.put(None)
         th.join()
-        torch.cuda.synchronize()
         secs = time.perf_counter() - t0
         if werr:
             raise werr[0]
+    if stats is not None:
+        stats.update(device_seconds=dev_secs, eager_batches=n_eager, graph_batches=n_graph, redone_batches=n_redo, buckets=len(pools))
     return frames, secs
 
 

@@ -128,14 +128,21 @@ class Caps(object):
 class DeviceFrames(object):
     """Frame bookkeeping of a device-driven pass: utterance frame starts [B + 1] and totals live in HBM until somebody needs them on the host."""
 
-    def __init__(self, maps, caps, device):
-        self.utt_frame0, self.totals, self.caps, self.device = maps["utt_frame0"], maps["totals"], caps, device
+    def __init__(self, maps, caps, device, status=None):
+        self.utt_frame0, self.totals, self.live_rows, self.caps, self.device = maps["utt_frame0"], maps["totals"], maps["live_rows"], caps, device
+        self.status = status  # the pass's own status word (None: the per-device one)
         self._host = None
 
     def resolve(self):
         """Synchronising read: raises FclError when the pass violated a capacity or met a zero duration; returns the per-utterance frame counts."""
         if self._host is None:
-            ops.check_status(self.device)
+            if self.status is None:
+                ops.check_status(self.device)
+            else:
+                bits = int(self.status.item()) & 0xFFFFFFFF
+                if bits:
+                    self.status.zero_()
+                    raise ops._lib.FclError("fcl-taco2_amd: device status 0x%x: %s" % (bits, ops.status_message(bits)))
             f0 = self.utt_frame0.cpu().numpy()
             self._host = [int(v) for v in (f0[1:] - f0[:-1])]
         return self._host
@@ -246,7 +253,8 @@ class _DevMaps(object):
         self.order = None
 
 
-def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_algo=0, return_intermediates=False, seed_dev=None, caps=None):
+def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_algo=0, return_intermediates=False, seed_dev=None, caps=None,
+        status=None):
     """One pass of the hot path over a prepared batch.  Returns the packed mel [F, odim] (after postnet) and
     the per-utterance frame counts; with forced durations nothing here touches the host.
     caps (engine.Caps): build the row maps on the DEVICE from the durations in HBM — predicted by this pass, or forced and uploaded by
@@ -274,11 +282,12 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
                 if inter is not None:
                     inter["d_log"], inter["d_int"] = d_log, d_int
             if caps is not None:  # device-built maps over the padded [B, T] row universe: no host round trip
-                dm = ops.row_maps_build(prep.B * prep.T, prep.B, caps.lmax, caps.frames, dur_i64=d_int, dur_i32=prep.dur_pad, t_max=prep.T, pad=prep.pad)
+                dm = ops.row_maps_build(prep.B * prep.T, prep.B, caps.lmax, caps.frames, dur_i64=d_int, dur_i32=prep.dur_pad, t_max=prep.T, pad=prep.pad,
+                                        status=status)
                 rm = PreparedBatch()
                 rm.maps = _DevMaps(dm, caps)
                 rm.src_rows, rm.dur, rm.frame_off, rm.frame_lo, rm.frame_hi = dm["src_rows"], dm["dur"], dm["frame_off"], dm["frame_lo"], dm["frame_hi"]
-                frames_info = DeviceFrames(dm, caps, dev)
+                frames_info = DeviceFrames(dm, caps, dev, status)
             else:
                 if d_int is None:
                     raise ValueError("prepare(device_maps=True) leaves the row maps to the device: run() needs caps")
@@ -304,7 +313,7 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
             keep_dev = torch.from_numpy(keep).to(dev)
         before = ops.decoder_loop(plan.decoder, att_c, rm.dur, maps.live_rows, rm.frame_off, maps.n_frames,
                                   dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed, seed_dev=seed_dev, att_c_p=att_c_p, want_before_p=planes,
-                                  live_rows_dev=getattr(maps, "live_dev", None))
+                                  live_rows_dev=getattr(maps, "live_dev", None), status=status)
         n_post = len(plan.postnet)
         if planes:
             before, xp = before
@@ -427,19 +436,19 @@ class BatchRunner(object):
             p.f0e, p.maps = None, None
             self.prep = p
             self.seed_word = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)  # this runner's own status word (violations are attributed to ITS batches)
             # warm-up on a minimal valid batch (one phoneme of duration 1 per utterance), then capture
             self.load([np.ones(1, dtype=np.int64)] * self.B, [np.ones(1, dtype=np.int64)] * self.B if self.forced else None)
             with torch.cuda.stream(self.stream):
-                run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps)
+                run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
             self.stream.synchronize()
-            if self.forced:
-                ops.check_status(dev)
-            else:
-                ops.status_word(dev).zero_()  # (the warm-up ids need not predict valid durations)
+            if self.forced and int(self.status.item()):
+                raise ops._lib.FclError("fcl-taco2_amd: BatchRunner warm-up failed: %s" % ops.status_message(int(self.status.item()) & 0xFFFFFFFF))
+            self.status.zero_()  # (predicted durations: the warm-up ids need not predict valid ones)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 ops.u32_add(self.seed_word, 1)
-                self.mel, self._frames = run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps)
+                self.mel, self._frames = run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
         self.n_loaded = 0
 
     def load(self, xs, durs=None):

@@ -1,49 +1,34 @@
-"""Decode-driver throughput on a synthetic manifest (developer tool): the pipelined loop of fcl_taco2_amd.decode against a serial
-synchronise-per-batch loop (what the driver did before), forced durations so that closed-form weights give LJSpeech-like lengths."""
-import sys, time, tempfile, os
+"""Decode-driver throughput on a synthetic manifest (developer tool): fcl_taco2_amd.decode (one captured graph per batch, PREDICTED durations,
+device-built row maps, no read-back inside a pass) on 512 utterances of 60-100 phonemes; closed-form weights with the synthetic duration head
+(SYN.positive_duration_head: ~10 frames per phoneme).  Prints the end-to-end rate (incl. D2H of the mels and the Kaldi ark/scp writing) and the
+device-side rate (first submit -> last batch complete on the GPU, the 'synchronised' figure of DESIGN.md)."""
+import os
+import sys
+import tempfile
+
 sys.path.insert(0, ".")
-import numpy as np, torch
-import fcl_taco2_amd
+import numpy as np
+import torch
+
+import fcl_taco2_amd  # noqa: F401
 from fcl_taco2_amd import decode as D, hparams as HP, synthetic as SYN
 
 dev = "cuda:0"
 S, T = HP.student_hparams(), HP.teacher_hparams()
 model = SYN.build_model("student", S, T, dev).eval()
+sd = SYN.positive_duration_head(SYN.closed_form_state_dict(HP.param_spec(S, T, True)))
+model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+model = model.to(dev).eval()
 rng = np.random.RandomState(0)
-n_utt = 512
-utts, durs = [], {}
-for i in range(n_utt):
-    n = int(rng.randint(60, 101))
-    ids = rng.randint(1, S.idim, size=n).astype(np.int64)
-    utts.append(("utt%04d" % i, ids))
-    durs[ids.tobytes()] = np.clip(rng.poisson(10, size=n), 1, 50).astype(np.int64)
-orig = model.inference_batch
-model.inference_batch = lambda xs, **kw: orig(xs, durs=[durs[np.asarray(x).tobytes()] for x in xs], **kw)
-
-def serial(model, utts, out_prefix, batch_size=32):
-    from fcl_taco2_amd.kaldi_io import ArkScpWriter
-    order = sorted(range(len(utts)), key=lambda i: -len(utts[i][1]))
-    frames = 0
-    with ArkScpWriter(out_prefix) as w:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for s in range(0, len(order), batch_size):
-            chunk = [utts[i] for i in order[s : s + batch_size]]
-            mels = model.inference_batch([x for _, x in chunk])
-            torch.cuda.synchronize()
-            for (uid, _), mel in zip(chunk, mels):
-                frames += mel.shape[0]
-                w[uid] = mel.cpu().numpy()
-        secs = time.perf_counter() - t0
-    return frames, secs
-
+n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+utts = [("utt%04d" % i, rng.randint(1, S.idim, size=int(rng.randint(60, 101))).astype(np.int64)) for i in range(n_utt)]
+torch.set_num_threads(4)
 with tempfile.TemporaryDirectory() as d:
-    with torch.no_grad():
-        D.decode(model, utts[:64], os.path.join(d, "w"))  # warm-up
-        f0, s0 = serial(model, utts, os.path.join(d, "a"))
-        f1, s1 = D.decode(model, utts, os.path.join(d, "b"))
-        f2, s2 = D.decode(model, utts, os.path.join(d, "c"), depth=3)
-    print("serial    : %d frames in %.3f s = %.2f M frames/s" % (f0, s0, f0 / s0 / 1e6))
-    print("pipelined : %d frames in %.3f s = %.2f M frames/s" % (f1, s1, f1 / s1 / 1e6))
-    print("depth 3   : %d frames in %.3f s = %.2f M frames/s" % (f2, s2, f2 / s2 / 1e6))
-    a = open(os.path.join(d, "a.scp")).read().split("\n")[:2]; print("scp sample:", a[0][:60])
-
+    for depth in (2, 3, 4):
+        D.decode(model, utts, os.path.join(d, "w%d" % depth), depth=depth)  # first call: captures the buckets' graphs (kept on the model's plan)
+        st = {}
+        f, s = D.decode(model, utts, os.path.join(d, "b%d" % depth), depth=depth, stats=st)
+        f2, s2 = D.decode(model, utts, None, depth=depth)
+        print("depth %d, nothing written (synthesis + D2H of every mel): %.3f s = %.2f M frames/s" % (depth, s2, f2 / s2 / 1e6))
+        print("depth %d (graphs captured by a previous call): %d frames; end to end %.3f s = %.2f M frames/s; device side %.3f s = %.2f M frames/s; %s" %
+              (depth, f, s, f / s / 1e6, st["device_seconds"], f / st["device_seconds"] / 1e6, {k: v for k, v in st.items() if k != "device_seconds"}))
