@@ -35,7 +35,7 @@ class DecoderIO(C.Structure):
 class RowMaps(C.Structure):  # fcl_row_maps_t
     _fields_ = [("b", _I), ("n", _I), ("lmax_cap", _I), ("frames_cap", _I), ("t_max", _I)] + [
         (n, _P) for n in ("row_src", "utt_row0", "pad", "dur_i64", "dur_i32", "src_rows", "dur_sorted", "frame_off", "order", "live_rows", "utt_frame0",
-                          "frame_lo", "frame_hi", "totals", "status")]
+                          "frame_lo", "frame_hi", "totals", "status", "scratch")]
 
 
 class GemmTerm(C.Structure):

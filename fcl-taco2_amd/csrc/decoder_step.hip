@@ -113,10 +113,11 @@ __device__ __forceinline__ float drop_apply(float v, int mode, const uint8_t* ke
 
 __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a) {
     // rows of this launch: the host's counts, or -- device-driven loop -- the smaller of the host's bounds and the device's live counts
-    const int M_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat;
-    const int M_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    // device-driven loops: LOADS and the MFMA chains use the host's row bounds (rows between the device count and the bound hold stale but finite state);
+    // only the STORES are limited to the device's live-row counts -- their scalar loads are then off the kernel's critical path (first use: an epilogue)
+    const int M_feat = a.M_feat, M_pre = a.M_pre;
+    const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
     if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
-    if ((int)blockIdx.x * (16) >= (a.h1 ? M_feat : M_pre)) return;  // tile beyond the live rows (uniform per workgroup, before any barrier)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ldU = a.U + 4, ldO = a.O + 4, ldP = a.P + 4;
     float* A1 = smem;            // [16, U]  h1 tile
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
             for (int r = 0; r < 4; ++r) {
                 const int row = rq * 4 + r, m = m0 + row;
                 float v = 0.f;
-                if (m < M_feat && nc < a.O) {
+                if (m < Ms_feat && nc < a.O) {
                     v = acc[r] + f0v[r];
                     a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
                 }
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + rq * 4 + r;
-                    if (m >= M_pre) continue;
+                    if (m >= Ms_pre) continue;
                     float v = fmaxf(accv[tt][r] + bn, 0.f);
                     v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
                     a.pre_out[(size_t)m * a.P + nc] = v;
@@ -338,10 +339,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int SU, int SO, int SP>
 __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArgs a) {
     // rows of this launch: the host's counts, or -- device-driven loop -- the smaller of the host's bounds and the device's live counts
-    const int M_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat;
-    const int M_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    // device-driven loops: LOADS and the MFMA chains use the host's row bounds (rows between the device count and the bound hold stale but finite state);
+    // only the STORES are limited to the device's live-row counts -- their scalar loads are then off the kernel's critical path (first use: an epilogue)
+    const int M_feat = a.M_feat, M_pre = a.M_pre;
+    const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
     if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
-    if ((int)blockIdx.x * (16) >= (a.h1 ? M_feat : M_pre)) return;  // tile beyond the live rows (uniform per workgroup, before any barrier)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ldU = a.U + 8, ldO = a.O + 8, ldP = a.P + 8;  // bf16 elements per plane row
     u16* A1h = reinterpret_cast<u16*>(smem);
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
             for (int r = 0; r < 4; ++r) {
                 const int row = rq * 4 + r, m = m0 + row;
                 float v = 0.f;
-                if (m < M_feat && nc < a.O) {
+                if (m < Ms_feat && nc < a.O) {
                     v = accv[0][r] + f0v[r];
                     a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
                     if (a.before_p) store_p32(a.before_p, (a.O + 31) >> 5, fo[r] + a.t_prev, nc, v);
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
             const int padc = 32 - (a.O & 31);
             for (int i = threadIdx.x; i < 16 * padc; i += blockDim.x) {
                 const int m = m0 + i / padc;
-                if (m < M_feat) store_p32(a.before_p, (a.O + 31) >> 5, a.frame_off[m] + a.t_prev, a.O + i % padc, 0.f);
+                if (m < Ms_feat) store_p32(a.before_p, (a.O + 31) >> 5, a.frame_off[m] + a.t_prev, a.O + i % padc, 0.f);
             }
         }
     } else {
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + rq * 4 + r;
-                    if (m >= M_pre) continue;
+                    if (m >= Ms_pre) continue;
                     float v = fmaxf(accv[tt][r] + bn, 0.f);
                     v = drop_apply(v, a.drop_mode, a.keep1, a.P, m, nc, a.P, a.keep_scale, a.drop_p, seed1);
                     if (a.pre_out) a.pre_out[(size_t)m * a.P + nc] = v;
@@ -502,10 +504,11 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
 template <int SU, int SO, int SP, int DROP, int RT>
 __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetArgs a) {
     // rows of this launch: the host's counts, or -- device-driven loop -- the smaller of the host's bounds and the device's live counts
-    const int M_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat;
-    const int M_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    // device-driven loops: LOADS and the MFMA chains use the host's row bounds (rows between the device count and the bound hold stale but finite state);
+    // only the STORES are limited to the device's live-row counts -- their scalar loads are then off the kernel's critical path (first use: an epilogue)
+    const int M_feat = a.M_feat, M_pre = a.M_pre;
+    const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
     if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
-    if ((int)blockIdx.x * (16 * RT) >= (a.h1 ? M_feat : M_pre)) return;  // tile beyond the live rows (uniform per workgroup, before any barrier)
     constexpr int U = SU * 32, OP = SO * 32, P = SP * 32;
     constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8, ROWS = 16 * RT;
     static_assert(2 * SP <= 16, "two prenet column tiles per wave, 8 waves");
@@ -601,7 +604,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
                 const int row = q * 16 + rq * 4 + r, m = m0 + row;
                 if (fnc < O) {
                     float v = 0.f;
-                    if (m < M_feat) {
+                    if (m < Ms_feat) {
                         v = accv[0][r] + f0v[q][r];
                         a.before[(size_t)(fo[q][r] + a.t_prev) * O + fnc] = v;
                         if (a.before_p) store_p32(a.before_p, (O + 31) >> 5, fo[q][r] + a.t_prev, fnc, v);
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
         const int padc = 32 - (O & 31);
         for (int i = threadIdx.x; i < ROWS * padc; i += blockDim.x) {
             const int m = m0 + i / padc;
-            if (m < M_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
+            if (m < Ms_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
         }
     }
     if (!has_pre || a.dbg_phase == 2) return;
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + q * 16 + rq * 4 + r;
-                if (m >= M_pre) continue;
+                if (m >= Ms_pre) continue;
                 float v = fmaxf(accv[tt][r] + pb1[tt], 0.f);
                 if (DROP == 1) v = k1[q][tt][r] ? v * a.keep_scale : 0.f;
                 if (DROP == 2) {
@@ -682,8 +685,9 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
 // PRE: both terms have K = 256 (the student's decoder LSTMs) -> all 2 x 8 weight fragments are requested at kernel entry.
 template <bool PRE>
 __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a) {
-    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
-    if ((int)blockIdx.y * 16 >= M) return;      // tile beyond the live rows (uniform per workgroup, before any barrier)
+    // device-driven loops: loads and MFMAs run on the host's row bound, only the final store is limited to the device's live-row count (its scalar
+    // load is then off the critical path: first use after the K walk)
+    const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
     constexpr int KC = 512;
     __shared__ __attribute__((aligned(16))) u16 A_h[16 * (KC + 8)];
     __shared__ __attribute__((aligned(16))) u16 A_lo[16 * (KC + 8)];
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
         for (int r = 0; r < 4; ++r) g_l[g][rq * 4 + r][col] = acc[r];
     }
     __syncthreads();
-    if (!evalid) return;
+    if (!evalid || em >= Ms) return;
     const float pre[4] = {g_l[0][erow][euc], g_l[1][erow][euc], g_l[2][erow][euc], g_l[3][erow][euc]};
     cell_finish(a, em, eu, pre, ci);
 }
@@ -747,8 +751,9 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
 constexpr int SMALL_KC = 512;  // K chunk resident in LDS
 
 __device__ __forceinline__ void lstm_small_body(const LstmStepArgs& a) {
-    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
-    if ((int)blockIdx.y * 16 >= M) return;      // tile beyond the live rows (uniform per workgroup, before any barrier)
+    // device-driven loops: loads and MFMAs run on the host's row bound, only the final store is limited to the device's live-row count (its scalar
+    // load is then off the critical path: first use after the K walk)
+    const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
     __shared__ __attribute__((aligned(16))) float A_l[16 * (SMALL_KC + 4)];
     __shared__ float g_l[4][16][17];
     const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
@@ -778,7 +783,7 @@ __device__ __forceinline__ void lstm_small_body(const LstmStepArgs& a) {
     // cell epilogue: thread -> (row, unit)
     const int row = threadIdx.x >> 4, uc = threadIdx.x & 15;
     const int m = m0 + row, uu = u0 + uc;
-    if (m >= M || uu >= a.U) return;
+    if (m >= Ms || uu >= a.U) return;
     const CellIn ci = cell_prefetch(a, m, uu);
     const float pre[4] = {g_l[0][row][uc], g_l[1][row][uc], g_l[2][row][uc], g_l[3][row][uc]};
     cell_finish(a, m, uu, pre, ci);

@@ -308,8 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
     int bx, by;
     xcd_tile(bx, by);
     const int m0 = by * G::BM, u0 = bx * (16 * WN);
-    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
-    if (m0 >= M) return;                        // tile beyond the live rows (uniform per workgroup, before any barrier / LDS-DMA)
+    const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);  // device-driven loops: loads on the host's bound, stores on the device's count
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);
@@ -334,7 +333,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
-            if (m >= M) continue;
+            if (m >= Ms) continue;
             const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
             cell_finish(a, m, u, pre, ci[tm][r]);
         }

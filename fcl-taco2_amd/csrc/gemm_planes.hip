@@ -376,8 +376,9 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
     int bx, by;
     xcd_tile_p(bx, by);
     const int m0 = by * G::BM, u0 = bx * (16 * WN);
-    const int M = live_rows_of(a.M, a.m_dev);  // device-driven loops: min(host bound, device count)
-    if (m0 >= M) return;                        // tile beyond the live rows (uniform per workgroup, before any barrier / LDS-DMA)
+    // device-driven loops: the LDS-DMA stream and the MFMAs run on the host's row bound; only the write-out is limited to the device's live-row
+    // count, whose scalar load is then hidden behind the whole K loop
+    const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
         for (int r = 0; r < 4; ++r) {
             const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + rm;
             float h_w = 0.f, c_w = 0.f;
-            if (m < M && u < a.U) {
+            if (m < Ms && u < a.U) {  // (cell_math also stores the optional taps / saved gates: live rows only)
                 const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
                 cell_math(a, m, u, pre, ci[tm][r], h_w, c_w);
             }
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
             tc[rm * LDT + wn * 16 + (lane & 15)] = c_w;
         }
     __syncthreads();
-    const int rows = min(G::BM, M - m0);
+    const int rows = min(G::BM, Ms - m0);  // (<= 0: nothing to write)
     const bool vec = (a.U & 3) == 0;
     for (int i = threadIdx.x; i < rows * (UW / 4); i += G::CTHREADS) {
         const int rm = i / (UW / 4), c4 = (i - rm * (UW / 4)) * 4, uu = u0 + c4;

@@ -425,6 +425,8 @@ class BatchRunner(object):
         self._host = [torch.zeros(off, dtype=torch.uint8).pin_memory() for _ in range(depth)]
         self._host_ev = [None] * depth
         self._slot = 0
+        rows = np.arange(n, dtype=np.int32)
+        self._rows = (rows // self.T, rows - (rows // self.T) * self.T, ((rows // self.T) * self.T).astype(np.int32))
         with torch.cuda.device(dev):
             self._dev = torch.zeros(off, dtype=torch.uint8, device=dev)
             view = lambda name, dt: self._dev[self._off[name][0] : self._off[name][0] + self._off[name][1]].view(dt)
@@ -465,27 +467,28 @@ class BatchRunner(object):
             self._host_ev[j].synchronize()  # the copy that last read this staging buffer (depth loads ago)
         hb = self._host[j].numpy()
         seg = lambda name, dt: hb[self._off[name][0] : self._off[name][0] + self._off[name][1]].view(dt)
-        ids, dur, lens = seg("ids", np.int64).reshape(B, T), seg("dur", np.int32).reshape(B, T), seg("lens", np.int32)
+        ids, dur, lens = seg("ids", np.int64), seg("dur", np.int32), seg("lens", np.int32)
+        as_np = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        xs = [as_np(x).reshape(-1) for x in xs]
+        ln = np.fromiter((x.shape[0] for x in xs), np.int32, nb)
+        if int(ln.max()) > T or int(ln.min()) < 1:
+            raise ValueError("BatchRunner: utterances of %d..%d phonemes, capacity %d" % (int(ln.min()), int(ln.max()), T))
+        lens[:nb] = ln
+        lens[nb:] = 0
+        b_of, t_of, base = self._rows
+        lfull = lens[:B][b_of]
+        valid = t_of < lfull  # the non-padded rows, row-major: exactly the order of the concatenated utterances
         ids[:] = 0
-        dur[:] = 0
-        lens[:] = 0
-        for b in range(nb):
-            x = xs[b].cpu().numpy() if torch.is_tensor(xs[b]) else np.asarray(xs[b])
-            k = x.shape[0]
-            if k > T or k == 0:
-                raise ValueError("BatchRunner: utterance of %d phonemes, capacity %d" % (k, T))
-            ids[b, :k] = x
-            lens[b] = k
-            if durs is not None:
-                d = np.asarray(durs[b]).reshape(-1)
-                if d.shape[0] != k:
-                    raise ValueError("duration count != phoneme count")
-                dur[b, :k] = d
-        rows = np.arange(n, dtype=np.int32)
-        b_of = rows // T
-        seg("seg_lo", np.int32)[:] = b_of * T
-        seg("seg_hi", np.int32)[:] = b_of * T + lens[:B][b_of]
-        seg("pad", np.uint8)[:] = (rows - b_of * T) >= lens[:B][b_of]
+        ids[valid] = np.concatenate(xs)
+        if durs is not None:
+            dcat = np.concatenate([np.asarray(d).reshape(-1) for d in durs])
+            if dcat.shape[0] != int(ln.sum()) or any(np.asarray(d).size != k for d, k in zip(durs, ln)):
+                raise ValueError("duration count != phoneme count")
+            dur[:] = 0
+            dur[valid] = dcat
+        seg("seg_lo", np.int32)[:] = base
+        np.add(base, lfull, out=seg("seg_hi", np.int32))
+        np.logical_not(valid, out=seg("pad", np.uint8).view(np.bool_))
         with torch.cuda.stream(self.stream):
             self._dev.copy_(self._host[j], non_blocking=True)
             ev = torch.cuda.Event()

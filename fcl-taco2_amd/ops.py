@@ -291,7 +291,8 @@ def row_maps_build(n, b, lmax_cap, frames_cap, dur_i64=None, dur_i32=None, row_s
     ref = dur_i64 if dur_i64 is not None else dur_i32
     dev = ref.device
     # one allocation for all the maps (a graph-private pool then holds one block; slices are 16-byte aligned)
-    sizes = dict(src_rows=n, dur=n, frame_off=n, live_rows=lmax_cap + 1, utt_frame0=b + 1, frame_lo=frames_cap, frame_hi=frames_cap, totals=4)
+    sizes = dict(src_rows=n, dur=n, frame_off=n, live_rows=lmax_cap + 1, utt_frame0=b + 1, frame_lo=frames_cap, frame_hi=frames_cap, totals=4,
+                 scratch=2 * n)
     if want_order:
         sizes["order"] = n
     offs, tot = {}, 0
@@ -306,7 +307,7 @@ def row_maps_build(n, b, lmax_cap, frames_cap, dur_i64=None, dur_i32=None, row_s
                      dur_sorted=_p(out["dur"], torch.int32), frame_off=_p(out["frame_off"], torch.int32),
                      order=_p(out.get("order"), torch.int32), live_rows=_p(out["live_rows"], torch.int32), utt_frame0=_p(out["utt_frame0"], torch.int32),
                      frame_lo=_p(out["frame_lo"], torch.int32), frame_hi=_p(out["frame_hi"], torch.int32), totals=_p(out["totals"], torch.int32),
-                     status=st.data_ptr())
+                     status=st.data_ptr(), scratch=_p(out["scratch"], torch.int32))
     check(_lib.load().fcl_row_maps_build(C.byref(a), _stream()))
     return out
 

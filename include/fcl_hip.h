@@ -297,7 +297,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
  *        frame_lo / frame_hi [frames_cap]         : utterance frame range of every frame row (0, 0 beyond the total): the postnet's segment bounds
  *        totals[0] = total frames, totals[1] = max duration, totals[2] = zero-duration rows
  *      Violations are reported in *status (FCL_STATUS_ZERO_DURATION / LMAX_CAP / FRAMES_CAP) and live_rows is then zeroed, so a decoder loop
- *      driven by these maps does nothing instead of writing out of bounds.  Two launches, O(N) work per thread (N <= ~1e5). */
+ *      driven by these maps does nothing instead of writing out of bounds.  Two launches. */
 typedef struct {
     int b, n;                   /* utterances; rows of the row universe (see row_src) */
     int lmax_cap, frames_cap;
@@ -320,6 +320,8 @@ typedef struct {
     int32_t* frame_hi;          /* [frames_cap] */
     int32_t* totals;            /* [4] */
     uint32_t* status;           /* device status word, OR-ed */
+    int32_t* scratch;           /* optional [2 N] workspace: with it and lmax_cap <= 254 the maps are built by a one-workgroup COUNTING sort (O(N):
+                                 * wave-ballot ranks per duration value, block scans), a few microseconds; without it by the O(N^2 / threads) form */
 } fcl_row_maps_t;
 int fcl_row_maps_build(const fcl_row_maps_t* maps, fcl_stream_t stream);
 
