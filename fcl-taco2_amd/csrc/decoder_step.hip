@@ -118,6 +118,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
     const int M_feat = a.M_feat, M_pre = a.M_pre;
     const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
     if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * (16) >= (a.h1 ? Ms_feat : Ms_pre)) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ldU = a.U + 4, ldO = a.O + 4, ldP = a.P + 4;
     float* A1 = smem;            // [16, U]  h1 tile
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     const int M_feat = a.M_feat, M_pre = a.M_pre;
     const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
     if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * (16) >= (a.h1 ? Ms_feat : Ms_pre)) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ldU = a.U + 8, ldO = a.O + 8, ldP = a.P + 8;  // bf16 elements per plane row
     u16* A1h = reinterpret_cast<u16*>(smem);
@@ -509,6 +511,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     const int M_feat = a.M_feat, M_pre = a.M_pre;
     const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
     if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * (16 * RT) >= (a.h1 ? Ms_feat : Ms_pre)) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier)
     constexpr int U = SU * 32, OP = SO * 32, P = SP * 32;
     constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8, ROWS = 16 * RT;
     static_assert(2 * SP <= 16, "two prenet column tiles per wave, 8 waves");
@@ -688,6 +691,7 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
     // device-driven loops: loads and MFMAs run on the host's row bound, only the final store is limited to the device's live-row count (its scalar
     // load is then off the critical path: first use after the K walk)
     const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
+    if ((int)blockIdx.y * 16 >= Ms) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier): a step of a loose bound costs a launch, not a pass
     constexpr int KC = 512;
     __shared__ __attribute__((aligned(16))) u16 A_h[16 * (KC + 8)];
     __shared__ __attribute__((aligned(16))) u16 A_lo[16 * (KC + 8)];
@@ -754,6 +758,7 @@ __device__ __forceinline__ void lstm_small_body(const LstmStepArgs& a) {
     // device-driven loops: loads and MFMAs run on the host's row bound, only the final store is limited to the device's live-row count (its scalar
     // load is then off the critical path: first use after the K walk)
     const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
+    if ((int)blockIdx.y * 16 >= Ms) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier): a step of a loose bound costs a launch, not a pass
     __shared__ __attribute__((aligned(16))) float A_l[16 * (SMALL_KC + 4)];
     __shared__ float g_l[4][16][17];
     const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;

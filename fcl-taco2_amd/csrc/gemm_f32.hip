@@ -309,6 +309,7 @@ __global__ __launch_bounds__(64 * WM * WN) void lstm_step_kernel(const LstmStepA
     xcd_tile(bx, by);
     const int m0 = by * G::BM, u0 = bx * (16 * WN);
     const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);  // device-driven loops: loads on the host's bound, stores on the device's count
+    if (m0 >= Ms) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);

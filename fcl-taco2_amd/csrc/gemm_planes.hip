@@ -379,6 +379,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
     // device-driven loops: the LDS-DMA stream and the MFMAs run on the host's row bound; only the write-out is limited to the device's live-row
     // count, whose scalar load is then hidden behind the whole K loop
     const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
+    if (m0 >= Ms) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier / LDS-DMA)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int u = u0 + wn * 16 + (lane & 15);
