@@ -92,6 +92,13 @@ class PwgLayer(C.Structure):  # fcl_pwg_layer_t
                           "kp", "pt_a", "pt_b")] + [("ld_pt", C.c_int32), ("hop", C.c_int32)]
 
 
+class BernoulliSite(C.Structure):  # fcl_bernoulli_site_t
+    _fields_ = [("out", _P), ("n", C.c_int64), ("p_one", _F), ("seed", C.c_uint32)]
+
+
+BERNOULLI_MAX_SITES = 16
+
+
 class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
 
@@ -142,6 +149,7 @@ SIGNATURES = {
     "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scale": (_I, [_P, _Z, _F, _P]),
     "fcl_bernoulli_u8": (_I, [_P, _Z, _F, C.c_uint32, _P, _P]),
+    "fcl_bernoulli_batch": (_I, [C.POINTER(BernoulliSite), _I, _P]),
     "fcl_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _F, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "fcl_scatter_add_rows": (_I, [_P, _P, _P, _I, _I, C.c_int64, _P]),
     "fcl_transpose2d": (_I, [_P, _P, _I, _I, _P]),

@@ -538,6 +538,33 @@ __global__ void bernoulli_u8_kernel(uint8_t* __restrict__ out, long long n, unsi
     }
 }
 
+// fcl_bernoulli_batch: the sites travel as kernel arguments; a workgroup draws 4 096 consecutive bytes of one site
+struct BernBatch {
+    int n;
+    unsigned char* out[FCL_BERNOULLI_MAX_SITES];
+    long long len[FCL_BERNOULLI_MAX_SITES];
+    unsigned int thresh[FCL_BERNOULLI_MAX_SITES], seed[FCL_BERNOULLI_MAX_SITES];
+    int first_block[FCL_BERNOULLI_MAX_SITES + 1];
+};
+
+__global__ __launch_bounds__(256) void bernoulli_batch_kernel(const BernBatch b) {
+    int k = 0;
+    while (k + 1 < b.n && b.first_block[k + 1] <= (int)blockIdx.x) ++k;
+    const long long i0 = (long long)((int)blockIdx.x - b.first_block[k]) * 4096;
+    const unsigned int s = hash_u32(b.seed[k]);
+    unsigned char* out = b.out[k];
+    const long long n = b.len[k];
+    const unsigned int thresh = b.thresh[k];
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const long long i = i0 + j * 256 + threadIdx.x;
+        if (i < n) {
+            const unsigned int h = hash_u32(hash_u32((unsigned int)i ^ s) + (unsigned int)(i >> 32) * 0x9e3779b9U);
+            out[i] = (h >> 8) < thresh ? 1 : 0;
+        }
+    }
+}
+
 __global__ void scale_kernel(float* __restrict__ x, long long n, float alpha) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) x[i] *= alpha;
 }
@@ -777,6 +804,28 @@ int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const u
     const unsigned int thresh = (unsigned int)((double)p_one * 16777216.0 + 0.5);  // 24-bit uniform
     hipLaunchKernelGGL(bernoulli_u8_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, thresh, seed, seed_dev);
     return check_hip(hipGetLastError(), "bernoulli_u8");
+}
+
+int fcl_bernoulli_batch(const fcl_bernoulli_site_t* sites, int n_sites, fcl_stream_t stream) {
+    FCL_REQUIRE(n_sites >= 0 && n_sites <= FCL_BERNOULLI_MAX_SITES && (n_sites == 0 || sites), FCL_ERR_INVALID, "bernoulli_batch: 0 .. %d sites", FCL_BERNOULLI_MAX_SITES);
+    BernBatch b = {};
+    int blocks = 0;
+    for (int k = 0; k < n_sites; ++k) {
+        FCL_REQUIRE(sites[k].out && sites[k].n >= 0 && sites[k].p_one >= 0.f && sites[k].p_one <= 1.f, FCL_ERR_INVALID, "bernoulli_batch: bad site %d", k);
+        if (sites[k].n == 0) continue;
+        FCL_REQUIRE(sites[k].n < (1LL << 42), FCL_ERR_SHAPE, "bernoulli_batch: site too large");
+        b.out[b.n] = sites[k].out;
+        b.len[b.n] = sites[k].n;
+        b.thresh[b.n] = (unsigned int)((double)sites[k].p_one * 16777216.0 + 0.5);
+        b.seed[b.n] = sites[k].seed;
+        b.first_block[b.n] = blocks;
+        blocks += (int)((sites[k].n + 4095) / 4096);
+        ++b.n;
+    }
+    if (b.n == 0) return 0;
+    b.first_block[b.n] = blocks;
+    hipLaunchKernelGGL(bernoulli_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+    return check_hip(hipGetLastError(), "bernoulli_batch");
 }
 
 int fcl_scale(float* x, size_t n, float alpha, fcl_stream_t stream) {

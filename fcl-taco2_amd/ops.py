@@ -488,6 +488,33 @@ def bernoulli_u8(shape, p_one, seed, device, seed_dev=None):
     return out
 
 
+def bernoulli_batch(sites, device):
+    """sites: [(shape, p_one, seed)] -> list of uint8 masks, byte for byte what bernoulli_u8 would draw for each, in as few launches as the
+    per-launch site limit allows (one, for the groups a training forward asks for) and one allocation."""
+    if not sites:
+        return []
+    sizes = []
+    for shape, _, _ in sites:
+        n = 1
+        for v in shape:
+            n *= int(v)
+        sizes.append(n)
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (n + 255) // 256 * 256
+    buf = torch.empty(tot, device=device, dtype=torch.uint8)
+    outs = [buf[o : o + n].view(tuple(shape)) for o, n, (shape, _, _) in zip(offs, sizes, sites)]
+    lib = _lib.load()
+    for k0 in range(0, len(sites), _lib.BERNOULLI_MAX_SITES):
+        grp = sites[k0 : k0 + _lib.BERNOULLI_MAX_SITES]
+        arr = (_lib.BernoulliSite * len(grp))()
+        for j, (shape, p_one, seed) in enumerate(grp):
+            arr[j].out, arr[j].n, arr[j].p_one, arr[j].seed = outs[k0 + j].data_ptr(), sizes[k0 + j], float(p_one), seed & 0xFFFFFFFF
+        check(lib.fcl_bernoulli_batch(arr, len(grp), _stream()))
+    return outs
+
+
 def lstm_cell_bwd(gates, c_old, c_new, dh_out, dc_out, zoneout, zone_keep_h=None, zone_keep_c=None, row_len=None, step=0, out=None, dh_out2=None):
     m, u = c_old.shape
     if out is not None:

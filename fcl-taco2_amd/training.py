@@ -276,6 +276,36 @@ class LossReport(dict):
             self._extra[k] = v
 
 
+class ZeroArena(object):
+    """Zero-initialised scratch of one training step from ONE buffer cleared by ONE launch: a step used to issue ~90 fill launches for its
+    accumulation targets (per-layer dbeta / dgamma / packed dW / scatter targets / loss sums: torch.zeros each).  take() bumps a pointer; begin()
+    -- called when a step starts, i.e. after the previous step's side-stream consumers were joined -- clears what the previous step used.  The
+    first step (and any step that outgrows the buffer) falls back to torch.zeros and sizes the buffer for the next one."""
+
+    def __init__(self, device):
+        self.device, self.buf, self.used, self.want = device, None, 0, 0
+
+    def begin(self):
+        need = self.want
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.zeros(max(need * 5 // 4, 1 << 20), dtype=torch.uint8, device=self.device) if need else None
+        elif self.used:
+            self.buf[: self.used].zero_()
+        self.used, self.want = 0, 0
+
+    def take(self, shape, dtype=torch.float32):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        nbytes = (n * torch.empty(0, dtype=dtype).element_size() + 255) // 256 * 256
+        self.want += nbytes
+        if self.buf is None or self.used + nbytes > self.buf.numel():
+            return torch.zeros(tuple(shape), dtype=dtype, device=self.device)
+        out = self.buf[self.used : self.used + nbytes].view(dtype)[:n].view(tuple(shape))
+        self.used += nbytes
+        return out
+
+
 _DW_PLANES_MIN = int(os.environ.get("FCL_DW_PLANES_MIN", str(1 << 20)))  # output elements from which a weight gradient runs on transposed planes
 
 
@@ -309,6 +339,8 @@ class TrainEngine(object):
         self.buckets = GradBuckets(self.gflat, bounds, group)
         self.B = dict(model.named_buffers())
         self.lr, self.eps, self.betas, self.grad_clip, self.accum_grad = lr, eps, betas, grad_clip, int(accum_grad)
+        self.arena = ZeroArena(self.dev)
+        self._z = self.arena.take
         self.forward_count, self.seed = 0, int(seed)
         if amp not in (None, "bf16"):
             raise ValueError("amp must be None or 'bf16'")
@@ -467,6 +499,14 @@ class TrainEngine(object):
         tag = zlib.crc32(repr(name).encode()) & 0x7FFFFFFF
         return ops.bernoulli_u8(shape, p_one, self.seed * 7919 + c.draw * 104729 + tag, self.dev)
 
+    def _keeps(self, c, sites):
+        """[(name, shape, p_one)] -> masks: what _keep would return for each site (same seeds, same bytes), drawn in ONE launch per group of sites
+        (ops.bernoulli_batch) instead of one each: a train-mode forward has ~22 sites."""
+        if c.masks is not None:
+            return [self._keep(c, name, shape, p) for name, shape, p in sites]
+        seeds = [self.seed * 7919 + c.draw * 104729 + (zlib.crc32(repr(name).encode()) & 0x7FFFFFFF) for name, _, _ in sites]
+        return ops.bernoulli_batch([(shape, p, sd) for (_, shape, p), sd in zip(sites, seeds)], self.dev)
+
     # ------------------------------------------------------------------------------------------------ layers
     def _wt(self, w):
         rec = self._recipe_of(w)
@@ -547,7 +587,7 @@ class TrainEngine(object):
         else:
             dz = dy
         if c.train:
-            dbeta, dgamma = torch.zeros(cout, device=self.dev), torch.zeros(cout, device=self.dev)
+            dbeta, dgamma = self._z((cout,)), self._z((cout,))
             ops.colsum(dz, dbeta)
             ops.colsum(dz, dgamma, y=cc["z"], gamma=cc["invstd"], beta=cc["mean"], mode=3)
             ops.add2d(G[pre + ".1.bias"].reshape(1, -1), dbeta.reshape(1, -1))
@@ -564,7 +604,7 @@ class TrainEngine(object):
             if eval_affine:
                 ops.colsum(dz, G[pre + ".1.bias"])
                 ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
-            dwp = torch.zeros(k, cout, cin, device=self.dev)
+            dwp = self._z((k, cout, cin))
             self._dw_gemm(dz, [(cc["x"], dwp)], taps=(k, cc["lo"], cc["hi"]))
             ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
 
@@ -596,19 +636,22 @@ class TrainEngine(object):
 
         def dw():
             ops.colsum(dz, G[pre + ".bias"])
-            dwp = torch.zeros(k, cout, cin, device=self.dev)
+            dwp = self._z((k, cout, cin))
             self._dw_gemm(dz, [(cc["x"], dwp)], taps=(k, cc["lo"], cc["hi"]))
             ops.unpack_conv1d_grad(dwp, G[pre + ".weight"])
 
         self._dw(dw)
         return self._conv_dx(dz, dzp, cc["wt"], pre, cc["lo"], cc["hi"])
 
-    def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad, hs_p=None):
+    def _predictor_fwd(self, c, hs, name, layers, p_drop, lo, hi, pad, hs_p=None, keeps=None):
         caches, x, xp, out = [], hs, hs_p, None
         for i in range(layers):
             y, cc = self._conv_bias_relu_fwd(x, "%s.conv.%d.0" % (name, i), lo, hi, need_t=c.save, xp=xp)
             last = i == layers - 1
-            keep = self._keep(c, (name, i), tuple(y.shape), 1.0 - p_drop) if (c.train and p_drop > 0) else None
+            if keeps is not None:
+                keep = keeps[i]
+            else:
+                keep = self._keep(c, (name, i), tuple(y.shape), 1.0 - p_drop) if (c.train and p_drop > 0) else None
             ks = 1.0 / (1.0 - p_drop) if keep is not None else 1.0
             g, b = self.P["%s.conv.%d.2.weight" % (name, i)], self.P["%s.conv.%d.2.bias" % (name, i)]
             wantp = hs_p is not None and not last and y.shape[1] % 32 == 0
@@ -660,14 +703,14 @@ class TrainEngine(object):
                 gx.append(ops.linear(x, P["enc.blstm.weight_ih_l0" + sfx], bias))  # [B*T, 4H]
             whh.append(P["enc.blstm.weight_hh_l0" + sfx])
             # gates, c_new, c_old, h_old (t-major); zero-filled: dead cells are never written but are read by the batched weight-gradient GEMM
-            sv.append([torch.zeros(T, B, 4 * H, device=dev)] + [torch.zeros(T, B, H, device=dev) for _ in range(3)])
+            sv.append([self._z((T, B, 4 * H))] + [self._z((T, B, H)) for _ in range(3)])
         ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv, status=self.status)
         return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev, perm=perm), (ops.pack_planes(out) if use_p else None)
 
     def _bilstm_bwd(self, d_out, c):
         P, G, dev = self.P, self.G, self.dev
         B, T, H = c["B"], c["T"], self.hp.eunits // 2
-        dx = torch.zeros_like(c["x"])
+        dx = self._z(c["x"].shape)
         perm = c["perm"]  # (b, t) row -> t-major row of the saved / gradient tensors
         sfxs = ("", "_reverse")
         dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in sfxs]  # d_out is already zero on padded rows (masked by the caller); dead cells get dg = 0
@@ -679,7 +722,7 @@ class TrainEngine(object):
             def dw(dg2=dg2, dgx=dgx, d=d, sfx=sfx):
                 ops.gemm_tn(dg2, c["dirs"][d][3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
                 ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
-                db = torch.zeros(1, 4 * H, device=dev)
+                db = self._z((1, 4 * H))
                 ops.colsum(dgx, db.reshape(-1))
                 ops.add2d(G["enc.blstm.bias_ih_l0" + sfx].reshape(1, -1), db)
                 ops.add2d(G["enc.blstm.bias_hh_l0" + sfx].reshape(1, -1), db)
@@ -734,30 +777,44 @@ class TrainEngine(object):
         else:
             c.emb = ops.embedding(c.xs, P["enc.embed.weight"])
         x, c.conv_c, c.enc_taps = c.emb, [], [c.emb]
+        enc_keeps = (self._keeps(c, [(("enc.convs", i), (B * T, hp.econv_chans), 1.0 - p_conv) for i in range(hp.econv_layers)]) if drop_conv
+                     else [None] * hp.econv_layers)
         for i in range(hp.econv_layers):
-            keep = self._keep(c, ("enc.convs", i), (B * T, hp.econv_chans), 1.0 - p_conv) if drop_conv else None
+            keep = enc_keeps[i]
             r = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep, xp=xp, want_planes=pl)
             x, cc, xp = r if len(r) == 3 else (r[0], r[1], None)
             c.conv_c.append(cc)
             c.enc_taps.append(x)
         c.hs, c.bl_c, hs_p = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save, perm=c.perm_tb, xp=xp)
-        # ---- predictors + embeds
+        # ---- predictors + embeds (their dropout masks: one launch for all of them)
+        p_emb = hp.variance_embed_dropout_rate
+        pk = {}
+        if c.train:
+            sites = []
+            for nm, layers, chans, pd_ in (("duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_chans, hp.duration_predictor_dropout_rate),
+                                           ("pitch_predictor", hp.variance_predictor_layers, hp.variance_predictor_chans, hp.variance_predictor_dropout_rate),
+                                           ("energy_predictor", hp.variance_predictor_layers, hp.variance_predictor_chans, hp.variance_predictor_dropout_rate)):
+                if pd_ > 0:
+                    sites += [((nm, i), (B * T, chans), 1.0 - pd_) for i in range(layers)]
+            if p_emb > 0:
+                sites += [(("pitch_embed",), (B * T, C), 1.0 - p_emb), (("energy_embed",), (B * T, C), 1.0 - p_emb)]
+            pk = dict(zip([st[0] for st in sites], self._keeps(c, sites)))
+        pkeeps = lambda nm, layers: [pk.get((nm, i)) for i in range(layers)]
         c.d_outs, c.dur_c = self._predictor_fwd(c, c.hs, "duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_dropout_rate,
-                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p)
+                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("duration_predictor", hp.duration_predictor_layers))
         c.p_outs, c.pit_c = self._predictor_fwd(c, c.hs, "pitch_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
-                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p)
+                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("pitch_predictor", hp.variance_predictor_layers))
         c.e_outs, c.en_c = self._predictor_fwd(c, c.hs, "energy_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
-                                               c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p)
+                                               c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("energy_predictor", hp.variance_predictor_layers))
         c.f0 = batch["f0"][:, :T].to(dev).float().reshape(-1).contiguous()
         c.en = batch["energy"][:, :T].to(dev).float().reshape(-1).contiguous()
         c.ds = batch["extras"][:, :T].to(dev).float().reshape(-1).contiguous()
         kk = hp.variance_embed_kernel_size
         att, pe, ee = ops.variance_embed_add(c.hs, c.f0, c.en, P["pitch_embed.0.weight"].reshape(C, kk), P["pitch_embed.0.bias"],
                                              P["energy_embed.0.weight"].reshape(C, kk), P["energy_embed.0.bias"], c.e_lo, c.e_hi, want_embs=True)
-        p_emb = hp.variance_embed_dropout_rate
         c.emb_keep, c.emb_ks = (None, None), 1.0
         if c.train and p_emb > 0:
-            c.emb_keep = (self._keep(c, ("pitch_embed",), (B * T, C), 1.0 - p_emb), self._keep(c, ("energy_embed",), (B * T, C), 1.0 - p_emb))
+            c.emb_keep = (pk[("pitch_embed",)], pk[("energy_embed",)])
             c.emb_ks = 1.0 / (1.0 - p_emb)
             pe, ee = ops.act_fwd(pe, ops.ACT_NONE, c.emb_keep[0], c.emb_ks), ops.act_fwd(ee, ops.ACT_NONE, c.emb_keep[1], c.emb_ks)
             att = ops.add2d(ops.add2d(c.hs.clone(), pe), ee)
@@ -782,9 +839,13 @@ class TrainEngine(object):
             if c.masks is not None:
                 pk = np.asarray(c.masks["prenet"])
                 c.k0, c.k1 = self._cells(c, pk[:, 0]), self._cells(c, pk[:, 1])
-            else:
-                c.k0 = self._keep(c, ("prenet", 0), (F, Pn), 1.0 - hp.dropout_rate)
-                c.k1 = self._keep(c, ("prenet", 1), (F, Pn), 1.0 - hp.dropout_rate)
+            else:  # (with the zoneout masks of a train-mode pass: one launch for the decoder's six mask tensors)
+                sites = [(("prenet", 0), (F, Pn), 1.0 - hp.dropout_rate), (("prenet", 1), (F, Pn), 1.0 - hp.dropout_rate)]
+                if c.train and float(hp.zoneout_rate) > 0:
+                    sites += [(("zoneout", l, j), (F, U), float(hp.zoneout_rate)) for l in range(2) for j in range(2)]
+                dk = self._keeps(c, sites)
+                c.k0, c.k1 = dk[0], dk[1]
+                c.zk_pre = [[dk[2 + 2 * l + j] for j in range(2)] for l in range(2)] if len(dk) == 6 else None
         w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
         p1d_p = None
         if dpl:
@@ -818,8 +879,10 @@ class TrainEngine(object):
             if c.masks is not None:
                 zm = np.asarray(c.masks["zoneout"])
                 c.zk = [[self._cells(c, zm[:, l, j]) for j in range(2)] for l in range(2)]
+            elif getattr(c, "zk_pre", None) is not None:
+                c.zk = c.zk_pre
             else:
-                c.zk = [[self._keep(c, ("zoneout", l, j), (F, U), c.zr) for j in range(2)] for l in range(2)]
+                c.zk = [[dk_ for dk_ in self._keeps(c, [(("zoneout", l, j), (F, U), c.zr) for j in range(2)])] for l in range(2)]
         c.S0 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
         c.S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
         c.h0_all, c.h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
@@ -842,9 +905,11 @@ class TrainEngine(object):
         # ---- postnet
         x, c.post_c, c.post_taps = c.before, [], []
         n_post = hp.postnet_layers
+        post_keeps = (self._keeps(c, [(("postnet", i), (B * L, hp.odim if i == n_post - 1 else hp.postnet_chans), 1.0 - p_conv) for i in range(n_post)])
+                      if drop_conv else [None] * n_post)
         for i in range(n_post):
             cout = hp.odim if i == n_post - 1 else hp.postnet_chans
-            keep = self._keep(c, ("postnet", i), (B * L, cout), 1.0 - p_conv) if drop_conv else None
+            keep = post_keeps[i]
             r = self._conv_bn_fwd(c, x, "dec.postnet.postnet.%d" % i, c.f_lo, c.f_hi, ops.ACT_NONE if i == n_post - 1 else ops.ACT_TANH, keep,
                                   xp=xp, want_planes=pl and i < n_post - 1)
             x, cc, xp = r if len(r) == 3 else (r[0], r[1], None)
@@ -872,7 +937,7 @@ class TrainEngine(object):
         """Named losses into one device buffer + the gradient every loss term injects at its tap (c.inj[name])."""
         dev, P, G, hp = self.dev, self.P, self.G, self.hp
         nf, ne = c.n_frames * hp.odim, c.n_enc
-        sums = torch.zeros(48, 3, dtype=torch.float64, device=dev)
+        sums = self._z((48, 3), torch.float64)
         names = []
 
         def term(name, a, b, valid, count, w_l1, w_mse, b_log=None, da=None):
@@ -961,7 +1026,7 @@ class TrainEngine(object):
         dh1_all = ops.linear(d_out_cells, self._wt(c.wf_h))  # [F, U]
         if "h1" in inj:
             ops.add2d(dh1_all, inj["h1"])
-        dF0 = torch.zeros(N, hp.odim, device=dev)
+        dF0 = self._z((N, hp.odim))
         ops.scatter_add_rows(d_out_cells, c.cell_row_i64, dF0)
         self._dw(lambda: ops.gemm_tn(dF0, c.att_c, g_wf[:, U:]))
         d_att_c = ops.linear(dF0, self._wt(c.wf_att))
@@ -982,17 +1047,17 @@ class TrainEngine(object):
         def dw_cells():  # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
             self._dw_gemm(dg1_all, [(c.h0_all, G["dec.lstm.1.cell.weight_ih"]), (S1[3], G["dec.lstm.1.cell.weight_hh"])])
             for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
-                db = torch.zeros(1, 4 * U, device=dev)
+                db = self._z((1, 4 * U))
                 ops.colsum(dg, db.reshape(-1))
                 ops.add2d(G["dec.lstm.%d.cell.bias_ih" % l].reshape(1, -1), db)
                 ops.add2d(G["dec.lstm.%d.cell.bias_hh" % l].reshape(1, -1), db)
             self._dw_gemm(dg0_all, [(S0[3], G["dec.lstm.0.cell.weight_hh"]), (c.p1d, g_ih0[:, C : C + Pn])])
-            dw0_pos4 = torch.zeros(4 * U, 4, device=dev)
+            dw0_pos4 = self._z((4 * U, 4))
             ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
             ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
 
         self._dw(dw_cells)
-        dG0 = torch.zeros(N, 4 * U, device=dev)
+        dG0 = self._z((N, 4 * U))
         ops.scatter_add_rows(dg0_all, c.cell_row_i64, dG0)
         self._dw(lambda: ops.gemm_tn(dG0, c.att_c, g_ih0[:, :C]))
         ops.add2d(d_att_c, ops.linear(dG0, self._wt(c.w0_att)))
@@ -1024,11 +1089,11 @@ class TrainEngine(object):
                 d_e = ops.act_bwd(d_e, None, ops.ACT_NONE, keep, c.emb_ks)
             def dw_embed(nm=nm, sig=sig, d_e=d_e):
                 ops.colsum(d_e, G[nm + "_embed.0.bias"])
-                sig4 = torch.zeros(B * T, 4, device=dev)
+                sig4 = self._z((B * T, 4))
                 ops.copy2d(sig4[:, :1], sig.reshape(-1, 1))
                 gw = G[nm + "_embed.0.weight"].reshape(C, kk)
                 for j in range(kk):
-                    tmp = torch.zeros(C, 4, device=dev)
+                    tmp = self._z((C, 4))
                     ops.gemm_tn(d_e, sig4, tmp, shift=j - (kk - 1) // 2, seg_lo=c.e_lo, seg_hi=c.e_hi)
                     ops.add2d(gw[:, j : j + 1], tmp[:, :1])
 
@@ -1041,7 +1106,7 @@ class TrainEngine(object):
         # ---- encoder
         if "hs" in inj:
             ops.add2d(d_hs, inj["hs"])
-        d_hs_live = ops.add2d(torch.zeros_like(d_hs), d_hs, row_valid=c.enc_valid)  # pad_packed_sequence: padded outputs are constants
+        d_hs_live = ops.add2d(self._z(d_hs.shape), d_hs, row_valid=c.enc_valid)  # pad_packed_sequence: padded outputs are constants
         dx = self._bilstm_bwd(d_hs_live, c.bl_c)
         for i in range(len(c.conv_c) - 1, -1, -1):
             if "enc%d" % (i + 1) in inj:
@@ -1062,6 +1127,7 @@ class TrainEngine(object):
             raise ValueError("mode must be 'eval' or 'train'")
         c = _Ctx()
         c.train, c.masks, c.save, c.reduce = mode == "train", masks, save, reduce
+        self.arena.begin()  # (every consumer of the previous pass's scratch has been joined: _backward ends with _join_dw())
         self.forward_count += 1
         c.draw = self.forward_count
         self._maps(c, batch)

@@ -468,6 +468,16 @@ int fcl_scale(float* x, size_t n, float alpha, fcl_stream_t stream);
 /* out[i] = 1 with probability p_one: counter hash of (seed + *seed_dev, i).  The training path's source of dropout keep masks
  * (p_one = 1 - p) and zoneout keep-old masks (p_one = zoneout rate); not bit-compatible with torch's Philox stream by design. */
 int fcl_bernoulli_u8(uint8_t* out, size_t n, float p_one, uint32_t seed, const uint32_t* seed_dev, fcl_stream_t stream);
+/* Up to FCL_BERNOULLI_MAX_SITES masks in ONE launch (a training forward draws ~22 of them: one launch per site was ~10 % of its launches):
+ * site k gets exactly the bytes fcl_bernoulli_u8(out, n, p_one, seed, NULL) would write.  `sites` is a HOST array (passed to the kernel by value). */
+#define FCL_BERNOULLI_MAX_SITES 16
+typedef struct {
+    uint8_t* out;
+    int64_t n;
+    float p_one;
+    uint32_t seed;
+} fcl_bernoulli_site_t;
+int fcl_bernoulli_batch(const fcl_bernoulli_site_t* sites, int n_sites, fcl_stream_t stream);
 /* LSTMCell + zoneout backward of one step from the forward's saved gate activations [M,4U] (i,f,g,o), c_old and c_new (raw):
  * dgates [M,4U] (pre-activation), dh_old (zoneout keep path), dc_old.  The caller adds dgates . W_hh to dh_old.
  * dh_out2 (optional, row stride ld_dh2) is added to dh_out: the per-step output gradient next to the recurrent carry. */
