@@ -232,15 +232,16 @@ def prepare(plan, xs, durs=None, f0=None, energy=None, device_maps=False):
 def encode(plan, prep, bilstm_algo=0, planes=False):
     """H1-H3: embedding -> 3 x conv/BN/ReLU -> packed BiLSTM.  Returns hs [B*T, C] (planes: (hs, P32 planes of hs))."""
     bl = plan.blstm
+    res = plan.hp.use_residual  # convs[i](xs) + xs (encoder_sa_kd.py:213-214): the residual rides in the conv's epilogue (after ReLU), fp32 kept for it
     if planes:  # every GEMM operand travels pre-split: embedding -> planes, conv -> planes, ..., BiLSTM -> fp32 + planes
-        _, xp = ops.embedding(prep.ids, plan.embed, want_f32=False, want_planes=True)
+        x, xp = ops.embedding(prep.ids, plan.embed, want_f32=res, want_planes=True)
         for cv in plan.enc_convs:
-            _, xp = ops.conv1d_planes(xp, cv, prep.seg_lo, prep.seg_hi, ops.ACT_RELU)
+            x, xp = ops.conv1d_planes(xp, cv, prep.seg_lo, prep.seg_hi, ops.ACT_RELU, residual=x if res else None, want_f32=res)
         return ops.bilstm(None, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo,
                           x_p=xp, w_ih_p=(bl["w_ih_p_f"], bl["w_ih_p_r"]), want_planes=True)
     x = ops.embedding(prep.ids, plan.embed)
     for cv in plan.enc_convs:
-        x = ops.conv1d(x, cv.wp, cv.bias, prep.seg_lo, prep.seg_hi, ops.ACT_RELU)
+        x = ops.conv1d(x, cv.wp, cv.bias, prep.seg_lo, prep.seg_hi, ops.ACT_RELU, residual=x if res else None)
     return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo)
 
 

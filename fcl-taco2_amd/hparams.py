@@ -68,7 +68,8 @@ class HParams:
         if self.postnet_layers < 2: bad.append("postnet_layers < 2")
         if not self.use_batch_norm: bad.append("use_batch_norm False")
         if not self.use_concate: bad.append("use_concate False")
-        if self.use_residual: bad.append("use_residual True")
+        if self.use_residual and not (self.embed_dim == self.econv_chans):
+            bad.append("use_residual True needs embed_dim == econv_chans (the reference's `convs[i](xs) + xs` has no projection)")
         if self.reduction_factor != 1: bad.append("reduction_factor != 1")
         if not self.use_fe_condition: bad.append("use_fe_condition False")
         if not self.append_position: bad.append("append_position False")

@@ -53,7 +53,7 @@ def forward_pass(plan, batch, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=
         r.enc_taps = [emb]
         x = emb
         for cv in plan.enc_convs:
-            x = ops.conv1d(x, cv.wp, cv.bias, seg_lo, seg_hi, ops.ACT_RELU)
+            x = ops.conv1d(x, cv.wp, cv.bias, seg_lo, seg_hi, ops.ACT_RELU, residual=x if hp.use_residual else None)  # convs[i](xs) + xs
             r.enc_taps.append(x)
         bl = plan.blstm
         lens_dev = torch.from_numpy(lens_np.astype(np.int32)).to(dev)

@@ -781,8 +781,12 @@ class TrainEngine(object):
                      else [None] * hp.econv_layers)
         for i in range(hp.econv_layers):
             keep = enc_keeps[i]
-            r = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep, xp=xp, want_planes=pl)
-            x, cc, xp = r if len(r) == 3 else (r[0], r[1], None)
+            r = self._conv_bn_fwd(c, x, "enc.convs.%d" % i, c.e_lo, c.e_hi, ops.ACT_RELU, keep, xp=xp, want_planes=pl and not hp.use_residual)
+            y, cc, yp = r if len(r) == 3 else (r[0], r[1], None)
+            if hp.use_residual:  # convs[i](xs) + xs, after the block's ReLU and Dropout (encoder_sa_kd.py:158-171); the taps are the sums
+                y = ops.add_vec(y, x)
+                yp = ops.pack_planes(y) if pl else None
+            x, xp = y, yp
             c.conv_c.append(cc)
             c.enc_taps.append(x)
         c.hs, c.bl_c, hs_p = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save, perm=c.perm_tb, xp=xp)
@@ -1111,7 +1115,8 @@ class TrainEngine(object):
         for i in range(len(c.conv_c) - 1, -1, -1):
             if "enc%d" % (i + 1) in inj:
                 ops.add2d(dx, inj["enc%d" % (i + 1)])
-            dx = self._conv_bn_bwd(c, dx, c.conv_c[i])
+            dxi = self._conv_bn_bwd(c, dx, c.conv_c[i])
+            dx = ops.add2d(dxi, dx) if self.hp.use_residual else dxi  # the skip path of `convs[i](xs) + xs`
         if "enc0" in inj:
             ops.add2d(dx, inj["enc0"])
         self._dw(lambda: ops.scatter_add_rows(dx, c.xs, G["enc.embed.weight"], skip=0))  # padding_idx = 0 gets no gradient

@@ -73,7 +73,7 @@ def _drop(x, keep, p):
     return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
 
 
-def encoder_convs(sd, x_bct, n_layers, bn_train=False, keeps=None, p=0.5):
+def encoder_convs(sd, x_bct, n_layers, bn_train=False, keeps=None, p=0.5, residual=False):
     """H2 — reference encoder_sa.py:61-78,136-140 / encoder_sa_kd.py:158-171.
 
     3 x {Conv1d(k5, pad 2, no bias) -> BatchNorm1d -> ReLU -> Dropout}.  Padded positions are NOT
@@ -84,7 +84,8 @@ def encoder_convs(sd, x_bct, n_layers, bn_train=False, keeps=None, p=0.5):
         w = sd["enc.convs.%d.0.weight" % i]
         y = F.conv1d(x, w, None, 1, (w.shape[2] - 1) // 2)
         y = (batch_norm_train if bn_train else batch_norm_eval)(y, sd, "enc.convs.%d.1" % i)
-        x = _drop(torch.relu(y), None if keeps is None else keeps[i], p)
+        y = _drop(torch.relu(y), None if keeps is None else keeps[i], p)
+        x = y + x if residual else y  # use_residual: convs[i](x) + x, after the block's ReLU and Dropout (encoder_sa_kd.py:158-171, 213-214)
         taps.append(x)
     return taps
 
@@ -134,7 +135,7 @@ def encoder_forward(sd, hp, xs, ilens, bn_train=False, keeps=None):
     keeps: optional per-layer dropout keep masks [B,T,C] (train form)."""
     emb = F.embedding(xs, sd["enc.embed.weight"], padding_idx=0)  # H1
     kt = None if keeps is None else [_t(k).transpose(1, 2) for k in keeps]
-    taps = encoder_convs(sd, emb.transpose(1, 2), hp.econv_layers, bn_train, kt, hp.dropout_rate)
+    taps = encoder_convs(sd, emb.transpose(1, 2), hp.econv_layers, bn_train, kt, hp.dropout_rate, residual=hp.use_residual)
     enc = blstm_packed(sd, taps[-1].transpose(1, 2), ilens)
     return enc, [emb] + [t.transpose(1, 2) for t in taps]
 

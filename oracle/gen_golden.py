@@ -519,14 +519,57 @@ def gen_g10():
     print("records.json use_weighted_masking ->", rec["use_weighted_masking"])
 
 
+def gen_g11():
+    """G11: `--use-residual True` (the reference's argparse default; the shipped yaml sets false): `convs[i](xs) + xs` in the encoder
+    (encoder_sa_kd.py:158-171, 213-214).  Teacher: inference mel + training step (eval form); student: KD step against a use_residual teacher."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, use_residual=True)
+    TR = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **kw)
+    SR = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, **kw)
+    rng = np.random.RandomState(11)
+    x = torch.from_numpy(rng.randint(1, TR.idim, size=7).astype(np.int64))
+    dur = torch.tensor([1, 3, 2, 5, 1, 4, 2])
+    te, _ = build("teacher", TR)
+    assert te.enc.use_residual is True
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+        h = te.enc.inference(x)
+    d = dict(x=t2n(x), dur=t2n(dur), after=t2n(after), h=t2n(h))
+    save("g11_teacher_residual", **d)
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    # the plain teacher class cannot TRAIN with it: encoder_sa.py:137-138 adds in place (`xs += self.convs[i](xs)`) and autograd refuses
+    rec_path = os.path.join(OUT, "records.json")
+    rec = json.load(open(rec_path)) if os.path.exists(rec_path) else {}
+    try:
+        te(**b).backward()
+        rec["use_residual_teacher_training"] = "runs"
+    except RuntimeError as e:
+        rec["use_residual_teacher_training"] = "RuntimeError: " + str(e).splitlines()[0][:120]
+    with open(rec_path, "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print("records.json use_residual_teacher_training ->", rec["use_residual_teacher_training"])
+    kt, _ = build("kd_teacher", TR)
+    with torch.no_grad():
+        know = kt(**b)
+    st, _ = build("student", SR, TR, True)
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), t_enc1=t2n(know[2][1]), t_enc4=t2n(know[2][4]))
+    _named_losses(st, d)
+    _grads(st, [k for k in GRAD_KEYS] + KD_KEYS, d)
+    save("g11_student_kd_residual", **d)
+
+
 def main():
     assert os.path.isdir(REF), "gen_golden.py needs /root/reference (survey container only)"
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10"}, only
-        gen_g10()
+        assert only <= {"g10", "g11"}, only
+        if "g10" in only:
+            gen_g10()
+        if "g11" in only:
+            gen_g11()
         return
     gen_manifest()
     gen_g1()
@@ -536,6 +579,7 @@ def main():
     gen_g6(rec)
     gen_g7_g8_g9()
     gen_g10()
+    gen_g11()
 
 
 if __name__ == "__main__":

@@ -36,3 +36,9 @@ TINY_SU = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_cha
                              postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0, use_masking=False)
 TINY_TU = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, use_masking=False)
+
+# the `--use-residual True` variant (G11): same shapes / weights, encoder convs with skip connections
+TINY_SR = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20,
+                             postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0, use_residual=True)
+TINY_TR = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
+                             postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, use_residual=True)

@@ -25,7 +25,7 @@ COM = argparse.Namespace(use_fe_condition=True, append_position=True, distill_ou
 
 def _ns(hp):
     return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
-                              postnet_chans=hp.postnet_chans, use_residual=False, use_masking=hp.use_masking, dropout_rate=hp.dropout_rate,
+                              postnet_chans=hp.postnet_chans, use_residual=hp.use_residual, use_masking=hp.use_masking, dropout_rate=hp.dropout_rate,
                               duration_predictor_chans=hp.duration_predictor_chans)
 
 
@@ -232,6 +232,35 @@ def test_unmasked_loss_variant_vs_reference_g10():
     eng = TrainEngine(_model("student", TINY_SU, TINY_TU))
     rep = eng.forward_backward(batch, teacher_knowledge=_g1_knowledge())
     assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
+
+
+def test_use_residual_variant_vs_reference_g11():
+    """G11: `--use-residual True` (encoder `convs[i](xs) + xs`) on the HIP path: synthesis vs the reference's mel, the KD teacher's taps and the
+    student KD step vs the reference's losses / gradients, the plain teacher step (which the reference cannot run: in-place add) vs the oracle."""
+    from helpers import TINY_SR, TINY_TR
+    from fcl_taco2_amd import engine
+    from fcl_taco2_amd.plan import SynthesisPlan
+    from fcl_taco2_amd.training import TrainEngine
+    from helpers import np_state_dict
+
+    g = _golden("g11_teacher_residual")
+    plan = SynthesisPlan(np_state_dict(TINY_TR), TINY_TR, DEV)
+    mel = engine.synthesize(plan, [g["x"]], [g["dur"]])[0]
+    assert max_abs(mel.cpu(), g["after"]) < 1e-3
+    batch = _batch()
+    g = _golden("g11_student_kd_residual")
+    know = TrainEngine(_model("kd_teacher", TINY_TR)).knowledge(batch, mode="eval")
+    assert max_abs(know[2][1].cpu(), g["t_enc1"]) < 1e-4 and max_abs(know[2][4].cpu(), g["t_enc4"]) < 1e-4
+    eng = TrainEngine(_model("student", TINY_SR, TINY_TR))
+    rep = eng.forward_backward(batch, teacher_knowledge=know)
+    assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
+    eng = TrainEngine(_model("teacher", TINY_TR))
+    rep = eng.forward_backward(batch)
+    sd = _grad_sd(TINY_TR)
+    orep = O.model_forward(sd, TINY_TR, _cpu(batch), "teacher")
+    orep["loss"].backward()
+    assert abs(rep["loss"] - float(orep["loss"])) < 5e-4
+    _check_vs_oracle(eng, sd)
 
 
 def test_device_rng_masks_statistics_and_repeatability():

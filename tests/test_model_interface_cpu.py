@@ -67,8 +67,11 @@ def test_unsupported_configurations_fail_loudly():
     cls = dynamic_import("fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa:Tacotron2_sa")
     with pytest.raises(NotImplementedError):
         cls(80, 80, argparse.Namespace(spk_embed_dim=64, **T_ARGS), com())
+    cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True)), com())  # round 3: encoder skip connections are on the HIP path (G11)
+    with pytest.raises(NotImplementedError):  # ... which need embed_dim == econv_chans, as the reference's `convs[i](xs) + xs` does
+        cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True, embed_dim=256)), com())
     with pytest.raises(NotImplementedError):
-        cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True)), com())
+        cls(80, 80, argparse.Namespace(**dict(T_ARGS, reduction_factor=2)), com())
     m = cls(80, 80, argparse.Namespace(**T_ARGS), com())
     with pytest.raises(RuntimeError, match="no CPU fallback"):  # train-mode forward runs the fused HIP engine: needs the model on a GPU
         m.train().forward(torch.zeros(1, 3, dtype=torch.long), [3], torch.zeros(1, 3, 80), [3])

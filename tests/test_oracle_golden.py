@@ -258,6 +258,36 @@ def test_g10_unmasked_loss_variant(golden):
     assert rec["use_weighted_masking"].startswith("RuntimeError")  # the reference itself cannot run that variant: refusing it is parity
 
 
+def test_g11_use_residual_variant(golden):
+    """`--use-residual True` (the reference's argparse default): encoder `convs[i](xs) + xs`.  Inference mel (teacher class) and the student KD
+    step against a use_residual KD teacher vs the real reference.  (The plain teacher class cannot TRAIN with it in the reference: its encoder
+    adds in place and autograd raises -- recorded in records.json.)"""
+    import json
+
+    from helpers import TINY_SR, TINY_TR
+
+    g4, g = golden("g4_integer"), golden("g11_teacher_residual")
+    sd0 = torch_state_dict(TINY_TR)
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        out = O.inference(sd0, TINY_TR, x, dur=torch.from_numpy(g["dur"]))
+        h = O.encoder_inference(sd0, TINY_TR, x)
+    assert max_abs(out["after"], g["after"]) < TOL_STAGE and max_abs(h, g["h"]) < TOL_STAGE
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden("g11_student_kd_residual")
+    with torch.no_grad():
+        know = O.model_forward(torch_state_dict(TINY_TR), TINY_TR, b, "kd_teacher")
+    assert max_abs(know[2][1], g["t_enc1"]) < TOL_STAGE and max_abs(know[2][4], g["t_enc4"]) < TOL_STAGE
+    sd = _grad_sd(TINY_SR, TINY_TR, True)
+    rep = O.model_forward(sd, TINY_SR, b, "student", TINY_TR, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "encoder_loss", "decoder_loss", "prosody_loss", "output_l1_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 20
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "records.json")))
+    assert rec["use_residual_teacher_training"].startswith("RuntimeError")
+
+
 def test_g6_padding_leak_and_zero_duration(golden):
     g = golden("g6_padding_leak")
     rec = json.load(open(os.path.join(GOLDEN, "records.json")))
