@@ -204,3 +204,36 @@ def test_batch_runner_one_graph_for_many_batches():
         fr = r2.frames()
         ref = engine.synthesize(plan2, xs)
         assert fr == [int(m_.shape[0]) for m_ in ref] and max_abs(mel[: sum(fr)], torch.cat(ref)) < 2e-5
+
+
+def test_decode_driver_recovers_from_a_capacity_overflow(tmp_path, monkeypatch):
+    """fcl_taco2_amd.decode: a batch that exceeds its bucket's calibrated capacities is reported by the device, re-run on the host-mapped path and the
+    bucket's graphs are re-captured with larger capacities; every utterance's mel still equals the plain synthesis.  Forced here by shrinking the
+    calibration (half the frames, two thirds of the steps of the calibrating batch)."""
+    from fcl_taco2_amd import decode as D, engine
+    from fcl_taco2_amd.kaldi_io import read_scp
+
+    S, T = HP.student_hparams(dropout_rate=0.0), HP.teacher_hparams()
+    model = SYN.build_model("student", S, T, DEV).eval()
+    sd = SYN.positive_duration_head(SYN.closed_form_state_dict(HP.param_spec(S, T, True)))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    rng = np.random.RandomState(4)
+    utts = [("u%03d" % i, rng.randint(1, S.idim, size=int(rng.randint(40, 48))).astype(np.int64)) for i in range(40)]  # one bucket (48), 5 batches of 8
+
+    def tight(eng, maps, n_rows, scale=1.3):
+        lmax = max(2, (2 * maps.lmax) // 3)
+        return eng.Caps(lmax, max(256, maps.n_frames // 2), np.full(lmax, n_rows, dtype=np.int32))
+
+    real = D._grown_caps
+    calls = []
+    monkeypatch.setattr(D, "_grown_caps", lambda eng, maps, n_rows, scale=1.3: (calls.append(scale), tight(eng, maps, n_rows) if len(calls) == 1 else real(eng, maps, n_rows, scale))[1])
+    st = {}
+    frames, _ = D.decode(model, utts, str(tmp_path / "f"), batch_size=8, depth=2, stats=st)
+    assert st["redone_batches"] >= 1 and st["eager_batches"] == 1 and st["graph_batches"] >= 3
+    mels = read_scp(str(tmp_path / "f.scp"))
+    assert sorted(mels) == sorted(u for u, _ in utts) and frames == sum(m.shape[0] for m in mels.values())
+    plan = model.plan()
+    for uid, x in utts[::7]:
+        ref = engine.synthesize(plan, [x])[0]
+        assert mels[uid].shape == tuple(ref.shape) and max_abs(mels[uid], ref) < 2e-5
