@@ -125,6 +125,8 @@ SIGNATURES = {
     "fcl_linear_fwd": (_I, [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcl_conv1d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcl_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
+    "fcl_layernorm_group_fwd": (_I, [_P, _I, C.c_int64, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fcl_conv1d_planes_group_fwd": (_I, [_P, _I, C.c_int64, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcl_duration_round_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P]),
     "fcl_variance_embed_add_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),
     "fcl_position_table_fwd": (_I, [_P, _P, _I, _I, _P]),

@@ -214,6 +214,40 @@ int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int fcl_conv1d_planes_group_fwd(const uint16_t* xp, int ldxp, int64_t x_group_stride, const uint16_t* wpp, const float* bias, const int32_t* seg_lo,
+                                const int32_t* seg_hi, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, int groups, fcl_stream_t stream) {
+    FCL_REQUIRE(xp && wpp && (y || yp) && seg_lo && seg_hi && groups >= 1 && groups <= 65535, FCL_ERR_INVALID, "conv1d_planes_group_fwd: bad arguments");
+    FCL_REQUIRE(k >= 3 && (k & 1) && k <= FCL_MAX_TERMS, FCL_ERR_SHAPE, "conv1d_planes_group_fwd: kernel size %d must be odd, 3 .. %d", k, FCL_MAX_TERMS);
+    FCL_REQUIRE(act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "conv1d_planes_group_fwd: bad act %d", act);
+    FCL_REQUIRE(ldxp * 32 >= cin && cin <= 384 && !(cout & 31), FCL_ERR_SHAPE, "conv1d_planes_group_fwd: needs Cin <= 384 (the stencil kernel) and Cout %% 32 == 0");
+    FCL_REQUIRE(tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0 && tunable("PCONV", 1) != 0, FCL_ERR_INVALID,
+                "conv1d_planes_group_fwd: the pre-split stencil path is off (FCL_PRECISION / FCL_PLANES / FCL_PCONV)");
+    const int ldw = (cin + 31) / 32;
+    GemmArgs g = {};
+    for (int j = 0; j < k; ++j) {
+        g.term[j].K = cin;
+        g.term[j].shift = j - (k - 1) / 2;
+        g.term[j].Ap = xp; g.term[j].lda_p = ldxp;
+        g.term[j].Wp = wpp + (size_t)j * cout * ldw * 64; g.term[j].ldw_p = ldw;
+    }
+    g.nterms = k;
+    g.conv_k = k;
+    g.M = m; g.N = cout;
+    g.seg_lo = seg_lo; g.seg_hi = seg_hi;
+    g.bias = bias; g.act = act;
+    g.Y = y; g.ldy = cout;
+    g.Yp = yp; g.ldyp = cout / 32;
+    // group g: x planes at xp + g * x_group_stride (uint16 elements; 0 = every group reads the same input), weights [G][k * Cout][Cin planes], bias
+    // [G][Cout], outputs group-major [G][M][Cout]
+    g.nblk = groups;
+    g.g_a = x_group_stride;
+    g.g_w = (long long)k * cout * ldw * 64;
+    g.g_bias = cout;
+    g.g_y = (long long)m * cout;
+    g.g_yp = (long long)m * (cout / 32) * 64;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int fcl_lstm_step_fwd(const fcl_lstm_step_t* args, fcl_stream_t stream) {
     FCL_REQUIRE(args, FCL_ERR_INVALID, "lstm_step_fwd: null argument");
     FCL_REQUIRE(!args->save_gates || (args->save_c_new && args->save_c_old && args->save_h_old), FCL_ERR_INVALID,

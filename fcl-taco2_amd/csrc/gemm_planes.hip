@@ -263,7 +263,13 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
 __device__ __forceinline__ int rho16(int i) { return i < 4 ? 2 * i : (i < 12 ? 2 * (i - 4) + 1 : 2 * (i - 8)); }
 
 template <int WN, int TM, int TN, int BM, int BN, int CTHREADS, int LDS_BYTES, bool RP = false>
-__device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[TM][TN], u8* smem, int m0, int n0) {
+__device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[TM][TN], u8* smem, int m0, int n0, long long ob = 0, long long oy = 0,
+                                               long long oyp = 0) {
+    // (ob / oy / oyp: this group's offsets into bias / Y / Yp for the grouped Conv1d; 0 otherwise)
+    const GemmArgs& a = a_;
+    const float* const e_bias = a.bias ? a.bias + ob : nullptr;
+    float* const e_Y = a.Y ? a.Y + oy : nullptr;
+    unsigned short* const e_Yp = a.Yp ? a.Yp + oyp : nullptr;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, rq = lane >> 4;
@@ -281,7 +287,7 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
         for (int tn = 0; tn < TN; ++tn) {
             const int cn = (wn * TN + tn) * 16 + col, n = n0 + cn;
             const bool nin = n < a.N;
-            const float bn = (a.bias && nin) ? a.bias[n] : 0.f;
+            const float bn = (e_bias && nin) ? e_bias[n] : 0.f;
             const float r1w = (a.rank1_w && nin) ? a.rank1_w[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -320,13 +326,13 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
         }
         return;
     }
-    if (a.Y) {
-        const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Y) & 15u) == 0;
+    if (e_Y) {
+        const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(e_Y) & 15u) == 0;
         for (int i = threadIdx.x; i < rows * (BN / 4); i += CTHREADS) {
             const int rm = i / (BN / 4), c4 = (i - rm * (BN / 4)) * 4, n = n0 + c4, gm = m0 + trow(rm);
             if (n >= a.N || gm >= a.M) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c4);
-            float* dst = a.Y + (size_t)gm * a.ldy + n;
+            float* dst = e_Y + (size_t)gm * a.ldy + n;
             if (vec && n + 3 < a.N) {
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
@@ -336,7 +342,7 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
             }
         }
     }
-    if (a.Yp) {  // item = (row, 32-column line, quarter q): 8 values -> 16 bytes of hi at piece q and 16 bytes of lo at piece 4 + q
+    if (e_Yp) {  // item = (row, 32-column line, quarter q): 8 values -> 16 bytes of hi at piece q and 16 bytes of lo at piece 4 + q
         const int np = a.ldyp * 32;
         for (int i = threadIdx.x; i < rows * (BN / 8); i += CTHREADS) {
             const int rm = i / (BN / 8), c8 = (i - rm * (BN / 8)) * 8, n = n0 + c8, gm = m0 + trow(rm);
@@ -345,7 +351,7 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a, f32x4 (&acc)[T
             uint2 h0, l0, h1, l1;
             split4(v0, h0, l0);
             split4(v1, h1, l1);
-            u16* line = a.Yp + ((size_t)gm * a.ldyp + (n >> 5)) * 64 + (n & 31);
+            u16* line = e_Yp + ((size_t)gm * a.ldyp + (n >> 5)) * 64 + (n & 31);
             *reinterpret_cast<uint4*>(line) = make_uint4(h0.x, h0.y, h1.x, h1.y);
             *reinterpret_cast<uint4*>(line + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
@@ -530,7 +536,10 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = a.conv_k, pad = (k - 1) >> 1;
-    const GemmTerm T0 = a.term[0];
+    GemmTerm T0 = a.term[0];
+    const long long gz = blockIdx.z;  // grouped Conv1d: group gz of gridDim.z independent problems
+    T0.Ap += gz * a.g_a;
+    T0.Wp += gz * a.g_w;
     const int cc = (T0.K + 31) >> 5, S = cc * k;  // channel chunks, steps (chunk-major, tap-minor)
     u8* const wring = smem + 2 * G::A_BYTES;
 
@@ -646,7 +655,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
         }
         if (++j == k) { j = 0; ++c; }
     }
-    pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES, true>(a, acc, smem, m0, n0);
+    pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES, true>(a, acc, smem, m0, n0, gz * a.g_bias, gz * a.g_y, gz * a.g_yp);
 }
 
 template <int WM, int WN, int TM, int TN, int NL>
@@ -657,7 +666,8 @@ static int launch_pconv_nl(const GemmArgs& a, hipStream_t s, double flops) {
     const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
     if (rc) return rc;
     const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;
-    dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
+    const int groups = (a.g_a || a.g_w || a.g_y || a.g_yp) ? max(1, a.nblk) : 1;  // (nblk carries the group count of a grouped Conv1d)
+    dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM, groups);
     char full[48];
     snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, NL, hi ? "/bf16" : "");
     ProfScope ps(full, flops, a.M, s);

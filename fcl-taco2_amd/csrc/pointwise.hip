@@ -108,10 +108,21 @@ template <int MAXPER>
 __global__ void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                  float eps, float* __restrict__ y, unsigned short* __restrict__ yp, const float* __restrict__ lin_w,
                                  const float* __restrict__ lin_b, const uint8_t* __restrict__ pad_mask,
-                                 const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ scalar, int m, int c) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+                                 const uint8_t* __restrict__ keep, float keep_scale, float* __restrict__ scalar, int m, int c,
+                                 int ldx = 0, long long gstride = 0, int groups = 1) {
+    // groups > 1 (fcl_layernorm_group_fwd): G independent LayerNorms of the same shape in one launch -- wave r handles (group g, row mi) = (r / m, r % m),
+    // reads x + g * gstride + mi * ldx, its own gamma / beta / head [g][c], and writes GROUP-MAJOR outputs (row g * m + mi)
+    const int grow = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
-    if (row >= m) return;
+    if (grow >= m * groups) return;
+    const int g_ = groups > 1 ? grow / m : 0, mi = grow - g_ * m;
+    if (groups > 1) {
+        x += (long long)g_ * gstride + (long long)mi * ldx - (long long)grow * c;  // so that x[row * c + j] below addresses this row
+        gamma += g_ * c; beta += g_ * c;
+        if (lin_w) { lin_w += g_ * c; lin_b += g_; }
+        if (pad_mask) pad_mask += mi - grow;  // the pad mask is per row of ONE group
+    }
+    const int row = grow;
     float v[MAXPER];
     float s = 0.f;
 #pragma unroll
@@ -592,6 +603,28 @@ int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, flo
     else if (c <= 512) hipLaunchKernelGGL((layernorm_kernel<8>), grid, block, 0, s, x, gamma, beta, eps, y, yp, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
     else hipLaunchKernelGGL((layernorm_kernel<16>), grid, block, 0, s, x, gamma, beta, eps, y, yp, lin_w, lin_b, pad_mask, keep, keep_scale, scalar, m, c);
     return check_hip(hipGetLastError(), "layernorm_fwd");
+}
+
+int fcl_layernorm_group_fwd(const float* x, int ldx, int64_t x_group_stride, const float* gamma, const float* beta, float eps, float* y, uint16_t* yp,
+                            const float* lin_w, const float* lin_b, const uint8_t* pad_mask, float* scalar, int m, int c, int groups,
+                            fcl_stream_t stream) {
+    FCL_REQUIRE(x && gamma && beta && m >= 0 && c > 0 && groups >= 1 && ldx >= c, FCL_ERR_INVALID, "layernorm_group_fwd: bad arguments");
+    FCL_REQUIRE(y || yp || lin_w, FCL_ERR_INVALID, "layernorm_group_fwd: nothing to compute (y, yp and lin_w all NULL)");
+    FCL_REQUIRE((reinterpret_cast<uintptr_t>(yp) & 127u) == 0, FCL_ERR_ALIGN, "layernorm_group_fwd: planes must be 128-byte aligned");
+    FCL_REQUIRE(!lin_w || (lin_b && scalar), FCL_ERR_INVALID, "layernorm_group_fwd: lin_w needs lin_b and scalar");
+    FCL_REQUIRE(c <= 1024, FCL_ERR_SHAPE, "layernorm_group_fwd: C=%d > 1024 unsupported", c);
+    if (m == 0) return 0;
+    dim3 grid(((long long)m * groups + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t* keep = nullptr;
+#define FCL_LNG(P) hipLaunchKernelGGL((layernorm_kernel<P>), grid, block, 0, s, x, gamma, beta, eps, y, yp, lin_w, lin_b, pad_mask, keep, 1.0f, scalar, m, c, ldx, \
+                                      (long long)x_group_stride, groups)
+    if (c <= 64) FCL_LNG(1);
+    else if (c <= 256) FCL_LNG(4);
+    else if (c <= 512) FCL_LNG(8);
+    else FCL_LNG(16);
+#undef FCL_LNG
+    return check_hip(hipGetLastError(), "layernorm_group_fwd");
 }
 
 int fcl_duration_round_fwd(const float* x, int64_t* out, int n, int linear_domain, float offset, const uint8_t* pad_mask,

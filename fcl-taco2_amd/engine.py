@@ -87,6 +87,28 @@ def _predictor_scalar_planes(pp, hs_p, seg_lo, seg_hi, pad_mask_u8):
     return out
 
 
+def _predictors_grouped(grp, hs_p, seg_lo, seg_hi, pad_u8, m, masked):
+    """All predictors of `grp` (plan.PredictorGroup) in one launch per layer: conv-0 with the stacked output channels, then grouped LayerNorm /
+    Conv1d / LayerNorm + head.  Returns the [m] outputs in grp.names order; `masked[i]`: apply the pad mask to output i (the duration predictor's
+    inference path masks later, in the rounding kernel)."""
+    G, C = grp.G, grp.chans
+    y, _ = ops.conv1d_planes(hs_p, grp.w0, seg_lo, seg_hi, ops.ACT_RELU, want_f32=True, want_planes=False)  # [m, G * C]
+    ldx, gstride = G * C, C
+    out = None
+    for i in range(grp.layers):
+        last = i == grp.layers - 1
+        if last:
+            same_mask = all(masked) or not any(masked)
+            assert same_mask, "grouped predictors share one pad-mask policy"
+            _, out, _ = ops.layernorm_group(y, ldx, gstride, grp.gamma[i], grp.beta[i], LN_EPS, m, C, G, lin_w=grp.lin_w, lin_b=grp.lin_b,
+                                            pad_mask=pad_u8 if all(masked) else None)
+        else:
+            _, _, xp = ops.layernorm_group(y, ldx, gstride, grp.gamma[i], grp.beta[i], LN_EPS, m, C, G, want_planes=True)
+            y, _ = ops.conv1d_planes_group(xp, m * (C // 32) * 64, grp.wpp[i], grp.bias[i], seg_lo, seg_hi, m, C, C, grp.k, G, act=ops.ACT_RELU)
+            ldx, gstride = C, m * C
+    return [out[g * m : (g + 1) * m] for g in range(G)]
+
+
 def use_planes(plan):
     """Pre-split (P32) operands end to end: on by default (FCL_PRECISION=0 / FCL_PLANES=0 turn it off), needs whole 32-column lines."""
     hp = plan.hp
@@ -149,6 +171,9 @@ class DeviceFrames(object):
 
 
 _RING = None
+import os as _os
+
+_GROUP_PREDICTORS = _os.environ.get("FCL_PRED_GROUP", "1") not in ("", "0")  # 0: one launch per predictor and layer (rounds 1-2)
 
 
 def _ring():
@@ -275,10 +300,17 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
         inter = {"hs": hs, "T": prep.T} if return_intermediates else None
         rm = prep  # holder of the row maps
         frames_info = None
+        # the predictors share one geometry in the shipped recipes: one launch per layer for all of them (plan.PredictorGroup) instead of one each
+        grouped = planes and prep.f0e is None and _GROUP_PREDICTORS
+        m_rows = prep.B * prep.T
+        p = e = None
         if prep.maps is None:  # maps depend on durations that live in HBM: predicted by this pass, or forced and uploaded
             d_int = None
             if prep.dur_pad is None:
-                d_log = predictor(plan.duration, None)
+                if grouped and plan.group_dpe is not None:
+                    d_log, p, e = _predictors_grouped(plan.group_dpe, hs_p, prep.seg_lo, prep.seg_hi, prep.pad, m_rows, [True, True, True])
+                else:
+                    d_log = predictor(plan.duration, None)
                 d_int = ops.duration_round(d_log, False, 1.0, prep.pad)
                 if inter is not None:
                     inter["d_log"], inter["d_int"] = d_log, d_int
@@ -295,11 +327,13 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
                 d_host = d_int.cpu().numpy().reshape(prep.B, prep.T)  # the one host sync of the predicted-duration path
                 rm = PreparedBatch()
                 _upload_maps(rm, build_row_maps(prep.lens, [d_host[b, : prep.lens[b]] for b in range(prep.B)], prep.T), dev)
-        if prep.f0e is None:
+        if prep.f0e is not None:
+            p, e = prep.f0e[0], prep.f0e[1]
+        elif p is None and grouped and plan.group_pe is not None:
+            p, e = _predictors_grouped(plan.group_pe, hs_p, prep.seg_lo, prep.seg_hi, prep.pad, m_rows, [True, True])
+        elif p is None:
             p = predictor(plan.pitch, prep.pad)
             e = predictor(plan.energy, prep.pad)
-        else:
-            p, e = prep.f0e[0], prep.f0e[1]
         att, p_emb, e_emb = ops.variance_embed_add(hs, p, e, plan.pitch_embed_w, plan.pitch_embed_b, plan.energy_embed_w,
                                                    plan.energy_embed_b, prep.seg_lo, prep.seg_hi, want_embs=return_intermediates)
         maps = rm.maps

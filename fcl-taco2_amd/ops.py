@@ -172,6 +172,29 @@ def layernorm(x, gamma, beta, eps, want_y=True, lin_w=None, lin_b=None, pad_mask
     return (y, scalar, yp) if want_planes else (y, scalar)
 
 
+def conv1d_planes_group(xp, x_group_stride, wpp, bias, seg_lo, seg_hi, m, cin, cout, k, groups, act=ACT_NONE, want_f32=True, want_planes=False):
+    """G Conv1d's of one shape in ONE launch (include/fcl_hip.h fcl_conv1d_planes_group_fwd).  xp: P32 planes, group g at + g * x_group_stride uint16
+    elements (0: every group reads the same input); wpp [G][k * Cout][Cin planes]; bias [G * Cout].  Returns (y [G * m, Cout] or None, planes or None),
+    group-major."""
+    ldxp = xp.shape[1] // 64
+    y = torch.empty(groups * m, cout, device=xp.device, dtype=torch.float32) if want_f32 else None
+    yp = planes_empty(groups * m, cout, xp.device) if want_planes else None
+    check(_lib.load().fcl_conv1d_planes_group_fwd(_p(xp, torch.int16), ldxp, int(x_group_stride), _p(wpp, torch.int16), _p(bias), _p(seg_lo, torch.int32),
+                                                  _p(seg_hi, torch.int32), _p(y), _p(yp, torch.int16), m, cin, cout, k, act, groups, _stream()))
+    return y, yp
+
+
+def layernorm_group(x, ldx, x_group_stride, gamma, beta, eps, m, c, groups, want_y=False, want_planes=False, lin_w=None, lin_b=None, pad_mask=None):
+    """G LayerNorms of one shape in ONE launch (fcl_layernorm_group_fwd): row mi of group g at x + g * x_group_stride + mi * ldx; outputs group-major.
+    Returns (y [G * m, c] or None, scalar [G * m] or None, planes or None)."""
+    y = torch.empty(groups * m, c, device=x.device, dtype=torch.float32) if want_y else None
+    yp = planes_empty(groups * m, c, x.device) if want_planes else None
+    scalar = torch.empty(groups * m, device=x.device, dtype=torch.float32) if lin_w is not None else None
+    check(_lib.load().fcl_layernorm_group_fwd(_p(x), ldx, int(x_group_stride), _p(gamma), _p(beta), eps, _p(y), _p(yp, torch.int16), _p(lin_w), _p(lin_b),
+                                              _p(pad_mask, torch.uint8), _p(scalar), m, c, groups, _stream()))
+    return y, scalar, yp
+
+
 def duration_round(x, linear_domain=False, offset=1.0, pad_mask=None):
     out = torch.empty(x.numel(), device=x.device, dtype=torch.int64)
     check(_lib.load().fcl_duration_round_fwd(_p(x), _p(out, torch.int64), x.numel(), int(linear_domain), offset, _p(pad_mask, torch.uint8), _stream()))

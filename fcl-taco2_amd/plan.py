@@ -31,6 +31,38 @@ class PredictorPack(object):
     __slots__ = ("convs", "ln", "lin_w", "lin_b")
 
 
+class PredictorGroup(object):
+    """G predictors of one shape stacked for the grouped launches (ops.conv1d_planes_group / ops.layernorm_group): the first layer's taps stacked
+    along Cout (all predictors read the same hs: ONE Conv1d with G * Cout output channels), the other layers' planes group-major."""
+    __slots__ = ("names", "G", "layers", "cin", "chans", "k", "w0", "b0", "wpp", "bias", "gamma", "beta", "lin_w", "lin_b")
+
+
+def _predictor_group(preds, names):
+    """None unless the predictors share one geometry (the shipped recipes': 2 layers, 384 channels, kernel 3) and the pre-split path is on."""
+    p0 = preds[0]
+    same = all(len(p.convs) == len(p0.convs) and all((a.cin, a.cout, a.k) == (b.cin, b.cout, b.k) for a, b in zip(p.convs, p0.convs)) for p in preds)
+    c0 = p0.convs[0]
+    if not (ops.planes_enabled() and same and len(p0.convs) >= 1 and c0.cout % 32 == 0 and c0.cin <= 384 and c0.cout <= 384 and c0.k >= 3 and c0.wpp is not None):
+        return None
+    g = PredictorGroup()
+    g.names, g.G, g.layers, g.cin, g.chans, g.k = list(names), len(preds), len(p0.convs), c0.cin, c0.cout, c0.k
+    # layer 0: [k, G * Cout, Cin] taps -> one ConvPack-like pair (planes of the stacked taps, stacked bias)
+    w0 = torch.cat([p.convs[0].wp for p in preds], dim=1).contiguous()
+    g.w0 = ConvPack()
+    g.w0.k, g.w0.cout, g.w0.cin, g.w0.wp = c0.k, g.G * c0.cout, c0.cin, w0
+    g.w0.bias = torch.cat([p.convs[0].bias for p in preds]).contiguous()
+    _conv_planes(g.w0)
+    g.b0 = g.w0.bias
+    # layers >= 1: group-major planes [G][k * Cout][Cin planes], bias [G * Cout]
+    g.wpp = [torch.cat([p.convs[i].wpp for p in preds], dim=0).contiguous() for i in range(1, g.layers)]
+    g.bias = [torch.cat([p.convs[i].bias for p in preds]).contiguous() for i in range(1, g.layers)]
+    g.gamma = [torch.cat([p.ln[i][0] for p in preds]).contiguous() for i in range(g.layers)]
+    g.beta = [torch.cat([p.ln[i][1] for p in preds]).contiguous() for i in range(g.layers)]
+    g.lin_w = torch.cat([p.lin_w for p in preds]).contiguous()
+    g.lin_b = torch.cat([p.lin_b.reshape(-1) for p in preds]).contiguous()
+    return g
+
+
 class DecoderPack(object):
     """Holds the ctypes struct and keeps alive every tensor it points to."""
 
@@ -72,6 +104,9 @@ class SynthesisPlan(object):
             self.duration = self._predictor(g, "duration_predictor", hp.duration_predictor_layers)
             self.pitch = self._predictor(g, "pitch_predictor", hp.variance_predictor_layers)
             self.energy = self._predictor(g, "energy_predictor", hp.variance_predictor_layers)
+            # grouped forms: pitch + energy (forced durations) and duration + pitch + energy (predicted durations) as one launch per layer
+            self.group_pe = _predictor_group([self.pitch, self.energy], ["pitch", "energy"])
+            self.group_dpe = _predictor_group([self.duration, self.pitch, self.energy], ["duration", "pitch", "energy"])
             self.pitch_embed_w = g("pitch_embed.0.weight").reshape(hp.eunits, -1).contiguous()
             self.pitch_embed_b = g("pitch_embed.0.bias")
             self.energy_embed_w = g("energy_embed.0.weight").reshape(hp.eunits, -1).contiguous()

@@ -126,6 +126,13 @@ int fcl_linear_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
 int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
                           const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, fcl_stream_t stream);
 
+/* G independent Conv1d's of the SAME shape in one launch (the duration / pitch / energy predictors' layers, variance_predictor.py:48-66): group g
+ * reads planes xp + g * x_group_stride (uint16 elements; 0 = all groups read the same input), weights wpp [G][k * Cout][Cin planes] (each group
+ * packed as for fcl_conv1d_planes_fwd), bias [G][Cout], and writes y / yp GROUP-MAJOR: [G][M][Cout].  Cin <= 384, Cout % 32 == 0, k >= 3. */
+int fcl_conv1d_planes_group_fwd(const uint16_t* xp, int ldxp, int64_t x_group_stride, const uint16_t* wpp, const float* bias, const int32_t* seg_lo,
+                                const int32_t* seg_hi, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, int groups,
+                                fcl_stream_t stream);
+
 /* ---- H4/H5: channel LayerNorm (+ the predictor's Linear(C->1) and masked_fill) ---------------------- */
 /* y[m,:] = LN(x[m,:]) * gamma + beta (y may be NULL).  If lin_w != NULL:
  * scalar[m] = pad_mask[m] ? 0 : (y[m,:] . lin_w + lin_b[0])   (variance_predictor.py:90-93).
@@ -133,6 +140,13 @@ int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
 int fcl_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, uint16_t* yp /* optional P32 planes of y */,
                       const float* lin_w, const float* lin_b, const uint8_t* pad_mask, const uint8_t* keep, float keep_scale,
                       float* scalar, int m, int c, fcl_stream_t stream);
+/* G independent LayerNorms of the same shape in one launch: row mi of group g is read at x + g * x_group_stride + mi * ldx (so both a
+ * [M][G * C] matrix -- ldx = G * C, stride C: the output of a Conv1d whose output channels are G predictors' stacked -- and a group-major
+ * [G][M][C] one -- ldx = C, stride M * C -- work); gamma / beta / lin_w are [G][C], lin_b [G], pad_mask [M] (shared); y / yp / scalar are written
+ * group-major ([G][M][C], [G][M]). */
+int fcl_layernorm_group_fwd(const float* x, int ldx, int64_t x_group_stride, const float* gamma, const float* beta, float eps, float* y, uint16_t* yp,
+                            const float* lin_w, const float* lin_b, const uint8_t* pad_mask, float* scalar, int m, int c, int groups,
+                            fcl_stream_t stream);
 
 /* ---- H4: DurationPredictor.inference rounding (ESPnet; call site ..._kd_student.py:825) ------------- */
 /* out = pad_mask ? 0 : (int64) max(rint(linear_domain ? x : exp(x) - offset), 0); rint = half-to-even. */

@@ -237,3 +237,32 @@ def test_decode_driver_recovers_from_a_capacity_overflow(tmp_path, monkeypatch):
     for uid, x in utts[::7]:
         ref = engine.synthesize(plan, [x])[0]
         assert mels[uid].shape == tuple(ref.shape) and max_abs(mels[uid], ref) < 2e-5
+
+
+def test_grouped_predictor_launches_equal_the_per_predictor_path():
+    """plan.PredictorGroup: the duration / pitch / energy predictors (one geometry in the shipped recipes) as ONE launch per layer -- a Conv1d with
+    the stacked output channels, grouped LayerNorms, a grouped Conv1d, grouped LayerNorm + head -- against one launch per predictor and layer:
+    same outputs (the stacked layer-0 GEMM and the grouped kernels compute every output element exactly as the separate ones do)."""
+    from fcl_taco2_amd import engine, ops
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    plan = _plan(hp, SYN.positive_duration_head(np_state_dict(hp)))
+    assert plan.group_pe is not None and plan.group_dpe is not None and plan.group_dpe.G == 3
+    xs, _ = SYN.batch_c2(hp.idim, batch=6, t_lo=30, t_hi=70, seed=5)
+    prep = engine.prepare(plan, xs)
+    hs, hs_p = engine.encode(plan, prep, planes=True)
+    m = prep.B * prep.T
+    d, p, e = engine._predictors_grouped(plan.group_dpe, hs_p, prep.seg_lo, prep.seg_hi, prep.pad, m, [True, True, True])
+    p2, e2 = engine._predictors_grouped(plan.group_pe, hs_p, prep.seg_lo, prep.seg_hi, prep.pad, m, [True, True])
+    for got, pp in ((d, plan.duration), (p, plan.pitch), (e, plan.energy), (p2, plan.pitch), (e2, plan.energy)):
+        ref = engine._predictor_scalar_planes(pp, hs_p, prep.seg_lo, prep.seg_hi, prep.pad)
+        assert got.shape == ref.shape and max_abs(got, ref) < 1e-6 * max(1.0, float(ref.abs().max()))
+    # and end to end: the pass with grouped predictors (default) against the reference-pinned oracle path is covered by the mel tests; here
+    # grouped vs ungrouped synthesis of the same batch
+    mel_g, fr, _ = engine.run(plan, prep, return_intermediates=True)
+    engine._GROUP_PREDICTORS = False
+    try:
+        mel_u, fr_u, _ = engine.run(plan, prep, return_intermediates=True)
+    finally:
+        engine._GROUP_PREDICTORS = True
+    assert list(fr) == list(fr_u) and max_abs(mel_g, mel_u) < 1e-5
