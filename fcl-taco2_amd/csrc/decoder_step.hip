@@ -513,7 +513,9 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
     if ((int)blockIdx.x * (16 * RT) >= (a.h1 ? Ms_feat : Ms_pre)) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier)
     constexpr int U = SU * 32, OP = SO * 32, P = SP * 32;
-    constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8, ROWS = 16 * RT;
+    // row strides of 34 / 14 / 34 sixteen-byte slots: = 2 (mod 4) makes every ds_read_b128 lane group (8 rows at k-piece a + 8 rows at piece a + 1)
+    // hit 16 distinct slots; the + 8 padding of rounds 1-2 (33 / 13 slots) cost 1 - 5 extra LDS cycles per 4 (r3 PMC: 39 % of this kernel's LDS cycles)
+    constexpr int ldU = U + 16, ldO = OP + 16, ldP = P + 16, ROWS = 16 * RT;
     static_assert(2 * SP <= 16, "two prenet column tiles per wave, 8 waves");
     extern __shared__ __attribute__((aligned(16))) u16 fp_lds[];
     u16* A1h = fp_lds;
@@ -693,8 +695,8 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
     const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
     if ((int)blockIdx.y * 16 >= Ms) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier): a step of a loose bound costs a launch, not a pass
     constexpr int KC = 512;
-    __shared__ __attribute__((aligned(16))) u16 A_h[16 * (KC + 8)];
-    __shared__ __attribute__((aligned(16))) u16 A_lo[16 * (KC + 8)];
+    __shared__ __attribute__((aligned(16))) u16 A_h[16 * (KC + 16)];  // row stride = 2 (mod 4) sixteen-byte slots: conflict-free fragment reads
+    __shared__ __attribute__((aligned(16))) u16 A_lo[16 * (KC + 16)];
     __shared__ float g_l[4][16][17];
     const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
@@ -718,10 +720,10 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (t) __syncthreads();
-            load_rowtile_split(A_h, A_lo, 256 + 8, a.term[t].A, a.term[t].lda, 256, m0, M);
+            load_rowtile_split(A_h, A_lo, 256 + 16, a.term[t].A, a.term[t].lda, 256, m0, M);
             __syncthreads();
             f32x4 part[1];
-            wf[t].mma(A_h, A_lo, 256 + 8, 256, r16, kq, part);
+            wf[t].mma(A_h, A_lo, 256 + 16, 256, r16, kq, part);
             acc += part[0];
         }
     }
@@ -730,13 +732,13 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
         for (int k0 = 0; k0 < T.K; k0 += KC) {
             const int kc = min(KC, T.K - k0);
             __syncthreads();
-            load_rowtile_split(A_h, A_lo, kc + 8, T.A + k0, T.lda, kc, m0, M);
+            load_rowtile_split(A_h, A_lo, kc + 16, T.A + k0, T.lda, kc, m0, M);
             __syncthreads();
             const size_t fo = ((size_t)((g * a.U + u0) >> 4) * ((T.K + 31) >> 5) + (k0 >> 5)) * 512 + (size_t)lane * 8;
             const u16* const wh[1] = {T.Whi + fo};
             const u16* const wl[1] = {T.Wlo + fo};
             f32x4 part[1];
-            rowtile_mma_x3<1>(A_h, A_lo, kc + 8, wh, wl, kc, r16, kq, part);
+            rowtile_mma_x3<1>(A_h, A_lo, kc + 16, wh, wl, kc, r16, kq, part);
             acc += part[0];
         }
     }
@@ -1015,7 +1017,7 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
             const dim3 b(512);
 #define FCL_FP_LAUNCH(RT_)                                                                                                               \
     do {                                                                                                                                 \
-        constexpr size_t lds_rt = 2 * sizeof(unsigned short) * 16 * RT_ * ((256 + 8) + (96 + 8) + (256 + 8));                            \
+        constexpr size_t lds_rt = 2 * sizeof(unsigned short) * 16 * RT_ * ((256 + 16) + (96 + 16) + (256 + 16));                            \
         const dim3 g((rows + 16 * RT_ - 1) / (16 * RT_));                                                                                \
         const void* fn = a.drop_mode == 1   ? reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 1, RT_>)                      \
                          : a.drop_mode == 2 ? reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 2, RT_>)                      \
