@@ -186,24 +186,70 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
                                                      const float* __restrict__ b, float* __restrict__ out, int M, int C, int mode, int rows_per_block) {
     // fp64 accumulation (the kernel is HBM-bound either way): these sums are the dbeta / dgamma that train-mode BatchNorm's backward SUBTRACTS from
-    // dy, i.e. operands of a cancellation; 7e-8 instead of 3e-7 relative at 1 600 rows
+    // dy, i.e. operands of a cancellation; 7e-8 instead of 3e-7 relative at 1 600 rows.
+    // 64 columns x rows_per_block rows per block; a wave reads 64 consecutive columns of one row (256-byte coalesced) and keeps EIGHT rows in
+    // flight per thread: with one load per iteration the kernel ran at the latency of its row loop (r3 trace: 55 us for 16 MB).
     __shared__ double part[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // a wave reads 64 consecutive columns of one row: 256-byte coalesced
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
     double s = 0.0;
     if (c < C) {
         const float bc = mode >= 2 ? b[c] : 0.f, gc = mode == 2 ? 1.0f / g[c] : (mode == 3 ? g[c] : 1.f);
-        for (int m = m_lo + ty; m < m_hi; m += 4) {
-            float v = x[(size_t)m * C + c];
-            if (mode == 1) v *= y[(size_t)m * C + c];
-            else if (mode >= 2) v *= (y[(size_t)m * C + c] - bc) * gc;
-            s += (double)v;
+        for (int m = m_lo + ty; m < m_hi; m += 32) {
+            float v[8], w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const size_t o = (size_t)min(m + 4 * j, m_hi - 1) * C + c;
+                v[j] = x[o];
+                w[j] = mode >= 1 ? y[o] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = v[j];
+                if (mode == 1) t *= w[j];
+                else if (mode >= 2) t *= (w[j] - bc) * gc;
+                if (m + 4 * j < m_hi) s += (double)t;
+            }
         }
     }
     part[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && c < C) atomicAdd(out + c, (float)((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
+}
+
+// ---- weight / bias gradients of a Conv1d with ONE input channel (the pitch / energy embeddings, ..._sa.py:435-443: Conv1d(1 -> C, k = 9)):
+// dw[c, j] += sum_m dy[m, c] * x[m + j - pad] (positions inside row m's utterance), db[c] += sum_m dy[m, c].  The signal value of a tap is the same
+// for the 64 columns a wave owns, so the inner loop is one dy load and k FMAs per row; rounds 1-2 issued k skinny TN GEMMs + k adds per embedding.
+template <int KMAX>
+__global__ __launch_bounds__(256) void conv1d_in1_dw_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x, const int* __restrict__ seg_lo,
+                                                            const int* __restrict__ seg_hi, float* __restrict__ dw, float* __restrict__ db, int M, int C,
+                                                            int k, int rows_per_block) {
+    __shared__ float part[4][KMAX + 1][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx, cc = min(c, C - 1);
+    const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block), pad = (k - 1) / 2;
+    float acc[KMAX + 1];
+#pragma unroll
+    for (int j = 0; j <= KMAX; ++j) acc[j] = 0.f;
+    for (int m = m_lo + ty; m < m_hi; m += 4) {
+        const float v = dy[(size_t)m * ldy + cc];
+        const int lo = seg_lo ? seg_lo[m] : 0, hi = seg_hi ? seg_hi[m] : M;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            const int src = m + j - pad;
+            const float xv = (j < k && src >= lo && src < hi) ? x[src] : 0.f;
+            acc[j] = fmaf(v, xv, acc[j]);
+        }
+        acc[KMAX] += v;
+    }
+#pragma unroll
+    for (int j = 0; j <= KMAX; ++j) part[ty][j][tx] = acc[j];
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        for (int j = 0; j < k; ++j) atomicAdd(dw + (size_t)c * k + j, (part[0][j][tx] + part[1][j][tx]) + (part[2][j][tx] + part[3][j][tx]));
+        if (db) atomicAdd(db + c, (part[0][KMAX][tx] + part[1][KMAX][tx]) + (part[2][KMAX][tx] + part[3][KMAX][tx]));
+    }
 }
 
 // dz = dy * act'(y) * (keep ? keep*scale : 1)
@@ -261,7 +307,8 @@ __global__ void l1_mse_grad_kernel(const float* __restrict__ a, const float* __r
 // the loss sums of fcl_masked_l1_mse_fwd and the gradient of fcl_l1_mse_grad in one pass over a and b (the KD terms read 100 MB teacher taps)
 __global__ __launch_bounds__(256) void l1_mse_loss_grad_kernel(const float* __restrict__ a, const float* __restrict__ b, const uint8_t* __restrict__ valid,
                                                                int M, int C, int b_log, float off, float w1, float w2, float inv_count,
-                                                               float* __restrict__ da, int accumulate, double* __restrict__ sums) {
+                                                               float* __restrict__ da, int accumulate, double* __restrict__ sums,
+                                                               unsigned short* __restrict__ dap) {
     double s1 = 0.0, s2 = 0.0, cnt = 0.0;
     const int c4 = C >> 2;  // C % 4 == 0: one float4 per thread-iteration
     const long long total = (long long)M * c4;
@@ -289,6 +336,14 @@ __global__ __launch_bounds__(256) void l1_mse_loss_grad_kernel(const float* __re
             for (int e = 0; e < 4; ++e) g[e] += old[e];
         }
         *o = g;
+        if (dap) {  // the gradient as P32 planes too (C % 32 == 0): the pre-split operand of the input-gradient GEMM that consumes it
+            const int n = (int)(i - (long long)r * c4) * 4;
+            uint2 hi, lo;
+            split4(g, hi, lo);
+            unsigned short* line = dap + ((size_t)r * (C >> 5) + (n >> 5)) * 64 + (n & 31);
+            *reinterpret_cast<uint2*>(line) = hi;
+            *reinterpret_cast<uint2*>(line + 32) = lo;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -468,28 +523,49 @@ __global__ void add2d_kernel(float* __restrict__ dst, int ld_dst, const float* _
 }
 
 // ---- train-mode BatchNorm1d over rows (the reference normalises over ALL B x T positions of the padded batch, padding included) ----------------
-// pass 1: per-column sum and sum of squares in fp64 (ws[0:C], ws[C:2C], zeroed by the caller of the kernel)
-__global__ void bn_stats_kernel(const float* __restrict__ z, int M, int C, int rows_per_block, double* __restrict__ ws) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// One launch: per-column sum and sum of squares in fp64 (ws[0:C], ws[C:2C], zero on entry), 64 columns x rows_per_block rows per block with eight
+// rows in flight per thread; the LAST block of a column group to finish (a ticket per group, zero on entry) turns the sums into mean,
+// 1/sqrt(biased var + eps) and the running statistics as torch (momentum m: r = (1-m) r + m stat, variance unbiased), and leaves the sums and its
+// ticket zero again -- the workspace of one call is ready for the next (rounds 1-2: memset + statistics + finalize = 3 launches per BatchNorm).
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int M, int C, int rows_per_block, double* __restrict__ ws,
+                                                       unsigned int* __restrict__ tickets, float eps, float momentum, float* __restrict__ mean,
+                                                       float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    __shared__ double ps[4][64], pq[4][64];
+    __shared__ int last;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
     double s = 0.0, q = 0.0;
-    for (int m = m_lo; m < m_hi; ++m) {
-        const double v = (double)z[(size_t)m * C + c];
-        s += v;
-        q += v * v;
+    if (c < C) {
+        for (int m = m_lo + ty; m < m_hi; m += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = z[(size_t)min(m + 4 * j, m_hi - 1) * C + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double d = m + 4 * j < m_hi ? (double)v[j] : 0.0;
+                s += d;
+                q += d * d;
+            }
+        }
     }
-    atomicAdd(ws + c, s);
-    atomicAdd(ws + C + c, q);
-}
-
-// pass 2: mean, 1/sqrt(biased var + eps); running statistics as torch (momentum m: r = (1-m) r + m stat, variance unbiased)
-__global__ void bn_finalize_kernel(const double* __restrict__ ws, int M, int C, float eps, float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mu = ws[c] / M;
-    double var = ws[C + c] / M - mu * mu;
+    ps[ty][tx] = s;
+    pq[ty][tx] = q;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        // RETURNING atomics: the wave waits for the old values, i.e. both adds have been performed (at the device's coherence point) before this
+        // block draws its ticket -- the ordering a __threadfence() would give, without its L2 write-back (buffer_wbl2: 157 us per call at 243 blocks)
+        const double o1 = atomicAdd(ws + c, (ps[0][tx] + ps[1][tx]) + (ps[2][tx] + ps[3][tx]));
+        const double o2 = atomicAdd(ws + C + c, (pq[0][tx] + pq[1][tx]) + (pq[2][tx] + pq[3][tx]));
+        asm volatile("" ::"v"(o1), "v"(o2));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(tickets + blockIdx.x, 1u) == gridDim.y - 1;
+    __syncthreads();
+    if (!last || ty != 0 || c >= C) return;
+    const double S = atomicAdd(ws + c, 0.0), Q = atomicAdd(ws + C + c, 0.0);  // (atomic reads: served by L2, where the other blocks' atomics landed)
+    const double mu = S / M;
+    double var = Q / M - mu * mu;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -498,7 +574,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ ws, int M, int C, 
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
+    ws[c] = 0.0;
+    ws[C + c] = 0.0;
+    if (tx == 0) tickets[blockIdx.x] = 0u;
 }
+
 
 // y_act = act(gamma * (z - mean) * invstd + beta) ; y_drop = y_act * keep * scale (optional second output)
 __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -583,12 +663,21 @@ __global__ void transpose2d_kernel(const float* __restrict__ src, float* __restr
     }
 }
 
-__global__ void sumsq_kernel(const float* __restrict__ x, long long n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, double* __restrict__ out) {
+    // one fp64 atomic per BLOCK of a capped grid (one per wave of an uncapped grid was 100 000 serialised atomics on one address: 200 us for 26 MB)
+    __shared__ double part[4];
     double s = 0.0;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += (double)x[i] * x[i];
+    const long long n4 = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 ? n >> 2 : 0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+    for (long long i = 4 * n4 + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += (double)x[i] * x[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 // Adam (torch.optim.Adam semantics, weight_decay 0, amsgrad off) with the clip coefficient and the NaN guard read from device memory:
@@ -667,7 +756,7 @@ int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* 
     FCL_REQUIRE(mode == 0 || y, FCL_ERR_INVALID, "colsum_fwd: mode needs y");
     FCL_REQUIRE(mode < 2 || (g && b), FCL_ERR_INVALID, "colsum_fwd: modes 2 and 3 need g and b");
     if (m == 0) return 0;
-    const int rpb = 256;
+    const int rpb = m >= 8192 ? 128 : 64;
     hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, y, g, b, out, m, c, mode, rpb);
     return check_hip(hipGetLastError(), "colsum_fwd");
 }
@@ -708,13 +797,15 @@ int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, in
 }
 
 int fcl_l1_mse_loss_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1, float w_mse,
-                         double count, float* da, int accumulate, double* sums, fcl_stream_t stream) {
+                         double count, float* da, int accumulate, double* sums, uint16_t* da_planes, fcl_stream_t stream) {
+    FCL_REQUIRE(!da_planes || ((c & 31) == 0 && (reinterpret_cast<uintptr_t>(da_planes) & 127u) == 0), FCL_ERR_SHAPE,
+                "l1_mse_loss_grad: planes need C %% 32 == 0 and a 128-byte aligned buffer");
     FCL_REQUIRE(a && b && da && sums && m >= 0 && c > 0 && count > 0, FCL_ERR_INVALID, "l1_mse_loss_grad: bad arguments");
     FCL_REQUIRE(!(c & 3) && aligned16(a) && aligned16(b) && aligned16(da), FCL_ERR_ALIGN, "l1_mse_loss_grad: C %% 4 == 0 and 16-byte aligned operands required");
     if (m == 0) return 0;
     const int grid = std::min(grid1d((long long)m * (c / 4), 256), 1024);
     hipLaunchKernelGGL(l1_mse_loss_grad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, row_valid, m, c, b_log, b_log_offset, w_l1, w_mse,
-                       (float)(1.0 / count), da, accumulate, sums);
+                       (float)(1.0 / count), da, accumulate, sums, da_planes);
     return check_hip(hipGetLastError(), "l1_mse_loss_grad");
 }
 
@@ -765,16 +856,26 @@ int fcl_add2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, in
     return check_hip(hipGetLastError(), "add2d");
 }
 
-int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
-                     double* workspace, fcl_stream_t stream) {
+static int bn_stats_launch(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                           double* workspace, bool clear, hipStream_t s) {
     FCL_REQUIRE(z && mean && invstd && workspace && m > 0 && c > 0, FCL_ERR_INVALID, "bn_stats_fwd: bad arguments");
     FCL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FCL_ERR_INVALID, "bn_stats_fwd: running statistics come in pairs");
-    hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(workspace, 0, 2 * sizeof(double) * (size_t)c, s) != hipSuccess) return check_hip(hipGetLastError(), "bn_stats_fwd memset");
-    const int rpb = std::max(64, (m + 255) / 256);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(64), 0, s, z, m, c, rpb, workspace);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, s, workspace, m, c, eps, momentum, mean, invstd, running_mean, running_var);
+    const int groups = (c + 63) / 64;
+    if (clear && hipMemsetAsync(workspace, 0, sizeof(double) * (size_t)(2 * c + groups), s) != hipSuccess) return check_hip(hipGetLastError(), "bn_stats_fwd memset");
+    const int rpb = m >= 8192 ? 128 : 64;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(groups, (m + rpb - 1) / rpb), dim3(256), 0, s, z, m, c, rpb, workspace,
+                       reinterpret_cast<unsigned int*>(workspace + 2 * (size_t)c), eps, momentum, mean, invstd, running_mean, running_var);
     return check_hip(hipGetLastError(), "bn_stats_fwd");
+}
+
+int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                     double* workspace, fcl_stream_t stream) {
+    return bn_stats_launch(z, m, c, eps, momentum, mean, invstd, running_mean, running_var, workspace, true, (hipStream_t)stream);
+}
+
+int fcl_bn_stats_ws_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                        double* zero_workspace, fcl_stream_t stream) {
+    return bn_stats_launch(z, m, c, eps, momentum, mean, invstd, running_mean, running_var, zero_workspace, false, (hipStream_t)stream);
 }
 
 int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
@@ -835,6 +936,17 @@ int fcl_scale(float* x, size_t n, float alpha, fcl_stream_t stream) {
     return check_hip(hipGetLastError(), "scale");
 }
 
+int fcl_conv1d_in1_dw(const float* dy, int ldy, const float* x, const int32_t* seg_lo, const int32_t* seg_hi, float* dw, float* db, int m, int c, int k,
+                      fcl_stream_t stream) {
+    FCL_REQUIRE(dy && x && dw && m >= 0 && c > 0 && ldy >= c && k >= 1 && k <= 16 && (k & 1), FCL_ERR_INVALID, "conv1d_in1_dw: bad arguments (odd k <= 16)");
+    FCL_REQUIRE((seg_lo == nullptr) == (seg_hi == nullptr), FCL_ERR_INVALID, "conv1d_in1_dw: segment bounds come in pairs");
+    if (m == 0) return 0;
+    const int rpb = 64;
+    hipLaunchKernelGGL(conv1d_in1_dw_kernel<16>, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, dy, ldy, x, seg_lo, seg_hi, dw, db,
+                       m, c, k, rpb);
+    return check_hip(hipGetLastError(), "conv1d_in1_dw");
+}
+
 int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream_t stream) {
     FCL_REQUIRE(src && dst && rows > 0 && cols > 0 && src != dst, FCL_ERR_INVALID, "transpose2d: bad arguments");
     hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, src, dst, rows, cols);
@@ -844,7 +956,7 @@ int fcl_transpose2d(const float* src, float* dst, int rows, int cols, fcl_stream
 int fcl_sumsq_accum(const float* x, size_t n, double* out, fcl_stream_t stream) {
     FCL_REQUIRE(x && out, FCL_ERR_INVALID, "sumsq_accum: bad arguments");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(std::min(grid1d((long long)(n + 3) / 4, 256), 2048)), dim3(256), 0, (hipStream_t)stream, x, (long long)n, out);
     return check_hip(hipGetLastError(), "sumsq_accum");
 }
 

@@ -419,26 +419,38 @@ def gemm_tn_taps(a, b, out, shift0, seg_lo=None, seg_hi=None):
     return out
 
 
-def l1_mse_loss_grad(a, b, row_valid, count, w_l1, w_mse, sums_f64, da=None, b_log_offset=None):
-    """Loss sums (into sums_f64[0:3]) and gradient in one pass; falls back to the two separate kernels when C % 4 != 0."""
+def l1_mse_loss_grad(a, b, row_valid, count, w_l1, w_mse, sums_f64, da=None, b_log_offset=None, want_planes=False):
+    """Loss sums (into sums_f64[0:3]) and gradient in one pass; falls back to the two separate kernels when C % 4 != 0.
+    want_planes (C % 32 == 0): returns (da, P32 planes of da)."""
     if a.dim() == 1:
         a, b = a.reshape(-1, 1), b.reshape(-1, 1)
     m, c = a.shape
     if c % 4:
+        assert not want_planes
         masked_l1_mse(a, b, row_valid, sums_f64, b_log_offset)
         return l1_mse_grad(a, b, row_valid, count, w_l1, w_mse, da=da, b_log_offset=b_log_offset)
     acc = da is not None
     if da is None:
         da = torch.empty_like(a)
+    dap = planes_empty(m, c, a.device) if want_planes else None
     check(_lib.load().fcl_l1_mse_loss_grad(_p(a), _p(b), _p(row_valid, torch.uint8), m, c, int(b_log_offset is not None), float(b_log_offset or 0.0),
-                                           w_l1, w_mse, float(count), _p(da), int(acc), sums_f64.data_ptr(), _stream()))
-    return da
+                                           w_l1, w_mse, float(count), _p(da), int(acc), sums_f64.data_ptr(), _p(dap, torch.int16), _stream()))
+    return (da, dap) if want_planes else da
 
 
 def colsum(x, out, y=None, gamma=None, beta=None, mode=0):
     m, c = x.shape
     check(_lib.load().fcl_colsum_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(out), m, c, mode, _stream()))
     return out
+
+
+def conv1d_in1_dw(dy, x, dw, db=None, seg_lo=None, seg_hi=None):
+    """dw [C, 1, k] += sum_m dy[m, c] x[m + j - pad] (inside each row's utterance), db [C] += colsum(dy): Conv1d(1 -> C, k) weight / bias gradients."""
+    m, c = dy.shape
+    k = dw.shape[-1]
+    assert dy.stride(1) == 1 and x.numel() == m and x.is_contiguous() and dw.is_contiguous() and dw.numel() == c * k
+    check(_lib.load().fcl_conv1d_in1_dw(_p(dy), dy.stride(0), _p(x), _p(seg_lo, torch.int32), _p(seg_hi, torch.int32), _p(dw), _p(db), m, c, k, _stream()))
+    return dw
 
 
 def act_bwd(dy, y, act, keep=None, keep_scale=1.0, want_planes=False):
@@ -471,12 +483,19 @@ def layernorm_bwd(x, gamma, beta, eps, dgamma, dbeta, dy=None, lin_w=None, ds=No
     return dx
 
 
+_BN_WS = {}  # (device, stream) -> zero workspace of fcl_bn_stats_ws_fwd (left zero by every call; calls on one stream are ordered)
+
+
 def bn_stats(z, eps, momentum=0.1, running_mean=None, running_var=None):
     """Train-mode BatchNorm statistics over the rows of z: returns (mean, invstd); updates the running buffers in place."""
     m, c = z.shape
     mean, invstd = torch.empty(c, device=z.device), torch.empty(c, device=z.device)
-    ws = torch.empty(2 * c, device=z.device, dtype=torch.float64)
-    check(_lib.load().fcl_bn_stats_fwd(_p(z), m, c, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var), ws.data_ptr(), _stream()))
+    key = (z.device, _stream())
+    ws = _BN_WS.get(key)
+    need = 2 * c + (c + 63) // 64
+    if ws is None or ws.numel() < need:
+        ws = _BN_WS[key] = torch.zeros(max(need, 4096), device=z.device, dtype=torch.float64)
+    check(_lib.load().fcl_bn_stats_ws_fwd(_p(z), m, c, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var), ws.data_ptr(), _stream()))
     return mean, invstd
 
 

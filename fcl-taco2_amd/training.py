@@ -307,6 +307,8 @@ class ZeroArena(object):
 
 
 _DW_PLANES_MIN = int(os.environ.get("FCL_DW_PLANES_MIN", str(1 << 20)))  # output elements from which a weight gradient runs on transposed planes
+# (measured r3: sending the student's long-contraction / small-output gradients -- 13 GFLOP into [1024, 256] over ~25 k frames, 65 - 110 TFLOP/s on the
+# fp32-operand kernel -- to the planes kernel as well is a wash: its two transposing passes cost what the faster GEMM saves; KD update 12.66 vs 12.59 ms)
 
 
 class TrainEngine(object):
@@ -944,11 +946,11 @@ class TrainEngine(object):
         sums = self._z((48, 3), torch.float64)
         names = []
 
-        def term(name, a, b, valid, count, w_l1, w_mse, b_log=None, da=None):
+        def term(name, a, b, valid, count, w_l1, w_mse, b_log=None, da=None, want_planes=False):
             a2, b2 = (a.reshape(-1, 1), b.reshape(-1, 1)) if a.dim() == 1 else (a, b)
             names.append(name)
             return ops.l1_mse_loss_grad(a2, b2, valid, count * self.accum_grad, w_l1, w_mse, sums[len(names) - 1], da=da,
-                                        b_log_offset=b_log)  # loss sums + d(loss / accum_grad) in one pass
+                                        b_log_offset=b_log, want_planes=want_planes)  # loss sums + d(loss / accum_grad) in one pass
 
         inj = c.inj = {}
         # use_masking False (the reference's argparse default): Tacotron2Loss, Tacotron2Loss_KD and prosody_criterions average over the PADDED
@@ -974,6 +976,14 @@ class TrainEngine(object):
             def kd(name, s_in, proj, t, valid, nvalid):
                 """MSE(s_in . W^T, t) over valid rows: accumulates dW, returns the gradient w.r.t. s_in."""
                 w = P[proj + ".weight"]
+                n, k = w.shape
+                if ops.planes_enabled() and n % 32 == 0 and k % 32 == 0 and s_in.shape[0] >= 4096:
+                    # the projections over every frame (7 taps x ~25 k rows x up to [1024, 256]) on pre-split operands: the tap is packed once, the
+                    # loss kernel hands its gradient over as planes too (r3 trace: 1.4 ms of the update's critical path on the fp32-operand kernel)
+                    s = ops.linear_planes(ops.pack_planes(s_in), self._wplanes(proj + ".weight", w), n, k)[0]
+                    ds_, ds_p = term(name, s, t, valid, nvalid * n, 0.0, 1.0, want_planes=True)
+                    self._dw(lambda: self._dw_gemm(ds_, [(s_in, G[proj + ".weight"])]))
+                    return ops.linear_planes(ds_p, self._wplanes(proj + ".weight.t", self._wt(w)), k, n)[0]
                 s = ops.linear(s_in, w)
                 ds_ = term(name, s, t, valid, nvalid * s.shape[1], 0.0, 1.0)
                 self._dw(lambda: ops.gemm_tn(ds_, s_in, G[proj + ".weight"]))
@@ -1091,15 +1101,8 @@ class TrainEngine(object):
                 d_e = ops.add2d(d_att.clone(), inj[tap])
             if keep is not None:
                 d_e = ops.act_bwd(d_e, None, ops.ACT_NONE, keep, c.emb_ks)
-            def dw_embed(nm=nm, sig=sig, d_e=d_e):
-                ops.colsum(d_e, G[nm + "_embed.0.bias"])
-                sig4 = self._z((B * T, 4))
-                ops.copy2d(sig4[:, :1], sig.reshape(-1, 1))
-                gw = G[nm + "_embed.0.weight"].reshape(C, kk)
-                for j in range(kk):
-                    tmp = self._z((C, 4))
-                    ops.gemm_tn(d_e, sig4, tmp, shift=j - (kk - 1) // 2, seg_lo=c.e_lo, seg_hi=c.e_hi)
-                    ops.add2d(gw[:, j : j + 1], tmp[:, :1])
+            def dw_embed(nm=nm, sig=sig, d_e=d_e):  # Conv1d(1 -> C, k): weight and bias gradients in one launch
+                ops.conv1d_in1_dw(d_e, sig, G[nm + "_embed.0.weight"], G[nm + "_embed.0.bias"], seg_lo=c.e_lo, seg_hi=c.e_hi)
 
             self._dw(dw_embed)
         # ---- predictors

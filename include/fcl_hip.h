@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 300
+#define FCL_ABI_VERSION 301
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -376,6 +376,11 @@ int fcl_gemm_tn_planes(const uint16_t* ap_t, const uint16_t* bp_t, float* c, int
 /* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm)
  * | x*(y - b[c])*g[c] (mode 3: b = batch mean, g = invstd: gamma gradient of a train-mode BatchNorm). */
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream);
+/* Weight / bias gradients of a Conv1d with ONE input channel and odd k <= 16 (the pitch / energy embeddings, ..._sa.py:435-443,
+ * ..._kd_student.py:570-596): dw[c, j] += sum_m dy[m, c] * x[m + j - (k-1)/2] over the positions inside row m's utterance [seg_lo[m], seg_hi[m])
+ * (null: [0, m)), db[c] += sum_m dy[m, c] (db may be null).  dw is the [C, 1, k] weight gradient, contiguous. */
+int fcl_conv1d_in1_dw(const float* dy, int ldy, const float* x, const int32_t* seg_lo, const int32_t* seg_hi, float* dw, float* db, int m, int c, int k,
+                      fcl_stream_t stream);
 /* dst[r, 0:cols] += alpha * src[r, 0:cols] on rows with row_valid[r] != 0 (null: every row).  Strided on both sides: accumulates a
  * gradient block into a column range of weight_ih / feat_out.weight, adds residual-path gradients, masks padded rows. */
 int fcl_add2d(float* dst, int ld_dst, const float* src, int ld_src, int rows, int cols, float alpha, const uint8_t* row_valid, fcl_stream_t stream);
@@ -390,19 +395,24 @@ int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep
 /* da (+)= (w_l1 * sign(a - b') + 2 * w_mse * (a - b')) / count on the valid rows, 0 elsewhere  (b' as in fcl_masked_l1_mse_fwd). */
 int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1,
                     float w_mse, double count, float* da, int accumulate, fcl_stream_t stream);
-/* fcl_masked_l1_mse_fwd (sums[0:3] += sum|d|, sum d^2, count) and fcl_l1_mse_grad in ONE pass over a and b (C % 4 == 0). */
+/* fcl_masked_l1_mse_fwd (sums[0:3] += sum|d|, sum d^2, count) and fcl_l1_mse_grad in ONE pass over a and b (C % 4 == 0).  da_planes (optional,
+ * C % 32 == 0): the gradient also as P32 planes [m][C/32][2][32] for the input-gradient GEMM that consumes it (the KD projections). */
 int fcl_l1_mse_loss_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1,
-                         float w_mse, double count, float* da, int accumulate, double* sums, fcl_stream_t stream);
+                         float w_mse, double count, float* da, int accumulate, double* sums, uint16_t* da_planes, fcl_stream_t stream);
 /* Channel LayerNorm backward (+ the predictor's scalar head: ds = gradient of scalar[m]).  dgamma/dbeta/dlin_w/dlin_b accumulate. */
 int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,
                       const uint8_t* pad_mask, const uint8_t* keep, float keep_scale, float* dx, float* dgamma, float* dbeta, float* dlin_w,
                       float* dlin_b, int m, int c, fcl_stream_t stream);
 /* Train-mode BatchNorm1d over the rows of z [M, C] (encoder_sa.py:61-78, decoder_sa.py:199-263 under model.train(): statistics over every
- * position of the padded batch).  stats: mean / 1/sqrt(biased var + eps) accumulated in fp64 (workspace: 2*C doubles), running statistics
- * updated as torch (momentum 0.1, unbiased variance) when given.  act: y_act = act(gamma*zhat + beta), y_drop = y_act*keep*keep_scale.
+ * position of the padded batch).  stats: mean / 1/sqrt(biased var + eps) accumulated in fp64, running statistics updated as torch (momentum 0.1,
+ * unbiased variance) when given; ONE kernel (the last workgroup of a column group to finish finalises it).  workspace: 2*C + (C+63)/64 doubles;
+ * fcl_bn_stats_fwd clears it first (any content on entry), fcl_bn_stats_ws_fwd requires it ZERO on entry and leaves it zero on return (a
+ * workspace allocated once per stream serves every call: no clearing launch).  act: y_act = act(gamma*zhat + beta), y_drop = y_act*keep*keep_scale.
  * bwd: dz = gamma*invstd*(dy - dbeta/M - zhat*dgamma/M) with THIS batch's dbeta = sum dy, dgamma = sum dy*zhat (fcl_colsum_fwd modes 0 / 3). */
 int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                      double* workspace, fcl_stream_t stream);
+int fcl_bn_stats_ws_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
+                     double* zero_workspace, fcl_stream_t stream);
 int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
                    float* y_act, float* y_drop, uint16_t* yp /* optional P32 planes of the block output (after dropout), C % 32 == 0 */, int m, int c, int act,
                    fcl_stream_t stream);
