@@ -475,7 +475,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * (double)a.N * ksum;
     const GemmTerm& t0 = a.term[0];
-    static const int smallm = tunable("GEMM_SMALLM", 64);
+    static const int smallm = tunable("GEMM_SMALLM", 256);  // (r3: 64 -> 256; the BPTT steps with 65 - 256 live rows ran 34 us each on one lonely 64-row tile per 16 columns)
     if (a.M <= smallm && a.nterms == 1 && t0.shift == 0 && !a.seg_lo && !a.rank1_a && !a.C0 && a.act == FCL_ACT_NONE && a.drop_mode == 0 && !a.keep &&
         !a.Y2 && t0.K >= 256) {  // plain Y = A.W^T (+bias) (+R) on a few rows: split K over the waves instead of one lonely big tile
         ProfScope ps("gemm_smallm_kernel", flops, a.M, s);
