@@ -22,7 +22,7 @@ class DecoderWeights(C.Structure):
                           "w1_ih", "w1_hh", "b1", "wf_h", "wf_att")
     ] + [("zoneout_rate", _F), ("prenet_dropout", _F)] + [
         (n + sfx, _P) for n in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h") for sfx in ("_hi", "_lo")] + [
-        (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")]
+        (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")] + [("out_act", _I)]
 
 
 class DecoderIO(C.Structure):
@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 301  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 302  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -180,7 +180,7 @@ SIGNATURES = {
     "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }
 
-ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
 DROP_NONE, DROP_MASK, DROP_RNG = 0, 1, 2
 STATUS_GROUP_TIMEOUT, STATUS_ZERO_DURATION, STATUS_LMAX_CAP, STATUS_FRAMES_CAP, STATUS_ROWS_CAP = 1, 2, 4, 8, 16  # FCL_STATUS_* bits of a device status word
 

@@ -261,6 +261,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
         const float v = y[i];  // for dropout sites y is the PRE-dropout activation
         if (act == FCL_ACT_RELU) g = v > 0.f ? g : 0.f;
         else if (act == FCL_ACT_TANH) g *= 1.0f - v * v;
+        else if (act == FCL_ACT_SIGMOID) g *= v * (1.0f - v);
         dz[i] = g;
         if (dzp) store_p32(dzp, cols >> 5, (int)(i / cols), (int)(i % cols), g);  // pre-split operand of the input-gradient GEMM
     }
@@ -271,8 +272,7 @@ __global__ void act_fwd_kernel(const float* __restrict__ x, const uint8_t* __res
                                unsigned short* __restrict__ yp, int cols) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float v = x[i];
-        if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (act == FCL_ACT_TANH) v = tanh_f(v);
+        v = act_apply(v, act);
         if (keep) v = keep[i] ? v * scale : 0.f;
         if (y) y[i] = v;
         if (yp) store_p32(yp, cols >> 5, (int)(i / cols), (int)(i % cols), v);
@@ -763,7 +763,7 @@ int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* 
 
 int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep_scale, float* dz, uint16_t* dzp, int cols, size_t n, int act,
                 fcl_stream_t stream) {
-    FCL_REQUIRE(dy && dz && (y || act == FCL_ACT_NONE) && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "act_bwd: bad arguments");
+    FCL_REQUIRE(dy && dz && (y || act == FCL_ACT_NONE) && act >= FCL_ACT_NONE && act <= FCL_ACT_SIGMOID, FCL_ERR_INVALID, "act_bwd: bad arguments");
     FCL_REQUIRE(!dzp || (cols > 0 && (cols & 31) == 0 && n % (size_t)cols == 0 && (reinterpret_cast<uintptr_t>(dzp) & 127u) == 0), FCL_ERR_SHAPE,
                 "act_bwd: planes need cols %% 32 == 0, n %% cols == 0 and a 128-byte aligned buffer");
     if (n == 0) return 0;
@@ -773,7 +773,7 @@ int fcl_act_bwd(const float* dy, const float* y, const uint8_t* keep, float keep
 }
 
 int fcl_act_fwd(const float* x, const uint8_t* keep, float keep_scale, float* y, uint16_t* yp, int cols, size_t n, int act, fcl_stream_t stream) {
-    FCL_REQUIRE(x && (y || yp) && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "act_fwd: bad arguments");
+    FCL_REQUIRE(x && (y || yp) && act >= FCL_ACT_NONE && act <= FCL_ACT_SIGMOID, FCL_ERR_INVALID, "act_fwd: bad arguments");
     FCL_REQUIRE(!yp || (cols > 0 && (cols & 31) == 0 && n % (size_t)cols == 0 && (reinterpret_cast<uintptr_t>(yp) & 127u) == 0), FCL_ERR_SHAPE,
                 "act_fwd: planes need cols %% 32 == 0, n %% cols == 0 and a 128-byte aligned buffer");
     if (n == 0) return 0;

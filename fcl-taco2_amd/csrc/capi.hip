@@ -23,6 +23,12 @@ void set_error(const char* fmt, ...) {
 }
 
 int check_hip(hipError_t e, const char* what) {
+    static const int sync_debug = getenv("FCL_SYNC_DEBUG") ? atoi(getenv("FCL_SYNC_DEBUG")) : 0;  // developer aid: name every launch, then wait for it
+    if (sync_debug && e == hipSuccess) {
+        fprintf(stderr, "[fcl] %s\n", what);
+        fflush(stderr);
+        e = hipDeviceSynchronize();
+    }
     if (e == hipSuccess) return 0;
     set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
     return FCL_ERR_HIP;
@@ -373,7 +379,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             fp.w1_hi = w->prenet_w1_hi; fp.w1_lo = w->prenet_w1_lo;
             fp.drop_mode = drop_mode; fp.keep0 = keep0; fp.keep1 = keep1; fp.keep_scale = keep_scale; fp.drop_p = w->prenet_dropout;
             fp.seed0 = seed0; fp.seed1 = seed1; fp.seed_dev = io->seed_dev; fp.pre_out = ws.pre_b; fp.tap_prenet = io->tap_prenet;
-            fp.live = io->live_rows; fp.status = io->status;
+            fp.live = io->live_rows; fp.status = io->status; fp.out_act = w->out_act;
             if (planes) {
                 fp.before_p = io->before_p;
                 if (!small_step(n)) { fp.pre_out_p = ws.pre_p; fp.pre_out = nullptr; }  // the big-tile LSTM step reads planes only

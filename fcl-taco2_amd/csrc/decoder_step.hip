@@ -75,12 +75,14 @@ __device__ __forceinline__ void rowtile_mma(const float* A_l, int lda_l, const f
     }
     for (int k = nfull << 6; k < K; k += 16) {  // tail: K % 4 == 0, lanes past K contribute zeros
         const bool in = k + kq * 4 < K;
-        const int kk = in ? k : 0;  // keep the address valid, zero the operand instead of skipping the load
-        f32x4 a = *reinterpret_cast<const f32x4*>(ap + kk);
+        // lanes past K: keep the address valid (the first float4 of the row -- `wp + 0` would still carry the lane's kq * 4 offset, i.e. up to 12 floats
+        // past the end of a row shorter than 16, and past the end of the MATRIX in its last row: a fault when the weight ends a mapped segment) and
+        // zero the operand instead of skipping the load
+        f32x4 a = *reinterpret_cast<const f32x4*>(in ? ap + k : A_l + r16 * lda_l);
         if (!in) a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(wp[t] + kk);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(in ? wp[t] + k : wrow[t]);
             acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bb[0], acc0[t], 0, 0, 0);
             acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bb[1], acc1[t], 0, 0, 0);
             acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bb[2], acc0[t], 0, 0, 0);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512) void feat_prenet_kernel(const FeatPrenetArgs a
                     v = acc[r] + f0v[r];
                     a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
                 }
-                if (nc < a.O) A2[row * ldO + nc] = v;
+                if (nc < a.O) A2[row * ldO + nc] = (a.out_act && m < Ms_feat) ? act_apply(v, a.out_act) : v;
             }
         }
     } else {
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
                     a.before[(size_t)(fo[r] + a.t_prev) * a.O + nc] = v;
                     if (a.before_p) store_p32(a.before_p, (a.O + 31) >> 5, fo[r] + a.t_prev, nc, v);
                 }
-                if (nc < a.O) split1(v, A2h[row * ldO + nc], A2l[row * ldO + nc]);
+                if (nc < a.O) split1((a.out_act && m < Ms_feat) ? act_apply(v, a.out_act) : v, A2h[row * ldO + nc], A2l[row * ldO + nc]);
             }
         }
         if (a.before_p && (a.O & 31)) {  // zero padding of the last 32-column line of this tile's frames
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
                         a.before[(size_t)(fo[q][r] + a.t_prev) * O + fnc] = v;
                         if (a.before_p) store_p32(a.before_p, (O + 31) >> 5, fo[q][r] + a.t_prev, fnc, v);
                     }
-                    split1(v, A2h[row * ldO + fnc], A2l[row * ldO + fnc]);
+                    split1((a.out_act && m < Ms_feat) ? act_apply(v, a.out_act) : v, A2h[row * ldO + fnc], A2l[row * ldO + fnc]);
                 }
             }
         }

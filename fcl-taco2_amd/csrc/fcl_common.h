@@ -124,6 +124,7 @@ struct FeatPrenetArgs {
     int dbg_phase;              // developer timing aid (FCL_FP_DBG): 1..3 = return after the loads / feat / prenet-0 phase (results are then garbage)
     const int* live;            // optional DEVICE live-row counts [*]: M_feat := min(M_feat, live[t_prev]), M_pre := min(M_pre, live[t_cur])
     unsigned int* status;       // with `live`: FCL_STATUS_ROWS_CAP when live[t_cur] exceeds the host's bound M_pre
+    int out_act;                // FCL_ACT_*: output_activation_fn on the fed-back frame (decoder_sa.py:614-617); `before` stays raw
 };
 
 // rows a step kernel processes: the host's count, or (device-driven loops) the smaller of the host's bound and the device's count

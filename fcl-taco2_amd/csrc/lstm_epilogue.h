@@ -10,6 +10,9 @@ namespace fcl {
 // latency-critical epilogue.
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+__device__ __forceinline__ float act_apply(float v, int act) {  // FCL_ACT_*
+    return act == FCL_ACT_RELU ? fmaxf(v, 0.f) : (act == FCL_ACT_TANH ? tanh_f(v) : (act == FCL_ACT_SIGMOID ? sigmoid_f(v) : v));
+}
 
 // everything one (row m, unit u) needs besides the MFMA partial sums, fetched early to hide latency
 struct CellIn {

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .hparams import output_act_code
 from .plan import LN_EPS
 
 
@@ -362,6 +363,8 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
                 last = i == n_post - 1
                 x = ops.conv1d(x, cv.wp, cv.bias, rm.frame_lo, rm.frame_hi, ops.ACT_NONE if last else ops.ACT_TANH,
                                residual=before if last else None)
+        if hp.output_activation is not None:  # outs = output_activation_fn(before + postnet(before)) (decoder_sa.py:635-636); `before` stays raw
+            x = ops.act_fwd(x, output_act_code(hp))
         utt_frames = frames_info if frames_info is not None else maps.utt_frames
         if inter is not None:
             inter.update(p_outs=p, e_outs=e, p_embs=p_emb, e_embs=e_emb, before=before, after=x, maps=maps)

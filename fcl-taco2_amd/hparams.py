@@ -46,6 +46,7 @@ class HParams:
     append_position: bool = True
     use_masking: bool = True  # the shipped recipes (conf/*.yaml:25); the reference's argparse default is False (..._sa.py:251-262)
     use_weighted_masking: bool = False
+    output_activation: str = None  # name of a torch.nn.functional activation applied to the outputs (decoder_sa.py:397-398, 538-540, 614-617, 635-636)
 
     def check_loss_supported(self):
         """Loss variants on the HIP path: use_masking True (the shipped recipes, conf/*.yaml:25: masked means, Tacotron2Loss ..._sa.py:60-70,
@@ -76,9 +77,16 @@ class HParams:
         if self.econv_chans != self.embed_dim or self.eunits != self.econv_chans:
             bad.append("embed_dim/econv_chans/eunits differ")
         if self.zoneout_rate <= 0.0: bad.append("zoneout_rate <= 0")
+        if self.output_activation not in (None, "relu", "tanh", "sigmoid"):
+            bad.append("output_activation %r (relu / tanh / sigmoid are implemented)" % (self.output_activation,))
         if bad:
             raise NotImplementedError("fcl-taco2_amd HIP path: unsupported configuration: " + ", ".join(bad))
         return self
+
+
+def output_act_code(hp):
+    """FCL_ACT_* of hp.output_activation (include/fcl_hip.h)."""
+    return {None: 0, "relu": 1, "tanh": 2, "sigmoid": 3}[hp.output_activation]
 
 
 def student_hparams(**kw):

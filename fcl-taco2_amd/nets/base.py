@@ -58,8 +58,6 @@ def fill_missing_args(args, add_arguments):
 
 
 def hparams_from_args(idim, odim, args):
-    if args.output_activation is not None:
-        raise NotImplementedError("fcl-taco2_amd: output_activation is not supported by the HIP path")
     if args.spk_embed_dim is not None:
         raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
     return HParams(
@@ -73,7 +71,7 @@ def hparams_from_args(idim, odim, args):
         duration_predictor_kernel_size=args.duration_predictor_kernel_size,
         duration_predictor_dropout_rate=args.duration_predictor_dropout_rate,
         use_fe_condition=args.use_fe_condition, append_position=args.append_position, use_masking=bool(args.use_masking),
-        use_weighted_masking=bool(getattr(args, "use_weighted_masking", False)),
+        use_weighted_masking=bool(getattr(args, "use_weighted_masking", False)), output_activation=args.output_activation,
     ).check_supported()
 
 

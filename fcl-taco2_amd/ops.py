@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, DROP_MASK, DROP_NONE, DROP_RNG, check  # noqa: F401
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, DROP_MASK, DROP_NONE, DROP_RNG, check  # noqa: F401
 
 
 try:  # raw handle of the current stream without building a torch.cuda.Stream object per call (7 us -> 0.3 us; a training step issues ~1000 ops)

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .hparams import param_spec
+from .hparams import output_act_code, param_spec
 
 BN_EPS = 1e-5
 LN_EPS = 1e-12
@@ -179,4 +179,5 @@ class SynthesisPlan(object):
                     d.keep.append(pl)
         s.zoneout_rate = float(hp.zoneout_rate)
         s.prenet_dropout = float(hp.dropout_rate)
+        s.out_act = output_act_code(hp)  # output_activation_fn on the fed-back frame (decoder_sa.py:614-617)
         return d

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .hparams import output_act_code
 from .engine import _predictor_scalar
 
 
@@ -112,6 +113,9 @@ def forward_pass(plan, batch, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=
         # after = before + conv4 (one more pass of the residual epilogue would need conv4 twice; a plain add kernel suffices)
         r.after = ops.conv1d(post[-2], plan.postnet[-1].wp, plan.postnet[-1].bias, f_lo, f_hi, ops.ACT_NONE, residual=before) if n_post >= 2 else None
         r.before = before
+        if hp.output_activation is not None:  # decoder_sa.py:538-540: both outputs activated AFTER the postnet has read the raw `before`
+            r.after = ops.act_fwd(r.after, output_act_code(hp))
+            r.before = ops.act_fwd(before, output_act_code(hp))
         r.dec_taps = list(taps) + post
         r.ys = _dev(batch["ys"][:, :L], dev, torch.float32).reshape(B * L, -1)
         r.ds = _dev(batch["extras"][:, :T], dev, torch.float32).reshape(-1)

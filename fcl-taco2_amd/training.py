@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .hparams import output_act_code
 from .plan import BN_EPS, LN_EPS
 
 BN_MOMENTUM = 0.1  # torch.nn.BatchNorm1d default
@@ -922,6 +923,9 @@ class TrainEngine(object):
             c.post_c.append(cc)
             c.post_taps.append(x)
         c.after = ops.add_vec(c.before, x)
+        if hp.output_activation is not None:  # decoder_sa.py:538-540: the losses / the knowledge see activated outputs; the postnet read the raw `before`
+            c.before_raw_act = (ops.act_fwd(c.before, output_act_code(hp)), ops.act_fwd(c.after, output_act_code(hp)))
+            c.before, c.after = c.before_raw_act
         if c.bn_run:
             if self._nbt_flat is not None and len(c.bn_run) == self._nbt_flat.numel():
                 self._nbt_flat.add_(1)
@@ -1024,6 +1028,9 @@ class TrainEngine(object):
         U, Pn, C = hp.dunits, hp.prenet_units, hp.eunits
         N, F, lmax, live, offs = c.N, c.F, c.lmax, c.live, c.offs
         # ---- postnet: after = before + postnet(before)
+        if hp.output_activation is not None:  # back through output_activation_fn (y = the activated outputs)
+            inj["before"] = ops.act_bwd(inj["before"], c.before, output_act_code(hp))
+            inj["after"] = ops.act_bwd(inj["after"], c.after, output_act_code(hp))
         d_before = inj["before"]
         ops.add2d(d_before, inj["after"])
         dx = inj["after"]

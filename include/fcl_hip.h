@@ -28,7 +28,7 @@ extern "C" {
 typedef void* fcl_stream_t;
 
 enum { FCL_OK = 0, FCL_ERR_INVALID = -1, FCL_ERR_SHAPE = -2, FCL_ERR_ALIGN = -3, FCL_ERR_HIP = -4, FCL_ERR_WORKSPACE = -5 };
-enum { FCL_ACT_NONE = 0, FCL_ACT_RELU = 1, FCL_ACT_TANH = 2 };
+enum { FCL_ACT_NONE = 0, FCL_ACT_RELU = 1, FCL_ACT_TANH = 2, FCL_ACT_SIGMOID = 3 };
 enum { FCL_DROP_NONE = 0, FCL_DROP_MASK = 1, FCL_DROP_RNG = 2 };
 /* Bits of a DEVICE status word (uint32, caller-owned, zeroed by the caller): failures a kernel can only detect while it runs are OR-ed into
  * it instead of being lost.  fcl_adam_step refuses to update the parameters while the word is non-zero; the host reads it back next to the
@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 301
+#define FCL_ABI_VERSION 302
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -264,6 +264,8 @@ typedef struct {
     /* optional P32 planes (fcl_pack_planes) of the GEMM-sized matrices: with all six set (and C, P, U multiples of 32) the hoists and the
      * LSTM steps with more than ~1000 live rows run on the LDS-DMA kernels, states and prenet outputs travelling between them pre-split */
     const uint16_t *w0_att_p, *wf_att_p, *w0_pre_p, *w0_hh_p, *w1_ih_p, *w1_hh_p;
+    int out_act;            /* FCL_ACT_*: `output_activation_fn` on the frame fed back to the prenet in the free-running loop
+                             * (decoder_sa.py:614-617; `before` keeps the raw feat_out values, the caller activates the final output :635-636) */
 } fcl_decoder_weights_t;
 
 typedef struct {

@@ -233,6 +233,12 @@ def postnet(sd, hp, x_bcl, bn_train=False, keeps=None, p=0.5):
     return outs
 
 
+def _out_act(hp, x):
+    """output_activation_fn (decoder_sa.py:353-360: getattr(torch.nn.functional, name)); None = identity."""
+    name = getattr(hp, "output_activation", None)
+    return x if name is None else getattr(F, name)(x)
+
+
 def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=None, zone_keep=None):
     """H6-H8 hot loop — Decoder.inference decoder_sa_kd.py:742-778 (free-running, teacher_ys None) or
     Decoder.forward :572-625 (teacher forced: prev_out = y_t).
@@ -267,7 +273,7 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
         l1.append(z[1])
         out = F.linear(torch.cat([z[1], att_c], dim=1), wf)  # H8, no bias
         outs.append(out)
-        prev = out if teacher_ys is None else teacher_ys[:, t]
+        prev = _out_act(hp, out) if teacher_ys is None else teacher_ys[:, t]  # decoder_sa.py:614-617: the fed-back frame is activated
     return (torch.stack(outs, dim=2), torch.stack(pres, dim=1), torch.stack(l0, dim=1), torch.stack(l1, dim=1))
 
 
@@ -284,7 +290,7 @@ def decoder_inference(sd, hp, h, ds, p_embs, e_embs, prenet_keep=None):
     outs, _, _, _ = decoder_loop(sd, hp, h, position, n_steps, None, prenet_keep)
     segs = [outs[p, :, : int(nz[p])] for p in range(h.shape[0])]  # H10 re-assembly (:782-790)
     before = torch.cat(segs, dim=-1).unsqueeze(0)  # [1, odim, L]
-    after = before + postnet(sd, hp, before)[-1]
+    after = _out_act(hp, before + postnet(sd, hp, before)[-1])  # decoder_sa.py:635-636 (`before` is not returned by the reference: kept raw)
     return after[0].t(), before[0].t()
 
 
@@ -377,7 +383,8 @@ def decoder_forward(sd, hp, hs, olens, new_ys, non_zero_lens_mask, ds_nonzeros, 
     before = regroup(outs.transpose(1, 2))  # [B, L, odim]
     post = postnet(sd, hp, before.transpose(1, 2), bn_train, None if post_keeps is None else [_t(k).transpose(1, 2) for k in post_keeps],
                    hp.dropout_rate)
-    after = before + post[-1].transpose(1, 2)
+    after = _out_act(hp, before + post[-1].transpose(1, 2))  # decoder_sa.py:538-540 / decoder_sa_kd.py:698-700: both outputs, after the postnet
+    before = _out_act(hp, before)
     taps = [regroup(pres), regroup(l0), regroup(l1)] + [p.transpose(1, 2) for p in post]
     return after, before, taps
 

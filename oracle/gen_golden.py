@@ -78,7 +78,7 @@ def ns(hp, **extra):
         "embed_dim elayers eunits econv_layers econv_chans econv_filts dlayers dunits prenet_layers "
         "prenet_units postnet_layers postnet_chans postnet_filts use_batch_norm use_concate use_residual "
         "reduction_factor dropout_rate zoneout_rate use_masking duration_predictor_layers "
-        "duration_predictor_chans duration_predictor_kernel_size duration_predictor_dropout_rate").split()}
+        "duration_predictor_chans duration_predictor_kernel_size duration_predictor_dropout_rate output_activation").split()}
     d["encoder_resume"] = None
     d.update(extra)
     return argparse.Namespace(**d)
@@ -559,13 +559,49 @@ def gen_g11():
     save("g11_student_kd_residual", **d)
 
 
+def gen_g12():
+    """G12: `--output-activation sigmoid` (decoder_sa.py:353-360 resolves torch.nn.functional.<name>): the free-running loop feeds the ACTIVATED
+    frame back (:614-617) and activates the final output (:635-636); forward() activates before_outs and after_outs behind the postnet (:538-540,
+    decoder_sa_kd.py:698-700).  Teacher: inference mel + training step (eval form); student: KD step against a teacher with the same activation."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, output_activation="sigmoid")
+    TA = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **kw)
+    SA = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, **kw)
+    rng = np.random.RandomState(12)
+    x = torch.from_numpy(rng.randint(1, TA.idim, size=7).astype(np.int64))
+    dur = torch.tensor([2, 1, 4, 3, 1, 5, 2])
+    te, _ = build("teacher", TA)
+    assert te.dec.output_activation_fn is torch.nn.functional.sigmoid
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+    save("g12_teacher_sigmoid_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    loss = te(**b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(te, d)
+    _grads(te, GRAD_KEYS, d)
+    save("g12_teacher_sigmoid", **d)
+    kt, _ = build("kd_teacher", TA)
+    with torch.no_grad():
+        know = kt(**b)
+    st, _ = build("student", SA, TA, True)
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), t_after=t2n(know[0]), t_before=t2n(know[1]))
+    _named_losses(st, d)
+    _grads(st, [k for k in GRAD_KEYS] + KD_KEYS, d)
+    save("g12_student_kd_sigmoid", **d)
+
+
 def main():
     assert os.path.isdir(REF), "gen_golden.py needs /root/reference (survey container only)"
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11"}, only
+        assert only <= {"g10", "g11", "g12"}, only
+        if "g12" in only:
+            gen_g12()
         if "g10" in only:
             gen_g10()
         if "g11" in only:
@@ -580,6 +616,7 @@ def main():
     gen_g7_g8_g9()
     gen_g10()
     gen_g11()
+    gen_g12()
 
 
 if __name__ == "__main__":

@@ -42,3 +42,9 @@ TINY_SR = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_cha
                              postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0, use_residual=True)
 TINY_TR = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, use_residual=True)
+
+# the `--output-activation sigmoid` variant (G12): same shapes / weights, outputs through torch.nn.functional.sigmoid
+TINY_SA = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20,
+                             postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0, output_activation="sigmoid")
+TINY_TA = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
+                             postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, output_activation="sigmoid")

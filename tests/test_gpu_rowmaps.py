@@ -245,6 +245,8 @@ def test_grouped_predictor_launches_equal_the_per_predictor_path():
     same outputs (the stacked layer-0 GEMM and the grouped kernels compute every output element exactly as the separate ones do)."""
     from fcl_taco2_amd import engine, ops
 
+    if not ops.planes_enabled():
+        pytest.skip("FCL_PRECISION=0: the grouped launches exist on the pre-split operand path only")
     hp = HP.student_hparams(dropout_rate=0.0)
     plan = _plan(hp, SYN.positive_duration_head(np_state_dict(hp)))
     assert plan.group_pe is not None and plan.group_dpe is not None and plan.group_dpe.G == 3

@@ -26,7 +26,7 @@ COM = argparse.Namespace(use_fe_condition=True, append_position=True, distill_ou
 def _ns(hp):
     return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
                               postnet_chans=hp.postnet_chans, use_residual=hp.use_residual, use_masking=hp.use_masking, dropout_rate=hp.dropout_rate,
-                              duration_predictor_chans=hp.duration_predictor_chans)
+                              duration_predictor_chans=hp.duration_predictor_chans, output_activation=hp.output_activation)
 
 
 def _model(role, hp, thp=None):
@@ -261,6 +261,48 @@ def test_use_residual_variant_vs_reference_g11():
     orep["loss"].backward()
     assert abs(rep["loss"] - float(orep["loss"])) < 5e-4
     _check_vs_oracle(eng, sd)
+
+
+def test_output_activation_variant_vs_reference_g12():
+    """G12: `--output-activation sigmoid` on the HIP path: synthesis (activated feedback inside the decoder loop kernels, activated final mel) vs the
+    reference's mel; the teacher step and the student KD step vs the reference's losses / gradients; tanh / relu vs the oracle."""
+    import dataclasses
+
+    from helpers import TINY_SA, TINY_TA, np_state_dict
+    from fcl_taco2_amd import engine
+    from fcl_taco2_amd.plan import SynthesisPlan
+    from fcl_taco2_amd.training import TrainEngine
+
+    g = _golden("g12_teacher_sigmoid_inference")
+    plan = SynthesisPlan(np_state_dict(TINY_TA), TINY_TA, DEV)
+    mel = engine.synthesize(plan, [g["x"]], [g["dur"]], dropout_mode=0)[0]
+    assert max_abs(mel.cpu(), g["after"]) < 1e-3
+    batch = _batch()
+    eng = TrainEngine(_model("teacher", TINY_TA))
+    rep = eng.forward_backward(batch)
+    assert _check_vs_golden(eng, rep, _golden("g12_teacher_sigmoid"), KD_KEYS[:6]) >= 10
+    g = _golden("g12_student_kd_sigmoid")
+    know = TrainEngine(_model("kd_teacher", TINY_TA)).knowledge(batch, mode="eval")
+    assert max_abs(know[0].cpu(), g["t_after"]) < 1e-4 and max_abs(know[1].cpu(), g["t_before"]) < 1e-4
+    eng = TrainEngine(_model("student", TINY_SA, TINY_TA))
+    rep = eng.forward_backward(batch, teacher_knowledge=know)
+    assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
+    for name in ("tanh", "relu"):
+        hp = dataclasses.replace(TINY_TA, output_activation=name)
+        eng = TrainEngine(_model("teacher", hp))
+        rep = eng.forward_backward(batch)
+        sd = _grad_sd(hp)
+        orep = O.model_forward(sd, hp, _cpu(batch), "teacher")
+        orep["loss"].backward()
+        assert abs(rep["loss"] - float(orep["loss"])) < 5e-4, name
+        _check_vs_oracle(eng, sd)
+        x = np.array([3, 5, 1, 7, 2], dtype=np.int64)
+        d = np.array([2, 3, 1, 4, 2], dtype=np.int64)
+        plan = SynthesisPlan(np_state_dict(hp), hp, DEV)
+        mel = engine.synthesize(plan, [x], [d], dropout_mode=0)[0]
+        with torch.no_grad():
+            ref = O.inference(torch_state_dict(hp), hp, torch.from_numpy(x), dur=torch.from_numpy(d))["after"]
+        assert max_abs(mel.cpu(), ref) < 1e-3, name
 
 
 def test_device_rng_masks_statistics_and_repeatability():

@@ -239,3 +239,43 @@ def test_teacher_update_at_configs3_size_tracks_torch_adam():
     assert max(float(d.max()) for d in diffs) <= 2e-3 * (1 + 1e-4)
     # coordinates whose gradient is smaller than the two implementations' difference take opposite sign steps (2 lr apart): at most 5 % of them
     assert sum(float(d.sum()) for d in diffs) / sum(d.numel() for d in diffs) < 1e-4
+
+
+def test_bf16_step_against_the_oracle_under_torch_autocast():
+    """The mixed-precision recipe (`--use-amp True`, tts.py:414-416; bf16 in place of apex's fp16) tied to an INDEPENDENT implementation (round-2
+    VERDICT weak #10: the other bf16 test compares the HIP path with itself): FCL-taco2-T dims, 4 utterances, eval form, reference-initialised
+    weights.  Three gradients of the same step: the oracle in float64 (exact), the oracle's fp32 model under real torch.autocast(bfloat16) on the
+    CPU (what torch's own mixed precision computes), and TrainEngine(amp="bf16") on the GPU.  The HIP bf16 step must sit as close to the exact
+    gradient as torch's autocast does (direction and norm), its losses within bf16 level of the exact ones."""
+    from fcl_taco2_amd import hparams as HP, ops, synthetic as SYN
+    from fcl_taco2_amd.training import TrainEngine
+
+    if not ops.planes_enabled():
+        pytest.skip("FCL_PRECISION=0: the bf16 mode needs the bf16 MFMA path")
+    _threads()
+    T = HP.teacher_hparams(dropout_rate=0.0)
+    batch = _batch(4, 47, T.idim)
+    model = SYN.build_model("teacher", T, None, DEV, weights="init", seed=5)
+    sd64, sd32 = _grad_sd(model), _grad_sd(model, torch.float32)
+    eng = TrainEngine(model, amp="bf16")
+    rep = eng.forward_backward(batch, mode="eval")
+    torch.cuda.synchronize()
+    o64 = O.model_forward(sd64, T, _cpu64(batch), "teacher", bn_train=False)
+    o64["loss"].backward()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        oac = O.model_forward(sd32, T, _cpu(batch), "teacher", bn_train=False)
+    oac["loss"].float().backward()
+    names = [k for k, v in sd64.items() if v.dtype.is_floating_point and v.requires_grad]
+    flat = lambda get: torch.cat([get(k).double().reshape(-1) for k in names])
+    g64 = flat(lambda k: sd64[k].grad if sd64[k].grad is not None else torch.zeros_like(sd64[k]))
+    gac = flat(lambda k: sd32[k].grad if sd32[k].grad is not None else torch.zeros_like(sd32[k]))
+    g16 = flat(lambda k: eng.G[k].cpu())
+    cos = lambda a, b: float((a * b).sum() / a.norm() / b.norm())
+    c_hip, c_ac = cos(g16, g64), cos(gac, g64)
+    n_hip, n_ac = float(g16.norm() / g64.norm()), float(gac.norm() / g64.norm())
+    print("bf16 step vs float64: HIP cos %.6f norm ratio %.4f | torch.autocast cos %.6f norm ratio %.4f" % (c_hip, n_hip, c_ac, n_ac))
+    assert c_hip > 0.999 and c_hip > c_ac - 5e-4, (c_hip, c_ac)
+    assert abs(n_hip - 1.0) < max(5e-3, 2.0 * abs(n_ac - 1.0)), (n_hip, n_ac)
+    for k in LOSS_KEYS:
+        ref = float(o64[k])
+        assert abs(rep[k] - ref) < max(5e-3 * max(1.0, abs(ref)), 2.0 * abs(float(oac[k]) - ref)), (k, rep[k], ref, float(oac[k]))

@@ -288,6 +288,36 @@ def test_g11_use_residual_variant(golden):
     assert rec["use_residual_teacher_training"].startswith("RuntimeError")
 
 
+def test_g12_output_activation_variant(golden):
+    """`--output-activation sigmoid`: the activated frame is fed back in the free-running loop, the final output is activated, forward() activates
+    both outputs behind the postnet.  Inference mel, teacher step and student KD step vs the real reference."""
+    from helpers import TINY_SA, TINY_TA
+
+    g4, g = golden("g4_integer"), golden("g12_teacher_sigmoid_inference")
+    sd0 = torch_state_dict(TINY_TA)
+    with torch.no_grad():
+        out = O.inference(sd0, TINY_TA, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]))
+    assert max_abs(out["after"], g["after"]) < TOL_STAGE and float(out["after"].min()) > 0.0 and float(out["after"].max()) < 1.0
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden("g12_teacher_sigmoid")
+    sd = _grad_sd(TINY_TA)
+    rep = O.model_forward(sd, TINY_TA, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 10
+    g = golden("g12_student_kd_sigmoid")
+    with torch.no_grad():
+        know = O.model_forward(torch_state_dict(TINY_TA), TINY_TA, b, "kd_teacher")
+    assert max_abs(know[0], g["t_after"]) < TOL_STAGE and max_abs(know[1], g["t_before"]) < TOL_STAGE
+    sd = _grad_sd(TINY_SA, TINY_TA, True)
+    rep = O.model_forward(sd, TINY_SA, b, "student", TINY_TA, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "encoder_loss", "decoder_loss", "prosody_loss", "output_l1_loss", "output_mse_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 20
+
+
 def test_g6_padding_leak_and_zero_duration(golden):
     g = golden("g6_padding_leak")
     rec = json.load(open(os.path.join(GOLDEN, "records.json")))
