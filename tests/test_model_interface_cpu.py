@@ -72,6 +72,16 @@ def test_unsupported_configurations_fail_loudly():
         cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True, embed_dim=256)), com())
     with pytest.raises(NotImplementedError):
         cls(80, 80, argparse.Namespace(**dict(T_ARGS, reduction_factor=2)), com())
+    for name in ("relu", "tanh", "sigmoid"):  # round 3: output_activation is on the HIP path (G12) for the activations with a kernel ...
+        assert cls(80, 80, argparse.Namespace(**dict(T_ARGS, output_activation=name)), com()).hp.output_activation == name
+    with pytest.raises(NotImplementedError):  # ... any other torch.nn.functional name is refused
+        cls(80, 80, argparse.Namespace(**dict(T_ARGS, output_activation="softplus")), com())
+    # what the reference itself does with speaker embeddings (tests/golden/records.json, written by oracle/gen_golden.py from the real classes):
+    # the teacher runs, the KD student -- the point of the repository -- cannot (its pemb / eemb projections are built for `eunits` inputs)
+    import json
+    import os
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "records.json")))
+    assert rec["spk_embed_teacher_training_and_inference"] == "runs" and rec["spk_embed_student_kd_training"].startswith("RuntimeError")
     m = cls(80, 80, argparse.Namespace(**T_ARGS), com())
     with pytest.raises(RuntimeError, match="no CPU fallback"):  # train-mode forward runs the fused HIP engine: needs the model on a GPU
         m.train().forward(torch.zeros(1, 3, dtype=torch.long), [3], torch.zeros(1, 3, 80), [3])
