@@ -703,6 +703,13 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     }
     if (a.accumulate && force == 0)  // split contraction fills the device whatever the tile count: the largest tiles that fit the output
         return (a.M >= 128 && a.N >= 128) ? launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops) : launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
+    // 256 x 128 tiles (64 x 64 per wave): 48 KB instead of 64 KB of LDS-DMA per 256 x 128 x 32 MACs -- the main loop is bound by the global -> LDS
+    // fill rate, so -25 % bytes per FLOP.  Measured r3 (tools/time_pgemm.py): +6 ... +12 % on frame-sized GEMMs with K >= 512 (12 400 x 4 096 x 512:
+    // 203 -> 226 TFLOP/s fp32-equivalent), -10 ... -50 % at K <= 256 (the epilogue of a 256-row tile is not overlapped by anything at one workgroup
+    // per CU), and no change of the KD / teacher update (12.58 / 12.93 vs 12.60 / 12.95 ms: few of their GEMMs qualify) -> off unless asked for
+    static const int big_min = tunable("PGEMM_BIG_MIN_WG", 1 << 30);
+    const long long t256x128 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+    if (force == 3 || (force == 0 && t256x128 >= big_min && a.N >= 128 && ksum >= 512)) return launch_pgemm_cfg<4, 2, 4, 4, 3>(a, s, flops);
     if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
     if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pgemm_cfg<2, 2, 2, 4, 3>(a, s, flops);
     return launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
