@@ -204,6 +204,28 @@ __global__ void variance_embed_add_kernel(const float* __restrict__ hs, const fl
     }
 }
 
+// ---- speaker embedding: hs <- cat[hs, F.normalize(spemb)] (..._sa.py:555-557, 636-638) -------------------------------------------------
+// out[row, 0:C] = hs[row, 0:C]; out[row, C:C+S] = spk[b] / max(||spk[b]||_2, 1e-12) with b = row / T (the padded [B, T] row layout).  One wave per
+// row: the norm of its utterance's vector by a wave reduction (S <= a few hundred floats, L2-resident), then C + S contiguous outputs; outp
+// (optional): the row also as P32 planes ((C + S) % 32 == 0).
+__global__ __launch_bounds__(256) void concat_spk_kernel(const float* __restrict__ hs, int ldh, const float* __restrict__ spk, int C, int S, int T, int M,
+                                                         float* __restrict__ out, unsigned short* __restrict__ outp) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* sv = spk + (size_t)(row / T) * S;
+    float q = 0.f;
+    for (int i = lane; i < S; i += 64) q = fmaf(sv[i], sv[i], q);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float inv = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+    const int W = C + S;
+    for (int i = lane; i < W; i += 64) {
+        const float v = i < C ? hs[(size_t)row * ldh + i] : sv[i - C] * inv;
+        if (out) out[(size_t)row * W + i] = v;
+        if (outp) store_p32(outp, W >> 5, row, i, v);
+    }
+}
+
 // ---- H10 position table ---------------------------------------------------------------------------
 __global__ void position_table_kernel(const int* __restrict__ dur, float* __restrict__ pos, int n, int lmax) {
     const long long total = (long long)n * lmax;
@@ -655,6 +677,15 @@ int fcl_masked_l1_mse_fwd(const float* a, int lda, const float* b, int ldb, cons
     hipLaunchKernelGGL(masked_l1_mse_kernel, dim3(std::min(grid_for((long long)m * c, 256 * 8), 512)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb,
                        row_valid, m, c, b_log, b_log_offset, out);
     return check_hip(hipGetLastError(), "masked_l1_mse_fwd");
+}
+
+int fcl_concat_spk_fwd(const float* hs, int ldh, const float* spk, float* out, uint16_t* out_p, int m, int c, int s, int t, fcl_stream_t stream) {
+    FCL_REQUIRE(hs && spk && (out || out_p) && m >= 0 && c > 0 && s > 0 && t > 0 && ldh >= c, FCL_ERR_INVALID, "concat_spk_fwd: bad arguments");
+    FCL_REQUIRE(!out_p || (((c + s) & 31) == 0 && (reinterpret_cast<uintptr_t>(out_p) & 127u) == 0), FCL_ERR_SHAPE,
+                "concat_spk_fwd: planes need (C + S) %% 32 == 0 and a 128-byte aligned buffer");
+    if (m == 0) return 0;
+    hipLaunchKernelGGL(concat_spk_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, hs, ldh, spk, c, s, t, m, out, out_p);
+    return check_hip(hipGetLastError(), "concat_spk_fwd");
 }
 
 int fcl_position_table_fwd(const int32_t* dur, float* pos, int n, int lmax, fcl_stream_t stream) {

@@ -114,7 +114,7 @@ def use_planes(plan):
     """Pre-split (P32) operands end to end: on by default (FCL_PRECISION=0 / FCL_PLANES=0 turn it off), needs whole 32-column lines."""
     hp = plan.hp
     return (ops.planes_enabled() and plan.enc_convs[0].wpp is not None and plan.decoder.struct.w0_att_p is not None
-            and all(x % 32 == 0 for x in (hp.embed_dim, hp.econv_chans, hp.eunits, hp.postnet_chans, hp.duration_predictor_chans,
+            and all(x % 32 == 0 for x in (hp.embed_dim, hp.econv_chans, hp.eunits, hp.adim, hp.postnet_chans, hp.duration_predictor_chans,
                                           hp.variance_predictor_chans)))
 
 
@@ -122,7 +122,7 @@ class PreparedBatch(object):
     """Everything `run` needs, resident in HBM: padded ids, segment bounds, and (forced durations) row maps -- built on the host (`maps`), or
     left to the device (`dur_pad`: the forced durations in the padded [B, T] layout; run() then needs `caps`)."""
     __slots__ = ("B", "T", "lens", "ids", "seg_lo", "seg_hi", "pad", "lens_dev", "f0e", "maps", "src_rows", "dur", "frame_off",
-                 "frame_lo", "frame_hi", "dur_pad")
+                 "frame_lo", "frame_hi", "dur_pad", "spk")
 
 
 class Caps(object):
@@ -203,7 +203,7 @@ def _upload_maps(holder, maps, dev):
         setattr(holder, k, up[o : o + n])
 
 
-def prepare(plan, xs, durs=None, f0=None, energy=None, device_maps=False):
+def prepare(plan, xs, durs=None, f0=None, energy=None, device_maps=False, spembs=None):
     """Input hand-over: pad + upload phoneme ids, build the integer segment bounds, and — when durations are
     forced — the row maps.  This is the host batch layout step (the reference's loader/converter side).  Every integer array of the batch
     travels in ONE packed int32 block (plus the ids and the pad mask) through fixed pinned staging buffers, non-blocking: three copies per
@@ -247,9 +247,17 @@ def prepare(plan, xs, durs=None, f0=None, energy=None, device_maps=False):
             pe[0, b, : p.lens[b]] = np.asarray(f0[b]).reshape(-1)
             pe[1, b, : p.lens[b]] = np.asarray(energy[b]).reshape(-1)
         items["f0e"] = torch.from_numpy(pe.reshape(2, -1))
+    if plan.hp.spk_embed_dim is not None:  # one speaker-embedding vector per utterance (tts.py:285-287, ..._sa.py:636-638)
+        if spembs is None:
+            raise ValueError("fcl-taco2_amd: the model was built with spk_embed_dim=%d: every utterance needs its speaker embedding" % plan.hp.spk_embed_dim)
+        sp = np.stack([(s.detach().cpu().numpy() if torch.is_tensor(s) else np.asarray(s)).reshape(-1) for s in spembs]).astype(np.float32)
+        assert sp.shape == (p.B, plan.hp.spk_embed_dim), "speaker embeddings must be [B, spk_embed_dim]"
+        items["spk"] = torch.from_numpy(np.ascontiguousarray(sp))
+    elif spembs is not None:
+        raise ValueError("fcl-taco2_amd: speaker embeddings given to a model without spk_embed_dim")
     with torch.cuda.device(dev):
         up = _ring().upload(items, dev)
-    p.ids, p.pad, p.f0e = up["ids"], up["pad"], up.get("f0e")
+    p.ids, p.pad, p.f0e, p.spk = up["ids"], up["pad"], up.get("f0e"), up.get("spk")
     for k, (o, n) in layout.items():
         setattr(p, k, up["i32"][o : o + n])
     return p
@@ -299,6 +307,10 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
             hs = encode(plan, prep, bilstm_algo)
             predictor = lambda pp, pad: _predictor_scalar(pp, hs, prep.seg_lo, prep.seg_hi, pad)
         inter = {"hs": hs, "T": prep.T} if return_intermediates else None
+        if hp.spk_embed_dim is not None:  # hs <- cat[hs, F.normalize(spemb)]: predictors, embeddings and decoder see eunits + spk_embed_dim channels
+            if getattr(prep, "spk", None) is None:
+                raise ValueError("fcl-taco2_amd: this pass needs speaker embeddings (prepare(..., spembs=...))")
+            hs, hs_p = ops.concat_spk(hs, prep.spk, prep.T, want_f32=True, want_planes=planes)
         rm = prep  # holder of the row maps
         frames_info = None
         # the predictors share one geometry in the shipped recipes: one launch per layer for all of them (plan.PredictorGroup) instead of one each
@@ -373,12 +385,13 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
 
 
 def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0,
-               bilstm_algo=0, return_intermediates=False, caps=None):
+               bilstm_algo=0, return_intermediates=False, caps=None, spembs=None):
     """xs: list of 1-D int64 id arrays/tensors; durs: optional list of forced durations (else predicted).
+    spembs: list of speaker-embedding vectors [spk_embed_dim], one per utterance (models built with spk_embed_dim).
     f0/energy: optional lists of [T] arrays replacing the predictors (inference(f0=..., energy=...)).
     prenet_keep: optional uint8 [Lmax, 2, N, P] in (utterance, phoneme) row order (FCL_DROP_MASK).
     Returns a list of mel tensors [L_b, odim] (views into one packed device buffer)."""
-    prep = prepare(plan, xs, durs, f0, energy, device_maps=caps is not None)
+    prep = prepare(plan, xs, durs, f0, energy, device_maps=caps is not None, spembs=spembs)
     out = run(plan, prep, dropout_mode, prenet_keep, seed, bilstm_algo, return_intermediates, caps=caps)
     import os
 
@@ -450,6 +463,9 @@ class BatchRunner(object):
 
     def __init__(self, plan, batch, t_cap, caps, forced=True, stream=None, dropout_mode=ops.DROP_RNG, seed=0, depth=3):
         dev = plan.device
+        if plan.hp.spk_embed_dim is not None:
+            raise NotImplementedError("fcl-taco2_amd: the capacity-graph feed (BatchRunner / the decode driver) does not carry speaker embeddings yet; "
+                                      "use engine.synthesize(..., spembs=...) / model.inference(..., spemb=...)")
         self.plan, self.B, self.T, self.caps, self.forced = plan, int(batch), int(t_cap), caps, bool(forced)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         n = self.B * self.T

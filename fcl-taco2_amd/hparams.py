@@ -46,7 +46,13 @@ class HParams:
     append_position: bool = True
     use_masking: bool = True  # the shipped recipes (conf/*.yaml:25); the reference's argparse default is False (..._sa.py:251-262)
     use_weighted_masking: bool = False
+    spk_embed_dim: int = None  # speaker-embedding width: F.normalize(spemb) is concatenated to every encoder state (..._sa.py:555-557, 636-638)
     output_activation: str = None  # name of a torch.nn.functional activation applied to the outputs (decoder_sa.py:397-398, 538-540, 614-617, 635-636)
+
+    @property
+    def adim(self):
+        """Width of the decoder / predictor input: eunits, + spk_embed_dim with speaker embeddings (`dec_idim`, ..._sa.py:380-384)."""
+        return self.eunits + (self.spk_embed_dim or 0)
 
     def check_loss_supported(self):
         """Loss variants on the HIP path: use_masking True (the shipped recipes, conf/*.yaml:25: masked means, Tacotron2Loss ..._sa.py:60-70,
@@ -77,6 +83,8 @@ class HParams:
         if self.econv_chans != self.embed_dim or self.eunits != self.econv_chans:
             bad.append("embed_dim/econv_chans/eunits differ")
         if self.zoneout_rate <= 0.0: bad.append("zoneout_rate <= 0")
+        if self.spk_embed_dim is not None and (self.spk_embed_dim <= 0 or self.spk_embed_dim % 4):
+            bad.append("spk_embed_dim %r (a positive multiple of 4 is implemented)" % (self.spk_embed_dim,))
         if self.output_activation not in (None, "relu", "tanh", "sigmoid"):
             bad.append("output_activation %r (relu / tanh / sigmoid are implemented)" % (self.output_activation,))
         if bad:
@@ -144,7 +152,7 @@ def param_spec(hp, projections_to=None, share_proj=True):
         for i in range(1 if share_proj else hp.econv_layers):
             s["enc.convs_proj.%d.weight" % i] = (T.econv_chans, C)
         s["enc.blstm_proj.weight"] = (T.eunits, hp.eunits)
-    D, U, P = hp.eunits, hp.dunits, hp.prenet_units
+    D, U, P = hp.adim, hp.dunits, hp.prenet_units  # D: the decoder's / predictors' input width (`dec_idim`)
     for l in range(hp.dlayers):
         iu = D + P + (1 if hp.append_position else 0) if l == 0 else U
         s["dec.lstm.%d.cell.weight_ih" % l] = (4 * U, iu)

@@ -58,8 +58,6 @@ def fill_missing_args(args, add_arguments):
 
 
 def hparams_from_args(idim, odim, args):
-    if args.spk_embed_dim is not None:
-        raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
     return HParams(
         idim=idim, odim=odim, embed_dim=args.embed_dim, elayers=args.elayers, eunits=args.eunits, econv_layers=args.econv_layers,
         econv_chans=args.econv_chans, econv_filts=args.econv_filts, dlayers=args.dlayers, dunits=args.dunits,
@@ -72,6 +70,7 @@ def hparams_from_args(idim, odim, args):
         duration_predictor_dropout_rate=args.duration_predictor_dropout_rate,
         use_fe_condition=args.use_fe_condition, append_position=args.append_position, use_masking=bool(args.use_masking),
         use_weighted_masking=bool(getattr(args, "use_weighted_masking", False)), output_activation=args.output_activation,
+        spk_embed_dim=args.spk_embed_dim,
     ).check_supported()
 
 
@@ -139,7 +138,7 @@ class _Encoder(torch.nn.Module):
 class _Decoder(torch.nn.Module):
     def __init__(self, hp, thp, share_proj):
         super().__init__()
-        d, u, p = hp.eunits, hp.dunits, hp.prenet_units
+        d, u, p = hp.adim, hp.dunits, hp.prenet_units
         self.lstm = torch.nn.ModuleList(_Cell(d + p + 1 if l == 0 else u, u) for l in range(hp.dlayers))
         self.prenet = _Prenet(hp.odim, p, hp.prenet_layers)
         self.postnet = _Postnet(hp)
@@ -212,13 +211,13 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
         hp = self.hp
         self.enc = _Encoder(hp, thp, self.share_proj)
         self.dec = _Decoder(hp, thp, self.share_proj)
-        self.duration_predictor = _Predictor(hp.eunits, hp.duration_predictor_layers, hp.duration_predictor_chans,
+        self.duration_predictor = _Predictor(hp.adim, hp.duration_predictor_layers, hp.duration_predictor_chans,
                                              hp.duration_predictor_kernel_size, hp.duration_predictor_dropout_rate)
         for nm in ("pitch", "energy"):
-            setattr(self, nm + "_predictor", _Predictor(hp.eunits, hp.variance_predictor_layers, hp.variance_predictor_chans,
+            setattr(self, nm + "_predictor", _Predictor(hp.adim, hp.variance_predictor_layers, hp.variance_predictor_chans,
                                                         hp.variance_predictor_kernel_size, hp.variance_predictor_dropout_rate))
             k = hp.variance_embed_kernel_size
-            setattr(self, nm + "_embed", _seq(torch.nn.Conv1d(1, hp.eunits, k, padding=(k - 1) // 2),
+            setattr(self, nm + "_embed", _seq(torch.nn.Conv1d(1, hp.adim, k, padding=(k - 1) // 2),
                                               torch.nn.Dropout(hp.variance_embed_dropout_rate)))
         if self.role == "student":  # created whenever use_fe_condition, regardless of is_train (..._kd_student.py:602-603)
             self.pemb_proj = torch.nn.Linear(hp.eunits, self.teacher_hp.eunits, bias=False)
@@ -266,14 +265,12 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
         """x: LongTensor (T,) -> Tensor (L, odim), as ..._kd_student.py:804-863 / ..._sa.py:624-683.
         Prenet dropout stays ON (decoder_sa.py:156-158); masks come from the on-device generator, seeded from
         torch's default generator so `torch.manual_seed` makes a run repeatable."""
-        if spemb is not None:
-            raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
         mels = self.inference_batch([x], None if dur is None else [dur], None if f0 is None else [f0],
-                                    None if energy is None else [energy])
+                                    None if energy is None else [energy], spembs=None if spemb is None else [spemb])
         return mels[0]
 
     @torch.no_grad()
-    def inference_batch(self, xs, durs=None, f0s=None, energies=None, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=None):
+    def inference_batch(self, xs, durs=None, f0s=None, energies=None, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=None, spembs=None):
         """Build extension: equals len(xs) independent inference() calls, in one pass."""
         plan = self.plan(xs[0].device if torch.is_tensor(xs[0]) and xs[0].is_cuda else None)
         if seed is None:
@@ -281,7 +278,7 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
         cpu = lambda a: a.detach().cpu().numpy() if torch.is_tensor(a) else a
         return engine.synthesize(plan, [cpu(x) for x in xs], None if durs is None else [cpu(d).reshape(-1) for d in durs],
                                  None if f0s is None else [cpu(f) for f in f0s], None if energies is None else [cpu(e) for e in energies],
-                                 dropout_mode=dropout_mode, prenet_keep=prenet_keep, seed=seed)
+                                 dropout_mode=dropout_mode, prenet_keep=prenet_keep, seed=seed, spembs=spembs)
 
     def forward(self, xs, ilens, ys, olens, spembs=None, extras=None, new_ys=None, non_zero_lens_mask=None, ds_nonzeros=None,
                 output_masks=None, position=None, f0=None, energy=None, teacher_knowledge=None, *args, **kwargs):
@@ -293,14 +290,15 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
                     (fcl_taco2_amd.training.TrainEngine, train-form BatchNorm / dropout / zoneout, masks drawn on the device); the returned
                     loss is attached to the parameters through a torch.autograd.Function whose backward hands the HIP-computed gradients
                     to autograd, so the reference's `loss.backward(); clip_grad_norm_(model.parameters()); optimizer.step()` works as is."""
-        if spembs is not None:
-            raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
+        if self.role == "student" and self.hp.spk_embed_dim is not None:
+            # the reference's own KD student cannot run forward() with speaker embeddings: pemb_proj / eemb_proj are Linear(eunits, ...) but receive
+            # eunits + spk_embed_dim channels (..._kd_student.py:602-603 vs :709-711, 749-750; the RuntimeError is recorded in tests/golden/records.json)
+            raise NotImplementedError("fcl-taco2_amd: KD training with speaker embeddings is undefined in the reference (its student's pemb_proj / "
+                                      "eemb_proj do not fit eunits + spk_embed_dim inputs); synthesis with a speaker-embedding student is supported")
         batch = dict(xs=xs, ilens=ilens, ys=ys, olens=olens, extras=extras, new_ys=new_ys, non_zero_lens_mask=non_zero_lens_mask,
-                     ds_nonzeros=ds_nonzeros, f0=f0, energy=energy)
+                     ds_nonzeros=ds_nonzeros, f0=f0, energy=energy, spembs=spembs)
         if self.training:
             return self._forward_train(batch, teacher_knowledge, kwargs.get("masks"))
-        if spembs is not None:
-            raise NotImplementedError("fcl-taco2_amd: speaker embeddings are not supported by the HIP path")
         from .. import teacher_forced as TF
 
         plan = self.plan(xs.device if xs.is_cuda else None)

@@ -115,6 +115,17 @@ def pack_planes(x):
     return out
 
 
+def concat_spk(hs, spk, t, want_f32=True, want_planes=False):
+    """cat[hs, F.normalize(spk)[row // t]] over the padded [B, t] rows (..._sa.py:555-557): returns (fp32 [M, C + S] or None, planes or None)."""
+    m, c = hs.shape
+    s = spk.shape[1]
+    assert hs.stride(1) == 1 and spk.is_contiguous() and spk.dtype == torch.float32 and m <= spk.shape[0] * t
+    out = torch.empty(m, c + s, device=hs.device, dtype=torch.float32) if want_f32 else None
+    outp = planes_empty(m, c + s, hs.device) if want_planes else None
+    check(_lib.load().fcl_concat_spk_fwd(_p(hs), hs.stride(0), _p(spk), _p(out), _p(outp, torch.int16), m, c, s, t, _stream()))
+    return out, outp
+
+
 def add_vec(a, b):
     out = torch.empty_like(a)
     check(_lib.load().fcl_add_vec(_p(a), _p(b), _p(out), a.numel(), _stream()))

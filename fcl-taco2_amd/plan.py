@@ -107,9 +107,9 @@ class SynthesisPlan(object):
             # grouped forms: pitch + energy (forced durations) and duration + pitch + energy (predicted durations) as one launch per layer
             self.group_pe = _predictor_group([self.pitch, self.energy], ["pitch", "energy"])
             self.group_dpe = _predictor_group([self.duration, self.pitch, self.energy], ["duration", "pitch", "energy"])
-            self.pitch_embed_w = g("pitch_embed.0.weight").reshape(hp.eunits, -1).contiguous()
+            self.pitch_embed_w = g("pitch_embed.0.weight").reshape(hp.adim, -1).contiguous()
             self.pitch_embed_b = g("pitch_embed.0.bias")
-            self.energy_embed_w = g("energy_embed.0.weight").reshape(hp.eunits, -1).contiguous()
+            self.energy_embed_w = g("energy_embed.0.weight").reshape(hp.adim, -1).contiguous()
             self.energy_embed_b = g("energy_embed.0.bias")
             self.postnet = [self._conv_bn(g, "dec.postnet.postnet.%d" % i) for i in range(hp.postnet_layers)]
             self.decoder = self._decoder(g)
@@ -145,7 +145,7 @@ class SynthesisPlan(object):
 
     def _decoder(self, g):
         hp = self.hp
-        C, P, U, O = hp.eunits, hp.prenet_units, hp.dunits, hp.odim
+        C, P, U, O = hp.adim, hp.prenet_units, hp.dunits, hp.odim  # C: att_c width = eunits (+ spk_embed_dim)
         d = DecoderPack()
         s = d.struct
         s.c, s.p, s.u, s.odim = C, P, U, O

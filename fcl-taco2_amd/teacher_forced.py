@@ -59,7 +59,11 @@ def forward_pass(plan, batch, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=
         bl = plan.blstm
         lens_dev = torch.from_numpy(lens_np.astype(np.int32)).to(dev)
         hs = ops.bilstm(x, lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], B, T)
-        r.hs = hs
+        r.hs = hs  # (the encoder-KD tap: BEFORE the speaker embedding is appended, encoder_sa_kd.py:178-188)
+        if hp.spk_embed_dim is not None:  # hs <- cat[hs, F.normalize(spembs)] (..._sa.py:555-557)
+            if batch.get("spembs") is None:
+                raise ValueError("fcl-taco2_amd: the model was built with spk_embed_dim=%d: forward() needs spembs" % hp.spk_embed_dim)
+            hs = ops.concat_spk(hs, _dev(batch["spembs"], dev, torch.float32), T)[0]
         # H4/H5 (log-domain duration output, pitch, energy; masked_fill on padded positions)
         r.d_outs = _predictor_scalar(plan.duration, hs, seg_lo, seg_hi, r.enc_pad)
         r.p_outs = _predictor_scalar(plan.pitch, hs, seg_lo, seg_hi, r.enc_pad)

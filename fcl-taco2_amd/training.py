@@ -321,6 +321,9 @@ class TrainEngine(object):
         if not p0.is_cuda:
             raise RuntimeError("fcl-taco2_amd: TrainEngine needs the model on a GPU (no CPU fallback)")
         self.model, self.hp, self.dev, self.role = model, model.hp, p0.device, model.role
+        if self.role == "student" and self.hp.spk_embed_dim is not None:
+            raise NotImplementedError("fcl-taco2_amd: KD training with speaker embeddings is undefined in the reference (its student's pemb_proj / eemb_proj "
+                                      "are built for eunits inputs but receive eunits + spk_embed_dim channels: tests/golden/records.json)")
         if self.role != "kd_teacher":  # the frozen KD teacher computes no loss
             self.hp.check_loss_supported()
         self.share_proj = bool(getattr(model, "share_proj", True))
@@ -768,7 +771,7 @@ class TrainEngine(object):
         hp, dev, P = self.hp, self.dev, self.P
         c.bn_run = []
         B, T, L = c.B, c.T, c.L
-        O, U, Pn, C = hp.odim, hp.dunits, hp.prenet_units, hp.eunits
+        O, U, Pn, C = hp.odim, hp.dunits, hp.prenet_units, hp.adim  # C: width of the decoder / predictor input (eunits + spk_embed_dim)
         p_conv = hp.dropout_rate
         drop_conv = c.train and p_conv > 0
         # ---- encoder
@@ -793,6 +796,12 @@ class TrainEngine(object):
             c.conv_c.append(cc)
             c.enc_taps.append(x)
         c.hs, c.bl_c, hs_p = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save, perm=c.perm_tb, xp=xp)
+        c.hs_enc = c.hs  # the encoder's own output: the KD tap (encoder_sa_kd.py:178-188) and what the BiLSTM's backward receives
+        if hp.spk_embed_dim is not None:  # hs <- cat[hs, F.normalize(spembs)] (..._sa.py:555-557); the embeddings are inputs: no gradient leaves here
+            if batch.get("spembs") is None:
+                raise ValueError("fcl-taco2_amd: the model was built with spk_embed_dim=%d: forward() needs spembs" % hp.spk_embed_dim)
+            spk = batch["spembs"].to(dev).float().contiguous()
+            c.hs, hs_p = ops.concat_spk(c.hs_enc, spk, T, want_planes=pl and C % 32 == 0)
         # ---- predictors + embeds (their dropout masks: one launch for all of them)
         p_emb = hp.variance_embed_dropout_rate
         pk = {}
@@ -939,7 +948,7 @@ class TrainEngine(object):
         e = lambda x: x.reshape(B, T, -1)
         f = lambda x: x.reshape(B, L, -1)
         cells = [ops.gather_rows(x, c.frame_cell) for x in (c.p1d, c.h0_all, c.h1_all)]
-        return (f(c.after), f(c.before), [e(t) for t in c.enc_taps] + [e(c.hs)], [f(t) for t in cells + c.post_taps],
+        return (f(c.after), f(c.before), [e(t) for t in c.enc_taps] + [e(c.hs_enc)], [f(t) for t in cells + c.post_taps],
                 [e(c.d_outs), e(c.p_outs), e(c.e_outs), e(c.p_embs), e(c.e_embs)])
 
     # ------------------------------------------------------------------------------------------------ losses and their gradients
@@ -1025,7 +1034,7 @@ class TrainEngine(object):
     def _backward(self, c):
         hp, dev, P, G, inj = self.hp, self.dev, self.P, self.G, c.inj
         B, T = c.B, c.T
-        U, Pn, C = hp.dunits, hp.prenet_units, hp.eunits
+        U, Pn, C = hp.dunits, hp.prenet_units, hp.adim
         N, F, lmax, live, offs = c.N, c.F, c.lmax, c.live, c.offs
         # ---- postnet: after = before + postnet(before)
         if hp.output_activation is not None:  # back through output_activation_fn (y = the activated outputs)
@@ -1120,6 +1129,8 @@ class TrainEngine(object):
         # ---- encoder
         if "hs" in inj:
             ops.add2d(d_hs, inj["hs"])
+        if hp.spk_embed_dim is not None:
+            d_hs = ops.copy_cols(d_hs, 0, hp.eunits)  # the speaker-embedding columns are inputs; the encoder sees the first eunits only
         d_hs_live = ops.add2d(self._z(d_hs.shape), d_hs, row_valid=c.enc_valid)  # pad_packed_sequence: padded outputs are constants
         dx = self._bilstm_bwd(d_hs_live, c.bl_c)
         for i in range(len(c.conv_c) - 1, -1, -1):

@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 302
+#define FCL_ABI_VERSION 303
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -160,6 +160,11 @@ int fcl_duration_round_fwd(const float* x, int64_t* out, int n, int linear_domai
 int fcl_variance_embed_add_fwd(const float* hs, const float* p, const float* e, const float* wp, const float* bp,
                                const float* we, const float* be, const int32_t* seg_lo, const int32_t* seg_hi,
                                float* out, float* p_emb, float* e_emb, int m, int c, int k, fcl_stream_t stream);
+
+/* ---- speaker embedding (..._sa.py:555-557 forward, :636-638 inference; `--spk-embed-dim`): out [M, C + S] = cat[hs, F.normalize(spemb)] over the
+ *      padded [B, T] row layout (row m belongs to utterance m / t; spk [B, S]; F.normalize: x / max(||x||_2, 1e-12)).  out_p (optional, (C + S) % 32
+ *      == 0): the same rows as P32 planes; out may then be NULL. */
+int fcl_concat_spk_fwd(const float* hs, int ldh, const float* spk, float* out, uint16_t* out_p, int m, int c, int s, int t, fcl_stream_t stream);
 
 /* ---- H10: position table (..._kd_student.py:845-851): pos[n, t] = t < dur[n] ? (float)t/(float)dur[n] : 0 */
 int fcl_position_table_fwd(const int32_t* dur, float* pos, int n, int lmax, fcl_stream_t stream);

@@ -294,12 +294,14 @@ def decoder_inference(sd, hp, h, ds, p_embs, e_embs, prenet_keep=None):
     return after[0].t(), before[0].t()
 
 
-def inference(sd, hp, x, dur=None, f0=None, energy=None, prenet_keep=None):
+def inference(sd, hp, x, dur=None, f0=None, energy=None, prenet_keep=None, spemb=None):
     """Tacotron2_sa.inference (..._kd_student.py:804-863 == teacher ..._sa.py:624-683).
 
     prenet_keep None => prenet dropout disabled (the golden sets G1/G2 run the reference with
     dropout_rate=0); otherwise the injected keep masks (G3).  Returns a dict of intermediates."""
     h = encoder_inference(sd, hp, x)
+    if getattr(hp, "spk_embed_dim", None) is not None:  # ..._sa.py:636-638
+        h = torch.cat([h, F.normalize(spemb, dim=0).unsqueeze(0).expand(h.size(0), -1)], dim=-1)
     pad = make_pad_mask([h.shape[0]])
     if dur is not None:
         d_outs = dur.reshape(-1).long()
@@ -457,6 +459,9 @@ def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher
     ys = ys[:, : int(max(olens))]
     mk = masks or {}
     hs, enc_taps = encoder_forward(sd, hp, xs, ilens, bn_train, mk.get("enc.convs"))
+    hs_enc = hs  # the encoder-KD tap is the encoder's own output (encoder_sa_kd.py:178-188)
+    if getattr(hp, "spk_embed_dim", None) is not None:  # ..._sa.py:555-557
+        hs = torch.cat([hs, F.normalize(batch["spembs"]).unsqueeze(1).expand(-1, hs.size(1), -1)], dim=-1)
     ds = batch["extras"].squeeze(-1)
     pad = make_pad_mask(ilens)
     d_outs = duration_predictor(sd, hp, hs, pad, keeps=mk.get("duration_predictor"))  # log domain, masked_fill 0
@@ -474,7 +479,7 @@ def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher
         batch["output_masks"], batch["position"], p_embs, e_embs, prenet_keep if masks is None else mk.get("prenet"),
         None if mk.get("zoneout") is None else _t(mk["zoneout"]), bn_train, mk.get("postnet"))
     if role == "kd_teacher":
-        return after, before, enc_taps + [hs], dec_taps, [d_outs.unsqueeze(-1), p_outs, e_outs, p_embs, e_embs]
+        return after, before, enc_taps + [hs_enc], dec_taps, [d_outs.unsqueeze(-1), p_outs, e_outs, p_embs, e_embs]
     l1, mse = taco2_loss(after, before, ys, olens, hp.use_masking)
     rep = dict(l1_loss=l1, mse_loss=mse, dur_loss=dur_loss, pitch_loss=pitch_loss, energy_loss=energy_loss)
     loss = l1 + mse + dur_loss + pitch_loss + energy_loss
@@ -490,7 +495,7 @@ def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher
             lp = ["dec.lstm0_proj.weight", "dec.lstm1_proj.weight"]
             pp = ["dec.post%d_proj.weight" % i for i in range(4)]
         s_enc = [lin(enc_taps[0], "enc.embed_proj.weight")] + [lin(enc_taps[1 + i], cp[i]) for i in range(3)] \
-            + [lin(hs, "enc.blstm_proj.weight")]
+            + [lin(hs_enc, "enc.blstm_proj.weight")]
         s_dec = [lin(dec_taps[0], "dec.prenet_proj.weight"), lin(dec_taps[1], lp[0]), lin(dec_taps[2], lp[1])] \
             + [lin(dec_taps[3 + i], pp[i]) for i in range(4)] + [dec_taps[7]]
         s_pro = [d_outs.unsqueeze(-1), p_outs, e_outs, lin(p_embs, "pemb_proj.weight"), lin(e_embs, "eemb_proj.weight")]

@@ -78,7 +78,7 @@ def ns(hp, **extra):
         "embed_dim elayers eunits econv_layers econv_chans econv_filts dlayers dunits prenet_layers "
         "prenet_units postnet_layers postnet_chans postnet_filts use_batch_norm use_concate use_residual "
         "reduction_factor dropout_rate zoneout_rate use_masking duration_predictor_layers "
-        "duration_predictor_chans duration_predictor_kernel_size duration_predictor_dropout_rate output_activation").split()}
+        "duration_predictor_chans duration_predictor_kernel_size duration_predictor_dropout_rate output_activation spk_embed_dim").split()}
     d["encoder_resume"] = None
     d.update(extra)
     return argparse.Namespace(**d)
@@ -593,6 +593,33 @@ def gen_g12():
     save("g12_student_kd_sigmoid", **d)
 
 
+def gen_g13():
+    """G13: speaker embeddings (`spk_embed_dim`, ..._sa.py:380-384, 555-557, 636-638): F.normalize(spemb) appended to every encoder state; the
+    predictors, the pitch / energy embeddings and the decoder run on eunits + spk_embed_dim channels.  Teacher: inference mel + training step (eval
+    form); KD teacher: the 5-tuple (the encoder tap stays eunits wide).  The KD student cannot run with them in the reference (records.json)."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, spk_embed_dim=8)
+    TK = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **kw)
+    rng = np.random.RandomState(13)
+    x = torch.from_numpy(rng.randint(1, TK.idim, size=7).astype(np.int64))
+    dur = torch.tensor([3, 1, 2, 4, 1, 2, 3])
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    spk = torch.from_numpy(rng.randn(b["xs"].shape[0], 8).astype(np.float32))
+    te, _ = build("teacher", TK)
+    with torch.no_grad():
+        after = te.inference(x, None, spemb=spk[1], dur=dur)
+    save("g13_teacher_spk_inference", x=t2n(x), dur=t2n(dur), spemb=t2n(spk[1]), after=t2n(after))
+    loss = te(spembs=spk, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), spembs=t2n(spk))
+    _named_losses(te, d)
+    _grads(te, GRAD_KEYS + ["pitch_embed.0.weight", "duration_predictor.conv.0.0.weight", "enc.blstm.weight_hh_l0"], d)
+    save("g13_teacher_spk", **d)
+    kt, _ = build("kd_teacher", TK)
+    with torch.no_grad():
+        know = kt(spembs=spk, **b)
+    save("g13_kd_teacher_spk", after=t2n(know[0]), enc4=t2n(know[2][4]), dec1=t2n(know[3][1]), p_embs=t2n(know[4][3]), d_outs=t2n(know[4][0]))
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -642,7 +669,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "records"}, only
+        if "g13" in only:
+            gen_g13()
         if "records" in only:
             gen_option_records()
         if "g12" in only:
@@ -662,6 +691,7 @@ def main():
     gen_g10()
     gen_g11()
     gen_g12()
+    gen_g13()
     gen_option_records()
 
 

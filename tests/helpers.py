@@ -48,3 +48,7 @@ TINY_SA = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_cha
                              postnet_chans=12, duration_predictor_chans=20, dropout_rate=0.0, output_activation="sigmoid")
 TINY_TA = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, output_activation="sigmoid")
+
+# speaker embeddings (G13): F.normalize(spemb) appended to the encoder states; predictors / embeddings / decoder on eunits + 8 channels
+TINY_TK = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
+                             postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, spk_embed_dim=8)

@@ -336,6 +336,28 @@ def test_g2b_batched_equals_per_utterance_reference(ops, golden):
             assert max_abs(mels[j].cpu(), g["after%d" % i]) < 1e-3
 
 
+@pytest.mark.parametrize("model,spk", [("student", 64), ("teacher", 64), ("student", 20)])
+def test_speaker_embeddings_full_size_synthesis_vs_oracle(ops, model, spk):
+    """`spk_embed_dim` at the shipped S / T dims (G13 pins the arithmetic to the real reference at tiny dims): the concatenated states travel as P32
+    planes when eunits + spk_embed_dim is a whole number of 32-column lines (S: 320 -> the stencil Conv1d and the grouped predictors; T: 576 -> the
+    K-term GEMM form) and as fp32 otherwise (276); batched synthesis of 3 ragged utterances with different speakers vs the oracle per utterance."""
+    from fcl_taco2_amd import engine
+
+    hp = (HP.student_hparams if model == "student" else HP.teacher_hparams)(dropout_rate=0.0, spk_embed_dim=spk)
+    plan = _plan(hp)
+    assert engine.use_planes(plan) == (ops.planes_enabled() and hp.adim % 32 == 0)
+    rng = np.random.RandomState(21)
+    xs = [rng.randint(1, hp.idim, size=n).astype(np.int64) for n in (23, 9, 31)]
+    ds = [SYN.durations(rng, len(x), lam=4.0, hi=12) for x in xs]
+    sp = [rng.randn(spk).astype(np.float32) * s for s in (1.0, 0.01, 30.0)]  # F.normalize: the scale must not matter
+    mels = engine.synthesize(plan, xs, ds, spembs=sp)
+    sd = torch_state_dict(hp)
+    for x, d, s, mel in zip(xs, ds, sp, mels):
+        with torch.no_grad():
+            ref = O.inference(sd, hp, torch.from_numpy(x), dur=torch.from_numpy(d), spemb=torch.from_numpy(s))["after"]
+        assert mel.shape == ref.shape and max_abs(mel.cpu(), ref) < 1e-3
+
+
 def test_zero_duration_raises_like_reference(ops):
     from fcl_taco2_amd import engine
 

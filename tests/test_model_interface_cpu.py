@@ -65,8 +65,10 @@ def test_flags_and_plot_keys_match_reference():
 
 def test_unsupported_configurations_fail_loudly():
     cls = dynamic_import("fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa:Tacotron2_sa")
-    with pytest.raises(NotImplementedError):
-        cls(80, 80, argparse.Namespace(spk_embed_dim=64, **T_ARGS), com())
+    m = cls(80, 80, argparse.Namespace(spk_embed_dim=64, **T_ARGS), com())  # round 3: speaker embeddings are on the HIP path (G13) ...
+    assert m.hp.adim == m.hp.eunits + 64 and m.state_dict()["dec.feat_out.weight"].shape[1] == m.hp.dunits + m.hp.eunits + 64
+    with pytest.raises(NotImplementedError):  # ... in whole float4 columns
+        cls(80, 80, argparse.Namespace(spk_embed_dim=30, **T_ARGS), com())
     cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True)), com())  # round 3: encoder skip connections are on the HIP path (G11)
     with pytest.raises(NotImplementedError):  # ... which need embed_dim == econv_chans, as the reference's `convs[i](xs) + xs` does
         cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True, embed_dim=256)), com())

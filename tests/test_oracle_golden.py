@@ -318,6 +318,33 @@ def test_g12_output_activation_variant(golden):
     assert _check_grads(sd, g) >= 20
 
 
+def test_g13_speaker_embeddings(golden):
+    """`spk_embed_dim`: F.normalize(spemb) appended to every encoder state (..._sa.py:555-557, 636-638).  Inference mel, the teacher step and the KD
+    teacher's 5-tuple vs the real reference (the KD student cannot run with speaker embeddings in the reference: records.json)."""
+    from helpers import TINY_TK
+
+    g4, g = golden("g4_integer"), golden("g13_teacher_spk_inference")
+    sd0 = torch_state_dict(TINY_TK)
+    with torch.no_grad():
+        out = O.inference(sd0, TINY_TK, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]), spemb=torch.from_numpy(g["spemb"]))
+    assert max_abs(out["after"], g["after"]) < TOL_STAGE
+    g = golden("g13_teacher_spk")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    b["spembs"] = torch.from_numpy(g["spembs"])
+    sd = _grad_sd(TINY_TK)
+    rep = O.model_forward(sd, TINY_TK, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 12
+    gk = golden("g13_kd_teacher_spk")
+    with torch.no_grad():
+        know = O.model_forward(sd0, TINY_TK, b, "kd_teacher")
+    assert know[2][4].shape[-1] == TINY_TK.eunits and know[4][3].shape[-1] == TINY_TK.adim
+    for got, key in ((know[0], "after"), (know[2][4], "enc4"), (know[3][1], "dec1"), (know[4][3], "p_embs"), (know[4][0], "d_outs")):
+        assert max_abs(got, gk[key]) < TOL_STAGE, key
+
+
 def test_g6_padding_leak_and_zero_duration(golden):
     g = golden("g6_padding_leak")
     rec = json.load(open(os.path.join(GOLDEN, "records.json")))
