@@ -504,7 +504,9 @@ bool lstm_step_is_small(int M, int U) {
     static const int small_m = tunable("LSTM_SMALL_M", 0);  // 0 = by width: the wave-per-gate small-tile kernel re-streams W per 16-row tile,
     // which stops paying earlier at U = 1024 (FCL-taco2-T); with the pre-split operand kernels available (32-row tiles) at ~500 rows for U = 256
     static const bool planes_on = tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0;
-    return M <= (small_m ? small_m : (U >= 512 ? 256 : (planes_on ? 512 : 1024)));
+    // (U >= 512: 256 -> 64 rows in round 3 -- FCL-taco2-T synthesis 6.88 -> 7.18 M frames/s, teacher update 12.93 -> 12.78 ms: at 4 096 gate columns the
+    // 32-row pre-split tiles beat the wave-per-gate kernel's W re-streaming from 65 rows on)
+    return M <= (small_m ? small_m : (U >= 512 ? (planes_on ? 64 : 256) : (planes_on ? 512 : 1024)));
 }
 
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
