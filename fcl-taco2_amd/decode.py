@@ -151,10 +151,7 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
             chunk, arr, counts, slot = item
             try:
                 if not werr:
-                    s0 = 0
-                    for (uid, _), c in zip(chunk, counts):
-                        w[uid] = arr[s0 : s0 + c]
-                        s0 += c
+                    w.write_batch([uid for uid, _ in chunk], arr[: int(sum(counts))], counts)
             except Exception as e:  # surfaced by the main thread after the join
                 werr.append(e)
             finally:
@@ -192,6 +189,9 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
             return False
 
         def __setitem__(self, k, v):
+            pass
+
+        def write_batch(self, keys, mats, counts):
             pass
 
     with (ArkScpWriter(out_prefix) if out_prefix is not None else _Discard()) as w, torch.cuda.device(dev):

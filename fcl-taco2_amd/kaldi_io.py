@@ -25,6 +25,29 @@ class ArkScpWriter(object):
         self._ark.write(mat.tobytes())
         self._scp.write("%s %s:%d\n" % (key, self.ark_path, off))
 
+    def write_batch(self, keys, mats, counts):
+        """The mels of a decoded batch: `mats` float32 [sum(counts), cols] holds them back to back (the pinned landing buffer), counts[i] rows each.
+        One native call (fcl_kaldi_ark_append: writev straight from `mats`) and one scp write per batch instead of three writes and a copy per
+        utterance."""
+        import ctypes as C
+
+        from . import _lib
+
+        mats = np.ascontiguousarray(mats, dtype=np.float32)
+        n = len(keys)
+        assert mats.ndim == 2 and len(counts) == n and int(sum(counts)) == mats.shape[0] and all(" " not in k for k in keys)
+        self._ark.flush()
+        pos = self._ark.tell()
+        kb = [k.encode("utf-8") for k in keys]
+        karr = (C.c_char_p * n)(*kb)
+        rows = np.ascontiguousarray(counts, dtype=np.int32)
+        offs = np.zeros(n, dtype=np.int64)
+        end = _lib.load().fcl_kaldi_ark_append(self._ark.fileno(), pos, n, karr, mats.ctypes.data, rows.ctypes.data, int(mats.shape[1]), offs.ctypes.data)
+        if end < 0:
+            raise _lib.FclError(_lib.load().fcl_last_error().decode())
+        self._ark.seek(end)
+        self._scp.write("".join("%s %s:%d\n" % (k, self.ark_path, o) for k, o in zip(keys, offs.tolist())))
+
     def close(self):
         self._ark.close()
         self._scp.close()

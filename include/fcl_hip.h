@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 303
+#define FCL_ABI_VERSION 304
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -626,6 +626,14 @@ int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
  * (both unused, may be NULL, for s_ch = 64: one launch that reads skips once). */
 int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const float* b1, const float* w2, float b2, uint16_t* yp, float* h, float* wav,
                      int64_t m, int s_ch, fcl_stream_t stream);
+
+/* ---- N3: the wire format handed to the vocoder (tts.py:652,674: kaldiio.WriteHelper("ark,scp:..."); inference_student.sh:20-23) --------------
+ * HOST function (no device work): appends n Kaldi binary FloatMatrix records -- <key> ' ' "\0BFM " '\4' <int32 rows> '\4' <int32 cols> <float32 data>
+ * -- to the open file descriptor `fd` with writev, straight from `data` (the utterances' matrices back to back, rows[i] x cols each; e.g. the
+ * pinned landing buffer of a decoded batch).  file_pos: the file offset the first byte lands at; offsets[i] receives the offset of utterance i's
+ * "\0B" marker (what its scp line points at).  Returns the new file offset (>= file_pos), or a negative FCL_ERR_* (fcl_last_error()). */
+long long fcl_kaldi_ark_append(int fd, long long file_pos, int n, const char* const* keys, const float* data, const int* rows, int cols,
+                               long long* offsets);
 
 #ifdef __cplusplus
 }

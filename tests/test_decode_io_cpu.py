@@ -2,6 +2,7 @@
 import json
 
 import numpy as np
+import pytest
 import torch
 
 import fcl_taco2_amd  # noqa: F401
@@ -21,6 +22,33 @@ def test_ark_scp_roundtrip(tmp_path):
         assert back[k].shape == mats[k].shape and np.array_equal(back[k], mats[k])
     raw = open(tmp_path / "feats.ark", "rb").read()
     assert raw.startswith(b"LJ001-0001 \0BFM \x04\x07\x00\x00\x00\x04\x50\x00\x00\x00")  # Kaldi binary FloatMatrix header
+
+
+def test_native_batch_writer_produces_the_same_files(tmp_path):
+    """ArkScpWriter.write_batch (fcl_kaldi_ark_append: one writev per batch straight from the landing buffer) == one `w[key] = mat` per utterance:
+    byte-identical ark and scp, also when the two forms are mixed in one file and for empty matrices."""
+    rng = np.random.RandomState(1)
+    counts = [5, 0, 13, 1, 700]
+    keys = ["utt%03d" % i for i in range(len(counts))]
+    big = rng.randn(sum(counts), 80).astype(np.float32)
+    with ArkScpWriter(str(tmp_path / "a")) as w:
+        w["first"] = big[:3]
+        s = 0
+        for k, c in zip(keys, counts):
+            w[k] = big[s : s + c]
+            s += c
+        w["last"] = big[:2]
+    with ArkScpWriter(str(tmp_path / "b")) as w:
+        w["first"] = big[:3]
+        w.write_batch(keys, big, counts)
+        w["last"] = big[:2]
+    assert open(tmp_path / "a.ark", "rb").read() == open(tmp_path / "b.ark", "rb").read()
+    assert open(tmp_path / "a.scp").read().replace("/a.ark", "/x.ark") == open(tmp_path / "b.scp").read().replace("/b.ark", "/x.ark")
+    back = read_scp(str(tmp_path / "b.scp"))
+    assert list(back) == ["first"] + keys + ["last"] and np.array_equal(back["utt004"], big[-700:]) and back["utt001"].shape == (0, 80)
+    with pytest.raises(Exception):
+        with ArkScpWriter(str(tmp_path / "c")) as w:
+            w.write_batch(["bad key"], big[:1], [1])
 
 
 def test_model_conf_manifest_and_checkpoint_formats(tmp_path):
