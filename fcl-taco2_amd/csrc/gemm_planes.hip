@@ -697,7 +697,8 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     // pass rate with several passes in flight (+1.7 ... +4 %, batch 64 +3.6 %).  At Cin >= 512 (FCL-taco2-T: 33.8 vs 28.0, 124 vs 115 us) the
     // single-stream training step loses 2 % with it, so those keep the K-term form (PCONV=2 forces the stencil everywhere).
     if (pconv && a.conv_k >= 3 && a.conv_k <= 17 && !a.accumulate && (a.term[0].K <= 384 || pconv >= 2)) {
-        if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pconv_cfg<4, 2, 2, 4>(a, s, flops);
+        static const int cbig_min = tunable("PCONV_BIG_MIN", 150);
+        if (force == 1 || (force == 0 && t128x128 >= cbig_min && a.N >= 128)) return launch_pconv_cfg<4, 2, 2, 4>(a, s, flops);
         if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pconv_cfg<2, 2, 2, 4>(a, s, flops);
         return launch_pconv_cfg<2, 2, 2, 2>(a, s, flops);
     }
@@ -710,7 +711,8 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     static const int big_min = tunable("PGEMM_BIG_MIN_WG", 1 << 30);
     const long long t256x128 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     if (force == 3 || (force == 0 && t256x128 >= big_min && a.N >= 128 && ksum >= 512)) return launch_pgemm_cfg<4, 2, 4, 4, 3>(a, s, flops);
-    if (force == 1 || (force == 0 && t128x128 >= 150 && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
+    static const int gbig_min = tunable("PGEMM_BIG_MIN", 150);
+    if (force == 1 || (force == 0 && t128x128 >= gbig_min && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
     if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pgemm_cfg<2, 2, 2, 4, 3>(a, s, flops);
     return launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
 }
@@ -758,8 +760,13 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     // (BM + BN) * K * 4 bytes / ~47 GB/s, so 96 + 128 instead of 128 + 128 rows is -12.5 % per workgroup
     if ((force == 5 || (force == 0 && use96 && t128 >= 150 && t128 < 230 && t96 <= 256)) && loader_waves() > 0 && gemm_mode() != FCL_GEMM_BF16)
         return loader_waves() == 4 ? launch_plstm_lw<3, 2, 2, 3, 4, false>(a, s, flops) : launch_plstm_lw<3, 2, 2, 3, 2, false>(a, s, flops);  // (6 compute waves: loader-specialised only)
-    if (force == 1 || (force == 0 && t128 >= 150)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
-    if (force == 2 || (force == 0 && t64 >= 200)) return launch_plstm_cfg<2, 2, 2, 3>(a, s, flops);
+    // thresholds as tunables (r3, 4 passes in flight, B = 32: 64-row tiles everywhere -- two workgroups per CU, also from different streams -- are +1.5 ...
+    // +4.5 % on the replayed pass and within noise on the fresh feed, but -22 % on FCL-taco2-T synthesis and +6 % on the KD update: the 128-row tiles
+    // stay where they are; PLSTM_BIG_MIN=300 PLSTM_MID_MIN=80 is the S-only variant)
+    static const int big_min = tunable("PLSTM_BIG_MIN", 150);
+    if (force == 1 || (force == 0 && t128 >= big_min)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
+    static const int mid_min = tunable("PLSTM_MID_MIN", 200);
+    if (force == 2 || (force == 0 && t64 >= mid_min)) return launch_plstm_cfg<2, 2, 2, 3>(a, s, flops);
     static const int row32_m = tunable("PLSTM_ROW32_M", 1100);
     if (force == 4 || (force == 0 && a.M <= row32_m)) return launch_plstm_cfg<2, 2, 1, 4>(a, s, flops);  // 32 x 128 tiles: M = 500 .. 1100 (measured)
     return launch_plstm_cfg<2, 1, 2, 4>(a, s, flops);  // 64 x 64 gate-column tiles (16 units): M <~ 1600 at U = 256
