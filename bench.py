@@ -507,6 +507,7 @@ def main():
                     "one H2D copy + one capacity graph with device-built row maps (default: what inference() times); replay = one prepared batch "
                     "(host-built maps, outside the clock) replayed from a hipGraph (rounds 1-2)")
     ap.add_argument("--batches", type=int, default=4, help="synthesis: distinct synthetic batches fed round-robin")
+    ap.add_argument("--cap-slack", type=int, default=0, help="synthesis: decoder steps of the capacity graph beyond the longest duration of the batches it serves (each costs three launches that exit at once)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="kd_step: run teacher forward and student update back to back on one stream")
@@ -609,7 +610,7 @@ def main():
     # many batches in flight.  `--feed replay` = rounds 1-2: one prepared batch (host-built maps, outside the clock) replayed from a hipGraph;
     # --eager launches that pass kernel by kernel.
     host_maps = [engine.build_row_maps([len(x) for x in b[0]], b[1], T_CAP) for b in batches]
-    lmax_cap = max(m.lmax for m in host_maps) + 2
+    lmax_cap = max(m.lmax for m in host_maps) + args.cap_slack  # capacities = the maximum over the batches this graph serves (a batch beyond them is reported by the device)
     bounds = np.ones(lmax_cap, dtype=np.int32)
     for m in host_maps:
         bounds[: m.lmax] = np.maximum(bounds[: m.lmax], m.live_rows)
@@ -705,7 +706,7 @@ def main():
             del gr
             plan_p = SynthesisPlan(SYN.positive_duration_head(sd_np), hp, dev)
             cal = [engine.run(plan_p, engine.prepare(plan_p, b[0]), ops.DROP_RNG, return_intermediates=True)[2]["maps"] for b in batches]
-            pl_cap = max(m.lmax for m in cal) + 2
+            pl_cap = max(m.lmax for m in cal) + args.cap_slack
             pb = np.ones(pl_cap, dtype=np.int32)
             for m in cal:
                 pb[: m.lmax] = np.maximum(pb[: m.lmax], m.live_rows)
