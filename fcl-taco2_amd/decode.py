@@ -70,7 +70,17 @@ def build_model(model_path, conf_path, teacher_conf=None, device="cuda:0", share
 def read_manifest(json_path):
     with open(json_path, "rb") as f:
         js = json.load(f)["utts"]
-    return [(k, np.array(list(map(int, v["output"][0]["tokenid"].split())), dtype=np.int64)) for k, v in js.items()]
+    utts = []
+    for k, v in js.items():
+        ids = np.array(list(map(int, v["output"][0]["tokenid"].split())), dtype=np.int64)
+        if len(v.get("input", [])) > 1 and "feat" in v["input"][1]:  # speaker embedding: `--use-speaker-embedding` data (tts.py:327-332, 285-287)
+            from .kaldi_io import read_vec
+
+            path, off = v["input"][1]["feat"].rsplit(":", 1)
+            utts.append((k, ids, read_vec(path, int(off))))
+        else:
+            utts.append((k, ids))
+    return utts
 
 
 class _Slot(object):
@@ -115,7 +125,7 @@ def _grown_caps(engine, maps, n_rows, scale=1.3):
 
 @torch.no_grad()
 def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None):
-    """utts: [(utt_id, ids)].  Writes PREFIX.ark/.scp (out_prefix None: nothing is written); returns (frames, seconds).
+    """utts: [(utt_id, ids)] or, for a model with spk_embed_dim, [(utt_id, ids, spemb)].  Writes PREFIX.ark/.scp (out_prefix None: nothing is written); returns (frames, seconds).
     Every batch runs as ONE captured graph with predicted durations (engine.BatchRunner): the host packs the phoneme ids, enqueues one H2D
     copy, one graph launch and one D2H copy of the mel buffer + the per-utterance frame starts, and only synchronises on a batch when it
     harvests it `depth` batches later -- no read-back of the predicted durations in the middle of a pass (rounds 1-2 did one per batch).  The
@@ -131,6 +141,10 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
     order = sorted(range(len(utts)), key=lambda i: -len(utts[i][1]))
     dev = next(model.parameters()).device
     plan = model.plan(dev)
+    has_spk = plan.hp.spk_embed_dim is not None
+    if has_spk and any(len(u) < 3 for u in utts):
+        raise ValueError("fcl-taco2_amd: the model has spk_embed_dim=%d: every utterance needs a speaker embedding" % plan.hp.spk_embed_dim)
+    spk_of = (lambda chunk: [u[2] for u in chunk]) if has_spk else (lambda chunk: None)
     frames = 0
     depth = max(1, int(depth))
     cache = plan.__dict__.setdefault("_decode_cache", {})
@@ -151,7 +165,7 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
             chunk, arr, counts, slot = item
             try:
                 if not werr:
-                    w.write_batch([uid for uid, _ in chunk], arr[: int(sum(counts))], counts)
+                    w.write_batch([u[0] for u in chunk], arr[: int(sum(counts))], counts)
             except Exception as e:  # surfaced by the main thread after the join
                 werr.append(e)
             finally:
@@ -160,7 +174,7 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
 
     def eager(chunk):
         """Host-round-trip pass (calibration / fallback): exact maps of THIS batch."""
-        prep = engine.prepare(plan, [x for _, x in chunk])
+        prep = engine.prepare(plan, [u[1] for u in chunk], spembs=spk_of(chunk))
         mel, utt_frames, inter = engine.run(plan, prep, ops.DROP_RNG, seed=int(torch.randint(0, 2 ** 31 - 1, (1,)).item()), return_intermediates=True)
         arr = mel.cpu().numpy()
         wq.put((chunk, arr, list(utt_frames), None))
@@ -201,7 +215,7 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
         t0 = time.perf_counter()
         for bi, s in enumerate(range(0, len(order), batch_size)):
             chunk = [utts[i] for i in order[s : s + batch_size]]
-            t_cap = (max(len(x) for _, x in chunk) + 15) // 16 * 16
+            t_cap = (max(len(u[1]) for u in chunk) + 15) // 16 * 16
             pool = pools.get(t_cap)
             if pool is not None and pool.grow is not None:  # a batch overflowed this bucket: drain it, widen the capacities, capture anew
                 for it in [p_ for p_ in pending if p_[0] is pool]:
@@ -226,7 +240,7 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
             slot = pool.slots[j][(pool.next // len(streams)) % 2]
             slot.free.wait()  # the writer thread is done with what this landing buffer held
             slot.free.clear()
-            r.load([x for _, x in chunk])
+            r.load([u[1] for u in chunk], spembs=spk_of(chunk))
             r.replay()
             with torch.cuda.stream(r.stream):
                 slot.mel.copy_(r.mel, non_blocking=True)
@@ -268,7 +282,7 @@ def main(argv=None):
     dev = "cuda:%d" % (args.job % max(torch.cuda.device_count(), 1))
     model = build_model(args.model, args.model_conf, args.teacher_config, dev)
     utts = read_manifest(args.json)
-    mine = shard_utterances([len(x) for _, x in utts], args.nj)[args.job]
+    mine = shard_utterances([len(u[1]) for u in utts], args.nj)[args.job]
     out = args.out if args.nj == 1 else "%s.%d" % (args.out, args.job + 1)
     frames, secs = decode(model, [utts[i] for i in mine], out, args.batch_size, args.seed)
     logging.info("average inference speed = %.1f frames / sec. (%d utterances, %d frames)", frames / max(secs, 1e-9), len(mine), frames)

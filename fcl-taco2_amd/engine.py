@@ -463,16 +463,15 @@ class BatchRunner(object):
 
     def __init__(self, plan, batch, t_cap, caps, forced=True, stream=None, dropout_mode=ops.DROP_RNG, seed=0, depth=3):
         dev = plan.device
-        if plan.hp.spk_embed_dim is not None:
-            raise NotImplementedError("fcl-taco2_amd: the capacity-graph feed (BatchRunner / the decode driver) does not carry speaker embeddings yet; "
-                                      "use engine.synthesize(..., spembs=...) / model.inference(..., spemb=...)")
         self.plan, self.B, self.T, self.caps, self.forced = plan, int(batch), int(t_cap), caps, bool(forced)
+        self.S = int(plan.hp.spk_embed_dim or 0)  # speaker-embedding width: one vector per utterance rides in the same block
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         n = self.B * self.T
         # one byte block: ids int64 [n] | seg_lo, seg_hi int32 [n] each | dur int32 [n] | lens int32 [B, padded to 4] | pad uint8 [n]
         self._off = {}
         off = 0
-        for name, nbytes in (("ids", 8 * n), ("seg_lo", 4 * n), ("seg_hi", 4 * n), ("dur", 4 * n), ("lens", 4 * ((self.B + 3) // 4 * 4)), ("pad", n)):
+        for name, nbytes in (("ids", 8 * n), ("seg_lo", 4 * n), ("seg_hi", 4 * n), ("dur", 4 * n), ("lens", 4 * ((self.B + 3) // 4 * 4)), ("pad", n),
+                             ("spk", 4 * self.B * self.S)):
             self._off[name] = (off, nbytes)
             off += (nbytes + 15) // 16 * 16
         self._nbytes = off
@@ -490,11 +489,13 @@ class BatchRunner(object):
             p.lens_dev, p.pad = view("lens", torch.int32)[: self.B], view("pad", torch.uint8)
             p.dur_pad = view("dur", torch.int32) if self.forced else None
             p.f0e, p.maps = None, None
+            p.spk = view("spk", torch.float32).view(self.B, self.S) if self.S else None
             self.prep = p
             self.seed_word = torch.zeros(1, dtype=torch.int32, device=dev)
             self.status = torch.zeros(1, dtype=torch.int32, device=dev)  # this runner's own status word (violations are attributed to ITS batches)
             # warm-up on a minimal valid batch (one phoneme of duration 1 per utterance), then capture
-            self.load([np.ones(1, dtype=np.int64)] * self.B, [np.ones(1, dtype=np.int64)] * self.B if self.forced else None)
+            self.load([np.ones(1, dtype=np.int64)] * self.B, [np.ones(1, dtype=np.int64)] * self.B if self.forced else None,
+                      [np.ones(self.S, dtype=np.float32)] * self.B if self.S else None)
             with torch.cuda.stream(self.stream):
                 run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
             self.stream.synchronize()
@@ -507,9 +508,12 @@ class BatchRunner(object):
                 self.mel, self._frames = run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
         self.n_loaded = 0
 
-    def load(self, xs, durs=None):
-        """Hand one batch to the graph's input block: host packing + ONE non-blocking copy on this runner's stream (ordered before the next replay)."""
+    def load(self, xs, durs=None, spembs=None):
+        """Hand one batch to the graph's input block: host packing + ONE non-blocking copy on this runner's stream (ordered before the next replay).
+        spembs: one speaker-embedding vector per utterance (models built with spk_embed_dim)."""
         nb = len(xs)
+        if (spembs is not None) != bool(self.S):
+            raise ValueError("BatchRunner: speaker embeddings %s" % ("missing (the model has spk_embed_dim=%d)" % self.S if self.S else "given to a model without spk_embed_dim"))
         if nb > self.B or nb == 0:
             raise ValueError("BatchRunner: %d utterances, capacity %d" % (nb, self.B))
         if (durs is not None) != self.forced:
@@ -540,6 +544,11 @@ class BatchRunner(object):
                 raise ValueError("duration count != phoneme count")
             dur[:] = 0
             dur[valid] = dcat
+        if self.S:
+            sp = seg("spk", np.float32).reshape(B, self.S)
+            sp[nb:] = 0.0
+            for i_, v in enumerate(spembs):
+                sp[i_] = as_np(v).reshape(-1)
         seg("seg_lo", np.int32)[:] = base
         np.add(base, lfull, out=seg("seg_hi", np.int32))
         np.logical_not(valid, out=seg("pad", np.uint8).view(np.bool_))

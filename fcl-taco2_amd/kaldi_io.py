@@ -70,6 +70,20 @@ def read_mat(ark_path, offset):
         return np.frombuffer(f.read(4 * rows * cols), dtype=np.float32).reshape(rows, cols).copy()
 
 
+def read_vec(ark_path, offset):
+    """A Kaldi binary FloatVector ('\\0B' 'FV ' '\\x04' <int32 dim> <float32 data>) -- the x-vector of an utterance as the reference's data.json points
+    at it (`input[1].feat = "<ark>:<offset>"`, tts.py:330, 285-287); a 1 x dim or dim x 1 FloatMatrix is accepted too."""
+    with open(ark_path, "rb") as f:
+        f.seek(offset)
+        assert f.read(2) == b"\0B"
+        kind = f.read(3)
+        if kind == b"FM ":
+            return read_mat(ark_path, offset).reshape(-1)
+        assert kind == b"FV " and f.read(1) == b"\x04"
+        dim = struct.unpack("<i", f.read(4))[0]
+        return np.frombuffer(f.read(4 * dim), dtype=np.float32).copy()
+
+
 def read_scp(scp_path):
     """{key: matrix} for every line of an scp file written by ArkScpWriter (or by Kaldi/kaldiio for float matrices)."""
     out = {}

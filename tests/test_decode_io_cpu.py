@@ -51,6 +51,29 @@ def test_native_batch_writer_produces_the_same_files(tmp_path):
             w.write_batch(["bad key"], big[:1], [1])
 
 
+def test_speaker_embedding_vectors_in_the_manifest(tmp_path):
+    """data.json of a multi-speaker recipe: input[1].feat = "<ark>:<offset>" of a Kaldi FloatVector (x-vector) per utterance (tts.py:327-332)."""
+    import struct
+
+    from fcl_taco2_amd.decode import read_manifest
+    from fcl_taco2_amd.kaldi_io import read_vec
+
+    v = np.arange(8, dtype=np.float32) - 3.0
+    ark = tmp_path / "xvector.ark"
+    with open(ark, "wb") as f:
+        f.write(b"spk1 ")
+        off = f.tell()
+        f.write(b"\0BFV \x04" + struct.pack("<i", 8) + v.tobytes())
+    assert np.array_equal(read_vec(str(ark), off), v)
+    js = {"utts": {"u1": {"input": [{"name": "input1"}, {"name": "input2", "feat": "%s:%d" % (ark, off), "shape": [8]}],
+                          "output": [{"tokenid": "3 4 5"}]},
+                   "u2": {"input": [{"name": "input1"}], "output": [{"tokenid": "7"}]}}}
+    p = tmp_path / "data.json"
+    p.write_text(json.dumps(js))
+    utts = read_manifest(str(p))
+    assert utts[0][0] == "u1" and np.array_equal(utts[0][1], [3, 4, 5]) and np.array_equal(utts[0][2], v) and len(utts[1]) == 2
+
+
 def test_model_conf_manifest_and_checkpoint_formats(tmp_path):
     conf = tmp_path / "model.json"
     args = dict(model_module="nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student:Tacotron2_sa", embed_dim=256, eunits=256,

@@ -268,3 +268,41 @@ def test_grouped_predictor_launches_equal_the_per_predictor_path():
     finally:
         engine._GROUP_PREDICTORS = True
     assert list(fr) == list(fr_u) and max_abs(mel_g, mel_u) < 1e-5
+
+
+def test_decode_driver_and_capacity_graphs_carry_speaker_embeddings(tmp_path):
+    """spk_embed_dim through the capacity-graph feed: the speaker vectors of a batch travel in the runner's input block (one H2D copy), the graph
+    appends F.normalize(spemb) to the encoder states (fcl_concat_spk_fwd); the decode driver reads (utt_id, ids, spemb) and every mel equals the
+    eager synthesis of that utterance with its own speaker; a speaker-embedding model without vectors is refused."""
+    from fcl_taco2_amd import decode as D, engine
+    from fcl_taco2_amd.kaldi_io import read_scp
+
+    S, T = HP.student_hparams(dropout_rate=0.0, spk_embed_dim=32), HP.teacher_hparams()
+    import argparse
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+
+    ns = lambda h: argparse.Namespace(embed_dim=h.embed_dim, eunits=h.eunits, econv_chans=h.econv_chans, dunits=h.dunits, prenet_units=h.prenet_units,
+                                      postnet_chans=h.postnet_chans, use_residual=False, use_masking=True, dropout_rate=h.dropout_rate,
+                                      duration_predictor_chans=h.duration_predictor_chans, spk_embed_dim=h.spk_embed_dim)
+    com = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
+                             distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=False, share_proj=True)
+    model = Student(S.idim, S.odim, ns(S), com, ns(T))
+    spec = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = SYN.positive_duration_head(SYN.closed_form_state_dict(spec))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    rng = np.random.RandomState(9)
+    utts = [("s%03d" % i, rng.randint(1, S.idim, size=int(rng.randint(20, 32))).astype(np.int64), rng.randn(32).astype(np.float32)) for i in range(24)]
+    st = {}
+    frames, _ = D.decode(model, utts, str(tmp_path / "g"), batch_size=8, depth=2, stats=st)
+    assert st["graph_batches"] >= 1
+    mels = read_scp(str(tmp_path / "g.scp"))
+    assert sorted(mels) == sorted(u[0] for u in utts) and frames == sum(m.shape[0] for m in mels.values())
+    plan = model.plan()
+    for uid, x, sp in utts[::5]:
+        ref = engine.synthesize(plan, [x], spembs=[sp])[0]
+        other = engine.synthesize(plan, [x], spembs=[-sp])[0]
+        assert mels[uid].shape == tuple(ref.shape) and max_abs(mels[uid], ref) < 2e-5
+        assert other.shape != ref.shape or max_abs(other, ref) > 1e-3  # the speaker vector matters
+    with pytest.raises(ValueError):
+        D.decode(model, [(u, x) for u, x, _ in utts], None, batch_size=8)
