@@ -77,6 +77,7 @@ struct GemmArgs {
     // grouped Conv1d (fcl_conv1d_planes_group_fwd, pconv_kernel only): gridDim.z independent problems of the same shape; group g reads / writes at
     // base + g * stride (A / W / Yp in uint16 elements, bias / Y in floats)
     long long g_a, g_w, g_bias, g_y, g_yp;
+    int dbg_phase;  // developer timing aid (FCL_PGEMM_DBG): 1 = return after the main loop (results are then garbage)
 };
 
 // ---- fused LSTM step (gemm_f32.hip / decoder_step.hip): the argument block is the public fcl_lstm_step_t ----------

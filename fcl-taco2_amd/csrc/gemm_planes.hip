@@ -14,6 +14,8 @@
 // Numerics: a.b ~= al.bh + ah.bl + ah.bh on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, exactly the products of the in-kernel split.
 #include <string.h>
 
+#include <type_traits>
+
 #include "fcl_common.h"
 #include "lstm_epilogue.h"
 
@@ -34,14 +36,26 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// XCD-aware tile order (see gemm_f32.hip): the workgroups one XCD receives walk a contiguous range of tiles.
+// XCD-aware tile order (see gemm_f32.hip): the workgroups one XCD receives walk a contiguous range of tiles.  Round 3: the linear tile order
+// itself is GROUPED (groups of g_tile_group row tiles, rows innermost, as in the usual matmul swizzle) instead of row-major: the ~32 workgroups
+// an XCD runs at a time then form 8 row tiles x 4 column tiles, not 1 x 32, so per K-chunk step they pull 8 A + 4 W chunk-lines through the
+// XCD's L2 instead of 1 A + 32 W -- with W larger than the 4 MB L2 (every frame-sized GEMM of the training step, every FCL-taco2-T LSTM step)
+// the row-major order streamed the whole W from the Infinity Cache for every row of tiles.
+__constant__ int g_tile_group = 8;
 __device__ __forceinline__ void xcd_tile_p(int& bx, int& by) {
-    const int nx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int nx = gridDim.x, ny = gridDim.y, nwg = nx * ny;
     const int orig = blockIdx.y * nx + blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    by = t / nx;
-    bx = t - by * nx;
+    const int G = g_tile_group;
+    if (G <= 1) {
+        by = t / nx;
+        bx = t - by * nx;
+        return;
+    }
+    const int per = G * nx, grp = t / per, first = grp * G, gsz = min(ny - first, G), rem = t - grp * per;
+    bx = rem / gsz;
+    by = first + (rem - bx * gsz);
 }
 
 // one 32-k chunk of a wave's TM x TN tiles: fragment reads (bank-conflict free by the piece permutation) and 3 bf16 MFMAs per tile pair
@@ -274,6 +288,19 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, rq = lane >> 4;
     const unsigned int seed = hash_u32(a.rng_seed + (a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u));
+    // Every argument the element loop reads, ONCE, into locals: the loop contains stores through pointers that came from the argument block (Y2),
+    // so the compiler re-read each a.<field> from the kernel-argument segment for every one of the 32 elements (156 s_load + 94 s_waitcnt lgkmcnt(0)
+    // in the ISA of the 128 x 128 instantiation: ~5 us per workgroup, the fixed cost every kernel of this family paid per tile -- r3 probe)
+    const int a_M = a.M, a_N = a.N, a_act = a.act, a_drop = a.drop_mode, a_ldkeep = a.ldkeep, a_ldr = a.ldr, a_ldc0 = a.ldc0, a_r1lda = a.rank1_lda;
+    const int a_ldy2 = a.ldy2, a_y2add = a.y2_row_add;
+    const float a_kscale = a.keep_scale, a_dropp = a.drop_p;
+    const float* const a_r1a = a.rank1_a;
+    const float* const a_r1w = a.rank1_w;
+    const float* const a_C0 = a.C0;
+    const float* const a_R = a.R;
+    const uint8_t* const a_keep = a.keep;
+    float* const a_Y2 = a.Y2;
+    const int* const a_y2base = a.y2_row_base;
     // Epilogue through LDS: the MFMA accumulator layout gives every lane ONE column of four rows, i.e. 4-byte (fp32) or 2-byte (planes) stores,
     // 32 - 64 store instructions per lane.  The finished tile is staged as fp32 in the (now idle) ring and written out row-wise: 16 bytes per
     // lane, whole 128-byte lines for the planes (hi | lo of 32 columns), a quarter / an eighth of the store instructions.
@@ -281,77 +308,130 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[
     static_assert(BM * LDT * 4 <= LDS_BYTES, "the staging tile must fit the ring");
     float* tile = reinterpret_cast<float*>(smem);
     __syncthreads();  // every wave is done with the last chunk
+    if (a.dbg_phase == 3) {
+        if (acc[0][0][0] + acc[TM - 1][TN - 1][3] == 12345.678f) a.Y[1] = 1.f;
+        return;
+    }
+    if (a.dbg_phase == 4) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tile[((wm * TM + tm) * 16 + rq * 4 + r) * LDT + (wn * TN + tn) * 16 + col] = acc[tm][tn][r];
+        __syncthreads();
+        if (tile[threadIdx.x] == 12345.678f) a.Y[1] = 1.f;
+        return;
+    }
+    // The element loop is INSTRUCTION-bound: 32 elements per lane, and with every option tested per element (rank-1 term, C0, two dropout modes,
+    // residual, second output) ~40 instructions and ~10 branches each = 1 300 instructions per wave, two waves per SIMD: ~5 us per workgroup
+    // (r3 probe: 31 of the 80 us of a 24 320 x 1 024 x 256 GEMM).  The options are wave-uniform, so they are tested ONCE: the plain forms
+    // (bias + activation, what most launches are) run a 3-instruction element, everything else the general loop.
+    const bool plain = !a_r1a && !a_C0 && a_drop == 0 && !a_Y2 && a.dbg_phase != 5;  // (FCL_PGEMM_DBG=5: the general loop, for A/B timing)
+    auto plain_loop = [&](auto act_c, auto res_c) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool RES = decltype(res_c)::value;  // + R[m, n] behind the activation (the postnet's `before + postnet(before)`, encoder skips)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int cn = (wn * TN + tn) * 16 + col, n = n0 + cn;
+                const bool nin = n < a_N;
+                const float bn = (e_bias && nin) ? e_bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + (RP ? (wm * TM + tm) * 16 + rho16(rq * 4 + r) : rm);
+                    float v = acc[tm][tn][r] + bn;
+                    if (ACT == FCL_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (ACT == FCL_ACT_TANH) v = tanh_f(v);
+                    const bool in = nin && m < a_M;
+                    if (RES) v += a_R[(size_t)(in ? m : 0) * a_ldr + (in ? n : 0)];
+                    tile[rm * LDT + cn] = in ? v : 0.f;  // zeros past N / M: the planes' padding
+                }
+            }
+    };
+    using std::integral_constant;
+    if (plain && !a_R && a_act == FCL_ACT_NONE) plain_loop(integral_constant<int, FCL_ACT_NONE>(), integral_constant<bool, false>());
+    else if (plain && !a_R && a_act == FCL_ACT_RELU) plain_loop(integral_constant<int, FCL_ACT_RELU>(), integral_constant<bool, false>());
+    else if (plain && !a_R && a_act == FCL_ACT_TANH) plain_loop(integral_constant<int, FCL_ACT_TANH>(), integral_constant<bool, false>());
+    else if (plain && a_act == FCL_ACT_NONE) plain_loop(integral_constant<int, FCL_ACT_NONE>(), integral_constant<bool, true>());
+    else if (plain && a_act == FCL_ACT_RELU) plain_loop(integral_constant<int, FCL_ACT_RELU>(), integral_constant<bool, true>());
+    else {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int cn = (wn * TN + tn) * 16 + col, n = n0 + cn;
-            const bool nin = n < a.N;
+            const bool nin = n < a_N;
             const float bn = (e_bias && nin) ? e_bias[n] : 0.f;
-            const float r1w = (a.rank1_w && nin) ? a.rank1_w[n] : 0.f;
+            const float r1w = (a_r1w && nin) ? a_r1w[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 // staging row = MFMA row order (conflict-free ds_write pattern); RP: the tile row it holds is rho16 of it
                 const int rm = (wm * TM + tm) * 16 + rq * 4 + r, m = m0 + (RP ? (wm * TM + tm) * 16 + rho16(rq * 4 + r) : rm);
                 float v = 0.f;
-                if (nin && m < a.M) {
+                if (nin && m < a_M) {
                     v = acc[tm][tn][r] + bn;
-                    if (a.rank1_a) v += a.rank1_a[(size_t)m * a.rank1_lda] * r1w;
-                    if (a.C0) v += a.C0[(size_t)m * a.ldc0 + n];
-                    if (a.act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (a.act == FCL_ACT_TANH) v = tanh_f(v);
-                    if (a.drop_mode == 1) {
-                        v = a.keep[(size_t)m * a.ldkeep + n] ? v * a.keep_scale : 0.f;
-                    } else if (a.drop_mode == 2) {
-                        const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)a.N + (unsigned int)n) ^ seed);
-                        v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
+                    if (a_r1a) v += a_r1a[(size_t)m * a_r1lda] * r1w;
+                    if (a_C0) v += a_C0[(size_t)m * a_ldc0 + n];
+                    if (a_act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (a_act == FCL_ACT_TANH) v = tanh_f(v);
+                    if (a_drop == 1) {
+                        v = a_keep[(size_t)m * a_ldkeep + n] ? v * a_kscale : 0.f;
+                    } else if (a_drop == 2) {
+                        const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)a_N + (unsigned int)n) ^ seed);
+                        v = ((h >> 8) * (1.0f / 16777216.0f) >= a_dropp) ? v * a_kscale : 0.f;
                     }
-                    if (a.R) v += a.R[(size_t)m * a.ldr + n];
-                    if (a.Y2) a.Y2[(size_t)(a.y2_row_base[m] + a.y2_row_add) * a.ldy2 + n] = v;
+                    if (a_R) v += a_R[(size_t)m * a_ldr + n];
+                    if (a_Y2) a_Y2[(size_t)(a_y2base[m] + a_y2add) * a_ldy2 + n] = v;
                 }
                 tile[rm * LDT + cn] = v;  // zeros past N / M: the planes' padding
             }
         }
+    }
     __syncthreads();
-    const int rows = RP ? BM : min(BM, a.M - m0);  // staging rows to write out; RP: staging row rm holds tile row (rm & ~15) + rho16(rm & 15)
+    if (a.dbg_phase == 2) return;  // developer timing aid: no write-out
+    const int rows = RP ? BM : min(BM, a_M - m0);  // staging rows to write out; RP: staging row rm holds tile row (rm & ~15) + rho16(rm & 15)
     auto trow = [&](int rm) { return RP ? (rm & ~15) + rho16(rm & 15) : rm; };
+    const int a_ldy = a.ldy, a_ldyp = a.ldyp, a_nblk = a.nblk;  // (locals: the loops below store through argument pointers, see above)
+    const long long a_blk = a.blk_stride;
     if (a.accumulate) {  // weight gradients (split contraction, accumulation over micro-batches): one float per lane, consecutive lanes on
                          // consecutive addresses, so a wave's atomic instruction touches two cache lines
+        float* const Yacc = a.Y;
         for (int i = threadIdx.x; i < rows * BN; i += CTHREADS) {
             const int rm = i / BN, cn = i - rm * BN, n = n0 + cn, gm = m0 + trow(rm);
-            if (n >= a.N || gm >= a.M) continue;
-            float* dst = a.nblk > 0 ? a.Y + (size_t)(n / a.nblk) * a.blk_stride + (size_t)gm * a.ldy + (n % a.nblk)
-                                    : a.Y + (size_t)gm * a.ldy + n;
+            if (n >= a_N || gm >= a_M) continue;
+            float* dst = a_nblk > 0 ? Yacc + (size_t)(n / a_nblk) * a_blk + (size_t)gm * a_ldy + (n % a_nblk) : Yacc + (size_t)gm * a_ldy + n;
             atomicAdd(dst, tile[rm * LDT + cn]);
         }
         return;
     }
     if (e_Y) {
-        const bool vec = (a.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(e_Y) & 15u) == 0;
+        const bool vec = (a_ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(e_Y) & 15u) == 0;
         for (int i = threadIdx.x; i < rows * (BN / 4); i += CTHREADS) {
             const int rm = i / (BN / 4), c4 = (i - rm * (BN / 4)) * 4, n = n0 + c4, gm = m0 + trow(rm);
-            if (n >= a.N || gm >= a.M) continue;
+            if (n >= a_N || gm >= a_M) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c4);
-            float* dst = e_Y + (size_t)gm * a.ldy + n;
-            if (vec && n + 3 < a.N) {
+            float* dst = e_Y + (size_t)gm * a_ldy + n;
+            if (vec && n + 3 < a_N) {
                 *reinterpret_cast<f32x4*>(dst) = v;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (n + e < a.N) dst[e] = v[e];
+                    if (n + e < a_N) dst[e] = v[e];
             }
         }
     }
     if (e_Yp) {  // item = (row, 32-column line, quarter q): 8 values -> 16 bytes of hi at piece q and 16 bytes of lo at piece 4 + q
-        const int np = a.ldyp * 32;
+        const int np = a_ldyp * 32;
         for (int i = threadIdx.x; i < rows * (BN / 8); i += CTHREADS) {
             const int rm = i / (BN / 8), c8 = (i - rm * (BN / 8)) * 8, n = n0 + c8, gm = m0 + trow(rm);
-            if (n >= np || gm >= a.M) continue;
+            if (n >= np || gm >= a_M) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8), v1 = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c8 + 4);
             uint2 h0, l0, h1, l1;
             split4(v0, h0, l0);
             split4(v1, h1, l1);
-            u16* line = e_Yp + ((size_t)gm * a.ldyp + (n >> 5)) * 64 + (n & 31);
+            u16* line = e_Yp + ((size_t)gm * a_ldyp + (n >> 5)) * 64 + (n & 31);
             *reinterpret_cast<uint4*>(line) = make_uint4(h0.x, h0.y, h1.x, h1.y);
             *reinterpret_cast<uint4*>(line + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
@@ -371,6 +451,15 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (!pmainloop<WM, WN, TM, TN, NST, false, LW, HI>(a.term, a.nterms, a.M, m0, n0, a.N, a.seg_lo, a.seg_hi, smem, acc, a.ksplit_chunks)) return;  // loader wave
+    if (a.dbg_phase == 1) {  // developer timing aid (FCL_PGEMM_DBG=1): main loop only, results are garbage
+        float sdbg = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sdbg += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        if (sdbg == 12345.678f) a.Y[0] = sdbg;
+        return;
+    }
 
     pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES>(a, acc, smem, m0, n0);
 }
@@ -421,7 +510,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
             float h_w = 0.f, c_w = 0.f;
             if (m < Ms && u < a.U) {  // (cell_math also stores the optional taps / saved gates: live rows only)
                 const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
-                cell_math(a, m, u, pre, ci[tm][r], h_w, c_w);
+                cell_math<MODE>(a, m, u, pre, ci[tm][r], h_w, c_w);
             }
             th[rm * LDT + wn * 16 + (lane & 15)] = h_w;
             tc[rm * LDT + wn * 16 + (lane & 15)] = c_w;
@@ -458,8 +547,19 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
     }
 }
 
+// experiments only: FCL_TILE_GROUP=<g> overrides the grouped tile order's group size (1 = row-major, rounds 1-2) on the calling device
+static void tile_group_override() {
+    static const int done = [] {
+        const int v = tunable("TILE_GROUP", -1);
+        if (v >= 1) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tile_group), &v, sizeof(int));
+        return 1;
+    }();
+    (void)done;
+}
+
 // --------------------------------------------------------------------------------------------------------------------------------------
 bool planes_ok(const GemmTerm* t, int n) {
+    tile_group_override();
     static const int on = tunable("PLANES", 1);
     if (!on) return false;
     for (int i = 0; i < n; ++i)
@@ -494,6 +594,13 @@ static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
         int splits = std::max(1, std::min(wg_target / std::max(tiles, 1), total / std::max(min_chunks, 1)));
         b.ksplit_chunks = (total + splits - 1) / splits;
         grid.z = (unsigned)((total + b.ksplit_chunks - 1) / b.ksplit_chunks);
+        hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+        return check_hip(hipGetLastError(), "pgemm launch");
+    }
+    static const int dbg = tunable("PGEMM_DBG", 0);
+    if (dbg) {
+        GemmArgs b = a;
+        b.dbg_phase = dbg;
         hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
         return check_hip(hipGetLastError(), "pgemm launch");
     }
@@ -671,8 +778,11 @@ static int launch_pconv_nl(const GemmArgs& a, hipStream_t s, double flops) {
     char full[48];
     snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, NL, hi ? "/bf16" : "");
     ProfScope ps(full, flops, a.M, s);
-    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
+    static const int dbg = tunable("PGEMM_DBG", 0);
+    GemmArgs b = a;
+    b.dbg_phase = dbg;
+    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
     return check_hip(hipGetLastError(), "pconv launch");
 }
 
@@ -711,6 +821,7 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     static const int big_min = tunable("PGEMM_BIG_MIN_WG", 1 << 30);
     const long long t256x128 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     if (force == 3 || (force == 0 && t256x128 >= big_min && a.N >= 128 && ksum >= 512)) return launch_pgemm_cfg<4, 2, 4, 4, 3>(a, s, flops);
+    if (force == 6) return launch_pgemm_cfg<4, 2, 2, 4, 4>(a, s, flops);  // 128 x 128 tiles, FOUR ring stages (three chunks = 96 KB in flight per CU)
     static const int gbig_min = tunable("PGEMM_BIG_MIN", 150);
     if (force == 1 || (force == 0 && t128x128 >= gbig_min && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
     if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pgemm_cfg<2, 2, 2, 4, 3>(a, s, flops);
@@ -720,7 +831,7 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
 template <int WM, int WN, int TM, int NST, int LW, bool HI>
 static int launch_plstm_lw(const LstmStepArgs& a, hipStream_t s, double flops) {
     using G = PGeo<WM, WN, TM, 4, NST, LW>;
-    const bool plain = !a.zone_keep_h && !a.row_len;
+    const bool plain = !a.zone_keep_h && !a.row_len && !a.save_gates && !a.out2;  // (MODE >= 0 compiles these options out of the cell code)
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     char full[64];
@@ -763,6 +874,7 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     // thresholds as tunables (r3, 4 passes in flight, B = 32: 64-row tiles everywhere -- two workgroups per CU, also from different streams -- are +1.5 ...
     // +4.5 % on the replayed pass and within noise on the fresh feed, but -22 % on FCL-taco2-T synthesis and +6 % on the KD update: the 128-row tiles
     // stay where they are; PLSTM_BIG_MIN=300 PLSTM_MID_MIN=80 is the S-only variant)
+    if (force == 6) return launch_plstm_cfg<4, 2, 2, 4>(a, s, flops);  // 128-row tiles, four ring stages
     static const int big_min = tunable("PLSTM_BIG_MIN", 150);
     if (force == 1 || (force == 0 && t128 >= big_min)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
     static const int mid_min = tunable("PLSTM_MID_MIN", 200);

@@ -51,6 +51,10 @@ __device__ __forceinline__ CellIn cell_prefetch(const LstmStepArgs& a, int m, in
 
 // the cell + zoneout update of one (row m, unit u): new hidden / cell state in h_w / c_w; the training-only side outputs (saved gates, out2 tap)
 // are stored here, the states themselves by the caller (directly: cell_finish; or staged through LDS for row-wise stores: plstm_kernel)
+// MODE >= 0 (the launchers pick it only when no train-form mask, no row_len, no saved gates and no out2 tap is set): those options are compiled
+// out -- the element code of the big-tile step is instruction-bound (8 cells per lane, ~150 VALU instructions each with every option tested per
+// cell: ~4 us per workgroup of the 17 us launch, r3 ISA count), and the synthesis loop uses none of them.
+template <int MODE = -1>
 __device__ __forceinline__ void cell_math(const LstmStepArgs& a, int m, int u, const float (&acc)[4], const CellIn& ci, float& h_w, float& c_w) {
     const float ig = sigmoid_f(acc[0] + ci.add[0]), fg = sigmoid_f(acc[1] + ci.add[1]);
     const float gg = tanh_f(acc[2] + ci.add[2]), og = sigmoid_f(acc[3] + ci.add[3]);
@@ -58,12 +62,17 @@ __device__ __forceinline__ void cell_math(const LstmStepArgs& a, int m, int u, c
     const float h_new = og * tanh_f(c_new);
     const size_t off = (size_t)m * a.U + u;
     float h_o, c_o;
-    if (a.zone_keep_h) {  // train-form zoneout: mask = 1 keeps the OLD state
+    if (MODE < 0 && a.zone_keep_h) {  // train-form zoneout: mask = 1 keeps the OLD state
         h_o = a.zone_keep_h[off] ? ci.h_old : h_new;
         c_o = a.zone_keep_c[off] ? ci.c_old : c_new;
     } else {  // eval form (rate 0 => plain cell): rate*old + (1-rate)*new
         h_o = a.zoneout * ci.h_old + (1.0f - a.zoneout) * h_new;
         c_o = a.zoneout * ci.c_old + (1.0f - a.zoneout) * c_new;
+    }
+    if (MODE >= 0) {  // (no row_len: every row of the launch is live; no side outputs)
+        h_w = h_o;
+        c_w = c_o;
+        return;
     }
     h_w = ci.live ? h_o : ci.h_old;
     c_w = ci.live ? c_o : ci.c_old;
