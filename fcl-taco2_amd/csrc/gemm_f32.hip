@@ -271,6 +271,33 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const GemmArgs a) {
     const int wm = wave / WN, wn = wave % WN;
     const int col = lane & 15, rq = lane >> 4;
     const unsigned int seed = hash_u32(a.rng_seed + (a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u));
+    // plain launches (bias / activation / residual only: most of them) skip the per-element option tests -- the element code of these epilogues is
+    // instruction-bound (gemm_planes.hip pgemm_epilogue: ~5 us per workgroup with every option tested per element)
+    if (!a.rank1_a && !a.C0 && a.drop_mode == 0 && !a.Y2) {
+        const int a_M = a.M, a_N = a.N, a_act = a.act, a_ldy = a.ldy, a_ldr = a.ldr;
+        const float* const a_bias = a.bias;
+        const float* const a_R = a.R;
+        float* const a_Y = a.Y;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + col;
+                if (n >= a_N) continue;
+                const float bn = a_bias ? a_bias[n] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + (wm * TM + tm) * 16 + rq * 4 + r;
+                    if (m >= a_M) continue;
+                    float v = acc[tm][j][r] + bn;
+                    if (a_act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (a_act == FCL_ACT_TANH) v = tanh_f(v);
+                    if (a_R) v += a_R[(size_t)m * a_ldr + n];
+                    a_Y[(size_t)m * a_ldy + n] = v;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll

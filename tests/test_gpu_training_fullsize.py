@@ -154,7 +154,7 @@ def test_teacher_step_at_configs3_size_vs_oracle_autograd(form):
     from fcl_taco2_amd import ops
 
     if ops.planes_enabled():
-        _on_path(prof, ("plstm_kernel<", ",-1," if form == "train" else ",0,"), ("pgemm_kernel<4,2,2,4,3", ), ("pgemm_kernel<", "/dW"))
+        _on_path(prof, ("plstm_kernel<", ",-1,"), ("pgemm_kernel<4,2,2,4,3", ), ("pgemm_kernel<", "/dW"))
     _on_path(prof, ("bilstm_group_kernel<256>/train",), ("bilstm_bptt_group_kernel<256>",))
     if form == "train":  # BatchNorm running buffers after one train-mode forward: first encoder block and first postnet block against plain torch
         msd = model.state_dict()
@@ -206,7 +206,7 @@ def test_kd_step_at_configs2_size_vs_oracle_autograd(form):
     worst = _compare_grads(eng, sd)
     print("configs[2] %s form: worst gradient error max-abs %.2e / L2 %.2e over %d tensors" % (form, worst[0], worst[1], len(eng.G)))
     if ops.planes_enabled():  # (the student's weight gradients stay below the 1 M-output threshold of the transposed-plane dW GEMM: configs[3] covers it)
-        _on_path(prof, ("plstm_kernel<", ",-1," if train else ",0,"), ("pgemm_kernel<",))
+        _on_path(prof, ("plstm_kernel<", ",-1,"), ("pgemm_kernel<",))
     _on_path(prof, ("bilstm_persistent_kernel/train",), ("bilstm_bptt_persistent_kernel",), ("gemm_tn_kernel",))
 
 
