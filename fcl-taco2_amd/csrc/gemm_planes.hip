@@ -818,9 +818,12 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     // fill rate, so -25 % bytes per FLOP.  Measured r3 (tools/time_pgemm.py): +6 ... +12 % on frame-sized GEMMs with K >= 512 (12 400 x 4 096 x 512:
     // 203 -> 226 TFLOP/s fp32-equivalent), -10 ... -50 % at K <= 256 (the epilogue of a 256-row tile is not overlapped by anything at one workgroup
     // per CU), and no change of the KD / teacher update (12.58 / 12.93 vs 12.60 / 12.95 ms: few of their GEMMs qualify) -> off unless asked for
-    static const int big_min = tunable("PGEMM_BIG_MIN_WG", 1 << 30);
+    // After the epilogue pass (plain element loop) the 256-row tile no longer pays for its epilogue: 24 300 x 1 024 x 256 64 -> 58 us,
+    // 12 400 x 4 096 x 512 222 -> 188, 31 000 x 512 x 512 65 -> 54.5; still slower at N = 128 and below two rounds of workgroups -> ON for N >= 256,
+    // K >= 256, >= 512 tiles (KD / teacher update: 11.84 / 12.42 vs 11.88 / 12.40 ms)
+    static const int big_min = tunable("PGEMM_BIG_MIN_WG", 512);  // (>= two rounds of 256 workgroups; 1 << 30 turns the configuration off)
     const long long t256x128 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
-    if (force == 3 || (force == 0 && t256x128 >= big_min && a.N >= 128 && ksum >= 512)) return launch_pgemm_cfg<4, 2, 4, 4, 3>(a, s, flops);
+    if (force == 3 || (force == 0 && t256x128 >= big_min && a.N >= 256 && ksum >= 256)) return launch_pgemm_cfg<4, 2, 4, 4, 3>(a, s, flops);
     if (force == 6) return launch_pgemm_cfg<4, 2, 2, 4, 4>(a, s, flops);  // 128 x 128 tiles, FOUR ring stages (three chunks = 96 KB in flight per CU)
     static const int gbig_min = tunable("PGEMM_BIG_MIN", 150);
     if (force == 1 || (force == 0 && t128x128 >= gbig_min && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
