@@ -67,6 +67,49 @@ __global__ __launch_bounds__(64 * (8 + LW)) void probe_kernel(const unsigned cha
     s16x8 ah[TM], al[TM], bh[TN], bl[TN];
     for (int i = 0; i < TM; ++i) { ah[i] = (s16x8){1, 2, 3, 4, 5, 6, 7, (short)lane}; al[i] = ah[i]; }
     for (int j = 0; j < TN; ++j) { bh[j] = (s16x8){1, 2, 3, 4, 5, 6, 7, (short)lane}; bl[j] = bh[j]; }
+    if (EXP == 8) {  // fragment reads of chunk i+1 issued BEFORE the MFMAs of chunk i (register double buffer); lgkmcnt(0) before every barrier
+        s16x8 ah2[TM], al2[TM], bh2[TN], bl2[TN];
+        auto rd = [&](const unsigned char* sb, s16x8 (&xah)[TM], s16x8 (&xal)[TM], s16x8 (&xbh)[TN], s16x8 (&xbl)[TN]) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) { xah[tm] = *reinterpret_cast<const s16x8*>(sb + a_hi + tm * 2048); xal[tm] = *reinterpret_cast<const s16x8*>(sb + a_lo + tm * 2048); }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) { xbh[tn] = *reinterpret_cast<const s16x8*>(sb + b_hi + tn * 2048); xbl[tn] = *reinterpret_cast<const s16x8*>(sb + b_lo + tn * 2048); }
+        };
+        auto mm = [&](s16x8 (&xah)[TM], s16x8 (&xal)[TM], s16x8 (&xbh)[TN], s16x8 (&xbl)[TN]) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xal[tm], xbh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xah[tm], xbl[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xah[tm], xbh[tn], acc[tm][tn], 0, 0, 0);
+            }
+        };
+        asm volatile("s_barrier" ::: "memory");
+        rd(smem, ah, al, bh, bl);
+        int i = 0, st = 0;
+        while (true) {
+            if (i + 1 < nchunks) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                st = st + 1 == NST ? 0 : st + 1;
+                rd(smem + st * STAGE, ah2, al2, bh2, bl2);
+            }
+            mm(ah, al, bh, bl);
+            if (++i >= nchunks) break;
+            if (i + 1 < nchunks) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                st = st + 1 == NST ? 0 : st + 1;
+                rd(smem + st * STAGE, ah, al, bh, bl);
+            }
+            mm(ah2, al2, bh2, bl2);
+            if (++i >= nchunks) break;
+        }
+        float s8 = 0.f;
+        for (int ii = 0; ii < TM; ++ii) for (int j = 0; j < TN; ++j) s8 += acc[ii][j][0] + acc[ii][j][1] + acc[ii][j][2] + acc[ii][j][3];
+        if (s8 == 12345.678f) Y[0] = s8;
+        return;
+    }
     int cs = 0;
     for (int i = 0; i < nchunks; ++i) {
         asm volatile("s_barrier" ::: "memory");
@@ -154,6 +197,7 @@ void suite(const unsigned char* A, const unsigned char* W, int M, int N, int K, 
     run<3, LW, NST, GROUP>(A, W, M, N, K, Y, "no DMA (fragment reads + MFMAs)");
     run<4, LW, NST, GROUP>(A, W, M, N, K, Y, "DMA only");
     run<5, LW, NST, GROUP>(A, W, M, N, K, Y, "MFMAs only");
+    run<8, LW, NST, GROUP>(A, W, M, N, K, Y, "full main loop, fragment reads one chunk ahead");
     run<6, LW, NST, GROUP>(A, W, M, N, K, Y, "full main loop + epilogue (stage, 16-byte stores)");
     run<7, LW, NST, GROUP>(A, W, M, N, K, Y, "full main loop + epilogue, non-temporal stores");
 }
