@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcl_hip.so")
+LIB_PATH = os.environ.get("FCL_LIB") or os.path.join(_HERE, "libfcl_hip.so")  # (FCL_LIB: developer A/B builds of the same ABI)
 
 # name -> (restype, argtypes); mirrors include/fcl_hip.h one to one
 _P = C.c_void_p

@@ -38,7 +38,7 @@ __device__ __forceinline__ CellIn cell_prefetch(const LstmStepArgs& a, int m, in
         for (int g = 0; g < 4; ++g) ci.add[g] += gr[g * a.U + u];
     }
     if (has_pos) {
-        const float pos = (float)a.step / (float)a.dur[m];  // reference: arange(d).float() / d
+        const float pos = (float)a.step / (float)a.dur[m];  // reference: arange(d).float() / d  (a reciprocal instead: no measurable gain, r3)
 #pragma unroll
         for (int g = 0; g < 4; ++g) ci.add[g] += pos * a.rank1_w[g * a.U + u];
     }
