@@ -106,7 +106,7 @@ struct PGeo {
     static constexpr int STAGE = (BM + BN) * 128;
     static constexpr int LDS_BYTES = NST * STAGE;
     static_assert((BM / 8) % NL == 0 && (BN / 8) % NL == 0 && (NL % 2) == 0, "tile rows must split evenly over the loading waves");
-    static_assert(NST == 3 || NST == 4, "ring depth");
+    static_assert(NST >= 2 && NST <= 4, "ring depth (2: 64 KB for a 128 x 128 tile -> TWO workgroups per CU, one's epilogue beside the other's main loop)");
     static_assert(2 * GPW <= 60, "s_waitcnt vmcnt is a 6-bit field");
 };
 
@@ -214,7 +214,8 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
             int is = NST - 1;
             for (int i = 0; i < nchunks; ++i) {
                 const int left = nchunks - 1 - i;
-                if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
+                if (NST == 2) wait_vm<0>();  // two stages: only the chunk consumed next is in flight
+                else if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
                 else if (left >= 1) wait_vm<G::GPW>();
                 else wait_vm<0>();
                 asm volatile("s_barrier" ::: "memory");
@@ -235,7 +236,8 @@ __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, in
         int cs = 0, is = NST - 1;
         for (int i = 0; i < nchunks; ++i) {  // chunk i is consumed while chunks i+1 .. i+NST-2 stay in flight and chunk i+NST-1 is issued
             const int left = nchunks - 1 - i;
-            if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
+            if (NST == 2) wait_vm<0>();
+            else if (NST >= 4 && left >= 2) wait_vm<2 * G::GPW>();
             else if (left >= 1) wait_vm<G::GPW>();
             else wait_vm<0>();
             asm volatile("s_barrier" ::: "memory");  // chunk i has landed for every wave; every wave is done reading the buffer refilled now
@@ -305,7 +307,9 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[
     // Epilogue through LDS: the MFMA accumulator layout gives every lane ONE column of four rows, i.e. 4-byte (fp32) or 2-byte (planes) stores,
     // 32 - 64 store instructions per lane.  The finished tile is staged as fp32 in the (now idle) ring and written out row-wise: 16 bytes per
     // lane, whole 128-byte lines for the planes (hi | lo of 32 columns), a quarter / an eighth of the store instructions.
-    constexpr int LDT = BN + 4;  // staging row stride (floats): keeps float4 alignment, spreads rows over banks
+    // staging row stride (floats): + 4 keeps float4 alignment and spreads rows over banks; a two-stage ring (64 KB) holds the 128 x 128 tile only
+    // unpadded (rows 4 apart then share a bank pair: 2-way on ds_write_b32, which costs nothing extra; the row-wise reads stay conflict-free)
+    constexpr int LDT = BM * (BN + 4) * 4 <= LDS_BYTES ? BN + 4 : BN;
     static_assert(BM * LDT * 4 <= LDS_BYTES, "the staging tile must fit the ring");
     float* tile = reinterpret_cast<float*>(smem);
     __syncthreads();  // every wave is done with the last chunk
@@ -439,8 +443,10 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[
     }
 }
 
+// (HIP's second __launch_bounds__ argument is waves per SIMD: two stages = 64 KB of LDS = two 12-wave workgroups per CU = 6 waves per SIMD, i.e. at
+// most 80 VGPRs -- the three-stage instantiation needs 78, so asking for it costs nothing)
 template <int WM, int WN, int TM, int TN, int NST, int LW, bool HI>
-__global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12) ? 6 : 1) void pgemm_kernel(const GemmArgs a) {
     using G = PGeo<WM, WN, TM, TN, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
@@ -465,8 +471,10 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void pgemm_kernel(const GemmAr
     pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES>(a, acc, smem, m0, n0);
 }
 
+// NST = 2 (two ring stages, 64 KB: TWO workgroups per CU, 6 waves per SIMD, <= 80 VGPRs): the epilogue operands are then NOT requested before
+// the K loop (48 VGPRs held across it) but where they are used -- the other workgroup's main loop covers their latency.
 template <int WM, int WN, int TM, int NST, int MODE, int LW, bool HI>
-__global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmStepArgs a) {
+__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12) ? 6 : 1) void plstm_kernel(const LstmStepArgs a) {
     using G = PGeo<WM, WN, TM, 4, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
@@ -482,9 +490,10 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
     const int rq = lane >> 4;
     // epilogue operands (G0 / bias / position / old state) are requested BEFORE the K loop (plain loads: they are older than every LDS-DMA
     // piece, so the counted vmcnt waits of the loop cover them and their latency hides under it)
-    CellIn ci[TM][4];
+    constexpr bool PRE = NST != 2;
+    CellIn ci[PRE ? TM : 1][4];
     const int uc = min(u, a.U - 1);
-    if (LW == 0 || wave < G::NW) {
+    if (PRE && (LW == 0 || wave < G::NW)) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -520,7 +529,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void plstm_kernel(const LstmSt
             float h_w = 0.f, c_w = 0.f;
             if (m < Ms && u < a.U) {  // (cell_math also stores the optional taps / saved gates: live rows only)
                 const float pre[4] = {acc[tm][0][r], acc[tm][1][r], acc[tm][2][r], acc[tm][3][r]};
-                cell_math<MODE>(a, m, u, pre, ci[tm][r], h_w, c_w);
+                if (PRE) {
+                    cell_math<MODE>(a, m, u, pre, ci[PRE ? tm : 0][r], h_w, c_w);
+                } else {
+                    const CellIn cl = cell_prefetch<MODE>(a, m, u);
+                    cell_math<MODE>(a, m, u, pre, cl, h_w, c_w);
+                }
             }
             th[rm * LDT + wn * 16 + (lane & 15)] = h_w;
             tc[rm * LDT + wn * 16 + (lane & 15)] = c_w;
@@ -833,10 +847,16 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     // After the epilogue pass (plain element loop) the 256-row tile no longer pays for its epilogue: 24 300 x 1 024 x 256 64 -> 58 us,
     // 12 400 x 4 096 x 512 222 -> 188, 31 000 x 512 x 512 65 -> 54.5; still slower at N = 128 and below two rounds of workgroups -> ON for N >= 256,
     // K >= 256, >= 512 tiles (KD / teacher update: 11.84 / 12.42 vs 11.88 / 12.40 ms)
-    static const int big_min = tunable("PGEMM_BIG_MIN_WG", 512);  // (>= two rounds of 256 workgroups; 1 << 30 turns the configuration off)
+    static const int big_min = tunable("PGEMM_BIG_MIN_WG", 1 << 30);  // (off again: the two-stage 128 x 128 configuration below beats it on every shape)
     const long long t256x128 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128);
     if (force == 3 || (force == 0 && t256x128 >= big_min && a.N >= 256 && ksum >= 256)) return launch_pgemm_cfg<4, 2, 4, 4, 3>(a, s, flops);
     if (force == 6) return launch_pgemm_cfg<4, 2, 2, 4, 4>(a, s, flops);  // 128 x 128 tiles, FOUR ring stages (three chunks = 96 KB in flight per CU)
+    // 128 x 128 tiles with TWO ring stages: 64 KB of LDS and 80 VGPRs = two workgroups per CU, so one's epilogue (staging + stores, 2 - 3 us that
+    // nothing overlapped at one workgroup per CU) runs beside the other's main loop.  Only where the launch has more than one round of workgroups
+    // (a single round runs one per CU whatever it could share): 24 300 x 1 024 x 256 63 -> 52 us, 12 400 x 4 096 x 512 199 -> 152 (343 TFLOP/s
+    // fp32-equivalent), 31 000 x 512 x 512 64 -> 49, 2 480 x 4 096 x 1 024 72 -> 66; N = 128 is 13 % slower with it (tools/time_pgemm.py)
+    static const int two_stage_min = tunable("PGEMM_2STAGE_MIN_WG", 300);
+    if (force == 7 || (force == 0 && t128x128 >= two_stage_min && a.N >= 256)) return launch_pgemm_cfg<4, 2, 2, 4, 2>(a, s, flops);
     static const int gbig_min = tunable("PGEMM_BIG_MIN", 150);
     if (force == 1 || (force == 0 && t128x128 >= gbig_min && a.N >= 128)) return launch_pgemm_cfg<4, 2, 2, 4, 3>(a, s, flops);
     if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pgemm_cfg<2, 2, 2, 4, 3>(a, s, flops);
@@ -890,6 +910,12 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     // +4.5 % on the replayed pass and within noise on the fresh feed, but -22 % on FCL-taco2-T synthesis and +6 % on the KD update: the 128-row tiles
     // stay where they are; PLSTM_BIG_MIN=300 PLSTM_MID_MIN=80 is the S-only variant)
     if (force == 6) return launch_plstm_cfg<4, 2, 2, 4>(a, s, flops);  // 128-row tiles, four ring stages
+    // 128-row tiles, TWO ring stages = two workgroups per CU (see pgemm): where the launch has more than one round of workgroups (FCL-taco2-T,
+    // batch >= 64 at FCL-taco2-S): the step kernel itself +10 % (FCL-taco2-T: frac 0.33 -> 0.36), batch 64 +2.7 %, T synthesis +1 %.  Synthesis
+    // steps only: in the KD update the frozen teacher's forward runs BESIDE the student's critical path, and a teacher step that holds two
+    // workgroups' worth of every CU slows that path more than it gains (12.20 vs 11.98 ms)
+    static const int two_stage_min = tunable("PLSTM_2STAGE_MIN_WG", 300);
+    if (force == 7 || (force == 0 && t128 >= two_stage_min && !a.zone_keep_h && !a.save_gates)) return launch_plstm_cfg<4, 2, 2, 2>(a, s, flops);
     static const int big_min = tunable("PLSTM_BIG_MIN", 150);
     if (force == 1 || (force == 0 && t128 >= big_min)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
     static const int mid_min = tunable("PLSTM_MID_MIN", 200);

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(64 * (8 + LW)) void probe_kernel(const unsigned cha
         int is = NST - 1;
         for (int i = 0; i < nchunks; ++i) {
             const int left = nchunks - 1 - i;
-            if (NST >= 4 && left >= 2) wait_vm<2 * GPW>();
+            if (NST == 2) wait_vm<0>();  // two stages: only the chunk consumed next is in flight
+            else if (NST >= 4 && left >= 2) wait_vm<2 * GPW>();
             else if (left >= 1) wait_vm<GPW>();
             else wait_vm<0>();
             asm volatile("s_barrier" ::: "memory");
@@ -213,5 +214,10 @@ int main() {
     suite<4, 3, 8>(A, W, 24320, 1024, 256, Y);   // KD projection over every frame
     suite<4, 3, 8>(A, W, 24320, 512, 128, Y);
     suite<4, 3, 1>(A, W, 2560, 1024, 512, Y);    // FCL-taco2-S LSTM step (160 workgroups)
+    printf("---- two ring stages (64 KB: TWO workgroups per CU)\n");
+    suite<4, 2, 8>(A, W, 2560, 4096, 2048, Y);
+    suite<4, 2, 8>(A, W, 12800, 4096, 512, Y);
+    suite<4, 2, 8>(A, W, 24320, 1024, 256, Y);
+    suite<4, 2, 1>(A, W, 2560, 1024, 512, Y);
     return 0;
 }
