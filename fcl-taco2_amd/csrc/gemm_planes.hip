@@ -649,19 +649,19 @@ static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
 // k taps read it at row offsets -pad .. +pad; only the W chunk changes per step: (BM + 16 + k * BN) * 128 B per channel chunk instead of
 // k * (BM + BN) * 128 B (-39 % for k = 5, 64 x 64 tiles).  Utterance edges: a row outside the segment of the OUTPUT row it contributes to is
 // zeroed per lane at fragment-read time (one shared tile serves rows of two utterances when a tile straddles a boundary).
-template <int WM, int WN, int TM, int TN, int NL_ = 2>
+template <int WM, int WN, int TM, int TN, int NL_ = 2, int NSTW_ = 3>
 struct CGeo {
     static constexpr int BM = 16 * WM * TM, BN = 16 * WN * TN, NW = WM * WN, NL = NL_, THREADS = 64 * (NW + NL), CTHREADS = 64 * NW;
-    static constexpr int HALO = NL_ == 4 ? 16 : 8, AROWS = BM + 2 * HALO, A_BYTES = AROWS * 128, W_BYTES = BN * 128, NSTW = 3;
+    static constexpr int HALO = NL_ == 4 ? 16 : 8, AROWS = BM + 2 * HALO, A_BYTES = AROWS * 128, W_BYTES = BN * 128, NSTW = NSTW_;  // W ring stages (2: 68 KB for the 128 x 128 tile -> two workgroups per CU)
     static constexpr int LDS_BYTES = 2 * A_BYTES + NSTW * W_BYTES;
     static constexpr int GAH = AROWS / 8 / NL, GB = BN / 8 / NL;
     static_assert((AROWS / 8) % NL == 0 && (BN / 8) % NL == 0, "tile rows must split evenly over the loader waves");
     static_assert(GAH + GB <= 60, "s_waitcnt vmcnt is a 6-bit field");
 };
 
-template <int WM, int WN, int TM, int TN, bool HI, int NL>
+template <int WM, int WN, int TM, int TN, bool HI, int NL, int NSTW = 3>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmArgs a) {
-    using G = CGeo<WM, WN, TM, TN, NL>;
+    using G = CGeo<WM, WN, TM, TN, NL, NSTW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
     xcd_tile_p(bx, by);
@@ -716,6 +716,14 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
             if (++ij == k) { ij = 0; ++ic; }
         };
         issue();
+        if (G::NSTW == 2) {  // two W stages: one bundle ahead (the other workgroup on the CU covers the exposed DMA latency)
+            for (int s = 0; s < S; ++s) {
+                wait_vm<0>();
+                asm volatile("s_barrier" ::: "memory");
+                if (s + 1 < S) issue();
+            }
+            return;
+        }
         if (S > 1) issue();
         for (int s = 0; s < S; ++s) {
             // everything but the newest bundle (step s + 1) has landed; that bundle carries an A tile when s + 1 opens a chunk
@@ -791,30 +799,34 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
     pgemm_epilogue<WN, TM, TN, G::BM, G::BN, G::CTHREADS, G::LDS_BYTES, true>(a, acc, smem, m0, n0, gz * a.g_bias, gz * a.g_y, gz * a.g_yp);
 }
 
-template <int WM, int WN, int TM, int TN, int NL>
+template <int WM, int WN, int TM, int TN, int NL, int NSTW = 3>
 static int launch_pconv_nl(const GemmArgs& a, hipStream_t s, double flops) {
-    using G = CGeo<WM, WN, TM, TN, NL>;
+    using G = CGeo<WM, WN, TM, TN, NL, NSTW>;
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
-    const void* fn = hi ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, true, NL>) : reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, false, NL>);
+    const void* fn = hi ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, true, NL, NSTW>) : reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, false, NL, NSTW>);
     const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
     if (rc) return rc;
     const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;
     const int groups = (a.g_a || a.g_w || a.g_y || a.g_yp) ? max(1, a.nblk) : 1;  // (nblk carries the group count of a grouped Conv1d)
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM, groups);
     char full[48];
-    snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, TN, NL, hi ? "/bf16" : "");
+    snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NL, NSTW == 2 ? "/2st" : "", hi ? "/bf16" : "");
     ProfScope ps(full, flops, a.M, s);
     static const int dbg = tunable("PGEMM_DBG", 0);
     GemmArgs b = a;
     b.dbg_phase = dbg;
-    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
-    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false, NL>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true, NL, NSTW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false, NL, NSTW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
     return check_hip(hipGetLastError(), "pconv launch");
 }
 
 template <int WM, int WN, int TM, int TN>
 static int launch_pconv_cfg(const GemmArgs& a, hipStream_t s, double flops) {
     static const int nl = tunable("PCONV_LOADERS", 2);
+    // 128 x 128 tiles (the postnet): two W stages = 68 KB, 10 waves, 96 VGPRs -> two workgroups per CU.  Measured r3: the fresh feed LOSES 1 %
+    // with it (39.2 vs 39.6 M frames/s over three runs each: one bundle ahead exposes the W latency of a 5-tap step) -> off
+    static const int two = tunable("PCONV_2STAGE", 0);
+    if (two && WM * TM == 8 && WN * TN == 8 && nl < 4) return launch_pconv_nl<WM, WN, TM, TN, 2, 2>(a, s, flops);
     return nl >= 4 ? launch_pconv_nl<WM, WN, TM, TN, 4>(a, s, flops) : launch_pconv_nl<WM, WN, TM, TN, 2>(a, s, flops);
 }
 
