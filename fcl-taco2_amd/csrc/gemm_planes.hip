@@ -926,7 +926,7 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     // batch >= 64 at FCL-taco2-S): the step kernel itself +10 % (FCL-taco2-T: frac 0.33 -> 0.36), batch 64 +2.7 %, T synthesis +1 %.  Synthesis
     // steps only: in the KD update the frozen teacher's forward runs BESIDE the student's critical path, and a teacher step that holds two
     // workgroups' worth of every CU slows that path more than it gains (12.20 vs 11.98 ms)
-    static const int two_stage_min = tunable("PLSTM_2STAGE_MIN_WG", 150);  // (150 = wherever the 128-row tile is chosen: with several passes in flight two 64 KB workgroups of DIFFERENT streams share a CU too: B = 32 fresh feed +2 %, replayed +1.5 %)
+    static const int two_stage_min = tunable("PLSTM_2STAGE_MIN_WG", 300);  // (150 = wherever the 128-row tile is chosen: B = 32 with four passes in flight +2 % -- workgroups of different streams share a CU --, but the step ALONE is 8 % slower without its pre-loop operand requests: 111 vs 120 TFLOP/s)
     if (force == 7 || (force == 0 && t128 >= two_stage_min && !a.zone_keep_h && !a.save_gates)) return launch_plstm_cfg<4, 2, 2, 2>(a, s, flops);
     static const int big_min = tunable("PLSTM_BIG_MIN", 150);
     if (force == 1 || (force == 0 && t128 >= big_min)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
