@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 304  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 305  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -135,7 +135,7 @@ SIGNATURES = {
     "fcl_row_maps_build": (_I, [C.POINTER(RowMaps), _P]),
     "fcl_gather_rows_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "fcl_bilstm_workspace_bytes": (_Z, [_I, _I, _I]),
-    "fcl_bilstm_fwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    "fcl_bilstm_fwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),
     "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
     "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
     "fcl_masked_l1_mse_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),

@@ -10,6 +10,7 @@
 //   algo 1 "steps": one fused LSTM-step GEMM launch (gemm_f32.hip) per time step and direction, rows =
 //          utterances, packed-sequence semantics via row_len.  Any H; also the cross-check of algo 2.
 #include "fcl_common.h"
+#include "row_maps.h"
 #include "lstm_epilogue.h"
 
 namespace fcl {
@@ -17,11 +18,24 @@ namespace fcl {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 
-template <int H, bool SAVE = false>
+// MAPS: the launch carries one more workgroup column (blockIdx.x == B): its first workgroup builds the row / frame maps of the batch
+// (row_maps.h: forced durations depend on nothing the encoder computes) beside the 2 B recurrences -- ~25 us of a 100 us launch that leaves
+// three quarters of the CUs idle -- instead of two launches on the pass's dependent chain.
+template <int H, bool SAVE = false, bool MAPS = false>
 __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
                                                                    const float* __restrict__ whh_f, const float* __restrict__ whh_r,
                                                                    const int* __restrict__ lens, float* __restrict__ out, int T, BilstmSave sv = BilstmSave(),
-                                                                   unsigned short* __restrict__ out_p = nullptr /* optional P32 planes of out */) {
+                                                                   unsigned short* __restrict__ out_p = nullptr /* optional P32 planes of out */,
+                                                                   fcl_row_maps_t mp = fcl_row_maps_t()) {
+    if constexpr (MAPS) {
+        if (blockIdx.x == gridDim.x - 1) {
+            if (blockIdx.y == 0) {
+                row_maps_block<4 * H>(mp);
+                row_maps_finish_block<4 * H>(mp);
+            }
+            return;
+        }
+    }
     __shared__ __attribute__((aligned(16))) float h_s[H];
     __shared__ float g_s[4 * H];
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
@@ -399,7 +413,7 @@ size_t fcl_bilstm_workspace_bytes(int b, int t, int h) {
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
                    const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, uint16_t* out_p, const uint16_t* x_p,
                    const uint16_t* w_ih_f_p, const uint16_t* w_ih_r_p, int b, int t, int c, int h,
-                   int algo, void* workspace, size_t workspace_bytes, uint32_t* status, fcl_stream_t stream) {
+                   int algo, void* workspace, size_t workspace_bytes, uint32_t* status, const fcl_row_maps_t* row_maps, fcl_stream_t stream) {
     FCL_REQUIRE((x || x_p) && lens && w_ih_f && w_hh_f && b_f && w_ih_r && w_hh_r && b_r && out, FCL_ERR_INVALID, "bilstm_fwd: null argument");
     FCL_REQUIRE((x_p == nullptr) == (w_ih_f_p == nullptr) && (x_p == nullptr) == (w_ih_r_p == nullptr), FCL_ERR_INVALID,
                 "bilstm_fwd: x_p / w_ih_f_p / w_ih_r_p come together");
@@ -436,16 +450,35 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     // several synthesis passes are in flight on other streams (3.52 vs 3.85 M frames/s) — so algo 0 keeps the per-step launches there.
     static const int group_infer = tunable("BILSTM_GROUP_INFER", 0);
     FCL_REQUIRE(algo != 3 || status, FCL_ERR_INVALID, "bilstm_fwd: algo 3 (cooperating workgroups) needs a device status word");
+    // row_maps: also build the batch's row / frame maps (fcl_row_maps_build).  With the persistent recurrence at H = 128 they ride in the same
+    // launch (one extra workgroup); every other path builds them with their own two launches after the recurrence
+    bool maps_fusable = false;
+    if (row_maps) {
+        const int rc = row_maps_check(row_maps, &maps_fusable);
+        if (rc) return rc;
+    }
+    static const int fuse_on = tunable("ROWMAPS_FUSE", 1);
+    struct MapsAfter {  // the non-fused paths below return from several places
+        const fcl_row_maps_t* m;
+        fcl_stream_t st;
+        int finish(int rc) const { return (rc || !m) ? rc : fcl_row_maps_build(m, st); }
+    } after{row_maps, stream};
     if (h == 256 && status && (algo == 3 || (algo == 0 && group_infer))) {
         void* gws = hbuf;  // the Gx buffers are final, so the tail of the workspace (per-step state of algo 1) is free for the flags and the exchange buffer
         const size_t gbytes = workspace_bytes - sizeof(float) * ((size_t)2 * b * t * 4 * h);
         if (launch_bilstm_group(gx_f, gx_r, w_hh_f, w_hh_r, lens, out, b, t, h, nullptr, gws, gbytes, status, s)) {
             FCL_HIP(hipGetLastError());
-            return out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0;
+            return after.finish(out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0);
         }
     }
     if (algo == 0 || algo == 3) algo = can_persist ? 2 : 1;
     FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);
+    if (algo == 2 && h == 128 && row_maps && maps_fusable && fuse_on) {
+        ProfScope ps("bilstm_persistent_kernel+maps", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
+        hipLaunchKernelGGL((bilstm_persistent_kernel<128, false, true>), dim3(b + 1, 2), dim3(512), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t, BilstmSave(),
+                           out_p, *row_maps);
+        return check_hip(hipGetLastError(), "bilstm persistent (+ row maps) launch");
+    }
     if (algo == 2) {
         ProfScope ps("bilstm_persistent_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
         dim3 grid(b, 2);
@@ -459,7 +492,7 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
             FCL_BILSTM_CASE(128)
         }
 #undef FCL_BILSTM_CASE
-        return check_hip(hipGetLastError(), "bilstm persistent launch");
+        return after.finish(check_hip(hipGetLastError(), "bilstm persistent launch"));
     }
     // algo 1: per-step launches
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, s, hbuf, (long long)6 * b * h, 0.f);
@@ -507,7 +540,7 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
             }
         }
     }
-    return out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0;  // the per-step path writes fp32 only: split once at the end
+    return after.finish(out_p ? fcl_pack_planes(out, 2 * h, b * t, 2 * h, out_p, stream) : 0);  // the per-step path writes fp32 only: split once at the end
 }
 
 }  // extern "C"

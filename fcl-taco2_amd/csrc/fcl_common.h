@@ -128,6 +128,8 @@ struct FeatPrenetArgs {
     int out_act;                // FCL_ACT_*: output_activation_fn on the fed-back frame (decoder_sa.py:614-617); `before` stays raw
 };
 
+int row_maps_check(const fcl_row_maps_t* a, bool* fusable);  // pointwise.hip
+
 // rows a step kernel processes: the host's count, or (device-driven loops) the smaller of the host's bound and the device's count
 __device__ __forceinline__ int live_rows_of(int m_host, const int* m_dev) { return m_dev ? min(m_host, *m_dev) : m_host; }
 

@@ -7,6 +7,7 @@
 #include <sys/uio.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "fcl_common.h"

@@ -2,6 +2,7 @@
 // Every kernel is coalesced along the channel dimension (channels-last rows), float4 where widths allow.
 #include <algorithm>
 #include "fcl_common.h"
+#include "row_maps.h"
 
 namespace fcl {
 
@@ -323,15 +324,6 @@ __global__ void __launch_bounds__(256) derive_batch_kernel(const fcl_derive_t* _
 // Every output element is a count or a prefix sum over the N compact rows, so each thread walks the durations once (staged through LDS in
 // chunks: broadcast reads): O(N) per thread, N/256 + a few workgroups -- ~10 us for a 32-utterance batch, no sort network, no atomics,
 // deterministic.  Role by workgroup: rows (stable descending rank + exclusive prefix sum), live-row counts, utterance frame starts / totals.
-constexpr int RM_CHUNK = 4096;
-constexpr int RM_DMAX = 65535;  // durations are clamped here (sum over <= 32 k rows stays inside int32); anything near it trips FCL_STATUS_LMAX_CAP
-
-__device__ __forceinline__ int rm_dur(const fcl_row_maps_t& a, int j) {
-    const long long d = a.dur_i32 ? (long long)a.dur_i32[j] : (long long)a.dur_i64[a.row_src ? a.row_src[j] : j];
-    const int v = (int)(d < 0 ? 0 : (d > RM_DMAX ? RM_DMAX : d));
-    return (a.pad && a.pad[j]) ? -1 - v : v;  // padding rows: tagged negative for the zero-duration test, counted as 0 everywhere else
-}
-
 __global__ __launch_bounds__(256) void row_maps_kernel(const fcl_row_maps_t a, int wg_rows, int wg_live) {
     __shared__ __attribute__((aligned(16))) int d_l[RM_CHUNK];
     const int wg = blockIdx.x;
@@ -414,131 +406,10 @@ __global__ __launch_bounds__(256) void row_maps_kernel(const fcl_row_maps_t a, i
 // their duration value with wave ballots (one iteration per distinct value in the wave), the per-wave counts are scanned across the waves and
 // carried across the rounds, durations get a block-wide exclusive prefix sum the same way; a second sweep adds the number of rows with a larger
 // duration and scatters.  O(N) work, ~5 us for a 32-utterance batch (the form above: 98 us at 3 200 rows, 30 ns per row and thread).
-constexpr int RMF_V = 256;  // value buckets 0 .. 254; 255 = anything larger (then > lmax_cap: the pass is void anyway)
+__global__ __launch_bounds__(1024) void row_maps_fast_kernel(const fcl_row_maps_t a) { row_maps_block<1024>(a); }
 
-__global__ __launch_bounds__(1024) void row_maps_fast_kernel(const fcl_row_maps_t a) {
-    __shared__ unsigned short cnt[16][RMF_V];
-    __shared__ int running[RMF_V], start[RMF_V], wsum[16], carry, zeros_l, dmax_l;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < RMF_V; k += 1024) running[k] = 0;
-    if (tid == 0) { carry = 0; zeros_l = 0; dmax_l = 0; }
-    int my_zero = 0, my_max = 0;
-    const int rounds = (a.n + 1023) / 1024;
-    for (int r = 0; r < rounds; ++r) {
-        const int i = r * 1024 + tid;
-        const bool valid = i < a.n;
-        const int raw = valid ? rm_dur(a, i) : -1;  // padding rows are tagged negative
-        const int d = max(raw, 0), v = min(d, RMF_V - 1);
-        my_zero += valid && raw == 0;
-        my_max = max(my_max, d);
-        __syncthreads();  // (the previous round is done with cnt / wsum)
-        for (int k = tid; k < 16 * RMF_V; k += 1024) (&cnt[0][0])[k] = 0;
-        __syncthreads();
-        // stable rank inside the (wave, value) group: lanes below me with my value
-        int inw = 0;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int lv = __shfl(v, leader);
-            const unsigned long long mask = __ballot(valid && v == lv);
-            if (valid && v == lv) inw = __popcll(mask & ((1ull << lane) - 1ull));
-            if (lane == leader) cnt[wave][lv] = (unsigned short)__popcll(mask);
-            todo &= ~mask;
-        }
-        // exclusive prefix sum of the durations inside the wave
-        int incl = d;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        if (tid < RMF_V) {  // rows of value `tid` before each wave of this round, earlier rounds included (<= N <= 32 768: fits 16 bits)
-            int s = running[tid];
-            for (int w = 0; w < 16; ++w) {
-                const int c = cnt[w][tid];
-                cnt[w][tid] = (unsigned short)s;
-                s += c;
-            }
-            running[tid] = s;
-        } else if (tid == RMF_V) {
-            int s = carry;
-            for (int w = 0; w < 16; ++w) {
-                const int t = wsum[w];
-                wsum[w] = s;
-                s += t;
-            }
-            carry = s;
-        }
-        __syncthreads();
-        if (valid) {
-            a.scratch[i] = (int)cnt[wave][v] + inw;          // rows with my value before me
-            a.scratch[a.n + i] = wsum[wave] + incl - d;      // frames before me = my first output frame (H10)
-        }
-    }
-    atomicAdd(&zeros_l, my_zero);
-    atomicMax(&dmax_l, my_max);
-    __syncthreads();
-    if (tid == 0) {  // rows with a larger duration, per value (suffix sums of the 256 totals)
-        int s = 0;
-        for (int v = RMF_V - 1; v >= 0; --v) {
-            start[v] = s;
-            s += running[v];
-        }
-    }
-    __syncthreads();
-    __threadfence_block();
-    for (int r = 0; r < rounds; ++r) {
-        const int i = r * 1024 + tid;
-        if (i >= a.n) break;
-        const int d = max(rm_dur(a, i), 0), v = min(d, RMF_V - 1);
-        const int rank = start[v] + a.scratch[i];
-        a.src_rows[rank] = a.row_src ? a.row_src[i] : i;
-        a.dur_sorted[rank] = d;
-        a.frame_off[rank] = a.scratch[a.n + i];
-        if (a.order) a.order[rank] = i;
-    }
-    const int total = carry;
-    for (int t = tid; t <= a.lmax_cap; t += 1024) a.live_rows[t] = t < RMF_V ? start[t] : 0;
-    for (int b = tid; b <= a.b; b += 1024) {
-        const int row0 = a.utt_row0 ? a.utt_row0[b] : b * a.t_max;
-        a.utt_frame0[b] = row0 < a.n ? a.scratch[a.n + row0] : total;
-    }
-    if (tid == 0) {
-        a.totals[0] = total;
-        a.totals[1] = dmax_l;
-        a.totals[2] = zeros_l;
-        a.totals[3] = 0;
-        unsigned int bits = 0;
-        if (zeros_l) bits |= FCL_STATUS_ZERO_DURATION;
-        if (dmax_l > a.lmax_cap) bits |= FCL_STATUS_LMAX_CAP;
-        if (total > a.frames_cap) bits |= FCL_STATUS_FRAMES_CAP;
-        if (bits) atomicOr(a.status, bits);
-    }
-}
-
-// second launch (the totals are complete): frame -> utterance bounds, and -- on any violation -- no live rows at all, so that a decoder loop
-// driven by these maps neither runs past its launched steps nor scatters past the frame buffers
-__global__ __launch_bounds__(256) void row_maps_finish_kernel(const fcl_row_maps_t a) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    const int total = a.totals[0];
-    const bool bad = a.totals[2] > 0 || a.totals[1] > a.lmax_cap || total > a.frames_cap;
-    if (bad && f <= a.lmax_cap) a.live_rows[f] = 0;
-    if (f >= a.frames_cap) return;
-    int lo = 0, hi = 0;
-    if (!bad && f < total) {
-        int l = 0, r = a.b;  // utt_frame0[l] <= f < utt_frame0[r]
-        while (r - l > 1) {
-            const int mid = (l + r) >> 1;
-            if (a.utt_frame0[mid] <= f) l = mid; else r = mid;
-        }
-        lo = a.utt_frame0[l];
-        hi = a.utt_frame0[l + 1];
-    }
-    a.frame_lo[f] = lo;
-    a.frame_hi[f] = hi;
-}
+// second launch (the totals are complete): frame -> utterance bounds, and -- on any violation -- no live rows at all
+__global__ __launch_bounds__(256) void row_maps_finish_kernel(const fcl_row_maps_t a) { row_maps_finish_item(a, blockIdx.x * 256 + threadIdx.x); }
 
 }  // namespace fcl
 
@@ -708,7 +579,12 @@ int fcl_derive_batch(const fcl_derive_t* descs_dev, int n, int total_blocks, fcl
     return check_hip(hipGetLastError(), "derive_batch");
 }
 
-int fcl_row_maps_build(const fcl_row_maps_t* a, fcl_stream_t stream) {
+}  // extern "C"
+
+namespace fcl {
+// argument check of fcl_row_maps_build, shared with the BiLSTM launch that builds the maps in an extra workgroup (bilstm.hip);
+// *fusable: the one-workgroup counting-sort form applies (scratch given, lmax_cap below its value buckets)
+int row_maps_check(const fcl_row_maps_t* a, bool* fusable) {
     FCL_REQUIRE(a, FCL_ERR_INVALID, "row_maps_build: null argument");
     FCL_REQUIRE(a->b > 0 && a->n > 0 && a->lmax_cap > 0 && a->frames_cap > 0, FCL_ERR_SHAPE, "row_maps_build: bad sizes B=%d N=%d lmax_cap=%d frames_cap=%d",
                 a->b, a->n, a->lmax_cap, a->frames_cap);
@@ -718,9 +594,22 @@ int fcl_row_maps_build(const fcl_row_maps_t* a, fcl_stream_t stream) {
     FCL_REQUIRE(a->src_rows && a->dur_sorted && a->frame_off && a->live_rows && a->utt_frame0 && a->frame_lo && a->frame_hi &&
                     a->totals && a->status,
                 FCL_ERR_INVALID, "row_maps_build: null pointer");
-    hipStream_t s = (hipStream_t)stream;
     static const int fast_on = tunable("ROWMAPS_FAST", 1);
-    if (fast_on && a->scratch && a->lmax_cap < RMF_V - 1) {
+    if (fusable) *fusable = fast_on && a->scratch && a->lmax_cap < RMF_V - 1;
+    return 0;
+}
+}  // namespace fcl
+
+extern "C" {
+
+int fcl_row_maps_build(const fcl_row_maps_t* a, fcl_stream_t stream) {
+    bool fast = false;
+    {
+        const int rc = row_maps_check(a, &fast);
+        if (rc) return rc;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (fast) {
         hipLaunchKernelGGL(row_maps_fast_kernel, dim3(1), dim3(1024), 0, s, *a);
     } else {
         const int wg_rows = (a->n + 255) / 256, wg_live = (a->lmax_cap + 1 + 255) / 256, wg_utt = (a->b + 1 + 255) / 256;

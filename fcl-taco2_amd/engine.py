@@ -263,8 +263,9 @@ def prepare(plan, xs, durs=None, f0=None, energy=None, device_maps=False, spembs
     return p
 
 
-def encode(plan, prep, bilstm_algo=0, planes=False):
-    """H1-H3: embedding -> 3 x conv/BN/ReLU -> packed BiLSTM.  Returns hs [B*T, C] (planes: (hs, P32 planes of hs))."""
+def encode(plan, prep, bilstm_algo=0, planes=False, row_maps=None):
+    """H1-H3: embedding -> 3 x conv/BN/ReLU -> packed BiLSTM.  Returns hs [B*T, C] (planes: (hs, P32 planes of hs)).
+    row_maps (ops.RowMapsRequest): maps of FORCED durations, which depend on nothing the encoder computes: built inside the BiLSTM's launch."""
     bl = plan.blstm
     res = plan.hp.use_residual  # convs[i](xs) + xs (encoder_sa_kd.py:213-214): the residual rides in the conv's epilogue (after ReLU), fp32 kept for it
     if planes:  # every GEMM operand travels pre-split: embedding -> planes, conv -> planes, ..., BiLSTM -> fp32 + planes
@@ -272,11 +273,12 @@ def encode(plan, prep, bilstm_algo=0, planes=False):
         for cv in plan.enc_convs:
             x, xp = ops.conv1d_planes(xp, cv, prep.seg_lo, prep.seg_hi, ops.ACT_RELU, residual=x if res else None, want_f32=res)
         return ops.bilstm(None, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo,
-                          x_p=xp, w_ih_p=(bl["w_ih_p_f"], bl["w_ih_p_r"]), want_planes=True)
+                          x_p=xp, w_ih_p=(bl["w_ih_p_f"], bl["w_ih_p_r"]), want_planes=True, row_maps=row_maps)
     x = ops.embedding(prep.ids, plan.embed)
     for cv in plan.enc_convs:
         x = ops.conv1d(x, cv.wp, cv.bias, prep.seg_lo, prep.seg_hi, ops.ACT_RELU, residual=x if res else None)
-    return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo)
+    return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo,
+                      row_maps=row_maps)
 
 
 class _DevMaps(object):
@@ -300,11 +302,15 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
     with torch.cuda.device(dev):
         planes = use_planes(plan)
         hs_p = None
+        maps_req = None
+        if prep.maps is None and prep.dur_pad is not None and caps is not None:  # forced durations, device-built maps: nothing to wait for
+            maps_req = ops.row_maps_request(prep.B * prep.T, prep.B, caps.lmax, caps.frames, dur_i32=prep.dur_pad, t_max=prep.T, pad=prep.pad,
+                                            status=status)
         if planes:
-            hs, hs_p = encode(plan, prep, bilstm_algo, planes=True)
+            hs, hs_p = encode(plan, prep, bilstm_algo, planes=True, row_maps=maps_req)
             predictor = lambda pp, pad: _predictor_scalar_planes(pp, hs_p, prep.seg_lo, prep.seg_hi, pad)
         else:
-            hs = encode(plan, prep, bilstm_algo)
+            hs = encode(plan, prep, bilstm_algo, row_maps=maps_req)
             predictor = lambda pp, pad: _predictor_scalar(pp, hs, prep.seg_lo, prep.seg_hi, pad)
         inter = {"hs": hs, "T": prep.T} if return_intermediates else None
         if hp.spk_embed_dim is not None:  # hs <- cat[hs, F.normalize(spemb)]: predictors, embeddings and decoder see eunits + spk_embed_dim channels
@@ -328,8 +334,8 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
                 if inter is not None:
                     inter["d_log"], inter["d_int"] = d_log, d_int
             if caps is not None:  # device-built maps over the padded [B, T] row universe: no host round trip
-                dm = ops.row_maps_build(prep.B * prep.T, prep.B, caps.lmax, caps.frames, dur_i64=d_int, dur_i32=prep.dur_pad, t_max=prep.T, pad=prep.pad,
-                                        status=status)
+                dm = maps_req.maps if maps_req is not None else ops.row_maps_build(prep.B * prep.T, prep.B, caps.lmax, caps.frames, dur_i64=d_int,
+                                                                                   t_max=prep.T, pad=prep.pad, status=status)
                 rm = PreparedBatch()
                 rm.maps = _DevMaps(dm, caps)
                 rm.src_rows, rm.dur, rm.frame_off, rm.frame_lo, rm.frame_hi = dm["src_rows"], dm["dur"], dm["frame_off"], dm["frame_lo"], dm["frame_hi"]

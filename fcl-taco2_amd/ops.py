@@ -282,10 +282,10 @@ def check_status(device, reset=True):
         raise _lib.FclError("fcl-taco2_amd: device status 0x%x: %s" % (bits, status_message(bits)))
 
 
-def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0, status=None, x_p=None, w_ih_p=None, want_planes=False):
+def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0, status=None, x_p=None, w_ih_p=None, want_planes=False, row_maps=None):
     """status: device status word for algo 3 (default: the per-device word of status_word(); callers check it at their next sync point).
     x_p / w_ih_p = (forward, reverse): pre-split P32 operands of the input projection (x may then be None); want_planes: also return the
-    output as P32 planes."""
+    output as P32 planes.  row_maps: a RowMapsRequest (row_maps_request) whose maps this call also builds (fcl_hip.h fcl_bilstm_fwd)."""
     c, dev = w_ih_f.shape[1], w_ih_f.device
     h = w_hh_f.shape[1]
     lib = _lib.load()
@@ -296,7 +296,8 @@ def bilstm(x, lens_i32, w_ih_f, w_hh_f, b_f, w_ih_r, w_hh_r, b_r, b, t, algo=0, 
     wf_p, wr_p = w_ih_p if (x_p is not None and w_ih_p is not None) else (None, None)
     check(lib.fcl_bilstm_fwd(_p(x), _p(lens_i32, torch.int32), _p(w_ih_f), _p(w_hh_f), _p(b_f), _p(w_ih_r), _p(w_hh_r), _p(b_r), _p(out),
                              _p(outp, torch.int16), _p(x_p if wf_p is not None else None, torch.int16), _p(wf_p, torch.int16), _p(wr_p, torch.int16),
-                             b, t, c, h, algo, ws.data_ptr(), nbytes, _p(status if status is not None else status_word(dev), torch.int32), _stream()))
+                             b, t, c, h, algo, ws.data_ptr(), nbytes, _p(status if status is not None else status_word(dev), torch.int32),
+                             C.byref(row_maps.struct) if row_maps is not None else None, _stream()))
     return (out, outp) if want_planes else out
 
 
@@ -313,15 +314,28 @@ def u32_add(word_i32, v=1):
     check(_lib.load().fcl_u32_add(_p(word_i32, torch.int32), v, _stream()))
 
 
+class RowMapsRequest(object):
+    """Output tensors (`maps`: the dict row_maps_build returns) + the fcl_row_maps_t that describes them, for a later launch to fill."""
+    __slots__ = ("maps", "struct", "_keep")
+
+
 def row_maps_build(n, b, lmax_cap, frames_cap, dur_i64=None, dur_i32=None, row_src=None, utt_row0=None, t_max=0, pad=None, want_order=False,
                    status=None):
+    """Device-built maps, built now: see row_maps_request."""
+    req = row_maps_request(n, b, lmax_cap, frames_cap, dur_i64, dur_i32, row_src, utt_row0, t_max, pad, want_order, status)
+    check(_lib.load().fcl_row_maps_build(C.byref(req.struct), _stream()))
+    return req.maps
+
+
+def row_maps_request(n, b, lmax_cap, frames_cap, dur_i64=None, dur_i32=None, row_src=None, utt_row0=None, t_max=0, pad=None, want_order=False,
+                     status=None):
     """Device-built row / frame maps (include/fcl_hip.h fcl_row_maps_build; bit-identical to engine.build_row_maps on the real rows).
     Row universe: compact rows (row_src [N] / utt_row0 [B + 1] int32 device tensors that depend on the phoneme counts alone) or, with
     row_src=None, the padded [B, t_max] layout (n = B * t_max; `pad` marks the padding rows).  Durations: int64 (fcl_duration_round_fwd's
     output, read through row_src) or int32 per row.  Returns a dict of int32 device tensors: src_rows, dur, frame_off [n]; live_rows
     [lmax_cap + 1]; utt_frame0 [B + 1]; frame_lo / frame_hi [frames_cap]; totals [4] = (frames, max duration, zero-duration rows, 0); order [n] on
     request.  Violations (a zero duration, a duration > lmax_cap, more than frames_cap frames) set FCL_STATUS_* bits in the device status word
-    and zero live_rows."""
+    and zero live_rows.  Returns a RowMapsRequest: row_maps_build runs it at once, bilstm(row_maps=...) as part of the encoder's recurrence."""
     ref = dur_i64 if dur_i64 is not None else dur_i32
     dev = ref.device
     # one allocation for all the maps (a graph-private pool then holds one block; slices are 16-byte aligned)
@@ -342,8 +356,9 @@ def row_maps_build(n, b, lmax_cap, frames_cap, dur_i64=None, dur_i32=None, row_s
                      order=_p(out.get("order"), torch.int32), live_rows=_p(out["live_rows"], torch.int32), utt_frame0=_p(out["utt_frame0"], torch.int32),
                      frame_lo=_p(out["frame_lo"], torch.int32), frame_hi=_p(out["frame_hi"], torch.int32), totals=_p(out["totals"], torch.int32),
                      status=st.data_ptr(), scratch=_p(out["scratch"], torch.int32))
-    check(_lib.load().fcl_row_maps_build(C.byref(a), _stream()))
-    return out
+    req = RowMapsRequest()
+    req.maps, req.struct, req._keep = out, a, (blk, st, row_src, utt_row0, pad, dur_i64, dur_i32)
+    return req
 
 
 def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher_ys=None, dropout_mode=DROP_NONE,

@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 304
+#define FCL_ABI_VERSION 305
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -182,12 +182,17 @@ int fcl_gather_rows_fwd(const float* src, const int32_t* idx, float* dst, uint16
  * (FCL_STATUS_*): a group that times out reports there and its outputs are partial.  It is refused (per-step launches instead) when
  * 8*B workgroups do not fit the device one per CU.  status may be NULL for the other algorithms.
  * Optional P32 planes: out_p receives out as planes (for the predictor convolutions); x_p / w_ih_f_p / w_ih_r_p (all or none) are the
- * pre-split operands of the input projection, in which case x may be NULL. */
+ * pre-split operands of the input projection, in which case x may be NULL.
+ * row_maps (optional; fcl_row_maps_t is declared with fcl_row_maps_build below): also build the batch's row / frame maps, exactly as
+ * fcl_row_maps_build(row_maps, stream) would.  Forced durations are known before the encoder runs, so with the persistent recurrence at H = 128
+ * (the shipped encoders) the map build is one more workgroup of the recurrence's launch and leaves the pass's dependent chain; every other path
+ * issues fcl_row_maps_build's launches after the recurrence.  Same contract and status bits either way. */
+struct fcl_row_maps;
 size_t fcl_bilstm_workspace_bytes(int b, int t, int h);
 int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, const float* w_hh_f, const float* b_f,
                    const float* w_ih_r, const float* w_hh_r, const float* b_r, float* out, uint16_t* out_p, const uint16_t* x_p,
                    const uint16_t* w_ih_f_p, const uint16_t* w_ih_r_p, int b, int t, int c, int h,
-                   int algo, void* workspace, size_t workspace_bytes, uint32_t* status, fcl_stream_t stream);
+                   int algo, void* workspace, size_t workspace_bytes, uint32_t* status, const struct fcl_row_maps* row_maps, fcl_stream_t stream);
 
 /* ---- H7 as a single step: one LSTMCell (+ zoneout) update of M rows — the building block of the decoder loop, of the per-step
  *      BiLSTM, and of the TRAINING forward, which also saves what the backward pass needs (decoder_sa.py:63-96, 500-504) ------ */
@@ -318,8 +323,8 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
  *        frame_lo / frame_hi [frames_cap]         : utterance frame range of every frame row (0, 0 beyond the total): the postnet's segment bounds
  *        totals[0] = total frames, totals[1] = max duration, totals[2] = zero-duration rows
  *      Violations are reported in *status (FCL_STATUS_ZERO_DURATION / LMAX_CAP / FRAMES_CAP) and live_rows is then zeroed, so a decoder loop
- *      driven by these maps does nothing instead of writing out of bounds.  Two launches. */
-typedef struct {
+ *      driven by these maps does nothing instead of writing out of bounds.  Two launches (none of its own through fcl_bilstm_fwd's row_maps). */
+typedef struct fcl_row_maps {
     int b, n;                   /* utterances; rows of the row universe (see row_src) */
     int lmax_cap, frames_cap;
     int t_max;                  /* with utt_row0 == NULL: utterance b owns rows [b * t_max, (b + 1) * t_max) */

@@ -94,6 +94,41 @@ def test_device_row_maps_report_violations_and_decode_nothing():
         assert status == 0 and d["live_rows"][0] == 7 and d["totals"][0] == 18
 
 
+def test_row_maps_built_inside_the_bilstm_launch_equal_the_standalone_builder():
+    """fcl_bilstm_fwd(row_maps=...): H = 128 builds the maps in one extra workgroup of the persistent recurrence, every other width with the
+    builder's own launches after it: identical tensors and status bits, and the recurrence's output is unchanged."""
+    from fcl_taco2_amd import _lib, ops
+
+    rng = np.random.RandomState(5)
+    for h, c, lens, hi in [(128, 64, [37, 30, 9, 1], 12), (128, 32, sorted(rng.randint(1, 120, size=33).tolist(), reverse=True), 40),
+                           (64, 32, [21, 20, 3], 6), (128, 32, [5, 4], 0)]:
+        B, T = len(lens), max(lens)
+        dpad = np.zeros((B, T), dtype=np.int32)
+        pad = np.ones((B, T), dtype=np.uint8)
+        for b, n in enumerate(lens):
+            dpad[b, :n] = rng.randint(1, hi + 1, size=n) if hi else 0  # hi = 0: every duration zero (the reference's AssertionError)
+            pad[b, :n] = 0
+        lmax, frames = int(max(dpad.max(), 1)) + 3, int(dpad.sum()) + 50
+        g = torch.Generator().manual_seed(h + B)
+        w = [(0.2 * torch.randn(sh, generator=g)).to(DEV) for sh in [(4 * h, c), (4 * h, h), (4 * h,), (4 * h, c), (4 * h, h), (4 * h,)]]
+        x = torch.randn(B * T, c, generator=g).to(DEV)
+        lens_dev = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        d_dev, pad_dev = torch.from_numpy(dpad.reshape(-1)).to(DEV), torch.from_numpy(pad.reshape(-1)).to(DEV)
+        st_a, st_b = (torch.zeros(1, dtype=torch.int32, device=DEV) for _ in range(2))
+        alone = ops.row_maps_build(B * T, B, lmax, frames, dur_i32=d_dev, t_max=T, pad=pad_dev, want_order=True, status=st_a)
+        req = ops.row_maps_request(B * T, B, lmax, frames, dur_i32=d_dev, t_max=T, pad=pad_dev, want_order=True, status=st_b)
+        for v in req.maps.values():
+            v.fill_(-7)
+        out = ops.bilstm(x, lens_dev, *w, B, T, row_maps=req)
+        ref = ops.bilstm(x, lens_dev, *w, B, T)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+        assert int(st_a.item()) == int(st_b.item()) == (0 if hi else _lib.STATUS_ZERO_DURATION)
+        for k in alone:
+            if k != "scratch":
+                assert torch.equal(alone[k], req.maps[k]), (h, k)
+
+
 def _plan(hp, sd=None):
     from fcl_taco2_amd.plan import SynthesisPlan
 
