@@ -12,6 +12,12 @@ rocprofv3 --kernel-trace --stats -d $OUT/fresh4 -o g --output-format csv -- pyth
 stats $OUT/fresh4 $OUT/fresh_4streams_kernel_stats.csv; rm -rf $OUT/fresh4
 rocprofv3 --kernel-trace --stats -d $OUT/eager1 -o e --output-format csv -- python3 bench.py --streams 1 --eager --feed replay --no-cpu-baseline --no-extras --regions 3 > $OUT/eager1_bench.json 2>/dev/null
 stats $OUT/eager1 $OUT/eager_1stream_kernel_stats.csv; rm -rf $OUT/eager1
+# one stream: the capacity graph (fresh feed) against the baked graph of one prepared batch, and the host cost of the feed
+rocprofv3 --kernel-trace --stats -d $OUT/cap1 -o c --output-format csv -- python3 bench.py --streams 1 --no-cpu-baseline --no-extras --regions 3 > $OUT/cap1_bench.json 2>/dev/null
+stats $OUT/cap1 $OUT/capacity_graph_1stream_kernel_stats.csv; rm -rf $OUT/cap1
+rocprofv3 --kernel-trace --stats -d $OUT/bak1 -o b --output-format csv -- python3 bench.py --streams 1 --feed replay --no-cpu-baseline --no-extras --regions 3 > $OUT/bak1_bench.json 2>/dev/null
+stats $OUT/bak1 $OUT/baked_graph_1stream_kernel_stats.csv; rm -rf $OUT/bak1
+python3 tools/feed_cost.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/feed_cost.log
 E1="python3 bench.py --streams 1 --eager --feed replay --no-cpu-baseline --no-extras --steps 6 --warmup 2 --regions 1"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- $E1 > /dev/null 2>&1
 pmc $OUT/pmc_fetch $OUT/pmc_fetch_size.csv pmc_summary.py
