@@ -120,10 +120,13 @@ def run_child(extra_args, env_extra, timeout):
     return {"error": "rc %d: %s" % (r.returncode, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "no output")}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, workload=""):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC summaries (profiles/*pmc_fetch_size.csv and
     *pmc_write_size.csv, separate --pmc passes of this same command): 2 x FETCH_SIZE (gfx950 counts 128-B requests as 64 B,
-    MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes.  None when no profile of that kernel is committed."""
+    MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes.  None when no profile of that kernel is committed.
+    workload: "" = the synthesis profile (rN_pmc_fetch_size.csv), else the tag of the workload's pair (rN_pmc_<workload>_fetch_size.csv); the
+    latest round's pair that holds the kernel is the one used."""
+    import re
     import csv
     import glob
 
@@ -148,10 +151,13 @@ def pmc_traffic(kernel):
         n = min(len(xa), len(xb))
         return xa[:n] == xb[:n]
 
-    # per-workload summary pairs (..._pmc_fetch_size.csv / ..._pmc_write_size.csv, ..._pmc_vocoder_fetch_size.csv / ...): the pair in which the kernel
-    # has the most launches is the run that was profiled for it
+    # per-workload summary pairs (rN_pmc_fetch_size.csv / rN_pmc_write_size.csv, rN_pmc_vocoder_fetch_size.csv / ...): this workload's pair of the
+    # latest round that holds the kernel
     best = None
-    for fpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_*fetch_size.csv"))):
+    want = "pmc_%s_fetch_size.csv" % workload if workload else "pmc_fetch_size.csv"
+    paths = [p for p in glob.glob(os.path.join(ROOT, "profiles", "*pmc_*fetch_size.csv")) if os.path.basename(p).split("_", 1)[-1] == want]
+    rnd = lambda p: int((re.match(r"r(\d+)_", os.path.basename(p)) or [0, 0])[1])
+    for fpath in sorted(paths, key=rnd):
         wpath = fpath[: -len("fetch_size.csv")] + "write_size.csv"
         if not os.path.exists(wpath):
             continue
@@ -164,7 +170,7 @@ def pmc_traffic(kernel):
             if hits:
                 n = sum(h[0] for h in hits)
                 pair[tag] = (sum(h[0] * h[1] for h in hits) / n, os.path.basename(path), n)
-        if len(pair) == 2 and (best is None or pair["fetch"][2] >= best["fetch"][2]):
+        if len(pair) == 2:
             best = pair
     vals = best or {}
     if len(vals) != 2:
@@ -245,7 +251,7 @@ def e2e_workload(args, rank, world, dev, dist):
         aux_b = 128 if V.aux_frame_rate(gen.plan) else 384
         bytes_per_launch = (1024.0 + aux_b) * samples
         achieved = bytes_per_launch * d["launches"] / (d["ms"] * 1e-3) / 1e9
-        traffic, src = pmc_traffic(dom)
+        traffic, src = pmc_traffic(dom, "vocoder")
         out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "traffic_source": src, "avg_launch_us": 1e3 * d["ms"] / d["launches"], "launches_per_step": d["launches"],
                            "bytes_per_launch": bytes_per_launch, "share_of_kernel_time": d["ms"] / sum(v["ms"] for v in prof.values()),
@@ -411,7 +417,7 @@ def train_workload(args, rank, world, dev, dist):
             dname = max(gemm_fams, key=lambda k: gemm_fams[k]["ms"])
             d = gemm_fams[dname]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic, tsrc = pmc_traffic(dname)
+            traffic, tsrc = pmc_traffic(dname, args.workload)
             dom_roof = {"bound": "mfma", "kernel": dname, "instantiations": sorted(d["members"]), "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                         "launches_per_step": d["launches"], "flops_per_launch": d["flops"] / d["launches"],
