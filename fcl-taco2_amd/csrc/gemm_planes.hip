@@ -928,9 +928,11 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     // workgroups' worth of every CU slows that path more than it gains (12.20 vs 11.98 ms)
     static const int two_stage_min = tunable("PLSTM_2STAGE_MIN_WG", 300);  // (150 = wherever the 128-row tile is chosen: B = 32 with four passes in flight +2 % -- workgroups of different streams share a CU --, but the step ALONE is 8 % slower without its pre-loop operand requests: 111 vs 120 TFLOP/s)
     if (force == 7 || (force == 0 && t128 >= two_stage_min && !a.zone_keep_h && !a.save_gates)) return launch_plstm_cfg<4, 2, 2, 2>(a, s, flops);
-    // narrow synthesis steps (U <= 256, no training-side outputs: FCL-taco2-S inference) have their own pair of thresholds
-    static const int big_min_t = tunable("PLSTM_BIG_MIN", 150), big_min_s = tunable("PLSTM_BIG_MIN_S", 150);
-    static const int mid_min_t = tunable("PLSTM_MID_MIN", 200), mid_min_s = tunable("PLSTM_MID_MIN_S", 200);
+    // narrow synthesis steps (U <= 256, no training-side outputs: FCL-taco2-S inference) have their own pair of thresholds: 64-row tiles (two
+    // workgroups per CU, also of different passes) up to 300 128-row tiles -- same-box A/B, three rounds, (150, 200) vs (300, 80): replayed pass
+    // 47.5 -> 48.6 M frames/s, fresh feed 39.4 -> 39.8 M; the wide / training steps keep the 128-row tiles (-22 % on FCL-taco2-T synthesis otherwise)
+    static const int big_min_t = tunable("PLSTM_BIG_MIN", 150), big_min_s = tunable("PLSTM_BIG_MIN_S", 300);
+    static const int mid_min_t = tunable("PLSTM_MID_MIN", 200), mid_min_s = tunable("PLSTM_MID_MIN_S", 80);
     const bool narrow = a.U <= 256 && !a.zone_keep_h && !a.save_gates;
     const int big_min = narrow ? big_min_s : big_min_t, mid_min = narrow ? mid_min_s : mid_min_t;
     if (force == 1 || (force == 0 && t128 >= big_min)) return launch_plstm_cfg<4, 2, 2, 3>(a, s, flops);
