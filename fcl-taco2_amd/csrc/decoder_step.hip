@@ -1014,8 +1014,9 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
         static const int fast = tunable("FEAT_PRENET_FAST", 1);
         if (fast && a.U == 256 && a.O > 64 && a.O <= 96 && a.P == 256) {
             // RT row tiles per workgroup share one fetch of the weight fragments (see the kernel); few rows keep one tile per workgroup (latency)
+            // (four tiles would need 164 KB of LDS: two is the most a workgroup can carry)
             static const int rt_max = tunable("FP_ROW_TILES", 2), rt_m = tunable("FP_ROW_TILES_M", 512);
-            const int rt = (rt_max >= 4 && rows >= 2 * rt_m) ? 4 : (rt_max >= 2 && rows >= rt_m) ? 2 : 1;
+            const int rt = (rt_max >= 2 && rows >= rt_m) ? 2 : 1;
             const dim3 b(512);
 #define FCL_FP_LAUNCH(RT_)                                                                                                               \
     do {                                                                                                                                 \
@@ -1030,8 +1031,7 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
         else if (a.drop_mode == 2) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 2, RT_>), g, b, lds_rt, s, a);                   \
         else hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 0, RT_>), g, b, lds_rt, s, a);                                         \
     } while (0)
-            if (rt == 4) FCL_FP_LAUNCH(4);
-            else if (rt == 2) FCL_FP_LAUNCH(2);
+            if (rt == 2) FCL_FP_LAUNCH(2);
             else FCL_FP_LAUNCH(1);
 #undef FCL_FP_LAUNCH
         } else if (a.U == 256 && a.O == 80 && a.P == 256) {
