@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 305  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 306  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -142,6 +142,7 @@ SIGNATURES = {
     "fcl_gemm_tn_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "fcl_gemm_tn_taps_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _Z, _P, _P, _P]),
     "fcl_colsum_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fcl_colsum2_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fcl_conv1d_in1_dw": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "fcl_act_fwd": (_I, [_P, _P, _F, _P, _P, _I, _Z, _I, _P]),
     "fcl_unpack_conv1d_grad": (_I, [_P, _P, _P, _I, _I, _I, _P]),
@@ -152,7 +153,7 @@ SIGNATURES = {
     "fcl_bn_stats_fwd": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "fcl_bn_stats_ws_fwd": (_I, [_P, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
     "fcl_bn_act_fwd": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P]),
-    "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "fcl_scale": (_I, [_P, _Z, _F, _P]),
     "fcl_bernoulli_u8": (_I, [_P, _Z, _F, C.c_uint32, _P, _P]),
     "fcl_bernoulli_batch": (_I, [C.POINTER(BernoulliSite), _I, _P]),

@@ -184,16 +184,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 
 // ---- bias / BatchNorm-affine gradients: column sums over rows --------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
-                                                     const float* __restrict__ b, float* __restrict__ out, int M, int C, int mode, int rows_per_block) {
+                                                     const float* __restrict__ b, float* __restrict__ out, int M, int C, int mode, int rows_per_block,
+                                                     float* __restrict__ out_x) {
     // fp64 accumulation (the kernel is HBM-bound either way): these sums are the dbeta / dgamma that train-mode BatchNorm's backward SUBTRACTS from
     // dy, i.e. operands of a cancellation; 7e-8 instead of 3e-7 relative at 1 600 rows.
     // 64 columns x rows_per_block rows per block; a wave reads 64 consecutive columns of one row (256-byte coalesced) and keeps EIGHT rows in
     // flight per thread: with one load per iteration the kernel ran at the latency of its row loop (r3 trace: 55 us for 16 MB).
-    __shared__ double part[4][64];
+    // out_x (optional): the plain column sums of x from the same pass (train-mode BatchNorm: dbeta beside dgamma, dy read once)
+    __shared__ double part[4][64], part_x[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
     const int m_lo = blockIdx.y * rows_per_block, m_hi = min(M, m_lo + rows_per_block);
-    double s = 0.0;
+    double s = 0.0, sx = 0.0;
     if (c < C) {
         const float bc = mode >= 2 ? b[c] : 0.f, gc = mode == 2 ? 1.0f / g[c] : (mode == 3 ? g[c] : 1.f);
         for (int m = m_lo + ty; m < m_hi; m += 32) {
@@ -209,13 +211,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
                 float t = v[j];
                 if (mode == 1) t *= w[j];
                 else if (mode >= 2) t *= (w[j] - bc) * gc;
-                if (m + 4 * j < m_hi) s += (double)t;
+                if (m + 4 * j < m_hi) {
+                    s += (double)t;
+                    sx += (double)v[j];
+                }
             }
         }
     }
     part[ty][tx] = s;
+    part_x[ty][tx] = sx;
     __syncthreads();
-    if (ty == 0 && c < C) atomicAdd(out + c, (float)((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
+    if (ty == 0 && c < C) {
+        atomicAdd(out + c, (float)((part[0][tx] + part[1][tx]) + (part[2][tx] + part[3][tx])));
+        if (out_x) atomicAdd(out_x + c, (float)((part_x[0][tx] + part_x[1][tx]) + (part_x[2][tx] + part_x[3][tx])));
+    }
 }
 
 // ---- weight / bias gradients of a Conv1d with ONE input channel (the pitch / energy embeddings, ..._sa.py:435-443: Conv1d(1 -> C, k = 9)):
@@ -599,7 +608,14 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __re
 // dz = gamma * invstd * (dy - dbeta/M - zhat * dgamma/M), dbeta = sum dy, dgamma = sum dy*zhat (this batch's sums)
 __global__ void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
                               const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float* __restrict__ dz,
-                              long long total, int C, float inv_m, unsigned short* __restrict__ dzp) {
+                              long long total, int C, float inv_m, unsigned short* __restrict__ dzp, float* __restrict__ acc_dbeta,
+                              float* __restrict__ acc_dgamma) {
+    if (acc_dbeta && blockIdx.x == 0) {  // this batch's affine gradients join the accumulated ones (g += d: what the two fcl_add2d launches did)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            acc_dbeta[c] += dbeta[c];
+            acc_dgamma[c] += dgamma[c];
+        }
+    }
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const float zh = (z[i] - mean[c]) * invstd[c];
@@ -751,13 +767,18 @@ int fcl_gemm_tn_fwd(const float* a, int lda, const float* b, int ldb, float* c, 
     return fcl_gemm_tn_taps_fwd(a, lda, b, ldb, c, ldc, m, n, k, shift, 1, 0, seg_lo, seg_hi, stream);
 }
 
+int fcl_colsum2_fwd(const float* x, const float* y, const float* g, const float* b, float* out, float* out_x, int m, int c, int mode, fcl_stream_t stream);
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream) {
+    return fcl_colsum2_fwd(x, y, g, b, out, nullptr, m, c, mode, stream);
+}
+
+int fcl_colsum2_fwd(const float* x, const float* y, const float* g, const float* b, float* out, float* out_x, int m, int c, int mode, fcl_stream_t stream) {
     FCL_REQUIRE(x && out && m >= 0 && c > 0 && mode >= 0 && mode <= 3, FCL_ERR_INVALID, "colsum_fwd: bad arguments");
     FCL_REQUIRE(mode == 0 || y, FCL_ERR_INVALID, "colsum_fwd: mode needs y");
     FCL_REQUIRE(mode < 2 || (g && b), FCL_ERR_INVALID, "colsum_fwd: modes 2 and 3 need g and b");
     if (m == 0) return 0;
     const int rpb = m >= 8192 ? 128 : 64;
-    hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, y, g, b, out, m, c, mode, rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64, (m + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, x, y, g, b, out, m, c, mode, rpb, out_x);
     return check_hip(hipGetLastError(), "colsum_fwd");
 }
 
@@ -891,11 +912,12 @@ int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const
 }
 
 int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
-               float* dz, uint16_t* dzp, int m, int c, fcl_stream_t stream) {
+               float* dz, uint16_t* dzp, int m, int c, float* acc_dbeta, float* acc_dgamma, fcl_stream_t stream) {
     FCL_REQUIRE(dy && z && mean && invstd && gamma && dbeta && dgamma && dz && m > 0 && c > 0, FCL_ERR_INVALID, "bn_bwd: bad arguments");
+    FCL_REQUIRE((acc_dbeta == nullptr) == (acc_dgamma == nullptr), FCL_ERR_INVALID, "bn_bwd: acc_dbeta / acc_dgamma come in pairs");
     FCL_REQUIRE(!dzp || ((c & 31) == 0 && (reinterpret_cast<uintptr_t>(dzp) & 127u) == 0), FCL_ERR_SHAPE, "bn_bwd: planes need C %% 32 == 0, 128-byte aligned");
     hipLaunchKernelGGL(bn_bwd_kernel, dim3(grid1d((long long)m * c, 256)), dim3(256), 0, (hipStream_t)stream, dy, z, mean, invstd, gamma, dbeta, dgamma, dz,
-                       (long long)m * c, c, 1.0f / (float)m, dzp);
+                       (long long)m * c, c, 1.0f / (float)m, dzp, acc_dbeta, acc_dgamma);
     return check_hip(hipGetLastError(), "bn_bwd");
 }
 

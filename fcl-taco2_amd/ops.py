@@ -464,9 +464,10 @@ def l1_mse_loss_grad(a, b, row_valid, count, w_l1, w_mse, sums_f64, da=None, b_l
     return (da, dap) if want_planes else da
 
 
-def colsum(x, out, y=None, gamma=None, beta=None, mode=0):
+def colsum(x, out, y=None, gamma=None, beta=None, mode=0, out_x=None):
+    """out_x: also the plain column sums of x, from the same pass."""
     m, c = x.shape
-    check(_lib.load().fcl_colsum_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(out), m, c, mode, _stream()))
+    check(_lib.load().fcl_colsum2_fwd(_p(x), _p(y), _p(gamma), _p(beta), _p(out), _p(out_x), m, c, mode, _stream()))
     return out
 
 
@@ -537,11 +538,13 @@ def bn_act(z, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0, want_pl
     return res + (yp,) if want_planes else res
 
 
-def bn_bwd(dy, z, mean, invstd, gamma, dbeta, dgamma, want_planes=False):
+def bn_bwd(dy, z, mean, invstd, gamma, dbeta, dgamma, want_planes=False, acc=None):
+    """acc = (g_beta, g_gamma): the parameters' gradient accumulators, += this batch's dbeta / dgamma in the same launch."""
     m, c = z.shape
     dz = torch.empty_like(z)
     dzp = planes_empty(m, c, z.device) if want_planes else None
-    check(_lib.load().fcl_bn_bwd(_p(dy), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), _p(dzp, torch.int16), m, c, _stream()))
+    check(_lib.load().fcl_bn_bwd(_p(dy), _p(z), _p(mean), _p(invstd), _p(gamma), _p(dbeta), _p(dgamma), _p(dz), _p(dzp, torch.int16), m, c,
+                                  _p(acc[0]) if acc else None, _p(acc[1]) if acc else None, _stream()))
     return (dz, dzp) if want_planes else dz
 
 

@@ -594,11 +594,9 @@ class TrainEngine(object):
             dz = dy
         if c.train:
             dbeta, dgamma = self._z((cout,)), self._z((cout,))
-            ops.colsum(dz, dbeta)
-            ops.colsum(dz, dgamma, y=cc["z"], gamma=cc["invstd"], beta=cc["mean"], mode=3)
-            ops.add2d(G[pre + ".1.bias"].reshape(1, -1), dbeta.reshape(1, -1))
-            ops.add2d(G[pre + ".1.weight"].reshape(1, -1), dgamma.reshape(1, -1))
-            r = ops.bn_bwd(dz, cc["z"], cc["mean"], cc["invstd"], P[pre + ".1.weight"], dbeta, dgamma, want_planes=pl)
+            ops.colsum(dz, dgamma, y=cc["z"], gamma=cc["invstd"], beta=cc["mean"], mode=3, out_x=dbeta)  # both sums from one pass over dz
+            r = ops.bn_bwd(dz, cc["z"], cc["mean"], cc["invstd"], P[pre + ".1.weight"], dbeta, dgamma, want_planes=pl,
+                           acc=(G[pre + ".1.bias"], G[pre + ".1.weight"]))  # ... and G += (dbeta, dgamma) in the same launch: 5 -> 2 launches per layer
             dz, dzp = r if pl else (r, None)
             scale = None
         else:
@@ -608,8 +606,7 @@ class TrainEngine(object):
 
         def dw(dz=dz, scale=scale, eval_affine=not c.train):
             if eval_affine:
-                ops.colsum(dz, G[pre + ".1.bias"])
-                ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2)
+                ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2, out_x=G[pre + ".1.bias"])
             dwp = self._z((k, cout, cin))
             self._dw_gemm(dz, [(cc["x"], dwp)], taps=(k, cc["lo"], cc["hi"]))
             ops.unpack_conv1d_grad(dwp, G[pre + ".0.weight"], scale)
@@ -728,10 +725,8 @@ class TrainEngine(object):
             def dw(dg2=dg2, dgx=dgx, d=d, sfx=sfx):
                 ops.gemm_tn(dg2, c["dirs"][d][3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
                 ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
-                db = self._z((1, 4 * H))
-                ops.colsum(dgx, db.reshape(-1))
-                ops.add2d(G["enc.blstm.bias_ih_l0" + sfx].reshape(1, -1), db)
-                ops.add2d(G["enc.blstm.bias_hh_l0" + sfx].reshape(1, -1), db)
+                # bias_ih and bias_hh enter the gates as a sum: the same column sums, straight into both accumulators (one launch)
+                ops.colsum(dgx, G["enc.blstm.bias_ih_l0" + sfx], out_x=G["enc.blstm.bias_hh_l0" + sfx])
 
             self._dw(dw)
             ops.add2d(dx, ops.linear(dgx, self._wt(P["enc.blstm.weight_ih_l0" + sfx])))
@@ -1077,10 +1072,7 @@ class TrainEngine(object):
         def dw_cells():  # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
             self._dw_gemm(dg1_all, [(c.h0_all, G["dec.lstm.1.cell.weight_ih"]), (S1[3], G["dec.lstm.1.cell.weight_hh"])])
             for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
-                db = self._z((1, 4 * U))
-                ops.colsum(dg, db.reshape(-1))
-                ops.add2d(G["dec.lstm.%d.cell.bias_ih" % l].reshape(1, -1), db)
-                ops.add2d(G["dec.lstm.%d.cell.bias_hh" % l].reshape(1, -1), db)
+                ops.colsum(dg, G["dec.lstm.%d.cell.bias_ih" % l], out_x=G["dec.lstm.%d.cell.bias_hh" % l])
             self._dw_gemm(dg0_all, [(S0[3], G["dec.lstm.0.cell.weight_hh"]), (c.p1d, g_ih0[:, C : C + Pn])])
             dw0_pos4 = self._z((4 * U, 4))
             ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)

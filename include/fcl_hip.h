@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 305
+#define FCL_ABI_VERSION 306
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -388,6 +388,8 @@ int fcl_gemm_tn_planes(const uint16_t* ap_t, const uint16_t* bp_t, float* c, int
 /* out[c] += sum_m x[m,c] (mode 0) | x*y (mode 1) | x*(y - b[c])/g[c] (mode 2: gamma gradient of a folded eval BatchNorm)
  * | x*(y - b[c])*g[c] (mode 3: b = batch mean, g = invstd: gamma gradient of a train-mode BatchNorm). */
 int fcl_colsum_fwd(const float* x, const float* y, const float* g, const float* b, float* out, int m, int c, int mode, fcl_stream_t stream);
+/* the same pass with a second output: out_x[c] += sum_m x[m,c] (optional) -- train-mode BatchNorm's dbeta beside its dgamma (mode 3), dy read once */
+int fcl_colsum2_fwd(const float* x, const float* y, const float* g, const float* b, float* out, float* out_x, int m, int c, int mode, fcl_stream_t stream);
 /* Weight / bias gradients of a Conv1d with ONE input channel and odd k <= 16 (the pitch / energy embeddings, ..._sa.py:435-443,
  * ..._kd_student.py:570-596): dw[c, j] += sum_m dy[m, c] * x[m + j - (k-1)/2] over the positions inside row m's utterance [seg_lo[m], seg_hi[m])
  * (null: [0, m)), db[c] += sum_m dy[m, c] (db may be null).  dw is the [C, 1, k] weight gradient, contiguous. */
@@ -429,7 +431,9 @@ int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const
                    float* y_act, float* y_drop, uint16_t* yp /* optional P32 planes of the block output (after dropout), C % 32 == 0 */, int m, int c, int act,
                    fcl_stream_t stream);
 int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* invstd, const float* gamma, const float* dbeta, const float* dgamma,
-               float* dz, uint16_t* dzp /* optional P32 planes of dz, C % 32 == 0 */, int m, int c, fcl_stream_t stream);
+               float* dz, uint16_t* dzp /* optional P32 planes of dz, C % 32 == 0 */, int m, int c,
+               float* acc_dbeta, float* acc_dgamma /* optional pair: acc += this batch's dbeta / dgamma (the parameters' gradient accumulators) */,
+               fcl_stream_t stream);
 /* ---- the training step's time loops, enqueued by ONE call each (H13; decoder_sa.py:472-515, encoder_sa.py:143-146) ----------------------------
  * Cells are step-major: rows sorted by duration descending, cell (t, m) at offset(t) + m with offset(t) = sum_{t' < t} live_rows[t'].
  * s0 / s1 (decoder layers) and s (BiLSTM direction) are the saved tensors {gates [.,4U], c_new, c_old, h_old [.,U]} fcl_lstm_cell_bwd needs. */
