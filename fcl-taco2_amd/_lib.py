@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 306  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 307  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -132,6 +132,8 @@ SIGNATURES = {
     "fcl_position_table_fwd": (_I, [_P, _P, _I, _I, _P]),
     "fcl_concat_spk_fwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "fcl_kaldi_ark_append": (C.c_longlong, [_I, C.c_longlong, _I, _P, _P, _P, _I, _P]),
+    "fcl_host_device_ptr": (_P, [_P]),
+    "fcl_feed_copy": (_I, [_P, _P, _Z, _P, _P, _P, _P]),
     "fcl_row_maps_build": (_I, [C.POINTER(RowMaps), _P]),
     "fcl_gather_rows_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "fcl_bilstm_workspace_bytes": (_Z, [_I, _I, _I]),

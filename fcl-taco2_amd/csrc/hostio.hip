@@ -1,4 +1,5 @@
-// hostio.hip — host-side output of the decode driver: Kaldi ark records of a whole batch in ONE call (no device code).
+// hostio.hip — the host's two ends of a synthesis pass: the input feed of a capacity graph (a graph node that pulls the packed batch out of pinned
+// host memory) and the decode driver's output, Kaldi ark records of a whole batch in ONE call.
 // The reference hands every mel to kaldiio's WriteHelper("ark,scp:...") one utterance at a time (tts.py:652,674); at 36 M frames/s the Python
 // side of that (3 writes + a copy per utterance, ~12 us) was the decode driver's bound (20 M frames/s end to end).  Here the records of a batch
 // are gathered with writev straight from the pinned landing buffer: one system call per <= 512 utterances, no intermediate copy.
@@ -14,7 +15,47 @@
 
 using namespace fcl;
 
+namespace fcl {
+
+// The input block of a capacity graph (ids, segment bounds, durations, lengths, pad mask, speaker vectors: ~70 KB) comes out of PINNED host memory
+// by a kernel that is the graph's first node, instead of a hipMemcpyAsync in front of every launch: the runtime's copy call costs the host ~80 us
+// per pass (measured: as much as enqueueing the 90-node graph), the kernel costs nothing beside the graph launch and ~5 us of one workgroup on
+// the GPU (the reads cross PCIe once; fine-grained host memory is uncached on the device, so every pass sees what the host packed).  When every
+// read has returned the kernel publishes a sequence number in host memory: the host packs the next batch into the same block once it sees the
+// number of its last launch.
+__global__ __launch_bounds__(1024) void feed_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16, unsigned int* seq_dev,
+                                                         unsigned int* seq_host, unsigned int* bump) {
+    for (int i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    __syncthreads();  // a thread issues its stores with the loaded data: past this barrier every read of the host block has returned
+    if (threadIdx.x == 0) {
+        const unsigned int s = *seq_dev + 1;
+        *seq_dev = s;
+        if (bump) *bump += 1;
+        __hip_atomic_store(seq_host, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace fcl
+
 extern "C" {
+
+void* fcl_host_device_ptr(void* pinned_host) {
+    void* p = nullptr;
+    if (!pinned_host || hipHostGetDevicePointer(&p, pinned_host, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("host_device_ptr: not pinned, mapped host memory");
+        return nullptr;
+    }
+    return p;
+}
+
+int fcl_feed_copy(void* dst, const void* src, size_t bytes, uint32_t* seq_dev, uint32_t* seq_host, uint32_t* bump, fcl_stream_t stream) {
+    FCL_REQUIRE(dst && src && seq_dev && seq_host && bytes > 0 && (bytes & 15) == 0 && bytes <= (1u << 26), FCL_ERR_INVALID, "feed_copy: bad arguments");
+    FCL_REQUIRE(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) == 0, FCL_ERR_ALIGN, "feed_copy: 16-byte alignment required");
+    hipLaunchKernelGGL(feed_copy_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, reinterpret_cast<uint4*>(dst), reinterpret_cast<const uint4*>(src),
+                       (int)(bytes / 16), seq_dev, seq_host, bump);
+    return check_hip(hipGetLastError(), "feed_copy");
+}
 
 // Record layout (Kaldi binary FloatMatrix): <key> ' ' '\0' 'B' 'F' 'M' ' ' '\4' <int32 rows> '\4' <int32 cols> <rows*cols float32>.
 // offsets[i] (scp): byte offset of utterance i's '\0B' marker in the file, given that the first byte written lands at file_pos.

@@ -10,6 +10,9 @@ Host work here is integer index bookkeeping only (numpy): segment bounds, the ex
 places phoneme p's frames in its utterance (H10), and the duration sort that makes the live decoder rows
 a shrinking prefix (SURVEY.md §7 "ragged work").  All arithmetic on activations is in libfcl_hip.so.
 """
+import os
+import time
+
 import numpy as np
 import torch
 
@@ -481,9 +484,16 @@ class BatchRunner(object):
             self._off[name] = (off, nbytes)
             off += (nbytes + 15) // 16 * 16
         self._nbytes = off
-        self._host = [torch.zeros(off, dtype=torch.uint8).pin_memory() for _ in range(depth)]
-        self._host_ev = [None] * depth
+        # the feed: by default the graph's FIRST NODE pulls the packed block out of pinned host memory (ops.feed_copy: no copy call per pass, the
+        # host waits for the sequence number of its last launch before it repacks the block); FCL_FEED_INGRAPH=0 = one hipMemcpyAsync per pass
+        # out of `depth` rotating staging buffers in front of the launch (the form of the first half of round 3)
+        self._ingraph = os.environ.get("FCL_FEED_INGRAPH", "1") not in ("", "0")
+        self._host = [torch.zeros(off, dtype=torch.uint8).pin_memory() for _ in range(1 if self._ingraph else depth)]
+        self._host_ev = [None] * len(self._host)
         self._slot = 0
+        self._launched = 0
+        self._seq_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._seq_np = self._seq_host.numpy()
         rows = np.arange(n, dtype=np.int32)
         self._rows = (rows // self.T, rows - (rows // self.T) * self.T, ((rows // self.T) * self.T).astype(np.int32))
         with torch.cuda.device(dev):
@@ -499,10 +509,16 @@ class BatchRunner(object):
             self.prep = p
             self.seed_word = torch.zeros(1, dtype=torch.int32, device=dev)
             self.status = torch.zeros(1, dtype=torch.int32, device=dev)  # this runner's own status word (violations are attributed to ITS batches)
+            self._seq_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            if self._ingraph:
+                self._src_dev, self._seq_host_dev = ops.host_device_ptr(self._host[0]), ops.host_device_ptr(self._seq_host)
+            self.stream.wait_stream(torch.cuda.current_stream(dev))  # the zero fills above ran on the caller's stream
             # warm-up on a minimal valid batch (one phoneme of duration 1 per utterance), then capture
             self.load([np.ones(1, dtype=np.int64)] * self.B, [np.ones(1, dtype=np.int64)] * self.B if self.forced else None,
                       [np.ones(self.S, dtype=np.float32)] * self.B if self.S else None)
             with torch.cuda.stream(self.stream):
+                if self._ingraph:
+                    self._feed(False)
                 run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
             self.stream.synchronize()
             if self.forced and int(self.status.item()):
@@ -510,12 +526,31 @@ class BatchRunner(object):
             self.status.zero_()  # (predicted durations: the warm-up ids need not predict valid ones)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
-                ops.u32_add(self.seed_word, 1)
+                if self._ingraph:
+                    ops.feed_copy(self._dev, self._src_dev, self._nbytes, self._seq_dev, self._seq_host_dev, self.seed_word)  # + the seed bump
+                else:
+                    ops.u32_add(self.seed_word, 1)
                 self.mel, self._frames = run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
         self.n_loaded = 0
 
+    def _feed(self, bump):
+        """The feed node outside the graph (warm-up): same kernel, counted like a launch."""
+        ops.feed_copy(self._dev, self._src_dev, self._nbytes, self._seq_dev, self._seq_host_dev, self.seed_word if bump else None)
+        self._launched += 1
+
+    def _wait_consumed(self):
+        """In-graph feed: the block may be repacked once the feed node of the last launch has read it (normally long ago: it is that pass's first node)."""
+        if int(self._seq_np[0]) == self._launched:
+            return
+        t0 = time.perf_counter()
+        while int(self._seq_np[0]) != self._launched:
+            if time.perf_counter() - t0 > 60.0:
+                raise ops._lib.FclError("fcl-taco2_amd: BatchRunner: the feed node of launch %d never ran (sequence word %d; device hung?)"
+                                        % (self._launched, int(self._seq_np[0])))
+
     def load(self, xs, durs=None, spembs=None):
-        """Hand one batch to the graph's input block: host packing + ONE non-blocking copy on this runner's stream (ordered before the next replay).
+        """Hand one batch to the graph's input block: host packing into the pinned block the graph's first node reads (FCL_FEED_INGRAPH=0: + ONE
+        non-blocking copy on this runner's stream, ordered before the next replay).
         spembs: one speaker-embedding vector per utterance (models built with spk_embed_dim)."""
         nb = len(xs)
         if (spembs is not None) != bool(self.S):
@@ -527,7 +562,9 @@ class BatchRunner(object):
         B, T, n = self.B, self.T, self.B * self.T
         j = self._slot % len(self._host)
         self._slot += 1
-        if self._host_ev[j] is not None:
+        if self._ingraph:
+            self._wait_consumed()
+        elif self._host_ev[j] is not None:
             self._host_ev[j].synchronize()  # the copy that last read this staging buffer (depth loads ago)
         hb = self._host[j].numpy()
         seg = lambda name, dt: hb[self._off[name][0] : self._off[name][0] + self._off[name][1]].view(dt)
@@ -558,17 +595,19 @@ class BatchRunner(object):
         seg("seg_lo", np.int32)[:] = base
         np.add(base, lfull, out=seg("seg_hi", np.int32))
         np.logical_not(valid, out=seg("pad", np.uint8).view(np.bool_))
-        with torch.cuda.stream(self.stream):
-            self._dev.copy_(self._host[j], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.stream)
-        self._host_ev[j] = ev
+        if not self._ingraph:
+            with torch.cuda.stream(self.stream):
+                self._dev.copy_(self._host[j], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+            self._host_ev[j] = ev
         self.n_loaded = nb
 
     def replay(self):
         """Enqueue one pass over the loaded batch; returns the static mel buffer [caps.frames, odim] (rows past the batch's total are not valid)."""
         with torch.cuda.stream(self.stream):
             self.graph.replay()
+        self._launched += 1
         return self.mel
 
     def frames(self):

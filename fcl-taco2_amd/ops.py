@@ -314,6 +314,21 @@ def u32_add(word_i32, v=1):
     check(_lib.load().fcl_u32_add(_p(word_i32, torch.int32), v, _stream()))
 
 
+def host_device_ptr(pinned):
+    """Device view (an address) of a pinned host tensor, for kernels that read / write host memory directly (feed_copy)."""
+    p = _lib.load().fcl_host_device_ptr(pinned.data_ptr())
+    if not p:
+        msg = _lib.load().fcl_last_error()
+        raise _lib.FclError("fcl-taco2_amd: %s" % (msg.decode("utf-8", "replace") if msg else "host_device_ptr failed"))
+    return p
+
+
+def feed_copy(dst_u8, src_devptr, nbytes, seq_dev_i32, seq_host_devptr, bump_i32=None):
+    """One kernel on the current stream: dst <- the pinned host block, ++*seq_dev -> *seq_host, ++*bump (include/fcl_hip.h fcl_feed_copy)."""
+    check(_lib.load().fcl_feed_copy(_p(dst_u8, torch.uint8), src_devptr, nbytes, _p(seq_dev_i32, torch.int32), seq_host_devptr, _p(bump_i32, torch.int32),
+                                    _stream()))
+
+
 class RowMapsRequest(object):
     """Output tensors (`maps`: the dict row_maps_build returns) + the fcl_row_maps_t that describes them, for a later launch to fill."""
     __slots__ = ("maps", "struct", "_keep")

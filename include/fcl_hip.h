@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 306
+#define FCL_ABI_VERSION 307
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -635,6 +635,14 @@ int fcl_pwg_layer_fwd(const fcl_pwg_layer_t* a, fcl_stream_t stream);
  * (both unused, may be NULL, for s_ch = 64: one launch that reads skips once). */
 int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const float* b1, const float* w2, float b2, uint16_t* yp, float* h, float* wav,
                      int64_t m, int s_ch, fcl_stream_t stream);
+
+/* ---- the input feed of a capacity graph (..._kd_student.py:821-843: what inference() receives per call) -------------------------------------
+ * fcl_feed_copy: ONE kernel that copies `bytes` (a multiple of 16) from pinned, mapped host memory (`src`: the DEVICE view of the block,
+ * fcl_host_device_ptr) to `dst`, then increments *seq_dev, stores the new value to *seq_host (device view of a pinned word) and, when given,
+ * adds 1 to *bump (the pass's RNG seed word).  Captured as the first node of a pass's hipGraph it replaces the hipMemcpyAsync in front of every
+ * launch (~80 us of host time per pass); the host may repack the block once *seq_host equals the number of launches it has made. */
+void* fcl_host_device_ptr(void* pinned_host);
+int fcl_feed_copy(void* dst, const void* src, size_t bytes, uint32_t* seq_dev, uint32_t* seq_host, uint32_t* bump, fcl_stream_t stream);
 
 /* ---- N3: the wire format handed to the vocoder (tts.py:652,674: kaldiio.WriteHelper("ark,scp:..."); inference_student.sh:20-23) --------------
  * HOST function (no device work): appends n Kaldi binary FloatMatrix records -- <key> ' ' "\0BFM " '\4' <int32 rows> '\4' <int32 cols> <float32 data>
