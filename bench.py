@@ -510,7 +510,7 @@ def main():
                     "fp32 accumulate / master weights / optimizer) of the reference's --use-amp recipes")
     ap.add_argument("--streams", type=int, default=4, help="batches in flight per GPU (independent passes on separate HIP streams)")
     ap.add_argument("--feed", choices=["fresh", "replay"], default="fresh", help="synthesis: fresh = every pass takes a NEW batch through host packing + "
-                    "one H2D copy + one capacity graph with device-built row maps (default: what inference() times); replay = one prepared batch "
+                    "one capacity graph (first node: the H2D pull of the packed block; device-built row maps) -- what inference() times; replay = one prepared batch "
                     "(host-built maps, outside the clock) replayed from a hipGraph (rounds 1-2)")
     ap.add_argument("--batches", type=int, default=4, help="synthesis: distinct synthetic batches fed round-robin")
     ap.add_argument("--cap-slack", type=int, default=0, help="synthesis: decoder steps of the capacity graph beyond the longest duration of the batches it serves (each costs three launches that exit at once)")
@@ -611,7 +611,7 @@ def main():
             torch.cuda.synchronize()
 
     # Default (`--feed fresh`): what the reference's inference() call covers per batch (tts.py:665-667) -- the host hand-over of a NEW batch (pack +
-    # one H2D copy of ids / lengths / durations), then the whole pass incl. the integer bookkeeping of the durations, which runs on the device
+    # the H2D pull of ids / lengths / durations as the graph's first node), then the whole pass incl. the integer bookkeeping of the durations, which runs on the device
     # inside the captured graph (engine.BatchRunner: capacities instead of a baked-in batch; ops.row_maps_build).  `--streams` runners keep as
     # many batches in flight.  `--feed replay` = rounds 1-2: one prepared batch (host-built maps, outside the clock) replayed from a hipGraph;
     # --eager launches that pass kernel by kernel.
@@ -687,8 +687,8 @@ def main():
                                                         "/".join(str(f) for f in (bframes if fresh else [frames])), n_rows),
                    "parallelism": "%d independent replicas (utterance-sharded, no collective)" % world,
                    "streams_per_gpu": args.streams,
-                   "timed_per_step": ("host packing of a NEW batch (%d distinct batches round-robin) + one H2D copy (ids, lengths, durations) + one "
-                                      "hipGraph launch: encoder, predictors, device-built row maps (fcl_row_maps_build), decoder loop on device "
+                   "timed_per_step": ("host packing of a NEW batch (%d distinct batches round-robin) into a pinned block + one hipGraph launch: the H2D pull of that "
+                                      "block (ids, lengths, durations; fcl_feed_copy), encoder, predictors, device-built row maps (fcl_row_maps_build), decoder loop on device "
                                       "live-row counts, postnet; capacities %d steps / %d frames, per-step row bounds = the batches' maximum"
                                       % (len(batches), caps.lmax, caps.frames)) if fresh else
                                      ("kernel-by-kernel launches of one prepared batch (host-built maps outside the clock)" if args.eager else

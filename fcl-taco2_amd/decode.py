@@ -126,8 +126,8 @@ def _grown_caps(engine, maps, n_rows, scale=1.3):
 @torch.no_grad()
 def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None):
     """utts: [(utt_id, ids)] or, for a model with spk_embed_dim, [(utt_id, ids, spemb)].  Writes PREFIX.ark/.scp (out_prefix None: nothing is written); returns (frames, seconds).
-    Every batch runs as ONE captured graph with predicted durations (engine.BatchRunner): the host packs the phoneme ids, enqueues one H2D
-    copy, one graph launch and one D2H copy of the mel buffer + the per-utterance frame starts, and only synchronises on a batch when it
+    Every batch runs as ONE captured graph with predicted durations (engine.BatchRunner): the host packs the phoneme ids, enqueues one
+    graph launch (its first node pulls the packed block into HBM) and one D2H copy of the mel buffer + the per-utterance frame starts, and only synchronises on a batch when it
     harvests it `depth` batches later -- no read-back of the predicted durations in the middle of a pass (rounds 1-2 did one per batch).  The
     mels go from the pinned landing buffer straight into the ark on a writer thread (no intermediate copy on the submitting thread).
     Utterances are sorted by length and bucketed by padded phoneme count (multiples of 16); the first batch of a bucket runs eagerly with the

@@ -463,7 +463,7 @@ class GraphRunner(object):
 class BatchRunner(object):
     """A captured pass whose every size is a CAPACITY: one hipGraph replays for any batch of at most `batch` utterances, `t_cap` phonemes each and
     `caps` (decoder steps, frames, live rows per step).  Per batch the host does three things: pack ids / lengths / pad mask (/ forced durations)
-    into ONE pinned block, enqueue ONE host-to-device copy, launch ONE graph.  Everything the reference's inference() does per utterance on the
+    into ONE pinned block, launch ONE graph, whose first node pulls the block into HBM (ops.feed_copy).  Everything the reference's inference() does per utterance on the
     host -- the `ds_nonzeros` filter, the position table, the per-phoneme trim and concat loops (..._kd_student.py:821-851,
     decoder_sa_kd.py:736-791) -- and this build's own numpy row maps run on the device inside the graph (ops.row_maps_build over the padded
     [batch, t_cap] row universe), with predicted OR forced durations.  Nothing about the durations is known to the host until it reads the mels
