@@ -544,6 +544,7 @@ class BatchRunner(object):
             return
         t0 = time.perf_counter()
         while int(self._seq_np[0]) != self._launched:
+            time.sleep(0)  # (yields the GIL: the decode driver's writer thread runs beside this one)
             if time.perf_counter() - t0 > 60.0:
                 raise ops._lib.FclError("fcl-taco2_amd: BatchRunner: the feed node of launch %d never ran (sequence word %d; device hung?)"
                                         % (self._launched, int(self._seq_np[0])))
