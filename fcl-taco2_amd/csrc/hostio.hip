@@ -25,7 +25,10 @@ namespace fcl {
 // number of its last launch.
 __global__ __launch_bounds__(1024) void feed_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int n16, unsigned int* seq_dev,
                                                          unsigned int* seq_host, unsigned int* bump) {
-    for (int i = threadIdx.x; i < n16; i += 1024) dst[i] = src[i];
+    // system-scope loads: past every cache of the device whatever the mapping of the host block (what a previous pass read must never be served again)
+    const unsigned long long* s64 = reinterpret_cast<const unsigned long long*>(src);
+    unsigned long long* d64 = reinterpret_cast<unsigned long long*>(dst);
+    for (int i = threadIdx.x; i < 2 * n16; i += 1024) d64[i] = __hip_atomic_load(s64 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();  // a thread issues its stores with the loaded data: past this barrier every read of the host block has returned
     if (threadIdx.x == 0) {
         const unsigned int s = *seq_dev + 1;
