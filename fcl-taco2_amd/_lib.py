@@ -62,7 +62,7 @@ class DecoderBptt(C.Structure):  # fcl_decoder_bptt_t
     _fields_ = [("n", _I), ("lmax", _I), ("u", _I), ("live_rows_host", _P), ("s0", _P * 3), ("s1", _P * 3), ("zoneout", _F), ("zk_h0", _P),
                 ("zk_c0", _P), ("zk_h1", _P), ("zk_c1", _P), ("dh1_all", _P), ("dh0_all", _P), ("w1_ih_t", _P), ("w1_hh_t", _P), ("w0_hh_t", _P),
                 ("dg0_all", _P), ("dg1_all", _P), ("workspace", _P), ("workspace_bytes", _Z), ("w1_ih_t_p", _P), ("w1_hh_t_p", _P), ("w0_hh_t_p", _P),
-                ("dg0_all_p", _P), ("dg1_all_p", _P)]
+                ("dg0_all_p", _P), ("dg1_all_p", _P), ("w1_cat_t", _P), ("w1_cat_t_p", _P)]
 
 
 class BilstmTrain(C.Structure):  # fcl_bilstm_train_t
@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 307  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 308  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t

@@ -465,16 +465,18 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ x, const float* _
 // LSTMCell + zoneout backward for one step.  Saved from forward: gates act [M,4U] (i,f,g,o after their nonlinearity), c_old, c_new (raw cell, before
 // zoneout) -- see LstmStepArgs.save_*.  In: dh_out, dc_out (gradients w.r.t. the zoneout-ed outputs).  Out: dgates [M,4U] (pre-activation),
 // dh_old_direct / dc_old (the zoneout "keep old" path and the f-gate path), to which the caller adds dgates . W_hh.
-__global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_old, const float* __restrict__ c_new,
-                                     const float* __restrict__ dh_out, const float* __restrict__ dh_out2, int ld_dh2,
+// dh_out and dh_old have their own row strides (ld_dh, ld_dho) and MAY BE THE SAME BUFFER (an element is read before it is written by the same
+// thread): the decoder's reverse pass keeps both layers' hidden-state carries side by side in one [N, 2U] array.
+__global__ void lstm_cell_bwd_kernel(const float* gates, const float* __restrict__ c_old, const float* __restrict__ c_new,
+                                     const float* dh_out, int ld_dh, int ld_dho, const float* __restrict__ dh_out2, int ld_dh2,
                                      const float* __restrict__ dc_out, float zoneout,
                                      const uint8_t* __restrict__ zk_h, const uint8_t* __restrict__ zk_c, const int* __restrict__ row_len, int step,
-                                     float* __restrict__ dgates, float* __restrict__ dh_old, float* __restrict__ dc_old_out, int M, int U,
+                                     float* __restrict__ dgates, float* dh_old, float* __restrict__ dc_old_out, int M, int U,
                                      unsigned short* __restrict__ dgates_p) {
     const long long total = (long long)M * U;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx / U), u = (int)(idx - (long long)m * U);
-        const float dho = dh_out[idx] + (dh_out2 ? dh_out2[(size_t)m * ld_dh2 + u] : 0.f), dco = dc_out ? dc_out[idx] : 0.f;
+        const float dho = dh_out[(size_t)m * ld_dh + u] + (dh_out2 ? dh_out2[(size_t)m * ld_dh2 + u] : 0.f), dco = dc_out ? dc_out[idx] : 0.f;
         const bool live = row_len ? (step < row_len[m]) : true;
         float dh_new, dc_new_z, dh_keep, dc_keep;
         if (!live) {  // state passed through untouched
@@ -504,7 +506,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const floa
             store_p32(dgates_p, ld, m, 2 * U + u, d2);
             store_p32(dgates_p, ld, m, 3 * U + u, d3);
         }
-        dh_old[idx] = dh_keep;
+        dh_old[(size_t)m * ld_dho + u] = dh_keep;
         dc_old_out[idx] = dc_new * fg + dc_keep;
     }
 }
@@ -851,16 +853,30 @@ int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new
                       const float* dc_out, float zoneout,
                       const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step, float* dgates, float* dh_old,
                       float* dc_old, uint16_t* dgates_p, int m, int u, fcl_stream_t stream) {
+    return fcl::launch_lstm_cell_bwd(gates, c_old, c_new, dh_out, u, dh_out2, ld_dh2, dc_out, zoneout, zone_keep_h, zone_keep_c, row_len, step, dgates, dh_old, u,
+                                     dc_old, dgates_p, m, u, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+namespace fcl {
+int launch_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, int ld_dh, const float* dh_out2, int ld_dh2,
+                         const float* dc_out, float zoneout, const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step,
+                         float* dgates, float* dh_old, int ld_dho, float* dc_old, uint16_t* dgates_p, int m, int u, hipStream_t stream) {
+    FCL_REQUIRE(ld_dh >= u && ld_dho >= u, FCL_ERR_SHAPE, "lstm_cell_bwd: row strides smaller than U");
     FCL_REQUIRE(gates && c_old && c_new && dh_out && dgates && dh_old && dc_old && m >= 0 && u > 0, FCL_ERR_INVALID, "lstm_cell_bwd: bad arguments");
     FCL_REQUIRE(!dgates_p || (((4 * u) & 31) == 0 && (reinterpret_cast<uintptr_t>(dgates_p) & 127u) == 0), FCL_ERR_SHAPE,
                 "lstm_cell_bwd: planes need 4U %% 32 == 0 and a 128-byte aligned buffer");
     FCL_REQUIRE((zone_keep_h == nullptr) == (zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_cell_bwd: zoneout masks come in pairs");
     if (m == 0) return 0;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)m * u, 256)), dim3(256), 0, (hipStream_t)stream, gates, c_old, c_new, dh_out, dh_out2,
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)m * u, 256)), dim3(256), 0, stream, gates, c_old, c_new, dh_out, ld_dh, ld_dho, dh_out2,
                        ld_dh2, dc_out,
                        zoneout, zone_keep_h, zone_keep_c, row_len, step, dgates, dh_old, dc_old, m, u, dgates_p);
     return check_hip(hipGetLastError(), "lstm_cell_bwd");
 }
+}  // namespace fcl
+
+extern "C" {
 
 int fcl_scatter_add_rows(const float* src, const int64_t* idx, float* dst, int m, int c, int64_t skip, fcl_stream_t stream) {
     FCL_REQUIRE(src && idx && dst && m >= 0 && c > 0, FCL_ERR_INVALID, "scatter_add_rows: bad arguments");

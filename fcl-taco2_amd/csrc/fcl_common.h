@@ -129,6 +129,10 @@ struct FeatPrenetArgs {
 };
 
 int row_maps_check(const fcl_row_maps_t* a, bool* fusable);  // pointwise.hip
+// fcl_lstm_cell_bwd with row strides for the incoming / outgoing hidden-state carries (backward.hip)
+int launch_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, int ld_dh, const float* dh_out2, int ld_dh2,
+                         const float* dc_out, float zoneout, const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step,
+                         float* dgates, float* dh_old, int ld_dho, float* dc_old, uint16_t* dgates_p, int m, int u, hipStream_t stream);
 
 // rows a step kernel processes: the host's count, or (device-driven loops) the smaller of the host's bound and the device's count
 __device__ __forceinline__ int live_rows_of(int m_host, const int* m_dev) { return m_dev ? min(m_host, *m_dev) : m_host; }

@@ -785,9 +785,10 @@ def decoder_train_fwd(live_rows, p1d, g0, w0_pre, w0_hh, w0_pos, dur_i32, w1_ih,
     check(lib.fcl_decoder_train_fwd(C.byref(a), _stream()))
 
 
-def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=None):
+def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=None, w1_cat=None):
     """planes: optional (w1_ih_t_p, w1_hh_t_p, w0_hh_t_p, dg0_all_p, dg1_all_p): P32 planes of the transposed weights (in) and of the gate
-    gradients of every cell (out) -> the recurrence's GEMMs of the steps with enough live rows run on the pre-split-operand kernels."""
+    gradients of every cell (out) -> the recurrence's GEMMs of the steps with enough live rows run on the pre-split-operand kernels.
+    w1_cat: optional ([W1_hh^T ; W1_ih^T] as one [2U, 4U] tensor, its planes or None): four launches per step instead of five."""
     lib = _lib.load()
     u = dh1_all.shape[1]
     a = _lib.DecoderBptt(n=n, lmax=int(live_rows.shape[0]), u=u, live_rows_host=live_rows.ctypes.data, zoneout=zoneout, dh1_all=_p(dh1_all),
@@ -798,6 +799,8 @@ def decoder_bptt(live_rows, n, s0, s1, zoneout, zk, dh1_all, dh0_all, w1_ih_t, w
     _ptrs(a.s1, s1[:3])
     if planes is not None:
         a.w1_ih_t_p, a.w1_hh_t_p, a.w0_hh_t_p, a.dg0_all_p, a.dg1_all_p = [_p(t, torch.int16) for t in planes]
+    if w1_cat is not None and (planes is None or w1_cat[1] is not None):
+        a.w1_cat_t, a.w1_cat_t_p = _p(w1_cat[0]), _p(w1_cat[1], torch.int16)
     nbytes = lib.fcl_decoder_train_workspace_bytes(n, u)
     ws = torch.empty(nbytes, device=dh1_all.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes

@@ -1061,7 +1061,10 @@ class TrainEngine(object):
         if ops.planes_enabled() and U % 8 == 0:  # the recurrence's GEMMs on pre-split operands: the cell-backward kernel writes dgates as planes too
             dg0_p, dg1_p = ops.planes_empty(F, 4 * U, dev), ops.planes_empty(F, 4 * U, dev)
             bpl = (self._wplanes("w1_ih_t", w1_ih_t), self._wplanes("w1_hh_t", w1_hh_t), self._wplanes("w0_hh_t", w0_hh_t), dg0_p, dg1_p)
-        ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=bpl)
+        w1_cat_t = torch.cat([w1_hh_t, w1_ih_t], 0)  # [2U, 4U]: both GEMMs that leave layer 1's gate gradients in one launch per step
+        w1_cat = (w1_cat_t, self._wplanes("w1_cat_t", w1_cat_t) if bpl is not None else None)
+        ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=bpl,
+                         w1_cat=w1_cat)
         if bpl is not None:  # [F, P]: gradient w.r.t. the prenet output of every cell
             dp1_all = ops.linear_planes(bpl[3], self._wplanes("w0_pre_t", w0_pre_t), Pn, 4 * U)[0]
         else:

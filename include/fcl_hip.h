@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 307
+#define FCL_ABI_VERSION 308
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -473,6 +473,10 @@ typedef struct {
      * [F, 4U/32 lines].  The recurrence's three GEMMs per step then run on the pre-split-operand kernels for steps with enough live rows. */
     const uint16_t *w1_ih_t_p, *w1_hh_t_p, *w0_hh_t_p;
     uint16_t *dg0_all_p, *dg1_all_p;
+    /* optional: [W1_hh^T ; W1_ih^T] as one [2U, 4U] matrix (and its planes when the five above are given): the two GEMMs that leave layer 1's gate
+     * gradients are then ONE launch per step (four dependent launches per step instead of five) */
+    const float* w1_cat_t;
+    const uint16_t* w1_cat_t_p;
 } fcl_decoder_bptt_t;
 typedef struct {
     int b, t, h;
