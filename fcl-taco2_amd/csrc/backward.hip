@@ -467,12 +467,22 @@ __global__ void layernorm_bwd_kernel(const float* __restrict__ x, const float* _
 // dh_old_direct / dc_old (the zoneout "keep old" path and the f-gate path), to which the caller adds dgates . W_hh.
 // dh_out and dh_old have their own row strides (ld_dh, ld_dho) and MAY BE THE SAME BUFFER (an element is read before it is written by the same
 // thread): the decoder's reverse pass keeps both layers' hidden-state carries side by side in one [N, 2U] array.
-__global__ void lstm_cell_bwd_kernel(const float* gates, const float* __restrict__ c_old, const float* __restrict__ c_new,
-                                     const float* dh_out, int ld_dh, int ld_dho, const float* __restrict__ dh_out2, int ld_dh2,
-                                     const float* __restrict__ dc_out, float zoneout,
-                                     const uint8_t* __restrict__ zk_h, const uint8_t* __restrict__ zk_c, const int* __restrict__ row_len, int step,
-                                     float* __restrict__ dgates, float* dh_old, float* __restrict__ dc_old_out, int M, int U,
-                                     unsigned short* __restrict__ dgates_p) {
+__device__ __forceinline__ void lstm_cell_bwd_body(const CellBwdArgs& a) {
+    const float* __restrict__ gates = a.gates;
+    const float* __restrict__ c_old = a.c_old;
+    const float* __restrict__ c_new = a.c_new;
+    const float* dh_out = a.dh_out;
+    const float* __restrict__ dh_out2 = a.dh_out2;
+    const float* __restrict__ dc_out = a.dc_out;
+    const uint8_t* __restrict__ zk_h = a.zk_h;
+    const uint8_t* __restrict__ zk_c = a.zk_c;
+    const int* __restrict__ row_len = a.row_len;
+    float* __restrict__ dgates = a.dgates;
+    float* dh_old = a.dh_old;
+    float* __restrict__ dc_old_out = a.dc_old;
+    unsigned short* __restrict__ dgates_p = a.dgates_p;
+    const int ld_dh = a.ld_dh, ld_dho = a.ld_dho, ld_dh2 = a.ld_dh2, step = a.step, M = a.m, U = a.u;
+    const float zoneout = a.zoneout;
     const long long total = (long long)M * U;
     for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int m = (int)(idx / U), u = (int)(idx - (long long)m * U);
@@ -509,6 +519,13 @@ __global__ void lstm_cell_bwd_kernel(const float* gates, const float* __restrict
         dh_old[(size_t)m * ld_dho + u] = dh_keep;
         dc_old_out[idx] = dc_new * fg + dc_keep;
     }
+}
+
+__global__ void lstm_cell_bwd_kernel(const CellBwdArgs a) { lstm_cell_bwd_body(a); }
+// two independent cell problems in one launch (blockIdx.y): layer 0 of step t beside layer 1 of step t - 1 in the decoder's reverse pass
+__global__ void lstm_cell_bwd_pair_kernel(const CellBwdArgs a0, const CellBwdArgs a1) {
+    if (blockIdx.y == 0) lstm_cell_bwd_body(a0);
+    else lstm_cell_bwd_body(a1);
 }
 
 // dst[idx[m], :] += src[m, :]   (embedding gradient; rows with idx == skip contribute nothing: padding_idx)
@@ -860,20 +877,41 @@ int fcl_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new
 }  // extern "C"
 
 namespace fcl {
+static int cell_bwd_check(const CellBwdArgs& a) {
+    FCL_REQUIRE(a.ld_dh >= a.u && a.ld_dho >= a.u, FCL_ERR_SHAPE, "lstm_cell_bwd: row strides smaller than U");
+    FCL_REQUIRE(a.gates && a.c_old && a.c_new && a.dh_out && a.dgates && a.dh_old && a.dc_old && a.m >= 0 && a.u > 0, FCL_ERR_INVALID, "lstm_cell_bwd: bad arguments");
+    FCL_REQUIRE(!a.dgates_p || (((4 * a.u) & 31) == 0 && (reinterpret_cast<uintptr_t>(a.dgates_p) & 127u) == 0), FCL_ERR_SHAPE,
+                "lstm_cell_bwd: planes need 4U %% 32 == 0 and a 128-byte aligned buffer");
+    FCL_REQUIRE((a.zk_h == nullptr) == (a.zk_c == nullptr), FCL_ERR_INVALID, "lstm_cell_bwd: zoneout masks come in pairs");
+    return 0;
+}
+
+int launch_lstm_cell_bwd(const CellBwdArgs& a, hipStream_t stream) {
+    const int rc = cell_bwd_check(a);
+    if (rc || a.m == 0) return rc;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)a.m * a.u, 256)), dim3(256), 0, stream, a);
+    return check_hip(hipGetLastError(), "lstm_cell_bwd");
+}
+
+int launch_lstm_cell_bwd_pair(const CellBwdArgs& a0, const CellBwdArgs& a1, hipStream_t stream) {
+    int rc = cell_bwd_check(a0);
+    if (!rc) rc = cell_bwd_check(a1);
+    if (rc) return rc;
+    if (a0.m == 0) return launch_lstm_cell_bwd(a1, stream);
+    if (a1.m == 0) return launch_lstm_cell_bwd(a0, stream);
+    const long long big = (long long)std::max(a0.m, a1.m) * a0.u;
+    hipLaunchKernelGGL(lstm_cell_bwd_pair_kernel, dim3(grid1d(big, 256), 2), dim3(256), 0, stream, a0, a1);
+    return check_hip(hipGetLastError(), "lstm_cell_bwd pair");
+}
+
 int launch_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, int ld_dh, const float* dh_out2, int ld_dh2,
                          const float* dc_out, float zoneout, const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step,
                          float* dgates, float* dh_old, int ld_dho, float* dc_old, uint16_t* dgates_p, int m, int u, hipStream_t stream) {
-    FCL_REQUIRE(ld_dh >= u && ld_dho >= u, FCL_ERR_SHAPE, "lstm_cell_bwd: row strides smaller than U");
-    FCL_REQUIRE(gates && c_old && c_new && dh_out && dgates && dh_old && dc_old && m >= 0 && u > 0, FCL_ERR_INVALID, "lstm_cell_bwd: bad arguments");
-    FCL_REQUIRE(!dgates_p || (((4 * u) & 31) == 0 && (reinterpret_cast<uintptr_t>(dgates_p) & 127u) == 0), FCL_ERR_SHAPE,
-                "lstm_cell_bwd: planes need 4U %% 32 == 0 and a 128-byte aligned buffer");
-    FCL_REQUIRE((zone_keep_h == nullptr) == (zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_cell_bwd: zoneout masks come in pairs");
-    if (m == 0) return 0;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1d((long long)m * u, 256)), dim3(256), 0, stream, gates, c_old, c_new, dh_out, ld_dh, ld_dho, dh_out2,
-                       ld_dh2, dc_out,
-                       zoneout, zone_keep_h, zone_keep_c, row_len, step, dgates, dh_old, dc_old, m, u, dgates_p);
-    return check_hip(hipGetLastError(), "lstm_cell_bwd");
+    CellBwdArgs a = {gates, c_old, c_new, dh_out, dh_out2, dc_out, zone_keep_h, zone_keep_c, row_len, dgates, dh_old, dc_old, dgates_p,
+                     ld_dh, ld_dho, ld_dh2, step, m, u, zoneout};
+    return launch_lstm_cell_bwd(a, stream);
 }
+
 }  // namespace fcl
 
 extern "C" {

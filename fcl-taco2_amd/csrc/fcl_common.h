@@ -129,7 +129,19 @@ struct FeatPrenetArgs {
 };
 
 int row_maps_check(const fcl_row_maps_t* a, bool* fusable);  // pointwise.hip
-// fcl_lstm_cell_bwd with row strides for the incoming / outgoing hidden-state carries (backward.hip)
+// fcl_lstm_cell_bwd with row strides for the incoming / outgoing hidden-state carries (backward.hip); the pair form runs two independent problems
+// of the same width in one launch
+struct CellBwdArgs {
+    const float *gates, *c_old, *c_new, *dh_out, *dh_out2, *dc_out;
+    const uint8_t *zk_h, *zk_c;
+    const int32_t* row_len;
+    float *dgates, *dh_old, *dc_old;
+    unsigned short* dgates_p;
+    int ld_dh, ld_dho, ld_dh2, step, m, u;
+    float zoneout;
+};
+int launch_lstm_cell_bwd(const CellBwdArgs& a, hipStream_t stream);
+int launch_lstm_cell_bwd_pair(const CellBwdArgs& a0, const CellBwdArgs& a1, hipStream_t stream);
 int launch_lstm_cell_bwd(const float* gates, const float* c_old, const float* c_new, const float* dh_out, int ld_dh, const float* dh_out2, int ld_dh2,
                          const float* dc_out, float zoneout, const uint8_t* zone_keep_h, const uint8_t* zone_keep_c, const int32_t* row_len, int step,
                          float* dgates, float* dh_old, int ld_dho, float* dc_old, uint16_t* dgates_p, int m, int u, hipStream_t stream);

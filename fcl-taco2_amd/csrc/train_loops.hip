@@ -4,6 +4,8 @@
 //   fcl_decoder_bptt       : its reverse-time pass (gate gradients of both layers for every cell)
 //   fcl_bilstm_train_fwd   : one direction of the packed encoder BiLSTM with saved gates (encoder_sa.py:98-100,143-146)
 //   fcl_bilstm_bptt        : its reverse pass
+#include <vector>
+
 #include "fcl_common.h"
 
 using namespace fcl;
@@ -148,26 +150,44 @@ int fcl_decoder_bptt(const fcl_decoder_bptt_t* a, fcl_stream_t stream) {
         // kernels read and write in place (their "keep" path is the GEMMs' residual): 38 fewer dependent launches on a KD update's critical path
         float* X = ws;  // (the ch0 | ch1 region of the workspace, zeroed above)
         const int U2 = 2 * U;
+        float* tmp_c1 = tmp_h;  // (the keep paths live in X: the old tmp_h buffer is layer 1's second cell-carry buffer)
+        // ... and THREE once the two cell kernels that follow that GEMM -- layer 0 of step t and layer 1 of step t - 1, both waiting for nothing
+        // else -- share a launch: per step  [W1 GEMM(t)] -> [cell L0(t) | cell L1(t - 1)] -> [W0_hh GEMM(t)]
+        std::vector<size_t> offs((size_t)a->lmax);
+        for (int t = 0; t < a->lmax; ++t) { offs[(size_t)t] = t ? offs[(size_t)t - 1] + (size_t)a->live_rows_host[t - 1] : 0; }
+        auto cell1 = [&](int t) {  // layer 1 of step t: carry X[:, :U] in place, cell carry cc1 -> tmp_c1 (swapped by the caller)
+            const size_t o = offs[(size_t)t];
+            return CellBwdArgs{a->s1[0] + o * G4, a->s1[2] + o * U, a->s1[1] + o * U, X, a->dh1_all + o * U, cc1, a->zk_h1 ? a->zk_h1 + o * U : nullptr,
+                               a->zk_c1 ? a->zk_c1 + o * U : nullptr, nullptr, a->dg1_all + o * G4, X, tmp_c1,
+                               planes ? a->dg1_all_p + o * (size_t)ldg * 64 : nullptr, U2, U2, U, t, a->live_rows_host[t], U, a->zoneout};
+        };
+        auto cell0 = [&](int t) {
+            const size_t o = offs[(size_t)t];
+            return CellBwdArgs{a->s0[0] + o * G4, a->s0[2] + o * U, a->s0[1] + o * U, X + U, a->dh0_all ? a->dh0_all + o * U : nullptr, cc0,
+                               a->zk_h0 ? a->zk_h0 + o * U : nullptr, a->zk_c0 ? a->zk_c0 + o * U : nullptr, nullptr, a->dg0_all + o * G4, X + U, tmp_c,
+                               planes ? a->dg0_all_p + o * (size_t)ldg * 64 : nullptr, U2, U2, U, t, a->live_rows_host[t], U, a->zoneout};
+        };
+        int rc = launch_lstm_cell_bwd(cell1(a->lmax - 1), s);
+        if (rc) return rc;
+        std::swap(cc1, tmp_c1);
         for (int t = a->lmax - 1; t >= 0; --t) {
             const int n = a->live_rows_host[t];
-            off -= (size_t)n;
-            unsigned short* dg1p = planes ? a->dg1_all_p + off * (size_t)ldg * 64 : nullptr;
-            unsigned short* dg0p = planes ? a->dg0_all_p + off * (size_t)ldg * 64 : nullptr;
-            int rc = launch_lstm_cell_bwd(a->s1[0] + off * G4, a->s1[2] + off * U, a->s1[1] + off * U, X, U2, a->dh1_all + off * U, U, cc1, a->zoneout,
-                                          a->zk_h1 ? a->zk_h1 + off * U : nullptr, a->zk_c1 ? a->zk_c1 + off * U : nullptr, nullptr, t,
-                                          a->dg1_all + off * G4, X, U2, tmp_c, dg1p, n, U, s);
-            if (rc) return rc;
-            std::swap(cc1, tmp_c);
-            GemmArgs g = lin(a->dg1_all + off * G4, G4, a->w1_cat_t, G4, G4, X, U2, n, U2, X, U2);
+            const size_t o = offs[(size_t)t];
+            unsigned short* dg1p = planes ? a->dg1_all_p + o * (size_t)ldg * 64 : nullptr;
+            unsigned short* dg0p = planes ? a->dg0_all_p + o * (size_t)ldg * 64 : nullptr;
+            GemmArgs g = lin(a->dg1_all + o * G4, G4, a->w1_cat_t, G4, G4, X, U2, n, U2, X, U2);
             if (planes && n > planes_min_rows) { g.term[0].Ap = dg1p; g.term[0].Wp = a->w1_cat_t_p; g.term[0].lda_p = g.term[0].ldw_p = ldg; }
             rc = launch_gemm(g, s);
             if (rc) return rc;
-            rc = launch_lstm_cell_bwd(a->s0[0] + off * G4, a->s0[2] + off * U, a->s0[1] + off * U, X + U, U2, a->dh0_all ? a->dh0_all + off * U : nullptr, U, cc0,
-                                      a->zoneout, a->zk_h0 ? a->zk_h0 + off * U : nullptr, a->zk_c0 ? a->zk_c0 + off * U : nullptr, nullptr, t,
-                                      a->dg0_all + off * G4, X + U, U2, tmp_c, dg0p, n, U, s);
+            if (t > 0) {
+                rc = launch_lstm_cell_bwd_pair(cell0(t), cell1(t - 1), s);
+                std::swap(cc1, tmp_c1);
+            } else {
+                rc = launch_lstm_cell_bwd(cell0(t), s);
+            }
             if (rc) return rc;
             std::swap(cc0, tmp_c);
-            GemmArgs g0 = lin(a->dg0_all + off * G4, G4, a->w0_hh_t, G4, G4, X + U, U2, n, U, X + U, U2);
+            GemmArgs g0 = lin(a->dg0_all + o * G4, G4, a->w0_hh_t, G4, G4, X + U, U2, n, U, X + U, U2);
             if (planes && n > planes_min_rows) { g0.term[0].Ap = dg0p; g0.term[0].Wp = a->w0_hh_t_p; g0.term[0].lda_p = g0.term[0].ldw_p = ldg; }
             rc = launch_gemm(g0, s);
             if (rc) return rc;
