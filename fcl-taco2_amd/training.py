@@ -20,6 +20,7 @@ rows sorted by duration (descending), cell (t, m) at offset[t] + m, so the live 
 Gradients, Adam moments and (re-pointed) parameters live in three flat buffers ordered by when backward finishes them, so the optimizer is one
 launch and the all-reduce runs over contiguous buckets while backward is still producing the later ones.
 """
+import contextlib
 import os
 import zlib
 
@@ -359,6 +360,13 @@ class TrainEngine(object):
         # stream and joined at the end of backward / before a bucket's all-reduce
         self.overlap_dw = overlap_dw
         self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
+        # The three predictors feed nothing but their own losses in a teacher-forced step (the variance embeddings take the ground-truth pitch /
+        # energy): their forward runs beside the decoder's forward and their backward beside the decoder's backward -- ~90 small dependent
+        # launches off the main stream's chain -- on the weight-gradient stream, which is idle through the forward and far from full in the
+        # backward.  NOT a stream of their own: with the frozen teacher's stream that made five active queues in a KD update (18.6 instead of
+        # 11.7 ms: DESIGN §5, the device runs four queues well).  FCL_PRED_STREAM=0: in line, as before
+        self.pstream = self.side if (overlap_dw and os.environ.get("FCL_PRED_STREAM", "1") not in ("", "0")) else None
+        self._pred_ev = None
         self._dw_keep = []
         self._plane_cache = {}
         # operand forms of the parameters (packed taps, transposes, column blocks, bias sums, their P32 planes): one batched launch per update
@@ -668,6 +676,27 @@ class TrainEngine(object):
             x = ln
         return out, caches
 
+    def _pred_fork(self, c):
+        """Context in which the predictors' launches go to their own stream, ordered after everything enqueued on the current stream so far.
+        Steps with a backward only (c.save): a frozen KD teacher already runs beside the student's three streams, and a fifth active queue
+        halves the device's throughput."""
+        if self.pstream is None or not c.save:
+            return contextlib.nullcontext()
+        self.pstream.wait_stream(torch.cuda.current_stream(self.dev))
+        return self._pred_ctx()
+
+    @contextlib.contextmanager
+    def _pred_ctx(self):
+        with torch.cuda.stream(self.pstream):
+            yield
+            self._pred_ev = torch.cuda.Event()
+            self._pred_ev.record(self.pstream)  # (the join waits for the predictors, not for weight gradients queued behind them)
+
+    def _pred_join(self):
+        if self._pred_ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._pred_ev)
+            self._pred_ev = None
+
     def _predictor_bwd(self, d_out, name, caches, pad):
         G, P = self.G, self.P
         dx = None
@@ -811,12 +840,13 @@ class TrainEngine(object):
                 sites += [(("pitch_embed",), (B * T, C), 1.0 - p_emb), (("energy_embed",), (B * T, C), 1.0 - p_emb)]
             pk = dict(zip([st[0] for st in sites], self._keeps(c, sites)))
         pkeeps = lambda nm, layers: [pk.get((nm, i)) for i in range(layers)]
-        c.d_outs, c.dur_c = self._predictor_fwd(c, c.hs, "duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_dropout_rate,
-                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("duration_predictor", hp.duration_predictor_layers))
-        c.p_outs, c.pit_c = self._predictor_fwd(c, c.hs, "pitch_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
-                                                c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("pitch_predictor", hp.variance_predictor_layers))
-        c.e_outs, c.en_c = self._predictor_fwd(c, c.hs, "energy_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
-                                               c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("energy_predictor", hp.variance_predictor_layers))
+        with self._pred_fork(c):  # (joined at the end of this forward)
+            c.d_outs, c.dur_c = self._predictor_fwd(c, c.hs, "duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_dropout_rate,
+                                                    c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("duration_predictor", hp.duration_predictor_layers))
+            c.p_outs, c.pit_c = self._predictor_fwd(c, c.hs, "pitch_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
+                                                    c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("pitch_predictor", hp.variance_predictor_layers))
+            c.e_outs, c.en_c = self._predictor_fwd(c, c.hs, "energy_predictor", hp.variance_predictor_layers, hp.variance_predictor_dropout_rate,
+                                                   c.e_lo, c.e_hi, c.enc_pad, hs_p=hs_p, keeps=pkeeps("energy_predictor", hp.variance_predictor_layers))
         c.f0 = batch["f0"][:, :T].to(dev).float().reshape(-1).contiguous()
         c.en = batch["energy"][:, :T].to(dev).float().reshape(-1).contiguous()
         c.ds = batch["extras"][:, :T].to(dev).float().reshape(-1).contiguous()
@@ -930,6 +960,7 @@ class TrainEngine(object):
         if hp.output_activation is not None:  # decoder_sa.py:538-540: the losses / the knowledge see activated outputs; the postnet read the raw `before`
             c.before_raw_act = (ops.act_fwd(c.before, output_act_code(hp)), ops.act_fwd(c.after, output_act_code(hp)))
             c.before, c.after = c.before_raw_act
+        self._pred_join()
         if c.bn_run:
             if self._nbt_flat is not None and len(c.bn_run) == self._nbt_flat.numel():
                 self._nbt_flat.add_(1)
@@ -1035,6 +1066,10 @@ class TrainEngine(object):
         if hp.output_activation is not None:  # back through output_activation_fn (y = the activated outputs)
             inj["before"] = ops.act_bwd(inj["before"], c.before, output_act_code(hp))
             inj["after"] = ops.act_bwd(inj["after"], c.after, output_act_code(hp))
+        with self._pred_fork(c):  # the predictors' backward needs nothing but their loss gradients: beside the whole decoder backward
+            d_preds = [self._predictor_bwd(inj["d_outs"].reshape(-1), "duration_predictor", c.dur_c, c.enc_pad),
+                       self._predictor_bwd(inj["p_outs"].reshape(-1), "pitch_predictor", c.pit_c, c.enc_pad),
+                       self._predictor_bwd(inj["e_outs"].reshape(-1), "energy_predictor", c.en_c, c.enc_pad)]
         d_before = inj["before"]
         ops.add2d(d_before, inj["after"])
         dx = inj["after"]
@@ -1116,10 +1151,10 @@ class TrainEngine(object):
                 ops.conv1d_in1_dw(d_e, sig, G[nm + "_embed.0.weight"], G[nm + "_embed.0.bias"], seg_lo=c.e_lo, seg_hi=c.e_hi)
 
             self._dw(dw_embed)
-        # ---- predictors
-        ops.add2d(d_hs, self._predictor_bwd(inj["d_outs"].reshape(-1), "duration_predictor", c.dur_c, c.enc_pad))
-        ops.add2d(d_hs, self._predictor_bwd(inj["p_outs"].reshape(-1), "pitch_predictor", c.pit_c, c.enc_pad))
-        ops.add2d(d_hs, self._predictor_bwd(inj["e_outs"].reshape(-1), "energy_predictor", c.en_c, c.enc_pad))
+        # ---- predictors (their backward was enqueued at the top of this function, on their own stream)
+        self._pred_join()
+        for d_pred in d_preds:
+            ops.add2d(d_hs, d_pred)
         self._launch_bucket(c, 2)
         # ---- encoder
         if "hs" in inj:
