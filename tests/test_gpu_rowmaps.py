@@ -241,6 +241,41 @@ def test_batch_runner_one_graph_for_many_batches():
         assert fr == [int(m_.shape[0]) for m_ in ref] and max_abs(mel[: sum(fr)], torch.cat(ref)) < 2e-5
 
 
+def test_the_in_graph_feed_equals_the_copy_in_front_of_the_launch(monkeypatch):
+    """BatchRunner's input block: pulled out of pinned host memory by the graph's first node (fcl_feed_copy, the default) or copied by one
+    hipMemcpyAsync in front of every launch (FCL_FEED_INGRAPH=0): the same mels bit for bit, batch after batch, also when the host repacks the
+    block right after a launch (it must wait for the feed node's sequence number) and when a pass is replayed without a new load."""
+    from fcl_taco2_amd import engine
+
+    hp = HP.student_hparams(dropout_rate=0.0)
+    plan = _plan(hp)
+    B, T_cap = 6, 48
+    batches = [SYN.batch_c2(hp.idim, batch=B, t_lo=12, t_hi=T_cap, seed=s) for s in (11, 12, 13, 14)]
+    maps = [engine.build_row_maps([len(x) for x in xs], ds, T_cap) for xs, ds in batches]
+    caps = engine.Caps.generous(B * T_cap, max(m.lmax for m in maps) + 1, max(m.n_frames for m in maps) + 64)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FCL_FEED_INGRAPH", mode)
+        r = engine.BatchRunner(plan, B, T_cap, caps, forced=True)
+        assert r._ingraph == (mode == "1")
+        res = []
+        for i in range(12):  # back to back: the host is ahead of the device, every load() finds the previous pass still queued
+            xs, ds = batches[i % 4]
+            r.load(xs, ds)
+            with torch.cuda.stream(r.stream):  # (the copy is ordered behind the pass on the runner's stream: no host synchronisation in the loop)
+                res.append(r.replay().clone())
+        with torch.cuda.stream(r.stream):
+            res.append(r.replay().clone())  # the same block again
+        assert r.frames() == list(maps[11 % 4].utt_frames)
+        outs[mode] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+    for i, m in enumerate(maps):
+        ref = torch.cat(engine.synthesize(plan, *batches[i]))
+        assert max_abs(outs["1"][i][: m.n_frames], ref) < 2e-5
+    assert torch.equal(outs["1"][12][: maps[3].n_frames], outs["1"][11][: maps[3].n_frames])
+
+
 def test_decode_driver_recovers_from_a_capacity_overflow(tmp_path, monkeypatch):
     """fcl_taco2_amd.decode: a batch that exceeds its bucket's calibrated capacities is reported by the device, re-run on the host-mapped path and the
     bucket's graphs are re-captured with larger capacities; every utterance's mel still equals the plain synthesis.  Forced here by shrinking the
