@@ -766,7 +766,8 @@ int fcl_gemm_tn_taps_fwd(const float* a, int lda, const float* b, int ldb, float
     FCL_REQUIRE((seg_lo == nullptr) == (seg_hi == nullptr), FCL_ERR_INVALID, "gemm_tn_fwd: seg_lo/seg_hi come in pairs");
     if (m == 0) return 0;
     const int tiles = ((n + 63) / 64) * ((k + 63) / 64) * ntaps;
-    int slices = (1024 + tiles - 1) / tiles;  // ~1024 workgroups in flight, but at least 128 rows each: every slice ends in 4096 atomics per tile
+    static const int tn_wgs = tunable("TN_WORKGROUPS", 1024);
+    int slices = (tn_wgs + tiles - 1) / tiles;  // ~1024 workgroups in flight, but at least 128 rows each: every slice ends in 4096 atomics per tile
     int rps = ((m + slices - 1) / slices + TN_BM - 1) / TN_BM * TN_BM;
     if (rps < 4 * TN_BM) rps = 4 * TN_BM;
     slices = (m + rps - 1) / rps;
