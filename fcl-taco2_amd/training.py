@@ -367,6 +367,8 @@ class TrainEngine(object):
         # 11.7 ms: DESIGN §5, the device runs four queues well).  FCL_PRED_STREAM=0: in line, as before
         self.pstream = self.side if (overlap_dw and os.environ.get("FCL_PRED_STREAM", "1") not in ("", "0")) else None
         self._pred_ev = None
+        self._late_ev = None
+        self._late_losses = os.environ.get("FCL_KD_LATE_LOSSES", "1") not in ("", "0")
         self._dw_keep = []
         self._plane_cache = {}
         # operand forms of the parameters (packed taps, transposes, column blocks, bias sums, their P32 planes): one batched launch per update
@@ -696,6 +698,25 @@ class TrainEngine(object):
         if self._pred_ev is not None:
             torch.cuda.current_stream(self.dev).wait_event(self._pred_ev)
             self._pred_ev = None
+
+    @contextlib.contextmanager
+    def _late_fork(self, c):
+        """The KD terms whose gradients the backward needs LATE (encoder taps: at its very end; prenet / LSTM taps: after the postnet's backward) run
+        on the weight-gradient stream while the main stream computes the frame-level terms and starts the postnet's backward (FCL_KD_LATE_LOSSES=0:
+        in line)."""
+        if self.pstream is None or not c.save or not self._late_losses:
+            yield
+            return
+        self.pstream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.pstream):
+            yield
+            self._late_ev = torch.cuda.Event()
+            self._late_ev.record(self.pstream)
+
+    def _late_join(self):
+        if self._late_ev is not None:
+            torch.cuda.current_stream(self.dev).wait_event(self._late_ev)
+            self._late_ev = None
 
     def _predictor_bwd(self, d_out, name, caches, pad):
         G, P = self.G, self.P
@@ -1028,20 +1049,22 @@ class TrainEngine(object):
                 self._dw(lambda: ops.gemm_tn(ds_, s_in, G[proj + ".weight"]))
                 return ops.linear(ds_, self._wt(w))
 
+            with self._late_fork(c):  # (joined in _backward after the postnet)
+                if self.distill[2]:
+                    cellv = c.cell_valid
+                    tc = lambda t: ops.gather_rows(flat(t), c.cell_frame)
+                    inj["h1"] = kd("dec2", c.h1_all, lp[1], tc(t_dec[2]), cellv, c.n_frames)
+                    inj["h0"] = kd("dec1", c.h0_all, lp[0], tc(t_dec[1]), cellv, c.n_frames)
+                    inj["p1d"] = kd("dec0", c.p1d, "dec.prenet_proj", tc(t_dec[0]), cellv, c.n_frames)
+                if self.distill[1]:
+                    inj["enc0"] = kd("enc0", c.enc_taps[0], "enc.embed_proj", flat(t_enc[0]), c.enc_valid, ne)
+                    for i in range(3):
+                        inj["enc%d" % (i + 1)] = kd("enc%d" % (i + 1), c.enc_taps[1 + i], cp[i], flat(t_enc[1 + i]), c.enc_valid, ne)
+                    inj["hs"] = kd("enc4", c.hs, "enc.blstm_proj", flat(t_enc[4]), c.enc_valid, ne)
             if self.distill[0]:
                 term("o_after", c.after, flat(t_after), fv, nfm, 1.0, 1.0, da=inj["after"])
                 term("o_before", c.before, flat(t_before), fv, nfm, 1.0, 1.0, da=inj["before"])
-            if self.distill[1]:
-                inj["enc0"] = kd("enc0", c.enc_taps[0], "enc.embed_proj", flat(t_enc[0]), c.enc_valid, ne)
-                for i in range(3):
-                    inj["enc%d" % (i + 1)] = kd("enc%d" % (i + 1), c.enc_taps[1 + i], cp[i], flat(t_enc[1 + i]), c.enc_valid, ne)
-                inj["hs"] = kd("enc4", c.hs, "enc.blstm_proj", flat(t_enc[4]), c.enc_valid, ne)
             if self.distill[2]:
-                cellv = c.cell_valid
-                tc = lambda t: ops.gather_rows(flat(t), c.cell_frame)
-                inj["p1d"] = kd("dec0", c.p1d, "dec.prenet_proj", tc(t_dec[0]), cellv, c.n_frames)
-                inj["h0"] = kd("dec1", c.h0_all, lp[0], tc(t_dec[1]), cellv, c.n_frames)
-                inj["h1"] = kd("dec2", c.h1_all, lp[1], tc(t_dec[2]), cellv, c.n_frames)
                 for i in range(4):
                     inj["post%d" % i] = kd("dec%d" % (3 + i), c.post_taps[i], pp[i], flat(t_dec[3 + i]), c.frame_valid, c.n_frames)
                 inj["post4"] = term("dec7", c.post_taps[4], flat(t_dec[7]), c.frame_valid, nf, 0.0, 1.0)
@@ -1054,6 +1077,7 @@ class TrainEngine(object):
         c.sums, c.loss_names = sums, names
 
     def _report(self, c):
+        self._late_join()  # (a loss-only caller: the sums of the terms on the weight-gradient stream must be complete before they are copied)
         return LossReport(c.sums, c.loss_names, status_dev=self.status)
 
     # ------------------------------------------------------------------------------------------------ backward
@@ -1078,6 +1102,7 @@ class TrainEngine(object):
                 ops.add2d(dx, inj["post%d" % i])
             dx = self._conv_bn_bwd(c, dx, c.post_c[i])
         ops.add2d(d_before, dx)
+        self._late_join()  # the KD gradients at the prenet / LSTM / encoder taps (computed beside the frame-level terms and the postnet's backward)
         self._launch_bucket(c, 0)
         # ---- decoder BPTT
         d_out_cells = ops.gather_rows(d_before, c.cell_frame)  # [F, O]
