@@ -92,11 +92,18 @@ class gemm_mode(object):
         return False
 
 
-def planes_enabled():
-    """The pre-split (P32) operand path is on unless exact-fp32 arithmetic (FCL_PRECISION=0) or FCL_PLANES=0 is requested."""
-    import os
+_PLANES_ON = None
 
-    return os.environ.get("FCL_PRECISION", "1") != "0" and os.environ.get("FCL_PLANES", "1") != "0"
+
+def planes_enabled():
+    """The pre-split (P32) operand path is on unless exact-fp32 arithmetic (FCL_PRECISION=0) or FCL_PLANES=0 is requested.  Read once per process,
+    as the library reads its tunables (a training update asks ~180 times)."""
+    global _PLANES_ON
+    if _PLANES_ON is None:
+        import os
+
+        _PLANES_ON = os.environ.get("FCL_PRECISION", "1") != "0" and os.environ.get("FCL_PLANES", "1") != "0"
+    return _PLANES_ON
 
 
 def planes_empty(rows, cols, device):
