@@ -18,6 +18,8 @@ stats $OUT/cap1 $OUT/capacity_graph_1stream_kernel_stats.csv; rm -rf $OUT/cap1
 rocprofv3 --kernel-trace --stats -d $OUT/bak1 -o b --output-format csv -- python3 bench.py --streams 1 --feed replay --no-cpu-baseline --no-extras --regions 3 > $OUT/bak1_bench.json 2>/dev/null
 stats $OUT/bak1 $OUT/baked_graph_1stream_kernel_stats.csv; rm -rf $OUT/bak1
 python3 tools/feed_cost.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/feed_cost.log
+python3 tools/host_pieces.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/host_pieces.log
+(python3 tools/kd_host_lead.py kd; python3 tools/kd_host_lead.py teacher) 2>&1 | grep "host enqueue" > $OUT/kd_host_lead.log
 E1="python3 bench.py --streams 1 --eager --feed replay --no-cpu-baseline --no-extras --steps 6 --warmup 2 --regions 1"
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o f --output-format csv -- $E1 > /dev/null 2>&1
 pmc $OUT/pmc_fetch $OUT/pmc_fetch_size.csv pmc_summary.py
