@@ -421,6 +421,13 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     FCL_REQUIRE(b > 0 && t > 0 && c > 0 && h > 0 && (c & 3) == 0 && (h & 3) == 0, FCL_ERR_SHAPE, "bilstm_fwd: bad sizes B=%d T=%d C=%d H=%d", b, t, c, h);
     FCL_REQUIRE(workspace && workspace_bytes >= fcl_bilstm_workspace_bytes(b, t, h), FCL_ERR_WORKSPACE, "bilstm_fwd: workspace too small");
     FCL_REQUIRE(aligned16(workspace) && aligned16(out), FCL_ERR_ALIGN, "bilstm_fwd: 16-byte alignment required");
+    // row_maps: also build the batch's row / frame maps (fcl_row_maps_build).  With the persistent recurrence at H = 128 they ride in the same
+    // launch (one extra workgroup); every other path builds them with their own two launches after the recurrence
+    bool maps_fusable = false;
+    if (row_maps) {
+        const int rc = row_maps_check(row_maps, &maps_fusable);
+        if (rc) return rc;
+    }
     hipStream_t s = (hipStream_t)stream;
     float* gx_f = reinterpret_cast<float*>(workspace);
     float* gx_r = gx_f + (size_t)b * t * 4 * h;
@@ -450,13 +457,6 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     // several synthesis passes are in flight on other streams (3.52 vs 3.85 M frames/s) — so algo 0 keeps the per-step launches there.
     static const int group_infer = tunable("BILSTM_GROUP_INFER", 0);
     FCL_REQUIRE(algo != 3 || status, FCL_ERR_INVALID, "bilstm_fwd: algo 3 (cooperating workgroups) needs a device status word");
-    // row_maps: also build the batch's row / frame maps (fcl_row_maps_build).  With the persistent recurrence at H = 128 they ride in the same
-    // launch (one extra workgroup); every other path builds them with their own two launches after the recurrence
-    bool maps_fusable = false;
-    if (row_maps) {
-        const int rc = row_maps_check(row_maps, &maps_fusable);
-        if (rc) return rc;
-    }
     static const int fuse_on = tunable("ROWMAPS_FUSE", 1);
     struct MapsAfter {  // the non-fused paths below return from several places
         const fcl_row_maps_t* m;

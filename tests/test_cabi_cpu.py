@@ -160,3 +160,24 @@ def test_row_maps_argument_validation(lib):
     assert lib.fcl_row_maps_build(C.byref(a), None) == -2 and b"padded" in lib.fcl_last_error()  # no utt_row0 and n != b * t_max
     a.t_max = 5
     assert lib.fcl_row_maps_build(C.byref(a), None) == -1 and b"null pointer" in lib.fcl_last_error()
+
+
+def test_round3_entry_points_validate_arguments_without_a_gpu(lib):
+    """The entry points added at the end of round 3 return FCL_ERR_* before any HIP call on bad arguments: the in-graph input feed, the BatchNorm
+    backward's paired accumulators, the second column sum, the BiLSTM's optional row maps, the Kaldi batch writer."""
+    from fcl_taco2_amd import _lib
+
+    assert lib.fcl_feed_copy(None, 128, 64, 128, 128, None, None) == -1
+    assert lib.fcl_feed_copy(256, 128, 60, 128, 128, None, None) == -1 and b"feed_copy" in lib.fcl_last_error()   # bytes % 16
+    assert lib.fcl_feed_copy(264, 128, 64, 128, 128, None, None) == -3 and b"16-byte" in lib.fcl_last_error()      # misaligned destination
+    assert lib.fcl_host_device_ptr(None) is None and b"host_device_ptr" in lib.fcl_last_error()
+    assert lib.fcl_colsum2_fwd(None, None, None, None, None, None, 4, 4, 0, None) == -1
+    assert lib.fcl_colsum2_fwd(128, None, None, None, 128, 128, 4, 4, 3, None) == -1 and b"mode needs y" in lib.fcl_last_error()
+    assert lib.fcl_bn_bwd(128, 128, 128, 128, 128, 128, 128, 128, None, 4, 32, 128, None, None) == -1 and b"pairs" in lib.fcl_last_error()
+    # fcl_bilstm_fwd: a row-map request is validated with the same rules as fcl_row_maps_build, before anything is launched
+    a = _lib.RowMaps()
+    ws = lib.fcl_bilstm_workspace_bytes(2, 5, 128)
+    assert ws > 0
+    rc = lib.fcl_bilstm_fwd(128, 128, 128, 128, 128, 128, 128, 128, 256, None, None, None, None, 2, 5, 32, 128, 0, 256, ws, None, C.byref(a), None)
+    assert rc == -2 and lib.fcl_last_error()  # (empty request: sizes)
+    assert lib.fcl_kaldi_ark_append(-1, 0, 0, None, None, None, 80, None) == -1
