@@ -308,7 +308,7 @@ class ZeroArena(object):
         return out
 
 
-_DW_PLANES_MIN = int(os.environ.get("FCL_DW_PLANES_MIN", str(1 << 20)))  # output elements from which a weight gradient runs on transposed planes
+_DW_PLANES_MIN = int(os.environ.get("FCL_DW_PLANES_MIN", "0"))  # output elements from which a weight gradient runs on transposed planes (0: per role, below)
 # (measured r3: sending the student's long-contraction / small-output gradients -- 13 GFLOP into [1024, 256] over ~25 k frames, 65 - 110 TFLOP/s on the
 # fp32-operand kernel -- to the planes kernel as well is a wash: its two transposing passes cost what the faster GEMM saves; KD update 12.66 vs 12.59 ms)
 
@@ -322,6 +322,10 @@ class TrainEngine(object):
         if not p0.is_cuda:
             raise RuntimeError("fcl-taco2_amd: TrainEngine needs the model on a GPU (no CPU fallback)")
         self.model, self.hp, self.dev, self.role = model, model.hp, p0.device, model.role
+        # weight gradients on transposed planes from 1 M outputs on; from 256 k in the teacher's OWN update (same-box A/B at the end of round 3: teacher
+        # update 11.32 -> 11.15 ms; the KD update, whose weight-gradient stream also carries the predictors and the late loss terms beside the frozen
+        # teacher's forward, loses with it: 10.78 -> 10.83 ms)
+        self._dw_planes_min = _DW_PLANES_MIN or ((1 << 18) if model.role == "teacher" else (1 << 20))
         if self.role == "student" and self.hp.spk_embed_dim is not None:
             raise NotImplementedError("fcl-taco2_amd: KD training with speaker embeddings is undefined in the reference (its student's pemb_proj / eemb_proj "
                                       "are built for eunits inputs but receive eunits + spk_embed_dim channels: tests/golden/records.json)")
@@ -474,7 +478,7 @@ class TrainEngine(object):
         per-launch cost is lower than the two extra passes."""
         m, n = dz.shape
         outs = sum(out.numel() for _, out in pairs)
-        if ops.planes_enabled() and outs >= _DW_PLANES_MIN and all(x.shape[1] % 4 == 0 for x, _ in pairs) and m >= 512:
+        if ops.planes_enabled() and outs >= self._dw_planes_min and all(x.shape[1] % 4 == 0 for x, _ in pairs) and m >= 512:
             ap = ops.pack_planes_t(dz)
             for x, out in pairs:
                 if taps is None:
