@@ -425,6 +425,33 @@ def train_workload(args, rank, world, dev, dist):
                         "note": "achieved = algorithmic fp32-equivalent FLOPs (2*M*N*K) of this kernel family's launches in one update / their "
                                 "HIP-event durations; only the library's GEMM-class launches carry profile scopes"}
         launches_per_step = int(sum(v["launches"] for v in prof.values()))
+    # ---- the same update on the schedule a rank of an N-GPU job runs (VERDICT r3 #5c): a ONE-rank RCCL group, every bucket's
+    # all_reduce(AVG, async_op=True) issued from the weight-gradient stream while backward continues, waited for in optimizer_step()
+    dp_sched = None
+    if rank == 0 and world == 1 and not args.no_dp_schedule:
+        try:
+            import socket
+
+            import torch.distributed as dist1
+
+            from fcl_taco2_amd.training import GradBuckets
+
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            dist1.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
+            eng.buckets = GradBuckets(eng.gflat, eng.buckets.bounds, None, force=True)
+            for _ in range(max(2, warmup)):
+                step()
+            dts_dp = timed_regions(region, lambda: torch.cuda.synchronize(), max(3, args.regions // 2))
+            dp_sched = {"ms_per_step": 1e3 * median(dts_dp) / steps, "collectives_issued": eng.buckets.collectives,
+                        "note": "one-rank RCCL process group, FCL_DP_FORCE_COLLECTIVE schedule: 4 bucketed all_reduce(AVG, async) per update issued from the "
+                                "weight-gradient stream (identity result); what a rank of an N-GPU job enqueues, minus the wire time"}
+            eng.buckets = GradBuckets(eng.gflat, eng.buckets.bounds, None, force=False)
+            dist1.destroy_process_group()
+        except Exception as e:  # reported, never fatal: the headline figure above is already measured
+            dp_sched = {"error": repr(e)}
     name = "KD step" if kd else "teacher training step"
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -490,6 +517,8 @@ def train_workload(args, rank, world, dev, dist):
                        "note": "algorithmic %.0f MFLOP per frame per step (SURVEY.md §8d) x frames / measured step time (per GPU)" % mflop},
     }
     out["roofline"] = dom_roof if dom_roof is not None else dict(out["whole_step"], bound="mfma", kernel="whole step", traffic=None)
+    if dp_sched is not None:
+        out["dp_schedule"] = dp_sched
     if launches_per_step is not None:
         out["profiled_gemm_launches_per_step"], out["host_enqueue_ms"] = launches_per_step, host_ms
     if cpu is not None:
@@ -516,6 +545,7 @@ def main():
     ap.add_argument("--cap-slack", type=int, default=0, help="synthesis: decoder steps of the capacity graph beyond the longest duration of the batches it serves (each costs three launches that exit at once)")
     ap.add_argument("--eager", action="store_true", help="launch kernel by kernel instead of replaying captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dp-schedule", action="store_true", help="kd_step / teacher_step: skip the one-rank RCCL leg (the N-GPU schedule on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="kd_step: run teacher forward and student update back to back on one stream")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the bounded baseline sample")
@@ -549,7 +579,7 @@ def main():
         kd = run_child(["--workload", "kd_step", "--cpu-threads", str(args.cpu_threads)] + common + (["--no-cpu-baseline"] if args.no_cpu_baseline else []),
                        {}, 900)
         extras["kd_step"] = ({k: kd.get(k) for k in ("metric", "value", "unit", "ms_per_step", "steps", "frames_per_s", "dtype", "roofline", "cpu_baseline",
-                                                      "timing", "whole_step", "profiled_gemm_launches_per_step", "host_enqueue_ms", "config")} if "error" not in kd else kd)
+                                                      "timing", "whole_step", "profiled_gemm_launches_per_step", "host_enqueue_ms", "dp_schedule", "config")} if "error" not in kd else kd)
         fx = run_child(["--workload", "synthesis", "--model", args.model, "--batch", str(args.batch), "--streams", str(args.streams), "--no-cpu-baseline"]
                        + common, {"FCL_PRECISION": "0"}, 600)
         extras["fp32_exact"] = ({k: fx.get(k) for k in ("value", "unit", "ms_per_step", "dtype", "roofline", "timing")} if "error" not in fx else fx)
@@ -616,11 +646,10 @@ def main():
     # many batches in flight.  `--feed replay` = rounds 1-2: one prepared batch (host-built maps, outside the clock) replayed from a hipGraph;
     # --eager launches that pass kernel by kernel.
     host_maps = [engine.build_row_maps([len(x) for x in b[0]], b[1], T_CAP) for b in batches]
-    lmax_cap = max(m.lmax for m in host_maps) + args.cap_slack  # capacities = the maximum over the batches this graph serves (a batch beyond them is reported by the device)
-    bounds = np.ones(lmax_cap, dtype=np.int32)
-    for m in host_maps:
-        bounds[: m.lmax] = np.maximum(bounds[: m.lmax], m.live_rows)
-    caps = engine.Caps(lmax_cap, (max(bframes) + 255) // 256 * 256, bounds)
+    # capacities = the exact maximum over the batches this graph serves, forced durations: the BEST case.  The realistic forms -- the
+    # decode driver's calibrated capacities with slack and PREDICTED durations, and the driver itself -- ride on the same line as
+    # `value_calibrated_caps` / `value_decode_driver`.
+    caps = engine.Caps.for_batches(host_maps, slack_steps=args.cap_slack)
     fresh = args.feed == "fresh" and not args.eager
     if args.eager:
         streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [torch.cuda.current_stream()]
@@ -689,7 +718,8 @@ def main():
                    "streams_per_gpu": args.streams,
                    "timed_per_step": ("host packing of a NEW batch (%d distinct batches round-robin) into a pinned block + one hipGraph launch: the H2D pull of that "
                                       "block (ids, lengths, durations; fcl_feed_copy), encoder, predictors, device-built row maps (fcl_row_maps_build), decoder loop on device "
-                                      "live-row counts, postnet; capacities %d steps / %d frames, per-step row bounds = the batches' maximum"
+                                      "live-row counts, postnet; EXACT capacities, forced durations: %d steps / %d frames, per-step row bounds = the maximum over the fed batches "
+                                      "(best case; value_calibrated_caps / value_decode_driver are the calibrated-with-slack, predicted-duration forms)"
                                       % (len(batches), caps.lmax, caps.frames)) if fresh else
                                      ("kernel-by-kernel launches of one prepared batch (host-built maps outside the clock)" if args.eager else
                                       "hipGraph replay of one prepared batch (host-built maps outside the clock)")},
@@ -739,7 +769,68 @@ def main():
             out["predicted_durations"] = {"value": tot / pdt, "unit": "mel-frames/s", "ms_per_step": 1e3 * pdt / 40, "frames_per_batch": pframes,
                                           "note": "same feed, durations PREDICTED inside the graph (duration predictor -> clamp(round(exp(x) - 1), 0) -> device "
                                                   "row maps); synthetic duration head (log-durations ~ N(2.3, 0.35)) on the closed-form weights"}
-            del pr, plan_p
+            # ---- the same feed the way the decode driver sizes it: the bucket is calibrated on ONE eager batch (its exact maps),
+            # every count gets decode._grown_caps' shipped slack (steps x1.5 + 4, frames / live rows x1.3), the graph serves the other batches;
+            # durations predicted; a batch beyond the capacities is reported by the device and counted (the driver would re-run it eagerly)
+            from fcl_taco2_amd import decode as DEC
+
+            t_bucket = (max(len(x) for b in batches for x in b[0]) + 15) // 16 * 16  # the driver's padded-length bucket
+            ccaps = DEC._grown_caps(engine, cal[0], args.batch * t_bucket)
+            cr = [engine.BatchRunner(plan_p, args.batch, t_bucket, ccaps, forced=False, stream=runners[j].stream, seed=19 + j) for j in range(args.streams)]
+
+            def cpass(i):
+                r, j = cr[i % len(cr)], i % len(batches)
+                r.load(batches[j][0])
+                r.replay()
+                return pframes[j]
+
+            for i in range(8):
+                cpass(i)
+            torch.cuda.synchronize()
+            overflow = 0
+            for r in cr:
+                try:
+                    r.frames()
+                except Exception:
+                    overflow += 1
+            t1, tot = time.perf_counter(), 0
+            for i in range(40):
+                tot += cpass(i)
+            torch.cuda.synchronize()
+            cdt = time.perf_counter() - t1
+            for r in cr:
+                try:
+                    r.frames()
+                except Exception:
+                    overflow += 1
+            out["value_calibrated_caps"] = tot / cdt if overflow == 0 else None
+            out["calibrated_caps"] = {"value": tot / cdt, "unit": "mel-frames/s", "ms_per_step": 1e3 * cdt / 40, "frames_per_batch": pframes,
+                                      "overflowed_runners": overflow, "caps": {"steps": ccaps.lmax, "frames": ccaps.frames, "t_bucket": t_bucket},
+                                      "exact": {"steps": max(m.lmax for m in cal), "frames": max(m.n_frames for m in cal)},
+                                      "note": "fresh feed, PREDICTED durations, capacities = decode._grown_caps(the first batch's exact maps): the shipped slack of "
+                                              "the decode driver (steps x1.5 + 4, frames and live rows x1.3 + 32), padded-length bucket of 16"}
+            del cr, pr, plan_p
+            # ---- the decode driver itself (python -m fcl_taco2_amd.decode): length-sorted manifest, buckets of 16 phonemes, one eager calibration
+            # batch per bucket, graphs with slack, D2H of every mel, nothing written; second call = graphs already captured (steady state of a corpus)
+            S_, T_ = HP.student_hparams(), HP.teacher_hparams()
+            dmodel = SYN.build_model("student", S_, T_, dev).eval()
+            dsd = SYN.positive_duration_head(SYN.closed_form_state_dict(HP.param_spec(S_, T_, True)))
+            dmodel.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in dsd.items()})
+            dmodel = dmodel.to(dev).eval()
+            rng_d = np.random.RandomState(0)
+            dutts = [("utt%04d" % i, rng_d.randint(1, S_.idim, size=int(rng_d.randint(60, 101))).astype(np.int64)) for i in range(1024)]
+            st0, st1 = {}, {}
+            f_cold, s_cold = DEC.decode(dmodel, dutts, None, batch_size=args.batch, depth=args.streams, stats=st0)
+            f_d, s_d = DEC.decode(dmodel, dutts, None, batch_size=args.batch, depth=args.streams, stats=st1)
+            out["value_decode_driver"] = f_d / s_d
+            out["decode_driver"] = {"value": f_d / s_d, "unit": "mel-frames/s", "frames": f_d, "seconds": s_d, "device_seconds": st1["device_seconds"],
+                                    "first_call": {"value": f_cold / s_cold, "seconds": s_cold, **{k: v for k, v in st0.items() if k != "device_seconds"}},
+                                    "stats": {k: v for k, v in st1.items() if k != "device_seconds"},
+                                    "note": "fcl_taco2_amd.decode.decode(): 1 024 utterances of 60-100 phonemes, predicted durations, batch %d, %d graphs in flight, "
+                                            "synthesis + D2H of every mel into pinned memory, synchronised; first_call includes graph capture and one eager "
+                                            "calibration batch per bucket" % (args.batch, args.streams)}
+            DEC.release_graphs(dmodel)
+            del dmodel
 
         # ---- live roofline of the dominant kernel: HIP events around every launch; 5 profiled passes, per-kernel MEDIAN over the passes
         # (one pass in ~10 shows a single launch stretched by whatever else the box is doing; a sum would let that outlier pick the "dominant" kernel)

@@ -123,8 +123,17 @@ def _grown_caps(engine, maps, n_rows, scale=1.3):
     return engine.Caps(lmax, (int(maps.n_frames * scale) + 255) // 256 * 256, bounds)
 
 
+MAX_BUCKETS = 8  # captured-graph pools kept per (batch size, depth): least recently used buckets are released beyond this
+
+
+def release_graphs(model_or_plan):
+    """Drop every captured decode graph (and its pinned landing buffers) kept on the model's plan by earlier decode() calls."""
+    plan = model_or_plan.plan() if hasattr(model_or_plan, "plan") and callable(model_or_plan.plan) else model_or_plan
+    plan.__dict__.pop("_decode_cache", None)
+
+
 @torch.no_grad()
-def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None):
+def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None, keep_graphs=True, max_buckets=None):
     """utts: [(utt_id, ids)] or, for a model with spk_embed_dim, [(utt_id, ids, spemb)].  Writes PREFIX.ark/.scp (out_prefix None: nothing is written); returns (frames, seconds).
     Every batch runs as ONE captured graph with predicted durations (engine.BatchRunner): the host packs the phoneme ids, enqueues one
     graph launch (its first node pulls the packed block into HBM) and one D2H copy of the mel buffer + the per-utterance frame starts, and only synchronises on a batch when it
@@ -133,7 +142,11 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
     Utterances are sorted by length and bucketed by padded phoneme count (multiples of 16); the first batch of a bucket runs eagerly with the
     host round trip, which both produces its mels and calibrates the bucket's capacities (decoder steps, frames, live rows per step, with
     slack); a later batch that exceeds them is reported by the device (FCL_STATUS_*), re-run eagerly, and the bucket's capacities grow.  The
-    captured graphs stay with the model's plan: a second decode() on the same model replays them.
+    captured graphs stay with the model's plan: a second decode() on the same model replays them -- at most `max_buckets` (MAX_BUCKETS) length
+    buckets per (batch size, depth), least recently used first out (each holds up to `depth` graphs with private memory pools and two pinned
+    landing buffers per graph); keep_graphs=False releases all of them when the call returns (release_graphs() does it later).
+    An error inside the loop (a zero-duration phoneme raising like the reference, a failing writer) still drains the device, stops the writer
+    thread and closes the ark before it propagates.
     stats (dict, optional): receives `device_seconds` — first submit -> last batch complete on the GPU, excluding the ark writing."""
     from . import engine, ops
 
@@ -149,9 +162,12 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
     depth = max(1, int(depth))
     cache = plan.__dict__.setdefault("_decode_cache", {})
     streams = cache.setdefault(("streams", depth), [torch.cuda.Stream(device=dev) for _ in range(depth)])
-    pools = cache.setdefault(("pools", batch_size, depth), {})
+    import collections
+
+    pools = cache.setdefault(("pools", batch_size, depth), collections.OrderedDict())
+    max_buckets = max(1, int(MAX_BUCKETS if max_buckets is None else max_buckets))
     pending = []
-    n_eager = n_graph = n_redo = 0
+    n_eager = n_graph = n_redo = n_evict = 0
 
     # the ark / scp file is written by a worker thread (file writes release the GIL): storage keeps up with the GPU instead of stalling the loop
     wq = queue.Queue(maxsize=4 * (depth + 1))
@@ -213,54 +229,82 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
         th.start()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for bi, s in enumerate(range(0, len(order), batch_size)):
-            chunk = [utts[i] for i in order[s : s + batch_size]]
-            t_cap = (max(len(u[1]) for u in chunk) + 15) // 16 * 16
-            pool = pools.get(t_cap)
-            if pool is not None and pool.grow is not None:  # a batch overflowed this bucket: drain it, widen the capacities, capture anew
-                for it in [p_ for p_ in pending if p_[0] is pool]:
+        try:
+            for bi, s in enumerate(range(0, len(order), batch_size)):
+                chunk = [utts[i] for i in order[s : s + batch_size]]
+                t_cap = (max(len(u[1]) for u in chunk) + 15) // 16 * 16
+                pool = pools.get(t_cap)
+                if pool is not None:
+                    pools.move_to_end(t_cap)
+                if pool is not None and pool.grow is not None:  # a batch overflowed this bucket: drain it, widen the capacities, capture anew
+                    for it in [p_ for p_ in pending if p_[0] is pool]:
+                        pending.remove(it)
+                        frames += harvest(it)
+                    g = _grown_caps(engine, pool.grow, batch_size * t_cap, scale=1.6)
+                    lmax = max(g.lmax, pool.caps.lmax)
+                    caps = engine.Caps(lmax, max(g.frames, pool.caps.frames), np.full(lmax, batch_size * t_cap, np.int32))
+                    pool = pools[t_cap] = _Pool(plan, batch_size, t_cap, caps, streams, seed + 31 * bi)
+                if pool is None:  # first batch of the bucket: eager pass = its result + the bucket's calibration
+                    got, maps = eager(chunk)
+                    frames += got
+                    n_eager += 1
+                    pools[t_cap] = _Pool(plan, batch_size, t_cap, _grown_caps(engine, maps, batch_size * t_cap), streams, seed + 31 * bi)
+                    while len(pools) > max_buckets:  # least recently used bucket out: its batches in flight are harvested first
+                        old_cap, old_pool = next(iter(pools.items()))
+                        for it in [p_ for p_ in pending if p_[0] is old_pool]:
+                            pending.remove(it)
+                            frames += harvest(it)
+                        for sl in [x for pair in old_pool.slots if pair for x in pair]:
+                            sl.free.wait()  # the writer thread still reads the pinned landing buffers it was handed
+                        del pools[old_cap]
+                        n_evict += 1
+                    continue
+                j = pool.next % len(streams)
+                pool.next += 1
+                for it in [p_ for p_ in pending if p_[1] == j]:  # stream j's previous batch (of any bucket) must have left the runner's static buffers
                     pending.remove(it)
                     frames += harvest(it)
-                g = _grown_caps(engine, pool.grow, batch_size * t_cap, scale=1.6)
-                lmax = max(g.lmax, pool.caps.lmax)
-                caps = engine.Caps(lmax, max(g.frames, pool.caps.frames), np.full(lmax, batch_size * t_cap, np.int32))
-                pool = pools[t_cap] = _Pool(plan, batch_size, t_cap, caps, streams, seed + 31 * bi)
-            if pool is None:  # first batch of the bucket: eager pass = its result + the bucket's calibration
-                got, maps = eager(chunk)
-                frames += got
-                n_eager += 1
-                pools[t_cap] = _Pool(plan, batch_size, t_cap, _grown_caps(engine, maps, batch_size * t_cap), streams, seed + 31 * bi)
-                continue
-            j = pool.next % len(streams)
-            pool.next += 1
-            for it in [p_ for p_ in pending if p_[1] == j]:  # stream j's previous batch (of any bucket) must have left the runner's static buffers
-                pending.remove(it)
-                frames += harvest(it)
-            r = pool.runner(j)
-            slot = pool.slots[j][(pool.next // len(streams)) % 2]
-            slot.free.wait()  # the writer thread is done with what this landing buffer held
-            slot.free.clear()
-            r.load([u[1] for u in chunk], spembs=spk_of(chunk))
-            r.replay()
-            with torch.cuda.stream(r.stream):
-                slot.mel.copy_(r.mel, non_blocking=True)
-                slot.f0.copy_(r._frames.utt_frame0, non_blocking=True)
-                slot.st.copy_(r.status, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(r.stream)
-            pending.append((pool, j, chunk, slot, ev))
-            n_graph += 1
-        while pending:
-            frames += harvest(pending.pop(0))
-        torch.cuda.synchronize()
-        dev_secs = time.perf_counter() - t0
-        wq.put(None)
-        th.join()
+                r = pool.runner(j)
+                slot = pool.slots[j][(pool.next // len(streams)) % 2]
+                slot.free.wait()  # the writer thread is done with what this landing buffer held
+                slot.free.clear()
+                try:
+                    r.load([u[1] for u in chunk], spembs=spk_of(chunk))
+                except Exception:
+                    slot.free.set()
+                    raise
+                r.replay()
+                with torch.cuda.stream(r.stream):
+                    slot.mel.copy_(r.mel, non_blocking=True)
+                    slot.f0.copy_(r._frames.utt_frame0, non_blocking=True)
+                    slot.st.copy_(r.status, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(r.stream)
+                pending.append((pool, j, chunk, slot, ev))
+                n_graph += 1
+            while pending:
+                frames += harvest(pending.pop(0))
+            torch.cuda.synchronize()
+            dev_secs = time.perf_counter() - t0
+        except BaseException:
+            # graphs already launched keep copying into the pinned landing buffers: wait for the device, hand the slots back, and let the
+            # writer finish what it was given -- then the ark is closed by the `with` and the error propagates
+            torch.cuda.synchronize()
+            for it in pending:
+                it[0].runners[it[1]].status.zero_()
+                it[3].free.set()
+            del pending[:]
+            raise
+        finally:
+            wq.put(None)
+            th.join()
+            if not keep_graphs:
+                release_graphs(plan)
         secs = time.perf_counter() - t0
         if werr:
             raise werr[0]
     if stats is not None:
-        stats.update(device_seconds=dev_secs, eager_batches=n_eager, graph_batches=n_graph, redone_batches=n_redo, buckets=len(pools))
+        stats.update(device_seconds=dev_secs, eager_batches=n_eager, graph_batches=n_graph, redone_batches=n_redo, buckets=len(pools), evicted_buckets=n_evict)
     return frames, secs
 
 

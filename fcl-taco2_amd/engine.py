@@ -146,6 +146,17 @@ class Caps(object):
         return Caps(maps.lmax, maps.n_frames, maps.live_rows)
 
     @staticmethod
+    def for_batches(host_maps, slack_steps=0, frame_round=256):
+        """Exact capacities of a KNOWN set of batches (their host-built maps): steps = the longest duration (+ slack_steps), frames = the largest
+        total rounded up to `frame_round`, per-step row bounds = the maximum over the batches.  This is the best case -- what bench.py's headline
+        line uses for the four batches it feeds; a driver that cannot know its batches in advance calibrates with slack (decode._grown_caps)."""
+        lmax = max(m.lmax for m in host_maps) + int(slack_steps)
+        bounds = np.ones(lmax, dtype=np.int32)
+        for m in host_maps:
+            bounds[: m.lmax] = np.maximum(bounds[: m.lmax], m.live_rows)
+        return Caps(lmax, (max(m.n_frames for m in host_maps) + frame_round - 1) // frame_round * frame_round, bounds)
+
+    @staticmethod
     def generous(n_rows, lmax, frames):
         """Capacities that hold for ANY durations up to lmax per phoneme and `frames` in total: every step may keep every row."""
         return Caps(lmax, frames, np.full(lmax, n_rows, dtype=np.int32))
@@ -561,6 +572,23 @@ class BatchRunner(object):
         if (durs is not None) != self.forced:
             raise ValueError("BatchRunner(forced=%s): durations %s" % (self.forced, "missing" if self.forced else "not taken (the graph predicts them)"))
         B, T, n = self.B, self.T, self.B * self.T
+        # every check first: the pinned block is only repacked once the whole batch is known to fit (a load() that raises leaves the previous
+        # batch in place, so a replay() after a caught error still runs a consistent block)
+        as_np = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        xs = [as_np(x).reshape(-1) for x in xs]
+        ln = np.fromiter((x.shape[0] for x in xs), np.int32, nb)
+        if int(ln.max()) > T or int(ln.min()) < 1:
+            raise ValueError("BatchRunner: utterances of %d..%d phonemes, capacity %d" % (int(ln.min()), int(ln.max()), T))
+        dcat = None
+        if durs is not None:
+            if len(durs) != nb or any(np.asarray(d).size != k for d, k in zip(durs, ln)):
+                raise ValueError("duration count != phoneme count")
+            dcat = np.concatenate([np.asarray(d).reshape(-1) for d in durs])
+        spk_rows = None
+        if self.S:
+            spk_rows = [as_np(v).reshape(-1) for v in spembs]
+            if len(spk_rows) != nb or any(v.shape[0] != self.S for v in spk_rows):
+                raise ValueError("BatchRunner: speaker embeddings must be %d vectors of %d values" % (nb, self.S))
         j = self._slot % len(self._host)
         self._slot += 1
         if self._ingraph:
@@ -570,11 +598,6 @@ class BatchRunner(object):
         hb = self._host[j].numpy()
         seg = lambda name, dt: hb[self._off[name][0] : self._off[name][0] + self._off[name][1]].view(dt)
         ids, dur, lens = seg("ids", np.int64), seg("dur", np.int32), seg("lens", np.int32)
-        as_np = lambda v: v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
-        xs = [as_np(x).reshape(-1) for x in xs]
-        ln = np.fromiter((x.shape[0] for x in xs), np.int32, nb)
-        if int(ln.max()) > T or int(ln.min()) < 1:
-            raise ValueError("BatchRunner: utterances of %d..%d phonemes, capacity %d" % (int(ln.min()), int(ln.max()), T))
         lens[:nb] = ln
         lens[nb:] = 0
         b_of, t_of, base = self._rows
@@ -582,17 +605,14 @@ class BatchRunner(object):
         valid = t_of < lfull  # the non-padded rows, row-major: exactly the order of the concatenated utterances
         ids[:] = 0
         ids[valid] = np.concatenate(xs)
-        if durs is not None:
-            dcat = np.concatenate([np.asarray(d).reshape(-1) for d in durs])
-            if dcat.shape[0] != int(ln.sum()) or any(np.asarray(d).size != k for d, k in zip(durs, ln)):
-                raise ValueError("duration count != phoneme count")
+        if dcat is not None:
             dur[:] = 0
             dur[valid] = dcat
         if self.S:
             sp = seg("spk", np.float32).reshape(B, self.S)
             sp[nb:] = 0.0
-            for i_, v in enumerate(spembs):
-                sp[i_] = as_np(v).reshape(-1)
+            for i_, v in enumerate(spk_rows):
+                sp[i_] = v
         seg("seg_lo", np.int32)[:] = base
         np.add(base, lfull, out=seg("seg_hi", np.int32))
         np.logical_not(valid, out=seg("pad", np.uint8).view(np.bool_))

@@ -62,19 +62,29 @@ class GradBuckets(object):
     is final; the collective runs on the backend's own stream while the caller keeps producing the later buckets; finish() waits for all.
     gloo + device tensors (the 2-processes-on-one-GPU test): buckets are staged through host memory in finish(), without overlap."""
 
-    def __init__(self, flat, bounds, group=None):
+    def __init__(self, flat, bounds, group=None, force=None):
+        """force: run the collective branch for a ONE-rank group too (default: the FCL_DP_FORCE_COLLECTIVE environment flag).  A one-rank
+        `nccl` group then executes exactly what a rank of an N-GPU job executes -- all_reduce(AVG, async_op=True) on slices of the flat device
+        buffer, ordered against the compute streams -- with the identity as its result: the single-GPU test / timing of the data-parallel schedule."""
         import torch.distributed as dist
 
         self.flat, self.bounds, self.group, self.work, self.staged, self.launched = flat, bounds, group, [], [], set()
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        backend = dist.get_backend(group) if self.world > 1 else None
+        ready = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ready else 1
+        if force is None:
+            force = os.environ.get("FCL_DP_FORCE_COLLECTIVE", "0") not in ("", "0")
+        self.active = self.world > 1 or (bool(force) and ready)
+        backend = dist.get_backend(group) if self.active else None
         self.avg = backend == "nccl"
         self.stage_host = backend == "gloo" and flat.is_cuda
+        self.collectives = 0  # all_reduce calls issued so far (tests assert the branch really ran)
 
     def launch(self, i):
         """Start averaging bucket i.  Once per optimizer step: with gradient accumulation only the LAST micro-batch may launch (an in-flight
-        all-reduce must not overlap the next micro-batch's writes into the same gradient memory), so a second launch before finish() raises."""
-        if self.world == 1:
+        all-reduce must not overlap the next micro-batch's writes into the same gradient memory), so a second launch before finish() raises.
+        The collective is ordered behind the CURRENT stream (torch's ProcessGroupNCCL makes its own stream wait for it): the caller issues it
+        from the stream that wrote the bucket last."""
+        if not self.active:
             return
         import torch.distributed as dist
 
@@ -89,6 +99,7 @@ class GradBuckets(object):
             return
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
         self.work.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
+        self.collectives += 1
 
     def finish(self, scale_fn=None):
         import torch.distributed as dist
@@ -104,7 +115,7 @@ class GradBuckets(object):
         reduced, self.launched = bool(self.launched), set()
         if not reduced:
             return
-        if self.world > 1 and not self.avg:
+        if self.active and not self.avg:
             (scale_fn or (lambda t, s: t.mul_(s)))(self.flat, 1.0 / self.world)
 
 
@@ -498,11 +509,21 @@ class TrainEngine(object):
             self._dw_keep.clear()  # main-stream reuse of these buffers is ordered after the join
 
     def _launch_bucket(self, c, i):
+        """Bucket i's gradients are final once (a) the main stream has reached this point (BatchNorm / LayerNorm / bias gradients are written
+        there) and (b) the weight-gradient stream has run the closures enqueued so far.  The collective is therefore issued FROM the
+        weight-gradient stream after it has waited for the main stream's position -- a wait every later _dw() would make anyway -- and RCCL's
+        stream orders itself behind that: the main stream, i.e. the backward's critical path, never waits for weight gradients here (until round 4
+        it joined the side stream at every bucket, which since round 3 also carries the predictors' and the late KD terms' backward)."""
         if not c.reduce:  # a micro-batch that is not the last of its accumulation (or the autograd path): gradients stay local
             return
-        if self.buckets.world > 1:
-            self._join_dw()
-        self.buckets.launch(i)
+        if not self.buckets.active:
+            return
+        if self.side is None:
+            self.buckets.launch(i)
+            return
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.side):
+            self.buckets.launch(i)
 
     def param_offsets(self):
         """{parameter name: (offset, numel, shape)} into pflat / gflat / mflat / vflat (checkpoint writers)."""
@@ -694,9 +715,11 @@ class TrainEngine(object):
     @contextlib.contextmanager
     def _pred_ctx(self):
         with torch.cuda.stream(self.pstream):
-            yield
-            self._pred_ev = torch.cuda.Event()
-            self._pred_ev.record(self.pstream)  # (the join waits for the predictors, not for weight gradients queued behind them)
+            try:
+                yield
+            finally:  # also when the body raises: whatever it enqueued is joined, never left racing the next step's arena clear
+                self._pred_ev = torch.cuda.Event()
+                self._pred_ev.record(self.pstream)  # (the join waits for the predictors, not for weight gradients queued behind them)
 
     def _pred_join(self):
         if self._pred_ev is not None:
@@ -713,9 +736,11 @@ class TrainEngine(object):
             return
         self.pstream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.pstream):
-            yield
-            self._late_ev = torch.cuda.Event()
-            self._late_ev.record(self.pstream)
+            try:
+                yield
+            finally:
+                self._late_ev = torch.cuda.Event()
+                self._late_ev.record(self.pstream)
 
     def _late_join(self):
         if self._late_ev is not None:
@@ -1200,8 +1225,8 @@ class TrainEngine(object):
         if "enc0" in inj:
             ops.add2d(dx, inj["enc0"])
         self._dw(lambda: ops.scatter_add_rows(dx, c.xs, G["enc.embed.weight"], skip=0))  # padding_idx = 0 gets no gradient
-        self._join_dw()
         self._launch_bucket(c, 3)
+        self._join_dw()
 
     # ------------------------------------------------------------------------------------------------ public API
     def zero_grad(self):
@@ -1212,7 +1237,13 @@ class TrainEngine(object):
             raise ValueError("mode must be 'eval' or 'train'")
         c = _Ctx()
         c.train, c.masks, c.save, c.reduce = mode == "train", masks, save, reduce
-        self.arena.begin()  # (every consumer of the previous pass's scratch has been joined: _backward ends with _join_dw())
+        if self.side is not None:
+            # the arena's clear must not depend on the previous step having ENDED with _join_dw() (a step that raised half way leaves weight
+            # gradients / predictor launches queued on the side stream): order this step behind everything that stream still holds
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self._dw_keep.clear()
+            self._pred_ev = self._late_ev = None
+        self.arena.begin()
         self.forward_count += 1
         c.draw = self.forward_count
         self._maps(c, batch)

@@ -615,6 +615,88 @@ def test_two_process_data_parallel_step_on_one_gpu():
     assert l0 != l1 and g0 == pytest.approx(g1, rel=1e-9)  # different local losses, one global grad-norm (fp64 atomics: last-bit order noise)
 
 
+def _nccl_one_rank_worker(port, q):
+    """A ONE-rank `nccl` (= RCCL) process group on cuda:0 with FCL_DP_FORCE_COLLECTIVE: the engine then runs, for every bucket of every update,
+    exactly what a rank of an N-GPU job runs -- dist.all_reduce(AVG, async_op=True) on a slice of the flat gradient buffer, issued from the
+    weight-gradient stream behind the main stream's position, waited for in optimizer_step() -- with the identity as the collective's result."""
+    import torch.distributed as dist
+
+    from fcl_taco2_amd import hparams as HP, synthetic as SYN
+    from fcl_taco2_amd.converter import CustomConverter
+    from fcl_taco2_amd.training import KDPipeline, TrainEngine
+
+    try:
+        S, T = HP.student_hparams(), HP.teacher_hparams()
+        bs = []
+        for sd_ in (5, 6):
+            xs, ys, ds, f0, en = SYN.training_batch(80, S.idim, batch=8, t_lo=60, t_hi=100, seed=sd_, zero_frac=0.03, lam=10.0, hi=50)
+            bs.append(CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)]))
+
+        def run(n_steps=3):
+            teng = TrainEngine(SYN.build_model("kd_teacher", T, None, DEV), seed=11)
+            eng = TrainEngine(SYN.build_model("student", S, T, DEV), seed=5)
+            pipe = KDPipeline(teng, eng)
+            losses = []
+            for i in range(n_steps):
+                losses.append(float(pipe.step(bs[i % 2], bs[(i + 1) % 2] if i + 1 < n_steps else None)["loss"]))
+            torch.cuda.synchronize()
+            return losses, eng.pflat.clone(), eng
+
+        l0, w0, e0 = run()  # no process group: the world-1 schedule (no collective, buckets inactive)
+        assert not e0.buckets.active and e0.buckets.collectives == 0
+        os.environ["FCL_DP_FORCE_COLLECTIVE"] = "1"
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(DEV))
+        l1, w1, e1 = run()
+        assert e1.buckets.active and e1.buckets.avg and e1.buckets.world == 1
+        n_coll = e1.buckets.collectives
+        # the collective alone: AVG over one rank is the identity, bit for bit, on every bucket
+        e1.zero_grad()
+        e1.forward_backward(bs[0], teacher_knowledge=TrainEngine(SYN.build_model("kd_teacher", T, None, DEV), seed=11).knowledge(bs[0], mode="train"),
+                            mode="train", reduce=False)
+        torch.cuda.synchronize()
+        g_local = e1.gflat.clone()
+        for i in range(len(e1.buckets.bounds) - 1):
+            e1.buckets.launch(i)
+        e1.buckets.finish()
+        torch.cuda.synchronize()
+        ident = bool(torch.equal(e1.gflat, g_local))
+        dist.destroy_process_group()
+        q.put(("ok", l0, l1, float((w0 - w1).abs().max()), float((w0 - w1).abs().mean()), n_coll, ident))
+    except Exception as e:  # pragma: no cover - reported to the parent
+        import traceback
+
+        q.put(("error", traceback.format_exc() + repr(e)))
+
+
+def test_one_rank_nccl_group_runs_the_data_parallel_branch_on_one_gpu():
+    """the RCCL branch of GradBuckets had never executed.  A one-rank nccl group with FCL_DP_FORCE_COLLECTIVE runs the
+    N-GPU schedule on the one GPU of the test box (full FCL-taco2-S / -T dims, 8 utterances, the KD pipeline, train mode, device RNG with fixed
+    seeds): three updates equal the three updates of the no-group engine up to the summation-order noise of atomically accumulated gradients (a
+    collective racing the streams that write its bucket would show O(1) differences), 4 buckets x 3 updates were issued, and the collective
+    itself returns its input bit for bit."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert res[0] == "ok", res[1]
+    _, l0, l1, wmax, wmean, n_coll, ident = res
+    assert n_coll == 12, n_coll
+    assert ident
+    assert l0[0] == pytest.approx(l1[0], rel=1e-9) and l0 == pytest.approx(l1, rel=1e-4)
+    assert wmax <= 2 * 1e-3 * 3 and wmean < 1e-5  # sign-flip bound of three Adam steps / mean, as in test_kd_pipeline_equals_sequential_updates
+
+
 def test_full_size_kd_step_properties():
     """BASELINE-size dims (FCL-taco2-S student, FCL-taco2-T teacher, 8 utterances of 60-100 phonemes) through size-independent properties:
     (1) the training engine's eval-form forward and the synthesis-path teacher-forced forward() are two independent implementations of the same
