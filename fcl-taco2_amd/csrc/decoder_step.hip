@@ -689,6 +689,299 @@ __global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetA
     }
 }
 
+// ---- round 4: the same chain with TRANSPOSED accumulators and (optionally) prenet layer 1's columns split over NS workgroups per row tile.
+// Where feat_prenet_fast_kernel's 14 us go (r4 phase stamps, 2 400 rows: launch floor 3.6, feat_out +2.5..3.4, layer 0 +3.0..3.5, layer 1 +3.6..3.9):
+// not into the weight stream alone -- a first column-split form that only cut the fragments per workgroup from 442 to 245 KB ran exactly as long --
+// but into the per-ELEMENT epilogues.  With the activations as the MFMA's A operand a lane ends up with ONE column of FOUR rows: every finished
+// element then costs its own bias / mask load, its own counter hash, its own fp32 -> (hi, lo) split, two 2-byte LDS stores and up to five scattered
+// 2- / 4-byte global stores with 64-bit address arithmetic: ~30 VALU + ~5 memory instructions per element, 16 - 32 elements per lane and phase, two
+// waves per SIMD.  Swapping the operands (weights as A, activations as B: the same fragments, the same products in the same order, D^T instead of D)
+// gives a lane FOUR CONSECUTIVE COLUMNS of ONE row: one float4 bias / F0 load, one 4-byte mask load, two hashes (16 bits per decision), one packed
+// split (v_cvt_pk_bf16_f32), two 8-byte LDS stores = the next layer's operand, and 8- / 16-byte global stores (the P32 line's hi and lo halves,
+// the fp32 frame) -- about a quarter of the instructions.
+// Column split NS (gridDim.y): a workgroup owns 16 RT rows x 256 / NS columns of layer 1 and recomputes feat_out and layer 0 for its rows (61 k of
+// the 127 k weights): 82 + 98 + 262 / NS KB of fragments per workgroup, NS x the workgroups; split 0 alone stores feat_out.  NS = 1: no split.
+// The layer-1 operand tile re-uses the h1 tile's LDS (96 KB at RT = 4).  All fragments are requested at entry (layer 1's once the h1 staging
+// registers are free); no __syncthreads (its vmcnt(0) would wait for every fragment before the first phase).
+// RNG mode draws a different (equally distributed) stream than the other feat/prenet kernels: 16 bits of a counter hash per decision instead of 24.
+__device__ __forceinline__ void p32_store4(unsigned short* __restrict__ p, int ld, long long m, int n, uint2 hi, uint2 lo) {
+    unsigned short* line = p + ((size_t)m * ld + (n >> 5)) * 64 + (n & 31);
+    *reinterpret_cast<uint2*>(line) = hi;
+    *reinterpret_cast<uint2*>(line + 32) = lo;
+}
+
+template <int NT, int NS_>
+__device__ __forceinline__ void mma_t(const WFrag<NT, NS_>& w, const u16* Ah, const u16* Al, int ldk, int r16, int kq, f32x4 (&out)[NT]) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const u16* ah = Ah + r16 * ldk + kq * 8;
+    const u16* al = Al + r16 * ldk + kq * 8;
+#pragma unroll
+    for (int st = 0; st < NS_; ++st) {
+        const s16x8 a_hi = *reinterpret_cast<const s16x8*>(ah + st * 32);
+        const s16x8 a_lo = *reinterpret_cast<const s16x8*>(al + st * 32);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi[t][st], a_lo, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.lo[t][st], a_hi, acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.hi[t][st], a_hi, acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t] = acc[t];
+}
+
+// dropout of four consecutive columns n .. n + 3 of row m (DROP: 0 none, 1 mask bytes, 2 counter hash: 16 bits per decision)
+template <int DROP>
+__device__ __forceinline__ f32x4 drop4(f32x4 v, unsigned int keep4, unsigned int idx, unsigned int seed, unsigned int thr16, float scale) {
+    if (DROP == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((keep4 >> (8 * r)) & 0xFFu) ? v[r] * scale : 0.f;
+    }
+    if (DROP == 2) {
+        const unsigned int h0 = hash_u32(idx ^ seed), h1 = hash_u32((idx + 2u) ^ seed);
+        v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * scale : 0.f;
+        v[1] = (h0 >> 16) >= thr16 ? v[1] * scale : 0.f;
+        v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * scale : 0.f;
+        v[3] = (h1 >> 16) >= thr16 ? v[3] * scale : 0.f;
+    }
+    return v;
+}
+
+template <int DROP, int RT, int NS>
+__global__ __launch_bounds__(512) void feat_prenet_split_kernel(const FeatPrenetArgs a) {
+    constexpr int SU = 8, SO = 3, SP = 8, U = 256, OP = 96, P = 256, CT = 16 / NS, NW1 = CT < 8 ? CT : 8, T1 = CT / NW1;
+    static_assert(NS == 1 || NS == 2 || NS == 4 || NS == 8, "layer-1 column split");
+    const int M_feat = a.M_feat, M_pre = a.M_pre;
+    const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    const int split = blockIdx.y;
+    if (a.live && a.w0 && blockIdx.x == 0 && split == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * (16 * RT) >= (a.h1 ? Ms_feat : Ms_pre)) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier)
+    constexpr int ldU = U + 16, ldO = OP + 16, ldP = P + 16, ROWS = 16 * RT;
+    static_assert(ldU == ldP, "the layer-1 operand tile re-uses the h1 tile's LDS");
+    extern __shared__ __attribute__((aligned(16))) u16 fp_lds[];
+    u16* A1h = fp_lds;
+    u16* A1l = A1h + ROWS * ldU;
+    u16* A2h = A1l + ROWS * ldU;
+    u16* A2l = A2h + ROWS * ldO;
+    u16* A3h = A1h;  // written in phase 2, when every wave is past its last read of the h1 tile (the barrier that ends phase 1)
+    u16* A3l = A1l;
+    const int O = a.O;
+    const int m0 = blockIdx.x * ROWS;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;   // operand fragments: row / column r16, k-group kq
+    const int arow = lane & 15, cq = lane >> 4;  // transposed accumulators: activation row arow, columns cq * 4 .. cq * 4 + 3 of the column tile
+    const bool has_feat = a.h1 != nullptr, has_pre = a.w0 != nullptr && m0 < M_pre;
+    if (!has_pre && split != 0) return;  // feat-only launch (after the last step): one workgroup per row tile does it
+    const bool feat_wave = has_feat && wave * 16 < O;
+    const bool l1_wave = has_pre && wave >= 8 - NW1;
+    const size_t lane8 = (size_t)lane * 8;
+    auto frag = [&](const u16* base, int tile, int ns) { return base + (size_t)tile * ns * 512 + lane8; };
+    const int t0 = wave, t1 = wave + 8;                   // this wave's layer-0 column tiles
+    const int c1 = split * CT + (wave - (8 - NW1)) * T1;  // first of this wave's T1 layer-1 column tiles (l1_wave only)
+
+    // ---- phase 0 operands first (loads return in order: the first wait then covers the h1 rows alone) ---------------------------------------
+    constexpr int HV = RT * 2;  // float4 loads of h1 per thread: ROWS x 64 float4 over 512 threads
+    f32x4 hreg[HV];
+    if (has_feat) {
+#pragma unroll
+        for (int j = 0; j < HV; ++j) {
+            const int i = threadIdx.x + j * 512, r = i >> 6, c = (i & 63) * 4;
+            hreg[j] = *reinterpret_cast<const f32x4*>(a.h1 + (size_t)min(m0 + r, M_feat - 1) * U + c);
+        }
+    }
+    // The CU's address path serves its 8 waves' requests in ISSUE order (one 1 KB wave-load per 16 clocks): a wave that runs ahead and queues its 30 - 44
+    // fragment loads puts them in front of the other waves' h1 loads, and phase 0 ends at a barrier -- so the phase used to wait for ~2 us of weight
+    // traffic it does not need (r4).  An s_barrier (no data wait: ~100 clocks) between the request groups makes the queue's order the order of use:
+    // every wave's h1 rows, then feat_out's fragments, then layer 0's, then layer 1's.
+    asm volatile("s_barrier" ::: "memory");
+    // ---- weight fragments and epilogue operands of phases 1 and 2, requested now ------------------------------------------------------------------
+    WFrag<1, SU> ff;
+    WFrag<2, SO> f0;
+    WFrag<T1, SP> f1;
+    const int fnc = wave * 16 + cq * 4;  // feat_out columns fnc .. fnc + 3 of this lane (whole groups of four: O % 4 == 0)
+    f32x4 f0v[RT];
+    int fo[RT];
+    if (feat_wave) {
+        const u16* const wh[1] = {frag(a.wf_hi, wave, SU)};
+        const u16* const wl[1] = {frag(a.wf_lo, wave, SU)};
+        ff.load(wh, wl);
+    }
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        f0v[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        fo[q] = 0;
+        if (feat_wave && fnc < O) {
+            const int mc = min(m0 + q * 16 + arow, M_feat - 1);
+            f0v[q] = *reinterpret_cast<const f32x4*>(a.F0 + (size_t)mc * O + fnc);
+            if (split == 0) fo[q] = a.frame_off[mc];
+        }
+    }
+    unsigned int seed0 = 0, seed1 = 0;
+    const unsigned int thr16 = (unsigned int)(a.drop_p * 65536.0f);
+    if (DROP == 2) {
+        const unsigned int sbump = a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u;
+        seed0 = hash_u32(a.seed0 + sbump);
+        seed1 = hash_u32(a.seed1 + sbump);
+    }
+    f32x4 pb0[2], pb1[T1];
+    unsigned int k0[RT][2], k1[RT][T1];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) pb0[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (has_feat) asm volatile("s_barrier" ::: "memory");  // (feat_out's fragments are queued before anybody's layer-0 fragments)
+    if (has_pre) {
+        const u16* const wh0[2] = {frag(a.w0_hi, t0, SO), frag(a.w0_hi, t1, SO)};
+        const u16* const wl0[2] = {frag(a.w0_lo, t0, SO), frag(a.w0_lo, t1, SO)};
+        f0.load(wh0, wl0);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + cq * 4;
+            pb0[tt] = *reinterpret_cast<const f32x4*>(a.b0 + nc);
+            if (DROP == 1) {
+#pragma unroll
+                for (int q = 0; q < RT; ++q) k0[q][tt] = *reinterpret_cast<const unsigned int*>(a.keep0 + (size_t)min(m0 + q * 16 + arow, M_pre - 1) * P + nc);
+            }
+        }
+    }
+    // ---- phase 0: h1 tiles -> LDS planes; prenet-input tiles zeroed (prev_out = 0 at t = 0; zero padding past O otherwise) ------------------
+    for (int i = threadIdx.x; i < ROWS * ldO / 8; i += 512) {
+        reinterpret_cast<uint4*>(A2h)[i] = make_uint4(0, 0, 0, 0);
+        reinterpret_cast<uint4*>(A2l)[i] = make_uint4(0, 0, 0, 0);
+    }
+    if (has_feat) {
+#pragma unroll
+        for (int j = 0; j < HV; ++j) {
+            const int i = threadIdx.x + j * 512, r = i >> 6, c = (i & 63) * 4;
+            uint2 h, l;
+            split4(hreg[j], h, l);
+            *reinterpret_cast<uint2*>(A1h + r * ldU + c) = h;
+            *reinterpret_cast<uint2*>(A1l + r * ldU + c) = l;
+        }
+    }
+    // layer-1 fragments: requested once the h1 staging registers are free (they are consumed last; the stream behind feat_out / layer 0 is
+    // unbroken) -- NS = 1 (all 16 column tiles: 128 VGPRs of fragments): once feat_out's fragments are dead too, i.e. after phase 1
+#pragma unroll
+    for (int tt = 0; tt < T1; ++tt) pb1[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto request_l1 = [&]() {
+        if (l1_wave) {
+            const u16* wh1[T1];
+            const u16* wl1[T1];
+#pragma unroll
+            for (int tt = 0; tt < T1; ++tt) {
+                wh1[tt] = frag(a.w1_hi, c1 + tt, SP);
+                wl1[tt] = frag(a.w1_lo, c1 + tt, SP);
+            }
+            f1.load(wh1, wl1);
+#pragma unroll
+            for (int tt = 0; tt < T1; ++tt) {
+                const int nc = (c1 + tt) * 16 + cq * 4;
+                pb1[tt] = *reinterpret_cast<const f32x4*>(a.b1 + nc);
+                if (DROP == 1) {
+#pragma unroll
+                    for (int q = 0; q < RT; ++q) k1[q][tt] = *reinterpret_cast<const unsigned int*>(a.keep1 + (size_t)min(m0 + q * 16 + arow, M_pre - 1) * P + nc);
+                }
+            }
+        }
+    };
+    if (NS > 1) {
+        asm volatile("s_barrier" ::: "memory");  // (layer 0's fragments are queued before anybody's layer-1 fragments)
+        request_l1();
+    }
+    lds_barrier();
+    if (a.dbg_phase == 1) return;
+    // ---- phase 1: H8 feat_out of the previous step (+ H10 scatter by split 0) -----------------------------------------------------------------
+    if (feat_wave) {
+#pragma unroll
+        for (int q = 0; q < RT; ++q) {
+            f32x4 accv[1];
+            mma_t<1, SU>(ff, A1h + q * 16 * ldU, A1l + q * 16 * ldU, ldU, r16, kq, accv);
+            const int row = q * 16 + arow, m = m0 + row;
+            if (fnc < O) {
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                uint2 h, l;
+                if (m < Ms_feat) {
+                    v = accv[0] + f0v[q];
+                    if (split == 0) {
+                        const long long fr = (long long)fo[q] + a.t_prev;
+                        *reinterpret_cast<f32x4*>(a.before + (size_t)fr * O + fnc) = v;
+                        if (a.before_p) {
+                            split4(v, h, l);
+                            p32_store4(a.before_p, (O + 31) >> 5, fr, fnc, h, l);
+                        }
+                    }
+                    if (a.out_act) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.out_act);
+                    }
+                }
+                split4(v, h, l);
+                *reinterpret_cast<uint2*>(A2h + row * ldO + fnc) = h;
+                *reinterpret_cast<uint2*>(A2l + row * ldO + fnc) = l;
+            }
+        }
+    }
+    if (has_feat && split == 0 && a.before_p && (O & 31)) {  // zero padding of the last 32-column line of this tile's frames
+        const int padc = 32 - (O & 31);
+        for (int i = threadIdx.x; i < ROWS * padc; i += 512) {
+            const int m = m0 + i / padc;
+            if (m < Ms_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
+        }
+    }
+    if (!has_pre || a.dbg_phase == 2) return;
+    if (NS == 1) request_l1();
+    lds_barrier();
+    if (a.teacher_in) {  // teacher forcing: prenet input is y_{t-1}, not the decoder's own output
+#pragma unroll
+        for (int q = 0; q < RT; ++q) load_rowtile_split(A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, a.teacher_in, a.teacher_ld, O, m0 + q * 16, M_pre);
+        lds_barrier();
+    }
+    // ---- phase 2: H6 prenet layer 0 (all 256 columns; recomputed by every column split) ----------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        f32x4 accv[2];
+        mma_t<2, SO>(f0, A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, r16, kq, accv);
+        const int row = q * 16 + arow, m = m0 + row;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + cq * 4;
+            f32x4 v = accv[tt] + pb0[tt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            v = drop4<DROP>(v, DROP == 1 ? k0[q][tt] : 0u, (unsigned int)m * (unsigned int)P + (unsigned int)nc, seed0, thr16, a.keep_scale);
+            uint2 h, l;
+            split4(v, h, l);
+            *reinterpret_cast<uint2*>(A3h + row * ldP + nc) = h;
+            *reinterpret_cast<uint2*>(A3l + row * ldP + nc) = l;
+        }
+    }
+    lds_barrier();
+    if (a.dbg_phase == 3 || !l1_wave) return;
+    // ---- phase 3: H6 prenet layer 1, this split's columns -> global (+ KD tap, + P32 planes) --------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < RT; ++q) {
+        f32x4 accv[T1];
+        mma_t<T1, SP>(f1, A3h + q * 16 * ldP, A3l + q * 16 * ldP, ldP, r16, kq, accv);
+        const int m = m0 + q * 16 + arow;
+        if (m >= Ms_pre) continue;
+#pragma unroll
+        for (int tt = 0; tt < T1; ++tt) {
+            const int nc = (c1 + tt) * 16 + cq * 4;
+            f32x4 v = accv[tt] + pb1[tt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            v = drop4<DROP>(v, DROP == 1 ? k1[q][tt] : 0u, (unsigned int)m * (unsigned int)P + (unsigned int)nc, seed1, thr16, a.keep_scale);
+            if (a.pre_out) *reinterpret_cast<f32x4*>(a.pre_out + (size_t)m * P + nc) = v;
+            if (a.pre_out_p) {
+                uint2 h, l;
+                split4(v, h, l);
+                p32_store4(a.pre_out_p, SP, m, nc, h, l);
+            }
+            if (a.tap_prenet) *reinterpret_cast<f32x4*>(a.tap_prenet + (size_t)(a.frame_off[m] + a.t_cur) * P + nc) = v;
+        }
+    }
+}
+
 // PRE: both terms have K = 256 (the student's decoder LSTMs) -> all 2 x 8 weight fragments are requested at kernel entry.
 template <bool PRE>
 __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a) {
@@ -1031,7 +1324,42 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
         else if (a.drop_mode == 2) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 2, RT_>), g, b, lds_rt, s, a);                   \
         else hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 0, RT_>), g, b, lds_rt, s, a);                                         \
     } while (0)
-            if (rt == 2) FCL_FP_LAUNCH(2);
+            // round 4: feat_prenet_split_kernel (transposed accumulators: vectorised epilogues; optional column split of layer 1).  Measured on one box,
+            // 2 400 live rows, rocprofv3 durations: the kernel above (RT = 2) 14.1 us; this one at (NS, RT) = (1, 1) 9.5, (1, 2) 11.9, (2, 2) 10.2,
+            // (2, 1) 9.6, (4, 1) 17 (600 workgroups x 245 KB: the L2 -> CU traffic of a launch, not the per-workgroup stream, is what a split costs).
+            // The 4-stream bench line does not move with any of them (44.5 - 45.7 M frames/s for all, same box): with four passes in flight the
+            // pass is bound by the sum of workgroup-time, which RT = 1 doubles while it halves the latency.  Default: no split, one row tile per
+            // workgroup (lowest single-pass latency: 339 -> 269 us of a 1.38 ms eager pass) below 4 096 rows, two above.
+            // FCL_FP_SPLIT = 0 (the kernel above) / 1 / 2 / 4 / 8; FCL_FP_SPLIT_RT = row tiles per workgroup (0: by row count)
+            static const int ns_t = tunable("FP_SPLIT", 1), rt_t = tunable("FP_SPLIT_RT", 0);
+            if (ns_t >= 1) {
+                const int rt_s = rt_t > 0 ? rt_t : (rows >= 4096 ? 2 : 1);
+#define FCL_FPS_CASE(RT_, NS_)                                                                                                           \
+    do {                                                                                                                                 \
+        constexpr size_t lds_s = 2 * sizeof(unsigned short) * 16 * RT_ * ((256 + 16) + (96 + 16));                                        \
+        const dim3 g((rows + 16 * RT_ - 1) / (16 * RT_), NS_);                                                                           \
+        const void* fn = a.drop_mode == 1   ? reinterpret_cast<const void*>(feat_prenet_split_kernel<1, RT_, NS_>)                        \
+                         : a.drop_mode == 2 ? reinterpret_cast<const void*>(feat_prenet_split_kernel<2, RT_, NS_>)                        \
+                                            : reinterpret_cast<const void*>(feat_prenet_split_kernel<0, RT_, NS_>);                       \
+        const int rc = ensure_dyn_lds(fn, (int)lds_s);                                                                                   \
+        if (rc) return rc;                                                                                                               \
+        if (a.drop_mode == 1) hipLaunchKernelGGL((feat_prenet_split_kernel<1, RT_, NS_>), g, b, lds_s, s, a);                            \
+        else if (a.drop_mode == 2) hipLaunchKernelGGL((feat_prenet_split_kernel<2, RT_, NS_>), g, b, lds_s, s, a);                       \
+        else hipLaunchKernelGGL((feat_prenet_split_kernel<0, RT_, NS_>), g, b, lds_s, s, a);                                             \
+    } while (0)
+#define FCL_FPS_RT(NS_)                                                                                                                  \
+    do {                                                                                                                                 \
+        if (rt_s >= 4) FCL_FPS_CASE(4, NS_);                                                                                             \
+        else if (rt_s >= 2) FCL_FPS_CASE(2, NS_);                                                                                        \
+        else FCL_FPS_CASE(1, NS_);                                                                                                       \
+    } while (0)
+                if (ns_t >= 8) FCL_FPS_RT(8);
+                else if (ns_t >= 4) FCL_FPS_RT(4);
+                else if (ns_t >= 2) FCL_FPS_RT(2);
+                else FCL_FPS_RT(1);
+#undef FCL_FPS_RT
+#undef FCL_FPS_CASE
+            } else if (rt == 2) FCL_FP_LAUNCH(2);
             else FCL_FP_LAUNCH(1);
 #undef FCL_FP_LAUNCH
         } else if (a.U == 256 && a.O == 80 && a.P == 256) {

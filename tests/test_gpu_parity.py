@@ -251,6 +251,44 @@ def test_decoder_rng_dropout_statistics(ops):
     assert max_abs(outs[0], outs[1]) > 1e-6
 
 
+def test_prenet_rng_dropout_is_fair_and_independent(ops):
+    """The production dropout of the fused feat/prenet kernel (round 4: 16 bits of a counter hash per decision, two hashes per four columns):
+    with the last prenet bias pushed far positive every output is positive unless it was dropped, so the zero pattern of the prenet tap IS
+    the drop mask.  Drop rate 0.5 within 4 sigma overall, per column and per row; decisions of neighbouring columns (which share a hash word)
+    and of neighbouring rows / steps are independent (joint rate 0.25); kept values are scaled by 1 / (1 - p); two seeds give different masks."""
+    from fcl_taco2_amd.plan import SynthesisPlan
+
+    hp = HP.student_hparams()
+    sd = np_state_dict(hp)
+    sd["dec.prenet.prenet.1.0.bias"] = np.full_like(sd["dec.prenet.prenet.1.0.bias"], 50.0)
+    plan = SynthesisPlan(sd, hp, DEV)
+    n, lmax = 640, 6
+    dur = np.full(n, lmax, np.int32)
+    att = dev(rnd(np.random.RandomState(0), n, hp.eunits))
+    foff = (np.arange(n) * lmax).astype(np.int32)
+    live = np.full(lmax, n, np.int32)
+    masks = []
+    for seed in (3, 4):
+        _, taps = ops.decoder_loop(plan.decoder, att, dev(dur), live, dev(foff), n * lmax, dropout_mode=ops.DROP_RNG, seed=seed, want_taps=True)
+        t = taps[0].cpu().numpy().reshape(n, lmax, hp.prenet_units)  # frame row = row * lmax + step
+        assert np.isfinite(t).all()
+        kept = t[t != 0]
+        assert kept.min() > 50.0  # (bias 50 + non-negative layer-1 terms) * 2: the kept values carry the 1 / (1 - p) scale
+        masks.append(t == 0)
+    z = masks[0]
+    tot = z.size
+    sig = 0.5 / np.sqrt(tot)
+    assert abs(z.mean() - 0.5) < 4 * sig, z.mean()
+    col = z.mean(axis=(0, 1))
+    assert np.abs(col - 0.5).max() < 5 * 0.5 / np.sqrt(n * lmax), np.abs(col - 0.5).max()
+    row = z.mean(axis=(1, 2))
+    assert np.abs(row - 0.5).max() < 5 * 0.5 / np.sqrt(lmax * hp.prenet_units)
+    for a, b in ((z[:, :, :-1], z[:, :, 1:]), (z[:, :, :-2], z[:, :, 2:]), (z[:-1], z[1:]), (z[:, :-1], z[:, 1:])):
+        joint = float((a & b).mean())
+        assert abs(joint - 0.25) < 5 * np.sqrt(0.25 * 0.75 / a.size), joint
+    assert abs(float((masks[0] ^ masks[1]).mean()) - 0.5) < 0.01  # another seed: an independent mask
+
+
 # ------------------------------------------------------------------------------------------ end to end
 def _plan(hp, thp=None, share=True):
     from fcl_taco2_amd.plan import SynthesisPlan

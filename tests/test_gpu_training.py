@@ -648,8 +648,14 @@ def _nccl_one_rank_worker(port, q):
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(DEV))
         l1, w1, e1 = run()
-        assert e1.buckets.active and e1.buckets.avg and e1.buckets.world == 1
+        assert e1.buckets.active and e1.buckets.avg and e1.buckets.world == 1 and e1.buckets.inline
         n_coll = e1.buckets.collectives
+        os.environ["FCL_DP_INLINE"] = "0"  # the async form: async_op=True on RCCL's own stream, waited for in optimizer_step()
+        l2, w2, e2 = run()
+        os.environ["FCL_DP_INLINE"] = "1"
+        assert e2.buckets.active and not e2.buckets.inline and e2.buckets.collectives == n_coll
+        assert abs(l2[0] - l0[0]) <= 1e-9 * abs(l0[0]) and all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l2)), (l0, l2)
+        assert float((w0 - w2).abs().max()) <= 6e-3 and float((w0 - w2).abs().mean()) < 1e-5
         # the collective alone: AVG over one rank is the identity, bit for bit, on every bucket
         e1.zero_grad()
         e1.forward_backward(bs[0], teacher_knowledge=TrainEngine(SYN.build_model("kd_teacher", T, None, DEV), seed=11).knowledge(bs[0], mode="train"),
@@ -693,8 +699,11 @@ def test_one_rank_nccl_group_runs_the_data_parallel_branch_on_one_gpu():
     _, l0, l1, wmax, wmean, n_coll, ident = res
     assert n_coll == 12, n_coll
     assert ident
-    assert l0[0] == pytest.approx(l1[0], rel=1e-9) and l0 == pytest.approx(l1, rel=1e-4)
-    assert wmax <= 2 * 1e-3 * 3 and wmean < 1e-5  # sign-flip bound of three Adam steps / mean, as in test_kd_pipeline_equals_sequential_updates
+    # first update: the same arithmetic on the same weights.  Later ones: atomically accumulated gradients differ in their last bits from run to
+    # run, and Adam's first steps (|m / sqrt(v)| ~ 1) turn a last-bit difference in a near-zero gradient into a +-lr difference of that weight; on
+    # these full-size closed-form (stiff) weights that moves the third loss by ~2e-4 relative between ANY two runs
+    assert l0[0] == pytest.approx(l1[0], rel=1e-9) and l0 == pytest.approx(l1, rel=2e-3), (l0, l1)
+    assert wmax <= 2 * 1e-3 * 3 and wmean < 1e-5, (wmax, wmean)  # sign-flip bound of three Adam steps / mean, as in test_kd_pipeline_equals_sequential_updates
 
 
 def test_full_size_kd_step_properties():
