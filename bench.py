@@ -44,6 +44,28 @@ def mfma_ceiling(amp=None):
     return PEAK_BF16_MFMA_TFLOPS / 3.0, "bf16 MFMA dense peak / 3: each fp32-equivalent product issues three bf16 MFMAs (bf16x3 split)"
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """Everything libraries print on fd 1 (RCCL writes a version banner there when its first communicator comes up) goes to stderr; the ONE JSON
+    line is written to the real stdout by emit()."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is None:
+        os.write(1, line)
+    else:
+        os.write(_REAL_STDOUT, line)
+
+
 def timed_regions(one_region, barrier, regions):
     """`regions` repetitions of the timed region (each: barrier + synchronize, EXACTLY K steps, barrier + synchronize); returns the list of wall
     times.  The reported figure is their MEDIAN (median of >= 20 timed iterations after warm-up; one region of K steps is only ~10 ms)."""
@@ -561,6 +583,7 @@ def main():
     if args.dry_run_launch:
         raise SystemExit(dry_run_launch(args))
 
+    quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -610,14 +633,14 @@ def main():
     if args.workload in ("tts_e2e", "vocoder"):
         out = e2e_workload(args, rank, world, dev, dist)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if dist is not None:
             dist.destroy_process_group()
         return
     if args.workload != "synthesis":
         out = train_workload(args, rank, world, dev, dist)
         if rank == 0:
-            print(json.dumps(out))
+            emit(out)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -913,7 +936,7 @@ def main():
         out["value_fp32_exact"] = fx.get("value")  # the headline metric with every contraction on exact fp32 MFMAs (FCL_PRECISION=0)
         out["fp32_exact"] = fx
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 
