@@ -230,6 +230,25 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
         assert mine == {k: tuple(v) for k, v in spec.items()}, "parameter tree does not match hparams.param_spec"
         self._plan = None
         self._plan_key = None
+        # `--encoder-resume PATH` (tts_train.py:319; teacher and student constructors pass it to their Encoder, ..._sa.py:378,
+        # ..._kd_student.py:504): the encoder's OWN state_dict, loaded strictly in place of encoder_init (encoder_sa.py:117-120,
+        # encoder_sa_kd.py:137-140 -- for a student under KD training that includes its embed_proj / convs_proj / blstm_proj)
+        if args.encoder_resume is not None:
+            self.enc.load_state_dict(torch.load(args.encoder_resume, map_location="cpu", weights_only=False))
+        # `--pretrained-model PATH`: the whole model, after construction (..._sa.py:480-481, ..._kd_student.py:622-623, ..._kd_teacher.py:481-482)
+        if getattr(args, "pretrained_model", None) is not None:
+            self.load_pretrained_model(args.pretrained_model)
+
+    def load_pretrained_model(self, model_path):
+        """ESPnet's TTSInterface.load_pretrained_model = espnet.asr.pytorch_backend.asr_init / asr_utils.torch_load(model_path, self) (ESPnet
+        0.8, restated: parity unpinned at this boundary): a trainer snapshot (file name contains "snapshot") holds the weights under "model",
+        any other file IS the state_dict; keys of a DataParallel-wrapped model ("module." prefix) are accepted."""
+        import os
+
+        obj = torch.load(model_path, map_location="cpu", weights_only=False)
+        if "snapshot" in os.path.basename(model_path) or (isinstance(obj, dict) and isinstance(obj.get("model"), dict)):
+            obj = obj["model"]
+        self.load_state_dict({k[len("module."):] if k.startswith("module.") else k: v for k, v in obj.items()})
 
     # ---- plan management --------------------------------------------------------------------------
     def _load_from_state_dict(self, *a, **k):  # any (re)load invalidates the packed device weights

@@ -168,6 +168,8 @@ def get_parser():
     p.add_argument("--teacher-conf", default=None, help="KD: the teacher's model.json")
     p.add_argument("--teacher-model", default=None, help="KD: the teacher's amp_checkpoint_*.pt / snapshot")
     p.add_argument("--resume", "-r", default=None, help="snapshot.ep.N to continue from")
+    p.add_argument("--encoder-resume", default=None, type=str, help="state_dict file of the ENCODER alone, loaded in place of its initialisation "
+                   "(tts_train.py:319-323; encoder_sa.py:117-120).  --pretrained-model (a model flag) loads the whole model")
     p.add_argument("--batch-size", "-b", default=32, type=int)
     p.add_argument("--batch-sort-key", default="shuffle", choices=["shuffle", "input", "output"])
     p.add_argument("--epochs", "-e", default=30, type=int)

@@ -177,3 +177,48 @@ def test_interface_stands_alone_without_espnet():
     assert TI.ESPNET_BASE is None  # this session has no `espnet` on its path: the local class is the whole interface
     cls = dynamic_import("fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa:Tacotron2_sa")
     assert issubclass(cls, TI.TTSInterface)
+
+
+def test_encoder_resume_and_pretrained_model_are_loaded_like_the_reference(tmp_path):
+    """`--encoder-resume` (the encoder's own state_dict, strict, in place of encoder_init: encoder_sa.py:117-120, encoder_sa_kd.py:137-140) and
+    `--pretrained-model` (the whole model after construction through ESPnet's torch_load: a bare state_dict, or a trainer snapshot with the
+    weights under "model": ..._sa.py:480-481, ..._kd_student.py:622-623) -- accepted AND ignored until round 4."""
+    import argparse
+
+    import torch
+
+    from fcl_taco2_amd.nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_student import Tacotron2_sa as Student
+    from fcl_taco2_amd.nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa as Teacher
+
+    small = dict(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, duration_predictor_chans=20, use_residual=False,
+                 use_masking=True)
+    com = argparse.Namespace(use_fe_condition=True, append_position=True, distill_output_knowledge=True, distill_encoder_knowledge=True,
+                             distill_decoder_knowledge=True, distill_prosody_knowledge=True, is_train=True, share_proj=True)
+    torch.manual_seed(0)
+    donor = Teacher(12, 8, argparse.Namespace(**small), com)
+    enc_path, full_path, snap_path = str(tmp_path / "enc.pt"), str(tmp_path / "model.loss.best"), str(tmp_path / "snapshot.ep.3")
+    torch.save(donor.enc.state_dict(), enc_path)
+    torch.save(donor.state_dict(), full_path)
+    torch.save({"model": {"module." + k: v for k, v in donor.state_dict().items()}, "optimizer": None}, snap_path)
+    torch.manual_seed(1)
+    fresh = Teacher(12, 8, argparse.Namespace(**small), com)
+    assert not torch.equal(fresh.enc.convs[0][0].weight, donor.enc.convs[0][0].weight)
+    torch.manual_seed(1)
+    resumed = Teacher(12, 8, argparse.Namespace(encoder_resume=enc_path, **small), com)
+    for k, v in donor.enc.state_dict().items():
+        assert torch.equal(resumed.enc.state_dict()[k], v), k
+    assert torch.equal(resumed.dec.feat_out.weight, fresh.dec.feat_out.weight)  # everything but the encoder keeps its own initialisation
+    for path in (full_path, snap_path):
+        torch.manual_seed(2)
+        m = Teacher(12, 8, argparse.Namespace(pretrained_model=path, **small), com)
+        for k, v in donor.state_dict().items():
+            assert torch.equal(m.state_dict()[k], v), (path, k)
+    # a KD student's encoder carries the projection layers: a teacher's encoder file does not fit it (strict load, as in the reference)
+    with pytest.raises(RuntimeError):
+        Student(12, 8, argparse.Namespace(encoder_resume=enc_path, **small), com, argparse.Namespace(**dict(small, embed_dim=32, eunits=32, econv_chans=32)))
+    torch.manual_seed(3)
+    sdonor = Student(12, 8, argparse.Namespace(**small), com, argparse.Namespace(**dict(small, embed_dim=32, eunits=32, econv_chans=32)))
+    s_enc = str(tmp_path / "senc.pt")
+    torch.save(sdonor.enc.state_dict(), s_enc)
+    s2 = Student(12, 8, argparse.Namespace(encoder_resume=s_enc, **small), com, argparse.Namespace(**dict(small, embed_dim=32, eunits=32, econv_chans=32)))
+    assert torch.equal(s2.enc.embed_proj.weight, sdonor.enc.embed_proj.weight) and torch.equal(s2.enc.blstm.weight_hh_l0, sdonor.enc.blstm.weight_hh_l0)
