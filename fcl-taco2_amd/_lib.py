@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 308  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 400  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -103,7 +103,49 @@ class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
 
 
+TE_MAX_SITES, TE_MAX_LOSSES = 48, 48
+TE_TEACHER, TE_KD_TEACHER, TE_STUDENT = 0, 1, 2
+
+
+class TeConfig(C.Structure):  # fcl_te_config_t
+    _fields_ = ([(n, C.c_int32) for n in ("role", "idim", "odim", "embed_dim", "econv_layers", "econv_chans", "econv_filts", "eunits", "dunits", "prenet_units",
+                                          "postnet_layers", "postnet_chans", "postnet_filts", "dp_layers", "dp_chans", "dp_kernel", "vp_layers", "vp_chans",
+                                          "vp_kernel", "ve_kernel")]
+                + [(n, _F) for n in ("dropout_rate", "zoneout_rate", "dp_dropout", "vp_dropout", "ve_dropout")]
+                + [(n, C.c_int32) for n in ("use_masking", "t_embed_dim", "t_econv_chans", "t_eunits", "t_prenet_units", "t_dunits", "t_postnet_chans", "share_proj",
+                                            "distill_output", "distill_encoder", "distill_decoder", "distill_prosody", "accum_grad")]
+                + [("seed", C.c_uint32), ("site_tag", C.c_uint32 * TE_MAX_SITES), ("dw_planes_min", C.c_int32), ("pred_stream", C.c_int32),
+                   ("late_losses", C.c_int32)])
+
+
+class TeBatch(C.Structure):  # fcl_te_batch_t
+    _fields_ = ([(n, C.c_int32) for n in ("B", "T", "L", "N", "F", "lmax")]
+                + [(n, _P) for n in ("xs", "ys", "f0", "energy", "ds", "lens", "e_lo", "e_hi", "f_lo", "f_hi", "src_sorted", "row_of_enc", "cell_frame", "frame_cell",
+                                     "prev_frame", "cell_row", "dur", "perm_tb", "cell_row_i64", "enc_pad", "enc_valid", "frame_valid", "cell_valid", "pos4",
+                                     "live_rows_host")]
+                + [("n_enc", C.c_double), ("n_frames", C.c_double)])
+
+
+class TeKnowledge(C.Structure):  # fcl_te_knowledge_t
+    _fields_ = [("after", _P), ("before", _P), ("enc", _P * 5), ("dec", _P * 8), ("pro", _P * 5), ("dec_cell_major", C.c_int32)]
+
+
 SIGNATURES = {
+    "fcl_te_create": (_I, [C.POINTER(TeConfig), C.POINTER(_P)]),
+    "fcl_te_destroy": (None, [_P]),
+    "fcl_te_site_name": (C.c_char_p, [_I]),
+    "fcl_te_loss_name": (C.c_char_p, [_I]),
+    "fcl_te_bind_param": (_I, [_P, C.c_char_p, _P, _P, C.c_int64]),
+    "fcl_te_bind_buffer": (_I, [_P, C.c_char_p, _P]),
+    "fcl_te_finalize": (_I, [_P, _P]),
+    "fcl_te_params_changed": (_I, [_P]),
+    "fcl_te_side_stream": (_P, [_P]),
+    "fcl_te_knowledge": (_I, [_P, C.POINTER(TeBatch), C.c_uint32, C.POINTER(TeKnowledge), _P]),
+    "fcl_te_forward_backward": (_I, [_P, C.POINTER(TeBatch), C.POINTER(TeKnowledge), C.c_uint32, _P, _P, _P]),
+    "fcl_te_backward_stage": (_I, [_P, _I, _P]),
+    "fcl_te_join": (_I, [_P, _P]),
+    "fcl_te_last_launches": (C.c_int64, [_P]),
+    "fcl_te_arena_bytes": (C.c_int64, [_P]),
     "fcl_last_error": (C.c_char_p, []),
     "fcl_version": (_I, []),
     "fcl_debug_ptr": (_P, []),

@@ -220,15 +220,20 @@ class LossReport(dict):
     """The named losses of a step.  The fp64 loss sums are copied to pinned host memory asynchronously; the dict fills itself on first access, so a
     training loop that only logs every N steps never stalls the CPU on the GPU (the .cpu() read-back used to cost a full pipeline drain per step)."""
 
-    def __init__(self, sums_dev, names, extra=None, status_dev=None):
+    def __init__(self, sums_dev, names, extra=None, status_dev=None, host=None):
+        """host = (pinned [len(names), 3] float64, pinned int32 [1] or None): the copies were already enqueued on the current stream by the caller
+        (the native step, fcl_te_forward_backward); slots whose count is 0 (terms the configuration does not compute) are ignored."""
         super().__init__()
         self._names = list(names)
-        self._host = torch.empty((len(names), 3), dtype=torch.float64, pin_memory=True)
-        self._host.copy_(sums_dev[: len(names)], non_blocking=True)
-        self._status = None
-        if status_dev is not None:  # the device status word rides along: 4 bytes on the same stream
-            self._status = torch.empty(1, dtype=torch.int32, pin_memory=True)
-            self._status.copy_(status_dev, non_blocking=True)
+        if host is not None:
+            self._host, self._status = host
+        else:
+            self._host = torch.empty((len(names), 3), dtype=torch.float64, pin_memory=True)
+            self._host.copy_(sums_dev[: len(names)], non_blocking=True)
+            self._status = None
+            if status_dev is not None:  # the device status word rides along: 4 bytes on the same stream
+                self._status = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                self._status.copy_(status_dev, non_blocking=True)
         self._event = torch.cuda.Event()
         self._event.record()
         self._extra = dict(extra or {})
@@ -246,7 +251,7 @@ class LossReport(dict):
                 raise FclError("fcl-taco2_amd: device status 0x%x during this step (the parameter update was skipped on the device): %s"
                                % (bits, ops.status_message(bits)))
         host = self._host.numpy()
-        m = {n: (host[i, 0] / host[i, 2], host[i, 1] / host[i, 2]) for i, n in enumerate(self._names)}
+        m = {n: (host[i, 0] / host[i, 2], host[i, 1] / host[i, 2]) for i, n in enumerate(self._names) if host[i, 2] > 0}
         rep = dict(l1_loss=m["after"][0] + m["before"][0], mse_loss=m["after"][1] + m["before"][1], dur_loss=m["dur"][1], pitch_loss=m["pitch"][1],
                    energy_loss=m["energy"][1])
         rep["loss"] = rep["l1_loss"] + rep["mse_loss"] + rep["dur_loss"] + rep["pitch_loss"] + rep["energy_loss"]
@@ -328,14 +333,207 @@ class ZeroArena(object):
         return out
 
 
+class NativeKnowledge(object):
+    """The frozen KD teacher's knowledge as produced by the native step (csrc/train_engine.hip): device pointers into one of the teacher engine's
+    two alternating arenas (valid until the second next knowledge() call on that engine), decoder taps CELL-major (teacher and student share the
+    batch's index maps, so the frame round trip of the reference's tuple is skipped)."""
+    __slots__ = ("struct", "engine", "batch_id")
+
+    def __init__(self, struct, engine, batch_id):
+        self.struct, self.engine, self.batch_id = struct, engine, batch_id
+
+
+class _NativeStep(object):
+    """TrainEngine's native form of the step: fcl_te_* of include/fcl_hip.h.  The ~530 launches of a KD update are issued by ONE C++ routine per
+    backward stage instead of one ctypes call each (8.7 of 11.0 ms per update were host time)."""
+
+    @staticmethod
+    def unsupported(eng):
+        """None when the native routine covers this engine's configuration, else the reason (the per-launch Python path is used then)."""
+        hp = eng.hp
+        if os.environ.get("FCL_TRAIN_NATIVE", "1") in ("", "0"):
+            return "FCL_TRAIN_NATIVE=0"
+        if not ops.planes_enabled():
+            return "pre-split operands are off (FCL_PRECISION=0 / FCL_PLANES=0)"
+        if hp.spk_embed_dim is not None or hp.use_residual or hp.output_activation is not None:
+            return "speaker embeddings / residual encoder / output activation"
+        if not eng.overlap_dw:
+            return "overlap_dw=False"
+        widths = (hp.embed_dim, hp.econv_chans, hp.dunits, hp.prenet_units, hp.postnet_chans, hp.duration_predictor_chans, hp.variance_predictor_chans)
+        if any(v % 32 for v in widths) or hp.eunits % 64 or hp.odim % 4 or not (hp.embed_dim == hp.econv_chans == hp.eunits):
+            return "channel widths that are not multiples of 32"
+        if eng.role == "student" and eng.distill[2] and hp.postnet_layers != 5:
+            return "decoder distillation with postnet_layers != 5"
+        if eng.role == "student" and eng.distill[1] and hp.econv_layers != 3:
+            return "encoder distillation with econv_layers != 3"
+        return None
+
+    def __init__(self, eng):
+        import ctypes as C
+        from . import _lib
+
+        self.eng, self.C, self._lib = eng, C, _lib
+        lib = self.lib = _lib.load()
+        hp = eng.hp
+        role = {"teacher": _lib.TE_TEACHER, "kd_teacher": _lib.TE_KD_TEACHER, "student": _lib.TE_STUDENT}[eng.role]
+        cfg = _lib.TeConfig(role=role, idim=hp.idim, odim=hp.odim, embed_dim=hp.embed_dim, econv_layers=hp.econv_layers, econv_chans=hp.econv_chans,
+                            econv_filts=hp.econv_filts, eunits=hp.eunits, dunits=hp.dunits, prenet_units=hp.prenet_units, postnet_layers=hp.postnet_layers,
+                            postnet_chans=hp.postnet_chans, postnet_filts=hp.postnet_filts, dp_layers=hp.duration_predictor_layers,
+                            dp_chans=hp.duration_predictor_chans, dp_kernel=hp.duration_predictor_kernel_size, vp_layers=hp.variance_predictor_layers,
+                            vp_chans=hp.variance_predictor_chans, vp_kernel=hp.variance_predictor_kernel_size, ve_kernel=hp.variance_embed_kernel_size,
+                            dropout_rate=hp.dropout_rate, zoneout_rate=float(hp.zoneout_rate), dp_dropout=hp.duration_predictor_dropout_rate,
+                            vp_dropout=hp.variance_predictor_dropout_rate, ve_dropout=hp.variance_embed_dropout_rate, use_masking=int(bool(hp.use_masking)),
+                            accum_grad=eng.accum_grad, seed=eng.seed & 0xFFFFFFFF, dw_planes_min=eng._dw_planes_min,
+                            pred_stream=int(eng.pstream is not None), late_losses=int(eng._late_losses))
+        if eng.role == "student":
+            thp = eng.model.teacher_hp
+            cfg.t_embed_dim, cfg.t_econv_chans, cfg.t_eunits = thp.embed_dim, thp.econv_chans, thp.eunits
+            cfg.t_prenet_units, cfg.t_dunits, cfg.t_postnet_chans = thp.prenet_units, thp.dunits, thp.postnet_chans
+            cfg.share_proj = int(eng.share_proj)
+            cfg.distill_output, cfg.distill_encoder, cfg.distill_decoder, cfg.distill_prosody = [int(v) for v in eng.distill]
+        # mask seeds: training.py's per-site tags (crc32 of the Python site name), in the order of the library's site table
+        for i in range(_lib.TE_MAX_SITES):
+            nm = lib.fcl_te_site_name(i)
+            if nm is None:
+                break
+            parts = nm.decode().split("/")
+            key = (parts[0],) + tuple(int(v) for v in parts[1:])
+            cfg.site_tag[i] = zlib.crc32(repr(key).encode()) & 0x7FFFFFFF
+        self.loss_names = []
+        for i in range(_lib.TE_MAX_LOSSES):
+            nm = lib.fcl_te_loss_name(i)
+            if nm is None:
+                break
+            self.loss_names.append(nm.decode())
+        h = C.c_void_p()
+        _lib.check(lib.fcl_te_create(C.byref(cfg), C.byref(h)))
+        self.h, self.cfg = h, cfg
+        for k, v in eng.P.items():
+            _lib.check(lib.fcl_te_bind_param(h, k.encode(), v.data_ptr(), eng.G[k].data_ptr(), v.numel()))
+        for k, v in eng.B.items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
+                _lib.check(lib.fcl_te_bind_buffer(h, k.encode(), v.data_ptr()))
+        _lib.check(lib.fcl_te_finalize(h, eng.status.data_ptr()))
+        self.side = torch.cuda.ExternalStream(lib.fcl_te_side_stream(h), device=eng.dev)
+        self._hosts = []  # pinned landing buffers of the last steps' loss sums (kept until their copies have certainly run)
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) is not None and self.h.value:
+                self.lib.fcl_te_destroy(self.h)
+                self.h = None
+        except Exception:  # pragma: no cover - interpreter shutdown
+            pass
+
+    def params_changed(self):
+        self._lib.check(self.lib.fcl_te_params_changed(self.h))
+
+    def batch_struct(self, batch):
+        """fcl_te_batch_t of a converter batch: the engine's index maps (TrainEngine._maps: built once per batch, shared by teacher and student) plus
+        the float inputs, flattened once and cached on the batch."""
+        eng, _lib = self.eng, self._lib
+        hit = batch.get("_fcl_te_batch") if isinstance(batch, dict) else None
+        if hit is not None and hit[0] == str(eng.dev):
+            return hit[1]
+        c = _Ctx()
+        eng._maps(c, batch)
+        dev, T, L = eng.dev, c.T, c.L
+        xs = batch["xs"][:, :T].to(dev).to(torch.int64).reshape(-1).contiguous()
+        ys = batch["ys"][:, :L].to(dev).float().reshape(c.B * L, eng.hp.odim).contiguous()
+        f0 = batch["f0"][:, :T].to(dev).float().reshape(-1).contiguous()
+        en = batch["energy"][:, :T].to(dev).float().reshape(-1).contiguous()
+        ds = batch["extras"][:, :T].to(dev).float().reshape(-1).contiguous()
+        live = np.ascontiguousarray(c.live_i32, dtype=np.int32)
+        st = _lib.TeBatch(B=c.B, T=T, L=L, N=c.N, F=c.F, lmax=c.lmax, xs=xs.data_ptr(), ys=ys.data_ptr(), f0=f0.data_ptr(), energy=en.data_ptr(), ds=ds.data_ptr(),
+                          lens=c.lens_dev.data_ptr(), e_lo=c.e_lo.data_ptr(), e_hi=c.e_hi.data_ptr(), f_lo=c.f_lo.data_ptr(), f_hi=c.f_hi.data_ptr(),
+                          src_sorted=c.src_sorted.data_ptr(), row_of_enc=c.row_of_enc.data_ptr(), cell_frame=c.cell_frame.data_ptr(),
+                          frame_cell=c.frame_cell.data_ptr(), prev_frame=c.prev_frame.data_ptr(), cell_row=c.cell_row_i32.data_ptr(), dur=c.dur_dev.data_ptr(),
+                          perm_tb=c.perm_tb.data_ptr(), cell_row_i64=c.cell_row_i64.data_ptr(), enc_pad=c.enc_pad.data_ptr(), enc_valid=c.enc_valid.data_ptr(),
+                          frame_valid=c.frame_valid.data_ptr(), cell_valid=c.cell_valid.data_ptr(), pos4=c.pos4.data_ptr(), live_rows_host=live.ctypes.data,
+                          n_enc=float(c.n_enc), n_frames=float(c.n_frames))
+        keep = (xs, ys, f0, en, ds, live, c)  # everything the struct points at lives as long as the batch's cache entry
+        if isinstance(batch, dict):
+            batch["_fcl_te_batch"] = (str(eng.dev), (st, keep))
+        return st, keep
+
+    def knowledge(self, batch):
+        eng, C = self.eng, self.C
+        st, keep = self.batch_struct(batch)
+        eng.forward_count += 1
+        know = self._lib.TeKnowledge()
+        with torch.cuda.device(eng.dev), ops.gemm_mode(eng.amp):
+            self._lib.check(self.lib.fcl_te_knowledge(self.h, C.byref(st), eng.forward_count & 0xFFFFFFFF, C.byref(know), ops._stream()))
+        eng._native_nbt()
+        return NativeKnowledge(know, eng, id(batch))
+
+    def _knowledge_struct(self, know, c_batch):
+        """fcl_te_knowledge_t of whatever the caller handed to the student: a NativeKnowledge, or the reference-shaped 5-tuple of tensors."""
+        if isinstance(know, NativeKnowledge):
+            return know.struct, know
+        eng = self.eng
+        t_after, t_before, t_enc, t_dec, t_pro = know
+        flat = lambda t: t.to(device=eng.dev, dtype=torch.float32).reshape(-1, t.shape[-1]).contiguous()
+        tens = [flat(t_after), flat(t_before)] + [flat(t) for t in t_enc] + [flat(t) for t in t_dec] + [flat(t) for t in t_pro]
+        ks = self._lib.TeKnowledge(after=tens[0].data_ptr(), before=tens[1].data_ptr(), dec_cell_major=0)
+        for i in range(5):
+            ks.enc[i] = tens[2 + i].data_ptr()
+        for i in range(8):
+            ks.dec[i] = tens[7 + i].data_ptr()
+        for i in range(5):
+            ks.pro[i] = tens[15 + i].data_ptr()
+        return ks, tens
+
+    def forward_backward(self, batch, teacher_knowledge, reduce):
+        eng, C, lib = self.eng, self.C, self.lib
+        st, keep = self.batch_struct(batch)
+        kptr = None
+        if eng.role == "student":
+            ks, kkeep = self._knowledge_struct(teacher_knowledge, st)
+            kptr, self._keep = C.byref(ks), (ks, kkeep, keep)
+        else:
+            self._keep = keep
+        eng.forward_count += 1
+        host = torch.empty((self._lib.TE_MAX_LOSSES, 3), dtype=torch.float64, pin_memory=True)
+        stat = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        self._hosts.append((host, stat))
+        del self._hosts[:-16]
+        do_reduce = reduce and eng.buckets.active
+        main = torch.cuda.current_stream(eng.dev)
+
+        def bucket(i):
+            if do_reduce:
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    eng.buckets.launch(i)
+
+        with torch.cuda.device(eng.dev), ops.gemm_mode(eng.amp):
+            s = ops._stream()
+            self._lib.check(lib.fcl_te_forward_backward(self.h, C.byref(st), kptr, eng.forward_count & 0xFFFFFFFF, host.data_ptr(), stat.data_ptr(), s))
+            rep = LossReport(None, self.loss_names, host=(host, stat))
+            eng._native_nbt()
+            bucket(0)
+            for stage in (1, 2, 3):
+                self._lib.check(lib.fcl_te_backward_stage(self.h, stage, s))
+                bucket(stage)
+            self._lib.check(lib.fcl_te_join(self.h, s))
+        return rep
+
+    def launches(self):
+        return int(self.lib.fcl_te_last_launches(self.h))
+
+
 _DW_PLANES_MIN = int(os.environ.get("FCL_DW_PLANES_MIN", "0"))  # output elements from which a weight gradient runs on transposed planes (0: per role, below)
 # (measured r3: sending the student's long-contraction / small-output gradients -- 13 GFLOP into [1024, 256] over ~25 k frames, 65 - 110 TFLOP/s on the
 # fp32-operand kernel -- to the planes kernel as well is a wash: its two transposing passes cost what the faster GEMM saves; KD update 12.66 vs 12.59 ms)
 
 
 class TrainEngine(object):
-    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None, overlap_dw=True, amp=None):
-        """amp: None = fp32-equivalent arithmetic; "bf16" = the mixed-precision form of the reference's `--use-amp True` recipe (apex O1,
+    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None, overlap_dw=True, amp=None, native=True):
+        """native: train-form passes without injected masks run as ONE C++ routine per backward stage (fcl_te_*, csrc/train_engine.hip) when the
+        configuration is covered (`native_reason` says why not); False = always the per-launch path below, which is also its reference.
+        amp: None = fp32-equivalent arithmetic; "bf16" = the mixed-precision form of the reference's `--use-amp True` recipe (apex O1,
         tts.py:414-416) with bf16 in place of fp16: the big-tile forward / input-gradient / weight-gradient GEMMs take bf16-rounded operands and
         accumulate in fp32 (ops.gemm_mode), master weights, norms, losses, gradients and Adam stay fp32, no loss scaling is needed."""
         p0 = next(model.parameters())
@@ -408,6 +606,22 @@ class TrainEngine(object):
             model._engine = self  # load_state_dict() on the module reaches invalidate_planes() through this back-reference
         except Exception:  # pragma: no cover - a module that refuses attributes only loses the cache invalidation hook
             pass
+        # the native form of the step (csrc/train_engine.hip), created on first use; None + a reason when this configuration is not covered
+        self._native, self.native_reason = None, _NativeStep.unsupported(self) if native else "native=False"
+
+    @property
+    def native(self):
+        """The native step (fcl_te_*), or None: mode="train" passes without injected masks go through it."""
+        if self.native_reason is not None:
+            return None
+        if self._native is None:
+            self._native = _NativeStep(self)
+        return self._native
+
+    def _native_nbt(self):
+        """torch's integer BatchNorm bookkeeping (num_batches_tracked) after a native train-form forward: every layer advanced once."""
+        if self._nbt_flat is not None:
+            self._nbt_flat.add_(1)
 
     @property
     def step_count(self):
@@ -444,6 +658,8 @@ class TrainEngine(object):
         """Parameters were overwritten in place (load_state_dict): cached weight planes are stale."""
         self._plane_cache.clear()
         self._forms.stamp = None
+        if self._native is not None:
+            self._native.params_changed()
 
     def _stamp(self):
         return (self.update_calls, self.pflat._version)
@@ -1259,8 +1475,12 @@ class TrainEngine(object):
         self._maps(c, batch)
         return c
 
-    def knowledge(self, batch, mode="train", masks=None):
-        """Forward only: the frozen KD teacher's 5-tuple (tts_distill.py:159; the reference leaves the teacher in train mode)."""
+    def knowledge(self, batch, mode="train", masks=None, native=False):
+        """Forward only: the frozen KD teacher's 5-tuple (tts_distill.py:159; the reference leaves the teacher in train mode).
+        native=True (KDPipeline, when both engines have the native step): a NativeKnowledge -- pointers into the native engine's arena, decoder
+        taps cell-major -- instead of the reference-shaped tuple of tensors."""
+        if native and mode == "train" and masks is None and self.native is not None:
+            return self.native.knowledge(batch)
         with torch.cuda.device(self.dev), ops.gemm_mode(self.amp):
             c = self._ctx(batch, mode, masks, save=False)
             self._forward(c, batch)
@@ -1273,6 +1493,10 @@ class TrainEngine(object):
         gradients local (optimizer_step() then averages nothing)."""
         if self.role == "student" and teacher_knowledge is None:
             raise ValueError("the student step needs teacher_knowledge (tts_distill.py:159-161)")
+        if mode == "train" and masks is None and self.role != "kd_teacher" and self.native is not None:
+            return self.native.forward_backward(batch, teacher_knowledge, reduce)
+        if isinstance(teacher_knowledge, NativeKnowledge):
+            raise ValueError("a NativeKnowledge can only be consumed by the native step (mode='train', no injected masks)")
         with torch.cuda.device(self.dev), ops.gemm_mode(self.amp):
             c = self._ctx(batch, mode, masks, reduce=reduce)
             self._forward(c, batch)
@@ -1289,6 +1513,8 @@ class TrainEngine(object):
             self.update_calls += 1
             ops.adam_step(self.pflat, self.gflat, self.mflat, self.vflat, self.gn_sq, self.grad_clip, self.lr, self.betas[0], self.betas[1], self.eps,
                           self.step_dev, self.status)  # skipped on the device (counter included) on a NaN / inf norm or a non-zero status word
+            if self._native is not None:
+                self._native.params_changed()
             self.model.refresh_plan()
         return self.update_calls
 
@@ -1318,6 +1544,8 @@ class KDPipeline(object):
         self.teng, self.eng, self.mode = teacher_engine, student_engine, mode
         self.side = torch.cuda.Stream(device=student_engine.dev)
         self.pending = None  # (batch id, knowledge, event)
+        # both engines native (and train form): the knowledge stays in the teacher engine's arena, cell-major (no frame round trip, no torch tensors)
+        self.native = mode == "train" and teacher_engine.native is not None and student_engine.native is not None
 
     def _launch_teacher(self, batch):
         main = torch.cuda.current_stream(self.eng.dev)
@@ -1325,9 +1553,10 @@ class KDPipeline(object):
         self.teng._maps(c, batch)  # index maps are allocated and uploaded on the main stream (both engines use them), then cached on the batch
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
-            know = self.teng.knowledge(batch, mode=self.mode)
-            for t in (know[0], know[1], *know[2], *know[3], *know[4]):
-                t.record_stream(main)
+            know = self.teng.knowledge(batch, mode=self.mode, native=self.native)
+            if not isinstance(know, NativeKnowledge):
+                for t in (know[0], know[1], *know[2], *know[3], *know[4]):
+                    t.record_stream(main)
             ev = torch.cuda.Event()
             ev.record(self.side)
         return id(batch), know, ev

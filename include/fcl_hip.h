@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 308
+#define FCL_ABI_VERSION 400
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -655,6 +655,93 @@ int fcl_feed_copy(void* dst, const void* src, size_t bytes, uint32_t* seq_dev, u
  * "\0B" marker (what its scp line points at).  Returns the new file offset (>= file_pos), or a negative FCL_ERR_* (fcl_last_error()). */
 long long fcl_kaldi_ark_append(int fd, long long file_pos, int n, const char* const* keys, const float* data, const int* rows, int cols,
                                long long* offsets);
+
+/* ---- H13 as ONE native routine: the teacher-forced training step orchestrated in C++ (round 4) -------------------------------------------------
+ * Replaces, per update, the reference's `[teacher_knowledge = teacher(**x)]; loss = model(**x); loss.backward()` (tts_distill.py:143-182,
+ * tts.py:137-179; forward()s: ..._kd_teacher.py:521-603, ..._kd_student.py:673-802, ..._sa.py:520-622) with a handful of host calls: the ~530
+ * kernel launches of a KD update were issued one by one through Python / ctypes (16 us each: 8.7 ms of host time per 11 ms update);
+ * here the same launches -- the very entry points above, in the same order, on the same three streams -- are issued from C++.
+ * An engine (fcl_te_t) is bound to the flat parameter / gradient buffers of ONE model; it owns the operand forms of the parameters (packed taps,
+ * transposes, column blocks, P32 planes: fcl_derive_batch, refreshed after every fcl_te_params_changed), a work arena and a zero arena in device
+ * memory (sized by a dry run of the step before anything is launched; grown between steps), its weight-gradient stream and its events.
+ * Scope: model.train() form (batch-statistics BatchNorm, sampled dropout / zoneout drawn on the device with the seeds the Python engine uses,
+ * so both engines produce the same masks), the shipped-recipe structure (use_batch_norm, use_concate, no speaker embedding, no residual encoder,
+ * no output activation), channel widths that are multiples of 32 (odim: of 4).  Everything else stays on fcl_taco2_amd.training.TrainEngine's
+ * per-launch path, which is also the reference implementation this routine is tested against (equal losses / gradients on the same batch). */
+typedef struct fcl_te fcl_te_t;
+enum { FCL_TE_TEACHER = 0, FCL_TE_KD_TEACHER = 1, FCL_TE_STUDENT = 2 };
+enum { FCL_TE_MAX_SITES = 48, FCL_TE_MAX_LOSSES = 48 };
+typedef struct {
+    int32_t role;                 /* FCL_TE_* */
+    int32_t idim, odim, embed_dim, econv_layers, econv_chans, econv_filts, eunits, dunits, prenet_units, postnet_layers, postnet_chans, postnet_filts;
+    int32_t dp_layers, dp_chans, dp_kernel;   /* duration predictor (ESPnet DurationPredictor) */
+    int32_t vp_layers, vp_chans, vp_kernel;   /* pitch / energy predictors (variance_predictor.py) */
+    int32_t ve_kernel;                         /* pitch / energy embedding Conv1d(1 -> C, k) */
+    float dropout_rate, zoneout_rate, dp_dropout, vp_dropout, ve_dropout;
+    int32_t use_masking;
+    /* student: the teacher's widths (targets of the KD projections) and the distillation switches (..._kd_student.py:438-456) */
+    int32_t t_embed_dim, t_econv_chans, t_eunits, t_prenet_units, t_dunits, t_postnet_chans;
+    int32_t share_proj, distill_output, distill_encoder, distill_decoder, distill_prosody;
+    int32_t accum_grad;
+    uint32_t seed;                /* the engine's RNG seed (TrainEngine.seed) */
+    uint32_t site_tag[FCL_TE_MAX_SITES]; /* per mask site: crc32(repr(site name)) & 0x7fffffff, order of fcl_te_site_name() */
+    int32_t dw_planes_min;        /* weight gradients with at least this many outputs run on transposed planes */
+    int32_t pred_stream;          /* predictors' forward / backward beside the decoder's on the weight-gradient stream (FCL_PRED_STREAM) */
+    int32_t late_losses;          /* late KD terms on the weight-gradient stream (FCL_KD_LATE_LOSSES) */
+} fcl_te_config_t;
+/* one batch in the converter's layout (tts.py:215-306) with the integer maps of fcl_taco2_amd.training.build_maps_host, all in DEVICE memory
+ * except live_rows_host */
+typedef struct {
+    int32_t B, T, L, N, F, lmax;
+    const int64_t* xs;            /* [B*T] phoneme ids, 0 = padding */
+    const float* ys;              /* [B*L, odim] target mels, zero padded */
+    const float *f0, *energy, *ds;/* [B*T] ground-truth pitch / energy, durations as floats */
+    const int32_t *lens, *e_lo, *e_hi, *f_lo, *f_hi, *src_sorted, *row_of_enc, *cell_frame, *frame_cell, *prev_frame, *cell_row, *dur, *perm_tb;
+    const int64_t* cell_row_i64;
+    const uint8_t *enc_pad, *enc_valid, *frame_valid, *cell_valid;
+    const float* pos4;            /* [F, 4]: t / d in column 0 */
+    const int32_t* live_rows_host;/* [lmax] HOST */
+    double n_enc, n_frames;       /* valid phoneme positions / valid frames */
+} fcl_te_batch_t;
+/* the KD teacher's knowledge (..._kd_teacher.py:597-603) as device pointers.  dec[0..2] (prenet, LSTM-0, LSTM-1 taps): CELL-major [F, .] when
+ * dec_cell_major != 0 (the native hand-over between two engines that share the batch's maps: no frame round trip), else frame-major [B*L, .] like
+ * the reference's tuple. */
+typedef struct {
+    const float *after, *before;  /* [B*L, odim] */
+    const float* enc[5];          /* embed, conv x3, blstm: [B*T, C_t] */
+    const float* dec[8];          /* prenet, lstm0, lstm1 taps; postnet layer outputs x5 */
+    const float* pro[5];          /* d_outs, p_outs, e_outs [B*T]; p_embs, e_embs [B*T, C_t] */
+    int32_t dec_cell_major;
+} fcl_te_knowledge_t;
+int fcl_te_create(const fcl_te_config_t* cfg, fcl_te_t** out);
+void fcl_te_destroy(fcl_te_t* te);
+/* names of the mask sites (for site_tag) and of the loss slots (rows of the [FCL_TE_MAX_LOSSES][3] sums), NULL past the end */
+const char* fcl_te_site_name(int i);
+const char* fcl_te_loss_name(int i);
+/* bind a parameter (value + gradient accumulator inside the caller's flat buffers) or a buffer (BatchNorm running statistics) by its state_dict
+ * name; fcl_te_finalize checks that everything the configuration needs is bound */
+int fcl_te_bind_param(fcl_te_t* te, const char* name, float* value, float* grad, int64_t numel);
+int fcl_te_bind_buffer(fcl_te_t* te, const char* name, float* value);
+int fcl_te_finalize(fcl_te_t* te, uint32_t* status_word);
+/* the parameters were written (optimizer step, load_state_dict): operand forms are re-derived before the next forward */
+int fcl_te_params_changed(fcl_te_t* te);
+/* the engine's weight-gradient stream (created by the engine): the caller issues bucketed all-reduces from it between backward stages */
+fcl_stream_t fcl_te_side_stream(fcl_te_t* te);
+/* forward only (frozen KD teacher, train-mode statistics): *know points into one of the engine's two alternating arenas: valid until the
+ * second next fcl_te_knowledge call on this engine */
+int fcl_te_knowledge(fcl_te_t* te, const fcl_te_batch_t* batch, uint32_t draw, fcl_te_knowledge_t* know, fcl_stream_t stream);
+/* forward + losses + backward stage 0 (postnet; gradient bucket 0 is final when it returns, in stream order); then fcl_te_backward_stage 1 (decoder:
+ * bucket 1), 2 (predictors / embeddings: bucket 2), 3 (encoder: bucket 3 + the join of the weight-gradient stream).  know: required for the student.
+ * loss_sums_host: pinned [FCL_TE_MAX_LOSSES][3] doubles receiving (sum |d|, sum d^2, count) per loss slot, status_host: pinned uint32, both copied
+ * asynchronously on `stream` at the end of stage 0.  draw: the forward's ordinal (seeds the masks with cfg.seed and the site tags). */
+int fcl_te_forward_backward(fcl_te_t* te, const fcl_te_batch_t* batch, const fcl_te_knowledge_t* know, uint32_t draw, double* loss_sums_host,
+                            uint32_t* status_host, fcl_stream_t stream);
+int fcl_te_backward_stage(fcl_te_t* te, int stage, fcl_stream_t stream);
+/* the end-of-backward join: `stream` waits for everything on the weight-gradient stream (after the caller issued its last bucket's collective there) */
+int fcl_te_join(fcl_te_t* te, fcl_stream_t stream);
+/* diagnostics: launches issued by the last forward_backward (all stages) / knowledge call, and the arena bytes it used */
+int64_t fcl_te_last_launches(fcl_te_t* te);
+int64_t fcl_te_arena_bytes(fcl_te_t* te);
 
 #ifdef __cplusplus
 }

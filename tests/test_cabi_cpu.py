@@ -132,7 +132,8 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
     pairs = [("fcl_decoder_weights_t", _lib.DecoderWeights), ("fcl_decoder_io_t", _lib.DecoderIO), ("fcl_gemm_term_t", _lib.GemmTerm),
              ("fcl_lstm_step_t", _lib.LstmStep), ("fcl_decoder_train_t", _lib.DecoderTrain), ("fcl_decoder_bptt_t", _lib.DecoderBptt),
              ("fcl_bilstm_train_t", _lib.BilstmTrain), ("fcl_bilstm_bptt_t", _lib.BilstmBptt), ("fcl_derive_t", _lib.Derive),
-             ("fcl_pwg_layer_t", _lib.PwgLayer), ("fcl_prof_entry_t", _lib.ProfEntry), ("fcl_row_maps_t", _lib.RowMaps)]
+             ("fcl_pwg_layer_t", _lib.PwgLayer), ("fcl_prof_entry_t", _lib.ProfEntry), ("fcl_row_maps_t", _lib.RowMaps),
+             ("fcl_te_config_t", _lib.TeConfig), ("fcl_te_batch_t", _lib.TeBatch), ("fcl_te_knowledge_t", _lib.TeKnowledge)]
     body = ['#include <stdio.h>', '#include <stddef.h>', '#include "fcl_hip.h"', "int main(void) {"]
     for cname, cls in pairs:
         last = cls._fields_[-1][0]
@@ -181,3 +182,32 @@ def test_round3_entry_points_validate_arguments_without_a_gpu(lib):
     rc = lib.fcl_bilstm_fwd(128, 128, 128, 128, 128, 128, 128, 128, 256, None, None, None, None, 2, 5, 32, 128, 0, 256, ws, None, C.byref(a), None)
     assert rc == -2 and lib.fcl_last_error()  # (empty request: sizes)
     assert lib.fcl_kaldi_ark_append(-1, 0, 0, None, None, None, 80, None) == -1
+
+
+def test_native_training_engine_validates_its_configuration_and_bindings_without_a_gpu(lib):
+    """fcl_te_* (round 4: the training step orchestrated in C++): creation checks the configuration, finalize checks that every parameter the
+    configuration needs is bound with the right size -- all before any HIP call; the name tables are exported for the Python side."""
+    from fcl_taco2_amd import _lib
+
+    sites = [lib.fcl_te_site_name(i) for i in range(_lib.TE_MAX_SITES)]
+    assert sites[0] == b"enc.convs/0" and b"zoneout/1/1" in sites and sites[-1] is None
+    losses = [lib.fcl_te_loss_name(i) for i in range(_lib.TE_MAX_LOSSES)]
+    assert losses[:5] == [b"after", b"before", b"dur", b"pitch", b"energy"] and b"pro4" in losses and losses[-1] is None
+    h = C.c_void_p()
+    assert lib.fcl_te_create(None, C.byref(h)) == -1
+    cfg = _lib.TeConfig()
+    cfg.role = 7
+    assert lib.fcl_te_create(C.byref(cfg), C.byref(h)) == -1 and b"role" in lib.fcl_last_error()
+    cfg = _lib.TeConfig(role=_lib.TE_TEACHER, idim=40, odim=80, embed_dim=48, econv_layers=3, econv_chans=48, econv_filts=5, eunits=48, dunits=64, prenet_units=32,
+                        postnet_layers=5, postnet_chans=32, postnet_filts=5, dp_layers=2, dp_chans=32, dp_kernel=3, vp_layers=2, vp_chans=32, vp_kernel=3,
+                        ve_kernel=9, dropout_rate=0.5, zoneout_rate=0.1, dp_dropout=0.1, vp_dropout=0.5, ve_dropout=0.5, use_masking=1, accum_grad=1)
+    assert lib.fcl_te_create(C.byref(cfg), C.byref(h)) == -2 and b"multiples of 32" in lib.fcl_last_error()
+    cfg.embed_dim = cfg.econv_chans = cfg.eunits = 64
+    assert lib.fcl_te_create(C.byref(cfg), C.byref(h)) == 0 and h.value
+    assert lib.fcl_te_finalize(h, 128) == -1 and b"enc.embed.weight is not bound" in lib.fcl_last_error()
+    assert lib.fcl_te_bind_param(h, b"enc.embed.weight", 130, 256, 40 * 64) == -3  # misaligned
+    assert lib.fcl_te_bind_param(h, b"enc.embed.weight", 256, 512, 40 * 63) == 0
+    assert lib.fcl_te_finalize(h, 128) == -2 and b"expected 2560" in lib.fcl_last_error()
+    assert lib.fcl_te_backward_stage(h, 1, None) == -1
+    assert lib.fcl_te_last_launches(h) == 0 and lib.fcl_te_arena_bytes(h) == 0 and lib.fcl_te_side_stream(h) is None
+    lib.fcl_te_destroy(h)

@@ -1,0 +1,178 @@
+"""-m gpu: the native form of the training step (fcl_te_*, csrc/train_engine.hip: the update's ~530 launches issued from C++) against the
+per-launch Python engine (fcl_taco2_amd.training.TrainEngine(native=False)), which the goldens G5 - G13 pin to the real reference's losses and
+gradients.  Both engines draw their dropout / zoneout masks on the device from (engine seed, forward ordinal, site tag): with the same seeds they
+draw the SAME masks, so the two paths must agree on every named loss, every gradient tensor, the BatchNorm running statistics and the teacher's
+knowledge up to the summation-order noise of atomically accumulated sums.  Full FCL-taco2-S / -T widths (the native routine needs channel widths
+that are multiples of 32), reference-initialised weights (the closed-form ones amplify rounding 1000x: DESIGN section 2)."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from fcl_taco2_amd import hparams as HP, synthetic as SYN
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(seed, b=6, t_lo=40, t_hi=70):
+    from fcl_taco2_amd.converter import CustomConverter
+
+    S = HP.student_hparams()
+    xs, ys, ds, f0, en = SYN.training_batch(80, S.idim, batch=b, t_lo=t_lo, t_hi=t_hi, seed=seed, zero_frac=0.03, lam=10.0, hi=50)
+    return CustomConverter(1, True, True)([(xs, ys, None, ds, f0, en)])
+
+
+def _engines(role, native, seed=5, **kw):
+    from fcl_taco2_amd.training import TrainEngine
+
+    S, T = HP.student_hparams(), HP.teacher_hparams()
+    if role == "student":
+        model = SYN.build_model("student", S, T, DEV, weights="init", seed=3)
+    else:
+        model = SYN.build_model(role, T, None, DEV, weights="init", seed=4)
+    return TrainEngine(model, seed=seed, native=native, **kw)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def _compare_grads(e_nat, e_ref, tol):
+    bad = {}
+    for k in e_ref.G:
+        r = _rel(e_nat.G[k], e_ref.G[k])
+        if not r <= tol:
+            bad[k] = r
+    assert not bad, bad
+    for k in e_ref.B:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert _rel(e_nat.B[k].float(), e_ref.B[k].float()) < 1e-6, k
+
+
+def test_native_step_needs_the_shipped_structure():
+    """What the native routine does not cover stays on the per-launch path, with the reason on the engine."""
+    from fcl_taco2_amd.training import TrainEngine
+
+    if os.environ.get("FCL_PRECISION", "1") == "0":
+        e = _engines("teacher", True)
+        assert e.native is None and "pre-split" in e.native_reason
+        return
+    import dataclasses
+
+    from fcl_taco2_amd.training import _NativeStep
+
+    e2 = _engines("teacher", False)
+    assert e2.native is None and e2.native_reason == "native=False"
+    e3 = _engines("teacher", True)
+    assert e3.native_reason is None and e3.native is not None
+    hp = e3.hp
+    for change, word in ((dict(use_residual=True), "residual"), (dict(output_activation="tanh"), "output activation"), (dict(spk_embed_dim=64), "speaker"),
+                         (dict(prenet_units=250), "multiples of 32")):
+        e3.hp = dataclasses.replace(hp, **change)
+        assert word in _NativeStep.unsupported(e3), (change, _NativeStep.unsupported(e3))
+    e3.hp = hp
+
+
+@pytest.mark.skipif(os.environ.get("FCL_PRECISION", "1") == "0", reason="the native step runs on pre-split operands")
+def test_native_teacher_step_equals_the_per_launch_engine():
+    """FCL-taco2-T's own training step (tts.py:137-179), train form: losses, every gradient, BatchNorm buffers, and two full updates."""
+    batch = _batch(11)
+    e_ref, e_nat = _engines("teacher", False), _engines("teacher", True)
+    assert e_nat.native is not None
+    e_ref.zero_grad(); e_nat.zero_grad()
+    r_ref = e_ref.forward_backward(batch, mode="train")
+    r_nat = e_nat.forward_backward(batch, mode="train")
+    torch.cuda.synchronize()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"):
+        assert abs(r_nat[k] - r_ref[k]) <= 1e-6 * max(1.0, abs(r_ref[k])), (k, r_nat[k], r_ref[k])
+    _compare_grads(e_nat, e_ref, 2e-5)
+    assert e_nat.native.launches() > 100
+    # whole updates (zero_grad, step, clip, Adam; the forms of the new weights re-derived by both engines)
+    for i in range(2):
+        a, b = e_ref.train_step(batch, mode="train"), e_nat.train_step(batch, mode="train")
+        assert abs(a["loss"] - b["loss"]) <= 2e-4 * abs(a["loss"]), (i, a["loss"], b["loss"])
+        assert abs(a["grad_norm"] - b["grad_norm"]) <= 2e-3 * a["grad_norm"]
+    torch.cuda.synchronize()
+    assert e_ref.step_count == e_nat.step_count == 2
+    d = (e_ref.pflat - e_nat.pflat).abs()
+    assert float(d.max()) <= 2 * 1e-3 * 2 and float(d.mean()) < 1e-5  # Adam's first steps turn last-bit gradient noise into +-lr on a few weights
+
+
+@pytest.mark.skipif(os.environ.get("FCL_PRECISION", "1") == "0", reason="the native step runs on pre-split operands")
+@pytest.mark.parametrize("share,flags,masking", [(True, (True, True, True, True), True), (False, (True, False, True, True), False)])
+def test_native_kd_step_equals_the_per_launch_engine(share, flags, masking):
+    """The KD update (tts_distill.py:143-182): the frozen train-mode teacher's knowledge and the student's forward / losses / backward, natively and
+    per launch; the student also fed with the reference-shaped tuple (frame-major decoder taps, gathered to cells inside the routine)."""
+    from fcl_taco2_amd.training import NativeKnowledge, TrainEngine
+
+    S, T = HP.student_hparams(use_masking=masking), HP.teacher_hparams()
+    batch = _batch(21)
+
+    def student(native):
+        m = SYN.build_model("student", S, T, DEV, share_proj=share, weights="init", seed=3)
+        m.distill_output_knowledge, m.distill_encoder_knowledge, m.distill_decoder_knowledge, m.distill_prosody_knowledge = flags
+        return TrainEngine(m, seed=5, native=native)
+
+    t_ref, t_nat = _engines("kd_teacher", False, seed=11), _engines("kd_teacher", True, seed=11)
+    k_ref = t_ref.knowledge(batch, mode="train")
+    k_nat = t_nat.knowledge(batch, mode="train", native=True)
+    assert isinstance(k_nat, NativeKnowledge) and k_nat.struct.dec_cell_major == 1
+    s_ref, s_nat, s_tup = student(False), student(True), student(True)
+    for e in (s_ref, s_nat, s_tup):
+        e.zero_grad()
+    r_ref = s_ref.forward_backward(batch, k_ref, mode="train")
+    r_nat = s_nat.forward_backward(batch, k_nat, mode="train")
+    r_tup = s_tup.forward_backward(batch, k_ref, mode="train")  # native student, tuple of tensors from the per-launch teacher
+    torch.cuda.synchronize()
+    keys = ["loss", "l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss"]
+    keys += ["output_l1_loss", "output_mse_loss"] if flags[0] else []
+    keys += ["encoder_loss"] if flags[1] else []
+    keys += ["decoder_loss"] if flags[2] else []
+    keys += ["prosody_loss"] if flags[3] else []
+    assert set(keys) <= set(r_ref.keys())
+    for k in keys:
+        for r in (r_nat, r_tup):
+            assert abs(r[k] - r_ref[k]) <= 2e-6 * max(1.0, abs(r_ref[k])), (k, r[k], r_ref[k])
+    assert ("encoder_loss" in r_nat) == flags[1] and ("decoder_loss" in r_nat) == flags[2]
+    _compare_grads(s_nat, s_ref, 2e-5)
+    _compare_grads(s_tup, s_ref, 2e-5)
+    for k in t_ref.B:  # the frozen teacher's BatchNorm buffers advance in train mode (the reference never calls teacher.eval())
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert _rel(t_nat.B[k].float(), t_ref.B[k].float()) < 1e-6, k
+        if k.endswith("num_batches_tracked"):
+            assert int(t_nat.B[k]) == int(t_ref.B[k]) == 1
+
+
+@pytest.mark.skipif(os.environ.get("FCL_PRECISION", "1") == "0", reason="the native step runs on pre-split operands")
+def test_native_kd_pipeline_tracks_the_per_launch_pipeline_and_costs_less_host_time():
+    """KDPipeline on two native engines (teacher one batch ahead on its own stream, knowledge handed over cell-major inside the engines' arenas)
+    against the same pipeline on per-launch engines: the same losses over four updates of two alternating batches; and the point of the exercise:
+    the submitting thread's time per update (enqueue only, no synchronisation) drops several-fold."""
+    from fcl_taco2_amd.training import KDPipeline
+
+    bs = [_batch(31, b=16, t_lo=60, t_hi=100), _batch(32, b=16, t_lo=60, t_hi=100)]
+
+    def run(native, n=4):
+        teng, eng = _engines("kd_teacher", native, seed=11), _engines("student", native, seed=5)
+        pipe = KDPipeline(teng, eng)
+        assert pipe.native == native
+        losses = []
+        for i in range(n):
+            losses.append(float(pipe.step(bs[i % 2], bs[(i + 1) % 2])["loss"]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n, n + 6):
+            pipe.step(bs[i % 2], bs[(i + 1) % 2])
+        host = (time.perf_counter() - t0) / 6
+        torch.cuda.synchronize()
+        return losses, host, eng
+
+    l_ref, h_ref, _ = run(False)
+    l_nat, h_nat, eng = run(True)
+    assert l_ref[0] == pytest.approx(l_nat[0], rel=1e-6) and l_ref == pytest.approx(l_nat, rel=3e-3), (l_ref, l_nat)
+    print("host enqueue per KD update: per-launch %.2f ms, native %.2f ms (%d launches in the student's step)" % (1e3 * h_ref, 1e3 * h_nat, eng.native.launches()))
+    assert h_nat < 0.6 * h_ref
