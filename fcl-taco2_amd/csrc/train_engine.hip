@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -30,13 +31,14 @@ struct Param {
 
 struct Arena {
     char* base = nullptr;
-    size_t cap = 0, used = 0;
+    size_t cap = 0, used = 0, dirty = 0;  // dirty: high-water mark of real allocations since the last clear (the zero arena's next memset)
     bool dry = false;
     void reset() { used = 0; }
     void* take(size_t bytes) {
         const size_t o = (used + 255) & ~(size_t)255;
         used = o + bytes;
         if (dry) return reinterpret_cast<char*>((size_t)1 << 30) + o;  // never dereferenced: the dry run launches nothing
+        if (used > dirty) dirty = used;
         return base + o;
     }
 };
@@ -154,7 +156,6 @@ struct fcl_te {
     // arenas: work (two alternating for the frozen teacher: its knowledge outlives the call), zero
     Arena work[2], zero[2];
     int cur_arena = 0, n_arenas = 1;
-    size_t zero_used_prev[2] = {0, 0};
     double* bn_ws[2] = {nullptr, nullptr};  // zero workspaces of fcl_bn_stats_ws_fwd: [0] main stream, [1] weight-gradient stream
     // operand forms
     std::unordered_map<std::string, Form> forms;
@@ -165,7 +166,7 @@ struct fcl_te {
     std::vector<void*> form_allocs;
     float* cat_f = nullptr;  // [W1_hh^T ; W1_ih^T] (fcl_decoder_bptt's w1_cat_t) and its planes
     uint16_t* cat_p = nullptr;
-    size_t dry_zero_used = 0;
+    std::vector<std::array<long long, 6>> sized[2];  // per arena: (B, T, L, N, F, lmax) of batches a dry run has verified to fit it
     bool dry = false;
     int64_t launches = 0, last_launches = 0;
     Ctx c;
@@ -1500,44 +1501,66 @@ static int te_check_batch(const fcl_te_batch_t* b) {
 template <typename Body>
 static int te_run_sized(fcl_te& E, Body body) {
     Arena &W = E.work[E.cur_arena], &Z = E.zero[E.cur_arena];
-    E.dry = true;
-    W.dry = Z.dry = true;
-    W.reset();
-    Z.reset();
-    const int64_t l0 = E.launches;
-    const bool pp = E.pred_pending, lp = E.late_pending, dp = E.dw_pending, pd = E.params_dirty;
-    int rc = body();
-    E.dry = false;
-    W.dry = Z.dry = false;
-    E.launches = l0;
-    E.pred_pending = pp; E.late_pending = lp; E.dw_pending = dp; E.params_dirty = pd;
-    if (rc) return rc;
-    E.dry_zero_used = Z.used;
-    const size_t need_w = W.used + 4096, need_z = Z.used + 4096;
-    if (need_w > W.cap || need_z > Z.cap) {
-        FCL_HIP(hipStreamSynchronize(E.main));
-        FCL_HIP(hipStreamSynchronize(E.side));
-        if (need_w > W.cap) {
-            if (W.base) FCL_HIP(hipFree(W.base));
-            W.base = nullptr;
-            W.cap = need_w + need_w / 4;
-            void* p = nullptr;
-            FCL_HIP(hipMalloc(&p, W.cap));
-            W.base = static_cast<char*>(p);
+    const fcl_te_batch_t& b = E.c.b;
+    const std::array<long long, 6> dims = {b.B, b.T, b.L, b.N, b.F, b.lmax};
+    std::vector<std::array<long long, 6>>& ok = E.sized[E.cur_arena];
+    bool fits = false;
+    if (W.base != nullptr && Z.base != nullptr)
+        for (const auto& v : ok) {
+            bool le = true;
+            for (int i = 0; i < 6; ++i) le = le && dims[i] <= v[i];
+            fits = fits || le;
         }
-        if (need_z > Z.cap) {
-            if (Z.base) FCL_HIP(hipFree(Z.base));
-            Z.base = nullptr;
-            Z.cap = need_z + need_z / 4;
-            void* p = nullptr;
-            FCL_HIP(hipMalloc(&p, Z.cap));
-            Z.base = static_cast<char*>(p);
-            FCL_HIP(hipMemsetAsync(Z.base, 0, Z.cap, E.main));
-            E.zero_used_prev[E.cur_arena] = 0;
+    if (!fits) {  // every allocation of a pass is a product of these six counts and configuration constants: a batch that is no larger in any
+                  // of them than one a dry run has verified fits as well -- the dry run (all the host bookkeeping of a step, once more) is skipped
+        E.dry = true;
+        W.dry = Z.dry = true;
+        W.reset();
+        Z.reset();
+        const int64_t l0 = E.launches;
+        const bool pp = E.pred_pending, lp = E.late_pending, dp = E.dw_pending, pd = E.params_dirty;
+        int rc = body();
+        E.dry = false;
+        W.dry = Z.dry = false;
+        E.launches = l0;
+        E.pred_pending = pp; E.late_pending = lp; E.dw_pending = dp; E.params_dirty = pd;
+        if (rc) return rc;
+        const size_t need_w = W.used + 4096, need_z = Z.used + 4096;
+        if (need_w > W.cap || need_z > Z.cap) {
+            FCL_HIP(hipStreamSynchronize(E.main));
+            FCL_HIP(hipStreamSynchronize(E.side));
+            if (need_w > W.cap) {
+                if (W.base) FCL_HIP(hipFree(W.base));
+                W.base = nullptr;
+                W.cap = need_w + need_w / 4;
+                void* p = nullptr;
+                FCL_HIP(hipMalloc(&p, W.cap));
+                W.base = static_cast<char*>(p);
+            }
+            if (need_z > Z.cap) {
+                if (Z.base) FCL_HIP(hipFree(Z.base));
+                Z.base = nullptr;
+                Z.cap = need_z + need_z / 4;
+                void* p = nullptr;
+                FCL_HIP(hipMalloc(&p, Z.cap));
+                Z.base = static_cast<char*>(p);
+                FCL_HIP(hipMemsetAsync(Z.base, 0, Z.cap, E.main));
+                Z.dirty = 0;
+            }
         }
+        if (ok.size() >= 32) ok.erase(ok.begin());
+        ok.push_back(dims);  // verified: the arenas (which only ever grow) hold this geometry
     }
     W.reset();
     Z.reset();
+    return 0;
+}
+
+// clear what earlier passes dirtied of the zero arena (one launch for every accumulation target of a pass)
+static int te_clear_zero(fcl_te& E) {
+    Arena& Z = E.zero[E.cur_arena];
+    if (Z.dirty) FCL_HIP(hipMemsetAsync(Z.base, 0, Z.dirty, E.main));
+    Z.dirty = 0;
     return 0;
 }
 
@@ -1556,8 +1579,7 @@ int fcl_te_knowledge(fcl_te_t* Ep, const fcl_te_batch_t* batch, uint32_t draw, f
     const int64_t l0 = E.launches;
     // the frozen teacher enqueues nothing on its weight-gradient stream: nothing to order the clear behind
     TE_TRY(te_run_sized(E, [&]() { return te_forward(E); }));
-    if (E.zero_used_prev[E.cur_arena]) FCL_HIP(hipMemsetAsync(E.zero[E.cur_arena].base, 0, E.zero_used_prev[E.cur_arena], E.main));
-    E.zero_used_prev[E.cur_arena] = E.dry_zero_used;  // what THIS pass will dirty (known from the dry run, also if the pass is abandoned half way)
+    TE_TRY(te_clear_zero(E));
     TE_TRY(te_forward(E));
     Ctx& c = E.c;
     memset(know, 0, sizeof(*know));
@@ -1609,8 +1631,7 @@ int fcl_te_forward_backward(fcl_te_t* Ep, const fcl_te_batch_t* batch, const fcl
     // stream still holds, then clear what the previous step used of the zero arena (one launch for every accumulation target of the step)
     TE_TRY(ev_wait(E, E.main, E.side));
     E.pred_pending = E.late_pending = E.dw_pending = false;
-    if (E.zero_used_prev[0]) FCL_HIP(hipMemsetAsync(E.zero[0].base, 0, E.zero_used_prev[0], E.main));
-    E.zero_used_prev[0] = E.dry_zero_used;  // what THIS step will dirty (known from the dry run, also if the step is abandoned half way)
+    TE_TRY(te_clear_zero(E));
     TE_TRY(te_forward(E));
     TE_TRY(te_losses(E, kp));
     TE_TRY(te_backward_stage0(E));
