@@ -465,6 +465,37 @@ static void launch_lstm_cfg(const LstmStepArgs& a, hipStream_t s, const char* na
     }
 }
 
+// ---- exact fp32 on the LDS-DMA machinery of gemm_planes.hip (round 4) ------------------------------------------------------------------------
+// Under FCL_PRECISION=0 a contraction whose operands are plain row-major fp32 matrices with K, lda, ldw multiples of 32 floats and 128-byte aligned
+// bases IS a set of 128-byte lines in the geometry the pre-split kernels stream (a P32 line holds 32 hi | 32 lo bf16 halves of 32 columns, an fp32
+// line the 32 columns themselves): the same loaders, ring, swizzle and epilogues run it with v_mfma_f32_16x16x4_f32 (pchunk_mma, HI = 2).
+extern thread_local bool t_exact_lines;  // gemm_planes.hip
+static bool exact_lines_on() {
+    static const int v = tunable("EXACT_LINES", 1);
+    return v != 0;
+}
+static bool exact_lines_ok(const GemmTerm* t, int n) {
+    if (precision() || !exact_lines_on()) return false;
+    for (int i = 0; i < n; ++i) {
+        if (!t[i].A || !t[i].W || (t[i].K & 31) || (t[i].lda & 31) || (t[i].ldw & 31) || t[i].lda < t[i].K || t[i].ldw < t[i].K || t[i].a_chunk_stride) return false;
+        if ((reinterpret_cast<uintptr_t>(t[i].A) | reinterpret_cast<uintptr_t>(t[i].W)) & 127u) return false;
+    }
+    return true;
+}
+template <typename Args>
+static void exact_lines_terms(Args& b, int n) {  // the fp32 rows as "planes": lines per row = floats per row / 32
+    for (int i = 0; i < n; ++i) {
+        b.term[i].Ap = reinterpret_cast<const uint16_t*>(b.term[i].A);
+        b.term[i].Wp = reinterpret_cast<const uint16_t*>(b.term[i].W);
+        b.term[i].lda_p = b.term[i].lda / 32;
+        b.term[i].ldw_p = b.term[i].ldw / 32;
+    }
+}
+struct ExactScope {
+    ExactScope() { t_exact_lines = true; }
+    ~ExactScope() { t_exact_lines = false; }
+};
+
 // --------------------------------------------------------------------------------------------------
 static int check_terms(const GemmTerm* t, int n, int maxn, bool need_seg, const int* lo) {
     FCL_REQUIRE(n >= 1 && n <= maxn, FCL_ERR_INVALID, "gemm: nterms %d out of range [1,%d]", n, maxn);
@@ -497,6 +528,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     FCL_REQUIRE(!a.Y2 || a.y2_row_base, FCL_ERR_INVALID, "gemm: Y2 needs y2_row_base");
     if (precision() && planes_ok(a.term, a.nterms)) return launch_gemm_planes(a, s);  // pre-split operands: the LDS-DMA kernels
     FCL_REQUIRE(a.Y && !a.Yp, FCL_ERR_INVALID, "gemm: the fp32-operand kernels write fp32 outputs only (planes output needs planes inputs)");
+    static const int exact_min_m = tunable("EXACT_LINES_MIN_M", 257);  // (fewer rows: the split-K / 64-row fp32-operand kernels below)
+    if (a.M >= exact_min_m && exact_lines_ok(a.term, a.nterms)) {
+        GemmArgs b = a;
+        exact_lines_terms(b, a.nterms);
+        ExactScope sc;
+        return launch_gemm_planes(b, s);
+    }
     for (int i = 0; i < a.nterms; ++i) FCL_REQUIRE(a.term[i].A && a.term[i].W, FCL_ERR_INVALID, "gemm: term %d has no fp32 operands for the fp32-operand kernels", i);
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
@@ -530,7 +568,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
 bool lstm_step_is_small(int M, int U) {
     static const int small_m = tunable("LSTM_SMALL_M", 0);  // 0 = by width: the wave-per-gate small-tile kernel re-streams W per 16-row tile,
     // which stops paying earlier at U = 1024 (FCL-taco2-T); with the pre-split operand kernels available (32-row tiles) at ~500 rows for U = 256
-    static const bool planes_on = tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0;
+    static const bool planes_on = (tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0) || (tunable("PRECISION", 1) == 0 && tunable("EXACT_LINES", 1) != 0);
     // (U >= 512: 256 -> 64 rows in round 3 -- FCL-taco2-T synthesis 6.88 -> 7.18 M frames/s, teacher update 12.93 -> 12.78 ms: at 4 096 gate columns the
     // 32-row pre-split tiles beat the wave-per-gate kernel's W re-streaming from 65 rows on)
     return M <= (small_m ? small_m : (U >= 512 ? (planes_on ? 64 : 256) : (planes_on ? 512 : 1024)));
@@ -555,6 +593,12 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     if (precision() && planes_ok(a.term, a.nterms) && (!small || !has_f32)) return launch_lstm_planes(a, s);  // pre-split operands, LDS-DMA ring
     FCL_REQUIRE(has_f32, FCL_ERR_INVALID, "lstm_step: the fp32-operand kernels need A and W of every term");
     if (small) return launch_lstm_small(a, s);
+    if (!a.h_out_p && exact_lines_ok(a.term, a.nterms)) {  // FCL_PRECISION=0: the step on the LDS-DMA kernels with exact fp32 MFMAs
+        LstmStepArgs b = a;
+        exact_lines_terms(b, a.nterms);
+        ExactScope sc;
+        return launch_lstm_planes(b, s);
+    }
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
     const double flops = 2.0 * a.M * 4.0 * a.U * ksum;

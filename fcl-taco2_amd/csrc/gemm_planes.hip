@@ -60,10 +60,42 @@ __device__ __forceinline__ void xcd_tile_p(int& bx, int& by) {
 }
 
 // one 32-k chunk of a wave's TM x TN tiles: fragment reads (bank-conflict free by the piece permutation) and 3 bf16 MFMAs per tile pair
-template <int TM, int TN, bool HI>
+// HI = 0: bf16x3 split (hi | lo planes, three MFMAs per product); 1: the hi planes alone (autocast); 2 (round 4): EXACT fp32 -- the "planes" are
+// plain row-major fp32 matrices (a 128-byte line = 32 consecutive floats of a row instead of 32 hi | 32 lo halves: same line geometry, same LDS-DMA
+// ring, same swizzle), consumed by v_mfma_f32_16x16x4_f32: lane (r16, kq) reads floats 4 kq .. 4 kq + 3 and 16 + 4 kq .. + 3 of its row's line (the two
+// 16-byte pieces the bf16 form reads as hi and lo) and MFMA e of a piece contracts k = 4 kq + e of all four lane groups -- a permutation of the 32
+// k's that is the same for both operands.  8 MFMAs of 32 cycles per (row tile, column tile) and chunk: the loop is MFMA-bound, as an exact-fp32
+// GEMM should be (FCL_PRECISION=0; until round 4 that mode ran on gemm_f32.hip's register-staged kernels at 0.32 of the fp32 matrix peak).
+template <int TM, int TN, int HI>
 __device__ __forceinline__ void pchunk_mma(const u8* sb, int a_hi, int a_lo, int b_hi, int b_lo, f32x4 (&acc)[TM][TN]) {
+    if constexpr (HI == 2) {
+        f32x4 a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            a0[tm] = *reinterpret_cast<const f32x4*>(sb + a_hi + tm * 16 * 128);
+            a1[tm] = *reinterpret_cast<const f32x4*>(sb + a_lo + tm * 16 * 128);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            b0[tn] = *reinterpret_cast<const f32x4*>(sb + b_hi + tn * 16 * 128);
+            b1[tn] = *reinterpret_cast<const f32x4*>(sb + b_lo + tn * 16 * 128);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tm][e], b0[tn][e], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tm][e], b1[tn][e], acc[tm][tn], 0, 0, 0);
+        return;
+    }
     s16x8 ah[TM], al[TM], bh[TN], bl[TN];
-    if constexpr (HI) {  // FCL_GEMM_BF16 (autocast): operands rounded to bf16 = the hi plane alone, one MFMA per product, fp32 accumulation
+    if constexpr (HI == 1) {  // FCL_GEMM_BF16 (autocast): operands rounded to bf16 = the hi plane alone, one MFMA per product, fp32 accumulation
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) ah[tm] = *reinterpret_cast<const s16x8*>(sb + a_hi + tm * 16 * 128);
 #pragma unroll
@@ -112,7 +144,7 @@ struct PGeo {
 
 // The shared main loop.  LSTM: tile column c of the wave strip wn is gate (c >> 4) & 3 of unit u0 + wn*16 + (c & 15), i.e. W row g*NU + u
 // (TN must be 4); generic: W row n0 + c.  NU = N (generic) or U.  Returns false in a loader wave (LW > 0), which is done and must return.
-template <int WM, int WN, int TM, int TN, int NST, bool LSTM, int LW, bool HI>
+template <int WM, int WN, int TM, int TN, int NST, bool LSTM, int LW, int HI>
 __device__ __forceinline__ bool pmainloop(const GemmTerm* __restrict__ terms, int nterms, int M, int m0, int n0, int NU, const int* __restrict__ seg_lo,
                                           const int* __restrict__ seg_hi, u8* smem, f32x4 (&acc)[TM][TN], int ksplit_chunks = 0) {
     using G = PGeo<WM, WN, TM, TN, NST, LW>;
@@ -445,8 +477,8 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[
 
 // (HIP's second __launch_bounds__ argument is waves per SIMD: two stages = 64 KB of LDS = two 12-wave workgroups per CU = 6 waves per SIMD, i.e. at
 // most 80 VGPRs -- the three-stage instantiation needs 78, so asking for it costs nothing)
-template <int WM, int WN, int TM, int TN, int NST, int LW, bool HI>
-__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12) ? 6 : 1) void pgemm_kernel(const GemmArgs a) {
+template <int WM, int WN, int TM, int TN, int NST, int LW, int HI>
+__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12 && HI != 2) ? 6 : 1) void pgemm_kernel(const GemmArgs a) {
     using G = PGeo<WM, WN, TM, TN, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
@@ -473,8 +505,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 1
 
 // NST = 2 (two ring stages, 64 KB: TWO workgroups per CU, 6 waves per SIMD, <= 80 VGPRs): the epilogue operands are then NOT requested before
 // the K loop (48 VGPRs held across it) but where they are used -- the other workgroup's main loop covers their latency.
-template <int WM, int WN, int TM, int NST, int MODE, int LW, bool HI>
-__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12) ? 6 : 1) void plstm_kernel(const LstmStepArgs a) {
+template <int WM, int WN, int TM, int NST, int MODE, int LW, int HI>
+__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12 && HI != 2) ? 6 : 1) void plstm_kernel(const LstmStepArgs a) {
     using G = PGeo<WM, WN, TM, 4, NST, LW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
@@ -602,7 +634,7 @@ static int loader_waves() {
     return v;
 }
 
-template <int WM, int WN, int TM, int TN, int NST, int LW, bool HI>
+template <int WM, int WN, int TM, int TN, int NST, int LW, int HI>
 static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
     using G = PGeo<WM, WN, TM, TN, NST, LW>;
     auto k = pgemm_kernel<WM, WN, TM, TN, NST, LW, HI>;
@@ -611,7 +643,7 @@ static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
     const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;  // the tiles also cover the zero padding of the output planes
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
     char full[64];
-    snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NST, LW, HI ? "/bf16" : "", a.accumulate ? "/dW" : "");
+    snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NST, LW, HI == 2 ? "/f32" : HI ? "/bf16" : "", a.accumulate ? "/dW" : "");
     ProfScope ps(full, flops, a.M, s);
     if (a.accumulate && a.nterms == 1) {  // weight gradient: few output tiles, long contraction -> slices of the contraction over gridDim.z, ~512 workgroups
         GemmArgs b = a;
@@ -634,8 +666,12 @@ static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
     return check_hip(hipGetLastError(), "pgemm launch");
 }
 
+// set by launch_gemm / launch_lstm_step (gemm_f32.hip) around a dispatch whose "planes" are plain fp32 rows: the exact-fp32 instantiations
+thread_local bool t_exact_lines = false;
+
 template <int WM, int WN, int TM, int TN, int NST>
 static int launch_pgemm_cfg(const GemmArgs& a, hipStream_t s, double flops) {
+    if (t_exact_lines) return launch_pgemm_lw<WM, WN, TM, TN, NST, 4, 2>(a, s, flops);
     if (gemm_mode() == FCL_GEMM_BF16)  // autocast: bf16-rounded operands (the hi planes alone), one MFMA per product
         return loader_waves() ? launch_pgemm_lw<WM, WN, TM, TN, NST, 2, true>(a, s, flops) : launch_pgemm_lw<WM, WN, TM, TN, NST, 0, true>(a, s, flops);
     if (loader_waves() == 4) return launch_pgemm_lw<WM, WN, TM, TN, NST, 4, false>(a, s, flops);
@@ -875,14 +911,14 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     return launch_pgemm_cfg<2, 2, 2, 2, 4>(a, s, flops);
 }
 
-template <int WM, int WN, int TM, int NST, int LW, bool HI>
+template <int WM, int WN, int TM, int NST, int LW, int HI>
 static int launch_plstm_lw(const LstmStepArgs& a, hipStream_t s, double flops) {
     using G = PGeo<WM, WN, TM, 4, NST, LW>;
     const bool plain = !a.zone_keep_h && !a.row_len && !a.save_gates && !a.out2;  // (MODE >= 0 compiles these options out of the cell code)
     const int mode = (plain && a.G && a.rank1_w && !a.bias) ? 0 : (plain && a.bias && !a.G && !a.rank1_w) ? 1 : -1;
     dim3 grid((a.U + 16 * WN - 1) / (16 * WN), (a.M + G::BM - 1) / G::BM);
     char full[64];
-    snprintf(full, sizeof(full), "plstm_kernel<%d,%d,%d,%d,%d,%d>%s", WM, WN, TM, NST, mode, LW, HI ? "/bf16" : "");
+    snprintf(full, sizeof(full), "plstm_kernel<%d,%d,%d,%d,%d,%d>%s", WM, WN, TM, NST, mode, LW, HI == 2 ? "/f32" : HI ? "/bf16" : "");
     const void* fn = mode == 0 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 0, LW, HI>)
                    : mode == 1 ? reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, 1, LW, HI>)
                                : reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, -1, LW, HI>);
@@ -897,6 +933,7 @@ static int launch_plstm_lw(const LstmStepArgs& a, hipStream_t s, double flops) {
 
 template <int WM, int WN, int TM, int NST>
 static int launch_plstm_cfg(const LstmStepArgs& a, hipStream_t s, double flops) {
+    if (t_exact_lines) return launch_plstm_lw<WM, WN, TM, NST, 4, 2>(a, s, flops);
     if (gemm_mode() == FCL_GEMM_BF16)
         return loader_waves() ? launch_plstm_lw<WM, WN, TM, NST, 2, true>(a, s, flops) : launch_plstm_lw<WM, WN, TM, NST, 0, true>(a, s, flops);
     if (loader_waves() == 4) return launch_plstm_lw<WM, WN, TM, NST, 4, false>(a, s, flops);
