@@ -884,7 +884,8 @@ def main():
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = pmc_traffic(dom)
+        # (the exact-fp32 mode has its own PMC pair: rN_pmc_fp32_fetch_size.csv / ..._write_size.csv, collected under FCL_PRECISION=0)
+        traffic, traffic_src = pmc_traffic(dom, "fp32" if os.environ.get("FCL_PRECISION", "1") == "0" else "")
         peak, peak_note = mfma_ceiling()
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "instantiations": sorted(d["members"]), "achieved": achieved, "peak": peak, "unit": "TFLOP/s",

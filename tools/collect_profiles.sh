@@ -1,7 +1,7 @@
 # Collects the round's profile evidence on the GPU box into gpurun_out/prof_$1/ (copy the summaries to profiles/ afterwards):
 #   default bench JSON (fresh feed, 4 capacity graphs in flight), rocprofv3 kernel stats of that command and of the eager single-stream pass,
 #   PMC FETCH_SIZE / WRITE_SIZE / SQ counters (separate --pmc passes, --kernel-trace only), training-step JSONs + kernel stats + PMC traffic.
-TAG=${1:-r3}
+TAG=${1:-r4}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -27,6 +27,13 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o w --output-format csv -- $E1 > /
 pmc $OUT/pmc_write $OUT/pmc_write_size.csv pmc_summary.py
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS -d $OUT/pmc_sq -o s --output-format csv -- $E1 > /dev/null 2>&1
 pmc $OUT/pmc_sq $OUT/pmc_sq_counters.csv pmc_multi.py
+# the exact-fp32 mode's own traffic pair (FCL_PRECISION=0: the LDS-DMA kernels on fp32 lines since round 4) and kernel stats
+FCL_PRECISION=0 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_ffetch -o f --output-format csv -- $E1 > /dev/null 2>&1
+pmc $OUT/pmc_ffetch $OUT/pmc_fp32_fetch_size.csv pmc_summary.py
+FCL_PRECISION=0 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_fwrite -o w --output-format csv -- $E1 > /dev/null 2>&1
+pmc $OUT/pmc_fwrite $OUT/pmc_fp32_write_size.csv pmc_summary.py
+FCL_PRECISION=0 rocprofv3 --kernel-trace --stats -d $OUT/eagerf -o e --output-format csv -- python3 bench.py --streams 1 --eager --feed replay --no-cpu-baseline --no-extras --regions 3 > /dev/null 2>&1
+stats $OUT/eagerf $OUT/fp32_eager_1stream_kernel_stats.csv; rm -rf $OUT/eagerf
 # training workloads: bench JSON (with the CPU baseline) in both arithmetic modes, kernel stats and PMC traffic of the KD and teacher steps
 for w in kd_step teacher_step; do
   python3 bench.py --workload $w > $OUT/bench_$w.json 2> /dev/null
