@@ -34,4 +34,15 @@ for i in range(K):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print("host enqueue %.2f ms / update, wall %.2f ms / update" % ((t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3))
+# the enqueue of ONE update on an idle queue (round 4: with the native step the host runs far ahead of the device, so K back-to-back enqueues
+# measure the HIP queue's back-pressure, i.e. the device, not the host)
+one = []
+for i in range(9):
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    step(i)
+    one.append(time.perf_counter() - a)
+torch.cuda.synchronize()
+one.sort()
+print("host enqueue of one update (idle queue, median of 9) %.2f ms; %d back-to-back updates: host %.2f ms / update, wall %.2f ms / update; native step: %s"
+      % (one[4] * 1e3, K, (t1 - t0) / K * 1e3, (t2 - t0) / K * 1e3, eng.native is not None))
