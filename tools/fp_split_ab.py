@@ -1,6 +1,7 @@
-"""Developer aid: the column-split feat/prenet kernel (FCL_FP_SPLIT=4, default) against the unsplit one (FCL_FP_SPLIT=0): mels of the configs[1]
-batch (dropout off, RNG mode and injected masks) must be IDENTICAL bit for bit; prints per-kernel times of one eager pass for both.
-Each arm runs in its own child process (the tunable is read once per process)."""
+"""Developer aid: same-box A/B of library tunables (read once per process, so each arm is a child process): mels of the configs[1] batch and two small
+ones (dropout off, RNG mode, injected masks) are compared bit for bit against the first arm, and the per-kernel times of one eager pass are printed.
+    python tools/fp_split_ab.py 0 1,1          # feat/prenet: FCL_FP_SPLIT[,FCL_FP_SPLIT_RT] per arm (the round-4 use)
+    python tools/fp_split_ab.py FCL_LSTM_WD=0 FCL_LSTM_WD=1 FCL_LSTM_WD=1,FCL_LSTM_WD_TM=2     # any NAME=VALUE[,NAME=VALUE] per arm"""
 import os
 import subprocess
 import sys
@@ -46,13 +47,19 @@ np.savez(out, **res)
 
 outs = {}
 for ns in sys.argv[1:] or ["0", "4"]:
-    path = "/tmp/fp_ab_%s.npz" % ns.replace(",", "_")
+    path = "/tmp/fp_ab_%s.npz" % ns.replace(",", "_").replace("=", "-")
     env = dict(os.environ)
     parts = ns.split(",")
-    env["FCL_FP_SPLIT"] = parts[0]
-    if len(parts) > 1:
-        env["FCL_FP_SPLIT_RT"] = parts[1]
-    print("FCL_FP_SPLIT=%s" % ns, flush=True)
+    if "=" in ns:
+        for kv in parts:
+            k_, v_ = kv.split("=", 1)
+            env[k_] = v_
+        print(ns, flush=True)
+    else:
+        env["FCL_FP_SPLIT"] = parts[0]
+        if len(parts) > 1:
+            env["FCL_FP_SPLIT_RT"] = parts[1]
+        print("FCL_FP_SPLIT=%s" % ns, flush=True)
     r = subprocess.run([sys.executable, "-c", CHILD, path], env=env, capture_output=True, text=True)
     print(r.stdout + r.stderr[-2000:] if r.returncode else r.stdout, flush=True)
     outs[ns] = dict(np.load(path)) if r.returncode == 0 else None
