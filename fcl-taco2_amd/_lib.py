@@ -22,7 +22,7 @@ class DecoderWeights(C.Structure):
                           "w1_ih", "w1_hh", "b1", "wf_h", "wf_att")
     ] + [("zoneout_rate", _F), ("prenet_dropout", _F)] + [
         (n + sfx, _P) for n in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h") for sfx in ("_hi", "_lo")] + [
-        (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")] + [("out_act", _I)]
+        (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")] + [("out_act", _I), ("stream", _P)]
 
 
 class DecoderIO(C.Structure):
@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 400  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 410  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -181,6 +181,8 @@ SIGNATURES = {
     "fcl_bilstm_workspace_bytes": (_Z, [_I, _I, _I]),
     "fcl_bilstm_fwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),
     "fcl_decoder_loop_workspace_bytes": (_Z, [C.POINTER(DecoderWeights), _I]),
+    "fcl_decoder_stream_bytes": (_Z, [C.POINTER(DecoderWeights)]),
+    "fcl_decoder_stream_pack": (_I, [C.POINTER(DecoderWeights), _P, _Z, _P]),
     "fcl_decoder_loop_fwd": (_I, [C.POINTER(DecoderWeights), C.POINTER(DecoderIO), _P]),
     "fcl_masked_l1_mse_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _F, _P, _P]),
     "fcl_gemm_tn_fwd": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -297,6 +297,17 @@ size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n) {
     return carve(w, n, nullptr).bytes + 256;
 }
 
+size_t fcl_decoder_stream_bytes(const fcl_decoder_weights_t* w) { return w ? decoder_stream_bytes(w) : 0; }
+
+int fcl_decoder_stream_pack(const fcl_decoder_weights_t* w, void* out, size_t out_bytes, fcl_stream_t stream) {
+    FCL_REQUIRE(w && out, FCL_ERR_INVALID, "decoder_stream_pack: null argument");
+    const size_t need = decoder_stream_bytes(w);
+    FCL_REQUIRE(need > 0, FCL_ERR_SHAPE, "decoder_stream_pack: U = %d / P = %d / odim = %d is not covered by the row-tile kernel (U = P = 256, odim <= 128)", w->u, w->p, w->odim);
+    FCL_REQUIRE(out_bytes >= need && aligned16(out), FCL_ERR_WORKSPACE, "decoder_stream_pack: the buffer needs %zu bytes, 16-byte aligned", need);
+    FCL_REQUIRE(w->prenet_w0 && w->prenet_w1 && w->w0_pre && w->w0_hh && w->w1_ih && w->w1_hh && w->wf_h, FCL_ERR_INVALID, "decoder_stream_pack: null weight pointer");
+    return decoder_stream_pack(w, out, (hipStream_t)stream);
+}
+
 int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, fcl_stream_t stream) {
     FCL_REQUIRE(w && io, FCL_ERR_INVALID, "decoder_loop_fwd: null argument");
     FCL_REQUIRE(w->c > 0 && w->p > 0 && w->u > 0 && w->odim > 0 && !(w->c & 3) && !(w->p & 3) && !(w->u & 3) && !(w->odim & 3),
@@ -356,6 +367,16 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
     }
     const float keep_scale = 1.0f / (1.0f - w->prenet_dropout);
     const int drop_mode = (w->prenet_dropout > 0.f) ? io->dropout_mode : FCL_DROP_NONE;
+    {
+        // round 4, opt-in (FCL_DEC_TILE=1): the whole loop as ONE launch of persistent 32-row workgroups (decoder_tile.hip) -- free-running synthesis
+        // of the covered shape.  OFF by default: it halves the decoder's CU-time but a step of a tile is the 4.7 MB weight stream through ONE CU
+        // (58 - 70 us) where the per-step launches put all 256 CUs on the step (45 us): with four passes in flight the pass is bound by that
+        // chain, and the line drops from 45 to 38 M frames/s (HISTORY "round 4")
+        static const int tile_on = tunable("DEC_TILE", 0), tile_min = tunable("DEC_TILE_MIN_ROWS", 1024);
+        if (tile_on && planes && w->stream && decoder_tile_shape_ok(w) && N >= tile_min && io->lmax <= 64 && !io->teacher_ys && !io->tap_prenet && !io->tap_lstm0 &&
+            !io->tap_lstm1 && drop_mode != FCL_DROP_MASK && gemm_mode() != FCL_GEMM_BF16)
+            return launch_decoder_tile(w, io, ws.G0, ws.F0, ws.c0, ws.c1, drop_mode, s);
+    }
     static const int fused = tunable("FUSED_PRENET", 1);
     FCL_REQUIRE(fused || !io->live_rows, FCL_ERR_INVALID, "decoder_loop_fwd: device live_rows need the fused feat/prenet kernel (FCL_FUSED_PRENET=1)");
     int cur = 0;

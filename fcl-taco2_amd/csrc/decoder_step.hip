@@ -732,23 +732,6 @@ __device__ __forceinline__ void mma_t(const WFrag<NT, NS_>& w, const u16* Ah, co
     for (int t = 0; t < NT; ++t) out[t] = acc[t];
 }
 
-// dropout of four consecutive columns n .. n + 3 of row m (DROP: 0 none, 1 mask bytes, 2 counter hash: 16 bits per decision)
-template <int DROP>
-__device__ __forceinline__ f32x4 drop4(f32x4 v, unsigned int keep4, unsigned int idx, unsigned int seed, unsigned int thr16, float scale) {
-    if (DROP == 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = ((keep4 >> (8 * r)) & 0xFFu) ? v[r] * scale : 0.f;
-    }
-    if (DROP == 2) {
-        const unsigned int h0 = hash_u32(idx ^ seed), h1 = hash_u32((idx + 2u) ^ seed);
-        v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * scale : 0.f;
-        v[1] = (h0 >> 16) >= thr16 ? v[1] * scale : 0.f;
-        v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * scale : 0.f;
-        v[3] = (h1 >> 16) >= thr16 ? v[3] * scale : 0.f;
-    }
-    return v;
-}
-
 template <int DROP, int RT, int NS>
 __global__ __launch_bounds__(512) void feat_prenet_split_kernel(const FeatPrenetArgs a) {
     constexpr int SU = 8, SO = 3, SP = 8, U = 256, OP = 96, P = 256, CT = 16 / NS, NW1 = CT < 8 ? CT : 8, T1 = CT / NW1;

@@ -228,4 +228,29 @@ __host__ __device__ static inline unsigned int hash_u32(unsigned int x) {
     return x;
 }
 
+// dropout of four consecutive columns n .. n + 3 of row m (DROP: 0 none, 1 mask bytes, 2 counter hash: 16 bits per decision; idx = m * N + n) --
+// shared by feat_prenet_split_kernel (decoder_step.hip) and decoder_tile_kernel (decoder_tile.hip): the same (seed, row, column) draws the same bits
+template <int DROP>
+__device__ __forceinline__ f32x4_t drop4(f32x4_t v, unsigned int keep4, unsigned int idx, unsigned int seed, unsigned int thr16, float scale) {
+    if (DROP == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = ((keep4 >> (8 * r)) & 0xFFu) ? v[r] * scale : 0.f;
+    }
+    if (DROP == 2) {
+        const unsigned int h0 = hash_u32(idx ^ seed), h1 = hash_u32((idx + 2u) ^ seed);
+        v[0] = (h0 & 0xFFFFu) >= thr16 ? v[0] * scale : 0.f;
+        v[1] = (h0 >> 16) >= thr16 ? v[1] * scale : 0.f;
+        v[2] = (h1 & 0xFFFFu) >= thr16 ? v[2] * scale : 0.f;
+        v[3] = (h1 >> 16) >= thr16 ? v[3] * scale : 0.f;
+    }
+    return v;
+}
+
+// ---- the persistent row-tile decoder loop (decoder_tile.hip) ---------------------------------------------------------------------------
+bool decoder_tile_shape_ok(const fcl_decoder_weights_t* w);
+size_t decoder_stream_bytes(const fcl_decoder_weights_t* w);
+int decoder_stream_pack(const fcl_decoder_weights_t* w, void* out, hipStream_t s);
+int launch_decoder_tile(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, const float* G0, const float* F0, float* c0, float* c1, int drop_mode,
+                        hipStream_t s);
+
 }  // namespace fcl

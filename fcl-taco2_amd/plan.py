@@ -8,6 +8,8 @@ Packing (all by libfcl_hip kernels, not torch ops):
   * bias_ih + bias_hh summed.
 LSTM / Linear matrices are used in place: torch's [out, in] layout is already the K-contiguous W the GEMM wants.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -177,6 +179,14 @@ class SynthesisPlan(object):
                     pl = ops.pack_planes(t[k])
                     setattr(s, k + "_p", pl.data_ptr())
                     d.keep.append(pl)
+                # the step's weights in the consumption order of the persistent row-tile decoder kernel (csrc/decoder_tile.hip; 0 bytes: shape not covered)
+                lib = _lib.load()
+                nbytes = lib.fcl_decoder_stream_bytes(ctypes.byref(s))
+                if nbytes:
+                    stream = torch.empty(nbytes, device=self.device, dtype=torch.uint8)
+                    ops.check(lib.fcl_decoder_stream_pack(ctypes.byref(s), stream.data_ptr(), nbytes, ops._stream()))
+                    s.stream = stream.data_ptr()
+                    d.keep.append(stream)
         s.zoneout_rate = float(hp.zoneout_rate)
         s.prenet_dropout = float(hp.dropout_rate)
         s.out_act = output_act_code(hp)  # output_activation_fn on the fed-back frame (decoder_sa.py:614-617)

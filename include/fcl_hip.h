@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 400
+#define FCL_ABI_VERSION 410
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -276,6 +276,10 @@ typedef struct {
     const uint16_t *w0_att_p, *wf_att_p, *w0_pre_p, *w0_hh_p, *w1_ih_p, *w1_hh_p;
     int out_act;            /* FCL_ACT_*: `output_activation_fn` on the frame fed back to the prenet in the free-running loop
                              * (decoder_sa.py:614-617; `before` keeps the raw feat_out values, the caller activates the final output :635-636) */
+    const uint16_t* stream; /* optional (round 4): the step's weights in the consumption order of the persistent row-tile kernel
+                             * (fcl_decoder_stream_pack; fcl_decoder_stream_bytes() bytes, 0 = shape not covered).  With it, the P32 planes above and
+                             * a free-running loop of >= FCL_DEC_TILE_MIN_ROWS rows (no teacher forcing, taps or injected masks), fcl_decoder_loop_fwd
+                             * runs the whole loop as ONE launch: 32 rows per workgroup, states resident in LDS / registers for all their steps */
 } fcl_decoder_weights_t;
 
 typedef struct {
@@ -308,6 +312,10 @@ typedef struct {
 } fcl_decoder_io_t;
 
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n);
+/* the weight stream of the persistent row-tile decoder kernel (csrc/decoder_tile.hip): bytes (0: this U / P / odim is not covered: U = P = 256,
+ * odim <= 128) and the packing of the fp32 matrices of `w` (hi | lo bf16 lines, tile-major in consumption order, swizzled for the fragment reads) */
+size_t fcl_decoder_stream_bytes(const fcl_decoder_weights_t* w);
+int fcl_decoder_stream_pack(const fcl_decoder_weights_t* w, void* out, size_t out_bytes, fcl_stream_t stream);
 int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, fcl_stream_t stream);
 
 /* ---- H10 on the device: the integer row / frame maps of a batch from durations that live in HBM (predicted by fcl_duration_round_fwd, or

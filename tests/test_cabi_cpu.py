@@ -64,6 +64,13 @@ def test_decoder_loop_argument_validation(lib):
     w.odim = 80
     assert lib.fcl_decoder_loop_fwd(C.byref(w), C.byref(io), None) == -1  # null weights
     assert lib.fcl_decoder_loop_workspace_bytes(C.byref(w), 2500) > 2500 * 4 * (1024 + 80 + 512 + 6 * 256 + 80)
+    # the weight stream of the persistent row-tile kernel: 8 + 2 * 3 + 16 + 256 slots of 16 KB for FCL-taco2-S; other widths are not covered
+    assert lib.fcl_decoder_stream_bytes(C.byref(w)) == (8 + 6 + 16 + 256) * 16384
+    assert lib.fcl_decoder_stream_pack(C.byref(w), None, 0, None) == -1
+    buf = (C.c_char * 64)()
+    assert lib.fcl_decoder_stream_pack(C.byref(w), C.cast(buf, C.c_void_p), 64, None) == -5  # FCL_ERR_WORKSPACE: too small
+    w.u = 1024
+    assert lib.fcl_decoder_stream_bytes(C.byref(w)) == 0 and lib.fcl_decoder_stream_pack(C.byref(w), C.cast(buf, C.c_void_p), 64, None) == -2
 
 
 def test_missing_library_fails_loudly(monkeypatch):
