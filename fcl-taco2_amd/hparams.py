@@ -74,15 +74,13 @@ class HParams:
         if self.prenet_layers != 2: bad.append("prenet_layers != 2")
         if self.postnet_layers < 2: bad.append("postnet_layers < 2")
         if not self.use_batch_norm: bad.append("use_batch_norm False")
-        if not self.use_concate: bad.append("use_concate False")
         if self.use_residual and not (self.embed_dim == self.econv_chans):
             bad.append("use_residual True needs embed_dim == econv_chans (the reference's `convs[i](xs) + xs` has no projection)")
         if self.reduction_factor != 1: bad.append("reduction_factor != 1")
         if not self.use_fe_condition: bad.append("use_fe_condition False")
-        if not self.append_position: bad.append("append_position False")
         if self.econv_chans != self.embed_dim or self.eunits != self.econv_chans:
             bad.append("embed_dim/econv_chans/eunits differ")
-        if self.zoneout_rate <= 0.0: bad.append("zoneout_rate <= 0")
+        if not (0.0 <= self.zoneout_rate < 1.0): bad.append("zoneout_rate outside [0, 1)")
         if self.spk_embed_dim is not None and (self.spk_embed_dim <= 0 or self.spk_embed_dim % 4):
             bad.append("spk_embed_dim %r (a positive multiple of 4 is implemented)" % (self.spk_embed_dim,))
         if self.output_activation not in (None, "relu", "tanh", "sigmoid"):
@@ -90,6 +88,12 @@ class HParams:
         if bad:
             raise NotImplementedError("fcl-taco2_amd HIP path: unsupported configuration: " + ", ".join(bad))
         return self
+
+
+def lstm_key(hp, layer, name):
+    """state_dict key of a decoder LSTMCell parameter: the reference wraps the cell in ZoneOutCell only when zoneout_rate > 0 (decoder_sa.py:366-369),
+    and the wrapper keeps it under `.cell`."""
+    return ("dec.lstm.%d.cell.%s" if hp.zoneout_rate > 0.0 else "dec.lstm.%d.%s") % (layer, name)
 
 
 def output_act_code(hp):
@@ -155,10 +159,10 @@ def param_spec(hp, projections_to=None, share_proj=True):
     D, U, P = hp.adim, hp.dunits, hp.prenet_units  # D: the decoder's / predictors' input width (`dec_idim`)
     for l in range(hp.dlayers):
         iu = D + P + (1 if hp.append_position else 0) if l == 0 else U
-        s["dec.lstm.%d.cell.weight_ih" % l] = (4 * U, iu)
-        s["dec.lstm.%d.cell.weight_hh" % l] = (4 * U, U)
-        s["dec.lstm.%d.cell.bias_ih" % l] = (4 * U,)
-        s["dec.lstm.%d.cell.bias_hh" % l] = (4 * U,)
+        s[lstm_key(hp, l, "weight_ih")] = (4 * U, iu)
+        s[lstm_key(hp, l, "weight_hh")] = (4 * U, U)
+        s[lstm_key(hp, l, "bias_ih")] = (4 * U,)
+        s[lstm_key(hp, l, "bias_hh")] = (4 * U,)
     for l in range(hp.prenet_layers):
         s["dec.prenet.prenet.%d.0.weight" % l] = (P, hp.odim if l == 0 else P)
         s["dec.prenet.prenet.%d.0.bias" % l] = (P,)
@@ -168,7 +172,7 @@ def param_spec(hp, projections_to=None, share_proj=True):
         co = hp.odim if l == hp.postnet_layers - 1 else Cp
         s["dec.postnet.postnet.%d.0.weight" % l] = (co, ci, hp.postnet_filts)
         _bn(s, "dec.postnet.postnet.%d.1" % l, co)
-    s["dec.feat_out.weight"] = (hp.odim * hp.reduction_factor, U + D)
+    s["dec.feat_out.weight"] = (hp.odim * hp.reduction_factor, U + D if hp.use_concate else U)  # decoder_sa.py:397
     if T is not None:
         s["dec.prenet_proj.weight"] = (T.prenet_units, P)
         if share_proj:

@@ -139,10 +139,12 @@ class _Decoder(torch.nn.Module):
     def __init__(self, hp, thp, share_proj):
         super().__init__()
         d, u, p = hp.adim, hp.dunits, hp.prenet_units
-        self.lstm = torch.nn.ModuleList(_Cell(d + p + 1 if l == 0 else u, u) for l in range(hp.dlayers))
+        i0 = d + p + (1 if hp.append_position else 0)  # decoder_sa.py:361-365
+        mk = _Cell if hp.zoneout_rate > 0.0 else torch.nn.LSTMCell  # ZoneOutCell wraps the cell only for a positive rate (:366-369)
+        self.lstm = torch.nn.ModuleList(mk(i0 if l == 0 else u, u) for l in range(hp.dlayers))
         self.prenet = _Prenet(hp.odim, p, hp.prenet_layers)
         self.postnet = _Postnet(hp)
-        self.feat_out = torch.nn.Linear(u + d, hp.odim * hp.reduction_factor, bias=False)
+        self.feat_out = torch.nn.Linear(u + d if hp.use_concate else u, hp.odim * hp.reduction_factor, bias=False)  # decoder_sa.py:397-398
         if thp is not None:
             self.prenet_proj = torch.nn.Linear(p, thp.prenet_units, bias=False)
             if share_proj:

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .hparams import output_act_code, param_spec
+from .hparams import lstm_key, output_act_code, param_spec
 
 BN_EPS = 1e-5
 LN_EPS = 1e-12
@@ -151,17 +151,21 @@ class SynthesisPlan(object):
         d = DecoderPack()
         s = d.struct
         s.c, s.p, s.u, s.odim = C, P, U, O
-        w_ih0 = g("dec.lstm.0.cell.weight_ih")  # [4U, C + P + 1] = [att_c | prenet | position]
-        wf = g("dec.feat_out.weight")  # [odim, U + C]      = [lstm | att_c]
+        lk = lambda l, n: g(lstm_key(hp, l, n))
+        w_ih0 = lk(0, "weight_ih")  # [4U, C + P (+ 1)] = [att_c | prenet (| position: --append-position)]
+        wf = g("dec.feat_out.weight")  # [odim, U (+ C)]      = [lstm (| att_c: --use-concate)]
+        zeros = lambda *shape: torch.zeros(*shape, device=self.device, dtype=torch.float32)
         t = dict(
             prenet_w0=g("dec.prenet.prenet.0.0.weight"), prenet_b0=g("dec.prenet.prenet.0.0.bias"),
             prenet_w1=g("dec.prenet.prenet.1.0.weight"), prenet_b1=g("dec.prenet.prenet.1.0.bias"),
-            w0_att=ops.copy_cols(w_ih0, 0, C), w0_pre=ops.copy_cols(w_ih0, C, P), w0_pos=ops.copy_cols(w_ih0, C + P, 1).reshape(-1),
-            w0_hh=g("dec.lstm.0.cell.weight_hh"),
-            b0=ops.add_vec(g("dec.lstm.0.cell.bias_ih"), g("dec.lstm.0.cell.bias_hh")),
-            w1_ih=g("dec.lstm.1.cell.weight_ih"), w1_hh=g("dec.lstm.1.cell.weight_hh"),
-            b1=ops.add_vec(g("dec.lstm.1.cell.bias_ih"), g("dec.lstm.1.cell.bias_hh")),
-            wf_h=ops.copy_cols(wf, 0, U), wf_att=ops.copy_cols(wf, U, C),
+            w0_att=ops.copy_cols(w_ih0, 0, C), w0_pre=ops.copy_cols(w_ih0, C, P),
+            # options off = the term is absent in the reference: a zero block here (same kernels, one shape)
+            w0_pos=ops.copy_cols(w_ih0, C + P, 1).reshape(-1) if hp.append_position else zeros(4 * U),
+            w0_hh=lk(0, "weight_hh"),
+            b0=ops.add_vec(lk(0, "bias_ih"), lk(0, "bias_hh")),
+            w1_ih=lk(1, "weight_ih"), w1_hh=lk(1, "weight_hh"),
+            b1=ops.add_vec(lk(1, "bias_ih"), lk(1, "bias_hh")),
+            wf_h=ops.copy_cols(wf, 0, U), wf_att=ops.copy_cols(wf, U, C) if hp.use_concate else zeros(O, C),
         )
         for k, v in t.items():
             setattr(s, k, v.data_ptr())

@@ -247,7 +247,7 @@ def train(argv=None):
             from .nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
 
             t_idim, t_odim, targs = get_model_conf(args.teacher_conf)
-            kt = KDTeacher(t_idim, t_odim, targs, argparse.Namespace(use_fe_condition=True, append_position=True))
+            kt = KDTeacher(t_idim, t_odim, targs, argparse.Namespace(use_fe_condition=True, append_position=args.append_position))
             kt.load_state_dict(teacher.state_dict())
             teacher = kt.to(dev)
         for p_ in teacher.parameters():

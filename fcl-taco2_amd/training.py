@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .hparams import output_act_code
+from .hparams import lstm_key, output_act_code
 from .plan import BN_EPS, LN_EPS
 
 BN_MOMENTUM = 0.1  # torch.nn.BatchNorm1d default
@@ -357,6 +357,8 @@ class _NativeStep(object):
             return "pre-split operands are off (FCL_PRECISION=0 / FCL_PLANES=0)"
         if hp.spk_embed_dim is not None or hp.use_residual or hp.output_activation is not None:
             return "speaker embeddings / residual encoder / output activation"
+        if not (hp.zoneout_rate > 0.0 and hp.use_concate and hp.append_position):
+            return "zoneout_rate 0 / use_concate False / append_position False (decoder options outside the shipped recipes)"
         if not eng.overlap_dw:
             return "overlap_dw=False"
         widths = (hp.embed_dim, hp.econv_chans, hp.dunits, hp.prenet_units, hp.postnet_chans, hp.duration_predictor_chans, hp.variance_predictor_chans)
@@ -547,6 +549,9 @@ class TrainEngine(object):
         if self.role == "student" and self.hp.spk_embed_dim is not None:
             raise NotImplementedError("fcl-taco2_amd: KD training with speaker embeddings is undefined in the reference (its student's pemb_proj / eemb_proj "
                                       "are built for eunits inputs but receive eunits + spk_embed_dim channels: tests/golden/records.json)")
+        if self.role in ("student", "kd_teacher") and not self.hp.use_concate:
+            raise NotImplementedError("fcl-taco2_amd: KD training with use_concate False is undefined in the reference (its KD decoder's forward() hands "
+                                      "feat_out the list z_list[-1]: decoder_sa_kd.py:617-622, tests/golden/records.json)")
         if self.role != "kd_teacher":  # the frozen KD teacher computes no loss
             self.hp.check_loss_supported()
         self.share_proj = bool(getattr(model, "share_proj", True))
@@ -691,6 +696,15 @@ class TrainEngine(object):
         """Contiguous copy of the parameter block w[:, col0:col0+n]."""
         rows, ld = w.shape
         return self._form((self._param_ptr[w.data_ptr()], "c", col0, n), w, (1, rows, n, 0, ld, 1), base=col0)
+
+    def _zeros_const(self, name, shape):
+        """A zero tensor that lives as long as the engine (the stand-in of a parameter block an option removed)."""
+        z = self._zero_consts.get(name) if hasattr(self, "_zero_consts") else None
+        if z is None:
+            if not hasattr(self, "_zero_consts"):
+                self._zero_consts = {}
+            z = self._zero_consts[name] = torch.zeros(*shape, device=self.dev, dtype=torch.float32)
+        return z
 
     def _bsum(self, b1, b2):
         """bias_ih + bias_hh."""
@@ -1175,15 +1189,18 @@ class TrainEngine(object):
             c.p0d = ops.act_fwd(c.p0, ops.ACT_NONE, c.k0, c.pks) if c.k0 is not None else c.p0
             c.p1 = ops.linear(c.p0d, P[w1n], P[b1n], ops.ACT_RELU)
             c.p1d = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks) if c.k1 is not None else c.p1
-        w_ih0 = P["dec.lstm.0.cell.weight_ih"]
+        lk = lambda l, n: lstm_key(hp, l, n)
+        w_ih0 = P[lk(0, "weight_ih")]
         c.w0_att, c.w0_pre = self._cols(w_ih0, 0, C), self._cols(w_ih0, C, Pn)
-        w0_pos = self._cols(w_ih0, C + Pn, 1).reshape(-1)
-        c.w0_hh = P["dec.lstm.0.cell.weight_hh"]
-        b0s = self._bsum(P["dec.lstm.0.cell.bias_ih"], P["dec.lstm.0.cell.bias_hh"])
-        c.w1_ih, c.w1_hh = P["dec.lstm.1.cell.weight_ih"], P["dec.lstm.1.cell.weight_hh"]
-        b1s = self._bsum(P["dec.lstm.1.cell.bias_ih"], P["dec.lstm.1.cell.bias_hh"])
+        # options off = the term does not exist in the reference (decoder_sa.py:361-365, :397): a zero block keeps the kernels on one shape
+        w0_pos = self._cols(w_ih0, C + Pn, 1).reshape(-1) if hp.append_position else self._zeros_const("w0_pos0", (4 * U,))
+        c.w0_hh = P[lk(0, "weight_hh")]
+        b0s = self._bsum(P[lk(0, "bias_ih")], P[lk(0, "bias_hh")])
+        c.w1_ih, c.w1_hh = P[lk(1, "weight_ih")], P[lk(1, "weight_hh")]
+        b1s = self._bsum(P[lk(1, "bias_ih")], P[lk(1, "bias_hh")])
         wf = P["dec.feat_out.weight"]
-        c.wf_h, c.wf_att = self._cols(wf, 0, U), self._cols(wf, U, C)
+        c.wf_h = self._cols(wf, 0, U)
+        c.wf_att = self._cols(wf, U, C) if hp.use_concate else self._zeros_const("wf_att0", (O, C))
         if dpl:
             G0 = ops.linear_planes(att_p, self._wplanes("w0_att", c.w0_att), 4 * U, C, b0s)[0]  # hoisted att_c share of the layer-0 gates
             F0 = ops.linear_planes(att_p, self._wplanes("wf_att", c.wf_att), O, C)[0]
@@ -1341,6 +1358,7 @@ class TrainEngine(object):
         B, T = c.B, c.T
         U, Pn, C = hp.dunits, hp.prenet_units, hp.adim
         N, F, lmax, live, offs = c.N, c.F, c.lmax, c.live, c.offs
+        lk = lambda l, n: lstm_key(hp, l, n)
         # ---- postnet: after = before + postnet(before)
         if hp.output_activation is not None:  # back through output_activation_fn (y = the activated outputs)
             inj["before"] = ops.act_bwd(inj["before"], c.before, output_act_code(hp))
@@ -1368,7 +1386,8 @@ class TrainEngine(object):
             ops.add2d(dh1_all, inj["h1"])
         dF0 = self._z((N, hp.odim))
         ops.scatter_add_rows(d_out_cells, c.cell_row_i64, dF0)
-        self._dw(lambda: ops.gemm_tn(dF0, c.att_c, g_wf[:, U:]))
+        if hp.use_concate:
+            self._dw(lambda: ops.gemm_tn(dF0, c.att_c, g_wf[:, U:]))
         d_att_c = ops.linear(dF0, self._wt(c.wf_att))
         dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
         w1_ih_t, w1_hh_t, w0_hh_t, w0_pre_t = self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh), self._wt(c.w0_pre)
@@ -1385,16 +1404,17 @@ class TrainEngine(object):
         else:
             dp1_all = ops.linear(dg0_all, w0_pre_t)
         S0, S1 = c.S0, c.S1
-        g_ih0 = G["dec.lstm.0.cell.weight_ih"]  # [4U, C + P + 1] = [att_c | prenet | position]
+        g_ih0 = G[lk(0, "weight_ih")]  # [4U, C + P (+ 1)] = [att_c | prenet (| position)]
 
         def dw_cells():  # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
-            self._dw_gemm(dg1_all, [(c.h0_all, G["dec.lstm.1.cell.weight_ih"]), (S1[3], G["dec.lstm.1.cell.weight_hh"])])
+            self._dw_gemm(dg1_all, [(c.h0_all, G[lk(1, "weight_ih")]), (S1[3], G[lk(1, "weight_hh")])])
             for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
-                ops.colsum(dg, G["dec.lstm.%d.cell.bias_ih" % l], out_x=G["dec.lstm.%d.cell.bias_hh" % l])
-            self._dw_gemm(dg0_all, [(S0[3], G["dec.lstm.0.cell.weight_hh"]), (c.p1d, g_ih0[:, C : C + Pn])])
-            dw0_pos4 = self._z((4 * U, 4))
-            ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
-            ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
+                ops.colsum(dg, G[lk(l, "bias_ih")], out_x=G[lk(l, "bias_hh")])
+            self._dw_gemm(dg0_all, [(S0[3], G[lk(0, "weight_hh")]), (c.p1d, g_ih0[:, C : C + Pn])])
+            if hp.append_position:
+                dw0_pos4 = self._z((4 * U, 4))
+                ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
+                ops.add2d(g_ih0[:, C + Pn :], dw0_pos4[:, :1])
 
         self._dw(dw_cells)
         dG0 = self._z((N, 4 * U))

@@ -249,7 +249,9 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
     Returns outs [N, odim, n_steps], prenet_outs [N, n_steps, P], lstm0 [N, n_steps, U], lstm1 [...]."""
     N = att_c.shape[0]
     U, zr = hp.dunits, hp.zoneout_rate
-    W = [[sd["dec.lstm.%d.cell.%s" % (l, k)] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] for l in range(2)]
+    # decoder_sa.py:366-369: the cell is wrapped in ZoneOutCell (parameters under `.cell`) only for a positive rate
+    pat = "dec.lstm.%d.cell.%s" if zr > 0.0 else "dec.lstm.%d.%s"
+    W = [[sd[pat % (l, k)] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] for l in range(2)]
     wf = sd["dec.feat_out.weight"]
     z = [att_c.new_zeros(N, U), att_c.new_zeros(N, U)]
     c = [att_c.new_zeros(N, U), att_c.new_zeros(N, U)]
@@ -262,7 +264,10 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
             kp = None if prenet_keep is None else [_t(k) for k in prenet_keep[t]]
         pre = prenet(sd, prev, kp, hp.dropout_rate if kp is not None else 0.5)
         pres.append(pre)
-        xs = torch.cat([att_c, pre, position[:, t].reshape(-1, 1)], dim=1)
+        base_cat = [att_c, pre]
+        if getattr(hp, "append_position", True):  # decoder_sa.py:494-498 / :594-597
+            base_cat.append(position[:, t].reshape(-1, 1))
+        xs = torch.cat(base_cat, dim=1)
         for l in range(2):
             inp = xs if l == 0 else z[0]
             h2, c2 = lstm_cell(inp, z[l], c[l], *W[l])
@@ -271,7 +276,7 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
             c[l] = zoneout(c[l], c2, zr, None if zk is None else zk[1])
         l0.append(z[0])
         l1.append(z[1])
-        out = F.linear(torch.cat([z[1], att_c], dim=1), wf)  # H8, no bias
+        out = F.linear(torch.cat([z[1], att_c], dim=1) if getattr(hp, "use_concate", True) else z[1], wf)  # H8, no bias (decoder_sa.py:505-511)
         outs.append(out)
         prev = _out_act(hp, out) if teacher_ys is None else teacher_ys[:, t]  # decoder_sa.py:614-617: the fed-back frame is activated
     return (torch.stack(outs, dim=2), torch.stack(pres, dim=1), torch.stack(l0, dim=1), torch.stack(l1, dim=1))

@@ -17,6 +17,7 @@ layout), G5 (training losses + a few gradients, eval-dropout-off), G6 (padding l
 failure record).
 """
 import argparse
+import dataclasses
 import contextlib
 import io
 import json
@@ -94,7 +95,7 @@ def build(role, hp, thp=None, share_proj=True):
     from nets.knowledge_distillation.e2e_tts_tacotron2_sa_kd_teacher import Tacotron2_sa as KDTeacher
     from nets.teacher_training.e2e_tts_tacotron2_sa import Tacotron2_sa as Teacher
 
-    com = argparse.Namespace(share_proj=share_proj, **COM)
+    com = argparse.Namespace(share_proj=share_proj, **dict(COM, append_position=bool(getattr(hp, "append_position", True))))
     if role == "student":
         m = _quiet(Student, hp.idim, hp.odim, ns(hp), com, ns(thp))
         spec = HP.param_spec(hp, thp, share_proj)
@@ -620,6 +621,48 @@ def gen_g13():
     save("g13_kd_teacher_spk", after=t2n(know[0]), enc4=t2n(know[2][4]), dec1=t2n(know[3][1]), p_embs=t2n(know[4][3]), d_outs=t2n(know[4][0]))
 
 
+def gen_g14():
+    """G14: decoder options outside the shipped recipes, all three at once -- zoneout_rate 0 (plain LSTMCell: the parameters lose the `.cell` level,
+    decoder_sa.py:366-369), use_concate False (feat_out reads the LSTM state alone, :397, :505-511), append_position False (no position column in
+    LSTM 0's input, :361-365, :494-498).  Teacher: inference mel + training step (eval form); student: KD step against a teacher with the same options."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, zoneout_rate=0.0, use_concate=False, append_position=False)
+    TA = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **kw)
+    SA = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, **kw)
+    rng = np.random.RandomState(14)
+    x = torch.from_numpy(rng.randint(1, TA.idim, size=7).astype(np.int64))
+    dur = torch.tensor([2, 4, 1, 3, 1, 2, 5])
+    te, spec = build("teacher", TA)
+    assert "dec.lstm.0.weight_ih" in spec and spec["dec.lstm.0.weight_ih"][1] == TA.adim + TA.prenet_units and spec["dec.feat_out.weight"][1] == TA.dunits
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+    save("g14_teacher_options_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    loss = te(**b)
+    loss.backward()
+    keys = [k.replace(".cell.", ".") for k in GRAD_KEYS]
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(te, d)
+    _grads(te, keys, d)
+    save("g14_teacher_options", **d)
+    # the KD pair: the reference's KD decoder cannot run forward() with use_concate False (decoder_sa_kd.py:617-622 hands feat_out the LIST z_list[-1]:
+    # records.json), so the KD step carries the other two options; the student's inference() works with all three (:765-770)
+    st3, _ = build("student", SA, TA, True)
+    with torch.no_grad():
+        after = st3.inference(x, None, dur=dur)
+    save("g14_student_options_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    TK, SK = dataclasses.replace(TA, use_concate=True), dataclasses.replace(SA, use_concate=True)
+    kt, _ = build("kd_teacher", TK)
+    with torch.no_grad():
+        know = kt(**b)
+    st, _ = build("student", SK, TK, True)
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), t_after=t2n(know[0]), t_before=t2n(know[1]))
+    _named_losses(st, d)
+    _grads(st, keys + KD_KEYS, d)
+    save("g14_student_kd_options", **d)
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -657,6 +700,13 @@ def gen_option_records():
         st.eval()
         st(teacher_knowledge=know, spembs=spk, **b).backward()
 
+    def kd_no_concat():
+        kt = _quiet(KDTeacher, TINY_T.idim, TINY_T.odim, ns(TINY_T, use_concate=False), com)
+        kt.eval()
+        with torch.no_grad():
+            kt(**b)
+
+    attempt("use_concate_false_kd_forward", kd_no_concat)
     attempt("spk_embed_teacher_training_and_inference", teacher_spk)
     attempt("spk_embed_student_kd_training", student_spk)
     with open(rec_path, "w") as f:
@@ -669,7 +719,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "g13", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "g14", "records"}, only
+        if "g14" in only:
+            gen_g14()
         if "g13" in only:
             gen_g13()
         if "records" in only:
@@ -692,6 +744,7 @@ def main():
     gen_g11()
     gen_g12()
     gen_g13()
+    gen_g14()
     gen_option_records()
 
 

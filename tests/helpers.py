@@ -49,6 +49,14 @@ TINY_SA = HP.student_hparams(idim=12, odim=8, embed_dim=16, eunits=16, econv_cha
 TINY_TA = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, output_activation="sigmoid")
 
+# decoder options outside the shipped recipes (G14): zoneout_rate 0 (plain LSTMCell, no `.cell` key level), use_concate False, append_position False;
+# the KD pair keeps use_concate (the reference's KD decoder cannot run forward() without it: tests/golden/records.json)
+_OPT = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, zoneout_rate=0.0, append_position=False)
+TINY_TO = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, use_concate=False, **_OPT)
+TINY_SO = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, use_concate=False, **_OPT)
+TINY_TOK = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **_OPT)
+TINY_SOK = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, **_OPT)
+
 # speaker embeddings (G13): F.normalize(spemb) appended to the encoder states; predictors / embeddings / decoder on eunits + 8 channels
 TINY_TK = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, spk_embed_dim=8)

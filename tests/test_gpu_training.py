@@ -27,7 +27,7 @@ def _ns(hp):
     return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
                               postnet_chans=hp.postnet_chans, use_residual=hp.use_residual, use_masking=hp.use_masking, dropout_rate=hp.dropout_rate,
                               duration_predictor_chans=hp.duration_predictor_chans, output_activation=hp.output_activation,
-                              spk_embed_dim=hp.spk_embed_dim)
+                              spk_embed_dim=hp.spk_embed_dim, zoneout_rate=hp.zoneout_rate, use_concate=hp.use_concate, append_position=hp.append_position)
 
 
 def _model(role, hp, thp=None):
@@ -304,6 +304,40 @@ def test_output_activation_variant_vs_reference_g12():
         with torch.no_grad():
             ref = O.inference(torch_state_dict(hp), hp, torch.from_numpy(x), dur=torch.from_numpy(d))["after"]
         assert max_abs(mel.cpu(), ref) < 1e-3, name
+
+
+def test_decoder_options_vs_reference_g14():
+    """G14: zoneout_rate 0 (plain LSTMCell keys), use_concate False, append_position False on the HIP path: synthesis of the teacher and of the student
+    vs the reference's mels; the teacher step vs the reference's losses / gradients; the KD step with the two options the reference's KD decoder can
+    run; and the KD roles refuse use_concate False in training the way the reference fails on it."""
+    from helpers import TINY_SO, TINY_SOK, TINY_TO, TINY_TOK, np_state_dict
+    from fcl_taco2_amd import engine
+    from fcl_taco2_amd.plan import SynthesisPlan
+    from fcl_taco2_amd.training import TrainEngine
+
+    for hp, thp, name in ((TINY_TO, None, "g14_teacher_options_inference"), (TINY_SO, TINY_TO, "g14_student_options_inference")):
+        g = _golden(name)
+        plan = SynthesisPlan(np_state_dict(hp, thp, True) if thp is not None else np_state_dict(hp), hp, DEV)
+        mel = engine.synthesize(plan, [g["x"]], [g["dur"]], dropout_mode=0)[0]
+        assert max_abs(mel.cpu(), g["after"]) < 1e-3, name
+    batch = _batch()
+    eng = TrainEngine(_model("teacher", TINY_TO))
+    assert eng.native is None and "zoneout_rate 0" in eng.native_reason
+    rep = eng.forward_backward(batch)
+    assert _check_vs_golden(eng, rep, _golden("g14_teacher_options"), KD_KEYS[:6]) >= 10
+    g = _golden("g14_student_kd_options")
+    know = TrainEngine(_model("kd_teacher", TINY_TOK)).knowledge(batch, mode="eval")
+    assert max_abs(know[0].cpu(), g["t_after"]) < 1e-4 and max_abs(know[1].cpu(), g["t_before"]) < 1e-4
+    eng = TrainEngine(_model("student", TINY_SOK, TINY_TOK))
+    rep = eng.forward_backward(batch, teacher_knowledge=know)
+    assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
+    # train-mode step (sampled prenet dropout, no zoneout draws at rate 0) against the oracle with the engine's own masks: two updates stay finite
+    eng = TrainEngine(_model("teacher", TINY_TO), seed=3)
+    for _ in range(2):
+        r = eng.train_step(batch, mode="train")
+        assert np.isfinite(r["loss"]) and np.isfinite(r["grad_norm"])
+    with pytest.raises(NotImplementedError, match="use_concate"):
+        TrainEngine(_model("kd_teacher", TINY_TO)).knowledge(batch, mode="eval")
 
 
 def test_speaker_embeddings_vs_reference_g13():

@@ -318,6 +318,42 @@ def test_g12_output_activation_variant(golden):
     assert _check_grads(sd, g) >= 20
 
 
+def test_g14_decoder_options(golden):
+    """zoneout_rate 0 + use_concate False + append_position False (teacher: inference mel, training step; student: inference mel) and the KD step on
+    the two options the reference's KD decoder can run -- all against the real reference; its failure with use_concate False is on record."""
+    from helpers import TINY_SO, TINY_SOK, TINY_TO, TINY_TOK
+
+    g4 = golden("g4_integer")
+    for hp, name in ((TINY_TO, "g14_teacher_options_inference"), (TINY_SO, "g14_student_options_inference")):
+        g = golden(name)
+        thp = TINY_TO if hp is TINY_SO else None
+        sd0 = torch_state_dict(hp, thp, True) if thp is not None else torch_state_dict(hp)
+        assert "dec.lstm.0.weight_ih" in sd0 and sd0["dec.feat_out.weight"].shape[1] == hp.dunits and sd0["dec.lstm.0.weight_ih"].shape[1] == hp.adim + hp.prenet_units
+        with torch.no_grad():
+            out = O.inference(sd0, hp, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]))
+        assert max_abs(out["after"], g["after"]) < TOL_STAGE, name
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden("g14_teacher_options")
+    sd = _grad_sd(TINY_TO)
+    rep = O.model_forward(sd, TINY_TO, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 10
+    g = golden("g14_student_kd_options")
+    with torch.no_grad():
+        know = O.model_forward(torch_state_dict(TINY_TOK), TINY_TOK, b, "kd_teacher")
+    assert max_abs(know[0], g["t_after"]) < TOL_STAGE and max_abs(know[1], g["t_before"]) < TOL_STAGE
+    sd = _grad_sd(TINY_SOK, TINY_TOK, True)
+    rep = O.model_forward(sd, TINY_SOK, b, "student", TINY_TOK, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "encoder_loss", "decoder_loss", "prosody_loss", "output_l1_loss", "output_mse_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 20
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "records.json")))
+    assert rec["use_concate_false_kd_forward"].startswith("TypeError")
+
+
 def test_g13_speaker_embeddings(golden):
     """`spk_embed_dim`: F.normalize(spemb) appended to every encoder state (..._sa.py:555-557, 636-638).  Inference mel, the teacher step and the KD
     teacher's 5-tuple vs the real reference (the KD student cannot run with speaker embeddings in the reference: records.json)."""
