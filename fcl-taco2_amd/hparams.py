@@ -73,7 +73,6 @@ class HParams:
         if self.dlayers != 2: bad.append("dlayers != 2")
         if self.prenet_layers != 2: bad.append("prenet_layers != 2")
         if self.postnet_layers < 2: bad.append("postnet_layers < 2")
-        if not self.use_batch_norm: bad.append("use_batch_norm False")
         if self.use_residual and not (self.embed_dim == self.econv_chans):
             bad.append("use_residual True needs embed_dim == econv_chans (the reference's `convs[i](xs) + xs` has no projection)")
         if self.reduction_factor != 1: bad.append("reduction_factor != 1")
@@ -144,7 +143,8 @@ def param_spec(hp, projections_to=None, share_proj=True):
     s["enc.embed.weight"] = (hp.idim, E)
     for i in range(hp.econv_layers):
         s["enc.convs.%d.0.weight" % i] = (C, E if i == 0 else C, hp.econv_filts)
-        _bn(s, "enc.convs.%d.1" % i, C)
+        if hp.use_batch_norm:  # encoder_sa.py:63-90: without it the block is Conv1d -> ReLU -> Dropout
+            _bn(s, "enc.convs.%d.1" % i, C)
     for sfx in ("", "_reverse"):
         s["enc.blstm.weight_ih_l0" + sfx] = (4 * H, C)
         s["enc.blstm.weight_hh_l0" + sfx] = (4 * H, H)
@@ -171,7 +171,8 @@ def param_spec(hp, projections_to=None, share_proj=True):
         ci = hp.odim if l == 0 else Cp
         co = hp.odim if l == hp.postnet_layers - 1 else Cp
         s["dec.postnet.postnet.%d.0.weight" % l] = (co, ci, hp.postnet_filts)
-        _bn(s, "dec.postnet.postnet.%d.1" % l, co)
+        if hp.use_batch_norm:  # decoder_sa.py:203-263
+            _bn(s, "dec.postnet.postnet.%d.1" % l, co)
     s["dec.feat_out.weight"] = (hp.odim * hp.reduction_factor, U + D if hp.use_concate else U)  # decoder_sa.py:397
     if T is not None:
         s["dec.prenet_proj.weight"] = (T.prenet_units, P)

@@ -79,8 +79,8 @@ def _seq(*mods):
     return torch.nn.Sequential(*mods)
 
 
-def _conv_bn(cin, cout, k, act, p):
-    layers = [torch.nn.Conv1d(cin, cout, k, stride=1, padding=(k - 1) // 2, bias=False), torch.nn.BatchNorm1d(cout)]
+def _conv_bn(cin, cout, k, act, p, bn=True):
+    layers = [torch.nn.Conv1d(cin, cout, k, stride=1, padding=(k - 1) // 2, bias=False)] + ([torch.nn.BatchNorm1d(cout)] if bn else [])
     if act is not None:
         layers.append(act)
     layers.append(torch.nn.Dropout(p))
@@ -105,7 +105,7 @@ class _Postnet(torch.nn.Module):
         n, cp = hp.postnet_layers, hp.postnet_chans
         self.postnet = torch.nn.ModuleList(
             _conv_bn(hp.odim if i == 0 else cp, hp.odim if i == n - 1 else cp, hp.postnet_filts,
-                     None if i == n - 1 else torch.nn.Tanh(), hp.dropout_rate) for i in range(n))
+                     None if i == n - 1 else torch.nn.Tanh(), hp.dropout_rate, hp.use_batch_norm) for i in range(n))
 
 
 class _Predictor(torch.nn.Module):
@@ -122,7 +122,7 @@ class _Encoder(torch.nn.Module):
         super().__init__()
         self.embed = torch.nn.Embedding(hp.idim, hp.embed_dim, padding_idx=0)
         self.convs = torch.nn.ModuleList(
-            _conv_bn(hp.embed_dim if i == 0 else hp.econv_chans, hp.econv_chans, hp.econv_filts, torch.nn.ReLU(), hp.dropout_rate)
+            _conv_bn(hp.embed_dim if i == 0 else hp.econv_chans, hp.econv_chans, hp.econv_filts, torch.nn.ReLU(), hp.dropout_rate, hp.use_batch_norm)
             for i in range(hp.econv_layers))
         self.blstm = torch.nn.LSTM(hp.econv_chans, hp.eunits // 2, hp.elayers, batch_first=True, bidirectional=True)
         if thp is not None:

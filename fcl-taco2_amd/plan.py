@@ -122,10 +122,13 @@ class SynthesisPlan(object):
 
     def _conv_bn(self, g, prefix):
         w = g(prefix + ".0.weight")
-        scale, shift = ops.fold_batchnorm(g(prefix + ".1.weight"), g(prefix + ".1.bias"), g(prefix + ".1.running_mean"),
-                                          g(prefix + ".1.running_var"), BN_EPS)
         c = ConvPack()
         c.cout, c.cin, c.k = w.shape
+        if self.hp.use_batch_norm:
+            scale, shift = ops.fold_batchnorm(g(prefix + ".1.weight"), g(prefix + ".1.bias"), g(prefix + ".1.running_mean"),
+                                              g(prefix + ".1.running_var"), BN_EPS)
+        else:  # `--use-batch-norm false`: Conv1d(no bias) -> activation (encoder_sa.py:78-90, decoder_sa.py:219-232, :250-262)
+            scale, shift = None, torch.zeros(c.cout, device=self.device, dtype=torch.float32)
         c.wp = ops.pack_conv1d_weight(w, scale)
         c.bias = shift
         return _conv_planes(c)

@@ -357,8 +357,8 @@ class _NativeStep(object):
             return "pre-split operands are off (FCL_PRECISION=0 / FCL_PLANES=0)"
         if hp.spk_embed_dim is not None or hp.use_residual or hp.output_activation is not None:
             return "speaker embeddings / residual encoder / output activation"
-        if not (hp.zoneout_rate > 0.0 and hp.use_concate and hp.append_position):
-            return "zoneout_rate 0 / use_concate False / append_position False (decoder options outside the shipped recipes)"
+        if not (hp.zoneout_rate > 0.0 and hp.use_concate and hp.append_position and hp.use_batch_norm):
+            return "zoneout_rate 0 / use_concate False / append_position False / use_batch_norm False (options outside the shipped recipes)"
         if not eng.overlap_dw:
             return "overlap_dw=False"
         widths = (hp.embed_dim, hp.econv_chans, hp.dunits, hp.prenet_units, hp.postnet_chans, hp.duration_predictor_chans, hp.variance_predictor_chans)
@@ -825,6 +825,18 @@ class TrainEngine(object):
                 return ops.conv1d_planes(xp, _ConvP(wpp, bias, cout, cin, k), lo, hi, ops.ACT_NONE, want_f32=True, want_planes=False)[0]
             return ops.conv1d(x, wp, bias, lo, hi, ops.ACT_NONE)
 
+        if not self.hp.use_batch_norm:  # `--use-batch-norm false`: Conv1d(no bias) -> act -> Dropout (encoder_sa.py:78-90, decoder_sa.py:219-232)
+            wp, wt = self._conv_pack(P[prefix + ".0.weight"], need_t=c.save)
+            z = conv(wp, None)
+            y_act = ops.act_fwd(z, act) if act != ops.ACT_NONE else z
+            yp = None
+            if keep is not None or want_planes:
+                r = ops.act_fwd(y_act, ops.ACT_NONE, keep, ks, want_planes=want_planes)
+                y, yp = r if want_planes else (r, None)
+            else:
+                y = y_act
+            cache = dict(x=x, z=z, y_act=y_act, wt=wt, scale=None, prefix=prefix, act=act, lo=lo, hi=hi, keep=keep, ks=ks, no_bn=True)
+            return (y, cache, yp) if want_planes else (y, cache)
         if c.train:
             wp, wt = self._conv_pack(P[prefix + ".0.weight"], need_t=c.save)
             z = conv(wp, None)
@@ -867,7 +879,12 @@ class TrainEngine(object):
             dz, dzp = r if (pl and not c.train) else (r, None)
         else:
             dz = dy
-        if c.train:
+        no_bn = cc.get("no_bn", False)
+        if no_bn:
+            scale = None
+            if pl and dzp is None:
+                dzp = ops.pack_planes(dz)
+        elif c.train:
             dbeta, dgamma = self._z((cout,)), self._z((cout,))
             ops.colsum(dz, dgamma, y=cc["z"], gamma=cc["invstd"], beta=cc["mean"], mode=3, out_x=dbeta)  # both sums from one pass over dz
             r = ops.bn_bwd(dz, cc["z"], cc["mean"], cc["invstd"], P[pre + ".1.weight"], dbeta, dgamma, want_planes=pl,
@@ -879,7 +896,7 @@ class TrainEngine(object):
             if pl and dzp is None:
                 dzp = ops.pack_planes(dz)
 
-        def dw(dz=dz, scale=scale, eval_affine=not c.train):
+        def dw(dz=dz, scale=scale, eval_affine=not c.train and not no_bn):
             if eval_affine:
                 ops.colsum(dz, G[pre + ".1.weight"], y=cc["z"], gamma=P[pre + ".1.weight"], beta=P[pre + ".1.bias"], mode=2, out_x=G[pre + ".1.bias"])
             dwp = self._z((k, cout, cin))
@@ -888,7 +905,7 @@ class TrainEngine(object):
 
         self._dw(dw)
         # eval mode folds the running statistics into the taps: those transposed taps are not a function of the parameters alone (no caching)
-        if dzp is not None and not c.train:
+        if dzp is not None and not c.train and not no_bn:
             kk, ci, co = cc["wt"].shape
             wpp = ops.pack_planes(cc["wt"].reshape(kk * ci, co))
             return ops.conv1d_planes(dzp, _ConvP(wpp, None, ci, co, kk), cc["lo"], cc["hi"], ops.ACT_NONE, want_f32=True, want_planes=False)[0]

@@ -83,7 +83,8 @@ def encoder_convs(sd, x_bct, n_layers, bn_train=False, keeps=None, p=0.5, residu
     for i in range(n_layers):
         w = sd["enc.convs.%d.0.weight" % i]
         y = F.conv1d(x, w, None, 1, (w.shape[2] - 1) // 2)
-        y = (batch_norm_train if bn_train else batch_norm_eval)(y, sd, "enc.convs.%d.1" % i)
+        if "enc.convs.%d.1.weight" % i in sd:  # `use_batch_norm` (encoder_sa.py:63-90): without it the block has no normalisation layer
+            y = (batch_norm_train if bn_train else batch_norm_eval)(y, sd, "enc.convs.%d.1" % i)
         y = _drop(torch.relu(y), None if keeps is None else keeps[i], p)
         x = y + x if residual else y  # use_residual: convs[i](x) + x, after the block's ReLU and Dropout (encoder_sa_kd.py:158-171, 213-214)
         taps.append(x)
@@ -225,7 +226,8 @@ def postnet(sd, hp, x_bcl, bn_train=False, keeps=None, p=0.5):
     for l in range(n):
         w = sd["dec.postnet.postnet.%d.0.weight" % l]
         y = F.conv1d(x, w, None, 1, (w.shape[2] - 1) // 2)
-        y = (batch_norm_train if bn_train else batch_norm_eval)(y, sd, "dec.postnet.postnet.%d.1" % l)
+        if "dec.postnet.postnet.%d.1.weight" % l in sd:  # `use_batch_norm` (decoder_sa.py:203-263)
+            y = (batch_norm_train if bn_train else batch_norm_eval)(y, sd, "dec.postnet.postnet.%d.1" % l)
         if l != n - 1:
             y = torch.tanh(y)
         x = _drop(y, None if keeps is None else keeps[l], p)

@@ -663,6 +663,44 @@ def gen_g14():
     save("g14_student_kd_options", **d)
 
 
+def gen_g15():
+    """G15: `--use-batch-norm false` (encoder_sa.py:63-90, decoder_sa.py:203-263; decoder_sa_kd.py likewise): the encoder blocks are Conv1d -> ReLU ->
+    Dropout and the postnet blocks Conv1d -> Tanh -> Dropout with no normalisation layer (and no `.1.*` parameters).  Teacher: inference mel + training
+    step (eval form); student: inference mel + KD step against a teacher with the same option."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, use_batch_norm=False)
+    TA = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **kw)
+    SA = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, **kw)
+    rng = np.random.RandomState(15)
+    x = torch.from_numpy(rng.randint(1, TA.idim, size=7).astype(np.int64))
+    dur = torch.tensor([1, 3, 2, 5, 1, 2, 4])
+    te, spec = build("teacher", TA)
+    assert "enc.convs.0.1.weight" not in spec and "dec.postnet.postnet.0.1.weight" not in spec
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+    save("g15_teacher_nobn_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    loss = te(**b)
+    loss.backward()
+    keys = [k for k in GRAD_KEYS if ".1.weight" not in k and ".1.bias" not in k] + ["enc.convs.1.0.weight", "dec.postnet.postnet.0.0.weight"]
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(te, d)
+    _grads(te, keys, d)
+    save("g15_teacher_nobn", **d)
+    kt, _ = build("kd_teacher", TA)
+    with torch.no_grad():
+        know = kt(**b)
+    st, _ = build("student", SA, TA, True)
+    with torch.no_grad():
+        after = st.inference(x, None, dur=dur)
+    save("g15_student_nobn_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), t_after=t2n(know[0]), t_before=t2n(know[1]), t_enc1=t2n(know[2][1]))
+    _named_losses(st, d)
+    _grads(st, keys + KD_KEYS, d)
+    save("g15_student_kd_nobn", **d)
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -719,7 +757,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "g13", "g14", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "records"}, only
+        if "g15" in only:
+            gen_g15()
         if "g14" in only:
             gen_g14()
         if "g13" in only:
@@ -745,6 +785,7 @@ def main():
     gen_g12()
     gen_g13()
     gen_g14()
+    gen_g15()
     gen_option_records()
 
 

@@ -27,7 +27,8 @@ def _ns(hp):
     return argparse.Namespace(embed_dim=hp.embed_dim, eunits=hp.eunits, econv_chans=hp.econv_chans, dunits=hp.dunits, prenet_units=hp.prenet_units,
                               postnet_chans=hp.postnet_chans, use_residual=hp.use_residual, use_masking=hp.use_masking, dropout_rate=hp.dropout_rate,
                               duration_predictor_chans=hp.duration_predictor_chans, output_activation=hp.output_activation,
-                              spk_embed_dim=hp.spk_embed_dim, zoneout_rate=hp.zoneout_rate, use_concate=hp.use_concate, append_position=hp.append_position)
+                              spk_embed_dim=hp.spk_embed_dim, zoneout_rate=hp.zoneout_rate, use_concate=hp.use_concate, append_position=hp.append_position,
+                              use_batch_norm=hp.use_batch_norm)
 
 
 def _model(role, hp, thp=None):
@@ -78,6 +79,24 @@ def _check_vs_golden(eng, rep, g, loss_keys, tol=5e-4):
     eng.gn_sq.zero_()
     ops.sumsq_accum(eng.gflat, eng.gn_sq)
     assert abs(eng.grad_norm() - float(g["grad_norm"])) < 2e-3 * float(g["grad_norm"])
+    return n
+
+
+def _check_vs_golden_illcond(eng, rep, g, loss_keys):
+    """_check_vs_golden for a closed-form net whose eps-1e-12 LayerNorms amplify rounding ~100x (see the G13 test): on bf16x3 operands (2^-16 per
+    product) the losses are held at 5e-4 and the gradients at 1e-1 of the tensor's scale; the exact-fp32 mode of the same test (FCL_PRECISION=0) pins
+    every tensor at 5e-4."""
+    from fcl_taco2_amd import ops
+
+    if not ops.planes_enabled():
+        return _check_vs_golden(eng, rep, g, loss_keys)
+    for k in loss_keys:
+        assert abs(rep[k] - float(g[k])) < 5e-4 * max(1.0, abs(float(g[k]))), (k, rep[k], float(g[k]))
+    n = 0
+    for k, ref in g.items():
+        if k.startswith("grad:"):
+            n += 1
+            assert max_abs(eng.G[k[5:]].cpu(), ref) < 1e-1 * max(1.0, float(np.abs(ref).max())), k
     return n
 
 
@@ -322,7 +341,7 @@ def test_decoder_options_vs_reference_g14():
         assert max_abs(mel.cpu(), g["after"]) < 1e-3, name
     batch = _batch()
     eng = TrainEngine(_model("teacher", TINY_TO))
-    assert eng.native is None and "zoneout_rate 0" in eng.native_reason
+    assert eng.native is None and ("zoneout_rate 0" in eng.native_reason or "pre-split" in eng.native_reason)
     rep = eng.forward_backward(batch)
     assert _check_vs_golden(eng, rep, _golden("g14_teacher_options"), KD_KEYS[:6]) >= 10
     g = _golden("g14_student_kd_options")
@@ -338,6 +357,50 @@ def test_decoder_options_vs_reference_g14():
         assert np.isfinite(r["loss"]) and np.isfinite(r["grad_norm"])
     with pytest.raises(NotImplementedError, match="use_concate"):
         TrainEngine(_model("kd_teacher", TINY_TO)).knowledge(batch, mode="eval")
+
+
+def test_no_batch_norm_vs_reference_g15():
+    """G15: `--use-batch-norm false` on the HIP path: synthesis (teacher, student), the teacher step and the student KD step vs the real reference;
+    a train-mode step (sampled dropout behind the un-normalised blocks) against the oracle with the engine's own masks."""
+    from helpers import TINY_SN, TINY_TN, np_state_dict
+    from fcl_taco2_amd import engine
+    from fcl_taco2_amd.plan import SynthesisPlan
+    from fcl_taco2_amd.training import TrainEngine
+
+    for hp, thp, name in ((TINY_TN, None, "g15_teacher_nobn_inference"), (TINY_SN, TINY_TN, "g15_student_nobn_inference")):
+        g = _golden(name)
+        plan = SynthesisPlan(np_state_dict(hp, thp, True) if thp is not None else np_state_dict(hp), hp, DEV)
+        mel = engine.synthesize(plan, [g["x"]], [g["dur"]], dropout_mode=0)[0]
+        assert max_abs(mel.cpu(), g["after"]) < 1e-3, name
+    batch = _batch()
+    eng = TrainEngine(_model("teacher", TINY_TN))
+    assert eng.native is None and ("use_batch_norm False" in eng.native_reason or "pre-split" in eng.native_reason)
+    rep = eng.forward_backward(batch)
+    # (without BatchNorm the un-normalised encoder output makes the closed-form predictors' LayerNorms ill-conditioned: tools/diag_g15.py -- decoder /
+    # postnet gradients sit at 1e-7 of the oracle's, the energy predictor's at 5e-2 on bf16x3 operands)
+    assert _check_vs_golden_illcond(eng, rep, _golden("g15_teacher_nobn"), KD_KEYS[:6]) >= 10
+    g = _golden("g15_student_kd_nobn")
+    know = TrainEngine(_model("kd_teacher", TINY_TN)).knowledge(batch, mode="eval")
+    assert max_abs(know[0].cpu(), g["t_after"]) < 1e-4 and max_abs(know[1].cpu(), g["t_before"]) < 1e-4 and max_abs(know[2][1].cpu(), g["t_enc1"]) < 1e-4
+    eng = TrainEngine(_model("student", TINY_SN, TINY_TN))
+    rep = eng.forward_backward(batch, teacher_knowledge=know)
+    assert _check_vs_golden_illcond(eng, rep, g, KD_KEYS) >= 20
+    import dataclasses
+
+    # train mode (dropout masks behind the un-normalised blocks, sampled zoneout): G7's injected draws -- their shapes do not depend on the option --
+    # through the engine and through the oracle
+    hp = dataclasses.replace(TINY_T7, use_batch_norm=False)
+    g7 = _golden("g7_teacher_train_mode")
+    masks = O.masks_from_sequence([g7["mask%03d" % i] for i in range(int(g7["n_masks"]))], hp)
+    eng = TrainEngine(_model("teacher", hp))
+    rep = eng.forward_backward(batch, mode="train", masks=masks)
+    sd = _grad_sd(hp)
+    orep = O.model_forward(sd, hp, _cpu(batch), "teacher", bn_train=True, masks=masks)
+    orep["loss"].backward()
+    assert abs(rep["loss"] - float(orep["loss"])) < 5e-4 * max(1.0, abs(float(orep["loss"])))
+    from fcl_taco2_amd import ops
+
+    _check_vs_oracle(eng, sd, tol=1e-1 if ops.planes_enabled() else 5e-4)
 
 
 def test_speaker_embeddings_vs_reference_g13():

@@ -354,6 +354,38 @@ def test_g14_decoder_options(golden):
     assert rec["use_concate_false_kd_forward"].startswith("TypeError")
 
 
+def test_g15_no_batch_norm(golden):
+    """`--use-batch-norm false`: inference mels (teacher, student), teacher step, student KD step vs the real reference."""
+    from helpers import TINY_SN, TINY_TN
+
+    g4 = golden("g4_integer")
+    for hp, thp, name in ((TINY_TN, None, "g15_teacher_nobn_inference"), (TINY_SN, TINY_TN, "g15_student_nobn_inference")):
+        g = golden(name)
+        sd0 = torch_state_dict(hp, thp, True) if thp is not None else torch_state_dict(hp)
+        assert not any(".1.running_mean" in k for k in sd0)
+        with torch.no_grad():
+            out = O.inference(sd0, hp, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]))
+        assert max_abs(out["after"], g["after"]) < TOL_STAGE, name
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden("g15_teacher_nobn")
+    sd = _grad_sd(TINY_TN)
+    rep = O.model_forward(sd, TINY_TN, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 10
+    g = golden("g15_student_kd_nobn")
+    with torch.no_grad():
+        know = O.model_forward(torch_state_dict(TINY_TN), TINY_TN, b, "kd_teacher")
+    assert max_abs(know[0], g["t_after"]) < TOL_STAGE and max_abs(know[1], g["t_before"]) < TOL_STAGE and max_abs(know[2][1], g["t_enc1"]) < TOL_STAGE
+    sd = _grad_sd(TINY_SN, TINY_TN, True)
+    rep = O.model_forward(sd, TINY_SN, b, "student", TINY_TN, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "encoder_loss", "decoder_loss", "prosody_loss", "output_l1_loss", "output_mse_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 20
+
+
 def test_g13_speaker_embeddings(golden):
     """`spk_embed_dim`: F.normalize(spemb) appended to every encoder state (..._sa.py:555-557, 636-638).  Inference mel, the teacher step and the KD
     teacher's 5-tuple vs the real reference (the KD student cannot run with speaker embeddings in the reference: records.json)."""
