@@ -77,8 +77,6 @@ class HParams:
             bad.append("use_residual True needs embed_dim == econv_chans (the reference's `convs[i](xs) + xs` has no projection)")
         if self.reduction_factor != 1: bad.append("reduction_factor != 1")
         if not self.use_fe_condition: bad.append("use_fe_condition False")
-        if self.econv_chans != self.embed_dim or self.eunits != self.econv_chans:
-            bad.append("embed_dim/econv_chans/eunits differ")
         if not (0.0 <= self.zoneout_rate < 1.0): bad.append("zoneout_rate outside [0, 1)")
         if self.spk_embed_dim is not None and (self.spk_embed_dim <= 0 or self.spk_embed_dim % 4):
             bad.append("spk_embed_dim %r (a positive multiple of 4 is implemented)" % (self.spk_embed_dim,))

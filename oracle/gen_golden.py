@@ -701,6 +701,42 @@ def gen_g15():
     save("g15_student_kd_nobn", **d)
 
 
+def gen_g16():
+    """G16: encoder widths that all differ (embed_dim != econv_chans != eunits; every shipped recipe sets them equal): the first encoder block maps
+    embed_dim -> econv_chans, the BiLSTM econv_chans -> eunits, and everything behind the encoder runs on eunits.  Teacher: inference mel + training
+    step (eval form); student (its three widths differ too, and from the teacher's): inference mel + KD step."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0)
+    TA = HP.teacher_hparams(embed_dim=24, econv_chans=32, eunits=40, dunits=40, prenet_units=28, postnet_chans=20, **kw)
+    SA = HP.student_hparams(embed_dim=12, econv_chans=16, eunits=24, dunits=24, prenet_units=20, postnet_chans=12, **kw)
+    rng = np.random.RandomState(16)
+    x = torch.from_numpy(rng.randint(1, TA.idim, size=7).astype(np.int64))
+    dur = torch.tensor([3, 1, 2, 2, 4, 1, 3])
+    te, _ = build("teacher", TA)
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+    save("g16_teacher_widths_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    loss = te(**b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(te, d)
+    _grads(te, GRAD_KEYS + ["enc.convs.0.0.weight", "enc.blstm.weight_ih_l0"], d)
+    save("g16_teacher_widths", **d)
+    kt, _ = build("kd_teacher", TA)
+    with torch.no_grad():
+        know = kt(**b)
+    st, _ = build("student", SA, TA, True)
+    with torch.no_grad():
+        after = st.inference(x, None, dur=dur)
+    save("g16_student_widths_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), t_after=t2n(know[0]), t_before=t2n(know[1]), t_enc0=t2n(know[2][0]), t_enc4=t2n(know[2][4]))
+    _named_losses(st, d)
+    _grads(st, GRAD_KEYS + KD_KEYS + ["enc.convs.0.0.weight", "enc.blstm.weight_ih_l0"], d)
+    save("g16_student_kd_widths", **d)
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -757,7 +793,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "records"}, only
+        if "g16" in only:
+            gen_g16()
         if "g15" in only:
             gen_g15()
         if "g14" in only:
@@ -786,6 +824,7 @@ def main():
     gen_g13()
     gen_g14()
     gen_g15()
+    gen_g16()
     gen_option_records()
 
 

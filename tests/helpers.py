@@ -62,6 +62,11 @@ _NOBN = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, use
 TINY_TN = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, **_NOBN)
 TINY_SN = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, **_NOBN)
 
+# encoder widths that all differ (G16; every shipped recipe sets embed_dim == econv_chans == eunits)
+_WID = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0)
+TINY_TW = HP.teacher_hparams(embed_dim=24, econv_chans=32, eunits=40, dunits=40, prenet_units=28, postnet_chans=20, **_WID)
+TINY_SW = HP.student_hparams(embed_dim=12, econv_chans=16, eunits=24, dunits=24, prenet_units=20, postnet_chans=12, **_WID)
+
 # speaker embeddings (G13): F.normalize(spemb) appended to the encoder states; predictors / embeddings / decoder on eunits + 8 channels
 TINY_TK = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, spk_embed_dim=8)

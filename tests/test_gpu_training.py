@@ -403,6 +403,32 @@ def test_no_batch_norm_vs_reference_g15():
     _check_vs_oracle(eng, sd, tol=1e-1 if ops.planes_enabled() else 5e-4)
 
 
+def test_encoder_widths_differ_vs_reference_g16():
+    """G16: embed_dim != econv_chans != eunits on the HIP path: synthesis (teacher, student), the teacher step and the student KD step vs the real
+    reference (the native step covers equal widths only: these run on the per-launch engine)."""
+    from helpers import TINY_SW, TINY_TW, np_state_dict
+    from fcl_taco2_amd import engine
+    from fcl_taco2_amd.plan import SynthesisPlan
+    from fcl_taco2_amd.training import TrainEngine
+
+    for hp, thp, name in ((TINY_TW, None, "g16_teacher_widths_inference"), (TINY_SW, TINY_TW, "g16_student_widths_inference")):
+        g = _golden(name)
+        plan = SynthesisPlan(np_state_dict(hp, thp, True) if thp is not None else np_state_dict(hp), hp, DEV)
+        mel = engine.synthesize(plan, [g["x"]], [g["dur"]], dropout_mode=0)[0]
+        assert max_abs(mel.cpu(), g["after"]) < 1e-3, name
+    batch = _batch()
+    eng = TrainEngine(_model("teacher", TINY_TW))
+    assert eng.native is None
+    rep = eng.forward_backward(batch)
+    assert _check_vs_golden(eng, rep, _golden("g16_teacher_widths"), KD_KEYS[:6]) >= 12
+    g = _golden("g16_student_kd_widths")
+    know = TrainEngine(_model("kd_teacher", TINY_TW)).knowledge(batch, mode="eval")
+    assert max_abs(know[0].cpu(), g["t_after"]) < 1e-4 and max_abs(know[2][0].cpu(), g["t_enc0"]) < 1e-4 and max_abs(know[2][4].cpu(), g["t_enc4"]) < 1e-4
+    eng = TrainEngine(_model("student", TINY_SW, TINY_TW))
+    rep = eng.forward_backward(batch, teacher_knowledge=know)
+    assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
+
+
 def test_speaker_embeddings_vs_reference_g13():
     """G13: `spk_embed_dim` on the HIP path (fcl_concat_spk_fwd: F.normalize(spemb) appended to the encoder states; predictors, embeddings and decoder
     on eunits + spk_embed_dim channels): synthesis vs the reference's mel (one utterance and a 3-utterance batch vs the oracle), the teacher step vs

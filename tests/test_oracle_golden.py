@@ -386,6 +386,37 @@ def test_g15_no_batch_norm(golden):
     assert _check_grads(sd, g) >= 20
 
 
+def test_g16_encoder_widths_differ(golden):
+    """embed_dim != econv_chans != eunits (teacher 24 / 32 / 40, student 12 / 16 / 24): inference mels, teacher step, student KD step vs the real reference."""
+    from helpers import TINY_SW, TINY_TW
+
+    g4 = golden("g4_integer")
+    for hp, thp, name in ((TINY_TW, None, "g16_teacher_widths_inference"), (TINY_SW, TINY_TW, "g16_student_widths_inference")):
+        g = golden(name)
+        sd0 = torch_state_dict(hp, thp, True) if thp is not None else torch_state_dict(hp)
+        with torch.no_grad():
+            out = O.inference(sd0, hp, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]))
+        assert max_abs(out["after"], g["after"]) < TOL_STAGE, name
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden("g16_teacher_widths")
+    sd = _grad_sd(TINY_TW)
+    rep = O.model_forward(sd, TINY_TW, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 12
+    g = golden("g16_student_kd_widths")
+    with torch.no_grad():
+        know = O.model_forward(torch_state_dict(TINY_TW), TINY_TW, b, "kd_teacher")
+    assert max_abs(know[0], g["t_after"]) < TOL_STAGE and max_abs(know[2][0], g["t_enc0"]) < TOL_STAGE and max_abs(know[2][4], g["t_enc4"]) < TOL_STAGE
+    sd = _grad_sd(TINY_SW, TINY_TW, True)
+    rep = O.model_forward(sd, TINY_SW, b, "student", TINY_TW, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "encoder_loss", "decoder_loss", "prosody_loss", "output_l1_loss", "output_mse_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 20
+
+
 def test_g13_speaker_embeddings(golden):
     """`spk_embed_dim`: F.normalize(spemb) appended to every encoder state (..._sa.py:555-557, 636-638).  Inference mel, the teacher step and the KD
     teacher's 5-tuple vs the real reference (the KD student cannot run with speaker embeddings in the reference: records.json)."""
