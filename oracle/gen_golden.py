@@ -737,6 +737,29 @@ def gen_g16():
     save("g16_student_kd_widths", **d)
 
 
+def gen_g17():
+    """G17: layer counts outside the shipped recipes that the plain teacher class runs (the KD classes index fixed tap lists and raise on them:
+    records.json): econv_layers 2, postnet_layers 3.  Teacher: inference mel + training step (eval form)."""
+    TA = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20,
+                            duration_predictor_chans=20, dropout_rate=0.0, econv_layers=2, postnet_layers=3)
+    rng = np.random.RandomState(17)
+    x = torch.from_numpy(rng.randint(1, TA.idim, size=7).astype(np.int64))
+    dur = torch.tensor([2, 2, 5, 1, 3, 1, 2])
+    te, spec = build("teacher", TA)
+    assert "enc.convs.2.0.weight" not in spec and "dec.postnet.postnet.3.0.weight" not in spec and "dec.postnet.postnet.2.0.weight" in spec
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+    save("g17_teacher_layers_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    loss = te(**b)
+    loss.backward()
+    keys = [k for k in GRAD_KEYS if "postnet.4" not in k] + ["dec.postnet.postnet.2.0.weight", "enc.convs.0.0.weight"]
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(te, d)
+    _grads(te, keys, d)
+    save("g17_teacher_layers", **d)
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -781,6 +804,37 @@ def gen_option_records():
             kt(**b)
 
     attempt("use_concate_false_kd_forward", kd_no_concat)
+
+    # structural options the HIP path refuses (hparams.check_supported): what the reference's own classes do with them on the tiny shapes --
+    # training step + inference of the plain teacher class, and the KD pair (KD teacher forward, student step, student inference)
+    def teacher_with(com_kw=None, **kw):
+        def f():
+            c = argparse.Namespace(**dict(vars(com), **(com_kw or {})))
+            m = _quiet(Teacher, TINY_T.idim, TINY_T.odim, ns(TINY_T, **kw), c)
+            m.eval()
+            m(**b).backward()
+            m.inference(torch.tensor([1, 2, 3, 4, 5]), None, dur=torch.tensor([1, 2, 3, 1, 2]))
+        return f
+
+    def kd_with(com_kw=None, **kw):
+        def f():
+            c = argparse.Namespace(**dict(vars(com), **(com_kw or {})))
+            kt = _quiet(KDTeacher, TINY_T.idim, TINY_T.odim, ns(TINY_T, **kw), c)
+            kt.eval()
+            with torch.no_grad():
+                know = kt(**b)
+            st = _quiet(Student, TINY_S.idim, TINY_S.odim, ns(TINY_S, **kw), c, ns(TINY_T, **kw))
+            st.eval()
+            st(teacher_knowledge=know, **b).backward()
+            st.inference(torch.tensor([1, 2, 3, 4, 5]), None, dur=torch.tensor([1, 2, 3, 1, 2]))
+        return f
+
+    attempt("use_fe_condition_false_teacher", teacher_with(dict(use_fe_condition=False)))
+    attempt("use_fe_condition_false_kd", kd_with(dict(use_fe_condition=False)))
+    for key, vals in (("elayers", (2,)), ("dlayers", (1, 3)), ("prenet_layers", (0, 1, 3)), ("postnet_layers", (0, 1, 3)), ("econv_layers", (0, 2))):
+        for v in vals:
+            attempt("%s_%d_teacher" % (key, v), teacher_with(**{key: v}))
+            attempt("%s_%d_kd" % (key, v), kd_with(**{key: v}))
     attempt("spk_embed_teacher_training_and_inference", teacher_spk)
     attempt("spk_embed_student_kd_training", student_spk)
     with open(rec_path, "w") as f:
@@ -793,7 +847,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "records"}, only
+        if "g17" in only:
+            gen_g17()
         if "g16" in only:
             gen_g16()
         if "g15" in only:
@@ -825,6 +881,7 @@ def main():
     gen_g14()
     gen_g15()
     gen_g16()
+    gen_g17()
     gen_option_records()
 
 

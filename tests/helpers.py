@@ -67,6 +67,10 @@ _WID = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0)
 TINY_TW = HP.teacher_hparams(embed_dim=24, econv_chans=32, eunits=40, dunits=40, prenet_units=28, postnet_chans=20, **_WID)
 TINY_SW = HP.student_hparams(embed_dim=12, econv_chans=16, eunits=24, dunits=24, prenet_units=20, postnet_chans=12, **_WID)
 
+# layer counts outside the shipped recipes that the reference's teacher class runs (G17): two encoder blocks, three postnet blocks
+TINY_TL = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20,
+                             duration_predictor_chans=20, dropout_rate=0.0, econv_layers=2, postnet_layers=3)
+
 # speaker embeddings (G13): F.normalize(spemb) appended to the encoder states; predictors / embeddings / decoder on eunits + 8 channels
 TINY_TK = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, spk_embed_dim=8)

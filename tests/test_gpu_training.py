@@ -28,7 +28,7 @@ def _ns(hp):
                               postnet_chans=hp.postnet_chans, use_residual=hp.use_residual, use_masking=hp.use_masking, dropout_rate=hp.dropout_rate,
                               duration_predictor_chans=hp.duration_predictor_chans, output_activation=hp.output_activation,
                               spk_embed_dim=hp.spk_embed_dim, zoneout_rate=hp.zoneout_rate, use_concate=hp.use_concate, append_position=hp.append_position,
-                              use_batch_norm=hp.use_batch_norm)
+                              use_batch_norm=hp.use_batch_norm, econv_layers=hp.econv_layers, postnet_layers=hp.postnet_layers)
 
 
 def _model(role, hp, thp=None):
@@ -357,6 +357,11 @@ def test_decoder_options_vs_reference_g14():
         assert np.isfinite(r["loss"]) and np.isfinite(r["grad_norm"])
     with pytest.raises(NotImplementedError, match="use_concate"):
         TrainEngine(_model("kd_teacher", TINY_TO)).knowledge(batch, mode="eval")
+    import dataclasses
+
+    for change in (dict(postnet_layers=3), dict(econv_layers=2)):  # the reference's KD classes raise IndexError on these (records.json); its teacher class runs them
+        with pytest.raises(NotImplementedError, match="KD training needs"):
+            TrainEngine(_model("kd_teacher", dataclasses.replace(TINY_TOK, **change)))
 
 
 def test_no_batch_norm_vs_reference_g15():
@@ -427,6 +432,22 @@ def test_encoder_widths_differ_vs_reference_g16():
     eng = TrainEngine(_model("student", TINY_SW, TINY_TW))
     rep = eng.forward_backward(batch, teacher_knowledge=know)
     assert _check_vs_golden(eng, rep, g, KD_KEYS) >= 20
+
+
+def test_layer_counts_vs_reference_g17():
+    """G17: econv_layers 2 and postnet_layers 3 on the HIP path (teacher class): synthesis and the training step vs the real reference."""
+    from helpers import TINY_TL, np_state_dict
+    from fcl_taco2_amd import engine
+    from fcl_taco2_amd.plan import SynthesisPlan
+    from fcl_taco2_amd.training import TrainEngine
+
+    g = _golden("g17_teacher_layers_inference")
+    plan = SynthesisPlan(np_state_dict(TINY_TL), TINY_TL, DEV)
+    mel = engine.synthesize(plan, [g["x"]], [g["dur"]], dropout_mode=0)[0]
+    assert max_abs(mel.cpu(), g["after"]) < 1e-3
+    eng = TrainEngine(_model("teacher", TINY_TL))
+    rep = eng.forward_backward(_batch())
+    assert _check_vs_golden(eng, rep, _golden("g17_teacher_layers"), KD_KEYS[:6]) >= 12
 
 
 def test_speaker_embeddings_vs_reference_g13():
@@ -867,7 +888,10 @@ def test_full_size_kd_step_properties():
             vals.append(eng.forward_backward(batch, teacher_knowledge=know)["loss"])
         eng.P[name].copy_(w0)
         fd = (vals[0] - vals[1]) / (2 * eps)
-        assert abs(fd - gnorm) < 2e-2 * gnorm + 1e-3, (name, fd, gnorm)
+        # (absolute term: the fp32 loss (17.8) carries ~2e-5 of summation-order noise from the atomically accumulated sums, i.e. 5e-3 on a central
+        # difference over 2 eps = 4e-3 -- 4 % of the smallest of the three gradient norms (0.135), where the test used to sit at 1.7 - 2.2 % of a 2.7 %
+        # bound and failed once in ~10 full runs: tools/fd_probe.py)
+        assert abs(fd - gnorm) < 2e-2 * gnorm + 6e-3, (name, fd, gnorm)
     eng.zero_grad()
     before = eng.forward_backward(batch, teacher_knowledge=know)["loss"]
     w_before = eng.pflat.clone()

@@ -352,6 +352,12 @@ def test_g14_decoder_options(golden):
     assert _check_grads(sd, g) >= 20
     rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "records.json")))
     assert rec["use_concate_false_kd_forward"].startswith("TypeError")
+    # what the reference does with the options the HIP path still refuses (hparams.check_supported / TrainEngine): it fails on them itself, or only
+    # its KD classes do
+    assert rec["use_fe_condition_false_teacher"].startswith("AttributeError") and rec["use_fe_condition_false_kd"].startswith("AttributeError")
+    assert rec["prenet_layers_0_teacher"].startswith("AttributeError") and rec["postnet_layers_0_teacher"].startswith("TypeError")
+    assert rec["postnet_layers_3_teacher"] == "runs" and rec["postnet_layers_3_kd"].startswith("IndexError")
+    assert rec["econv_layers_2_teacher"] == "runs" and rec["econv_layers_2_kd"].startswith("IndexError")
 
 
 def test_g15_no_batch_norm(golden):
@@ -415,6 +421,24 @@ def test_g16_encoder_widths_differ(golden):
     for k in ("loss", "encoder_loss", "decoder_loss", "prosody_loss", "output_l1_loss", "output_mse_loss"):
         assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
     assert _check_grads(sd, g) >= 20
+
+
+def test_g17_layer_counts(golden):
+    """econv_layers 2, postnet_layers 3 (teacher class): inference mel and training step vs the real reference."""
+    from helpers import TINY_TL
+
+    g4, g = golden("g4_integer"), golden("g17_teacher_layers_inference")
+    with torch.no_grad():
+        out = O.inference(torch_state_dict(TINY_TL), TINY_TL, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]))
+    assert max_abs(out["after"], g["after"]) < TOL_STAGE
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden("g17_teacher_layers")
+    sd = _grad_sd(TINY_TL)
+    rep = O.model_forward(sd, TINY_TL, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 12
 
 
 def test_g13_speaker_embeddings(golden):
