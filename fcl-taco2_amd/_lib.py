@@ -29,7 +29,7 @@ class DecoderIO(C.Structure):
     _fields_ = [("n", _I), ("lmax", _I), ("att_c", _P), ("dur", _P), ("live_rows_host", _P), ("frame_off", _P),
                 ("teacher_ys", _P), ("dropout_mode", _I), ("prenet_keep", _P), ("seed", C.c_uint32), ("seed_dev", _P), ("before", _P),
                 ("tap_prenet", _P), ("tap_lstm0", _P), ("tap_lstm1", _P), ("workspace", _P), ("workspace_bytes", _Z), ("att_c_p", _P), ("before_p", _P),
-                ("live_rows", _P), ("status", _P)]
+                ("live_rows", _P), ("status", _P), ("tail_from", _I)]
 
 
 class RowMaps(C.Structure):  # fcl_row_maps_t
@@ -83,7 +83,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 410  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 411  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t

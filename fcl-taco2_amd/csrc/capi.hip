@@ -375,13 +375,20 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
         static const int tile_on = tunable("DEC_TILE", 0), tile_min = tunable("DEC_TILE_MIN_ROWS", 1024);
         if (tile_on && planes && w->stream && decoder_tile_shape_ok(w) && N >= tile_min && io->lmax <= 64 && !io->teacher_ys && !io->tap_prenet && !io->tap_lstm0 &&
             !io->tap_lstm1 && drop_mode != FCL_DROP_MASK && gemm_mode() != FCL_GEMM_BF16)
-            return launch_decoder_tile(w, io, ws.G0, ws.F0, ws.c0, ws.c1, drop_mode, s);
+            return launch_decoder_tile(w, io, ws.G0, ws.F0, ws.c0, ws.c1, drop_mode, 0, nullptr, nullptr, s);
     }
+    // fcl_decoder_io_t.tail_from: from that step on the rows still live continue in ONE launch of the persistent row-tile kernel, from the loop's own
+    // fp32 states -- in a capacity graph the steps beyond the longest duration seen so far then cost one launch in all instead of three each
+    const bool tile_ok = planes && w->stream && decoder_tile_shape_ok(w) && io->lmax <= 64 && !io->teacher_ys && !io->tap_prenet && !io->tap_lstm0 && !io->tap_lstm1 &&
+                         drop_mode != FCL_DROP_MASK && gemm_mode() != FCL_GEMM_BF16;
+    const int tail_from = (tile_ok && io->tail_from > 0 && io->tail_from < io->lmax) ? io->tail_from : 0;
     static const int fused = tunable("FUSED_PRENET", 1);
     FCL_REQUIRE(fused || !io->live_rows, FCL_ERR_INVALID, "decoder_loop_fwd: device live_rows need the fused feat/prenet kernel (FCL_FUSED_PRENET=1)");
+    FCL_REQUIRE(fused || !tail_from, FCL_ERR_INVALID, "decoder_loop_fwd: tail_from needs the fused feat/prenet kernel (FCL_FUSED_PRENET=1)");
     int cur = 0;
     for (int t = 0; t <= io->lmax; ++t) {
-        const int n = t < io->lmax ? io->live_rows_host[t] : 0;        // rows live at step t
+        const bool hand_over = tail_from > 0 && t == tail_from;      // this step and all later ones: the tile kernel (after feat_out(t - 1) of every row live at t - 1)
+        const int n = (t < io->lmax && !hand_over) ? io->live_rows_host[t] : 0;        // rows live at step t
         const int n_prev = t > 0 ? io->live_rows_host[t - 1] : 0;      // rows whose feat_out(t-1) is due
         const uint8_t* keep0 = drop_mode == FCL_DROP_MASK && t < io->lmax ? io->prenet_keep + ((size_t)(t * 2 + 0) * N) * P : nullptr;
         const uint8_t* keep1 = drop_mode == FCL_DROP_MASK && t < io->lmax ? io->prenet_keep + ((size_t)(t * 2 + 1) * N) * P : nullptr;
@@ -395,7 +402,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             fp.h1 = t > 0 ? ws.h1[cur] : nullptr; fp.wf_h = w->wf_h; fp.F0 = ws.F0;
             fp.before = io->before; fp.frame_off = io->frame_off; fp.t_prev = t - 1; fp.t_cur = t;
             fp.teacher_in = teacher_in; fp.teacher_ld = io->lmax * O;
-            if (t < io->lmax) { fp.w0 = w->prenet_w0; fp.b0 = w->prenet_b0; fp.w1 = w->prenet_w1; fp.b1 = w->prenet_b1; }
+            if (t < io->lmax && !hand_over) { fp.w0 = w->prenet_w0; fp.b0 = w->prenet_b0; fp.w1 = w->prenet_w1; fp.b1 = w->prenet_b1; }
             fp.wf_hi = w->wf_h_hi; fp.wf_lo = w->wf_h_lo; fp.w0_hi = w->prenet_w0_hi; fp.w0_lo = w->prenet_w0_lo;
             fp.w1_hi = w->prenet_w1_hi; fp.w1_lo = w->prenet_w1_lo;
             fp.drop_mode = drop_mode; fp.keep0 = keep0; fp.keep1 = keep1; fp.keep_scale = keep_scale; fp.drop_p = w->prenet_dropout;
@@ -433,6 +440,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
                 if (rc) return rc;
             }
         }
+        if (hand_over) return launch_decoder_tile(w, io, ws.G0, ws.F0, ws.c0, ws.c1, drop_mode, t, ws.h0[cur], ws.h1[cur], s);
         if (t == io->lmax) break;
         // H7 layer 0: gates = G0 + prenet . W_pre^T + pos * w_pos + h0 . W_hh^T ; cell ; zoneout
         LstmStepArgs l0 = {};

@@ -42,7 +42,10 @@ struct DecTileArgs {
     unsigned int* status;
     float* before;
     u16* before_p;
-    float *c0, *c1;  // [n, U] fp32 cell states (the loop workspace: zeroed before the launch)
+    float *c0, *c1;  // [n, U] fp32 cell states (the loop workspace: zeroed before the launch, or the per-step loop's own states at a hand-over)
+    // hand-over from the per-step loop (fcl_decoder_io_t.tail_from): the rows still live at step t_start continue here from the loop's fp32 states
+    int t_start, n_start;          // first step of this launch; the host's bound on the rows live at it (t_start = 0: n_start = n)
+    const float *h0_init, *h1_init;  // [n, U] fp32 hidden states entering step t_start (NULL at t_start = 0: zeros)
     float zoneout, keep_scale, drop_p;
     int out_act;
     unsigned int seed;
@@ -80,16 +83,19 @@ __global__ __launch_bounds__(64 * (8 + DT_NL)) void decoder_tile_kernel(const De
             if (t < a.lmax && a.live[t] > a.bound[t]) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
     }
     // (values loaded from global memory are per-lane to the compiler: readfirstlane makes every loop bound below a scalar)
-    const int n_live = __builtin_amdgcn_readfirstlane(a.live ? min(a.live[0], a.n) : a.n);
+    const int t0 = a.t_start;
+    const int n_live = __builtin_amdgcn_readfirstlane(a.live ? min(a.live[t0], a.n_start) : a.n_start);
     const int T = __builtin_amdgcn_readfirstlane(r0 < n_live ? min(a.dur[r0], a.lmax) : 0);
-    if (T <= 0) return;
+    if (T <= t0) return;
     const DtPhases ph(a.oc);
-    const int sps = ph.total, total = T * sps;  // step 0 skips feat_out's 8 slots, the feat-only step T adds them back
+    // steps t0 .. T - 1 run the step body (everything but feat_out), feat_out runs at every t in (max(t0, 1) - 1 .. T] -- at a hand-over (t0 > 0) the
+    // first one recomputes the frame of step t0 - 1 as the prenet's input (the per-step loop has stored it)
+    const int sps = ph.total, total = (T - t0) * (sps - 8) + (T - max(t0, 1) + 1) * 8;
 
     if (wave >= 8) {  // ---- loader waves: linear 1 KB pieces in stream order, one counted wait and one barrier per slot --------------------------
         const int lw = wave - 8;
         const u8* src = a.stream + lw * DT_PPL * 1024 + lane * 16;
-        int s = ph.p0, issued = 0;
+        int s = t0 > 0 ? 0 : ph.p0, issued = 0;
         auto issue = [&]() {
             u8* dst = ring + (issued & (DT_NS - 1)) * DT_SLOT + lw * DT_PPL * 1024;
             const u8* g = src + (size_t)s * DT_SLOT;
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(64 * (8 + DT_NL)) void decoder_tile_kernel(const De
         };
 #pragma unroll
         for (int p = 0; p < DT_NS - 1; ++p) issue();
-        int cs = ph.p0;
+        int cs = t0 > 0 ? 0 : ph.p0;
         for (int i = 0; i < total; ++i) {
             if (total - 1 - i >= DT_NS - 2) wait_vm<(DT_NS - 2) * DT_PPL>();
             else wait_vm<0>();
@@ -127,13 +133,23 @@ __global__ __launch_bounds__(64 * (8 + DT_NL)) void decoder_tile_kernel(const De
         *reinterpret_cast<uint2*>(buf + o + ((pc ^ s2) << 4)) = h;
         *reinterpret_cast<uint2*>(buf + o + (((4 + pc) ^ s2) << 4)) = l;
     };
-    for (int i = tid; i < 3 * DT_BUF / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);  // prev_out = h = 0 before step 0
+    // prev_out = 0; h = 0 before step 0, or (hand-over) the hidden states entering step t0 split into the state lines -- every line of h0 / h1 is then
+    // written by exactly one thread here and nobody zeroes it (no barrier orders two threads before the first slot's)
+    for (int i = tid; i < (a.h0_init ? 1 : 3) * DT_BUF / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+    if (a.h0_init) {
+        for (int i = tid; i < DT_ROWS * (DT_U / 4); i += 512) {
+            const int row = i / (DT_U / 4), col = (i % (DT_U / 4)) * 4;
+            const size_t g = (size_t)min(r0 + row, a.n - 1) * DT_U + col;
+            st_store(h0b, row, col, *reinterpret_cast<const f32x4*>(a.h0_init + g));
+            st_store(h1b, row, col, *reinterpret_cast<const f32x4*>(a.h1_init + g));
+        }
+    }
     int mrow[2], mc[2], durv[2], fo[2];
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
         mrow[tm] = r0 + tm * 16 + arow;
         mc[tm] = min(mrow[tm], a.n - 1);
-        durv[tm] = mrow[tm] < n_live ? a.dur[mc[tm]] : 0;
+        durv[tm] = mrow[tm] < n_live ? a.dur[mc[tm]] : 0;  // (rows of the tile that are not live at t0 have nothing left to do: they never store)
         fo[tm] = a.frame_off[mc[tm]];
     }
     const unsigned int thr16 = (unsigned int)(a.drop_p * 65536.0f);
@@ -246,7 +262,7 @@ __global__ __launch_bounds__(64 * (8 + DT_NL)) void decoder_tile_kernel(const De
             }
     };
     auto publish_x = [&] { publish(xb, pah, pal); };
-    for (int t = 0; t <= T; ++t) {
+    for (int t = t0; t <= T; ++t) {
         if (t > 0) {  // ---- H8 feat_out of step t - 1 (+ H10 scatter); its first slot publishes LSTM 1's new h1 -------------------------------------
             const int fnc = wave * 16 + cq * 4;
             const bool fw = wave * 16 < oc * 32;
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(64 * (8 + DT_NL)) void decoder_tile_kernel(const De
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm) f0v[tm] = (fw && fnc < O) ? *reinterpret_cast<const f32x4*>(a.F0 + (size_t)mc[tm] * O + fnc) : (f32x4){0.f, 0.f, 0.f, 0.f};
             f32x4 acc[2];
-            gemm_phase(h1b, 8, acc, [&] { publish(h1b, hnh, hnl); }, true);
+            gemm_phase(h1b, 8, acc, [&] { if (t > t0) publish(h1b, hnh, hnl); }, true);  // (first step of a hand-over: h1 is the loaded state)
             tick(0);
             if (fw) {
 #pragma unroll
@@ -262,11 +278,12 @@ __global__ __launch_bounds__(64 * (8 + DT_NL)) void decoder_tile_kernel(const De
                     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
                     const bool live = durv[tm] > t - 1;
                     const long long fr = (long long)fo[tm] + (t - 1);
+                    const bool store = live && t > t0;  // (t == t0 > 0: the per-step loop's feat_out launch has stored this frame)
                     if (live && fnc < O) {
                         v = acc[tm] + f0v[tm];
-                        *reinterpret_cast<f32x4*>(a.before + (size_t)fr * O + fnc) = v;
+                        if (store) *reinterpret_cast<f32x4*>(a.before + (size_t)fr * O + fnc) = v;
                     }
-                    if (live && a.before_p) {  // (columns O .. 32 oc - 1: the zero padding of the frame's last line)
+                    if (store && a.before_p) {  // (columns O .. 32 oc - 1: the zero padding of the frame's last line)
                         uint2 h, l;
                         split4(v, h, l);
                         u16* line = a.before_p + ((size_t)fr * ldbp + (fnc >> 5)) * 64 + (fnc & 31);
@@ -428,7 +445,7 @@ int decoder_stream_pack(const fcl_decoder_weights_t* w, void* out, hipStream_t s
 
 // the loop of fcl_decoder_loop_fwd from its hoisted terms on (G0, F0 in the workspace): one launch, ceil(n / 32) workgroups
 int launch_decoder_tile(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, const float* G0, const float* F0, float* c0, float* c1, int drop_mode,
-                        hipStream_t s) {
+                        int t_start, const float* h0_init, const float* h1_init, hipStream_t s) {
     DecTileArgs a = {};
     a.stream = reinterpret_cast<const u8*>(w->stream);
     a.oc = (w->odim + 31) >> 5;
@@ -437,6 +454,7 @@ int launch_decoder_tile(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* 
     a.G0 = G0; a.F0 = F0; a.w_pos = w->w0_pos; a.b1 = w->b1; a.pb0 = w->prenet_b0; a.pb1 = w->prenet_b1;
     a.dur = io->dur; a.frame_off = io->frame_off; a.live = io->live_rows; a.status = io->status;
     a.before = io->before; a.before_p = io->before_p; a.c0 = c0; a.c1 = c1;
+    a.t_start = t_start; a.n_start = t_start > 0 ? io->live_rows_host[t_start] : io->n; a.h0_init = h0_init; a.h1_init = h1_init;
     a.zoneout = w->zoneout_rate; a.keep_scale = 1.0f / (1.0f - w->prenet_dropout); a.drop_p = w->prenet_dropout;
     a.out_act = w->out_act; a.seed = io->seed; a.seed_dev = io->seed_dev;
     static const int want_ts = tunable("DEC_TILE_TS", 0);
@@ -448,9 +466,9 @@ int launch_decoder_tile(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* 
     const void* fn = drop_mode == FCL_DROP_RNG ? reinterpret_cast<const void*>(decoder_tile_kernel<2>) : reinterpret_cast<const void*>(decoder_tile_kernel<0>);
     const int rc = ensure_dyn_lds(fn, DT_LDS);
     if (rc) return rc;
-    const dim3 grid((io->n + DT_ROWS - 1) / DT_ROWS), block(64 * (8 + DT_NL));
+    const dim3 grid((a.n_start + DT_ROWS - 1) / DT_ROWS), block(64 * (8 + DT_NL));
     double steps = 0;
-    for (int t = 0; t < io->lmax; ++t) steps += io->live_rows_host[t];
+    for (int t = t_start; t < io->lmax; ++t) steps += io->live_rows_host[t];
     // algorithmic flops: per live row-step 2 * (4U (P + U) + 4U * 2U + P (O + P) + O U)
     const double per = 2.0 * (4.0 * DT_U * (DT_P + DT_U) + 4.0 * DT_U * 2 * DT_U + (double)DT_P * (w->odim + DT_P) + (double)w->odim * DT_U);
     ProfScope prof(drop_mode == FCL_DROP_RNG ? "decoder_tile_kernel<rng>" : "decoder_tile_kernel<none>", per * steps, steps, s);

@@ -251,6 +251,6 @@ bool decoder_tile_shape_ok(const fcl_decoder_weights_t* w);
 size_t decoder_stream_bytes(const fcl_decoder_weights_t* w);
 int decoder_stream_pack(const fcl_decoder_weights_t* w, void* out, hipStream_t s);
 int launch_decoder_tile(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, const float* G0, const float* F0, float* c0, float* c1, int drop_mode,
-                        hipStream_t s);
+                        int t_start, const float* h0_init, const float* h1_init, hipStream_t s);
 
 }  // namespace fcl

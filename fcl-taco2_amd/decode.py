@@ -120,7 +120,8 @@ def _grown_caps(engine, maps, n_rows, scale=1.3):
     bounds[: maps.lmax] = live
     bounds[maps.lmax :] = live[-1]
     bounds = np.maximum.accumulate(bounds[::-1])[::-1].astype(np.int32)  # non-increasing, as the loop requires
-    return engine.Caps(lmax, (int(maps.n_frames * scale) + 255) // 256 * 256, bounds)
+    # the steps past this batch's own longest duration (+ 2) are slack: the rows that do reach them continue in one launch of the row-tile kernel
+    return engine.Caps(lmax, (int(maps.n_frames * scale) + 255) // 256 * 256, bounds, tail_from=maps.lmax + 2)
 
 
 MAX_BUCKETS = 8  # captured-graph pools kept per (batch size, depth): least recently used buckets are released beyond this
@@ -242,7 +243,7 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
                         frames += harvest(it)
                     g = _grown_caps(engine, pool.grow, batch_size * t_cap, scale=1.6)
                     lmax = max(g.lmax, pool.caps.lmax)
-                    caps = engine.Caps(lmax, max(g.frames, pool.caps.frames), np.full(lmax, batch_size * t_cap, np.int32))
+                    caps = engine.Caps(lmax, max(g.frames, pool.caps.frames), np.full(lmax, batch_size * t_cap, np.int32), tail_from=g.tail_from)
                     pool = pools[t_cap] = _Pool(plan, batch_size, t_cap, caps, streams, seed + 31 * bi)
                 if pool is None:  # first batch of the bucket: eager pass = its result + the bucket's calibration
                     got, maps = eager(chunk)

@@ -133,11 +133,14 @@ class Caps(object):
     durations.  lmax: decoder steps to launch; frames: rows of the frame-major buffers; bounds: int32 [lmax] upper bounds of the live rows per
     step (grid sizes and kernel selection only).  None of them is trusted: a batch that exceeds one raises FCL_STATUS_* in the device status word
     (read it with DeviceFrames.resolve() / ops.check_status) and decodes nothing."""
-    __slots__ = ("lmax", "frames", "bounds")
+    __slots__ = ("lmax", "frames", "bounds", "tail_from")
 
-    def __init__(self, lmax, frames, bounds):
+    def __init__(self, lmax, frames, bounds, tail_from=0):
+        """tail_from (0 = off): from that decoder step on, the rows still live continue in ONE launch of the persistent row-tile kernel
+        (fcl_decoder_io_t.tail_from): set it to where the slack of `lmax` begins -- steps nobody reaches then cost one launch instead of three each."""
         self.lmax, self.frames = int(lmax), int(frames)
         self.bounds = np.ascontiguousarray(np.asarray(bounds, dtype=np.int32))
+        self.tail_from = int(tail_from) if 0 < int(tail_from) < self.lmax else 0
         assert self.bounds.shape == (self.lmax,) and self.lmax > 0 and self.frames > 0
 
     @staticmethod
@@ -301,6 +304,7 @@ class _DevMaps(object):
     def __init__(self, dm, caps):
         self.src_rows, self.dur, self.frame_off, self.frame_lo, self.frame_hi = dm["src_rows"], dm["dur"], dm["frame_off"], dm["frame_lo"], dm["frame_hi"]
         self.live_dev, self.live_rows, self.n_frames, self.lmax = dm["live_rows"], caps.bounds, caps.frames, caps.lmax
+        self.tail_from = caps.tail_from
         self.order = None
 
 
@@ -381,7 +385,7 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
             keep_dev = torch.from_numpy(keep).to(dev)
         before = ops.decoder_loop(plan.decoder, att_c, rm.dur, maps.live_rows, rm.frame_off, maps.n_frames,
                                   dropout_mode=dropout_mode, prenet_keep=keep_dev, seed=seed, seed_dev=seed_dev, att_c_p=att_c_p, want_before_p=planes,
-                                  live_rows_dev=getattr(maps, "live_dev", None), status=status)
+                                  live_rows_dev=getattr(maps, "live_dev", None), status=status, tail_from=getattr(maps, "tail_from", 0))
         n_post = len(plan.postnet)
         if planes:
             before, xp = before

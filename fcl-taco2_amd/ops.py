@@ -385,13 +385,14 @@ def row_maps_request(n, b, lmax_cap, frames_cap, dur_i64=None, dur_i32=None, row
 
 def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher_ys=None, dropout_mode=DROP_NONE,
                  prenet_keep=None, seed=0, want_taps=False, seed_dev=None, zero_init=False, att_c_p=None, want_before_p=False, live_rows_dev=None,
-                 status=None):
+                 status=None, tail_from=0):
     """dw: plan.DecoderPack (holds the ctypes DecoderWeights + the tensors it points to).
     live_rows: host numpy int32 [Lmax].  Returns before [F, odim] (+ taps).  att_c_p: P32 planes of att_c (att_c may then be None);
     want_before_p: also return `before` as P32 planes (appended to the result).
     live_rows_dev: device int32 [Lmax + 1] (row_maps_build): the loop is then driven by the DEVICE counts, `live_rows` are per-step upper bounds
     (grid sizes, kernel selection) and n_frames is the capacity of the frame buffers (rows past the real total are never written; the
-    postnet's segment bounds of such rows are empty, so nothing reads them either)."""
+    postnet's segment bounds of such rows are empty, so nothing reads them either).
+    tail_from: fcl_decoder_io_t.tail_from (steps from there on: one launch of the persistent row-tile kernel for the rows still live)."""
     lib = _lib.load()
     dev = att_c.device if att_c is not None else att_c_p.device
     n = att_c.shape[0] if att_c is not None else att_c_p.shape[0]
@@ -414,7 +415,7 @@ def decoder_loop(dw, att_c, dur_i32, live_rows, frame_off_i32, n_frames, teacher
         prenet_keep=_p(prenet_keep, torch.uint8), seed=seed & 0xFFFFFFFF, seed_dev=_p(seed_dev, torch.int32), before=_p(before),
         tap_prenet=_p(taps[0]) if taps else None, tap_lstm0=_p(taps[1]) if taps else None, tap_lstm1=_p(taps[2]) if taps else None,
         workspace=ws.data_ptr(), workspace_bytes=nbytes, att_c_p=_p(att_c_p, torch.int16), before_p=_p(before_p, torch.int16),
-        live_rows=_p(live_rows_dev, torch.int32), status=None if live_rows_dev is None else status.data_ptr())
+        live_rows=_p(live_rows_dev, torch.int32), status=None if live_rows_dev is None else status.data_ptr(), tail_from=int(tail_from))
     check(lib.fcl_decoder_loop_fwd(C.byref(dw.struct), C.byref(io), _stream()))
     res = (before, taps) if want_taps else before
     if want_before_p:

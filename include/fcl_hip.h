@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 410
+#define FCL_ABI_VERSION 411
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -309,6 +309,10 @@ typedef struct {
                                  * rows, `lmax` is the number of steps LAUNCHED (>= the true maximum, else FCL_STATUS_LMAX_CAP was raised by the map
                                  * builder), and a step with more live rows than its bound raises FCL_STATUS_ROWS_CAP in `status`.  NULL: host counts are exact */
     uint32_t* status;           /* device status word (FCL_STATUS_*); required with live_rows */
+    int tail_from;              /* 0 = off.  Steps tail_from .. lmax - 1 (0 < tail_from < lmax) of the rows still live then run as ONE launch of the persistent
+                                 * row-tile kernel (csrc/decoder_tile.hip; needs fcl_decoder_weights_t.stream and a free-running loop without taps / injected
+                                 * masks, ignored otherwise), continuing from the loop's own states: in a capacity graph (lmax = a bound with slack) the steps
+                                 * beyond the durations actually seen cost one launch in all instead of three each; rows that do reach them pay ~2x per step */
 } fcl_decoder_io_t;
 
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n);
