@@ -22,7 +22,8 @@ class DecoderWeights(C.Structure):
                           "w1_ih", "w1_hh", "b1", "wf_h", "wf_att")
     ] + [("zoneout_rate", _F), ("prenet_dropout", _F)] + [
         (n + sfx, _P) for n in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h") for sfx in ("_hi", "_lo")] + [
-        (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")] + [("out_act", _I), ("stream", _P)]
+        (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")] + [("out_act", _I), ("wf_h_ff", _P), ("prenet_w0_ff", _P), ("prenet_w1_ff", _P),
+                                                                                           ("w0_pre_ff", _P), ("w0_hh_ff", _P), ("w1_ih_ff", _P), ("w1_hh_ff", _P), ("stream", _P)]
 
 
 class DecoderIO(C.Structure):
@@ -40,7 +41,7 @@ class RowMaps(C.Structure):  # fcl_row_maps_t
 
 class GemmTerm(C.Structure):
     _fields_ = [("A", _P), ("W", _P), ("lda", _I), ("ldw", _I), ("K", _I), ("shift", _I), ("Whi", _P), ("Wlo", _P), ("Ap", _P), ("Wp", _P),
-                ("lda_p", _I), ("ldw_p", _I), ("a_chunk_stride", C.c_int64)]
+                ("lda_p", _I), ("ldw_p", _I), ("a_chunk_stride", C.c_int64), ("Wff", _P)]
 
 
 class LstmStep(C.Structure):
@@ -83,7 +84,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 411  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 412  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -157,6 +158,7 @@ SIGNATURES = {
     "fcl_add2d": (_I, [_P, _I, _P, _I, _I, _I, _F, _P, _P]),
     "fcl_frag_bf16_elems": (_Z, [_I, _I]),
     "fcl_pack_frag_bf16": (_I, [_P, _I, _I, _P, _P, _P]),
+    "fcl_pack_frag_f32": (_I, [_P, _I, _I, _P, _P]),
     "fcl_add_vec": (_I, [_P, _P, _P, _I, _P]),
     "fcl_u32_add": (_I, [_P, C.c_uint32, _P]),
     "fcl_planes_elems": (_Z, [_I, _I]),

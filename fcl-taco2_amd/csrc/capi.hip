@@ -405,6 +405,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             if (t < io->lmax && !hand_over) { fp.w0 = w->prenet_w0; fp.b0 = w->prenet_b0; fp.w1 = w->prenet_w1; fp.b1 = w->prenet_b1; }
             fp.wf_hi = w->wf_h_hi; fp.wf_lo = w->wf_h_lo; fp.w0_hi = w->prenet_w0_hi; fp.w0_lo = w->prenet_w0_lo;
             fp.w1_hi = w->prenet_w1_hi; fp.w1_lo = w->prenet_w1_lo;
+            fp.wf_ff = w->wf_h_ff; fp.w0_ff = w->prenet_w0_ff; fp.w1_ff = w->prenet_w1_ff;
             fp.drop_mode = drop_mode; fp.keep0 = keep0; fp.keep1 = keep1; fp.keep_scale = keep_scale; fp.drop_p = w->prenet_dropout;
             fp.seed0 = seed0; fp.seed1 = seed1; fp.seed_dev = io->seed_dev; fp.pre_out = ws.pre_b; fp.tap_prenet = io->tap_prenet;
             fp.live = io->live_rows; fp.status = io->status; fp.out_act = w->out_act;
@@ -453,6 +454,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             l0.term[1].Ap = ws.h0_p[cur]; l0.term[1].Wp = w->w0_hh_p; l0.term[1].lda_p = l0.term[1].ldw_p = ldu;
             l0.h_out_p = ws.h0_p[cur ^ 1]; l0.ld_hp = ldu;  // read by layer 1 now and by layer 0 of the next step
         }
+        l0.term[0].Wff = w->w0_pre_ff; l0.term[1].Wff = w->w0_hh_ff;
         l0.nterms = 2; l0.M = n; l0.U = U; l0.G = ws.G0; l0.g_row_mul = 1; l0.g_row_add = 0;
         l0.m_dev = io->live_rows ? io->live_rows + t : nullptr;
         l0.rank1_w = w->w0_pos; l0.dur = io->dur; l0.step = t;
@@ -469,6 +471,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
             l1.term[1].Ap = ws.h1_p[cur]; l1.term[1].Wp = w->w1_hh_p; l1.term[1].lda_p = l1.term[1].ldw_p = ldu;
             if (next_big) { l1.h_out_p = ws.h1_p[cur ^ 1]; l1.ld_hp = ldu; }
         }
+        l1.term[0].Wff = w->w1_ih_ff; l1.term[1].Wff = w->w1_hh_ff;
         l1.nterms = 2; l1.M = n; l1.U = U; l1.bias = w->b1; l1.step = t;
         l1.m_dev = l0.m_dev;
         l1.h_in = ws.h1[cur]; l1.h_out = ws.h1[cur ^ 1]; l1.c = ws.c1; l1.zoneout = w->zoneout_rate;

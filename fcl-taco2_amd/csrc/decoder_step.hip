@@ -965,6 +965,192 @@ __global__ __launch_bounds__(512) void feat_prenet_split_kernel(const FeatPrenet
     }
 }
 
+
+// The same launch in EXACT fp32 (FCL_PRECISION=0; round 4): v_mfma_f32_16x16x4_f32 on fragment-major fp32 weights (fcl_pack_frag_f32), one row tile per
+// workgroup, no column split.  Same structure as feat_prenet_split_kernel -- every weight fragment register-resident (a lane's two float4 per tile and
+// 32-k step are exactly the bytes of its hi + lo pair), transposed accumulators (the weight fragment is the MFMA's A operand), vector epilogues,
+// three phases chained through LDS -- with fp32 tiles in LDS instead of split planes.  Replaces feat_prenet_kernel (weights re-streamed from L2 at
+// every k-step: 19.2 us per launch at 2 400 rows, the largest item of the exact-mode pass) where the shape is covered.
+template <int NT, int NS_>
+struct WFragF {
+    f32x4 w0[NT][NS_], w1[NT][NS_];
+    __device__ __forceinline__ void load(const float* const (&f)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int st = 0; st < NS_; ++st) {
+                w0[t][st] = *reinterpret_cast<const f32x4*>(f[t] + st * 512);
+                w1[t][st] = *reinterpret_cast<const f32x4*>(f[t] + st * 512 + 4);
+            }
+    }
+};
+
+template <int NT, int NS_>
+__device__ __forceinline__ void mma_tf(const WFragF<NT, NS_>& w, const float* A, int ldk, int r16, int kq, f32x4 (&out)[NT]) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* a = A + r16 * ldk + kq * 4;
+#pragma unroll
+    for (int st = 0; st < NS_; ++st) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(a + st * 32), a1 = *reinterpret_cast<const f32x4*>(a + st * 32 + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w0[t][st][e], a0[e], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w1[t][st][e], a1[e], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t] = acc[t];
+}
+
+template <int DROP>
+__global__ __launch_bounds__(512) void feat_prenet_split_f32_kernel(const FeatPrenetArgs a) {
+    constexpr int SU = 8, SO = 3, SP = 8, U = 256, OP = 96, P = 256;
+    const int M_feat = a.M_feat, M_pre = a.M_pre;
+    const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
+    if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
+    if ((int)blockIdx.x * 16 >= (a.h1 ? Ms_feat : Ms_pre)) return;
+    constexpr int ldU = U + 8, ldO = OP + 8, ldP = P + 8;  // floats: rows 32 bytes apart modulo the 256-byte bank period, as the plane tiles are
+    static_assert(ldU == ldP, "the layer-1 operand tile re-uses the h1 tile's LDS");
+    extern __shared__ __attribute__((aligned(16))) float fpf_lds[];
+    float* A1 = fpf_lds;            // [16][ldU]  h1 tile, then (phase 2 on) layer 0's output
+    float* A2 = A1 + 16 * ldU;      // [16][ldO]  feat_out / prenet input
+    const int O = a.O;
+    const int m0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int arow = lane & 15, cq = lane >> 4;
+    const bool has_feat = a.h1 != nullptr, has_pre = a.w0 != nullptr && m0 < M_pre;
+    const bool feat_wave = has_feat && wave * 16 < O;
+    const size_t lane8 = (size_t)lane * 8;
+    auto frag = [&](const float* base, int tile, int ns) { return base + (size_t)tile * ns * 512 + lane8; };
+    const int t0 = wave, t1 = wave + 8;  // this wave's column tiles of both prenet layers
+    // ---- phase 0 operands first
+    f32x4 hreg[2];
+    if (has_feat) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + j * 512, r = i >> 6, c = (i & 63) * 4;
+            hreg[j] = *reinterpret_cast<const f32x4*>(a.h1 + (size_t)min(m0 + r, M_feat - 1) * U + c);
+        }
+    }
+    asm volatile("s_barrier" ::: "memory");  // (queue order = order of use: see feat_prenet_split_kernel)
+    WFragF<1, SU> ff;
+    WFragF<2, SO> f0;
+    WFragF<2, SP> f1;
+    const int fnc = wave * 16 + cq * 4;
+    f32x4 f0v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int fo = 0;
+    if (feat_wave) {
+        const float* const wf[1] = {frag(a.wf_ff, wave, SU)};
+        ff.load(wf);
+        if (fnc < O) {
+            const int mc = min(m0 + arow, M_feat - 1);
+            f0v = *reinterpret_cast<const f32x4*>(a.F0 + (size_t)mc * O + fnc);
+            fo = a.frame_off[mc];
+        }
+    }
+    unsigned int seed0 = 0, seed1 = 0;
+    const unsigned int thr16 = (unsigned int)(a.drop_p * 65536.0f);
+    if (DROP == 2) {
+        const unsigned int sbump = a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u;
+        seed0 = hash_u32(a.seed0 + sbump);
+        seed1 = hash_u32(a.seed1 + sbump);
+    }
+    f32x4 pb0[2], pb1[2];
+    unsigned int k0[2] = {0u, 0u}, k1[2] = {0u, 0u};
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) pb0[tt] = pb1[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (has_feat) asm volatile("s_barrier" ::: "memory");
+    if (has_pre) {
+        const float* const w0p[2] = {frag(a.w0_ff, t0, SO), frag(a.w0_ff, t1, SO)};
+        f0.load(w0p);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + cq * 4;
+            pb0[tt] = *reinterpret_cast<const f32x4*>(a.b0 + nc);
+            if (DROP == 1) k0[tt] = *reinterpret_cast<const unsigned int*>(a.keep0 + (size_t)min(m0 + arow, M_pre - 1) * P + nc);
+        }
+    }
+    // ---- phase 0: h1 tile -> LDS; the prenet-input tile zeroed (prev_out = 0 at t = 0; zero padding past O otherwise)
+    for (int i = threadIdx.x; i < 16 * ldO / 4; i += 512) reinterpret_cast<f32x4*>(A2)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (has_feat) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = threadIdx.x + j * 512, r = i >> 6, c = (i & 63) * 4;
+            *reinterpret_cast<f32x4*>(A1 + r * ldU + c) = hreg[j];
+        }
+    }
+    lds_barrier();
+    // ---- phase 1: feat_out of the previous step (+ frame scatter)
+    if (feat_wave) {
+        f32x4 accv[1];
+        mma_tf<1, SU>(ff, A1, ldU, r16, kq, accv);
+        const int m = m0 + arow;
+        if (fnc < O) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (m < Ms_feat) {
+                v = accv[0] + f0v;
+                *reinterpret_cast<f32x4*>(a.before + (size_t)((long long)fo + a.t_prev) * O + fnc) = v;
+                if (a.out_act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], a.out_act);
+                }
+            }
+            *reinterpret_cast<f32x4*>(A2 + arow * ldO + fnc) = v;
+        }
+    }
+    if (!has_pre) return;
+    {   // layer 1's fragments: requested once feat_out's are dead (128 VGPRs)
+        const float* const w1p[2] = {frag(a.w1_ff, t0, SP), frag(a.w1_ff, t1, SP)};
+        f1.load(w1p);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + cq * 4;
+            pb1[tt] = *reinterpret_cast<const f32x4*>(a.b1 + nc);
+            if (DROP == 1) k1[tt] = *reinterpret_cast<const unsigned int*>(a.keep1 + (size_t)min(m0 + arow, M_pre - 1) * P + nc);
+        }
+    }
+    lds_barrier();
+    // ---- phase 2: prenet layer 0 -> LDS (over the h1 tile: every wave is past its last read of it)
+    {
+        f32x4 accv[2];
+        mma_tf<2, SO>(f0, A2, ldO, r16, kq, accv);
+        const int m = m0 + arow;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + cq * 4;
+            f32x4 v = accv[tt] + pb0[tt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            v = drop4<DROP>(v, k0[tt], (unsigned int)m * (unsigned int)P + (unsigned int)nc, seed0, thr16, a.keep_scale);
+            *reinterpret_cast<f32x4*>(A1 + arow * ldP + nc) = v;
+        }
+    }
+    lds_barrier();
+    // ---- phase 3: prenet layer 1 -> global (+ KD tap)
+    {
+        f32x4 accv[2];
+        mma_tf<2, SP>(f1, A1, ldP, r16, kq, accv);
+        const int m = m0 + arow;
+        if (m >= Ms_pre) return;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int nc = (tt ? t1 : t0) * 16 + cq * 4;
+            f32x4 v = accv[tt] + pb1[tt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            v = drop4<DROP>(v, k1[tt], (unsigned int)m * (unsigned int)P + (unsigned int)nc, seed1, thr16, a.keep_scale);
+            if (a.pre_out) *reinterpret_cast<f32x4*>(a.pre_out + (size_t)m * P + nc) = v;
+            if (a.tap_prenet) *reinterpret_cast<f32x4*>(a.tap_prenet + (size_t)(a.frame_off[m] + a.t_cur) * P + nc) = v;
+        }
+    }
+}
+
 // PRE: both terms have K = 256 (the student's decoder LSTMs) -> all 2 x 8 weight fragments are requested at kernel entry.
 template <bool PRE>
 __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a) {
@@ -1024,6 +1210,51 @@ __global__ __launch_bounds__(256) void lstm_small_x3_kernel(const LstmStepArgs a
         const int col = lane & 15, rq = lane >> 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) g_l[g][rq * 4 + r][col] = acc[r];
+    }
+    __syncthreads();
+    if (!evalid || em >= Ms) return;
+    const float pre[4] = {g_l[0][erow][euc], g_l[1][erow][euc], g_l[2][erow][euc], g_l[3][erow][euc]};
+    cell_finish(a, em, eu, pre, ci);
+}
+
+
+// The small step in EXACT fp32 with register-resident weights (FCL_PRECISION=0; round 4): the structure of lstm_small_x3_kernel<true> on fragment-major
+// fp32 weights (fcl_gemm_term_t.Wff) and v_mfma_f32_16x16x4_f32, the weight fragment as the A operand (a lane's accumulators: four consecutive units
+// of one row).  Both terms K = 256.
+__global__ __launch_bounds__(256) void lstm_small_ff_kernel(const LstmStepArgs a) {
+    const int M = a.M, Ms = live_rows_of(a.M, a.m_dev);
+    if ((int)blockIdx.y * 16 >= Ms) return;
+    constexpr int LD = 256 + 8;
+    __shared__ __attribute__((aligned(16))) float A_f[16 * LD];
+    __shared__ float g_l[4][16][17];
+    const int m0 = blockIdx.y * 16, u0 = blockIdx.x * 16;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int erow = threadIdx.x >> 4, euc = threadIdx.x & 15;
+    const int em = m0 + erow, eu = u0 + euc;
+    const bool evalid = em < M && eu < a.U;
+    CellIn ci;
+    if (evalid) ci = cell_prefetch(a, em, eu);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    WFragF<1, 8> wf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float* const w[1] = {a.term[t].Wff + (size_t)((g * a.U + u0) >> 4) * 8 * 512 + (size_t)lane * 8};
+        wf[t].load(w);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t) __syncthreads();
+        load_rowtile(A_f, LD, a.term[t].A, a.term[t].lda, 256, m0, M);
+        __syncthreads();
+        f32x4 part[1];
+        mma_tf<1, 8>(wf[t], A_f, LD, r16, kq, part);
+        acc += part[0];
+    }
+    {
+        const int arow = lane & 15, cq = lane >> 4;  // accumulators: row arow, units cq * 4 .. + 3 of the tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g_l[g][arow][cq * 4 + i] = acc[i];
     }
     __syncthreads();
     if (!evalid || em >= Ms) return;
@@ -1234,6 +1465,11 @@ int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled) {
     return check_hip(hipGetLastError(), "lstm_wres launch");
 }
 
+static bool fp_exact_split() {
+    static const int v = tunable("FP_EXACT_SPLIT", 1);  // 0: the exact-fp32 mode keeps its fp32-operand feat/prenet and small-step kernels
+    return v != 0;
+}
+
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s) {
     double ksum = 0;
     for (int i = 0; i < a.nterms; ++i) ksum += a.term[i].K;
@@ -1245,6 +1481,9 @@ int launch_lstm_small(const LstmStepArgs& a, hipStream_t s) {
         ProfScope ps("lstm_small_kernel/bf16x3", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
         if (a.nterms == 2 && a.term[0].K == 256 && a.term[1].K == 256) hipLaunchKernelGGL(lstm_small_x3_kernel<true>, grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(lstm_small_x3_kernel<false>, grid, dim3(256), 0, s, a);
+    } else if (a.nterms == 2 && a.term[0].Wff && a.term[1].Wff && a.term[0].K == 256 && a.term[1].K == 256 && (a.U & 15) == 0 && fp_exact_split()) {
+        ProfScope ps("lstm_small_ff_kernel/f32", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
+        hipLaunchKernelGGL(lstm_small_ff_kernel, grid, dim3(256), 0, s, a);
     } else {
         ProfScope ps("lstm_small_kernel", 2.0 * a.M * 4.0 * a.U * ksum, a.M, s);
         hipLaunchKernelGGL(lstm_small_kernel, grid, dim3(256), 0, s, a);
@@ -1350,6 +1589,20 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
         } else {
             hipLaunchKernelGGL((feat_prenet_x3_kernel<0, 0, 0>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
         }
+    } else if (a.wf_ff && a.w0_ff && a.w1_ff && a.U == 256 && a.P == 256 && a.O > 64 && a.O <= 96 && !a.teacher_in && !a.pre_out_p && !a.before_p &&
+               (!a.w0 || a.pre_out) && fp_exact_split()) {
+        // exact-fp32 mode with fragment-major fp32 weights: the register-resident form (19.2 -> ~9 us per launch at 2 400 rows)
+        ProfScope ps("feat_prenet_split_kernel/f32", fl, rows, s);
+        constexpr size_t lds_f = sizeof(float) * 16 * ((256 + 8) + (96 + 8));
+        const dim3 g((rows + 15) / 16), b(512);
+        const void* fn = a.drop_mode == 1   ? reinterpret_cast<const void*>(feat_prenet_split_f32_kernel<1>)
+                         : a.drop_mode == 2 ? reinterpret_cast<const void*>(feat_prenet_split_f32_kernel<2>)
+                                            : reinterpret_cast<const void*>(feat_prenet_split_f32_kernel<0>);
+        const int rc = ensure_dyn_lds(fn, (int)lds_f);
+        if (rc) return rc;
+        if (a.drop_mode == 1) hipLaunchKernelGGL(feat_prenet_split_f32_kernel<1>, g, b, lds_f, s, a);
+        else if (a.drop_mode == 2) hipLaunchKernelGGL(feat_prenet_split_f32_kernel<2>, g, b, lds_f, s, a);
+        else hipLaunchKernelGGL(feat_prenet_split_f32_kernel<0>, g, b, lds_f, s, a);
     } else {
         ProfScope ps("feat_prenet_kernel", fl, rows, s);
         hipLaunchKernelGGL(feat_prenet_kernel, dim3((rows + 15) / 16), dim3(512), lds, s, a);

@@ -113,6 +113,7 @@ struct FeatPrenetArgs {
     int teacher_ld;
     const float *w0, *b0, *w1, *b1;
     const unsigned short *wf_hi, *wf_lo, *w0_hi, *w0_lo, *w1_hi, *w1_lo;  // optional bf16x3 planes (all or none)
+    const float *wf_ff, *w0_ff, *w1_ff;  // optional fragment-major fp32 forms (fcl_pack_frag_f32; exact-fp32 mode: all or none)
     int drop_mode;  // FCL_DROP_*
     const uint8_t *keep0, *keep1;  // [*, P] masks of the two layers
     float keep_scale, drop_p;

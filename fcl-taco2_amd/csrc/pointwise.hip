@@ -450,6 +450,27 @@ int fcl_pack_frag_bf16(const float* w, int rows, int cols, uint16_t* hi, uint16_
     return check_hip(hipGetLastError(), "pack_frag_bf16");
 }
 
+// Fragment-major fp32 form of W [rows, cols] for v_mfma_f32_16x16x4_f32 (the exact-fp32 feat/prenet kernel): lane (r16, kq) of (16-row tile, 32-k
+// step) holds eight floats -- W[row][32 st + 4 kq + 0..3] and W[row][32 st + 16 + 4 kq + 0..3] (the two 16-byte pieces the "lines" form of the
+// exact-mode GEMMs reads per row and step: MFMA e of a piece contracts k = 4 kq + e of all four lane groups) -- zero past rows / cols.
+__global__ void pack_frag_f32_kernel(const float* __restrict__ w, int rows, int cols, int nsteps, float* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long long ts = i >> 9;
+    const int st = (int)(ts % nsteps), tile = (int)(ts / nsteps);
+    const int row = tile * 16 + (lane & 15), k = st * 32 + (j < 4 ? 0 : 16) + 4 * (lane >> 4) + (j & 3);
+    out[i] = (row < rows && k < cols) ? w[(size_t)row * cols + k] : 0.f;
+}
+
+int fcl_pack_frag_f32(const float* w, int rows, int cols, float* out, fcl_stream_t stream) {
+    FCL_REQUIRE(w && out && rows > 0 && cols > 0, FCL_ERR_INVALID, "pack_frag_f32: bad arguments");
+    const size_t n = fcl_frag_bf16_elems(rows, cols);  // same element count: (rows / 16 tiles) x (cols / 32 steps) x 64 lanes x 8
+    hipLaunchKernelGGL(pack_frag_f32_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols, (cols + 31) / 32, out,
+                       (long long)n);
+    return check_hip(hipGetLastError(), "pack_frag_f32");
+}
+
 int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream) {
     FCL_REQUIRE(p, FCL_ERR_INVALID, "u32_add: null pointer");
     hipLaunchKernelGGL(u32_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, v);

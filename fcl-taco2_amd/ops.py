@@ -70,6 +70,14 @@ def pack_frag_bf16(w):
     return hi, lo
 
 
+def pack_frag_f32(w):
+    """Fragment-major fp32 form of a float32 matrix [rows, cols] (include/fcl_hip.h fcl_pack_frag_f32): the exact-fp32 feat/prenet kernel's operand."""
+    rows, cols = w.shape
+    out = torch.empty(_lib.load().fcl_frag_bf16_elems(rows, cols), device=w.device, dtype=torch.float32)
+    check(_lib.load().fcl_pack_frag_f32(_p(w), rows, cols, _p(out), _stream()))
+    return out
+
+
 class gemm_mode(object):
     """Context manager for the calling thread's contraction arithmetic (include/fcl_hip.h fcl_set_gemm_mode): `with ops.gemm_mode("bf16"):` runs the
     big-tile GEMMs inside on bf16-rounded operands (autocast); "f32" (default) is the fp32-equivalent bf16x3 split."""

@@ -194,6 +194,12 @@ class SynthesisPlan(object):
                     ops.check(lib.fcl_decoder_stream_pack(ctypes.byref(s), stream.data_ptr(), nbytes, ops._stream()))
                     s.stream = stream.data_ptr()
                     d.keep.append(stream)
+        if os.environ.get("FCL_PRECISION", "1") == "0" and U == 256 and P == 256 and 64 < O <= 96:
+            # exact-fp32 mode: register-resident fp32 weight fragments for the fused feat/prenet launch (csrc/decoder_step.hip feat_prenet_split_f32_kernel)
+            for k in ("wf_h", "prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh"):
+                ff = ops.pack_frag_f32(t[k])
+                setattr(s, k + "_ff", ff.data_ptr())
+                d.keep.append(ff)
         s.zoneout_rate = float(hp.zoneout_rate)
         s.prenet_dropout = float(hp.dropout_rate)
         s.out_act = output_act_code(hp)  # output_activation_fn on the fed-back frame (decoder_sa.py:614-617)

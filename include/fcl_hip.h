@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 411
+#define FCL_ABI_VERSION 412
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -86,6 +86,9 @@ int fcl_u32_add(uint32_t* p, uint32_t v, fcl_stream_t stream);
  * fcl_frag_bf16_elems() gives the plane length in uint16 elements.  Optional plan-time step for the decoder's small tiles. */
 size_t fcl_frag_bf16_elems(int rows, int cols);
 int fcl_pack_frag_bf16(const float* w, int rows, int cols, uint16_t* hi, uint16_t* lo, fcl_stream_t stream);
+/* the same fragment order in fp32 (fcl_frag_bf16_elems(rows, cols) floats): lane (r16, kq) of (16-row tile, 32-k step) holds W[row][32 st + 4 kq + 0..3]
+ * and W[row][32 st + 16 + 4 kq + 0..3] -- the operand form of the exact-fp32 (FCL_PRECISION=0) feat/prenet kernel (v_mfma_f32_16x16x4_f32) */
+int fcl_pack_frag_f32(const float* w, int rows, int cols, float* out, fcl_stream_t stream);
 
 /* ---- bf16x3 operand planes ("P32" layout) -----------------------------------------------------------------------------------------
  * The default arithmetic computes a.b as a_lo.b_hi + a_hi.b_lo + a_hi.b_hi on the bf16 MFMA pipe with fp32 accumulation, hi = bf16_rn(x),
@@ -209,6 +212,7 @@ typedef struct {
     int64_t a_chunk_stride; /* 0: Ap is row-major as above.  != 0: CHUNK-MAJOR planes of A -- line (row m, 32-column chunk c) at byte offset
                              * c * a_chunk_stride + m * 128 (lda_p unused): a tile's rows of one chunk are one contiguous stream, which is what
                              * the vocoder's sample-major activations use (DRAM-friendly: [chunk][row] instead of [row][chunk]) */
+    const float* Wff;       /* optional (round 4, exact-fp32 mode): fcl_pack_frag_f32 of W -- small LSTM steps (K = 256 per term) keep it in registers */
 } fcl_gemm_term_t;
 
 typedef struct {
@@ -276,6 +280,9 @@ typedef struct {
     const uint16_t *w0_att_p, *wf_att_p, *w0_pre_p, *w0_hh_p, *w1_ih_p, *w1_hh_p;
     int out_act;            /* FCL_ACT_*: `output_activation_fn` on the frame fed back to the prenet in the free-running loop
                              * (decoder_sa.py:614-617; `before` keeps the raw feat_out values, the caller activates the final output :635-636) */
+    const float *wf_h_ff, *prenet_w0_ff, *prenet_w1_ff; /* optional (round 4, exact-fp32 mode): fcl_pack_frag_f32 of wf_h / prenet_w0 / prenet_w1: with all
+                             * three (and U = P = 256, 64 < odim <= 96) the fused feat/prenet launch keeps its weights in registers as the bf16x3 one does */
+    const float *w0_pre_ff, *w0_hh_ff, *w1_ih_ff, *w1_hh_ff; /* ... and of the four LSTM matrices: the small steps' register-resident operands in that mode */
     const uint16_t* stream; /* optional (round 4): the step's weights in the consumption order of the persistent row-tile kernel
                              * (fcl_decoder_stream_pack; fcl_decoder_stream_bytes() bytes, 0 = shape not covered).  With it, the P32 planes above and
                              * a free-running loop of >= FCL_DEC_TILE_MIN_ROWS rows (no teacher forcing, taps or injected masks), fcl_decoder_loop_fwd
