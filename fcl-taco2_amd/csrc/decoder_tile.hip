@@ -457,6 +457,8 @@ int launch_decoder_tile(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* 
     a.t_start = t_start; a.n_start = t_start > 0 ? io->live_rows_host[t_start] : io->n; a.h0_init = h0_init; a.h1_init = h1_init;
     a.zoneout = w->zoneout_rate; a.keep_scale = 1.0f / (1.0f - w->prenet_dropout); a.drop_p = w->prenet_dropout;
     a.out_act = w->out_act; a.seed = io->seed; a.seed_dev = io->seed_dev;
+    // developer aid only (FCL_DEC_TILE_TS=1): phase stamps of workgroup 0, printed after a stream synchronisation -- not usable under graph capture
+    // and not thread-safe (one static device buffer on the device of the first call)
     static const int want_ts = tunable("DEC_TILE_TS", 0);
     static long long* ts_dev = nullptr;
     if (want_ts && !ts_dev) (void)hipMalloc(&ts_dev, 4096 * 8 * sizeof(long long));
