@@ -57,7 +57,12 @@ def quiet_stdout():
         os.dup2(2, 1)
 
 
+RANKS = []  # sharding.verify_world's per-rank records (filled in main() once the process group is up)
+
+
 def emit(obj):
+    if RANKS:
+        obj = dict(obj, ranks=list(RANKS))
     line = (json.dumps(obj) + "\n").encode()
     sys.stdout.flush()
     if _REAL_STDOUT is None:
@@ -620,7 +625,6 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
-
     import __graft_entry__ as ge
 
     ge.build() if rank == 0 and not os.path.exists(os.path.join(ROOT, "fcl-taco2_amd", "libfcl_hip.so")) else None
@@ -629,6 +633,14 @@ def main():
     import fcl_taco2_amd  # noqa: F401
     from fcl_taco2_amd import _lib, engine, hparams as HP, ops, synthetic as SYN
     from fcl_taco2_amd.plan import SynthesisPlan
+
+    # every rank: the RCCL communicator's size as seen here must be --gpus and an all-reduce of ones on the device must return it (raises
+    # otherwise); one line per rank on stderr, the gathered records on rank 0's JSON line ("ranks")
+    from fcl_taco2_amd import sharding as _sh
+
+    RANKS[:] = _sh.verify_world(dist, args.gpus, dev)
+    print("bench.py rank %d/%d on %s: communicator size %d, all-reduce of ones = %g" % (
+        rank, world, dev, RANKS[rank]["world_size_seen"], RANKS[rank]["allreduce_of_ones"]), file=sys.stderr, flush=True)
 
     if args.workload in ("tts_e2e", "vocoder"):
         out = e2e_workload(args, rank, world, dev, dist)

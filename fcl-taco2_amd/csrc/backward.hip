@@ -765,6 +765,10 @@ int fcl_gemm_tn_taps_fwd(const float* a, int lda, const float* b, int ldb, float
                 "gemm_tn_fwd: N, K, lda, ldb must be multiples of 4 and operands 16-byte aligned");
     FCL_REQUIRE((seg_lo == nullptr) == (seg_hi == nullptr), FCL_ERR_INVALID, "gemm_tn_fwd: seg_lo/seg_hi come in pairs");
     if (m == 0) return 0;
+    static const int prec0 = tunable("PRECISION", 1);
+    // bf16x3 / bf16 arithmetic: the 128 x 128 kernel with the transposition fused into its LDS reads (dw_gemm.hip) takes every shape it covers
+    if (prec0 && launch_dw_mfma(a, lda, b, ldb, c, ldc, m, n, k, shift0, ntaps, c_tap_stride, seg_lo, seg_hi, fcl::gemm_mode() == FCL_GEMM_BF16, (hipStream_t)stream))
+        return check_hip(hipGetLastError(), "gemm_tn_fwd");
     const int tiles = ((n + 63) / 64) * ((k + 63) / 64) * ntaps;
     static const int tn_wgs = tunable("TN_WORKGROUPS", 1024);
     int slices = (tn_wgs + tiles - 1) / tiles;  // ~1024 workgroups in flight, but at least 128 rows each: every slice ends in 4096 atomics per tile

@@ -209,6 +209,9 @@ int launch_pwg_layer_fused(const fcl_pwg_layer_t& a, hipStream_t s);  // one Par
 int launch_pwg_last_fused(const float* skips, float scale, const unsigned short* w1p, const float* b1, const float* w2, float b2, float* wav, long long m,
                           hipStream_t s);  // last_conv_layers in one launch (64 skip channels)
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// dw_gemm.hip: dW[n, k] += sum_m a[m, n] * b[m + shift, k] on bf16x3 MFMAs with transposing LDS reads; false = shape left to gemm_tn_kernel
+bool launch_dw_mfma(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift0, int ntaps, size_t c_tap_stride,
+                    const int32_t* seg_lo, const int32_t* seg_hi, int hi_only, hipStream_t stream);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wave-per-gate kernel (fp32 operands) rather than a big-tile kernel
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);

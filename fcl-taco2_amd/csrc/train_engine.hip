@@ -33,11 +33,16 @@ struct Arena {
     char* base = nullptr;
     size_t cap = 0, used = 0, dirty = 0;  // dirty: high-water mark of real allocations since the last clear (the zero arena's next memset)
     bool dry = false;
-    void reset() { used = 0; }
+    bool overflow = false;  // a real allocation ran past the capacity (a pass that was not sized): TE_L refuses every further launch of the pass
+    void reset() { used = 0; overflow = false; }
     void* take(size_t bytes) {
         const size_t o = (used + 255) & ~(size_t)255;
         used = o + bytes;
         if (dry) return reinterpret_cast<char*>((size_t)1 << 30) + o;  // never dereferenced: the dry run launches nothing
+        if (used > cap) {  // never hand out memory beyond the arena: the pointer stays inside it and the pass fails with FCL_ERR_WORKSPACE
+            overflow = true;
+            return base;
+        }
         if (used > dirty) dirty = used;
         return base + o;
     }
@@ -166,7 +171,7 @@ struct fcl_te {
     std::vector<void*> form_allocs;
     float* cat_f = nullptr;  // [W1_hh^T ; W1_ih^T] (fcl_decoder_bptt's w1_cat_t) and its planes
     uint16_t* cat_p = nullptr;
-    std::vector<std::array<long long, 6>> sized[2];  // per arena: (B, T, L, N, F, lmax) of batches a dry run has verified to fit it
+    std::vector<std::array<long long, 7>> sized[2];  // per arena: (B, T, L, N, F, lmax, variant) of passes a dry run has verified to fit it
     bool dry = false;
     int64_t launches = 0, last_launches = 0;
     Ctx c;
@@ -175,13 +180,15 @@ struct fcl_te {
     Param& Pm(const std::string& k) { return P.at(k); }
 };
 
-#define TE_L(expr)                            \
-    do {                                      \
-        ++E.launches;                         \
-        if (!E.dry) {                         \
-            const int rc_ = (expr);           \
-            if (rc_) return rc_;              \
-        }                                     \
+#define TE_L(expr)                                                                                                        \
+    do {                                                                                                                  \
+        ++E.launches;                                                                                                     \
+        if (!E.dry) {                                                                                                     \
+            if (E.work[E.cur_arena].overflow || E.zero[E.cur_arena].overflow)                                             \
+                FCL_REQUIRE(false, FCL_ERR_WORKSPACE, "fcl_te: the pass needs more arena memory than its sizing run found"); \
+            const int rc_ = (expr);                                                                                       \
+            if (rc_) return rc_;                                                                                          \
+        }                                                                                                                 \
     } while (0)
 #define TE_TRY(expr)                \
     do {                            \
@@ -1498,17 +1505,20 @@ static int te_check_batch(const fcl_te_batch_t* b) {
 
 // size the arenas by a dry run of `body` (no launches), grow them if needed (rare: the first steps), then clear what the previous pass used of the
 // zero arena -- ordered behind everything the weight-gradient stream still holds
+// variant: what else gates an allocation besides the six counts -- 1 = forward only (fcl_te_knowledge), 2 = the whole update, 3 = the whole update
+// fed a FRAME-major knowledge tuple (te_losses gathers three extra cell-major copies).  Each form allocates a superset of the one below it, so a
+// verified pass covers every pass with a variant and counts that are no larger (the key used to be the six counts alone).
 template <typename Body>
-static int te_run_sized(fcl_te& E, Body body) {
+static int te_run_sized(fcl_te& E, int variant, Body body) {
     Arena &W = E.work[E.cur_arena], &Z = E.zero[E.cur_arena];
     const fcl_te_batch_t& b = E.c.b;
-    const std::array<long long, 6> dims = {b.B, b.T, b.L, b.N, b.F, b.lmax};
-    std::vector<std::array<long long, 6>>& ok = E.sized[E.cur_arena];
+    const std::array<long long, 7> dims = {b.B, b.T, b.L, b.N, b.F, b.lmax, variant};
+    std::vector<std::array<long long, 7>>& ok = E.sized[E.cur_arena];
     bool fits = false;
     if (W.base != nullptr && Z.base != nullptr)
         for (const auto& v : ok) {
             bool le = true;
-            for (int i = 0; i < 6; ++i) le = le && dims[i] <= v[i];
+            for (int i = 0; i < 7; ++i) le = le && dims[i] <= v[i];
             fits = fits || le;
         }
     if (!fits) {  // every allocation of a pass is a product of these six counts and configuration constants: a batch that is no larger in any
@@ -1578,7 +1588,7 @@ int fcl_te_knowledge(fcl_te_t* Ep, const fcl_te_batch_t* batch, uint32_t draw, f
     E.c.draw = draw;
     const int64_t l0 = E.launches;
     // the frozen teacher enqueues nothing on its weight-gradient stream: nothing to order the clear behind
-    TE_TRY(te_run_sized(E, [&]() { return te_forward(E); }));
+    TE_TRY(te_run_sized(E, 1, [&]() { return te_forward(E); }));
     TE_TRY(te_clear_zero(E));
     TE_TRY(te_forward(E));
     Ctx& c = E.c;
@@ -1626,7 +1636,7 @@ int fcl_te_forward_backward(fcl_te_t* Ep, const fcl_te_batch_t* batch, const fcl
         TE_TRY(te_backward_stage3(E));
         return 0;
     };
-    TE_TRY(te_run_sized(E, whole));
+    TE_TRY(te_run_sized(E, (kp && !kp->dec_cell_major) ? 3 : 2, whole));
     // the arena's clear must not depend on the previous step having ended with its join: order this step behind everything the weight-gradient
     // stream still holds, then clear what the previous step used of the zero arena (one launch for every accumulation target of the step)
     TE_TRY(ev_wait(E, E.main, E.side));

@@ -39,3 +39,25 @@ def gather_frame_counts(local_counts, dist=None):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, list(map(int, local_counts)))
     return out
+
+
+def verify_world(dist, expected, device="cpu"):
+    """Proof that an N-rank job really is N ranks on one communicator (bench.py --gpus N; VERDICT r4 #7a): every rank checks the communicator size it
+    sees, an all-reduce of ones must return N on the device, and every rank's (rank, world size seen, device) record is gathered on all ranks.
+    Raises on any rank that sees something else; returns the gathered records (rank 0 prints them on the bench line)."""
+    import torch
+
+    if dist is None or not dist.is_initialized():
+        if expected != 1:
+            raise RuntimeError("verify_world: %d ranks expected but no process group is initialised" % expected)
+        return [{"rank": 0, "world_size_seen": 1, "device": str(device), "allreduce_of_ones": 1.0}]
+    seen = dist.get_world_size()
+    ones = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    rec = {"rank": dist.get_rank(), "world_size_seen": seen, "device": str(device), "allreduce_of_ones": float(ones.item())}
+    out = [None] * seen
+    dist.all_gather_object(out, rec)
+    bad = [r for r in out if r["world_size_seen"] != expected or r["allreduce_of_ones"] != float(expected)]
+    if seen != expected or bad or sorted(r["rank"] for r in out) != list(range(expected)):
+        raise RuntimeError("verify_world: expected %d ranks, gathered %r" % (expected, out))
+    return out

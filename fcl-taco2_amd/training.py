@@ -791,6 +791,48 @@ class TrainEngine(object):
         seeds = [self.seed * 7919 + c.draw * 104729 + (zlib.crc32(repr(name).encode()) & 0x7FFFFFFF) for name, _, _ in sites]
         return ops.bernoulli_batch([(shape, p, sd) for (_, shape, p), sd in zip(sites, seeds)], self.dev)
 
+    def device_masks(self, batch, draw=None):
+        """Every Bernoulli draw of the train-mode forward with ordinal `draw` (default: the last one) as host {0,1} arrays in the dictionary layout
+        of injected masks (`masks=` here, oracle.masks_from_sequence): the device draws are a pure function of (engine seed, forward ordinal, site
+        tag), so what the native / per-launch step used can be replayed into an independent implementation (tests: the native step vs the oracle)."""
+        hp, dev = self.hp, self.dev
+        c = _Ctx()
+        c.masks, c.draw = None, self.forward_count if draw is None else int(draw)
+        self._maps(c, batch)
+        B, T, L, N, F, lmax = c.B, c.T, c.L, c.N, c.F, c.lmax
+        C = hp.adim
+        host = lambda t: t.cpu().numpy()
+        bt = lambda sites: [host(m).reshape(B, -1, m.shape[-1]) for m in self._keeps(c, sites)]
+        out = {"enc.convs": None, "postnet": None, "prenet": None}
+        with torch.cuda.device(dev):
+            if hp.dropout_rate > 0:
+                out["enc.convs"] = bt([(("enc.convs", i), (B * T, hp.econv_chans), 1.0 - hp.dropout_rate) for i in range(hp.econv_layers)])
+                n_post = hp.postnet_layers
+                out["postnet"] = bt([(("postnet", i), (B * L, hp.odim if i == n_post - 1 else hp.postnet_chans), 1.0 - hp.dropout_rate) for i in range(n_post)])
+            for nm, layers, chans, pd_ in (("duration_predictor", hp.duration_predictor_layers, hp.duration_predictor_chans, hp.duration_predictor_dropout_rate),
+                                           ("pitch_predictor", hp.variance_predictor_layers, hp.variance_predictor_chans, hp.variance_predictor_dropout_rate),
+                                           ("energy_predictor", hp.variance_predictor_layers, hp.variance_predictor_chans, hp.variance_predictor_dropout_rate)):
+                out[nm] = bt([((nm, i), (B * T, chans), 1.0 - pd_) for i in range(layers)]) if pd_ > 0 else [np.ones((B, T, chans), np.uint8)] * layers
+            p_emb = hp.variance_embed_dropout_rate
+            for nm in ("pitch_embed", "energy_embed"):
+                out[nm] = bt([((nm,), (B * T, C), 1.0 - p_emb)])[0] if p_emb > 0 else np.ones((B, T, C), np.uint8)
+
+            def rows(cells):  # step-major cells [F, X] of the duration-sorted rows -> [lmax, N (the converter's row order), X]; cells no row reaches: 1
+                cells = host(cells)
+                full = np.ones((lmax, N, cells.shape[-1]), np.uint8)
+                for t in range(lmax):
+                    full[t, c.order[: c.live[t]]] = cells[c.offs[t] : c.offs[t + 1]]
+                return full
+
+            if hp.dropout_rate > 0:
+                k0, k1 = self._keeps(c, [(("prenet", l), (F, hp.prenet_units), 1.0 - hp.dropout_rate) for l in range(2)])
+                out["prenet"] = np.stack([rows(k0), rows(k1)], 1)
+            zr = float(hp.zoneout_rate)
+            if zr > 0:
+                zk = self._keeps(c, [(("zoneout", l, j), (F, hp.dunits), zr) for l in range(2) for j in range(2)])
+                out["zoneout"] = np.stack([np.stack([rows(zk[2 * l + j]) for j in range(2)], 1) for l in range(2)], 1)
+        return out
+
     # ------------------------------------------------------------------------------------------------ layers
     def _wt(self, w):
         rec = self._recipe_of(w)

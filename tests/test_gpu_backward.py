@@ -260,3 +260,72 @@ def test_bilstm_group_kernel_more_workgroups_than_cus(ops):
     ref = ops.bilstm(x, lens, *a, B, T, 1)
     out = ops.bilstm(x, lens, *a, B, T, 3)
     assert max_abs(out.cpu(), ref.cpu()) < 1e-5
+
+
+# ---- round 5: the weight-gradient GEMM with the transposition fused into its LDS reads (csrc/dw_gemm.hip, `ds_read_b64_tr_b16`) -----------------
+def _dw_on_path(ops_mod):
+    """True when fcl_gemm_tn_* dispatches to dw_mfma_kernel (bf16x3 / bf16 arithmetic; FCL_PRECISION=0 keeps the exact-fp32 kernel)."""
+    return ops_mod.planes_enabled()
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 32, 32), (300, 128, 128), (2501, 256, 256), (4999, 80, 256), (3333, 256, 80), (1030, 384, 36), (20000, 1024, 256),
+                                   (513, 132, 260)])
+def test_dw_mfma_linear_weight_grad(ops, m, n, k):
+    """dW = dY^T X against float64: ragged N / K (not multiples of the 128-wide tile, of 16, of 32), contraction lengths that are not multiples of
+    the 32-row chunk or of the slice, a strided output block whose neighbours must stay untouched, accumulation into a non-zero gradient."""
+    from fcl_taco2_amd import _lib
+
+    rng = np.random.RandomState(m + n + k)
+    dy, x = rnd(rng, m, n), rnd(rng, m, k)
+    ref = dy.astype(np.float64).T @ x.astype(np.float64)
+    base = dev(rnd(rng, n, k + 8))
+    out = base.clone()
+    _lib.prof_enable(True)
+    ops.gemm_tn(dev(dy), dev(x), out[:, 4 : 4 + k])
+    torch.cuda.synchronize()
+    prof = _lib.prof_collect()
+    _lib.prof_enable(False)
+    if _dw_on_path(ops):
+        assert any(name.startswith("dw_mfma_kernel") for name in prof), sorted(prof)
+    scale = float(np.abs(ref).max())
+    assert max_abs((out[:, 4 : 4 + k] - base[:, 4 : 4 + k]).cpu().double(), ref) < 3e-5 * scale
+    assert torch.equal(out[:, :4], base[:, :4]) and torch.equal(out[:, 4 + k :], base[:, 4 + k :])
+    ops.gemm_tn(dev(dy), dev(x), out[:, 4 : 4 + k])  # accumulates
+    assert max_abs((out[:, 4 : 4 + k] - base[:, 4 : 4 + k]).cpu().double(), 2 * ref) < 6e-5 * scale
+
+
+@pytest.mark.parametrize("cin,cout,ksz", [(80, 128, 5), (256, 384, 3), (128, 80, 5)])
+def test_dw_mfma_conv_taps_vs_autograd(ops, cin, cout, ksz):
+    """All taps of a Conv1d weight gradient in one launch (fcl_gemm_tn_taps_fwd): shifted rows, zero outside each utterance's segment --
+    segments of 1, 3, 31, 32, 33 and a few hundred rows, so chunk and slice boundaries fall inside and between segments."""
+    rng = np.random.RandomState(cin + ksz)
+    seg_lens = [3, 1, 350, 31, 32, 33, 129, 500, 2]
+    M = sum(seg_lens)
+    starts = np.cumsum([0] + seg_lens[:-1])
+    lo = np.repeat(starts, seg_lens).astype(np.int32)
+    hi = (lo + np.repeat(seg_lens, seg_lens)).astype(np.int32)
+    x = torch.from_numpy(rnd(rng, M, cin)).requires_grad_(True)
+    w = torch.from_numpy((rnd(rng, cout, cin, ksz) / np.sqrt(cin * ksz)).astype(np.float32)).requires_grad_(True)
+    dy = torch.from_numpy(rnd(rng, M, cout))
+    y = torch.cat([F.conv1d(x[s : s + n].t().unsqueeze(0).double(), w.double(), None, 1, (ksz - 1) // 2)[0].t() for s, n in zip(starts, seg_lens)])
+    (y * dy.double()).sum().backward()
+    dwp = torch.zeros(ksz, cout, cin, device=DEV)
+    ops.gemm_tn_taps(dev(dy), dev(x.detach()), dwp, -((ksz - 1) // 2), seg_lo=dev(lo), seg_hi=dev(hi))
+    ref = w.grad.permute(2, 0, 1)
+    assert max_abs(dwp.cpu(), ref) < 3e-5 * float(ref.abs().max())
+
+
+def test_dw_mfma_bf16_mode_rounds_operands_once(ops):
+    """fcl_set_gemm_mode(BF16) (the --use-amp recipe): the product of the bf16-ROUNDED operands, accumulated in fp32."""
+    if not _dw_on_path(ops):
+        pytest.skip("FCL_PRECISION=0: no bf16 mode")
+    rng = np.random.RandomState(5)
+    m, n, k = 3000, 256, 128
+    dy, x = dev(rnd(rng, m, n)), dev(rnd(rng, m, k))
+    out = torch.zeros(n, k, device=DEV)
+    with ops.gemm_mode("bf16"):
+        ops.gemm_tn(dy, x, out)
+    ref = dy.bfloat16().double().t() @ x.bfloat16().double()
+    assert max_abs(out.double(), ref) < 3e-5 * float(ref.abs().max())
+    exact = dy.double().t() @ x.double()
+    assert float((out.double() - exact).abs().max()) > 1e-3  # the rounding is visible

@@ -279,3 +279,119 @@ def test_bf16_step_against_the_oracle_under_torch_autocast():
     for k in LOSS_KEYS:
         ref = float(o64[k])
         assert abs(rep[k] - ref) < max(5e-3 * max(1.0, abs(ref)), 2.0 * abs(float(oac[k]) - ref)), (k, rep[k], ref, float(oac[k]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# Round 5 (VERDICT r4 weak #1a): the NATIVE step -- the path bench.py's kd_step / teacher_step legs time -- against the oracle DIRECTLY, at the sizes
+# the bench times.  The native routine draws its masks on the device from (engine seed, forward ordinal, site tag); TrainEngine.device_masks replays
+# exactly those draws to the host in the injected-mask layout, the oracle's float64 autograd consumes them.  No per-launch HIP engine in the chain.
+def _native_or_skip(eng):
+    if eng.native is None:
+        pytest.skip("native step unavailable here: %s" % eng.native_reason)
+
+
+def test_native_teacher_update_at_configs3_size_vs_oracle_autograd():
+    """BASELINE configs[3] through fcl_te_forward_backward (mode='train', device RNG): named losses, every gradient tensor, BatchNorm buffers and
+    one Adam update (tts.py:160-182) against oracle + torch.optim.Adam in float64."""
+    from fcl_taco2_amd import hparams as HP, synthetic as SYN
+    from fcl_taco2_amd.training import TrainEngine
+
+    _threads()
+    T = HP.teacher_hparams()
+    batch = _batch(16, 41, T.idim)
+    model = SYN.build_model("teacher", T, None, DEV, weights="init", seed=1)
+    sd = _grad_sd(model)
+    bufs0 = {k: v.clone() for k, v in sd.items() if "running" in k}
+    eng = TrainEngine(model, lr=1e-3, eps=1e-6, grad_clip=1.0, seed=17)
+    _native_or_skip(eng)
+    w0 = eng.pflat.clone()
+    eng.zero_grad()
+    rep = eng.forward_backward(batch, mode="train")
+    assert eng.native.launches() > 0  # the C++ routine issued this step
+    masks = eng.device_masks(batch)
+    orep = O.model_forward(sd, T, _cpu64(batch), "teacher", bn_train=True, masks=masks)
+    orep["loss"].backward()
+    for k in LOSS_KEYS:
+        assert abs(rep[k] - float(orep[k])) < 1e-4 * max(1.0, abs(float(orep[k]))), (k, rep[k], float(orep[k]))
+    worst = _compare_grads(eng, sd)
+    print("native configs[3]: worst gradient error max-abs %.2e / L2 %.2e over %d tensors" % (worst[0], worst[1], len(eng.G)))
+    msd = model.state_dict()
+    xs = _cpu(batch)["xs"][:, : int(max(batch["ilens"]))]
+    emb = torch.nn.functional.embedding(xs, sd["enc.embed.weight"].detach(), padding_idx=0).transpose(1, 2)
+    for name, x in (("enc.convs.0", emb), ("dec.postnet.postnet.0", orep["_before"].detach().transpose(1, 2))):
+        m_exp, v_exp = _bn_buffers_expected(x, sd[name + ".0.weight"].detach(), bufs0[name + ".1.running_mean"], bufs0[name + ".1.running_var"])
+        assert max_abs(msd[name + ".1.running_mean"].cpu().double(), m_exp) < 1e-4 * max(1.0, float(m_exp.abs().max())), name
+        assert max_abs(msd[name + ".1.running_var"].cpu().double(), v_exp) < 1e-4 * max(1.0, float(v_exp.abs().max())), name
+    # one Adam update from these gradients
+    params = [v for v in sd.values() if v.dtype.is_floating_point and v.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    opt = torch.optim.Adam(params, lr=1e-3, eps=1e-6)
+    gn = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+    opt.step()
+    eng.optimizer_step()
+    assert abs(eng.grad_norm() - gn) < 5e-3 * gn, (eng.grad_norm(), gn)
+    assert eng.step_count == 1
+    assert 0 < float((eng.pflat - w0).abs().max()) <= 1e-3 * (1 + 1e-4)
+    diffs = [(eng.P[k].cpu().double() - v.detach()).abs() for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad]
+    assert max(float(d.max()) for d in diffs) <= 2e-3 * (1 + 1e-4)
+    assert sum(float(d.sum()) for d in diffs) / sum(d.numel() for d in diffs) < 1e-4
+
+
+def test_native_kd_update_at_configs2_size_vs_oracle_autograd():
+    """BASELINE configs[2] exactly as bench.py's kd_step runs it: the frozen train-mode FCL-taco2-T through fcl_te_knowledge (cell-major
+    NativeKnowledge), the student through fcl_te_forward_backward, both with device RNG; the oracle gets both engines' replayed draws and runs
+    teacher -> student KD loss -> float64 autograd.  Named losses (incl. the four distillation groups), every gradient tensor incl. the eight
+    projections, the student's BatchNorm buffers, one Adam update."""
+    from fcl_taco2_amd import hparams as HP, synthetic as SYN
+    from fcl_taco2_amd.training import NativeKnowledge, TrainEngine
+
+    _threads()
+    S, T = HP.student_hparams(), HP.teacher_hparams()
+    batch = _batch(32, 43, S.idim)
+    b_cpu = _cpu64(batch)
+    teacher = SYN.build_model("kd_teacher", T, None, DEV, weights="init", seed=2)
+    tsd = {k: (v.detach().cpu().double() if v.dtype.is_floating_point else v.detach().cpu().clone()) for k, v in teacher.state_dict().items()}
+    student = SYN.build_model("student", S, T, DEV, weights="init", seed=3)
+    sd = _grad_sd(student)
+    bufs0 = {k: v.clone() for k, v in sd.items() if "running" in k}
+    teng, eng = TrainEngine(teacher, seed=19), TrainEngine(student, lr=1e-3, eps=1e-6, grad_clip=1.0, seed=23)
+    _native_or_skip(teng)
+    _native_or_skip(eng)
+    know = teng.knowledge(batch, mode="train", native=True)
+    assert isinstance(know, NativeKnowledge)
+    tm = teng.device_masks(batch)
+    w0 = eng.pflat.clone()
+    eng.zero_grad()
+    rep = eng.forward_backward(batch, teacher_knowledge=know, mode="train")
+    assert eng.native.launches() > 0
+    sm = eng.device_masks(batch)
+    with torch.no_grad():
+        oknow = O.model_forward(tsd, T, b_cpu, "kd_teacher", bn_train=True, masks=tm)
+    orep = O.model_forward(sd, S, b_cpu, "student", T, True, oknow, bn_train=True, masks=sm)
+    orep["loss"].backward()
+    for k in KD_KEYS:
+        assert abs(rep[k] - float(orep[k])) < 1e-4 * max(1.0, abs(float(orep[k]))), (k, rep[k], float(orep[k]))
+    worst = _compare_grads(eng, sd)
+    print("native configs[2]: worst gradient error max-abs %.2e / L2 %.2e over %d tensors" % (worst[0], worst[1], len(eng.G)))
+    msd = student.state_dict()
+    xs = _cpu(batch)["xs"][:, : int(max(batch["ilens"]))]
+    emb = torch.nn.functional.embedding(xs, sd["enc.embed.weight"].detach(), padding_idx=0).transpose(1, 2)
+    name = "enc.convs.0"
+    m_exp, v_exp = _bn_buffers_expected(emb, sd[name + ".0.weight"].detach(), bufs0[name + ".1.running_mean"], bufs0[name + ".1.running_var"])
+    assert max_abs(msd[name + ".1.running_mean"].cpu().double(), m_exp) < 1e-4 * max(1.0, float(m_exp.abs().max()))
+    assert max_abs(msd[name + ".1.running_var"].cpu().double(), v_exp) < 1e-4 * max(1.0, float(v_exp.abs().max()))
+    params = [v for v in sd.values() if v.dtype.is_floating_point and v.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    opt = torch.optim.Adam(params, lr=1e-3, eps=1e-6)
+    gn = float(torch.nn.utils.clip_grad_norm_(params, 1.0))
+    opt.step()
+    eng.optimizer_step()
+    assert abs(eng.grad_norm() - gn) < 5e-3 * gn, (eng.grad_norm(), gn)
+    assert 0 < float((eng.pflat - w0).abs().max()) <= 1e-3 * (1 + 1e-4)
+    diffs = [(eng.P[k].cpu().double() - v.detach()).abs() for k, v in sd.items() if v.dtype.is_floating_point and v.requires_grad]
+    assert max(float(d.max()) for d in diffs) <= 2e-3 * (1 + 1e-4)
+    assert sum(float(d.sum()) for d in diffs) / sum(d.numel() for d in diffs) < 1e-4

@@ -32,7 +32,13 @@ def _worker(rank, world, port, q):
     local_frames = sum(frames[i] for i in mine)
     t, f = sharding.aggregate_throughput(1.0 + rank, local_frames, dist)
     counts = sharding.gather_frame_counts([frames[i] for i in mine], dist)
-    q.put((rank, mine, t, f, counts))
+    recs = sharding.verify_world(dist, world)  # bench.py --gpus N: every rank proves the communicator holds N ranks
+    wrong = False
+    try:
+        sharding.verify_world(dist, world + 1)  # a job that believes it is larger than its communicator must be loud on every rank
+    except RuntimeError:
+        wrong = True
+    q.put((rank, mine, t, f, counts, recs, wrong))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,7 +59,10 @@ def test_two_rank_gloo_reduction():
         assert p.exitcode == 0
     xs, ds = SYN.batch_c2(batch=8, seed=5)
     total = sum(int(d.sum()) for d in ds)
-    (r0, m0, t0, f0, c0), (r1, m1, t1, f1, c1) = res
+    (r0, m0, t0, f0, c0, v0, w0), (r1, m1, t1, f1, c1, v1, w1) = res
+    assert w0 and w1 and v0 == v1 and [r["rank"] for r in v0] == [0, 1]
+    assert all(r["world_size_seen"] == 2 and r["allreduce_of_ones"] == 2.0 for r in v0)
+    assert sharding.verify_world(None, 1)[0]["world_size_seen"] == 1  # single process: no group needed
     assert sorted(m0 + m1) == list(range(8)) and not set(m0) & set(m1)
     assert t0 == t1 == 2.0  # MAX over ranks
     assert f0 == f1 == float(total)  # SUM over ranks
