@@ -497,200 +497,8 @@ __global__ __launch_bounds__(512) void feat_prenet_x3_kernel(const FeatPrenetArg
     }
 }
 
-// ---- the same chain, specialised and straightened for the shapes that fit registers (U = 32 SU, P = 32 SP <= 256, O <= 32 SO): every weight
-// fragment, bias, hoisted operand and (mask mode) keep byte is REQUESTED at kernel entry or one phase ahead, the three MFMA chains are
-// branch-free (LDS tiles are zero-padded to whole 32-k steps), the dropout mode is a template argument, and the two inner barriers are LDS-only
-// (lds_barrier) so the fragment loads of the next phase stay in flight across them.  The generic kernel above had a conditional global load +
-// s_waitcnt vmcnt(0) in every epilogue, which drained the 32 in-flight fragment loads of the next layer: +3.3 us per layer on a ~5 us kernel.
-// RT = 16-row tiles a workgroup carries through every phase TOGETHER: each weight fragment set is fetched once (426 KB from L2 per workgroup) and
-// drives RT MFMA chains before it dies, so per row the L2 traffic and -- with several passes in flight, what bounds the throughput -- the
-// kernel's CU-time fall by RT (the fragment registers cannot stay resident ACROSS tiles: 240 VGPRs for the three sets).
-template <int SU, int SO, int SP, int DROP, int RT>
-__global__ __launch_bounds__(512) void feat_prenet_fast_kernel(const FeatPrenetArgs a) {
-    // rows of this launch: the host's counts, or -- device-driven loop -- the smaller of the host's bounds and the device's live counts
-    // device-driven loops: LOADS and the MFMA chains use the host's row bounds (rows between the device count and the bound hold stale but finite state);
-    // only the STORES are limited to the device's live-row counts -- their scalar loads are then off the kernel's critical path (first use: an epilogue)
-    const int M_feat = a.M_feat, M_pre = a.M_pre;
-    const int Ms_feat = (a.live && a.t_prev >= 0) ? min(a.M_feat, a.live[a.t_prev]) : a.M_feat, Ms_pre = a.live ? min(a.M_pre, a.live[a.t_cur]) : a.M_pre;
-    if (a.live && a.w0 && blockIdx.x == 0 && threadIdx.x == 0 && a.live[a.t_cur] > a.M_pre) atomicOr(a.status, (unsigned int)FCL_STATUS_ROWS_CAP);
-    if ((int)blockIdx.x * (16 * RT) >= (a.h1 ? Ms_feat : Ms_pre)) return;  // tile beyond the device's live rows (uniform per workgroup, before any barrier)
-    constexpr int U = SU * 32, OP = SO * 32, P = SP * 32;
-    // row strides of 34 / 14 / 34 sixteen-byte slots: = 2 (mod 4) makes every ds_read_b128 lane group (8 rows at k-piece a + 8 rows at piece a + 1)
-    // hit 16 distinct slots; the + 8 padding of rounds 1-2 (33 / 13 slots) cost 1 - 5 extra LDS cycles per 4 (r3 PMC: 39 % of this kernel's LDS cycles)
-    constexpr int ldU = U + 16, ldO = OP + 16, ldP = P + 16, ROWS = 16 * RT;
-    static_assert(2 * SP <= 16, "two prenet column tiles per wave, 8 waves");
-    extern __shared__ __attribute__((aligned(16))) u16 fp_lds[];
-    u16* A1h = fp_lds;
-    u16* A1l = A1h + ROWS * ldU;
-    u16* A2h = A1l + ROWS * ldU;
-    u16* A2l = A2h + ROWS * ldO;
-    u16* A3h = A2l + ROWS * ldO;
-    u16* A3l = A3h + ROWS * ldP;
-    const int O = a.O;
-    const int m0 = blockIdx.x * ROWS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int col = lane & 15, rq = lane >> 4;
-    const bool has_feat = a.h1 != nullptr, has_pre = a.w0 != nullptr && m0 < M_pre;
-    const bool feat_wave = has_feat && wave * 16 < O;
-    const size_t lane8 = (size_t)lane * 8;
-    auto frag = [&](const u16* base, int tile, int ns) { return base + (size_t)tile * ns * 512 + lane8; };
-    const int t0 = wave, t1 = wave + 8;  // this wave's prenet column tiles
-
-    // ---- everything the epilogues need, requested now ---------------------------------------------------------------------------
-    unsigned int seed0 = 0, seed1 = 0;
-    if (DROP == 2) {
-        const unsigned int sbump = a.seed_dev ? *a.seed_dev * 0x9E3779B9u : 0u;
-        seed0 = hash_u32(a.seed0 + sbump);
-        seed1 = hash_u32(a.seed1 + sbump);
-    }
-    float pb0[2] = {0.f, 0.f}, pb1[2] = {0.f, 0.f};
-    uint8_t k0[RT][2][4], k1[RT][2][4];
-    if (has_pre) {
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int nc = (tt ? t1 : t0) * 16 + col;
-            pb0[tt] = a.b0[nc];
-            pb1[tt] = a.b1[nc];
-            if (DROP == 1) {
-#pragma unroll
-                for (int q = 0; q < RT; ++q)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int mc = min(m0 + q * 16 + rq * 4 + r, M_pre - 1);
-                        k0[q][tt][r] = a.keep0[(size_t)mc * P + nc];
-                        k1[q][tt][r] = a.keep1[(size_t)mc * P + nc];
-                    }
-            }
-        }
-    }
-    float f0v[RT][4];
-    int fo[RT][4];
-    const int fnc = wave * 16 + col;
-#pragma unroll
-    for (int q = 0; q < RT; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            f0v[q][r] = 0.f;
-            fo[q][r] = 0;
-            if (feat_wave) {
-                const int mc = min(m0 + q * 16 + rq * 4 + r, M_feat - 1);
-                f0v[q][r] = a.F0[(size_t)mc * O + min(fnc, O - 1)];
-                fo[q][r] = a.frame_off[mc];
-            }
-        }
-    WFrag<1, SU> ff;
-    WFrag<2, SO> f0;
-    WFrag<2, SP> f1;
-    if (feat_wave) {
-        const u16* const wh[1] = {frag(a.wf_hi, wave, SU)};
-        const u16* const wl[1] = {frag(a.wf_lo, wave, SU)};
-        ff.load(wh, wl);
-    }
-    if (has_pre) {
-        const u16* const wh0[2] = {frag(a.w0_hi, t0, SO), frag(a.w0_hi, t1, SO)};
-        const u16* const wl0[2] = {frag(a.w0_lo, t0, SO), frag(a.w0_lo, t1, SO)};
-        f0.load(wh0, wl0);
-    }
-    // ---- phase 0: h1 tiles -> LDS planes; prenet-input tiles zeroed (prev_out = 0 at t = 0; zero padding past O otherwise) ------------------
-    for (int i = threadIdx.x; i < ROWS * ldO; i += blockDim.x) { A2h[i] = 0; A2l[i] = 0; }
-    if (has_feat) {
-#pragma unroll
-        for (int q = 0; q < RT; ++q) load_rowtile_split(A1h + q * 16 * ldU, A1l + q * 16 * ldU, ldU, a.h1, U, U, m0 + q * 16, M_feat);
-    }
-    __syncthreads();
-    if (a.dbg_phase == 1) return;
-    // ---- phase 1: H8 feat_out of the previous step (+ H10 scatter) ---------------------------------------------------------------------
-    if (feat_wave) {
-#pragma unroll
-        for (int q = 0; q < RT; ++q) {
-            f32x4 accv[1];
-            ff.template mma<false>(A1h + q * 16 * ldU, A1l + q * 16 * ldU, ldU, U, r16, kq, accv);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = q * 16 + rq * 4 + r, m = m0 + row;
-                if (fnc < O) {
-                    float v = 0.f;
-                    if (m < Ms_feat) {
-                        v = accv[0][r] + f0v[q][r];
-                        a.before[(size_t)(fo[q][r] + a.t_prev) * O + fnc] = v;
-                        if (a.before_p) store_p32(a.before_p, (O + 31) >> 5, fo[q][r] + a.t_prev, fnc, v);
-                    }
-                    split1((a.out_act && m < Ms_feat) ? act_apply(v, a.out_act) : v, A2h[row * ldO + fnc], A2l[row * ldO + fnc]);
-                }
-            }
-        }
-    }
-    if (has_feat && a.before_p && (O & 31)) {  // zero padding of the last 32-column line of this tile's frames
-        const int padc = 32 - (O & 31);
-        for (int i = threadIdx.x; i < ROWS * padc; i += blockDim.x) {
-            const int m = m0 + i / padc;
-            if (m < Ms_feat) store_p32(a.before_p, (O + 31) >> 5, a.frame_off[m] + a.t_prev, O + i % padc, 0.f);
-        }
-    }
-    if (!has_pre || a.dbg_phase == 2) return;
-    {   // layer-1 fragments: in flight across the next two phases
-        const u16* const wh1[2] = {frag(a.w1_hi, t0, SP), frag(a.w1_hi, t1, SP)};
-        const u16* const wl1[2] = {frag(a.w1_lo, t0, SP), frag(a.w1_lo, t1, SP)};
-        f1.load(wh1, wl1);
-    }
-    lds_barrier();
-    if (a.teacher_in) {  // teacher forcing: prenet input is y_{t-1}, not the decoder's own output
-#pragma unroll
-        for (int q = 0; q < RT; ++q) load_rowtile_split(A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, a.teacher_in, a.teacher_ld, O, m0 + q * 16, M_pre);
-        __syncthreads();
-    }
-    // ---- phase 2: H6 prenet layer 0 ---------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-        f32x4 accv[2];
-        f0.template mma<false>(A2h + q * 16 * ldO, A2l + q * 16 * ldO, ldO, OP, r16, kq, accv);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int nc = (tt ? t1 : t0) * 16 + col;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = q * 16 + rq * 4 + r, m = m0 + row;
-                float v = fmaxf(accv[tt][r] + pb0[tt], 0.f);
-                if (DROP == 1) v = k0[q][tt][r] ? v * a.keep_scale : 0.f;
-                if (DROP == 2) {
-                    const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)P + (unsigned int)nc) ^ seed0);
-                    v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
-                }
-                split1(v, A3h[row * ldP + nc], A3l[row * ldP + nc]);
-            }
-        }
-    }
-    lds_barrier();
-    if (a.dbg_phase == 3) return;
-    // ---- phase 3: H6 prenet layer 1 -> global (+ KD tap, + P32 planes) ------------------------------------------------------------------------
-#pragma unroll
-    for (int q = 0; q < RT; ++q) {
-        f32x4 accv[2];
-        f1.template mma<false>(A3h + q * 16 * ldP, A3l + q * 16 * ldP, ldP, P, r16, kq, accv);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int nc = (tt ? t1 : t0) * 16 + col;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + q * 16 + rq * 4 + r;
-                if (m >= Ms_pre) continue;
-                float v = fmaxf(accv[tt][r] + pb1[tt], 0.f);
-                if (DROP == 1) v = k1[q][tt][r] ? v * a.keep_scale : 0.f;
-                if (DROP == 2) {
-                    const unsigned int h = hash_u32(((unsigned int)m * (unsigned int)P + (unsigned int)nc) ^ seed1);
-                    v = ((h >> 8) * (1.0f / 16777216.0f) >= a.drop_p) ? v * a.keep_scale : 0.f;
-                }
-                if (a.pre_out) a.pre_out[(size_t)m * P + nc] = v;
-                if (a.pre_out_p) store_p32(a.pre_out_p, SP, m, nc, v);
-                if (a.tap_prenet) a.tap_prenet[(size_t)(a.frame_off[m] + a.t_cur) * P + nc] = v;
-            }
-        }
-    }
-}
-
 // ---- round 4: the same chain with TRANSPOSED accumulators and (optionally) prenet layer 1's columns split over NS workgroups per row tile.
-// Where feat_prenet_fast_kernel's 14 us go (r4 phase stamps, 2 400 rows: launch floor 3.6, feat_out +2.5..3.4, layer 0 +3.0..3.5, layer 1 +3.6..3.9):
+// Where the round-3 kernel's (feat_prenet_fast_kernel, deleted in round 5) 14 us went (r4 phase stamps, 2 400 rows: launch floor 3.6, feat_out +2.5..3.4, layer 0 +3.0..3.5, layer 1 +3.6..3.9):
 // not into the weight stream alone -- a first column-split form that only cut the fragments per workgroup from 442 to 245 KB ran exactly as long --
 // but into the per-ELEMENT epilogues.  With the activations as the MFMA's A operand a lane ends up with ONE column of FOUR rows: every finished
 // element then costs its own bias / mask load, its own counter hash, its own fp32 -> (hi, lo) split, two 2-byte LDS stores and up to five scattered
@@ -1314,157 +1122,6 @@ __global__ __launch_bounds__(256) void lstm_small_pair_kernel(const LstmStepArgs
     else lstm_small_body(a1);
 }
 
-// ---- weights-stationary LSTM step (U <= 256-class models: the 64 x Kt weight slice of 16 units lives in LDS) ----
-// grid = (U/16 unit slices) x (R row groups) ~ 256 workgroups = one per CU; 4 waves split K in quarters, so a
-// workgroup's work is balanced to the MFMA instead of quantised in 64-row tiles.  Wave q loads ITS K-quarter of the
-// slice into LDS itself and only ever reads that quarter back, so the weight fill needs no workgroup barrier; A
-// fragments stream from L2 straight into registers one row tile ahead; the 4 partial sums meet in LDS.
-constexpr int WRES_KT = 512;
-constexpr int WRES_LD = WRES_KT + 4;  // row stride = 2064 B = 16 (mod 256): conflict-free ds_read_b128 across 16 rows
-
-template <int MODE>
-__global__ __launch_bounds__(256) void lstm_wres_kernel(const LstmStepArgs a, int rows_per_group) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* W_l = smem;                   // [64][WRES_LD]
-    float* red = smem + 64 * WRES_LD;    // [4 waves][4 gates][16 rows][16 units]
-    constexpr int KQ = WRES_KT / 4;      // 128 k per wave
-    constexpr int NJ = KQ / 16;          // 8 float4 A fragments per lane per row tile
-    const int u0 = blockIdx.x * 16;
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-    // which source term this wave's K-quarter lives in (terms are quarter-aligned; checked by the launcher)
-    const int kbase = q * KQ;
-    const int t = kbase < a.term[0].K ? 0 : 1;
-    const GemmTerm T = a.term[t];
-    const int koff = kbase - (t ? a.term[0].K : 0);
-
-    // ---- fill this wave's quarter of the weight slice: 64 rows x 128 k, 16 loads in flight per lane ------
-    {
-        const int c4 = (lane & 31) * 4, rsub = lane >> 5;  // 32 lanes cover 128 k of a row; 2 rows per pass
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 tmp[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = half * 32 + i * 2 + rsub;
-                const int g = r >> 4, u = u0 + (r & 15);
-                tmp[i] = *reinterpret_cast<const f32x4*>(T.W + (size_t)(g * a.U + u) * T.ldw + koff + c4);  // U % 16 == 0
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int r = half * 32 + i * 2 + rsub;
-                *reinterpret_cast<f32x4*>(W_l + r * WRES_LD + kbase + c4) = tmp[i];
-            }
-        }
-    }
-    const int m_lo = blockIdx.y * rows_per_group;
-    const int m_hi = min(a.M, m_lo + rows_per_group);
-    if (m_lo >= m_hi) return;
-    const float* a_src = T.A + koff + kq * 4;
-
-    f32x4 af[NJ];
-    auto load_a = [&](int m0) {
-        const int m = m0 + r16;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < m_hi) v = *reinterpret_cast<const f32x4*>(a_src + (size_t)m * T.lda + j * 16);
-            af[j] = v;
-        }
-    };
-    load_a(m_lo);
-    const float* wl = W_l + r16 * WRES_LD + kbase + kq * 4;
-    const int erow = threadIdx.x >> 4, euc = threadIdx.x & 15;  // epilogue role: one (row, unit) per thread
-    for (int m0 = m_lo; m0 < m_hi; m0 += 16) {
-        // epilogue inputs for this tile, fetched before the MFMA block
-        const int em = m0 + erow, eu = u0 + euc;
-        const bool evalid = em < m_hi && eu < a.U;
-        CellIn ci;
-        if (evalid) ci = cell_prefetch<MODE>(a, em, eu);
-        f32x4 cur[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) cur[j] = af[j];
-        if (m0 + 16 < m_hi) load_a(m0 + 16);  // next tile's A in flight during this tile's MFMAs
-        f32x4 acc[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        {   // B fragments are read one k-step ahead of the MFMAs that consume them
-            f32x4 b[2][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) b[0][g] = *reinterpret_cast<const f32x4*>(wl + g * 16 * WRES_LD);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                if (j + 1 < NJ) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) b[(j + 1) & 1][g] = *reinterpret_cast<const f32x4*>(wl + g * 16 * WRES_LD + (j + 1) * 16);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j][e], b[j & 1][g][e], acc[g], 0, 0, 0);
-                }
-            }
-        }
-        // partial sums -> LDS: red[q][g][row][col]
-        {
-            const int col = lane & 15, rq = lane >> 4;
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[((q * 4 + g) * 16 + rq * 4 + r) * 16 + col] = acc[g][r];
-        }
-        __syncthreads();
-        if (evalid) {
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float s = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) s += red[((w * 4 + g) * 16 + erow) * 16 + euc];
-                pre[g] = s;
-            }
-            cell_finish(a, em, eu, pre, ci);
-        }
-        __syncthreads();  // red is reused by the next tile
-    }
-}
-
-static bool wres_applicable(const LstmStepArgs& a) {
-    // latency mode: ~10 % faster for a single pass in flight, but its 156 KB of LDS per workgroup blocks the
-    // co-residency that several passes in flight rely on (bench default), so it is opt-in: FCL_LSTM_WRES=1
-    static const int on = tunable("LSTM_WRES", 0);
-    if (!on || a.nterms != 2 || a.m_dev) return false;  // (device row counts: the grouped row split of this kernel is computed on the host)
-    // the kernel reads the fp32 operands: a step whose producers wrote planes only (big decoder steps on the pre-split path set A = the buffer
-    // but never fill it; round-2 ADVICE) is not its to take
-    for (int i = 0; i < 2; ++i)
-        if (!a.term[i].A || !a.term[i].W || a.term[i].Ap) return false;
-    const int k0 = a.term[0].K, k1 = a.term[1].K;
-    return k0 + k1 == WRES_KT && (k0 % (WRES_KT / 4)) == 0 && a.U % 16 == 0 && a.U <= 1024;
-}
-
-int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled) {
-    *handled = false;
-    if (!wres_applicable(a)) return 0;
-    *handled = true;
-    const size_t lds = sizeof(float) * (64 * WRES_LD + 4 * 4 * 256);
-    for (const void* f : {reinterpret_cast<const void*>(lstm_wres_kernel<-1>), reinterpret_cast<const void*>(lstm_wres_kernel<0>),
-                          reinterpret_cast<const void*>(lstm_wres_kernel<1>)}) {
-        const int rc = ensure_dyn_lds(f, (int)lds);
-        if (rc) return rc;
-    }
-    const int slices = a.U / 16;
-    int groups = 256 / slices;
-    if (groups < 1) groups = 1;
-    int rpg = ((a.M + groups - 1) / groups + 15) / 16 * 16;  // rows per group, whole 16-row tiles
-    groups = (a.M + rpg - 1) / rpg;
-    ProfScope ps("lstm_wres_kernel", 2.0 * a.M * 4.0 * a.U * WRES_KT, a.M, s);
-    const bool plain = !a.zone_keep_h && !a.row_len;
-    if (plain && a.G && a.rank1_w && !a.bias) hipLaunchKernelGGL(lstm_wres_kernel<0>, dim3(slices, groups), dim3(256), lds, s, a, rpg);
-    else if (plain && a.bias && !a.G && !a.rank1_w) hipLaunchKernelGGL(lstm_wres_kernel<1>, dim3(slices, groups), dim3(256), lds, s, a, rpg);
-    else hipLaunchKernelGGL(lstm_wres_kernel<-1>, dim3(slices, groups), dim3(256), lds, s, a, rpg);
-    return check_hip(hipGetLastError(), "lstm_wres launch");
-}
-
 static bool fp_exact_split() {
     static const int v = tunable("FP_EXACT_SPLIT", 1);  // 0: the exact-fp32 mode keeps its fp32-operand feat/prenet and small-step kernels
     return v != 0;
@@ -1528,33 +1185,16 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
         ProfScope ps("feat_prenet_kernel/bf16x3", fl, rows, s);
         static const int fast = tunable("FEAT_PRENET_FAST", 1);
         if (fast && a.U == 256 && a.O > 64 && a.O <= 96 && a.P == 256) {
-            // RT row tiles per workgroup share one fetch of the weight fragments (see the kernel); few rows keep one tile per workgroup (latency)
-            // (four tiles would need 164 KB of LDS: two is the most a workgroup can carry)
-            static const int rt_max = tunable("FP_ROW_TILES", 2), rt_m = tunable("FP_ROW_TILES_M", 512);
-            const int rt = (rt_max >= 2 && rows >= rt_m) ? 2 : 1;
             const dim3 b(512);
-#define FCL_FP_LAUNCH(RT_)                                                                                                               \
-    do {                                                                                                                                 \
-        constexpr size_t lds_rt = 2 * sizeof(unsigned short) * 16 * RT_ * ((256 + 16) + (96 + 16) + (256 + 16));                            \
-        const dim3 g((rows + 16 * RT_ - 1) / (16 * RT_));                                                                                \
-        const void* fn = a.drop_mode == 1   ? reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 1, RT_>)                      \
-                         : a.drop_mode == 2 ? reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 2, RT_>)                      \
-                                            : reinterpret_cast<const void*>(feat_prenet_fast_kernel<8, 3, 8, 0, RT_>);                     \
-        const int rc = ensure_dyn_lds(fn, (int)lds_rt);                                                                                  \
-        if (rc) return rc;                                                                                                               \
-        if (a.drop_mode == 1) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 1, RT_>), g, b, lds_rt, s, a);                        \
-        else if (a.drop_mode == 2) hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 2, RT_>), g, b, lds_rt, s, a);                   \
-        else hipLaunchKernelGGL((feat_prenet_fast_kernel<8, 3, 8, 0, RT_>), g, b, lds_rt, s, a);                                         \
-    } while (0)
             // round 4: feat_prenet_split_kernel (transposed accumulators: vectorised epilogues; optional column split of layer 1).  Measured on one box,
-            // 2 400 live rows, rocprofv3 durations: the kernel above (RT = 2) 14.1 us; this one at (NS, RT) = (1, 1) 9.5, (1, 2) 11.9, (2, 2) 10.2,
+            // 2 400 live rows, rocprofv3 durations: the round-3 kernel (RT = 2) 14.1 us; this one at (NS, RT) = (1, 1) 9.5, (1, 2) 11.9, (2, 2) 10.2,
             // (2, 1) 9.6, (4, 1) 17 (600 workgroups x 245 KB: the L2 -> CU traffic of a launch, not the per-workgroup stream, is what a split costs).
             // The 4-stream bench line does not move with any of them (44.5 - 45.7 M frames/s for all, same box): with four passes in flight the
             // pass is bound by the sum of workgroup-time, which RT = 1 doubles while it halves the latency.  Default: no split, one row tile per
             // workgroup (lowest single-pass latency: 339 -> 269 us of a 1.38 ms eager pass) below 4 096 rows, two above.
-            // FCL_FP_SPLIT = 0 (the kernel above) / 1 / 2 / 4 / 8; FCL_FP_SPLIT_RT = row tiles per workgroup (0: by row count)
+            // FCL_FP_SPLIT = 1 / 2 / 4 / 8; FCL_FP_SPLIT_RT = row tiles per workgroup (0: by row count)
             static const int ns_t = tunable("FP_SPLIT", 1), rt_t = tunable("FP_SPLIT_RT", 0);
-            if (ns_t >= 1) {
+            {
                 const int rt_s = rt_t > 0 ? rt_t : (rows >= 4096 ? 2 : 1);
 #define FCL_FPS_CASE(RT_, NS_)                                                                                                           \
     do {                                                                                                                                 \
@@ -1581,9 +1221,7 @@ int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {
                 else FCL_FPS_RT(1);
 #undef FCL_FPS_RT
 #undef FCL_FPS_CASE
-            } else if (rt == 2) FCL_FP_LAUNCH(2);
-            else FCL_FP_LAUNCH(1);
-#undef FCL_FP_LAUNCH
+            }
         } else if (a.U == 256 && a.O == 80 && a.P == 256) {
             hipLaunchKernelGGL((feat_prenet_x3_kernel<8, 3, 8>), dim3((rows + 15) / 16), dim3(512), lds3, s, a);
         } else {

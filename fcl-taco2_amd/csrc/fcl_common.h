@@ -216,7 +216,6 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wave-per-gate kernel (fp32 operands) rather than a big-tile kernel
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
 int launch_lstm_small_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s);  // two same-shape small steps, one launch (fp32 operands)
-int launch_lstm_wres(const LstmStepArgs& a, hipStream_t s, bool* handled);
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s);
 int gemm_mode();  // capi.hip: the calling thread's fcl_set_gemm_mode() value (FCL_GEMM_F32 / FCL_GEMM_BF16)
 int tunable(const char* name, int dflt);  // FCL_<NAME> environment override, read once

@@ -582,11 +582,6 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     FCL_REQUIRE(a.h_in && a.h_out && a.c && a.h_in != a.h_out, FCL_ERR_INVALID, "lstm_step: h_in/h_out/c must be set and h_out must not alias h_in");
     FCL_REQUIRE(!a.rank1_w || a.dur, FCL_ERR_INVALID, "lstm_step: rank1_w needs dur");
     FCL_REQUIRE((a.zone_keep_h == nullptr) == (a.zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_step: zoneout masks come in pairs");
-    {
-        bool handled = false;
-        rc = launch_lstm_wres(a, s, &handled);
-        if (handled) return rc;
-    }
     const bool small = lstm_step_is_small(a.M, a.U);
     bool has_f32 = true;
     for (int i = 0; i < a.nterms; ++i) has_f32 = has_f32 && a.term[i].A && a.term[i].W;

@@ -502,38 +502,6 @@ def test_model_class_inference_matches_reference_golden(ops, golden):
     assert max_abs(out.cpu(), g["after"]) < 1e-3
 
 
-@pytest.mark.parametrize("batch,t_lo,t_hi", [(6, 30, 60), (16, 60, 100)], ids=["small_steps_only", "with_big_plane_steps"])
-def test_weights_stationary_lstm_kernel_matches(ops, batch, t_lo, t_hi):
-    """The opt-in latency-mode LSTM step (FCL_LSTM_WRES=1: weight slice resident in LDS, K split over 4 waves)
-    is exercised in a child process (the tunable is read once per process) and must reproduce the default path.  The second case has > 512 live
-    rows in its first steps: those run on pre-split planes whose fp32 prenet output is never written, so the fp32-operand kernel must decline
-    them (round-2 ADVICE: it used to read the unwritten buffer)."""
-    import os
-    import subprocess
-    import sys
-
-    code = (
-        "import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from helpers import np_state_dict\n"
-        "import fcl_taco2_amd\n"
-        "from fcl_taco2_amd import engine, hparams as HP, synthetic as SYN\n"
-        "from fcl_taco2_amd.plan import SynthesisPlan\n"
-        "hp = HP.student_hparams(dropout_rate=0.0)\n"
-        "plan = SynthesisPlan(np_state_dict(hp), hp, 'cuda:0')\n"
-        "xs, ds = SYN.batch_c2(hp.idim, batch=%d, t_lo=%d, t_hi=%d, seed=4)\n"
-        "mels = engine.synthesize(plan, xs, ds)\n"
-        "np.save(sys.argv[1], torch.cat(mels).cpu().numpy())\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), batch, t_lo, t_hi)
-    outs = []
-    for flag in ("0", "1"):
-        path = "/tmp/fcl_wres_%s.npy" % flag
-        env = dict(os.environ, FCL_LSTM_WRES=flag)
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
-        outs.append(np.load(path))
-    assert outs[0].shape == outs[1].shape
-    assert float(np.abs(outs[0] - outs[1]).max()) < 1e-4
-
-
 # ------------------------------------------------------------------------------------------ teacher-forced forward
 def _conv_batch(golden):
     from fcl_taco2_amd.converter import CustomConverter
