@@ -84,7 +84,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 412  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 413  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -220,6 +220,7 @@ SIGNATURES = {
     "fcl_derive_batch": (_I, [_P, _I, _I, _P]),
     "fcl_sumsq_accum": (_I, [_P, _Z, _P, _P]),
     "fcl_adam_step": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _P, _P, _P]),
+    "fcl_adam_step_wd": (_I, [_P, _P, _P, _P, _Z, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     "fcl_lstm_step_fwd": (_I, [C.POINTER(LstmStep), _P]),
     "fcl_decoder_train_workspace_bytes": (_Z, [_I, _I]),
     "fcl_decoder_train_fwd": (_I, [C.POINTER(DecoderTrain), _P]),

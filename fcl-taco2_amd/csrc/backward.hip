@@ -724,15 +724,16 @@ __device__ __forceinline__ bool adam_skip(const double* ctrl, const unsigned int
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
-                            const double* __restrict__ ctrl, float max_norm, float lr, float beta1, float beta2, float eps, const int* __restrict__ step_dev,
-                            const unsigned int* __restrict__ status) {
+                            const double* __restrict__ ctrl, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                            const int* __restrict__ step_dev, const unsigned int* __restrict__ status) {
     if (adam_skip(ctrl, status)) return;
     const double norm = sqrt(ctrl[0]);
     const float t = (float)(*step_dev + 1);  // the counter is advanced by adam_commit_kernel, after every block has read it
     const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     const float clip = max_norm > 0.f ? fminf(1.0f, max_norm / ((float)norm + 1e-6f)) : 1.0f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * clip;
+        // torch.optim.Adam(weight_decay): L2 term added to the (already clipped: clip_grad_norm_ ran on .grad before step()) gradient
+        const float gi = g[i] * clip + weight_decay * p[i];
         const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
         m[i] = mi;
@@ -1041,14 +1042,20 @@ int fcl_sumsq_accum(const float* x, size_t n, double* out, fcl_stream_t stream) 
     return check_hip(hipGetLastError(), "sumsq_accum");
 }
 
-int fcl_adam_step(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
-                  float beta2, float eps, int32_t* step_dev, const uint32_t* status, fcl_stream_t stream) {
+int fcl_adam_step_wd(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int32_t* step_dev, const uint32_t* status, fcl_stream_t stream) {
     FCL_REQUIRE(p && g && m && v && gradnorm_sq && step_dev, FCL_ERR_INVALID, "adam_step: bad arguments");
+    FCL_REQUIRE(weight_decay >= 0.f, FCL_ERR_INVALID, "adam_step: weight_decay must be >= 0 (torch.optim.Adam raises on a negative value)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d((long long)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, gradnorm_sq, max_norm, lr,
-                       beta1, beta2, eps, step_dev, status);
+                       beta1, beta2, eps, weight_decay, step_dev, status);
     hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, gradnorm_sq, step_dev, status);
     return check_hip(hipGetLastError(), "adam_step");
+}
+
+int fcl_adam_step(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
+                  float beta2, float eps, int32_t* step_dev, const uint32_t* status, fcl_stream_t stream) {
+    return fcl_adam_step_wd(p, g, m, v, n, gradnorm_sq, max_norm, lr, beta1, beta2, eps, 0.0f, step_dev, status, stream);
 }
 
 }  // extern "C"

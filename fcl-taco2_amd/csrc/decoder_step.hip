@@ -1149,12 +1149,30 @@ int launch_lstm_small(const LstmStepArgs& a, hipStream_t s) {
 }
 
 int launch_lstm_small_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s) {
-    double ksum = 0;
-    for (int i = 0; i < a0.nterms; ++i) ksum += a0.term[i].K;
-    dim3 grid((a0.U + 15) / 16, (a0.M + 15) / 16, 2);
-    ProfScope ps("lstm_small_pair_kernel", 2.0 * 2.0 * a0.M * 4.0 * a0.U * ksum, 2 * a0.M, s);
+    double fl = 0;
+    for (const LstmStepArgs* a : {&a0, &a1}) {
+        double ksum = 0;
+        for (int i = 0; i < a->nterms; ++i) ksum += a->term[i].K;
+        fl += 2.0 * a->M * 4.0 * a->U * ksum;
+    }
+    const int mmax = a0.M > a1.M ? a0.M : a1.M;  // (tiles beyond a problem's own rows exit at once)
+    dim3 grid((a0.U + 15) / 16, (mmax + 15) / 16, 2);
+    ProfScope ps("lstm_small_pair_kernel", fl, a0.M + a1.M, s);
     hipLaunchKernelGGL(lstm_small_pair_kernel, grid, dim3(256), 0, s, a0, a1);
     return check_hip(hipGetLastError(), "lstm_small_pair launch");
+}
+
+// two independent small steps that launch_lstm_step would both send to lstm_small_kernel (fp32 operands, no fragment-major weights): one launch;
+// *handled = false when either step has another form (the caller launches them one after the other)
+int launch_lstm_small_pair_any(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s, bool* handled) {
+    *handled = false;
+    static const int on = tunable("LSTM_SMALL_PAIR", 1);
+    if (!on || a0.U != a1.U || a0.m_dev || a1.m_dev) return 0;
+    for (const LstmStepArgs* a : {&a0, &a1})
+        for (int i = 0; i < a->nterms; ++i)
+            if (!a->term[i].A || !a->term[i].W || a->term[i].Whi || a->term[i].Wff) return 0;
+    *handled = true;
+    return launch_lstm_small_pair(a0, a1, s);
 }
 
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s) {

@@ -226,7 +226,8 @@ bool launch_dw_mfma(const float* a, int lda, const float* b, int ldb, float* c, 
     static const int big_min = tunable("DW_BIG_TILES_MIN", 16), wgs_big = tunable("DW_WORKGROUPS", 512), wgs_small = tunable("DW_WORKGROUPS_SMALL", 768);
     static const int min_chunks = tunable("DW_MIN_CHUNKS", 8);
     const int tiles_big = ((n + 127) / 128) * ((k + 127) / 128) * ntaps;
-    const bool big = tiles_big >= big_min;
+    static const int big_rows = tunable("DW_BIG_TILES_MIN_ROWS", 8192);  // (short contractions: the 64 x 64 form wins whatever the output, r5 sweep)
+    const bool big = tiles_big >= big_min && m >= big_rows;
     const int te = big ? 128 : 64;
     const int tiles = ((n + te - 1) / te) * ((k + te - 1) / te) * ntaps;
     int slices = ((big ? wgs_big : wgs_small) + tiles - 1) / tiles;

@@ -205,6 +205,7 @@ __device__ __forceinline__ void store_p32(unsigned short* __restrict__ p, int ld
 bool planes_ok(const GemmTerm* t, int n);                  // every term carries A and W planes (and FCL_PLANES != 0)
 int launch_gemm_planes(const GemmArgs& a, hipStream_t s);  // gemm_planes.hip
 int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s);
+int launch_lstm_planes_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s, bool* handled);  // two independent steps, one launch
 int launch_pwg_layer_fused(const fcl_pwg_layer_t& a, hipStream_t s);  // one Parallel WaveGAN residual block in one launch (r = 64, ksize = 3, aux <= 96)
 int launch_pwg_last_fused(const float* skips, float scale, const unsigned short* w1p, const float* b1, const float* w2, float b2, float* wav, long long m,
                           hipStream_t s);  // last_conv_layers in one launch (64 skip channels)
@@ -215,7 +216,8 @@ bool launch_dw_mfma(const float* a, int lda, const float* b, int ldb, float* c, 
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
 bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wave-per-gate kernel (fp32 operands) rather than a big-tile kernel
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
-int launch_lstm_small_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s);  // two same-shape small steps, one launch (fp32 operands)
+int launch_lstm_small_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s);
+int launch_lstm_small_pair_any(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s, bool* handled);  // only where both would run lstm_small_kernel  // two same-shape small steps, one launch (fp32 operands)
 int launch_feat_prenet(const FeatPrenetArgs& a, hipStream_t s);
 int gemm_mode();  // capi.hip: the calling thread's fcl_set_gemm_mode() value (FCL_GEMM_F32 / FCL_GEMM_BF16)
 int tunable(const char* name, int dflt);  // FCL_<NAME> environment override, read once

@@ -506,9 +506,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 1
 // NST = 2 (two ring stages, 64 KB: TWO workgroups per CU, 6 waves per SIMD, <= 80 VGPRs): the epilogue operands are then NOT requested before
 // the K loop (48 VGPRs held across it) but where they are used -- the other workgroup's main loop covers their latency.
 template <int WM, int WN, int TM, int NST, int MODE, int LW, int HI>
-__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12 && HI != 2) ? 6 : 1) void plstm_kernel(const LstmStepArgs a) {
+__device__ __forceinline__ void plstm_body(const LstmStepArgs& a, u8* smem) {
     using G = PGeo<WM, WN, TM, 4, NST, LW>;
-    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
     xcd_tile_p(bx, by);
     const int m0 = by * G::BM, u0 = bx * (16 * WN);
@@ -601,6 +600,22 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 1
             *reinterpret_cast<uint4*>(line + 32) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
     }
+}
+
+template <int WM, int WN, int TM, int NST, int MODE, int LW, int HI>
+__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12 && HI != 2) ? 6 : 1) void plstm_kernel(const LstmStepArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    plstm_body<WM, WN, TM, NST, MODE, LW, HI>(a, smem);
+}
+
+// Two INDEPENDENT steps in one launch (blockIdx.z picks the problem; the grid covers the larger row count, tiles beyond a problem's rows exit at
+// once).  Under teacher forcing layer 0 of step t + 1 needs the ground-truth frame and h0(t), not h1(t): it runs beside layer 1 of step t
+// (fcl_decoder_train_fwd) -- half the dependent launches of the training forward and twice the workgroups per launch (fewer part-filled rounds).
+template <int WM, int WN, int TM, int NST, int LW, int HI>
+__global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 12 && HI != 2) ? 6 : 1) void plstm_pair_kernel(const LstmStepArgs a0, const LstmStepArgs a1) {
+    extern __shared__ __attribute__((aligned(1024))) u8 smem[];
+    if (blockIdx.z == 0) plstm_body<WM, WN, TM, NST, -1, LW, HI>(a0, smem);
+    else plstm_body<WM, WN, TM, NST, -1, LW, HI>(a1, smem);
 }
 
 // experiments only: FCL_TILE_GROUP=<g> overrides the grouped tile order's group size (1 = row-major, rounds 1-2) on the calling device
@@ -977,6 +992,50 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     static const int row32_m = tunable("PLSTM_ROW32_M", 1100);
     if (force == 4 || (force == 0 && a.M <= row32_m)) return launch_plstm_cfg<2, 2, 1, 4>(a, s, flops);  // 32 x 128 tiles: M = 500 .. 1100 (measured)
     return launch_plstm_cfg<2, 1, 2, 4>(a, s, flops);  // 64 x 64 gate-column tiles (16 units): M <~ 1600 at U = 256
+}
+
+template <int WM, int WN, int TM, int NST, int HI>
+static int launch_plstm_pair_cfg(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s, double flops) {
+    constexpr int LW = 4;
+    using G = PGeo<WM, WN, TM, 4, NST, LW>;
+    auto k = plstm_pair_kernel<WM, WN, TM, NST, LW, HI>;
+    const int rc = ensure_dyn_lds(reinterpret_cast<const void*>(k), G::LDS_BYTES);
+    if (rc) return rc;
+    const int mmax = a0.M > a1.M ? a0.M : a1.M;
+    dim3 grid((a0.U + 16 * WN - 1) / (16 * WN), (mmax + G::BM - 1) / G::BM, 2);
+    char full[64];
+    snprintf(full, sizeof(full), "plstm_pair_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, NST, LW, HI ? "/bf16" : "");
+    ProfScope ps(full, flops, a0.M + a1.M, s);
+    hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, a0, a1);
+    return check_hip(hipGetLastError(), "plstm pair launch");
+}
+
+// two independent pre-split LSTM steps of the same width in one launch; *handled = false when the pair form does not cover the configuration
+// (the caller then launches the two steps one after the other)
+int launch_lstm_planes_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s, bool* handled) {
+    *handled = false;
+    static const int on = tunable("PLSTM_PAIR", 1);
+    if (!on || a0.U != a1.U || t_exact_lines || loader_waves() != 4 || a0.m_dev || a1.m_dev) return 0;
+    for (const LstmStepArgs* a : {&a0, &a1})
+        if (a->h_out_p && !((a->U & 31) == 0 && a->ld_hp * 32 >= a->U && (reinterpret_cast<uintptr_t>(a->h_out_p) & 127u) == 0)) return 0;
+    *handled = true;
+    double flops = 0;
+    for (const LstmStepArgs* a : {&a0, &a1}) {
+        double ksum = 0;
+        for (int i = 0; i < a->nterms; ++i) ksum += a->term[i].K;
+        flops += 2.0 * a->M * 4.0 * a->U * ksum;
+    }
+    const int M = a0.M > a1.M ? a0.M : a1.M, U = a0.U;
+    const bool hi = gemm_mode() == FCL_GEMM_BF16;
+    // the training-side thresholds of launch_lstm_planes on the larger of the two row counts (both problems share one tile shape)
+    static const int big_min = tunable("PLSTM_BIG_MIN", 150), mid_min = tunable("PLSTM_MID_MIN", 200), row32_m = tunable("PLSTM_ROW32_M", 1100);
+    const long long t128 = (long long)((M + 127) / 128) * ((U + 31) / 32), t64 = (long long)((M + 63) / 64) * ((U + 31) / 32);
+#define FCL_PAIR(WM_, WN_, TM_, NST_) (hi ? launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 1>(a0, a1, s, flops) : launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 0>(a0, a1, s, flops))
+    if (t128 >= big_min) return FCL_PAIR(4, 2, 2, 3);
+    if (t64 >= mid_min) return FCL_PAIR(2, 2, 2, 3);
+    if (M <= row32_m) return FCL_PAIR(2, 2, 1, 4);
+    return FCL_PAIR(2, 1, 2, 4);
+#undef FCL_PAIR
 }
 
 // --------------------------------------------------------------------------------------------------------------------------------------

@@ -51,18 +51,25 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
     unsigned short* h0p[2] = {reinterpret_cast<unsigned short*>(ws + 6 * NU), reinterpret_cast<unsigned short*>(ws + 7 * NU)};
     unsigned short* h1p[2] = {reinterpret_cast<unsigned short*>(ws + 8 * NU), reinterpret_cast<unsigned short*>(ws + 9 * NU)};
     const int ldp = a->p / 32, ldu = U / 32;
-    int cur = 0;
-    size_t off = 0;
-    int prev = a->n;
-    for (int t = 0; t < a->lmax; ++t) {
-        const int n = a->live_rows_host[t];
-        FCL_REQUIRE(n > 0 && n <= prev, FCL_ERR_SHAPE, "decoder_train_fwd: live_rows must be positive and non-increasing");
-        prev = n;
-        const bool big = planes && !lstm_step_is_small(n, U);  // pre-split operands for the big-tile steps (their h planes feed the next big step)
+    // step-major cell offsets; h0 of step t lives in h0[(t + 1) & 1] (step t reads h0[t & 1]), the same for h1
+    std::vector<size_t> offs((size_t)a->lmax + 1, 0);
+    {
+        int prev = a->n;
+        for (int t = 0; t < a->lmax; ++t) {
+            const int n = a->live_rows_host[t];
+            FCL_REQUIRE(n > 0 && n <= prev, FCL_ERR_SHAPE, "decoder_train_fwd: live_rows must be positive and non-increasing");
+            prev = n;
+            offs[t + 1] = offs[t] + (size_t)n;
+        }
+    }
+    auto is_big = [&](int t) { return planes && !lstm_step_is_small(a->live_rows_host[t], U); };  // pre-split operands for the big-tile steps (their h planes feed the next big step)
+    auto layer0 = [&](int t) {
+        const int n = a->live_rows_host[t], cur = t & 1;
+        const size_t off = offs[t];
         LstmStepArgs l0 = {};
         l0.term[0] = GemmTerm{a->p1d + off * a->p, a->w0_pre, a->p, a->p, a->p, 0, nullptr, nullptr};
         l0.term[1] = GemmTerm{h0[cur], a->w0_hh, U, U, U, 0, nullptr, nullptr};
-        if (big) {
+        if (is_big(t)) {
             l0.term[0].Ap = a->p1d_p + off * (size_t)ldp * 64; l0.term[0].Wp = a->w0_pre_p; l0.term[0].lda_p = l0.term[0].ldw_p = ldp;
             l0.term[1].Ap = h0p[cur]; l0.term[1].Wp = a->w0_hh_p; l0.term[1].lda_p = l0.term[1].ldw_p = ldu;
             l0.h_out_p = h0p[cur ^ 1]; l0.ld_hp = ldu;
@@ -87,12 +94,15 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
         l0.save_c_new = a->s0[1] + off * U;
         l0.save_c_old = a->s0[2] + off * U;
         l0.save_h_old = a->s0[3] + off * U;
-        int rc = launch_lstm_step(l0, s);
-        if (rc) return rc;
+        return l0;
+    };
+    auto layer1 = [&](int t) {
+        const int n = a->live_rows_host[t], cur = t & 1;
+        const size_t off = offs[t];
         LstmStepArgs l1 = {};
         l1.term[0] = GemmTerm{h0[cur ^ 1], a->w1_ih, U, U, U, 0, nullptr, nullptr};
         l1.term[1] = GemmTerm{h1[cur], a->w1_hh, U, U, U, 0, nullptr, nullptr};
-        if (big) {
+        if (is_big(t)) {
             l1.term[0].Ap = h0p[cur ^ 1]; l1.term[0].Wp = a->w1_ih_p; l1.term[0].lda_p = l1.term[0].ldw_p = ldu;
             l1.term[1].Ap = h1p[cur]; l1.term[1].Wp = a->w1_hh_p; l1.term[1].lda_p = l1.term[1].ldw_p = ldu;
             l1.h_out_p = h1p[cur ^ 1]; l1.ld_hp = ldu;
@@ -114,10 +124,48 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
         l1.save_c_new = a->s1[1] + off * U;
         l1.save_c_old = a->s1[2] + off * U;
         l1.save_h_old = a->s1[3] + off * U;
-        rc = launch_lstm_step(l1, s);
-        if (rc) return rc;
-        cur ^= 1;
-        off += (size_t)n;
+        return l1;
+    };
+    // Under teacher forcing layer 0 never waits for layer 1 (its input is the ground-truth frame's prenet output and its own state), so the two
+    // recurrences run as a WAVEFRONT: [L0(0)] -> [L0(1) | L1(0)] -> [L0(2) | L1(1)] -> ... -> [L1(lmax - 1)].  L0(t + 1) reads h0(t) from
+    // h0[(t + 1) & 1] and writes h0[t & 1], whose last readers -- L0(t), L1(t - 1) -- ran in earlier launches; L1(t) reads h0(t) beside it.
+    // One launch per pair where both steps run the same kernel family (round 5): lmax + 1 dependent launches instead of 2 lmax, and twice the
+    // workgroups per launch (fewer part-filled rounds of 128-row tiles at FCL-taco2-T width).  FCL_TRAIN_WAVEFRONT=0: the step-by-step order.
+    static const int wavefront = tunable("TRAIN_WAVEFRONT", 1);
+    if (!wavefront) {
+        for (int t = 0; t < a->lmax; ++t) {
+            int rc = launch_lstm_step(layer0(t), s);
+            if (rc) return rc;
+            rc = launch_lstm_step(layer1(t), s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    int rc = launch_lstm_step(layer0(0), s);
+    if (rc) return rc;
+    for (int t = 0; t < a->lmax; ++t) {
+        const LstmStepArgs l1 = layer1(t);
+        if (t + 1 == a->lmax) {
+            rc = launch_lstm_step(l1, s);
+            if (rc) return rc;
+            break;
+        }
+        const LstmStepArgs l0 = layer0(t + 1);
+        bool done = false;
+        const bool sm1 = lstm_step_is_small(l1.M, U), sm0 = lstm_step_is_small(l0.M, U);
+        if (is_big(t) && is_big(t + 1)) {
+            rc = launch_lstm_planes_pair(l1, l0, s, &done);  // (l1 first: it has the larger row count)
+            if (rc) return rc;
+        } else if (sm1 && sm0 && l1.nterms == l0.nterms) {
+            rc = launch_lstm_small_pair_any(l1, l0, s, &done);
+            if (rc) return rc;
+        }
+        if (!done) {
+            rc = launch_lstm_step(l1, s);
+            if (rc) return rc;
+            rc = launch_lstm_step(l0, s);
+            if (rc) return rc;
+        }
     }
     return 0;
 }

@@ -725,10 +725,11 @@ def sumsq_accum(x, out_f64):
     check(_lib.load().fcl_sumsq_accum(_p(x), x.numel(), out_f64.data_ptr(), _stream()))
 
 
-def adam_step(p, g, m, v, gradnorm_sq_f64, max_norm, lr, beta1, beta2, eps, step_i32, status=None):
-    """step_i32: device int32 count of APPLIED updates (advanced on the device only when this update is applied); status: device status word."""
-    check(_lib.load().fcl_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), gradnorm_sq_f64.data_ptr(), max_norm, lr, beta1, beta2, eps,
-                                    _p(step_i32, torch.int32), _p(status, torch.int32), _stream()))
+def adam_step(p, g, m, v, gradnorm_sq_f64, max_norm, lr, beta1, beta2, eps, step_i32, status=None, weight_decay=0.0):
+    """step_i32: device int32 count of APPLIED updates (advanced on the device only when this update is applied); status: device status word;
+    weight_decay: torch.optim.Adam's L2 term (tts.py:397-399), added to the clipped gradient inside the step."""
+    check(_lib.load().fcl_adam_step_wd(_p(p), _p(g), _p(m), _p(v), p.numel(), gradnorm_sq_f64.data_ptr(), max_norm, lr, beta1, beta2, eps,
+                                       float(weight_decay), _p(step_i32, torch.int32), _p(status, torch.int32), _stream()))
 
 
 def act_fwd(x, act, keep=None, keep_scale=1.0, want_planes=False):

@@ -128,7 +128,7 @@ def adam_state_dict(engine):
         o, n, shape = offs[k]
         state[i] = {"step": torch.tensor(float(engine.step_count)), "exp_avg": engine.mflat[o : o + n].view(shape).detach().cpu().clone(),
                     "exp_avg_sq": engine.vflat[o : o + n].view(shape).detach().cpu().clone()}
-    group = {"lr": engine.lr, "betas": tuple(engine.betas), "eps": engine.eps, "weight_decay": 0, "amsgrad": False, "params": list(range(len(names)))}
+    group = {"lr": engine.lr, "betas": tuple(engine.betas), "eps": engine.eps, "weight_decay": getattr(engine, "weight_decay", 0.0), "amsgrad": False, "params": list(range(len(names)))}
     return {"state": state, "param_groups": [group]}
 
 
@@ -145,6 +145,7 @@ def load_adam_state_dict(engine, sd):
         engine.step_count = int(float(st["step"]))
     g = sd["param_groups"][0]
     engine.lr, engine.eps, engine.betas = g["lr"], g["eps"], tuple(g["betas"])
+    engine.weight_decay = float(g.get("weight_decay", 0.0))  # (torch.optim.Adam.load_state_dict restores the group's options too)
 
 
 def save_checkpoints(outdir, engine, epoch, iteration, valid_loss, best):
@@ -209,8 +210,6 @@ def train(argv=None):
     cls = dynamic_import(args.model_module)
     cls.add_arguments(parser)
     args = parser.parse_args(argv)
-    if args.weight_decay != 0.0:
-        raise NotImplementedError("fcl-taco2_amd: weight decay is 0 in every shipped recipe and is not implemented on the HIP path")
     # The host side of a step is ~1000 kernel launches issued from this thread.  torch's default intra-op pool (one thread per core: 256 on an
     # MI355X host) spins after every small CPU op of the converter and slows those launches 4x (46 vs 16 ms per KD update, measured); cap it.
     torch.set_num_threads(max(1, args.host_threads))
@@ -259,7 +258,7 @@ def train(argv=None):
         teng = None
         model = cls(idim, odim, args, args)
     model = model.to(dev)
-    eng = TrainEngine(model, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip, accum_grad=args.accum_grad, seed=args.seed * 1000 + rank,
+    eng = TrainEngine(model, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip, accum_grad=args.accum_grad, seed=args.seed * 1000 + rank, weight_decay=args.weight_decay,
                       amp="bf16" if args.use_amp else None)
     epoch0, iteration = 0, 0
     if args.resume:

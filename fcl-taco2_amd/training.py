@@ -532,7 +532,8 @@ _DW_PLANES_MIN = int(os.environ.get("FCL_DW_PLANES_MIN", "0"))  # output element
 
 
 class TrainEngine(object):
-    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None, overlap_dw=True, amp=None, native=True):
+    def __init__(self, model, lr=1e-3, eps=1e-6, betas=(0.9, 0.999), grad_clip=1.0, accum_grad=1, seed=0, group=None, overlap_dw=True, amp=None, native=True,
+                 weight_decay=0.0):
         """native: train-form passes without injected masks run as ONE C++ routine per backward stage (fcl_te_*, csrc/train_engine.hip) when the
         configuration is covered (`native_reason` says why not); False = always the per-launch path below, which is also its reference.
         amp: None = fp32-equivalent arithmetic; "bf16" = the mixed-precision form of the reference's `--use-amp True` recipe (apex O1,
@@ -576,6 +577,9 @@ class TrainEngine(object):
         self.buckets = GradBuckets(self.gflat, bounds, group)
         self.B = dict(model.named_buffers())
         self.lr, self.eps, self.betas, self.grad_clip, self.accum_grad = lr, eps, betas, grad_clip, int(accum_grad)
+        self.weight_decay = float(weight_decay)  # torch.optim.Adam(weight_decay=...) of tts.py:397-399 / tts_distill.py:418-420
+        if self.weight_decay < 0.0:
+            raise ValueError("Invalid weight_decay value: %g" % self.weight_decay)  # (torch.optim.Adam's own check)
         self.arena = ZeroArena(self.dev)
         self._z = self.arena.take
         self.forward_count, self.seed = 0, int(seed)
@@ -1594,7 +1598,7 @@ class TrainEngine(object):
             ops.sumsq_accum(self.gflat, self.gn_sq)
             self.update_calls += 1
             ops.adam_step(self.pflat, self.gflat, self.mflat, self.vflat, self.gn_sq, self.grad_clip, self.lr, self.betas[0], self.betas[1], self.eps,
-                          self.step_dev, self.status)  # skipped on the device (counter included) on a NaN / inf norm or a non-zero status word
+                          self.step_dev, self.status, weight_decay=self.weight_decay)  # skipped on the device (counter included) on a NaN / inf norm or a non-zero status word
             if self._native is not None:
                 self._native.params_changed()
             self.model.refresh_plan()

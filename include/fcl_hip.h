@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 412
+#define FCL_ABI_VERSION 413
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -582,6 +582,10 @@ int fcl_derive_batch(const fcl_derive_t* descs_dev, int n, int total_blocks, fcl
 int fcl_sumsq_accum(const float* x, size_t n, double* out, fcl_stream_t stream);
 int fcl_adam_step(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
                   float beta2, float eps, int32_t* step_dev, const uint32_t* status, fcl_stream_t stream);
+/* fcl_adam_step with torch.optim.Adam's weight_decay (`--weight-decay`, /root/reference/tts.py:397-399, tts_distill.py:418-420): the L2 term
+ * weight_decay * p is added to the clipped gradient inside the step, before the moment updates (torch's non-decoupled form). */
+int fcl_adam_step_wd(float* p, const float* g, float* m, float* v, size_t n, const double* gradnorm_sq, float max_norm, float lr, float beta1,
+                     float beta2, float eps, float weight_decay, int32_t* step_dev, const uint32_t* status, fcl_stream_t stream);
 
 /* ---- measurement hook (bench.py's live roofline figures) ------------------------------- */
 /* While enabled, every GEMM / LSTM-step / BiLSTM launch is bracketed by HIP events on the stream it is

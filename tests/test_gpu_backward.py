@@ -187,6 +187,36 @@ def test_scatter_add_and_adam_step(ops):
     assert torch.equal(p, before) and int(step_dev.item()) == 2
 
 
+@pytest.mark.parametrize("wd", [0.01, 0.3])
+def test_adam_step_weight_decay_matches_torch(ops, wd):
+    """`--weight-decay` (tts.py:397-399, tts_distill.py:418-420: torch.optim.Adam(weight_decay=...)): the L2 term joins the CLIPPED gradient inside
+    the step.  Three steps vs torch.optim.Adam on CPU, with clip_grad_norm_(1.0) in between as the reference's update has it."""
+    rng = np.random.RandomState(11)
+    p0, grads = rnd(rng, 1500), [5 * rnd(rng, 1500), rnd(rng, 1500), 0.1 * rnd(rng, 1500)]
+    pt = torch.nn.Parameter(torch.from_numpy(p0.copy()))
+    opt = torch.optim.Adam([pt], lr=1e-3, eps=1e-6, weight_decay=wd)
+    p, m, v = dev(p0.copy()), torch.zeros(1500, device=DEV), torch.zeros(1500, device=DEV)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step, gnp in enumerate(grads, 1):
+        pt.grad = torch.from_numpy(gnp.copy())
+        torch.nn.utils.clip_grad_norm_([pt], 1.0)
+        opt.step()
+        nsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.sumsq_accum(dev(gnp), nsq)
+        ops.adam_step(p, dev(gnp), m, v, nsq, 1.0, 1e-3, 0.9, 0.999, 1e-6, step_dev, weight_decay=wd)
+        assert max_abs(p.cpu(), pt.detach()) < 3e-6 and int(step_dev.item()) == step
+    st = opt.state[pt]
+    assert max_abs(m.cpu(), st["exp_avg"]) < 1e-6 and max_abs(v.cpu(), st["exp_avg_sq"]) < 1e-6
+    # without the decay term the trajectories differ visibly: the flag is not a no-op
+    p2, m2, v2 = dev(p0.copy()), torch.zeros(1500, device=DEV), torch.zeros(1500, device=DEV)
+    s2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nsq = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.sumsq_accum(dev(grads[0]), nsq)
+    ops.adam_step(p2, dev(grads[0]), m2, v2, nsq, 1.0, 1e-3, 0.9, 0.999, 1e-6, s2)
+    ops.adam_step(p2, dev(grads[1]), m2, v2, nsq, 1.0, 1e-3, 0.9, 0.999, 1e-6, s2)
+    assert float((m2 - m).abs().max()) > 1e-4
+
+
 @pytest.mark.parametrize("m,n,k", [(1, 16, 256), (7, 100, 260), (16, 256, 1024), (33, 256, 1024), (64, 1024, 512)])
 def test_small_m_split_k_gemm(ops, m, n, k):
     """The split-K kernel launch_gemm picks for M <= 64, K >= 256 (the per-step GEMMs of the BPTT recurrences; their residual epilogue is covered by
