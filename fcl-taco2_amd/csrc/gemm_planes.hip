@@ -1031,6 +1031,8 @@ int launch_lstm_planes_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipS
     static const int big_min = tunable("PLSTM_BIG_MIN", 150), mid_min = tunable("PLSTM_MID_MIN", 200), row32_m = tunable("PLSTM_ROW32_M", 1100);
     const long long t128 = (long long)((M + 127) / 128) * ((U + 31) / 32), t64 = (long long)((M + 63) / 64) * ((U + 31) / 32);
 #define FCL_PAIR(WM_, WN_, TM_, NST_) (hi ? launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 1>(a0, a1, s, flops) : launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 0>(a0, a1, s, flops))
+    static const int two_stage = tunable("PLSTM_PAIR_2STAGE_MIN_WG", 1 << 30);  // (r5 A/B: two ring stages = two workgroups per CU for the pair's big tiles)
+    if (t128 >= two_stage) return FCL_PAIR(4, 2, 2, 2);
     if (t128 >= big_min) return FCL_PAIR(4, 2, 2, 3);
     if (t64 >= mid_min) return FCL_PAIR(2, 2, 2, 3);
     if (M <= row32_m) return FCL_PAIR(2, 2, 1, 4);

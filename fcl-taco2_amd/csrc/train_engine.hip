@@ -117,6 +117,9 @@ struct Ctx {  // one forward's tensors (training.py's _Ctx)
     // backward carries between stages
     float *d_before = nullptr, *d_att_c = nullptr, *d_hs = nullptr, *d_att = nullptr;
     float* d_preds[3] = {nullptr, nullptr, nullptr};
+    // P32 planes the forward already wrote for a tap (embedding, conv blocks, BiLSTM output, prenet): the KD projections read them instead of
+    // packing the fp32 tap once more (round 5: 9 of 14 fcl_pack_planes launches of a KD update)
+    std::unordered_map<const float*, const uint16_t*> planes_of;
 };
 
 }  // namespace te
@@ -600,6 +603,8 @@ static int te_forward(fcl_te& E) {
     c.emb = f32(E, BT, Ee);
     uint16_t* xp = pl16(E, BT, Ee);
     TE_L(fcl_embedding_fwd(b.xs, E.Pm("enc.embed.weight").p, c.emb, xp, BT, cf.idim, Ee, E.cur));
+    c.planes_of.clear();
+    c.planes_of[c.emb] = xp;
     const float* x = c.emb;
     c.conv_c.assign(cf.econv_layers, ConvBn());
     c.enc_taps.assign(1, c.emb);
@@ -617,6 +622,7 @@ static int te_forward(fcl_te& E) {
                            &yp, &c.conv_c[i]));
         x = y;
         xp = yp;
+        if (yp) c.planes_of[y] = yp;
         c.enc_taps.push_back(y);
     }
     // ---- BiLSTM (packed sequences)
@@ -658,6 +664,7 @@ static int te_forward(fcl_te& E) {
             TE_L(fcl_pack_planes(c.hs, 2 * H, BT, 2 * H, hs_p, E.cur));
         }
     }
+    if (hs_p) c.planes_of[c.hs] = hs_p;
     c.enc_taps.push_back(c.hs);
     // ---- predictors + embeds: their dropout masks in one launch, their forward beside the decoder's (weight-gradient stream) when a backward follows
     const float p_emb = cf.ve_dropout;
@@ -772,6 +779,7 @@ static int te_forward(fcl_te& E) {
     c.p1d = f32(E, F, Pn);
     uint16_t* p1d_p = pl16(E, F, Pn);
     TE_L(fcl_act_fwd(c.p1, c.k1, c.pks, c.p1d, p1d_p, Pn, (size_t)F * Pn, FCL_ACT_NONE, E.cur));
+    c.planes_of[c.p1d] = p1d_p;
     const std::string wih0 = "dec.lstm.0.cell.weight_ih";
     const int ld0 = C + Pn + 1;
     const float *w0_att, *w0_pre, *w0_pos, *b0s, *b1s, *wf_h, *wf_att;
@@ -839,6 +847,7 @@ static int te_forward(fcl_te& E) {
                            p_conv, i < n_post - 1, &y, &yp, &c.post_c[i]));
         x = y;
         xp = yp;
+        if (yp) c.planes_of[y] = yp;
         c.post_taps.push_back(y);
     }
     c.after = f32(E, BL, O);
@@ -875,8 +884,14 @@ static int te_kd(fcl_te& E, const char* lname, const float* s_in, int rows, cons
                  float** ds_in) {
     Param& W = E.Pm(proj + ".weight");
     if (n % 32 == 0 && k % 32 == 0 && rows >= 4096) {
-        uint16_t* sp = pl16(E, rows, k);
-        TE_L(fcl_pack_planes(s_in, k, rows, k, sp, E.cur));
+        const uint16_t* sp;
+        auto hit = E.c.planes_of.find(s_in);
+        if (hit != E.c.planes_of.end()) sp = hit->second;
+        else {
+            uint16_t* spk = pl16(E, rows, k);
+            TE_L(fcl_pack_planes(s_in, k, rows, k, spk, E.cur));
+            sp = spk;
+        }
         const uint16_t* wp;
         TE_TRY(w_planes(E, proj + ".weight", n, k, &wp));
         float* s = f32(E, rows, n);

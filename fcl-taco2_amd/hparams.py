@@ -143,11 +143,12 @@ def param_spec(hp, projections_to=None, share_proj=True):
         s["enc.convs.%d.0.weight" % i] = (C, E if i == 0 else C, hp.econv_filts)
         if hp.use_batch_norm:  # encoder_sa.py:63-90: without it the block is Conv1d -> ReLU -> Dropout
             _bn(s, "enc.convs.%d.1" % i, C)
-    for sfx in ("", "_reverse"):
-        s["enc.blstm.weight_ih_l0" + sfx] = (4 * H, C)
-        s["enc.blstm.weight_hh_l0" + sfx] = (4 * H, H)
-        s["enc.blstm.bias_ih_l0" + sfx] = (4 * H,)
-        s["enc.blstm.bias_hh_l0" + sfx] = (4 * H,)
+    for l in range(hp.elayers):  # torch.nn.LSTM(num_layers=elayers, bidirectional=True): layer l > 0 reads [forward | reverse] = 2H channels
+        for sfx in ("", "_reverse"):
+            s["enc.blstm.weight_ih_l%d%s" % (l, sfx)] = (4 * H, C if l == 0 else 2 * H)
+            s["enc.blstm.weight_hh_l%d%s" % (l, sfx)] = (4 * H, H)
+            s["enc.blstm.bias_ih_l%d%s" % (l, sfx)] = (4 * H,)
+            s["enc.blstm.bias_hh_l%d%s" % (l, sfx)] = (4 * H,)
     T = projections_to
     if T is not None:
         s["enc.embed_proj.weight"] = (T.embed_dim, E)

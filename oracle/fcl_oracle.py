@@ -100,18 +100,19 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
     return h2, c2
 
 
-def blstm_packed(sd, x_btc, ilens, prefix="enc.blstm"):
-    """H3 — 1-layer bidirectional nn.LSTM over pack_padded_sequence (encoder_sa.py:98-100,143-146).
+def blstm_packed(sd, x_btc, ilens, prefix="enc.blstm", layer=0):
+    """H3 — one layer of the bidirectional nn.LSTM over pack_padded_sequence (encoder_sa.py:98-100,143-146).
 
     Restated as an explicit masked time loop: the forward direction runs t = 0..len-1, the reverse
     direction starts from zero state at t = len-1; outputs past each length are zero
-    (pad_packed_sequence)."""
+    (pad_packed_sequence).  `elayers` > 1 (blstm_stack): layer l reads the [forward | reverse] outputs of layer l - 1
+    (torch.nn.LSTM(num_layers=elayers, bidirectional=True): parameters `..._l<l>[_reverse]`)."""
     B, T, _ = x_btc.shape
     lens = torch.tensor([int(l) for l in ilens])
     outs = []
     for sfx, order in (("", range(T)), ("_reverse", range(T - 1, -1, -1))):
-        w_ih, w_hh = sd[prefix + ".weight_ih_l0" + sfx], sd[prefix + ".weight_hh_l0" + sfx]
-        b_ih, b_hh = sd[prefix + ".bias_ih_l0" + sfx], sd[prefix + ".bias_hh_l0" + sfx]
+        w_ih, w_hh = sd[prefix + ".weight_ih_l%d%s" % (layer, sfx)], sd[prefix + ".weight_hh_l%d%s" % (layer, sfx)]
+        b_ih, b_hh = sd[prefix + ".bias_ih_l%d%s" % (layer, sfx)], sd[prefix + ".bias_hh_l%d%s" % (layer, sfx)]
         H = w_hh.shape[1]
         h = x_btc.new_zeros(B, H)
         c = x_btc.new_zeros(B, H)
@@ -130,6 +131,14 @@ def blstm_packed(sd, x_btc, ilens, prefix="enc.blstm"):
     return torch.cat(outs, dim=2)
 
 
+def blstm_stack(sd, x_btc, ilens, n_layers=1, prefix="enc.blstm"):
+    """`elayers` stacked bidirectional layers (encoder_sa.py:96-100: nn.LSTM(iunits, eunits // 2, elayers, batch_first=True, bidirectional=True);
+    no dropout between layers: the reference passes none)."""
+    for l in range(n_layers):
+        x_btc = blstm_packed(sd, x_btc, ilens, prefix, l)
+    return x_btc
+
+
 def encoder_forward(sd, hp, xs, ilens, bn_train=False, keeps=None):
     """Batched Encoder.forward (encoder_sa_kd.py:144-197): returns (enc_out [B,T,C], taps) where taps =
     [embed, conv0, conv1, conv2] as [B,T,C] (un-projected; student projections are applied by callers).
@@ -137,7 +146,7 @@ def encoder_forward(sd, hp, xs, ilens, bn_train=False, keeps=None):
     emb = F.embedding(xs, sd["enc.embed.weight"], padding_idx=0)  # H1
     kt = None if keeps is None else [_t(k).transpose(1, 2) for k in keeps]
     taps = encoder_convs(sd, emb.transpose(1, 2), hp.econv_layers, bn_train, kt, hp.dropout_rate, residual=hp.use_residual)
-    enc = blstm_packed(sd, taps[-1].transpose(1, 2), ilens)
+    enc = blstm_stack(sd, taps[-1].transpose(1, 2), ilens, getattr(hp, "elayers", 1))
     return enc, [emb] + [t.transpose(1, 2) for t in taps]
 
 
@@ -198,10 +207,10 @@ def position_table(ds_nonzero):
     return pad_list(rows, 0)
 
 
-def prenet(sd, x, keep_pair=None, p=0.5):
-    """H6 — Prenet.forward (decoder_sa.py:146-158): 2 x {Linear -> ReLU -> dropout(always on)}.
-    keep_pair: None = dropout disabled (rate 0), else two {0,1} masks [N, P]."""
-    for l in range(2):
+def prenet(sd, x, keep_pair=None, p=0.5, n_layers=2):
+    """H6 — Prenet.forward (decoder_sa.py:119-158): n_layers x {Linear -> ReLU -> dropout(always on)} (2 in every shipped recipe).
+    keep_pair: None = dropout disabled (rate 0), else n_layers {0,1} masks [N, P]."""
+    for l in range(n_layers):
         x = torch.relu(F.linear(x, sd["dec.prenet.prenet.%d.0.weight" % l], sd["dec.prenet.prenet.%d.0.bias" % l]))
         if keep_pair is not None and p > 0:
             x = _drop(x, keep_pair[l], p)
@@ -246,39 +255,41 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
     Decoder.forward :572-625 (teacher forced: prev_out = y_t).
 
     att_c [N, C] (already hs + p_embs + e_embs), position [N, >=n_steps].
-    prenet_keep: None (dropout off) or uint8 [n_steps, 2, N, P]; zone_keep: None (eval zoneout) or
-    uint8 [n_steps, 2(layer), 2(h,c), N, U].
-    Returns outs [N, odim, n_steps], prenet_outs [N, n_steps, P], lstm0 [N, n_steps, U], lstm1 [...]."""
+    prenet_keep: None (dropout off) or uint8 [n_steps, prenet_layers, N, P]; zone_keep: None (eval zoneout) or
+    uint8 [n_steps, dlayers, 2(h,c), N, U].  `dlayers` cells (decoder_sa.py:357-369, 500-504: cell l > 0 reads cell l - 1's new state;
+    feat_out reads the LAST cell), `prenet_layers` prenet blocks.
+    Returns outs [N, odim, n_steps], prenet_outs [N, n_steps, P], lstm0 [N, n_steps, U], last cell [N, n_steps, U]."""
     N = att_c.shape[0]
     U, zr = hp.dunits, hp.zoneout_rate
     # decoder_sa.py:366-369: the cell is wrapped in ZoneOutCell (parameters under `.cell`) only for a positive rate
     pat = "dec.lstm.%d.cell.%s" if zr > 0.0 else "dec.lstm.%d.%s"
-    W = [[sd[pat % (l, k)] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] for l in range(2)]
+    DL, PL = getattr(hp, "dlayers", 2), getattr(hp, "prenet_layers", 2)
+    W = [[sd[pat % (l, k)] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] for l in range(DL)]
     wf = sd["dec.feat_out.weight"]
-    z = [att_c.new_zeros(N, U), att_c.new_zeros(N, U)]
-    c = [att_c.new_zeros(N, U), att_c.new_zeros(N, U)]
+    z = [att_c.new_zeros(N, U) for _ in range(DL)]
+    c = [att_c.new_zeros(N, U) for _ in range(DL)]
     prev = att_c.new_zeros(N, hp.odim)
     outs, pres, l0, l1 = [], [], [], []
     for t in range(n_steps):
         if isinstance(prenet_keep, str):  # "rng": the reference's always-on F.dropout with fresh Bernoulli masks
-            kp = [(torch.rand(N, hp.prenet_units) >= hp.dropout_rate) for _ in range(2)] if hp.dropout_rate > 0 else None
+            kp = [(torch.rand(N, hp.prenet_units) >= hp.dropout_rate) for _ in range(PL)] if hp.dropout_rate > 0 else None
         else:
             kp = None if prenet_keep is None else [_t(k) for k in prenet_keep[t]]
-        pre = prenet(sd, prev, kp, hp.dropout_rate if kp is not None else 0.5)
+        pre = prenet(sd, prev, kp, hp.dropout_rate if kp is not None else 0.5, PL)
         pres.append(pre)
         base_cat = [att_c, pre]
         if getattr(hp, "append_position", True):  # decoder_sa.py:494-498 / :594-597
             base_cat.append(position[:, t].reshape(-1, 1))
         xs = torch.cat(base_cat, dim=1)
-        for l in range(2):
-            inp = xs if l == 0 else z[0]
+        for l in range(DL):
+            inp = xs if l == 0 else z[l - 1]
             h2, c2 = lstm_cell(inp, z[l], c[l], *W[l])
             zk = None if zone_keep is None else zone_keep[t, l]
             z[l] = zoneout(z[l], h2, zr, None if zk is None else zk[0])
             c[l] = zoneout(c[l], c2, zr, None if zk is None else zk[1])
         l0.append(z[0])
-        l1.append(z[1])
-        out = F.linear(torch.cat([z[1], att_c], dim=1) if getattr(hp, "use_concate", True) else z[1], wf)  # H8, no bias (decoder_sa.py:505-511)
+        l1.append(z[-1])
+        out = F.linear(torch.cat([z[-1], att_c], dim=1) if getattr(hp, "use_concate", True) else z[-1], wf)  # H8, no bias (decoder_sa.py:505-511)
         outs.append(out)
         prev = _out_act(hp, out) if teacher_ys is None else teacher_ys[:, t]  # decoder_sa.py:614-617: the fed-back frame is activated
     return (torch.stack(outs, dim=2), torch.stack(pres, dim=1), torch.stack(l0, dim=1), torch.stack(l1, dim=1))
@@ -438,17 +449,18 @@ def masks_from_sequence(seq, hp):
     rest = list(it)
     n_post = hp.postnet_layers if hp.dropout_rate > 0 else 0
     dec, post = rest[: len(rest) - n_post], rest[len(rest) - n_post:]
-    per = (2 if hp.dropout_rate > 0 else 0) + 4
+    DL, PL = getattr(hp, "dlayers", 2), getattr(hp, "prenet_layers", 2)
+    per = (PL if hp.dropout_rate > 0 else 0) + 2 * DL
     assert len(dec) % per == 0
     steps = len(dec) // per
     pk, zk = [], []
     for t in range(steps):
         g = dec[t * per : (t + 1) * per]
         if hp.dropout_rate > 0:
-            pk.append(np.stack(g[:2]))
-            g = g[2:]
-        zk.append(np.stack([np.stack(g[0:2]), np.stack(g[2:4])]))
-    m["prenet"] = np.stack(pk) if pk else None  # [steps, 2, N, P]
+            pk.append(np.stack(g[:PL]))
+            g = g[PL:]
+        zk.append(np.stack([np.stack(g[2 * l : 2 * l + 2]) for l in range(DL)]))
+    m["prenet"] = np.stack(pk) if pk else None  # [steps, prenet_layers, N, P]
     m["zoneout"] = np.stack(zk)  # [steps, layer, (h, c), N, U]
     m["postnet"] = [np.ascontiguousarray(np.transpose(a, (0, 2, 1))) for a in post] if n_post else None
     return m

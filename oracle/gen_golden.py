@@ -760,6 +760,47 @@ def gen_g17():
     save("g17_teacher_layers", **d)
 
 
+def _teacher_variant(name, hp, seed, extra_keys):
+    """One golden pair for a structure option the reference's plain teacher class runs: inference mel + training step (eval form)."""
+    rng = np.random.RandomState(seed)
+    x = torch.from_numpy(rng.randint(1, hp.idim, size=7).astype(np.int64))
+    dur = torch.tensor([2, 1, 4, 1, 3, 2, 2])
+    te, spec = build("teacher", hp)
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+    save(name + "_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    loss = te(**b)
+    loss.backward()
+    keys = [k for k in GRAD_KEYS if k in spec] + [k for k in extra_keys if k in spec]
+    d = dict(loss=np.float32(loss.item()))
+    _named_losses(te, d)
+    _grads(te, keys, d)
+    save(name, **d)
+    return spec
+
+
+def gen_g18_g19_g20():
+    """G18 - G20 (round 5): the structure options of the reference's teacher class that the HIP path used to refuse (hparams.py:70-86).
+    G18 `dlayers` 1 and 3 (decoder_sa.py:357-369, 500-504: a stack of ZoneOut LSTMCells, cell l > 0 on cell l - 1's state, feat_out on the last);
+    G19 `prenet_layers` 1 and 3 (decoder_sa.py:119-158); G20 `elayers` 2 (encoder_sa.py:96-100: a two-layer bidirectional nn.LSTM).
+    Each: inference mel and training step (losses + gradients, eval form) of the real class.  The KD classes index fixed tap lists and fail on
+    most of these (records.json): teacher class only."""
+    kw = dict(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0)
+    for dl in (1, 3):
+        spec = _teacher_variant("g18_teacher_dlayers%d" % dl, HP.teacher_hparams(dlayers=dl, **kw), 180 + dl,
+                                ["dec.lstm.%d.cell.weight_ih" % (dl - 1), "dec.lstm.%d.cell.weight_hh" % (dl - 1), "dec.lstm.%d.cell.bias_ih" % (dl - 1)])
+        assert ("dec.lstm.2.cell.weight_ih" in spec) == (dl == 3) and ("dec.lstm.1.cell.weight_ih" in spec) == (dl == 3)
+    for pl in (1, 3):
+        spec = _teacher_variant("g19_teacher_prenet%d" % pl, HP.teacher_hparams(prenet_layers=pl, **kw), 190 + pl,
+                                ["dec.prenet.prenet.%d.0.weight" % (pl - 1), "dec.prenet.prenet.%d.0.bias" % (pl - 1)])
+        assert ("dec.prenet.prenet.2.0.weight" in spec) == (pl == 3)
+    spec = _teacher_variant("g20_teacher_elayers2", HP.teacher_hparams(elayers=2, **kw), 200,
+                            ["enc.blstm.weight_ih_l0", "enc.blstm.weight_hh_l0_reverse", "enc.blstm.weight_ih_l1", "enc.blstm.weight_hh_l1", "enc.blstm.bias_ih_l1_reverse",
+                             "enc.blstm.weight_ih_l1_reverse", "enc.convs.0.0.weight"])
+    assert "enc.blstm.weight_ih_l1_reverse" in spec
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -847,7 +888,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "records"}, only
+        if "g18" in only:
+            gen_g18_g19_g20()
         if "g17" in only:
             gen_g17()
         if "g16" in only:
@@ -882,6 +925,7 @@ def main():
     gen_g15()
     gen_g16()
     gen_g17()
+    gen_g18_g19_g20()
     gen_option_records()
 
 

@@ -74,3 +74,14 @@ TINY_TL = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_cha
 # speaker embeddings (G13): F.normalize(spemb) appended to the encoder states; predictors / embeddings / decoder on eunits + 8 channels
 TINY_TK = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28,
                              postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0, spk_embed_dim=8)
+
+# structure options of the reference's teacher class beyond the shipped recipes (G18 - G20, round 5): decoder cell count, prenet block count,
+# stacked encoder BiLSTM
+_OPT = dict(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, duration_predictor_chans=20, dropout_rate=0.0)
+TINY_VARIANTS = {
+    "g18_teacher_dlayers1": HP.teacher_hparams(dlayers=1, **_OPT),
+    "g18_teacher_dlayers3": HP.teacher_hparams(dlayers=3, **_OPT),
+    "g19_teacher_prenet1": HP.teacher_hparams(prenet_layers=1, **_OPT),
+    "g19_teacher_prenet3": HP.teacher_hparams(prenet_layers=3, **_OPT),
+    "g20_teacher_elayers2": HP.teacher_hparams(elayers=2, **_OPT),
+}

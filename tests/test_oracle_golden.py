@@ -441,6 +441,27 @@ def test_g17_layer_counts(golden):
     assert _check_grads(sd, g) >= 12
 
 
+@pytest.mark.parametrize("name", ["g18_teacher_dlayers1", "g18_teacher_dlayers3", "g19_teacher_prenet1", "g19_teacher_prenet3", "g20_teacher_elayers2"])
+def test_g18_g19_g20_structure_options(golden, name):
+    """`dlayers` 1 / 3 (decoder_sa.py:357-369, 500-504), `prenet_layers` 1 / 3 (decoder_sa.py:119-158), `elayers` 2 (encoder_sa.py:96-100) on the
+    teacher class: inference mel and training step (losses, gradients) vs the real reference."""
+    from helpers import TINY_VARIANTS
+
+    hp = TINY_VARIANTS[name]
+    g4, g = golden("g4_integer"), golden(name + "_inference")
+    with torch.no_grad():
+        out = O.inference(torch_state_dict(hp), hp, torch.from_numpy(g["x"]), dur=torch.from_numpy(g["dur"]))
+    assert max_abs(out["after"], g["after"]) < TOL_STAGE
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    g = golden(name)
+    sd = _grad_sd(hp)
+    rep = O.model_forward(sd, hp, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 10
+
+
 def test_g13_speaker_embeddings(golden):
     """`spk_embed_dim`: F.normalize(spemb) appended to every encoder state (..._sa.py:555-557, 636-638).  Inference mel, the teacher step and the KD
     teacher's 5-tuple vs the real reference (the KD student cannot run with speaker embeddings in the reference: records.json)."""
