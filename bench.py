@@ -687,14 +687,15 @@ def main():
     caps = engine.Caps.for_batches(host_maps, slack_steps=args.cap_slack)
     fresh = args.feed == "fresh" and not args.eager
     if args.eager:
-        streams = [torch.cuda.Stream(device=dev) for _ in range(args.streams)] if args.streams > 1 else [torch.cuda.current_stream()]
+        streams = engine.shared_streams(dev, args.streams) if args.streams > 1 else [torch.cuda.current_stream()]
 
         def one_pass(i, seed):
             with torch.cuda.stream(streams[i % len(streams)]):
                 engine.run(plan, prep, ops.DROP_RNG, seed=seed)
             return frames
     elif fresh:
-        runners = [engine.BatchRunner(plan, args.batch, T_CAP, caps, forced=True, seed=77 + 1000 * j) for j in range(args.streams)]
+        pass_streams = engine.shared_streams(dev, args.streams)  # one pool per process: every later runner set and the decode driver reuse these queues
+        runners = [engine.BatchRunner(plan, args.batch, T_CAP, caps, forced=True, stream=pass_streams[j], seed=77 + 1000 * j) for j in range(args.streams)]
 
         def one_pass(i, seed):
             r, j = runners[i % len(runners)], i % len(batches)
@@ -702,7 +703,8 @@ def main():
             r.replay()
             return bframes[j]
     else:
-        runners = [engine.GraphRunner(plan, prep, seed=77 + 1000 * j) for j in range(args.streams)]
+        pass_streams = engine.shared_streams(dev, args.streams)
+        runners = [engine.GraphRunner(plan, prep, stream=pass_streams[j], seed=77 + 1000 * j) for j in range(args.streams)]
 
         def one_pass(i, seed):
             runners[i % len(runners)].replay()

@@ -23,7 +23,9 @@ class DecoderWeights(C.Structure):
     ] + [("zoneout_rate", _F), ("prenet_dropout", _F)] + [
         (n + sfx, _P) for n in ("prenet_w0", "prenet_w1", "w0_pre", "w0_hh", "w1_ih", "w1_hh", "wf_h") for sfx in ("_hi", "_lo")] + [
         (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")] + [("out_act", _I), ("wf_h_ff", _P), ("prenet_w0_ff", _P), ("prenet_w1_ff", _P),
-                                                                                           ("w0_pre_ff", _P), ("w0_hh_ff", _P), ("w1_ih_ff", _P), ("w1_hh_ff", _P), ("stream", _P)]
+                                                                                           ("w0_pre_ff", _P), ("w0_hh_ff", _P), ("w1_ih_ff", _P), ("w1_hh_ff", _P), ("stream", _P),
+                                                                                           ("prenet_layers", _I), ("dlayers", _I), ("prenet_w2", _P), ("prenet_b2", _P), ("w2_ih", _P),
+                                                                                           ("w2_hh", _P), ("b2", _P)]
 
 
 class DecoderIO(C.Structure):
@@ -84,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 413  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 414  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t

@@ -81,6 +81,7 @@ static inline size_t align_up(size_t x) { return (x + 127) & ~(size_t)127; }  //
 
 struct DecoderWs {
     float *G0, *F0, *pre_a, *pre_b, *h0[2], *c0, *h1[2], *c1, *prev;
+    float *h2[2], *c2;  // third cell (fcl_decoder_weights_t.dlayers == 3)
     unsigned short *h0_p[2], *h1_p[2], *pre_p;  // P32 planes of the recurrent states / the prenet output (the LSTM steps' pre-split operands)
     size_t bytes, state_bytes;                  // state_bytes: h0 .. h1_p, zeroed before the loop
 };
@@ -109,6 +110,11 @@ static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
     ws.c0 = take(N * w->u);
     ws.h1[0] = take(N * w->u);
     ws.c1 = take(N * w->u);
+    ws.h2[0] = ws.h2[1] = ws.c2 = nullptr;
+    if (w->dlayers == 3) {  // inside the zeroed region
+        ws.h2[0] = take(N * w->u);
+        ws.c2 = take(N * w->u);
+    }
     ws.h0_p[0] = reinterpret_cast<unsigned short*>(take(N * w->u));  // as many bytes as the fp32 form (2 x 2 bytes per element)
     ws.h1_p[0] = reinterpret_cast<unsigned short*>(take(N * w->u));
     ws.prev = take(N * w->odim);
@@ -118,6 +124,7 @@ static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
     ws.h0_p[1] = reinterpret_cast<unsigned short*>(take(N * w->u));
     ws.h1_p[1] = reinterpret_cast<unsigned short*>(take(N * w->u));
     ws.pre_p = reinterpret_cast<unsigned short*>(take(N * w->p));
+    if (w->dlayers == 3) ws.h2[1] = take(N * w->u);
     ws.bytes = off;
     return ws;
 }
@@ -292,6 +299,101 @@ int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries) {
     return n;
 }
 
+
+// The loop for a decoder whose cell / prenet block counts are not the shipped (2, 2) (fcl_decoder_weights_t.dlayers / prenet_layers): the same
+// arithmetic launch by launch on the fp32 operands -- hoists as in the main form, then per step feat_out(t - 1) as a GEMM with the frame scatter in
+// its epilogue, one GEMM per prenet block (bias + ReLU + always-on dropout in the epilogue), one LSTM-step launch per cell.
+// /root/reference/nets/modules/decoder_sa.py:119-158 (Prenet), :357-369 (the cell stack), :590-617 (the inference loop), :472-515 (teacher forcing).
+static int decoder_loop_generic(const fcl_decoder_weights_t* w, const fcl_decoder_io_t* io, hipStream_t s) {
+    const int PL = w->prenet_layers ? w->prenet_layers : 2, DL = w->dlayers ? w->dlayers : 2;
+    FCL_REQUIRE(PL >= 1 && PL <= 3 && DL >= 1 && DL <= 3, FCL_ERR_SHAPE, "decoder_loop_fwd: prenet_layers %d / dlayers %d (1 .. 3 are implemented)", PL, DL);
+    FCL_REQUIRE(PL < 3 || (w->prenet_w2 && w->prenet_b2), FCL_ERR_INVALID, "decoder_loop_fwd: prenet_layers 3 needs prenet_w2 / prenet_b2");
+    FCL_REQUIRE(PL < 2 || (w->prenet_w1 && w->prenet_b1), FCL_ERR_INVALID, "decoder_loop_fwd: prenet_layers >= 2 needs prenet_w1 / prenet_b1");
+    FCL_REQUIRE(DL < 2 || (w->w1_ih && w->w1_hh && w->b1), FCL_ERR_INVALID, "decoder_loop_fwd: dlayers >= 2 needs w1_ih / w1_hh / b1");
+    FCL_REQUIRE(DL < 3 || (w->w2_ih && w->w2_hh && w->b2), FCL_ERR_INVALID, "decoder_loop_fwd: dlayers 3 needs w2_ih / w2_hh / b2");
+    FCL_REQUIRE(!io->live_rows && !io->tail_from, FCL_ERR_INVALID, "decoder_loop_fwd: device row counts / tail_from need the (2, 2) decoder structure");
+    FCL_REQUIRE(io->att_c, FCL_ERR_INVALID, "decoder_loop_fwd: this decoder structure runs on the fp32 operands: att_c is required");
+    const int N = io->n, C = w->c, P = w->p, U = w->u, O = w->odim;
+    DecoderWs ws = carve(w, N, io->workspace);
+    hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, ws.h0[0], (long long)(ws.state_bytes / 4));
+    FCL_HIP(hipGetLastError());
+    {
+        GemmArgs g = {};
+        g.term[0] = GemmTerm{io->att_c, w->w0_att, C, C, C, 0};
+        g.nterms = 1; g.M = N; g.N = 4 * U; g.bias = w->b0; g.Y = ws.G0; g.ldy = 4 * U;
+        int rc = launch_gemm(g, s);
+        if (rc) return rc;
+        GemmArgs f = {};
+        f.term[0] = GemmTerm{io->att_c, w->wf_att, C, C, C, 0};
+        f.nterms = 1; f.M = N; f.N = O; f.Y = ws.F0; f.ldy = O;
+        rc = launch_gemm(f, s);
+        if (rc) return rc;
+    }
+    const float keep_scale = 1.0f / (1.0f - w->prenet_dropout);
+    const int drop_mode = (w->prenet_dropout > 0.f) ? io->dropout_mode : FCL_DROP_NONE;
+    const float* pw[3] = {w->prenet_w0, w->prenet_w1, w->prenet_w2};
+    const float* pb[3] = {w->prenet_b0, w->prenet_b1, w->prenet_b2};
+    const float* wih[3] = {nullptr, w->w1_ih, w->w2_ih};
+    const float* whh[3] = {w->w0_hh, w->w1_hh, w->w2_hh};
+    const float* bl[3] = {nullptr, w->b1, w->b2};
+    float* hh[3][2] = {{ws.h0[0], ws.h0[1]}, {ws.h1[0], ws.h1[1]}, {ws.h2[0], ws.h2[1]}};
+    float* cc[3] = {ws.c0, ws.c1, ws.c2};
+    int cur = 0;
+    for (int t = 0; t <= io->lmax; ++t) {
+        const int n = t < io->lmax ? io->live_rows_host[t] : 0, n_prev = t > 0 ? io->live_rows_host[t - 1] : 0;
+        const float* teacher_in = (io->teacher_ys && t > 0) ? io->teacher_ys + (size_t)(t - 1) * O : nullptr;
+        int rc;
+        if (t > 0) {  // feat_out(t - 1) on the last cell's new state (+ frame scatter); the fed-back frame is activated (decoder_sa.py:614-617), `before` is raw
+            GemmArgs f = {};
+            f.term[0] = GemmTerm{hh[DL - 1][cur], w->wf_h, U, U, U, 0};
+            f.nterms = 1; f.M = n_prev; f.N = O; f.C0 = ws.F0; f.ldc0 = O; f.Y = ws.prev; f.ldy = O;
+            f.Y2 = io->before; f.ldy2 = O; f.y2_row_base = io->frame_off; f.y2_row_add = t - 1;
+            rc = launch_gemm(f, s);
+            if (rc) return rc;
+            if (w->out_act != FCL_ACT_NONE && t < io->lmax && !teacher_in) {
+                rc = fcl_act_fwd(ws.prev, nullptr, 1.0f, ws.prev, nullptr, 0, (size_t)n_prev * O, w->out_act, (fcl_stream_t)s);
+                if (rc) return rc;
+            }
+        }
+        if (t == io->lmax) break;
+        // prenet: PL x {Linear -> ReLU -> dropout (always on)}; the last block's output lands in pre_b
+        const float* x = teacher_in ? teacher_in : ws.prev;
+        int ldx = teacher_in ? io->lmax * O : O, kx = O;
+        for (int l = 0; l < PL; ++l) {
+            float* y = ((PL - 1 - l) & 1) ? ws.pre_a : ws.pre_b;
+            GemmArgs p0 = {};
+            p0.term[0] = GemmTerm{x, pw[l], ldx, kx, kx, 0};
+            p0.nterms = 1; p0.M = n; p0.N = P; p0.bias = pb[l]; p0.act = FCL_ACT_RELU; p0.Y = y; p0.ldy = P;
+            p0.drop_mode = drop_mode; p0.keep_scale = keep_scale; p0.drop_p = w->prenet_dropout;
+            p0.keep = drop_mode == FCL_DROP_MASK ? io->prenet_keep + ((size_t)(t * PL + l) * N) * P : nullptr;
+            p0.ldkeep = P; p0.rng_seed = io->seed * 2654435761u + (unsigned)(t * PL + l); p0.seed_dev = io->seed_dev;
+            if (l == PL - 1 && io->tap_prenet) { p0.Y2 = io->tap_prenet; p0.ldy2 = P; p0.y2_row_base = io->frame_off; p0.y2_row_add = t; }
+            rc = launch_gemm(p0, s);
+            if (rc) return rc;
+            x = y; ldx = P; kx = P;
+        }
+        for (int l = 0; l < DL; ++l) {
+            LstmStepArgs a = {};
+            if (l == 0) {
+                a.term[0] = GemmTerm{ws.pre_b, w->w0_pre, P, P, P, 0};
+                a.G = ws.G0; a.g_row_mul = 1; a.rank1_w = w->w0_pos; a.dur = io->dur;
+            } else {
+                a.term[0] = GemmTerm{hh[l - 1][cur ^ 1], wih[l], U, U, U, 0};
+                a.bias = bl[l];
+            }
+            a.term[1] = GemmTerm{hh[l][cur], whh[l], U, U, U, 0};
+            a.nterms = 2; a.M = n; a.U = U; a.step = t;
+            a.h_in = hh[l][cur]; a.h_out = hh[l][cur ^ 1]; a.c = cc[l]; a.zoneout = w->zoneout_rate;
+            float* tap = l == 0 ? io->tap_lstm0 : (l == DL - 1 ? io->tap_lstm1 : nullptr);  // (one cell: tap_lstm0 alone is written)
+            if (tap) { a.out2 = tap; a.out2_row_base = io->frame_off; a.out2_row_add = t; a.ld2 = U; }
+            rc = launch_lstm_step(a, s);
+            if (rc) return rc;
+        }
+        cur ^= 1;
+    }
+    return 0;
+}
+
 size_t fcl_decoder_loop_workspace_bytes(const fcl_decoder_weights_t* w, int n) {
     if (!w || n <= 0) return 0;
     return carve(w, n, nullptr).bytes + 256;
@@ -312,8 +414,9 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
     FCL_REQUIRE(w && io, FCL_ERR_INVALID, "decoder_loop_fwd: null argument");
     FCL_REQUIRE(w->c > 0 && w->p > 0 && w->u > 0 && w->odim > 0 && !(w->c & 3) && !(w->p & 3) && !(w->u & 3) && !(w->odim & 3),
                 FCL_ERR_SHAPE, "decoder_loop_fwd: C/P/U/odim must be positive multiples of 4 (got %d/%d/%d/%d)", w->c, w->p, w->u, w->odim);
-    FCL_REQUIRE(w->prenet_w0 && w->prenet_b0 && w->prenet_w1 && w->prenet_b1 && w->w0_att && w->w0_pre && w->w0_pos && w->w0_hh && w->b0 &&
-                    w->w1_ih && w->w1_hh && w->b1 && w->wf_h && w->wf_att,
+    const bool generic = (w->prenet_layers != 0 && w->prenet_layers != 2) || (w->dlayers != 0 && w->dlayers != 2);
+    FCL_REQUIRE(w->prenet_w0 && w->prenet_b0 && w->w0_att && w->w0_pre && w->w0_pos && w->w0_hh && w->b0 && w->wf_h && w->wf_att &&
+                    (generic || (w->prenet_w1 && w->prenet_b1 && w->w1_ih && w->w1_hh && w->b1)),
                 FCL_ERR_INVALID, "decoder_loop_fwd: null weight pointer");
     FCL_REQUIRE(io->n >= 0 && io->lmax >= 0, FCL_ERR_SHAPE, "decoder_loop_fwd: bad N=%d Lmax=%d", io->n, io->lmax);
     if (io->n == 0 || io->lmax == 0) return 0;
@@ -335,6 +438,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
         }
     }
     hipStream_t s = (hipStream_t)stream;
+    if (generic) return decoder_loop_generic(w, io, s);
     const int N = io->n, C = w->c, P = w->p, U = w->u, O = w->odim;
     DecoderWs ws = carve(w, N, io->workspace);
 

@@ -162,13 +162,15 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
     frames = 0
     depth = max(1, int(depth))
     cache = plan.__dict__.setdefault("_decode_cache", {})
-    streams = cache.setdefault(("streams", depth), [torch.cuda.Stream(device=dev) for _ in range(depth)])
+    streams = engine.shared_streams(dev, depth)  # the process's pass streams (one pool per device: see engine.shared_streams)
     import collections
 
     pools = cache.setdefault(("pools", batch_size, depth), collections.OrderedDict())
     max_buckets = max(1, int(MAX_BUCKETS if max_buckets is None else max_buckets))
     pending = []
     n_eager = n_graph = n_redo = n_evict = 0
+    # dlayers / prenet_layers / elayers other than 2 / 2 / 1 run on the fp32-operand loop with host row counts (fcl_decoder_weights_t.dlayers ...)
+    eager_only = bool(getattr(plan, "generic_decoder", False)) or plan.hp.elayers != 1
 
     # the ark / scp file is written by a worker thread (file writes release the GIL): storage keeps up with the GPU instead of stalling the loop
     wq = queue.Queue(maxsize=4 * (depth + 1))
@@ -233,6 +235,11 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
         try:
             for bi, s in enumerate(range(0, len(order), batch_size)):
                 chunk = [utts[i] for i in order[s : s + batch_size]]
+                if eager_only:  # structure options beyond the shipped recipes: the launch-by-launch pass (no capacity graphs for them)
+                    got, _ = eager(chunk)
+                    frames += got
+                    n_eager += 1
+                    continue
                 t_cap = (max(len(u[1]) for u in chunk) + 15) // 16 * 16
                 pool = pools.get(t_cap)
                 if pool is not None:

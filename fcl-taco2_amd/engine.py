@@ -116,6 +116,8 @@ def _predictors_grouped(grp, hs_p, seg_lo, seg_hi, pad_u8, m, masked):
 def use_planes(plan):
     """Pre-split (P32) operands end to end: on by default (FCL_PRECISION=0 / FCL_PLANES=0 turn it off), needs whole 32-column lines."""
     hp = plan.hp
+    if getattr(plan, "generic_decoder", False) or hp.elayers != 1:  # structure options beyond the shipped recipes: the fp32-operand path end to end
+        return False
     return (ops.planes_enabled() and plan.enc_convs[0].wpp is not None and plan.decoder.struct.w0_att_p is not None
             and all(x % 32 == 0 for x in (hp.embed_dim, hp.econv_chans, hp.eunits, hp.adim, hp.postnet_chans, hp.duration_predictor_chans,
                                           hp.variance_predictor_chans)))
@@ -294,8 +296,10 @@ def encode(plan, prep, bilstm_algo=0, planes=False, row_maps=None):
     x = ops.embedding(prep.ids, plan.embed)
     for cv in plan.enc_convs:
         x = ops.conv1d(x, cv.wp, cv.bias, prep.seg_lo, prep.seg_hi, ops.ACT_RELU, residual=x if res else None)
-    return ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo,
-                      row_maps=row_maps)
+    for i, bl in enumerate(plan.blstm_layers):  # (`elayers` > 1: the stacked layers run one after the other; use_planes() is off for them)
+        x = ops.bilstm(x, prep.lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], prep.B, prep.T, bilstm_algo,
+                       row_maps=row_maps if i == 0 else None)
+    return x
 
 
 class _DevMaps(object):
@@ -429,6 +433,23 @@ def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_
         mels.append(after[s : s + n])
         s += n
     return (mels, out[2]) if return_intermediates else mels
+
+
+_SHARED_STREAMS = {}
+
+
+def shared_streams(device, n):
+    """The first `n` of this process's synthesis streams on `device` (created on first use, then reused by every runner set and by the decode
+    driver).  This device runs FOUR concurrently active HIP queues well and falls off a cliff at the fifth, and the runtime
+    maps streams onto its hardware queues round-robin: a second set of four streams created beside an idle first set can land two ACTIVE streams
+    on one queue (the decode driver inside bench.py measured 28.6 M frames/s on its own fresh streams against 38 M in a process that had created
+    no others).  One pool per device keeps the pass streams of a process the same four queues whoever drives them."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    pool = _SHARED_STREAMS.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
 
 
 class GraphRunner(object):

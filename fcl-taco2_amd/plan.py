@@ -97,12 +97,16 @@ class SynthesisPlan(object):
         with torch.cuda.device(self.device):
             self.embed = g("enc.embed.weight")
             self.enc_convs = [self._conv_bn(g, "enc.convs.%d" % i) for i in range(hp.econv_layers)]
-            self.blstm = {}
-            for sfx, tag in (("", "f"), ("_reverse", "r")):
-                self.blstm["w_ih_" + tag] = g("enc.blstm.weight_ih_l0" + sfx)
-                self.blstm["w_hh_" + tag] = g("enc.blstm.weight_hh_l0" + sfx)
-                self.blstm["b_" + tag] = ops.add_vec(g("enc.blstm.bias_ih_l0" + sfx), g("enc.blstm.bias_hh_l0" + sfx))
-                self.blstm["w_ih_p_" + tag] = ops.pack_planes(self.blstm["w_ih_" + tag]) if ops.planes_enabled() else None
+            self.blstm_layers = []  # `elayers` stacked bidirectional layers (encoder_sa.py:96-100); layer l > 0 reads [forward | reverse] of layer l - 1
+            for l in range(hp.elayers):
+                bl = {}
+                for sfx, tag in (("", "f"), ("_reverse", "r")):
+                    bl["w_ih_" + tag] = g("enc.blstm.weight_ih_l%d%s" % (l, sfx))
+                    bl["w_hh_" + tag] = g("enc.blstm.weight_hh_l%d%s" % (l, sfx))
+                    bl["b_" + tag] = ops.add_vec(g("enc.blstm.bias_ih_l%d%s" % (l, sfx)), g("enc.blstm.bias_hh_l%d%s" % (l, sfx)))
+                    bl["w_ih_p_" + tag] = ops.pack_planes(bl["w_ih_" + tag]) if ops.planes_enabled() else None
+                self.blstm_layers.append(bl)
+            self.blstm = self.blstm_layers[0]
             self.duration = self._predictor(g, "duration_predictor", hp.duration_predictor_layers)
             self.pitch = self._predictor(g, "pitch_predictor", hp.variance_predictor_layers)
             self.energy = self._predictor(g, "energy_predictor", hp.variance_predictor_layers)
@@ -160,19 +164,31 @@ class SynthesisPlan(object):
         zeros = lambda *shape: torch.zeros(*shape, device=self.device, dtype=torch.float32)
         t = dict(
             prenet_w0=g("dec.prenet.prenet.0.0.weight"), prenet_b0=g("dec.prenet.prenet.0.0.bias"),
-            prenet_w1=g("dec.prenet.prenet.1.0.weight"), prenet_b1=g("dec.prenet.prenet.1.0.bias"),
             w0_att=ops.copy_cols(w_ih0, 0, C), w0_pre=ops.copy_cols(w_ih0, C, P),
             # options off = the term is absent in the reference: a zero block here (same kernels, one shape)
             w0_pos=ops.copy_cols(w_ih0, C + P, 1).reshape(-1) if hp.append_position else zeros(4 * U),
             w0_hh=lk(0, "weight_hh"),
             b0=ops.add_vec(lk(0, "bias_ih"), lk(0, "bias_hh")),
-            w1_ih=lk(1, "weight_ih"), w1_hh=lk(1, "weight_hh"),
-            b1=ops.add_vec(lk(1, "bias_ih"), lk(1, "bias_hh")),
             wf_h=ops.copy_cols(wf, 0, U), wf_att=ops.copy_cols(wf, U, C) if hp.use_concate else zeros(O, C),
         )
+        # the shipped structure: two prenet blocks, two cells; other counts (decoder_sa.py:119-158, 357-369) fill the optional third slots / leave the
+        # second ones empty and run the loop launch by launch on the fp32 operands (fcl_decoder_weights_t.prenet_layers / dlayers)
+        self.generic_decoder = (hp.prenet_layers, hp.dlayers) != (2, 2)
+        for l in range(1, hp.prenet_layers):
+            t["prenet_w%d" % l], t["prenet_b%d" % l] = g("dec.prenet.prenet.%d.0.weight" % l), g("dec.prenet.prenet.%d.0.bias" % l)
+        for l in range(1, hp.dlayers):
+            t["w%d_ih" % l], t["w%d_hh" % l] = lk(l, "weight_ih"), lk(l, "weight_hh")
+            t["b%d" % l] = ops.add_vec(lk(l, "bias_ih"), lk(l, "bias_hh"))
+        if self.generic_decoder:
+            s.prenet_layers, s.dlayers = hp.prenet_layers, hp.dlayers
         for k, v in t.items():
             setattr(s, k, v.data_ptr())
             d.keep.append(v)
+        if self.generic_decoder:
+            s.zoneout_rate = float(hp.zoneout_rate)
+            s.prenet_dropout = float(hp.dropout_rate)
+            s.out_act = output_act_code(hp)
+            return d
         # fragment-major bf16x3 planes for the small-tile decoder kernels
         import os
         if os.environ.get("FCL_PRECISION", "1") != "0" and U % 16 == 0 and all(x % 8 == 0 for x in (C, P, O)):

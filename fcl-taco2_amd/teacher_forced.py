@@ -58,7 +58,9 @@ def forward_pass(plan, batch, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=
             r.enc_taps.append(x)
         bl = plan.blstm
         lens_dev = torch.from_numpy(lens_np.astype(np.int32)).to(dev)
-        hs = ops.bilstm(x, lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], B, T)
+        hs = x
+        for bl in plan.blstm_layers:
+            hs = ops.bilstm(hs, lens_dev, bl["w_ih_f"], bl["w_hh_f"], bl["b_f"], bl["w_ih_r"], bl["w_hh_r"], bl["b_r"], B, T)
         r.hs = hs  # (the encoder-KD tap: BEFORE the speaker embedding is appended, encoder_sa_kd.py:178-188)
         if hp.spk_embed_dim is not None:  # hs <- cat[hs, F.normalize(spembs)] (..._sa.py:555-557)
             if batch.get("spembs") is None:

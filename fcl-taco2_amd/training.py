@@ -364,6 +364,8 @@ class _NativeStep(object):
         widths = (hp.embed_dim, hp.econv_chans, hp.dunits, hp.prenet_units, hp.postnet_chans, hp.duration_predictor_chans, hp.variance_predictor_chans)
         if any(v % 32 for v in widths) or hp.eunits % 64 or hp.odim % 4 or not (hp.embed_dim == hp.econv_chans == hp.eunits):
             return "channel widths that are not multiples of 32"
+        if (hp.elayers, hp.dlayers, hp.prenet_layers) != (1, 2, 2):
+            return "elayers / dlayers / prenet_layers other than 1 / 2 / 2 (the native routine issues the shipped structure's launches)"
         if eng.role == "student" and eng.distill[2] and hp.postnet_layers != 5:
             return "decoder distillation with postnet_layers != 5"
         if eng.role == "student" and eng.distill[1] and hp.econv_layers != 3:
@@ -556,6 +558,11 @@ class TrainEngine(object):
         if self.role in ("student", "kd_teacher") and (self.hp.econv_layers != 3 or self.hp.postnet_layers != 5):
             raise NotImplementedError("fcl-taco2_amd: KD training needs econv_layers 3 and postnet_layers 5: the reference's KD classes index fixed lists of "
                                       "encoder / postnet taps and raise IndexError otherwise (tests/golden/records.json)")
+        if self.role in ("student", "kd_teacher") and self.hp.dlayers != 2:
+            # the reference's KD decoder taps cells 0 and 1 by index (decoder_sa_kd.py:626-627): IndexError with one cell (records.json); with three it
+            # runs, tapping the MIDDLE cell -- not built here (no shipped recipe, no golden): refused rather than guessed
+            raise NotImplementedError("fcl-taco2_amd: KD training needs dlayers 2 (the reference's KD decoder taps lstm cells 0 and 1 by index: "
+                                      "decoder_sa_kd.py:626-627); the teacher class trains with dlayers 1 .. 3")
         if self.role != "kd_teacher":  # the frozen KD teacher computes no loss
             self.hp.check_loss_supported()
         self.share_proj = bool(getattr(model, "share_proj", True))
@@ -1068,14 +1075,16 @@ class TrainEngine(object):
         return dx
 
     # ------------------------------------------------------------------------------------------------ BiLSTM (per-step, saved)
-    def _bilstm_fwd(self, x, lens_dev, B, T, save=True, perm=None, xp=None):
-        """Returns (out, cache, P32 planes of out or None).  xp: P32 planes of x (the input projections then run on the pre-split kernels)."""
+    def _bilstm_fwd(self, x, lens_dev, B, T, save=True, perm=None, xp=None, layer=0):
+        """One bidirectional layer (`elayers` > 1: the caller stacks them, encoder_sa.py:96-100).  Returns (out, cache, P32 planes of out or None).
+        xp: P32 planes of x (the input projections then run on the pre-split kernels)."""
         P, dev = self.P, self.dev
         H = self.hp.eunits // 2
+        L = "_l%d" % layer
         use_p = xp is not None and x.shape[1] % 32 == 0 and (2 * H) % 32 == 0
-        wip = [self._wplanes("enc.blstm.weight_ih_l0" + sfx, P["enc.blstm.weight_ih_l0" + sfx]) for sfx in ("", "_reverse")] if use_p else None
+        wip = [self._wplanes("enc.blstm.weight_ih" + L + sfx, P["enc.blstm.weight_ih" + L + sfx]) for sfx in ("", "_reverse")] if use_p else None
         if not save:  # forward only (the frozen KD teacher): the persistent register-resident kernel of the synthesis path
-            g = lambda k: P["enc.blstm." + k]
+            g = lambda k: P["enc.blstm." + k.replace("_l0", L)]
             r = ops.bilstm(x, lens_dev, g("weight_ih_l0"), g("weight_hh_l0"), self._bsum(g("bias_ih_l0"), g("bias_hh_l0")),
                            g("weight_ih_l0_reverse"), g("weight_hh_l0_reverse"), self._bsum(g("bias_ih_l0_reverse"), g("bias_hh_l0_reverse")),
                            B, T, algo=3 if H == 256 else 0, status=self.status,  # one group kernel at a time (this engine's stream)
@@ -1084,37 +1093,38 @@ class TrainEngine(object):
         out = torch.empty(B * T, 2 * H, device=dev)
         gx, whh, sv = [], [], []
         for d, sfx in enumerate(("", "_reverse")):
-            bias = self._bsum(P["enc.blstm.bias_ih_l0" + sfx], P["enc.blstm.bias_hh_l0" + sfx])
+            bias = self._bsum(P["enc.blstm.bias_ih" + L + sfx], P["enc.blstm.bias_hh" + L + sfx])
             if use_p:
                 gx.append(ops.linear_planes(xp, wip[d], 4 * H, x.shape[1], bias)[0])
             else:
-                gx.append(ops.linear(x, P["enc.blstm.weight_ih_l0" + sfx], bias))  # [B*T, 4H]
-            whh.append(P["enc.blstm.weight_hh_l0" + sfx])
+                gx.append(ops.linear(x, P["enc.blstm.weight_ih" + L + sfx], bias))  # [B*T, 4H]
+            whh.append(P["enc.blstm.weight_hh" + L + sfx])
             # gates, c_new, c_old, h_old (t-major); zero-filled: dead cells are never written but are read by the batched weight-gradient GEMM
             sv.append([self._z((T, B, 4 * H))] + [self._z((T, B, H)) for _ in range(3)])
         ops.bilstm_train_fwd(gx, whh, lens_dev, B, T, out, sv, status=self.status)
-        return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev, perm=perm), (ops.pack_planes(out) if use_p else None)
+        return out, dict(x=x, dirs=sv, B=B, T=T, lens=lens_dev, perm=perm, layer=layer), (ops.pack_planes(out) if use_p else None)
 
     def _bilstm_bwd(self, d_out, c):
         P, G, dev = self.P, self.G, self.dev
         B, T, H = c["B"], c["T"], self.hp.eunits // 2
+        L = "_l%d" % c.get("layer", 0)
         dx = self._z(c["x"].shape)
         perm = c["perm"]  # (b, t) row -> t-major row of the saved / gradient tensors
         sfxs = ("", "_reverse")
         dgs = [torch.empty(T, B, 4 * H, device=dev) for _ in sfxs]  # d_out is already zero on padded rows (masked by the caller); dead cells get dg = 0
-        ops.bilstm_bptt(c["dirs"], c["lens"], B, T, d_out, [self._wt(P["enc.blstm.weight_hh_l0" + sfx]) for sfx in sfxs], dgs, status=self.status)
+        ops.bilstm_bptt(c["dirs"], c["lens"], B, T, d_out, [self._wt(P["enc.blstm.weight_hh" + L + sfx]) for sfx in sfxs], dgs, status=self.status)
         for d, sfx in enumerate(sfxs):
             dg2 = dgs[d].reshape(T * B, 4 * H)
             dgx = ops.gather_rows(dg2, perm)  # back to (b, t) rows like x
 
             def dw(dg2=dg2, dgx=dgx, d=d, sfx=sfx):
-                ops.gemm_tn(dg2, c["dirs"][d][3].reshape(T * B, H), G["enc.blstm.weight_hh_l0" + sfx])  # one TN GEMM over every (t, b) cell
-                ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih_l0" + sfx])
+                ops.gemm_tn(dg2, c["dirs"][d][3].reshape(T * B, H), G["enc.blstm.weight_hh" + L + sfx])  # one TN GEMM over every (t, b) cell
+                ops.gemm_tn(dgx, c["x"], G["enc.blstm.weight_ih" + L + sfx])
                 # bias_ih and bias_hh enter the gates as a sum: the same column sums, straight into both accumulators (one launch)
-                ops.colsum(dgx, G["enc.blstm.bias_ih_l0" + sfx], out_x=G["enc.blstm.bias_hh_l0" + sfx])
+                ops.colsum(dgx, G["enc.blstm.bias_ih" + L + sfx], out_x=G["enc.blstm.bias_hh" + L + sfx])
 
             self._dw(dw)
-            ops.add2d(dx, ops.linear(dgx, self._wt(P["enc.blstm.weight_ih_l0" + sfx])))
+            ops.add2d(dx, ops.linear(dgx, self._wt(P["enc.blstm.weight_ih" + L + sfx])))
         return dx
 
     # ------------------------------------------------------------------------------------------------ index maps (host, integers)
@@ -1146,6 +1156,60 @@ class TrainEngine(object):
         a = np.asarray(arr)[: c.lmax][:, c.order]
         return _u8(np.concatenate([a[t, : c.live[t]] for t in range(c.lmax)]), self.dev)
 
+    # ------------------------------------------------------------------------------------------------ decoder cell stack, any depth
+    def _decoder_cells_fwd(self, c, G0, w0_pos):
+        """`dlayers` != 2 (decoder_sa.py:357-369, 500-504: a stack of ZoneOut LSTMCells, cell l > 0 on cell l - 1's NEW state): one fcl_lstm_step_fwd
+        per (step, cell) over the step-major cells, saving what the reverse pass needs.  The two-cell recipe has its own C loop
+        (fcl_decoder_train_fwd); this is the launch-by-launch form of the same step."""
+        hp, P, dev = self.hp, self.P, self.dev
+        U, Pn, DL, N = hp.dunits, hp.prenet_units, hp.dlayers, c.N
+        lk = lambda l, n: lstm_key(hp, l, n)
+        h = [[torch.zeros(N, U, device=dev), torch.zeros(N, U, device=dev)] for _ in range(DL)]
+        cst = [torch.zeros(N, U, device=dev) for _ in range(DL)]
+        bs = [None] + [self._bsum(P[lk(l, "bias_ih")], P[lk(l, "bias_hh")]) for l in range(1, DL)]
+        cur = 0
+        for t in range(c.lmax):
+            n, o = int(c.live[t]), int(c.offs[t])
+            for l in range(DL):
+                kw = dict(step=t, zoneout=c.zr, out2=c.h_all[l][o:], out2_row_mul=1, ld2=U, save=[q[o:] for q in c.S[l]])
+                if c.zk is not None:
+                    kw.update(zone_keep_h=c.zk[l][0][o:], zone_keep_c=c.zk[l][1][o:])
+                if l == 0:
+                    terms = [(c.p1d[o : o + n], c.w0_pre, Pn), (h[0][cur], c.w0_hh, U)]
+                    kw.update(G=G0, g_row_mul=1, rank1_w=w0_pos, dur=c.dur_dev)
+                else:
+                    terms = [(h[l - 1][cur ^ 1], P[lk(l, "weight_ih")], U), (h[l][cur], P[lk(l, "weight_hh")], U)]
+                    kw.update(bias=bs[l])
+                ops.lstm_step(terms, n, U, h[l][cur], h[l][cur ^ 1], cst[l], **kw)
+            cur ^= 1
+
+    def _decoder_cells_bptt(self, c, dh_last_all):
+        """Reverse pass of _decoder_cells_fwd: gate gradients dg[l] [F, 4U] of every cell.  Per step, top cell first: the cell's backward from its
+        saved activations (carry from step t + 1 + this step's output gradient), dh carry <- keep path + dg . W_hh, and dg . W_ih as the output
+        gradient of the cell below at the same step."""
+        hp, P, dev = self.hp, self.P, self.dev
+        U, DL, N, F = hp.dunits, hp.dlayers, c.N, c.F
+        lk = lambda l, n: lstm_key(hp, l, n)
+        dg = [torch.empty(F, 4 * U, device=dev) for _ in range(DL)]
+        dh = [torch.zeros(N, U, device=dev) for _ in range(DL)]  # rows that only become live at earlier steps must see zero carries
+        dc = [torch.zeros(N, U, device=dev) for _ in range(DL)]
+        whh_t = [self._wt(P[lk(l, "weight_hh")]) for l in range(DL)]
+        wih_t = [None] + [self._wt(P[lk(l, "weight_ih")]) for l in range(1, DL)]
+        for t in range(c.lmax - 1, -1, -1):
+            n, o = int(c.live[t]), int(c.offs[t])
+            below = dh_last_all[o : o + n]  # output gradient of the top cell at this step (feat_out, KD taps)
+            for l in range(DL - 1, -1, -1):
+                S = c.S[l]
+                zk = (c.zk[l][0][o : o + n], c.zk[l][1][o : o + n]) if c.zk is not None else (None, None)
+                dgl, dh_old, dc_old = ops.lstm_cell_bwd(S[0][o : o + n], S[2][o : o + n], S[1][o : o + n], dh[l][:n], dc[l][:n], c.zr, zk[0], zk[1],
+                                                        out=(dg[l][o : o + n], torch.empty(n, U, device=dev), torch.empty(n, U, device=dev)), dh_out2=below)
+                ops.add2d(dh_old, ops.linear(dgl, whh_t[l]))
+                ops.copy2d(dh[l][:n], dh_old)
+                ops.copy2d(dc[l][:n], dc_old)
+                if l > 0:
+                    below = ops.linear(dgl, wih_t[l])
+        return dg
+
     # ------------------------------------------------------------------------------------------------ forward
     def _forward(self, c, batch):
         hp, dev, P = self.hp, self.dev, self.P
@@ -1176,6 +1240,10 @@ class TrainEngine(object):
             c.conv_c.append(cc)
             c.enc_taps.append(x)
         c.hs, c.bl_c, hs_p = self._bilstm_fwd(x, c.lens_dev, B, T, save=c.save, perm=c.perm_tb, xp=xp)
+        c.bl_stack = [c.bl_c]
+        for l in range(1, hp.elayers):  # stacked layers (encoder_sa.py:96-100): layer l reads [forward | reverse] of layer l - 1
+            c.hs, bl_l, hs_p = self._bilstm_fwd(c.hs, c.lens_dev, B, T, save=c.save, perm=c.perm_tb, xp=hs_p, layer=l)
+            c.bl_stack.append(bl_l)
         c.hs_enc = c.hs  # the encoder's own output: the KD tap (encoder_sa_kd.py:178-188) and what the BiLSTM's backward receives
         if hp.spk_embed_dim is not None:  # hs <- cat[hs, F.normalize(spembs)] (..._sa.py:555-557); the embeddings are inputs: no gradient leaves here
             if batch.get("spembs") is None:
@@ -1229,32 +1297,36 @@ class TrainEngine(object):
             c.pre_in, pre_in_p = ops.gather_rows(c.ys, c.prev_frame, want_planes=True)  # [F, O]; idx -1 -> zero row
         else:
             c.pre_in = ops.gather_rows(c.ys, c.prev_frame)
-        c.k0 = c.k1 = None
+        PL, DL = hp.prenet_layers, hp.dlayers  # (2, 2) in every shipped recipe; other counts: decoder_sa.py:119-158, 357-369 (G18 / G19)
+        c.pre_keep = [None] * PL
         c.pks = 1.0
         if hp.dropout_rate > 0:  # the prenet's dropout is on in BOTH modes (decoder_sa.py:156-158)
             c.pks = 1.0 / (1.0 - hp.dropout_rate)
             if c.masks is not None:
                 pk = np.asarray(c.masks["prenet"])
-                c.k0, c.k1 = self._cells(c, pk[:, 0]), self._cells(c, pk[:, 1])
-            else:  # (with the zoneout masks of a train-mode pass: one launch for the decoder's six mask tensors)
-                sites = [(("prenet", 0), (F, Pn), 1.0 - hp.dropout_rate), (("prenet", 1), (F, Pn), 1.0 - hp.dropout_rate)]
+                c.pre_keep = [self._cells(c, pk[:, l]) for l in range(PL)]
+            else:  # (with the zoneout masks of a train-mode pass: one launch for the decoder's mask tensors)
+                sites = [(("prenet", l), (F, Pn), 1.0 - hp.dropout_rate) for l in range(PL)]
                 if c.train and float(hp.zoneout_rate) > 0:
-                    sites += [(("zoneout", l, j), (F, U), float(hp.zoneout_rate)) for l in range(2) for j in range(2)]
+                    sites += [(("zoneout", l, j), (F, U), float(hp.zoneout_rate)) for l in range(DL) for j in range(2)]
                 dk = self._keeps(c, sites)
-                c.k0, c.k1 = dk[0], dk[1]
-                c.zk_pre = [[dk[2 + 2 * l + j] for j in range(2)] for l in range(2)] if len(dk) == 6 else None
-        w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
-        p1d_p = None
-        if dpl:
-            c.p0 = ops.linear_planes(pre_in_p, self._wplanes(w0n, P[w0n]), Pn, O, P[b0n], ops.ACT_RELU)[0]  # pre-dropout activations are kept
-            c.p0d, p0d_p = ops.act_fwd(c.p0, ops.ACT_NONE, c.k0, c.pks, want_planes=True)
-            c.p1 = ops.linear_planes(p0d_p, self._wplanes(w1n, P[w1n]), Pn, Pn, P[b1n], ops.ACT_RELU)[0]
-            c.p1d, p1d_p = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks, want_planes=True)
-        else:
-            c.p0 = ops.linear(c.pre_in, P[w0n], P[b0n], ops.ACT_RELU)  # pre-dropout activations are kept
-            c.p0d = ops.act_fwd(c.p0, ops.ACT_NONE, c.k0, c.pks) if c.k0 is not None else c.p0
-            c.p1 = ops.linear(c.p0d, P[w1n], P[b1n], ops.ACT_RELU)
-            c.p1d = ops.act_fwd(c.p1, ops.ACT_NONE, c.k1, c.pks) if c.k1 is not None else c.p1
+                c.pre_keep = list(dk[:PL])
+                c.zk_pre = [[dk[PL + 2 * l + j] for j in range(2)] for l in range(DL)] if len(dk) == PL + 2 * DL else None
+        # prenet: PL x {Linear -> ReLU -> dropout}; the pre-dropout activations are kept for the backward
+        c.pre_act, c.pre_drop = [], []
+        x, x_p, kin = c.pre_in, pre_in_p, O
+        for l in range(PL):
+            wn, bn = "dec.prenet.prenet.%d.0.weight" % l, "dec.prenet.prenet.%d.0.bias" % l
+            if dpl:
+                a = ops.linear_planes(x_p, self._wplanes(wn, P[wn]), Pn, kin, P[bn], ops.ACT_RELU)[0]
+                d, d_p = ops.act_fwd(a, ops.ACT_NONE, c.pre_keep[l], c.pks, want_planes=True)
+            else:
+                a = ops.linear(x, P[wn], P[bn], ops.ACT_RELU)
+                d, d_p = (ops.act_fwd(a, ops.ACT_NONE, c.pre_keep[l], c.pks) if c.pre_keep[l] is not None else a), None
+            c.pre_act.append(a)
+            c.pre_drop.append(d)
+            x, x_p, kin = d, d_p, Pn
+        c.p1d, p1d_p = x, x_p  # the prenet's output (what LSTM 0 reads; the KD tap)
         lk = lambda l, n: lstm_key(hp, l, n)
         w_ih0 = P[lk(0, "weight_ih")]
         c.w0_att, c.w0_pre = self._cols(w_ih0, 0, C), self._cols(w_ih0, C, Pn)
@@ -1262,8 +1334,6 @@ class TrainEngine(object):
         w0_pos = self._cols(w_ih0, C + Pn, 1).reshape(-1) if hp.append_position else self._zeros_const("w0_pos0", (4 * U,))
         c.w0_hh = P[lk(0, "weight_hh")]
         b0s = self._bsum(P[lk(0, "bias_ih")], P[lk(0, "bias_hh")])
-        c.w1_ih, c.w1_hh = P[lk(1, "weight_ih")], P[lk(1, "weight_hh")]
-        b1s = self._bsum(P[lk(1, "bias_ih")], P[lk(1, "bias_hh")])
         wf = P["dec.feat_out.weight"]
         c.wf_h = self._cols(wf, 0, U)
         c.wf_att = self._cols(wf, U, C) if hp.use_concate else self._zeros_const("wf_att0", (O, C))
@@ -1278,20 +1348,27 @@ class TrainEngine(object):
         if c.train and c.zr > 0:  # sampled zoneout: mask = 1 keeps the OLD state, P(1) = rate; [layer][h, c] -> [F, U]
             if c.masks is not None:
                 zm = np.asarray(c.masks["zoneout"])
-                c.zk = [[self._cells(c, zm[:, l, j]) for j in range(2)] for l in range(2)]
+                c.zk = [[self._cells(c, zm[:, l, j]) for j in range(2)] for l in range(DL)]
             elif getattr(c, "zk_pre", None) is not None:
                 c.zk = c.zk_pre
             else:
-                c.zk = [[dk_ for dk_ in self._keeps(c, [(("zoneout", l, j), (F, U), c.zr) for j in range(2)])] for l in range(2)]
-        c.S0 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]  # gates, c_new, c_old, h_old
-        c.S1 = [torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)]
-        c.h0_all, c.h1_all = torch.empty(F, U, device=dev), torch.empty(F, U, device=dev)  # zoneout-ed outputs per cell
-        dec_planes = None
-        if dpl and (N * U * 4) % 128 == 0:  # big steps on the LDS-DMA kernels (pre-split operands)
-            dec_planes = (p1d_p, self._wplanes("w0_pre", c.w0_pre), self._wplanes("w0_hh", c.w0_hh),
-                          self._wplanes("w1_ih", c.w1_ih), self._wplanes("w1_hh", c.w1_hh))
-        ops.decoder_train_fwd(c.live_i32, c.p1d, G0, c.w0_pre, c.w0_hh, w0_pos, c.dur_dev, c.w1_ih, c.w1_hh, b1s, c.zr, c.zk, c.S0, c.S1, c.h0_all,
-                              c.h1_all, planes=dec_planes)
+                c.zk = [[dk_ for dk_ in self._keeps(c, [(("zoneout", l, j), (F, U), c.zr) for j in range(2)])] for l in range(DL)]
+        # per cell: saved (gates, c_new, c_old, h_old) and the zoneout-ed output of every cell
+        c.S = [[torch.empty(F, 4 * U, device=dev)] + [torch.empty(F, U, device=dev) for _ in range(3)] for _ in range(DL)]
+        c.h_all = [torch.empty(F, U, device=dev) for _ in range(DL)]
+        c.S0, c.h0_all = c.S[0], c.h_all[0]
+        c.S1, c.h1_all = c.S[-1], c.h_all[-1]  # (the LAST cell: what feat_out reads)
+        if DL == 2:
+            c.w1_ih, c.w1_hh = P[lk(1, "weight_ih")], P[lk(1, "weight_hh")]
+            b1s = self._bsum(P[lk(1, "bias_ih")], P[lk(1, "bias_hh")])
+            dec_planes = None
+            if dpl and (N * U * 4) % 128 == 0:  # big steps on the LDS-DMA kernels (pre-split operands)
+                dec_planes = (p1d_p, self._wplanes("w0_pre", c.w0_pre), self._wplanes("w0_hh", c.w0_hh),
+                              self._wplanes("w1_ih", c.w1_ih), self._wplanes("w1_hh", c.w1_hh))
+            ops.decoder_train_fwd(c.live_i32, c.p1d, G0, c.w0_pre, c.w0_hh, w0_pos, c.dur_dev, c.w1_ih, c.w1_hh, b1s, c.zr, c.zk, c.S0, c.S1, c.h0_all,
+                                  c.h1_all, planes=dec_planes)
+        else:
+            self._decoder_cells_fwd(c, G0, w0_pos)
         if dpl:
             out_cells = ops.linear_planes(ops.pack_planes(c.h1_all), self._wplanes("wf_h", c.wf_h), O, U)[0]
         else:
@@ -1455,28 +1532,35 @@ class TrainEngine(object):
         if hp.use_concate:
             self._dw(lambda: ops.gemm_tn(dF0, c.att_c, g_wf[:, U:]))
         d_att_c = ops.linear(dF0, self._wt(c.wf_att))
-        dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
-        w1_ih_t, w1_hh_t, w0_hh_t, w0_pre_t = self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh), self._wt(c.w0_pre)
+        DL, PL = hp.dlayers, hp.prenet_layers
+        w0_pre_t = self._wt(c.w0_pre)
         bpl = None
-        if ops.planes_enabled() and U % 8 == 0:  # the recurrence's GEMMs on pre-split operands: the cell-backward kernel writes dgates as planes too
-            dg0_p, dg1_p = ops.planes_empty(F, 4 * U, dev), ops.planes_empty(F, 4 * U, dev)
-            bpl = (self._wplanes("w1_ih_t", w1_ih_t), self._wplanes("w1_hh_t", w1_hh_t), self._wplanes("w0_hh_t", w0_hh_t), dg0_p, dg1_p)
-        w1_cat_t = torch.cat([w1_hh_t, w1_ih_t], 0)  # [2U, 4U]: both GEMMs that leave layer 1's gate gradients in one launch per step
-        w1_cat = (w1_cat_t, self._wplanes("w1_cat_t", w1_cat_t) if bpl is not None else None)
-        ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=bpl,
-                         w1_cat=w1_cat)
+        if DL == 2:
+            dg0_all, dg1_all = torch.empty(F, 4 * U, device=dev), torch.empty(F, 4 * U, device=dev)
+            w1_ih_t, w1_hh_t, w0_hh_t = self._wt(c.w1_ih), self._wt(c.w1_hh), self._wt(c.w0_hh)
+            if ops.planes_enabled() and U % 8 == 0:  # the recurrence's GEMMs on pre-split operands: the cell-backward kernel writes dgates as planes too
+                dg0_p, dg1_p = ops.planes_empty(F, 4 * U, dev), ops.planes_empty(F, 4 * U, dev)
+                bpl = (self._wplanes("w1_ih_t", w1_ih_t), self._wplanes("w1_hh_t", w1_hh_t), self._wplanes("w0_hh_t", w0_hh_t), dg0_p, dg1_p)
+            w1_cat_t = torch.cat([w1_hh_t, w1_ih_t], 0)  # [2U, 4U]: both GEMMs that leave layer 1's gate gradients in one launch per step
+            w1_cat = (w1_cat_t, self._wplanes("w1_cat_t", w1_cat_t) if bpl is not None else None)
+            ops.decoder_bptt(c.live_i32, N, c.S0, c.S1, c.zr, c.zk, dh1_all, inj.get("h0"), w1_ih_t, w1_hh_t, w0_hh_t, dg0_all, dg1_all, planes=bpl,
+                             w1_cat=w1_cat)
+            dgs = [dg0_all, dg1_all]
+        else:  # any other depth: the launch-by-launch reverse pass (G18); KD taps on the cells do not exist there (the reference's KD classes fail)
+            dgs = self._decoder_cells_bptt(c, dh1_all)
+            dg0_all = dgs[0]
         if bpl is not None:  # [F, P]: gradient w.r.t. the prenet output of every cell
             dp1_all = ops.linear_planes(bpl[3], self._wplanes("w0_pre_t", w0_pre_t), Pn, 4 * U)[0]
         else:
             dp1_all = ops.linear(dg0_all, w0_pre_t)
-        S0, S1 = c.S0, c.S1
         g_ih0 = G[lk(0, "weight_ih")]  # [4U, C + P (+ 1)] = [att_c | prenet (| position)]
 
-        def dw_cells():  # weight gradients of the two cells from the saved step-major tensors (one TN GEMM each)
-            self._dw_gemm(dg1_all, [(c.h0_all, G[lk(1, "weight_ih")]), (S1[3], G[lk(1, "weight_hh")])])
-            for l, dg in ((0, dg0_all), (1, dg1_all)):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
+        def dw_cells():  # weight gradients of the cells from the saved step-major tensors (one TN GEMM each)
+            for l in range(DL - 1, 0, -1):
+                self._dw_gemm(dgs[l], [(c.h_all[l - 1], G[lk(l, "weight_ih")]), (c.S[l][3], G[lk(l, "weight_hh")])])
+            for l, dg in enumerate(dgs):  # bias_ih and bias_hh enter the gates as a sum: identical gradients
                 ops.colsum(dg, G[lk(l, "bias_ih")], out_x=G[lk(l, "bias_hh")])
-            self._dw_gemm(dg0_all, [(S0[3], G[lk(0, "weight_hh")]), (c.p1d, g_ih0[:, C : C + Pn])])
+            self._dw_gemm(dg0_all, [(c.S[0][3], G[lk(0, "weight_hh")]), (c.p1d, g_ih0[:, C : C + Pn])])
             if hp.append_position:
                 dw0_pos4 = self._z((4 * U, 4))
                 ops.gemm_tn(dg0_all, c.pos4, dw0_pos4)
@@ -1487,21 +1571,19 @@ class TrainEngine(object):
         ops.scatter_add_rows(dg0_all, c.cell_row_i64, dG0)
         self._dw(lambda: ops.gemm_tn(dG0, c.att_c, g_ih0[:, :C]))
         ops.add2d(d_att_c, ops.linear(dG0, self._wt(c.w0_att)))
-        # prenet (batched over all cells)
-        w0n, b0n, w1n, b1n = ["dec.prenet.prenet.%d.0.%s" % (l, s) for l in (0, 1) for s in ("weight", "bias")]
+        # prenet (batched over all cells), last block first
         if "p1d" in inj:
             ops.add2d(dp1_all, inj["p1d"])
-        if bpl is not None and Pn % 32 == 0:
-            dz1, dz1_p = ops.act_bwd(dp1_all, c.p1, ops.ACT_RELU, c.k1, c.pks, want_planes=True)
-        else:
-            dz1, dz1_p = ops.act_bwd(dp1_all, c.p1, ops.ACT_RELU, c.k1, c.pks), None
-        self._dw(lambda: (ops.gemm_tn(dz1, c.p0d, G[w1n]), ops.colsum(dz1, G[b1n])))
-        if dz1_p is not None:
-            dp0 = ops.linear_planes(dz1_p, self._wplanes(w1n + ".t", self._wt(P[w1n])), Pn, Pn)[0]
-        else:
-            dp0 = ops.linear(dz1, self._wt(P[w1n]))
-        dz0 = ops.act_bwd(dp0, c.p0, ops.ACT_RELU, c.k0, c.pks)
-        self._dw(lambda: (ops.gemm_tn(dz0, c.pre_in, G[w0n]), ops.colsum(dz0, G[b0n])))
+        d = dp1_all
+        for l in range(PL - 1, -1, -1):
+            wn, bn = "dec.prenet.prenet.%d.0.weight" % l, "dec.prenet.prenet.%d.0.bias" % l
+            want_p = l > 0 and bpl is not None and Pn % 32 == 0
+            r = ops.act_bwd(d, c.pre_act[l], ops.ACT_RELU, c.pre_keep[l], c.pks, want_planes=want_p)
+            dz, dz_p = r if want_p else (r, None)
+            inp = c.pre_drop[l - 1] if l > 0 else c.pre_in
+            self._dw(lambda dz=dz, inp=inp, wn=wn, bn=bn: (ops.gemm_tn(dz, inp, G[wn]), ops.colsum(dz, G[bn])))
+            if l > 0:
+                d = ops.linear_planes(dz_p, self._wplanes(wn + ".t", self._wt(P[wn])), Pn, Pn)[0] if dz_p is not None else ops.linear(dz, self._wt(P[wn]))
         self._launch_bucket(c, 1)
         # ---- att = hs + p_embs + e_embs
         d_att = ops.gather_rows(d_att_c, c.row_of_enc)  # back to (b, t) rows; rows without a phoneme get 0
@@ -1528,7 +1610,9 @@ class TrainEngine(object):
         if hp.spk_embed_dim is not None:
             d_hs = ops.copy_cols(d_hs, 0, hp.eunits)  # the speaker-embedding columns are inputs; the encoder sees the first eunits only
         d_hs_live = ops.add2d(self._z(d_hs.shape), d_hs, row_valid=c.enc_valid)  # pad_packed_sequence: padded outputs are constants
-        dx = self._bilstm_bwd(d_hs_live, c.bl_c)
+        dx = d_hs_live
+        for bl_l in reversed(c.bl_stack):  # (dead cells get dg = 0, so the gradient handed to the layer below is zero on padded rows as well)
+            dx = self._bilstm_bwd(dx, bl_l)
         for i in range(len(c.conv_c) - 1, -1, -1):
             if "enc%d" % (i + 1) in inj:
                 ops.add2d(dx, inj["enc%d" % (i + 1)])

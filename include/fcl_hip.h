@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 413
+#define FCL_ABI_VERSION 414
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -287,6 +287,15 @@ typedef struct {
                              * (fcl_decoder_stream_pack; fcl_decoder_stream_bytes() bytes, 0 = shape not covered).  With it, the P32 planes above and
                              * a free-running loop of >= FCL_DEC_TILE_MIN_ROWS rows (no teacher forcing, taps or injected masks), fcl_decoder_loop_fwd
                              * runs the whole loop as ONE launch: 32 rows per workgroup, states resident in LDS / registers for all their steps */
+    /* ---- structure options beyond the shipped recipes (round 5; /root/reference/nets/modules/decoder_sa.py:119-158, 357-369, 500-504) ----
+     * prenet_layers: 0 or 2 = the two blocks above; 1 = prenet_w0 / prenet_b0 alone; 3 = a third block prenet_w2 [P, P] / prenet_b2 [P].
+     * dlayers: 0 or 2 = the two cells above; 1 = cell 0 alone (w1_* / b1 unused, feat_out reads cell 0); 3 = a third cell w2_ih [4U, U],
+     * w2_hh [4U, U], b2 [4U] on cell 1's new state (feat_out reads it).  Anything but (2, 2) runs the loop launch by launch on the fp32
+     * operands (one GEMM per prenet block, one LSTM-step launch per cell, feat_out as a GEMM): host row counts only (fcl_decoder_io_t.live_rows
+     * and tail_from are refused), prenet_keep is then [Lmax, prenet_layers, N, P], tap_lstm1 the LAST cell's state. */
+    int prenet_layers;
+    int dlayers;
+    const float *prenet_w2, *prenet_b2, *w2_ih, *w2_hh, *b2;
 } fcl_decoder_weights_t;
 
 typedef struct {

@@ -127,12 +127,15 @@ def test_exact_fp32_mode_in_a_child_process_meets_the_reference_goldens():
     subprocess (this process keeps running and holds its own GPU context)."""
     env = dict(os.environ, FCL_PRECISION="0")
     sel = ("test_g2_student_c1_mel_vs_reference or test_g2t_teacher_c1_mel_vs_reference or test_g3_injected_dropout_vs_reference "
-           "or test_decoder_loop_vs_oracle or test_the_bench_timed_configuration_equals_eager_and_the_oracle")
+           "or test_decoder_loop_vs_oracle or test_the_bench_timed_configuration_equals_eager_and_the_oracle "
+           # (round 5) the training-step tests whose default-arithmetic form needs a loose gradient tolerance (ill-conditioned closed-form nets):
+           # here every tensor is held at 5e-4 against the reference and the oracle
+           "or test_structure_options_vs_reference_g18_g19_g20 or test_no_batch_norm_vs_reference_g15")
     cmd = [sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_gpu_bench_config.py"),
-           "-m", "gpu", "-q", "-x", "-k", sel, "-p", "no:cacheprovider"]
+           os.path.join(ROOT, "tests", "test_gpu_training.py"), "-m", "gpu", "-q", "-x", "-k", sel, "-p", "no:cacheprovider"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     tail = "\n".join((r.stdout + "\n" + r.stderr).strip().splitlines()[-25:])
     assert r.returncode == 0, "the FCL_PRECISION=0 child failed:\n" + tail
     assert " passed" in r.stdout and "failed" not in r.stdout.splitlines()[-1], tail
     n_passed = int(r.stdout.strip().splitlines()[-1].split(" passed")[0].split()[-1])
-    assert n_passed >= 12, tail  # G2 + G2T + G3 + 8 decoder-loop cases + the bench configuration
+    assert n_passed >= 17, tail  # G2 + G2T + G3 + 8 decoder-loop cases + the bench configuration + 5 structure variants (+ G15)

@@ -59,8 +59,8 @@ def random_masks(hp, batch, seed):
         m[nm + "_predictor"] = [keep((B, T, hp.variance_predictor_chans), 1.0 - hp.variance_predictor_dropout_rate) for _ in range(hp.variance_predictor_layers)]
     m["pitch_embed"] = keep((B, T, hp.eunits), 1.0 - hp.variance_embed_dropout_rate)
     m["energy_embed"] = keep((B, T, hp.eunits), 1.0 - hp.variance_embed_dropout_rate)
-    m["prenet"] = keep((steps, 2, N, hp.prenet_units), 1.0 - hp.dropout_rate) if hp.dropout_rate > 0 else None
-    m["zoneout"] = keep((steps, 2, 2, N, hp.dunits), hp.zoneout_rate)
+    m["prenet"] = keep((steps, hp.prenet_layers, N, hp.prenet_units), 1.0 - hp.dropout_rate) if hp.dropout_rate > 0 else None
+    m["zoneout"] = keep((steps, hp.dlayers, 2, N, hp.dunits), hp.zoneout_rate)
     chans = [hp.postnet_chans] * (hp.postnet_layers - 1) + [hp.odim]
     m["postnet"] = [keep((B, L, c), 1.0 - hp.dropout_rate) for c in chans] if hp.dropout_rate > 0 else None
     return m
