@@ -173,6 +173,7 @@ int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int
     GemmArgs g = {};
     for (int j = 0; j < k; ++j) g.term[j] = GemmTerm{x, wp + (size_t)j * cout * cin, cin, cin, cin, j - (k - 1) / 2};
     g.nterms = k;
+    g.conv_k = k >= 3 ? k : 0;  // one Conv1d: same input, tap-major contiguous weights -> the stencil kernel may load each input tile once (exact-fp32 lines, round 5)
     g.M = m;
     g.N = cout;
     g.seg_lo = seg_lo;
@@ -202,8 +203,9 @@ int fcl_linear_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
     return launch_gemm(g, (hipStream_t)stream);
 }
 
-int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
-                          const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, fcl_stream_t stream) {
+int fcl_conv1d_planes_rows_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
+                               const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, const int32_t* m_dev,
+                               fcl_stream_t stream) {
     FCL_REQUIRE(xp && wpp && (y || yp) && seg_lo && seg_hi, FCL_ERR_INVALID, "conv1d_planes_fwd: null argument");
     FCL_REQUIRE(k >= 1 && (k & 1) && k <= FCL_MAX_TERMS, FCL_ERR_SHAPE, "conv1d_planes_fwd: kernel size %d must be odd and <= %d", k, FCL_MAX_TERMS);
     FCL_REQUIRE(act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "conv1d_planes_fwd: bad act %d", act);
@@ -224,7 +226,13 @@ int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
     g.R = residual; g.ldr = cout;
     g.Y = y; g.ldy = cout;
     g.Yp = yp; g.ldyp = (cout + 31) / 32;
+    g.m_dev = m_dev;
     return launch_gemm(g, (hipStream_t)stream);
+}
+
+int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
+                          const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, fcl_stream_t stream) {
+    return fcl_conv1d_planes_rows_fwd(xp, ldxp, wpp, bias, seg_lo, seg_hi, residual, y, yp, m, cin, cout, k, act, nullptr, stream);
 }
 
 int fcl_conv1d_planes_group_fwd(const uint16_t* xp, int ldxp, int64_t x_group_stride, const uint16_t* wpp, const float* bias, const int32_t* seg_lo,

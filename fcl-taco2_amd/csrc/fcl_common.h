@@ -78,6 +78,8 @@ struct GemmArgs {
     // base + g * stride (A / W / Yp in uint16 elements, bias / Y in floats)
     long long g_a, g_w, g_bias, g_y, g_yp;
     int dbg_phase;  // developer timing aid (FCL_PGEMM_DBG): 1 = return after the main loop (results are then garbage)
+    const int* m_dev;  // optional DEVICE row count (planes kernels): tiles at or beyond *m_dev exit at once -- the frame buffers of a capacity graph
+                       // are sized with slack and nothing reads the rows past the batch's real total (fcl_conv1d_planes_rows_fwd)
 };
 
 // ---- fused LSTM step (gemm_f32.hip / decoder_step.hip): the argument block is the public fcl_lstm_step_t ----------

@@ -484,6 +484,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW), (NST == 2 && WM * WN + LW == 1
     int bx, by;
     xcd_tile_p(bx, by);
     const int m0 = by * G::BM, n0 = bx * G::BN;
+    if (a.m_dev && m0 >= *a.m_dev) return;  // tile beyond the device's row count (uniform per workgroup, before any barrier / LDS-DMA)
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -710,13 +711,17 @@ struct CGeo {
     static_assert(GAH + GB <= 60, "s_waitcnt vmcnt is a 6-bit field");
 };
 
-template <int WM, int WN, int TM, int TN, bool HI, int NL, int NSTW = 3>
+// HI: 0 = bf16x3 planes, 1 = the hi planes alone (autocast), 2 (round 5) = EXACT fp32 lines (FCL_PRECISION=0: a row-major fp32 activation / the
+// tap-major fp32 weights ARE 128-byte lines of 32 floats, see pchunk_mma<HI = 2>): the exact mode's convolutions used to run as k-term GEMMs that
+// re-fetch the input tile for every tap
+template <int WM, int WN, int TM, int TN, int HI, int NL, int NSTW = 3>
 __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmArgs a) {
     using G = CGeo<WM, WN, TM, TN, NL, NSTW>;
     extern __shared__ __attribute__((aligned(1024))) u8 smem[];
     int bx, by;
     xcd_tile_p(bx, by);
     const int m0 = by * G::BM, n0 = bx * G::BN;
+    if (a.m_dev && m0 >= *a.m_dev) return;  // tile beyond the device's row count (uniform per workgroup, before any barrier / LDS-DMA)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k = a.conv_k, pad = (k - 1) >> 1;
@@ -816,34 +821,68 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
         const int sh = j - pad;
         const u8* abase = smem + (c & 1) * G::A_BYTES;
         const u8* wb = wring + (s % G::NSTW) * G::W_BYTES;
+        if constexpr (HI == 2) {
+            f32x4 a0[TM], a1[TM], b0[TN], b1[TN];
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const int lr = (wm * TM + tm) * 16 + ar16 + G::HALO + sh;
+                const int swz = (lr >> 1) & 7;
+                const bool ok = sh >= lo_off[tm] && sh < hi_off[tm];
+                a0[tm] = *reinterpret_cast<const f32x4*>(abase + lr * 128 + ((kq ^ swz) << 4));
+                a1[tm] = *reinterpret_cast<const f32x4*>(abase + lr * 128 + (((4 + kq) ^ swz) << 4));
+                if (!ok) {
+                    a0[tm] = z4;
+                    a1[tm] = z4;
+                }
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                b0[tn] = *reinterpret_cast<const f32x4*>(wb + b_hi + tn * 16 * 128);
+                b1[tn] = *reinterpret_cast<const f32x4*>(wb + b_lo + tn * 16 * 128);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[tm][e], b0[tn][e], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[tm][e], b1[tn][e], acc[tm][tn], 0, 0, 0);
+        } else {
         s16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int lr = (wm * TM + tm) * 16 + ar16 + G::HALO + sh;
-            const int swz = (lr >> 1) & 7;
-            const bool ok = sh >= lo_off[tm] && sh < hi_off[tm];
-            ah[tm] = *reinterpret_cast<const s16x8*>(abase + lr * 128 + ((kq ^ swz) << 4));
-            if (!HI) al[tm] = *reinterpret_cast<const s16x8*>(abase + lr * 128 + (((4 + kq) ^ swz) << 4));
-            if (!ok) {
-                ah[tm] = zero8;
-                al[tm] = zero8;
-            }
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            bh[tn] = *reinterpret_cast<const s16x8*>(wb + b_hi + tn * 16 * 128);
-            if (!HI) bl[tn] = *reinterpret_cast<const s16x8*>(wb + b_lo + tn * 16 * 128);
-        }
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            if (!HI) {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            for (int tm = 0; tm < TM; ++tm) {
+                const int lr = (wm * TM + tm) * 16 + ar16 + G::HALO + sh;
+                const int swz = (lr >> 1) & 7;
+                const bool ok = sh >= lo_off[tm] && sh < hi_off[tm];
+                ah[tm] = *reinterpret_cast<const s16x8*>(abase + lr * 128 + ((kq ^ swz) << 4));
+                if (!HI) al[tm] = *reinterpret_cast<const s16x8*>(abase + lr * 128 + (((4 + kq) ^ swz) << 4));
+                if (!ok) {
+                    ah[tm] = zero8;
+                    al[tm] = zero8;
+                }
             }
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn) {
+                bh[tn] = *reinterpret_cast<const s16x8*>(wb + b_hi + tn * 16 * 128);
+                if (!HI) bl[tn] = *reinterpret_cast<const s16x8*>(wb + b_lo + tn * 16 * 128);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                if (!HI) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                }
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            }
         }
         if (++j == k) { j = 0; ++c; }
     }
@@ -853,21 +892,24 @@ __global__ __launch_bounds__(64 * (WM * WN + NL)) void pconv_kernel(const GemmAr
 template <int WM, int WN, int TM, int TN, int NL, int NSTW = 3>
 static int launch_pconv_nl(const GemmArgs& a, hipStream_t s, double flops) {
     using G = CGeo<WM, WN, TM, TN, NL, NSTW>;
-    const bool hi = gemm_mode() == FCL_GEMM_BF16;
-    const void* fn = hi ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, true, NL, NSTW>) : reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, false, NL, NSTW>);
+    const bool hi = gemm_mode() == FCL_GEMM_BF16 && !t_exact_lines;
+    const void* fn = t_exact_lines ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, 2, NL, NSTW>)
+                     : hi          ? reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, 1, NL, NSTW>)
+                                   : reinterpret_cast<const void*>(pconv_kernel<WM, WN, TM, TN, 0, NL, NSTW>);
     const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
     if (rc) return rc;
     const int ncols = a.Yp ? max(a.N, a.ldyp * 32) : a.N;
     const int groups = (a.g_a || a.g_w || a.g_y || a.g_yp) ? max(1, a.nblk) : 1;  // (nblk carries the group count of a grouped Conv1d)
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM, groups);
     char full[48];
-    snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NL, NSTW == 2 ? "/2st" : "", hi ? "/bf16" : "");
+    snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NL, NSTW == 2 ? "/2st" : "", t_exact_lines ? "/f32" : hi ? "/bf16" : "");
     ProfScope ps(full, flops, a.M, s);
     static const int dbg = tunable("PGEMM_DBG", 0);
     GemmArgs b = a;
     b.dbg_phase = dbg;
-    if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, true, NL, NSTW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
-    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, false, NL, NSTW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+    if (t_exact_lines) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, 2, NL, NSTW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+    else if (hi) hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, 1, NL, NSTW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
+    else hipLaunchKernelGGL((pconv_kernel<WM, WN, TM, TN, 0, NL, NSTW>), grid, dim3(G::THREADS), G::LDS_BYTES, s, b);
     return check_hip(hipGetLastError(), "pconv launch");
 }
 
@@ -895,7 +937,10 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     // 25 026 x 128 x 5 x 128: 24.7 vs 25.6); its smaller LDS footprint (44 vs 64 KB, 86 vs 96 KB) and 10 instead of 12 waves are what raise the
     // pass rate with several passes in flight (+1.7 ... +4 %, batch 64 +3.6 %).  At Cin >= 512 (FCL-taco2-T: 33.8 vs 28.0, 124 vs 115 us) the
     // single-stream training step loses 2 % with it, so those keep the K-term form (PCONV=2 forces the stencil everywhere).
-    if (pconv && a.conv_k >= 3 && a.conv_k <= 17 && !a.accumulate && (a.term[0].K <= 384 || pconv >= 2)) {
+    // exact-fp32 lines (round 5, pconv_kernel<HI = 2>): built, parity-green under FCL_PRECISION=0 and SLOWER -- 22.6 vs 23.2 M frames/s on the
+    // four-stream line: that mode's loops are bound by their 32-cycle fp32 MFMAs, not by the input-tile re-fetch the stencil saves -> opt-in
+    static const int pconv_exact = tunable("PCONV_EXACT", 0);
+    if (pconv && (!t_exact_lines || pconv_exact) && a.conv_k >= 3 && a.conv_k <= 17 && !a.accumulate && (a.term[0].K <= 384 || pconv >= 2)) {
         static const int cbig_min = tunable("PCONV_BIG_MIN", 150);
         if (force == 1 || (force == 0 && t128x128 >= cbig_min && a.N >= 128)) return launch_pconv_cfg<4, 2, 2, 4>(a, s, flops);
         if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pconv_cfg<2, 2, 2, 4>(a, s, flops);

@@ -393,10 +393,12 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
         n_post = len(plan.postnet)
         if planes:
             before, xp = before
+            # device-built maps: the frame buffers are capacities (decode driver: x 1.3 slack) -- tiles beyond the batch's real total are skipped
+            f_dev = frames_info.totals[:1] if frames_info is not None else None
             for i, cv in enumerate(plan.postnet):
                 last = i == n_post - 1
                 x, xp = ops.conv1d_planes(xp, cv, rm.frame_lo, rm.frame_hi, ops.ACT_NONE if last else ops.ACT_TANH, residual=before if last else None,
-                                          want_f32=last, want_planes=not last)
+                                          want_f32=last, want_planes=not last, m_dev=f_dev)
         else:
             x = before
             for i, cv in enumerate(plan.postnet):

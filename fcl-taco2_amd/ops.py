@@ -175,15 +175,16 @@ def conv1d(x, wp, bias, seg_lo, seg_hi, act=ACT_NONE, residual=None):
     return y
 
 
-def conv1d_planes(xp, cv, seg_lo, seg_hi, act=ACT_NONE, residual=None, want_f32=False, want_planes=True):
+def conv1d_planes(xp, cv, seg_lo, seg_hi, act=ACT_NONE, residual=None, want_f32=False, want_planes=True, m_dev=None):
     """Conv1d on pre-split operands: xp = P32 planes of x [m, cin]; cv: a plan ConvPack with .wpp (planes of the packed taps).
-    Returns (y fp32 or None, y planes or None)."""
+    Returns (y fp32 or None, y planes or None).  m_dev: device int32 row count -- tiles at or beyond it are skipped (capacity buffers)."""
     m = xp.shape[0]
     ldxp = xp.shape[1] // 64
     y = torch.empty(m, cv.cout, device=xp.device, dtype=torch.float32) if want_f32 else None
     yp = planes_empty(m, cv.cout, xp.device) if want_planes else None
-    check(_lib.load().fcl_conv1d_planes_fwd(_p(xp, torch.int16), ldxp, _p(cv.wpp, torch.int16), _p(cv.bias), _p(seg_lo, torch.int32),
-                                            _p(seg_hi, torch.int32), _p(residual), _p(y), _p(yp, torch.int16), m, cv.cin, cv.cout, cv.k, act, _stream()))
+    check(_lib.load().fcl_conv1d_planes_rows_fwd(_p(xp, torch.int16), ldxp, _p(cv.wpp, torch.int16), _p(cv.bias), _p(seg_lo, torch.int32),
+                                                 _p(seg_hi, torch.int32), _p(residual), _p(y), _p(yp, torch.int16), m, cv.cin, cv.cout, cv.k, act,
+                                                 _p(m_dev, torch.int32), _stream()))
     return y, yp
 
 

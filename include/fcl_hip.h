@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 414
+#define FCL_ABI_VERSION 415
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -128,6 +128,12 @@ int fcl_linear_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
                           int m, int n, int k, int act, fcl_stream_t stream);
 int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
                           const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, fcl_stream_t stream);
+/* fcl_conv1d_planes_fwd with a DEVICE row count (round 5): m is then the capacity of the buffers and tiles at or beyond *m_dev are not computed
+ * (their output rows are left untouched).  The postnet of a capacity graph: the frame buffers carry slack (decode driver: x 1.3) and the batch's real
+ * frame total lives in HBM (fcl_row_maps_t.totals[0]); nothing reads the rows beyond it (/root/reference/nets/modules/decoder_sa.py:199-263). */
+int fcl_conv1d_planes_rows_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
+                               const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, const int32_t* m_dev,
+                               fcl_stream_t stream);
 
 /* G independent Conv1d's of the SAME shape in one launch (the duration / pitch / energy predictors' layers, variance_predictor.py:48-66): group g
  * reads planes xp + g * x_group_stride (uint16 elements; 0 = all groups read the same input), weights wpp [G][k * Cout][Cin planes] (each group
