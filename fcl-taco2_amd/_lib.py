@@ -25,7 +25,7 @@ class DecoderWeights(C.Structure):
         (n + "_p", _P) for n in ("w0_att", "wf_att", "w0_pre", "w0_hh", "w1_ih", "w1_hh")] + [("out_act", _I), ("wf_h_ff", _P), ("prenet_w0_ff", _P), ("prenet_w1_ff", _P),
                                                                                            ("w0_pre_ff", _P), ("w0_hh_ff", _P), ("w1_ih_ff", _P), ("w1_hh_ff", _P), ("stream", _P),
                                                                                            ("prenet_layers", _I), ("dlayers", _I), ("prenet_w2", _P), ("prenet_b2", _P), ("w2_ih", _P),
-                                                                                           ("w2_hh", _P), ("b2", _P)]
+                                                                                           ("w2_hh", _P), ("b2", _P), ("reduction_factor", _I)]
 
 
 class DecoderIO(C.Structure):
@@ -86,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 415  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 416  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t

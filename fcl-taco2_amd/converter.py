@@ -20,9 +20,9 @@ def _pad_list(arrs, dtype, trailing=()):
 
 class CustomConverter(object):
     def __init__(self, reduction_factor=1, use_fe_condition=False, append_position=False):
-        if reduction_factor != 1:
-            raise NotImplementedError("fcl-taco2_amd: reduction_factor > 1 is not supported")
-        self.reduction_factor = reduction_factor
+        if int(reduction_factor) < 1:
+            raise ValueError("reduction_factor must be >= 1")
+        self.reduction_factor = int(reduction_factor)  # tts.py:250-258: segments, ds_nonzeros and the position table are in FRAMES = r x the durations
         self.use_fe_condition = use_fe_condition
         self.append_position = append_position
 
@@ -44,7 +44,7 @@ class CustomConverter(object):
             seg_rows, seg_len, masks = [], [], []
             for ib in range(len(xs)):
                 d = np.asarray(extras[ib], dtype=np.float64).reshape(-1)[: ilens[ib]]
-                edges = np.concatenate([[0.0], np.cumsum(d)]).astype(np.int64)  # int(sum(ds[:it])) for every it at once
+                edges = np.concatenate([[0.0], np.cumsum(d)]).astype(np.int64) * self.reduction_factor  # int(sum(ds[:it])) * r for every it at once
                 length = edges[1:] - edges[:-1]
                 nz = length != 0
                 masks.append(nz.astype(np.int64))

@@ -100,8 +100,9 @@ static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
         return p;
     };
     const size_t N = (size_t)n;
+    const size_t RF = w->reduction_factor > 1 ? (size_t)w->reduction_factor : 1;  // frames per step: F0 / prev hold a step's r frames
     ws.G0 = take(N * 4 * w->u);
-    ws.F0 = take(N * w->odim);
+    ws.F0 = take(N * w->odim * RF);
     ws.pre_a = take(N * w->p);
     ws.pre_b = take(N * w->p);
     // what the loop READS before it writes — the states entering step 0 (fp32 and, for the pre-split path, planes) and prev_out — is contiguous, so
@@ -117,7 +118,7 @@ static DecoderWs carve(const fcl_decoder_weights_t* w, int n, void* base) {
     }
     ws.h0_p[0] = reinterpret_cast<unsigned short*>(take(N * w->u));  // as many bytes as the fp32 form (2 x 2 bytes per element)
     ws.h1_p[0] = reinterpret_cast<unsigned short*>(take(N * w->u));
-    ws.prev = take(N * w->odim);
+    ws.prev = take(N * w->odim * RF);
     ws.state_bytes = off - (size_t)(reinterpret_cast<char*>(ws.h0[0]) - reinterpret_cast<char*>(base));
     ws.h0[1] = take(N * w->u);
     ws.h1[1] = take(N * w->u);
@@ -322,6 +323,8 @@ static int decoder_loop_generic(const fcl_decoder_weights_t* w, const fcl_decode
     FCL_REQUIRE(!io->live_rows && !io->tail_from, FCL_ERR_INVALID, "decoder_loop_fwd: device row counts / tail_from need the (2, 2) decoder structure");
     FCL_REQUIRE(io->att_c, FCL_ERR_INVALID, "decoder_loop_fwd: this decoder structure runs on the fp32 operands: att_c is required");
     const int N = io->n, C = w->c, P = w->p, U = w->u, O = w->odim;
+    const int R = w->reduction_factor > 1 ? w->reduction_factor : 1, OR = O * R;  // a step emits R frames (wf_h / wf_att: [R * odim, .], frame-major rows)
+    FCL_REQUIRE(R == 1 || (!io->tap_prenet && !io->tap_lstm0 && !io->tap_lstm1), FCL_ERR_INVALID, "decoder_loop_fwd: step-level taps are frame-indexed: reduction_factor 1 only");
     DecoderWs ws = carve(w, N, io->workspace);
     hipLaunchKernelGGL(zero_kernel, dim3(512), dim3(256), 0, s, ws.h0[0], (long long)(ws.state_bytes / 4));
     FCL_HIP(hipGetLastError());
@@ -333,7 +336,7 @@ static int decoder_loop_generic(const fcl_decoder_weights_t* w, const fcl_decode
         if (rc) return rc;
         GemmArgs f = {};
         f.term[0] = GemmTerm{io->att_c, w->wf_att, C, C, C, 0};
-        f.nterms = 1; f.M = N; f.N = O; f.Y = ws.F0; f.ldy = O;
+        f.nterms = 1; f.M = N; f.N = OR; f.Y = ws.F0; f.ldy = OR;
         rc = launch_gemm(f, s);
         if (rc) return rc;
     }
@@ -349,24 +352,27 @@ static int decoder_loop_generic(const fcl_decoder_weights_t* w, const fcl_decode
     int cur = 0;
     for (int t = 0; t <= io->lmax; ++t) {
         const int n = t < io->lmax ? io->live_rows_host[t] : 0, n_prev = t > 0 ? io->live_rows_host[t - 1] : 0;
-        const float* teacher_in = (io->teacher_ys && t > 0) ? io->teacher_ys + (size_t)(t - 1) * O : nullptr;
+        // teacher forcing: step t reads the target frame that closes step t - 1's group (decoder_sa.py:487-489, 513: ys[:, r - 1 :: r]); the caller's
+        // teacher_ys holds one frame per FRAME index: [N, lmax * R, odim]
+        const float* teacher_in = (io->teacher_ys && t > 0) ? io->teacher_ys + (size_t)(t * R - 1) * O : nullptr;
         int rc;
-        if (t > 0) {  // feat_out(t - 1) on the last cell's new state (+ frame scatter); the fed-back frame is activated (decoder_sa.py:614-617), `before` is raw
+        if (t > 0) {  // feat_out(t - 1) on the last cell's new state: R frames = R * odim consecutive floats of the frame-major `before`, starting at
+                      // frame frame_off[m] + (t - 1) R; the fed-back frame (the last of them) is activated (decoder_sa.py:614-617), `before` is raw
             GemmArgs f = {};
             f.term[0] = GemmTerm{hh[DL - 1][cur], w->wf_h, U, U, U, 0};
-            f.nterms = 1; f.M = n_prev; f.N = O; f.C0 = ws.F0; f.ldc0 = O; f.Y = ws.prev; f.ldy = O;
-            f.Y2 = io->before; f.ldy2 = O; f.y2_row_base = io->frame_off; f.y2_row_add = t - 1;
+            f.nterms = 1; f.M = n_prev; f.N = OR; f.C0 = ws.F0; f.ldc0 = OR; f.Y = ws.prev; f.ldy = OR;
+            f.Y2 = io->before; f.ldy2 = O; f.y2_row_base = io->frame_off; f.y2_row_add = (t - 1) * R;
             rc = launch_gemm(f, s);
             if (rc) return rc;
             if (w->out_act != FCL_ACT_NONE && t < io->lmax && !teacher_in) {
-                rc = fcl_act_fwd(ws.prev, nullptr, 1.0f, ws.prev, nullptr, 0, (size_t)n_prev * O, w->out_act, (fcl_stream_t)s);
+                rc = fcl_act_fwd(ws.prev, nullptr, 1.0f, ws.prev, nullptr, 0, (size_t)n_prev * OR, w->out_act, (fcl_stream_t)s);
                 if (rc) return rc;
             }
         }
         if (t == io->lmax) break;
         // prenet: PL x {Linear -> ReLU -> dropout (always on)}; the last block's output lands in pre_b
-        const float* x = teacher_in ? teacher_in : ws.prev;
-        int ldx = teacher_in ? io->lmax * O : O, kx = O;
+        const float* x = teacher_in ? teacher_in : ws.prev + (size_t)(R - 1) * O;
+        int ldx = teacher_in ? io->lmax * R * O : OR, kx = O;
         for (int l = 0; l < PL; ++l) {
             float* y = ((PL - 1 - l) & 1) ? ws.pre_a : ws.pre_b;
             GemmArgs p0 = {};
@@ -422,7 +428,7 @@ int fcl_decoder_loop_fwd(const fcl_decoder_weights_t* w, const fcl_decoder_io_t*
     FCL_REQUIRE(w && io, FCL_ERR_INVALID, "decoder_loop_fwd: null argument");
     FCL_REQUIRE(w->c > 0 && w->p > 0 && w->u > 0 && w->odim > 0 && !(w->c & 3) && !(w->p & 3) && !(w->u & 3) && !(w->odim & 3),
                 FCL_ERR_SHAPE, "decoder_loop_fwd: C/P/U/odim must be positive multiples of 4 (got %d/%d/%d/%d)", w->c, w->p, w->u, w->odim);
-    const bool generic = (w->prenet_layers != 0 && w->prenet_layers != 2) || (w->dlayers != 0 && w->dlayers != 2);
+    const bool generic = (w->prenet_layers != 0 && w->prenet_layers != 2) || (w->dlayers != 0 && w->dlayers != 2) || w->reduction_factor > 1;
     FCL_REQUIRE(w->prenet_w0 && w->prenet_b0 && w->w0_att && w->w0_pre && w->w0_pos && w->w0_hh && w->b0 && w->wf_h && w->wf_att &&
                     (generic || (w->prenet_w1 && w->prenet_b1 && w->w1_ih && w->w1_hh && w->b1)),
                 FCL_ERR_INVALID, "decoder_loop_fwd: null weight pointer");

@@ -27,9 +27,11 @@ class RowMaps(object):
                  "frame_lo", "frame_hi")
 
 
-def build_row_maps(lens, durs, t_max):
+def build_row_maps(lens, durs, t_max, frames_per_step=1):
     """lens [B]; durs: list of int arrays (len_b each).  Raises AssertionError on a zero duration, like the
-    reference's `assert ds_nonzeros.shape[0] == hs.shape[0]` (decoder_sa_kd.py:739)."""
+    reference's `assert ds_nonzeros.shape[0] == hs.shape[0]` (decoder_sa_kd.py:739).
+    frames_per_step (`reduction_factor`, decoder_sa.py:573, 627): a duration unit is one decoder STEP and frames_per_step output frames --
+    live rows / lmax / dur_sorted count steps, frame offsets and frame totals count frames."""
     B = len(lens)
     lens_np = np.asarray(lens, dtype=np.int64)
     parts = [np.asarray(d).reshape(-1) for d in durs]
@@ -41,8 +43,8 @@ def build_row_maps(lens, durs, t_max):
     starts = np.zeros(B + 1, dtype=np.int64)
     np.cumsum(lens_np, out=starts[1:])
     src = np.arange(n, dtype=np.int64) + np.repeat(np.arange(B, dtype=np.int64) * t_max - starts[:-1], lens_np)  # row b * t_max + position
-    csum = np.cumsum(dur)
-    foff = csum - dur  # exclusive cumsum over the whole batch = utterance base + exclusive cumsum inside the utterance (H10)
+    csum = np.cumsum(dur) * int(frames_per_step)
+    foff = csum - dur * int(frames_per_step)  # exclusive cumsum over the whole batch = utterance base + exclusive cumsum inside the utterance (H10)
     fstarts = np.zeros(B + 1, dtype=np.int64)
     fstarts[1:] = csum[starts[1:] - 1]
     utt = fstarts[1:] - fstarts[:-1]
@@ -249,7 +251,7 @@ def prepare(plan, xs, durs=None, f0=None, energy=None, device_maps=False, spembs
             dpad[b, : p.lens[b]] = d
         blocks["dur_pad"] = dpad.reshape(-1)
     elif durs is not None:
-        p.maps = m = build_row_maps(p.lens, durs, T)
+        p.maps = m = build_row_maps(p.lens, durs, T, plan.hp.reduction_factor)
         blocks.update(src_rows=m.src_rows, dur=m.dur_sorted, frame_off=m.frame_off_sorted, frame_lo=m.frame_lo, frame_hi=m.frame_hi)
     layout, off = {}, 0
     for k, v in blocks.items():
@@ -367,7 +369,7 @@ def run(plan, prep, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0, bilstm_
                     raise ValueError("prepare(device_maps=True) leaves the row maps to the device: run() needs caps")
                 d_host = d_int.cpu().numpy().reshape(prep.B, prep.T)  # the one host sync of the predicted-duration path
                 rm = PreparedBatch()
-                _upload_maps(rm, build_row_maps(prep.lens, [d_host[b, : prep.lens[b]] for b in range(prep.B)], prep.T), dev)
+                _upload_maps(rm, build_row_maps(prep.lens, [d_host[b, : prep.lens[b]] for b in range(prep.B)], prep.T, hp.reduction_factor), dev)
         if prep.f0e is not None:
             p, e = prep.f0e[0], prep.f0e[1]
         elif p is None and grouped and plan.group_pe is not None:

@@ -76,7 +76,7 @@ class HParams:
         if self.postnet_layers < 2: bad.append("postnet_layers < 2")
         if self.use_residual and not (self.embed_dim == self.econv_chans):
             bad.append("use_residual True needs embed_dim == econv_chans (the reference's `convs[i](xs) + xs` has no projection)")
-        if self.reduction_factor != 1: bad.append("reduction_factor != 1")
+        if not 1 <= self.reduction_factor <= 8: bad.append("reduction_factor outside 1 .. 8")
         if not self.use_fe_condition: bad.append("use_fe_condition False")
         if not (0.0 <= self.zoneout_rate < 1.0): bad.append("zoneout_rate outside [0, 1)")
         if self.spk_embed_dim is not None and (self.spk_embed_dim <= 0 or self.spk_embed_dim % 4):

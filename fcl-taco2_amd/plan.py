@@ -160,7 +160,11 @@ class SynthesisPlan(object):
         s.c, s.p, s.u, s.odim = C, P, U, O
         lk = lambda l, n: g(lstm_key(hp, l, n))
         w_ih0 = lk(0, "weight_ih")  # [4U, C + P (+ 1)] = [att_c | prenet (| position: --append-position)]
-        wf = g("dec.feat_out.weight")  # [odim, U (+ C)]      = [lstm (| att_c: --use-concate)]
+        wf = g("dec.feat_out.weight")  # [odim * r, U (+ C)]  = [lstm (| att_c: --use-concate)]
+        R = int(hp.reduction_factor)
+        if R > 1:  # row o * r + j = bin o of the step's frame j (decoder_sa.py:512 `.view(B, odim, -1)`): frame-major rows j * odim + o, so that a
+                   # step's output is r consecutive frames of the frame-major mel buffer (fcl_decoder_weights_t.reduction_factor)
+            wf = wf.reshape(O, R, -1).permute(1, 0, 2).reshape(O * R, -1).contiguous()
         zeros = lambda *shape: torch.zeros(*shape, device=self.device, dtype=torch.float32)
         t = dict(
             prenet_w0=g("dec.prenet.prenet.0.0.weight"), prenet_b0=g("dec.prenet.prenet.0.0.bias"),
@@ -169,18 +173,18 @@ class SynthesisPlan(object):
             w0_pos=ops.copy_cols(w_ih0, C + P, 1).reshape(-1) if hp.append_position else zeros(4 * U),
             w0_hh=lk(0, "weight_hh"),
             b0=ops.add_vec(lk(0, "bias_ih"), lk(0, "bias_hh")),
-            wf_h=ops.copy_cols(wf, 0, U), wf_att=ops.copy_cols(wf, U, C) if hp.use_concate else zeros(O, C),
+            wf_h=ops.copy_cols(wf, 0, U), wf_att=ops.copy_cols(wf, U, C) if hp.use_concate else zeros(O * R, C),
         )
         # the shipped structure: two prenet blocks, two cells; other counts (decoder_sa.py:119-158, 357-369) fill the optional third slots / leave the
         # second ones empty and run the loop launch by launch on the fp32 operands (fcl_decoder_weights_t.prenet_layers / dlayers)
-        self.generic_decoder = (hp.prenet_layers, hp.dlayers) != (2, 2)
+        self.generic_decoder = (hp.prenet_layers, hp.dlayers) != (2, 2) or R > 1
         for l in range(1, hp.prenet_layers):
             t["prenet_w%d" % l], t["prenet_b%d" % l] = g("dec.prenet.prenet.%d.0.weight" % l), g("dec.prenet.prenet.%d.0.bias" % l)
         for l in range(1, hp.dlayers):
             t["w%d_ih" % l], t["w%d_hh" % l] = lk(l, "weight_ih"), lk(l, "weight_hh")
             t["b%d" % l] = ops.add_vec(lk(l, "bias_ih"), lk(l, "bias_hh"))
         if self.generic_decoder:
-            s.prenet_layers, s.dlayers = hp.prenet_layers, hp.dlayers
+            s.prenet_layers, s.dlayers, s.reduction_factor = hp.prenet_layers, hp.dlayers, R
         for k, v in t.items():
             setattr(s, k, v.data_ptr())
             d.keep.append(v)

@@ -267,7 +267,7 @@ def train(argv=None):
         if "optimizer" in snap:
             load_adam_state_dict(eng, snap["optimizer"])
         epoch0, iteration = int(snap.get("epoch", 0)), int(snap.get("iteration", 0))
-    conv = CustomConverter(1, args.use_fe_condition, args.append_position)
+    conv = CustomConverter(getattr(args, "reduction_factor", 1), args.use_fe_condition, args.append_position)  # tts.py:361-364
     cache = {} if args.keep_all_data_on_mem else None
     log, best = [], float("inf")
     for epoch in range(epoch0 + 1, args.epochs + 1):

@@ -144,9 +144,13 @@ def flat_layout(names_sizes):
 from .hostio import PinnedRing  # noqa: E402,F401  (fixed pinned staging buffers; shared with engine.prepare)
 
 
-def build_maps_host(batch):
+def build_maps_host(batch, r=1):
     """The host half of the index maps (SURVEY.md H9/H10 for the teacher-forced layout): pure numpy on the converter's integer tensors, safe to run
-    in a loader process.  Returns scalars, two packed blocks (int32, uint8) with their {name: (offset, size)} layouts, and the position column."""
+    in a loader process.  Returns scalars, two packed blocks (int32, uint8) with their {name: (offset, size)} layouts, and the position column.
+    r (`reduction_factor`, decoder_sa.py:487-489, 512-516): the converter's ds_nonzeros count FRAMES (tts.py:256); a decoder cell is one STEP = r
+    consecutive frames.  Cells, live rows and lmax count steps; `cell_frame` is the first frame of a cell's group, `prev_frame` the frame before it
+    (the teacher-forced input), `frame_cell` / `cell_frame` index GROUPS of r frames when r > 1 (a [B * L, odim] frame buffer viewed as
+    [B * L / r, r * odim]); the position column is t / (r d) as the converter's table has it (tts.py:258)."""
     ilens = [int(v) for v in batch["ilens"]]
     olens = [int(v) for v in batch["olens"]]
     B, T, L = len(ilens), max(ilens), max(olens)
@@ -157,14 +161,19 @@ def build_maps_host(batch):
     frows = np.arange(B * L)
     fvalid_np = (frows % L) < np.asarray(olens)[frows // L]
     nzm = np.asarray(batch["non_zero_lens_mask"])[:, :T] != 0
-    dsn = np.asarray(batch["ds_nonzeros"]).astype(np.int64)
+    dsn_frames = np.asarray(batch["ds_nonzeros"]).astype(np.int64)
+    r = int(r)
+    if r > 1 and ((dsn_frames % r).any() or any(o % r for o in olens) or L % r):
+        raise ValueError("fcl-taco2_amd: reduction_factor %d needs segment and utterance lengths that are multiples of it (the converter's ds_nonzeros "
+                         "are r x the durations, tts.py:256; the class splits the concatenated frames by olens, decoder_sa.py:519-522)" % r)
+    dsn = dsn_frames // r  # decoder STEPS per phoneme row
     src = np.flatnonzero(nzm.reshape(-1))
     assert src.shape[0] == dsn.shape[0], "hs.shape[0] != len(ds_nonzeros)"  # decoder_sa.py:468
     N = src.shape[0]
     b_row = src // T
-    excl = np.cumsum(dsn) - dsn
+    excl = np.cumsum(dsn_frames) - dsn_frames
     first = np.concatenate([[0], np.cumsum(np.bincount(b_row, minlength=B))[:-1]])
-    foff = b_row * L + (excl - excl[first[b_row]])
+    foff = b_row * L + (excl - excl[first[b_row]])  # frame row (b * L + l) of the phoneme's first frame
     order = np.argsort(-dsn, kind="stable")
     dur_s, foff_s = dsn[order], foff[order]
     lmax = int(dur_s[0])
@@ -172,16 +181,16 @@ def build_maps_host(batch):
     offs = np.concatenate([[0], np.cumsum(live)])  # step-major cell offsets
     cell_row = np.concatenate([np.arange(n) for n in live])  # sorted-row index of every cell
     cell_t = np.repeat(np.arange(lmax), live)
-    cell_frame = foff_s[cell_row] + cell_t  # frame row (b*L + l) of every cell
+    cell_frame = foff_s[cell_row] + cell_t * r  # frame row (b*L + l) of every cell's (first) frame
     F = int(offs[-1])
-    assert F == int(fvalid_np.sum()), "sum of durations != olens"
-    frame_cell = np.full(B * L, -1, dtype=np.int64)
-    frame_cell[cell_frame] = np.arange(F)
+    assert F * r == int(fvalid_np.sum()), "sum of durations != olens"
+    frame_cell = np.full(B * L // r, -1, dtype=np.int64)  # per GROUP of r frames: the cell that emits it
+    frame_cell[cell_frame // r] = np.arange(F)
     inv = np.full(B * T, -1, dtype=np.int64)
     inv[src[order]] = np.arange(N)
     i32 = dict(lens_dev=lens_np, e_lo=b_of * T, e_hi=b_of * T + T, f_lo=(frows // L) * L, f_hi=(frows // L) * L + L, src_sorted=src[order],
-               row_of_enc=inv, cell_frame=cell_frame, frame_cell=frame_cell, prev_frame=np.where(cell_t > 0, cell_frame - 1, -1),
-               cell_row_i32=cell_row, dur_dev=dur_s, perm_tb=(rows % T) * B + rows // T)
+               row_of_enc=inv, cell_frame=cell_frame // r, frame_cell=frame_cell, prev_frame=np.where(cell_t > 0, cell_frame - 1, -1),
+               cell_row_i32=cell_row, dur_dev=dur_s * r, perm_tb=(rows % T) * B + rows // T)  # dur_dev: the in-kernel position's divisor, in frames
     u8 = dict(enc_pad=pad_np, enc_valid=~pad_np, frame_valid=fvalid_np)
     out = dict(scalars=dict(B=B, T=T, L=L, N=N, F=F, lmax=lmax, live=live, offs=offs, order=order, cell_row=cell_row, cell_t=cell_t, dur_s=dur_s,
                             n_enc=float((~pad_np).sum()), n_frames=float(fvalid_np.sum()), live_i32=np.ascontiguousarray(live, dtype=np.int32)))
@@ -196,7 +205,7 @@ def build_maps_host(batch):
         out[name] = torch.from_numpy(host)
         out[name + "_layout"] = layout
     pos = np.zeros((F, 4), dtype=np.float32)
-    pos[:, 0] = cell_t.astype(np.float32) / dur_s[cell_row].astype(np.float32)  # the position input t/d, padded to 4 columns (TN-GEMM operand)
+    pos[:, 0] = cell_t.astype(np.float32) / (dur_s[cell_row] * r).astype(np.float32)  # the position input t / (r d), padded to 4 columns (TN-GEMM operand)
     out["pos4"] = torch.from_numpy(pos)
     return out
 
@@ -364,8 +373,8 @@ class _NativeStep(object):
         widths = (hp.embed_dim, hp.econv_chans, hp.dunits, hp.prenet_units, hp.postnet_chans, hp.duration_predictor_chans, hp.variance_predictor_chans)
         if any(v % 32 for v in widths) or hp.eunits % 64 or hp.odim % 4 or not (hp.embed_dim == hp.econv_chans == hp.eunits):
             return "channel widths that are not multiples of 32"
-        if (hp.elayers, hp.dlayers, hp.prenet_layers) != (1, 2, 2):
-            return "elayers / dlayers / prenet_layers other than 1 / 2 / 2 (the native routine issues the shipped structure's launches)"
+        if (hp.elayers, hp.dlayers, hp.prenet_layers, hp.reduction_factor) != (1, 2, 2, 1):
+            return "elayers / dlayers / prenet_layers / reduction_factor other than 1 / 2 / 2 / 1 (the native routine issues the shipped structure's launches)"
         if eng.role == "student" and eng.distill[2] and hp.postnet_layers != 5:
             return "decoder distillation with postnet_layers != 5"
         if eng.role == "student" and eng.distill[1] and hp.econv_layers != 3:
@@ -558,6 +567,9 @@ class TrainEngine(object):
         if self.role in ("student", "kd_teacher") and (self.hp.econv_layers != 3 or self.hp.postnet_layers != 5):
             raise NotImplementedError("fcl-taco2_amd: KD training needs econv_layers 3 and postnet_layers 5: the reference's KD classes index fixed lists of "
                                       "encoder / postnet taps and raise IndexError otherwise (tests/golden/records.json)")
+        if self.role in ("student", "kd_teacher") and self.hp.reduction_factor != 1:
+            raise NotImplementedError("fcl-taco2_amd: KD training is built for reduction_factor 1 (the KD taps are frame-level; no shipped recipe sets r > 1); "
+                                      "the teacher class trains and synthesises with r > 1")
         if self.role in ("student", "kd_teacher") and self.hp.dlayers != 2:
             # the reference's KD decoder taps cells 0 and 1 by index (decoder_sa_kd.py:626-627): IndexError with one cell (records.json); with three it
             # runs, tapping the MIDDLE cell -- not built here (no shipped recipe, no golden): refused rather than guessed
@@ -1138,7 +1150,7 @@ class TrainEngine(object):
             return
         host = batch.get("_fcl_maps_host") if isinstance(batch, dict) else None
         if host is None:
-            host = build_maps_host(batch)
+            host = build_maps_host(batch, self.hp.reduction_factor)
         m = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in host["scalars"].items()}  # a DataLoader hands numpy arrays over as tensors
         up = _RING.upload({"i32": host["i32"], "u8": host["u8"], "pos4": host["pos4"]}, dev)  # pinned staging: the CPU keeps running ahead
         for name in ("i32", "u8"):
@@ -1335,8 +1347,18 @@ class TrainEngine(object):
         c.w0_hh = P[lk(0, "weight_hh")]
         b0s = self._bsum(P[lk(0, "bias_ih")], P[lk(0, "bias_hh")])
         wf = P["dec.feat_out.weight"]
-        c.wf_h = self._cols(wf, 0, U)
-        c.wf_att = self._cols(wf, U, C) if hp.use_concate else self._zeros_const("wf_att0", (O, C))
+        R = hp.reduction_factor
+        if R == 1:
+            c.wf_h = self._cols(wf, 0, U)
+            c.wf_att = self._cols(wf, U, C) if hp.use_concate else self._zeros_const("wf_att0", (O, C))
+        else:  # a step emits R frames (decoder_sa.py:397-398, 512): rows re-ordered frame-major (row j * odim + o <- feat_out row o * R + j) so that a
+               # cell's output [R * odim] IS its R consecutive frames of the frame-major buffers
+            ldf = wf.shape[1]
+            pcols = lambda col0, n: self._form((self._param_ptr[wf.data_ptr()], "cp", col0, n, R), wf, (R, O, n, ldf, R * ldf, 1), base=col0)
+            c.wf_h = pcols(0, U)
+            c.wf_att = pcols(U, C) if hp.use_concate else self._zeros_const("wf_att0r", (O * R, C))
+        OR = O * R
+        dpl = dpl and R == 1  # (r > 1: the decoder-side GEMMs stay on the fp32 operands)
         if dpl:
             G0 = ops.linear_planes(att_p, self._wplanes("w0_att", c.w0_att), 4 * U, C, b0s)[0]  # hoisted att_c share of the layer-0 gates
             F0 = ops.linear_planes(att_p, self._wplanes("wf_att", c.wf_att), O, C)[0]
@@ -1372,13 +1394,14 @@ class TrainEngine(object):
         if dpl:
             out_cells = ops.linear_planes(ops.pack_planes(c.h1_all), self._wplanes("wf_h", c.wf_h), O, U)[0]
         else:
-            out_cells = ops.linear(c.h1_all, c.wf_h)
+            out_cells = ops.linear(c.h1_all, c.wf_h)  # [F, R * odim]: the cell's R frames, frame-major
         ops.add2d(out_cells, ops.gather_rows(F0, c.cell_row_i32))
         xp = None
-        if pl:
+        if pl and R == 1:
             c.before, xp = ops.gather_rows(out_cells, c.frame_cell, want_planes=True)  # [B*L, O], zero where no cell maps (padding)
-        else:
-            c.before = ops.gather_rows(out_cells, c.frame_cell)
+        else:  # (r > 1: frame_cell maps GROUPS of R frames to cells; [B * L / R, R * odim] viewed as [B * L, odim])
+            c.before = ops.gather_rows(out_cells, c.frame_cell).reshape(B * L, O)
+            xp = ops.pack_planes(c.before) if pl else None
         # ---- postnet
         x, c.post_c, c.post_taps = c.before, [], []
         n_post = hp.postnet_layers
@@ -1521,16 +1544,24 @@ class TrainEngine(object):
         self._late_join()  # the KD gradients at the prenet / LSTM / encoder taps (computed beside the frame-level terms and the postnet's backward)
         self._launch_bucket(c, 0)
         # ---- decoder BPTT
-        d_out_cells = ops.gather_rows(d_before, c.cell_frame)  # [F, O]
-        g_wf = G["dec.feat_out.weight"]
+        R = hp.reduction_factor
+        OR = hp.odim * R
+        # [F, R * odim]: the gradient of every cell's R frames (r > 1: d_before [B * L, odim] viewed as groups of R frames, cell_frame = group index)
+        d_out_cells = ops.gather_rows(d_before if R == 1 else d_before.reshape(-1, OR), c.cell_frame)
+        g_wf = G["dec.feat_out.weight"] if R == 1 else self._z((OR, G["dec.feat_out.weight"].shape[1]))  # (r > 1: frame-major rows, un-permuted below)
         self._dw(lambda: ops.gemm_tn(d_out_cells, c.h1_all, g_wf[:, :U]))  # column blocks of the [odim, U + C] gradient are written in place
         dh1_all = ops.linear(d_out_cells, self._wt(c.wf_h))  # [F, U]
         if "h1" in inj:
             ops.add2d(dh1_all, inj["h1"])
-        dF0 = self._z((N, hp.odim))
+        dF0 = self._z((N, OR))
         ops.scatter_add_rows(d_out_cells, c.cell_row_i64, dF0)
         if hp.use_concate:
             self._dw(lambda: ops.gemm_tn(dF0, c.att_c, g_wf[:, U:]))
+        if R > 1:  # feat_out.weight row o * R + j <- frame-major row j * odim + o
+            if getattr(self, "_wf_unperm", None) is None:
+                idx = np.arange(OR)
+                self._wf_unperm = torch.from_numpy(((idx % R) * hp.odim + idx // R).astype(np.int32)).to(dev)
+            self._dw(lambda: ops.add2d(G["dec.feat_out.weight"], ops.gather_rows(g_wf, self._wf_unperm)))
         d_att_c = ops.linear(dF0, self._wt(c.wf_att))
         DL, PL = hp.dlayers, hp.prenet_layers
         w0_pre_t = self._wt(c.w0_pre)

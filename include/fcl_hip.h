@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 415
+#define FCL_ABI_VERSION 416
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -302,6 +302,11 @@ typedef struct {
     int prenet_layers;
     int dlayers;
     const float *prenet_w2, *prenet_b2, *w2_ih, *w2_hh, *b2;
+    /* reduction_factor r (0 / 1 = one frame per step; decoder_sa.py:397-398, 512-516, 611-627): a step emits r frames.  wf_h / wf_att are then
+     * [r * odim, .] with the rows PERMUTED to frame-major order (row j * odim + o = feat_out.weight row o * r + j), so a step's output is r
+     * consecutive rows of the frame-major `before`; the last of them is the next step's prenet input.  `dur` / live rows count STEPS, frame_off
+     * and the frame buffers count FRAMES (r per step).  Runs on the launch-by-launch loop (see dlayers). */
+    int reduction_factor;
 } fcl_decoder_weights_t;
 
 typedef struct {

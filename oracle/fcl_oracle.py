@@ -258,7 +258,7 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
     prenet_keep: None (dropout off) or uint8 [n_steps, prenet_layers, N, P]; zone_keep: None (eval zoneout) or
     uint8 [n_steps, dlayers, 2(h,c), N, U].  `dlayers` cells (decoder_sa.py:357-369, 500-504: cell l > 0 reads cell l - 1's new state;
     feat_out reads the LAST cell), `prenet_layers` prenet blocks.
-    Returns outs [N, odim, n_steps], prenet_outs [N, n_steps, P], lstm0 [N, n_steps, U], last cell [N, n_steps, U]."""
+    Returns outs [N, odim, n_steps * reduction_factor], prenet_outs [N, n_steps, P], lstm0 [N, n_steps, U], last cell [N, n_steps, U]."""
     N = att_c.shape[0]
     U, zr = hp.dunits, hp.zoneout_rate
     # decoder_sa.py:366-369: the cell is wrapped in ZoneOutCell (parameters under `.cell`) only for a positive rate
@@ -290,9 +290,11 @@ def decoder_loop(sd, hp, att_c, position, n_steps, teacher_ys=None, prenet_keep=
         l0.append(z[0])
         l1.append(z[-1])
         out = F.linear(torch.cat([z[-1], att_c], dim=1) if getattr(hp, "use_concate", True) else z[-1], wf)  # H8, no bias (decoder_sa.py:505-511)
+        out = out.view(N, hp.odim, -1)  # [N, odim, reduction_factor]: a step emits r frames, feat_out row o * r + j = bin o of frame j (decoder_sa.py:512, 611)
         outs.append(out)
-        prev = _out_act(hp, out) if teacher_ys is None else teacher_ys[:, t]  # decoder_sa.py:614-617: the fed-back frame is activated
-    return (torch.stack(outs, dim=2), torch.stack(pres, dim=1), torch.stack(l0, dim=1), torch.stack(l1, dim=1))
+        # decoder_sa.py:513 / :614-617: teacher forcing feeds the ground-truth frame, free running the LAST of the step's r frames, activated
+        prev = _out_act(hp, out[:, :, -1]) if teacher_ys is None else teacher_ys[:, t]
+    return (torch.cat(outs, dim=2), torch.stack(pres, dim=1), torch.stack(l0, dim=1), torch.stack(l1, dim=1))
 
 
 def decoder_inference(sd, hp, h, ds, p_embs, e_embs, prenet_keep=None):
@@ -303,10 +305,11 @@ def decoder_inference(sd, hp, h, ds, p_embs, e_embs, prenet_keep=None):
     if nz.shape[0] != h.shape[0]:
         # decoder_sa_kd.py:739 — a zero predicted duration crashes reference inference
         raise AssertionError("zero duration: ds_nonzeros.shape[0] != hs.shape[0]")
-    position = position_table(nz)
+    r = getattr(hp, "reduction_factor", 1)
+    position = position_table(nz)  # ..._sa.py:665-669: t / d in STEPS (the converter's training table is t / (r d): tts.py:256-258)
     n_steps = int(ds.max())
     outs, _, _, _ = decoder_loop(sd, hp, h, position, n_steps, None, prenet_keep)
-    segs = [outs[p, :, : int(nz[p])] for p in range(h.shape[0])]  # H10 re-assembly (:782-790)
+    segs = [outs[p, :, : r * int(nz[p])] for p in range(h.shape[0])]  # H10 re-assembly (:782-790): r frames per step (decoder_sa.py:573, 627)
     before = torch.cat(segs, dim=-1).unsqueeze(0)  # [1, odim, L]
     after = _out_act(hp, before + postnet(sd, hp, before)[-1])  # decoder_sa.py:635-636 (`before` is not returned by the reference: kept raw)
     return after[0].t(), before[0].t()
@@ -338,9 +341,9 @@ def inference(sd, hp, x, dur=None, f0=None, energy=None, prenet_keep=None, spemb
 
 
 # ----------------------------------------------------------------------------- host batch layout (H15)
-def convert_batch(xs, ys, ds, f0, energy):
+def convert_batch(xs, ys, ds, f0, energy, reduction_factor=1):
     """CustomConverter.__call__ (tts.py:215-306) restated with the same start/end arithmetic
-    (start=int(sum(ds[:it])), end=int(sum(ds[:it+1])), :250-251), reduction_factor 1.
+    (start=int(sum(ds[:it])) * r, end=int(sum(ds[:it+1])) * r, :250-251; ds_nonzeros = int(d * r) :256; position = t / (end - start) :258).
 
     Inputs: lists of numpy arrays xs [T] int64, ys [L,odim] f32, ds [T,1] float, f0/energy [T,1] f32."""
     import numpy as np
@@ -353,11 +356,11 @@ def convert_batch(xs, ys, ds, f0, energy):
         csum = np.concatenate([[0.0], np.cumsum(d.astype(np.float64))])
         row = []
         for it in range(int(ilens[ib])):
-            start, end = int(csum[it]), int(csum[it + 1])
+            start, end = int(csum[it]) * reduction_factor, int(csum[it + 1]) * reduction_factor
             if start != end:
                 new_ys.append(torch.from_numpy(ys[ib][start:end]).float())
                 row.append(1)
-                dsnz.append(int(d[it]))
+                dsnz.append(int(d[it] * reduction_factor))
                 pos.append(torch.arange(end - start, dtype=torch.float32) / (end - start))
             else:
                 row.append(0)
@@ -389,7 +392,11 @@ def decoder_forward(sd, hp, hs, olens, new_ys, non_zero_lens_mask, ds_nonzeros, 
     hs = hs + p_embs + e_embs
     att_c = hs[non_zero_lens_mask.eq(1)]  # H9 row compaction, row-major over (b, t)
     assert att_c.shape[0] == len(ds_nonzeros)
-    outs, pres, l0, l1 = decoder_loop(sd, hp, att_c, position, new_ys.shape[1], new_ys, prenet_keep, zone_keep)
+    r = getattr(hp, "reduction_factor", 1)
+    # decoder_sa.py:487-489: every r-th frame (the LAST of each group of r) is the teacher-forced input of the next step; one step per group.
+    # The converter's position table is indexed by the STEP (position[:, itt], :494-498): step t reads t / (r d)
+    ys_in = new_ys[:, r - 1 :: r] if r > 1 else new_ys
+    outs, pres, l0, l1 = decoder_loop(sd, hp, att_c, position, ys_in.shape[1], ys_in, prenet_keep, zone_keep)
     ylens = [int(l) for l in olens]
 
     def regroup(x_nlc):  # [N, Lseg, C] -> [B, L, C] : mask-select then split by ylens then pad (:634-655)
@@ -405,7 +412,8 @@ def decoder_forward(sd, hp, hs, olens, new_ys, non_zero_lens_mask, ds_nonzeros, 
                    hp.dropout_rate)
     after = _out_act(hp, before + post[-1].transpose(1, 2))  # decoder_sa.py:538-540 / decoder_sa_kd.py:698-700: both outputs, after the postnet
     before = _out_act(hp, before)
-    taps = [regroup(pres), regroup(l0), regroup(l1)] + [p.transpose(1, 2) for p in post]
+    # (the step-level taps are the KD classes' business; with r > 1 a step is r frames and the plain teacher class has no use for them)
+    taps = ([regroup(pres), regroup(l0), regroup(l1)] if r == 1 else [None, None, None]) + [p.transpose(1, 2) for p in post]
     return after, before, taps
 
 
@@ -499,6 +507,10 @@ def model_forward(sd, hp, batch, role, teacher_hp=None, share_proj=True, teacher
         None if mk.get("zoneout") is None else _t(mk["zoneout"]), bn_train, mk.get("postnet"))
     if role == "kd_teacher":
         return after, before, enc_taps + [hs_enc], dec_taps, [d_outs.unsqueeze(-1), p_outs, e_outs, p_embs, e_embs]
+    if getattr(hp, "reduction_factor", 1) > 1:  # ..._sa.py:594-598: the target is cut to whole groups of r frames
+        r = hp.reduction_factor
+        olens = torch.tensor([int(o) - int(o) % r for o in olens])
+        ys = ys[:, : int(max(olens))]
     l1, mse = taco2_loss(after, before, ys, olens, hp.use_masking)
     rep = dict(l1_loss=l1, mse_loss=mse, dur_loss=dur_loss, pitch_loss=pitch_loss, energy_loss=energy_loss)
     loss = l1 + mse + dur_loss + pitch_loss + energy_loss

@@ -801,6 +801,44 @@ def gen_g18_g19_g20():
     assert "enc.blstm.weight_ih_l1_reverse" in spec
 
 
+def gen_g21():
+    """G21 (round 5): `reduction_factor` 2 on the teacher class (decoder_sa.py:397-398 feat_out emits r frames per step as [odim, r]; :456-457 /
+    :488-489 every r-th target frame is the next step's input; :512-516 / :627 the r frames of a step are consecutive output frames; converter
+    tts.py:250-258: segments, ds_nonzeros and the position table in FRAMES = r x the annotated durations; inference position t / d in STEPS,
+    ..._sa.py:665-669).  Targets hold exactly r * sum(d) frames per utterance (the class splits the concatenated frames by `olens`,
+    decoder_sa.py:519-522: any other length mis-assigns frames across utterances).  The real CustomConverter's outputs are stored too (bit-exact pin
+    of the vectorised converter at r = 2), then the inference mel and the training step."""
+    from tts import CustomConverter
+
+    r = 2
+    hp = HP.teacher_hparams(idim=12, odim=8, embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, duration_predictor_chans=20,
+                            dropout_rate=0.0, reduction_factor=r)
+    rng = np.random.RandomState(21)
+    x = torch.from_numpy(rng.randint(1, hp.idim, size=7).astype(np.int64))
+    dur = torch.tensor([2, 1, 3, 1, 2, 2, 1])
+    te, spec = build("teacher", hp)
+    assert tuple(spec["dec.feat_out.weight"]) == (hp.odim * r, hp.dunits + hp.eunits)
+    with torch.no_grad():
+        after = te.inference(x, None, dur=dur)
+    assert after.shape[0] == r * int(dur.sum())
+    save("g21_teacher_r2_inference", x=t2n(x), dur=t2n(dur), after=t2n(after))
+    xs, ys, ds, f0, en = SYN.training_batch(hp.odim, hp.idim, batch=4, seed=7)
+    ys = [rng.standard_normal((r * int(np.asarray(d).sum()), hp.odim)).astype(np.float32) for d in ds]  # r frames per annotated duration unit
+    conv = CustomConverter(reduction_factor=r, use_fe_condition=True, append_position=True)
+    b = conv([(xs, ys, None, ds, f0, en)])
+    d = {}
+    for i in range(4):
+        d["in_xs%d" % i], d["in_ys%d" % i], d["in_ds%d" % i], d["in_f0%d" % i], d["in_en%d" % i] = xs[i], ys[i], np.asarray(ds[i]), f0[i], en[i]
+    for k in ("xs", "ilens", "ys", "olens", "extras", "new_ys", "non_zero_lens_mask", "ds_nonzeros", "output_masks", "position", "f0", "energy"):
+        d["out_" + k] = t2n(b[k])
+    loss = te(**b)
+    loss.backward()
+    d["loss"] = np.float32(loss.item())
+    _named_losses(te, d)
+    _grads(te, GRAD_KEYS, d)
+    save("g21_teacher_r2", **d)
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -888,7 +926,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g21", "records"}, only
+        if "g21" in only:
+            gen_g21()
         if "g18" in only:
             gen_g18_g19_g20()
         if "g17" in only:
@@ -926,6 +966,7 @@ def main():
     gen_g16()
     gen_g17()
     gen_g18_g19_g20()
+    gen_g21()
     gen_option_records()
 
 

@@ -85,3 +85,6 @@ TINY_VARIANTS = {
     "g19_teacher_prenet3": HP.teacher_hparams(prenet_layers=3, **_OPT),
     "g20_teacher_elayers2": HP.teacher_hparams(elayers=2, **_OPT),
 }
+
+# reduction_factor 2 on the teacher class (G21)
+TINY_R2 = HP.teacher_hparams(reduction_factor=2, **_OPT)

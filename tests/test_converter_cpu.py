@@ -34,6 +34,18 @@ def test_converter_second_case_index_maps(golden):
         assert np.array_equal(out[k].numpy(), g["out2_" + k]), k
 
 
+def test_converter_reduction_factor_2_bit_exact(golden):
+    """tts.py:250-258 with reduction_factor 2 (segments, ds_nonzeros and the position table in frames = 2 x the durations): the vectorised
+    converter against the REAL class's outputs stored in G21."""
+    g = golden("g21_teacher_r2")
+    raw = ([g["in_xs%d" % i] for i in range(4)], [g["in_ys%d" % i] for i in range(4)], None, [g["in_ds%d" % i] for i in range(4)],
+           [g["in_f0%d" % i] for i in range(4)], [g["in_en%d" % i] for i in range(4)])
+    out = CustomConverter(2, True, True)([raw])
+    for k in ("xs", "ilens", "ys", "olens", "extras", "new_ys", "non_zero_lens_mask", "ds_nonzeros", "output_masks", "position", "f0", "energy"):
+        ref = g["out_" + k]
+        assert out[k].numpy().dtype == ref.dtype and np.array_equal(out[k].numpy(), ref), k
+
+
 def test_converter_is_fast_at_bench_scale():
     xs, ds = SYN.batch_c2(batch=32)
     rng = np.random.RandomState(0)

@@ -29,7 +29,7 @@ def _ns(hp):
                               duration_predictor_chans=hp.duration_predictor_chans, output_activation=hp.output_activation,
                               spk_embed_dim=hp.spk_embed_dim, zoneout_rate=hp.zoneout_rate, use_concate=hp.use_concate, append_position=hp.append_position,
                               use_batch_norm=hp.use_batch_norm, econv_layers=hp.econv_layers, postnet_layers=hp.postnet_layers,
-                              elayers=hp.elayers, dlayers=hp.dlayers, prenet_layers=hp.prenet_layers)
+                              elayers=hp.elayers, dlayers=hp.dlayers, prenet_layers=hp.prenet_layers, reduction_factor=hp.reduction_factor)
 
 
 def _model(role, hp, thp=None):
@@ -523,6 +523,47 @@ def test_structure_options_train_form_and_batched_synthesis_vs_oracle():
     orep["loss"].backward()
     assert abs(rep["loss"] - float(orep["loss"])) < 5e-4 * max(1.0, abs(float(orep["loss"])))
     _check_vs_oracle(eng, gsd, tol=2e-3)
+
+
+def test_reduction_factor_2_vs_reference_g21():
+    """G21: `reduction_factor` 2 on the HIP path (teacher class): a decoder step emits two frames (feat_out rows re-ordered frame-major at plan
+    time), durations count steps, frame offsets count frames; synthesis (position t / d) and the training step (every second target frame
+    teacher-forced, position t / (2 d), decoder_sa.py:487-516) vs the real reference, then vs the oracle's autograd for every parameter; a
+    3-utterance batch vs per-utterance oracle inference."""
+    from helpers import TINY_R2, np_state_dict
+    from fcl_taco2_amd import engine
+    from fcl_taco2_amd.converter import CustomConverter
+    from fcl_taco2_amd.plan import SynthesisPlan
+    from fcl_taco2_amd.training import TrainEngine
+
+    hp = TINY_R2
+    g = _golden("g21_teacher_r2_inference")
+    plan = SynthesisPlan(np_state_dict(hp), hp, DEV)
+    mel = engine.synthesize(plan, [g["x"]], [g["dur"]], dropout_mode=0)[0]
+    assert mel.shape == g["after"].shape and max_abs(mel.cpu(), g["after"]) < 1e-3
+    rng = np.random.RandomState(5)
+    xs = [rng.randint(1, hp.idim, size=n).astype(np.int64) for n in (6, 4, 7)]
+    ds = [rng.randint(1, 4, size=len(x)).astype(np.int64) for x in xs]
+    mels = engine.synthesize(plan, xs, ds, dropout_mode=0)
+    sd = torch_state_dict(hp)
+    with torch.no_grad():
+        for i in range(3):
+            ref = O.inference(sd, hp, torch.from_numpy(xs[i]), dur=torch.from_numpy(ds[i]))["after"]
+            assert mels[i].shape == ref.shape and max_abs(mels[i].cpu(), ref) < 1e-3, i
+    g = _golden("g21_teacher_r2")
+    raw = ([g["in_xs%d" % i] for i in range(4)], [g["in_ys%d" % i] for i in range(4)], None, [g["in_ds%d" % i] for i in range(4)],
+           [g["in_f0%d" % i] for i in range(4)], [g["in_en%d" % i] for i in range(4)])
+    batch = CustomConverter(2, True, True)([raw])
+    eng = TrainEngine(_model("teacher", hp))
+    assert eng.native is None
+    rep = eng.forward_backward(batch)
+    assert _check_vs_golden(eng, rep, g, KD_KEYS[:6]) >= 10
+    gsd = _grad_sd(hp)
+    orep = O.model_forward(gsd, hp, _cpu(batch), "teacher")
+    orep["loss"].backward()
+    _check_vs_oracle(eng, gsd)
+    with pytest.raises(NotImplementedError, match="reduction_factor 1"):
+        TrainEngine(_model("kd_teacher", hp))
 
 
 def test_kd_refuses_other_cell_counts_and_the_native_step_declines_the_options():

@@ -462,6 +462,27 @@ def test_g18_g19_g20_structure_options(golden, name):
     assert _check_grads(sd, g) >= 10
 
 
+def test_g21_reduction_factor_2(golden):
+    """`reduction_factor` 2 (teacher class): the converter's layout in frames (tts.py:250-258) bit-exact, inference mel (position t / d in steps,
+    r frames per step), training step (every r-th target frame teacher-forced, position t / (r d) from the converter, targets cut to whole groups)."""
+    from helpers import TINY_R2
+
+    g = golden("g21_teacher_r2")
+    b = O.convert_batch(*_raw_batch(g, 4), reduction_factor=2)
+    for k in ("xs", "ilens", "ys", "olens", "extras", "new_ys", "non_zero_lens_mask", "ds_nonzeros", "output_masks", "position", "f0", "energy"):
+        assert np.array_equal(b[k].numpy(), g["out_" + k]), k
+    gi = golden("g21_teacher_r2_inference")
+    with torch.no_grad():
+        out = O.inference(torch_state_dict(TINY_R2), TINY_R2, torch.from_numpy(gi["x"]), dur=torch.from_numpy(gi["dur"]))
+    assert out["after"].shape == gi["after"].shape and max_abs(out["after"], gi["after"]) < TOL_STAGE
+    sd = _grad_sd(TINY_R2)
+    rep = O.model_forward(sd, TINY_R2, b, "teacher")
+    rep["loss"].backward()
+    for k in ("loss", "l1_loss", "mse_loss", "dur_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 10
+
+
 def test_g13_speaker_embeddings(golden):
     """`spk_embed_dim`: F.normalize(spemb) appended to every encoder state (..._sa.py:555-557, 636-638).  Inference mel, the teacher step and the KD
     teacher's 5-tuple vs the real reference (the KD student cannot run with speaker embeddings in the reference: records.json)."""
