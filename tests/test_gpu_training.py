@@ -849,6 +849,20 @@ def _ddp_worker(rank, world, port, q):
     eng3.forward_backward(batch_of(rank + 2), reduce=True)
     eng3.buckets.finish(lambda t, s: ops.scale_(t, s))
     err = max(err, float((eng3.gflat - want_acc).abs().max() / want_acc.abs().max()))
+    # (round 5, VERDICT r4 #7b) the same exchange issued where a RCCL job issues it: every bucket as an asynchronous collective on the DEVICE slice,
+    # from the weight-gradient stream, at the point of the backward where the bucket becomes final -- not staged in finish().  A bucket issued
+    # before its last gradient was written would be averaged stale and miss `want`.
+    os.environ["FCL_DP_GLOO_DIRECT"] = "1"
+    eng4 = TrainEngine(_model("teacher", TINY_T))
+    assert eng4.buckets.active and not eng4.buckets.stage_host
+    for _ in range(2):  # twice: the second pass overwrites gradient memory the first pass's collectives have read
+        eng4.zero_grad()
+        eng4.forward_backward(batch_of(rank))
+        assert eng4.buckets.collectives > 0 and len(eng4.buckets.work) > 0  # issued during backward, still pending here
+        eng4.buckets.finish(lambda t, s: ops.scale_(t, s))
+        torch.cuda.synchronize()
+        err = max(err, float((eng4.gflat - want).abs().max() / want.abs().max()))
+    os.environ["FCL_DP_GLOO_DIRECT"] = "0"
     gathered = [torch.zeros_like(w_after.cpu()) for _ in range(world)]
     dist.all_gather(gathered, w_after.cpu())
     same = all(torch.equal(gathered[0], g) for g in gathered)

@@ -1,5 +1,7 @@
+import os
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import test_gpu_training as T
 from fcl_taco2_amd import hparams as HP, synthetic as SYN, teacher_forced as TF
