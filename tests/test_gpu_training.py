@@ -1029,7 +1029,7 @@ def test_full_size_kd_step_properties():
         fd = (vals[0] - vals[1]) / (2 * eps)
         # (absolute term: the fp32 loss (17.8) carries ~2e-5 of summation-order noise from the atomically accumulated sums, i.e. 5e-3 on a central
         # difference over 2 eps = 4e-3 -- 4 % of the smallest of the three gradient norms (0.135), where the test used to sit at 1.7 - 2.2 % of a 2.7 %
-        # bound and failed once in ~10 full runs: tools/fd_probe.py)
+        # bound and failed once in ~10 full runs: tools/attic/fd_probe.py)
         assert abs(fd - gnorm) < 2e-2 * gnorm + 6e-3, (name, fd, gnorm)
     eng.zero_grad()
     before = eng.forward_backward(batch, teacher_knowledge=know)["loss"]

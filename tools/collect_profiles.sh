@@ -1,7 +1,7 @@
 # Collects the round's profile evidence on the GPU box into gpurun_out/prof_$1/ (copy the summaries to profiles/ afterwards):
 #   default bench JSON (fresh feed, 4 capacity graphs in flight), rocprofv3 kernel stats of that command and of the eager single-stream pass,
 #   PMC FETCH_SIZE / WRITE_SIZE / SQ counters (separate --pmc passes, --kernel-trace only), training-step JSONs + kernel stats + PMC traffic.
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -38,14 +38,19 @@ stats $OUT/eagerf $OUT/fp32_eager_1stream_kernel_stats.csv; rm -rf $OUT/eagerf
 for w in kd_step teacher_step; do
   python3 bench.py --workload $w > $OUT/bench_$w.json 2> /dev/null
   python3 bench.py --workload $w --amp bf16 --no-cpu-baseline > $OUT/bench_${w}_bf16.json 2> /dev/null
-  rocprofv3 --kernel-trace --stats -d $OUT/$w -o t --output-format csv -- python3 bench.py --workload $w --steps 10 --warmup 3 --regions 1 --no-cpu-baseline > /dev/null 2>&1
+  # (--no-dp-schedule: the profiled update is the update alone, not followed by the one-rank RCCL leg's three more timed regions -- ADVICE r4)
+  rocprofv3 --kernel-trace --stats -d $OUT/$w -o t --output-format csv -- python3 bench.py --workload $w --steps 10 --warmup 3 --regions 1 --no-cpu-baseline --no-dp-schedule > /dev/null 2>&1
   stats $OUT/$w $OUT/${w}_kernel_stats.csv; rm -rf $OUT/$w
-  T1="python3 bench.py --workload $w --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-overlap"
+  T1="python3 bench.py --workload $w --steps 3 --warmup 1 --regions 1 --no-cpu-baseline --no-overlap --no-dp-schedule"
   rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o f --output-format csv -- $T1 > /dev/null 2>&1
   pmc $OUT/pf $OUT/pmc_${w}_fetch_size.csv pmc_summary.py
   rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o w --output-format csv -- $T1 > /dev/null 2>&1
   pmc $OUT/pw $OUT/pmc_${w}_write_size.csv pmc_summary.py
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS -d $OUT/ps -o s --output-format csv -- $T1 > /dev/null 2>&1
+  pmc $OUT/ps $OUT/pmc_${w}_sq_counters.csv pmc_multi.py
 done
+# the weight-gradient GEMM shapes of both updates: old kernel / dw_mfma_kernel (round 5)
+python3 tools/bench_dw2.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/bench_dw_shapes.log
 python3 bench.py --workload forward_tf > $OUT/bench_forward_tf.json 2> /dev/null
 python3 bench.py --batch 64 --no-cpu-baseline --no-extras > $OUT/bench_batch64.json 2> /dev/null
 python3 bench.py --model teacher --no-cpu-baseline --no-extras > $OUT/bench_teacher_synthesis.json 2> /dev/null
