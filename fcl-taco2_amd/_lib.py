@@ -86,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 416  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 417  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -148,6 +148,7 @@ SIGNATURES = {
     "fcl_te_backward_stage": (_I, [_P, _I, _P]),
     "fcl_te_join": (_I, [_P, _P]),
     "fcl_te_last_launches": (C.c_int64, [_P]),
+    "fcl_te_phase_ms": (_I, [_P, _P]),
     "fcl_te_arena_bytes": (C.c_int64, [_P]),
     "fcl_last_error": (C.c_char_p, []),
     "fcl_version": (_I, []),

@@ -179,6 +179,10 @@ struct fcl_te {
     int64_t launches = 0, last_launches = 0;
     Ctx c;
     int stage_done = -1;
+    // developer aid (FCL_TE_STAMPS=1): timing events on the main stream at the phase boundaries of an update (fcl_te_phase_ms)
+    bool stamps = false;
+    hipEvent_t stamp_ev[12] = {};
+    bool stamp_set[12] = {};
 
     Param& Pm(const std::string& k) { return P.at(k); }
 };
@@ -210,6 +214,12 @@ inline uint8_t* u8(E_t& E, long long n) { return static_cast<uint8_t*>(WA(E).tak
 inline size_t planes_elems(long long rows, int cols) { return (size_t)(rows > 0 ? rows : 1) * ((cols + 31) / 32) * 64; }
 inline uint16_t* pl16(E_t& E, long long rows, int cols) { return static_cast<uint16_t*>(WA(E).take(planes_elems(rows, cols) * 2)); }
 inline float* zf32(E_t& E, long long n) { return static_cast<float*>(ZA(E).take((size_t)n * 4)); }
+
+inline void stamp(E_t& E, int i) {  // FCL_TE_STAMPS=1: 0 start | 1 encoder | 2 prenet + hoists | 3 decoder cells | 4 forward end | 5 losses | 6 .. 9 backward stages 0 .. 3 | 10 join
+    if (!E.stamps || E.dry || i < 0 || i >= 12) return;
+    if (!E.stamp_ev[i] && hipEventCreate(&E.stamp_ev[i]) != hipSuccess) return;
+    E.stamp_set[i] = hipEventRecord(E.stamp_ev[i], E.main) == hipSuccess;
+}
 
 int ev_wait(E_t& E, hipStream_t waiter, hipStream_t on) {  // waiter waits for everything enqueued on `on` so far
     if (E.dry || waiter == on) return 0;
@@ -666,6 +676,7 @@ static int te_forward(fcl_te& E) {
     }
     if (hs_p) c.planes_of[c.hs] = hs_p;
     c.enc_taps.push_back(c.hs);
+    stamp(E, 1);
     // ---- predictors + embeds: their dropout masks in one launch, their forward beside the decoder's (weight-gradient stream) when a backward follows
     const float p_emb = cf.ve_dropout;
     std::vector<Site> ps;
@@ -815,7 +826,9 @@ static int te_forward(fcl_te& E) {
         if (((long long)N * U * 4) % 128 == 0) { a.p1d_p = p1d_p; a.w0_pre_p = w0_pre_p; a.w0_hh_p = w0_hh_p; a.w1_ih_p = w1_ih_p; a.w1_hh_p = w1_hh_p; }
         a.workspace_bytes = fcl_decoder_train_workspace_bytes(N, U);
         a.workspace = WA(E).take(a.workspace_bytes);
+        stamp(E, 2);
         TE_L(fcl_decoder_train_fwd(&a, E.cur));
+        stamp(E, 3);
     }
     uint16_t* h1_p = pl16(E, F, U);
     TE_L(fcl_pack_planes(c.h1_all, U, F, U, h1_p, E.cur));
@@ -1657,9 +1670,16 @@ int fcl_te_forward_backward(fcl_te_t* Ep, const fcl_te_batch_t* batch, const fcl
     TE_TRY(ev_wait(E, E.main, E.side));
     E.pred_pending = E.late_pending = E.dw_pending = false;
     TE_TRY(te_clear_zero(E));
+    static const int stamps_on = tunable("TE_STAMPS", 0);
+    E.stamps = stamps_on != 0;
+    for (bool& b : E.stamp_set) b = false;
+    stamp(E, 0);
     TE_TRY(te_forward(E));
+    stamp(E, 4);
     TE_TRY(te_losses(E, kp));
+    stamp(E, 5);
     TE_TRY(te_backward_stage0(E));
+    stamp(E, 6);
     // the named losses: complete once the late terms are joined (stage 0 ends with that join)
     FCL_HIP(hipMemcpyAsync(loss_sums_host, E.c.sums, FCL_TE_MAX_LOSSES * 3 * sizeof(double), hipMemcpyDeviceToHost, E.main));
     if (status_host) FCL_HIP(hipMemcpyAsync(status_host, E.status, sizeof(uint32_t), hipMemcpyDeviceToHost, E.main));
@@ -1678,6 +1698,7 @@ int fcl_te_backward_stage(fcl_te_t* Ep, int stage, fcl_stream_t stream) {
     if (stage == 1) TE_TRY(te_backward_stage1(E));
     if (stage == 2) TE_TRY(te_backward_stage2(E));
     if (stage == 3) TE_TRY(te_backward_stage3(E));
+    stamp(E, 6 + stage);
     E.stage_done = stage;
     E.last_launches += E.launches - l0;
     return 0;
@@ -1689,7 +1710,24 @@ int fcl_te_join(fcl_te_t* Ep, fcl_stream_t stream) {
     fcl_te& E = *Ep;
     E.main = (hipStream_t)stream;
     E.dw_pending = true;
-    return join_dw(E);
+    const int rc = join_dw(E);
+    stamp(E, 10);
+    return rc;
+}
+
+/* developer aid (FCL_TE_STAMPS=1): milliseconds from the start of the last fcl_te_forward_backward to each phase boundary on the main stream
+ * (see stamp(); -1 = not recorded); synchronises on the last recorded event */
+int fcl_te_phase_ms(fcl_te_t* E, float* out12) {
+    FCL_REQUIRE(E && out12, FCL_ERR_INVALID, "fcl_te_phase_ms: null argument");
+    for (int i = 0; i < 12; ++i) {
+        out12[i] = -1.f;
+        if (i == 0 || !E->stamp_set[i] || !E->stamp_set[0]) continue;
+        if (hipEventSynchronize(E->stamp_ev[i]) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, E->stamp_ev[0], E->stamp_ev[i]) == hipSuccess) out12[i] = ms;
+    }
+    if (E->stamp_set[0]) out12[0] = 0.f;
+    return 0;
 }
 
 }  // extern "C"

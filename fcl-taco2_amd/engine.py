@@ -451,6 +451,8 @@ def shared_streams(device, n):
     dev = torch.device(device)
     key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
     pool = _SHARED_STREAMS.setdefault(key, [])
+    if not pool:  # developer aid: FCL_STREAM_SKIP=k leaves the first k streams of torch's per-device pool unused (which hardware queue a stream lands on)
+        _SHARED_STREAMS[key + ("skipped",)] = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("FCL_STREAM_SKIP", "0")))]
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=dev))
     return pool[:n]

@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 416
+#define FCL_ABI_VERSION 417
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -784,6 +784,9 @@ int fcl_te_backward_stage(fcl_te_t* te, int stage, fcl_stream_t stream);
 int fcl_te_join(fcl_te_t* te, fcl_stream_t stream);
 /* diagnostics: launches issued by the last forward_backward (all stages) / knowledge call, and the arena bytes it used */
 int64_t fcl_te_last_launches(fcl_te_t* te);
+/* developer aid (FCL_TE_STAMPS=1): ms from the start of the last fcl_te_forward_backward to its phase boundaries on the main stream: [0] start,
+ * [1] encoder, [2] prenet + hoists, [3] decoder cells, [4] forward end, [5] losses, [6..9] backward stages 0..3, [10] join; -1 = not recorded */
+int fcl_te_phase_ms(fcl_te_t* te, float* out12);
 int64_t fcl_te_arena_bytes(fcl_te_t* te);
 
 #ifdef __cplusplus
