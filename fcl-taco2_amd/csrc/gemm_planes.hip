@@ -1073,13 +1073,16 @@ int launch_lstm_planes_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipS
     const int M = a0.M > a1.M ? a0.M : a1.M, U = a0.U;
     const bool hi = gemm_mode() == FCL_GEMM_BF16;
     // the training-side thresholds of launch_lstm_planes on the larger of the two row counts (both problems share one tile shape)
-    static const int big_min = tunable("PLSTM_BIG_MIN", 150), mid_min = tunable("PLSTM_MID_MIN", 200), row32_m = tunable("PLSTM_ROW32_M", 1100);
+    static const int big_min = tunable("PLSTM_PAIR_BIG_MIN", tunable("PLSTM_BIG_MIN", 150)), mid_min = tunable("PLSTM_PAIR_MID_MIN", tunable("PLSTM_MID_MIN", 200)),
+                     row32_m = tunable("PLSTM_PAIR_ROW32_M", tunable("PLSTM_ROW32_M", 1100));
     const long long t128 = (long long)((M + 127) / 128) * ((U + 31) / 32), t64 = (long long)((M + 63) / 64) * ((U + 31) / 32);
 #define FCL_PAIR(WM_, WN_, TM_, NST_) (hi ? launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 1>(a0, a1, s, flops) : launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 0>(a0, a1, s, flops))
     static const int two_stage = tunable("PLSTM_PAIR_2STAGE_MIN_WG", 1 << 30);  // (r5 A/B: two ring stages = two workgroups per CU for the pair's big tiles)
+    static const int all2 = tunable("PLSTM_PAIR_NST2", 0);  // (r5 A/B: two ring stages everywhere = <= 64 KB of LDS and <= 80 VGPRs per workgroup, so that
+                                                           // the frozen teacher's steps and the student's can share a CU in the KD update)
     if (t128 >= two_stage) return FCL_PAIR(4, 2, 2, 2);
-    if (t128 >= big_min) return FCL_PAIR(4, 2, 2, 3);
-    if (t64 >= mid_min) return FCL_PAIR(2, 2, 2, 3);
+    if (t128 >= big_min) return all2 ? FCL_PAIR(4, 2, 2, 2) : FCL_PAIR(4, 2, 2, 3);
+    if (t64 >= mid_min) return all2 ? FCL_PAIR(2, 2, 2, 2) : FCL_PAIR(2, 2, 2, 3);
     if (M <= row32_m) return FCL_PAIR(2, 2, 1, 4);
     return FCL_PAIR(2, 1, 2, 4);
 #undef FCL_PAIR
