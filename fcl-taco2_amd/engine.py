@@ -558,13 +558,22 @@ class BatchRunner(object):
             # warm-up on a minimal valid batch (one phoneme of duration 1 per utterance), then capture
             self.load([np.ones(1, dtype=np.int64)] * self.B, [np.ones(1, dtype=np.int64)] * self.B if self.forced else None,
                       [np.ones(self.S, dtype=np.float32)] * self.B if self.S else None)
-            with torch.cuda.stream(self.stream):
-                if self._ingraph:
-                    self._feed(False)
-                run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
-            self.stream.synchronize()
-            if self.forced and int(self.status.item()):
-                raise ops._lib.FclError("fcl-taco2_amd: BatchRunner warm-up failed: %s" % ops.status_message(int(self.status.item()) & 0xFFFFFFFF))
+            # the eager warm-up pass does the library's lazy one-time setup (per-kernel dynamic-LDS opt-ins, which a capture must not contain) for
+            # the kernel forms THIS geometry selects: once per (plan, geometry) -- the other runners of a bucket (the decode driver keeps one per
+            # stream) capture straight away (round 5: 16 warm-ups of a first decode() call -> 4)
+            warm_key = (self.B, self.T, caps.lmax, caps.frames, caps.bounds.tobytes(), caps.tail_from, self.forced, int(dropout_mode), self.S)
+            warmed = plan.__dict__.setdefault("_runner_warm", set())
+            if warm_key not in warmed:
+                with torch.cuda.stream(self.stream):
+                    if self._ingraph:
+                        self._feed(False)
+                    run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
+                self.stream.synchronize()
+                if self.forced and int(self.status.item()):
+                    raise ops._lib.FclError("fcl-taco2_amd: BatchRunner warm-up failed: %s" % ops.status_message(int(self.status.item()) & 0xFFFFFFFF))
+                warmed.add(warm_key)
+            else:
+                self.stream.synchronize()
             self.status.zero_()  # (predicted durations: the warm-up ids need not predict valid ones)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
