@@ -839,6 +839,27 @@ def gen_g21():
     save("g21_teacher_r2", **d)
 
 
+def gen_g22():
+    """G22 (round 5): the KD classes with the structure options their tap lists allow (records.json: `prenet_layers` 1 / 3 and `elayers` 2 run in
+    ..._kd_teacher / ..._kd_student; `dlayers` 1 raises IndexError, 3 taps the middle cell): a KD teacher with THREE prenet blocks and TWO BiLSTM
+    layers, a student with ONE prenet block and two BiLSTM layers.  The prenet tap is the last block's output, the encoder taps are unchanged."""
+    kw = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, elayers=2)
+    TA = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, prenet_layers=3, **kw)
+    SA = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, prenet_layers=1, **kw)
+    raw, b = make_converter_batch(TINY_S, seed=7)
+    kt, _ = build("kd_teacher", TA)
+    with torch.no_grad():
+        know = kt(**b)
+    st, spec = build("student", SA, TA, True)
+    assert "dec.prenet.prenet.1.0.weight" not in spec and "enc.blstm.weight_ih_l1_reverse" in spec
+    loss = st(teacher_knowledge=know, **b)
+    loss.backward()
+    d = dict(loss=np.float32(loss.item()), t_after=t2n(know[0]), t_before=t2n(know[1]), t_enc4=t2n(know[2][4]), t_dec0=t2n(know[3][0]), t_dec2=t2n(know[3][2]))
+    _named_losses(st, d)
+    _grads(st, [k for k in GRAD_KEYS if k in spec] + KD_KEYS + ["enc.blstm.weight_ih_l1", "enc.blstm.weight_hh_l1_reverse", "dec.prenet.prenet.0.0.weight"], d)
+    save("g22_student_kd_structure", **d)
+
+
 def gen_option_records():
     """records.json: what the reference itself does with the options the HIP path refuses (nets/base.py): speaker embeddings and reduction_factor > 1.
     Neither is in a shipped recipe (conf/*.yaml; LJSpeech is single-speaker).  The KD student cannot run with speaker embeddings in the reference:
@@ -926,7 +947,9 @@ def main():
     _install_stubs()
     only = set(sys.argv[1:])  # e.g. `gen_golden.py g10`: that set alone (every set is a pure function of the reference + closed-form inputs)
     if only:
-        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g21", "records"}, only
+        assert only <= {"g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18", "g21", "g22", "records"}, only
+        if "g22" in only:
+            gen_g22()
         if "g21" in only:
             gen_g21()
         if "g18" in only:
@@ -967,6 +990,7 @@ def main():
     gen_g17()
     gen_g18_g19_g20()
     gen_g21()
+    gen_g22()
     gen_option_records()
 
 

@@ -88,3 +88,8 @@ TINY_VARIANTS = {
 
 # reduction_factor 2 on the teacher class (G21)
 TINY_R2 = HP.teacher_hparams(reduction_factor=2, **_OPT)
+
+# the KD classes with the structure options their tap lists allow (G22): teacher with three prenet blocks, student with one; two BiLSTM layers each
+_KDS = dict(idim=12, odim=8, duration_predictor_chans=20, dropout_rate=0.0, elayers=2)
+TINY_TQ = HP.teacher_hparams(embed_dim=32, eunits=32, econv_chans=32, dunits=40, prenet_units=28, postnet_chans=20, prenet_layers=3, **_KDS)
+TINY_SQ = HP.student_hparams(embed_dim=16, eunits=16, econv_chans=16, dunits=24, prenet_units=20, postnet_chans=12, prenet_layers=1, **_KDS)

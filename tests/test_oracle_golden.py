@@ -462,6 +462,25 @@ def test_g18_g19_g20_structure_options(golden, name):
     assert _check_grads(sd, g) >= 10
 
 
+def test_g22_kd_classes_with_structure_options(golden):
+    """KD teacher with `prenet_layers` 3 / `elayers` 2, student with `prenet_layers` 1 / `elayers` 2: the teacher's 5-tuple and the student's KD step
+    (losses, gradients incl. the projections and the second BiLSTM layer) vs the real reference."""
+    from helpers import TINY_SQ, TINY_TQ
+
+    g4, g = golden("g4_integer"), golden("g22_student_kd_structure")
+    b = O.convert_batch(*_raw_batch(g4, 4))
+    with torch.no_grad():
+        know = O.model_forward(torch_state_dict(TINY_TQ), TINY_TQ, b, "kd_teacher")
+    assert max_abs(know[0], g["t_after"]) < TOL_STAGE and max_abs(know[2][4], g["t_enc4"]) < TOL_STAGE
+    assert max_abs(know[3][0], g["t_dec0"]) < TOL_STAGE and max_abs(know[3][2], g["t_dec2"]) < TOL_STAGE
+    sd = _grad_sd(TINY_SQ, TINY_TQ, True)
+    rep = O.model_forward(sd, TINY_SQ, b, "student", TINY_TQ, True, know)
+    rep["loss"].backward()
+    for k in ("loss", "encoder_loss", "decoder_loss", "prosody_loss", "output_l1_loss", "output_mse_loss"):
+        assert abs(float(rep[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), (k, float(rep[k]), float(g[k]))
+    assert _check_grads(sd, g) >= 18
+
+
 def test_g21_reduction_factor_2(golden):
     """`reduction_factor` 2 (teacher class): the converter's layout in frames (tts.py:250-258) bit-exact, inference mel (position t / d in steps,
     r frames per step), training step (every r-th target frame teacher-forced, position t / (r d) from the converter, targets cut to whole groups)."""
