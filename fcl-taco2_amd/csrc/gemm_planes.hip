@@ -660,6 +660,13 @@ static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM);
     char full[64];
     snprintf(full, sizeof(full), "pgemm_kernel<%d,%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NST, LW, HI == 2 ? "/f32" : HI ? "/bf16" : "", a.accumulate ? "/dW" : "");
+    static const int shapes = tunable("PROF_SHAPES", 0);  // developer aid: the profile records split by shape (M x N x sum K)
+    if (shapes && g_prof_on) {
+        long long ks = 0;
+        for (int i = 0; i < a.nterms; ++i) ks += a.term[i].K;
+        const size_t l = strlen(full);
+        snprintf(full + l, sizeof(full) - l, " %dx%dx%lld", a.M, a.N, ks);
+    }
     ProfScope ps(full, flops, a.M, s);
     if (a.accumulate && a.nterms == 1) {  // weight gradient: few output tiles, long contraction -> slices of the contraction over gridDim.z, ~512 workgroups
         GemmArgs b = a;

@@ -90,8 +90,10 @@ def test_plan_refuses_cpu_device():
     hp = HP.student_hparams()
     with pytest.raises(_lib.FclError, match="GPU"):
         SynthesisPlan(SYN.closed_form_state_dict(HP.param_spec(hp)), hp, "cpu")
-    with pytest.raises(NotImplementedError):
-        HP.student_hparams(reduction_factor=2).check_supported()
+    HP.student_hparams(reduction_factor=2, dlayers=3, prenet_layers=1, elayers=2).check_supported()  # round 5: the teacher class's structure options
+    for bad in (dict(reduction_factor=0), dict(dlayers=4), dict(prenet_layers=0), dict(elayers=0), dict(use_fe_condition=False)):
+        with pytest.raises(NotImplementedError):
+            HP.student_hparams(**bad).check_supported()
 
 
 def test_round2_entry_points_validate_arguments_without_a_gpu(lib):

@@ -72,8 +72,11 @@ def test_unsupported_configurations_fail_loudly():
     cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True)), com())  # round 3: encoder skip connections are on the HIP path (G11)
     with pytest.raises(NotImplementedError):  # ... which need embed_dim == econv_chans, as the reference's `convs[i](xs) + xs` does
         cls(80, 80, argparse.Namespace(**dict(T_ARGS, use_residual=True, embed_dim=256)), com())
-    with pytest.raises(NotImplementedError):
-        cls(80, 80, argparse.Namespace(**dict(T_ARGS, reduction_factor=2)), com())
+    m_r2 = cls(80, 80, argparse.Namespace(**dict(T_ARGS, reduction_factor=2, dlayers=3, prenet_layers=1, elayers=2)), com())  # round 5: the structure options (G18-G21)
+    assert m_r2.state_dict()["dec.feat_out.weight"].shape[0] == 160 and "dec.lstm.2.cell.weight_ih" in m_r2.state_dict()
+    for bad in (dict(reduction_factor=9), dict(dlayers=4), dict(prenet_layers=0)):  # ... inside the ranges the kernels cover
+        with pytest.raises(NotImplementedError):
+            cls(80, 80, argparse.Namespace(**dict(T_ARGS, **bad)), com())
     for name in ("relu", "tanh", "sigmoid"):  # round 3: output_activation is on the HIP path (G12) for the activations with a kernel ...
         assert cls(80, 80, argparse.Namespace(**dict(T_ARGS, output_activation=name)), com()).hp.output_activation == name
     with pytest.raises(NotImplementedError):  # ... any other torch.nn.functional name is refused
