@@ -95,6 +95,126 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
     }
 }
 
+// ---- H = 128, round 5: the same recurrence with the contraction split over the LANES instead of broadcast to every row.
+// The row-per-thread kernel above reads all H values of h per thread and step: 32 broadcast `ds_read_b128` per wave = 256 per workgroup, ~2 000 LDS
+// cycles of its ~2 500-cycle step (the FMAs are 64 v_pk_fma_f32 per wave).  Here a lane owns an [8 rows x 16 k] block of W_hh (the same 128 weights
+// in registers): the rows are the 4 gates of 2 units, the 8 lanes of a group cover the 8 k-slices of those rows, a wave covers 16 units.  Per step a
+// lane reads ITS 16 h values (4 ds_read_b128), 64 v_pk_fma_f32 (h splat by op_sel), then a reduce-scatter over the 8 lanes in three DPP exchanges
+// (row_half_mirror, quad_perm [2,3,0,1], quad_perm [1,0,3,2]: 4 + 2 + 1 adds) leaves lane q with gate q & 3 of unit 2 R + (q >> 2).  Every lane applies
+// ITS gate's activation (2 transcendentals instead of 8 on a quarter of the threads), the quad exchanges the four activated gates by DPP, the cell
+// update runs replicated in the quad, lane 0 of the quad publishes h into the other half of a double-buffered LDS vector: ONE barrier per step.
+// Gate pre-activations are prefetched four steps ahead (a step is shorter than a global load).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <bool SAVE = false, bool MAPS = false>
+__global__ __launch_bounds__(512) void bilstm_ksplit_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r,
+                                                            const float* __restrict__ whh_f, const float* __restrict__ whh_r,
+                                                            const int* __restrict__ lens, float* __restrict__ out, int T, BilstmSave sv = BilstmSave(),
+                                                            unsigned short* __restrict__ out_p = nullptr, fcl_row_maps_t mp = fcl_row_maps_t()) {
+    constexpr int H = 128;
+    if constexpr (MAPS) {
+        if (blockIdx.x == gridDim.x - 1) {
+            if (blockIdx.y == 0) {
+                row_maps_block<4 * H>(mp);
+                row_maps_finish_block<4 * H>(mp);
+            }
+            return;
+        }
+    }
+    __shared__ __attribute__((aligned(16))) float h_s[2][H];
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    const int q = j & 7, R = j >> 3;       // k-slice, row group (2 units x 4 gates)
+    const int g = q & 3, U = 2 * R + (q >> 2);  // the gate / unit this lane ends up with after the reduce-scatter
+    const float* gx = (dir ? gx_r : gx_f) + (size_t)b * T * (4 * H);
+    const float* whh = dir ? whh_r : whh_f;
+    const int len = lens[b];
+
+    f32x2 w[4][16];  // pair p = rows i = 2p, 2p + 1 of the block; row i = gate (i & 3) of unit 2R + (i >> 2)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float* r0 = whh + (size_t)(((2 * p) & 3) * H + 2 * R + ((2 * p) >> 2)) * H + 16 * q;
+        const float* r1 = whh + (size_t)(((2 * p + 1) & 3) * H + 2 * R + ((2 * p + 1) >> 2)) * H + 16 * q;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(r0 + kk), v1 = *reinterpret_cast<const f32x4*>(r1 + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[p][kk + e] = f32x2{v0[e], v1[e]};
+        }
+    }
+    if (j < 2 * H) (&h_s[0][0])[j] = 0.f;
+    // zero the padded tail of this direction's half of the output rows
+    for (int t = len + (j / H); t < T; t += 4) {
+        out[((size_t)b * T + t) * (2 * H) + dir * H + (j % H)] = 0.f;
+        if (out_p) store_p32(out_p, (2 * H + 31) >> 5, b * T + t, dir * H + (j % H), 0.f);
+    }
+    __syncthreads();
+
+    const int t0 = dir ? len - 1 : 0, dt = dir ? -1 : 1;
+    const float* gp = gx + g * H + U;
+    float gq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) gq[d] = d < len ? gp[(size_t)(t0 + d * dt) * (4 * H)] : 0.f;
+    float c = 0.f, h_prev = 0.f;
+    const bool lo1 = q < 4, lo2 = (q & 2) == 0, lo3 = (q & 1) == 0;
+    const float sc = g == 2 ? 2.f : 1.f;
+
+    for (int s0 = 0; s0 < len; s0 += 4) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int s = s0 + d;
+            if (s >= len) break;  // uniform
+            const int t = t0 + s * dt;
+            const float gcur = gq[d];
+            if (s + 4 < len) gq[d] = gp[(size_t)(t + 4 * dt) * (4 * H)];
+            const float* hs = h_s[d & 1];
+            f32x4 hv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = *reinterpret_cast<const f32x4*>(hs + 16 * q + 4 * e);
+            f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const float hk = hv[kk >> 2][kk & 3];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[p] = __builtin_elementwise_fma(w[p][kk], f32x2{hk, hk}, acc[p]);
+            }
+            const float a8[8] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
+            float k4[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) k4[x] = (lo1 ? a8[x] : a8[4 + x]) + dpp_f<0x141>(lo1 ? a8[4 + x] : a8[x]);  // row_half_mirror: lane q <-> 7 - q
+            float k2[2];
+#pragma unroll
+            for (int x = 0; x < 2; ++x) k2[x] = (lo2 ? k4[x] : k4[2 + x]) + dpp_f<0x4E>(lo2 ? k4[2 + x] : k4[x]);  // quad_perm [2,3,0,1]
+            const float z = gcur + ((lo3 ? k2[0] : k2[1]) + dpp_f<0xB1>(lo3 ? k2[1] : k2[0]));                      // quad_perm [1,0,3,2]
+            const float r = __builtin_amdgcn_rcpf(1.0f + __expf(-sc * z));
+            const float a = g == 2 ? 2.0f * r - 1.0f : r;  // tanh(z) = 2 sigmoid(2 z) - 1
+            const float ig = dpp_f<0x00>(a), fg = dpp_f<0x55>(a), gg = dpp_f<0xAA>(a), og = dpp_f<0xFF>(a);
+            const float c_new = fg * c + ig * gg;
+            const float h = og * tanh_f(c_new);
+            if (SAVE) {
+                const size_t cell = (size_t)t * sv.B + b;
+                sv.gates[dir][cell * (4 * H) + g * H + U] = a;
+                if (g == 0) {
+                    sv.c_old[dir][cell * H + U] = c;
+                    sv.h_old[dir][cell * H + U] = h_prev;
+                    sv.c_new[dir][cell * H + U] = c_new;
+                }
+            }
+            if (g == 0) {
+                h_s[(d & 1) ^ 1][U] = h;
+                out[((size_t)b * T + t) * (2 * H) + dir * H + U] = h;
+                if (out_p) store_p32(out_p, (2 * H + 31) >> 5, b * T + t, dir * H + U, h);
+            }
+            c = c_new;
+            h_prev = h;
+            __syncthreads();
+        }
+    }
+}
+
 // Reverse pass of one (utterance, direction): thread (q, k) = (j / H, j % H) keeps the H weights W_hh[qH .. qH+H, k] (read from the transposed
 // matrix, contiguous) in registers; per step the first H threads do the cell backward, all 4H threads a quarter of dh = dgates . W_hh, the quarters
 // meet in LDS.  Visits only live cells, in the reverse of the forward's order; the dead tail of dg is zeroed here.
@@ -330,6 +450,11 @@ namespace fcl {
 
 // both directions of the training forward / reverse pass in one launch each; false = H unsupported (the caller falls back to per-step launches)
 // H = 256: groups of 4 workgroups.  ws: [2B] flags + 1 error word (zeroed here) followed by the exchange buffer.
+static bool bilstm_ksplit_enabled() {
+    static const int on = tunable("BILSTM_KSPLIT", 1);
+    return on != 0;
+}
+
 size_t bilstm_group_workspace_bytes(int B, int H) { return 1024 + sizeof(unsigned int) * 2 * (size_t)B + sizeof(float) * 2 * (size_t)B * 2 * 4 * H; }
 
 static bool group_ok(int B, int H, void* ws, size_t ws_bytes, const unsigned int* status) {
@@ -369,6 +494,12 @@ bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const 
                                     int H, const BilstmSave& sv, hipStream_t s) {
     dim3 grid(B, 2);
     if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return false;
+    if (H == 128 && bilstm_ksplit_enabled()) {
+        ProfScope ps("bilstm_ksplit_kernel/train", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
+        hipLaunchKernelGGL((bilstm_ksplit_kernel<true, false>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, sv, (unsigned short*)nullptr,
+                           fcl_row_maps_t());
+        return true;
+    }
     ProfScope ps("bilstm_persistent_kernel/train", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
 #define FCL_BILSTM_CASE(HH) \
     case HH: hipLaunchKernelGGL((bilstm_persistent_kernel<HH, true>), grid, dim3(4 * HH), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, sv); return true;
@@ -473,6 +604,18 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     }
     if (algo == 0 || algo == 3) algo = can_persist ? 2 : 1;
     FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);
+    if (algo == 2 && h == 128 && bilstm_ksplit_enabled()) {
+        const bool fuse = row_maps && maps_fusable && fuse_on;
+        ProfScope ps(fuse ? "bilstm_ksplit_kernel+maps" : "bilstm_ksplit_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
+        if (fuse)
+            hipLaunchKernelGGL((bilstm_ksplit_kernel<false, true>), dim3(b + 1, 2), dim3(512), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t, BilstmSave(), out_p,
+                               *row_maps);
+        else
+            hipLaunchKernelGGL((bilstm_ksplit_kernel<false, false>), dim3(b, 2), dim3(512), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t, BilstmSave(), out_p,
+                               fcl_row_maps_t());
+        const int rc = check_hip(hipGetLastError(), "bilstm k-split launch");
+        return fuse ? rc : after.finish(rc);
+    }
     if (algo == 2 && h == 128 && row_maps && maps_fusable && fuse_on) {
         ProfScope ps("bilstm_persistent_kernel+maps", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
         hipLaunchKernelGGL((bilstm_persistent_kernel<128, false, true>), dim3(b + 1, 2), dim3(512), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t, BilstmSave(),

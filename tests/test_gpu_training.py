@@ -83,10 +83,18 @@ def _check_vs_golden(eng, rep, g, loss_keys, tol=5e-4):
     return n
 
 
-def _check_vs_golden_illcond(eng, rep, g, loss_keys):
+def _tol_dump(name, ratio):
+    """FCL_TEST_TOL_DUMP=<file>: append `test tensor ratio` (how the loose tolerances below were chosen: 4x the worst ratio seen)."""
+    dump = os.environ.get("FCL_TEST_TOL_DUMP")
+    if dump:
+        with open(dump, "a") as f:
+            f.write("%s %s %.3e\n" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0], name, ratio))
+
+
+def _check_vs_golden_illcond(eng, rep, g, loss_keys, tol=2e-2):
     """_check_vs_golden for a closed-form net whose eps-1e-12 LayerNorms amplify rounding ~100x (see the G13 test): on bf16x3 operands (2^-16 per
-    product) the losses are held at 5e-4 and the gradients at 1e-1 of the tensor's scale; the exact-fp32 mode of the same test (FCL_PRECISION=0) pins
-    every tensor at 5e-4."""
+    product) the losses are held at 5e-4 and the gradients at `tol` of the tensor's scale (2e-2: 4x the worst ratio over G15 / G20 / G22, 5.5e-3 on
+    BiLSTM layer 0 of the two-layer encoder; ADVICE r4: was a blanket 1e-1); the exact-fp32 mode of the same test (FCL_PRECISION=0) pins every tensor at 5e-4."""
     from fcl_taco2_amd import ops
 
     if not ops.planes_enabled():
@@ -97,7 +105,9 @@ def _check_vs_golden_illcond(eng, rep, g, loss_keys):
     for k, ref in g.items():
         if k.startswith("grad:"):
             n += 1
-            assert max_abs(eng.G[k[5:]].cpu(), ref) < 1e-1 * max(1.0, float(np.abs(ref).max())), k
+            ratio = max_abs(eng.G[k[5:]].cpu(), ref) / max(1.0, float(np.abs(ref).max()))
+            _tol_dump(k[5:], ratio)
+            assert ratio < tol, (k, ratio)
     return n
 
 
@@ -108,6 +118,7 @@ def _check_vs_oracle(eng, sd, tol=5e-4):
     for k, ref in og.items():
         ref = torch.zeros_like(eng.P[k]).cpu() if ref is None else ref
         err = max_abs(eng.G[k].cpu(), ref) / max(1.0, float(ref.abs().max()))
+        _tol_dump(k, err)
         if err > tol:
             bad[k] = err
     assert not bad, bad
@@ -637,7 +648,9 @@ def test_speaker_embeddings_vs_reference_g13():
         for k, ref in g.items():
             if k.startswith("grad:"):
                 n += 1
-                assert max_abs(eng.G[k[5:]].cpu(), ref) < 1e-1 * max(1.0, float(np.abs(ref).max())), k
+                ratio = max_abs(eng.G[k[5:]].cpu(), ref) / max(1.0, float(np.abs(ref).max()))
+                _tol_dump(k[5:], ratio)
+                assert ratio < 1e-1, (k, ratio)
         assert n >= 12
     else:
         assert _check_vs_golden(eng, rep, g, KD_KEYS[:6]) >= 12
