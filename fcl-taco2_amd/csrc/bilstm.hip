@@ -105,9 +105,66 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
 // update runs replicated in the quad, lane 0 of the quad publishes h into the other half of a double-buffered LDS vector: ONE barrier per step.
 // Gate pre-activations are prefetched four steps ahead (a step is shorter than a global load).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// DPP on gfx950 beside foreign waves (measured, round 5).  A DPP read of a VGPR needs two wait states after the VALU write of that register; hipcc inserts
+// them (s_nop or whatever two instructions are at hand).  With the device to itself these kernels -- two waves per SIMD, 168 - 194 VGPRs each -- are exact.  Beside
+// another stream's kernels they returned 1e-3 .. 1e-2 errors in single units in 299 of 300 launches (`tools/stress_bilstm_concurrent.py`), always in lanes 48 - 63
+// (the last pass of a wave64 instruction) of some wave: a partial sum read before its producer's last pass had written it.  Sixteen wait states around the DPP
+// reads, the DPP results or the transcendentals each removed it, two did not; so did claiming the SIMD's whole register file, which keeps a third (foreign) wave
+// off the SIMD: with more waves interleaving their passes the two architectural wait states are evidently not enough time.  Both are applied: ks_exclusive()
+// at the top of every kernel that uses dpp_f (the CU is this workgroup's anyway: 8 waves x 256 VGPRs), and four wait states tied to the DPP source.
+__device__ __forceinline__ void ks_exclusive() { asm volatile("v_mov_b32 v255, 0" ::: "v255"); }
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
+    asm volatile("s_nop 3" : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// a lane's [8 x 16] weight block against its 16-value slice of the vector in LDS: 4 ds_read_b128 + 64 v_pk_fma_f32 (the vector element splat by op_sel)
+__device__ __forceinline__ void ks_matvec(const f32x2 (&w)[4][16], const float* __restrict__ v16, float (&a8)[8]) {
+    f32x4 hv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hv[e] = *reinterpret_cast<const f32x4*>(v16 + 4 * e);
+    f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+        const float hk = hv[kk >> 2][kk & 3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = __builtin_elementwise_fma(w[p][kk], f32x2{hk, hk}, acc[p]);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        a8[2 * p] = acc[p][0];
+        a8[2 * p + 1] = acc[p][1];
+    }
+}
+
+// reduce-scatter of 8 values over the 8 lanes of a group (q3 = lane & 7): lane q3 returns the group's total of a8[q3].  Three DPP exchanges:
+// row_half_mirror (q3 <-> 7 - q3), quad_perm [2,3,0,1], quad_perm [1,0,3,2]; 4 + 2 + 1 adds
+__device__ __forceinline__ float ks_reduce_scatter8(const float (&a8)[8], int q3) {
+    const bool lo1 = q3 < 4, lo2 = (q3 & 2) == 0, lo3 = (q3 & 1) == 0;
+    float k4[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) k4[x] = (lo1 ? a8[x] : a8[4 + x]) + dpp_f<0x141>(lo1 ? a8[4 + x] : a8[x]);
+    float k2[2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x) k2[x] = (lo2 ? k4[x] : k4[2 + x]) + dpp_f<0x4E>(lo2 ? k4[2 + x] : k4[x]);
+    return (lo3 ? k2[0] : k2[1]) + dpp_f<0xB1>(lo3 ? k2[1] : k2[0]);
+}
+
+// lane (gate g = lane & 3 of its unit) holds the gate's pre-activation z: activation of that gate (tanh(z) = 2 sigmoid(2z) - 1: two transcendentals
+// per lane), the quad's four activated gates by DPP, the cell update replicated in the quad
+struct KsCell {
+    float a, c_new, h;
+};
+__device__ __forceinline__ KsCell ks_cell(float z, int g, float c) {
+    const float sc = g == 2 ? 2.f : 1.f;
+    const float r = __builtin_amdgcn_rcpf(1.0f + __expf(-sc * z));
+    KsCell o;
+    o.a = g == 2 ? 2.0f * r - 1.0f : r;
+    const float ig = dpp_f<0x00>(o.a), fg = dpp_f<0x55>(o.a), gg = dpp_f<0xAA>(o.a), og = dpp_f<0xFF>(o.a);
+    o.c_new = fg * c + ig * gg;
+    o.h = og * tanh_f(o.c_new);
+    return o;
 }
 
 template <bool SAVE = false, bool MAPS = false>
@@ -126,6 +183,7 @@ __global__ __launch_bounds__(512) void bilstm_ksplit_kernel(const float* __restr
         }
     }
     __shared__ __attribute__((aligned(16))) float h_s[2][H];
+    ks_exclusive();
     const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
     const int q = j & 7, R = j >> 3;       // k-slice, row group (2 units x 4 gates)
     const int g = q & 3, U = 2 * R + (q >> 2);  // the gate / unit this lane ends up with after the reduce-scatter
@@ -159,8 +217,6 @@ __global__ __launch_bounds__(512) void bilstm_ksplit_kernel(const float* __restr
 #pragma unroll
     for (int d = 0; d < 4; ++d) gq[d] = d < len ? gp[(size_t)(t0 + d * dt) * (4 * H)] : 0.f;
     float c = 0.f, h_prev = 0.f;
-    const bool lo1 = q < 4, lo2 = (q & 2) == 0, lo3 = (q & 1) == 0;
-    const float sc = g == 2 ? 2.f : 1.f;
 
     for (int s0 = 0; s0 < len; s0 += 4) {
 #pragma unroll
@@ -170,30 +226,10 @@ __global__ __launch_bounds__(512) void bilstm_ksplit_kernel(const float* __restr
             const int t = t0 + s * dt;
             const float gcur = gq[d];
             if (s + 4 < len) gq[d] = gp[(size_t)(t + 4 * dt) * (4 * H)];
-            const float* hs = h_s[d & 1];
-            f32x4 hv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = *reinterpret_cast<const f32x4*>(hs + 16 * q + 4 * e);
-            f32x2 acc[4] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                const float hk = hv[kk >> 2][kk & 3];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[p] = __builtin_elementwise_fma(w[p][kk], f32x2{hk, hk}, acc[p]);
-            }
-            const float a8[8] = {acc[0][0], acc[0][1], acc[1][0], acc[1][1], acc[2][0], acc[2][1], acc[3][0], acc[3][1]};
-            float k4[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) k4[x] = (lo1 ? a8[x] : a8[4 + x]) + dpp_f<0x141>(lo1 ? a8[4 + x] : a8[x]);  // row_half_mirror: lane q <-> 7 - q
-            float k2[2];
-#pragma unroll
-            for (int x = 0; x < 2; ++x) k2[x] = (lo2 ? k4[x] : k4[2 + x]) + dpp_f<0x4E>(lo2 ? k4[2 + x] : k4[x]);  // quad_perm [2,3,0,1]
-            const float z = gcur + ((lo3 ? k2[0] : k2[1]) + dpp_f<0xB1>(lo3 ? k2[1] : k2[0]));                      // quad_perm [1,0,3,2]
-            const float r = __builtin_amdgcn_rcpf(1.0f + __expf(-sc * z));
-            const float a = g == 2 ? 2.0f * r - 1.0f : r;  // tanh(z) = 2 sigmoid(2 z) - 1
-            const float ig = dpp_f<0x00>(a), fg = dpp_f<0x55>(a), gg = dpp_f<0xAA>(a), og = dpp_f<0xFF>(a);
-            const float c_new = fg * c + ig * gg;
-            const float h = og * tanh_f(c_new);
+            float a8[8];
+            ks_matvec(w, h_s[d & 1] + 16 * q, a8);
+            const KsCell cl = ks_cell(gcur + ks_reduce_scatter8(a8, q), g, c);
+            const float a = cl.a, c_new = cl.c_new, h = cl.h;
             if (SAVE) {
                 const size_t cell = (size_t)t * sv.B + b;
                 sv.gates[dir][cell * (4 * H) + g * H + U] = a;
@@ -265,6 +301,79 @@ __global__ __launch_bounds__(4 * H) void bilstm_bptt_persistent_kernel(BilstmBwd
         p_s[q][k] = (a0 + a1) + (a2 + a3);
         __syncthreads();
         if (j < H) dh = (p_s[0][j] + p_s[1][j]) + (p_s[2][j] + p_s[3][j]);
+    }
+}
+
+// Reverse pass at H = 128 with the same lane split: a lane owns [16 rows x 8 k] of W_hh (16 consecutive gate rows are contiguous in the transposed
+// matrix), 32 r-slices x 16 k-groups; dh[k] = sum over the 32 r-slices: reduce-scatter over 8 lanes, row_ror:8, and a swizzle across the two rows of
+// the 32-lane group.  The sum lands in the lane that owns unit k's cell backward (lanes j & 31 < 8: 16 per wave, all eight waves), so dh never leaves
+// registers; operands of the coming step are prefetched; the gate-row gradients go to everybody through a double-buffered LDS vector: one barrier per step.
+template <int DUMMY = 0>
+__global__ __launch_bounds__(512) void bilstm_bptt_ksplit_kernel(BilstmBwd a, const int* __restrict__ lens, int T) {
+    constexpr int H = 128;
+    __shared__ __attribute__((aligned(16))) float dg_s[2][4 * H];
+    ks_exclusive();
+    const int b = blockIdx.x, dir = blockIdx.y, j = threadIdx.x;
+    const int rs = j & 31, q3 = rs & 7, kg = j >> 5;
+    const bool owner = rs < 8;
+    const int u = 8 * kg + q3;  // the unit whose dh this lane ends up with
+    const int len = lens[b];
+    f32x2 w[4][16];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const float* c0 = a.whh_t[dir] + (size_t)(8 * kg + 2 * pr) * (4 * H) + 16 * rs;
+        const float* c1 = c0 + 4 * H;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(c0 + rr), v1 = *reinterpret_cast<const f32x4*>(c1 + rr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[pr][rr + e] = f32x2{v0[e], v1[e]};
+        }
+    }
+    float* dg = a.dg[dir];
+    for (int t = len; t < T; ++t) dg[((size_t)t * a.B + b) * (4 * H) + j] = 0.f;  // dead cells contribute nothing to the weight gradients
+    float dh = 0.f, dc = 0.f;
+    const int t0 = dir ? 0 : len - 1, dt = dir ? 1 : -1;  // reverse of the forward's visiting order
+    float pre[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int t) {
+        const size_t cell = (size_t)t * a.B + b;
+        const float* gsv = a.gates[dir] + cell * (4 * H);
+        pre[0] = gsv[u]; pre[1] = gsv[H + u]; pre[2] = gsv[2 * H + u]; pre[3] = gsv[3 * H + u];
+        pre[4] = a.d_out[((size_t)b * T + t) * a.ld + dir * H + u];
+        pre[5] = a.c_new[dir][cell * H + u];
+        pre[6] = a.c_old[dir][cell * H + u];
+    };
+    if (owner && len > 0) fetch(t0);
+    for (int s0 = 0; s0 < len; s0 += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int s = s0 + d;
+            if (s >= len) break;  // uniform
+            const int t = t0 + s * dt;
+            if (owner) {
+                const float ig = pre[0], fg = pre[1], gg = pre[2], og = pre[3], dout = pre[4], cn = pre[5], co = pre[6];
+                if (s + 1 < len) fetch(t + dt);
+                const float dho = dh + dout;
+                const float tc = tanh_f(cn);
+                const float dcn = dc + dho * og * (1.0f - tc * tc);
+                const float d0 = dcn * gg * ig * (1.0f - ig), d1 = dcn * co * fg * (1.0f - fg);
+                const float d2 = dcn * ig * (1.0f - gg * gg), d3 = dho * tc * og * (1.0f - og);
+                float* ds = dg_s[d];
+                ds[u] = d0; ds[H + u] = d1; ds[2 * H + u] = d2; ds[3 * H + u] = d3;
+                float* o = dg + ((size_t)t * a.B + b) * (4 * H);
+                o[u] = d0; o[H + u] = d1; o[2 * H + u] = d2; o[3 * H + u] = d3;
+                dc = dcn * fg;
+            }
+            __syncthreads();
+            if (s + 1 < len) {
+                float a8[8];
+                ks_matvec(w, dg_s[d] + 16 * rs, a8);
+                float v = ks_reduce_scatter8(a8, q3);
+                v += dpp_f<0x128>(v);                                                                                 // r-slices + 8
+                v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));  // r-slices + 16 (lane ^ 16)
+                dh = v;
+            }
+        }
     }
 }
 
@@ -438,6 +547,207 @@ __global__ __launch_bounds__(512) void bilstm_bptt_group_kernel(BilstmBwd a, con
     }
 }
 
+// ---- H = 256, round 5: the group kernels with (1) the lane-split contraction of bilstm_ksplit_kernel (a workgroup's [256 rows x 256 k] block: 16
+// k-slices per row group, so the reduce-scatter is followed by one row_ror:8 add), (2) every per-step global operand prefetched, and (3) the exchange
+// as ONE memory round trip: a published word carries its value AND the step number (8-byte relaxed agent-scope store), consumers poll the words
+// themselves until the tag is the step's (tags are 16 bits: sequences shorter than 65 535 steps, checked by the launchers).  The counter protocol above costs four dependent round trips per step (drain stores, atomic add, spin, load).
+// Double buffering by step parity is safe: nobody can publish step s + 2 before it has consumed every member's step s + 1, which a member publishes only
+// after it has consumed step s.  The exchange area is zeroed before each launch (tags start at 1).
+// The two dwords of a published word each carry 16 bits of the value and the step's 16-bit tag: a reader accepts the word only when BOTH halves carry
+// the tag, so nothing depends on the 8-byte store reaching a polling reader as one piece.  (Measured: with {value, tag} dwords and readers polling while the
+// word is written, `tools/stress_bilstm_concurrent.py` -- the kernel beside another stream's work, members not co-resident -- returned a step's tag with the
+// value of two steps before in 299 of 300 launches; alone on the device it never showed.)
+__device__ __forceinline__ void ll_store(unsigned long long* p, float v, unsigned int tag) {
+    const unsigned int u = __float_as_uint(v), t16 = tag & 0xffffu;
+    const unsigned long long w = (unsigned long long)((u & 0xffff0000u) | t16) | ((unsigned long long)((u << 16) | t16) << 32);
+    __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ll_poll(const unsigned long long* p, unsigned int tag, float& v) {
+    const unsigned int t16 = tag & 0xffffu;
+    for (int spin = 0; spin < (1 << 22); ++spin) {
+        const unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int w0 = (unsigned int)w, w1 = (unsigned int)(w >> 32);
+        if ((w0 & 0xffffu) == t16 && (w1 & 0xffffu) == t16) {
+            v = __uint_as_float((w0 & 0xffff0000u) | (w1 >> 16));
+            return true;
+        }
+    }
+    return false;
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(512) void bilstm_group_ks_kernel(const float* __restrict__ gx_f, const float* __restrict__ gx_r, const float* __restrict__ whh_f,
+                                                              const float* __restrict__ whh_r, const int* __restrict__ lens, float* __restrict__ out, int T,
+                                                              unsigned long long* __restrict__ hbuf /* [groups][2][H] */, GroupSync gs, BilstmSave sv) {
+    constexpr int H = 256, P = 4;
+    __shared__ __attribute__((aligned(16))) float h_s[2][H];
+    __shared__ int ok_s;
+    ks_exclusive();
+    const int p = blockIdx.x % P, group = blockIdx.x / P;  // group = b * 2 + dir
+    const int b = group >> 1, dir = group & 1;
+    const int j = threadIdx.x, q = j & 15, q3 = q & 7, R = j >> 4;  // k-slice (16 of 16 k), row group (2 units x 4 gates of this workgroup's 64 units)
+    const int g = q3 & 3, U = p * 64 + 2 * R + (q3 >> 2);           // after the reduction (both halves of the 16 lanes hold the same sums)
+    const bool first_half = (q & 8) == 0, publisher = first_half && g == 0;
+    const float* gx = (dir ? gx_r : gx_f) + (size_t)b * T * (4 * H);
+    const float* whh = dir ? whh_r : whh_f;
+    const int len = lens[b];
+    f32x2 w[4][16];
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const float* r0 = whh + (size_t)(((2 * pr) & 3) * H + p * 64 + 2 * R + ((2 * pr) >> 2)) * H + 16 * q;
+        const float* r1 = whh + (size_t)(((2 * pr + 1) & 3) * H + p * 64 + 2 * R + ((2 * pr + 1) >> 2)) * H + 16 * q;
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(r0 + kk), v1 = *reinterpret_cast<const f32x4*>(r1 + kk);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[pr][kk + e] = f32x2{v0[e], v1[e]};
+        }
+    }
+    (&h_s[0][0])[j] = 0.f;
+    if (j == 0) ok_s = 1;
+    if (j < 64)
+        for (int t = len; t < T; ++t) out[((size_t)b * T + t) * (2 * H) + dir * H + p * 64 + j] = 0.f;  // padded tail of this slice
+    __syncthreads();
+    const int t0 = dir ? len - 1 : 0, dt = dir ? -1 : 1;
+    const float* gp = gx + g * H + U;
+    float gq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) gq[d] = d < len ? gp[(size_t)(t0 + d * dt) * (4 * H)] : 0.f;
+    float c = 0.f, h_prev = 0.f;
+    unsigned long long* hb = hbuf + (size_t)group * 2 * H;
+    for (int s0 = 0; s0 < len; s0 += 4) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int s = s0 + d;
+            if (s >= len) break;  // uniform
+            const int t = t0 + s * dt;
+            const float gcur = gq[d];
+            if (s + 4 < len) gq[d] = gp[(size_t)(t + 4 * dt) * (4 * H)];
+            float a8[8];
+            ks_matvec(w, h_s[d & 1] + 16 * q, a8);
+            float z = ks_reduce_scatter8(a8, q3);
+            z = gcur + (z + dpp_f<0x128>(z));  // row_ror:8: the other eight k-slices
+            const KsCell cl = ks_cell(z, g, c);
+            if (SAVE && first_half) {
+                const size_t cell = (size_t)t * sv.B + b;
+                sv.gates[dir][cell * (4 * H) + g * H + U] = cl.a;
+                if (g == 0) {
+                    sv.c_old[dir][cell * H + U] = c;
+                    sv.h_old[dir][cell * H + U] = h_prev;
+                    sv.c_new[dir][cell * H + U] = cl.c_new;
+                }
+            }
+            if (publisher) {
+                ll_store(hb + (d & 1) * H + U, cl.h, (unsigned int)(s + 1));
+                out[((size_t)b * T + t) * (2 * H) + dir * H + U] = cl.h;
+            }
+            c = cl.c_new;
+            h_prev = cl.h;
+            if (j < H && s + 1 < len) {  // the next step's h: all four slices, this workgroup's own included
+                float v = 0.f;
+                if (!ll_poll(hb + (d & 1) * H + j, (unsigned int)(s + 1), v)) {
+                    atomicOr(gs.error, (unsigned int)FCL_STATUS_GROUP_TIMEOUT);
+                    ok_s = 0;
+                }
+                h_s[(d & 1) ^ 1][j] = v;
+            }
+            __syncthreads();
+            if (!ok_s) return;
+        }
+    }
+}
+
+// reverse pass: a lane owns [16 rows x 8 k] of this workgroup's [256 gate rows x 256 k] block of W_hh (from the transposed matrix: 16 consecutive rows of
+// one gate are contiguous); 16 r-slices x 32 k-groups.  The 64 owner lanes (wave 0) poll the four partial sums of their unit from the previous step, do the
+// cell backward with operands prefetched a step ahead and hand this workgroup's gate-row gradients to everybody through LDS: one barrier per step.
+__global__ __launch_bounds__(512) void bilstm_bptt_group_ks_kernel(BilstmBwd a, const int* __restrict__ lens, int T,
+                                                                   unsigned long long* __restrict__ part /* [groups][2][P][H] */, GroupSync gs) {
+    constexpr int H = 256, P = 4;
+    __shared__ __attribute__((aligned(16))) float dg_s[2][256];  // (gate, unit-in-slice) order
+    __shared__ int ok_s;
+    ks_exclusive();
+    const int p = blockIdx.x % P, group = blockIdx.x / P;
+    const int b = group >> 1, dir = group & 1;
+    const int j = threadIdx.x, rs = j & 15, q3 = rs & 7, kg = j >> 4;
+    const int len = lens[b];
+    f32x2 w[4][16];  // pair pr: k = 8 kg + 2 pr, + 1; rr: local row 16 rs + rr = (gate, unit-in-slice)
+    {
+        const int lr = 16 * rs, grow = (lr >> 6) * H + p * 64 + (lr & 63);
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const float* c0 = a.whh_t[dir] + (size_t)(8 * kg + 2 * pr) * (4 * H) + grow;
+            const float* c1 = c0 + 4 * H;
+#pragma unroll
+            for (int rr = 0; rr < 16; rr += 4) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(c0 + rr), v1 = *reinterpret_cast<const f32x4*>(c1 + rr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[pr][rr + e] = f32x2{v0[e], v1[e]};
+            }
+        }
+    }
+    float* dg = a.dg[dir];
+    if (j < 256)
+        for (int t = len; t < T; ++t) dg[((size_t)t * a.B + b) * (4 * H) + (j >> 6) * H + p * 64 + (j & 63)] = 0.f;  // dead cells of this slice
+    if (j == 0) ok_s = 1;
+    __syncthreads();
+    float dh = 0.f, dc = 0.f;
+    const int t0 = dir ? 0 : len - 1, dt = dir ? 1 : -1;  // reverse of the forward's visiting order
+    unsigned long long* pb = part + (size_t)group * 2 * P * H;
+    const int u = p * 64 + (j & 63);
+    float pre[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // ig, fg, gg, og, d_out, c_new, c_old of the owner's unit at the coming step
+    auto fetch = [&](int t) {
+        const size_t cell = (size_t)t * a.B + b;
+        const float* gsv = a.gates[dir] + cell * (4 * H);
+        pre[0] = gsv[u]; pre[1] = gsv[H + u]; pre[2] = gsv[2 * H + u]; pre[3] = gsv[3 * H + u];
+        pre[4] = a.d_out[((size_t)b * T + t) * a.ld + dir * H + u];
+        pre[5] = a.c_new[dir][cell * H + u];
+        pre[6] = a.c_old[dir][cell * H + u];
+    };
+    if (j < 64 && len > 0) fetch(t0);
+    for (int s0 = 0; s0 < len; s0 += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int s = s0 + d;
+            if (s >= len) break;  // uniform
+            const int t = t0 + s * dt;
+            if (j < 64) {
+                const float ig = pre[0], fg = pre[1], gg = pre[2], og = pre[3], dout = pre[4], cn = pre[5], co = pre[6];
+                if (s + 1 < len) fetch(t + dt);
+                if (s > 0) {  // dh = the four workgroups' partial sums of the previous step
+                    float v[4];
+                    bool ok = true;
+#pragma unroll
+                    for (int pp = 0; pp < P; ++pp) ok = ll_poll(pb + ((d ^ 1) * P + pp) * H + u, (unsigned int)s, v[pp]) && ok;
+                    if (!ok) {
+                        atomicOr(gs.error, (unsigned int)FCL_STATUS_GROUP_TIMEOUT);
+                        ok_s = 0;
+                    }
+                    dh = (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                const float dho = dh + dout;
+                const float tc = tanh_f(cn);
+                const float dcn = dc + dho * og * (1.0f - tc * tc);
+                const float d0 = dcn * gg * ig * (1.0f - ig), d1 = dcn * co * fg * (1.0f - fg);
+                const float d2 = dcn * ig * (1.0f - gg * gg), d3 = dho * tc * og * (1.0f - og);
+                float* ds = dg_s[d];
+                ds[j] = d0; ds[64 + j] = d1; ds[128 + j] = d2; ds[192 + j] = d3;
+                float* o = dg + ((size_t)t * a.B + b) * (4 * H);
+                o[u] = d0; o[H + u] = d1; o[2 * H + u] = d2; o[3 * H + u] = d3;
+                dc = dcn * fg;
+            }
+            __syncthreads();
+            if (!ok_s) return;
+            if (s + 1 < len) {
+                float a8[8];
+                ks_matvec(w, dg_s[d] + 16 * rs, a8);
+                float v = ks_reduce_scatter8(a8, q3);
+                v += dpp_f<0x128>(v);
+                if ((rs & 8) == 0) ll_store(pb + (d * P + p) * H + 8 * kg + q3, v, (unsigned int)(s + 1));
+            }
+        }
+    }
+}
+
 __global__ void fill_kernel(float* p, long long n, float v) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -455,7 +765,11 @@ static bool bilstm_ksplit_enabled() {
     return on != 0;
 }
 
-size_t bilstm_group_workspace_bytes(int B, int H) { return 1024 + sizeof(unsigned int) * 2 * (size_t)B + sizeof(float) * 2 * (size_t)B * 2 * 4 * H; }
+// 1 KB (error word, flags from +1 KB) | flags [2B] | exchange area: [groups][2][4][H] 8-byte words (value + step tag; the counter-protocol kernels use it as floats)
+size_t bilstm_group_workspace_bytes(int B, int H) { return 1024 + sizeof(unsigned int) * 2 * (size_t)B + 32 + sizeof(unsigned long long) * 2 * (size_t)B * 2 * 4 * H; }
+static char* group_exchange_base(void* ws, int B) {  // 16-byte aligned, behind the error word and the flags
+    return (char*)(((uintptr_t)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B + 15) & ~(uintptr_t)15);
+}
 
 static bool group_ok(int B, int H, void* ws, size_t ws_bytes, const unsigned int* status) {
     static const int enabled = tunable("BILSTM_GROUP", 1);
@@ -469,10 +783,19 @@ bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_
                          const BilstmSave* sv, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s) {
     if (!group_ok(B, H, ws, ws_bytes, status)) return false;
     unsigned int* flags = (unsigned int*)ws;
-    if (hipMemsetAsync(flags, 0, 1024 + sizeof(unsigned int) * 2 * (size_t)B, s) != hipSuccess) return false;
+    static const int ll_on = tunable("BILSTM_GROUP_LL", 1);
+    const bool ll = ll_on && T < 65535;  // 16-bit step tags
+    char* xb = group_exchange_base(ws, B);
+    if (hipMemsetAsync(flags, 0, (size_t)(xb - (char*)ws) + (ll ? sizeof(unsigned long long) * 2 * (size_t)B * 2 * H : 0), s) != hipSuccess) return false;
     GroupSync gs{flags + 256, status};
-    float* hbuf = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
+    float* hbuf = (float*)xb;
     dim3 grid(2 * B * 4);
+    if (ll) {
+        ProfScope ps(sv ? "bilstm_group_ks_kernel/train" : "bilstm_group_ks_kernel", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
+        if (sv) hipLaunchKernelGGL((bilstm_group_ks_kernel<true>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, (unsigned long long*)hbuf, gs, *sv);
+        else hipLaunchKernelGGL((bilstm_group_ks_kernel<false>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, (unsigned long long*)hbuf, gs, BilstmSave());
+        return true;
+    }
     ProfScope ps(sv ? "bilstm_group_kernel<256>/train" : "bilstm_group_kernel<256>", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
     if (sv) hipLaunchKernelGGL((bilstm_group_kernel<256, true>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, hbuf, gs, *sv);
     else hipLaunchKernelGGL((bilstm_group_kernel<256, false>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, hbuf, gs, BilstmSave());
@@ -482,9 +805,17 @@ bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_
 bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T, int H, void* ws, size_t ws_bytes, unsigned int* status, hipStream_t s) {
     if (!group_ok(B, H, ws, ws_bytes, status)) return false;
     unsigned int* flags = (unsigned int*)ws;
-    if (hipMemsetAsync(flags, 0, 1024 + sizeof(unsigned int) * 2 * (size_t)B, s) != hipSuccess) return false;
+    static const int ll_on = tunable("BILSTM_GROUP_LL", 1);
+    const bool ll = ll_on && T < 65535;  // 16-bit step tags
+    char* xb = group_exchange_base(ws, B);
+    if (hipMemsetAsync(flags, 0, (size_t)(xb - (char*)ws) + (ll ? sizeof(unsigned long long) * 2 * (size_t)B * 2 * 4 * H : 0), s) != hipSuccess) return false;
     GroupSync gs{flags + 256, status};
-    float* part = (float*)((char*)ws + 1024 + sizeof(unsigned int) * 2 * (size_t)B);
+    float* part = (float*)xb;
+    if (ll) {
+        ProfScope ps("bilstm_bptt_group_ks_kernel", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
+        hipLaunchKernelGGL(bilstm_bptt_group_ks_kernel, dim3(2 * B * 4), dim3(512), 0, s, a, lens, T, (unsigned long long*)part, gs);
+        return true;
+    }
     ProfScope ps("bilstm_bptt_group_kernel<256>", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
     hipLaunchKernelGGL((bilstm_bptt_group_kernel<256>), dim3(2 * B * 4), dim3(512), 0, s, a, lens, T, part, gs);
     return true;
@@ -517,6 +848,11 @@ bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const 
 bool launch_bilstm_bptt_persistent(const BilstmBwd& a, const int* lens, int B, int T, int H, hipStream_t s) {
     dim3 grid(B, 2);
     if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return false;
+    if (H == 128 && bilstm_ksplit_enabled()) {
+        ProfScope ps("bilstm_bptt_ksplit_kernel", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
+        hipLaunchKernelGGL((bilstm_bptt_ksplit_kernel<0>), grid, dim3(512), 0, s, a, lens, T);
+        return true;
+    }
     ProfScope ps("bilstm_bptt_persistent_kernel", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
 #define FCL_BILSTM_CASE(HH) \
     case HH: hipLaunchKernelGGL((bilstm_bptt_persistent_kernel<HH>), grid, dim3(4 * HH), 0, s, a, lens, T); return true;

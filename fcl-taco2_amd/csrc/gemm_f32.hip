@@ -389,38 +389,59 @@ static int precision() {
 // BiLSTM step).  One workgroup = a 16 x 16 output tile, its 4 waves each contract a quarter of K with exact fp32 MFMAs straight from global
 // memory (each lane: one float4 of A and one of W per 16 k's; the 4 MFMAs of a chunk use k = kb + 4*lanegroup + e on both operands), the four
 // partial tiles meet in LDS.  N/16 x ceil(M/16) workgroups instead of the single 16 x 256 tile a big-tile kernel would give such a GEMM.
+// Round 5: TR x TC MFMA tiles per workgroup (16 TR x 16 TC outputs): the 16 x 16 form re-reads W once per 16 rows and A once per 16 columns -- at
+// FCL-taco2-T size (M = 256, N = 2 048, K = 4 096) ~1 GB of L2 traffic per launch, 55 us; 32 x 32 halves both.
+template <int TR, int TC>
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw, int K,
                                                           const float* __restrict__ bias, const float* __restrict__ R, int ldr, float* __restrict__ Y,
                                                           int ldy, int M, int N) {
-    __shared__ f32x4 part[4][64];
+    __shared__ f32x4 part[4][TR * TC][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
-    const int arow = min(m0 + r16, M - 1), wrow = min(n0 + r16, N - 1);  // clamped loads, masked stores
+    const int n0 = blockIdx.x * 16 * TC, m0 = blockIdx.y * 16 * TR;
     const int kchunk = ((K + 63) / 64) * 16;  // K range of one wave, a multiple of 16
     const int k_lo = wave * kchunk, k_hi = min(K, k_lo + kchunk);
-    const float* ap = A + (size_t)arow * lda + q * 4;
-    const float* wp = W + (size_t)wrow * ldw + q * 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kb = k_lo; kb < k_hi; kb += 16) {
-        f32x4 av = {0.f, 0.f, 0.f, 0.f}, wv = {0.f, 0.f, 0.f, 0.f};
-        if (kb + q * 4 < k_hi) {  // K % 4 == 0: a float4 is all in or all out
-            av = *reinterpret_cast<const f32x4*>(ap + kb);
-            wv = *reinterpret_cast<const f32x4*>(wp + kb);
-        }
+    const float* ap[TR];
+    const float* wp[TC];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wv[e], acc, 0, 0, 0);
+    for (int i = 0; i < TR; ++i) ap[i] = A + (size_t)min(m0 + 16 * i + r16, M - 1) * lda + q * 4;  // clamped loads, masked stores
+#pragma unroll
+    for (int c = 0; c < TC; ++c) wp[c] = W + (size_t)min(n0 + 16 * c + r16, N - 1) * ldw + q * 4;
+    f32x4 acc[TR][TC];
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kb = k_lo; kb < k_hi; kb += 16) {
+        f32x4 av[TR], wv[TC];
+        const bool in = kb + q * 4 < k_hi;  // K % 4 == 0: a float4 is all in or all out
+#pragma unroll
+        for (int i = 0; i < TR; ++i) av[i] = in ? *reinterpret_cast<const f32x4*>(ap[i] + kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < TC; ++c) wv[c] = in ? *reinterpret_cast<const f32x4*>(wp[c] + kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < TR; ++i)
+#pragma unroll
+                for (int c = 0; c < TC; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][e], wv[c][e], acc[i][c], 0, 0, 0);
     }
-    part[wave][lane] = acc;
+#pragma unroll
+    for (int i = 0; i < TR; ++i)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) part[wave][i * TC + c][lane] = acc[i][c];
     __syncthreads();
-    if (wave == 0) {
-        const f32x4 p1 = part[1][lane], p2 = part[2][lane], p3 = part[3][lane];
-        const int n = n0 + r16;
+#pragma unroll
+    for (int tt = 0; tt < (TR * TC + 3) / 4; ++tt) {  // tile tt * 4 + wave is summed and stored by this wave
+        const int tile = tt * 4 + wave;
+        if (tile >= TR * TC) continue;
+        const f32x4 p0 = part[0][tile][lane], p1 = part[1][tile][lane], p2 = part[2][tile][lane], p3 = part[3][tile][lane];
+        const int n = n0 + 16 * (tile % TC) + r16;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int m = m0 + q * 4 + e;  // C layout of the 16x16 MFMA: lane (r16, q) holds rows 4q..4q+3 of column r16
+            const int m = m0 + 16 * (tile / TC) + q * 4 + e;  // C layout of the 16x16 MFMA: lane (r16, q) holds rows 4q..4q+3 of column r16
             if (m < M && n < N) {
-                float v = (acc[e] + p1[e]) + (p2[e] + p3[e]);
+                float v = (p0[e] + p1[e]) + (p2[e] + p3[e]);
                 if (bias) v += bias[n];
                 if (R) v += R[(size_t)m * ldr + n];
                 Y[(size_t)m * ldy + n] = v;
@@ -544,8 +565,17 @@ int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (a.M <= smallm && a.nterms == 1 && t0.shift == 0 && !a.seg_lo && !a.rank1_a && !a.C0 && a.act == FCL_ACT_NONE && a.drop_mode == 0 && !a.keep &&
         !a.Y2 && t0.K >= 256) {  // plain Y = A.W^T (+bias) (+R) on a few rows: split K over the waves instead of one lonely big tile
         ProfScope ps("gemm_smallm_kernel", flops, a.M, s);
-        hipLaunchKernelGGL(gemm_smallm_kernel, dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, t0.A, t0.lda, t0.W, t0.ldw, t0.K, a.bias, a.R, a.ldr,
-                           a.Y, a.ldy, a.M, a.N);
+        static const int big_min = tunable("GEMM_SMALLM_32_MIN_WG", 256);  // 32 x 32 (16 x 32) tiles while they still give a workgroup per CU
+        const long long wg32 = (long long)((a.N + 31) / 32) * ((a.M + 31) / 32), wg16x32 = (long long)((a.N + 31) / 32) * ((a.M + 15) / 16);
+        if (wg32 >= big_min)
+            hipLaunchKernelGGL((gemm_smallm_kernel<2, 2>), dim3((a.N + 31) / 32, (a.M + 31) / 32), dim3(256), 0, s, t0.A, t0.lda, t0.W, t0.ldw, t0.K, a.bias, a.R,
+                               a.ldr, a.Y, a.ldy, a.M, a.N);
+        else if (wg16x32 >= big_min)
+            hipLaunchKernelGGL((gemm_smallm_kernel<1, 2>), dim3((a.N + 31) / 32, (a.M + 15) / 16), dim3(256), 0, s, t0.A, t0.lda, t0.W, t0.ldw, t0.K, a.bias, a.R,
+                               a.ldr, a.Y, a.ldy, a.M, a.N);
+        else
+            hipLaunchKernelGGL((gemm_smallm_kernel<1, 1>), dim3((a.N + 15) / 16, (a.M + 15) / 16), dim3(256), 0, s, t0.A, t0.lda, t0.W, t0.ldw, t0.K, a.bias, a.R,
+                               a.ldr, a.Y, a.ldy, a.M, a.N);
         return check_hip(hipGetLastError(), "gemm_smallm launch");
     }
     // 64x64 tiles measured best for every GEMM of the path (the 32x128 / 16x256 variants only win for a single 16/32-row tile)

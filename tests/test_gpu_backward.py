@@ -292,6 +292,64 @@ def test_bilstm_group_kernel_more_workgroups_than_cus(ops):
     assert max_abs(out.cpu(), ref.cpu()) < 1e-5
 
 
+def test_bilstm_group_kernel_beside_another_streams_work(ops):
+    """Round 5: the lane-split BiLSTM kernels reduce with DPP.  hipcc fills the two wait states a DPP read needs after the VALU write of its source with
+    whatever instructions are at hand (two v_pk_fma_f32 of the contraction); on gfx950 that is too short when the wave's sibling on the SIMD is stalled:
+    with the device to itself the waves run in lock step and nothing shows, beside another stream's kernels (workgroups of a group out of step) lanes
+    48 - 63 of a partial sum were read before they were written -- 1e-2 errors in 299 of 300 launches (`tools/stress_bilstm_concurrent.py`; fixed by an
+    explicit s_nop tied to the DPP source, `dpp_f` in csrc/bilstm.hip).  Every launch of the H = 256 forward and reverse pass beside a stream of H = 128
+    recurrences, in both orders of submission, must equal the serial result bit for bit, and the status word stays clear."""
+    g = torch.Generator().manual_seed(3)
+
+    def case(B, T, C, H):
+        lens = torch.randint(30, T + 1, (B,), generator=g).to(torch.int32)
+        lens[0] = T
+        w = [(torch.randn(4 * H, d, generator=g) * 0.05).to(DEV) for d in (C, H, C, H)]
+        bs = [(torch.randn(4 * H, generator=g) * 0.1).to(DEV) for _ in range(2)]
+        return dict(B=B, T=T, H=H, x=torch.randn(B * T, C, generator=g).to(DEV), w=w, bs=bs, ld=lens.to(DEV))
+
+    st = ops.status_word(DEV)
+
+    def fwd(c):
+        return ops.bilstm(c["x"], c["ld"], c["w"][0], c["w"][1], c["bs"][0], c["w"][2], c["w"][3], c["bs"][1], c["B"], c["T"], 3 if c["H"] == 256 else 2, status=st)
+
+    big, small = case(8, 60, 512, 256), case(8, 60, 256, 128)
+    B, T, H = big["B"], big["T"], 256
+    gx = [torch.randn(B * T, 4 * H, generator=g).to(DEV) for _ in range(2)]
+    sv = [[torch.zeros(T * B, 4 * H, device=DEV)] + [torch.zeros(T * B, H, device=DEV) for _ in range(3)] for _ in range(2)]
+    o2 = torch.empty(B * T, 2 * H, device=DEV)
+    ops.bilstm_train_fwd(gx, (big["w"][1], big["w"][3]), big["ld"], B, T, o2, sv, status=st)
+    d_out = torch.randn(B * T, 2 * H, generator=g).to(DEV)
+    wt = [big["w"][1].t().contiguous(), big["w"][3].t().contiguous()]
+
+    def bptt():
+        dg = [torch.empty(T * B, 4 * H, device=DEV) for _ in range(2)]
+        ops.bilstm_bptt(sv, big["ld"], B, T, d_out, wt, dg, status=st)
+        return dg
+
+    ref_f, ref_b, ref_s = fwd(big).clone(), [d.clone() for d in bptt()], fwd(small).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(60):
+        if it % 2:  # (both orders of submission: either kernel family can be the one whose waves fall out of step)
+            with torch.cuda.stream(s2):
+                outs = [fwd(small) for _ in range(8)]
+            with torch.cuda.stream(s1):
+                o1 = fwd(big)
+                dg = bptt()
+        else:
+            with torch.cuda.stream(s1):
+                o1 = fwd(big)
+                dg = bptt()
+            with torch.cuda.stream(s2):
+                outs = [fwd(small) for _ in range(4)]
+        torch.cuda.synchronize()
+        assert torch.equal(o1, ref_f), (it, float((o1 - ref_f).abs().max()))
+        assert all(torch.equal(a, b) for a, b in zip(dg, ref_b)), it
+        assert all(torch.equal(o, ref_s) for o in outs), it
+    assert int(st.item()) == 0
+
+
 # ---- round 5: the weight-gradient GEMM with the transposition fused into its LDS reads (csrc/dw_gemm.hip, `ds_read_b64_tr_b16`) -----------------
 def _dw_on_path(ops_mod):
     """True when fcl_gemm_tn_* dispatches to dw_mfma_kernel (bf16x3 / bf16 arithmetic; FCL_PRECISION=0 keeps the exact-fp32 kernel)."""

@@ -155,7 +155,7 @@ def test_teacher_step_at_configs3_size_vs_oracle_autograd(form):
 
     if ops.planes_enabled():
         _on_path(prof, ("plstm_kernel<", ",-1,"), ("pgemm_kernel<4,2,2,4,3", ), ("pgemm_kernel<", "/dW"))
-    _on_path(prof, ("bilstm_group_kernel<256>/train",), ("bilstm_bptt_group_kernel<256>",))
+    _on_path(prof, ("bilstm_group_", "/train"), ("bilstm_bptt_group_",))  # the 4-workgroup kernels (round 5: `_ks_kernel`, tagged exchange)
     if form == "train":  # BatchNorm running buffers after one train-mode forward: first encoder block and first postnet block against plain torch
         msd = model.state_dict()
         xs = _cpu(batch)["xs"][:, : int(max(batch["ilens"]))]
@@ -207,7 +207,7 @@ def test_kd_step_at_configs2_size_vs_oracle_autograd(form):
     print("configs[2] %s form: worst gradient error max-abs %.2e / L2 %.2e over %d tensors" % (form, worst[0], worst[1], len(eng.G)))
     if ops.planes_enabled():  # (the student's weight gradients stay below the 1 M-output threshold of the transposed-plane dW GEMM: configs[3] covers it)
         _on_path(prof, ("plstm_kernel<", ",-1,"), ("pgemm_kernel<",))
-    _on_path(prof, ("bilstm_persistent_kernel/train",), ("bilstm_bptt_persistent_kernel",), ("gemm_tn_kernel",))
+    _on_path(prof, ("bilstm_ksplit_kernel/train",), ("bilstm_bptt_",), ("gemm_tn_kernel",))
 
 
 def test_teacher_update_at_configs3_size_tracks_torch_adam():
