@@ -112,7 +112,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // reads, the DPP results or the transcendentals each removed it, two did not; so did claiming the SIMD's whole register file, which keeps a third (foreign) wave
 // off the SIMD: with more waves interleaving their passes the two architectural wait states are evidently not enough time.  Both are applied: ks_exclusive()
 // at the top of every kernel that uses dpp_f (the CU is this workgroup's anyway: 8 waves x 256 VGPRs), and four wait states tied to the DPP source.
-__device__ __forceinline__ void ks_exclusive() { asm volatile("v_mov_b32 v255, 0" ::: "v255"); }
+__device__ __forceinline__ void ks_exclusive() {
+#ifndef FCL_KS_NOT_EXCLUSIVE  // (developer A/B: the wait states alone)
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+#endif
+}
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
     asm volatile("s_nop 3" : "+v"(v));
