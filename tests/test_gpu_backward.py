@@ -217,10 +217,12 @@ def test_adam_step_weight_decay_matches_torch(ops, wd):
     assert float((m2 - m).abs().max()) > 1e-4
 
 
-@pytest.mark.parametrize("m,n,k", [(1, 16, 256), (7, 100, 260), (16, 256, 1024), (33, 256, 1024), (64, 1024, 512)])
+@pytest.mark.parametrize("m,n,k", [(1, 16, 256), (7, 100, 260), (16, 256, 1024), (33, 256, 1024), (64, 1024, 512),
+                                   (100, 2048, 1024), (129, 2040, 4096), (200, 2048, 4096), (256, 2048, 4096), (256, 512, 1024), (250, 1000, 268), (17, 8200, 256)])
 def test_small_m_split_k_gemm(ops, m, n, k):
-    """The split-K kernel launch_gemm picks for M <= 64, K >= 256 (the per-step GEMMs of the BPTT recurrences; their residual epilogue is covered by
-    the training-step parity tests under FCL_BILSTM_TRAIN_STEPS=1)."""
+    """The split-K kernel launch_gemm picks for M <= 256, K >= 256 (the per-step GEMMs of the BPTT recurrences; their residual epilogue is covered by
+    the training-step parity tests under FCL_BILSTM_TRAIN_STEPS=1).  Round 5: 32 x 32 and 16 x 32 output tiles per workgroup while they give a
+    workgroup per CU (the second row of shapes: FCL-taco2-T sizes, ragged M / N against every tile form)."""
     rng = np.random.RandomState(m + k)
     x, w, b = rnd(rng, m, k), rnd(rng, n, k) / np.sqrt(k), rnd(rng, n)
     ref = x.astype(np.float64) @ w.astype(np.float64).T + b
