@@ -105,13 +105,13 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
 // update runs replicated in the quad, lane 0 of the quad publishes h into the other half of a double-buffered LDS vector: ONE barrier per step.
 // Gate pre-activations are prefetched four steps ahead (a step is shorter than a global load).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// DPP on gfx950 beside foreign waves (measured, round 5).  A DPP read of a VGPR needs two wait states after the VALU write of that register; hipcc inserts
-// them (s_nop or whatever two instructions are at hand).  With the device to itself these kernels -- two waves per SIMD, 168 - 194 VGPRs each -- are exact.  Beside
-// another stream's kernels they returned 1e-3 .. 1e-2 errors in single units in 299 of 300 launches (`tools/stress_bilstm_concurrent.py`), always in lanes 48 - 63
-// (the last pass of a wave64 instruction) of some wave: a partial sum read before its producer's last pass had written it.  Sixteen wait states around the DPP
-// reads, the DPP results or the transcendentals each removed it, two did not; so did claiming the SIMD's whole register file, which keeps a third (foreign) wave
-// off the SIMD: with more waves interleaving their passes the two architectural wait states are evidently not enough time.  Both are applied: ks_exclusive()
-// at the top of every kernel that uses dpp_f (the CU is this workgroup's anyway: 8 waves x 256 VGPRs), and four wait states tied to the DPP source.
+// DPP on gfx950 beside foreign waves (measured, round 5; HISTORY.md has the experiments).  With the device to itself these kernels -- two waves per SIMD at
+// 168 - 194 VGPRs -- are exact.  Beside another stream's kernels they returned 1e-3 .. 1e-2 errors in single units in 299 of 300 launches
+// (`tools/stress_bilstm_concurrent.py`), always computed in lanes 48 - 63 (the last pass of a wave64 instruction) of some wave: a partial sum read before its
+// producer's last pass had written it.  Explicit wait states tied to the DPP sources did NOT remove it (2 or 4: 297 / 300 bad launches; sixteen in any of three
+// places did, as any reshuffling of the schedule did -- once).  What removes it with nothing else changed is keeping foreign waves off the SIMD: the kernel claims
+// the SIMD's whole register file (`.amdhsa_next_free_vgpr 256`: 2 waves x 256), 0 / 300 in both submission orders (`profiles/r5_dpp_hazard_ab.log`).  The CU is
+// this workgroup's anyway (8 waves, W_hh in registers); the four wait states in dpp_f stay as a margin.
 __device__ __forceinline__ void ks_exclusive() {
 #ifndef FCL_KS_NOT_EXCLUSIVE  // (developer A/B: the wait states alone)
     asm volatile("v_mov_b32 v255, 0" ::: "v255");

@@ -412,19 +412,27 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restric
     for (int i = 0; i < TR; ++i)
 #pragma unroll
         for (int c = 0; c < TC; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb = k_lo; kb < k_hi; kb += 16) {
-        f32x4 av[TR], wv[TC];
-        const bool in = kb + q * 4 < k_hi;  // K % 4 == 0: a float4 is all in or all out
+    // UN chunks of 16 k per trip with all their loads issued before the first MFMA: at a handful of rows the kernel is a stream of W (33 MB at FCL-taco2-T
+    // size) and two loads in flight per lane left it at 1.5 TB/s
+    constexpr int UN = TR * TC == 1 ? 4 : (TR * TC == 2 ? 2 : 1);  // (2 x 2 tiles: 16 MFMAs per chunk already cover the loads; deeper was 10 % slower)
+    for (int kb = k_lo; kb < k_hi; kb += 16 * UN) {
+        f32x4 av[UN][TR], wv[UN][TC];
 #pragma unroll
-        for (int i = 0; i < TR; ++i) av[i] = in ? *reinterpret_cast<const f32x4*>(ap[i] + kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int u = 0; u < UN; ++u) {
+            const bool in = kb + 16 * u + q * 4 < k_hi;  // K % 4 == 0: a float4 is all in or all out
 #pragma unroll
-        for (int c = 0; c < TC; ++c) wv[c] = in ? *reinterpret_cast<const f32x4*>(wp[c] + kb) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < TR; ++i) av[u][i] = in ? *reinterpret_cast<const f32x4*>(ap[i] + kb + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int c = 0; c < TC; ++c) wv[u][c] = in ? *reinterpret_cast<const f32x4*>(wp[c] + kb + 16 * u) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int i = 0; i < TR; ++i)
+        for (int u = 0; u < UN; ++u)
 #pragma unroll
-                for (int c = 0; c < TC; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][e], wv[c][e], acc[i][c], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TR; ++i)
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i][e], wv[u][c][e], acc[i][c], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < TR; ++i)

@@ -320,6 +320,22 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
                      ds_nonzeros=ds_nonzeros, f0=f0, energy=energy, spembs=spembs)
         if self.training:
             return self._forward_train(batch, teacher_knowledge, kwargs.get("masks"))
+        order = ["l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss", "encoder_loss",
+                 "decoder_loss", "prosody_loss", "loss"]
+        if self.hp.reduction_factor != 1:
+            # round 5: the no-gradient forward of teacher_forced.py covers reduction_factor 1; with r > 1 (teacher class only: the reference's KD
+            # classes fail on it) the evaluator's forward runs the training engine's eval form -- running-stat BatchNorm, expectation zoneout, the
+            # prenet's dropout on as in the reference (decoder_sa.py:156-158) -- and leaves the engine's gradient buffers as it found them
+            eng = self.train_engine()
+            eng.invalidate_planes()
+            kept = eng.gflat.clone()
+            try:
+                with torch.no_grad():
+                    rep = eng.forward_backward(batch, None, mode="eval", masks=kwargs.get("masks"), reduce=False)
+            finally:
+                eng.gflat.copy_(kept)
+            self.reporter.report([{k: float(rep[k])} for k in order if k in rep])
+            return torch.tensor(float(rep["loss"]), dtype=torch.float32, device=eng.dev)
         from .. import teacher_forced as TF
 
         plan = self.plan(xs.device if xs.is_cuda else None)
@@ -334,8 +350,6 @@ class Tacotron2Base(TTSInterface, torch.nn.Module):
                                              self.distill_decoder_knowledge, self.distill_prosody_knowledge), **kw)
             else:
                 rep, _ = TF.teacher_forward(plan, batch, **kw)
-        order = ["l1_loss", "mse_loss", "dur_loss", "pitch_loss", "energy_loss", "output_l1_loss", "output_mse_loss", "encoder_loss",
-                 "decoder_loss", "prosody_loss", "loss"]
         self.reporter.report([{k: float(rep[k])} for k in order if k in rep])
         return torch.tensor(float(rep["loss"]), dtype=torch.float32, device=plan.device)
 

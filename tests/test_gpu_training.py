@@ -595,6 +595,19 @@ def test_reduction_factor_2_vs_reference_g21():
     _check_vs_oracle(eng, gsd)
     with pytest.raises(NotImplementedError, match="reduction_factor 1"):
         TrainEngine(_model("kd_teacher", hp))
+    # the evaluator's forward (model.eval(); model(**batch), tts.py:76-108) with r = 2: the engine's eval form behind the plug-in class; gradients of a
+    # training forward that is still waiting for its backward() are left alone
+    model = _model("teacher", hp).eval()
+    with torch.no_grad():
+        loss_e = model(**batch)
+    assert abs(float(loss_e) - float(g["loss"])) < 5e-4 * max(1.0, abs(float(g["loss"]))), (float(loss_e), float(g["loss"]))
+    model.train()
+    loss_t = model(**batch)  # (train form: BatchNorm's running statistics move, so the order matters above)
+    g_before = model.train_engine().gflat.clone()
+    model.eval()
+    with torch.no_grad():
+        model(**batch)
+    assert torch.equal(model.train_engine().gflat, g_before) and loss_t.requires_grad
 
 
 def test_kd_refuses_other_cell_counts_and_the_native_step_declines_the_options():

@@ -51,6 +51,13 @@ for w in kd_step teacher_step; do
 done
 # the weight-gradient GEMM shapes of both updates: old kernel / dw_mfma_kernel (round 5)
 python3 tools/bench_dw2.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/bench_dw_shapes.log
+# round 5: the BiLSTM recurrences old / new at both widths, the small-M GEMM tile forms, the per-shape GEMM tables and the KD phase stamps
+python3 tools/bilstm_bench.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/bilstm_bench.log
+BILSTM_BENCH_MODEL=teacher python3 tools/bilstm_bench.py 2>&1 | grep -v -i "warn\|amdgpu.ids" >> $OUT/bilstm_bench.log
+python3 tools/time_smallm.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/smallm_tiles.log
+python3 tools/gemm_shapes.py teacher 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/gemm_shapes_teacher_step.log
+python3 tools/gemm_shapes.py kd 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/gemm_shapes_kd_step.log
+python3 tools/kd_phases.py 2>&1 | grep -v -i "warn\|amdgpu.ids" > $OUT/kd_phases.log
 python3 bench.py --workload forward_tf > $OUT/bench_forward_tf.json 2> /dev/null
 python3 bench.py --batch 64 --no-cpu-baseline --no-extras > $OUT/bench_batch64.json 2> /dev/null
 python3 bench.py --model teacher --no-cpu-baseline --no-extras > $OUT/bench_teacher_synthesis.json 2> /dev/null
