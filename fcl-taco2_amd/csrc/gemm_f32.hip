@@ -466,6 +466,13 @@ static void launch_gemm_cfg(const GemmArgs& a, hipStream_t s, const char* name, 
     GemmArgs b = a;
     b.hi_only = precision() && gemm_mode() == FCL_GEMM_BF16;
     snprintf(full, sizeof(full), "gemm_kernel<%d,%d,%d,%d>%s", WM, WN, precision() ? 1 : 0, TM, b.hi_only ? "/bf16" : precision() ? "/bf16x3" : "");
+    static const int shapes = tunable("PROF_SHAPES", 0);  // developer aid: the profile records split by shape (M x N x sum K)
+    if (shapes && g_prof_on) {
+        long long ks = 0;
+        for (int i = 0; i < a.nterms; ++i) ks += a.term[i].K;
+        const size_t l = strlen(full);
+        snprintf(full + l, sizeof(full) - l, " %dx%dx%lld", a.M, a.N, ks);
+    }
     (void)name;
     ProfScope ps(full, flops, a.M, s);
     if (precision()) hipLaunchKernelGGL((gemm_kernel<WM, WN, 1, TM>), grid, dim3(G::THREADS), 0, s, b);

@@ -1082,13 +1082,41 @@ static int te_backward_stage0(fcl_te& E) {  // predictors' backward forked; post
     return 0;
 }
 
+// round 5, measured and NOT adopted (FCL_TE_DX_PLANES=1 turns it on): four input-gradient GEMMs whose A operand is a gradient tensor nobody has planes of (K = odim
+// = 80 or K = 4 U / 4 H contractions) run on the fp32-operand kernel (`gemm_kernel<...>/bf16x3`, 25 - 60 TFLOP/s: 0.5 ms of kernel time per teacher update).  With
+// planes from the producer (the gathers write them) or one packing pass and the LDS-DMA kernels instead: teacher update 9.82 vs 9.77 ms, KD 9.03 vs 9.09 ms on one
+// box (`gpurun_out/r6i`) -- they are off the critical path and the packing passes cost what the faster GEMMs save.
+static bool dx_planes() {
+    static const int on = tunable("TE_DX_PLANES", 0);
+    return on != 0 && tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0;
+}
+// Y[m, n] = A[m, k] . Wt^T for a weight kept as the transposed form `key` ([n, k] rows): planes when ap / a packing pass can provide them
+static int dx_linear(fcl_te& E, const float* a, const uint16_t* ap, int m, int k, const std::string& key, const float* wsrc, int rows, int cols, int ld, float* y, int n) {
+    if (dx_planes() && n % 4 == 0) {
+        if (!ap) {
+            uint16_t* t = pl16(E, m, k);
+            TE_L(fcl_pack_planes(a, k, m, k, t, E.cur));
+            ap = t;
+        }
+        const uint16_t* wtp;
+        TE_TRY(w_t(E, key, wsrc, rows, cols, ld, false, true, nullptr, &wtp));
+        TE_L(fcl_linear_planes_fwd(ap, (k + 31) / 32, wtp, nullptr, y, n, nullptr, m, n, k, FCL_ACT_NONE, E.cur));
+        return 0;
+    }
+    const float* wt;
+    TE_TRY(w_t(E, key, wsrc, rows, cols, ld, true, false, &wt, nullptr));
+    TE_L(fcl_linear_fwd(a, k, wt, k, nullptr, y, n, m, n, k, FCL_ACT_NONE, E.cur));
+    return 0;
+}
+
 static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
     const fcl_te_config_t& cf = E.cfg;
     Ctx& c = E.c;
     const fcl_te_batch_t& b = c.b;
     const int N = b.N, F = b.F, O = cf.odim, U = cf.dunits, Pn = cf.prenet_units, C = cf.eunits;
     float* d_out_cells = f32(E, F, O);
-    TE_L(fcl_gather_rows_fwd(c.d_before, b.cell_frame, d_out_cells, nullptr, F, O, E.cur));
+    uint16_t* d_out_cells_p = dx_planes() ? pl16(E, F, O) : nullptr;
+    TE_L(fcl_gather_rows_fwd(c.d_before, b.cell_frame, d_out_cells, d_out_cells_p, F, O, E.cur));
     Param& WF = E.Pm("dec.feat_out.weight");
     {
         SideScope sc(E);
@@ -1096,13 +1124,11 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
         TE_L(fcl_gemm_tn_fwd(d_out_cells, O, c.h1_all, U, WF.g, U + C, F, O, U, 0, nullptr, nullptr, E.cur));  // column block [:, :U] written in place
         E.dw_pending = true;
     }
-    const float *wf_h, *wf_att, *wf_h_t, *wf_att_t;
+    const float *wf_h, *wf_att;
     TE_TRY(w_cols(E, "dec.feat_out.weight", O, U + C, 0, U, true, &wf_h, nullptr));
     TE_TRY(w_cols(E, "dec.feat_out.weight", O, U + C, U, C, true, &wf_att, nullptr));
-    TE_TRY(w_t(E, "dec.feat_out.weight/h", WF.p, O, U, U + C, true, false, &wf_h_t, nullptr));
-    TE_TRY(w_t(E, "dec.feat_out.weight/att", WF.p + U, O, C, U + C, true, false, &wf_att_t, nullptr));
     float* dh1_all = f32(E, F, U);
-    TE_L(fcl_linear_fwd(d_out_cells, O, wf_h_t, O, nullptr, dh1_all, U, F, U, O, FCL_ACT_NONE, E.cur));
+    TE_TRY(dx_linear(E, d_out_cells, d_out_cells_p, F, O, "dec.feat_out.weight/h", WF.p, O, U, U + C, dh1_all, U));
     if (c.inj.count("h1")) TE_L(fcl_add2d(dh1_all, U, c.inj["h1"], U, F, U, 1.0f, nullptr, E.cur));
     float* dF0 = zf32(E, (long long)N * O);
     TE_L(fcl_scatter_add_rows(d_out_cells, b.cell_row_i64, dF0, F, O, -1, E.cur));
@@ -1113,7 +1139,7 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
         E.dw_pending = true;
     }
     c.d_att_c = f32(E, N, C);
-    TE_L(fcl_linear_fwd(dF0, O, wf_att_t, O, nullptr, c.d_att_c, C, N, C, O, FCL_ACT_NONE, E.cur));
+    TE_TRY(dx_linear(E, dF0, nullptr, N, O, "dec.feat_out.weight/att", WF.p + U, O, C, U + C, c.d_att_c, C));
     float *dg0_all = f32(E, F, 4 * U), *dg1_all = f32(E, F, 4 * U);
     const std::string w1ih = "dec.lstm.1.cell.weight_ih", w1hh = "dec.lstm.1.cell.weight_hh", w0hh = "dec.lstm.0.cell.weight_hh", wih0 = "dec.lstm.0.cell.weight_ih";
     const int ld0 = C + Pn + 1;
@@ -1188,10 +1214,8 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
         E.dw_pending = true;
     }
     {
-        const float* w0_att_t;
-        TE_TRY(w_t(E, wih0 + "/att", E.Pm(wih0).p, 4 * U, C, ld0, true, false, &w0_att_t, nullptr));
         float* t = f32(E, N, C);
-        TE_L(fcl_linear_fwd(dG0, 4 * U, w0_att_t, 4 * U, nullptr, t, C, N, C, 4 * U, FCL_ACT_NONE, E.cur));
+        TE_TRY(dx_linear(E, dG0, nullptr, N, 4 * U, wih0 + "/att", E.Pm(wih0).p, 4 * U, C, ld0, t, C));
         TE_L(fcl_add2d(c.d_att_c, C, t, C, N, C, 1.0f, nullptr, E.cur));
     }
     // prenet (batched over all cells)
@@ -1287,7 +1311,8 @@ static int te_backward_stage3(fcl_te& E) {  // encoder
         TE_L(fcl_bilstm_bptt(&a, E.cur));
         for (int d = 0; d < 2; ++d) {
             float* dgx = f32(E, BT, 4 * H);
-            TE_L(fcl_gather_rows_fwd(dgs[d], b.perm_tb, dgx, nullptr, BT, 4 * H, E.cur));  // back to (b, t) rows like x
+            uint16_t* dgx_p = dx_planes() ? pl16(E, BT, 4 * H) : nullptr;
+            TE_L(fcl_gather_rows_fwd(dgs[d], b.perm_tb, dgx, dgx_p, BT, 4 * H, E.cur));  // back to (b, t) rows like x
             const std::string s_ = sfx[d];
             {
                 SideScope sc(E);
@@ -1297,11 +1322,9 @@ static int te_backward_stage3(fcl_te& E) {  // encoder
                 TE_L(fcl_colsum2_fwd(dgx, nullptr, nullptr, nullptr, E.Pm("enc.blstm.bias_ih_l0" + s_).g, E.Pm("enc.blstm.bias_hh_l0" + s_).g, BT, 4 * H, 0, E.cur));
                 E.dw_pending = true;
             }
-            const float* wih_t;
             const std::string wn = "enc.blstm.weight_ih_l0" + s_;
-            TE_TRY(w_t(E, wn, E.Pm(wn).p, 4 * H, Cc, Cc, true, false, &wih_t, nullptr));
             float* t = f32(E, BT, Cc);
-            TE_L(fcl_linear_fwd(dgx, 4 * H, wih_t, 4 * H, nullptr, t, Cc, BT, Cc, 4 * H, FCL_ACT_NONE, E.cur));
+            TE_TRY(dx_linear(E, dgx, dgx_p, BT, 4 * H, wn, E.Pm(wn).p, 4 * H, Cc, Cc, t, Cc));
             TE_L(fcl_add2d(dx, Cc, t, Cc, BT, Cc, 1.0f, nullptr, E.cur));
         }
     }
