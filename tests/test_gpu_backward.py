@@ -233,7 +233,10 @@ def test_small_m_split_k_gemm(ops, m, n, k):
 
 
 @pytest.mark.parametrize("H,lens", [(16, [19, 19, 12, 5, 1]), (128, [19, 19, 12, 5, 1]), (256, [19, 19, 12, 5, 1]), (24, [19, 19, 12, 5, 1]),
-                                    (256, sorted(np.random.RandomState(9).randint(40, 81, 32).tolist(), reverse=True))])
+                                    (256, sorted(np.random.RandomState(9).randint(40, 81, 32).tolist(), reverse=True)),
+                                    # round 5 (lane-split kernels: steps unrolled by 4 / 2 with operands prefetched 4 steps ahead): every residue of the
+                                    # sequence length, a long sequence
+                                    (128, [131, 64, 7, 6, 4, 3, 2, 1]), (256, [67, 66, 5, 4, 3, 2, 1, 1])])
 def test_bilstm_train_forward_and_bptt_vs_torch_lstm(ops, H, lens):
     """fcl_bilstm_train_fwd / fcl_bilstm_bptt (persistent kernels for H <= 128, the 4-workgroup group kernels for H = 256, the per-step fallback for
     any other H) against torch.nn.LSTM over packed sequences: outputs, and — through the saved gates — the gradients of W_hh, W_ih and x.
