@@ -417,7 +417,7 @@ def test_no_batch_norm_vs_reference_g15():
     assert abs(rep["loss"] - float(orep["loss"])) < 5e-4 * max(1.0, abs(float(orep["loss"])))
     from fcl_taco2_amd import ops
 
-    _check_vs_oracle(eng, sd, tol=1e-1 if ops.planes_enabled() else 5e-4)
+    _check_vs_oracle(eng, sd, tol=2e-2 if ops.planes_enabled() else 5e-4)  # (bf16x3: worst measured 3.0e-3, enc.embed.weight; was a blanket 1e-1)
 
 
 def test_encoder_widths_differ_vs_reference_g16():
@@ -654,7 +654,7 @@ def test_speaker_embeddings_vs_reference_g13():
     if ops.planes_enabled():
         # bf16x3 operands (2^-16 per product, 250x fp32's rounding) on THIS closed-form net: its eps-1e-12 LayerNorms amplify rounding ~100x (torch's own
         # fp32 CPU kernels sit 4e-6 from float64 here, tools/diag_g13.py), which lands at up to 6e-2 of a predictor's weight gradient; the formulas are
-        # pinned by the exact-fp32 mode of the same test (every tensor within 5e-4 of the reference) -- here: losses at 5e-4, gradients at 1e-1
+        # pinned by the exact-fp32 mode of the same test (every tensor within 5e-4 of the reference) -- here: losses at 5e-4, gradients at 5e-3 (round 5: measured)
         for k in KD_KEYS[:6]:
             assert abs(rep[k] - float(g[k])) < 5e-4 * max(1.0, abs(float(g[k]))), (k, rep[k], float(g[k]))
         n = 0
@@ -663,7 +663,7 @@ def test_speaker_embeddings_vs_reference_g13():
                 n += 1
                 ratio = max_abs(eng.G[k[5:]].cpu(), ref) / max(1.0, float(np.abs(ref).max()))
                 _tol_dump(k[5:], ratio)
-                assert ratio < 1e-1, (k, ratio)
+                assert ratio < 5e-3, (k, ratio)  # (worst measured 8.6e-4, enc.embed.weight; was a blanket 1e-1)
         assert n >= 12
     else:
         assert _check_vs_golden(eng, rep, g, KD_KEYS[:6]) >= 12
