@@ -86,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 417  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 418  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -100,6 +100,15 @@ class BernoulliSite(C.Structure):  # fcl_bernoulli_site_t
 
 
 BERNOULLI_MAX_SITES = 16
+
+
+class LossTerm(C.Structure):  # fcl_loss_term_t
+    _fields_ = [(n, _P) for n in ("a", "b", "b2", "valid", "valid2", "da", "da_planes", "sums", "sums2")] + [
+        ("m", C.c_int32), ("c", C.c_int32), ("b_log", C.c_int32), ("b_log_offset", _F), ("w_l1", _F), ("w_mse", _F), ("count", C.c_double),
+        ("w_l1_2", _F), ("w_mse_2", _F), ("count2", C.c_double)]
+
+
+LOSS_MAX_TERMS, SUM_ROWS_MAX = 12, 6
 
 
 class ProfEntry(C.Structure):
@@ -232,6 +241,14 @@ SIGNATURES = {
     "fcl_bilstm_train_workspace_bytes": (_Z, [_I, _I]),
     "fcl_bilstm_train_fwd": (_I, [C.POINTER(BilstmTrain), _P]),
     "fcl_bilstm_bptt": (_I, [C.POINTER(BilstmBptt), _P]),
+    "fcl_loss_terms_batch": (_I, [C.POINTER(LossTerm), _I, _P]),
+    "fcl_sum_rows": (_I, [C.POINTER(C.c_void_p), _I, _P, _P, _P, _I, _I, _P]),
+    "fcl_bn_bwd_sums": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_act_bwd_sum": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _Z, _I, _P]),
+    "fcl_gather_rows_sum_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "fcl_linear2_fwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "fcl_stream_create_cus": (_I, [_I, C.POINTER(C.c_void_p)]),
+    "fcl_stream_destroy": (_I, [_P]),
     "fcl_prof_enable": (_I, [_I]),
     "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }

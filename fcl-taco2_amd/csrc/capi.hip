@@ -165,6 +165,31 @@ int fcl_linear_fwd(const float* x, int lda, const float* w, int ldw, const float
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+int fcl_linear2_fwd(const float* x, int lda, const float* w, int ldw, int k, const float* x2, int lda2, const float* w2, int ldw2, int k2, const float* bias,
+                    const float* residual, int ldr, float* y, int ldy, int m, int n, int act, fcl_stream_t stream) {
+    FCL_REQUIRE(x && w && y, FCL_ERR_INVALID, "linear2_fwd: null argument");
+    FCL_REQUIRE((x2 == nullptr) == (w2 == nullptr), FCL_ERR_INVALID, "linear2_fwd: x2 and w2 come in pairs");
+    FCL_REQUIRE(act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID, "linear2_fwd: bad act %d", act);
+    FCL_REQUIRE(lda >= k && ldw >= k && ldy >= n && (!x2 || (lda2 >= k2 && ldw2 >= k2)) && (!residual || ldr >= n), FCL_ERR_SHAPE,
+                "linear2_fwd: leading dimensions too small");
+    GemmArgs g = {};
+    g.term[0] = GemmTerm{x, w, lda, ldw, k, 0};
+    g.nterms = 1;
+    if (x2) {
+        g.term[1] = GemmTerm{x2, w2, lda2, ldw2, k2, 0};
+        g.nterms = 2;
+    }
+    g.M = m;
+    g.N = n;
+    g.bias = bias;
+    g.act = act;
+    g.R = residual;
+    g.ldr = ldr;
+    g.Y = y;
+    g.ldy = ldy;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
                    const float* residual, float* y, int m, int cin, int cout, int k, int act, fcl_stream_t stream) {
     FCL_REQUIRE(x && wp && y && seg_lo && seg_hi, FCL_ERR_INVALID, "conv1d_fwd: null argument");

@@ -42,6 +42,29 @@ __global__ __launch_bounds__(1024) void feed_copy_kernel(uint4* __restrict__ dst
 
 extern "C" {
 
+int fcl_stream_create_cus(int n_cus, fcl_stream_t* out) {
+    FCL_REQUIRE(out, FCL_ERR_INVALID, "stream_create_cus: null argument");
+    int dev = 0, total = 0;
+    FCL_HIP(hipGetDevice(&dev));
+    FCL_HIP(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev));
+    hipStream_t s = nullptr;
+    if (n_cus <= 0 || n_cus >= total) {
+        FCL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    } else {
+        // bit i of the queue's CU mask lands on XCD i % 8 (the driver deals the bits round-robin over the XCCs): the low n_cus bits = n_cus / 8 CUs of every XCD
+        uint32_t mask[16] = {};
+        for (int i = 0; i < n_cus && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+        FCL_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask));
+    }
+    *out = (fcl_stream_t)s;
+    return 0;
+}
+
+int fcl_stream_destroy(fcl_stream_t stream) {
+    if (stream) FCL_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+
 void* fcl_host_device_ptr(void* pinned_host) {
     void* p = nullptr;
     if (!pinned_host || hipHostGetDevicePointer(&p, pinned_host, 0) != hipSuccess) {

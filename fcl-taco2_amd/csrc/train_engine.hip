@@ -115,7 +115,7 @@ struct Ctx {  // one forward's tensors (training.py's _Ctx)
     double* sums = nullptr;
     std::unordered_map<std::string, float*> inj;
     // backward carries between stages
-    float *d_before = nullptr, *d_att_c = nullptr, *d_hs = nullptr, *d_att = nullptr;
+    float *d_post_in = nullptr, *d_att_c = nullptr, *d_att = nullptr;
     float* d_preds[3] = {nullptr, nullptr, nullptr};
     // P32 planes the forward already wrote for a tap (embedding, conv blocks, BiLSTM output, prenet): the KD projections read them instead of
     // packing the fp32 tap once more (round 5: 9 of 14 fcl_pack_planes launches of a KD update)
@@ -485,18 +485,20 @@ int conv_dx(E_t& E, const float* dz, const uint16_t* dzp, int m, const std::stri
     return 0;
 }
 
-int conv_bn_bwd(E_t& E, const float* dy, const ConvBn& cc, float** dx) {
+// dy2 (optional): a second source of the block's output gradient (a KD term injected at this tap), added on the fly
+int conv_bn_bwd(E_t& E, const float* dy, const float* dy2, const ConvBn& cc, float** dx) {
     const std::string& pre = cc.prefix;
     const int m = cc.m, cout = cc.cout, cin = cc.cin, k = cc.k;
     const bool pl = cout % 32 == 0;
     const float* dz = dy;
-    if (cc.act != FCL_ACT_NONE || cc.keep) {
-        float* t = f32(E, m, cout);
-        TE_L(fcl_act_bwd(dy, cc.y_act, cc.keep, cc.ks, t, nullptr, 0, (size_t)m * cout, cc.act, E.cur));
-        dz = t;
-    }
     float *dbeta = zf32(E, cout), *dgamma = zf32(E, cout);
-    TE_L(fcl_colsum2_fwd(dz, cc.z, cc.invstd, cc.mean, dgamma, dbeta, m, cout, 3, E.cur));  // both sums from one pass over dz
+    if (cc.act != FCL_ACT_NONE || cc.keep || dy2) {  // round 6: activation / dropout backward as the prologue of the column sums (one pass, dz written once)
+        float* t = f32(E, m, cout);
+        TE_L(fcl_bn_bwd_sums(dy, dy2, cc.y_act, cc.keep, cc.ks, cc.act, cc.z, cc.mean, cc.invstd, t, dgamma, dbeta, m, cout, E.cur));
+        dz = t;
+    } else {
+        TE_L(fcl_colsum2_fwd(dz, cc.z, cc.invstd, cc.mean, dgamma, dbeta, m, cout, 3, E.cur));  // both sums from one pass over dz
+    }
     float* dz2 = f32(E, m, cout);
     uint16_t* dzp = pl ? pl16(E, m, cout) : nullptr;
     TE_L(fcl_bn_bwd(dz, cc.z, cc.mean, cc.invstd, E.Pm(pre + ".1.weight").p, dbeta, dgamma, dz2, dzp, m, cout, E.Pm(pre + ".1.bias").g, E.Pm(pre + ".1.weight").g, E.cur));
@@ -872,31 +874,65 @@ static int te_forward(fcl_te& E) {
 // ================================================================================================================================================
 // losses and the gradient every term injects at its tap (training.py _losses)
 // ================================================================================================================================================
-static int te_term(fcl_te& E, const char* name, const float* a, const float* bb, const uint8_t* valid, int m, int cc, double count, float w_l1, float w_mse, bool b_log,
-                   float* da_acc, bool want_planes, float** da_out, uint16_t** dap_out) {
-    const int slot = loss_slot(name);
-    FCL_REQUIRE(slot >= 0, FCL_ERR_INVALID, "fcl_te: unknown loss %s", name);
-    const bool acc = da_acc != nullptr;
-    float* da = acc ? da_acc : f32(E, m, cc);
-    const double cnt = count * E.cfg.accum_grad;
-    if (cc % 4) {  // the scalar heads: two separate kernels (fcl_l1_mse_loss_grad needs C % 4 == 0)
-        TE_L(fcl_masked_l1_mse_fwd(a, cc, bb, cc, valid, m, cc, b_log ? 1 : 0, b_log ? 1.0f : 0.0f, E.c.sums + 3 * slot, E.cur));
-        TE_L(fcl_l1_mse_grad(a, bb, valid, m, cc, b_log ? 1 : 0, b_log ? 1.0f : 0.0f, w_l1, w_mse, cnt, da, acc ? 1 : 0, E.cur));
-        if (da_out) *da_out = da;
+// Round 6: every element-wise term of a step is ONE fcl_loss_terms_batch launch (a term may carry the ground truth AND the teacher's output as targets),
+// and a KD projection term is split into its forward (s = s_in . W^T) and its backward (dW on the weight-gradient stream, ds_in = ds . W) around that
+// launch: the student's stream issues 9 launches for its loss phase instead of 35, each of which waited for a compute unit beside the frozen teacher.
+struct LossBatchBuilder {
+    fcl_te& E;
+    std::vector<fcl_loss_term_t> terms;
+    explicit LossBatchBuilder(fcl_te& e) : E(e) {}
+    // one target; returns the gradient buffer (allocated here unless da is given)
+    int add(const char* name, const float* a, const float* bb, const uint8_t* valid, int m, int cc, double count, float w_l1, float w_mse, bool b_log, bool want_planes,
+            float** da_out, uint16_t** dap_out) {
+        const int slot = loss_slot(name);
+        FCL_REQUIRE(slot >= 0, FCL_ERR_INVALID, "fcl_te: unknown loss %s", name);
+        fcl_loss_term_t t{};
+        t.a = a; t.b = bb; t.valid = valid; t.m = m; t.c = cc; t.b_log = b_log ? 1 : 0; t.b_log_offset = b_log ? 1.0f : 0.0f; t.w_l1 = w_l1; t.w_mse = w_mse;
+        t.count = count * E.cfg.accum_grad;
+        t.da = f32(E, m, cc);
+        t.da_planes = (want_planes && cc % 32 == 0) ? pl16(E, m, cc) : nullptr;
+        t.sums = E.c.sums + 3 * slot;
+        terms.push_back(t);
+        if (da_out) *da_out = t.da;
+        if (dap_out) *dap_out = t.da_planes;
         return 0;
     }
-    uint16_t* dap = want_planes ? pl16(E, m, cc) : nullptr;
-    TE_L(fcl_l1_mse_loss_grad(a, bb, valid, m, cc, b_log ? 1 : 0, b_log ? 1.0f : 0.0f, w_l1, w_mse, cnt, da, acc ? 1 : 0, E.c.sums + 3 * slot, dap, E.cur));
-    if (da_out) *da_out = da;
-    if (dap_out) *dap_out = dap;
-    return 0;
-}
+    // a second target for the term added last (its gradient joins the first's)
+    int second(const char* name, const float* b2, const uint8_t* valid2, double count2, float w_l1, float w_mse) {
+        const int slot = loss_slot(name);
+        FCL_REQUIRE(slot >= 0 && !terms.empty(), FCL_ERR_INVALID, "fcl_te: unknown loss %s", name);
+        fcl_loss_term_t& t = terms.back();
+        t.b2 = b2; t.valid2 = valid2; t.count2 = count2 * E.cfg.accum_grad; t.w_l1_2 = w_l1; t.w_mse_2 = w_mse; t.sums2 = E.c.sums + 3 * slot;
+        return 0;
+    }
+    int flush() {
+        for (size_t k0 = 0; k0 < terms.size(); k0 += FCL_LOSS_MAX_TERMS)
+            TE_L(fcl_loss_terms_batch(terms.data() + k0, (int)std::min<size_t>(FCL_LOSS_MAX_TERMS, terms.size() - k0), E.cur));
+        terms.clear();
+        return 0;
+    }
+};
 
-// MSE(s_in . W^T, t) over the valid rows: accumulates dW (weight-gradient stream), returns the gradient w.r.t. s_in
-static int te_kd(fcl_te& E, const char* lname, const float* s_in, int rows, const std::string& proj, int n, int k, const float* t, const uint8_t* valid, double nvalid,
-                 float** ds_in) {
+// MSE(s_in . W^T, t) over the valid rows, in two halves around the loss launch
+struct KdTerm {
+    std::string lname, proj, key;
+    const float* s_in;
+    int rows, n, k;
+    const float* t;
+    const uint8_t* valid;
+    double nvalid;
+    bool planes;
+    float* ds;
+    uint16_t* ds_p;
+};
+static int te_kd_fwd(fcl_te& E, LossBatchBuilder& lb, std::vector<KdTerm>& pend, const char* lname, const char* key, const float* s_in, int rows, const std::string& proj,
+                     int n, int k, const float* t, const uint8_t* valid, double nvalid) {
+    KdTerm q;
+    q.lname = lname; q.proj = proj; q.key = key; q.s_in = s_in; q.rows = rows; q.n = n; q.k = k; q.t = t; q.valid = valid; q.nvalid = nvalid;
+    q.planes = n % 32 == 0 && k % 32 == 0 && rows >= 4096;
     Param& W = E.Pm(proj + ".weight");
-    if (n % 32 == 0 && k % 32 == 0 && rows >= 4096) {
+    float* s = f32(E, rows, n);
+    if (q.planes) {
         const uint16_t* sp;
         auto hit = E.c.planes_of.find(s_in);
         if (hit != E.c.planes_of.end()) sp = hit->second;
@@ -907,37 +943,34 @@ static int te_kd(fcl_te& E, const char* lname, const float* s_in, int rows, cons
         }
         const uint16_t* wp;
         TE_TRY(w_planes(E, proj + ".weight", n, k, &wp));
-        float* s = f32(E, rows, n);
         TE_L(fcl_linear_planes_fwd(sp, k / 32, wp, nullptr, s, n, nullptr, rows, n, k, FCL_ACT_NONE, E.cur));
-        float* ds_;
-        uint16_t* ds_p;
-        TE_TRY(te_term(E, lname, s, t, valid, rows, n, nvalid * n, 0.0f, 1.0f, false, nullptr, true, &ds_, &ds_p));
-        {
-            SideScope sc(E);
-            TE_TRY(sc.rc);
-            TE_TRY(dw_gemm(E, ds_, rows, n, {{s_in, k, W.g, k}}));
-            E.dw_pending = true;
-        }
-        const uint16_t* wtp;
-        TE_TRY(w_t(E, proj + ".weight", W.p, n, k, k, false, true, nullptr, &wtp));
-        *ds_in = f32(E, rows, k);
-        TE_L(fcl_linear_planes_fwd(ds_p, n / 32, wtp, nullptr, *ds_in, k, nullptr, rows, k, n, FCL_ACT_NONE, E.cur));
-        return 0;
+    } else {
+        TE_L(fcl_linear_fwd(s_in, k, W.p, k, nullptr, s, n, rows, n, k, FCL_ACT_NONE, E.cur));
     }
-    float* s = f32(E, rows, n);
-    TE_L(fcl_linear_fwd(s_in, k, W.p, k, nullptr, s, n, rows, n, k, FCL_ACT_NONE, E.cur));
-    float* ds_;
-    TE_TRY(te_term(E, lname, s, t, valid, rows, n, nvalid * n, 0.0f, 1.0f, false, nullptr, false, &ds_, nullptr));
+    TE_TRY(lb.add(lname, s, t, valid, rows, n, nvalid * n, 0.0f, 1.0f, false, q.planes, &q.ds, &q.ds_p));
+    pend.push_back(q);
+    return 0;
+}
+static int te_kd_bwd(fcl_te& E, const KdTerm& q) {
+    Param& W = E.Pm(q.proj + ".weight");
     {
         SideScope sc(E);
         TE_TRY(sc.rc);
-        TE_L(fcl_gemm_tn_fwd(ds_, n, s_in, k, W.g, k, rows, n, k, 0, nullptr, nullptr, E.cur));
+        if (q.planes) TE_TRY(dw_gemm(E, q.ds, q.rows, q.n, {{q.s_in, q.k, W.g, q.k}}));
+        else TE_L(fcl_gemm_tn_fwd(q.ds, q.n, q.s_in, q.k, W.g, q.k, q.rows, q.n, q.k, 0, nullptr, nullptr, E.cur));
         E.dw_pending = true;
     }
-    const float* wt;
-    TE_TRY(w_t(E, proj + ".weight", W.p, n, k, k, true, false, &wt, nullptr));
-    *ds_in = f32(E, rows, k);
-    TE_L(fcl_linear_fwd(ds_, n, wt, n, nullptr, *ds_in, k, rows, k, n, FCL_ACT_NONE, E.cur));
+    float* ds_in = f32(E, q.rows, q.k);
+    if (q.planes) {
+        const uint16_t* wtp;
+        TE_TRY(w_t(E, q.proj + ".weight", W.p, q.n, q.k, q.k, false, true, nullptr, &wtp));
+        TE_L(fcl_linear_planes_fwd(q.ds_p, q.n / 32, wtp, nullptr, ds_in, q.k, nullptr, q.rows, q.k, q.n, FCL_ACT_NONE, E.cur));
+    } else {
+        const float* wt;
+        TE_TRY(w_t(E, q.proj + ".weight", W.p, q.n, q.k, q.k, true, false, &wt, nullptr));
+        TE_L(fcl_linear_fwd(q.ds, q.n, wt, q.n, nullptr, ds_in, q.k, q.rows, q.k, q.n, FCL_ACT_NONE, E.cur));
+    }
+    E.c.inj[q.key] = ds_in;
     return 0;
 }
 
@@ -954,31 +987,22 @@ static int te_losses(fcl_te& E, const fcl_te_knowledge_t* know) {
     const double nfm = um ? (double)BL * O : nf;
     const uint8_t* ev = um ? nullptr : b.enc_valid;
     const double nem = um ? (double)BT : ne;
-    float* g;
-    TE_TRY(te_term(E, "after", c.after, b.ys, fv, BL, O, nfm, 1.f, 1.f, false, nullptr, false, &g, nullptr));
-    c.inj["after"] = g;
-    TE_TRY(te_term(E, "before", c.before, b.ys, fv, BL, O, nfm, 1.f, 1.f, false, nullptr, false, &g, nullptr));
-    c.inj["before"] = g;
-    TE_TRY(te_term(E, "dur", c.dur.out, b.ds, b.enc_valid, BT, 1, ne, 0.f, 1.f, true, nullptr, false, &g, nullptr));
-    c.inj["d_outs"] = g;
-    TE_TRY(te_term(E, "pitch", c.pit.out, b.f0, ev, BT, 1, nem, 0.f, 1.f, false, nullptr, false, &g, nullptr));
-    c.inj["p_outs"] = g;
-    TE_TRY(te_term(E, "energy", c.en.out, b.energy, ev, BT, 1, nem, 0.f, 1.f, false, nullptr, false, &g, nullptr));
-    c.inj["e_outs"] = g;
-    if (cf.role != FCL_TE_STUDENT) return 0;
-    FCL_REQUIRE(know != nullptr, FCL_ERR_INVALID, "fcl_te: the student step needs the teacher's knowledge (tts_distill.py:159-161)");
+    const bool student = cf.role == FCL_TE_STUDENT;
+    FCL_REQUIRE(!student || know != nullptr, FCL_ERR_INVALID, "fcl_te: the student step needs the teacher's knowledge (tts_distill.py:159-161)");
     const int U = cf.dunits, Pn = cf.prenet_units, Cp = cf.postnet_chans;
     const std::string cp[3] = {cf.share_proj ? "enc.convs_proj.0" : "enc.convs_proj.0", cf.share_proj ? "enc.convs_proj.0" : "enc.convs_proj.1",
                                cf.share_proj ? "enc.convs_proj.0" : "enc.convs_proj.2"};
     const std::string lp[2] = {cf.share_proj ? "dec.lstm_proj" : "dec.lstm0_proj", cf.share_proj ? "dec.lstm_proj" : "dec.lstm1_proj"};
     auto pp = [&](int i) { return cf.share_proj ? std::string("dec.post_proj") : ("dec.post" + std::to_string(i) + "_proj"); };
-    {   // the KD terms whose gradients the backward needs LATE run on the weight-gradient stream beside the frame-level terms and the postnet's backward
+    if (student) {  // the KD terms whose gradients the backward needs LATE run on the weight-gradient stream beside the frame-level terms and the postnet's backward
         const bool fork = cf.pred_stream && c.save && cf.late_losses;
         hipStream_t saved = E.cur;
         if (fork) {
             TE_TRY(ev_wait(E, E.side, E.main));
             E.cur = E.side;
         }
+        LossBatchBuilder lb(E);
+        std::vector<KdTerm> pend;
         if (cf.distill_decoder) {
             const float* tc[3];
             const int wd[3] = {cf.t_prenet_units, cf.t_dunits, cf.t_dunits};
@@ -990,55 +1014,63 @@ static int te_losses(fcl_te& E, const fcl_te_knowledge_t* know) {
                     tc[i] = t;
                 }
             }
-            TE_TRY(te_kd(E, "dec2", c.h1_all, F, lp[1], cf.t_dunits, U, tc[2], b.cell_valid, b.n_frames, &g));
-            c.inj["h1"] = g;
-            TE_TRY(te_kd(E, "dec1", c.h0_all, F, lp[0], cf.t_dunits, U, tc[1], b.cell_valid, b.n_frames, &g));
-            c.inj["h0"] = g;
-            TE_TRY(te_kd(E, "dec0", c.p1d, F, "dec.prenet_proj", cf.t_prenet_units, Pn, tc[0], b.cell_valid, b.n_frames, &g));
-            c.inj["p1d"] = g;
+            TE_TRY(te_kd_fwd(E, lb, pend, "dec2", "h1", c.h1_all, F, lp[1], cf.t_dunits, U, tc[2], b.cell_valid, b.n_frames));
+            TE_TRY(te_kd_fwd(E, lb, pend, "dec1", "h0", c.h0_all, F, lp[0], cf.t_dunits, U, tc[1], b.cell_valid, b.n_frames));
+            TE_TRY(te_kd_fwd(E, lb, pend, "dec0", "p1d", c.p1d, F, "dec.prenet_proj", cf.t_prenet_units, Pn, tc[0], b.cell_valid, b.n_frames));
         }
         if (cf.distill_encoder) {
-            TE_TRY(te_kd(E, "enc0", c.enc_taps[0], BT, "enc.embed_proj", cf.t_embed_dim, cf.embed_dim, know->enc[0], b.enc_valid, ne, &g));
-            c.inj["enc0"] = g;
+            TE_TRY(te_kd_fwd(E, lb, pend, "enc0", "enc0", c.enc_taps[0], BT, "enc.embed_proj", cf.t_embed_dim, cf.embed_dim, know->enc[0], b.enc_valid, ne));
             for (int i = 0; i < 3; ++i) {
-                char nm[8], key[8];
+                char nm[8];
                 snprintf(nm, sizeof(nm), "enc%d", i + 1);
-                snprintf(key, sizeof(key), "enc%d", i + 1);
-                TE_TRY(te_kd(E, nm, c.enc_taps[1 + i], BT, cp[i], cf.t_econv_chans, cf.econv_chans, know->enc[1 + i], b.enc_valid, ne, &g));
-                c.inj[key] = g;
+                TE_TRY(te_kd_fwd(E, lb, pend, nm, nm, c.enc_taps[1 + i], BT, cp[i], cf.t_econv_chans, cf.econv_chans, know->enc[1 + i], b.enc_valid, ne));
             }
-            TE_TRY(te_kd(E, "enc4", c.hs, BT, "enc.blstm_proj", cf.t_eunits, C, know->enc[4], b.enc_valid, ne, &g));
-            c.inj["hs"] = g;
+            TE_TRY(te_kd_fwd(E, lb, pend, "enc4", "hs", c.hs, BT, "enc.blstm_proj", cf.t_eunits, C, know->enc[4], b.enc_valid, ne));
         }
+        if (cf.distill_prosody) {  // the embedding taps' gradients are wanted at backward stage 2: late as well
+            TE_TRY(te_kd_fwd(E, lb, pend, "pro3", "p_embs", c.p_embs, BT, "pemb_proj", cf.t_eunits, C, know->pro[3], b.enc_valid, ne));
+            TE_TRY(te_kd_fwd(E, lb, pend, "pro4", "e_embs", c.e_embs, BT, "eemb_proj", cf.t_eunits, C, know->pro[4], b.enc_valid, ne));
+        }
+        TE_TRY(lb.flush());
+        for (const KdTerm& q : pend) TE_TRY(te_kd_bwd(E, q));
         if (fork) {
             if (!E.dry) FCL_HIP(hipEventRecord(E.late_ev, E.side));
             E.late_pending = true;
             E.cur = saved;
         }
     }
-    if (cf.distill_output) {
-        TE_TRY(te_term(E, "o_after", c.after, know->after, fv, BL, O, nfm, 1.f, 1.f, false, c.inj["after"], false, nullptr, nullptr));
-        TE_TRY(te_term(E, "o_before", c.before, know->before, fv, BL, O, nfm, 1.f, 1.f, false, c.inj["before"], false, nullptr, nullptr));
-    }
-    if (cf.distill_decoder) {
+    // the student's stream: the postnet taps' projections, ONE loss launch (their terms + every element-wise term), their backward halves
+    LossBatchBuilder lb(E);
+    std::vector<KdTerm> pend;
+    if (student && cf.distill_decoder)
         for (int i = 0; i < 4; ++i) {
             char nm[8];
             snprintf(nm, sizeof(nm), "dec%d", 3 + i);
-            TE_TRY(te_kd(E, nm, c.post_taps[i], BL, pp(i), cf.t_postnet_chans, Cp, know->dec[3 + i], b.frame_valid, b.n_frames, &g));
-            c.inj["post" + std::to_string(i)] = g;
+            TE_TRY(te_kd_fwd(E, lb, pend, nm, ("post" + std::to_string(i)).c_str(), c.post_taps[i], BL, pp(i), cf.t_postnet_chans, Cp, know->dec[3 + i], b.frame_valid,
+                             b.n_frames));
         }
-        TE_TRY(te_term(E, "dec7", c.post_taps[4], know->dec[7], b.frame_valid, BL, O, nf, 0.f, 1.f, false, nullptr, false, &g, nullptr));
+    float* g;
+    TE_TRY(lb.add("after", c.after, b.ys, fv, BL, O, nfm, 1.f, 1.f, false, false, &g, nullptr));
+    if (student && cf.distill_output) TE_TRY(lb.second("o_after", know->after, fv, nfm, 1.f, 1.f));
+    c.inj["after"] = g;
+    TE_TRY(lb.add("before", c.before, b.ys, fv, BL, O, nfm, 1.f, 1.f, false, false, &g, nullptr));
+    if (student && cf.distill_output) TE_TRY(lb.second("o_before", know->before, fv, nfm, 1.f, 1.f));
+    c.inj["before"] = g;
+    TE_TRY(lb.add("dur", c.dur.out, b.ds, b.enc_valid, BT, 1, ne, 0.f, 1.f, true, false, &g, nullptr));
+    if (student && cf.distill_prosody) TE_TRY(lb.second("pro0", know->pro[0], b.enc_valid, ne, 0.f, 1.f));
+    c.inj["d_outs"] = g;
+    TE_TRY(lb.add("pitch", c.pit.out, b.f0, ev, BT, 1, nem, 0.f, 1.f, false, false, &g, nullptr));
+    if (student && cf.distill_prosody) TE_TRY(lb.second("pro1", know->pro[1], b.enc_valid, ne, 0.f, 1.f));
+    c.inj["p_outs"] = g;
+    TE_TRY(lb.add("energy", c.en.out, b.energy, ev, BT, 1, nem, 0.f, 1.f, false, false, &g, nullptr));
+    if (student && cf.distill_prosody) TE_TRY(lb.second("pro2", know->pro[2], b.enc_valid, ne, 0.f, 1.f));
+    c.inj["e_outs"] = g;
+    if (student && cf.distill_decoder) {
+        TE_TRY(lb.add("dec7", c.post_taps[4], know->dec[7], b.frame_valid, BL, O, nf, 0.f, 1.f, false, false, &g, nullptr));
         c.inj["post4"] = g;
     }
-    if (cf.distill_prosody) {
-        TE_TRY(te_term(E, "pro0", c.dur.out, know->pro[0], b.enc_valid, BT, 1, ne, 0.f, 1.f, false, c.inj["d_outs"], false, nullptr, nullptr));
-        TE_TRY(te_term(E, "pro1", c.pit.out, know->pro[1], b.enc_valid, BT, 1, ne, 0.f, 1.f, false, c.inj["p_outs"], false, nullptr, nullptr));
-        TE_TRY(te_term(E, "pro2", c.en.out, know->pro[2], b.enc_valid, BT, 1, ne, 0.f, 1.f, false, c.inj["e_outs"], false, nullptr, nullptr));
-        TE_TRY(te_kd(E, "pro3", c.p_embs, BT, "pemb_proj", cf.t_eunits, C, know->pro[3], b.enc_valid, ne, &g));
-        c.inj["p_embs"] = g;
-        TE_TRY(te_kd(E, "pro4", c.e_embs, BT, "eemb_proj", cf.t_eunits, C, know->pro[4], b.enc_valid, ne, &g));
-        c.inj["e_embs"] = g;
-    }
+    TE_TRY(lb.flush());
+    for (int i = (int)pend.size() - 1; i >= 0; --i) TE_TRY(te_kd_bwd(E, pend[i]));  // the postnet's backward consumes post3 first
     return 0;
 }
 
@@ -1067,17 +1099,16 @@ static int te_backward_stage0(fcl_te& E) {  // predictors' backward forked; post
             E.cur = saved;
         }
     }
-    c.d_before = c.inj["before"];
-    TE_L(fcl_add2d(c.d_before, O, c.inj["after"], O, BL, O, 1.0f, nullptr, E.cur));
     float* dx = c.inj["after"];
     for (int i = (int)c.post_c.size() - 1; i >= 0; --i) {
         auto it = c.inj.find("post" + std::to_string(i));
-        if (it != c.inj.end()) TE_L(fcl_add2d(dx, c.post_c[i].cout, it->second, c.post_c[i].cout, BL, c.post_c[i].cout, 1.0f, nullptr, E.cur));
         float* nx;
-        TE_TRY(conv_bn_bwd(E, dx, c.post_c[i], &nx));
+        TE_TRY(conv_bn_bwd(E, dx, it != c.inj.end() ? it->second : nullptr, c.post_c[i], &nx));
         dx = nx;
     }
-    TE_L(fcl_add2d(c.d_before, O, dx, O, BL, O, 1.0f, nullptr, E.cur));
+    c.d_post_in = dx;  // d before = inj[before] + inj[after] + the postnet's input gradient: summed by the gather of stage 1 (round 6)
+    (void)BL;
+    (void)O;
     TE_TRY(late_join(E));  // the KD gradients at the prenet / LSTM / encoder taps
     return 0;
 }
@@ -1116,7 +1147,7 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
     const int N = b.N, F = b.F, O = cf.odim, U = cf.dunits, Pn = cf.prenet_units, C = cf.eunits;
     float* d_out_cells = f32(E, F, O);
     uint16_t* d_out_cells_p = dx_planes() ? pl16(E, F, O) : nullptr;
-    TE_L(fcl_gather_rows_fwd(c.d_before, b.cell_frame, d_out_cells, d_out_cells_p, F, O, E.cur));
+    TE_L(fcl_gather_rows_sum_fwd(c.inj["before"], c.inj["after"], c.d_post_in, b.cell_frame, d_out_cells, d_out_cells_p, F, O, E.cur));
     Param& WF = E.Pm("dec.feat_out.weight");
     {
         SideScope sc(E);
@@ -1128,8 +1159,14 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
     TE_TRY(w_cols(E, "dec.feat_out.weight", O, U + C, 0, U, true, &wf_h, nullptr));
     TE_TRY(w_cols(E, "dec.feat_out.weight", O, U + C, U, C, true, &wf_att, nullptr));
     float* dh1_all = f32(E, F, U);
-    TE_TRY(dx_linear(E, d_out_cells, d_out_cells_p, F, O, "dec.feat_out.weight/h", WF.p, O, U, U + C, dh1_all, U));
-    if (c.inj.count("h1")) TE_L(fcl_add2d(dh1_all, U, c.inj["h1"], U, F, U, 1.0f, nullptr, E.cur));
+    if (!dx_planes()) {  // round 6: the KD gradient at the h1 tap joins as the GEMM's residual
+        const float* wt;
+        TE_TRY(w_t(E, "dec.feat_out.weight/h", WF.p, O, U, U + C, true, false, &wt, nullptr));
+        TE_L(fcl_linear2_fwd(d_out_cells, O, wt, O, O, nullptr, 0, nullptr, 0, 0, nullptr, c.inj.count("h1") ? c.inj["h1"] : nullptr, U, dh1_all, U, F, U, FCL_ACT_NONE, E.cur));
+    } else {
+        TE_TRY(dx_linear(E, d_out_cells, d_out_cells_p, F, O, "dec.feat_out.weight/h", WF.p, O, U, U + C, dh1_all, U));
+        if (c.inj.count("h1")) TE_L(fcl_add2d(dh1_all, U, c.inj["h1"], U, F, U, 1.0f, nullptr, E.cur));
+    }
     float* dF0 = zf32(E, (long long)N * O);
     TE_L(fcl_scatter_add_rows(d_out_cells, b.cell_row_i64, dF0, F, O, -1, E.cur));
     {
@@ -1139,7 +1176,7 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
         E.dw_pending = true;
     }
     c.d_att_c = f32(E, N, C);
-    TE_TRY(dx_linear(E, dF0, nullptr, N, O, "dec.feat_out.weight/att", WF.p + U, O, C, U + C, c.d_att_c, C));
+    if (dx_planes()) TE_TRY(dx_linear(E, dF0, nullptr, N, O, "dec.feat_out.weight/att", WF.p + U, O, C, U + C, c.d_att_c, C));
     float *dg0_all = f32(E, F, 4 * U), *dg1_all = f32(E, F, 4 * U);
     const std::string w1ih = "dec.lstm.1.cell.weight_ih", w1hh = "dec.lstm.1.cell.weight_hh", w0hh = "dec.lstm.0.cell.weight_hh", wih0 = "dec.lstm.0.cell.weight_ih";
     const int ld0 = C + Pn + 1;
@@ -1213,17 +1250,22 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
         TE_L(fcl_gemm_tn_fwd(dG0, 4 * U, c.att_c, C, g_ih0, ld0, N, 4 * U, C, 0, nullptr, nullptr, E.cur));
         E.dw_pending = true;
     }
-    {
+    if (!dx_planes()) {  // round 6: the two input gradients that reach att_c (through feat_out and through LSTM 0's input block) in ONE two-term GEMM
+        const float *wt_f, *wt_g;
+        TE_TRY(w_t(E, "dec.feat_out.weight/att", WF.p + U, O, C, U + C, true, false, &wt_f, nullptr));
+        TE_TRY(w_t(E, wih0 + "/att", E.Pm(wih0).p, 4 * U, C, ld0, true, false, &wt_g, nullptr));
+        TE_L(fcl_linear2_fwd(dF0, O, wt_f, O, O, dG0, 4 * U, wt_g, 4 * U, 4 * U, nullptr, nullptr, 0, c.d_att_c, C, N, C, FCL_ACT_NONE, E.cur));
+    } else {
         float* t = f32(E, N, C);
         TE_TRY(dx_linear(E, dG0, nullptr, N, 4 * U, wih0 + "/att", E.Pm(wih0).p, 4 * U, C, ld0, t, C));
         TE_L(fcl_add2d(c.d_att_c, C, t, C, N, C, 1.0f, nullptr, E.cur));
     }
     // prenet (batched over all cells)
     const std::string w0n = "dec.prenet.prenet.0.0.weight", b0n = "dec.prenet.prenet.0.0.bias", w1n = "dec.prenet.prenet.1.0.weight", b1n = "dec.prenet.prenet.1.0.bias";
-    if (c.inj.count("p1d")) TE_L(fcl_add2d(dp1_all, Pn, c.inj["p1d"], Pn, F, Pn, 1.0f, nullptr, E.cur));
     float* dz1 = f32(E, F, Pn);
     uint16_t* dz1_p = pl16(E, F, Pn);
-    TE_L(fcl_act_bwd(dp1_all, c.p1, c.k1, c.pks, dz1, dz1_p, Pn, (size_t)F * Pn, FCL_ACT_RELU, E.cur));
+    if (c.inj.count("p1d")) TE_L(fcl_act_bwd_sum(dp1_all, c.inj["p1d"], c.p1, c.k1, c.pks, dz1, dz1_p, Pn, (size_t)F * Pn, FCL_ACT_RELU, E.cur));
+    else TE_L(fcl_act_bwd(dp1_all, c.p1, c.k1, c.pks, dz1, dz1_p, Pn, (size_t)F * Pn, FCL_ACT_RELU, E.cur));
     {
         SideScope sc(E);
         TE_TRY(sc.rc);
@@ -1254,23 +1296,22 @@ static int te_backward_stage2(fcl_te& E) {  // att = hs + p_embs + e_embs; predi
     const int BT = b.B * b.T, C = cf.eunits;
     c.d_att = f32(E, BT, C);
     TE_L(fcl_gather_rows_fwd(c.d_att_c, b.row_of_enc, c.d_att, nullptr, BT, C, E.cur));  // back to (b, t) rows; rows without a phoneme get 0
-    c.d_hs = f32(E, BT, C);
-    TE_L(fcl_copy2d(c.d_hs, C, c.d_att, C, BT, C, E.cur));
     const int kk = cf.ve_kernel;
     const char* nm[2] = {"pitch", "energy"};
     const char* tap[2] = {"p_embs", "e_embs"};
     const float* sig[2] = {b.f0, b.energy};
     for (int q = 0; q < 2; ++q) {
         float* d_e = c.d_att;
-        if (c.inj.count(tap[q])) {
+        const float* inj_q = c.inj.count(tap[q]) ? c.inj[tap[q]] : nullptr;
+        if (c.emb_keep[q]) {  // round 6: the KD gradient at the embedding tap joins inside the dropout backward
             float* t = f32(E, BT, C);
-            TE_L(fcl_copy2d(t, C, c.d_att, C, BT, C, E.cur));
-            TE_L(fcl_add2d(t, C, c.inj[tap[q]], C, BT, C, 1.0f, nullptr, E.cur));
+            if (inj_q) TE_L(fcl_act_bwd_sum(d_e, inj_q, nullptr, c.emb_keep[q], c.emb_ks, t, nullptr, 0, (size_t)BT * C, FCL_ACT_NONE, E.cur));
+            else TE_L(fcl_act_bwd(d_e, nullptr, c.emb_keep[q], c.emb_ks, t, nullptr, 0, (size_t)BT * C, FCL_ACT_NONE, E.cur));
             d_e = t;
-        }
-        if (c.emb_keep[q]) {
+        } else if (inj_q) {
             float* t = f32(E, BT, C);
-            TE_L(fcl_act_bwd(d_e, nullptr, c.emb_keep[q], c.emb_ks, t, nullptr, 0, (size_t)BT * C, FCL_ACT_NONE, E.cur));
+            const float* srcs[2] = {c.d_att, inj_q};
+            TE_L(fcl_sum_rows(srcs, 2, nullptr, t, nullptr, BT, C, E.cur));
             d_e = t;
         }
         SideScope sc(E);  // Conv1d(1 -> C, k): weight and bias gradients in one launch
@@ -1279,8 +1320,7 @@ static int te_backward_stage2(fcl_te& E) {  // att = hs + p_embs + e_embs; predi
                                E.cur));
         E.dw_pending = true;
     }
-    TE_TRY(pred_join(E));  // the predictors' backward was enqueued at the top of stage 0, on the weight-gradient stream
-    for (int q = 0; q < 3; ++q) TE_L(fcl_add2d(c.d_hs, C, c.d_preds[q], C, BT, C, 1.0f, nullptr, E.cur));
+    TE_TRY(pred_join(E));  // the predictors' backward was enqueued at the top of stage 0, on the weight-gradient stream; stage 3 sums their input gradients
     return 0;
 }
 
@@ -1289,11 +1329,18 @@ static int te_backward_stage3(fcl_te& E) {  // encoder
     Ctx& c = E.c;
     const fcl_te_batch_t& b = c.b;
     const int B = b.B, T = b.T, BT = B * T, C = cf.eunits, H = C / 2, Cc = cf.econv_chans;
-    if (c.inj.count("hs")) TE_L(fcl_add2d(c.d_hs, C, c.inj["hs"], C, BT, C, 1.0f, nullptr, E.cur));
-    float* d_hs_live = zf32(E, (long long)BT * C);
-    TE_L(fcl_add2d(d_hs_live, C, c.d_hs, C, BT, C, 1.0f, b.enc_valid, E.cur));  // pad_packed_sequence: padded outputs are constants
+    // d hs = d att + the three predictors' input gradients (+ the KD term at the hs tap), zero on padded positions (pad_packed_sequence: padded outputs are
+    // constants): one launch (round 6; was copy + 4 adds + a masked add into a zeroed buffer)
+    float* d_hs_live = f32(E, BT, C);
+    {
+        const float* srcs[FCL_SUM_ROWS_MAX] = {c.d_att, c.d_preds[0], c.d_preds[1], c.d_preds[2], nullptr, nullptr};
+        int ns = 4;
+        if (c.inj.count("hs")) srcs[ns++] = c.inj["hs"];
+        TE_L(fcl_sum_rows(srcs, ns, b.enc_valid, d_hs_live, nullptr, BT, C, E.cur));
+    }
     // BiLSTM backward
-    float* dx = zf32(E, (long long)BT * Cc);
+    float* dx = dx_planes() ? zf32(E, (long long)BT * Cc) : f32(E, BT, Cc);
+    float* dgx2[2] = {nullptr, nullptr};
     {
         fcl_bilstm_bptt_t a{};
         a.b = B; a.t = T; a.h = H; a.lens = b.lens; a.d_out = d_hs_live; a.ld_dout = C; a.status = E.status;
@@ -1322,18 +1369,27 @@ static int te_backward_stage3(fcl_te& E) {  // encoder
                 TE_L(fcl_colsum2_fwd(dgx, nullptr, nullptr, nullptr, E.Pm("enc.blstm.bias_ih_l0" + s_).g, E.Pm("enc.blstm.bias_hh_l0" + s_).g, BT, 4 * H, 0, E.cur));
                 E.dw_pending = true;
             }
-            const std::string wn = "enc.blstm.weight_ih_l0" + s_;
-            float* t = f32(E, BT, Cc);
-            TE_TRY(dx_linear(E, dgx, dgx_p, BT, 4 * H, wn, E.Pm(wn).p, 4 * H, Cc, Cc, t, Cc));
-            TE_L(fcl_add2d(dx, Cc, t, Cc, BT, Cc, 1.0f, nullptr, E.cur));
+            dgx2[d] = dgx;
+            if (dx_planes()) {
+                const std::string wn = "enc.blstm.weight_ih_l0" + s_;
+                float* t = f32(E, BT, Cc);
+                TE_TRY(dx_linear(E, dgx, dgx_p, BT, 4 * H, wn, E.Pm(wn).p, 4 * H, Cc, Cc, t, Cc));
+                TE_L(fcl_add2d(dx, Cc, t, Cc, BT, Cc, 1.0f, nullptr, E.cur));
+            }
+        }
+        if (!dx_planes()) {  // round 6: both directions' input gradients in ONE two-term GEMM
+            const std::string wf = "enc.blstm.weight_ih_l0", wr = "enc.blstm.weight_ih_l0_reverse";
+            const float *wt_f, *wt_r;
+            TE_TRY(w_t(E, wf, E.Pm(wf).p, 4 * H, Cc, Cc, true, false, &wt_f, nullptr));
+            TE_TRY(w_t(E, wr, E.Pm(wr).p, 4 * H, Cc, Cc, true, false, &wt_r, nullptr));
+            TE_L(fcl_linear2_fwd(dgx2[0], 4 * H, wt_f, 4 * H, 4 * H, dgx2[1], 4 * H, wt_r, 4 * H, 4 * H, nullptr, nullptr, 0, dx, Cc, BT, Cc, FCL_ACT_NONE, E.cur));
         }
     }
     for (int i = (int)c.conv_c.size() - 1; i >= 0; --i) {
         char key[8];
         snprintf(key, sizeof(key), "enc%d", i + 1);
-        if (c.inj.count(key)) TE_L(fcl_add2d(dx, Cc, c.inj[key], Cc, BT, Cc, 1.0f, nullptr, E.cur));
         float* nx;
-        TE_TRY(conv_bn_bwd(E, dx, c.conv_c[i], &nx));
+        TE_TRY(conv_bn_bwd(E, dx, c.inj.count(key) ? c.inj[key] : nullptr, c.conv_c[i], &nx));
         dx = nx;
     }
     if (c.inj.count("enc0")) TE_L(fcl_add2d(dx, cf.embed_dim, c.inj["enc0"], cf.embed_dim, BT, cf.embed_dim, 1.0f, nullptr, E.cur));
@@ -1504,7 +1560,11 @@ int fcl_te_finalize(fcl_te_t* E, uint32_t* status_word) {
         }
     }
     if (!E->side) {
-        FCL_HIP(hipStreamCreateWithFlags(&E->side, hipStreamNonBlocking));
+        {   // FCL_TE_SIDE_CUS=n: the weight-gradient stream dispatches to n compute units only (fcl_stream_create_cus; 0 = all)
+            fcl_stream_t st = nullptr;
+            TE_TRY(fcl_stream_create_cus(tunable("TE_SIDE_CUS", 0), &st));
+            E->side = (hipStream_t)st;
+        }
         E->evpool.resize(64);
         for (hipEvent_t& ev : E->evpool) FCL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         FCL_HIP(hipEventCreateWithFlags(&E->pred_ev, hipEventDisableTiming));

@@ -851,3 +851,78 @@ def bilstm_bptt(s, lens_i32, b, t, d_out, w_hh_t, dg, status=None):
     ws = torch.empty(nbytes, device=d_out.device, dtype=torch.uint8)
     a.workspace, a.workspace_bytes = ws.data_ptr(), nbytes
     check(lib.fcl_bilstm_bptt(C.byref(a), _stream()))
+
+
+# ---- round 6: the fused small launches of the training update (csrc/fused_small.hip) ---------------------------------------------------------------
+def loss_terms_batch(terms, sums_f64):
+    """ONE launch for a list of element-wise loss terms.  Each term is a dict: a, b, slot (row of sums_f64 [n, 3]), count, w_l1, w_mse and optionally
+    valid, b_log_offset, want_planes, and the second target b2 / valid2 / slot2 / count2 / w_l1_2 / w_mse_2.  Returns [(da, da_planes or None), ...]."""
+    assert 1 <= len(terms) <= _lib.LOSS_MAX_TERMS
+    arr = (_lib.LossTerm * len(terms))()
+    outs = []
+    for t, d in zip(arr, terms):
+        a, b = d["a"], d["b"]
+        if a.dim() == 1:
+            a, b = a.reshape(-1, 1), b.reshape(-1, 1)
+        m, c = a.shape
+        da = torch.empty_like(a)
+        dap = planes_empty(m, c, a.device) if d.get("want_planes") else None
+        t.a, t.b, t.valid, t.da, t.da_planes = _p(a), _p(b), _p(d.get("valid"), torch.uint8), _p(da), _p(dap, torch.int16)
+        t.sums = sums_f64.data_ptr() + 24 * d["slot"]
+        t.m, t.c = m, c
+        t.b_log, t.b_log_offset = int(d.get("b_log_offset") is not None), float(d.get("b_log_offset") or 0.0)
+        t.w_l1, t.w_mse, t.count = d["w_l1"], d["w_mse"], float(d["count"])
+        if d.get("b2") is not None:
+            b2 = d["b2"].reshape(m, c)
+            t.b2, t.valid2 = _p(b2), _p(d.get("valid2"), torch.uint8)
+            t.sums2 = sums_f64.data_ptr() + 24 * d["slot2"]
+            t.w_l1_2, t.w_mse_2, t.count2 = d["w_l1_2"], d["w_mse_2"], float(d["count2"])
+        outs.append((da, dap))
+    check(_lib.load().fcl_loss_terms_batch(arr, len(terms), _stream()))
+    return outs
+
+
+def sum_rows(srcs, row_valid=None, want_f32=True, want_planes=False, out=None):
+    """row_valid[r] ? sum of the sources' row r : 0 (dense [rows, cols] fp32 matrices, cols % 4 == 0)."""
+    rows, cols = srcs[0].shape
+    ptrs = (C.c_void_p * len(srcs))(*[_p(s) for s in srcs])
+    dst = (out if out is not None else torch.empty_like(srcs[0])) if want_f32 else None
+    dp = planes_empty(rows, cols, srcs[0].device) if want_planes else None
+    check(_lib.load().fcl_sum_rows(ptrs, len(srcs), _p(row_valid, torch.uint8), _p(dst), _p(dp, torch.int16), rows, cols, _stream()))
+    return (dst, dp) if want_planes else dst
+
+
+def bn_bwd_sums(dy, z, mean, invstd, dgamma, dbeta, act=ACT_NONE, y_act=None, keep=None, keep_scale=1.0, dy2=None):
+    """dz = (dy [+ dy2]) [* keep * keep_scale] * act'(y_act); dgamma += colsum(dz * zhat), dbeta += colsum(dz).  Returns dz."""
+    m, c = dy.shape
+    dz = torch.empty_like(dy)
+    check(_lib.load().fcl_bn_bwd_sums(_p(dy), _p(dy2), _p(y_act), _p(keep, torch.uint8), keep_scale, act, _p(z), _p(mean), _p(invstd), _p(dz), _p(dgamma),
+                                      _p(dbeta), m, c, _stream()))
+    return dz
+
+
+def act_bwd_sum(dy, dy2, y, act, keep=None, keep_scale=1.0, want_planes=False):
+    dz = torch.empty_like(dy)
+    cols = dy.shape[-1]
+    dzp = planes_empty(dy.numel() // cols, cols, dy.device) if want_planes else None
+    check(_lib.load().fcl_act_bwd_sum(_p(dy), _p(dy2), _p(y), _p(keep, torch.uint8), keep_scale, _p(dz), _p(dzp, torch.int16), cols if want_planes else 0,
+                                      dy.numel(), act, _stream()))
+    return (dz, dzp) if want_planes else dz
+
+
+def gather_rows_sum(src, src2, src3, idx_i32, want_planes=False):
+    n, c = idx_i32.numel(), src.shape[1]
+    dst = torch.empty(n, c, device=src.device, dtype=torch.float32)
+    dp = planes_empty(n, c, src.device) if want_planes else None
+    check(_lib.load().fcl_gather_rows_sum_fwd(_p(src), _p(src2), _p(src3), _p(idx_i32, torch.int32), _p(dst), _p(dp, torch.int16), n, c, _stream()))
+    return (dst, dp) if want_planes else dst
+
+
+def linear2(x, w, x2=None, w2=None, bias=None, residual=None, act=ACT_NONE):
+    """act(x . w^T [+ x2 . w2^T] + bias) [+ residual] on fp32 operands."""
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty(m, n, device=x.device, dtype=torch.float32)
+    k2 = x2.shape[1] if x2 is not None else 0
+    check(_lib.load().fcl_linear2_fwd(_p(x), k, _p(w), k, k, _p(x2), k2, _p(w2), k2, k2, _p(bias), _p(residual), n, _p(y), n, m, n, act, _stream()))
+    return y

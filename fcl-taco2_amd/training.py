@@ -21,13 +21,14 @@ Gradients, Adam moments and (re-pointed) parameters live in three flat buffers o
 launch and the all-reduce runs over contiguous buckets while backward is still producing the later ones.
 """
 import contextlib
+import ctypes as C
 import os
 import zlib
 
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from .hparams import lstm_key, output_act_code
 from .plan import BN_EPS, LN_EPS
 
@@ -1750,6 +1751,9 @@ class TrainEngine(object):
         return rep
 
 
+KD_TEACHER_CUS_DEFAULT = 0  # compute units the frozen teacher's stream may use beside the student's update (0 = all; measured in DESIGN §5)
+
+
 class KDPipeline(object):
     """The KD update with the frozen teacher one batch ahead on its own HIP stream: teacher(batch i+1) has no dependency on student(batch i)
     (the teacher is frozen; its BatchNorm buffers still advance in batch order), and neither fills the GPU alone, so the two overlap.  The student's
@@ -1759,7 +1763,17 @@ class KDPipeline(object):
 
     def __init__(self, teacher_engine, student_engine, mode="train"):
         self.teng, self.eng, self.mode = teacher_engine, student_engine, mode
-        self.side = torch.cuda.Stream(device=student_engine.dev)
+        # FCL_KD_TEACHER_CUS=n: the frozen teacher's stream dispatches to n compute units only (fcl_stream_create_cus), the student's streams keep all
+        n_cus = int(os.environ.get("FCL_KD_TEACHER_CUS", str(KD_TEACHER_CUS_DEFAULT)))
+        if n_cus > 0:
+            with torch.cuda.device(student_engine.dev):
+                h = C.c_void_p()
+                _lib.check(_lib.load().fcl_stream_create_cus(n_cus, C.byref(h)))
+            self._side_handle = h  # lives as long as the pipeline (the process): the teacher's arena may be read on it until the last update
+            self.side = torch.cuda.ExternalStream(h.value, device=student_engine.dev)
+        else:
+            self.side = torch.cuda.Stream(device=student_engine.dev)
+        self.teacher_cus = n_cus
         self.pending = None  # (batch id, knowledge, event)
         # both engines native (and train form): the knowledge stays in the teacher engine's arena, cell-major (no frame round trip, no torch tensors)
         self.native = mode == "train" and teacher_engine.native is not None and student_engine.native is not None

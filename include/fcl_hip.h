@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 417
+#define FCL_ABI_VERSION 418
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -452,6 +452,56 @@ int fcl_l1_mse_grad(const float* a, const float* b, const uint8_t* row_valid, in
  * C % 32 == 0): the gradient also as P32 planes [m][C/32][2][32] for the input-gradient GEMM that consumes it (the KD projections). */
 int fcl_l1_mse_loss_grad(const float* a, const float* b, const uint8_t* row_valid, int m, int c, int b_log, float b_log_offset, float w_l1,
                          float w_mse, double count, float* da, int accumulate, double* sums, uint16_t* da_planes, fcl_stream_t stream);
+/* ---- round 6: the small-launch tail of the training update (csrc/fused_small.hip) ------------------------------------------------------------------
+ * Every ELEMENT-WISE loss term of a step in one launch (..._kd_student.py:759-802, ..._sa.py:60-70,122-126): term k computes, over the rows of a [m, c]
+ * with valid[r] != 0 (all rows when NULL),
+ *     sums[0:3]  += sum |a - b'|, sum (a - b')^2, count          b' = b_log ? log(b + b_log_offset) : b          (fcl_masked_l1_mse_fwd)
+ *     da          = (w_l1 sign(a - b') + 2 w_mse (a - b')) / count                                                (fcl_l1_mse_grad)
+ * and, when b2 is given (the teacher's output for the same tensor: the output-KD and prosody-KD terms), the same against b2 with valid2 / w_*_2 /
+ * count2 into sums2, its gradient ADDED to da -- what a second, accumulating fcl_l1_mse_loss_grad launch did.  da is written (never accumulated
+ * into); da_planes (optional, c % 32 == 0): the gradient as P32 planes too.  `terms` is a HOST array (passed to the kernel by value). */
+#define FCL_LOSS_MAX_TERMS 12
+typedef struct {
+    const float* a;
+    const float* b;
+    const float* b2;         /* optional second target */
+    const uint8_t* valid;    /* [m] or NULL */
+    const uint8_t* valid2;   /* [m] or NULL (second target) */
+    float* da;               /* [m, c] */
+    uint16_t* da_planes;     /* optional */
+    double* sums;            /* [3] */
+    double* sums2;           /* [3], required with b2 */
+    int32_t m, c;
+    int32_t b_log;
+    float b_log_offset;
+    float w_l1, w_mse;
+    double count;
+    float w_l1_2, w_mse_2;
+    double count2;
+} fcl_loss_term_t;
+int fcl_loss_terms_batch(const fcl_loss_term_t* terms, int n_terms, fcl_stream_t stream);
+/* dst[r, :] = row_valid[r] ? srcs[0][r, :] + ... + srcs[n_src - 1][r, :] : 0 over dense [rows, cols] matrices (cols % 4 == 0); dst_p (optional, cols % 32
+ * == 0): the result as P32 planes; dst may be NULL then, and may alias a source.  `srcs` is a HOST array of n_src <= FCL_SUM_ROWS_MAX device pointers.
+ * Replaces the chains of fcl_add2d that assemble a gradient from its sources (pad_packed_sequence's zero rows: row_valid). */
+#define FCL_SUM_ROWS_MAX 6
+int fcl_sum_rows(const float* const* srcs, int n_src, const uint8_t* row_valid, float* dst, uint16_t* dst_p, int rows, int cols, fcl_stream_t stream);
+/* Train-mode BatchNorm backward, first pass, with the activation / dropout backward as its prologue: dz = (dy [+ dy2]) [* keep * keep_scale] * act'(y_act)
+ * is written, and dbeta[c] += sum_m dz, dgamma[c] += sum_m dz * (z - mean[c]) * invstd[c] (fp64 accumulation) -- fcl_act_bwd + fcl_colsum2_fwd(mode 3)
+ * in one pass; fcl_bn_bwd consumes dz and the two sums. */
+int fcl_bn_bwd_sums(const float* dy, const float* dy2, const float* y_act, const uint8_t* keep, float keep_scale, int act, const float* z, const float* mean,
+                    const float* invstd, float* dz, float* dgamma, float* dbeta, int m, int c, fcl_stream_t stream);
+/* fcl_act_bwd of dy + dy2 (a gradient that arrives from two consumers); dz may be NULL when only the planes are wanted. */
+int fcl_act_bwd_sum(const float* dy, const float* dy2, const float* y, const uint8_t* keep, float keep_scale, float* dz, uint16_t* dzp, int cols, size_t n, int act,
+                    fcl_stream_t stream);
+/* fcl_gather_rows_fwd of src + src2 + src3 (src2 / src3 optional; c % 4 == 0): dst[i, :] = sum_k src_k[idx[i], :], zero rows for idx[i] < 0. */
+int fcl_gather_rows_sum_fwd(const float* src, const float* src2, const float* src3, const int32_t* idx, float* dst, uint16_t* dst_p, int n, int c,
+                            fcl_stream_t stream);
+/* y = act(x . w^T [+ x2 . w2^T] + bias) [+ residual]: nn.Linear on fp32 operands with an optional second (x2 [M, k2], w2 [N, k2]) pair contracted into the
+ * same output and an optional residual [M, N] (row stride ldr) -- the input gradients that reach one tensor through two weights, and a gradient
+ * injected at the GEMM's output, without a separate addition pass. */
+int fcl_linear2_fwd(const float* x, int lda, const float* w, int ldw, int k, const float* x2, int lda2, const float* w2, int ldw2, int k2, const float* bias,
+                    const float* residual, int ldr, float* y, int ldy, int m, int n, int act, fcl_stream_t stream);
+
 /* Channel LayerNorm backward (+ the predictor's scalar head: ds = gradient of scalar[m]).  dgamma/dbeta/dlin_w/dlin_b accumulate. */
 int fcl_layernorm_bwd(const float* x, const float* gamma, const float* beta, float eps, const float* dy, const float* lin_w, const float* ds,
                       const uint8_t* pad_mask, const uint8_t* keep, float keep_scale, float* dx, float* dgamma, float* dbeta, float* dlin_w,
@@ -688,6 +738,15 @@ int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const
  * fcl_host_device_ptr) to `dst`, then increments *seq_dev, stores the new value to *seq_host (device view of a pinned word) and, when given,
  * adds 1 to *bump (the pass's RNG seed word).  Captured as the first node of a pass's hipGraph it replaces the hipMemcpyAsync in front of every
  * launch (~80 us of host time per pass); the host may repack the block once *seq_host equals the number of launches it has made. */
+/* ---- streams restricted to a share of the compute units (round 6) --------------------------------------------------------------------------------
+ * The KD update (tts_distill.py:143-182) runs the frozen teacher's forward one batch ahead on its own stream beside the student's update.  Both
+ * are chains of dependent launches; the teacher's LSTM-step workgroups (72 - 96 KB of LDS, ~30 us each) fill every CU, so each of the student's
+ * ~260 dependent launches first waits for one of them to retire (kernel trace: median 8.8 us between two launches of the student's stream, 0.1 us
+ * on the teacher's).  A stream created here only dispatches to `n_cus` compute units, spread evenly over the XCDs (the queue's CU mask is
+ * interleaved across XCCs by the driver: bit i -> XCD i % 8), which leaves the other CUs to the unrestricted streams.  n_cus <= 0 or >= the
+ * device's CU count: an ordinary non-blocking stream. */
+int fcl_stream_create_cus(int n_cus, fcl_stream_t* out);
+int fcl_stream_destroy(fcl_stream_t stream);
 void* fcl_host_device_ptr(void* pinned_host);
 int fcl_feed_copy(void* dst, const void* src, size_t bytes, uint32_t* seq_dev, uint32_t* seq_host, uint32_t* bump, fcl_stream_t stream);
 

@@ -142,7 +142,8 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
              ("fcl_lstm_step_t", _lib.LstmStep), ("fcl_decoder_train_t", _lib.DecoderTrain), ("fcl_decoder_bptt_t", _lib.DecoderBptt),
              ("fcl_bilstm_train_t", _lib.BilstmTrain), ("fcl_bilstm_bptt_t", _lib.BilstmBptt), ("fcl_derive_t", _lib.Derive),
              ("fcl_pwg_layer_t", _lib.PwgLayer), ("fcl_prof_entry_t", _lib.ProfEntry), ("fcl_row_maps_t", _lib.RowMaps),
-             ("fcl_te_config_t", _lib.TeConfig), ("fcl_te_batch_t", _lib.TeBatch), ("fcl_te_knowledge_t", _lib.TeKnowledge)]
+             ("fcl_te_config_t", _lib.TeConfig), ("fcl_te_batch_t", _lib.TeBatch), ("fcl_te_knowledge_t", _lib.TeKnowledge),
+             ("fcl_loss_term_t", _lib.LossTerm)]
     body = ['#include <stdio.h>', '#include <stddef.h>', '#include "fcl_hip.h"', "int main(void) {"]
     for cname, cls in pairs:
         last = cls._fields_[-1][0]
