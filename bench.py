@@ -548,6 +548,12 @@ def train_workload(args, rank, world, dev, dist):
         out["dp_schedule"] = dp_sched
     if launches_per_step is not None:
         out["profiled_gemm_launches_per_step"], out["host_enqueue_ms"] = launches_per_step, host_ms
+    # launches of one update as the native engines count them (fcl_te_last_launches: every kernel / memset / copy they enqueue; Adam + norm on top)
+    try:
+        n_l = eng.native.launches() + (teng.native.launches() if (kd and teng.native is not None) else 0)
+        out["launches_per_update"] = {"student_or_teacher_engine": eng.native.launches(), "frozen_teacher_forward": teng.native.launches() if kd else 0, "sum": n_l}
+    except AttributeError:
+        pass
     if cpu is not None:
         out["cpu_baseline"] = cpu
     return out

@@ -9,8 +9,9 @@
   step     fcl_taco2_amd.training.TrainEngine: forward/backward on the HIP path, `--accum-grad`, bucketed gradient all-reduce when launched
            under torch.distributed.run (one process per GPU, batches sharded round-robin), clip `--grad-clip`, NaN guard, Adam `--lr --eps`;
   outputs  `outdir/model.json` (`[idim, odim, vars(args)]`, tts.py:341-348), `outdir/snapshot.ep.N` ({"model", "optimizer", "epoch",
-           "iteration"}), `outdir/amp_checkpoint_ep{N}.pt` ({"model", "optimizer" (torch.optim.Adam layout), "amp": None}, tts.py:193-198 —
-           the file the reference's KD recipe loads its teacher from), `outdir/model.loss.best` (bare state_dict of the best validation
+           "iteration"}), `outdir/amp_checkpoint_ep{N}.pt` ({"model", "optimizer" (torch.optim.Adam layout), "amp": apex's
+           `amp.state_dict()` layout {"loss_scaler0": {"loss_scale", "unskipped"}}}, tts.py:193-198 — the file the reference's KD recipe
+           loads its teacher from and its `--amp-checkpoint` resume reads with `amp.load_state_dict`, tts.py:418-423), `outdir/model.loss.best` (bare state_dict of the best validation
            loss, ESPnet torch_save), `outdir/log` (JSON list of per-epoch means of every reported loss, main/ and validation/main/ prefixed).
 Not here: chainer extensions (plots, tensorboard), sortagrad, apex AMP, early stopping.
 """
@@ -148,11 +149,34 @@ def load_adam_state_dict(engine, sd):
     engine.weight_decay = float(g.get("weight_decay", 0.0))  # (torch.optim.Adam.load_state_dict restores the group's options too)
 
 
+def amp_state_dict(engine):
+    """The `amp` entry of an amp_checkpoint in the layout apex's `amp.state_dict()` writes and `amp.load_state_dict()` reads (tts.py:193-198, 418-423):
+    one entry per loss scaler, {"loss_scale": float, "unskipped": int}.  Arithmetic here is bf16 without loss scaling, so the scaler is
+    carried, not used: a state loaded from a reference checkpoint is written back unchanged, a fresh run writes apex's initial dynamic scaler
+    (2^16, 0 unskipped steps) so that the reference's O1 recipe can resume from the file."""
+    from collections import OrderedDict
+
+    st = getattr(engine, "amp_state", None)
+    if st:
+        return OrderedDict((k, dict(v)) for k, v in st.items())
+    return OrderedDict([("loss_scaler0", {"loss_scale": 65536.0, "unskipped": 0})])
+
+
+def load_amp_state_dict(engine, sd):
+    """Keep a checkpoint's `amp` entry (apex layout; None / missing in files written before round 6) on the engine for the next save."""
+    engine.amp_state = None
+    if isinstance(sd, dict):
+        keep = {k: {"loss_scale": float(v["loss_scale"]), "unskipped": int(v["unskipped"])} for k, v in sd.items()
+                if "loss_scaler" in k and isinstance(v, dict) and "loss_scale" in v and "unskipped" in v}
+        engine.amp_state = keep or None
+    return engine.amp_state
+
+
 def save_checkpoints(outdir, engine, epoch, iteration, valid_loss, best):
     model_sd = {k: v.detach().cpu().clone() for k, v in engine.model.state_dict().items()}
     opt = adam_state_dict(engine)
-    torch.save({"model": model_sd, "optimizer": opt, "epoch": epoch, "iteration": iteration}, os.path.join(outdir, "snapshot.ep.%d" % epoch))
-    torch.save({"model": model_sd, "optimizer": opt, "amp": None}, os.path.join(outdir, "amp_checkpoint_ep%d.pt" % epoch))
+    torch.save({"model": model_sd, "optimizer": opt, "epoch": epoch, "iteration": iteration, "amp": amp_state_dict(engine)}, os.path.join(outdir, "snapshot.ep.%d" % epoch))
+    torch.save({"model": model_sd, "optimizer": opt, "amp": amp_state_dict(engine)}, os.path.join(outdir, "amp_checkpoint_ep%d.pt" % epoch))
     if valid_loss is not None and valid_loss < best:
         torch.save(model_sd, os.path.join(outdir, "model.loss.best"))
         return valid_loss
@@ -169,6 +193,8 @@ def get_parser():
     p.add_argument("--teacher-conf", default=None, help="KD: the teacher's model.json")
     p.add_argument("--teacher-model", default=None, help="KD: the teacher's amp_checkpoint_*.pt / snapshot")
     p.add_argument("--resume", "-r", default=None, help="snapshot.ep.N to continue from")
+    p.add_argument("--amp-checkpoint", default=None, help="amp_checkpoint_*.pt to initialise model, optimizer and the carried amp scaler state from "
+                                                           "(teacher_parser.py:312-315, tts.py:418-423)")
     p.add_argument("--encoder-resume", default=None, type=str, help="state_dict file of the ENCODER alone, loaded in place of its initialisation "
                    "(tts_train.py:319-323; encoder_sa.py:117-120).  --pretrained-model (a model flag) loads the whole model")
     p.add_argument("--batch-size", "-b", default=32, type=int)
@@ -266,7 +292,13 @@ def train(argv=None):
         model.load_state_dict(load_state_dict(args.resume))
         if "optimizer" in snap:
             load_adam_state_dict(eng, snap["optimizer"])
+        load_amp_state_dict(eng, snap.get("amp"))
         epoch0, iteration = int(snap.get("epoch", 0)), int(snap.get("iteration", 0))
+    if getattr(args, "amp_checkpoint", None):  # tts.py:418-423: model, optimizer and amp state from the reference's own checkpoint layout
+        ck = torch.load(args.amp_checkpoint, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck["model"])
+        load_adam_state_dict(eng, ck["optimizer"])
+        load_amp_state_dict(eng, ck.get("amp"))
     conv = CustomConverter(getattr(args, "reduction_factor", 1), args.use_fe_condition, args.append_position)  # tts.py:361-364
     cache = {} if args.keep_all_data_on_mem else None
     log, best = [], float("inf")

@@ -64,6 +64,51 @@ STUDENT_FLAGS = ["--embed-dim", "16", "--eunits", "16", "--econv-chans", "16", "
                  "--duration-predictor-chans", "20", "--use-residual", "false", "--use-masking", "true"]
 
 
+class _FakeEngine(object):
+    """What train.save_checkpoints / load_* touch of a TrainEngine, on CPU tensors (the checkpoint LAYOUT is host logic)."""
+
+    def __init__(self):
+        self.model = torch.nn.Linear(3, 2)
+        n = sum(p.numel() for p in self.model.parameters())
+        self.mflat, self.vflat = torch.arange(n, dtype=torch.float32), torch.arange(n, dtype=torch.float32) * 2
+        self.step_count, self.lr, self.eps, self.betas, self.weight_decay = 4, 1e-3, 1e-6, (0.9, 0.999), 0.0
+
+    def param_offsets(self):
+        out, o = {}, 0
+        for k, p in self.model.named_parameters():
+            out[k] = (o, p.numel(), tuple(p.shape))
+            o += p.numel()
+        return out
+
+
+def test_amp_checkpoint_layout_round_trips_with_the_reference_recipe(tmp_path):
+    """the reference resumes with `model.load_state_dict(ck['model']); optimizer.load_state_dict(ck['optimizer']);
+    amp.load_state_dict(ck['amp'])` (tts.py:418-423) and writes `amp.state_dict()` (tts.py:193-198) = apex's {"loss_scalerN": {"loss_scale",
+    "unskipped"}}.  A checkpoint written here carries that layout; one read from it is preserved through save."""
+    eng = _FakeEngine()
+    TR.save_checkpoints(str(tmp_path), eng, 1, 7, None, float("inf"))
+    ck = torch.load(str(tmp_path / "amp_checkpoint_ep1.pt"), weights_only=False)
+    assert set(ck) == {"model", "optimizer", "amp"}
+    # exactly what apex's amp.load_state_dict iterates over: keys containing 'loss_scaler', each with 'loss_scale' and 'unskipped'
+    assert list(ck["amp"]) == ["loss_scaler0"] and set(ck["amp"]["loss_scaler0"]) == {"loss_scale", "unskipped"}
+    assert ck["amp"]["loss_scaler0"] == {"loss_scale": 65536.0, "unskipped": 0}  # apex's initial dynamic scaler
+    torch.optim.Adam(eng.model.parameters()).load_state_dict(ck["optimizer"])  # torch.optim.Adam accepts the optimizer entry
+    snap = torch.load(str(tmp_path / "snapshot.ep.1"), weights_only=False)
+    assert snap["iteration"] == 7 and snap["amp"] == ck["amp"]
+    # a reference-written scaler state (after some overflow-free steps) is kept through load -> save
+    ref_amp = {"loss_scaler0": {"loss_scale": 32768.0, "unskipped": 1234}}
+    torch.save({"model": ck["model"], "optimizer": ck["optimizer"], "amp": ref_amp}, str(tmp_path / "ref_amp.pt"))
+    eng2 = _FakeEngine()
+    got = torch.load(str(tmp_path / "ref_amp.pt"), weights_only=False)
+    TR.load_adam_state_dict(eng2, got["optimizer"])
+    assert TR.load_amp_state_dict(eng2, got["amp"]) == ref_amp
+    TR.save_checkpoints(str(tmp_path), eng2, 2, 9, None, float("inf"))
+    assert torch.load(str(tmp_path / "amp_checkpoint_ep2.pt"), weights_only=False)["amp"] == ref_amp
+    # files written before round 6 ("amp": None) and junk entries load as "no state"
+    assert TR.load_amp_state_dict(eng2, None) is None and TR.load_amp_state_dict(eng2, {"x": 1}) is None
+    assert TR.amp_state_dict(eng2)["loss_scaler0"]["loss_scale"] == 65536.0
+
+
 @pytest.mark.gpu
 def test_train_teacher_then_kd_student_then_decode(tmp_path):
     from fcl_taco2_amd import decode as D
