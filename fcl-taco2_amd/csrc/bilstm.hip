@@ -9,6 +9,9 @@
 //          runs on the first H threads; 2 barriers per step, no global traffic but Gx in / h out.
 //   algo 1 "steps": one fused LSTM-step GEMM launch (gemm_f32.hip) per time step and direction, rows =
 //          utterances, packed-sequence semantics via row_len.  Any H; also the cross-check of algo 2.
+#include <map>
+#include <mutex>
+
 #include "fcl_common.h"
 #include "row_maps.h"
 #include "lstm_epilogue.h"
@@ -119,8 +122,15 @@ __device__ __forceinline__ void ks_exclusive() {
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
+#ifdef FCL_KS_BPERMUTE  // (developer experiment, round 6: the same lane exchange through the LDS crossbar -- ds_bpermute_b32 -- instead of DPP; profiles/r6_dpp_hazard_ab.log)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int src = CTRL == 0x141 ? ((lane & ~7) | (7 - (lane & 7))) : CTRL == 0x4E ? (lane ^ 2) : CTRL == 0xB1 ? (lane ^ 1) : CTRL == 0x128 ? ((lane & ~15) | ((lane + 8) & 15))
+                    : ((lane & ~3) | (CTRL & 3));  // 0x00 / 0x55 / 0xAA / 0xFF: quad broadcast of lane CTRL & 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v)));
+#else
     asm volatile("s_nop 3" : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+#endif
 }
 
 // a lane's [8 x 16] weight block against its 16-value slice of the vector in LDS: 4 ds_read_b128 + 64 v_pk_fma_f32 (the vector element splat by op_sel)
@@ -769,6 +779,32 @@ static bool bilstm_ksplit_enabled() {
     return on != 0;
 }
 
+// Round 6: the lane-split kernels are correct beside foreign waves only while they own their SIMDs' register files -- ks_exclusive()
+// makes the code object ask for 256 VGPRs, which is a property of what the compiler emitted, not of this source.  Before the first launch of a kernel
+// the runtime is asked what the loaded code object really requests (hipFuncGetAttributes: numRegs, in the hardware's 8-register granules 249 .. 256 all
+// allocate 256); a kernel that does not claim the whole file is NOT launched -- its callers fall back to the row-per-thread kernels (`bilstm_persistent_kernel`,
+// `bilstm_group_kernel<256>`), which need no such guard -- and the reason is left in fcl_last_error().  tests/test_cabi_cpu.py asserts the same number in
+// the code object's metadata on the CPU.  FCL_KS_GUARD=0 (developer A/B with -DFCL_KS_NOT_EXCLUSIVE builds) switches the check off.
+template <typename K>
+static bool ks_claims_simd(K kernel, const char* name) {
+    static const int guard = tunable("KS_GUARD", 1);
+    if (!guard) return true;
+    static std::mutex mu;
+    static std::map<const void*, bool> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    const void* key = reinterpret_cast<const void*>(kernel);
+    auto it = seen.find(key);
+    if (it != seen.end()) return it->second;
+    hipFuncAttributes at;
+    const bool got = hipFuncGetAttributes(&at, key) == hipSuccess;
+    if (!got) (void)hipGetLastError();
+    const bool ok = got && at.numRegs >= 249;
+    if (!ok) set_error("bilstm: %s does not claim the SIMD's register file (numRegs %d, 256 expected): the lane-split kernels are off, the row-per-thread kernels run", name,
+                       got ? at.numRegs : -1);
+    seen[key] = ok;
+    return ok;
+}
+
 // 1 KB (error word, flags from +1 KB) | flags [2B] | exchange area: [groups][2][4][H] 8-byte words (value + step tag; the counter-protocol kernels use it as floats)
 size_t bilstm_group_workspace_bytes(int B, int H) { return 1024 + sizeof(unsigned int) * 2 * (size_t)B + 32 + sizeof(unsigned long long) * 2 * (size_t)B * 2 * 4 * H; }
 static char* group_exchange_base(void* ws, int B) {  // 16-byte aligned, behind the error word and the flags
@@ -780,7 +816,14 @@ static bool group_ok(int B, int H, void* ws, size_t ws_bytes, const unsigned int
     if (!enabled || H != 256 || !ws || ws_bytes < bilstm_group_workspace_bytes(B, H) || !status) return false;  // no status word, no spinning kernel
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    return 2 * B * 4 <= cus;  // every workgroup of the grid resident (one 512-thread workgroup per CU): groups never wait for unscheduled members
+    // The grid must FIT the device (one 512-thread workgroup per CU; the lane-split form claims the CU's whole register file, so each workgroup needs a CU of
+    // its own).  That does not make the group's members co-resident beside other streams' kernels: a member may wait for a CU a foreign workgroup holds, and
+    // the members already resident spin meanwhile.  Progress then rests on the foreign kernels finishing (they never wait for these), on in-order dispatch of
+    // this grid, and on the bounded spin: after 2^22 polls a workgroup gives up and raises FCL_STATUS_GROUP_TIMEOUT -- the optimizer skips that update ON THE
+    // DEVICE and the step's LossReport.resolve() raises FclError with the status text (training.py), so starvation is loud, never a silently wrong gradient.
+    // Two spinning group kernels on two streams (or two processes) of one device can starve each other; the engines issue one group kernel at a time per
+    // device (the KD update's other recurrence is the student's single-workgroup H = 128 kernel, which does not spin).
+    return 2 * B * 4 <= cus;
 }
 
 bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_f, const float* whh_r, const int* lens, float* out, int B, int T, int H,
@@ -788,7 +831,8 @@ bool launch_bilstm_group(const float* gx_f, const float* gx_r, const float* whh_
     if (!group_ok(B, H, ws, ws_bytes, status)) return false;
     unsigned int* flags = (unsigned int*)ws;
     static const int ll_on = tunable("BILSTM_GROUP_LL", 1);
-    const bool ll = ll_on && T < 65535;  // 16-bit step tags
+    const bool ll = ll_on && T < 65535 &&  // 16-bit step tags
+                    (sv ? ks_claims_simd(bilstm_group_ks_kernel<true>, "bilstm_group_ks_kernel<true>") : ks_claims_simd(bilstm_group_ks_kernel<false>, "bilstm_group_ks_kernel<false>"));
     char* xb = group_exchange_base(ws, B);
     if (hipMemsetAsync(flags, 0, (size_t)(xb - (char*)ws) + (ll ? sizeof(unsigned long long) * 2 * (size_t)B * 2 * H : 0), s) != hipSuccess) return false;
     GroupSync gs{flags + 256, status};
@@ -810,7 +854,7 @@ bool launch_bilstm_bptt_group(const BilstmBwd& a, const int* lens, int B, int T,
     if (!group_ok(B, H, ws, ws_bytes, status)) return false;
     unsigned int* flags = (unsigned int*)ws;
     static const int ll_on = tunable("BILSTM_GROUP_LL", 1);
-    const bool ll = ll_on && T < 65535;  // 16-bit step tags
+    const bool ll = ll_on && T < 65535 && ks_claims_simd(bilstm_bptt_group_ks_kernel, "bilstm_bptt_group_ks_kernel");  // 16-bit step tags
     char* xb = group_exchange_base(ws, B);
     if (hipMemsetAsync(flags, 0, (size_t)(xb - (char*)ws) + (ll ? sizeof(unsigned long long) * 2 * (size_t)B * 2 * 4 * H : 0), s) != hipSuccess) return false;
     GroupSync gs{flags + 256, status};
@@ -829,7 +873,7 @@ bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const 
                                     int H, const BilstmSave& sv, hipStream_t s) {
     dim3 grid(B, 2);
     if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return false;
-    if (H == 128 && bilstm_ksplit_enabled()) {
+    if (H == 128 && bilstm_ksplit_enabled() && ks_claims_simd(bilstm_ksplit_kernel<true, false>, "bilstm_ksplit_kernel<true, false>")) {
         ProfScope ps("bilstm_ksplit_kernel/train", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
         hipLaunchKernelGGL((bilstm_ksplit_kernel<true, false>), grid, dim3(512), 0, s, gx_f, gx_r, whh_f, whh_r, lens, out, T, sv, (unsigned short*)nullptr,
                            fcl_row_maps_t());
@@ -852,7 +896,7 @@ bool launch_bilstm_train_persistent(const float* gx_f, const float* gx_r, const 
 bool launch_bilstm_bptt_persistent(const BilstmBwd& a, const int* lens, int B, int T, int H, hipStream_t s) {
     dim3 grid(B, 2);
     if (H != 8 && H != 16 && H != 32 && H != 64 && H != 128) return false;
-    if (H == 128 && bilstm_ksplit_enabled()) {
+    if (H == 128 && bilstm_ksplit_enabled() && ks_claims_simd(bilstm_bptt_ksplit_kernel<0>, "bilstm_bptt_ksplit_kernel<0>")) {
         ProfScope ps("bilstm_bptt_ksplit_kernel", 2.0 * 2 * B * (double)T * 4 * H * H, (double)B * T, s);
         hipLaunchKernelGGL((bilstm_bptt_ksplit_kernel<0>), grid, dim3(512), 0, s, a, lens, T);
         return true;
@@ -944,8 +988,11 @@ int fcl_bilstm_fwd(const float* x, const int32_t* lens, const float* w_ih_f, con
     }
     if (algo == 0 || algo == 3) algo = can_persist ? 2 : 1;
     FCL_REQUIRE(algo == 1 || (algo == 2 && can_persist), FCL_ERR_INVALID, "bilstm_fwd: algo %d unavailable for H=%d", algo, h);
-    if (algo == 2 && h == 128 && bilstm_ksplit_enabled()) {
-        const bool fuse = row_maps && maps_fusable && fuse_on;
+    const bool fuse_wanted = row_maps && maps_fusable && fuse_on;
+    if (algo == 2 && h == 128 && bilstm_ksplit_enabled() &&
+        (fuse_wanted ? ks_claims_simd(bilstm_ksplit_kernel<false, true>, "bilstm_ksplit_kernel<false, true>")
+                     : ks_claims_simd(bilstm_ksplit_kernel<false, false>, "bilstm_ksplit_kernel<false, false>"))) {
+        const bool fuse = fuse_wanted;
         ProfScope ps(fuse ? "bilstm_ksplit_kernel+maps" : "bilstm_ksplit_kernel", 2.0 * 2 * b * (double)t * 4 * h * h, (double)b * t, s);
         if (fuse)
             hipLaunchKernelGGL((bilstm_ksplit_kernel<false, true>), dim3(b + 1, 2), dim3(512), 0, s, gx_f, gx_r, w_hh_f, w_hh_r, lens, out, t, BilstmSave(), out_p,

@@ -161,6 +161,7 @@ struct fcl_te {
     size_t evnext = 0;
     hipEvent_t pred_ev = nullptr, late_ev = nullptr;
     bool pred_pending = false, late_pending = false, dw_pending = false;
+    bool forms_new = false;  // a sizing run registered operand forms: the real pass starts by deriving them (forms_refresh)
     // arenas: work (two alternating for the frozen teacher: its knowledge outlives the call), zero
     Arena work[2], zero[2];
     int cur_arena = 0, n_arenas = 1;
@@ -238,13 +239,9 @@ int form_get(E_t& E, const std::string& key0, const float* src, const float* src
         *out = &it->second;
         return 0;
     }
-    if (E.dry) {  // registration allocates persistent memory and launches: the dry run only needs a placeholder
-        static Form dummy;
-        dummy.dst = reinterpret_cast<float*>((size_t)1 << 31);
-        dummy.dst_p = reinterpret_cast<uint16_t*>((size_t)1 << 31);
-        *out = &dummy;
-        return 0;
-    }
+    // Round 6: a form first asked for during the SIZING run of a pass is registered there -- its memory allocated, its descriptor queued for the batched
+    // fcl_derive_batch launch that opens the real pass (forms_refresh) -- instead of on the fly in the middle of the step (hipMalloc + a synchronous descriptor
+    // upload + a one-entry launch per form: a first step used to carry ~60 of those between its kernels, on whichever stream was current).
     Form f;
     f.src = src; f.src2 = src2; f.a = a; f.b = b; f.c = c; f.sa = sa; f.sb = sb; f.sc = sc;
     f.blocks = fcl_derive_blocks(a, b, c);
@@ -266,6 +263,14 @@ int form_get(E_t& E, const std::string& key0, const float* src, const float* src
             E.form_allocs.push_back(p);
             f.dst_p = static_cast<uint16_t*>(p);
         }
+    }
+    if (E.dry) {
+        E.forms[key] = f;
+        E.form_order.push_back(key);
+        E.table_stale = true;
+        E.forms_new = true;
+        *out = &E.forms[key];
+        return 0;
     }
     // computed on the spot by a one-entry table (synchronous upload: first use only); part of the batched table from the next refresh on
     fcl_derive_t d{};
@@ -994,7 +999,12 @@ static int te_losses(fcl_te& E, const fcl_te_knowledge_t* know) {
                                cf.share_proj ? "enc.convs_proj.0" : "enc.convs_proj.2"};
     const std::string lp[2] = {cf.share_proj ? "dec.lstm_proj" : "dec.lstm0_proj", cf.share_proj ? "dec.lstm_proj" : "dec.lstm1_proj"};
     auto pp = [&](int i) { return cf.share_proj ? std::string("dec.post_proj") : ("dec.post" + std::to_string(i) + "_proj"); };
-    if (student) {  // the KD terms whose gradients the backward needs LATE run on the weight-gradient stream beside the frame-level terms and the postnet's backward
+    // FCL_TE_R6: bit 0 = the late group is enqueued BEFORE the student's stream's own terms (it then runs beside them: -0.15 ms per KD update on one box, and
+    // OFF: in the FIRST update of a fresh engine the two mel terms' gradients then came out wrong in lanes 48 - 63 of single waves in ~10 % of the runs --
+    // the signature of the round-5 "DPP" finding in a kernel without DPP; DESIGN §4c, profiles/r6_lanes48_63_loss_kernel.log); bit 1 = the prosody embedding
+    // terms join the late group (their gradients are wanted at backward stage 2)
+    static const int r6 = tunable("TE_R6", 2);
+    auto late_group = [&]() -> int {  // the KD terms whose gradients the backward needs LATE run on the weight-gradient stream beside the frame-level terms and the postnet's backward
         const bool fork = cf.pred_stream && c.save && cf.late_losses;
         hipStream_t saved = E.cur;
         if (fork) {
@@ -1027,7 +1037,7 @@ static int te_losses(fcl_te& E, const fcl_te_knowledge_t* know) {
             }
             TE_TRY(te_kd_fwd(E, lb, pend, "enc4", "hs", c.hs, BT, "enc.blstm_proj", cf.t_eunits, C, know->enc[4], b.enc_valid, ne));
         }
-        if (cf.distill_prosody) {  // the embedding taps' gradients are wanted at backward stage 2: late as well
+        if (cf.distill_prosody && (r6 & 2)) {  // the embedding taps' gradients are wanted at backward stage 2: late as well
             TE_TRY(te_kd_fwd(E, lb, pend, "pro3", "p_embs", c.p_embs, BT, "pemb_proj", cf.t_eunits, C, know->pro[3], b.enc_valid, ne));
             TE_TRY(te_kd_fwd(E, lb, pend, "pro4", "e_embs", c.e_embs, BT, "eemb_proj", cf.t_eunits, C, know->pro[4], b.enc_valid, ne));
         }
@@ -1038,10 +1048,16 @@ static int te_losses(fcl_te& E, const fcl_te_knowledge_t* know) {
             E.late_pending = true;
             E.cur = saved;
         }
-    }
+        return 0;
+    };
+    if (student && (r6 & 1)) TE_TRY(late_group());
     // the student's stream: the postnet taps' projections, ONE loss launch (their terms + every element-wise term), their backward halves
     LossBatchBuilder lb(E);
     std::vector<KdTerm> pend;
+    if (student && cf.distill_prosody && !(r6 & 2)) {
+        TE_TRY(te_kd_fwd(E, lb, pend, "pro3", "p_embs", c.p_embs, BT, "pemb_proj", cf.t_eunits, C, know->pro[3], b.enc_valid, ne));
+        TE_TRY(te_kd_fwd(E, lb, pend, "pro4", "e_embs", c.e_embs, BT, "eemb_proj", cf.t_eunits, C, know->pro[4], b.enc_valid, ne));
+    }
     if (student && cf.distill_decoder)
         for (int i = 0; i < 4; ++i) {
             char nm[8];
@@ -1071,6 +1087,7 @@ static int te_losses(fcl_te& E, const fcl_te_knowledge_t* know) {
     }
     TE_TRY(lb.flush());
     for (int i = (int)pend.size() - 1; i >= 0; --i) TE_TRY(te_kd_bwd(E, pend[i]));  // the postnet's backward consumes post3 first
+    if (student && !(r6 & 1)) TE_TRY(late_group());
     return 0;
 }
 
@@ -1188,10 +1205,7 @@ static int te_backward_stage1(fcl_te& E) {  // decoder BPTT + prenet
     TE_TRY(w_t(E, w0hh, E.Pm(w0hh).p, 4 * U, U, U, true, true, &w0_hh_t, &w0_hh_t_p));
     const float* cat_f = nullptr;
     const uint16_t* cat_p = nullptr;
-    if (E.dry) {
-        cat_f = reinterpret_cast<const float*>((size_t)1 << 31);
-        cat_p = reinterpret_cast<const uint16_t*>((size_t)1 << 31);
-    } else {
+    {
         if (!E.cat_f) {  // one [2U, 4U] buffer (fp32 and planes), filled by two forms: rows [0, U) = W1_hh^T, rows [U, 2U) = W1_ih^T
             void *pf = nullptr, *pp_ = nullptr;
             FCL_HIP(hipMalloc(&pf, (size_t)2 * U * 4 * U * 4 + 256));
@@ -1644,7 +1658,8 @@ static int te_run_sized(fcl_te& E, int variant, Body body) {
         E.dry = false;
         W.dry = Z.dry = false;
         E.launches = l0;
-        E.pred_pending = pp; E.late_pending = lp; E.dw_pending = dp; E.params_dirty = pd;
+        E.pred_pending = pp; E.late_pending = lp; E.dw_pending = dp; E.params_dirty = pd || E.forms_new;
+        E.forms_new = false;
         if (rc) return rc;
         const size_t need_w = W.used + 4096, need_z = Z.used + 4096;
         if (need_w > W.cap || need_z > Z.cap) {

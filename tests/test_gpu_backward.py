@@ -298,12 +298,13 @@ def test_bilstm_group_kernel_more_workgroups_than_cus(ops):
 
 
 def test_bilstm_group_kernel_beside_another_streams_work(ops):
-    """Round 5: the lane-split BiLSTM kernels reduce with DPP.  hipcc fills the two wait states a DPP read needs after the VALU write of its source with
-    whatever instructions are at hand (two v_pk_fma_f32 of the contraction); on gfx950 that is too short when the wave's sibling on the SIMD is stalled:
-    with the device to itself the waves run in lock step and nothing shows, beside another stream's kernels (workgroups of a group out of step) lanes
-    48 - 63 of a partial sum were read before they were written -- 1e-2 errors in 299 of 300 launches (`tools/stress_bilstm_concurrent.py`; fixed by an
-    explicit s_nop tied to the DPP source, `dpp_f` in csrc/bilstm.hip).  Every launch of the H = 256 forward and reverse pass beside a stream of H = 128
-    recurrences, in both orders of submission, must equal the serial result bit for bit, and the status word stays clear."""
+    """Round 5: the lane-split BiLSTM kernels reduce with DPP.  With the device to itself they are exact; beside another stream's kernels lanes 48 - 63 of a
+    partial sum were read before they were written -- 1e-2 errors in 299 of 300 launches (`tools/stress_bilstm_concurrent.py`).  The root cause is NOT
+    established: explicit wait states tied to the DPP sources did not remove it (csrc/bilstm.hip, HISTORY "round 5").  What removes it is keeping foreign waves
+    off the SIMD: `ks_exclusive()` makes the code object claim the whole register file (256 VGPRs); round 6 verifies that claim at run time
+    (`ks_claims_simd`: hipFuncGetAttributes before the first launch, fall-back to the row-per-thread kernels otherwise) and in the code object's metadata
+    (tests/test_cabi_cpu.py).  Every launch of the H = 256 forward and reverse pass beside a stream of H = 128 recurrences, in both orders of submission, must
+    equal the serial result bit for bit, and the status word stays clear; then the same for the H = 128 TRAINING pair (forward + BPTT) beside H = 256 work."""
     g = torch.Generator().manual_seed(3)
 
     def case(B, T, C, H):
@@ -352,6 +353,38 @@ def test_bilstm_group_kernel_beside_another_streams_work(ops):
         assert torch.equal(o1, ref_f), (it, float((o1 - ref_f).abs().max()))
         assert all(torch.equal(a, b) for a, b in zip(dg, ref_b)), it
         assert all(torch.equal(o, ref_s) for o in outs), it
+    assert int(st.item()) == 0
+    # round 6: the H = 128 training kernels (bilstm_ksplit_kernel<true> / bilstm_bptt_ksplit_kernel) beside a foreign stream of H = 256 recurrences
+    Bs, Ts, Hs = small["B"], small["T"], 128
+    gxs = [torch.randn(Bs * Ts, 4 * Hs, generator=g).to(DEV) for _ in range(2)]
+    svs = [[torch.zeros(Ts * Bs, 4 * Hs, device=DEV)] + [torch.zeros(Ts * Bs, Hs, device=DEV) for _ in range(3)] for _ in range(2)]
+    d_out_s = torch.randn(Bs * Ts, 2 * Hs, generator=g).to(DEV)
+    wts = [small["w"][1].t().contiguous(), small["w"][3].t().contiguous()]
+
+    def train_small():
+        o = torch.empty(Bs * Ts, 2 * Hs, device=DEV)
+        ops.bilstm_train_fwd(gxs, (small["w"][1], small["w"][3]), small["ld"], Bs, Ts, o, svs, status=st)
+        dgs = [torch.empty(Ts * Bs, 4 * Hs, device=DEV) for _ in range(2)]
+        ops.bilstm_bptt(svs, small["ld"], Bs, Ts, d_out_s, wts, dgs, status=st)
+        return [o] + dgs
+
+    ref_t = [t.clone() for t in train_small()]
+    torch.cuda.synchronize()
+    for it in range(40):
+        first, second = (s1, s2) if it % 2 else (s2, s1)
+        with torch.cuda.stream(first):
+            got = [train_small() for _ in range(3)] if it % 2 else None
+            if not it % 2:
+                o1 = fwd(big)
+        with torch.cuda.stream(second):
+            if it % 2:
+                o1 = fwd(big)
+            else:
+                got = [train_small() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert torch.equal(o1, ref_f), it
+        # (the three repetitions overwrite the same saved tensors with the same values; each result list is compared)
+        assert all(torch.equal(a, b) for res in got for a, b in zip(res, ref_t)), it
     assert int(st.item()) == 0
 
 

@@ -58,4 +58,4 @@ for it in range(int(os.environ.get('STRESS_ITERS', '300'))):
         bad += 1
         if bad < 10:
             print("iteration %d: group kernel max diff %.3e, H=128 kernel max diff %.3e, status %d" % (it, e1, e2, int(st.item())))
-print("mismatching iterations: %d of 300; status word %d" % (bad, int(st.item())))
+print("mismatching iterations: %d of %s; status word %d" % (bad, os.environ.get("STRESS_ITERS", "300"), int(st.item())))
