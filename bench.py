@@ -63,6 +63,18 @@ RANKS = []  # sharding.verify_world's per-rank records (filled in main() once th
 def emit(obj):
     if RANKS:
         obj = dict(obj, ranks=list(RANKS))
+    # key order of the ONE line: every scalar first (a reader that keeps only the head of the line sees the numbers), then roofline and
+    # cpu_baseline, then the long tables; the same scalars once more as the LAST key (a reader that keeps only the tail sees them too)
+    scal = {k: v for k, v in obj.items() if not isinstance(v, (dict, list))}
+    first = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]
+    ordered = {k: obj[k] for k in first if k in obj}
+    ordered.update({k: v for k, v in scal.items() if k not in ordered})
+    for k in ("roofline", "cpu_baseline", "config"):
+        if k in obj:
+            ordered[k] = obj[k]
+    ordered.update({k: v for k, v in obj.items() if k not in ordered})
+    ordered["scalars"] = {k: v for k, v in scal.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}
+    obj = ordered
     line = (json.dumps(obj) + "\n").encode()
     sys.stdout.flush()
     if _REAL_STDOUT is None:
@@ -203,6 +215,56 @@ def pmc_traffic(kernel, workload=""):
     if len(vals) != 2:
         return None, None
     return (2.0 * vals["fetch"][0] + vals["write"][0]) * 1024.0, "%s + %s" % (vals["fetch"][1], vals["write"][1])
+
+
+# ---- the BINDING resource of the tiled GEMM / Conv1d / LSTM-step loops (round 6) ---------------------------------------------------
+# These loops are bound by what a compute unit can pull through its vector-memory path into LDS, not by the matrix pipe: tools/stream_probe.hip
+# (profiles/r4_stream_probe.log) measured 35 B/clk per CU = 21.8 TB/s over the chip for LDS-DMA streaming out of L2 with nothing else going on.
+# The library reports the bytes every launch moves that way (fcl_prof_entry_t.fill_bytes: workgroups x k-chunks x (A lines + W lines) x 128 B).
+CU_FILL_CEILING_B_PER_CLK = 35.5  # tools/stream_probe.hip: 21.8 TB/s / 256 CUs / 2.4 GHz
+N_CUS, CLOCK_HZ = 256, 2.4e9     # MI355X_MICROARCH.md (max clock: a kernel that runs below it shows a LOWER delivered rate, never a higher one)
+
+
+def pmc_lds_active(kernel, workload=""):
+    """(SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES of `kernel`, source file) from the newest committed profiles/rN_pmc[_workload]_sq_counters.csv holding it."""
+    import csv
+    import glob
+    import re
+
+    want = "pmc_%s_sq_counters.csv" % workload if workload else "pmc_sq_counters.csv"
+    rnd = lambda p_: int((re.match(r"r(\d+)_", os.path.basename(p_)) or [0, 0])[1])
+    base = lambda n: n.split("(")[0].replace(" ", "").replace("fcl::", "").replace("void", "").split("/")[0]
+    want_b, want_t = (base(kernel).split("<") + [""])[:2]
+    for path in sorted([p_ for p_ in glob.glob(os.path.join(ROOT, "profiles", "*" + want)) if os.path.basename(p_).split("_", 1)[-1] == want], key=rnd, reverse=True):
+        with open(path) as f:
+            rows = list(csv.DictReader(f))
+        hits = []
+        for r in rows:
+            b_, t_ = (base(r["kernel"]).split("<") + [""])[:2]
+            xa, xb = want_t.rstrip(">").split(","), t_.rstrip(">").split(",")
+            if b_ == want_b and (not want_t or xa == xb[: len(xa)]):
+                hits.append(r)
+        if hits:
+            busy = sum(float(r["mean_SQ_BUSY_CYCLES"]) * float(r["launches"]) for r in hits)
+            lds = sum(float(r["mean_SQ_LDS_IDX_ACTIVE"]) * float(r["launches"]) for r in hits)
+            if busy > 0:
+                return lds / busy, os.path.basename(path)
+    return None, None
+
+
+def binding_record(name, ms, fill_bytes, workload=""):
+    """What the loop of a GEMM-class kernel is bound by: bytes delivered into LDS per clock and CU over the launch's whole duration (prologue and epilogue
+    included: a lower bound of the main loop's rate) against the measured per-CU ceiling, and the fraction of busy cycles the LDS array was active."""
+    if not fill_bytes or ms <= 0:
+        return None
+    rate = fill_bytes / (ms * 1e-3) / N_CUS / CLOCK_HZ
+    lds, src = pmc_lds_active(name, workload)
+    return {"resource": "per-CU global->LDS delivery (LDS-DMA)", "achieved_B_per_clk_per_cu": rate, "ceiling_B_per_clk_per_cu": CU_FILL_CEILING_B_PER_CLK,
+            "frac": rate / CU_FILL_CEILING_B_PER_CLK, "fill_bytes_per_launch_sum": fill_bytes, "chip_TB_per_s": fill_bytes / (ms * 1e-3) / 1e12,
+            "lds_active_frac": lds, "lds_active_source": src,
+            "note": "fill bytes = workgroups x 32-k chunks x (A + W lines) x 128 B as launched (fcl_prof_entry_t.fill_bytes) / HIP-event duration of the whole launch / "
+                    "256 CUs / 2.4 GHz; ceiling = tools/stream_probe.hip (21.8 TB/s chip-wide, profiles/r4_stream_probe.log); lds_active_frac = "
+                    "SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES from the committed PMC pass"}
 
 
 def e2e_workload(args, rank, world, dev, dist):
@@ -437,8 +499,8 @@ def train_workload(args, rank, world, dev, dist):
         _lib.prof_enable(False)
         fam = {}
         for k, v in prof.items():
-            f = fam.setdefault(k.split("<")[0].split("/")[0], {"ms": 0.0, "launches": 0, "flops": 0.0, "members": []})
-            f["ms"] += v["ms"]; f["launches"] += v["launches"]; f["flops"] += v["flops"]; f["members"].append(k)
+            f = fam.setdefault(k.split("<")[0].split("/")[0], {"ms": 0.0, "launches": 0, "flops": 0.0, "fill_bytes": 0.0, "members": []})
+            f["ms"] += v["ms"]; f["launches"] += v["launches"]; f["flops"] += v["flops"]; f["fill_bytes"] += v.get("fill_bytes", 0.0); f["members"].append(k)
         gemm_fams = {k: v for k, v in fam.items() if v["flops"] > 0}
         if gemm_fams:
             dname = max(gemm_fams, key=lambda k: gemm_fams[k]["ms"])
@@ -451,6 +513,16 @@ def train_workload(args, rank, world, dev, dist):
                         "share_of_profiled_kernel_time": d["ms"] / (sum(v["ms"] for v in fam.values()) or 1.0), "peak_is": peak_note,
                         "note": "achieved = algorithmic fp32-equivalent FLOPs (2*M*N*K) of this kernel family's launches in one update / their "
                                 "HIP-event durations; only the library's GEMM-class launches carry profile scopes"}
+            dom_roof["binding"] = binding_record(dname, d["ms"], d["fill_bytes"], args.workload)
+            dom_roof["kernels"] = {}
+            for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"]):
+                if v["flops"] <= 0:
+                    continue
+                e = {"ms_per_step": v["ms"], "launches_per_step": v["launches"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "mfma_frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak}
+                b_ = binding_record(k, v["ms"], v["fill_bytes"], args.workload)
+                if b_:
+                    e["binding"] = {kk: b_[kk] for kk in ("achieved_B_per_clk_per_cu", "frac", "lds_active_frac")}
+                dom_roof["kernels"][k] = e
         launches_per_step = int(sum(v["launches"] for v in prof.values()))
     # ---- the same update on the schedule a rank of an N-GPU job runs (VERDICT r3 #5c): a ONE-rank RCCL group, every bucket's
     # all_reduce(AVG, async_op=True) issued from the weight-gradient stream while backward continues, waited for in optimizer_step()
@@ -469,10 +541,11 @@ def train_workload(args, rank, world, dev, dist):
             sk.close()
             dist1.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
             eng.buckets = GradBuckets(eng.gflat, eng.buckets.bounds, None, force=True)
-            for _ in range(max(2, warmup)):
+            for _ in range(max(2, warmup, GradBuckets.TRIAL_WARMUP + 2 * GradBuckets.TRIAL_UPDATES + 1)):  # (the placement trial completes before the clock starts)
                 step()
             dts_dp = timed_regions(region, lambda: torch.cuda.synchronize(), max(3, args.regions // 2))
             dp_sched = {"ms_per_step": 1e3 * median(dts_dp) / steps, "collectives_issued": eng.buckets.collectives, "inline": eng.buckets.inline,
+                        "policy": eng.buckets.schedule(),
                         "note": "one-rank RCCL process group, FCL_DP_FORCE_COLLECTIVE schedule: 4 bucketed all_reduce(AVG, async) per update issued from the "
                                 "weight-gradient stream (identity result); what a rank of an N-GPU job enqueues, minus the wire time"}
             eng.buckets = GradBuckets(eng.gflat, eng.buckets.bounds, None, force=False)
@@ -890,16 +963,18 @@ def main():
         for k in passes[0]:
             ms = sorted(p_[k]["ms"] for p_ in passes if k in p_)
             ref = passes[0][k]
-            prof[k] = {"ms": 3.0 * ms[len(ms) // 2], "launches": 3 * ref["launches"], "flops": 3.0 * ref["flops"], "rows": 3.0 * ref["rows"]}
+            prof[k] = {"ms": 3.0 * ms[len(ms) // 2], "launches": 3 * ref["launches"], "flops": 3.0 * ref["flops"], "rows": 3.0 * ref["rows"],
+                       "fill_bytes": 3.0 * ref.get("fill_bytes", 0.0)}
         tot_ms = sum(v["ms"] for v in prof.values()) or 1.0
         # the dominant kernel is chosen per kernel FAMILY (template name): the tile-configuration instantiations of one kernel (picked per launch
         # from M, N) are the same code on the same roofline, and splitting them would let a latency-bound helper win by default
         fam = {}
         for k, v in prof.items():
-            f = fam.setdefault(k.split("<")[0].split("/")[0], {"ms": 0.0, "launches": 0, "flops": 0.0, "members": []})
+            f = fam.setdefault(k.split("<")[0].split("/")[0], {"ms": 0.0, "launches": 0, "flops": 0.0, "fill_bytes": 0.0, "members": []})
             f["ms"] += v["ms"]
             f["launches"] += v["launches"]
             f["flops"] += v["flops"]
+            f["fill_bytes"] += v.get("fill_bytes", 0.0)
             f["members"].append(k)
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
@@ -917,8 +992,18 @@ def main():
                     "rows) / HIP-event duration on the launch stream; peak = the ceiling of the pipe the kernel issues on (frac <= 1 by construction); "
                     "achieved_vs_fp32_matrix_peak (157.3 TFLOP/s, the pipe an exact-fp32 build would use) is informational only",
         }
-        out["kernels"] = {k: {"ms_per_step": v["ms"] / 3.0, "launches_per_step": v["launches"] / 3.0,
-                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0} for k, v in sorted(prof.items())}
+        pmc_wl = "fp32" if os.environ.get("FCL_PRECISION", "1") == "0" else ""
+        out["roofline"]["binding"] = binding_record(dom, d["ms"], d["fill_bytes"], pmc_wl)
+        out["roofline"]["bound_note"] = ("`bound` names the pipe `achieved` / `peak` are quoted on (the contract's field); what LIMITS the loop is `binding`: the per-CU "
+                                         "global->LDS delivery rate -- a 64 x 128 tile pulls 24 KB per 32-k chunk for 384 MFMA cycles per SIMD")
+        out["kernels"] = {}
+        for k, v in sorted(prof.items()):
+            e = {"ms_per_step": v["ms"] / 3.0, "launches_per_step": v["launches"] / 3.0, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0}
+            if v.get("fill_bytes"):
+                e["mfma_frac"] = e["tflops"] / peak
+                b_ = binding_record(k, v["ms"], v["fill_bytes"], pmc_wl)
+                e["binding"] = {kk: b_[kk] for kk in ("achieved_B_per_clk_per_cu", "frac", "lds_active_frac")}
+            out["kernels"][k] = e
 
         # ---- CPU baseline: the oracle ("port" of the reference's per-utterance inference) on the host cores
         if not args.no_cpu_baseline:

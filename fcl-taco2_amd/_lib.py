@@ -86,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 418  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 419  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -112,7 +112,7 @@ LOSS_MAX_TERMS, SUM_ROWS_MAX = 12, 6
 
 
 class ProfEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double)]
+    _fields_ = [("name", C.c_char * 56), ("launches", _I), ("ms", C.c_double), ("flops", C.c_double), ("rows", C.c_double), ("fill_bytes", C.c_double)]
 
 
 TE_MAX_SITES, TE_MAX_LOSSES = 48, 48
@@ -299,7 +299,7 @@ def prof_collect():
     n = load().fcl_prof_collect(buf, 256)
     if n < 0:
         check(n)
-    return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops, rows=buf[i].rows) for i in range(n)}
+    return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops, rows=buf[i].rows, fill_bytes=buf[i].fill_bytes) for i in range(n)}
 
 
 def check(rc):

@@ -58,14 +58,15 @@ int ensure_dyn_lds(const void* func, int bytes) {
 
 // ---- profiling records ------------------------------------------------------------------------------
 bool g_prof_on = false;
-struct ProfRec { char name[56]; double flops, rows; hipEvent_t a, b; };
+struct ProfRec { char name[56]; double flops, rows, fill; hipEvent_t a, b; };
 static std::vector<ProfRec> g_prof;
 
-void prof_begin(const char* name, double flops, double rows, hipStream_t s) {
+void prof_begin(const char* name, double flops, double rows, hipStream_t s, double fill_bytes) {
     ProfRec r{};
     strncpy(r.name, name, sizeof(r.name) - 1);
     r.flops = flops;
     r.rows = rows;
+    r.fill = fill_bytes;
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, s);
@@ -329,6 +330,7 @@ int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries) {
         out[i].ms += ms;
         out[i].flops += r.flops;
         out[i].rows += r.rows;
+        out[i].fill_bytes += r.fill;
     }
     return n;
 }

@@ -87,13 +87,13 @@ typedef fcl_lstm_step_t LstmStepArgs;
 
 // ---- profiling hook (capi.hip) ----------------------------------------------------------------------
 extern bool g_prof_on;
-void prof_begin(const char* name, double flops, double rows, hipStream_t s);
+void prof_begin(const char* name, double flops, double rows, hipStream_t s, double fill_bytes = 0.0);
 void prof_end(hipStream_t s);
 struct ProfScope {
     hipStream_t s;
     bool on;
-    ProfScope(const char* name, double flops, double rows, hipStream_t st) : s(st), on(g_prof_on) {
-        if (on) prof_begin(name, flops, rows, s);
+    ProfScope(const char* name, double flops, double rows, hipStream_t st, double fill_bytes = 0.0) : s(st), on(g_prof_on) {
+        if (on) prof_begin(name, flops, rows, s, fill_bytes);
     }
     ~ProfScope() {
         if (on) prof_end(s);

@@ -667,7 +667,13 @@ static int launch_pgemm_lw(const GemmArgs& a, hipStream_t s, double flops) {
         const size_t l = strlen(full);
         snprintf(full + l, sizeof(full) - l, " %dx%dx%lld", a.M, a.N, ks);
     }
-    ProfScope ps(full, flops, a.M, s);
+    double fill = 0.0;  // LDS-DMA bytes of the launch: every tile streams (BM + BN) 128-byte lines per 32-k chunk of every term
+    {
+        long long nch = 0;
+        for (int i = 0; i < a.nterms; ++i) nch += (a.term[i].K + 31) >> 5;
+        fill = (double)grid.x * grid.y * (double)nch * (G::BM + G::BN) * 128.0;
+    }
+    ProfScope ps(full, flops, a.M, s, fill);
     if (a.accumulate && a.nterms == 1) {  // weight gradient: few output tiles, long contraction -> slices of the contraction over gridDim.z, ~512 workgroups
         GemmArgs b = a;
         const int total = (a.term[0].K + 31) >> 5, tiles = (int)(grid.x * grid.y);
@@ -910,7 +916,9 @@ static int launch_pconv_nl(const GemmArgs& a, hipStream_t s, double flops) {
     dim3 grid((ncols + G::BN - 1) / G::BN, (a.M + G::BM - 1) / G::BM, groups);
     char full[48];
     snprintf(full, sizeof(full), "pconv_kernel<%d,%d,%d,%d,%d>%s%s", WM, WN, TM, TN, NL, NSTW == 2 ? "/2st" : "", t_exact_lines ? "/f32" : hi ? "/bf16" : "");
-    ProfScope ps(full, flops, a.M, s);
+    // LDS-DMA bytes: per 32-channel chunk of the input a tile streams its row window once (BM + halo rows) and one BN-row weight slab per tap
+    const double fill = (double)grid.x * grid.y * grid.z * (double)((a.term[0].K + 31) >> 5) * ((double)G::AROWS + (double)a.conv_k * G::BN) * 128.0;
+    ProfScope ps(full, flops, a.M, s, fill);
     static const int dbg = tunable("PGEMM_DBG", 0);
     GemmArgs b = a;
     b.dbg_phase = dbg;
@@ -991,7 +999,13 @@ static int launch_plstm_lw(const LstmStepArgs& a, hipStream_t s, double flops) {
                                : reinterpret_cast<const void*>(plstm_kernel<WM, WN, TM, NST, -1, LW, HI>);
     const int rc = ensure_dyn_lds(fn, G::LDS_BYTES);
     if (rc) return rc;
-    ProfScope ps(full, flops, a.M, s);
+    double fill = 0.0;
+    {
+        long long nch = 0;
+        for (int i = 0; i < a.nterms; ++i) nch += (a.term[i].K + 31) >> 5;
+        fill = (double)grid.x * grid.y * (double)nch * (G::BM + G::BN) * 128.0;
+    }
+    ProfScope ps(full, flops, a.M, s, fill);
     if (mode == 0) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 0, LW, HI>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     else if (mode == 1) hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, 1, LW, HI>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
     else hipLaunchKernelGGL((plstm_kernel<WM, WN, TM, NST, -1, LW, HI>), grid, dim3(G::THREADS), G::LDS_BYTES, s, a);
@@ -1057,7 +1071,13 @@ static int launch_plstm_pair_cfg(const LstmStepArgs& a0, const LstmStepArgs& a1,
     dim3 grid((a0.U + 16 * WN - 1) / (16 * WN), (mmax + G::BM - 1) / G::BM, 2);
     char full[64];
     snprintf(full, sizeof(full), "plstm_pair_kernel<%d,%d,%d,%d,%d>%s", WM, WN, TM, NST, LW, HI ? "/bf16" : "");
-    ProfScope ps(full, flops, a0.M + a1.M, s);
+    double fill = 0.0;
+    for (const LstmStepArgs* a : {&a0, &a1}) {
+        long long nch = 0;
+        for (int i = 0; i < a->nterms; ++i) nch += (a->term[i].K + 31) >> 5;
+        fill += (double)grid.x * (double)((a->M + G::BM - 1) / G::BM) * (double)nch * (G::BM + G::BN) * 128.0;
+    }
+    ProfScope ps(full, flops, a0.M + a1.M, s, fill);
     hipLaunchKernelGGL(k, grid, dim3(G::THREADS), G::LDS_BYTES, s, a0, a1);
     return check_hip(hipGetLastError(), "plstm pair launch");
 }

@@ -91,9 +91,89 @@ class GradBuckets(object):
         # update -- a ring all-reduce of b bytes moves ~2 b per rank over xGMI links of ~100 GB/s achievable: <= 64 MB is <= ~1.3 ms on the
         # weight-gradient stream (4.8 ms busy of a 9.6 ms KD update; the four buckets of FCL-taco2-S are 6.5 MB each, of FCL-taco2-T 29 MB) --,
         # async (overlapped on the backend's stream, at the price of that fifth queue) for anything larger.  Unmeasured on a multi-GPU node.
+        # Round 6: "auto" DECIDES BY MEASUREMENT on the job it runs in.  No 8-GPU node has been available to tune the placement on, and on one
+        # GPU the wire is free, so the first updates of a job with a real group time both forms -- after `TRIAL_WARMUP` updates the placement alternates
+        # for 2 x `TRIAL_UPDATES` updates, each update's wall time (finish() to finish(), device events) is booked to the form it ran under, the medians
+        # are MAX-reduced over the ranks (one 2-float collective, once: every rank takes the same decision) and the faster form is kept; the choice,
+        # both medians and the per-bucket wire times of the stream-ordered form are in `schedule()` (bench.py prints them as `dp_schedule`).
         env = os.environ.get("FCL_DP_INLINE", "auto")
         self.inline = env not in ("", "0")
         self.inline_max_bytes = (64 << 20) if env == "auto" else (1 << 62)
+        self.auto = env == "auto" and self.active and not self.stage_host  # (gloo on host tensors / FCL_DP_GLOO_DIRECT runs the same trial: the CPU tests)
+        self.forms_used = []                   # the placement of every update so far (tests read it)
+        self.updates = 0                       # finish() calls that reduced
+        self.trial = {"inline": [], "async": []}
+        self.decision = None if self.auto else ("inline" if self.inline else "async")
+        self.decided_at = None
+        self._prev_mark = None                 # device event / host time of the previous finish()
+        self._wire = {}                        # bucket -> [(start event, end event)] of its stream-ordered collectives during the trial
+        self.wire_ms = {}
+
+    TRIAL_WARMUP, TRIAL_UPDATES = 2, 3
+
+    def _form_now(self):
+        """The placement of the CURRENT update: the decision once taken, else the trial's alternation (even update inline, odd async)."""
+        if self.decision is not None or not self.auto:
+            return self.decision or ("inline" if self.inline else "async")
+        if self.updates < self.TRIAL_WARMUP:
+            return "inline"
+        return "inline" if (self.updates - self.TRIAL_WARMUP) % 2 == 0 else "async"
+
+    def _mark(self):
+        if self.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        import time as _time
+
+        return _time.perf_counter()
+
+    @staticmethod
+    def _elapsed_ms(a, b):
+        if isinstance(a, float):
+            return 1e3 * (b - a)
+        b.synchronize()
+        return a.elapsed_time(b)
+
+    def _trial_step(self):
+        """Called at the end of finish(): book this update's duration, decide when the trial is complete."""
+        import torch.distributed as dist
+
+        mark = self._mark()
+        u = self.updates
+        if self._prev_mark is not None and u >= self.TRIAL_WARMUP:
+            self.trial[self._form_now()].append((self._prev_mark, mark))
+        self._prev_mark = mark
+        self.updates = u + 1
+        if self.updates < self.TRIAL_WARMUP + 2 * self.TRIAL_UPDATES:
+            return
+        med = {}
+        for k, pairs in self.trial.items():
+            ms = sorted(self._elapsed_ms(a, b) for a, b in pairs)
+            med[k] = ms[len(ms) // 2] if ms else float("inf")
+        t = torch.tensor([med["inline"], med["async"]], dtype=torch.float32, device=self.flat.device if self.avg else "cpu")
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        m_in, m_as = (float(v) for v in t.tolist())
+        self.decision = "inline" if m_in <= m_as else "async"
+        self.decided_at = self.updates
+        self.trial_ms = {"inline": m_in, "async": m_as}
+        for i, pairs in self._wire.items():
+            ms = sorted(self._elapsed_ms(a, b) for a, b in pairs)
+            self.wire_ms[i] = ms[len(ms) // 2]
+        self._wire, self.trial = {}, {"inline": [], "async": []}
+        import logging
+
+        logging.info("GradBuckets: collective placement decided after %d updates: %s (median update %.3f ms stream-ordered on the issuing stream, %.3f ms on the "
+                     "backend's stream; per-bucket wire ms %s)", self.updates, self.decision, m_in, m_as, {k: round(v, 3) for k, v in sorted(self.wire_ms.items())})
+
+    def schedule(self):
+        """What bench.py prints as `dp_schedule.policy`."""
+        return {"policy": self.decision or "trial (%d of %d updates)" % (self.updates, self.TRIAL_WARMUP + 2 * self.TRIAL_UPDATES), "auto": bool(self.auto),
+                "decided_after_updates": self.decided_at, "trial_median_update_ms": getattr(self, "trial_ms", None),
+                "bucket_wire_ms": {str(k): v for k, v in sorted(self.wire_ms.items())}, "bucket_bytes": [int((self.bounds[i + 1] - self.bounds[i]) * self.flat.element_size())
+                                                                                                         for i in range(len(self.bounds) - 1)],
+                "world": self.world}
 
     def launch(self, i):
         """Start averaging bucket i.  Once per optimizer step: with gradient accumulation only the LAST micro-batch may launch (an in-flight
@@ -114,8 +194,16 @@ class GradBuckets(object):
             self.staged.append((a, b))
             return
         op = dist.ReduceOp.AVG if self.avg else dist.ReduceOp.SUM
-        if self.inline and self.avg and (b - a) * self.flat.element_size() <= self.inline_max_bytes:
+        if self.auto:
+            inline = self._form_now() == "inline"
+        else:
+            inline = self.inline and self.avg and (b - a) * self.flat.element_size() <= self.inline_max_bytes
+        if inline:
+            timing = self.auto and self.decision is None and self.flat.is_cuda and self.updates >= self.TRIAL_WARMUP
+            e0 = self._mark() if timing else None
             dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=False)  # the issuing stream is ordered behind it; the host is not
+            if timing:  # (events on the issuing stream around a stream-ordered collective: what the stream stood still for = the bucket's wire time)
+                self._wire.setdefault(i, []).append((e0, self._mark()))
         else:
             self.work.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
         self.collectives += 1
@@ -136,6 +224,9 @@ class GradBuckets(object):
             return
         if self.active and not self.avg:
             (scale_fn or (lambda t, s: t.mul_(s)))(self.flat, 1.0 / self.world)
+        self.forms_used.append(self._form_now())
+        if self.auto and self.decision is None:
+            self._trial_step()
 
 
 def flat_layout(names_sizes):

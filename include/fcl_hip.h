@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 418
+#define FCL_ABI_VERSION 419
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -668,6 +668,9 @@ typedef struct {
     double ms;
     double flops;
     double rows;
+    double fill_bytes; /* round 6: bytes the launch's workgroups move global -> LDS through the CU's vector-memory path (LDS-DMA lines of the tiled GEMM /
+                        * Conv1d / LSTM-step kernels: workgroups x k-chunks x (A lines + W lines) x 128 B); 0 for kernels that do not report it.  Against the
+                        * measured per-CU delivery ceiling (tools/stream_probe.hip) this is the BINDING resource of those loops */
 } fcl_prof_entry_t;
 int fcl_prof_enable(int on);
 int fcl_prof_collect(fcl_prof_entry_t* out, int max_entries);

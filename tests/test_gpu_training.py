@@ -981,6 +981,18 @@ def _nccl_one_rank_worker(port, q):
         n_coll = e1.buckets.collectives
         os.environ["FCL_DP_INLINE"] = "0"  # the async form: async_op=True on RCCL's own stream, waited for in optimizer_step()
         l2, w2, e2 = run()
+        # round 6: the self-deciding placement on the one-rank RCCL group -- warm-up, the alternating trial, a decision, the decided form kept
+        os.environ.pop("FCL_DP_INLINE", None)
+        from fcl_taco2_amd.training import GradBuckets
+
+        n_trial = GradBuckets.TRIAL_WARMUP + 2 * GradBuckets.TRIAL_UPDATES
+        l3, w3, e3 = run(n_steps=n_trial + 2)
+        sched = e3.buckets.schedule()
+        assert e3.buckets.auto and sched["policy"] in ("inline", "async") and sched["decided_after_updates"] == n_trial, sched
+        fu = e3.buckets.forms_used
+        assert fu[GradBuckets.TRIAL_WARMUP : n_trial] == ["inline", "async"] * GradBuckets.TRIAL_UPDATES and fu[n_trial:] == [sched["policy"]] * 2, fu
+        assert len(sched["bucket_wire_ms"]) == 4 and all(v >= 0 for v in sched["bucket_wire_ms"].values()), sched
+        assert abs(l3[0] - l0[0]) <= 1e-9 * abs(l0[0]) and all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l3)), (l0, l3)
         os.environ["FCL_DP_INLINE"] = "1"
         assert e2.buckets.active and not e2.buckets.inline and e2.buckets.collectives == n_coll
         assert abs(l2[0] - l0[0]) <= 1e-9 * abs(l0[0]) and all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l2)), (l0, l2)

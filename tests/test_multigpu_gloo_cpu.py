@@ -103,7 +103,20 @@ def _grad_worker(rank, world, port, q):
         twice = True
     b2.finish()
     b2.finish()  # nothing launched since: must not rescale again
-    q.put((rank, bounds, mine.numpy(), flat.numpy(), (m1 + m2).numpy(), acc.numpy(), twice))
+    # round 6: the self-deciding placement -- warm-up, alternating trial, one decision shared by the ranks, correct means throughout
+    g3 = torch.zeros(int(offs[-1]))
+    b3 = GradBuckets(g3, bounds)
+    n_trial = GradBuckets.TRIAL_WARMUP + 2 * GradBuckets.TRIAL_UPDATES
+    means_ok = True
+    for u in range(n_trial + 2):
+        g3.copy_(torch.from_numpy(np.random.RandomState(1000 * u + rank).randn(int(offs[-1])).astype(np.float32)))
+        want = sum(np.random.RandomState(1000 * u + r).randn(int(offs[-1])).astype(np.float32) for r in range(world)) / world
+        for i in range(len(bounds) - 1):
+            b3.launch(i)
+        b3.finish()
+        means_ok = means_ok and bool(np.allclose(g3.numpy()[: bounds[-1]], want[: bounds[-1]], atol=1e-6))
+    sched = b3.schedule()
+    q.put((rank, bounds, mine.numpy(), flat.numpy(), (m1 + m2).numpy(), acc.numpy(), twice, (means_ok, b3.auto, list(b3.forms_used), sched)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -124,8 +137,19 @@ def test_two_rank_gradient_buckets_average():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, bounds, g0, avg0, s0, acc0, tw0), (_, _, g1, avg1, s1, acc1, tw1) = res
+    (_, bounds, g0, avg0, s0, acc0, tw0, pol0), (_, _, g1, avg1, s1, acc1, tw1, pol1) = res
     assert tw0 and tw1  # double launch raises
+    # round 6: the placement policy decides by measurement -- the trial alternated both forms on both ranks, every update still averaged correctly, and the
+    # two ranks took the SAME decision (the medians are MAX-reduced before the comparison)
+    from fcl_taco2_amd.training import GradBuckets
+
+    for ok, auto, forms, sched in (pol0, pol1):
+        assert ok and auto
+        w, k = GradBuckets.TRIAL_WARMUP, GradBuckets.TRIAL_UPDATES
+        assert forms[:w] == ["inline"] * w and forms[w : w + 2 * k] == ["inline", "async"] * k
+        assert sched["policy"] in ("inline", "async") and sched["decided_after_updates"] == w + 2 * k and forms[w + 2 * k :] == [sched["policy"]] * 2
+        assert set(sched["trial_median_update_ms"]) == {"inline", "async"} and sched["world"] == 2 and len(sched["bucket_bytes"]) == len(bounds) - 1
+    assert pol0[3]["policy"] == pol1[3]["policy"] and pol0[3]["trial_median_update_ms"] == pol1[3]["trial_median_update_ms"]
     assert np.array_equal(acc0, acc1) and np.allclose(acc0, (s0 + s1) / 2, atol=1e-6)  # accum_grad=2: mean over ranks of the accumulated sums, once
     assert bounds[0] == 0 and bounds[-1] == g0.shape[0] and all(a <= b for a, b in zip(bounds, bounds[1:])) and len(bounds) == len(_GROUPS) + 1
     assert np.array_equal(avg0, avg1)  # every rank ends with the same gradients -> same grad-norm -> all skip / step together (tts.py:173-178)
