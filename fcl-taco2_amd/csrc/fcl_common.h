@@ -216,6 +216,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t s);
 bool launch_dw_mfma(const float* a, int lda, const float* b, int ldb, float* c, int ldc, int m, int n, int k, int shift0, int ntaps, size_t c_tap_stride,
                     const int32_t* seg_lo, const int32_t* seg_hi, int hi_only, hipStream_t stream);
 int launch_lstm_step(const LstmStepArgs& a, hipStream_t s);
+int validate_lstm_step(const LstmStepArgs& a);    // launch_lstm_step's argument checks alone (callers of the pair launches run them first)
+bool lstm_step_on_planes(const LstmStepArgs& a);  // the step would run on pre-split operands (FCL_PRECISION / FCL_PLANES on, planes on every term)
 bool lstm_step_is_small(int M, int U);  // M rows at width U go to the 16-row wave-per-gate kernel (fp32 operands) rather than a big-tile kernel
 int launch_lstm_small(const LstmStepArgs& a, hipStream_t s);
 int launch_lstm_small_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipStream_t s);

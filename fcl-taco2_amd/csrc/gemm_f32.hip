@@ -619,7 +619,9 @@ bool lstm_step_is_small(int M, int U) {
     return M <= (small_m ? small_m : (U >= 512 ? (planes_on ? 64 : 256) : (planes_on ? 512 : 1024)));
 }
 
-int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
+// the argument checks of one LSTM step, shared by launch_lstm_step and by the callers that hand two steps to a pair launch (train_loops.hip: ADVICE r5 --
+// the wavefront's pair path used to skip them)
+int validate_lstm_step(const LstmStepArgs& a) {
     FCL_REQUIRE(a.M >= 0 && a.U > 0, FCL_ERR_SHAPE, "lstm_step: bad M=%d U=%d", a.M, a.U);
     if (a.M == 0) return 0;
     int rc = check_terms(a.term, a.nterms, 3, false, nullptr);
@@ -627,6 +629,15 @@ int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
     FCL_REQUIRE(a.h_in && a.h_out && a.c && a.h_in != a.h_out, FCL_ERR_INVALID, "lstm_step: h_in/h_out/c must be set and h_out must not alias h_in");
     FCL_REQUIRE(!a.rank1_w || a.dur, FCL_ERR_INVALID, "lstm_step: rank1_w needs dur");
     FCL_REQUIRE((a.zone_keep_h == nullptr) == (a.zone_keep_c == nullptr), FCL_ERR_INVALID, "lstm_step: zoneout masks come in pairs");
+    return 0;
+}
+// true when launch_lstm_step would run this step on the pre-split operands (bf16x3 / bf16 arithmetic): FCL_PRECISION / FCL_PLANES on, every term with planes
+bool lstm_step_on_planes(const LstmStepArgs& a) { return precision() && planes_ok(a.term, a.nterms); }
+
+int launch_lstm_step(const LstmStepArgs& a, hipStream_t s) {
+    int rc = validate_lstm_step(a);
+    if (rc) return rc;
+    if (a.M == 0) return 0;
     const bool small = lstm_step_is_small(a.M, a.U);
     bool has_f32 = true;
     for (int i = 0; i < a.nterms; ++i) has_f32 = has_f32 && a.term[i].A && a.term[i].W;

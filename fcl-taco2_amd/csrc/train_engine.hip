@@ -1779,6 +1779,9 @@ int fcl_te_forward_backward(fcl_te_t* Ep, const fcl_te_batch_t* batch, const fcl
     TE_TRY(te_backward_stage0(E));
     stamp(E, 6);
     // the named losses: complete once the late terms are joined (stage 0 ends with that join)
+    // (after an arena overflow take() hands out the arena's base -- TE_L refuses every launch from then on, and so must the copies below: c.sums
+    // would alias live memory)
+    FCL_REQUIRE(!E.work[E.cur_arena].overflow && !E.zero[E.cur_arena].overflow, FCL_ERR_WORKSPACE, "fcl_te: the pass needs more arena memory than its sizing run found");
     FCL_HIP(hipMemcpyAsync(loss_sums_host, E.c.sums, FCL_TE_MAX_LOSSES * 3 * sizeof(double), hipMemcpyDeviceToHost, E.main));
     if (status_host) FCL_HIP(hipMemcpyAsync(status_host, E.status, sizeof(uint32_t), hipMemcpyDeviceToHost, E.main));
     E.stage_done = 0;

@@ -153,7 +153,13 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
         const LstmStepArgs l0 = layer0(t + 1);
         bool done = false;
         const bool sm1 = lstm_step_is_small(l1.M, U), sm0 = lstm_step_is_small(l0.M, U);
-        if (is_big(t) && is_big(t + 1)) {
+        //  the pair launches bypass launch_lstm_step: its argument checks run here, and the plane pair is only taken where launch_lstm_step itself would
+        // run both steps on the pre-split operands (FCL_PRECISION=0 / FCL_PLANES=0 keep their fp32 kernels for direct callers of the C ABI too)
+        rc = validate_lstm_step(l1);
+        if (rc) return rc;
+        rc = validate_lstm_step(l0);
+        if (rc) return rc;
+        if (is_big(t) && is_big(t + 1) && lstm_step_on_planes(l1) && lstm_step_on_planes(l0)) {
             rc = launch_lstm_planes_pair(l1, l0, s, &done);  // (l1 first: it has the larger row count)
             if (rc) return rc;
         } else if (sm1 && sm0 && l1.nterms == l0.nterms) {

@@ -31,11 +31,11 @@ def _dev(t, device, dtype=None):
 
 
 def forward_pass(plan, batch, dropout_mode=ops.DROP_RNG, prenet_keep=None, seed=0):
+    """Runs H1-H11 teacher-forced.  batch: the converter's dict (reference tts.py:277-305).  Returns a ForwardResult
+    with every tensor the losses / distillation items need, in padded row layouts [B*T, .] and [B*L, .]."""
     if plan.hp.reduction_factor != 1:
         raise NotImplementedError("fcl-taco2_amd: the no-gradient teacher-forced forward (model.eval(); model(**batch)) covers reduction_factor 1; with r > 1 "
                                   "the plug-in classes run TrainEngine.forward_backward(batch, mode='eval') (nets/base.py forward)")
-    """Runs H1-H11 teacher-forced.  batch: the converter's dict (reference tts.py:277-305).  Returns a ForwardResult
-    with every tensor the losses / distillation items need, in padded row layouts [B*T, .] and [B*L, .]."""
     hp, dev = plan.hp, plan.device
     ilens = [int(v) for v in batch["ilens"]]
     olens = [int(v) for v in batch["olens"]]

@@ -99,7 +99,9 @@ class GradBuckets(object):
         env = os.environ.get("FCL_DP_INLINE", "auto")
         self.inline = env not in ("", "0")
         self.inline_max_bytes = (64 << 20) if env == "auto" else (1 << 62)
-        self.auto = env == "auto" and self.active and not self.stage_host  # (gloo on host tensors / FCL_DP_GLOO_DIRECT runs the same trial: the CPU tests)
+        # (RCCL, and gloo on HOST tensors -- the CPU tests run the same trial; gloo on device tensors keeps its fixed forms: host-staged, or asynchronous under
+        # FCL_DP_GLOO_DIRECT, the ordering test)
+        self.auto = env == "auto" and self.active and (self.avg or not flat.is_cuda)
         self.forms_used = []                   # the placement of every update so far (tests read it)
         self.updates = 0                       # finish() calls that reduced
         self.trial = {"inline": [], "async": []}
@@ -109,15 +111,15 @@ class GradBuckets(object):
         self._wire = {}                        # bucket -> [(start event, end event)] of its stream-ordered collectives during the trial
         self.wire_ms = {}
 
-    TRIAL_WARMUP, TRIAL_UPDATES = 2, 3
+    TRIAL_WARMUP, TRIAL_UPDATES = 2, 4
 
     def _form_now(self):
-        """The placement of the CURRENT update: the decision once taken, else the trial's alternation (even update inline, odd async)."""
+        """The placement of the CURRENT update: the decision once taken, else the trial's -- warm-up and a block of TRIAL_UPDATES updates stream-ordered, then a
+        block on the backend's stream (blocks, not alternation: a backend stream that has just run a collective stays an active hardware queue for a while and
+        would tax the stream-ordered updates next to it; the first update of each block is the transition and is not booked)."""
         if self.decision is not None or not self.auto:
             return self.decision or ("inline" if self.inline else "async")
-        if self.updates < self.TRIAL_WARMUP:
-            return "inline"
-        return "inline" if (self.updates - self.TRIAL_WARMUP) % 2 == 0 else "async"
+        return "inline" if self.updates < self.TRIAL_WARMUP + self.TRIAL_UPDATES else "async"
 
     def _mark(self):
         if self.flat.is_cuda:
@@ -141,7 +143,8 @@ class GradBuckets(object):
 
         mark = self._mark()
         u = self.updates
-        if self._prev_mark is not None and u >= self.TRIAL_WARMUP:
+        first_of_block = u in (self.TRIAL_WARMUP, self.TRIAL_WARMUP + self.TRIAL_UPDATES)
+        if self._prev_mark is not None and u >= self.TRIAL_WARMUP and not first_of_block:
             self.trial[self._form_now()].append((self._prev_mark, mark))
         self._prev_mark = mark
         self.updates = u + 1

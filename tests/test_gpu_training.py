@@ -990,7 +990,7 @@ def _nccl_one_rank_worker(port, q):
         sched = e3.buckets.schedule()
         assert e3.buckets.auto and sched["policy"] in ("inline", "async") and sched["decided_after_updates"] == n_trial, sched
         fu = e3.buckets.forms_used
-        assert fu[GradBuckets.TRIAL_WARMUP : n_trial] == ["inline", "async"] * GradBuckets.TRIAL_UPDATES and fu[n_trial:] == [sched["policy"]] * 2, fu
+        assert fu[:n_trial] == ["inline"] * (GradBuckets.TRIAL_WARMUP + GradBuckets.TRIAL_UPDATES) + ["async"] * GradBuckets.TRIAL_UPDATES and fu[n_trial:] == [sched["policy"]] * 2, fu
         assert len(sched["bucket_wire_ms"]) == 4 and all(v >= 0 for v in sched["bucket_wire_ms"].values()), sched
         assert abs(l3[0] - l0[0]) <= 1e-9 * abs(l0[0]) and all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l3)), (l0, l3)
         os.environ["FCL_DP_INLINE"] = "1"

@@ -146,7 +146,7 @@ def test_two_rank_gradient_buckets_average():
     for ok, auto, forms, sched in (pol0, pol1):
         assert ok and auto
         w, k = GradBuckets.TRIAL_WARMUP, GradBuckets.TRIAL_UPDATES
-        assert forms[:w] == ["inline"] * w and forms[w : w + 2 * k] == ["inline", "async"] * k
+        assert forms[: w + k] == ["inline"] * (w + k) and forms[w + k : w + 2 * k] == ["async"] * k  # a block of each form
         assert sched["policy"] in ("inline", "async") and sched["decided_after_updates"] == w + 2 * k and forms[w + 2 * k :] == [sched["policy"]] * 2
         assert set(sched["trial_median_update_ms"]) == {"inline", "async"} and sched["world"] == 2 and len(sched["bucket_bytes"]) == len(bounds) - 1
     assert pol0[3]["policy"] == pol1[3]["policy"] and pol0[3]["trial_median_update_ms"] == pol1[3]["trial_median_update_ms"]

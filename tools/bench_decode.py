@@ -24,7 +24,7 @@ n_utt = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 utts = [("utt%04d" % i, rng.randint(1, S.idim, size=int(rng.randint(60, 101))).astype(np.int64)) for i in range(n_utt)]
 torch.set_num_threads(4)
 with tempfile.TemporaryDirectory() as d:
-    for depth in (2, 3, 4):
+    for depth in [int(x) for x in os.environ.get("BENCH_DECODE_DEPTHS", "2,3,4").split(",")]:  # (one depth per process = what bench.py's decode leg measures)
         D.decode(model, utts, os.path.join(d, "w%d" % depth), depth=depth)  # first call: captures the buckets' graphs (kept on the model's plan)
         st = {}
         f, s = D.decode(model, utts, os.path.join(d, "b%d" % depth), depth=depth, stats=st)
