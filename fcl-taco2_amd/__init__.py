@@ -7,4 +7,13 @@ library is missing.
 """
 __version__ = "0.1.0"
 
+import os as _os
+
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and reads the variable when it initialises.  The
+# synthesis drivers keep FOUR passes in flight on four streams beside the default stream (calibration batches, read-backs): five streams on four queues put
+# two ACTIVE streams on one queue -- the decode driver then runs at 28 M instead of 38 M mel-frames/s (round 6: tools/bench_decode.py without the setting
+# against bench.py's decode leg with it; depth 3 "beat" depth 4 for the same reason, profiles/r6_bench_decode.log).  Eight queues give every stream its own;
+# more do not help.  Set before the first HIP call: importing this package is early enough for the drivers (decode.py, train.py, bench.py).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .hparams import HParams, student_hparams, teacher_hparams, param_spec  # noqa: F401

@@ -28,7 +28,10 @@ with tempfile.TemporaryDirectory() as d:
         D.decode(model, utts, os.path.join(d, "w%d" % depth), depth=depth)  # first call: captures the buckets' graphs (kept on the model's plan)
         st = {}
         f, s = D.decode(model, utts, os.path.join(d, "b%d" % depth), depth=depth, stats=st)
-        f2, s2 = D.decode(model, utts, None, depth=depth)
-        print("depth %d, nothing written (synthesis + D2H of every mel): %.3f s = %.2f M frames/s" % (depth, s2, f2 / s2 / 1e6))
+        reps = []
+        for _ in range(int(os.environ.get("BENCH_DECODE_REPS", "1"))):
+            f2, s2 = D.decode(model, utts, None, depth=depth)
+            reps.append(f2 / s2 / 1e6)
+        print("depth %d, nothing written (synthesis + D2H of every mel): %.3f s = %.2f M frames/s%s" % (depth, s2, f2 / s2 / 1e6, "  (repeats: %s)" % " ".join("%.1f" % v for v in reps) if len(reps) > 1 else ""))
         print("depth %d (graphs captured by a previous call): %d frames; end to end %.3f s = %.2f M frames/s; device side %.3f s = %.2f M frames/s; %s" %
               (depth, f, s, f / s / 1e6, st["device_seconds"], f / st["device_seconds"] / 1e6, {k: v for k, v in st.items() if k != "device_seconds"}))
