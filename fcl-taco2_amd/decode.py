@@ -15,6 +15,7 @@ import argparse
 import importlib
 import json
 import logging
+import os
 import queue
 import threading
 import time
@@ -87,12 +88,21 @@ class _Slot(object):
     """One pinned landing area of a runner's outputs (mel buffer, frame starts, status word); `free` is set by the writer thread once the ark
     holds its utterances, and waited on before the next device-to-host copy may overwrite it."""
 
-    def __init__(self, frames_cap, odim, batch):
-        self.mel = torch.empty(frames_cap, odim, dtype=torch.float32, pin_memory=True)
-        self.f0 = torch.empty(batch + 1, dtype=torch.int32, pin_memory=True)
-        self.st = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    def __init__(self, frames_cap, odim, batch, slab=None):
+        """slab: a pinned float32 tensor of at least words(frames_cap, odim, batch) elements to carve the three buffers from (round 6: one pinned allocation
+        per bucket instead of three per slot -- 96 hipHostMalloc calls of a first decode() call -> 4)."""
+        if slab is None:
+            slab = torch.empty(self.words(frames_cap, odim, batch), dtype=torch.float32, pin_memory=True)
+        n = frames_cap * odim
+        self.mel = slab[:n].view(frames_cap, odim)
+        self.f0 = slab[n : n + batch + 1].view(torch.int32)
+        self.st = slab[n + batch + 1 : n + batch + 2].view(torch.int32)
         self.free = threading.Event()
         self.free.set()
+
+    @staticmethod
+    def words(frames_cap, odim, batch):
+        return (frames_cap * odim + batch + 2 + 63) // 64 * 64
 
 
 class _Pool(object):
@@ -102,13 +112,18 @@ class _Pool(object):
     def __init__(self, plan, batch, t_cap, caps, streams, seed):
         self.plan, self.batch, self.caps, self.t_cap, self.streams, self.seed = plan, batch, caps, t_cap, streams, seed
         self.runners, self.slots, self.next, self.grow = [None] * len(streams), [None] * len(streams), 0, None
+        self._slab = None
 
     def runner(self, j):
         from . import engine
 
         if self.runners[j] is None:
             r = self.runners[j] = engine.BatchRunner(self.plan, self.batch, self.t_cap, self.caps, forced=False, stream=self.streams[j], seed=self.seed + 7919 * j)
-            self.slots[j] = [_Slot(self.caps.frames, r.mel.shape[1], self.batch) for _ in range(2)]
+            odim = int(r.mel.shape[1])
+            w = _Slot.words(self.caps.frames, odim, self.batch)
+            if self._slab is None:  # the landing areas of every runner of the bucket: one pinned allocation
+                self._slab = torch.empty(2 * len(self.streams) * w, dtype=torch.float32, pin_memory=True)
+            self.slots[j] = [_Slot(self.caps.frames, odim, self.batch, self._slab[(2 * j + q) * w : (2 * j + q + 1) * w]) for q in range(2)]
         return self.runners[j]
 
 
@@ -124,6 +139,19 @@ def _grown_caps(engine, maps, n_rows, scale=1.3):
     return engine.Caps(lmax, (int(maps.n_frames * scale) + 255) // 256 * 256, bounds, tail_from=maps.lmax + 2)
 
 
+class _ScaledMaps(object):
+    """The exact maps of a calibration batch rescaled to another batch's phoneme count (round 6): durations are a per-phoneme quantity, so a
+    later bucket's frame total and live-row profile are the calibrated ones x (its phonemes / the calibrated batch's phonemes); _grown_caps adds the slack
+    and a batch that still overflows is reported by the device and redone eagerly (pool.grow), as before."""
+
+    def __init__(self, maps, n_ph_cal, n_ph):
+        ratio = float(n_ph) / float(max(n_ph_cal, 1))
+        self.lmax = int(maps.lmax)
+        self.live_rows = np.ceil(np.asarray(maps.live_rows, dtype=np.float64) * ratio).astype(np.int64)
+        self.n_frames = int(np.ceil(maps.n_frames * ratio))
+
+
+ESTIMATE_CAPS = os.environ.get("FCL_DECODE_ESTIMATE_CAPS", "1") not in ("", "0")  # capacities of later buckets from phoneme counts (0: one eager batch per bucket)
 MAX_BUCKETS = 8  # captured-graph pools kept per (batch size, depth): least recently used buckets are released beyond this
 
 
@@ -168,7 +196,7 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
     pools = cache.setdefault(("pools", batch_size, depth), collections.OrderedDict())
     max_buckets = max(1, int(MAX_BUCKETS if max_buckets is None else max_buckets))
     pending = []
-    n_eager = n_graph = n_redo = n_evict = 0
+    n_eager = n_graph = n_redo = n_evict = n_est = 0
     # dlayers / prenet_layers / elayers other than 2 / 2 / 1 run on the fp32-operand loop with host row counts (fcl_decoder_weights_t.dlayers ...)
     eager_only = bool(getattr(plan, "generic_decoder", False)) or plan.hp.elayers != 1
 
@@ -252,10 +280,26 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
                     lmax = max(g.lmax, pool.caps.lmax)
                     caps = engine.Caps(lmax, max(g.frames, pool.caps.frames), np.full(lmax, batch_size * t_cap, np.int32), tail_from=g.tail_from)
                     pool = pools[t_cap] = _Pool(plan, batch_size, t_cap, caps, streams, seed + 31 * bi)
+                cal = cache.get(("calibration", batch_size))  # (exact maps, phoneme count) of the first eagerly calibrated batch of this model
+                if pool is None and cal is not None and ESTIMATE_CAPS:
+                    # a later bucket: capacities ESTIMATED from the phoneme count (no eager batch, no host round trip); the batch itself goes through the graph below
+                    est = _ScaledMaps(cal[0], cal[1], sum(len(u[1]) for u in chunk))
+                    pool = pools[t_cap] = _Pool(plan, batch_size, t_cap, _grown_caps(engine, est, batch_size * t_cap), streams, seed + 31 * bi)
+                    n_est += 1
+                    while len(pools) > max_buckets:
+                        old_cap, old_pool = next(iter(pools.items()))
+                        for it in [p_ for p_ in pending if p_[0] is old_pool]:
+                            pending.remove(it)
+                            frames += harvest(it)
+                        for sl in [x for pair in old_pool.slots if pair for x in pair]:
+                            sl.free.wait()
+                        del pools[old_cap]
+                        n_evict += 1
                 if pool is None:  # first batch of the bucket: eager pass = its result + the bucket's calibration
                     got, maps = eager(chunk)
                     frames += got
                     n_eager += 1
+                    cache.setdefault(("calibration", batch_size), (maps, sum(len(u[1]) for u in chunk)))
                     pools[t_cap] = _Pool(plan, batch_size, t_cap, _grown_caps(engine, maps, batch_size * t_cap), streams, seed + 31 * bi)
                     while len(pools) > max_buckets:  # least recently used bucket out: its batches in flight are harvested first
                         old_cap, old_pool = next(iter(pools.items()))
@@ -312,7 +356,8 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
         if werr:
             raise werr[0]
     if stats is not None:
-        stats.update(device_seconds=dev_secs, eager_batches=n_eager, graph_batches=n_graph, redone_batches=n_redo, buckets=len(pools), evicted_buckets=n_evict)
+        stats.update(device_seconds=dev_secs, eager_batches=n_eager, graph_batches=n_graph, redone_batches=n_redo, buckets=len(pools), evicted_buckets=n_evict,
+                     estimated_buckets=n_est)
     return frames, secs
 
 

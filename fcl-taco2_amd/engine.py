@@ -442,6 +442,22 @@ def synthesize(plan, xs, durs=None, f0=None, energy=None, dropout_mode=ops.DROP_
 _SHARED_STREAMS = {}
 
 
+import contextlib as _contextlib
+
+
+@_contextlib.contextmanager
+def capture(graph, stream):
+    """hipGraph capture of what runs inside, on `stream` -- torch.cuda.graph() without its device-wide synchronize + empty_cache() in front of EVERY capture
+    (~1 ms each: a first decode() call captures 16 graphs back to back; round 6).  The caller has synchronised `stream`; allocations made inside go to the
+    graph's private pool as with torch.cuda.graph()."""
+    with torch.cuda.stream(stream):
+        graph.capture_begin(capture_error_mode="global")
+        try:
+            yield
+        finally:
+            graph.capture_end()
+
+
 def shared_streams(device, n):
     """The first `n` of this process's synthesis streams on `device` (created on first use, then reused by every runner set and by the decode
     driver).  This device runs FOUR concurrently active HIP queues well and falls off a cliff at the fifth, and the runtime
@@ -576,7 +592,7 @@ class BatchRunner(object):
                 self.stream.synchronize()
             self.status.zero_()  # (predicted durations: the warm-up ids need not predict valid ones)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
+            with capture(self.graph, self.stream):
                 if self._ingraph:
                     ops.feed_copy(self._dev, self._src_dev, self._nbytes, self._seq_dev, self._seq_host_dev, self.seed_word)  # + the seed bump
                 else:

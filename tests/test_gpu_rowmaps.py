@@ -309,6 +309,48 @@ def test_decode_driver_recovers_from_a_capacity_overflow(tmp_path, monkeypatch):
         assert mels[uid].shape == tuple(ref.shape) and max_abs(mels[uid], ref) < 2e-5
 
 
+def test_decode_driver_estimates_later_buckets_capacities_from_phoneme_counts(tmp_path, monkeypatch):
+    """Round 6: only the FIRST bucket of a corpus is calibrated by an eager batch; the capacities of later buckets are the calibrated maps
+    rescaled by phoneme count (decode._ScaledMaps) + the usual slack.  Three length buckets: one eager batch, two estimated buckets, every mel equal to plain
+    synthesis; an estimate that is too tight (forced: frames / 3) is caught by the device and recovered like any overflow."""
+    from fcl_taco2_amd import decode as D, engine
+    from fcl_taco2_amd.kaldi_io import read_scp
+
+    S, T = HP.student_hparams(dropout_rate=0.0), HP.teacher_hparams()
+    model = SYN.build_model("student", S, T, DEV).eval()
+    sd = SYN.positive_duration_head(SYN.closed_form_state_dict(HP.param_spec(S, T, True)))
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    model = model.to(DEV).eval()
+    rng = np.random.RandomState(9)
+    utts = [("u%03d" % i, rng.randint(1, S.idim, size=int(n)).astype(np.int64)) for i, n in enumerate(list(rng.randint(50, 64, 16)) + list(rng.randint(34, 48, 16)) +
+                                                                                                      list(rng.randint(18, 32, 16)))]
+    st = {}
+    frames, _ = D.decode(model, utts, str(tmp_path / "e"), batch_size=8, depth=2, stats=st)
+    assert st["eager_batches"] == 1 and st["estimated_buckets"] == 2 and st["buckets"] == 3 and st["redone_batches"] == 0, st
+    mels = read_scp(str(tmp_path / "e.scp"))
+    assert sorted(mels) == sorted(u for u, _ in utts) and frames == sum(m.shape[0] for m in mels.values())
+    plan = model.plan()
+    for uid, x in utts[::5]:
+        ref = engine.synthesize(plan, [x])[0]
+        assert mels[uid].shape == tuple(ref.shape) and max_abs(mels[uid], ref) < 2e-5
+    # an estimate that does not hold: the device reports it, the batch is redone on the host-mapped path, the bucket grows
+    D.release_graphs(model)
+    real = D._ScaledMaps
+
+    class Tight(real):
+        def __init__(self, maps, n_ph_cal, n_ph):
+            real.__init__(self, maps, n_ph_cal, n_ph)
+            self.n_frames = max(64, self.n_frames // 3)
+
+    monkeypatch.setattr(D, "_ScaledMaps", Tight)
+    st2 = {}
+    frames2, _ = D.decode(model, utts, str(tmp_path / "t"), batch_size=8, depth=2, stats=st2)
+    assert st2["estimated_buckets"] == 2 and st2["redone_batches"] >= 1 and frames2 == frames, st2
+    mels2 = read_scp(str(tmp_path / "t.scp"))
+    for uid, _ in utts[::5]:
+        assert max_abs(mels2[uid], mels[uid]) < 2e-5
+
+
 def test_grouped_predictor_launches_equal_the_per_predictor_path():
     """plan.PredictorGroup: the duration / pitch / energy predictors (one geometry in the shipped recipes) as ONE launch per layer -- a Conv1d with
     the stacked output channels, grouped LayerNorms, a grouped Conv1d, grouped LayerNorm + head -- against one launch per predictor and layer:
