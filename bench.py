@@ -261,9 +261,9 @@ def binding_record(name, ms, fill_bytes, workload=""):
     lds, src = pmc_lds_active(name, workload)
     return {"resource": "per-CU global->LDS delivery (LDS-DMA)", "achieved_B_per_clk_per_cu": rate, "ceiling_B_per_clk_per_cu": CU_FILL_CEILING_B_PER_CLK,
             "frac": rate / CU_FILL_CEILING_B_PER_CLK, "fill_bytes_per_launch_sum": fill_bytes, "chip_TB_per_s": fill_bytes / (ms * 1e-3) / 1e12,
-            "lds_active_frac": lds, "lds_active_source": src,
+            "lds_idx_active_over_sq_busy": lds, "lds_counter_source": src,
             "note": "fill bytes = workgroups x 32-k chunks x (A + W lines) x 128 B as launched (fcl_prof_entry_t.fill_bytes) / HIP-event duration of the whole launch / "
-                    "256 CUs / 2.4 GHz; ceiling = tools/stream_probe.hip (21.8 TB/s chip-wide, profiles/r4_stream_probe.log); lds_active_frac = "
+                    "256 CUs / 2.4 GHz; ceiling = tools/stream_probe.hip (21.8 TB/s chip-wide, profiles/r4_stream_probe.log); lds_idx_active_over_sq_busy = "
                     "SQ_LDS_IDX_ACTIVE / SQ_BUSY_CYCLES from the committed PMC pass"}
 
 
@@ -521,7 +521,7 @@ def train_workload(args, rank, world, dev, dist):
                 e = {"ms_per_step": v["ms"], "launches_per_step": v["launches"], "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12, "mfma_frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak}
                 b_ = binding_record(k, v["ms"], v["fill_bytes"], args.workload)
                 if b_:
-                    e["binding"] = {kk: b_[kk] for kk in ("achieved_B_per_clk_per_cu", "frac", "lds_active_frac")}
+                    e["binding"] = {kk: b_[kk] for kk in ("achieved_B_per_clk_per_cu", "frac", "lds_idx_active_over_sq_busy")}
                 dom_roof["kernels"][k] = e
         launches_per_step = int(sum(v["launches"] for v in prof.values()))
     # ---- the same update on the schedule a rank of an N-GPU job runs (VERDICT r3 #5c): a ONE-rank RCCL group, every bucket's
@@ -1002,7 +1002,7 @@ def main():
             if v.get("fill_bytes"):
                 e["mfma_frac"] = e["tflops"] / peak
                 b_ = binding_record(k, v["ms"], v["fill_bytes"], pmc_wl)
-                e["binding"] = {kk: b_[kk] for kk in ("achieved_B_per_clk_per_cu", "frac", "lds_active_frac")}
+                e["binding"] = {kk: b_[kk] for kk in ("achieved_B_per_clk_per_cu", "frac", "lds_idx_active_over_sq_busy")}
             out["kernels"][k] = e
 
         # ---- CPU baseline: the oracle ("port" of the reference's per-utterance inference) on the host cores

@@ -1,7 +1,7 @@
 # Collects the round's profile evidence on the GPU box into gpurun_out/prof_$1/ (copy the summaries to profiles/ afterwards):
 #   default bench JSON (fresh feed, 4 capacity graphs in flight), rocprofv3 kernel stats of that command and of the eager single-stream pass,
 #   PMC FETCH_SIZE / WRITE_SIZE / SQ counters (separate --pmc passes, --kernel-trace only), training-step JSONs + kernel stats + PMC traffic.
-TAG=${1:-r5}
+TAG=${1:-r6}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
