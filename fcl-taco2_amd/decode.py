@@ -93,6 +93,7 @@ class _Slot(object):
         per bucket instead of three per slot -- 96 hipHostMalloc calls of a first decode() call -> 4)."""
         if slab is None:
             slab = torch.empty(self.words(frames_cap, odim, batch), dtype=torch.float32, pin_memory=True)
+        self.whole = slab[: self.words(frames_cap, odim, batch)]  # the layout of BatchRunner.out: one device-to-host copy fills all three
         n = frames_cap * odim
         self.mel = slab[:n].view(frames_cap, odim)
         self.f0 = slab[n : n + batch + 1].view(torch.int32)
@@ -102,7 +103,9 @@ class _Slot(object):
 
     @staticmethod
     def words(frames_cap, odim, batch):
-        return (frames_cap * odim + batch + 2 + 63) // 64 * 64
+        from .engine import packed_words
+
+        return packed_words(frames_cap, odim, batch)
 
 
 class _Pool(object):
@@ -118,7 +121,10 @@ class _Pool(object):
         from . import engine
 
         if self.runners[j] is None:
-            r = self.runners[j] = engine.BatchRunner(self.plan, self.batch, self.t_cap, self.caps, forced=False, stream=self.streams[j], seed=self.seed + 7919 * j)
+            pools_ = self.plan.__dict__.setdefault("_decode_cache", {}).setdefault("graph_mempools", {})
+            mp = pools_.setdefault(self.streams[j].cuda_stream, torch.cuda.graph_pool_handle()) if SHARE_GRAPH_POOLS else None  # one per pass stream (stream-ordered graphs)
+            r = self.runners[j] = engine.BatchRunner(self.plan, self.batch, self.t_cap, self.caps, forced=False, stream=self.streams[j], seed=self.seed + 7919 * j,
+                                                     pack_outputs=True, mempool=mp)
             odim = int(r.mel.shape[1])
             w = _Slot.words(self.caps.frames, odim, self.batch)
             if self._slab is None:  # the landing areas of every runner of the bucket: one pinned allocation
@@ -151,6 +157,7 @@ class _ScaledMaps(object):
         self.n_frames = int(np.ceil(maps.n_frames * ratio))
 
 
+SHARE_GRAPH_POOLS = os.environ.get("FCL_DECODE_SHARE_POOLS", "1") not in ("", "0")  # the graphs of one pass stream share a memory pool (first call: fewer allocations)
 ESTIMATE_CAPS = os.environ.get("FCL_DECODE_ESTIMATE_CAPS", "1") not in ("", "0")  # capacities of later buckets from phoneme counts (0: one eager batch per bucket)
 MAX_BUCKETS = 8  # captured-graph pools kept per (batch size, depth): least recently used buckets are released beyond this
 
@@ -327,9 +334,12 @@ def decode(model, utts, out_prefix, batch_size=32, seed=137, depth=4, stats=None
                     raise
                 r.replay()
                 with torch.cuda.stream(r.stream):
-                    slot.mel.copy_(r.mel, non_blocking=True)
-                    slot.f0.copy_(r._frames.utt_frame0, non_blocking=True)
-                    slot.st.copy_(r.status, non_blocking=True)
+                    if r.out is not None and r.out.numel() == slot.whole.numel():
+                        slot.whole.copy_(r.out, non_blocking=True)  # mel | frame starts | status in one call (round 6)
+                    else:
+                        slot.mel.copy_(r.mel, non_blocking=True)
+                        slot.f0.copy_(r._frames.utt_frame0, non_blocking=True)
+                        slot.st.copy_(r.status, non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(r.stream)
                 pending.append((pool, j, chunk, slot, ev))

@@ -446,12 +446,15 @@ import contextlib as _contextlib
 
 
 @_contextlib.contextmanager
-def capture(graph, stream):
+def capture(graph, stream, pool=None):
     """hipGraph capture of what runs inside, on `stream` -- torch.cuda.graph() without its device-wide synchronize + empty_cache() in front of EVERY capture
     (~1 ms each: a first decode() call captures 16 graphs back to back; round 6).  The caller has synchronised `stream`; allocations made inside go to the
     graph's private pool as with torch.cuda.graph()."""
     with torch.cuda.stream(stream):
-        graph.capture_begin(capture_error_mode="global")
+        if pool is not None:
+            graph.capture_begin(pool, capture_error_mode="global")
+        else:
+            graph.capture_begin(capture_error_mode="global")
         try:
             yield
         finally:
@@ -472,6 +475,11 @@ def shared_streams(device, n):
     while len(pool) < n:
         pool.append(torch.cuda.Stream(device=dev))
     return pool[:n]
+
+
+def packed_words(frames_cap, odim, batch):
+    """float32 words of a runner's packed output block / a landing slot: mel | frame starts [batch + 1] | status word, rounded to 256 bytes."""
+    return (int(frames_cap) * int(odim) + int(batch) + 2 + 63) // 64 * 64
 
 
 class GraphRunner(object):
@@ -528,7 +536,12 @@ class BatchRunner(object):
     back (`frames()`): capacities are verified on the device (FCL_STATUS_*), a batch that does not fit is reported, never silently truncated.
     forced=True: the graph takes uploaded durations (load(xs, durs)); forced=False: it contains the duration predictor + rounding."""
 
-    def __init__(self, plan, batch, t_cap, caps, forced=True, stream=None, dropout_mode=ops.DROP_RNG, seed=0, depth=3):
+    def __init__(self, plan, batch, t_cap, caps, forced=True, stream=None, dropout_mode=ops.DROP_RNG, seed=0, depth=3, pack_outputs=False, mempool=None):
+        """pack_outputs (round 6, the decode driver): the graph also gathers its three results -- mel [frames cap, odim], frame starts [B + 1], status word --
+        into ONE float32 buffer `self.out` (two tiny copies and a ~5 us device copy inside the graph), so that a batch costs the host one device-to-host copy call
+        instead of three (the driver's loop is bound by its enqueue time: 3 x ~70 us of copy calls out of ~470 us per batch).
+        mempool: a torch graph-pool handle shared by the graphs that replay on THIS stream only (stream order keeps two of them from running at once): later
+        captures reuse the intermediates' memory of earlier ones instead of allocating theirs (a first decode() call: ~500 allocations -> ~150)."""
         dev = plan.device
         self.plan, self.B, self.T, self.caps, self.forced = plan, int(batch), int(t_cap), caps, bool(forced)
         self.S = int(plan.hp.spk_embed_dim or 0)  # speaker-embedding width: one vector per utterance rides in the same block
@@ -592,12 +605,19 @@ class BatchRunner(object):
                 self.stream.synchronize()
             self.status.zero_()  # (predicted durations: the warm-up ids need not predict valid ones)
             self.graph = torch.cuda.CUDAGraph()
-            with capture(self.graph, self.stream):
+            with capture(self.graph, self.stream, mempool):
                 if self._ingraph:
                     ops.feed_copy(self._dev, self._src_dev, self._nbytes, self._seq_dev, self._seq_host_dev, self.seed_word)  # + the seed bump
                 else:
                     ops.u32_add(self.seed_word, 1)
                 self.mel, self._frames = run(plan, p, dropout_mode, seed=seed, seed_dev=self.seed_word, caps=caps, status=self.status)
+                self.out = None
+                if pack_outputs:
+                    n, b1 = self.mel.numel(), self.B + 1
+                    self.out = torch.empty(packed_words(self.mel.shape[0], self.mel.shape[1], self.B), dtype=torch.float32, device=dev)
+                    self.out[:n].view_as(self.mel).copy_(self.mel)
+                    self.out[n : n + b1].view(torch.int32).copy_(self._frames.utt_frame0[:b1])
+                    self.out[n + b1 : n + b1 + 1].view(torch.int32).copy_(self.status)
         self.n_loaded = 0
 
     def _feed(self, bump):
