@@ -108,15 +108,16 @@ __global__ __launch_bounds__(4 * H) void bilstm_persistent_kernel(const float* _
 // update runs replicated in the quad, lane 0 of the quad publishes h into the other half of a double-buffered LDS vector: ONE barrier per step.
 // Gate pre-activations are prefetched four steps ahead (a step is shorter than a global load).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// DPP on gfx950 beside foreign waves (measured, round 5; HISTORY.md has the experiments).  With the device to itself these kernels -- two waves per SIMD at
-// 168 - 194 VGPRs -- are exact.  Beside another stream's kernels they returned 1e-3 .. 1e-2 errors in single units in 299 of 300 launches
-// (`tools/stress_bilstm_concurrent.py`), always computed in lanes 48 - 63 (the last pass of a wave64 instruction) of some wave: a partial sum read before its
-// producer's last pass had written it.  Explicit wait states tied to the DPP sources did NOT remove it (2 or 4: 297 / 300 bad launches; sixteen in any of three
-// places did, as any reshuffling of the schedule did -- once).  What removes it with nothing else changed is keeping foreign waves off the SIMD: the kernel claims
-// the SIMD's whole register file (`.amdhsa_next_free_vgpr 256`: 2 waves x 256), 0 / 300 in both submission orders (`profiles/r5_dpp_hazard_ab.log`).  The CU is
-// this workgroup's anyway (8 waves, W_hh in registers); the four wait states in dpp_f stay as a margin.
+// Wrong values beside foreign waves (rounds 5 - 6).  Round 5: beside another stream's kernels these kernels returned 1e-3 .. 1e-2 errors in single units in
+// 299 of 300 launches, always computed in lanes 48 - 63 of some wave, never with the device to itself; claiming the SIMD's whole register file (no third wave on the
+// SIMD) removed it and the round called it a DPP hazard.  Round 6 found the cause: it is the PACKED-FP32 arithmetic (`v_pk_fma_f32` of ks_matvec and whatever hipcc packs
+// from float4 code), whose results come out stale in the last quarter of the wave when ANOTHER wave on the SIMD issues MFMAs (any GEMM of another stream: 100 / 100
+// launches wrong beside `gemm_kernel`, 0 / 100 beside element-wise, copy or fill kernels; with `ds_bpermute` in place of DPP nothing changes; with the packed-FP32 feature
+// taken away from the compiler -- csrc/Makefile NOPK, the whole library -- 0 / 100 beside everything, `profiles/r6_packed_fp32_hazard_ab.log`).  The library is built
+// without packed-FP32 instructions (tests/test_cabi_cpu.py disassembles it), so these kernels share their SIMDs again; -DFCL_KS_EXCLUSIVE restores the round-5 guard
+// for builds that re-enable the feature (`make NOPK=`).
 __device__ __forceinline__ void ks_exclusive() {
-#ifndef FCL_KS_NOT_EXCLUSIVE  // (developer A/B: the wait states alone)
+#ifdef FCL_KS_EXCLUSIVE
     asm volatile("v_mov_b32 v255, 0" ::: "v255");
 #endif
 }
@@ -779,14 +780,15 @@ static bool bilstm_ksplit_enabled() {
     return on != 0;
 }
 
-// Round 6: the lane-split kernels are correct beside foreign waves only while they own their SIMDs' register files -- ks_exclusive()
-// makes the code object ask for 256 VGPRs, which is a property of what the compiler emitted, not of this source.  Before the first launch of a kernel
-// the runtime is asked what the loaded code object really requests (hipFuncGetAttributes: numRegs, in the hardware's 8-register granules 249 .. 256 all
-// allocate 256); a kernel that does not claim the whole file is NOT launched -- its callers fall back to the row-per-thread kernels (`bilstm_persistent_kernel`,
-// `bilstm_group_kernel<256>`), which need no such guard -- and the reason is left in fcl_last_error().  tests/test_cabi_cpu.py asserts the same number in
-// the code object's metadata on the CPU.  FCL_KS_GUARD=0 (developer A/B with -DFCL_KS_NOT_EXCLUSIVE builds) switches the check off.
+// Builds WITH packed-FP32 instructions (-DFCL_KS_EXCLUSIVE, `make NOPK=`) keep the round-5 guard, and verify it: before the first launch of a
+// lane-split kernel the runtime is asked what the loaded code object really requests (hipFuncGetAttributes: numRegs, in the hardware's 8-register granules 249 .. 256 all
+// allocate 256); a kernel that does not claim the whole file is NOT launched -- its callers fall back to the row-per-thread kernels -- and the reason is left in
+// fcl_last_error().  The default build has no packed-FP32 instruction to guard against (tests/test_cabi_cpu.py) and skips the check.
 template <typename K>
 static bool ks_claims_simd(K kernel, const char* name) {
+#ifndef FCL_KS_EXCLUSIVE
+    return true;  // (no packed-FP32 instructions in this build: nothing to guard -- see ks_exclusive())
+#endif
     static const int guard = tunable("KS_GUARD", 1);
     if (!guard) return true;
     static std::mutex mu;

@@ -999,11 +999,11 @@ static int te_losses(fcl_te& E, const fcl_te_knowledge_t* know) {
                                cf.share_proj ? "enc.convs_proj.0" : "enc.convs_proj.2"};
     const std::string lp[2] = {cf.share_proj ? "dec.lstm_proj" : "dec.lstm0_proj", cf.share_proj ? "dec.lstm_proj" : "dec.lstm1_proj"};
     auto pp = [&](int i) { return cf.share_proj ? std::string("dec.post_proj") : ("dec.post" + std::to_string(i) + "_proj"); };
-    // FCL_TE_R6: bit 0 = the late group is enqueued BEFORE the student's stream's own terms (it then runs beside them: -0.15 ms per KD update on one box, and
-    // OFF: in the FIRST update of a fresh engine the two mel terms' gradients then came out wrong in lanes 48 - 63 of single waves in ~10 % of the runs --
-    // the signature of the round-5 "DPP" finding in a kernel without DPP; DESIGN §4c, profiles/r6_lanes48_63_loss_kernel.log); bit 1 = the prosody embedding
-    // terms join the late group (their gradients are wanted at backward stage 2)
-    static const int r6 = tunable("TE_R6", 2);
+    // FCL_TE_R6: bit 0 = the late group is enqueued BEFORE the student's stream's own terms, so that it runs beside them (-0.15 ms per KD update, same-box A/B); bit 1 =
+    // the prosody embedding terms join the late group (their gradients are wanted at backward stage 2).  (Bit 0 was off for most of round 6: beside the late group's
+    // GEMMs the loss kernel's packed-FP32 arithmetic came out stale in lanes 48 - 63 in ~10 % of fresh engines' first updates -- DESIGN 4c; the library is built
+    // without packed-FP32 instructions since.)
+    static const int r6 = tunable("TE_R6", 3);
     auto late_group = [&]() -> int {  // the KD terms whose gradients the backward needs LATE run on the weight-gradient stream beside the frame-level terms and the postnet's backward
         const bool fork = cf.pred_stream && c.save && cf.late_losses;
         hipStream_t saved = E.cur;

@@ -298,13 +298,13 @@ def test_bilstm_group_kernel_more_workgroups_than_cus(ops):
 
 
 def test_bilstm_group_kernel_beside_another_streams_work(ops):
-    """Round 5: the lane-split BiLSTM kernels reduce with DPP.  With the device to itself they are exact; beside another stream's kernels lanes 48 - 63 of a
-    partial sum were read before they were written -- 1e-2 errors in 299 of 300 launches (`tools/stress_bilstm_concurrent.py`).  The root cause is NOT
-    established: explicit wait states tied to the DPP sources did not remove it (csrc/bilstm.hip, HISTORY "round 5").  What removes it is keeping foreign waves
-    off the SIMD: `ks_exclusive()` makes the code object claim the whole register file (256 VGPRs); round 6 verifies that claim at run time
-    (`ks_claims_simd`: hipFuncGetAttributes before the first launch, fall-back to the row-per-thread kernels otherwise) and in the code object's metadata
-    (tests/test_cabi_cpu.py).  Every launch of the H = 256 forward and reverse pass beside a stream of H = 128 recurrences, in both orders of submission, must
-    equal the serial result bit for bit, and the status word stays clear; then the same for the H = 128 TRAINING pair (forward + BPTT) beside H = 256 work."""
+    """Rounds 5 - 6.  With the device to itself the lane-split BiLSTM kernels are exact; beside another stream's GEMMs they returned 1e-2 errors in lanes 48 - 63 of
+    single waves in 299 of 300 launches (`tools/stress_bilstm_concurrent.py`).  Round 5 kept foreign waves off their SIMDs; round 6 found the cause -- packed-FP32
+    VALU results go stale in the wave's last quarter while another wave of the SIMD issues MFMAs (`tools/hazard_trigger_scan.py`, `profiles/r6_packed_fp32_hazard_ab.log`) --
+    and builds the library without packed-FP32 instructions (csrc/Makefile NOPK; tests/test_cabi_cpu.py disassembles it), so the kernels share their SIMDs again and THIS
+    test is the functional guard: every launch of the H = 256 forward and reverse pass beside a stream of H = 128 recurrences (each with its two input-projection
+    GEMMs), in both orders of submission, must equal the serial result bit for bit, and the status word stays clear; then the same for the H = 128 TRAINING pair
+    (forward + BPTT) beside H = 256 work."""
     g = torch.Generator().manual_seed(3)
 
     def case(B, T, C, H):
