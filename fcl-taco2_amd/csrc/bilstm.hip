@@ -818,8 +818,8 @@ static bool group_ok(int B, int H, void* ws, size_t ws_bytes, const unsigned int
     if (!enabled || H != 256 || !ws || ws_bytes < bilstm_group_workspace_bytes(B, H) || !status) return false;  // no status word, no spinning kernel
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-    // The grid must FIT the device (one 512-thread workgroup per CU; the lane-split form claims the CU's whole register file, so each workgroup needs a CU of
-    // its own).  That does not make the group's members co-resident beside other streams' kernels: a member may wait for a CU a foreign workgroup holds, and
+    // The grid must FIT the device (one 512-thread workgroup per CU: two waves per SIMD at 168 - 194 VGPRs leave no room for a second one of these;
+    // other streams' smaller waves may share the SIMDs since round 6).  That does not make the group's members co-resident beside other streams' kernels: a member may wait for a CU a foreign workgroup holds, and
     // the members already resident spin meanwhile.  Progress then rests on the foreign kernels finishing (they never wait for these), on in-order dispatch of
     // this grid, and on the bounded spin: after 2^22 polls a workgroup gives up and raises FCL_STATUS_GROUP_TIMEOUT -- the optimizer skips that update ON THE
     // DEVICE and the step's LossReport.resolve() raises FclError with the status text (training.py), so starvation is loud, never a silently wrong gradient.
