@@ -541,7 +541,7 @@ def train_workload(args, rank, world, dev, dist):
             sk.close()
             dist1.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
             eng.buckets = GradBuckets(eng.gflat, eng.buckets.bounds, None, force=True)
-            for _ in range(max(2, warmup, GradBuckets.TRIAL_WARMUP + 2 * GradBuckets.TRIAL_UPDATES + 1)):  # (the placement trial completes before the clock starts)
+            for _ in range(max(2, warmup, GradBuckets.TRIAL_TOTAL + 1)):  # (the placement trial completes before the clock starts)
                 step()
             dts_dp = timed_regions(region, lambda: torch.cuda.synchronize(), max(3, args.regions // 2))
             dp_sched = {"ms_per_step": 1e3 * median(dts_dp) / steps, "collectives_issued": eng.buckets.collectives, "inline": eng.buckets.inline,

@@ -92,8 +92,8 @@ class GradBuckets(object):
         # weight-gradient stream (4.8 ms busy of a 9.6 ms KD update; the four buckets of FCL-taco2-S are 6.5 MB each, of FCL-taco2-T 29 MB) --,
         # async (overlapped on the backend's stream, at the price of that fifth queue) for anything larger.  Unmeasured on a multi-GPU node.
         # Round 6: "auto" DECIDES BY MEASUREMENT on the job it runs in.  No 8-GPU node has been available to tune the placement on, and on one
-        # GPU the wire is free, so the first updates of a job with a real group time both forms -- after `TRIAL_WARMUP` updates the placement alternates
-        # for 2 x `TRIAL_UPDATES` updates, each update's wall time (finish() to finish(), device events) is booked to the form it ran under, the medians
+        # GPU the wire is free, so the first updates of a job with a real group time both forms -- after `TRIAL_WARMUP` updates the placement runs three blocks
+        # of `TRIAL_UPDATES` updates (stream-ordered, backend stream, stream-ordered), each update's wall time (finish() to finish(), device events) is booked to the form it ran under, the medians
         # are MAX-reduced over the ranks (one 2-float collective, once: every rank takes the same decision) and the faster form is kept; the choice,
         # both medians and the per-bucket wire times of the stream-ordered form are in `schedule()` (bench.py prints them as `dp_schedule`).
         env = os.environ.get("FCL_DP_INLINE", "auto")
@@ -104,14 +104,15 @@ class GradBuckets(object):
         self.auto = env == "auto" and self.active and (self.avg or not flat.is_cuda)
         self.forms_used = []                   # the placement of every update so far (tests read it)
         self.updates = 0                       # finish() calls that reduced
-        self.trial = {"inline": [], "async": []}
+        self.trial = {"inline": [], "async": [], "inline2": []}
         self.decision = None if self.auto else ("inline" if self.inline else "async")
         self.decided_at = None
         self._prev_mark = None                 # device event / host time of the previous finish()
         self._wire = {}                        # bucket -> [(start event, end event)] of its stream-ordered collectives during the trial
         self.wire_ms = {}
 
-    TRIAL_WARMUP, TRIAL_UPDATES = 2, 4
+    TRIAL_WARMUP, TRIAL_UPDATES, TRIAL_BLOCKS = 3, 3, 3  # warm-up, updates per block, blocks: stream-ordered | backend stream | stream-ordered
+    TRIAL_TOTAL = TRIAL_WARMUP + TRIAL_UPDATES * TRIAL_BLOCKS
 
     def _form_now(self):
         """The placement of the CURRENT update: the decision once taken, else the trial's -- warm-up and a block of TRIAL_UPDATES updates stream-ordered, then a
@@ -119,7 +120,8 @@ class GradBuckets(object):
         would tax the stream-ordered updates next to it; the first update of each block is the transition and is not booked)."""
         if self.decision is not None or not self.auto:
             return self.decision or ("inline" if self.inline else "async")
-        return "inline" if self.updates < self.TRIAL_WARMUP + self.TRIAL_UPDATES else "async"
+        blk = (self.updates - self.TRIAL_WARMUP) // self.TRIAL_UPDATES if self.updates >= self.TRIAL_WARMUP else 0
+        return "async" if blk == 1 else "inline"  # A B A: the two stream-ordered blocks bracket the backend-stream block, so a drift of the job's own pace cannot pick the winner
 
     def _mark(self):
         if self.flat.is_cuda:
@@ -143,28 +145,31 @@ class GradBuckets(object):
 
         mark = self._mark()
         u = self.updates
-        first_of_block = u in (self.TRIAL_WARMUP, self.TRIAL_WARMUP + self.TRIAL_UPDATES)
+        first_of_block = u >= self.TRIAL_WARMUP and (u - self.TRIAL_WARMUP) % self.TRIAL_UPDATES == 0
         if self._prev_mark is not None and u >= self.TRIAL_WARMUP and not first_of_block:
-            self.trial[self._form_now()].append((self._prev_mark, mark))
+            blk = (u - self.TRIAL_WARMUP) // self.TRIAL_UPDATES
+            self.trial["async" if blk == 1 else ("inline" if blk == 0 else "inline2")].append((self._prev_mark, mark))
         self._prev_mark = mark
         self.updates = u + 1
-        if self.updates < self.TRIAL_WARMUP + 2 * self.TRIAL_UPDATES:
+        if self.updates < self.TRIAL_TOTAL:
             return
         med = {}
         for k, pairs in self.trial.items():
             ms = sorted(self._elapsed_ms(a, b) for a, b in pairs)
             med[k] = ms[len(ms) // 2] if ms else float("inf")
-        t = torch.tensor([med["inline"], med["async"]], dtype=torch.float32, device=self.flat.device if self.avg else "cpu")
+        t = torch.tensor([med["inline"], med["async"], med.get("inline2", float("inf"))], dtype=torch.float32, device=self.flat.device if self.avg else "cpu")
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        m_in, m_as = (float(v) for v in t.tolist())
-        self.decision = "inline" if m_in <= m_as else "async"
+        m_in, m_as, m_in2 = (float(v) for v in t.tolist())
+        # the backend's stream is taken only if it beats BOTH stream-ordered blocks around it (a one-sided comparison picked it on a one-rank group whose first
+        # block was still warming up: 10.35 vs 9.65 ms in the trial, 10.2 against 9.0 ms in steady state)
+        self.decision = "async" if m_as < min(m_in, m_in2) else "inline"
         self.decided_at = self.updates
-        self.trial_ms = {"inline": m_in, "async": m_as}
+        self.trial_ms = {"inline": m_in, "async": m_as, "inline_after": m_in2}
         for i, pairs in self._wire.items():
             ms = sorted(self._elapsed_ms(a, b) for a, b in pairs)
             self.wire_ms[i] = ms[len(ms) // 2]
-        self._wire, self.trial = {}, {"inline": [], "async": []}
+        self._wire, self.trial = {}, {"inline": [], "async": [], "inline2": []}
         import logging
 
         logging.info("GradBuckets: collective placement decided after %d updates: %s (median update %.3f ms stream-ordered on the issuing stream, %.3f ms on the "
@@ -172,7 +177,7 @@ class GradBuckets(object):
 
     def schedule(self):
         """What bench.py prints as `dp_schedule.policy`."""
-        return {"policy": self.decision or "trial (%d of %d updates)" % (self.updates, self.TRIAL_WARMUP + 2 * self.TRIAL_UPDATES), "auto": bool(self.auto),
+        return {"policy": self.decision or "trial (%d of %d updates)" % (self.updates, self.TRIAL_TOTAL), "auto": bool(self.auto),
                 "decided_after_updates": self.decided_at, "trial_median_update_ms": getattr(self, "trial_ms", None),
                 "bucket_wire_ms": {str(k): v for k, v in sorted(self.wire_ms.items())}, "bucket_bytes": [int((self.bounds[i + 1] - self.bounds[i]) * self.flat.element_size())
                                                                                                          for i in range(len(self.bounds) - 1)],

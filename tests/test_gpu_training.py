@@ -985,12 +985,13 @@ def _nccl_one_rank_worker(port, q):
         os.environ.pop("FCL_DP_INLINE", None)
         from fcl_taco2_amd.training import GradBuckets
 
-        n_trial = GradBuckets.TRIAL_WARMUP + 2 * GradBuckets.TRIAL_UPDATES
+        n_trial = GradBuckets.TRIAL_TOTAL
         l3, w3, e3 = run(n_steps=n_trial + 2)
         sched = e3.buckets.schedule()
         assert e3.buckets.auto and sched["policy"] in ("inline", "async") and sched["decided_after_updates"] == n_trial, sched
         fu = e3.buckets.forms_used
-        assert fu[:n_trial] == ["inline"] * (GradBuckets.TRIAL_WARMUP + GradBuckets.TRIAL_UPDATES) + ["async"] * GradBuckets.TRIAL_UPDATES and fu[n_trial:] == [sched["policy"]] * 2, fu
+        w_, k_ = GradBuckets.TRIAL_WARMUP, GradBuckets.TRIAL_UPDATES
+        assert fu[:n_trial] == ["inline"] * (w_ + k_) + ["async"] * k_ + ["inline"] * k_ and fu[n_trial:] == [sched["policy"]] * 2, fu
         assert len(sched["bucket_wire_ms"]) == 4 and all(v >= 0 for v in sched["bucket_wire_ms"].values()), sched
         assert abs(l3[0] - l0[0]) <= 1e-9 * abs(l0[0]) and all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l3)), (l0, l3)
         os.environ["FCL_DP_INLINE"] = "1"

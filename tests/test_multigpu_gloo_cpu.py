@@ -106,7 +106,7 @@ def _grad_worker(rank, world, port, q):
     # round 6: the self-deciding placement -- warm-up, alternating trial, one decision shared by the ranks, correct means throughout
     g3 = torch.zeros(int(offs[-1]))
     b3 = GradBuckets(g3, bounds)
-    n_trial = GradBuckets.TRIAL_WARMUP + 2 * GradBuckets.TRIAL_UPDATES
+    n_trial = GradBuckets.TRIAL_TOTAL
     means_ok = True
     for u in range(n_trial + 2):
         g3.copy_(torch.from_numpy(np.random.RandomState(1000 * u + rank).randn(int(offs[-1])).astype(np.float32)))
@@ -146,9 +146,9 @@ def test_two_rank_gradient_buckets_average():
     for ok, auto, forms, sched in (pol0, pol1):
         assert ok and auto
         w, k = GradBuckets.TRIAL_WARMUP, GradBuckets.TRIAL_UPDATES
-        assert forms[: w + k] == ["inline"] * (w + k) and forms[w + k : w + 2 * k] == ["async"] * k  # a block of each form
-        assert sched["policy"] in ("inline", "async") and sched["decided_after_updates"] == w + 2 * k and forms[w + 2 * k :] == [sched["policy"]] * 2
-        assert set(sched["trial_median_update_ms"]) == {"inline", "async"} and sched["world"] == 2 and len(sched["bucket_bytes"]) == len(bounds) - 1
+        assert forms[: w + 3 * k] == ["inline"] * (w + k) + ["async"] * k + ["inline"] * k  # stream-ordered | backend stream | stream-ordered
+        assert sched["policy"] in ("inline", "async") and sched["decided_after_updates"] == w + 3 * k and forms[w + 3 * k :] == [sched["policy"]] * 2
+        assert set(sched["trial_median_update_ms"]) == {"inline", "async", "inline_after"} and sched["world"] == 2 and len(sched["bucket_bytes"]) == len(bounds) - 1
     assert pol0[3]["policy"] == pol1[3]["policy"] and pol0[3]["trial_median_update_ms"] == pol1[3]["trial_median_update_ms"]
     assert np.array_equal(acc0, acc1) and np.allclose(acc0, (s0 + s1) / 2, atol=1e-6)  # accum_grad=2: mean over ranks of the accumulated sums, once
     assert bounds[0] == 0 and bounds[-1] == g0.shape[0] and all(a <= b for a, b in zip(bounds, bounds[1:])) and len(bounds) == len(_GROUPS) + 1
