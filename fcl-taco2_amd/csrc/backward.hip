@@ -617,7 +617,7 @@ __global__ void bn_act_fwd_kernel(const float* __restrict__ z, const float* __re
         float v = (z[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
         if (act == FCL_ACT_RELU) v = fmaxf(v, 0.f);
         else if (act == FCL_ACT_TANH) v = tanh_f(v);
-        y_act[i] = v;
+        if (y_act) y_act[i] = v;  // (null: a forward that keeps nothing for a backward -- the frozen KD teacher -- writes the dropped output alone)
         const float vd = keep ? (keep[i] ? v * scale : 0.f) : v;
         if (y_drop) y_drop[i] = vd;
         if (yp) store_p32(yp, C >> 5, (int)(i / C), c, vd);  // the block's output (after dropout) as the next conv's pre-split operand
@@ -961,7 +961,7 @@ int fcl_bn_stats_ws_fwd(const float* z, int m, int c, float eps, float momentum,
 
 int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
                    float* y_act, float* y_drop, uint16_t* yp, int m, int c, int act, fcl_stream_t stream) {
-    FCL_REQUIRE(z && mean && invstd && gamma && beta && y_act && m >= 0 && c > 0 && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID,
+    FCL_REQUIRE(z && mean && invstd && gamma && beta && (y_act || y_drop || yp) && m >= 0 && c > 0 && act >= FCL_ACT_NONE && act <= FCL_ACT_TANH, FCL_ERR_INVALID,
                 "bn_act_fwd: bad arguments");
     FCL_REQUIRE(!keep || y_drop, FCL_ERR_INVALID, "bn_act_fwd: a keep mask needs y_drop");
     FCL_REQUIRE(!yp || ((c & 31) == 0 && (reinterpret_cast<uintptr_t>(yp) & 127u) == 0), FCL_ERR_SHAPE, "bn_act_fwd: planes need C %% 32 == 0, 128-byte aligned");

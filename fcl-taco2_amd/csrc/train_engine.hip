@@ -436,7 +436,8 @@ int conv_bn_fwd(E_t& E, const float* x, const uint16_t* xp, int m, const std::st
     float *mean = f32(E, cout), *invstd = f32(E, cout);
     TE_L(fcl_bn_stats_ws_fwd(z, m, cout, BN_EPS, BN_MOMENTUM, mean, invstd, E.B.at(prefix + ".1.running_mean"), E.B.at(prefix + ".1.running_var"), bnws(E), E.cur));
     const float ks = keep ? 1.0f / (1.0f - p_drop) : 1.0f;
-    float* y_act = f32(E, m, cout);
+    // (round 6) a forward that saves nothing for a backward (the frozen KD teacher) and drops: the pre-dropout activation has no reader -- one [m, cout] write less per block
+    float* y_act = (E.c.save || !keep) ? f32(E, m, cout) : nullptr;
     float* y_drop = keep ? f32(E, m, cout) : nullptr;
     uint16_t* yp = (want_planes && cout % 32 == 0) ? pl16(E, m, cout) : nullptr;
     TE_L(fcl_bn_act_fwd(z, mean, invstd, E.Pm(prefix + ".1.weight").p, E.Pm(prefix + ".1.bias").p, keep, ks, y_act, y_drop, yp, m, cout, act, E.cur));

@@ -516,6 +516,7 @@ int fcl_bn_stats_fwd(const float* z, int m, int c, float eps, float momentum, fl
                      double* workspace, fcl_stream_t stream);
 int fcl_bn_stats_ws_fwd(const float* z, int m, int c, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var,
                      double* zero_workspace, fcl_stream_t stream);
+/* (round 6) y_act may be NULL when y_drop / yp receive the result (a forward that keeps nothing for a backward). */
 int fcl_bn_act_fwd(const float* z, const float* mean, const float* invstd, const float* gamma, const float* beta, const uint8_t* keep, float keep_scale,
                    float* y_act, float* y_drop, uint16_t* yp /* optional P32 planes of the block output (after dropout), C % 32 == 0 */, int m, int c, int act,
                    fcl_stream_t stream);
