@@ -817,9 +817,9 @@ static int te_forward(fcl_te& E) {
     TE_L(fcl_linear_planes_fwd(att_p, C / 32, w0_att_p, b0s, G0, 4 * U, nullptr, N, 4 * U, C, FCL_ACT_NONE, E.cur));  // hoisted att_c share of the layer-0 gates
     float* F0 = f32(E, N, O);
     TE_L(fcl_linear_planes_fwd(att_p, C / 32, wf_att_p, nullptr, F0, O, nullptr, N, O, C, FCL_ACT_NONE, E.cur));
-    for (int q = 0; q < 4; ++q) {
-        c.S0[q] = f32(E, F, q == 0 ? 4 * U : U);  // gates, c_new, c_old, h_old
-        c.S1[q] = f32(E, F, q == 0 ? 4 * U : U);
+    for (int q = 0; q < 4; ++q) {  // gates, c_new, c_old, h_old: what the BPTT reads -- nothing of it for a forward without a backward (the frozen KD teacher)
+        c.S0[q] = c.save ? f32(E, F, q == 0 ? 4 * U : U) : nullptr;
+        c.S1[q] = c.save ? f32(E, F, q == 0 ? 4 * U : U) : nullptr;
     }
     c.h0_all = f32(E, F, U);
     c.h1_all = f32(E, F, U);

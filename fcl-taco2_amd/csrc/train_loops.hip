@@ -37,7 +37,15 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
     FCL_REQUIRE(a && a->live_rows_host && a->p1d && a->g0 && a->w0_pre && a->w0_hh && a->w0_pos && a->dur && a->w1_ih && a->w1_hh && a->b1,
                 FCL_ERR_INVALID, "decoder_train_fwd: null argument");
     FCL_REQUIRE(a->n > 0 && a->lmax > 0 && a->u > 0 && a->p > 0, FCL_ERR_SHAPE, "decoder_train_fwd: bad sizes");
-    FCL_REQUIRE(a->h0_all && a->h1_all && a->s0[0] && a->s1[0], FCL_ERR_INVALID, "decoder_train_fwd: outputs missing");
+    FCL_REQUIRE(a->h0_all && a->h1_all, FCL_ERR_INVALID, "decoder_train_fwd: outputs missing");
+    // (round 6) s0 / s1 all NULL: a forward that keeps nothing for a backward (the frozen KD teacher: 1.5 GB of gate / state stores per pass at FCL-taco2-T width that
+    // nobody read); otherwise all eight tensors
+    {
+        int have = 0;
+        for (int q = 0; q < 4; ++q) have += (a->s0[q] != nullptr) + (a->s1[q] != nullptr);
+        FCL_REQUIRE(have == 0 || have == 8, FCL_ERR_INVALID, "decoder_train_fwd: the saved tensors s0 / s1 come all together or not at all");
+    }
+    const bool keep = a->s0[0] != nullptr;
     FCL_REQUIRE((a->zk_h0 == nullptr) == (a->zk_c0 == nullptr) && (a->zk_h0 == nullptr) == (a->zk_h1 == nullptr) &&
                     (a->zk_h0 == nullptr) == (a->zk_c1 == nullptr), FCL_ERR_INVALID, "decoder_train_fwd: the four zoneout masks come together");
     FCL_REQUIRE(a->workspace && a->workspace_bytes >= fcl_decoder_train_workspace_bytes(a->n, a->u), FCL_ERR_WORKSPACE, "decoder_train_fwd: workspace too small");
@@ -90,10 +98,12 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
         l0.out2 = a->h0_all + off * U;
         l0.out2_row_mul = 1;
         l0.ld2 = U;
-        l0.save_gates = a->s0[0] + off * 4 * U;
-        l0.save_c_new = a->s0[1] + off * U;
-        l0.save_c_old = a->s0[2] + off * U;
-        l0.save_h_old = a->s0[3] + off * U;
+        if (keep) {
+            l0.save_gates = a->s0[0] + off * 4 * U;
+            l0.save_c_new = a->s0[1] + off * U;
+            l0.save_c_old = a->s0[2] + off * U;
+            l0.save_h_old = a->s0[3] + off * U;
+        }
         return l0;
     };
     auto layer1 = [&](int t) {
@@ -120,10 +130,12 @@ int fcl_decoder_train_fwd(const fcl_decoder_train_t* a, fcl_stream_t stream) {
         l1.out2 = a->h1_all + off * U;
         l1.out2_row_mul = 1;
         l1.ld2 = U;
-        l1.save_gates = a->s1[0] + off * 4 * U;
-        l1.save_c_new = a->s1[1] + off * U;
-        l1.save_c_old = a->s1[2] + off * U;
-        l1.save_h_old = a->s1[3] + off * U;
+        if (keep) {
+            l1.save_gates = a->s1[0] + off * 4 * U;
+            l1.save_c_new = a->s1[1] + off * U;
+            l1.save_c_old = a->s1[2] + off * U;
+            l1.save_h_old = a->s1[3] + off * U;
+        }
         return l1;
     };
     // Under teacher forcing layer 0 never waits for layer 1 (its input is the ground-truth frame's prenet output and its own state), so the two

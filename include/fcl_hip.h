@@ -526,7 +526,8 @@ int fcl_bn_bwd(const float* dy, const float* z, const float* mean, const float* 
                fcl_stream_t stream);
 /* ---- the training step's time loops, enqueued by ONE call each (H13; decoder_sa.py:472-515, encoder_sa.py:143-146) ----------------------------
  * Cells are step-major: rows sorted by duration descending, cell (t, m) at offset(t) + m with offset(t) = sum_{t' < t} live_rows[t'].
- * s0 / s1 (decoder layers) and s (BiLSTM direction) are the saved tensors {gates [.,4U], c_new, c_old, h_old [.,U]} fcl_lstm_cell_bwd needs. */
+ * s0 / s1 (decoder layers) and s (BiLSTM direction) are the saved tensors {gates [.,4U], c_new, c_old, h_old [.,U]} fcl_lstm_cell_bwd needs.
+ * fcl_decoder_train_fwd (round 6): s0 and s1 may ALL be NULL -- a forward that keeps nothing for a backward (the frozen KD teacher) then skips those stores. */
 typedef struct {
     int n, lmax, u, p;              /* sorted rows, steps, dunits, prenet units */
     const int32_t* live_rows_host;  /* [lmax] HOST */
