@@ -541,6 +541,7 @@ class _NativeStep(object):
         _lib.check(lib.fcl_te_finalize(h, eng.status.data_ptr()))
         self.side = torch.cuda.ExternalStream(lib.fcl_te_side_stream(h), device=eng.dev)
         self._hosts = []  # pinned landing buffers of the last steps' loss sums (kept until their copies have certainly run)
+        self.stage_hook = None  # optional callable(stage) run after backward stage 0 .. 3 has been enqueued (KDPipeline)
         self._keep = None
 
     def __del__(self):
@@ -643,9 +644,14 @@ class _NativeStep(object):
             rep = LossReport(None, self.loss_names, host=(host, stat))
             eng._native_nbt()
             bucket(0)
+            hook = self.stage_hook  # KDPipeline: the frozen teacher's next forward may be enqueued between two backward stages
+            if hook is not None:
+                hook(0)
             for stage in (1, 2, 3):
                 self._lib.check(lib.fcl_te_backward_stage(self.h, stage, s))
                 bucket(stage)
+                if hook is not None:
+                    hook(stage)
             self._lib.check(lib.fcl_te_join(self.h, s))
         return rep
 
@@ -1850,6 +1856,7 @@ class TrainEngine(object):
         return rep
 
 
+KD_TEACHER_AT_DEFAULT = -1  # where the next batch's frozen-teacher forward is enqueued: -1 = at the update's start, 0 .. 3 = behind that backward stage
 KD_TEACHER_CUS_DEFAULT = 0  # compute units the frozen teacher's stream may use beside the student's update (0 = all; measured in DESIGN §5)
 
 
@@ -1873,6 +1880,7 @@ class KDPipeline(object):
         else:
             self.side = torch.cuda.Stream(device=student_engine.dev)
         self.teacher_cus = n_cus
+        self.teacher_at = int(os.environ.get("FCL_KD_TEACHER_AT", str(KD_TEACHER_AT_DEFAULT)))
         self.pending = None  # (batch id, knowledge, event)
         # both engines native (and train form): the knowledge stays in the teacher engine's arena, cell-major (no frame round trip, no torch tensors)
         self.native = mode == "train" and teacher_engine.native is not None and student_engine.native is not None
@@ -1892,10 +1900,30 @@ class KDPipeline(object):
         return id(batch), know, ev
 
     def step(self, batch, next_batch=None):
-        """One student update on `batch`; `next_batch` (if given) starts its teacher forward now, concurrently with this update."""
+        """One student update on `batch`; `next_batch` (if given) starts its teacher forward concurrently with this update: at the update's start
+        (teacher_at = -1) or, on the native step, once backward stage `teacher_at` (0 .. 3) of this update has been enqueued -- the teacher's stream then
+        waits for that stage, and its forward runs beside the rest of this update and the beginning of the next (its outputs are first read by the next
+        update's loss phase)."""
         if self.pending is None or self.pending[0] != id(batch):
             self.pending = self._launch_teacher(batch)
         _, know, ev = self.pending
-        self.pending = self._launch_teacher(next_batch) if next_batch is not None else None
-        torch.cuda.current_stream(self.eng.dev).wait_event(ev)
-        return self.eng.train_step(batch, know, mode=self.mode)
+        main = torch.cuda.current_stream(self.eng.dev)
+        if self.teacher_at < 0 or not self.native or next_batch is None:
+            self.pending = self._launch_teacher(next_batch) if next_batch is not None else None
+            main.wait_event(ev)
+            return self.eng.train_step(batch, know, mode=self.mode)
+        self.pending = None
+
+        def hook(stage):
+            if stage == self.teacher_at:
+                self.pending = self._launch_teacher(next_batch)
+
+        main.wait_event(ev)
+        self.eng.native.stage_hook = hook
+        try:
+            rep = self.eng.train_step(batch, know, mode=self.mode)
+        finally:
+            self.eng.native.stage_hook = None
+        if self.pending is None:  # the update did not go through the native stages (accumulation micro-batch, fallback): launch now
+            self.pending = self._launch_teacher(next_batch)
+        return rep
