@@ -86,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 419  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 420  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -152,6 +152,7 @@ SIGNATURES = {
     "fcl_te_finalize": (_I, [_P, _P]),
     "fcl_te_params_changed": (_I, [_P]),
     "fcl_te_side_stream": (_P, [_P]),
+    "fcl_te_place_streams": (_I, [_P, _P, C.POINTER(C.c_int)]),
     "fcl_te_knowledge": (_I, [_P, C.POINTER(TeBatch), C.c_uint32, C.POINTER(TeKnowledge), _P]),
     "fcl_te_forward_backward": (_I, [_P, C.POINTER(TeBatch), C.POINTER(TeKnowledge), C.c_uint32, _P, _P, _P]),
     "fcl_te_backward_stage": (_I, [_P, _I, _P]),
@@ -249,6 +250,8 @@ SIGNATURES = {
     "fcl_linear2_fwd": (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
     "fcl_stream_create_cus": (_I, [_I, C.POINTER(C.c_void_p)]),
     "fcl_stream_destroy": (_I, [_P]),
+    "fcl_streams_share_pipe": (_I, [_P, _P, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "fcl_stream_create_apart": (_I, [C.POINTER(C.c_void_p), _I, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
     "fcl_prof_enable": (_I, [_I]),
     "fcl_prof_collect": (_I, [C.POINTER(ProfEntry), _I]),
 }

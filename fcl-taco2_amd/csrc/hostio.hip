@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "fcl_common.h"
@@ -38,9 +39,125 @@ __global__ __launch_bounds__(1024) void feed_copy_kernel(uint4* __restrict__ dst
     }
 }
 
+// ---- which streams share a compute pipe (round 6) ---------------------------------------------------------------------------------------------------
+// On MI355X the HSA queue behind a HIP stream sits on one of FOUR compute pipes (queue index mod 4, in order of queue creation in the process), and a pipe
+// advances one of its queues at a time: two chains of dependent launches on streams of the same pipe take 1.43x the time of one chain, on the same HSA queue
+// (more streams than GPU_MAX_HW_QUEUES) 2.0x, on different pipes 1.0x (tools/probe/queue_pipe_probe.hip, profiles/r6_queue_pipe_probe.log).  For the KD update
+// that is 8.4 ms against 12.7 ms (the frozen teacher's stream on the student's pipe), decided by how many streams the process happened to create before.  HIP
+// does not say which pipe a stream is on, so the library MEASURES: two short chains of ~20 us launches, alone and together.
+__global__ __launch_bounds__(256) void pipe_probe_kernel(float* p, int iters) {
+    float v = p[blockIdx.x * 256 + threadIdx.x];
+    for (int i = 0; i < iters; ++i) v = fmaf(v, 1.0000001f, 1e-7f);
+    p[blockIdx.x * 256 + threadIdx.x] = v;
+}
+
+namespace {
+constexpr int kProbeBlocks = 32, kProbeLaunches = 40, kProbeIters = 1200;
+
+struct ProbeBuf {
+    float* p[2] = {nullptr, nullptr};
+    int init() {
+        for (float*& q : p) {
+            FCL_HIP(hipMalloc(&q, kProbeBlocks * 256 * sizeof(float)));
+            FCL_HIP(hipMemset(q, 0, kProbeBlocks * 256 * sizeof(float)));
+        }
+        return 0;
+    }
+    ~ProbeBuf() {
+        for (float* q : p)
+            if (q) (void)hipFree(q);
+    }
+};
+
+// wall time of kProbeLaunches dependent launches on a (and, at the same time, on b when pair); the two streams are idle before and after
+int chain_ms(hipStream_t a, hipStream_t b, bool pair, const ProbeBuf& buf, double* ms) {
+    double best = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+        FCL_HIP(hipStreamSynchronize(a));
+        if (pair) FCL_HIP(hipStreamSynchronize(b));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int l = 0; l < kProbeLaunches; ++l) {
+            hipLaunchKernelGGL(pipe_probe_kernel, dim3(kProbeBlocks), dim3(256), 0, a, buf.p[0], kProbeIters);
+            if (pair) hipLaunchKernelGGL(pipe_probe_kernel, dim3(kProbeBlocks), dim3(256), 0, b, buf.p[1], kProbeIters);
+        }
+        FCL_HIP(hipStreamSynchronize(a));
+        if (pair) FCL_HIP(hipStreamSynchronize(b));
+        best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+    FCL_HIP(hipGetLastError());
+    *ms = best;
+    return 0;
+}
+
+int share_pipe(hipStream_t a, hipStream_t b, const ProbeBuf& buf, bool* shared, double* ratio) {
+    if (a == b) {
+        *shared = true;
+        if (ratio) *ratio = 2.0;
+        return 0;
+    }
+    double alone = 0.0, both = 0.0;
+    int rc = chain_ms(a, b, false, buf, &alone);
+    if (rc) return rc;
+    rc = chain_ms(a, b, true, buf, &both);
+    if (rc) return rc;
+    const double r = both / std::max(alone, 1e-6);
+    *shared = r > 1.2;  // measured: 1.00 - 1.01 apart, 1.42 - 1.44 same pipe, 2.00 same queue
+    if (ratio) *ratio = r;
+    return 0;
+}
+}  // namespace
+
 }  // namespace fcl
 
 extern "C" {
+
+/* Do two streams' queues sit on the same compute pipe?  Measured (two chains of 40 dependent ~20 us launches, alone and together: ~5 ms); both streams must be
+ * idle.  *ratio (optional) = pair time / alone: ~1.0 apart, ~1.43 same pipe, ~2.0 same hardware queue. */
+int fcl_streams_share_pipe(fcl_stream_t a, fcl_stream_t b, int* shared, double* ratio) {
+    FCL_REQUIRE(shared, FCL_ERR_INVALID, "streams_share_pipe: null argument");
+    ProbeBuf buf;
+    int rc = buf.init();
+    if (rc) return rc;
+    bool sh = false;
+    rc = share_pipe((hipStream_t)a, (hipStream_t)b, buf, &sh, ratio);
+    if (rc) return rc;
+    *shared = sh ? 1 : 0;
+    return 0;
+}
+
+/* A new stream whose queue shares a pipe with none of others[0 .. n): candidates are created until one measures apart from all of them (at most 12; the
+ * rejected ones are destroyed afterwards, not before -- a destroyed stream's queue slot would be handed out again).  n <= 3 can always be satisfied (four pipes);
+ * FCL_ERR_HIP when no candidate fits.  *tried (optional) = candidates created. */
+int fcl_stream_create_apart(const fcl_stream_t* others, int n, fcl_stream_t* out, int* tried) {
+    FCL_REQUIRE(out && n >= 0 && (others || n == 0), FCL_ERR_INVALID, "stream_create_apart: bad arguments");
+    ProbeBuf buf;
+    int rc = buf.init();
+    if (rc) return rc;
+    std::vector<hipStream_t> rejected;
+    hipStream_t good = nullptr;
+    int made = 0;
+    for (; made < 12 && !good; ++made) {
+        hipStream_t s = nullptr;
+        FCL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        bool clash = false;
+        for (int k = 0; k < n && !clash; ++k) {
+            rc = share_pipe((hipStream_t)others[k], s, buf, &clash, nullptr);
+            if (rc) break;
+        }
+        if (rc) {
+            rejected.push_back(s);
+            break;
+        }
+        if (clash) rejected.push_back(s);
+        else good = s;
+    }
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    if (tried) *tried = made;
+    if (rc) return rc;
+    FCL_REQUIRE(good, FCL_ERR_HIP, "stream_create_apart: no stream apart from the %d given ones in %d candidates", n, made);
+    *out = (fcl_stream_t)good;
+    return 0;
+}
 
 int fcl_stream_create_cus(int n_cus, fcl_stream_t* out) {
     FCL_REQUIRE(out, FCL_ERR_INVALID, "stream_create_cus: null argument");

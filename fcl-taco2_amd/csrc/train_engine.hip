@@ -1604,6 +1604,22 @@ int fcl_te_params_changed(fcl_te_t* E) {
 }
 
 fcl_stream_t fcl_te_side_stream(fcl_te_t* E) { return E ? (fcl_stream_t)E->side : nullptr; }
+
+/* Before the first pass: if the engine's weight-gradient stream shares a compute pipe with the stream the caller will run the passes on (measured,
+ * fcl_streams_share_pipe), it is replaced by one that does not.  *moved (optional) = 1 when it was replaced.  The old handle is invalid afterwards. */
+int fcl_te_place_streams(fcl_te_t* E, fcl_stream_t main_stream, int* moved) {
+    FCL_REQUIRE(E && E->finalized && E->side, FCL_ERR_INVALID, "fcl_te_place_streams: the engine is not finalized");
+    if (moved) *moved = 0;
+    int shared = 0;
+    TE_TRY(fcl_streams_share_pipe(main_stream, (fcl_stream_t)E->side, &shared, nullptr));
+    if (!shared) return 0;
+    fcl_stream_t others[1] = {main_stream}, fresh = nullptr;
+    TE_TRY(fcl_stream_create_apart(others, 1, &fresh, nullptr));
+    (void)hipStreamDestroy(E->side);
+    E->side = (hipStream_t)fresh;
+    if (moved) *moved = 1;
+    return 0;
+}
 int64_t fcl_te_last_launches(fcl_te_t* E) { return E ? E->last_launches : -1; }
 int64_t fcl_te_arena_bytes(fcl_te_t* E) { return E ? (int64_t)(E->work[0].cap + E->zero[0].cap + E->work[1].cap + E->zero[1].cap) : -1; }
 

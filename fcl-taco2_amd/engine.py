@@ -461,6 +461,9 @@ def capture(graph, stream, pool=None):
             graph.capture_end()
 
 
+_PLACE_STREAMS = int(os.environ.get("FCL_PLACE_STREAMS", "1")) != 0  # 0: streams as torch's pool hands them out (round 5 behaviour)
+
+
 def shared_streams(device, n):
     """The first `n` of this process's synthesis streams on `device` (created on first use, then reused by every runner set and by the decode
     driver).  This device runs FOUR concurrently active HIP queues well and falls off a cliff at the fifth, and the runtime
@@ -473,7 +476,12 @@ def shared_streams(device, n):
     if not pool:  # developer aid: FCL_STREAM_SKIP=k leaves the first k streams of torch's per-device pool unused (which hardware queue a stream lands on)
         _SHARED_STREAMS[key + ("skipped",)] = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("FCL_STREAM_SKIP", "0")))]
     while len(pool) < n:
-        pool.append(torch.cuda.Stream(device=dev))
+        # round 6: the first four pass streams are MEASURED onto four different compute pipes (ops.stream_apart; two passes on one pipe run as on one queue:
+        # the "cliff at the fifth stream" is two streams on one pipe, and which streams share one depends on every stream the process created before)
+        if len(pool) < 4 and _PLACE_STREAMS:
+            pool.append(ops.stream_apart(pool, device=dev))
+        else:
+            pool.append(torch.cuda.Stream(device=dev))
     return pool[:n]
 
 

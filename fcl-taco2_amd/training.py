@@ -539,6 +539,12 @@ class _NativeStep(object):
                 assert v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
                 _lib.check(lib.fcl_te_bind_buffer(h, k.encode(), v.data_ptr()))
         _lib.check(lib.fcl_te_finalize(h, eng.status.data_ptr()))
+        self.side_moved = False
+        if int(os.environ.get("FCL_PLACE_STREAMS", "1")):  # the weight-gradient stream on a compute pipe of its own (fcl_hip.h "Compute pipes")
+            moved = C.c_int(0)
+            with torch.cuda.device(eng.dev):
+                _lib.check(lib.fcl_te_place_streams(h, C.c_void_p(torch.cuda.current_stream(eng.dev).cuda_stream), C.byref(moved)))
+            self.side_moved = bool(moved.value)
         self.side = torch.cuda.ExternalStream(lib.fcl_te_side_stream(h), device=eng.dev)
         self._hosts = []  # pinned landing buffers of the last steps' loss sums (kept until their copies have certainly run)
         self.stage_hook = None  # optional callable(stage) run after backward stage 0 .. 3 has been enqueued (KDPipeline)
@@ -734,7 +740,11 @@ class TrainEngine(object):
         # weight gradients are off the critical path of backward (only the input-gradient chain is sequential): they are enqueued on a side
         # stream and joined at the end of backward / before a bucket's all-reduce
         self.overlap_dw = overlap_dw
-        self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
+        if overlap_dw and int(os.environ.get("FCL_PLACE_STREAMS", "1")):
+            with torch.cuda.device(self.dev):
+                self.side = ops.stream_apart([torch.cuda.current_stream(self.dev)], device=self.dev)  # on a compute pipe of its own (ops.stream_apart)
+        else:
+            self.side = torch.cuda.Stream(device=self.dev) if overlap_dw else None
         # The three predictors feed nothing but their own losses in a teacher-forced step (the variance embeddings take the ground-truth pitch /
         # energy): their forward runs beside the decoder's forward and their backward beside the decoder's backward -- ~90 small dependent
         # launches off the main stream's chain -- on the weight-gradient stream, which is idle through the forward and far from full in the
@@ -1877,6 +1887,17 @@ class KDPipeline(object):
                 _lib.check(_lib.load().fcl_stream_create_cus(n_cus, C.byref(h)))
             self._side_handle = h  # lives as long as the pipeline (the process): the teacher's arena may be read on it until the last update
             self.side = torch.cuda.ExternalStream(h.value, device=student_engine.dev)
+        elif int(os.environ.get("FCL_PLACE_STREAMS", "1")):
+            # round 6: the frozen teacher's stream is measured onto a compute pipe of its own, apart from the student's stream and the student's weight-gradient
+            # stream (ops.stream_apart): on a shared pipe the KD update takes 12.7 ms (with the student's stream) or 9.4 ms (with its weight-gradient stream)
+            # instead of 8.4 -- and which pipe a new stream lands on depends on how many streams the process created before
+            with torch.cuda.device(student_engine.dev):
+                busy = [torch.cuda.current_stream(student_engine.dev)]
+                if student_engine.native is not None:
+                    busy.append(student_engine.native.side)
+                elif getattr(student_engine, "side", None) is not None:
+                    busy.append(student_engine.side)
+                self.side = ops.stream_apart(busy, device=student_engine.dev)
         else:
             self.side = torch.cuda.Stream(device=student_engine.dev)
         self.teacher_cus = n_cus

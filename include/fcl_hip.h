@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 419
+#define FCL_ABI_VERSION 420
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -752,6 +752,14 @@ int fcl_pwg_last_fwd(const float* skips, float scale, const uint16_t* w1p, const
  * device's CU count: an ordinary non-blocking stream. */
 int fcl_stream_create_cus(int n_cus, fcl_stream_t* out);
 int fcl_stream_destroy(fcl_stream_t stream);
+/* Compute pipes (round 6).  The queue behind a HIP stream sits on one of MI355X's four compute pipes (queue index mod 4, in creation order within the process) and
+ * a pipe advances one of its queues at a time: two chains of dependent launches take 1.0x the time of one when their streams are on different pipes, 1.43x on
+ * the same pipe, 2.0x on the same hardware queue (more streams than GPU_MAX_HW_QUEUES).  HIP does not report the pipe; these two entries measure it (two chains
+ * of 40 dependent ~20 us launches, alone and together, ~5 ms per pair; the streams must be idle).
+ *   fcl_streams_share_pipe: *shared = 1 when a and b contend; *ratio (optional) = pair time / alone.
+ *   fcl_stream_create_apart: a new stream apart from every others[k] (<= 12 candidates; n <= 3 can always be met); *tried (optional) = candidates created. */
+int fcl_streams_share_pipe(fcl_stream_t a, fcl_stream_t b, int* shared, double* ratio);
+int fcl_stream_create_apart(const fcl_stream_t* others, int n, fcl_stream_t* out, int* tried);
 void* fcl_host_device_ptr(void* pinned_host);
 int fcl_feed_copy(void* dst, const void* src, size_t bytes, uint32_t* seq_dev, uint32_t* seq_host, uint32_t* bump, fcl_stream_t stream);
 
@@ -834,6 +842,9 @@ int fcl_te_finalize(fcl_te_t* te, uint32_t* status_word);
 int fcl_te_params_changed(fcl_te_t* te);
 /* the engine's weight-gradient stream (created by the engine): the caller issues bucketed all-reduces from it between backward stages */
 fcl_stream_t fcl_te_side_stream(fcl_te_t* te);
+/* before the first pass (round 6): should the weight-gradient stream share a compute pipe with `main_stream` (measured, see fcl_streams_share_pipe), it is
+ * replaced by a stream that does not; *moved (optional) = 1 then, and a handle obtained from fcl_te_side_stream before the call is invalid */
+int fcl_te_place_streams(fcl_te_t* te, fcl_stream_t main_stream, int* moved);
 /* forward only (frozen KD teacher, train-mode statistics): *know points into one of the engine's two alternating arenas: valid until the
  * second next fcl_te_knowledge call on this engine */
 int fcl_te_knowledge(fcl_te_t* te, const fcl_te_batch_t* batch, uint32_t draw, fcl_te_knowledge_t* know, fcl_stream_t stream);

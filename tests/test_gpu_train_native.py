@@ -160,6 +160,13 @@ def test_native_kd_pipeline_tracks_the_per_launch_pipeline_and_costs_less_host_t
         teng, eng = _engines("kd_teacher", native, seed=11), _engines("student", native, seed=5)
         pipe = KDPipeline(teng, eng)
         assert pipe.native == native
+        if native:  # round 6: the update's three busy streams are measured onto three different compute pipes (ops.stream_apart / fcl_te_place_streams)
+            from fcl_taco2_amd import ops
+
+            three = [torch.cuda.current_stream(), eng.native.side, pipe.side]
+            for i in range(3):
+                for j in range(i + 1, 3):
+                    assert not ops.streams_share_pipe(three[i], three[j])[0], (i, j)
         losses = []
         for i in range(n):
             losses.append(float(pipe.step(bs[i % 2], bs[(i + 1) % 2])["loss"]))
