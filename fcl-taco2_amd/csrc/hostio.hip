@@ -125,7 +125,7 @@ int fcl_streams_share_pipe(fcl_stream_t a, fcl_stream_t b, int* shared, double* 
     return 0;
 }
 
-/* A new stream whose queue shares a pipe with none of others[0 .. n): candidates are created until one measures apart from all of them (at most 12; the
+/* A new stream whose queue shares a pipe with none of others[0 .. n): candidates are created until one measures apart from all of them (at most 24; the
  * rejected ones are destroyed afterwards, not before -- a destroyed stream's queue slot would be handed out again).  n <= 3 can always be satisfied (four pipes);
  * FCL_ERR_HIP when no candidate fits.  *tried (optional) = candidates created. */
 int fcl_stream_create_apart(const fcl_stream_t* others, int n, fcl_stream_t* out, int* tried) {
@@ -136,7 +136,7 @@ int fcl_stream_create_apart(const fcl_stream_t* others, int n, fcl_stream_t* out
     std::vector<hipStream_t> rejected;
     hipStream_t good = nullptr;
     int made = 0;
-    for (; made < 12 && !good; ++made) {
+    for (; made < 24 && !good; ++made) {
         hipStream_t s = nullptr;
         FCL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         bool clash = false;

@@ -1610,11 +1610,15 @@ fcl_stream_t fcl_te_side_stream(fcl_te_t* E) { return E ? (fcl_stream_t)E->side 
 int fcl_te_place_streams(fcl_te_t* E, fcl_stream_t main_stream, int* moved) {
     FCL_REQUIRE(E && E->finalized && E->side, FCL_ERR_INVALID, "fcl_te_place_streams: the engine is not finalized");
     if (moved) *moved = 0;
+    if (tunable("TE_SIDE_CUS", 0) > 0) return 0;  // a CU-masked queue contends with every other queue whatever its pipe (12 of 12 candidates, round 6): left where it is
     int shared = 0;
     TE_TRY(fcl_streams_share_pipe(main_stream, (fcl_stream_t)E->side, &shared, nullptr));
     if (!shared) return 0;
     fcl_stream_t others[1] = {main_stream}, fresh = nullptr;
-    TE_TRY(fcl_stream_create_apart(others, 1, &fresh, nullptr));
+    if (fcl_stream_create_apart(others, 1, &fresh, nullptr) != 0) {  // no candidate fits (a process holding dozens of streams): keep what there is, say so
+        if (moved) *moved = -1;
+        return 0;
+    }
     (void)hipStreamDestroy(E->side);
     E->side = (hipStream_t)fresh;
     if (moved) *moved = 1;

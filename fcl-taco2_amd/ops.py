@@ -929,7 +929,24 @@ def linear2(x, w, x2=None, w2=None, bias=None, residual=None, act=ACT_NONE):
 
 
 # ---- compute pipes (fcl_hip.h "Compute pipes"): which streams contend, and a stream that does not --------------------------------------------------------------
-_apart_handles = []  # raw streams made by stream_apart live as long as the process (work may be queued on them until the last synchronisation)
+class PlacedStream(torch.cuda.ExternalStream):
+    """A raw HIP stream made by stream_apart.  It lives as long as the process unless destroy() is called: torch's caching allocator may hold a stream it was
+    shown with record_stream() long after the Python object is gone (an event is recorded on it when the block is freed), so the object must not take the
+    queue with it.  stream_apart() therefore hands out ONE stream per set of `others` (a cache), not one per caller."""
+
+    def __new__(cls, handle, device, tried):
+        self = super().__new__(cls, handle, device=device)
+        self.fcl_handle, self.fcl_candidates_tried, self.fcl_placed = handle, tried, True
+        return self
+
+    def destroy(self):
+        """Only for a stream that no tensor was ever record_stream()-ed on and that is idle (tests, probes)."""
+        h, self.fcl_handle = self.fcl_handle, None
+        if h:
+            check(_lib.load().fcl_stream_destroy(C.c_void_p(h)))
+
+
+_apart_cache = {}  # (device index, handles of `others`) -> the stream placed apart from them
 
 
 def streams_share_pipe(a, b):
@@ -940,17 +957,28 @@ def streams_share_pipe(a, b):
     return bool(shared.value), float(ratio.value)
 
 
-def stream_apart(others, device=None):
-    """A new stream whose queue shares a compute pipe with none of `others` (torch streams, at most three can always be satisfied on MI355X's four pipes).
+def stream_apart(others, device=None, strict=False, cache=True):
+    """A new stream whose queue shares a compute pipe with none of `others` (torch streams; at most three can always be satisfied on MI355X's four pipes).
     Two chains of dependent launches on one pipe run 1.43x slower than apart: for the KD update 12.7 ms instead of 8.4 when the frozen teacher's stream lands
-    on the student's pipe, which depends on how many streams the process created before (profiles/r6_idle_stream_probe_raw.log)."""
+    on the student's pipe, which depends on how many streams the process created before (profiles/r6_stream_placement_kd.log).  When no candidate measures
+    apart (more than three `others`, or a process that holds so many streams that new ones keep landing on one queue) the result is an ordinary stream with
+    `fcl_placed = False` -- or a RuntimeError under strict=True.  cache=True (default): the same `others` get the same stream again (see PlacedStream)."""
     others = [s for s in others if s is not None]
-    device = device if device is not None else (others[0].device if others else torch.device("cuda", torch.cuda.current_device()))
+    device = torch.device(device) if device is not None else (others[0].device if others else torch.device("cuda", torch.cuda.current_device()))
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tuple(int(s.cuda_stream) for s in others))
+    if cache and key in _apart_cache:
+        return _apart_cache[key]
     arr = (C.c_void_p * max(len(others), 1))(*[s.cuda_stream for s in others])
     out, tried = C.c_void_p(), C.c_int(0)
     with torch.cuda.device(device):
-        check(_lib.load().fcl_stream_create_apart(arr, len(others), C.byref(out), C.byref(tried)))
-    _apart_handles.append(out)
-    s = torch.cuda.ExternalStream(out.value, device=device)
-    s.fcl_candidates_tried = tried.value
+        rc = _lib.load().fcl_stream_create_apart(arr, len(others), C.byref(out), C.byref(tried))
+        if rc != 0:
+            if strict:
+                check(rc)
+            s = torch.cuda.Stream(device=device)
+            s.fcl_candidates_tried, s.fcl_placed = tried.value, False
+            return s
+    s = PlacedStream(out.value, device, tried.value)
+    if cache:
+        _apart_cache[key] = s
     return s

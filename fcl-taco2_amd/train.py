@@ -116,7 +116,24 @@ def batch_feed(batches, conv, cache, workers):
     ds = _BatchDataset(batches, conv, cache)
     if workers <= 0 or len(batches) == 0:
         return (ds[i] for i in range(len(ds)))
-    return iter(torch.utils.data.DataLoader(ds, batch_size=None, shuffle=False, num_workers=workers, prefetch_factor=2, persistent_workers=False))
+
+    def feed():
+        # The loader processes are forked from a process that holds a GPU context and its runtime threads: a worker can die at birth (seen once in a few
+        # hundred epochs: SIGSEGV before its first item).  Items are a pure function of their index, so a dead loader costs the epoch its prefetching, not the
+        # run: the remaining batches are converted in this process, loudly.
+        done = 0
+        try:
+            for b in torch.utils.data.DataLoader(ds, batch_size=None, shuffle=False, num_workers=workers, prefetch_factor=2, persistent_workers=False):
+                done += 1
+                yield b
+        except RuntimeError as e:
+            if "DataLoader worker" not in str(e):
+                raise
+            logging.warning("fcl-taco2_amd: %s -- converting the remaining %d batches of this epoch in the training process", e, len(ds) - done)
+            for i in range(done, len(ds)):
+                yield ds[i]
+
+    return feed()
 
 
 # ---- checkpoints -----------------------------------------------------------------------------------------------------------------------

@@ -544,7 +544,7 @@ class _NativeStep(object):
             moved = C.c_int(0)
             with torch.cuda.device(eng.dev):
                 _lib.check(lib.fcl_te_place_streams(h, C.c_void_p(torch.cuda.current_stream(eng.dev).cuda_stream), C.byref(moved)))
-            self.side_moved = bool(moved.value)
+            self.side_moved = moved.value  # 1 moved, 0 fine as created, -1 contends and could not be placed
         self.side = torch.cuda.ExternalStream(lib.fcl_te_side_stream(h), device=eng.dev)
         self._hosts = []  # pinned landing buffers of the last steps' loss sums (kept until their copies have certainly run)
         self.stage_hook = None  # optional callable(stage) run after backward stage 0 .. 3 has been enqueued (KDPipeline)
@@ -1897,7 +1897,7 @@ class KDPipeline(object):
                     busy.append(student_engine.native.side)
                 elif getattr(student_engine, "side", None) is not None:
                     busy.append(student_engine.side)
-                self.side = ops.stream_apart(busy, device=student_engine.dev)
+                self.side = ops.stream_apart(busy, device=student_engine.dev, cache=False)  # (a cached one may have been placed against a destroyed engine's stream)
         else:
             self.side = torch.cuda.Stream(device=student_engine.dev)
         self.teacher_cus = n_cus

@@ -20,7 +20,7 @@ import wave
 import numpy as np
 import torch
 
-from . import kaldi_io
+from . import kaldi_io, ops
 from .sharding import shard_utterances
 from .vocoder import CONFIG, PWGPlan, ParallelWaveGANGenerator
 
@@ -125,7 +125,8 @@ def decode(gen, feats, outdir, rate, batch_frames=51200, seed=0, depth=2):
 
     th = threading.Thread(target=writer, daemon=True)
     th.start()
-    copy_stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.device(dev):  # the copies' queue on a compute pipe apart from the generator's stream (ops.stream_apart: fcl_hip.h "Compute pipes")
+        copy_stream = ops.stream_apart([torch.cuda.current_stream(dev)], device=dev) if os.environ.get("FCL_PLACE_STREAMS", "1") != "0" else torch.cuda.Stream(device=dev)
     slots = [None] * (depth + 1)  # pinned staging, one per batch in flight
     pending, total = [], 0
     t0 = time.perf_counter()

@@ -757,7 +757,7 @@ int fcl_stream_destroy(fcl_stream_t stream);
  * the same pipe, 2.0x on the same hardware queue (more streams than GPU_MAX_HW_QUEUES).  HIP does not report the pipe; these two entries measure it (two chains
  * of 40 dependent ~20 us launches, alone and together, ~5 ms per pair; the streams must be idle).
  *   fcl_streams_share_pipe: *shared = 1 when a and b contend; *ratio (optional) = pair time / alone.
- *   fcl_stream_create_apart: a new stream apart from every others[k] (<= 12 candidates; n <= 3 can always be met); *tried (optional) = candidates created. */
+ *   fcl_stream_create_apart: a new stream apart from every others[k] (<= 24 candidates; n <= 3 can be met on four pipes; FCL_ERR_HIP when none fits, e.g. in a process holding dozens of streams); *tried (optional) = candidates created. */
 int fcl_streams_share_pipe(fcl_stream_t a, fcl_stream_t b, int* shared, double* ratio);
 int fcl_stream_create_apart(const fcl_stream_t* others, int n, fcl_stream_t* out, int* tried);
 void* fcl_host_device_ptr(void* pinned_host);
@@ -843,7 +843,8 @@ int fcl_te_params_changed(fcl_te_t* te);
 /* the engine's weight-gradient stream (created by the engine): the caller issues bucketed all-reduces from it between backward stages */
 fcl_stream_t fcl_te_side_stream(fcl_te_t* te);
 /* before the first pass (round 6): should the weight-gradient stream share a compute pipe with `main_stream` (measured, see fcl_streams_share_pipe), it is
- * replaced by a stream that does not; *moved (optional) = 1 then, and a handle obtained from fcl_te_side_stream before the call is invalid */
+ * replaced by a stream that does not; *moved (optional) = 1 then (a handle obtained from fcl_te_side_stream before the call is invalid), -1 when it contends but
+ * no replacement could be placed (the stream is kept), 0 when it was fine */
 int fcl_te_place_streams(fcl_te_t* te, fcl_stream_t main_stream, int* moved);
 /* forward only (frozen KD teacher, train-mode statistics): *know points into one of the engine's two alternating arenas: valid until the
  * second next fcl_te_knowledge call on this engine */

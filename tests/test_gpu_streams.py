@@ -11,10 +11,10 @@ from fcl_taco2_amd import _lib, ops
 pytestmark = pytest.mark.gpu
 
 
-def _raw_stream():
+def _raw_stream():  # a plain stream as hipStreamCreateWithFlags hands it out (wherever it lands); the tests destroy() what they made
     h = C.c_void_p()
     _lib.check(_lib.load().fcl_stream_create_cus(0, C.byref(h)))
-    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", 0))
+    return ops.PlacedStream(h.value, torch.device("cuda", 0), 0)
 
 
 def test_eight_streams_contain_a_pair_on_one_pipe_and_the_probe_finds_it():
@@ -36,28 +36,32 @@ def test_eight_streams_contain_a_pair_on_one_pipe_and_the_probe_finds_it():
         assert sh == (cls[i] == cls[j]), (i, j, cls)
     assert len(set(cls)) <= 4  # four pipes
     assert ops.streams_share_pipe(ss[0], ss[0]) == (True, 2.0)
+    for st in ss:
+        st.destroy()
 
 
 def test_stream_apart_places_four_streams_on_four_pipes_whatever_was_created_before():
     for idle_before in (0, 1, 2, 3):
         junk = [_raw_stream() for _ in range(idle_before)]  # shifts which pipe the next plain stream would land on
         cur = torch.cuda.current_stream()
-        a = ops.stream_apart([cur])
-        b = ops.stream_apart([cur, a])
-        c = ops.stream_apart([cur, a, b])
+        a = ops.stream_apart([cur], strict=True, cache=False)
+        b = ops.stream_apart([cur, a], strict=True, cache=False)
+        c = ops.stream_apart([cur, a, b], strict=True, cache=False)
         four = [cur, a, b, c]
         for i in range(4):
             for j in range(i + 1, 4):
                 sh, ratio = ops.streams_share_pipe(four[i], four[j])
                 assert not sh, (idle_before, i, j, ratio)
-        assert all(1 <= s.fcl_candidates_tried <= 12 for s in (a, b, c))
-        del junk
+        assert all(s.fcl_placed and 1 <= s.fcl_candidates_tried <= 24 for s in (a, b, c))
+        for st in junk + ([a, b, c] if idle_before < 3 else []):
+            st.destroy()
     with pytest.raises(RuntimeError):  # a fifth pipe does not exist
-        cur = torch.cuda.current_stream()
-        a = ops.stream_apart([cur])
-        b = ops.stream_apart([cur, a])
-        c = ops.stream_apart([cur, a, b])
-        ops.stream_apart([cur, a, b, c])
+        ops.stream_apart([cur, a, b, c], strict=True, cache=False)
+    fifth = ops.stream_apart([cur, a, b, c], cache=False)  # not strict: an ordinary stream, marked
+    assert not fifth.fcl_placed
+    assert ops.stream_apart([cur]) is ops.stream_apart([cur])  # the cache: one placed stream per set of neighbours
+    for st in (a, b, c):
+        st.destroy()
 
 
 def test_synthesis_pass_streams_are_on_four_pipes():

@@ -156,3 +156,26 @@ def test_train_teacher_then_kd_student_then_decode(tmp_path):
     model = D.build_model(os.path.join(sdir, "model.loss.best"), os.path.join(sdir, "model.json"), os.path.join(tdir, "model.json"))
     mel = model.inference(torch.tensor([3, 5, 2, 7]), None, dur=torch.tensor([2, 1, 3, 2]))
     assert tuple(mel.shape) == (8, 8) and bool(torch.isfinite(mel).all())
+
+
+def _conv_that_dies_in_a_worker(items):
+    import signal
+
+    i = items[0]
+    if torch.utils.data.get_worker_info() is not None and i >= 2:
+        os.kill(os.getpid(), signal.SIGSEGV)  # a loader process dying mid-epoch
+    return {"index": i}
+
+
+def test_a_dead_loader_process_costs_the_epoch_its_prefetching_not_the_run(monkeypatch, caplog):
+    """batch_feed: items are a pure function of their index, so when a forked loader dies (seen once on the GPU box: SIGSEGV at birth, forked from a process
+    holding a GPU context) the remaining batches are converted in the training process, with a warning."""
+    import fcl_taco2_amd.training as TRN
+
+    monkeypatch.setattr(TR, "load_batch", lambda b, cache: b)
+    monkeypatch.setattr(TRN, "build_maps_host", lambda b: None)
+    with caplog.at_level("WARNING"):
+        got = [b["index"] for b in TR.batch_feed(list(range(6)), _conv_that_dies_in_a_worker, None, workers=1)]
+    assert got == list(range(6))
+    assert any("DataLoader worker" in r.getMessage() for r in caplog.records)
+    assert [b["index"] for b in TR.batch_feed(list(range(3)), _conv_that_dies_in_a_worker, None, workers=0)] == [0, 1, 2]  # inline: no worker, nothing dies
