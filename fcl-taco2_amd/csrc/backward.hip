@@ -756,6 +756,30 @@ __global__ __launch_bounds__(256) void bernoulli_batch_kernel(const BernBatch b)
     unsigned char* out = b.out[k];
     const long long n = b.len[k];
     const unsigned int thresh = b.thresh[k];
+    if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0) {  // round 6: 16 consecutive bytes per thread, ONE 16-byte store (byte stores ran at 0.1 TB/s: 63 us for 7 MB)
+        const long long i = i0 + threadIdx.x * 16;
+        if (i + 16 <= n) {
+            unsigned int w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned int v = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const long long ii = i + q * 4 + e;
+                    const unsigned int h = hash_u32(hash_u32((unsigned int)ii ^ s) + (unsigned int)(ii >> 32) * 0x9e3779b9U);
+                    v |= ((h >> 8) < thresh ? 1u : 0u) << (8 * e);
+                }
+                w[q] = v;
+            }
+            *reinterpret_cast<uint4*>(out + i) = make_uint4(w[0], w[1], w[2], w[3]);
+        } else {
+            for (long long ii = i; ii < n; ++ii) {
+                const unsigned int h = hash_u32(hash_u32((unsigned int)ii ^ s) + (unsigned int)(ii >> 32) * 0x9e3779b9U);
+                out[ii] = (h >> 8) < thresh ? 1 : 0;
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int j = 0; j < 16; ++j) {
         const long long i = i0 + j * 256 + threadIdx.x;

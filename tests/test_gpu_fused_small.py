@@ -207,3 +207,25 @@ def test_linear2_two_terms_and_residual(ops, m, n, k, k2):
         old = ops.sum_rows([old, ops.linear(dev(x2), dev(w2))]) if n % 4 == 0 else old + ops.linear(dev(x2), dev(w2))
     old = old + dev(res)
     assert np.abs(got.cpu().numpy() - old.cpu().numpy()).max() < tol
+
+
+def test_bernoulli_batch_draws_byte_for_byte_what_the_single_site_kernel_draws():
+    """fcl_bernoulli_batch writes 16 bytes per thread (round 6); ragged ends, tiny sites and a site that is not 16-byte aligned take the byte path: every
+    site equals fcl_bernoulli_u8 with the same seed."""
+    import ctypes as C
+
+    from fcl_taco2_amd import _lib
+    from fcl_taco2_amd import ops as O
+
+    sizes = [1, 15, 16, 17, 4095, 4096, 4097, 100003, 1 << 20]
+    sites = [((n,), 0.1 + 0.08 * k, 1000 + k) for k, n in enumerate(sizes)]
+    got = O.bernoulli_batch(sites, DEV)
+    for (shape, p, seed), g in zip(sites, got):
+        want = O.bernoulli_u8(shape, p, seed, DEV)
+        assert torch.equal(g, want), shape
+    # an output that is NOT 16-byte aligned
+    buf = torch.zeros(5000 + 3, device=DEV, dtype=torch.uint8)
+    arr = (_lib.BernoulliSite * 1)()
+    arr[0].out, arr[0].n, arr[0].p_one, arr[0].seed = buf.data_ptr() + 3, 5000, 0.5, 77
+    _lib.check(_lib.load().fcl_bernoulli_batch(arr, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert torch.equal(buf[3:], O.bernoulli_u8((5000,), 0.5, 77, DEV)) and int(buf[:3].sum()) == 0
