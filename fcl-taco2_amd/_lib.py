@@ -86,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 420  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 421  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -177,6 +177,7 @@ SIGNATURES = {
     "fcl_planes_elems": (_Z, [_I, _I]),
     "fcl_pack_planes": (_I, [_P, _I, _I, _I, _P, _P]),
     "fcl_linear_planes_fwd": (_I, [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "fcl_linear_planes_mse_fwd": (_I, [_P, _I, _P, _P, _I, _P, C.c_double, _P, _I, _P, _P, _I, _I, _I, _P]),
     "fcl_conv1d_planes_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcl_conv1d_planes_rows_fwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "fcl_embedding_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

@@ -230,6 +230,29 @@ int fcl_linear_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
     return launch_gemm(g, (hipStream_t)stream);
 }
 
+/* y = x . W^T as fcl_linear_planes_fwd, the masked MSE against `target` and its gradient in ONE launch (the GEMM's epilogue): with d = y - target on the rows
+ * where row_valid is set (all rows when NULL), grad / grad_p (planes) receive 2 d / count (0 on the other rows) and sums[0 .. 2] += sum |d|, sum d^2, number of
+ * elements (fp64 atomics; the slots fcl_loss_terms_batch fills).  y itself is never stored.  Planes kernels only (refused under FCL_PLANES=0). */
+int fcl_linear_planes_mse_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* target, int ld_t, const uint8_t* row_valid, double count,
+                              float* grad, int ldg, uint16_t* grad_p, double* sums, int m, int n, int k, fcl_stream_t stream) {
+    FCL_REQUIRE(xp && wpp && target && sums && (grad || grad_p) && count > 0.0, FCL_ERR_INVALID, "linear_planes_mse_fwd: null argument / count <= 0");
+    FCL_REQUIRE(ldxp * 32 >= k && (!grad || ldg >= n) && ld_t >= n, FCL_ERR_SHAPE, "linear_planes_mse_fwd: leading dimensions too small");
+    FCL_REQUIRE((n & 3) == 0 && (ld_t & 3) == 0 && (reinterpret_cast<uintptr_t>(target) & 15u) == 0, FCL_ERR_ALIGN,
+                "linear_planes_mse_fwd: n %% 4 == 0 and a 16-byte aligned target with ld_t %% 4 == 0 required");
+    GemmArgs g = {};
+    g.term[0].K = k;
+    g.term[0].Ap = xp; g.term[0].lda_p = ldxp;
+    g.term[0].Wp = wpp; g.term[0].ldw_p = (k + 31) / 32;
+    g.nterms = 1;
+    g.M = m; g.N = n; g.act = FCL_ACT_NONE;
+    g.Y = grad; g.ldy = ldg;
+    g.Yp = grad_p; g.ldyp = (n + 31) / 32;
+    g.loss_t = target; g.ld_lt = ld_t; g.loss_valid = row_valid; g.loss_gscale = (float)(1.0 / count); g.loss_sums = sums;
+    FCL_REQUIRE(tunable("PRECISION", 1) != 0 && planes_ok(g.term, 1), FCL_ERR_INVALID, "linear_planes_mse_fwd: the planes kernels are off (FCL_PLANES=0 / FCL_PRECISION=0)");
+    if (m == 0) return 0;
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int fcl_conv1d_planes_rows_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
                                const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, const int32_t* m_dev,
                                fcl_stream_t stream) {

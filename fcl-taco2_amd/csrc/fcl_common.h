@@ -35,6 +35,11 @@ typedef fcl_gemm_term_t GemmTerm;  // public C struct (include/fcl_hip.h)
 
 enum { FCL_MAX_TERMS = 9 };
 
+// d(loss)/d(a) of w1 * mean|d| + w2 * mean d^2 at d = a - b (one definition: the term-table loss kernel and the GEMM's MSE epilogue must agree bit for bit)
+__device__ __forceinline__ float loss_grad1(float d, float w1, float w2, float inv_count) {
+    return (w1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * w2 * d) * inv_count;
+}
+
 struct GemmArgs {
     GemmTerm term[FCL_MAX_TERMS];
     int nterms;
@@ -80,6 +85,14 @@ struct GemmArgs {
     int dbg_phase;  // developer timing aid (FCL_PGEMM_DBG): 1 = return after the main loop (results are then garbage)
     const int* m_dev;  // optional DEVICE row count (planes kernels): tiles at or beyond *m_dev exit at once -- the frame buffers of a capacity graph
                        // are sized with slack and nothing reads the rows past the batch's real total (fcl_conv1d_planes_rows_fwd)
+    // MSE epilogue (planes kernels only, fcl_linear_planes_mse_fwd; round 6): with d = y - loss_t over the valid rows, Y / Yp receive the GRADIENT
+    // 2 d * loss_gscale (zero on the other rows) instead of y, and sum |d|, sum d^2 and the element count are added to loss_sums[0 .. 2] (fp64 atomics):
+    // the projection of a KD term, its loss and its gradient in one launch -- y itself never reaches memory
+    const float* loss_t;  // [M, N] target (ld_lt floats per row, 16-byte aligned rows), or null
+    int ld_lt;
+    const uint8_t* loss_valid;  // optional [M]
+    float loss_gscale;  // 1 / count
+    double* loss_sums;
 };
 
 // ---- fused LSTM step (gemm_f32.hip / decoder_step.hip): the argument block is the public fcl_lstm_step_t ----------

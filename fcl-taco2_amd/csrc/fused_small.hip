@@ -24,9 +24,7 @@ struct LossBatch {
     int n;
 };
 
-__device__ __forceinline__ float loss_grad1(float d, float w1, float w2, float inv_count) {
-    return (w1 * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) + 2.f * w2 * d) * inv_count;
-}
+// (loss_grad1: fcl_common.h)
 
 // one workgroup works on ONE term (first_block[] maps block -> term); the arithmetic per element is l1_mse_loss_grad_kernel's (backward.hip), the second
 // target's gradient is added to the first's exactly as the accumulate pass did (g1 + g2 in fp32)

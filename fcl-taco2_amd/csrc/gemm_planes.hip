@@ -430,6 +430,46 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[
     if (a.dbg_phase == 2) return;  // developer timing aid: no write-out
     const int rows = RP ? BM : min(BM, a_M - m0);  // staging rows to write out; RP: staging row rm holds tile row (rm & ~15) + rho16(rm & 15)
     auto trow = [&](int rm) { return RP ? (rm & ~15) + rho16(rm & 15) : rm; };
+    if (a.loss_t) {  // MSE epilogue (GemmArgs::loss_t): the staged y becomes the gradient in place, row-wise (16 bytes of the target per lane), sums per workgroup
+        __shared__ double loss_part[16][3];
+        const float* const lt = a.loss_t;
+        const uint8_t* const lv = a.loss_valid;
+        const int ldlt = a.ld_lt;
+        const float gsc = a.loss_gscale;
+        double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+        for (int i = threadIdx.x; i < rows * (BN / 4); i += CTHREADS) {
+            const int rm = i / (BN / 4), c4 = (i - rm * (BN / 4)) * 4, n = n0 + c4, gm = m0 + trow(rm);
+            if (n >= a_N || gm >= a_M) continue;  // (the staged padding is zero already)
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (!lv || lv[gm]) {
+                const f32x4 y = *reinterpret_cast<const f32x4*>(tile + rm * LDT + c4);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(lt + (size_t)gm * ldlt + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = y[e] - t[e];
+                    s1 += fabsf(d);
+                    s2 += (double)d * d;
+                    g[e] = loss_grad1(d, 0.f, 1.f, gsc);
+                }
+                cnt += 4.0;
+            }
+            *reinterpret_cast<f32x4*>(tile + rm * LDT + c4) = g;
+        }
+        double v[3] = {s1, s2, cnt};
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o);
+        if (lane == 0)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) loss_part[wave][q] = v[q];
+        __syncthreads();  // the gradients are staged, the waves' partial sums are in LDS
+        if (threadIdx.x < 3) {
+            double s = 0.0;
+            for (int w = 0; w < CTHREADS / 64; ++w) s += loss_part[w][threadIdx.x];
+            if (s != 0.0) atomicAdd(a.loss_sums + threadIdx.x, s);
+        }
+    }
     const int a_ldy = a.ldy, a_ldyp = a.ldyp, a_nblk = a.nblk;  // (locals: the loops below store through argument pointers, see above)
     const long long a_blk = a.blk_stride;
     if (a.accumulate) {  // weight gradients (split contraction, accumulation over micro-batches): one float per lane, consecutive lanes on

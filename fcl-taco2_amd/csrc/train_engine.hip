@@ -937,7 +937,11 @@ static int te_kd_fwd(fcl_te& E, LossBatchBuilder& lb, std::vector<KdTerm>& pend,
     q.lname = lname; q.proj = proj; q.key = key; q.s_in = s_in; q.rows = rows; q.n = n; q.k = k; q.t = t; q.valid = valid; q.nvalid = nvalid;
     q.planes = n % 32 == 0 && k % 32 == 0 && rows >= 4096;
     Param& W = E.Pm(proj + ".weight");
-    float* s = f32(E, rows, n);
+    // FCL_TE_KD_FUSED=1 (round 6): a term on the planes kernels is ONE launch -- projection, masked MSE and gradient in the GEMM's epilogue
+    // (fcl_linear_planes_mse_fwd); the projected tensor [rows, n] is never written or read back (8 of the 20 bytes per element the term moved)
+    static const int fused = tunable("TE_KD_FUSED", 1);
+    const bool fuse = fused && q.planes && (reinterpret_cast<uintptr_t>(t) & 15u) == 0 && (n & 3) == 0;
+    float* s = fuse ? nullptr : f32(E, rows, n);
     if (q.planes) {
         const uint16_t* sp;
         auto hit = E.c.planes_of.find(s_in);
@@ -949,6 +953,15 @@ static int te_kd_fwd(fcl_te& E, LossBatchBuilder& lb, std::vector<KdTerm>& pend,
         }
         const uint16_t* wp;
         TE_TRY(w_planes(E, proj + ".weight", n, k, &wp));
+        if (fuse) {
+            const int slot = loss_slot(lname);
+            FCL_REQUIRE(slot >= 0, FCL_ERR_INVALID, "fcl_te: unknown loss %s", lname);
+            q.ds = f32(E, rows, n);
+            q.ds_p = pl16(E, rows, n);
+            TE_L(fcl_linear_planes_mse_fwd(sp, k / 32, wp, t, n, valid, nvalid * n * E.cfg.accum_grad, q.ds, n, q.ds_p, E.c.sums + 3 * slot, rows, n, k, E.cur));
+            pend.push_back(q);
+            return 0;
+        }
         TE_L(fcl_linear_planes_fwd(sp, k / 32, wp, nullptr, s, n, nullptr, rows, n, k, FCL_ACT_NONE, E.cur));
     } else {
         TE_L(fcl_linear_fwd(s_in, k, W.p, k, nullptr, s, n, rows, n, k, FCL_ACT_NONE, E.cur));

@@ -585,6 +585,16 @@ def scale_(x, alpha):
     return x
 
 
+def linear_planes_mse(xp, wpp, target, row_valid, count, sums, m, n, k, want_f32=True, want_planes=True):
+    """fcl_linear_planes_mse_fwd: the projection of one KD term, its masked MSE against `target` [m, n] and the gradient 2 (x W^T - target) / count in one
+    launch; sums (float64 [3], device) += sum |d|, sum d^2, element count.  Returns (grad fp32 or None, grad planes or None)."""
+    g = torch.empty(m, n, device=target.device, dtype=torch.float32) if want_f32 else None
+    gp = planes_empty(m, n, target.device) if want_planes else None
+    check(_lib.load().fcl_linear_planes_mse_fwd(_p(xp, torch.int16), (k + 31) // 32, _p(wpp, torch.int16), _p(target), target.stride(0), _p(row_valid, torch.uint8),
+                                                float(count), _p(g), n, _p(gp, torch.int16), sums.data_ptr(), m, n, k, _stream()))
+    return g, gp
+
+
 def bernoulli_u8(shape, p_one, seed, device, seed_dev=None):
     out = torch.empty(shape, device=device, dtype=torch.uint8)
     check(_lib.load().fcl_bernoulli_u8(_p(out, torch.uint8), out.numel(), float(p_one), seed & 0xFFFFFFFF, _p(seed_dev, torch.int32), _stream()))

@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 420
+#define FCL_ABI_VERSION 421
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -126,6 +126,14 @@ int fcl_conv1d_fwd(const float* x, const float* wp, const float* bias, const int
  * ceil(N/32) lines per row, zero past N) receive the result; residual / bias as above. */
 int fcl_linear_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, float* y, int ldy, uint16_t* yp,
                           int m, int n, int k, int act, fcl_stream_t stream);
+/* round 6 (421): fcl_linear_planes_fwd + masked MSE against `target` + its gradient in ONE launch (the GEMM's epilogue) -- one KD term of the student's update
+ * (e2e_tts_tacotron2_sa_kd_student.py:134-179: MSE(proj(student tap), teacher tap) over the valid rows).  With d = x . W^T - target on the rows where row_valid is
+ * set (all rows when NULL): grad [m, n] (ldg) / grad_p (P32 planes) = 2 d / count, 0 on the other rows; sums[0 .. 2] += sum |d|, sum d^2, element count (fp64
+ * atomics: the three slots fcl_loss_terms_batch fills for a term).  The projection itself is never stored (8 bytes per element of HBM traffic less than
+ * projection + fcl_loss_terms_batch).  n % 4 == 0, target 16-byte aligned with ld_t % 4 == 0; planes kernels only (FCL_ERR_INVALID under FCL_PLANES=0 /
+ * FCL_PRECISION=0). */
+int fcl_linear_planes_mse_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* target, int ld_t, const uint8_t* row_valid, double count,
+                              float* grad, int ldg, uint16_t* grad_p, double* sums, int m, int n, int k, fcl_stream_t stream);
 int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const float* bias, const int32_t* seg_lo, const int32_t* seg_hi,
                           const float* residual, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, fcl_stream_t stream);
 /* fcl_conv1d_planes_fwd with a DEVICE row count (round 5): m is then the capacity of the buffers and tiles at or beyond *m_dev are not computed

@@ -1,6 +1,8 @@
 """-m gpu: the round-6 fused small launches of the training update (csrc/fused_small.hip) against numpy / torch float64 restatements and against the
 kernels they replace (fcl_l1_mse_loss_grad, fcl_masked_l1_mse_fwd + fcl_l1_mse_grad, fcl_add2d chains, fcl_act_bwd + fcl_colsum2_fwd, fcl_gather_rows_fwd,
 fcl_linear_fwd): the loss arithmetic is that of ..._kd_student.py:759-802 / ..._sa.py:60-70 (masked L1 + MSE means and their gradients)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -229,3 +231,40 @@ def test_bernoulli_batch_draws_byte_for_byte_what_the_single_site_kernel_draws()
     arr[0].out, arr[0].n, arr[0].p_one, arr[0].seed = buf.data_ptr() + 3, 5000, 0.5, 77
     _lib.check(_lib.load().fcl_bernoulli_batch(arr, 1, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     assert torch.equal(buf[3:], O.bernoulli_u8((5000,), 0.5, 77, DEV)) and int(buf[:3].sum()) == 0
+
+
+@pytest.mark.parametrize("m,n,k,masked", [(300, 64, 32, True), (4099, 512, 128, True), (2500, 1024, 256, False), (129, 96, 64, True)])
+def test_linear_planes_mse_is_projection_plus_loss_terms_in_one_launch(m, n, k, masked):
+    """fcl_linear_planes_mse_fwd (round 6: a KD term in the GEMM's epilogue) against the two launches it replaces -- fcl_linear_planes_fwd then
+    fcl_loss_terms_batch -- gradients and their planes BIT FOR BIT (same y, same d, same gradient expression), sums to fp64 rounding (another summation order);
+    and against float64."""
+    from fcl_taco2_amd import ops as O
+
+    if os.environ.get("FCL_PRECISION", "1") == "0" or os.environ.get("FCL_PLANES", "1") == "0":
+        pytest.skip("planes kernels only")
+    rs = np.random.RandomState(m + n)
+    x = torch.from_numpy(rs.randn(m, k).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rs.randn(n, k) / np.sqrt(k)).astype(np.float32)).to(DEV)
+    t = torch.from_numpy(rs.randn(m, n).astype(np.float32)).to(DEV)
+    valid = torch.from_numpy((rs.rand(m) < 0.8).astype(np.uint8)).to(DEV) if masked else None
+    count = float((int(valid.sum()) if masked else m) * n)
+    xp, wp = O.pack_planes(x), O.pack_planes(w)
+    y, _ = O.linear_planes(xp, wp, n, k)
+    sums_ref = torch.zeros(2, 3, dtype=torch.float64, device=DEV)
+    (da, dap), = O.loss_terms_batch([dict(a=y, b=t, valid=valid, slot=1, count=count, w_l1=0.0, w_mse=1.0, want_planes=True)], sums_ref)
+    sums = torch.zeros(2, 3, dtype=torch.float64, device=DEV)
+    g, gp = O.linear_planes_mse(xp, wp, t, valid, count, sums[1], m, n, k)
+    assert torch.equal(g, da)
+    assert torch.equal(gp[:m], dap[:m])
+    assert float(sums[0].abs().sum()) == 0.0 and torch.allclose(sums[1], sums_ref[1], rtol=1e-12, atol=0.0), (sums, sums_ref)
+    # float64: d = x w^T - t on the valid rows
+    d = x.double() @ w.double().t() - t.double()
+    if masked:
+        d = d * valid.bool().unsqueeze(1)
+    assert float((g.double() - 2.0 * d / count).abs().max()) < 2e-5 / count * max(1.0, float(d.abs().max())) + 1e-9
+    assert abs(float(sums[1, 1]) - float((d * d).sum())) < 1e-4 * float((d * d).sum())
+    assert float(sums[1, 2]) == count
+    # planes only / fp32 only
+    s2 = torch.zeros(3, dtype=torch.float64, device=DEV)
+    g2, gp2 = O.linear_planes_mse(xp, wp, t, valid, count, s2, m, n, k, want_f32=False)
+    assert g2 is None and torch.equal(gp2[:m], gp[:m])
