@@ -685,7 +685,9 @@ class TrainEngine(object):
         # weight gradients on transposed planes from 1 M outputs on; from 256 k in the teacher's OWN update (same-box A/B at the end of round 3: teacher
         # update 11.32 -> 11.15 ms; the KD update, whose weight-gradient stream also carries the predictors and the late loss terms beside the frozen
         # teacher's forward, loses with it: 10.78 -> 10.83 ms)
-        self._dw_planes_min = _DW_PLANES_MIN or ((1 << 18) if model.role == "teacher" else (1 << 20))
+        # (round 6, profiles/r6_dw_route_ab.log: with dw_mfma_kernel and an update whose pace is set by the bytes it moves, the teacher's threshold is 4 M outputs --
+        # only the 4 096 x 1 024 LSTM matrices keep the transposed-planes route: teacher update 9.70 -> 9.44 ms same box; 256 k, 1 M and "never" are all slower)
+        self._dw_planes_min = _DW_PLANES_MIN or ((1 << 22) if model.role == "teacher" else (1 << 20))
         if self.role == "student" and self.hp.spk_embed_dim is not None:
             raise NotImplementedError("fcl-taco2_amd: KD training with speaker embeddings is undefined in the reference (its student's pemb_proj / eemb_proj "
                                       "are built for eunits inputs but receive eunits + spk_embed_dim channels: tests/golden/records.json)")
