@@ -1144,10 +1144,13 @@ int launch_lstm_planes_pair(const LstmStepArgs& a0, const LstmStepArgs& a1, hipS
                      row32_m = tunable("PLSTM_PAIR_ROW32_M", tunable("PLSTM_ROW32_M", 1100));
     const long long t128 = (long long)((M + 127) / 128) * ((U + 31) / 32), t64 = (long long)((M + 63) / 64) * ((U + 31) / 32);
 #define FCL_PAIR(WM_, WN_, TM_, NST_) (hi ? launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 1>(a0, a1, s, flops) : launch_plstm_pair_cfg<WM_, WN_, TM_, NST_, 0>(a0, a1, s, flops))
-    static const int two_stage = tunable("PLSTM_PAIR_2STAGE_MIN_WG", 1 << 30);  // (r5 A/B: two ring stages = two workgroups per CU for the pair's big tiles)
+    // two ring stages = 64 KB of LDS = TWO workgroups per CU for the pair's 128-row tiles, from ..MIN_WG to below ..MAX_WG tiles per problem.  Round 6 (tools/tunable_scan.sh,
+    // profiles/r6_tunable_scan.log): on for 256 <= tiles < 512 -- the teacher's own update (16 utterances: 10 x 32 tiles per problem, 640 per pair on 256 CUs = 2.5 rounds
+    // of one-per-CU workgroups): 9.42 -> 9.36 ms; everywhere (FCL_PLSTM_PAIR_NST2=1) the KD update, whose pairs have 160 and 640 tiles, loses 1 %
+    static const int two_stage = tunable("PLSTM_PAIR_2STAGE_MIN_WG", 256), two_stage_max = tunable("PLSTM_PAIR_2STAGE_MAX_WG", 512);
     static const int all2 = tunable("PLSTM_PAIR_NST2", 0);  // (r5 A/B: two ring stages everywhere = <= 64 KB of LDS and <= 80 VGPRs per workgroup, so that
                                                            // the frozen teacher's steps and the student's can share a CU in the KD update)
-    if (t128 >= two_stage) return FCL_PAIR(4, 2, 2, 2);
+    if (t128 >= two_stage && t128 < two_stage_max) return FCL_PAIR(4, 2, 2, 2);
     if (t128 >= big_min) return all2 ? FCL_PAIR(4, 2, 2, 2) : FCL_PAIR(4, 2, 2, 3);
     if (t64 >= mid_min) return all2 ? FCL_PAIR(2, 2, 2, 2) : FCL_PAIR(2, 2, 2, 3);
     if (M <= row32_m) return FCL_PAIR(2, 2, 1, 4);

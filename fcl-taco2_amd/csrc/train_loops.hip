@@ -203,7 +203,7 @@ int fcl_decoder_bptt(const fcl_decoder_bptt_t* a, fcl_stream_t stream) {
     for (int t = 0; t < a->lmax; ++t) total += (size_t)a->live_rows_host[t];
     const bool planes = a->w1_ih_t_p && a->w1_hh_t_p && a->w0_hh_t_p && a->dg0_all_p && a->dg1_all_p && !(G4 & 31);
     const int ldg = G4 / 32;  // plane lines per gate-gradient row
-    static const int planes_min_rows = tunable("BPTT_PLANES_MIN_M", 256);  // below: the split-K small-M kernel on the fp32 operands is faster
+    static const int planes_min_rows = tunable("BPTT_PLANES_MIN_M", 128);  // below: the split-K small-M kernel on the fp32 operands is faster (round 6 re-scan: 256 -> 128: teacher update -0.75 %, KD neutral)
     auto linp = [&](const float* dg, const unsigned short* dgp, const float* wt, const unsigned short* wtp, float* y, int n, const float* residual) {
         GemmArgs g = lin(dg, G4, wt, G4, G4, y, U, n, U, residual, U);
         if (planes && n > planes_min_rows) { g.term[0].Ap = dgp; g.term[0].Wp = wtp; g.term[0].lda_p = g.term[0].ldw_p = ldg; }
