@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void pipe_probe_kernel(float* p, int iters) {
 }
 
 namespace {
-constexpr int kProbeBlocks = 32, kProbeLaunches = 40, kProbeIters = 1200;
+constexpr int kProbeBlocks = 32, kProbeLaunches = 16, kProbeIters = 1200;  // 16 dependent ~20 us launches per chain: ~0.35 ms alone, 0.35 - 0.9 ms for a pair
 
 struct ProbeBuf {
     float* p[2] = {nullptr, nullptr};
@@ -89,14 +89,15 @@ int chain_ms(hipStream_t a, hipStream_t b, bool pair, const ProbeBuf& buf, doubl
     return 0;
 }
 
-int share_pipe(hipStream_t a, hipStream_t b, const ProbeBuf& buf, bool* shared, double* ratio) {
+// alone_ms > 0: the single-chain time measured before (one measurement serves every pair a candidate stream is tested in)
+int share_pipe(hipStream_t a, hipStream_t b, const ProbeBuf& buf, bool* shared, double* ratio, double alone_ms = 0.0) {
     if (a == b) {
         *shared = true;
         if (ratio) *ratio = 2.0;
         return 0;
     }
-    double alone = 0.0, both = 0.0;
-    int rc = chain_ms(a, b, false, buf, &alone);
+    double alone = alone_ms, both = 0.0;
+    int rc = alone > 0.0 ? 0 : chain_ms(a, b, false, buf, &alone);
     if (rc) return rc;
     rc = chain_ms(a, b, true, buf, &both);
     if (rc) return rc;
@@ -111,7 +112,7 @@ int share_pipe(hipStream_t a, hipStream_t b, const ProbeBuf& buf, bool* shared, 
 
 extern "C" {
 
-/* Do two streams' queues sit on the same compute pipe?  Measured (two chains of 40 dependent ~20 us launches, alone and together: ~5 ms); both streams must be
+/* Do two streams' queues sit on the same compute pipe?  Measured (two chains of 16 dependent ~20 us launches, alone and together: ~2 ms); both streams must be
  * idle.  *ratio (optional) = pair time / alone: ~1.0 apart, ~1.43 same pipe, ~2.0 same hardware queue. */
 int fcl_streams_share_pipe(fcl_stream_t a, fcl_stream_t b, int* shared, double* ratio) {
     FCL_REQUIRE(shared, FCL_ERR_INVALID, "streams_share_pipe: null argument");
@@ -140,10 +141,9 @@ int fcl_stream_create_apart(const fcl_stream_t* others, int n, fcl_stream_t* out
         hipStream_t s = nullptr;
         FCL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         bool clash = false;
-        for (int k = 0; k < n && !clash; ++k) {
-            rc = share_pipe((hipStream_t)others[k], s, buf, &clash, nullptr);
-            if (rc) break;
-        }
+        double alone = 0.0;
+        if (n > 0) rc = chain_ms(s, s, false, buf, &alone);  // (also the new queue's warm-up)
+        for (int k = 0; k < n && !clash && !rc; ++k) rc = share_pipe((hipStream_t)others[k], s, buf, &clash, nullptr, alone);
         if (rc) {
             rejected.push_back(s);
             break;

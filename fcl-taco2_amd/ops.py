@@ -960,7 +960,7 @@ _apart_cache = {}  # (device index, handles of `others`) -> the stream placed ap
 
 
 def streams_share_pipe(a, b):
-    """(shared, ratio): do the queues of two idle torch streams sit on the same compute pipe (measured, ~5 ms)?  ratio = pair time / alone."""
+    """(shared, ratio): do the queues of two idle torch streams sit on the same compute pipe (measured, ~2 ms)?  ratio = pair time / alone."""
     shared, ratio = C.c_int(0), C.c_double(0.0)
     with torch.cuda.device(a.device):
         check(_lib.load().fcl_streams_share_pipe(C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), C.byref(shared), C.byref(ratio)))

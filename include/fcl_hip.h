@@ -763,7 +763,7 @@ int fcl_stream_destroy(fcl_stream_t stream);
 /* Compute pipes (round 6).  The queue behind a HIP stream sits on one of MI355X's four compute pipes (queue index mod 4, in creation order within the process) and
  * a pipe advances one of its queues at a time: two chains of dependent launches take 1.0x the time of one when their streams are on different pipes, 1.43x on
  * the same pipe, 2.0x on the same hardware queue (more streams than GPU_MAX_HW_QUEUES).  HIP does not report the pipe; these two entries measure it (two chains
- * of 40 dependent ~20 us launches, alone and together, ~5 ms per pair; the streams must be idle).
+ * of 16 dependent ~20 us launches, alone and together, ~2 ms per pair; the streams must be idle).
  *   fcl_streams_share_pipe: *shared = 1 when a and b contend; *ratio (optional) = pair time / alone.
  *   fcl_stream_create_apart: a new stream apart from every others[k] (<= 24 candidates; n <= 3 can be met on four pipes; FCL_ERR_HIP when none fits, e.g. in a process holding dozens of streams); *tried (optional) = candidates created. */
 int fcl_streams_share_pipe(fcl_stream_t a, fcl_stream_t b, int* shared, double* ratio);
