@@ -849,7 +849,7 @@ def test_kd_pipeline_equals_sequential_updates():
     l_seq, w_seq = run(False)
     l_pipe, w_pipe = run(True)
     assert l_seq[0] == pytest.approx(l_pipe[0], rel=1e-9) and l_seq == pytest.approx(l_pipe, rel=1e-4)
-    assert max_abs(w_seq.cpu(), w_pipe.cpu()) <= 2 * 1e-3 * 3 and float((w_seq - w_pipe).abs().mean()) < 1e-5  # sign-flip bound / mean, as in the Adam test
+    assert max_abs(w_seq.cpu(), w_pipe.cpu()) <= 2 * 1e-3 * 3 and float((w_seq - w_pipe).abs().mean()) < 3e-5  # sign-flip bound / mean, as in the Adam test (noise ~1e-5)
 
 
 def _ddp_worker(rank, world, port, q):
@@ -997,7 +997,7 @@ def _nccl_one_rank_worker(port, q):
         os.environ["FCL_DP_INLINE"] = "1"
         assert e2.buckets.active and not e2.buckets.inline and e2.buckets.collectives == n_coll
         assert abs(l2[0] - l0[0]) <= 1e-9 * abs(l0[0]) and all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l2)), (l0, l2)
-        assert float((w0 - w2).abs().max()) <= 6e-3 and float((w0 - w2).abs().mean()) < 1e-5
+        assert float((w0 - w2).abs().max()) <= 6e-3 and float((w0 - w2).abs().mean()) < 3e-5  # (run-to-run noise 0.8e-5 ... 1.1e-5: see the parent's comment)
         # the collective alone: AVG over one rank is the identity, bit for bit, on every bucket
         e1.zero_grad()
         e1.forward_backward(bs[0], teacher_knowledge=TrainEngine(SYN.build_model("kd_teacher", T, None, DEV), seed=11).knowledge(bs[0], mode="train"),
@@ -1045,7 +1045,9 @@ def test_one_rank_nccl_group_runs_the_data_parallel_branch_on_one_gpu():
     # run, and Adam's first steps (|m / sqrt(v)| ~ 1) turn a last-bit difference in a near-zero gradient into a +-lr difference of that weight; on
     # these full-size closed-form (stiff) weights that moves the third loss by ~2e-4 relative between ANY two runs
     assert l0[0] == pytest.approx(l1[0], rel=1e-9) and l0 == pytest.approx(l1, rel=2e-3), (l0, l1)
-    assert wmax <= 2 * 1e-3 * 3 and wmean < 1e-5, (wmax, wmean)  # sign-flip bound of three Adam steps / mean, as in test_kd_pipeline_equals_sequential_updates
+    # sign-flip bound of three Adam steps / mean, as in test_kd_pipeline_equals_sequential_updates.  The mean is noise of the same origin -- measured 0.8e-5 ... 1.12e-5 over
+    # this round's runs (it crossed 1e-5 once in five full-suite runs); a collective racing its bucket's writers moves it by two orders of magnitude
+    assert wmax <= 2 * 1e-3 * 3 and wmean < 3e-5, (wmax, wmean)
 
 
 def test_full_size_kd_step_properties():
