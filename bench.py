@@ -609,7 +609,11 @@ def train_workload(args, rank, world, dev, dist):
                                "closed-form weights" % ("C3" if kd else "C4", B, frames),
                    "parallelism": "dp%d: one process per GPU, gradient all-reduce (AVG) in 4 buckets overlapped with backward" % world,
                    "pipeline": ("frozen teacher one batch ahead on a second HIP stream (steady-state time per update)" if pipe is not None else
-                                "teacher forward and update back to back on one stream")},
+                                "teacher forward and update back to back on one stream"),
+                   "stream_placement": {"weight_gradient_stream": {1: "moved off the main stream's compute pipe", 0: "apart as created", -1: "contends, could not be placed"}.get(
+                                            getattr(eng.native, "side_moved", 0), "unplaced") if eng.native is not None else "per-launch engine",
+                                        "frozen_teacher_stream": ("measured apart from the student's two streams" if getattr(pipe.side, "fcl_placed", False) else "as created")
+                                        if pipe is not None else None}},
         "timing": {"statistic": "median over %d timed regions of exactly %d steps each (barrier + synchronize on both sides; MAX over ranks per region)"
                                 % (len(dts), steps), "region_ms": [round(1e3 * t, 3) for t in dts], "best_ms_per_step": 1e3 * min(dts) / steps},
         "whole_step": {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "peak_is": peak_note,
@@ -832,6 +836,9 @@ def main():
                                                         "/".join(str(f) for f in (bframes if fresh else [frames])), n_rows),
                    "parallelism": "%d independent replicas (utterance-sharded, no collective)" % world,
                    "streams_per_gpu": args.streams,
+                   "stream_placement": ("measured: the pass streams sit on %d different compute pipes (ops.stream_apart; DESIGN 5 'compute pipes')"
+                                        % sum(1 for s_ in pass_streams if getattr(s_, "fcl_placed", False) or s_ is pass_streams[0])
+                                        if (fresh or not args.eager) and args.streams > 1 and any(getattr(s_, "fcl_placed", False) for s_ in pass_streams) else "as created"),
                    "timed_per_step": ("host packing of a NEW batch (%d distinct batches round-robin) into a pinned block + one hipGraph launch: the H2D pull of that "
                                       "block (ids, lengths, durations; fcl_feed_copy), encoder, predictors, device-built row maps (fcl_row_maps_build), decoder loop on device "
                                       "live-row counts, postnet; EXACT capacities, forced durations: %d steps / %d frames, per-step row bounds = the maximum over the fed batches "
