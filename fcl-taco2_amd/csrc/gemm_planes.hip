@@ -1084,8 +1084,13 @@ int launch_lstm_planes(const LstmStepArgs& a, hipStream_t s) {
     // batch >= 64 at FCL-taco2-S): the step kernel itself +10 % (FCL-taco2-T: frac 0.33 -> 0.36), batch 64 +2.7 %, T synthesis +1 %.  Synthesis
     // steps only: in the KD update the frozen teacher's forward runs BESIDE the student's critical path, and a teacher step that holds two
     // workgroups' worth of every CU slows that path more than it gains (12.20 vs 11.98 ms)
-    static const int two_stage_min = tunable("PLSTM_2STAGE_MIN_WG", 300);  // (150 = wherever the 128-row tile is chosen: B = 32 with four passes in flight +2 % -- workgroups of different streams share a CU --, but the step ALONE is 8 % slower without its pre-loop operand requests: 111 vs 120 TFLOP/s)
-    if (force == 7 || (force == 0 && t128 >= two_stage_min && !a.zone_keep_h && !a.save_gates)) return launch_plstm_cfg<4, 2, 2, 2>(a, s, flops);
+    // Round 6 re-scan on the final build (tools/tunable_scan_synth*.sh, profiles/r6_tunable_scan_synth*.log): 300 -> 125, i.e. the first decoder steps of an FCL-taco2-S batch
+    // (>= 1 921 live rows) take the two-stage 128-row tile instead of 64-row tiles: four passes in flight 43.7 -> 45.2 M frames/s (+3.4 %), calibrated capacities +5 %,
+    // replayed pass +3 %, batch 64 +1 %; ONE pass alone 21.26 -> 20.91 M (-1.6 %: the step alone is slower without its pre-loop operand requests).  100: the same at four
+    // passes, -2.7 % alone.
+    static const int two_stage_min = tunable("PLSTM_2STAGE_MIN_WG", 125);
+    static const int two_stage_min_exact = tunable("PLSTM_2STAGE_MIN_WG_EXACT", 300);  // (exact-fp32 lines are MFMA-bound: 125 costs that mode 5 %, 23.2 -> 22.0 M frames/s)
+    if (force == 7 || (force == 0 && t128 >= (t_exact_lines ? two_stage_min_exact : two_stage_min) && !a.zone_keep_h && !a.save_gates)) return launch_plstm_cfg<4, 2, 2, 2>(a, s, flops);
     // narrow synthesis steps (U <= 256, no training-side outputs: FCL-taco2-S inference) have their own pair of thresholds: 64-row tiles (two
     // workgroups per CU, also of different passes) up to 300 128-row tiles -- same-box A/B, three rounds, (150, 200) vs (300, 80): replayed pass
     // 47.5 -> 48.6 M frames/s, fresh feed 39.4 -> 39.8 M; the wide / training steps keep the 128-row tiles (-22 % on FCL-taco2-T synthesis otherwise)
