@@ -996,7 +996,9 @@ int launch_gemm_planes(const GemmArgs& a, hipStream_t s) {
     // four-stream line: that mode's loops are bound by their 32-cycle fp32 MFMAs, not by the input-tile re-fetch the stencil saves -> opt-in
     static const int pconv_exact = tunable("PCONV_EXACT", 0);
     if (pconv && (!t_exact_lines || pconv_exact) && a.conv_k >= 3 && a.conv_k <= 17 && !a.accumulate && (a.term[0].K <= 384 || pconv >= 2)) {
-        static const int cbig_min = tunable("PCONV_BIG_MIN", 150);
+        // (round 6: 150 -> 60 -- the 128-row stencil wherever it has 60 tiles: +0.4 ... +1.0 % on the four-pass line in three same-box scans, everything else flat:
+        // profiles/r6_tile_sweep.log, r6_tunable_scan_synth_pconv.log)
+        static const int cbig_min = tunable("PCONV_BIG_MIN", 60);
         if (force == 1 || (force == 0 && t128x128 >= cbig_min && a.N >= 128)) return launch_pconv_cfg<4, 2, 2, 4>(a, s, flops);
         if (force == 2 || (force == 0 && t64x128 >= 250 && a.N >= 96)) return launch_pconv_cfg<2, 2, 2, 4>(a, s, flops);
         return launch_pconv_cfg<2, 2, 2, 2>(a, s, flops);
