@@ -15,5 +15,9 @@ import os as _os
 # against bench.py's decode leg with it; depth 3 "beat" depth 4 for the same reason, profiles/r6_bench_decode.log).  Eight queues give every stream its own;
 # more do not help.  Set before the first HIP call: importing this package is early enough for the drivers (decode.py, train.py, bench.py).
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Kernel arguments in device memory (the runtime's default on this ROCm): with HIP_FORCE_DEV_KERNARG=0 every launch fetches its argument block from host memory and the
+# training updates (300 launches each) are 7.7 % slower (profiles/r6_env_sweep2.log: KD 8.29 -> 8.93 ms, teacher update 9.26 -> 9.96).  Pinned here so that an inherited 0
+# from an older job script is a deliberate choice, not an accident (an exported value still wins).
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 from .hparams import HParams, student_hparams, teacher_hparams, param_spec  # noqa: F401
