@@ -86,7 +86,7 @@ class Derive(C.Structure):  # fcl_derive_t
                 ("sb", C.c_int32), ("sc", C.c_int32), ("first_block", C.c_int32), ("reserved", C.c_int32)]
 
 
-ABI_VERSION = 421  # FCL_ABI_VERSION of include/fcl_hip.h
+ABI_VERSION = 422  # FCL_ABI_VERSION of include/fcl_hip.h
 
 
 class PwgLayer(C.Structure):  # fcl_pwg_layer_t
@@ -185,6 +185,7 @@ SIGNATURES = {
     "fcl_conv1d_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "fcl_layernorm_fwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P]),
     "fcl_layernorm_group_fwd": (_I, [_P, _I, C.c_int64, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "fcl_conv1d_planes_bn_fwd": (_I, [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "fcl_conv1d_planes_group_fwd": (_I, [_P, _I, C.c_int64, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "fcl_duration_round_fwd": (_I, [_P, _P, _I, _I, _F, _P, _P]),
     "fcl_variance_embed_add_fwd": (_I, [_P] * 12 + [_I, _I, _I, _P]),

@@ -285,6 +285,38 @@ int fcl_conv1d_planes_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, con
     return fcl_conv1d_planes_rows_fwd(xp, ldxp, wpp, bias, seg_lo, seg_hi, residual, y, yp, m, cin, cout, k, act, nullptr, stream);
 }
 
+/* Conv1d (no bias) on pre-split operands with train-mode BatchNorm statistics from the GEMM's epilogue (round 6): z [m, cout] as fcl_conv1d_planes_fwd, and mean /
+ * invstd / running statistics exactly as fcl_bn_stats_ws_fwd(z, ...) would leave them (same fp64 sums, same ticketed finalize, `zero_workspace` = the same 2 cout
+ * doubles + tickets, zero on entry and on exit) -- without that kernel's pass over z.  Planes kernels only (FCL_ERR_INVALID under FCL_PLANES=0 / FCL_PRECISION=0). */
+int fcl_conv1d_planes_bn_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const int32_t* seg_lo, const int32_t* seg_hi, float* z, int m, int cin, int cout, int k,
+                             float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, double* zero_workspace,
+                             fcl_stream_t stream) {
+    FCL_REQUIRE(xp && wpp && z && seg_lo && seg_hi && mean && invstd && zero_workspace && m > 0, FCL_ERR_INVALID, "conv1d_planes_bn_fwd: null argument / m <= 0");
+    FCL_REQUIRE((running_mean == nullptr) == (running_var == nullptr), FCL_ERR_INVALID, "conv1d_planes_bn_fwd: running statistics come in pairs");
+    FCL_REQUIRE(k >= 1 && (k & 1) && k <= FCL_MAX_TERMS, FCL_ERR_SHAPE, "conv1d_planes_bn_fwd: kernel size %d must be odd and <= %d", k, FCL_MAX_TERMS);
+    FCL_REQUIRE(ldxp * 32 >= cin, FCL_ERR_SHAPE, "conv1d_planes_bn_fwd: input planes narrower than Cin");
+    const int ldw = (cin + 31) / 32;
+    GemmArgs g = {};
+    for (int j = 0; j < k; ++j) {
+        g.term[j].K = cin;
+        g.term[j].shift = j - (k - 1) / 2;
+        g.term[j].Ap = xp; g.term[j].lda_p = ldxp;
+        g.term[j].Wp = wpp + (size_t)j * cout * ldw * 64; g.term[j].ldw_p = ldw;
+    }
+    g.nterms = k;
+    g.conv_k = k >= 3 ? k : 0;
+    g.M = m; g.N = cout;
+    g.seg_lo = seg_lo; g.seg_hi = seg_hi;
+    g.act = FCL_ACT_NONE;
+    g.Y = z; g.ldy = cout;
+    g.bn_ws = zero_workspace;
+    g.bn_tickets = reinterpret_cast<unsigned int*>(zero_workspace + 2 * (size_t)cout);
+    g.bn_eps = eps; g.bn_momentum = momentum;
+    g.bn_mean = mean; g.bn_invstd = invstd; g.bn_rmean = running_mean; g.bn_rvar = running_var;
+    FCL_REQUIRE(tunable("PRECISION", 1) != 0 && planes_ok(g.term, g.nterms), FCL_ERR_INVALID, "conv1d_planes_bn_fwd: the planes kernels are off (FCL_PLANES=0 / FCL_PRECISION=0)");
+    return launch_gemm(g, (hipStream_t)stream);
+}
+
 int fcl_conv1d_planes_group_fwd(const uint16_t* xp, int ldxp, int64_t x_group_stride, const uint16_t* wpp, const float* bias, const int32_t* seg_lo,
                                 const int32_t* seg_hi, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, int groups, fcl_stream_t stream) {
     FCL_REQUIRE(xp && wpp && (y || yp) && seg_lo && seg_hi && groups >= 1 && groups <= 65535, FCL_ERR_INVALID, "conv1d_planes_group_fwd: bad arguments");

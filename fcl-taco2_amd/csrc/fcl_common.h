@@ -88,6 +88,14 @@ struct GemmArgs {
     // MSE epilogue (planes kernels only, fcl_linear_planes_mse_fwd; round 6): with d = y - loss_t over the valid rows, Y / Yp receive the GRADIENT
     // 2 d * loss_gscale (zero on the other rows) instead of y, and sum |d|, sum d^2 and the element count are added to loss_sums[0 .. 2] (fp64 atomics):
     // the projection of a KD term, its loss and its gradient in one launch -- y itself never reaches memory
+    // train-mode BatchNorm statistics in the epilogue (planes kernels only, fcl_conv1d_planes_bn_fwd; round 6): every workgroup adds the column sums and sums of
+    // squares of its tile of outputs to bn_ws[0 : N] / bn_ws[N : 2 N] (fp64, zero on entry); the LAST row tile of a column tile to finish (bn_tickets[column tile], zero
+    // on entry) turns them into mean, 1 / sqrt(biased var + eps) and the running statistics and leaves sums and ticket zero again -- bn_stats_kernel's protocol without
+    // bn_stats_kernel's pass over the outputs
+    double* bn_ws;
+    unsigned int* bn_tickets;
+    float bn_eps, bn_momentum;
+    float *bn_mean, *bn_invstd, *bn_rmean, *bn_rvar;
     const float* loss_t;  // [M, N] target (ld_lt floats per row, 16-byte aligned rows), or null
     int ld_lt;
     const uint8_t* loss_valid;  // optional [M]

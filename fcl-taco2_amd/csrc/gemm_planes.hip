@@ -430,6 +430,44 @@ __device__ __forceinline__ void pgemm_epilogue(const GemmArgs& a_, f32x4 (&acc)[
     if (a.dbg_phase == 2) return;  // developer timing aid: no write-out
     const int rows = RP ? BM : min(BM, a_M - m0);  // staging rows to write out; RP: staging row rm holds tile row (rm & ~15) + rho16(rm & 15)
     auto trow = [&](int rm) { return RP ? (rm & ~15) + rho16(rm & 15) : rm; };
+    if (a.bn_ws) {  // BatchNorm statistics of the staged outputs (GemmArgs::bn_ws): rows past M and columns past N are staged as zeros
+        __shared__ int bn_last;
+        constexpr int RG = CTHREADS / BN;  // row groups: RG threads per column
+        static_assert(CTHREADS % BN == 0 && RG >= 1, "one or more whole threads per tile column");
+        const int cn = threadIdx.x % BN, rg = threadIdx.x / BN, n = n0 + cn;
+        double sm = 0.0, sq = 0.0;
+        for (int rm = rg; rm < BM; rm += RG) {
+            const double d = (double)tile[rm * LDT + cn];
+            sm += d;
+            sq += d * d;
+        }
+        if (n < a_N) {
+            // RETURNING atomics: the wave waits for the old values, i.e. both adds are performed at the coherence point before the workgroup draws its ticket
+            const double o1 = atomicAdd(a.bn_ws + n, sm);
+            const double o2 = atomicAdd(a.bn_ws + a_N + n, sq);
+            asm volatile("" ::"v"(o1), "v"(o2));
+        }
+        __syncthreads();
+        const int col_tile = n0 / BN, row_tiles = (a_M + BM - 1) / BM;
+        if (threadIdx.x == 0) bn_last = atomicAdd(a.bn_tickets + col_tile, 1u) == (unsigned)(row_tiles - 1);
+        __syncthreads();
+        if (bn_last && rg == 0 && n < a_N) {
+            const double S = atomicAdd(a.bn_ws + n, 0.0), Q = atomicAdd(a.bn_ws + a_N + n, 0.0);  // (atomic reads: served where the other workgroups' atomics landed)
+            const double mu = S / a_M;
+            double var = Q / a_M - mu * mu;
+            if (var < 0.0) var = 0.0;
+            a.bn_mean[n] = (float)mu;
+            a.bn_invstd[n] = (float)(1.0 / sqrt(var + (double)a.bn_eps));
+            if (a.bn_rmean) {
+                const double unbiased = a_M > 1 ? var * (double)a_M / (double)(a_M - 1) : var;
+                a.bn_rmean[n] = (float)((1.0 - a.bn_momentum) * a.bn_rmean[n] + a.bn_momentum * mu);
+                a.bn_rvar[n] = (float)((1.0 - a.bn_momentum) * a.bn_rvar[n] + a.bn_momentum * unbiased);
+            }
+            a.bn_ws[n] = 0.0;
+            a.bn_ws[a_N + n] = 0.0;
+            if (cn == 0) a.bn_tickets[col_tile] = 0u;
+        }
+    }
     if (a.loss_t) {  // MSE epilogue (GemmArgs::loss_t): the staged y becomes the gradient in place, row-wise (16 bytes of the target per lane), sums per workgroup
         __shared__ double loss_part[16][3];
         const float* const lt = a.loss_t;

@@ -432,9 +432,17 @@ int conv_bn_fwd(E_t& E, const float* x, const uint16_t* xp, int m, const std::st
     const uint16_t* wpp;
     TE_TRY(conv_cp(E, wn, cout, cin, k, false, true, nullptr, &wpp));
     float* z = f32(E, m, cout);
-    TE_L(fcl_conv1d_planes_fwd(xp, (cin + 31) / 32, wpp, nullptr, lo, hi, nullptr, z, nullptr, m, cin, cout, k, FCL_ACT_NONE, E.cur));
     float *mean = f32(E, cout), *invstd = f32(E, cout);
-    TE_L(fcl_bn_stats_ws_fwd(z, m, cout, BN_EPS, BN_MOMENTUM, mean, invstd, E.B.at(prefix + ".1.running_mean"), E.B.at(prefix + ".1.running_var"), bnws(E), E.cur));
+    // FCL_TE_BN_FUSED=1 (round 6, VERDICT r5 #1b): the batch statistics come out of the convolution's epilogue (fcl_conv1d_planes_bn_fwd: same fp64 sums, same ticketed
+    // finalize) -- one launch and one pass over z [m, cout] less per block
+    static const int bn_fused = tunable("TE_BN_FUSED", 1);
+    if (bn_fused && tunable("PRECISION", 1) != 0 && tunable("PLANES", 1) != 0) {
+        TE_L(fcl_conv1d_planes_bn_fwd(xp, (cin + 31) / 32, wpp, lo, hi, z, m, cin, cout, k, BN_EPS, BN_MOMENTUM, mean, invstd, E.B.at(prefix + ".1.running_mean"),
+                                      E.B.at(prefix + ".1.running_var"), bnws(E), E.cur));
+    } else {
+        TE_L(fcl_conv1d_planes_fwd(xp, (cin + 31) / 32, wpp, nullptr, lo, hi, nullptr, z, nullptr, m, cin, cout, k, FCL_ACT_NONE, E.cur));
+        TE_L(fcl_bn_stats_ws_fwd(z, m, cout, BN_EPS, BN_MOMENTUM, mean, invstd, E.B.at(prefix + ".1.running_mean"), E.B.at(prefix + ".1.running_var"), bnws(E), E.cur));
+    }
     const float ks = keep ? 1.0f / (1.0f - p_drop) : 1.0f;
     // (round 6) a forward that saves nothing for a backward (the frozen KD teacher) and drops: the pre-dropout activation has no reader -- one [m, cout] write less per block
     float* y_act = (E.c.save || !keep) ? f32(E, m, cout) : nullptr;

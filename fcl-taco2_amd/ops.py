@@ -558,6 +558,22 @@ def bn_stats(z, eps, momentum=0.1, running_mean=None, running_var=None):
     return mean, invstd
 
 
+def conv1d_planes_bn(xp, wpp, seg_lo, seg_hi, cin, cout, k, eps, momentum=0.1, running_mean=None, running_var=None):
+    """fcl_conv1d_planes_bn_fwd: Conv1d (no bias) on pre-split operands + the train-mode BatchNorm statistics of its output from the GEMM's epilogue.  wpp = planes of
+    the tap-major packed weight [k, cout, cin].  Returns (z, mean, invstd); updates the running buffers in place."""
+    m = xp.shape[0]
+    z = torch.empty(m, cout, device=xp.device, dtype=torch.float32)
+    mean, invstd = torch.empty(cout, device=xp.device), torch.empty(cout, device=xp.device)
+    key = (xp.device, _stream())
+    ws = _BN_WS.get(key)
+    need = 2 * cout + (cout + 63) // 64
+    if ws is None or ws.numel() < need:
+        ws = _BN_WS[key] = torch.zeros(max(need, 4096), device=xp.device, dtype=torch.float64)
+    check(_lib.load().fcl_conv1d_planes_bn_fwd(_p(xp, torch.int16), xp.shape[1] // 64, _p(wpp, torch.int16), _p(seg_lo, torch.int32), _p(seg_hi, torch.int32), _p(z), m,
+                                               cin, cout, k, eps, momentum, _p(mean), _p(invstd), _p(running_mean), _p(running_var), ws.data_ptr(), _stream()))
+    return z, mean, invstd
+
+
 def bn_act(z, mean, invstd, gamma, beta, act, keep=None, keep_scale=1.0, want_planes=False):
     """Returns (y_act, y_drop); y_drop is y_act when there is no keep mask.  want_planes: (+ P32 planes of y_drop)."""
     m, c = z.shape

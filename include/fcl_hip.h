@@ -55,7 +55,7 @@ enum { FCL_GEMM_F32 = 0, FCL_GEMM_BF16 = 1 };
 const char* fcl_last_error(void);
 /* ABI revision of this header: bumped whenever a struct layout or a signature changes (100 = round 1; 200 = round 2: fcl_gemm_term_t.a_chunk_stride,
  * fcl_pwg_layer_t, the round-2 entry points).  A binding compares it with fcl_version() of the library it loaded before passing any struct. */
-#define FCL_ABI_VERSION 421
+#define FCL_ABI_VERSION 422
 int fcl_version(void);
 void* fcl_debug_ptr(void); /* developer aid: device buffer of the last instrumented launch (FCL_PWG_TS), NULL otherwise */
 int fcl_set_gemm_mode(int mode);
@@ -146,6 +146,13 @@ int fcl_conv1d_planes_rows_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp
 /* G independent Conv1d's of the SAME shape in one launch (the duration / pitch / energy predictors' layers, variance_predictor.py:48-66): group g
  * reads planes xp + g * x_group_stride (uint16 elements; 0 = all groups read the same input), weights wpp [G][k * Cout][Cin planes] (each group
  * packed as for fcl_conv1d_planes_fwd), bias [G][Cout], and writes y / yp GROUP-MAJOR: [G][M][Cout].  Cin <= 384, Cout % 32 == 0, k >= 3. */
+/* round 6 (422): Conv1d (no bias) on pre-split operands + the train-mode BatchNorm statistics of its output from the GEMM's epilogue (encoder / postnet blocks of the
+ * training forward, encoder_sa.py:61-78, decoder_sa.py:199-263): z [m, cout] as fcl_conv1d_planes_fwd; mean, invstd and the running statistics exactly as
+ * fcl_bn_stats_ws_fwd(z, ...) leaves them (fp64 column sums, the last row tile of a column tile finalises; `zero_workspace` = 2 cout doubles + ceil(cout / 64) tickets,
+ * zero on entry and on exit) -- one launch and one pass over z less.  Planes kernels only (FCL_ERR_INVALID under FCL_PLANES=0 / FCL_PRECISION=0). */
+int fcl_conv1d_planes_bn_fwd(const uint16_t* xp, int ldxp, const uint16_t* wpp, const int32_t* seg_lo, const int32_t* seg_hi, float* z, int m, int cin, int cout, int k,
+                             float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, double* zero_workspace,
+                             fcl_stream_t stream);
 int fcl_conv1d_planes_group_fwd(const uint16_t* xp, int ldxp, int64_t x_group_stride, const uint16_t* wpp, const float* bias, const int32_t* seg_lo,
                                 const int32_t* seg_hi, float* y, uint16_t* yp, int m, int cin, int cout, int k, int act, int groups,
                                 fcl_stream_t stream);

@@ -268,3 +268,46 @@ def test_linear_planes_mse_is_projection_plus_loss_terms_in_one_launch(m, n, k, 
     s2 = torch.zeros(3, dtype=torch.float64, device=DEV)
     g2, gp2 = O.linear_planes_mse(xp, wp, t, valid, count, s2, m, n, k, want_f32=False)
     assert g2 is None and torch.equal(gp2[:m], gp[:m])
+
+
+@pytest.mark.parametrize("m,cin,cout,k", [(2560, 256, 256, 5), (24301, 128, 128, 5), (1584, 512, 512, 5), (300, 80, 128, 5), (25001, 512, 80, 5)])
+def test_conv1d_planes_bn_is_conv_plus_bn_stats_in_one_launch(m, cin, cout, k):
+    """fcl_conv1d_planes_bn_fwd (round 6, VERDICT r5 #1b: BatchNorm statistics from the convolution's epilogue) against the two launches it replaces: z bit for bit,
+    mean / invstd / running statistics to fp64-summation-order rounding; the workspace is zero again afterwards (a second call gives the same result); the stencil
+    (Cin <= 384) and the K-term (Cin = 512) kernels, 64- and 128-row tiles, ragged last tiles."""
+    from fcl_taco2_amd import ops as O
+
+    if os.environ.get("FCL_PRECISION", "1") == "0" or os.environ.get("FCL_PLANES", "1") == "0":
+        pytest.skip("planes kernels only")
+    rs = np.random.RandomState(m + cout)
+    x = torch.from_numpy(rs.randn(m, cin).astype(np.float32)).to(DEV)
+    w = torch.from_numpy((rs.randn(cout, cin, k) / np.sqrt(cin * k)).astype(np.float32)).to(DEV)
+    # three utterances: segment bounds per row
+    cuts = [0, m // 3, m // 3 + m // 4, m]
+    lo = torch.zeros(m, dtype=torch.int32)
+    hi = torch.zeros(m, dtype=torch.int32)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        lo[a:b], hi[a:b] = a, b
+    lo, hi = lo.to(DEV), hi.to(DEV)
+    xp = O.pack_planes(x)
+    wpk = O.pack_conv1d_weight(w)  # [k, cout, cin]
+    wpp = O.pack_planes(wpk.reshape(k * cout, cin))
+
+    class CV:  # the plan's ConvPack, by hand
+        pass
+
+    cv = CV()
+    cv.wpp, cv.bias, cv.k, cv.cin, cv.cout = wpp, None, k, cin, cout
+    z_ref, _ = O.conv1d_planes(xp, cv, lo, hi, want_f32=True, want_planes=False)
+    rm_ref, rv_ref = torch.full((cout,), 0.25, device=DEV), torch.full((cout,), 2.0, device=DEV)
+    mean_ref, inv_ref = O.bn_stats(z_ref, 1e-5, 0.1, rm_ref, rv_ref)
+    for rep in range(2):  # twice: the workspace (sums, tickets) must be left zero
+        rm, rv = torch.full((cout,), 0.25, device=DEV), torch.full((cout,), 2.0, device=DEV)
+        z, mean, inv = O.conv1d_planes_bn(xp, wpp, lo, hi, cin, cout, k, 1e-5, 0.1, rm, rv)
+        assert torch.equal(z, z_ref), rep
+        assert torch.allclose(mean, mean_ref, rtol=1e-6, atol=1e-7) and torch.allclose(inv, inv_ref, rtol=1e-6, atol=0.0), rep
+        assert torch.allclose(rm, rm_ref, rtol=1e-6, atol=1e-7) and torch.allclose(rv, rv_ref, rtol=1e-6, atol=0.0), rep
+    # float64
+    zd = z.double()
+    assert torch.allclose(mean.double(), zd.mean(0), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(inv.double(), 1.0 / torch.sqrt(zd.var(0, unbiased=False) + 1e-5), rtol=1e-5)
