@@ -997,7 +997,10 @@ def main():
             "peak_is": peak_note, "achieved_vs_fp32_matrix_peak": achieved / PEAK_F32_MFMA_TFLOPS,
             "note": "achieved = algorithmic fp32-equivalent FLOPs (2*M*N*K of the kernel's launches; no credit for hoisted att_c terms or padded "
                     "rows) / HIP-event duration on the launch stream; peak = the ceiling of the pipe the kernel issues on (frac <= 1 by construction); "
-                    "achieved_vs_fp32_matrix_peak (157.3 TFLOP/s, the pipe an exact-fp32 build would use) is informational only",
+                    "achieved_vs_fp32_matrix_peak (157.3 TFLOP/s, the pipe an exact-fp32 build would use) is informational only.  Durations are of ISOLATED launches "
+                    "(eager passes, one at a time, events around every launch): the two-stage 128-row tiles that serve the first decoder steps since round 6 are ~9 % slower "
+                    "alone than the 64-row tiles they replaced (frac 0.140 -> 0.127) and 3.4 % faster on `value` -- two of their workgroups share a CU, so the four passes "
+                    "in flight interleave better",
         }
         pmc_wl = "fp32" if os.environ.get("FCL_PRECISION", "1") == "0" else ""
         out["roofline"]["binding"] = binding_record(dom, d["ms"], d["fill_bytes"], pmc_wl)
